@@ -1,0 +1,226 @@
+/*
+ * plslam_hip.h -- C ABI of the MI355X (gfx950) implementation of PL-SLAM's stereo
+ * point+line matching front end and local-BA row build.
+ *
+ * This is the drop-in boundary: every entry point is extern "C", takes plain pointers and
+ * sizes, never throws, and returns PLSLAM_OK (0) or a negative PLSLAM_E* code.  Each one
+ * cites the reference interface it replaces (paths relative to the pl-slam repository).
+ *
+ * Descriptor matrices are N x 32 uint8, row-major, contiguous -- the layout of the
+ * reference's cv::Mat descriptor blocks (ORB: DBoW2 FORB::L = 32,
+ * 3rdparty/DBoW2/include/DBoW2/FORB.h:31; LBD: cv::Mat(n,32,CV_8UC1),
+ * 3rdparty/line_descriptor/src/binary_descriptor_custom.cpp:639) and of the matrices the
+ * map-level drivers assemble with Mat::push_back (src/mapHandler.cpp:555,567,660,672).
+ * Rows must start on 4-byte boundaries (any cv::Mat / hipMalloc / torch allocation does).
+ *
+ * Pointer conventions: entry points WITHOUT a _dev suffix take HOST pointers and do their
+ * own H2D/D2H on the context's stream; *_dev entry points and match plans take DEVICE
+ * pointers and a hipStream_t (passed as void*; NULL = the context's own stream) and are
+ * asynchronous with respect to the host.
+ *
+ * Threading: the reference calls StVO::match() concurrently from the VO thread, the local
+ * mapping thread and the loop-closure thread (app/plslam_dataset.cpp:127,
+ * src/mapHandler.cpp:1103, :1164 -> :3223).  Host-pointer entry points serialise on the
+ * context; use one context per thread for concurrency.  Plans are immutable after
+ * creation; plslam_match_plan_run may be issued from any one thread at a time per plan.
+ *
+ * There is NO CPU fallback: without a HIP device plslam_ctx_create fails with
+ * PLSLAM_ENODEV and nothing else can be called.
+ */
+#ifndef PLSLAM_HIP_H
+#define PLSLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PLSLAM_ABI_VERSION 1
+#define PLSLAM_DESC_BYTES 32
+/* largest train set of one directed scan: the composite (distance,index) key keeps 23
+ * index bits beside the 9 distance bits */
+#define PLSLAM_MAX_TRAIN_ROWS (1 << 23)
+
+enum {
+    PLSLAM_OK = 0,
+    PLSLAM_EINVAL = -1,  /* bad argument (NULL pointer, negative size, misaligned rows)   */
+    PLSLAM_ENODEV = -2,  /* no usable HIP device / wrong architecture                     */
+    PLSLAM_EHIP = -3,    /* a HIP runtime call failed; see plslam_last_error()            */
+    PLSLAM_ENOMEM = -4,  /* device or host allocation failed                              */
+    PLSLAM_ERANGE = -5,  /* size beyond a documented limit (PLSLAM_MAX_TRAIN_ROWS)        */
+    PLSLAM_ENOTSUP = -6  /* optional component unavailable (e.g. RCCL not loadable)       */
+};
+
+/* kernel variants of the directed Hamming scan (plslam_ctx_set_option "scan_variant") */
+enum {
+    PLSLAM_SCAN_AUTO = 0,
+    PLSLAM_SCAN_LANE_PER_QUERY = 1, /* query in VGPRs, train rows streamed as SGPRs        */
+    PLSLAM_SCAN_WAVE_PER_QUERY = 2, /* train tile in LDS, query in SGPRs, wave best-2 reduce */
+    PLSLAM_SCAN_SYMMETRIC = 3       /* mutual problems: one distance serves both directions */
+};
+
+typedef struct plslam_ctx plslam_ctx;
+typedef struct plslam_match_plan plslam_match_plan;
+
+/* Pinhole stereo camera: the fields of stvo-pl's PinholeStereoCamera that the reference
+ * reads through cam->projection / getFx / getFy / getWidth / getHeight / getB
+ * (src/mapHandler.cpp:255,550-551,1374,1384-1385). */
+typedef struct plslam_cam {
+    double fx, fy, cx, cy, b;
+    int32_t width, height;
+} plslam_cam;
+
+const char* plslam_strerror(int code);
+/* text of the last failure on the calling thread (HIP error string, file:line) */
+const char* plslam_last_error(void);
+int plslam_abi_version(void);
+
+/* ---- context ------------------------------------------------------------------------ */
+/* Binds to HIP device `device_ordinal` (must be gfx950), creates the context stream and
+ * scratch pools.  Replaces nothing in the reference (it has no device state). */
+int plslam_ctx_create(int device_ordinal, plslam_ctx** out);
+void plslam_ctx_destroy(plslam_ctx* ctx);
+/* options: "scan_variant" (PLSLAM_SCAN_*), "scan_block" (queries per workgroup: 256|512|1024) */
+int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value);
+int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value);
+/* device facts for reports: CU count, max clock (kHz), LDS bytes per workgroup */
+int plslam_ctx_device_info(plslam_ctx* ctx, int32_t* cu_count, int32_t* clock_khz,
+                           int32_t* lds_bytes, char* name, int32_t name_len);
+
+/* ---- K1: brute-force Hamming kNN-2 ---------------------------------------------------- */
+/* Replaces cv::BFMatcher::create(NORM_HAMMING,false)->knnMatch(q, t, matches, 2) as called by
+ * stvo-pl's matchNNR (matching.cpp; reached from src/mapHandler.cpp:277,424,597,712,3223,3249).
+ * idx, dist: nq*2 int32.  Order is lexicographic (distance, trainIdx): ties keep the lowest
+ * train index, the second neighbour may share the first one's distance.  Absent neighbours
+ * (nt < 2) are idx = -1, dist = INT32_MAX. */
+int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const uint8_t* t,
+                           int32_t nt, int32_t* idx, int32_t* dist);
+
+/* ---- K1+K2: StVO::match ----------------------------------------------------------------- */
+/* Replaces  int StVO::match(const cv::Mat& desc1, const cv::Mat& desc2, float nnr,
+ *                           std::vector<int>& matches_12)           (stvo-pl matching.h,
+ * included at src/mapHandler.cpp:28; call sites :277,:424,:597,:712,:3223,:3249).
+ * matches_12 has n1 entries: matches_12[i1] = i2 or -1 (contract used at :280-283).
+ * Ratio test in fp32: accept iff (float)d0 < (float)d1 * nnr.  mutual != 0 is the
+ * reference's Config::bestLRMatches() (config/config/config_kitti.yaml:17): also run
+ * desc2 -> desc1 and keep i1 -> i2 only if matches_21[i2] == i1.  n2 < 2 => no matches
+ * (upstream indexes matches_[idx][1] out of range there; this ABI defines the case).
+ * *n_matches (may be NULL) receives the return value of StVO::match. */
+int plslam_match(plslam_ctx* ctx, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2,
+                 float nnr, int mutual, int32_t* matches_12, int32_t* n_matches);
+
+/* B independent match() problems in one launch.  off1/off2 have B+1 row offsets into d1/d2;
+ * matches_12 has off1[B] entries (problem b writes rows off1[b]..off1[b+1]); n_matches has B
+ * entries (may be NULL).  This is the per-frame work of StereoFrame::extractStereoFeatures +
+ * StereoFrameHandler::f2fTracking (stvo-pl; app/plslam_dataset.cpp:127) for a batch of frames. */
+int plslam_match_batched(plslam_ctx* ctx, const uint8_t* d1, const int32_t* off1,
+                         const uint8_t* d2, const int32_t* off2, int32_t B, float nnr,
+                         int mutual, int32_t* matches_12, int32_t* n_matches);
+
+/* ---- device-resident match plans (the throughput path) --------------------------------- */
+/* One StVO::match problem with DEVICE pointers.  matches_12: n1 int32 (device).
+ * n_matches: device pointer to one int32, or NULL. */
+typedef struct plslam_match_problem {
+    const uint8_t* d1;
+    const uint8_t* d2;
+    int32_t n1, n2;
+    float nnr;
+    int32_t mutual;
+    int32_t* matches_12;
+    int32_t* n_matches;
+} plslam_match_problem;
+
+typedef struct plslam_plan_info {
+    int64_t distance_evals;    /* 256-bit distances evaluated per run (directed, as executed) */
+    int64_t directed_evals;    /* distances the reference would evaluate (n1*n2 per direction) */
+    int64_t algorithmic_bytes; /* sum over directed scans of 32*(Q+T) + 16*Q      */
+    int32_t n_scans;           /* directed scans                                             */
+    int32_t scan_blocks;       /* workgroups of the scan kernel                               */
+    int32_t scan_variant;      /* PLSLAM_SCAN_* actually used                                 */
+    int32_t scan_block_threads;
+} plslam_plan_info;
+
+/* Builds the immutable launch tables for `nprob` problems (host array of structs holding
+ * device pointers) and uploads them.  Runs no kernel. */
+int plslam_match_plan_create(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob,
+                             plslam_match_plan** out);
+/* Enqueues scan + finalize on `stream` (hipStream_t; NULL = context stream).  Asynchronous. */
+int plslam_match_plan_run(plslam_match_plan* plan, void* stream);
+/* With profiling on, every run brackets each kernel with HIP events on the launch stream. */
+int plslam_match_plan_set_profiling(plslam_match_plan* plan, int enable);
+/* Synchronises the recorded events and returns accumulated kernel milliseconds since the
+ * last call (then resets): scan kernel(s), finalize kernel, number of profiled runs. */
+int plslam_match_plan_elapsed(plslam_match_plan* plan, double* scan_ms, double* finalize_ms,
+                              int64_t* runs);
+int plslam_match_plan_info(plslam_match_plan* plan, plslam_plan_info* info);
+void plslam_match_plan_destroy(plslam_match_plan* plan);
+
+/* ---- K3/K4: local-BA residual + Jacobian rows ------------------------------------------- */
+/* Point rows: the per-observation body of MapHandler::levMarquardtOptimizationLBA,
+ * src/mapHandler.cpp:1358-1407 (first pass) == :1587-1642 (iteration pass; the caller
+ * supplies poses/landmarks from X).  fp64, no FMA contraction, reference operation order.
+ *   T_kf_w  nkf*16  row-major KF->world poses (map_keyframes[kf]->T_kf_w, :1370)
+ *   Xw      npt*3   landmarks (:1368)          obs_uv nobs*2 observations (:1375)
+ *   lm_loc[o] -> row of Xw, kf_slot[o] -> pose in T_kf_w
+ * out: J_pose nobs*6 (:1392-1398, tangent order [t, w]), J_lm nobs*3 (:1401-1404),
+ *      r nobs (||p_err||, :1377), w nobs (robustWeightCauchy, :1407). */
+int plslam_lba_point_rows(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                          const double* T_kf_w, int32_t nkf, const double* Xw, int32_t npt,
+                          const double* obs_uv, const int32_t* lm_loc, const int32_t* kf_slot,
+                          int32_t nobs, double* J_pose, double* J_lm, double* r, double* w);
+/* Line rows: src/mapHandler.cpp:1436-1516.  compat_iter_pass != 0 reproduces the iteration
+ * pass :1668-1748 as written: both endpoints read Lw[3*lm_loc .. +3] (:1678-1679) and the
+ * threshold is the literal 1e-7 (:1698).  Lw holds n_lw doubles (6 per line landmark).
+ * out: J_pose nobs*6 (:1509), J_lm nobs*6 (:1486,:1506,:1512-1513), r (:1460), w (:1516). */
+int plslam_lba_line_rows(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                         int compat_iter_pass, const double* T_kf_w, int32_t nkf,
+                         const double* Lw, int32_t n_lw, const double* l_obs,
+                         const int32_t* lm_loc, const int32_t* kf_slot, int32_t nobs,
+                         double* J_pose, double* J_lm, double* r, double* w);
+/* device-pointer forms (all arrays on the device; asynchronous on `stream`) */
+int plslam_lba_point_rows_dev(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                              const double* T_kf_w, const double* Xw, const double* obs_uv,
+                              const int32_t* lm_loc, const int32_t* kf_slot, int32_t nobs,
+                              double* J_pose, double* J_lm, double* r, double* w, void* stream);
+int plslam_lba_line_rows_dev(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                             int compat_iter_pass, const double* T_kf_w, const double* Lw,
+                             const double* l_obs, const int32_t* lm_loc, const int32_t* kf_slot,
+                             int32_t nobs, double* J_pose, double* J_lm, double* r, double* w,
+                             void* stream);
+
+/* ---- K5/K6: map <-> keyframe geometric gates (the inlier masks) -------------------------- */
+/* Points: src/mapHandler.cpp:601-613.  mask[i] = 1 iff matches_12[i] >= 0 and
+ * || proj(Twf * Xw[i]) - pl[matches_12[i]] ||_2 < max_epip.  Twf: 16 doubles row-major.
+ * Xw nq*3 (the matched map points, query order), pl nt*2.  *n_inliers = #mask (may be NULL). */
+int plslam_map2kf_point_gate(plslam_ctx* ctx, const plslam_cam* K, const double* Twf,
+                             const double* Xw, const int32_t* matches_12, int32_t nq,
+                             const double* pl, int32_t nt, double max_epip, uint8_t* mask,
+                             int32_t* n_inliers);
+/* Lines: src/mapHandler.cpp:716-729 (signed test on both endpoints, no abs()).
+ * Lw nq*6, le nt*3 (normalised 2D line equations). */
+int plslam_map2kf_line_gate(plslam_ctx* ctx, const plslam_cam* K, const double* Twf,
+                            const double* Lw, const int32_t* matches_12, int32_t nq,
+                            const double* le, int32_t nt, double max_epip, uint8_t* mask,
+                            int32_t* n_inliers);
+/* Candidate pre-filter src/mapHandler.cpp:549-551 / :650-655: vis[i] = 1 iff the landmark
+ * projects strictly inside the image with positive depth (both endpoints for lines). */
+int plslam_map_point_visible(plslam_ctx* ctx, const plslam_cam* K, const double* Twf,
+                             const double* Xw, int32_t n, uint8_t* vis);
+int plslam_map_line_visible(plslam_ctx* ctx, const plslam_cam* K, const double* Twf,
+                            const double* Lw, int32_t n, uint8_t* vis);
+
+/* ---- multi-GPU: gather of per-frame match tables over RCCL/xGMI -------------------------- */
+/* No reference counterpart (the reference is single-process).  `comm` is an ncclComm_t the
+ * host created (one rank per GPU); `local` is this rank's n_local int32 match-table entries
+ * (device); `gathered` (device, root only) receives nranks*n_local entries in rank order.
+ * Implemented as one ncclGroup of point-to-point sends to root so each peer uses its own
+ * xGMI link.  RCCL is loaded lazily (dlopen); returns PLSLAM_ENOTSUP if it cannot be. */
+int plslam_gather_match_tables(plslam_ctx* ctx, void* comm, int nranks, int rank, int root,
+                               const int32_t* local, int64_t n_local, int32_t* gathered,
+                               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLSLAM_HIP_H */

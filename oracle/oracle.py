@@ -1,0 +1,324 @@
+"""ctypes front end of the C oracle + an independent numpy mirror.
+
+TEST INFRASTRUCTURE ONLY (see oracle/plslam_oracle.h for the parity status: matcher
+semantics are "parity unpinned" -- OpenCV/stvo-pl are not under /root/reference; the
+Hamming distance is pinned to the reference's own in-tree popcount code via oracle/_ref).
+
+Reference anchors: src/mapHandler.cpp:277,424,597,712,3223,3249 (match call sites),
+:1358-1540 / :1587-1772 (LBA rows), :605-613 / :720-729 (gates),
+src/mapFeatures.cpp:51-93 (median descriptor).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+_f64p = C.POINTER(C.c_double)
+
+
+class Cam(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("b", C.c_double), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+def _build(target: str = "libplslam_oracle.so") -> None:
+    subprocess.run(["make", "-C", _HERE, target], check=True, stdout=subprocess.DEVNULL)
+
+
+def _load(name: str) -> C.CDLL:
+    path = os.path.join(_HERE, name)
+    if not os.path.exists(path):
+        _build("native" if "native" in name else name)
+    return C.CDLL(path)
+
+
+def _bind(lib: C.CDLL) -> C.CDLL:
+    lib.plo_hamming256.restype = C.c_int
+    lib.plo_hamming256_swar.restype = C.c_int
+    lib.plo_hamming256_lut.restype = C.c_int
+    for f in (lib.plo_hamming256, lib.plo_hamming256_swar, lib.plo_hamming256_lut):
+        f.argtypes = [C.c_void_p, C.c_void_p]
+    lib.plo_knn2.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.plo_knn2.restype = None
+    lib.plo_match_nnr.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
+    lib.plo_match_nnr.restype = C.c_int32
+    lib.plo_match.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_int, C.c_void_p]
+    lib.plo_match.restype = C.c_int32
+    lib.plo_match_batched.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
+    lib.plo_match_batched.restype = None
+    lib.plo_match_batched_mt.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_int, C.c_void_p,
+                                                             C.c_void_p, C.c_int]
+    lib.plo_match_batched_mt.restype = None
+    lib.plo_median_desc.argtypes = [C.c_void_p, C.c_int32]
+    lib.plo_median_desc.restype = C.c_int32
+    for f in (lib.plo_inverse_se3, lib.plo_expmap_se3, lib.plo_logmap_se3):
+        f.argtypes = [C.c_void_p, C.c_void_p]
+        f.restype = None
+    lib.plo_lba_point_rows.argtypes = [C.POINTER(Cam), C.c_double] + [C.c_void_p] * 5 + [C.c_int32] + \
+        [C.c_void_p] * 4
+    lib.plo_lba_point_rows.restype = None
+    lib.plo_lba_line_rows.argtypes = [C.POINTER(Cam), C.c_double, C.c_int] + [C.c_void_p] * 5 + \
+        [C.c_int32] + [C.c_void_p] * 4
+    lib.plo_lba_line_rows.restype = None
+    for f in (lib.plo_lba_accumulate_points, lib.plo_lba_accumulate_lines):
+        f.argtypes = [C.c_int32] * 3 + [C.c_void_p] * 2 + [C.c_int32] + [C.c_void_p] * 7
+        f.restype = None
+    for f in (lib.plo_map2kf_point_gate, lib.plo_map2kf_line_gate):
+        f.argtypes = [C.POINTER(Cam), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
+                      C.c_double, C.c_void_p]
+        f.restype = C.c_int32
+    for f in (lib.plo_map_point_visible, lib.plo_map_line_visible):
+        f.argtypes = [C.POINTER(Cam), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        f.restype = None
+    return lib
+
+
+_LIB = None
+_NATIVE = None
+_REF = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = _bind(_load("libplslam_oracle.so"))
+    return _LIB
+
+
+def native_lib() -> C.CDLL:
+    """-march=native build made on the executing host (bench.py cpu_baseline leg only)."""
+    global _NATIVE
+    if _NATIVE is None:
+        try:
+            _build("native")
+            _NATIVE = _bind(C.CDLL(os.path.join(_HERE, "libplslam_oracle_native.so")))
+        except Exception:  # no compiler on this host: the portable build is the baseline
+            _NATIVE = lib()
+    return _NATIVE
+
+
+def ref_lib():
+    """oracle/_ref/libplslam_ref.so: the reference's OWN popcount code compiled from
+    /root/reference (bitops_custom.hpp:83-96, FORB.cpp:78-101).  None if never built."""
+    global _REF
+    if _REF is None:
+        p = os.path.join(_HERE, "_ref", "libplslam_ref.so")
+        if not os.path.exists(p):
+            if os.path.isdir("/root/reference/3rdparty"):
+                _build("ref")
+            if not os.path.exists(p):
+                return None
+        r = C.CDLL(p)
+        r.ref_ld_match.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        r.ref_ld_match.restype = C.c_int
+        r.ref_forb_distance.argtypes = [C.c_void_p, C.c_void_p]
+        r.ref_forb_distance.restype = C.c_int
+        _REF = r
+    return _REF
+
+
+def _c(a, dt):
+    a = np.ascontiguousarray(a, dtype=dt)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _desc(a):
+    a = _c(a, np.uint8).reshape(-1, 32)
+    return a
+
+
+# ------------------------------------------------------------------------------------------
+# C oracle wrappers
+# ------------------------------------------------------------------------------------------
+def hamming256(a, b, variant="popcnt32") -> int:
+    a, b = _c(a, np.uint8), _c(b, np.uint8)
+    f = {"popcnt32": lib().plo_hamming256, "swar": lib().plo_hamming256_swar,
+         "lut": lib().plo_hamming256_lut}[variant]
+    return int(f(_p(a), _p(b)))
+
+
+def knn2(q, t, L=None):
+    L = L or lib()
+    q, t = _desc(q), _desc(t)
+    idx = np.empty((q.shape[0], 2), np.int32)
+    dist = np.empty((q.shape[0], 2), np.int32)
+    L.plo_knn2(_p(q), q.shape[0], _p(t), t.shape[0], _p(idx), _p(dist))
+    return idx, dist
+
+
+def match(d1, d2, nnr, mutual=True, L=None):
+    L = L or lib()
+    d1, d2 = _desc(d1), _desc(d2)
+    m12 = np.empty(d1.shape[0], np.int32)
+    n = L.plo_match(_p(d1), d1.shape[0], _p(d2), d2.shape[0], float(nnr), int(bool(mutual)), _p(m12))
+    return m12, int(n)
+
+
+def match_batched(d1, off1, d2, off2, nnr, mutual=True, nthreads=1, L=None):
+    L = L or lib()
+    d1, d2 = _desc(d1), _desc(d2)
+    off1, off2 = _c(off1, np.int32), _c(off2, np.int32)
+    B = off1.shape[0] - 1
+    m12 = np.empty(int(off1[-1]), np.int32)
+    nm = np.empty(B, np.int32)
+    if nthreads > 1:
+        L.plo_match_batched_mt(_p(d1), _p(off1), _p(d2), _p(off2), B, float(nnr), int(bool(mutual)),
+                               _p(m12), _p(nm), int(nthreads))
+    else:
+        L.plo_match_batched(_p(d1), _p(off1), _p(d2), _p(off2), B, float(nnr), int(bool(mutual)),
+                            _p(m12), _p(nm))
+    return m12, nm
+
+
+def median_desc(descs) -> int:
+    d = _desc(descs)
+    return int(lib().plo_median_desc(_p(d), d.shape[0]))
+
+
+def inverse_se3(T):
+    T = _c(T, np.float64).reshape(4, 4)
+    o = np.empty((4, 4))
+    lib().plo_inverse_se3(_p(T), _p(o))
+    return o
+
+
+def expmap_se3(x):
+    x = _c(x, np.float64).reshape(6)
+    o = np.empty((4, 4))
+    lib().plo_expmap_se3(_p(x), _p(o))
+    return o
+
+
+def logmap_se3(T):
+    T = _c(T, np.float64).reshape(4, 4)
+    o = np.empty(6)
+    lib().plo_logmap_se3(_p(T), _p(o))
+    return o
+
+
+def make_cam(fx, fy, cx, cy, b=0.0, width=0, height=0) -> Cam:
+    return Cam(fx, fy, cx, cy, b, width, height)
+
+
+def lba_point_rows(cam: Cam, homog_th, T_kf_w, Xw, obs_uv, lm_loc, kf_slot):
+    T = _c(T_kf_w, np.float64).reshape(-1, 16)
+    Xw = _c(Xw, np.float64).reshape(-1, 3)
+    uv = _c(obs_uv, np.float64).reshape(-1, 2)
+    lm, kf = _c(lm_loc, np.int32), _c(kf_slot, np.int32)
+    n = uv.shape[0]
+    Jp, Jl, r, w = np.empty((n, 6)), np.empty((n, 3)), np.empty(n), np.empty(n)
+    lib().plo_lba_point_rows(C.byref(cam), float(homog_th), _p(T), _p(Xw), _p(uv), _p(lm), _p(kf), n,
+                             _p(Jp), _p(Jl), _p(r), _p(w))
+    return Jp, Jl, r, w
+
+
+def lba_line_rows(cam: Cam, homog_th, T_kf_w, Lw, l_obs, lm_loc, kf_slot, compat_iter_pass=False):
+    T = _c(T_kf_w, np.float64).reshape(-1, 16)
+    Lw = _c(Lw, np.float64).reshape(-1)
+    lo = _c(l_obs, np.float64).reshape(-1, 3)
+    lm, kf = _c(lm_loc, np.int32), _c(kf_slot, np.int32)
+    n = lo.shape[0]
+    Jp, Jl, r, w = np.empty((n, 6)), np.empty((n, 6)), np.empty(n), np.empty(n)
+    lib().plo_lba_line_rows(C.byref(cam), float(homog_th), int(bool(compat_iter_pass)), _p(T), _p(Lw),
+                            _p(lo), _p(lm), _p(kf), n, _p(Jp), _p(Jl), _p(r), _p(w))
+    return Jp, Jl, r, w
+
+
+def lba_accumulate(kind, nkf, npt, nls, lm_loc, kf_loc, Jp, Jl, r, w, H=None, g=None):
+    N = 6 * nkf + 3 * npt + 6 * nls
+    H = np.zeros((N, N)) if H is None else H
+    g = np.zeros(N) if g is None else g
+    err = np.zeros(1)
+    lm, kf = _c(lm_loc, np.int32), _c(kf_loc, np.int32)
+    Jp, Jl, r, w = (_c(x, np.float64) for x in (Jp, Jl, r, w))
+    f = lib().plo_lba_accumulate_points if kind == "points" else lib().plo_lba_accumulate_lines
+    f(nkf, npt, nls, _p(lm), _p(kf), r.shape[0], _p(Jp), _p(Jl), _p(r), _p(w), _p(H), _p(g), _p(err))
+    return H, g, float(err[0])
+
+
+def map2kf_point_gate(cam, Twf, Xw, m12, pl, max_epip):
+    Twf = _c(Twf, np.float64).reshape(16)
+    Xw = _c(Xw, np.float64).reshape(-1, 3)
+    m12 = _c(m12, np.int32)
+    pl = _c(pl, np.float64).reshape(-1, 2)
+    mask = np.empty(m12.shape[0], np.uint8)
+    n = lib().plo_map2kf_point_gate(C.byref(cam), _p(Twf), _p(Xw), _p(m12), m12.shape[0], _p(pl),
+                                    float(max_epip), _p(mask))
+    return mask, int(n)
+
+
+def map2kf_line_gate(cam, Twf, Lw, m12, le, max_epip):
+    Twf = _c(Twf, np.float64).reshape(16)
+    Lw = _c(Lw, np.float64).reshape(-1, 6)
+    m12 = _c(m12, np.int32)
+    le = _c(le, np.float64).reshape(-1, 3)
+    mask = np.empty(m12.shape[0], np.uint8)
+    n = lib().plo_map2kf_line_gate(C.byref(cam), _p(Twf), _p(Lw), _p(m12), m12.shape[0], _p(le),
+                                   float(max_epip), _p(mask))
+    return mask, int(n)
+
+
+def map_point_visible(cam, Twf, Xw):
+    Twf = _c(Twf, np.float64).reshape(16)
+    Xw = _c(Xw, np.float64).reshape(-1, 3)
+    vis = np.empty(Xw.shape[0], np.uint8)
+    lib().plo_map_point_visible(C.byref(cam), _p(Twf), _p(Xw), Xw.shape[0], _p(vis))
+    return vis
+
+
+def map_line_visible(cam, Twf, Lw):
+    Twf = _c(Twf, np.float64).reshape(16)
+    Lw = _c(Lw, np.float64).reshape(-1, 6)
+    vis = np.empty(Lw.shape[0], np.uint8)
+    lib().plo_map_line_visible(C.byref(cam), _p(Twf), _p(Lw), Lw.shape[0], _p(vis))
+    return vis
+
+
+# ------------------------------------------------------------------------------------------
+# independent numpy mirror (different formulation: full distance matrix + stable sort)
+# ------------------------------------------------------------------------------------------
+def np_dist_matrix(q, t):
+    q, t = _desc(q), _desc(t)
+    x = q[:, None, :] ^ t[None, :, :]
+    return np.bitwise_count(x).sum(axis=2, dtype=np.int32)
+
+
+def np_knn2(q, t):
+    """First two of a STABLE sort by distance == OpenCV batchDistance K=2 insertion order."""
+    D = np_dist_matrix(q, t)
+    nq, nt = D.shape
+    idx = np.full((nq, 2), -1, np.int32)
+    dist = np.full((nq, 2), np.iinfo(np.int32).max, np.int32)
+    if nt:
+        order = np.argsort(D, axis=1, kind="stable")[:, :2]
+        k = order.shape[1]
+        idx[:, :k] = order
+        dist[:, :k] = np.take_along_axis(D, order, axis=1)
+    return idx, dist
+
+
+def np_match_nnr(q, t, nnr):
+    idx, dist = np_knn2(q, t)
+    nnr32 = np.float32(nnr)
+    ok = (idx[:, 1] >= 0) & (dist[:, 0].astype(np.float32) < dist[:, 1].astype(np.float32) * nnr32)
+    return np.where(ok, idx[:, 0], -1).astype(np.int32)
+
+
+def np_match(d1, d2, nnr, mutual=True):
+    m12 = np_match_nnr(d1, d2, nnr)
+    if mutual:
+        m21 = np_match_nnr(d2, d1, nnr)
+        good = m12 >= 0
+        back = np.where(good, m21[np.clip(m12, 0, max(len(m21) - 1, 0))] if len(m21) else -2, -2)
+        m12 = np.where(good & (back == np.arange(len(m12))), m12, -1).astype(np.int32)
+    return m12, int((m12 >= 0).sum())

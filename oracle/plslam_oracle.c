@@ -1,0 +1,572 @@
+/*
+ * plslam_oracle.c -- CPU ORACLE (TEST INFRASTRUCTURE, NOT PRODUCT CODE).
+ * See plslam_oracle.h for the parity status ("parity unpinned" for kNN order / ratio /
+ * mutual semantics; distance pinned to the reference's in-tree popcount code).
+ *
+ * Build with -ffp-contract=off: the fp64 rows must not be FMA-contracted so that the
+ * operation order written below (the reference's source order) is what executes.
+ */
+#include "plslam_oracle.h"
+
+#include <limits.h>
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------ */
+/* distance                                                                             */
+/* ------------------------------------------------------------------------------------ */
+
+/* bitops_custom.hpp:83-96: for each 16-byte step, four u32 XOR + __builtin_popcount. */
+int plo_hamming256(const uint8_t* a, const uint8_t* b)
+{
+    int out = 0;
+    for (int i = 0; i <= PLO_DESC_BYTES - 16; i += 16) {
+        uint32_t a0, a1, a2, a3, b0, b1, b2, b3;
+        memcpy(&a0, a + i, 4);      memcpy(&b0, b + i, 4);
+        memcpy(&a1, a + i + 4, 4);  memcpy(&b1, b + i + 4, 4);
+        memcpy(&a2, a + i + 8, 4);  memcpy(&b2, b + i + 8, 4);
+        memcpy(&a3, a + i + 12, 4); memcpy(&b3, b + i + 12, 4);
+        out += __builtin_popcount(a0 ^ b0) + __builtin_popcount(a1 ^ b1) +
+               __builtin_popcount(a2 ^ b2) + __builtin_popcount(a3 ^ b3);
+    }
+    return out;
+}
+
+/* FORB.cpp:78-101: SWAR popcount of each of the four u64 words of a^b. */
+int plo_hamming256_swar(const uint8_t* a, const uint8_t* b)
+{
+    uint64_t ret = 0;
+    for (int i = 0; i < PLO_DESC_BYTES / 8; ++i) {
+        uint64_t pa, pb, v;
+        memcpy(&pa, a + 8 * i, 8);
+        memcpy(&pb, b + 8 * i, 8);
+        v = pa ^ pb;
+        v = v - ((v >> 1) & (uint64_t)~(uint64_t)0 / 3);
+        v = (v & (uint64_t)~(uint64_t)0 / 15 * 3) + ((v >> 2) & (uint64_t)~(uint64_t)0 / 15 * 3);
+        v = (v + (v >> 4)) & (uint64_t)~(uint64_t)0 / 255 * 15;
+        ret += (uint64_t)(v * ((uint64_t)~(uint64_t)0 / 255)) >> (sizeof(uint64_t) - 1) * CHAR_BIT;
+    }
+    return (int)ret;
+}
+
+/* bitops_custom.hpp:58-76 lookup[] semantics, generated instead of tabulated. */
+int plo_hamming256_lut(const uint8_t* a, const uint8_t* b)
+{
+    static int lut[256];
+    static int init = 0;
+    if (!init) {
+        for (int v = 0; v < 256; ++v) {
+            int c = 0;
+            for (int k = 0; k < 8; ++k) c += (v >> k) & 1;
+            lut[v] = c;
+        }
+        init = 1;
+    }
+    int out = 0;
+    for (int i = 0; i < PLO_DESC_BYTES; ++i) out += lut[a[i] ^ b[i]];
+    return out;
+}
+
+/* fast inner distance for the scans (same value as the three above; u64 builtin) */
+static inline int ham_fast(const uint8_t* a, const uint8_t* b)
+{
+    uint64_t x[4], y[4];
+    memcpy(x, a, 32);
+    memcpy(y, b, 32);
+    return __builtin_popcountll(x[0] ^ y[0]) + __builtin_popcountll(x[1] ^ y[1]) +
+           __builtin_popcountll(x[2] ^ y[2]) + __builtin_popcountll(x[3] ^ y[3]);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* kNN-2: OpenCV batchDistance(K=2) insertion semantics                                  */
+/* ------------------------------------------------------------------------------------ */
+void plo_knn2(const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_t* idx,
+              int32_t* dist)
+{
+    for (int32_t i = 0; i < nq; ++i) {
+        int32_t bd[2] = {INT32_MAX, INT32_MAX};
+        int32_t bi[2] = {-1, -1};
+        const uint8_t* qi = q + (size_t)i * PLO_DESC_BYTES;
+        for (int32_t j = 0; j < nt; ++j) {
+            const int32_t d = ham_fast(qi, t + (size_t)j * PLO_DESC_BYTES);
+            if (d < bd[1]) {            /* strict '<' against the worst kept slot         */
+                int k = 0;              /* K-2 = 0: shift slot 0 down while it is worse   */
+                if (bd[0] > d) {        /* strict '>' => equal distance keeps lower index */
+                    bd[1] = bd[0];
+                    bi[1] = bi[0];
+                    k = -1;
+                }
+                bd[k + 1] = d;
+                bi[k + 1] = j;
+            }
+        }
+        idx[2 * i] = bi[0];
+        idx[2 * i + 1] = bi[1];
+        dist[2 * i] = bd[0];
+        dist[2 * i + 1] = bd[1];
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* stvo-pl matchNNR / match                                                              */
+/* ------------------------------------------------------------------------------------ */
+int32_t plo_match_nnr(const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, float nnr,
+                      int32_t* m12)
+{
+    int32_t matches = 0;
+    for (int32_t i = 0; i < nq; ++i) {
+        int32_t idx[2], dist[2];
+        plo_knn2(q + (size_t)i * PLO_DESC_BYTES, 1, t, nt, idx, dist);
+        m12[i] = -1;
+        if (idx[1] < 0) continue;       /* nt < 2: defined as "no match" */
+        const volatile float d0 = (float)dist[0];
+        const volatile float d1n = (float)dist[1] * nnr; /* one fp32 multiply, then compare */
+        if (d0 < d1n) {
+            m12[i] = idx[0];
+            ++matches;
+        }
+    }
+    return matches;
+}
+
+int32_t plo_match(const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
+                  int mutual, int32_t* m12)
+{
+    int32_t matches = plo_match_nnr(d1, n1, d2, n2, nnr, m12);
+    if (!mutual) return matches;
+    int32_t* m21 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
+    plo_match_nnr(d2, n2, d1, n1, nnr, m21);
+    for (int32_t i1 = 0; i1 < n1; ++i1) {
+        const int32_t i2 = m12[i1];
+        if (i2 >= 0 && m21[i2] != i1) {
+            m12[i1] = -1;
+            --matches;
+        }
+    }
+    free(m21);
+    return matches;
+}
+
+void plo_match_batched(const uint8_t* d1, const int32_t* off1, const uint8_t* d2,
+                       const int32_t* off2, int32_t B, float nnr, int mutual, int32_t* m12,
+                       int32_t* n_matches)
+{
+    for (int32_t b = 0; b < B; ++b) {
+        const int32_t n = plo_match(d1 + (size_t)off1[b] * PLO_DESC_BYTES, off1[b + 1] - off1[b],
+                                    d2 + (size_t)off2[b] * PLO_DESC_BYTES, off2[b + 1] - off2[b],
+                                    nnr, mutual, m12 + off1[b]);
+        if (n_matches) n_matches[b] = n;
+    }
+}
+
+typedef struct {
+    const uint8_t *d1, *d2;
+    const int32_t *off1, *off2;
+    int32_t b0, b1;
+    float nnr;
+    int mutual;
+    int32_t *m12, *n_matches;
+} mt_job;
+
+static void* mt_worker(void* p)
+{
+    mt_job* j = (mt_job*)p;
+    for (int32_t b = j->b0; b < j->b1; ++b) {
+        const int32_t n =
+            plo_match(j->d1 + (size_t)j->off1[b] * PLO_DESC_BYTES, j->off1[b + 1] - j->off1[b],
+                      j->d2 + (size_t)j->off2[b] * PLO_DESC_BYTES, j->off2[b + 1] - j->off2[b],
+                      j->nnr, j->mutual, j->m12 + j->off1[b]);
+        if (j->n_matches) j->n_matches[b] = n;
+    }
+    return NULL;
+}
+
+void plo_match_batched_mt(const uint8_t* d1, const int32_t* off1, const uint8_t* d2,
+                          const int32_t* off2, int32_t B, float nnr, int mutual, int32_t* m12,
+                          int32_t* n_matches, int nthreads)
+{
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > B) nthreads = B > 0 ? B : 1;
+    pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)nthreads);
+    mt_job* jobs = (mt_job*)malloc(sizeof(mt_job) * (size_t)nthreads);
+    for (int k = 0; k < nthreads; ++k) {
+        jobs[k] = (mt_job){d1, d2, off1, off2, (int32_t)((int64_t)B * k / nthreads),
+                           (int32_t)((int64_t)B * (k + 1) / nthreads), nnr, mutual, m12, n_matches};
+        pthread_create(&th[k], NULL, mt_worker, &jobs[k]);
+    }
+    for (int k = 0; k < nthreads; ++k) pthread_join(th[k], NULL);
+    free(jobs);
+    free(th);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* representative descriptor: src/mapFeatures.cpp:51-93                                  */
+/* ------------------------------------------------------------------------------------ */
+static int cmp_int(const void* a, const void* b)
+{
+    const int x = *(const int*)a, y = *(const int*)b;
+    return (x > y) - (x < y);
+}
+
+int32_t plo_median_desc(const uint8_t* descs, int32_t n)
+{
+    if (n <= 1) return 0; /* ctor path (:28-38): a single observation is its own median */
+    int* conf = (int*)malloc(sizeof(int) * (size_t)n * (size_t)n);
+    int* row = (int*)malloc(sizeof(int) * (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        conf[i * n + i] = 0;
+        for (int j = i + 1; j < n; ++j) {
+            const int d = plo_hamming256(descs + (size_t)i * 32, descs + (size_t)j * 32);
+            conf[i * n + j] = d;
+            conf[j * n + i] = d;
+        }
+    }
+    int max_dist = 99999, max_idx = 0;
+    const int med = (int)(1 + 0.5 * (n - 1));
+    for (int i = 0; i < n; ++i) {
+        memcpy(row, conf + (size_t)i * n, sizeof(int) * (size_t)n);
+        qsort(row, (size_t)n, sizeof(int), cmp_int);
+        if (row[med] < max_dist) { /* strict '<': first minimum wins */
+            max_dist = row[med];
+            max_idx = i;
+        }
+    }
+    free(row);
+    free(conf);
+    return max_idx;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* SE(3) helpers (stvo-pl auxiliar.cpp [RECALL]); 4x4 row-major                          */
+/* ------------------------------------------------------------------------------------ */
+void plo_inverse_se3(const double T[16], double Ti[16])
+{
+    double o[16];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) o[4 * i + j] = T[4 * j + i];
+    for (int i = 0; i < 3; ++i)
+        o[4 * i + 3] = (-T[4 * 0 + i]) * T[3] + (-T[4 * 1 + i]) * T[7] + (-T[4 * 2 + i]) * T[11];
+    o[12] = 0.0; o[13] = 0.0; o[14] = 0.0; o[15] = 1.0;
+    memcpy(Ti, o, sizeof(o));
+}
+
+static void skew3(const double w[3], double s[9])
+{
+    s[0] = 0.0;   s[1] = -w[2]; s[2] = w[1];
+    s[3] = w[2];  s[4] = 0.0;   s[5] = -w[0];
+    s[6] = -w[1]; s[7] = w[0];  s[8] = 0.0;
+}
+
+static void mat3_mul(const double a[9], const double b[9], double c[9])
+{
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            c[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+
+void plo_expmap_se3(const double x[6], double T[16])
+{
+    const double* t = x;
+    const double* w = x + 3;
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    double tt[3] = {t[0], t[1], t[2]};
+    const double theta = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+    if (!(theta < 0.000001)) {
+        double s[9], s2[9], wn[3] = {w[0] / theta, w[1] / theta, w[2] / theta};
+        skew3(wn, s);
+        mat3_mul(s, s, s2);
+        const double sn = sin(theta), cs = cos(theta);
+        double V[9];
+        for (int k = 0; k < 9; ++k) {
+            const double id = (k % 4 == 0) ? 1.0 : 0.0;
+            R[k] = id + s[k] * sn + s2[k] * (1.0 - cs);
+            V[k] = id + s[k] * (1.0 - cs) / theta + s2[k] * (theta - sn) / theta;
+        }
+        for (int i = 0; i < 3; ++i)
+            tt[i] = V[3 * i] * t[0] + V[3 * i + 1] * t[1] + V[3 * i + 2] * t[2];
+    }
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 3; ++j) T[4 * i + j] = R[3 * i + j];
+        T[4 * i + 3] = tt[i];
+    }
+    T[12] = 0.0; T[13] = 0.0; T[14] = 0.0; T[15] = 1.0;
+}
+
+static int mat3_inv(const double m[9], double o[9])
+{
+    const double c0 = m[4] * m[8] - m[5] * m[7];
+    const double c1 = m[5] * m[6] - m[3] * m[8];
+    const double c2 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c0 + m[1] * c1 + m[2] * c2;
+    if (det == 0.0) return -1;
+    const double id = 1.0 / det;
+    o[0] = c0 * id; o[1] = (m[2] * m[7] - m[1] * m[8]) * id; o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c1 * id; o[4] = (m[0] * m[8] - m[2] * m[6]) * id; o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c2 * id; o[7] = (m[1] * m[6] - m[0] * m[7]) * id; o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return 0;
+}
+
+void plo_logmap_se3(const double T[16], double x[6])
+{
+    double R[9], V[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, w[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) R[3 * i + j] = T[4 * i + j];
+    double cosine = (R[0] + R[4] + R[8] - 1.0) / 2.0;
+    if (cosine > 1.0) cosine = 1.0; else if (cosine < -1.0) cosine = -1.0;
+    double sine = sqrt(1.0 - cosine * cosine);
+    if (sine > 1.0) sine = 1.0; else if (sine < -1.0) sine = -1.0;
+    const double theta = acos(cosine);
+    if (theta > 0.000001) {
+        /* w_hat = theta * (R - R^T) / (2 sine); w = skewcoords(w_hat) */
+        w[0] = theta * (R[7] - R[5]) / (2.0 * sine);
+        w[1] = theta * (R[2] - R[6]) / (2.0 * sine);
+        w[2] = theta * (R[3] - R[1]) / (2.0 * sine);
+        double s[9], s2[9], wn[3] = {w[0] / theta, w[1] / theta, w[2] / theta};
+        skew3(wn, s);
+        mat3_mul(s, s, s2);
+        for (int k = 0; k < 9; ++k) {
+            const double id = (k % 4 == 0) ? 1.0 : 0.0;
+            V[k] = id + s[k] * (1.0 - cosine) / theta + s2[k] * (theta - sine) / theta;
+        }
+    }
+    double Vi[9];
+    if (mat3_inv(V, Vi) != 0) memcpy(Vi, V, sizeof(Vi));
+    for (int i = 0; i < 3; ++i)
+        x[i] = Vi[3 * i] * T[3] + Vi[3 * i + 1] * T[7] + Vi[3 * i + 2] * T[11];
+    x[3] = w[0]; x[4] = w[1]; x[5] = w[2];
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* LBA rows                                                                              */
+/* ------------------------------------------------------------------------------------ */
+static inline double dmax(double a, double b) { return a > b ? a : b; } /* std::max(a,b) */
+
+/* stvo-pl PinholeStereoCamera::projection [RECALL]: u = cx + fx*X/Z, v = cy + fy*Y/Z */
+static inline void project(const plo_cam* K, const double P[3], double uv[2])
+{
+    uv[0] = K->cx + K->fx * P[0] / P[2];
+    uv[1] = K->cy + K->fy * P[1] / P[2];
+}
+
+/* Tiw = inverse_se3(T_kf_w) (:1372); returns R (row-major 3x3) and t */
+static inline void inv_pose(const double* T, double R[9], double t[3])
+{
+    double Ti[16];
+    plo_inverse_se3(T, Ti);
+    for (int i = 0; i < 3; ++i) {
+        R[3 * i] = Ti[4 * i]; R[3 * i + 1] = Ti[4 * i + 1]; R[3 * i + 2] = Ti[4 * i + 2];
+        t[i] = Ti[4 * i + 3];
+    }
+}
+
+static inline void xform(const double R[9], const double t[3], const double X[3], double o[3])
+{
+    for (int i = 0; i < 3; ++i)
+        o[i] = (R[3 * i] * X[0] + R[3 * i + 1] * X[1] + R[3 * i + 2] * X[2]) + t[i];
+}
+
+/* the 6-vector of :1392-1397 / :1475-1480 (before any normalisation) */
+static inline void jac6(double a, double b, double k, const double G[3], double J[6])
+{
+    const double gx = G[0], gy = G[1], gz = G[2];
+    J[0] = +k * a * gz;
+    J[1] = +k * b * gz;
+    J[2] = -k * (a * gx + b * gy);
+    J[3] = -k * (a * gx * gy + b * gy * gy + b * gz * gz);
+    J[4] = +k * (a * gx * gx + a * gz * gz + b * gx * gy);
+    J[5] = +k * (b * gx * gz - a * gy * gz);
+}
+
+void plo_lba_point_rows(const plo_cam* K, double th, const double* T_kf_w, const double* Xw,
+                        const double* obs_uv, const int32_t* lm_loc, const int32_t* kf_slot,
+                        int32_t nobs, double* J_pose, double* J_lm, double* r, double* w)
+{
+    for (int32_t o = 0; o < nobs; ++o) {
+        double R[9], t[3], G[3], p[2], Jc[6];
+        inv_pose(T_kf_w + 16 * (size_t)kf_slot[o], R, t);        /* :1370-1372 */
+        xform(R, t, Xw + 3 * (size_t)lm_loc[o], G);              /* :1373 */
+        project(K, G, p);                                        /* :1374 */
+        const double dx = obs_uv[2 * o] - p[0];                  /* :1376 */
+        const double dy = obs_uv[2 * o + 1] - p[1];
+        const double nrm = sqrt(dx * dx + dy * dy);              /* :1377 */
+        const double k = 1.0 / dmax(th, G[2] * G[2]);            /* :1382-1383 */
+        const double a = K->fx * dx, b = K->fy * dy;             /* :1388-1389 */
+        jac6(a, b, k, G, Jc);                                    /* :1392-1397 */
+        const double den = dmax(th, nrm);
+        for (int c = 0; c < 6; ++c) J_pose[6 * (size_t)o + c] = Jc[c] / den;   /* :1398 */
+        for (int j = 0; j < 3; ++j)                                            /* :1404 */
+            J_lm[3 * (size_t)o + j] = (Jc[0] * R[j] + Jc[1] * R[3 + j] + Jc[2] * R[6 + j]) / den;
+        r[o] = nrm;
+        w[o] = 1.0 / (1.0 + nrm * nrm);                          /* robustWeightCauchy :1407 */
+    }
+}
+
+void plo_lba_line_rows(const plo_cam* K, double th_in, int compat, const double* T_kf_w,
+                       const double* Lw, const double* l_obs, const int32_t* lm_loc,
+                       const int32_t* kf_slot, int32_t nobs, double* J_pose, double* J_lm,
+                       double* r, double* w)
+{
+    const double th = compat ? 0.0000001 : th_in;               /* :1698 literal */
+    for (int32_t o = 0; o < nobs; ++o) {
+        double R[9], t[3], P[3], Q[3], p[2], q[2], JP[6], JQ[6];
+        const double* Pw = compat ? Lw + 3 * (size_t)lm_loc[o] : Lw + 6 * (size_t)lm_loc[o];
+        const double* Qw = compat ? Lw + 3 * (size_t)lm_loc[o] : Lw + 6 * (size_t)lm_loc[o] + 3;
+        inv_pose(T_kf_w + 16 * (size_t)kf_slot[o], R, t);        /* :1449-1451 */
+        xform(R, t, Pw, P);                                      /* :1452 */
+        xform(R, t, Qw, Q);                                      /* :1453 */
+        project(K, P, p);
+        project(K, Q, q);
+        const double* l = l_obs + 3 * (size_t)o;
+        const double e0 = l[0] * p[0] + l[1] * p[1] + l[2];      /* :1458 */
+        const double e1 = l[0] * q[0] + l[1] * q[1] + l[2];      /* :1459 */
+        const double nrm = sqrt(e0 * e0 + e1 * e1);              /* :1460 */
+        const double a = K->fx * e0, b = K->fy * e1;             /* :1469-1472 (sic: l_err) */
+        const double kP = 1.0 / dmax(th, P[2] * P[2]);
+        const double kQ = 1.0 / dmax(th, Q[2] * Q[2]);
+        jac6(a, b, kP, P, JP);                                   /* :1475-1480 */
+        jac6(a, b, kQ, Q, JQ);                                   /* :1495-1500 */
+        const double den = dmax(th, nrm);
+        for (int j = 0; j < 3; ++j) {
+            const double vp = JP[0] * R[j] + JP[1] * R[3 + j] + JP[2] * R[6 + j];
+            const double vq = JQ[0] * R[j] + JQ[1] * R[3 + j] + JQ[2] * R[6 + j];
+            J_lm[6 * (size_t)o + j] = vp * e0 / den;             /* :1486 */
+            J_lm[6 * (size_t)o + 3 + j] = vq * e1 / den;         /* :1506 */
+        }
+        for (int c = 0; c < 6; ++c)
+            J_pose[6 * (size_t)o + c] = (JP[c] * e0 + JQ[c] * e1) / den;       /* :1509 */
+        r[o] = nrm;
+        w[o] = 1.0 / (1.0 + nrm * nrm);                          /* :1516 */
+    }
+}
+
+/* H/g accumulation :1410-1429 (dl = 3) and :1519-1538 (dl = 6) */
+static void accumulate(int32_t N, int32_t lm_base, int dl, const int32_t* lm_loc,
+                       const int32_t* kf_loc, int32_t nobs, const double* J_pose,
+                       const double* J_lm, const double* r, const double* w, double* H,
+                       double* g, double* err)
+{
+    for (int32_t o = 0; o < nobs; ++o) {
+        const double* Jp = J_pose + 6 * (size_t)o;
+        const double* Jl = J_lm + (size_t)dl * o;
+        const int32_t idx = 6 * kf_loc[o];
+        const int32_t jdx = lm_base + dl * lm_loc[o];
+        const double rr = r[o], ww = w[o];
+        for (int a = 0; a < dl; ++a) g[jdx + a] += Jl[a] * rr * ww;
+        *err += rr * rr * ww;
+        for (int a = 0; a < dl; ++a)
+            for (int b = 0; b < dl; ++b) H[(size_t)(jdx + a) * N + jdx + b] += Jl[a] * Jl[b] * ww;
+        if (kf_loc[o] == -1) continue;
+        for (int a = 0; a < 6; ++a) g[idx + a] += Jp[a] * rr * ww;
+        for (int a = 0; a < 6; ++a)
+            for (int b = 0; b < 6; ++b) H[(size_t)(idx + a) * N + idx + b] += Jp[a] * Jp[b] * ww;
+        for (int a = 0; a < dl; ++a)
+            for (int b = 0; b < 6; ++b) {
+                const double h = Jl[a] * Jp[b] * ww;            /* Haux */
+                H[(size_t)(jdx + a) * N + idx + b] += h;
+                H[(size_t)(idx + b) * N + jdx + a] += h;
+            }
+    }
+}
+
+void plo_lba_accumulate_points(int32_t nkf, int32_t npt, int32_t nls, const int32_t* lm_loc,
+                               const int32_t* kf_loc, int32_t nobs, const double* J_pose,
+                               const double* J_lm, const double* r, const double* w, double* H,
+                               double* g, double* err)
+{
+    const int32_t N = 6 * nkf + 3 * npt + 6 * nls;
+    accumulate(N, 6 * nkf, 3, lm_loc, kf_loc, nobs, J_pose, J_lm, r, w, H, g, err);
+}
+
+void plo_lba_accumulate_lines(int32_t nkf, int32_t npt, int32_t nls, const int32_t* lm_loc,
+                              const int32_t* kf_loc, int32_t nobs, const double* J_pose,
+                              const double* J_lm, const double* r, const double* w, double* H,
+                              double* g, double* err)
+{
+    const int32_t N = 6 * nkf + 3 * npt + 6 * nls;
+    accumulate(N, 6 * nkf + 3 * npt, 6, lm_loc, kf_loc, nobs, J_pose, J_lm, r, w, H, g, err);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* map<->KF gates                                                                        */
+/* ------------------------------------------------------------------------------------ */
+static inline void xform44(const double T[16], const double X[3], double o[3])
+{
+    for (int i = 0; i < 3; ++i)
+        o[i] = (T[4 * i] * X[0] + T[4 * i + 1] * X[1] + T[4 * i + 2] * X[2]) + T[4 * i + 3];
+}
+
+int32_t plo_map2kf_point_gate(const plo_cam* K, const double Twf[16], const double* Xw,
+                              const int32_t* m12, int32_t nq, const double* pl, double max_epip,
+                              uint8_t* mask)
+{
+    int32_t n = 0;
+    for (int32_t i = 0; i < nq; ++i) {
+        mask[i] = 0;
+        const int32_t i2 = m12[i];
+        if (i2 < 0) continue;                                    /* :603 */
+        double Pf[3], pf[2];
+        xform44(Twf, Xw + 3 * (size_t)i, Pf);                    /* :605 */
+        project(K, Pf, pf);                                      /* :610 */
+        const double ex = pf[0] - pl[2 * (size_t)i2], ey = pf[1] - pl[2 * (size_t)i2 + 1];
+        if (sqrt(ex * ex + ey * ey) < max_epip) {                /* :612-613 */
+            mask[i] = 1;
+            ++n;
+        }
+    }
+    return n;
+}
+
+int32_t plo_map2kf_line_gate(const plo_cam* K, const double Twf[16], const double* Lw,
+                             const int32_t* m12, int32_t nq, const double* le, double max_epip,
+                             uint8_t* mask)
+{
+    int32_t n = 0;
+    for (int32_t i = 0; i < nq; ++i) {
+        mask[i] = 0;
+        const int32_t i2 = m12[i];
+        if (i2 < 0) continue;                                    /* :718 */
+        double sP[3], eP[3], sp[2], ep[2];
+        xform44(Twf, Lw + 6 * (size_t)i, sP);                    /* :720 */
+        project(K, sP, sp);
+        xform44(Twf, Lw + 6 * (size_t)i + 3, eP);                /* :722 */
+        project(K, eP, ep);
+        const double* l = le + 3 * (size_t)i2;
+        const double e0 = l[0] * sp[0] + l[1] * sp[1] + l[2];    /* :727 */
+        const double e1 = l[0] * ep[0] + l[1] * ep[1] + l[2];    /* :728 */
+        if (e0 < max_epip && e1 < max_epip) {                    /* :729 signed, no abs() */
+            mask[i] = 1;
+            ++n;
+        }
+    }
+    return n;
+}
+
+static inline int inside(const plo_cam* K, const double P[3])
+{
+    double p[2];
+    project(K, P, p);
+    return p[0] > 0 && p[0] < K->width && p[1] > 0 && p[1] < K->height && P[2] > 0.0;
+}
+
+void plo_map_point_visible(const plo_cam* K, const double Twf[16], const double* Xw, int32_t n,
+                           uint8_t* vis)
+{
+    for (int32_t i = 0; i < n; ++i) {
+        double Pf[3];
+        xform44(Twf, Xw + 3 * (size_t)i, Pf);                    /* :549-551 */
+        vis[i] = (uint8_t)inside(K, Pf);
+    }
+}
+
+void plo_map_line_visible(const plo_cam* K, const double Twf[16], const double* Lw, int32_t n,
+                          uint8_t* vis)
+{
+    for (int32_t i = 0; i < n; ++i) {
+        double sP[3], eP[3];
+        xform44(Twf, Lw + 6 * (size_t)i, sP);                    /* :650-655 */
+        xform44(Twf, Lw + 6 * (size_t)i + 3, eP);
+        vis[i] = (uint8_t)(inside(K, sP) && inside(K, eP));
+    }
+}

@@ -1,0 +1,50 @@
+"""Builds plslam_amd/lib/libplslam_hip.so with hipcc for gfx950 (cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+CSRC = os.path.join(_HERE, "csrc")
+OUT = os.path.join(_HERE, "lib", "libplslam_hip.so")
+SOURCES = ["hamming.hip", "lba.hip", "capi.hip"]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(_ROOT, "include", "plslam_hip.h")]
+# -ffp-contract=off: the fp64 row kernels must execute the reference's operation order
+# (no FMA contraction) so that thresholded masks reproduce the CPU restatement bit for bit.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-Wall", "-Wextra", "-Wno-unused-command-line-argument"]
+
+
+def hipcc_path() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (ROCm toolchain required to build libplslam_hip.so)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return OUT
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    cmd = [hipcc_path()] + FLAGS + ["-I" + os.path.join(_ROOT, "include")] + \
+          [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT, "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build_hip(force=True, verbose=True))

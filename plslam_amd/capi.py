@@ -1,0 +1,347 @@
+"""ctypes binding of include/plslam_hip.h (libplslam_hip.so).
+
+This module is plumbing: it declares the C-ABI entry points and wraps them for numpy
+(host-pointer calls) and raw device pointers (plans).  It contains no algorithm and has NO
+CPU fallback: if the HIP library is missing it raises, and without a gfx950 device
+``Context()`` raises ``PlslamError(PLSLAM_ENODEV)``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libplslam_hip.so")
+
+OK, EINVAL, ENODEV, EHIP, ENOMEM, ERANGE, ENOTSUP = 0, -1, -2, -3, -4, -5, -6
+SCAN_AUTO, SCAN_LANE_PER_QUERY, SCAN_WAVE_PER_QUERY, SCAN_SYMMETRIC = 0, 1, 2, 3
+MAX_TRAIN_ROWS = 1 << 23
+
+# every symbol include/plslam_hip.h declares (tests check the .so exports all of them)
+ABI_SYMBOLS = (
+    "plslam_strerror", "plslam_last_error", "plslam_abi_version",
+    "plslam_ctx_create", "plslam_ctx_destroy", "plslam_ctx_set_option", "plslam_ctx_get_option",
+    "plslam_ctx_device_info",
+    "plslam_knn2_hamming256", "plslam_match", "plslam_match_batched",
+    "plslam_match_plan_create", "plslam_match_plan_run", "plslam_match_plan_set_profiling",
+    "plslam_match_plan_elapsed", "plslam_match_plan_info", "plslam_match_plan_destroy",
+    "plslam_lba_point_rows", "plslam_lba_line_rows", "plslam_lba_point_rows_dev",
+    "plslam_lba_line_rows_dev",
+    "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
+    "plslam_map_line_visible",
+    "plslam_gather_match_tables",
+)
+
+
+class Cam(C.Structure):
+    """plslam_cam"""
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("b", C.c_double), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class MatchProblem(C.Structure):
+    """plslam_match_problem (device pointers)"""
+    _fields_ = [("d1", C.c_void_p), ("d2", C.c_void_p), ("n1", C.c_int32), ("n2", C.c_int32),
+                ("nnr", C.c_float), ("mutual", C.c_int32), ("matches_12", C.c_void_p),
+                ("n_matches", C.c_void_p)]
+
+
+class PlanInfo(C.Structure):
+    """plslam_plan_info"""
+    _fields_ = [("distance_evals", C.c_int64), ("directed_evals", C.c_int64),
+                ("algorithmic_bytes", C.c_int64), ("n_scans", C.c_int32),
+                ("scan_blocks", C.c_int32), ("scan_variant", C.c_int32),
+                ("scan_block_threads", C.c_int32)]
+
+
+class PlslamError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str = ""):
+        self.code = code
+        super().__init__(f"{where}: {code} ({detail})")
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen libplslam_hip.so and declare prototypes.  Fails loudly if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, f64 = C.c_void_p, C.c_int32, C.c_double
+    L.plslam_strerror.restype = C.c_char_p
+    L.plslam_strerror.argtypes = [C.c_int]
+    L.plslam_last_error.restype = C.c_char_p
+    L.plslam_last_error.argtypes = []
+    L.plslam_abi_version.restype = C.c_int
+    L.plslam_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.plslam_ctx_destroy.argtypes = [vp]
+    L.plslam_ctx_destroy.restype = None
+    L.plslam_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.plslam_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int)]
+    L.plslam_ctx_device_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32),
+                                         C.c_char_p, i32]
+    L.plslam_knn2_hamming256.argtypes = [vp, vp, i32, vp, i32, vp, vp]
+    L.plslam_match.argtypes = [vp, vp, i32, vp, i32, C.c_float, C.c_int, vp, C.POINTER(i32)]
+    L.plslam_match_batched.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, C.c_int, vp, vp]
+    L.plslam_match_plan_create.argtypes = [vp, C.POINTER(MatchProblem), i32, C.POINTER(vp)]
+    L.plslam_match_plan_run.argtypes = [vp, vp]
+    L.plslam_match_plan_set_profiling.argtypes = [vp, C.c_int]
+    L.plslam_match_plan_elapsed.argtypes = [vp, C.POINTER(f64), C.POINTER(f64), C.POINTER(C.c_int64)]
+    L.plslam_match_plan_info.argtypes = [vp, C.POINTER(PlanInfo)]
+    L.plslam_match_plan_destroy.argtypes = [vp]
+    L.plslam_match_plan_destroy.restype = None
+    L.plslam_lba_point_rows.argtypes = [vp, C.POINTER(Cam), f64, vp, i32, vp, i32, vp, vp, vp, i32,
+                                        vp, vp, vp, vp]
+    L.plslam_lba_line_rows.argtypes = [vp, C.POINTER(Cam), f64, C.c_int, vp, i32, vp, i32, vp, vp, vp,
+                                       i32, vp, vp, vp, vp]
+    L.plslam_lba_point_rows_dev.argtypes = [vp, C.POINTER(Cam), f64, vp, vp, vp, vp, vp, i32,
+                                            vp, vp, vp, vp, vp]
+    L.plslam_lba_line_rows_dev.argtypes = [vp, C.POINTER(Cam), f64, C.c_int, vp, vp, vp, vp, vp, i32,
+                                           vp, vp, vp, vp, vp]
+    for f in (L.plslam_map2kf_point_gate, L.plslam_map2kf_line_gate):
+        f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, i32, vp, i32, f64, vp, C.POINTER(i32)]
+    for f in (L.plslam_map_point_visible, L.plslam_map_line_visible):
+        f.argtypes = [vp, C.POINTER(Cam), vp, vp, i32, vp]
+    L.plslam_gather_match_tables.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp]
+    for name in ABI_SYMBOLS:
+        f = getattr(L, name)
+        if name not in ("plslam_strerror", "plslam_last_error", "plslam_ctx_destroy",
+                        "plslam_match_plan_destroy"):
+            f.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _check(code: int, where: str) -> None:
+    if code != OK:
+        L = load()
+        raise PlslamError(code, where, f"{L.plslam_strerror(code).decode()}; "
+                                       f"{L.plslam_last_error().decode()}")
+
+
+def _arr(a, dt, shape=None):
+    a = np.ascontiguousarray(a, dtype=dt)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else C.c_void_p(
+        a.ctypes.data if a is not None else None)
+
+
+def make_cam(fx, fy, cx, cy, b=0.0, width=0, height=0) -> Cam:
+    return Cam(float(fx), float(fy), float(cx), float(cy), float(b), int(width), int(height))
+
+
+class Context:
+    """plslam_ctx: one HIP device, one stream, scratch pools."""
+
+    def __init__(self, device: int = 0):
+        self._L = load()
+        h = C.c_void_p()
+        _check(self._L.plslam_ctx_create(int(device), C.byref(h)), "plslam_ctx_create")
+        self._h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.plslam_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_option(self, key: str, value: int) -> None:
+        _check(self._L.plslam_ctx_set_option(self._h, key.encode(), int(value)), "plslam_ctx_set_option")
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int()
+        _check(self._L.plslam_ctx_get_option(self._h, key.encode(), C.byref(v)), "plslam_ctx_get_option")
+        return v.value
+
+    def device_info(self) -> dict:
+        cu, clk, lds = C.c_int32(), C.c_int32(), C.c_int32()
+        name = C.create_string_buffer(256)
+        _check(self._L.plslam_ctx_device_info(self._h, C.byref(cu), C.byref(clk), C.byref(lds), name, 256),
+               "plslam_ctx_device_info")
+        return {"cu_count": cu.value, "clock_khz": clk.value, "lds_bytes": lds.value,
+                "name": name.value.decode()}
+
+    # ---- host-pointer calls (numpy in, numpy out) ------------------------------------------
+    def knn2(self, q, t):
+        q = _arr(q, np.uint8, (-1, 32))
+        t = _arr(t, np.uint8, (-1, 32))
+        idx = np.empty((q.shape[0], 2), np.int32)
+        dist = np.empty((q.shape[0], 2), np.int32)
+        _check(self._L.plslam_knn2_hamming256(self._h, _p(q), q.shape[0], _p(t), t.shape[0], _p(idx),
+                                              _p(dist)), "plslam_knn2_hamming256")
+        return idx, dist
+
+    def match(self, d1, d2, nnr: float, mutual: bool = True):
+        """StVO::match(desc1, desc2, nnr, matches_12) -> (matches_12, n_matches)."""
+        d1 = _arr(d1, np.uint8, (-1, 32))
+        d2 = _arr(d2, np.uint8, (-1, 32))
+        m12 = np.empty(d1.shape[0], np.int32)
+        n = C.c_int32()
+        _check(self._L.plslam_match(self._h, _p(d1), d1.shape[0], _p(d2), d2.shape[0], float(nnr),
+                                    int(bool(mutual)), _p(m12), C.byref(n)), "plslam_match")
+        return m12, n.value
+
+    def match_batched(self, d1, off1, d2, off2, nnr: float, mutual: bool = True):
+        d1 = _arr(d1, np.uint8, (-1, 32))
+        d2 = _arr(d2, np.uint8, (-1, 32))
+        off1 = _arr(off1, np.int32)
+        off2 = _arr(off2, np.int32)
+        B = off1.shape[0] - 1
+        m12 = np.empty(int(off1[-1]) if B >= 0 else 0, np.int32)
+        nm = np.empty(max(B, 0), np.int32)
+        _check(self._L.plslam_match_batched(self._h, _p(d1), _p(off1), _p(d2), _p(off2), B, float(nnr),
+                                            int(bool(mutual)), _p(m12), _p(nm)), "plslam_match_batched")
+        return m12, nm
+
+    def lba_point_rows(self, cam: Cam, homog_th, T_kf_w, Xw, obs_uv, lm_loc, kf_slot):
+        T = _arr(T_kf_w, np.float64, (-1, 16))
+        Xw = _arr(Xw, np.float64, (-1, 3))
+        uv = _arr(obs_uv, np.float64, (-1, 2))
+        lm, kf = _arr(lm_loc, np.int32), _arr(kf_slot, np.int32)
+        n = uv.shape[0]
+        Jp, Jl, r, w = np.empty((n, 6)), np.empty((n, 3)), np.empty(n), np.empty(n)
+        _check(self._L.plslam_lba_point_rows(self._h, C.byref(cam), float(homog_th), _p(T), T.shape[0],
+                                             _p(Xw), Xw.shape[0], _p(uv), _p(lm), _p(kf), n, _p(Jp),
+                                             _p(Jl), _p(r), _p(w)), "plslam_lba_point_rows")
+        return Jp, Jl, r, w
+
+    def lba_line_rows(self, cam: Cam, homog_th, T_kf_w, Lw, l_obs, lm_loc, kf_slot,
+                      compat_iter_pass: bool = False):
+        T = _arr(T_kf_w, np.float64, (-1, 16))
+        Lw = _arr(Lw, np.float64, (-1,))
+        lo = _arr(l_obs, np.float64, (-1, 3))
+        lm, kf = _arr(lm_loc, np.int32), _arr(kf_slot, np.int32)
+        n = lo.shape[0]
+        Jp, Jl, r, w = np.empty((n, 6)), np.empty((n, 6)), np.empty(n), np.empty(n)
+        _check(self._L.plslam_lba_line_rows(self._h, C.byref(cam), float(homog_th),
+                                            int(bool(compat_iter_pass)), _p(T), T.shape[0], _p(Lw),
+                                            Lw.shape[0], _p(lo), _p(lm), _p(kf), n, _p(Jp), _p(Jl),
+                                            _p(r), _p(w)), "plslam_lba_line_rows")
+        return Jp, Jl, r, w
+
+    def _gate(self, fn, name, cam, Twf, LM, lw, m12, feat, fw, th):
+        Twf = _arr(Twf, np.float64, (16,))
+        LM = _arr(LM, np.float64, (-1, lw))
+        m12 = _arr(m12, np.int32)
+        feat = _arr(feat, np.float64, (-1, fw))
+        mask = np.empty(m12.shape[0], np.uint8)
+        n = C.c_int32()
+        _check(fn(self._h, C.byref(cam), _p(Twf), _p(LM), _p(m12), m12.shape[0], _p(feat), feat.shape[0],
+                  float(th), _p(mask), C.byref(n)), name)
+        return mask, n.value
+
+    def map2kf_point_gate(self, cam, Twf, Xw, m12, pl, max_epip):
+        return self._gate(self._L.plslam_map2kf_point_gate, "plslam_map2kf_point_gate", cam, Twf, Xw, 3,
+                          m12, pl, 2, max_epip)
+
+    def map2kf_line_gate(self, cam, Twf, Lw, m12, le, max_epip):
+        return self._gate(self._L.plslam_map2kf_line_gate, "plslam_map2kf_line_gate", cam, Twf, Lw, 6,
+                          m12, le, 3, max_epip)
+
+    def map_point_visible(self, cam, Twf, Xw):
+        Twf = _arr(Twf, np.float64, (16,))
+        Xw = _arr(Xw, np.float64, (-1, 3))
+        vis = np.empty(Xw.shape[0], np.uint8)
+        _check(self._L.plslam_map_point_visible(self._h, C.byref(cam), _p(Twf), _p(Xw), Xw.shape[0], _p(vis)),
+               "plslam_map_point_visible")
+        return vis
+
+    def map_line_visible(self, cam, Twf, Lw):
+        Twf = _arr(Twf, np.float64, (16,))
+        Lw = _arr(Lw, np.float64, (-1, 6))
+        vis = np.empty(Lw.shape[0], np.uint8)
+        _check(self._L.plslam_map_line_visible(self._h, C.byref(cam), _p(Twf), _p(Lw), Lw.shape[0], _p(vis)),
+               "plslam_map_line_visible")
+        return vis
+
+    # ---- device-pointer calls ----------------------------------------------------------------
+    def lba_point_rows_dev(self, cam, homog_th, T, Xw, uv, lm, kf, nobs, Jp, Jl, r, w, stream=0):
+        _check(self._L.plslam_lba_point_rows_dev(self._h, C.byref(cam), float(homog_th), T, Xw, uv, lm, kf,
+                                                 int(nobs), Jp, Jl, r, w, stream or None),
+               "plslam_lba_point_rows_dev")
+
+    def lba_line_rows_dev(self, cam, homog_th, compat, T, Lw, lo, lm, kf, nobs, Jp, Jl, r, w, stream=0):
+        _check(self._L.plslam_lba_line_rows_dev(self._h, C.byref(cam), float(homog_th), int(bool(compat)), T,
+                                                Lw, lo, lm, kf, int(nobs), Jp, Jl, r, w, stream or None),
+               "plslam_lba_line_rows_dev")
+
+    def plan(self, problems) -> "MatchPlan":
+        return MatchPlan(self, problems)
+
+
+class MatchPlan:
+    """plslam_match_plan over device pointers (ints, e.g. torch.Tensor.data_ptr()).
+
+    problems: iterable of (d1_ptr, n1, d2_ptr, n2, nnr, mutual, matches12_ptr, n_matches_ptr|0)
+    """
+
+    def __init__(self, ctx: Context, problems):
+        self._ctx = ctx
+        self._L = ctx._L
+        problems = list(problems)
+        arr = (MatchProblem * max(len(problems), 1))()
+        for i, (d1, n1, d2, n2, nnr, mutual, m12, nm) in enumerate(problems):
+            arr[i] = MatchProblem(d1 or None, d2 or None, int(n1), int(n2), float(nnr), int(bool(mutual)),
+                                  m12 or None, nm or None)
+        h = C.c_void_p()
+        _check(self._L.plslam_match_plan_create(ctx.handle, arr, len(problems), C.byref(h)),
+               "plslam_match_plan_create")
+        self._h = h
+
+    def run(self, stream: int = 0) -> None:
+        _check(self._L.plslam_match_plan_run(self._h, stream or None), "plslam_match_plan_run")
+
+    def set_profiling(self, on: bool) -> None:
+        _check(self._L.plslam_match_plan_set_profiling(self._h, int(bool(on))),
+               "plslam_match_plan_set_profiling")
+
+    def elapsed(self):
+        a, b, n = C.c_double(), C.c_double(), C.c_int64()
+        _check(self._L.plslam_match_plan_elapsed(self._h, C.byref(a), C.byref(b), C.byref(n)),
+               "plslam_match_plan_elapsed")
+        return a.value, b.value, n.value
+
+    def info(self) -> dict:
+        i = PlanInfo()
+        _check(self._L.plslam_match_plan_info(self._h, C.byref(i)), "plslam_match_plan_info")
+        return {k: getattr(i, k) for k, _ in PlanInfo._fields_}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.plslam_match_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

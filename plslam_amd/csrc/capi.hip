@@ -1,0 +1,783 @@
+// capi.hip -- the extern "C" boundary of libplslam_hip.so (see include/plslam_hip.h).
+// Context, match plans, host-pointer convenience entry points, RCCL gather.
+#include <dlfcn.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <new>
+
+#include "common.hpp"
+
+namespace plslam {
+
+static thread_local char g_err[512] = "";
+
+void set_last_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int DevBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return PLSLAM_OK;
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes + (bytes >> 2);  // grow by 25 % to damp re-allocation
+    want = (want + 255) & ~size_t(255);
+    PLSLAM_HIP_CHECK(hipMalloc(&p, want));
+    cap = want;
+    return PLSLAM_OK;
+}
+
+void DevBuf::release()
+{
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+struct DeviceGuard {  // every entry point runs on the context's device
+    int prev = -1;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+}  // namespace plslam
+
+using namespace plslam;
+
+// ---------------------------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------------------------
+struct plslam_match_plan {
+    plslam_ctx* ctx = nullptr;
+    int variant = 0, block_threads = 0;
+    int32_t nprob = 0, nscan = 0, nscan_blocks = 0, nfin_blocks = 0, ncounts = 0;
+    DevBuf keys, scans, probs, scan_blocks, fin_blocks, counts, count_dst;
+    int32_t* d_counts_zero = nullptr;  // contiguous int32 counters zeroed by the scan kernel
+    bool scatter_counts = false;       // user n_matches pointers are not one contiguous array
+    plslam_plan_info info{};
+    bool profiling = false;
+    struct Ev { hipEvent_t e0, e1, e2; };
+    std::vector<Ev> evs;
+    size_t ev_used = 0;
+    double acc_scan_ms = 0, acc_fin_ms = 0;
+    int64_t acc_runs = 0;
+    void free_all()
+    {
+        keys.release(); scans.release(); probs.release();
+        scan_blocks.release(); fin_blocks.release(); counts.release(); count_dst.release();
+        for (auto& e : evs) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2); }
+        evs.clear();
+    }
+};
+
+static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob,
+                      plslam_match_plan* P)
+{
+    PLSLAM_REQUIRE(nprob >= 0, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(nprob == 0 || probs != nullptr, PLSLAM_EINVAL);
+    P->ctx = ctx;
+    P->nprob = nprob;
+
+    int64_t rows = 0;
+    bool all_mutual = nprob > 0;
+    for (int32_t i = 0; i < nprob; ++i) {
+        const plslam_match_problem& p = probs[i];
+        PLSLAM_REQUIRE(p.n1 >= 0 && p.n2 >= 0, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(p.n1 == 0 || p.d1 != nullptr, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(p.n2 == 0 || p.d2 != nullptr, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(p.n1 == 0 || p.matches_12 != nullptr, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE((reinterpret_cast<uintptr_t>(p.d1) & 3) == 0, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE((reinterpret_cast<uintptr_t>(p.d2) & 3) == 0, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(p.n2 <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
+        PLSLAM_REQUIRE(!p.mutual || p.n1 <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
+        rows += p.n1 + (p.mutual ? p.n2 : 0);
+        all_mutual = all_mutual && p.mutual;
+    }
+    PLSLAM_REQUIRE(rows < (int64_t(1) << 31), PLSLAM_ERANGE);
+
+    P->variant = resolve_scan_variant(ctx, rows, all_mutual);
+    P->block_threads = ctx->scan_block ? ctx->scan_block : 256;
+    const int rpb = scan_rows_per_block(P->variant, P->block_threads);
+
+    int r = P->keys.reserve(sizeof(uint32_t) * 2 * (size_t)(rows > 0 ? rows : 1));
+    if (r) return r;
+    uint32_t* d_keys = P->keys.as<uint32_t>();
+    // #matches counters: accumulated with atomics by the finalize kernel, zeroed by the scan
+    // kernel.  If the caller's n_matches pointers form one contiguous array, count in place.
+    bool contiguous = nprob > 0, any_user = false;
+    for (int32_t i = 0; i < nprob; ++i) {
+        any_user = any_user || probs[i].n_matches != nullptr;
+        contiguous = contiguous && probs[i].n_matches != nullptr &&
+                     probs[i].n_matches == probs[0].n_matches + i;
+    }
+    int32_t* d_counts = nullptr;
+    if (contiguous) {
+        d_counts = probs[0].n_matches;
+    } else {
+        r = P->counts.reserve(sizeof(int32_t) * (size_t)(nprob > 0 ? nprob : 1));
+        if (r) return r;
+        d_counts = P->counts.as<int32_t>();
+    }
+    P->scatter_counts = any_user && !contiguous;
+    P->d_counts_zero = d_counts;
+    P->ncounts = nprob;
+
+    std::vector<ScanDesc> scans;
+    std::vector<ProblemDesc> pds;
+    std::vector<BlockDesc> sblocks, fblocks;
+    int64_t key_row = 0, evals = 0, abytes = 0;
+    std::vector<int32_t*> user_counts((size_t)nprob, nullptr);
+    for (int32_t i = 0; i < nprob; ++i) {
+        const plslam_match_problem& p = probs[i];
+        ProblemDesc pd{};
+        pd.n1 = p.n1; pd.n2 = p.n2; pd.nnr = p.nnr; pd.mutual = p.mutual ? 1 : 0;
+        pd.matches_12 = p.matches_12;
+        pd.n_matches = d_counts + i;
+        user_counts[i] = p.n_matches;
+        pd.keys12 = d_keys + 2 * key_row;
+        if (p.n1 > 0) {
+            ScanDesc s{p.d1, p.d2, d_keys + 2 * key_row, p.n1, p.n2};
+            for (int32_t r0 = 0; r0 < p.n1; r0 += rpb) sblocks.push_back({(int32_t)scans.size(), r0});
+            scans.push_back(s);
+            for (int32_t r0 = 0; r0 < p.n1; r0 += 256) fblocks.push_back({i, r0});
+            evals += (int64_t)p.n1 * p.n2;
+            abytes += 32LL * (p.n1 + p.n2) + 16LL * p.n1;
+        }
+        key_row += p.n1;
+        pd.keys21 = nullptr;
+        if (p.mutual) {
+            pd.keys21 = d_keys + 2 * key_row;
+            if (p.n2 > 0 && p.n1 > 0) {
+                ScanDesc s{p.d2, p.d1, d_keys + 2 * key_row, p.n2, p.n1};
+                for (int32_t r0 = 0; r0 < p.n2; r0 += rpb) sblocks.push_back({(int32_t)scans.size(), r0});
+                scans.push_back(s);
+                evals += (int64_t)p.n1 * p.n2;
+                abytes += 32LL * (p.n1 + p.n2) + 16LL * p.n2;
+            }
+            key_row += p.n2;
+        }
+        pds.push_back(pd);
+    }
+    P->nscan = (int32_t)scans.size();
+    P->nscan_blocks = (int32_t)sblocks.size();
+    P->nfin_blocks = (int32_t)fblocks.size();
+    P->info.distance_evals = evals;
+    P->info.directed_evals = evals;
+    P->info.algorithmic_bytes = abytes;
+    P->info.n_scans = P->nscan;
+    P->info.scan_blocks = P->nscan_blocks;
+    P->info.scan_variant = P->variant;
+    P->info.scan_block_threads = P->block_threads;
+
+    auto upload = [&](DevBuf& b, const void* src, size_t bytes) -> int {
+        int rr = b.reserve(bytes ? bytes : 16);
+        if (rr) return rr;
+        if (bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        return PLSLAM_OK;
+    };
+    if ((r = upload(P->scans, scans.data(), scans.size() * sizeof(ScanDesc)))) return r;
+    if ((r = upload(P->probs, pds.data(), pds.size() * sizeof(ProblemDesc)))) return r;
+    if ((r = upload(P->scan_blocks, sblocks.data(), sblocks.size() * sizeof(BlockDesc)))) return r;
+    if ((r = upload(P->fin_blocks, fblocks.data(), fblocks.size() * sizeof(BlockDesc)))) return r;
+    if (P->scatter_counts)
+        if ((r = upload(P->count_dst, user_counts.data(), user_counts.size() * sizeof(int32_t*)))) return r;
+    // the staging vectors die at scope exit: make the uploads complete first
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return PLSLAM_OK;
+}
+
+static int plan_run(plslam_match_plan* P, hipStream_t s)
+{
+    plslam_match_plan::Ev* ev = nullptr;
+    if (P->profiling) {
+        if (P->ev_used == P->evs.size()) {
+            plslam_match_plan::Ev e{};
+            PLSLAM_HIP_CHECK(hipEventCreate(&e.e0));
+            PLSLAM_HIP_CHECK(hipEventCreate(&e.e1));
+            PLSLAM_HIP_CHECK(hipEventCreate(&e.e2));
+            P->evs.push_back(e);
+        }
+        ev = &P->evs[P->ev_used++];
+        PLSLAM_HIP_CHECK(hipEventRecord(ev->e0, s));
+    }
+    int r = launch_scan(P->ctx, P->variant, P->block_threads, P->scans.as<ScanDesc>(),
+                        P->scan_blocks.as<BlockDesc>(), P->nscan_blocks, P->d_counts_zero,
+                        P->ncounts, s);
+    if (r) return r;
+    if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e1, s));
+    r = launch_finalize(P->probs.as<ProblemDesc>(), P->fin_blocks.as<BlockDesc>(), P->nfin_blocks, s);
+    if (r) return r;
+    if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e2, s));
+    if (P->scatter_counts)
+        return launch_scatter_counts(P->d_counts_zero, P->count_dst.as<int32_t*>(), P->nprob, s);
+    return PLSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// extern "C"
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* plslam_strerror(int code)
+{
+    switch (code) {
+        case PLSLAM_OK: return "ok";
+        case PLSLAM_EINVAL: return "invalid argument";
+        case PLSLAM_ENODEV: return "no usable gfx950 HIP device";
+        case PLSLAM_EHIP: return "HIP runtime error";
+        case PLSLAM_ENOMEM: return "out of memory";
+        case PLSLAM_ERANGE: return "size beyond documented limit";
+        case PLSLAM_ENOTSUP: return "optional component unavailable";
+        default: return "unknown error";
+    }
+}
+
+const char* plslam_last_error(void) { return g_err; }
+int plslam_abi_version(void) { return PLSLAM_ABI_VERSION; }
+
+int plslam_ctx_create(int device_ordinal, plslam_ctx** out)
+{
+    PLSLAM_REQUIRE(out != nullptr, PLSLAM_EINVAL);
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        set_last_error("no HIP device visible (this library has no CPU fallback)");
+        return PLSLAM_ENODEV;
+    }
+    PLSLAM_REQUIRE(device_ordinal >= 0 && device_ordinal < ndev, PLSLAM_ENODEV);
+    plslam_ctx* c = new (std::nothrow) plslam_ctx();
+    PLSLAM_REQUIRE(c != nullptr, PLSLAM_ENOMEM);
+    c->device = device_ordinal;
+    DeviceGuard g(device_ordinal);
+    if (hipGetDeviceProperties(&c->prop, device_ordinal) != hipSuccess) {
+        delete c;
+        set_last_error("hipGetDeviceProperties failed");
+        return PLSLAM_ENODEV;
+    }
+    if (strncmp(c->prop.gcnArchName, "gfx950", 6) != 0) {
+        set_last_error("device %d is %s; this library carries gfx950 code only", device_ordinal,
+                       c->prop.gcnArchName);
+        delete c;
+        return PLSLAM_ENODEV;
+    }
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        set_last_error("hipStreamCreate failed");
+        return PLSLAM_EHIP;
+    }
+    *out = c;
+    return PLSLAM_OK;
+}
+
+void plslam_ctx_destroy(plslam_ctx* ctx)
+{
+    if (!ctx) return;
+    DeviceGuard g(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->in_a.release(); ctx->in_b.release(); ctx->out_a.release(); ctx->out_b.release();
+    ctx->misc_a.release(); ctx->misc_b.release(); ctx->misc_c.release();
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
+{
+    PLSLAM_REQUIRE(ctx && key, PLSLAM_EINVAL);
+    if (!strcmp(key, "scan_variant")) {
+        PLSLAM_REQUIRE(value >= PLSLAM_SCAN_AUTO && value <= PLSLAM_SCAN_SYMMETRIC, PLSLAM_EINVAL);
+        ctx->scan_variant = value;
+        return PLSLAM_OK;
+    }
+    if (!strcmp(key, "scan_block")) {
+        PLSLAM_REQUIRE(value == 0 || value == 256 || value == 512 || value == 1024, PLSLAM_EINVAL);
+        ctx->scan_block = value;
+        return PLSLAM_OK;
+    }
+    set_last_error("unknown option '%s'", key);
+    return PLSLAM_EINVAL;
+}
+
+int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
+{
+    PLSLAM_REQUIRE(ctx && key && value, PLSLAM_EINVAL);
+    if (!strcmp(key, "scan_variant")) { *value = ctx->scan_variant; return PLSLAM_OK; }
+    if (!strcmp(key, "scan_block")) { *value = ctx->scan_block; return PLSLAM_OK; }
+    set_last_error("unknown option '%s'", key);
+    return PLSLAM_EINVAL;
+}
+
+int plslam_ctx_device_info(plslam_ctx* ctx, int32_t* cu_count, int32_t* clock_khz,
+                           int32_t* lds_bytes, char* name, int32_t name_len)
+{
+    PLSLAM_REQUIRE(ctx != nullptr, PLSLAM_EINVAL);
+    if (cu_count) *cu_count = ctx->prop.multiProcessorCount;
+    if (clock_khz) *clock_khz = ctx->prop.clockRate;
+    if (lds_bytes) *lds_bytes = (int32_t)ctx->prop.sharedMemPerBlock;
+    if (name && name_len > 0) {
+        snprintf(name, (size_t)name_len, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    }
+    return PLSLAM_OK;
+}
+
+// ---- plans ----------------------------------------------------------------------------------
+int plslam_match_plan_create(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob,
+                             plslam_match_plan** out)
+{
+    PLSLAM_REQUIRE(ctx && out, PLSLAM_EINVAL);
+    *out = nullptr;
+    DeviceGuard g(ctx->device);
+    plslam_match_plan* P = new (std::nothrow) plslam_match_plan();
+    PLSLAM_REQUIRE(P != nullptr, PLSLAM_ENOMEM);
+    const int r = plan_build(ctx, probs, nprob, P);
+    if (r) {
+        P->free_all();
+        delete P;
+        return r;
+    }
+    *out = P;
+    return PLSLAM_OK;
+}
+
+int plslam_match_plan_run(plslam_match_plan* plan, void* stream)
+{
+    PLSLAM_REQUIRE(plan != nullptr, PLSLAM_EINVAL);
+    DeviceGuard g(plan->ctx->device);
+    return plan_run(plan, stream ? static_cast<hipStream_t>(stream) : plan->ctx->stream);
+}
+
+int plslam_match_plan_set_profiling(plslam_match_plan* plan, int enable)
+{
+    PLSLAM_REQUIRE(plan != nullptr, PLSLAM_EINVAL);
+    plan->profiling = enable != 0;
+    return PLSLAM_OK;
+}
+
+int plslam_match_plan_elapsed(plslam_match_plan* plan, double* scan_ms, double* finalize_ms,
+                              int64_t* runs)
+{
+    PLSLAM_REQUIRE(plan != nullptr, PLSLAM_EINVAL);
+    DeviceGuard g(plan->ctx->device);
+    for (size_t i = 0; i < plan->ev_used; ++i) {
+        auto& e = plan->evs[i];
+        PLSLAM_HIP_CHECK(hipEventSynchronize(e.e2));
+        float a = 0.f, b = 0.f;
+        PLSLAM_HIP_CHECK(hipEventElapsedTime(&a, e.e0, e.e1));
+        PLSLAM_HIP_CHECK(hipEventElapsedTime(&b, e.e1, e.e2));
+        plan->acc_scan_ms += a;
+        plan->acc_fin_ms += b;
+        plan->acc_runs += 1;
+    }
+    plan->ev_used = 0;
+    if (scan_ms) *scan_ms = plan->acc_scan_ms;
+    if (finalize_ms) *finalize_ms = plan->acc_fin_ms;
+    if (runs) *runs = plan->acc_runs;
+    plan->acc_scan_ms = plan->acc_fin_ms = 0;
+    plan->acc_runs = 0;
+    return PLSLAM_OK;
+}
+
+int plslam_match_plan_info(plslam_match_plan* plan, plslam_plan_info* info)
+{
+    PLSLAM_REQUIRE(plan && info, PLSLAM_EINVAL);
+    *info = plan->info;
+    return PLSLAM_OK;
+}
+
+void plslam_match_plan_destroy(plslam_match_plan* plan)
+{
+    if (!plan) return;
+    DeviceGuard g(plan->ctx->device);
+    (void)hipDeviceSynchronize();
+    plan->free_all();
+    delete plan;
+}
+
+// ---- host-pointer matching -------------------------------------------------------------------
+int plslam_match_batched(plslam_ctx* ctx, const uint8_t* d1, const int32_t* off1,
+                         const uint8_t* d2, const int32_t* off2, int32_t B, float nnr, int mutual,
+                         int32_t* matches_12, int32_t* n_matches)
+{
+    PLSLAM_REQUIRE(ctx != nullptr && B >= 0, PLSLAM_EINVAL);
+    if (B == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(off1 && off2, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(off1[0] == 0 && off2[0] == 0, PLSLAM_EINVAL);
+    for (int32_t b = 0; b < B; ++b)
+        PLSLAM_REQUIRE(off1[b + 1] >= off1[b] && off2[b + 1] >= off2[b], PLSLAM_EINVAL);
+    const int64_t r1 = off1[B], r2 = off2[B];
+    PLSLAM_REQUIRE(r1 == 0 || (d1 && matches_12), PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(r2 == 0 || d2, PLSLAM_EINVAL);
+
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    int r;
+    if ((r = ctx->in_a.reserve((size_t)r1 * 32 + 16))) return r;
+    if ((r = ctx->in_b.reserve((size_t)r2 * 32 + 16))) return r;
+    if ((r = ctx->out_a.reserve((size_t)r1 * 4 + 16))) return r;
+    if ((r = ctx->out_b.reserve((size_t)B * 4))) return r;
+    if (r1) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_a.p, d1, (size_t)r1 * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (r2) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_b.p, d2, (size_t)r2 * 32, hipMemcpyHostToDevice, ctx->stream));
+
+    std::vector<plslam_match_problem> probs((size_t)B);
+    for (int32_t b = 0; b < B; ++b) {
+        plslam_match_problem& p = probs[b];
+        p.d1 = ctx->in_a.as<uint8_t>() + (size_t)off1[b] * 32;
+        p.d2 = ctx->in_b.as<uint8_t>() + (size_t)off2[b] * 32;
+        p.n1 = off1[b + 1] - off1[b];
+        p.n2 = off2[b + 1] - off2[b];
+        p.nnr = nnr;
+        p.mutual = mutual ? 1 : 0;
+        p.matches_12 = ctx->out_a.as<int32_t>() + off1[b];
+        p.n_matches = ctx->out_b.as<int32_t>() + b;
+    }
+    plslam_match_plan P;
+    r = plan_build(ctx, probs.data(), B, &P);
+    if (!r) r = plan_run(&P, ctx->stream);
+    if (!r) {
+        hipError_t e = hipSuccess;
+        if (r1) e = hipMemcpyAsync(matches_12, ctx->out_a.p, (size_t)r1 * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && n_matches)
+            e = hipMemcpyAsync(n_matches, ctx->out_b.p, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            set_last_error("%s:%d: D2H of match tables -> %s", __FILE__, __LINE__, hipGetErrorString(e));
+            r = PLSLAM_EHIP;
+        }
+    } else {
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    P.free_all();
+    return r;
+}
+
+int plslam_match(plslam_ctx* ctx, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2,
+                 float nnr, int mutual, int32_t* matches_12, int32_t* n_matches)
+{
+    PLSLAM_REQUIRE(n1 >= 0 && n2 >= 0, PLSLAM_EINVAL);
+    const int32_t off1[2] = {0, n1}, off2[2] = {0, n2};
+    int32_t n = 0;
+    const int r = plslam_match_batched(ctx, d1, off1, d2, off2, 1, nnr, mutual, matches_12, &n);
+    if (!r && n_matches) *n_matches = n;
+    return r;
+}
+
+int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const uint8_t* t,
+                           int32_t nt, int32_t* idx, int32_t* dist)
+{
+    PLSLAM_REQUIRE(ctx != nullptr && nq >= 0 && nt >= 0, PLSLAM_EINVAL);
+    if (nq == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(q && idx && dist && (nt == 0 || t), PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(nt <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    int r;
+    const int variant = ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_SYMMETRIC
+                            ? PLSLAM_SCAN_LANE_PER_QUERY : ctx->scan_variant;
+    const int bt = ctx->scan_block ? ctx->scan_block : 256;
+    const int rpb = scan_rows_per_block(variant, bt);
+    if ((r = ctx->in_a.reserve((size_t)nq * 32))) return r;
+    if ((r = ctx->in_b.reserve((size_t)nt * 32 + 16))) return r;
+    if ((r = ctx->misc_a.reserve((size_t)nq * 8))) return r;                 // keys
+    if ((r = ctx->out_a.reserve((size_t)nq * 8))) return r;                  // idx
+    if ((r = ctx->out_b.reserve((size_t)nq * 8))) return r;                  // dist
+    std::vector<BlockDesc> blocks;
+    for (int32_t r0 = 0; r0 < nq; r0 += rpb) blocks.push_back({0, r0});
+    if ((r = ctx->misc_b.reserve(sizeof(ScanDesc) + 16))) return r;
+    if ((r = ctx->misc_c.reserve(blocks.size() * sizeof(BlockDesc)))) return r;
+    ScanDesc sd{ctx->in_a.as<uint8_t>(), ctx->in_b.as<uint8_t>(), ctx->misc_a.as<uint32_t>(), nq, nt};
+    hipStream_t s = ctx->stream;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_a.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+    if (nt) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_b.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->misc_b.p, &sd, sizeof(sd), hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->misc_c.p, blocks.data(), blocks.size() * sizeof(BlockDesc),
+                                    hipMemcpyHostToDevice, s));
+    if ((r = launch_scan(ctx, variant, bt, ctx->misc_b.as<ScanDesc>(), ctx->misc_c.as<BlockDesc>(),
+                         (int)blocks.size(), nullptr, 0, s))) return r;
+    if ((r = launch_unpack_keys(ctx->misc_a.as<uint32_t>(), nq * 2, ctx->out_a.as<int32_t>(),
+                                ctx->out_b.as<int32_t>(), s))) return r;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(idx, ctx->out_a.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(dist, ctx->out_b.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return PLSLAM_OK;
+}
+
+// ---- LBA rows --------------------------------------------------------------------------------
+int plslam_lba_point_rows_dev(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                              const double* T_kf_w, const double* Xw, const double* obs_uv,
+                              const int32_t* lm_loc, const int32_t* kf_slot, int32_t nobs,
+                              double* J_pose, double* J_lm, double* r, double* w, void* stream)
+{
+    PLSLAM_REQUIRE(ctx && K && nobs >= 0, PLSLAM_EINVAL);
+    if (nobs == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(T_kf_w && Xw && obs_uv && lm_loc && kf_slot && J_pose && J_lm && r && w, PLSLAM_EINVAL);
+    DeviceGuard g(ctx->device);
+    return launch_point_rows(*K, homog_th, T_kf_w, Xw, obs_uv, lm_loc, kf_slot, nobs, J_pose, J_lm, r, w,
+                             stream ? static_cast<hipStream_t>(stream) : ctx->stream);
+}
+
+int plslam_lba_line_rows_dev(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                             int compat_iter_pass, const double* T_kf_w, const double* Lw,
+                             const double* l_obs, const int32_t* lm_loc, const int32_t* kf_slot,
+                             int32_t nobs, double* J_pose, double* J_lm, double* r, double* w,
+                             void* stream)
+{
+    PLSLAM_REQUIRE(ctx && K && nobs >= 0, PLSLAM_EINVAL);
+    if (nobs == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(T_kf_w && Lw && l_obs && lm_loc && kf_slot && J_pose && J_lm && r && w, PLSLAM_EINVAL);
+    DeviceGuard g(ctx->device);
+    return launch_line_rows(*K, homog_th, compat_iter_pass ? 1 : 0, T_kf_w, Lw, l_obs, lm_loc, kf_slot,
+                            nobs, J_pose, J_lm, r, w,
+                            stream ? static_cast<hipStream_t>(stream) : ctx->stream);
+}
+
+namespace {
+// carve several arrays out of one scratch DevBuf (256-byte aligned slices)
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~size_t(255); return o; }
+};
+}  // namespace
+
+static int lba_rows_host(plslam_ctx* ctx, const plslam_cam* K, double th, int lines, int compat,
+                         const double* T, int32_t nkf, const double* LM, int64_t n_lm_doubles,
+                         const double* obs, int obs_stride, const int32_t* lm_loc,
+                         const int32_t* kf_slot, int32_t nobs, double* Jp, double* Jl, double* r,
+                         double* w)
+{
+    PLSLAM_REQUIRE(ctx && K && nobs >= 0 && nkf >= 0 && n_lm_doubles >= 0, PLSLAM_EINVAL);
+    if (nobs == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(T && LM && obs && lm_loc && kf_slot && Jp && Jl && r && w, PLSLAM_EINVAL);
+    const int lmw = lines ? 6 : 3;
+    const int lm_stride = lines ? (compat ? 3 : 6) : 3;
+    for (int32_t o = 0; o < nobs; ++o) {  // index validation: the kernel trusts its inputs
+        PLSLAM_REQUIRE(kf_slot[o] >= 0 && kf_slot[o] < nkf, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(lm_loc[o] >= 0 && (int64_t)lm_loc[o] * lm_stride + 3 <= n_lm_doubles, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(!lines || compat || (int64_t)lm_loc[o] * 6 + 6 <= n_lm_doubles, PLSLAM_EINVAL);
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    Carver ci, co;
+    const size_t oT = ci.take((size_t)nkf * 128), oL = ci.take((size_t)n_lm_doubles * 8),
+                 oO = ci.take((size_t)nobs * obs_stride * 8), oLm = ci.take((size_t)nobs * 4),
+                 oKf = ci.take((size_t)nobs * 4);
+    const size_t oJp = co.take((size_t)nobs * 48), oJl = co.take((size_t)nobs * lmw * 8),
+                 oR = co.take((size_t)nobs * 8), oW = co.take((size_t)nobs * 8);
+    int rc;
+    if ((rc = ctx->in_a.reserve(ci.off))) return rc;
+    if ((rc = ctx->out_a.reserve(co.off))) return rc;
+    char* di = ctx->in_a.as<char>();
+    char* dout = ctx->out_a.as<char>();
+    hipStream_t s = ctx->stream;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(di + oT, T, (size_t)nkf * 128, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(di + oL, LM, (size_t)n_lm_doubles * 8, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(di + oO, obs, (size_t)nobs * obs_stride * 8, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(di + oLm, lm_loc, (size_t)nobs * 4, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(di + oKf, kf_slot, (size_t)nobs * 4, hipMemcpyHostToDevice, s));
+    if (!lines)
+        rc = launch_point_rows(*K, th, (double*)(di + oT), (double*)(di + oL), (double*)(di + oO),
+                               (int32_t*)(di + oLm), (int32_t*)(di + oKf), nobs, (double*)(dout + oJp),
+                               (double*)(dout + oJl), (double*)(dout + oR), (double*)(dout + oW), s);
+    else
+        rc = launch_line_rows(*K, th, compat, (double*)(di + oT), (double*)(di + oL), (double*)(di + oO),
+                              (int32_t*)(di + oLm), (int32_t*)(di + oKf), nobs, (double*)(dout + oJp),
+                              (double*)(dout + oJl), (double*)(dout + oR), (double*)(dout + oW), s);
+    if (rc) return rc;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(Jp, dout + oJp, (size_t)nobs * 48, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(Jl, dout + oJl, (size_t)nobs * lmw * 8, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(r, dout + oR, (size_t)nobs * 8, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(w, dout + oW, (size_t)nobs * 8, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return PLSLAM_OK;
+}
+
+int plslam_lba_point_rows(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                          const double* T_kf_w, int32_t nkf, const double* Xw, int32_t npt,
+                          const double* obs_uv, const int32_t* lm_loc, const int32_t* kf_slot,
+                          int32_t nobs, double* J_pose, double* J_lm, double* r, double* w)
+{
+    return lba_rows_host(ctx, K, homog_th, 0, 0, T_kf_w, nkf, Xw, (int64_t)npt * 3, obs_uv, 2, lm_loc,
+                         kf_slot, nobs, J_pose, J_lm, r, w);
+}
+
+int plslam_lba_line_rows(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                         int compat_iter_pass, const double* T_kf_w, int32_t nkf, const double* Lw,
+                         int32_t n_lw, const double* l_obs, const int32_t* lm_loc,
+                         const int32_t* kf_slot, int32_t nobs, double* J_pose, double* J_lm,
+                         double* r, double* w)
+{
+    return lba_rows_host(ctx, K, homog_th, 1, compat_iter_pass ? 1 : 0, T_kf_w, nkf, Lw, n_lw, l_obs, 3,
+                         lm_loc, kf_slot, nobs, J_pose, J_lm, r, w);
+}
+
+// ---- gates -----------------------------------------------------------------------------------
+static int gate_host(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, int lines,
+                     const double* LM, const int32_t* m12, int32_t nq, const double* feat, int32_t nt,
+                     double th, uint8_t* mask, int32_t* n_inliers)
+{
+    PLSLAM_REQUIRE(ctx && K && Twf && nq >= 0 && nt >= 0, PLSLAM_EINVAL);
+    if (n_inliers) *n_inliers = 0;
+    if (nq == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(LM && m12 && mask && (nt == 0 || feat), PLSLAM_EINVAL);
+    for (int32_t i = 0; i < nq; ++i) PLSLAM_REQUIRE(m12[i] < nt, PLSLAM_EINVAL);
+    const int lw = lines ? 6 : 3, fw = lines ? 3 : 2;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    Carver c;
+    const size_t oL = c.take((size_t)nq * lw * 8), oM = c.take((size_t)nq * 4),
+                 oF = c.take((size_t)nt * fw * 8 + 16), oMask = c.take((size_t)nq), oCnt = c.take(4);
+    int rc;
+    if ((rc = ctx->in_a.reserve(c.off))) return rc;
+    char* d = ctx->in_a.as<char>();
+    hipStream_t s = ctx->stream;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oL, LM, (size_t)nq * lw * 8, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oM, m12, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+    if (nt) PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oF, feat, (size_t)nt * fw * 8, hipMemcpyHostToDevice, s));
+    rc = lines ? launch_line_gate(*K, Twf, (double*)(d + oL), (int32_t*)(d + oM), nq, (double*)(d + oF), th,
+                                  (uint8_t*)(d + oMask), (int32_t*)(d + oCnt), s)
+               : launch_point_gate(*K, Twf, (double*)(d + oL), (int32_t*)(d + oM), nq, (double*)(d + oF), th,
+                                   (uint8_t*)(d + oMask), (int32_t*)(d + oCnt), s);
+    if (rc) return rc;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(mask, d + oMask, (size_t)nq, hipMemcpyDeviceToHost, s));
+    int32_t cnt = 0;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(&cnt, d + oCnt, 4, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (n_inliers) *n_inliers = cnt;
+    return PLSLAM_OK;
+}
+
+int plslam_map2kf_point_gate(plslam_ctx* ctx, const plslam_cam* K, const double* Twf,
+                             const double* Xw, const int32_t* matches_12, int32_t nq,
+                             const double* pl, int32_t nt, double max_epip, uint8_t* mask,
+                             int32_t* n_inliers)
+{
+    return gate_host(ctx, K, Twf, 0, Xw, matches_12, nq, pl, nt, max_epip, mask, n_inliers);
+}
+
+int plslam_map2kf_line_gate(plslam_ctx* ctx, const plslam_cam* K, const double* Twf,
+                            const double* Lw, const int32_t* matches_12, int32_t nq,
+                            const double* le, int32_t nt, double max_epip, uint8_t* mask,
+                            int32_t* n_inliers)
+{
+    return gate_host(ctx, K, Twf, 1, Lw, matches_12, nq, le, nt, max_epip, mask, n_inliers);
+}
+
+static int visible_host(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* X,
+                        int32_t n, int lines, uint8_t* vis)
+{
+    PLSLAM_REQUIRE(ctx && K && Twf && n >= 0, PLSLAM_EINVAL);
+    if (n == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(X && vis, PLSLAM_EINVAL);
+    const int lw = lines ? 6 : 3;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    Carver c;
+    const size_t oX = c.take((size_t)n * lw * 8), oV = c.take((size_t)n);
+    int rc;
+    if ((rc = ctx->in_a.reserve(c.off))) return rc;
+    char* d = ctx->in_a.as<char>();
+    hipStream_t s = ctx->stream;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oX, X, (size_t)n * lw * 8, hipMemcpyHostToDevice, s));
+    if ((rc = launch_visible(*K, Twf, (double*)(d + oX), n, lines, (uint8_t*)(d + oV), s))) return rc;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(vis, d + oV, (size_t)n, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return PLSLAM_OK;
+}
+
+int plslam_map_point_visible(plslam_ctx* ctx, const plslam_cam* K, const double* Twf,
+                             const double* Xw, int32_t n, uint8_t* vis)
+{
+    return visible_host(ctx, K, Twf, Xw, n, 0, vis);
+}
+
+int plslam_map_line_visible(plslam_ctx* ctx, const plslam_cam* K, const double* Twf,
+                            const double* Lw, int32_t n, uint8_t* vis)
+{
+    return visible_host(ctx, K, Twf, Lw, n, 1, vis);
+}
+
+// ---- RCCL gather -----------------------------------------------------------------------------
+namespace {
+typedef int (*nccl_group_fn)(void);
+typedef int (*nccl_p2p_fn)(void*, size_t, int, int, void*, hipStream_t);  // send/recv share a shape
+struct Rccl {
+    void* h = nullptr;
+    nccl_group_fn group_start = nullptr, group_end = nullptr;
+    nccl_p2p_fn send = nullptr, recv = nullptr;
+    bool tried = false;
+} g_rccl;
+std::mutex g_rccl_mu;
+
+bool rccl_load()
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl.tried) return g_rccl.h != nullptr;
+    g_rccl.tried = true;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+        g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.h) break;
+    }
+    if (!g_rccl.h) return false;
+    g_rccl.group_start = (nccl_group_fn)dlsym(g_rccl.h, "ncclGroupStart");
+    g_rccl.group_end = (nccl_group_fn)dlsym(g_rccl.h, "ncclGroupEnd");
+    g_rccl.send = (nccl_p2p_fn)dlsym(g_rccl.h, "ncclSend");
+    g_rccl.recv = (nccl_p2p_fn)dlsym(g_rccl.h, "ncclRecv");
+    if (!g_rccl.group_start || !g_rccl.group_end || !g_rccl.send || !g_rccl.recv) {
+        dlclose(g_rccl.h);
+        g_rccl.h = nullptr;
+    }
+    return g_rccl.h != nullptr;
+}
+}  // namespace
+
+int plslam_gather_match_tables(plslam_ctx* ctx, void* comm, int nranks, int rank, int root,
+                               const int32_t* local, int64_t n_local, int32_t* gathered,
+                               void* stream)
+{
+    PLSLAM_REQUIRE(ctx && comm && nranks > 0 && rank >= 0 && rank < nranks, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(root >= 0 && root < nranks && n_local >= 0, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(n_local == 0 || local, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(rank != root || n_local == 0 || gathered, PLSLAM_EINVAL);
+    if (!rccl_load()) {
+        set_last_error("librccl.so could not be loaded: %s", dlerror());
+        return PLSLAM_ENOTSUP;
+    }
+    DeviceGuard g(ctx->device);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    const int ncclInt32 = 2;  // ncclDataType_t: ncclInt8=0, ncclUint8=1, ncclInt32=2
+    int rc = g_rccl.group_start();
+    if (rank == root) {
+        for (int p = 0; p < nranks && rc == 0; ++p) {
+            if (p == root) continue;
+            rc = g_rccl.recv(gathered + (size_t)p * n_local, (size_t)n_local, ncclInt32, p, comm, s);
+        }
+    } else if (rc == 0) {
+        rc = g_rccl.send(const_cast<int32_t*>(local), (size_t)n_local, ncclInt32, root, comm, s);
+    }
+    const int rc2 = g_rccl.group_end();
+    if (rc || rc2) {
+        set_last_error("RCCL point-to-point gather failed (ncclResult %d/%d)", rc, rc2);
+        return PLSLAM_EHIP;
+    }
+    if (rank == root && n_local)
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(gathered + (size_t)root * n_local, local, (size_t)n_local * 4,
+                                        hipMemcpyDeviceToDevice, s));
+    return PLSLAM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,130 @@
+// common.hpp -- internal declarations shared by the HIP translation units of libplslam_hip.so.
+// Nothing here is part of the ABI (see include/plslam_hip.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstdio>
+#include <mutex>
+#include <vector>
+
+#include "plslam_hip.h"
+
+namespace plslam {
+
+void set_last_error(const char* fmt, ...);
+
+#define PLSLAM_HIP_CHECK(expr)                                                              \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            ::plslam::set_last_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr,           \
+                                     hipGetErrorString(e_));                                \
+            return e_ == hipErrorOutOfMemory ? PLSLAM_ENOMEM : PLSLAM_EHIP;                 \
+        }                                                                                   \
+    } while (0)
+
+#define PLSLAM_REQUIRE(cond, code)                                                          \
+    do {                                                                                    \
+        if (!(cond)) {                                                                      \
+            ::plslam::set_last_error("%s:%d: requirement failed: %s", __FILE__, __LINE__,    \
+                                     #cond);                                                \
+            return (code);                                                                  \
+        }                                                                                   \
+    } while (0)
+
+// grow-only device scratch buffer owned by a context
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace plslam
+
+struct plslam_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop;
+    int scan_variant = PLSLAM_SCAN_AUTO;
+    int scan_block = 0;  // 0 = variant default
+    std::mutex mu;       // serialises the host-pointer entry points
+    plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
+};
+
+namespace plslam {
+
+// --- Hamming scan (hamming.hip) ------------------------------------------------------------
+// composite key: (distance << 23) | trainIdx; 0xFFFFFFFF = "no neighbour"
+constexpr uint32_t KEY_IDX_BITS = 23;
+constexpr uint32_t KEY_IDX_MASK = (1u << KEY_IDX_BITS) - 1u;
+constexpr uint32_t KEY_NONE = 0xFFFFFFFFu;
+
+struct ScanDesc {       // one directed scan: every query row against every train row
+    const uint8_t* q;   // nq x 32
+    const uint8_t* t;   // nt x 32
+    uint32_t* keys;     // nq x 2 composite keys (best, second best)
+    int32_t nq, nt;
+};
+
+struct ProblemDesc {    // one StVO::match problem = scan12 (+ scan21 when mutual)
+    const uint32_t* keys12;
+    const uint32_t* keys21;  // nullptr when !mutual
+    int32_t* matches_12;
+    int32_t* n_matches;      // may be nullptr
+    int32_t n1, n2;
+    float nnr;
+    int32_t mutual;
+};
+
+struct BlockDesc {      // one workgroup's slice of a scan / problem
+    int32_t item;       // scan or problem index
+    int32_t row0;       // first query row of this workgroup
+};
+
+// launches (all asynchronous on `s`)
+int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const ScanDesc* d_scans,
+                const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero, hipStream_t s);
+int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int nblocks,
+                    hipStream_t s);
+int launch_scatter_counts(const int32_t* d_src, int32_t* const* d_dst, int32_t n, hipStream_t s);
+int launch_unpack_keys(const uint32_t* d_keys, int32_t n, int32_t* d_idx, int32_t* d_dist,
+                       hipStream_t s);
+// symmetric scan: one problem = one (d1 x d2) distance matrix feeding both directions
+struct SymDesc {
+    const uint8_t* a;       // d1 rows (lanes)
+    const uint8_t* b;       // d2 rows (streamed)
+    uint32_t* keys12;       // n1 x 2
+    uint32_t* part21;       // [n_iblk][n2][2] partial column best-2 per 64-row block of d1
+    int32_t n1, n2;
+    int32_t n_iblk;
+    int32_t pad;
+};
+int launch_scan_sym(const plslam_ctx* ctx, const SymDesc* d_sym, const BlockDesc* d_blocks,
+                    int nblocks, int32_t* d_zero, int nzero, hipStream_t s);
+int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks,
+                          uint32_t* const* d_keys21, hipStream_t s);
+
+int scan_rows_per_block(int variant, int block_threads);
+int resolve_scan_variant(const plslam_ctx* ctx, int64_t total_query_rows, bool all_mutual);
+
+// --- LBA rows + gates (lba.hip) --------------------------------------------------------------
+int launch_point_rows(const plslam_cam& K, double th, const double* T, const double* Xw,
+                      const double* uv, const int32_t* lm, const int32_t* kf, int32_t nobs,
+                      double* Jp, double* Jl, double* r, double* w, hipStream_t s);
+int launch_line_rows(const plslam_cam& K, double th, int compat, const double* T, const double* Lw,
+                     const double* lobs, const int32_t* lm, const int32_t* kf, int32_t nobs,
+                     double* Jp, double* Jl, double* r, double* w, hipStream_t s);
+int launch_point_gate(const plslam_cam& K, const double* Twf16, const double* Xw, const int32_t* m12,
+                      int32_t nq, const double* pl, double th, uint8_t* mask, int32_t* count,
+                      hipStream_t s);
+int launch_line_gate(const plslam_cam& K, const double* Twf16, const double* Lw, const int32_t* m12,
+                     int32_t nq, const double* le, double th, uint8_t* mask, int32_t* count,
+                     hipStream_t s);
+int launch_visible(const plslam_cam& K, const double* Twf16, const double* X, int32_t n, int lines,
+                   uint8_t* vis, hipStream_t s);
+
+}  // namespace plslam

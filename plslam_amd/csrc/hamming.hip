@@ -1,0 +1,270 @@
+// hamming.hip -- K1 (256-bit Hamming kNN-2 scans) and K2 (ratio + mutual finalize) for gfx950.
+//
+// Replaces cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) + stvo-pl matchNNR()/match()
+// (reached from src/mapHandler.cpp:277,424,597,712,3223,3249 of the reference).
+//
+// Integer XOR + popcount work: there is no dense contraction here, so no MFMA.  A 256-bit
+// distance costs 8 v_xor_b32 + 8 v_bcnt_u32_b32 (the bcnt accumulates for free); the scan is
+// VALU-issue bound, HBM sees each descriptor once.
+//
+// Result order == OpenCV batchDistance(K=2): lexicographic (distance, trainIdx).  It is encoded
+// as an unsigned min over composite keys  key = (distance << 23) | trainIdx  so that every
+// merge (per lane, across lanes, across workgroups) is associative and tie-exact.
+#include "common.hpp"
+
+namespace plslam {
+
+typedef const __attribute__((address_space(4))) uint32_t* sptr_t;  // scalar (SMEM) loads
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+
+// ---- tiny VALU helpers the compiler would otherwise re-associate / not select -----------------
+__device__ __forceinline__ uint32_t bcnt0(uint32_t x)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, 0" : "=v"(r) : "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc)
+{
+    uint32_t r;  // r = popcount(x) + acc in ONE VALU op
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t med3_u32(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// key = (d << 23) | j with j wave-uniform (SGPR): one v_lshl_or_b32.  Written as asm because the
+// compiler otherwise proves j % 4 == 0 and splits (j + k) into a shift plus a v_or3.
+__device__ __forceinline__ uint32_t make_key_s(uint32_t d, uint32_t j_uniform)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, 23, %2" : "=v"(r) : "v"(d), "s"(j_uniform));
+    return r;
+}
+static_assert(KEY_IDX_BITS == 23, "make_key_s hard-codes the shift");
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+// keep the two smallest keys; invariant b0 <= b1
+__device__ __forceinline__ void best2_push(uint32_t& b0, uint32_t& b1, uint32_t key)
+{
+    const uint32_t nb1 = med3_u32(b0, b1, key);
+    b0 = umin(b0, key);
+    b1 = nb1;
+}
+// merge two sorted pairs
+__device__ __forceinline__ void best2_merge(uint32_t& a0, uint32_t& a1, uint32_t c0, uint32_t c1)
+{
+    const uint32_t lo = umin(a0, c0);
+    const uint32_t hi = umin(umax(a0, c0), umin(a1, c1));
+    a0 = lo;
+    a1 = hi;
+}
+
+// 8 XOR + 8 BCNT: q in VGPRs, train row in SGPRs (wave-uniform)
+#define PLSLAM_DIST8(q, tp)                                                                      \
+    bcnt_acc(q[7] ^ (tp)[7],                                                                     \
+      bcnt_acc(q[6] ^ (tp)[6],                                                                   \
+        bcnt_acc(q[5] ^ (tp)[5],                                                                 \
+          bcnt_acc(q[4] ^ (tp)[4],                                                               \
+            bcnt_acc(q[3] ^ (tp)[3],                                                             \
+              bcnt_acc(q[2] ^ (tp)[2],                                                           \
+                bcnt_acc(q[1] ^ (tp)[1], bcnt0(q[0] ^ (tp)[0]))))))))
+
+// XCD-aware workgroup remap (bijective for any grid size): hardware places block b on XCD b % 8;
+// give each XCD a contiguous range of work items so that the workgroups of one scan -- which
+// stream the same train set -- share one XCD's L2.
+__device__ __forceinline__ int xcd_remap(int orig, int nwg)
+{
+    const int xcd = orig & 7;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + (orig >> 3);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1a  lane-per-query scan.  One lane owns one query row (8 VGPRs) for the whole scan and keeps
+// its private best-2; train rows are wave-uniform and arrive through the scalar data cache as
+// s_load_dwordx8/x16 into SGPRs, so a distance is exactly 16 VALU ops + 3 for the best-2 update,
+// with no LDS traffic and no cross-lane reduction.  All waves of a workgroup stream the same
+// train rows (K$/L2 hits).
+// ---------------------------------------------------------------------------------------------
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+k_scan_lane_per_query(const ScanDesc* __restrict__ scans, const BlockDesc* __restrict__ blocks,
+                      int32_t* __restrict__ zero, int nzero)
+{
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nzero; i += BLOCK) zero[i] = 0;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const BlockDesc bd = blocks[wg];
+    const ScanDesc sc = scans[bd.item];
+    const int nq = sc.nq, nt = sc.nt;
+    const int row = bd.row0 + (int)threadIdx.x;
+    const int rrow = row < nq ? row : nq - 1;
+
+    uint32_t q[8];
+    {
+        const u32x4* qp = reinterpret_cast<const u32x4*>(sc.q + (size_t)rrow * 32);
+        const u32x4 a = qp[0], b = qp[1];
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
+        q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    }
+
+    uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
+    sptr_t tp = (sptr_t)(uintptr_t)sc.t;
+
+    int j = 0;
+    const int nt4 = nt & ~3;
+    for (; j < nt4; j += 4) {
+        sptr_t t = tp + (size_t)j * 8;
+        const uint32_t d0 = PLSLAM_DIST8(q, t);
+        const uint32_t d1 = PLSLAM_DIST8(q, t + 8);
+        const uint32_t d2 = PLSLAM_DIST8(q, t + 16);
+        const uint32_t d3 = PLSLAM_DIST8(q, t + 24);
+        best2_push(b0, b1, make_key_s(d0, (uint32_t)j));
+        best2_push(b0, b1, make_key_s(d1, (uint32_t)(j + 1)));
+        best2_push(b0, b1, make_key_s(d2, (uint32_t)(j + 2)));
+        best2_push(b0, b1, make_key_s(d3, (uint32_t)(j + 3)));
+    }
+    for (; j < nt; ++j) {
+        sptr_t t = tp + (size_t)j * 8;
+        const uint32_t d = PLSLAM_DIST8(q, t);
+        best2_push(b0, b1, make_key_s(d, (uint32_t)j));
+    }
+
+    if (row < nq) reinterpret_cast<uint2*>(sc.keys)[row] = make_uint2(b0, b1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2  finalize: ratio test (fp32, one multiply) + mutual consistency -> matches_12, #matches.
+// stvo-pl matchNNR: accept iff (float)d0 < (float)d1 * nnr; match(): keep i1->i2 iff m21[i2]==i1.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int ratio_pick(uint32_t k0, uint32_t k1, float nnr)
+{
+    if (k1 == KEY_NONE) return -1;  // fewer than two neighbours: defined as "no match"
+    const float d0 = (float)(k0 >> KEY_IDX_BITS);
+    const float d1n = __fmul_rn((float)(k1 >> KEY_IDX_BITS), nnr);
+    return d0 < d1n ? (int)(k0 & KEY_IDX_MASK) : -1;
+}
+
+__global__ void __launch_bounds__(256)
+k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ blocks)
+{
+    const BlockDesc bd = blocks[blockIdx.x];
+    const ProblemDesc p = probs[bd.item];
+    const int i1 = bd.row0 + (int)threadIdx.x;
+    int m = -1;
+    if (i1 < p.n1) {
+        const uint2 k = reinterpret_cast<const uint2*>(p.keys12)[i1];
+        m = ratio_pick(k.x, k.y, p.nnr);
+        if (m >= 0 && p.mutual) {
+            const uint2 kb = reinterpret_cast<const uint2*>(p.keys21)[m];
+            if (ratio_pick(kb.x, kb.y, p.nnr) != i1) m = -1;
+        }
+        p.matches_12[i1] = m;
+    }
+    if (p.n_matches) {
+        const unsigned long long b = __ballot(m >= 0);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(p.n_matches, (int)__popcll(b));
+    }
+}
+
+// copies the per-problem counters to caller pointers that are not one contiguous array
+__global__ void __launch_bounds__(256)
+k_scatter_counts(const int32_t* __restrict__ src, int32_t* const* __restrict__ dst, int32_t n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && dst[i]) *dst[i] = src[i];
+}
+
+// keys -> (idx, dist) pairs of the knnMatch ABI
+__global__ void __launch_bounds__(256)
+k_unpack_keys(const uint32_t* __restrict__ keys, int32_t n, int32_t* __restrict__ idx,
+              int32_t* __restrict__ dist)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t k = keys[i];
+    idx[i] = k == KEY_NONE ? -1 : (int32_t)(k & KEY_IDX_MASK);
+    dist[i] = k == KEY_NONE ? INT32_MAX : (int32_t)(k >> KEY_IDX_BITS);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side launchers
+// ---------------------------------------------------------------------------------------------
+int scan_rows_per_block(int variant, int block_threads)
+{
+    (void)variant;
+    return block_threads;
+}
+
+int resolve_scan_variant(const plslam_ctx* ctx, int64_t total_query_rows, bool all_mutual)
+{
+    (void)total_query_rows;
+    (void)all_mutual;
+    if (ctx->scan_variant != PLSLAM_SCAN_AUTO) return ctx->scan_variant;
+    return PLSLAM_SCAN_LANE_PER_QUERY;
+}
+
+int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const ScanDesc* d_scans,
+                const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero, hipStream_t s)
+{
+    (void)ctx;
+    if (nblocks <= 0) {
+        if (nzero > 0) PLSLAM_HIP_CHECK(hipMemsetAsync(d_zero, 0, sizeof(int32_t) * nzero, s));
+        return PLSLAM_OK;
+    }
+    PLSLAM_REQUIRE(variant == PLSLAM_SCAN_LANE_PER_QUERY, PLSLAM_EINVAL);
+    switch (block_threads) {
+        case 256:
+            hipLaunchKernelGGL(k_scan_lane_per_query<256>, dim3(nblocks), dim3(256), 0, s, d_scans,
+                               d_blocks, d_zero, nzero);
+            break;
+        case 512:
+            hipLaunchKernelGGL(k_scan_lane_per_query<512>, dim3(nblocks), dim3(512), 0, s, d_scans,
+                               d_blocks, d_zero, nzero);
+            break;
+        case 1024:
+            hipLaunchKernelGGL(k_scan_lane_per_query<1024>, dim3(nblocks), dim3(1024), 0, s, d_scans,
+                               d_blocks, d_zero, nzero);
+            break;
+        default:
+            PLSLAM_REQUIRE(!"scan_block must be 256, 512 or 1024", PLSLAM_EINVAL);
+    }
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int nblocks,
+                    hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_finalize, dim3(nblocks), dim3(256), 0, s, d_probs, d_blocks);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int launch_scatter_counts(const int32_t* d_src, int32_t* const* d_dst, int32_t n, hipStream_t s)
+{
+    if (n <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_scatter_counts, dim3((n + 255) / 256), dim3(256), 0, s, d_src, d_dst, n);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int launch_unpack_keys(const uint32_t* d_keys, int32_t n, int32_t* d_idx, int32_t* d_dist,
+                       hipStream_t s)
+{
+    if (n <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_unpack_keys, dim3((n + 255) / 256), dim3(256), 0, s, d_keys, n, d_idx,
+                       d_dist);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+}  // namespace plslam

@@ -1,0 +1,299 @@
+// lba.hip -- K3/K4 (local-BA residual + Jacobian rows) and K5/K6 (map<->keyframe gates), gfx950.
+//
+// fp64 elementwise work, one lane per observation.  HBM-bound: 152 B (point) / 208 B (line) of
+// compulsory traffic per row against ~100 / ~220 flops.  The translation unit is compiled with
+// -ffp-contract=off and every expression keeps the reference's source order
+// (src/mapHandler.cpp:1358-1407, :1436-1516, :605-613, :720-729) so that thresholded results
+// (inlier masks) are reproducible bit for bit against the CPU restatement.
+#include "common.hpp"
+
+namespace plslam {
+
+struct CamD { double fx, fy, cx, cy; double width, height; };
+
+__device__ __forceinline__ double dmax(double a, double b) { return a > b ? a : b; }  // std::max
+
+// stvo-pl PinholeStereoCamera::projection: u = cx + fx*X/Z, v = cy + fy*Y/Z
+__device__ __forceinline__ void project(const CamD& K, const double P[3], double& u, double& v)
+{
+    u = K.cx + K.fx * P[0] / P[2];
+    v = K.cy + K.fy * P[1] / P[2];
+}
+
+// inverse_se3 (stvo-pl): Tiw = [R^T, -R^T t] of the row-major 4x4 at T  (:1372)
+__device__ __forceinline__ void inv_pose(const double* __restrict__ T, double R[9], double t[3])
+{
+    double m[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) m[i] = T[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        R[3 * i] = m[i];
+        R[3 * i + 1] = m[4 + i];
+        R[3 * i + 2] = m[8 + i];
+        t[i] = (-m[i]) * m[3] + (-m[4 + i]) * m[7] + (-m[8 + i]) * m[11];
+    }
+}
+
+__device__ __forceinline__ void xform(const double R[9], const double t[3], const double* X,
+                                      double o[3])
+{
+    const double x = X[0], y = X[1], z = X[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) o[i] = (R[3 * i] * x + R[3 * i + 1] * y + R[3 * i + 2] * z) + t[i];
+}
+
+// the 6-vector of :1392-1397 / :1475-1480
+__device__ __forceinline__ void jac6(double a, double b, double k, const double G[3], double J[6])
+{
+    const double gx = G[0], gy = G[1], gz = G[2];
+    J[0] = +k * a * gz;
+    J[1] = +k * b * gz;
+    J[2] = -k * (a * gx + b * gy);
+    J[3] = -k * (a * gx * gy + b * gy * gy + b * gz * gz);
+    J[4] = +k * (a * gx * gx + a * gz * gz + b * gx * gy);
+    J[5] = +k * (b * gx * gz - a * gy * gz);
+}
+
+__device__ __forceinline__ void store6(double* __restrict__ dst, const double v[6])
+{
+    double2* d = reinterpret_cast<double2*>(dst);  // rows are 48 B: 16-byte aligned
+    d[0] = make_double2(v[0], v[1]);
+    d[1] = make_double2(v[2], v[3]);
+    d[2] = make_double2(v[4], v[5]);
+}
+
+// K3: point rows
+__global__ void __launch_bounds__(256)
+k_point_rows(CamD K, double th, const double* __restrict__ T, const double* __restrict__ Xw,
+             const double* __restrict__ uv, const int32_t* __restrict__ lm,
+             const int32_t* __restrict__ kf, int32_t nobs, double* __restrict__ Jp,
+             double* __restrict__ Jl, double* __restrict__ r, double* __restrict__ w)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= nobs) return;
+    double R[9], t[3], G[3], Jc[6], out6[6];
+    inv_pose(T + 16 * (size_t)kf[o], R, t);
+    xform(R, t, Xw + 3 * (size_t)lm[o], G);
+    double pu, pv;
+    project(K, G, pu, pv);
+    const double2 ob = reinterpret_cast<const double2*>(uv)[o];
+    const double dx = ob.x - pu, dy = ob.y - pv;
+    const double nrm = sqrt(dx * dx + dy * dy);
+    const double k = 1.0 / dmax(th, G[2] * G[2]);
+    const double a = K.fx * dx, b = K.fy * dy;
+    jac6(a, b, k, G, Jc);
+    const double den = dmax(th, nrm);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) out6[c] = Jc[c] / den;
+    store6(Jp + 6 * (size_t)o, out6);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        Jl[3 * (size_t)o + j] = (Jc[0] * R[j] + Jc[1] * R[3 + j] + Jc[2] * R[6 + j]) / den;
+    r[o] = nrm;
+    w[o] = 1.0 / (1.0 + nrm * nrm);
+}
+
+// K4: line rows
+__global__ void __launch_bounds__(256)
+k_line_rows(CamD K, double th, int compat, const double* __restrict__ T,
+            const double* __restrict__ Lw, const double* __restrict__ lobs,
+            const int32_t* __restrict__ lm, const int32_t* __restrict__ kf, int32_t nobs,
+            double* __restrict__ Jp, double* __restrict__ Jl, double* __restrict__ r,
+            double* __restrict__ w)
+{
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    if (o >= nobs) return;
+    double R[9], t[3], P[3], Q[3], JP[6], JQ[6], out6[6];
+    const size_t l0 = (size_t)lm[o];
+    const double* Pw = compat ? Lw + 3 * l0 : Lw + 6 * l0;
+    const double* Qw = compat ? Lw + 3 * l0 : Lw + 6 * l0 + 3;
+    inv_pose(T + 16 * (size_t)kf[o], R, t);
+    xform(R, t, Pw, P);
+    xform(R, t, Qw, Q);
+    double pu, pv, qu, qv;
+    project(K, P, pu, pv);
+    project(K, Q, qu, qv);
+    const double lx = lobs[3 * (size_t)o], ly = lobs[3 * (size_t)o + 1], lz = lobs[3 * (size_t)o + 2];
+    const double e0 = lx * pu + ly * pv + lz;
+    const double e1 = lx * qu + ly * qv + lz;
+    const double nrm = sqrt(e0 * e0 + e1 * e1);
+    const double a = K.fx * e0, b = K.fy * e1;  // sic: the reference multiplies by l_err (:1469-1472)
+    const double kP = 1.0 / dmax(th, P[2] * P[2]);
+    const double kQ = 1.0 / dmax(th, Q[2] * Q[2]);
+    jac6(a, b, kP, P, JP);
+    jac6(a, b, kQ, Q, JQ);
+    const double den = dmax(th, nrm);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double vp = JP[0] * R[j] + JP[1] * R[3 + j] + JP[2] * R[6 + j];
+        const double vq = JQ[0] * R[j] + JQ[1] * R[3 + j] + JQ[2] * R[6 + j];
+        out6[j] = vp * e0 / den;
+        out6[3 + j] = vq * e1 / den;
+    }
+    store6(Jl + 6 * (size_t)o, out6);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) out6[c] = (JP[c] * e0 + JQ[c] * e1) / den;
+    store6(Jp + 6 * (size_t)o, out6);
+    r[o] = nrm;
+    w[o] = 1.0 / (1.0 + nrm * nrm);
+}
+
+struct Pose12 { double m[12]; };  // rows 0..2 of the row-major 4x4
+
+__device__ __forceinline__ void xform44(const Pose12& T, const double* X, double o[3])
+{
+    const double x = X[0], y = X[1], z = X[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        o[i] = (T.m[4 * i] * x + T.m[4 * i + 1] * y + T.m[4 * i + 2] * z) + T.m[4 * i + 3];
+}
+
+// K5: point gate  (:601-613)
+__global__ void __launch_bounds__(256)
+k_point_gate(CamD K, Pose12 Twf, const double* __restrict__ Xw, const int32_t* __restrict__ m12,
+             int32_t nq, const double* __restrict__ pl, double th, uint8_t* __restrict__ mask,
+             int32_t* __restrict__ count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int ok = 0;
+    if (i < nq) {
+        const int i2 = m12[i];
+        if (i2 >= 0) {
+            double Pf[3], u, v;
+            xform44(Twf, Xw + 3 * (size_t)i, Pf);
+            project(K, Pf, u, v);
+            const double ex = u - pl[2 * (size_t)i2], ey = v - pl[2 * (size_t)i2 + 1];
+            ok = sqrt(ex * ex + ey * ey) < th;
+        }
+        mask[i] = (uint8_t)ok;
+    }
+    if (count) {
+        const unsigned long long b = __ballot(ok);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (int)__popcll(b));
+    }
+}
+
+// K6: line gate  (:716-729), signed test on both endpoints
+__global__ void __launch_bounds__(256)
+k_line_gate(CamD K, Pose12 Twf, const double* __restrict__ Lw, const int32_t* __restrict__ m12,
+            int32_t nq, const double* __restrict__ le, double th, uint8_t* __restrict__ mask,
+            int32_t* __restrict__ count)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    int ok = 0;
+    if (i < nq) {
+        const int i2 = m12[i];
+        if (i2 >= 0) {
+            double sP[3], eP[3], su, sv, eu, ev;
+            xform44(Twf, Lw + 6 * (size_t)i, sP);
+            project(K, sP, su, sv);
+            xform44(Twf, Lw + 6 * (size_t)i + 3, eP);
+            project(K, eP, eu, ev);
+            const double lx = le[3 * (size_t)i2], ly = le[3 * (size_t)i2 + 1], lz = le[3 * (size_t)i2 + 2];
+            const double e0 = lx * su + ly * sv + lz;
+            const double e1 = lx * eu + ly * ev + lz;
+            ok = (e0 < th) && (e1 < th);
+        }
+        mask[i] = (uint8_t)ok;
+    }
+    if (count) {
+        const unsigned long long b = __ballot(ok);
+        if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (int)__popcll(b));
+    }
+}
+
+__device__ __forceinline__ int inside(const CamD& K, const double P[3])
+{
+    double u, v;
+    project(K, P, u, v);
+    return u > 0 && u < K.width && v > 0 && v < K.height && P[2] > 0.0;
+}
+
+// candidate pre-filter (:549-551, :650-655)
+__global__ void __launch_bounds__(256)
+k_visible(CamD K, Pose12 Twf, const double* __restrict__ X, int32_t n, int lines,
+          uint8_t* __restrict__ vis)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double P[3];
+    if (!lines) {
+        xform44(Twf, X + 3 * (size_t)i, P);
+        vis[i] = (uint8_t)inside(K, P);
+    } else {
+        double E[3];
+        xform44(Twf, X + 6 * (size_t)i, P);
+        xform44(Twf, X + 6 * (size_t)i + 3, E);
+        vis[i] = (uint8_t)(inside(K, P) && inside(K, E));
+    }
+}
+
+static CamD cam_d(const plslam_cam& K)
+{
+    return CamD{K.fx, K.fy, K.cx, K.cy, (double)K.width, (double)K.height};
+}
+static Pose12 pose12(const double* T16)
+{
+    Pose12 p;
+    for (int i = 0; i < 12; ++i) p.m[i] = T16[i];
+    return p;
+}
+
+int launch_point_rows(const plslam_cam& K, double th, const double* T, const double* Xw,
+                      const double* uv, const int32_t* lm, const int32_t* kf, int32_t nobs,
+                      double* Jp, double* Jl, double* r, double* w, hipStream_t s)
+{
+    if (nobs <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_point_rows, dim3((nobs + 255) / 256), dim3(256), 0, s, cam_d(K), th, T, Xw,
+                       uv, lm, kf, nobs, Jp, Jl, r, w);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int launch_line_rows(const plslam_cam& K, double th, int compat, const double* T, const double* Lw,
+                     const double* lobs, const int32_t* lm, const int32_t* kf, int32_t nobs,
+                     double* Jp, double* Jl, double* r, double* w, hipStream_t s)
+{
+    if (nobs <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_line_rows, dim3((nobs + 255) / 256), dim3(256), 0, s, cam_d(K), th, compat, T,
+                       Lw, lobs, lm, kf, nobs, Jp, Jl, r, w);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int launch_point_gate(const plslam_cam& K, const double* Twf16, const double* Xw, const int32_t* m12,
+                      int32_t nq, const double* pl, double th, uint8_t* mask, int32_t* count,
+                      hipStream_t s)
+{
+    if (count) PLSLAM_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    if (nq <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_point_gate, dim3((nq + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16),
+                       Xw, m12, nq, pl, th, mask, count);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int launch_line_gate(const plslam_cam& K, const double* Twf16, const double* Lw, const int32_t* m12,
+                     int32_t nq, const double* le, double th, uint8_t* mask, int32_t* count,
+                     hipStream_t s)
+{
+    if (count) PLSLAM_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), s));
+    if (nq <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_line_gate, dim3((nq + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16),
+                       Lw, m12, nq, le, th, mask, count);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int launch_visible(const plslam_cam& K, const double* Twf16, const double* X, int32_t n, int lines,
+                   uint8_t* vis, hipStream_t s)
+{
+    if (n <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_visible, dim3((n + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), X, n,
+                       lines, vis);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+}  // namespace plslam

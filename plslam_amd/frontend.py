@@ -1,0 +1,100 @@
+"""Batch stereo front end: the per-frame matching work of StVO::StereoFrame (L<->R association)
+and StVO::StereoFrameHandler::f2fTracking (prev<->curr) [stvo-pl; driven from
+app/plslam_dataset.cpp:127 of the reference] for a batch of independent stereo pairs, kept
+device-resident and executed through one match plan of the C-ABI library.
+
+Per pair four StVO::match() problems are solved:
+    ORB  L   -> R      (nnr_p)      table columns [0, n_orb)
+    ORB  prev-> curr   (nnr_p)                    [n_orb, 2 n_orb)
+    LBD  L   -> R      (nnr_l)                    [2 n_orb, 2 n_orb + n_lbd)
+    LBD  prev-> curr   (nnr_l)                    [2 n_orb + n_lbd, 2 n_orb + 2 n_lbd)
+so a pair's match table is a fixed-stride int32 row (13.6 kB at 1500 ORB + 200 LBD).
+
+This file is plumbing (torch owns the device memory and the process group); the arithmetic is in
+plslam_amd/csrc.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def shard_range(n_pairs: int, world: int, rank: int):
+    """Contiguous blocks of ceil(n/world) pairs per rank."""
+    per = -(-n_pairs // world)
+    lo = min(rank * per, n_pairs)
+    return lo, min(lo + per, n_pairs)
+
+
+def table_stride(n_orb: int, n_lbd: int) -> int:
+    return 2 * n_orb + 2 * n_lbd
+
+
+def table_slices(n_orb: int, n_lbd: int):
+    o = 0
+    out = {}
+    for name, n in (("orb_lr", n_orb), ("orb_pc", n_orb), ("lbd_lr", n_lbd), ("lbd_pc", n_lbd)):
+        out[name] = slice(o, o + n)
+        o += n
+    return out
+
+
+def pair_problems(orb_l, orb_r, lbd_l, lbd_r, i):
+    """The four (d1, d2) descriptor pairs of stereo pair i (arrays carry the halo at index 0)."""
+    return (("orb_lr", orb_l[i + 1], orb_r[i + 1]), ("orb_pc", orb_l[i], orb_l[i + 1]),
+            ("lbd_lr", lbd_l[i + 1], lbd_r[i + 1]), ("lbd_pc", lbd_l[i], lbd_l[i + 1]))
+
+
+class StereoBatchMatcher:
+    """Device-resident batch of `B` stereo pairs -> (B, stride) int32 match table."""
+
+    def __init__(self, ctx, stream_np: dict, nnr_p=0.75, nnr_l=0.75, mutual=True, device=None):
+        import torch
+        self.torch = torch
+        self.ctx = ctx
+        dev = device if device is not None else torch.device("cuda", ctx.device)
+        self.dev = dev
+        self.B = stream_np["orb_l"].shape[0] - 1
+        self.n_orb = stream_np["orb_l"].shape[1]
+        self.n_lbd = stream_np["lbd_l"].shape[1]
+        self.stride = table_stride(self.n_orb, self.n_lbd)
+        self.d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in stream_np.items()}
+        self.table = torch.full((self.B, self.stride), -2, dtype=torch.int32, device=dev)
+        self.counts = torch.zeros((self.B, 4), dtype=torch.int32, device=dev)
+        sl = table_slices(self.n_orb, self.n_lbd)
+        probs = []
+        tb, cb = self.table.data_ptr(), self.counts.data_ptr()
+        row_o, row_l = self.n_orb * 32, self.n_lbd * 32
+        ol, orr = self.d["orb_l"].data_ptr(), self.d["orb_r"].data_ptr()
+        ll, lr = self.d["lbd_l"].data_ptr(), self.d["lbd_r"].data_ptr()
+        for i in range(self.B):
+            t_i = tb + 4 * self.stride * i
+            c_i = cb + 16 * i
+            probs.append((ol + row_o * (i + 1), self.n_orb, orr + row_o * (i + 1), self.n_orb, nnr_p, mutual,
+                          t_i + 4 * sl["orb_lr"].start, c_i))
+            probs.append((ol + row_o * i, self.n_orb, ol + row_o * (i + 1), self.n_orb, nnr_p, mutual,
+                          t_i + 4 * sl["orb_pc"].start, c_i + 4))
+            probs.append((ll + row_l * (i + 1), self.n_lbd, lr + row_l * (i + 1), self.n_lbd, nnr_l, mutual,
+                          t_i + 4 * sl["lbd_lr"].start, c_i + 8))
+            probs.append((ll + row_l * i, self.n_lbd, ll + row_l * (i + 1), self.n_lbd, nnr_l, mutual,
+                          t_i + 4 * sl["lbd_pc"].start, c_i + 12))
+        self.plan = ctx.plan(probs)
+
+    def run(self):
+        """Enqueue one pass over the batch on torch's current stream."""
+        self.plan.run(self.torch.cuda.current_stream(self.dev).cuda_stream)
+        return self.table
+
+    def close(self):
+        self.plan.close()
+
+
+def gather_tables(local, world: int, rank: int, root: int = 0, group=None):
+    """Gather fixed-stride per-pair match tables to `root` (torch.distributed: backend 'nccl' is
+    RCCL over xGMI on MI355X, 'gloo' on CPU).  Returns the (world*B, stride) tensor on root."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == root else None
+    dist.gather(local, gather_list=bufs, dst=root, group=group)
+    return torch.cat(bufs, dim=0) if rank == root else None

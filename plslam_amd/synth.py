@@ -1,0 +1,143 @@
+"""Deterministic synthetic workloads: descriptor-level replays of stereo streams
+and a C3-shaped local map for the LBA rows.  Pure numpy; no algorithm of the hot path lives here.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED0 = 20170530
+EUROC = dict(fx=458.654, fy=457.296, cx=367.215, cy=248.375, b=0.110, width=752, height=480)
+KITTI00 = dict(fx=718.856, fy=718.856, cx=607.1928, cy=185.2157, b=0.537165719, width=1241, height=376)
+
+
+def random_desc(rng, n):
+    return rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+
+
+def noisy_copy(rng, src, keep_frac=0.70, flip_p=0.08):
+    """Rows of `src`: a random `keep_frac` get per-bit flips with prob. `flip_p` (true matches),
+    the rest are replaced by fresh random rows; the result is row-shuffled.  Returns (dst, perm)
+    where dst[k] descends from src[perm[k]] (or is fresh when fresh[k])."""
+    n = src.shape[0]
+    keep = rng.random(n) < keep_frac
+    flips = np.packbits(rng.random((n, 256), dtype=np.float32) < flip_p, axis=1)
+    dst = np.where(keep[:, None], src ^ flips, random_desc(rng, n))
+    perm = rng.permutation(n)
+    return np.ascontiguousarray(dst[perm]), perm, ~keep[perm]
+
+
+def tie_stress_desc(rng, n, entropy_bits=5):
+    """Rows drawn from only 2**entropy_bits distinct patterns => many exact ties/duplicates."""
+    pats = random_desc(rng, 1 << entropy_bits)
+    # make patterns near each other so that distances collide as well
+    base = random_desc(rng, 1)[0]
+    for k in range(pats.shape[0]):
+        p = base.copy()
+        bits = rng.integers(0, 256, size=3)
+        for b in bits:
+            p[b >> 3] ^= np.uint8(1 << (b & 7))
+        pats[k] = p
+    return np.ascontiguousarray(pats[rng.integers(0, pats.shape[0], size=n)])
+
+
+def stereo_stream(n_pairs, n_orb=1500, n_lbd=200, seed=SEED0, first_pair=0, tie_stress=False):
+    """A stream of stereo pairs.  Returns dict of uint8 arrays:
+         orb_l, orb_r : (n_pairs+1, n_orb, 32)   index 0 is the HALO = left image of the pair before
+         lbd_l, lbd_r : (n_pairs+1, n_lbd, 32)   `first_pair` (needed for prev<->curr of pair 0)
+    Frame f = first_pair - 1 + index.  Every frame's rows depend only on (seed, f) and on frame
+    f-1's left rows, and the chain restarts every 64 frames, so any shard can be generated
+    independently of the others (contiguous shards produce bit-identical data)."""
+    out = {k: np.empty((n_pairs + 1, n, 32), np.uint8)
+           for k, n in (("orb_l", n_orb), ("orb_r", n_orb), ("lbd_l", n_lbd), ("lbd_r", n_lbd))}
+    f0 = first_pair - 1
+    start = (f0 // 64) * 64 if f0 >= 0 else f0  # chain restart boundary at or before f0
+    prev = {}
+    for f in range(start, f0 + n_pairs + 1):
+        rng = np.random.Generator(np.random.PCG64(seed + 7919 * (f + 1)))
+        cur = {}
+        for kind, n in (("orb", n_orb), ("lbd", n_lbd)):
+            if tie_stress:
+                left = tie_stress_desc(rng, n)
+                right = tie_stress_desc(rng, n)
+            else:
+                if f == start or (f % 64) == 0 or kind not in prev:
+                    left = random_desc(rng, n)
+                else:
+                    left, _, _ = noisy_copy(rng, prev[kind])
+                right, _, _ = noisy_copy(rng, left)
+            cur[kind] = left
+            i = f - f0
+            if i >= 0:
+                out[kind + "_l"][i] = left
+                out[kind + "_r"][i] = right
+        prev = cur
+    return out
+
+
+def se3_exp(x):
+    t, w = np.asarray(x[:3], float), np.asarray(x[3:], float)
+    th = np.linalg.norm(w)
+    T = np.eye(4)
+    if th < 1e-6:
+        T[:3, 3] = t
+        return T
+    s = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]) / th
+    R = np.eye(3) + s * np.sin(th) + s @ s * (1 - np.cos(th))
+    V = np.eye(3) + s * (1 - np.cos(th)) / th + s @ s * (th - np.sin(th)) / th
+    T[:3, :3] = R
+    T[:3, 3] = V @ t
+    return T
+
+
+def local_map(n_kf=10, n_pt=10000, n_ls=2000, obs_per_lm=5, cam=EUROC, seed=7, noise_px=1.0):
+    """C3-shaped local map: forward-moving KF trajectory, landmarks inside the first KF's frustum at
+    2..30 m, observations = exact projection + N(0, noise_px).  Returns a dict of arrays laid out as
+    the LBA row ABI expects."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    fx, fy, cx, cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    W, H = cam["width"], cam["height"]
+    T_kf_w = np.empty((n_kf, 4, 4))
+    for k in range(n_kf):
+        x = np.concatenate([[0.02 * rng.standard_normal(), 0.02 * rng.standard_normal(), 0.25 * k],
+                            0.01 * rng.standard_normal(3)])
+        T_kf_w[k] = se3_exp(x)
+
+    def frustum(n):
+        z = rng.uniform(4.0, 30.0, n)
+        u = rng.uniform(0.15 * W, 0.85 * W, n)
+        v = rng.uniform(0.15 * H, 0.85 * H, n)
+        return np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], axis=1)
+
+    def project(T, X):
+        Ti = np.linalg.inv(T)
+        Xc = X @ Ti[:3, :3].T + Ti[:3, 3]
+        return np.stack([cx + fx * Xc[:, 0] / Xc[:, 2], cy + fy * Xc[:, 1] / Xc[:, 2]], axis=1)
+
+    Xw = frustum(n_pt)
+    kf_pt = np.stack([rng.permutation(n_kf)[:obs_per_lm] for _ in range(n_pt)]).astype(np.int32) \
+        if n_pt else np.zeros((0, obs_per_lm), np.int32)
+    lm_pt = np.repeat(np.arange(n_pt, dtype=np.int32), obs_per_lm)
+    kf_pt = kf_pt.reshape(-1)
+    uv = np.empty((lm_pt.shape[0], 2))
+    for k in range(n_kf):
+        sel = kf_pt == k
+        uv[sel] = project(T_kf_w[k], Xw[lm_pt[sel]])
+    uv += noise_px * rng.standard_normal(uv.shape)
+
+    P = frustum(n_ls)
+    Q = P + rng.uniform(-1.0, 1.0, (n_ls, 3)) * np.array([1.0, 1.0, 0.3])
+    Lw = np.concatenate([P, Q], axis=1)
+    kf_ls = np.stack([rng.permutation(n_kf)[:obs_per_lm] for _ in range(n_ls)]).astype(np.int32).reshape(-1) \
+        if n_ls else np.zeros(0, np.int32)
+    lm_ls = np.repeat(np.arange(n_ls, dtype=np.int32), obs_per_lm)
+    l_obs = np.empty((lm_ls.shape[0], 3))
+    for k in range(n_kf):
+        sel = kf_ls == k
+        p = project(T_kf_w[k], P[lm_ls[sel]]) + noise_px * rng.standard_normal((sel.sum(), 2))
+        q = project(T_kf_w[k], Q[lm_ls[sel]]) + noise_px * rng.standard_normal((sel.sum(), 2))
+        l = np.cross(np.concatenate([p, np.ones((p.shape[0], 1))], 1),
+                     np.concatenate([q, np.ones((q.shape[0], 1))], 1))
+        l /= np.sqrt(l[:, 0:1] ** 2 + l[:, 1:2] ** 2)  # normalised 2D line eq. (include/mapFeatures.h:93)
+        l_obs[sel] = l
+    return dict(T_kf_w=T_kf_w.reshape(n_kf, 16), Xw=Xw, obs_uv=uv, pt_lm=lm_pt, pt_kf=kf_pt,
+                Lw=Lw, l_obs=l_obs, ls_lm=lm_ls, ls_kf=kf_ls)

@@ -1,0 +1,52 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/plslam_hip.h declares; there is no CPU fallback (ctx creation fails without a device)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import plslam_amd
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "plslam_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(plslam_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported():
+    syms = _header_symbols()
+    assert len(syms) >= 20
+    lib = ctypes.CDLL(plslam_amd.LIB_PATH)
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(plslam_amd.ABI_SYMBOLS) == syms  # the binding declares exactly the header's surface
+
+
+def test_abi_version_and_strerror():
+    L = plslam_amd.load()
+    assert L.plslam_abi_version() == 1
+    assert L.plslam_strerror(0) == b"ok"
+    assert b"device" in L.plslam_strerror(-2)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the ENODEV path is exercised on CPU-only hosts")
+    with pytest.raises(plslam_amd.PlslamError) as e:
+        plslam_amd.Context(0)
+    assert e.value.code == -2
+
+
+def test_product_never_imports_oracle():
+    """The product path must not route through the oracle (or any CPU implementation)."""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "plslam_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in txt.replace("no CPU fallback", ""), os.path.join(dirpath, f)
+    assert "oracle" not in open(os.path.join(ROOT, "include", "plslam_hip.h")).read()

@@ -1,0 +1,183 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C-ABI, against the CPU oracle
+on identical seeded inputs -- bit-exact for indices, distances, match tables and counts -- plus the
+committed golden vectors and size-independent properties at BASELINE.json's full sizes."""
+import os
+
+import numpy as np
+import pytest
+
+from plslam_amd import frontend, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "match_golden.npz")
+
+
+def _rng(seed=0):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def test_library_is_the_hip_one(ctx):
+    info = ctx.device_info()
+    assert "gfx950" in info["name"], info
+    assert info["cu_count"] >= 200
+
+
+def test_golden_vectors(ctx):
+    g = np.load(GOLD)
+    for n in sorted({k.split("/")[0] for k in g.files}):
+        q, t = g[f"{n}/q"], g[f"{n}/t"]
+        idx, dist = ctx.knn2(q, t)
+        assert np.array_equal(idx, g[f"{n}/knn_idx"]), n
+        assert np.array_equal(dist, g[f"{n}/knn_dist"]), n
+        assert np.array_equal(np.take_along_axis(g[f"{n}/dist_ref_bitops"], np.clip(idx, 0, None), 1)[idx >= 0],
+                              dist[idx >= 0]), n   # distances == the reference's own popcount code
+        for nnr in (0.6, 0.75, 0.9):
+            for mut in (0, 1):
+                m, cnt = ctx.match(q, t, nnr, bool(mut))
+                exp = g[f"{n}/m12_nnr{nnr}_mut{mut}"]
+                assert np.array_equal(m, exp), (n, nnr, mut)
+                assert cnt == int((exp >= 0).sum())
+
+
+@pytest.mark.parametrize("nq,nt", [(0, 5), (5, 0), (3, 1), (3, 2), (1, 1), (64, 64), (65, 129), (255, 3),
+                                   (256, 256), (257, 511), (1000, 4), (7, 1025)])
+def test_knn2_and_match_edge_sizes(ctx, oracle, nq, nt):
+    r = _rng(nq * 4099 + nt)
+    q, t = synth.random_desc(r, nq), synth.random_desc(r, nt)
+    idx, dist = ctx.knn2(q, t)
+    eidx, edist = oracle.knn2(q, t)
+    assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+    for mutual in (False, True):
+        m, n = ctx.match(q, t, 0.9, mutual)
+        em, en = oracle.match(q, t, 0.9, mutual)
+        assert np.array_equal(m, em) and n == en
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_tie_stress_bit_exact(ctx, oracle, seed):
+    r = _rng(100 + seed)
+    q, t = synth.tie_stress_desc(r, 300 + 17 * seed), synth.tie_stress_desc(r, 280 + 31 * seed)
+    idx, dist = ctx.knn2(q, t)
+    eidx, edist = oracle.knn2(q, t)
+    assert np.array_equal(dist, edist)
+    assert np.array_equal(idx, eidx)          # lowest trainIdx wins every tie
+    for nnr in (0.6, 0.75, 0.9):
+        m, n = ctx.match(q, t, nnr, True)
+        em, en = oracle.match(q, t, nnr, True)
+        assert np.array_equal(m, em) and n == en
+
+
+def test_all_scan_block_sizes(ctx, oracle):
+    r = _rng(77)
+    q = synth.random_desc(r, 1500)
+    t, _, _ = synth.noisy_copy(r, q)
+    em, en = oracle.match(q, t, 0.75, True)
+    try:
+        for blk in (256, 512, 1024):
+            ctx.set_option("scan_block", blk)
+            m, n = ctx.match(q, t, 0.75, True)
+            assert np.array_equal(m, em) and n == en, blk
+    finally:
+        ctx.set_option("scan_block", 0)
+
+
+def test_c2_full_size_pair_bit_exact(ctx, oracle):
+    """BASELINE config 2: 1500 ORB + 200 LBD, L<->R and prev<->curr, mutual + ratio."""
+    s = synth.stereo_stream(2, 1500, 200, seed=synth.SEED0)
+    for i in range(2):
+        for name, d1, d2 in frontend.pair_problems(s["orb_l"], s["orb_r"], s["lbd_l"], s["lbd_r"], i):
+            nnr = 0.75
+            m, n = ctx.match(d1, d2, nnr, True)
+            em, en = oracle.match(d1, d2, nnr, True)
+            assert np.array_equal(m, em) and n == en, (i, name)
+            assert n > 0.4 * len(m)          # the planted true matches are found
+
+
+def test_c3_map_to_frame_sizes_bit_exact(ctx, oracle):
+    """BASELINE config 3 matching half: 10k map points x 1500 frame rows, 2k lines x 200."""
+    r = _rng(31)
+    frame_p = synth.random_desc(r, 1500)
+    map_p = np.concatenate([synth.noisy_copy(r, frame_p)[0], synth.random_desc(r, 8500)])
+    m, n = ctx.match(map_p, frame_p, 0.75, True)
+    em, en = oracle.match(map_p, frame_p, 0.75, True)
+    assert np.array_equal(m, em) and n == en and n > 500
+    frame_l = synth.random_desc(r, 200)
+    map_l = np.concatenate([synth.noisy_copy(r, frame_l)[0], synth.random_desc(r, 1800)])
+    m, n = ctx.match(map_l, frame_l, 0.9, True)
+    em, en = oracle.match(map_l, frame_l, 0.9, True)
+    assert np.array_equal(m, em) and n == en
+
+
+def test_c5_dense_size_properties(ctx, oracle):
+    """BASELINE config 5 size (4000 ORB): size-independent properties + oracle spot check."""
+    r = _rng(55)
+    a = synth.random_desc(r, 4000)
+    # identity: distinct rows matched against themselves -> every row matches itself (d0=0 < d1*nnr)
+    m, n = ctx.match(a, a, 0.75, True)
+    assert n == 4000 and np.array_equal(m, np.arange(4000))
+    # permutation equivariance + involution of mutual matches
+    b, perm, fresh = synth.noisy_copy(r, a)
+    m12, n12 = ctx.match(a, b, 0.75, True)
+    m21, n21 = ctx.match(b, a, 0.75, True)
+    assert n12 == n21
+    ok = m12 >= 0
+    assert np.array_equal(m21[m12[ok]], np.nonzero(ok)[0])       # mutual => involutive
+    inv = np.empty(4000, np.int64)
+    inv[perm] = np.arange(4000)
+    planted = ok & ~fresh[np.clip(m12, 0, None)]
+    assert (m12[planted] == inv[planted]).mean() > 0.999         # planted matches recovered
+    # checksum of the table equals the oracle's (full bit-exact compare is cheap enough here too)
+    em, en = oracle.match(a, b, 0.75, True)
+    assert np.array_equal(m12, em) and n12 == en
+
+
+def test_batched_ragged_problems(ctx, oracle):
+    r = _rng(9)
+    sizes1 = [30, 0, 17, 64, 300, 1, 2, 513]
+    sizes2 = [25, 10, 0, 70, 299, 5, 1, 255]
+    off1 = np.concatenate([[0], np.cumsum(sizes1)]).astype(np.int32)
+    off2 = np.concatenate([[0], np.cumsum(sizes2)]).astype(np.int32)
+    d1, d2 = synth.random_desc(r, off1[-1]), synth.random_desc(r, off2[-1])
+    for mutual in (False, True):
+        m, nm = ctx.match_batched(d1, off1, d2, off2, 0.9, mutual)
+        em, enm = oracle.match_batched(d1, off1, d2, off2, 0.9, mutual)
+        assert np.array_equal(m, em) and np.array_equal(nm, enm)
+
+
+def test_error_codes(ctx):
+    import plslam_amd
+    with pytest.raises(plslam_amd.PlslamError) as e:
+        ctx.set_option("scan_block", 100)
+    assert e.value.code == plslam_amd.capi.EINVAL
+    with pytest.raises(plslam_amd.PlslamError) as e:
+        ctx.set_option("no_such_option", 1)
+    assert e.value.code == plslam_amd.capi.EINVAL
+    off = np.array([0, 5, 3], np.int32)      # decreasing offsets
+    with pytest.raises(plslam_amd.PlslamError):
+        ctx.match_batched(np.zeros((5, 32), np.uint8), off, np.zeros((5, 32), np.uint8), off, 0.9, True)
+
+
+def test_device_resident_plan_matches_oracle(ctx, oracle):
+    """The throughput path: StereoBatchMatcher (device-resident, one plan, torch's stream)."""
+    import torch
+    s = synth.stereo_stream(3, 320, 70, seed=5)
+    bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.75, nnr_l=0.9, mutual=True)
+    info = bm.plan.info()
+    assert info["n_scans"] == 3 * 8 and info["directed_evals"] == 3 * 4 * (320 * 320 + 70 * 70)
+    for _ in range(2):                        # re-running a plan is idempotent
+        tab = bm.run()
+        torch.cuda.synchronize()
+        tab = tab.cpu().numpy()
+        cnt = bm.counts.cpu().numpy()
+        sl = frontend.table_slices(320, 70)
+        for i in range(3):
+            for k, (name, d1, d2) in enumerate(frontend.pair_problems(s["orb_l"], s["orb_r"], s["lbd_l"],
+                                                                      s["lbd_r"], i)):
+                em, en = oracle.match(d1, d2, 0.75 if name.startswith("orb") else 0.9, True)
+                assert np.array_equal(tab[i, sl[name]], em), (i, name)
+                assert cnt[i, k] == en
+    bm.plan.set_profiling(True)
+    bm.run()
+    scan_ms, fin_ms, runs = bm.plan.elapsed()
+    assert runs == 1 and scan_ms > 0 and fin_ms > 0
+    bm.close()

@@ -1,0 +1,397 @@
+"""CPU tests that PIN THE ORACLE (no GPU): distance against the reference's own in-tree popcount
+code (oracle/_ref), kNN-2 / ratio / mutual against an independent numpy formulation and the
+committed golden vectors, LBA rows against finite differences and a literal numpy restatement.
+
+Parity status: the reference holds no tests for this path and its matcher arithmetic is in
+OpenCV/stvo-pl (absent) -> kNN order / ratio / mutual are "parity unpinned" (SURVEY.md 8c).
+"""
+import os
+
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from oracle import oracle as O
+from plslam_amd import synth
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "match_golden.npz")
+
+
+def _rng(seed=0):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+# ---------------------------------------------------------------- distance ----------------
+def test_distance_known_answers():
+    z = np.zeros(32, np.uint8)
+    o = np.full(32, 0xFF, np.uint8)
+    one = z.copy()
+    one[17] = 0x10
+    for v in ("popcnt32", "swar", "lut"):
+        assert O.hamming256(z, z, v) == 0
+        assert O.hamming256(z, o, v) == 256
+        assert O.hamming256(z, one, v) == 1
+        assert O.hamming256(o, one, v) == 255
+        assert O.hamming256(np.full(32, 0xAA, np.uint8), np.full(32, 0x55, np.uint8), v) == 256
+
+
+def test_distance_three_restatements_agree():
+    r = _rng(1)
+    a, b = synth.random_desc(r, 500), synth.random_desc(r, 500)
+    for i in range(500):
+        d = O.hamming256(a[i], b[i])
+        assert d == O.hamming256(a[i], b[i], "swar") == O.hamming256(a[i], b[i], "lut")
+        assert d == int(np.bitwise_count(a[i] ^ b[i]).sum())
+
+
+def test_distance_pinned_to_reference_code():
+    """oracle/_ref = the reference's bitops_custom.hpp:83-96 and FORB.cpp:78-101 compiled as is."""
+    ref = O.ref_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    r = _rng(2)
+    a, b = synth.random_desc(r, 400), synth.random_desc(r, 400)
+    a[0] = 0
+    b[0] = 0xFF
+    for i in range(400):
+        d = O.hamming256(a[i], b[i])
+        assert d == ref.ref_ld_match(a[i].ctypes.data, b[i].ctypes.data, 32)
+        assert d == ref.ref_forb_distance(a[i].ctypes.data, b[i].ctypes.data)
+
+
+# ---------------------------------------------------------------- golden vectors ----------
+def _gold_cases():
+    g = np.load(GOLD)
+    names = sorted({k.split("/")[0] for k in g.files})
+    return g, names
+
+
+def test_golden_distances_and_knn():
+    g, names = _gold_cases()
+    for n in names:
+        q, t = g[f"{n}/q"], g[f"{n}/t"]
+        assert np.array_equal(O.np_dist_matrix(q, t), g[f"{n}/dist_ref_bitops"]), n
+        idx, dist = O.knn2(q, t)
+        assert np.array_equal(idx, g[f"{n}/knn_idx"]), n
+        assert np.array_equal(dist, g[f"{n}/knn_dist"]), n
+
+
+def test_golden_match_tables():
+    g, names = _gold_cases()
+    for n in names:
+        q, t = g[f"{n}/q"], g[f"{n}/t"]
+        for nnr in (0.6, 0.75, 0.9):
+            for mut in (0, 1):
+                m, cnt = O.match(q, t, nnr, bool(mut))
+                exp = g[f"{n}/m12_nnr{nnr}_mut{mut}"]
+                assert np.array_equal(m, exp), (n, nnr, mut)
+                assert cnt == int((exp >= 0).sum())
+
+
+def test_ratio_boundaries_fp32():
+    """d0 < d1*nnr evaluated in fp32 with ONE multiply: 9 vs 10*0.9f -> 9.0f exactly -> reject."""
+    g, _ = _gold_cases()
+    expect = {("9_10", 0.9): -1, ("3_4", 0.75): -1, ("75_100", 0.75): -1, ("0_0", 0.75): -1,
+              ("5_5", 0.9): -1, ("89_99", 0.9): 1, ("90_100", 0.9): -1, ("6_10", 0.6): -1,
+              ("59_99", 0.6): 1,
+              ("60_100", 0.6): 1}   # 100*0.6f rounds UP to 60.000004f in fp32 (fp64 would reject)
+    for (name, nnr), want in expect.items():
+        q, t = g[f"ratio_{name}/q"], g[f"ratio_{name}/t"]
+        m, _ = O.match(q, t, nnr, False)
+        assert m[0] == want, (name, nnr, m)
+        # same decision straight from IEEE fp32
+        d0, d1 = (int(x) for x in name.split("_"))
+        dec = np.float32(d0) < np.float32(d1) * np.float32(nnr)
+        assert (m[0] >= 0) == bool(dec)
+
+
+def test_fp32_vs_fp64_ratio_disagreements_exist_only_at_0p6():
+    """for the shipped thresholds fp32 and fp64 evaluation agree on every integer pair;
+    at nnr=0.6 they do not -- the implementation must be fp32."""
+    d = np.arange(0, 257)
+    d0, d1 = np.meshgrid(d, d, indexing="ij")
+    keep = d0 <= d1
+    for nnr in (0.7, 0.75, 0.8, 0.85, 0.9, 0.95):
+        f32 = d0.astype(np.float32) < d1.astype(np.float32) * np.float32(nnr)
+        f64 = d0.astype(np.float64) < d1.astype(np.float64) * float(nnr)
+        assert np.array_equal(f32[keep], f64[keep]), nnr
+    f32 = d0.astype(np.float32) < d1.astype(np.float32) * np.float32(0.6)
+    f64 = d0.astype(np.float64) < d1.astype(np.float64) * 0.6
+    assert (f32[keep] != f64[keep]).sum() > 0
+
+
+# ---------------------------------------------------------------- kNN-2 / match -----------
+@pytest.mark.parametrize("nq,nt", [(0, 5), (5, 0), (3, 1), (3, 2), (1, 1), (64, 64), (65, 129), (200, 37)])
+def test_knn2_edge_sizes(nq, nt):
+    r = _rng(nq * 1000 + nt)
+    q, t = synth.random_desc(r, nq), synth.random_desc(r, nt)
+    idx, dist = O.knn2(q, t)
+    eidx, edist = O.np_knn2(q, t)
+    assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+    if nt < 2:
+        m, n = O.match(q, t, 0.9, False)
+        assert n == 0 and (m == -1).all()
+
+
+def test_knn2_ties_lowest_index_first():
+    r = _rng(5)
+    t = np.repeat(synth.random_desc(r, 4), 5, axis=0)      # every row appears 5 times
+    q = t[::5].copy()
+    idx, dist = O.knn2(q, t)
+    assert np.array_equal(idx[:, 0], np.arange(4) * 5)
+    assert np.array_equal(idx[:, 1], np.arange(4) * 5 + 1)  # second best = same distance, next index
+    assert (dist == 0).all()
+    m, n = O.match(q, t, 0.9, False)
+    assert n == 0                                           # d0 == d1 == 0 -> 0 < 0 false
+
+
+def test_mutual_semantics_hand_case():
+    z = np.zeros((1, 32), np.uint8)
+
+    def row(d):
+        b = np.zeros(256, np.uint8)
+        b[:d] = 1
+        return np.packbits(b)
+    # d1 = {A}, d2 = {B(=A+2 bits), C(far)}; plus in d1 a row A' closer to B than A is
+    d1 = np.stack([row(10), row(4)])        # A (10 bits), A' (4 bits)
+    d2 = np.stack([row(6), row(200)])       # B (6 bits), C
+    m_nomut, _ = O.match(d1, d2, 0.75, False)
+    assert list(m_nomut) == [0, 0]          # both prefer B (dist 4 and 2)
+    m_mut, n = O.match(d1, d2, 0.75, True)
+    assert list(m_mut) == [-1, 0] and n == 1  # B's best is A' (dist 2 < 4*0.75) -> A is dropped
+    assert z.sum() == 0
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.integers(0, 40), st.integers(0, 40), st.integers(0, 2 ** 31 - 1), st.booleans(),
+       st.sampled_from([0.6, 0.75, 0.9]), st.booleans())
+def test_match_property_c_vs_numpy(nq, nt, seed, ties, nnr, mutual):
+    r = _rng(seed)
+    gen = synth.tie_stress_desc if ties else synth.random_desc
+    q, t = gen(r, nq), gen(r, nt)
+    if nq and nt and not ties:
+        k = min(nq, nt)
+        t[:k] = q[:k] ^ np.packbits(r.random((k, 256)) < 0.05, axis=1)
+    idx, dist = O.knn2(q, t)
+    eidx, edist = O.np_knn2(q, t)
+    assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+    m, n = O.match(q, t, nnr, mutual)
+    em, en = O.np_match(q, t, nnr, mutual)
+    assert np.array_equal(m, em) and n == en
+
+
+def test_match_batched_and_threads_agree():
+    r = _rng(9)
+    sizes1, sizes2 = [30, 0, 17, 64], [25, 10, 0, 70]
+    off1 = np.concatenate([[0], np.cumsum(sizes1)]).astype(np.int32)
+    off2 = np.concatenate([[0], np.cumsum(sizes2)]).astype(np.int32)
+    d1, d2 = synth.random_desc(r, off1[-1]), synth.random_desc(r, off2[-1])
+    m, nm = O.match_batched(d1, off1, d2, off2, 0.9, True)
+    m2, nm2 = O.match_batched(d1, off1, d2, off2, 0.9, True, nthreads=3)
+    assert np.array_equal(m, m2) and np.array_equal(nm, nm2)
+    for b in range(4):
+        e, n = O.np_match(d1[off1[b]:off1[b + 1]], d2[off2[b]:off2[b + 1]], 0.9, True)
+        assert np.array_equal(m[off1[b]:off1[b + 1]], e) and nm[b] == n
+
+
+def test_median_descriptor_restatement():
+    """src/mapFeatures.cpp:51-93 restated in python: sorted row, element int(1+0.5(n-1)), first min."""
+    r = _rng(3)
+    for n in (2, 3, 4, 5, 8, 11):
+        base = synth.random_desc(r, 1)
+        d = np.repeat(base, n, axis=0) ^ np.packbits(r.random((n, 256)) < 0.1, axis=1)
+        D = O.np_dist_matrix(d, d)
+        med = int(1 + 0.5 * (n - 1))
+        vals = [sorted(D[i])[med] for i in range(n)]
+        assert O.median_desc(d) == int(np.argmin(vals))
+    assert O.median_desc(synth.random_desc(r, 1)) == 0
+
+
+# ---------------------------------------------------------------- SE(3) --------------------
+def test_se3_helpers():
+    r = _rng(4)
+    for _ in range(20):
+        x = np.concatenate([r.standard_normal(3), 0.5 * r.standard_normal(3)])
+        T = O.expmap_se3(x)
+        assert np.allclose(T, synth.se3_exp(x), atol=1e-14)
+        assert np.allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=1e-12)
+        assert np.allclose(O.inverse_se3(T) @ T, np.eye(4), atol=1e-12)
+        assert np.allclose(O.logmap_se3(T), x, atol=1e-9)
+    assert np.allclose(O.expmap_se3(np.array([1, 2, 3, 0, 0, 0.0])), synth.se3_exp([1, 2, 3, 0, 0, 0]))
+
+
+# ---------------------------------------------------------------- LBA rows ------------------
+def _np_point_row(K, th, T, X, uv):
+    """Independent numpy restatement of src/mapHandler.cpp:1368-1407."""
+    Ti = np.linalg.inv(T.reshape(4, 4))
+    R, t = Ti[:3, :3], Ti[:3, 3]
+    g = R @ X + t
+    p = np.array([K["cx"] + K["fx"] * g[0] / g[2], K["cy"] + K["fy"] * g[1] / g[2]])
+    e = uv - p
+    r = np.linalg.norm(e)
+    k = 1.0 / max(th, g[2] ** 2)
+    a, b = K["fx"] * e[0], K["fy"] * e[1]
+    gx, gy, gz = g
+    Jc = k * np.array([a * gz, b * gz, -(a * gx + b * gy), -(a * gx * gy + b * gy * gy + b * gz * gz),
+                       a * gx * gx + a * gz * gz + b * gx * gy, b * gx * gz - a * gy * gz])
+    return Jc / max(th, r), (Jc[:3] @ R) / max(th, r), r, 1.0 / (1.0 + r * r)
+
+
+def test_point_rows_vs_numpy_restatement():
+    lm = synth.local_map(n_kf=5, n_pt=300, n_ls=0, obs_per_lm=3)
+    cam = O.make_cam(**synth.EUROC)
+    Jp, Jl, r, w = O.lba_point_rows(cam, 1e-7, lm["T_kf_w"], lm["Xw"], lm["obs_uv"], lm["pt_lm"], lm["pt_kf"])
+    for o in range(0, 900, 7):
+        eJp, eJl, er, ew = _np_point_row(synth.EUROC, 1e-7, lm["T_kf_w"][lm["pt_kf"][o]],
+                                         lm["Xw"][lm["pt_lm"][o]], lm["obs_uv"][o])
+        assert np.allclose(Jp[o], eJp, rtol=1e-9) and np.allclose(Jl[o], eJl, rtol=1e-9)
+        assert np.isclose(r[o], er, rtol=1e-12) and np.isclose(w[o], ew, rtol=1e-12)
+
+
+def test_point_rows_finite_differences():
+    """Pins the [RECALL] helpers: J_lm == -dr/dXw, J_pose == -dr/d(delta) under the reference's
+    update rule T <- T * inverse(expmap(delta)) (src/mapHandler.cpp:1563), tangent order [t, w]."""
+    lm = synth.local_map(n_kf=3, n_pt=40, n_ls=0, obs_per_lm=2, noise_px=3.0)
+    cam = O.make_cam(**synth.EUROC)
+    args = (lm["T_kf_w"], lm["Xw"], lm["obs_uv"], lm["pt_lm"], lm["pt_kf"])
+    Jp, Jl, r, _ = O.lba_point_rows(cam, 1e-7, *args)
+    h = 1e-6
+    for o in range(0, 80, 5):
+        l, k = lm["pt_lm"][o], lm["pt_kf"][o]
+        for j in range(3):
+            Xp, Xm = lm["Xw"].copy(), lm["Xw"].copy()
+            Xp[l, j] += h
+            Xm[l, j] -= h
+            rp = O.lba_point_rows(cam, 1e-7, lm["T_kf_w"], Xp, *args[2:])[2][o]
+            rm = O.lba_point_rows(cam, 1e-7, lm["T_kf_w"], Xm, *args[2:])[2][o]
+            assert np.isclose(Jl[o, j], -(rp - rm) / (2 * h), rtol=2e-4, atol=1e-6)
+        for j in range(6):
+            d = np.zeros(6)
+            d[j] = h
+            Tp, Tm = lm["T_kf_w"].copy(), lm["T_kf_w"].copy()
+            T0 = lm["T_kf_w"][k].reshape(4, 4)
+            Tp[k] = (T0 @ O.inverse_se3(O.expmap_se3(d))).reshape(16)
+            Tm[k] = (T0 @ O.inverse_se3(O.expmap_se3(-d))).reshape(16)
+            rp = O.lba_point_rows(cam, 1e-7, Tp, *args[1:])[2][o]
+            rm = O.lba_point_rows(cam, 1e-7, Tm, *args[1:])[2][o]
+            assert np.isclose(Jp[o, j], -(rp - rm) / (2 * h), rtol=2e-4, atol=1e-5)
+
+
+def _np_line_row(K, th, T, P, Q, l):
+    Ti = np.linalg.inv(T.reshape(4, 4))
+    R, t = Ti[:3, :3], Ti[:3, 3]
+
+    def proj(g):
+        return np.array([K["cx"] + K["fx"] * g[0] / g[2], K["cy"] + K["fy"] * g[1] / g[2]])
+    Pc, Qc = R @ P + t, R @ Q + t
+    p, q = proj(Pc), proj(Qc)
+    e0, e1 = l[0] * p[0] + l[1] * p[1] + l[2], l[0] * q[0] + l[1] * q[1] + l[2]
+    r = np.hypot(e0, e1)
+    a, b = K["fx"] * e0, K["fy"] * e1          # sic (:1469-1472)
+
+    def j6(g):
+        k = 1.0 / max(th, g[2] ** 2)
+        gx, gy, gz = g
+        return k * np.array([a * gz, b * gz, -(a * gx + b * gy), -(a * gx * gy + b * gy * gy + b * gz * gz),
+                             a * gx * gx + a * gz * gz + b * gx * gy, b * gx * gz - a * gy * gz])
+    JP, JQ = j6(Pc), j6(Qc)
+    den = max(th, r)
+    return (JP * e0 + JQ * e1) / den, np.concatenate([(JP[:3] @ R) * e0 / den, (JQ[:3] @ R) * e1 / den]), \
+        r, 1.0 / (1.0 + r * r)
+
+
+def test_line_rows_vs_numpy_restatement_and_compat():
+    lm = synth.local_map(n_kf=5, n_pt=0, n_ls=120, obs_per_lm=3)
+    cam = O.make_cam(**synth.EUROC)
+    Jp, Jl, r, w = O.lba_line_rows(cam, 1e-7, lm["T_kf_w"], lm["Lw"], lm["l_obs"], lm["ls_lm"], lm["ls_kf"])
+    cJp, cJl, cr, cw = O.lba_line_rows(cam, 1e-3, lm["T_kf_w"], lm["Lw"], lm["l_obs"], lm["ls_lm"],
+                                       lm["ls_kf"], compat_iter_pass=True)
+    flat = lm["Lw"].reshape(-1)
+    for o in range(0, 360, 5):
+        T = lm["T_kf_w"][lm["ls_kf"][o]]
+        L = lm["Lw"][lm["ls_lm"][o]]
+        e = _np_line_row(synth.EUROC, 1e-7, T, L[:3], L[3:], lm["l_obs"][o])
+        for got, exp in zip((Jp[o], Jl[o], r[o], w[o]), e):
+            assert np.allclose(got, exp, rtol=1e-9, atol=1e-300)
+        # iteration-pass quirk (:1678-1679): P = Q = X[3*lm_loc .. +3]; threshold is the literal 1e-7
+        Pq = flat[3 * lm["ls_lm"][o]: 3 * lm["ls_lm"][o] + 3]
+        e = _np_line_row(synth.EUROC, 1e-7, T, Pq, Pq, lm["l_obs"][o])
+        for got, exp in zip((cJp[o], cJl[o], cr[o], cw[o]), e):
+            assert np.allclose(got, exp, rtol=1e-9, atol=1e-300)
+
+
+def test_rows_degenerate_thresholds():
+    """z^2 < homog_th and r < homog_th branches (:1383, :1398)."""
+    cam = O.make_cam(**synth.EUROC)
+    T = np.eye(4).reshape(1, 16)
+    X = np.array([[0.0, 0.0, 1e-5], [0.1, -0.2, 5.0]])
+    uv_exact = np.array([[synth.EUROC["cx"], synth.EUROC["cy"]],
+                         [synth.EUROC["cx"] + synth.EUROC["fx"] * 0.1 / 5.0,
+                          synth.EUROC["cy"] + synth.EUROC["fy"] * -0.2 / 5.0]])
+    Jp, Jl, r, w = O.lba_point_rows(cam, 1e-7, T, X, uv_exact, [0, 1], [0, 0])
+    assert r[0] == 0.0 and w[0] == 1.0 and np.all(np.isfinite(Jp)) and np.all(np.isfinite(Jl))
+    assert abs(r[1]) < 1e-12 and np.all(Jp[1] == Jp[1])
+
+
+def test_accumulate_matches_numpy():
+    lm = synth.local_map(n_kf=4, n_pt=30, n_ls=10, obs_per_lm=3)
+    cam = O.make_cam(**synth.EUROC)
+    nkf, npt, nls = 3, 30, 10                     # KF 0 is not optimised: kf_loc = slot-1 (or -1)
+    kf_loc_p = lm["pt_kf"] - 1
+    kf_loc_l = lm["ls_kf"] - 1
+    rows_p = O.lba_point_rows(cam, 1e-7, lm["T_kf_w"], lm["Xw"], lm["obs_uv"], lm["pt_lm"], lm["pt_kf"])
+    rows_l = O.lba_line_rows(cam, 1e-7, lm["T_kf_w"], lm["Lw"], lm["l_obs"], lm["ls_lm"], lm["ls_kf"])
+    H, g, e1 = O.lba_accumulate("points", nkf, npt, nls, lm["pt_lm"], kf_loc_p, *rows_p)
+    H, g, e2 = O.lba_accumulate("lines", nkf, npt, nls, lm["ls_lm"], kf_loc_l, *rows_l, H=H, g=g)
+    N = 6 * nkf + 3 * npt + 6 * nls
+    He, ge, ee = np.zeros((N, N)), np.zeros(N), 0.0
+    for (Jp, Jl, r, w), lmi, kfl, base, dl in ((rows_p, lm["pt_lm"], kf_loc_p, 6 * nkf, 3),
+                                                (rows_l, lm["ls_lm"], kf_loc_l, 6 * nkf + 3 * npt, 6)):
+        for o in range(len(r)):
+            J = np.zeros(N)
+            J[base + dl * lmi[o]: base + dl * lmi[o] + dl] = Jl[o]
+            if kfl[o] >= 0:
+                J[6 * kfl[o]: 6 * kfl[o] + 6] = Jp[o]
+            He += np.outer(J, J) * w[o]
+            ge += J * r[o] * w[o]
+            ee += r[o] * r[o] * w[o]
+    assert np.allclose(H, He, rtol=1e-10, atol=1e-12) and np.allclose(g, ge, rtol=1e-10, atol=1e-12)
+    assert np.isclose(e1 + e2, ee, rtol=1e-12)
+    assert np.allclose(H, H.T)
+
+
+# ---------------------------------------------------------------- gates ---------------------
+def test_gates_against_numpy():
+    r = _rng(8)
+    K = synth.EUROC
+    cam = O.make_cam(**K)
+    Twf = np.linalg.inv(synth.se3_exp([0.1, -0.05, 0.3, 0.01, 0.02, -0.01]))
+    X = np.stack([r.uniform(-3, 3, 200), r.uniform(-2, 2, 200), r.uniform(-1, 20, 200)], 1)
+    Xc = X @ Twf[:3, :3].T + Twf[:3, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        uv = np.stack([K["cx"] + K["fx"] * Xc[:, 0] / Xc[:, 2], K["cy"] + K["fy"] * Xc[:, 1] / Xc[:, 2]], 1)
+    vis = O.map_point_visible(cam, Twf, X)
+    exp = (uv[:, 0] > 0) & (uv[:, 0] < K["width"]) & (uv[:, 1] > 0) & (uv[:, 1] < K["height"]) & (Xc[:, 2] > 0)
+    assert np.array_equal(vis.astype(bool), exp)
+    pl = uv[::-1].copy() + r.normal(0, 0.7, uv.shape)
+    m12 = np.arange(199, -1, -1, dtype=np.int32)
+    m12[::7] = -1
+    mask, n = O.map2kf_point_gate(cam, Twf, X, m12, pl, 1.0)
+    e = np.zeros(200, bool)
+    ok = m12 >= 0
+    e[ok] = np.linalg.norm(uv[ok] - pl[m12[ok]], axis=1) < 1.0
+    assert np.array_equal(mask.astype(bool), e) and n == e.sum()
+    # lines: signed test (:729) -- a large NEGATIVE error passes
+    Lw = np.concatenate([X, X + 0.5], 1)
+    le = r.normal(0, 1, (200, 3))
+    le /= np.linalg.norm(le[:, :2], axis=1, keepdims=True)
+    mask, n = O.map2kf_line_gate(cam, Twf, Lw, m12, le, 1.0)
+    Ec = Lw[:, 3:] @ Twf[:3, :3].T + Twf[:3, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        euv = np.stack([K["cx"] + K["fx"] * Ec[:, 0] / Ec[:, 2], K["cy"] + K["fy"] * Ec[:, 1] / Ec[:, 2]], 1)
+        l = le[np.clip(m12, 0, None)]
+        e0 = l[:, 0] * uv[:, 0] + l[:, 1] * uv[:, 1] + l[:, 2]
+        e1 = l[:, 0] * euv[:, 0] + l[:, 1] * euv[:, 1] + l[:, 2]
+    e = ok & (e0 < 1.0) & (e1 < 1.0)
+    assert np.array_equal(mask.astype(bool), e) and n == e.sum()
+    assert (e & ((e0 < -5) | (e1 < -5))).any()   # the signed quirk is exercised
