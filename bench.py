@@ -34,37 +34,41 @@ def cpu_baseline(stream, n_orb, n_lbd, nnr_p, nnr_l, budget_s=15.0):
     L = O.native_lib()
     cores = os.cpu_count() or 1
 
-    def problems(pairs):
+    def pack(lst, n):
+        return np.ascontiguousarray(np.concatenate(lst)), np.arange(0, (len(lst) + 1) * n, n, dtype=np.int32)
+
+    def problems(pairs):                                # packing is NOT part of the timed region
         d1o, d2o, d1l, d2l = [], [], [], []
         for i in pairs:
             d1o += [stream["orb_l"][i + 1], stream["orb_l"][i]]
             d2o += [stream["orb_r"][i + 1], stream["orb_l"][i + 1]]
             d1l += [stream["lbd_l"][i + 1], stream["lbd_l"][i]]
             d2l += [stream["lbd_r"][i + 1], stream["lbd_l"][i + 1]]
-        def pack(lst, n):
-            return np.ascontiguousarray(np.concatenate(lst)), np.arange(0, (len(lst) + 1) * n, n, dtype=np.int32)
         return pack(d1o, n_orb), pack(d2o, n_orb), pack(d1l, n_lbd), pack(d2l, n_lbd)
 
-    def run(pairs, threads):
-        (a, oa), (b, ob), (c, oc), (d, od) = problems(pairs)
+    def run(packed, threads):
+        (a, oa), (b, ob), (c, oc), (d, od) = packed
         t0 = time.perf_counter()
         O.match_batched(a, oa, b, ob, nnr_p, True, nthreads=threads, L=L)
         O.match_batched(c, oc, d, od, nnr_l, True, nthreads=threads, L=L)
         return time.perf_counter() - t0
 
     B = stream["orb_l"].shape[0] - 1
-    t1 = run([0], 1)                                   # one pair, one thread: calibrates the sample
-    # all-cores leg: whole passes over the batch until ~75 % of the budget is spent
-    est_pass = t1 * B / cores
-    reps = int(max(1, round(0.75 * budget_s / max(est_pass, 1e-6))))
-    t_mt = sum(run(list(range(B)), cores) for _ in range(reps))
-    n_mt = B * reps
-    n_1 = int(max(1, min(B, round(0.25 * budget_s / max(t1, 1e-6)))))
-    t_1 = run(list(range(n_1)), 1)
-    return {"value": n_mt / t_mt, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
+    n_1 = min(B, 8)
+    one = problems(list(range(n_1)))
+    t_1, reps_1 = 0.0, 0
+    while t_1 < 0.25 * budget_s:                        # single-thread leg, bounded by wall clock
+        t_1 += run(one, 1)
+        reps_1 += 1
+    full = problems(list(range(B)))
+    t_mt, reps = 0.0, 0
+    while t_mt < 0.75 * budget_s:                       # all-cores leg: whole passes over the batch
+        t_mt += run(full, cores)
+        reps += 1
+    return {"value": B * reps / t_mt, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
             "sample": f"{reps} pass(es) over the same {B}-pair batch on {cores} threads ({t_mt:.1f} s); "
-                      f"1 thread: {n_1} pairs in {t_1:.1f} s",
-            "value_1thread": n_1 / t_1}
+                      f"1 thread: {reps_1} pass(es) over {n_1} pairs ({t_1:.1f} s)",
+            "value_1thread": n_1 * reps_1 / t_1}
 
 
 def main():
@@ -83,10 +87,16 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()
 
+    T0 = time.perf_counter()
+
+    def note(msg):                                      # progress on stderr (stdout carries the JSON)
+        print(f"[bench +{time.perf_counter() - T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
     import torch
     import torch.distributed as dist
     import plslam_amd
     from plslam_amd import frontend, synth
+    note("imports done")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -107,6 +117,7 @@ def main():
     # weak scaling: rank r owns pairs [r*B, (r+1)*B) of one global stream (with a one-pair halo)
     stream = synth.stereo_stream(B, args.n_orb, args.n_lbd, seed=synth.SEED0, first_pair=rank * B)
 
+    note(f"synthetic stream of {B} pairs generated")
     ctx = plslam_amd.Context(local_rank)     # raises if libplslam_hip.so / a gfx950 device is missing
     if args.scan_variant:
         ctx.set_option("scan_variant", args.scan_variant)
@@ -128,9 +139,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    note(f"plan built: {info}")
     for _ in range(args.warmup):
         step()
     sync()
+    note("warmup done")
     bm.plan.set_profiling(True)
     bm.plan.elapsed()                         # reset the accumulators
     t0 = time.perf_counter()
@@ -140,6 +153,7 @@ def main():
     elapsed = time.perf_counter() - t0
     scan_ms, fin_ms, runs = bm.plan.elapsed()
     bm.plan.set_profiling(False)
+    note(f"timed {args.steps} steps in {elapsed:.4f}s; scan {scan_ms / max(runs, 1):.3f} ms/launch")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -203,6 +217,7 @@ def main():
             "device": devinfo["name"],
         }
         if world == 1 and not args.no_cpu_baseline:
+            note("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(stream, args.n_orb, args.n_lbd, args.nnr_p, args.nnr_l,
                                                args.cpu_budget_s)
         print(json.dumps(out), flush=True)

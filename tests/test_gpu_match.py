@@ -90,7 +90,8 @@ def test_c2_full_size_pair_bit_exact(ctx, oracle):
             m, n = ctx.match(d1, d2, nnr, True)
             em, en = oracle.match(d1, d2, nnr, True)
             assert np.array_equal(m, em) and n == en, (i, name)
-            assert n > 0.4 * len(m)          # the planted true matches are found
+            if name.endswith("_lr") or i > 0:   # (pair 0's prev frame is the unrelated halo)
+                assert n > 0.4 * len(m)         # the planted true matches are found
 
 
 def test_c3_map_to_frame_sizes_bit_exact(ctx, oracle):
