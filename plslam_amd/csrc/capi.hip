@@ -67,8 +67,10 @@ struct plslam_match_plan {
     plslam_ctx* ctx = nullptr;
     int variant = 0, block_threads = 0;
     int32_t nprob = 0, nscan = 0, nscan_blocks = 0, nfin_blocks = 0, ncounts = 0;
+    int32_t nsym = 0, nsym_blocks = 0, nmerge_blocks = 0;
     DevBuf keys, scans, probs, scan_blocks, fin_blocks, counts, count_dst;
-    int32_t* d_counts_zero = nullptr;  // contiguous int32 counters zeroed by the scan kernel
+    DevBuf syms, sym_blocks, merge_blocks, partials;
+    int32_t* d_counts_zero = nullptr;  // contiguous int32 counters zeroed by the first scan kernel
     bool scatter_counts = false;       // user n_matches pointers are not one contiguous array
     plslam_plan_info info{};
     bool profiling = false;
@@ -81,6 +83,7 @@ struct plslam_match_plan {
     {
         keys.release(); scans.release(); probs.release();
         scan_blocks.release(); fin_blocks.release(); counts.release(); count_dst.release();
+        syms.release(); sym_blocks.release(); merge_blocks.release(); partials.release();
         for (auto& e : evs) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2); }
         evs.clear();
     }
@@ -94,8 +97,13 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->ctx = ctx;
     P->nprob = nprob;
 
-    int64_t rows = 0;
-    bool all_mutual = nprob > 0;
+    // AUTO: mutual problems take the symmetric scan (one distance feeds both directions), the
+    // others the directed lane-per-query scan.  A forced variant applies to every problem.
+    const bool allow_sym = ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_SYMMETRIC;
+    PLSLAM_REQUIRE(ctx->scan_variant != PLSLAM_SCAN_WAVE_PER_QUERY, PLSLAM_ENOTSUP);
+    auto is_sym = [&](const plslam_match_problem& p) { return allow_sym && p.mutual && p.n1 > 0 && p.n2 > 0; };
+
+    int64_t rows = 0, part_rows = 0;
     for (int32_t i = 0; i < nprob; ++i) {
         const plslam_match_problem& p = probs[i];
         PLSLAM_REQUIRE(p.n1 >= 0 && p.n2 >= 0, PLSLAM_EINVAL);
@@ -107,17 +115,20 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         PLSLAM_REQUIRE(p.n2 <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
         PLSLAM_REQUIRE(!p.mutual || p.n1 <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
         rows += p.n1 + (p.mutual ? p.n2 : 0);
-        all_mutual = all_mutual && p.mutual;
+        if (is_sym(p)) part_rows += (int64_t)((p.n1 + 63) / 64) * p.n2;
     }
     PLSLAM_REQUIRE(rows < (int64_t(1) << 31), PLSLAM_ERANGE);
 
-    P->variant = resolve_scan_variant(ctx, rows, all_mutual);
+    P->variant = allow_sym ? PLSLAM_SCAN_SYMMETRIC : PLSLAM_SCAN_LANE_PER_QUERY;
     P->block_threads = ctx->scan_block ? ctx->scan_block : 256;
-    const int rpb = scan_rows_per_block(P->variant, P->block_threads);
+    const int rpb = scan_rows_per_block(PLSLAM_SCAN_LANE_PER_QUERY, P->block_threads);
 
     int r = P->keys.reserve(sizeof(uint32_t) * 2 * (size_t)(rows > 0 ? rows : 1));
     if (r) return r;
+    r = P->partials.reserve(sizeof(uint32_t) * 2 * (size_t)(part_rows > 0 ? part_rows : 1));
+    if (r) return r;
     uint32_t* d_keys = P->keys.as<uint32_t>();
+    uint32_t* d_part = P->partials.as<uint32_t>();
     // #matches counters: accumulated with atomics by the finalize kernel, zeroed by the scan
     // kernel.  If the caller's n_matches pointers form one contiguous array, count in place.
     bool contiguous = nprob > 0, any_user = false;
@@ -139,9 +150,10 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->ncounts = nprob;
 
     std::vector<ScanDesc> scans;
+    std::vector<SymDesc> syms;
     std::vector<ProblemDesc> pds;
-    std::vector<BlockDesc> sblocks, fblocks;
-    int64_t key_row = 0, evals = 0, abytes = 0;
+    std::vector<BlockDesc> sblocks, fblocks, yblocks, mblocks;
+    int64_t key_row = 0, part_row = 0, evals = 0, devals = 0, abytes = 0;
     std::vector<int32_t*> user_counts((size_t)nprob, nullptr);
     for (int32_t i = 0; i < nprob; ++i) {
         const plslam_match_problem& p = probs[i];
@@ -150,40 +162,58 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         pd.matches_12 = p.matches_12;
         pd.n_matches = d_counts + i;
         user_counts[i] = p.n_matches;
-        pd.keys12 = d_keys + 2 * key_row;
-        if (p.n1 > 0) {
-            ScanDesc s{p.d1, p.d2, d_keys + 2 * key_row, p.n1, p.n2};
-            for (int32_t r0 = 0; r0 < p.n1; r0 += rpb) sblocks.push_back({(int32_t)scans.size(), r0});
-            scans.push_back(s);
-            for (int32_t r0 = 0; r0 < p.n1; r0 += 256) fblocks.push_back({i, r0});
-            evals += (int64_t)p.n1 * p.n2;
-            abytes += 32LL * (p.n1 + p.n2) + 16LL * p.n1;
-        }
+        uint32_t* k12 = d_keys + 2 * key_row;
         key_row += p.n1;
-        pd.keys21 = nullptr;
-        if (p.mutual) {
-            pd.keys21 = d_keys + 2 * key_row;
-            if (p.n2 > 0 && p.n1 > 0) {
-                ScanDesc s{p.d2, p.d1, d_keys + 2 * key_row, p.n2, p.n1};
-                for (int32_t r0 = 0; r0 < p.n2; r0 += rpb) sblocks.push_back({(int32_t)scans.size(), r0});
-                scans.push_back(s);
+        uint32_t* k21 = p.mutual ? d_keys + 2 * key_row : nullptr;
+        if (p.mutual) key_row += p.n2;
+        pd.keys12 = k12;
+        pd.keys21 = k21;
+        for (int32_t r0 = 0; r0 < p.n1; r0 += 256) fblocks.push_back({i, r0});
+        if (is_sym(p)) {
+            SymDesc y{};
+            y.a = p.d1; y.b = p.d2; y.keys12 = k12; y.keys21 = k21;
+            y.part21 = d_part + 2 * part_row;
+            y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = (p.n1 + 63) / 64;
+            part_row += (int64_t)y.n_iblk * p.n2;
+            for (int32_t r0 = 0; r0 < p.n1; r0 += 256) yblocks.push_back({(int32_t)syms.size(), r0});
+            for (int32_t c0 = 0; c0 < p.n2; c0 += 256) mblocks.push_back({(int32_t)syms.size(), c0});
+            syms.push_back(y);
+            evals += (int64_t)p.n1 * p.n2;
+            devals += 2LL * p.n1 * p.n2;
+            abytes += 2 * 32LL * (p.n1 + p.n2) + 16LL * (p.n1 + p.n2);
+        } else {
+            if (p.n1 > 0) {
+                ScanDesc sc{p.d1, p.d2, k12, p.n1, p.n2};
+                for (int32_t r0 = 0; r0 < p.n1; r0 += rpb) sblocks.push_back({(int32_t)scans.size(), r0});
+                scans.push_back(sc);
                 evals += (int64_t)p.n1 * p.n2;
+                devals += (int64_t)p.n1 * p.n2;
+                abytes += 32LL * (p.n1 + p.n2) + 16LL * p.n1;
+            }
+            if (p.mutual && p.n2 > 0 && p.n1 > 0) {
+                ScanDesc sc{p.d2, p.d1, k21, p.n2, p.n1};
+                for (int32_t r0 = 0; r0 < p.n2; r0 += rpb) sblocks.push_back({(int32_t)scans.size(), r0});
+                scans.push_back(sc);
+                evals += (int64_t)p.n1 * p.n2;
+                devals += (int64_t)p.n1 * p.n2;
                 abytes += 32LL * (p.n1 + p.n2) + 16LL * p.n2;
             }
-            key_row += p.n2;
         }
         pds.push_back(pd);
     }
     P->nscan = (int32_t)scans.size();
     P->nscan_blocks = (int32_t)sblocks.size();
     P->nfin_blocks = (int32_t)fblocks.size();
-    P->info.distance_evals = evals;
-    P->info.directed_evals = evals;
-    P->info.algorithmic_bytes = abytes;
-    P->info.n_scans = P->nscan;
-    P->info.scan_blocks = P->nscan_blocks;
-    P->info.scan_variant = P->variant;
-    P->info.scan_block_threads = P->block_threads;
+    P->nsym = (int32_t)syms.size();
+    P->nsym_blocks = (int32_t)yblocks.size();
+    P->nmerge_blocks = (int32_t)mblocks.size();
+    P->info.distance_evals = evals;      // executed
+    P->info.directed_evals = devals;     // what two directed knnMatch calls per mutual problem evaluate
+    P->info.algorithmic_bytes = abytes;  // 32(Q+T)+16Q per DIRECTED scan, however executed
+    P->info.n_scans = P->nscan + 2 * P->nsym;
+    P->info.scan_blocks = P->nscan_blocks + P->nsym_blocks;
+    P->info.scan_variant = P->nsym ? PLSLAM_SCAN_SYMMETRIC : PLSLAM_SCAN_LANE_PER_QUERY;
+    P->info.scan_block_threads = P->nsym ? 256 : P->block_threads;
 
     auto upload = [&](DevBuf& b, const void* src, size_t bytes) -> int {
         int rr = b.reserve(bytes ? bytes : 16);
@@ -192,8 +222,11 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         return PLSLAM_OK;
     };
     if ((r = upload(P->scans, scans.data(), scans.size() * sizeof(ScanDesc)))) return r;
+    if ((r = upload(P->syms, syms.data(), syms.size() * sizeof(SymDesc)))) return r;
     if ((r = upload(P->probs, pds.data(), pds.size() * sizeof(ProblemDesc)))) return r;
     if ((r = upload(P->scan_blocks, sblocks.data(), sblocks.size() * sizeof(BlockDesc)))) return r;
+    if ((r = upload(P->sym_blocks, yblocks.data(), yblocks.size() * sizeof(BlockDesc)))) return r;
+    if ((r = upload(P->merge_blocks, mblocks.data(), mblocks.size() * sizeof(BlockDesc)))) return r;
     if ((r = upload(P->fin_blocks, fblocks.data(), fblocks.size() * sizeof(BlockDesc)))) return r;
     if (P->scatter_counts)
         if ((r = upload(P->count_dst, user_counts.data(), user_counts.size() * sizeof(int32_t*)))) return r;
@@ -216,9 +249,21 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
         ev = &P->evs[P->ev_used++];
         PLSLAM_HIP_CHECK(hipEventRecord(ev->e0, s));
     }
-    int r = launch_scan(P->ctx, P->variant, P->block_threads, P->scans.as<ScanDesc>(),
+    // the first scan kernel that runs zeroes the #matches counters
+    int r;
+    const bool sym_first = P->nsym_blocks > 0;
+    if (sym_first) {
+        r = launch_scan_sym(P->syms.as<SymDesc>(), P->sym_blocks.as<BlockDesc>(), P->nsym_blocks,
+                            P->d_counts_zero, P->ncounts, s);
+        if (r) return r;
+    }
+    if (P->nscan_blocks > 0 || !sym_first) {
+        r = launch_scan(P->ctx, PLSLAM_SCAN_LANE_PER_QUERY, P->block_threads, P->scans.as<ScanDesc>(),
                         P->scan_blocks.as<BlockDesc>(), P->nscan_blocks, P->d_counts_zero,
-                        P->ncounts, s);
+                        sym_first ? 0 : P->ncounts, s);
+        if (r) return r;
+    }
+    r = launch_merge_partials(P->syms.as<SymDesc>(), P->merge_blocks.as<BlockDesc>(), P->nmerge_blocks, s);
     if (r) return r;
     if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e1, s));
     r = launch_finalize(P->probs.as<ProblemDesc>(), P->fin_blocks.as<BlockDesc>(), P->nfin_blocks, s);

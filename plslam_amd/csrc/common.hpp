@@ -93,23 +93,22 @@ int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int n
 int launch_scatter_counts(const int32_t* d_src, int32_t* const* d_dst, int32_t n, hipStream_t s);
 int launch_unpack_keys(const uint32_t* d_keys, int32_t n, int32_t* d_idx, int32_t* d_dist,
                        hipStream_t s);
-// symmetric scan: one problem = one (d1 x d2) distance matrix feeding both directions
+// symmetric scan: one mutual problem = one (a x b) distance matrix feeding both directions
 struct SymDesc {
-    const uint8_t* a;       // d1 rows (lanes)
-    const uint8_t* b;       // d2 rows (streamed)
-    uint32_t* keys12;       // n1 x 2
-    uint32_t* part21;       // [n_iblk][n2][2] partial column best-2 per 64-row block of d1
+    const uint8_t* a;       // n1 rows: one per lane
+    const uint8_t* b;       // n2 rows: streamed
+    uint32_t* keys12;       // n1 x 2   row results (complete)
+    uint32_t* keys21;       // n2 x 2   column results (written by the merge kernel)
+    uint32_t* part21;       // [n_iblk][n2][2] column partials per 64-row block of a
     int32_t n1, n2;
     int32_t n_iblk;
     int32_t pad;
 };
-int launch_scan_sym(const plslam_ctx* ctx, const SymDesc* d_sym, const BlockDesc* d_blocks,
-                    int nblocks, int32_t* d_zero, int nzero, hipStream_t s);
-int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks,
-                          uint32_t* const* d_keys21, hipStream_t s);
+int launch_scan_sym(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
+                    int nzero, hipStream_t s);
+int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s);
 
 int scan_rows_per_block(int variant, int block_threads);
-int resolve_scan_variant(const plslam_ctx* ctx, int64_t total_query_rows, bool all_mutual);
 
 // --- LBA rows + gates (lba.hip) --------------------------------------------------------------
 int launch_point_rows(const plslam_cam& K, double th, const double* T, const double* Xw,

@@ -74,6 +74,16 @@ __device__ __forceinline__ void best2_merge(uint32_t& a0, uint32_t& a1, uint32_t
               bcnt_acc(q[2] ^ (tp)[2],                                                           \
                 bcnt_acc(q[1] ^ (tp)[1], bcnt0(q[0] ^ (tp)[0]))))))))
 
+// same with the popcount chain started from `bias` (a VGPR) instead of 0: d + bias at no extra cost
+#define PLSLAM_DIST8B(q, tp, bias)                                                               \
+    bcnt_acc(q[7] ^ (tp)[7],                                                                     \
+      bcnt_acc(q[6] ^ (tp)[6],                                                                   \
+        bcnt_acc(q[5] ^ (tp)[5],                                                                 \
+          bcnt_acc(q[4] ^ (tp)[4],                                                               \
+            bcnt_acc(q[3] ^ (tp)[3],                                                             \
+              bcnt_acc(q[2] ^ (tp)[2],                                                           \
+                bcnt_acc(q[1] ^ (tp)[1], bcnt_acc(q[0] ^ (tp)[0], bias))))))))
+
 // XCD-aware workgroup remap (bijective for any grid size): hardware places block b on XCD b % 8;
 // give each XCD a contiguous range of work items so that the workgroups of one scan -- which
 // stream the same train set -- share one XCD's L2.
@@ -141,6 +151,175 @@ k_scan_lane_per_query(const ScanDesc* __restrict__ scans, const BlockDesc* __res
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1b  symmetric scan for mutual problems: ONE distance d(i,j) serves both directions.
+//
+// A wave owns 64 rows of `a` (one per lane, 8 VGPRs) and streams every row of `b` (SGPRs).
+//   row side  (a -> b): lane-private best-2 on 32-bit keys (d<<23 | j), as in K1a.
+//   column side (b -> a): the wave also drops d as u16 into a wave-private, transposed LDS tile
+//     tile[jj][lane]; after 64 rows of b it re-reads the tile column-wise (lane = column jj, 128
+//     contiguous bytes = the 64 distances of that column) and reduces them with PACKED 16-bit keys
+//     (d << 6) | i_local  -- 10 distance bits + 6 index bits order exactly like (d, i) -- so one
+//     v_pk_min/v_pk_max handles two candidates.  The result is the column's best-2 over this
+//     wave's 64 rows: a partial, written to part21[iblk][j] and merged over iblk by K1c.
+// Cost per (i,j): 8 xor + 8 bcnt + 3 (row update) + 2 (column update) VALU ops for TWO directed
+// distances, against 2 x 19 for two directed scans.  LDS rows are 144 B (128 + 16 pad) so that
+// the column-mode ds_read_b128 of 16 consecutive lanes hit 16 distinct 16-byte slots.
+// No inter-wave communication: the four waves of a workgroup are independent (no barriers).
+// ---------------------------------------------------------------------------------------------
+constexpr int SYM_TILE_ROW_U16 = 72;                          // 144 bytes
+constexpr int SYM_TILE_U16 = 64 * SYM_TILE_ROW_U16;           // 9216 bytes per wave
+
+typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// packed keys of two candidates: ((d_hi << 6) | i_hi) << 16 | ((d_lo << 6) | i_lo);  w = d_hi<<16|d_lo.
+// Rows past the end of `a` (ragged last block) carry d + 512 (see SYM_INVALID_BIAS), i.e. key16 >=
+// 0x8000: they sort after every real candidate (real keys are <= (256 << 6) | 63 = 0x403F).
+constexpr uint32_t SYM_INVALID_BIAS = 512;
+__device__ __forceinline__ uint32_t pk_keys(uint32_t w, uint32_t ipair_uniform)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, 6, %2" : "=v"(r) : "v"(w), "s"(ipair_uniform));
+    return r;
+}
+__device__ __forceinline__ uint32_t key16_to_32(uint32_t c, uint32_t i_base)
+{
+    return c >= 0x8000u ? KEY_NONE : (((c >> 6) << KEY_IDX_BITS) | (i_base + (c & 63u)));
+}
+
+__device__ __forceinline__ void sym_column_reduce(const uint16_t* __restrict__ col, uint32_t& b0,
+                                                  uint32_t& b1)
+{
+    // col: this lane's 64 u16 distances d(i, j), i = 0..63 (16-byte aligned)
+    const uint4* cp = reinterpret_cast<const uint4*>(col);
+    b0 = 0xFFFFFFFFu;
+    b1 = 0xFFFFFFFFu;
+#pragma unroll
+    for (int v = 0; v < 8; ++v) {
+        const uint4 w4 = cp[v];
+        const uint32_t w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i_lo = 8 * v + 2 * u;
+            const uint32_t key = pk_keys(w[u], (uint32_t)(((i_lo + 1) << 16) | i_lo));
+            b1 = pk_min_u16(b1, pk_max_u16(b0, key));
+            b0 = pk_min_u16(b0, key);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_symmetric(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
+                 int32_t* __restrict__ zero, int nzero)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t lds[4 * SYM_TILE_U16];
+
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const BlockDesc bd = blocks[wg];
+    const SymDesc sd = syms[bd.item];
+    const int n1 = sd.n1, n2 = sd.n2;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int i0 = bd.row0 + 64 * wave;           // first a-row of this wave
+    if (i0 >= n1) return;                          // (no barriers in this kernel)
+    const int iblk = i0 >> 6;
+    const int row = i0 + lane;
+    const uint32_t bias = row < n1 ? 0u : SYM_INVALID_BIAS;   // start of the popcount chain
+    const int rrow = row < n1 ? row : n1 - 1;
+
+    uint32_t q[8];
+    {
+        const u32x4* qp = reinterpret_cast<const u32x4*>(sd.a + (size_t)rrow * 32);
+        const u32x4 a = qp[0], b = qp[1];
+        q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
+        q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
+    }
+    uint16_t* tile = lds + wave * SYM_TILE_U16;
+    uint16_t* wr = tile + lane;                                  // tile[jj][lane]
+    const uint16_t* col = tile + lane * SYM_TILE_ROW_U16;        // tile[lane][0..63]
+    uint2* part = reinterpret_cast<uint2*>(sd.part21) + (size_t)iblk * n2;
+    sptr_t tp = (sptr_t)(uintptr_t)sd.b;
+
+    uint32_t rb0 = KEY_NONE, rb1 = KEY_NONE;
+    for (int j0 = 0; j0 < n2; j0 += 64) {
+        const int jc = n2 - j0 < 64 ? n2 - j0 : 64;
+        // ---- row mode: stream jc rows of b ------------------------------------------------
+        int jj = 0;
+        for (; jj + 4 <= jc; jj += 4) {
+            sptr_t t = tp + (size_t)(j0 + jj) * 8;
+            const uint32_t d0 = PLSLAM_DIST8B(q, t, bias);
+            const uint32_t d1 = PLSLAM_DIST8B(q, t + 8, bias);
+            const uint32_t d2 = PLSLAM_DIST8B(q, t + 16, bias);
+            const uint32_t d3 = PLSLAM_DIST8B(q, t + 24, bias);
+            wr[(jj + 0) * SYM_TILE_ROW_U16] = (uint16_t)d0;
+            wr[(jj + 1) * SYM_TILE_ROW_U16] = (uint16_t)d1;
+            wr[(jj + 2) * SYM_TILE_ROW_U16] = (uint16_t)d2;
+            wr[(jj + 3) * SYM_TILE_ROW_U16] = (uint16_t)d3;
+            best2_push(rb0, rb1, make_key_s(d0, (uint32_t)(j0 + jj)));
+            best2_push(rb0, rb1, make_key_s(d1, (uint32_t)(j0 + jj + 1)));
+            best2_push(rb0, rb1, make_key_s(d2, (uint32_t)(j0 + jj + 2)));
+            best2_push(rb0, rb1, make_key_s(d3, (uint32_t)(j0 + jj + 3)));
+        }
+        for (; jj < jc; ++jj) {
+            sptr_t t = tp + (size_t)(j0 + jj) * 8;
+            const uint32_t d = PLSLAM_DIST8B(q, t, bias);
+            wr[jj * SYM_TILE_ROW_U16] = (uint16_t)d;
+            best2_push(rb0, rb1, make_key_s(d, (uint32_t)(j0 + jj)));
+        }
+        // LDS operations of one wave execute in order; only the compiler must not reorder them
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- column mode: lane = column j0 + lane -----------------------------------------
+        uint32_t c0p, c1p;
+        sym_column_reduce(col, c0p, c1p);
+        {
+            // two sorted streams (even i in the low halves, odd i in the high halves) -> best 2
+            const uint32_t e0 = c0p & 0xFFFFu, o0 = c0p >> 16, e1 = c1p & 0xFFFFu, o1 = c1p >> 16;
+            const uint32_t m0 = umin(e0, o0);
+            const uint32_t m1 = umin(umax(e0, o0), umin(e1, o1));
+            if (lane < jc)
+                part[j0 + lane] = make_uint2(key16_to_32(m0, (uint32_t)i0), key16_to_32(m1, (uint32_t)i0));
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if (row < n1) reinterpret_cast<uint2*>(sd.keys12)[row] = make_uint2(rb0, rb1);
+}
+
+// K1c  merge the per-block column partials of K1b: keys21[j] = best-2 over iblk of part21[iblk][j]
+__global__ void __launch_bounds__(256)
+k_merge_partials(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks)
+{
+    const BlockDesc bd = blocks[blockIdx.x];
+    const SymDesc sd = syms[bd.item];
+    const int j = bd.row0 + (int)threadIdx.x;
+    if (j >= sd.n2) return;
+    const uint2* part = reinterpret_cast<const uint2*>(sd.part21);
+    uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
+    for (int ib = 0; ib < sd.n_iblk; ++ib) {
+        const uint2 p = part[(size_t)ib * sd.n2 + j];
+        best2_merge(b0, b1, p.x, p.y);
+    }
+    reinterpret_cast<uint2*>(sd.keys21)[j] = make_uint2(b0, b1);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K2  finalize: ratio test (fp32, one multiply) + mutual consistency -> matches_12, #matches.
 // stvo-pl matchNNR: accept iff (float)d0 < (float)d1 * nnr; match(): keep i1->i2 iff m21[i2]==i1.
 // ---------------------------------------------------------------------------------------------
@@ -203,14 +382,6 @@ int scan_rows_per_block(int variant, int block_threads)
     return block_threads;
 }
 
-int resolve_scan_variant(const plslam_ctx* ctx, int64_t total_query_rows, bool all_mutual)
-{
-    (void)total_query_rows;
-    (void)all_mutual;
-    if (ctx->scan_variant != PLSLAM_SCAN_AUTO) return ctx->scan_variant;
-    return PLSLAM_SCAN_LANE_PER_QUERY;
-}
-
 int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const ScanDesc* d_scans,
                 const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero, hipStream_t s)
 {
@@ -236,6 +407,23 @@ int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const Sca
         default:
             PLSLAM_REQUIRE(!"scan_block must be 256, 512 or 1024", PLSLAM_EINVAL);
     }
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int launch_scan_sym(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
+                    int nzero, hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_scan_symmetric, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_merge_partials, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

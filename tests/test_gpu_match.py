@@ -67,18 +67,43 @@ def test_tie_stress_bit_exact(ctx, oracle, seed):
         assert np.array_equal(m, em) and n == en
 
 
+@pytest.mark.parametrize("n1,n2", [(1, 2), (2, 1), (63, 65), (64, 64), (65, 63), (129, 1), (200, 200), (1500, 1500),
+                                   (333, 1027), (1027, 333), (2, 2), (70, 3)])
+def test_symmetric_and_directed_variants_agree(ctx, oracle, n1, n2):
+    """Mutual problems default to the symmetric scan (one distance feeds both directions); forcing
+    the directed lane-per-query scan must give the same tables, and both must equal the oracle."""
+    import plslam_amd
+    r = _rng(n1 * 7919 + n2)
+    for gen in (synth.random_desc, synth.tie_stress_desc):
+        d1, d2 = gen(r, n1), gen(r, n2)
+        if gen is synth.random_desc and min(n1, n2) > 8:
+            k = min(n1, n2) // 2
+            d2[:k] = d1[:k] ^ np.packbits(r.random((k, 256)) < 0.06, axis=1)
+        em, en = oracle.match(d1, d2, 0.9, True)
+        try:
+            for variant in (plslam_amd.SCAN_SYMMETRIC, plslam_amd.SCAN_LANE_PER_QUERY, plslam_amd.SCAN_AUTO):
+                ctx.set_option("scan_variant", variant)
+                m, n = ctx.match(d1, d2, 0.9, True)
+                assert np.array_equal(m, em) and n == en, (variant, gen.__name__)
+        finally:
+            ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+
+
 def test_all_scan_block_sizes(ctx, oracle):
     r = _rng(77)
     q = synth.random_desc(r, 1500)
     t, _, _ = synth.noisy_copy(r, q)
     em, en = oracle.match(q, t, 0.75, True)
+    import plslam_amd
     try:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_LANE_PER_QUERY)
         for blk in (256, 512, 1024):
             ctx.set_option("scan_block", blk)
             m, n = ctx.match(q, t, 0.75, True)
             assert np.array_equal(m, em) and n == en, blk
     finally:
         ctx.set_option("scan_block", 0)
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
 
 
 def test_c2_full_size_pair_bit_exact(ctx, oracle):
@@ -165,6 +190,7 @@ def test_device_resident_plan_matches_oracle(ctx, oracle):
     bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.75, nnr_l=0.9, mutual=True)
     info = bm.plan.info()
     assert info["n_scans"] == 3 * 8 and info["directed_evals"] == 3 * 4 * (320 * 320 + 70 * 70)
+    assert info["distance_evals"] == info["directed_evals"] // 2     # symmetric scan: half the distances
     for _ in range(2):                        # re-running a plan is idempotent
         tab = bm.run()
         torch.cuda.synchronize()
