@@ -1,0 +1,129 @@
+// lba_rows.hpp -- C++ host side of the local-BA row build, mirroring the data flow of
+// PLSLAM::MapHandler::localBundleAdjustment / levMarquardtOptimizationLBA
+// (src/mapHandler.cpp:1220-1330 gather, :1332-1540 first pass, :1587-1772 iteration pass).
+//
+// The reference walks `pt_obs_list` / `ls_obs_list` (one Vector6i per observation:
+// [lm_idx, lm_loc, obs_idx, kf_idx, kf_loc, inlier], :1257-1264) and, per observation, computes the
+// residual, the two Jacobians and the Cauchy weight, then adds 6x6 / 3x6 / 3x3 (6x6 for lines) blocks
+// into a dense H and g.  Here the per-observation arithmetic runs on the MI355X
+// (plslam_lba_point_rows / plslam_lba_line_rows); this class owns the SoA staging around it and the
+// host-side accumulation with the reference's exact block placement (:1410-1429, :1519-1538).
+// The LM control flow and the sparse LDLT solve stay with the caller, as in the reference.
+#pragma once
+
+#include <stdint.h>
+
+#include <array>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "plslam_hip.h"
+
+namespace PLSLAM {
+
+typedef std::array<int, 6> Vector6i;  // include/mapHandler.h:63
+
+struct LbaProblem {
+    // local keyframes to optimise are kf_loc = 0..Nkf-1 (kf_idx 0 is never optimised, :1231);
+    // poses_T_kf_w holds one row-major 4x4 per distinct KF referenced by any observation
+    // ("pose slot"); kf_slot_of_obs maps an observation to its slot.
+    std::vector<double> poses_T_kf_w;   // n_slots * 16
+    std::vector<double> points;         // Npt * 3   (X block :1251-1253, or X.block(6Nkf+3*loc) :1597)
+    std::vector<double> lines;          // Nls * 6
+    std::vector<Vector6i> pt_obs_list, ls_obs_list;
+    std::vector<int32_t> pt_pose_slot, ls_pose_slot;
+    std::vector<double> pt_obs;         // Npt_obs * 2   map_points[..]->obs_list[..]   (:1375)
+    std::vector<double> ls_obs;         // Nls_obs * 3   map_lines[..]->obs_list[..]    (:1456)
+    int Nkf = 0;
+};
+
+struct LbaRows {
+    std::vector<double> J_pose, J_lm, r, w;
+};
+
+class LbaRowBuilder {
+public:
+    LbaRowBuilder(plslam_ctx* ctx, const plslam_cam& cam, double homog_th) : ctx_(ctx), cam_(cam), th_(homog_th) {}
+
+    // rows of every point observation (:1358-1407 / :1587-1642)
+    void pointRows(const LbaProblem& p, LbaRows& out) const
+    {
+        const int32_t n = (int32_t)p.pt_obs_list.size();
+        std::vector<int32_t> lm(n);
+        for (int32_t o = 0; o < n; ++o) lm[o] = p.pt_obs_list[o][1];
+        out.J_pose.resize((size_t)n * 6); out.J_lm.resize((size_t)n * 3); out.r.resize(n); out.w.resize(n);
+        check(plslam_lba_point_rows(ctx_, &cam_, th_, p.poses_T_kf_w.data(), (int32_t)(p.poses_T_kf_w.size() / 16),
+                                    p.points.data(), (int32_t)(p.points.size() / 3), p.pt_obs.data(), lm.data(),
+                                    p.pt_pose_slot.data(), n, out.J_pose.data(), out.J_lm.data(), out.r.data(),
+                                    out.w.data()), "plslam_lba_point_rows");
+    }
+
+    // rows of every line observation (:1436-1516; compat_iter_pass = the quirks of :1668-1748)
+    void lineRows(const LbaProblem& p, bool compat_iter_pass, LbaRows& out) const
+    {
+        const int32_t n = (int32_t)p.ls_obs_list.size();
+        std::vector<int32_t> lm(n);
+        for (int32_t o = 0; o < n; ++o) lm[o] = p.ls_obs_list[o][1];
+        out.J_pose.resize((size_t)n * 6); out.J_lm.resize((size_t)n * 6); out.r.resize(n); out.w.resize(n);
+        check(plslam_lba_line_rows(ctx_, &cam_, th_, compat_iter_pass ? 1 : 0, p.poses_T_kf_w.data(),
+                                   (int32_t)(p.poses_T_kf_w.size() / 16), p.lines.data(), (int32_t)p.lines.size(),
+                                   p.ls_obs.data(), lm.data(), p.ls_pose_slot.data(), n, out.J_pose.data(),
+                                   out.J_lm.data(), out.r.data(), out.w.data()), "plslam_lba_line_rows");
+    }
+
+    // dense accumulation exactly as :1410-1429 (dl = 3) and :1519-1538 (dl = 6); H is N x N row-major
+    static void accumulate(const std::vector<Vector6i>& obs, const LbaRows& rows, int dl, int lm_base, int N,
+                           std::vector<double>& H, std::vector<double>& g, double& err)
+    {
+        for (size_t o = 0; o < obs.size(); ++o) {
+            const double* Jp = &rows.J_pose[o * 6];
+            const double* Jl = &rows.J_lm[o * (size_t)dl];
+            const int kf_loc = obs[o][4];
+            const int idx = 6 * kf_loc, jdx = lm_base + dl * obs[o][1];
+            const double r = rows.r[o], w = rows.w[o];
+            for (int a = 0; a < dl; ++a) g[jdx + a] += Jl[a] * r * w;
+            err += r * r * w;
+            for (int a = 0; a < dl; ++a)
+                for (int b = 0; b < dl; ++b) H[(size_t)(jdx + a) * N + jdx + b] += Jl[a] * Jl[b] * w;
+            if (kf_loc == -1) continue;
+            for (int a = 0; a < 6; ++a) g[idx + a] += Jp[a] * r * w;
+            for (int a = 0; a < 6; ++a)
+                for (int b = 0; b < 6; ++b) H[(size_t)(idx + a) * N + idx + b] += Jp[a] * Jp[b] * w;
+            for (int a = 0; a < dl; ++a)
+                for (int b = 0; b < 6; ++b) {
+                    const double h = Jl[a] * Jp[b] * w;
+                    H[(size_t)(jdx + a) * N + idx + b] += h;
+                    H[(size_t)(idx + b) * N + jdx + a] += h;
+                }
+        }
+    }
+
+    // one H, g, err build = the body of the first pass (:1358-1540) or of an LM iteration (:1587-1772)
+    void buildNormalEquations(const LbaProblem& p, bool iteration_pass, std::vector<double>& H,
+                              std::vector<double>& g, double& err) const
+    {
+        const int Npt = (int)(p.points.size() / 3), Nls = (int)(p.lines.size() / 6);
+        const int N = 6 * p.Nkf + 3 * Npt + 6 * Nls;
+        H.assign((size_t)N * N, 0.0);
+        g.assign((size_t)N, 0.0);
+        err = 0.0;
+        LbaRows rows;
+        pointRows(p, rows);
+        accumulate(p.pt_obs_list, rows, 3, 6 * p.Nkf, N, H, g, err);
+        lineRows(p, iteration_pass, rows);
+        accumulate(p.ls_obs_list, rows, 6, 6 * p.Nkf + 3 * Npt, N, H, g, err);
+    }
+
+private:
+    static void check(int rc, const char* fn)
+    {
+        if (rc != PLSLAM_OK)
+            throw std::runtime_error(std::string("[") + fn + "] " + plslam_strerror(rc) + ": " + plslam_last_error());
+    }
+    plslam_ctx* ctx_;
+    plslam_cam cam_;
+    double th_;
+};
+
+}  // namespace PLSLAM

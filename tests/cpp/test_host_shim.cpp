@@ -1,0 +1,178 @@
+// Exercises the C++ host shim (plslam_amd/host) the way the reference's callers use the matcher
+// (src/mapHandler.cpp:277-283) and the LBA row build (:1358-1540), and checks every result against
+// the CPU oracle.  Built and run by tests/test_gpu_host_shim.py on a GPU box.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../../oracle/plslam_oracle.h"
+#include "../../plslam_amd/host/lba_rows.hpp"
+#include "../../plslam_amd/host/stvo_match.hpp"
+
+static int g_fail = 0;
+#define EXPECT(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); ++g_fail; } } while (0)
+
+static std::vector<uint8_t> rand_desc(std::mt19937& g, int n)
+{
+    std::vector<uint8_t> d((size_t)n * 32);
+    for (auto& b : d) b = (uint8_t)(g() & 0xFF);
+    return d;
+}
+
+static void noisy(std::mt19937& g, const std::vector<uint8_t>& src, std::vector<uint8_t>& dst)
+{
+    dst = src;
+    std::bernoulli_distribution flip(0.06);
+    for (auto& b : dst)
+        for (int k = 0; k < 8; ++k)
+            if (flip(g)) b ^= (uint8_t)(1u << k);
+}
+
+static void match_case(int n1, int n2, float nnr, bool mutual, unsigned seed)
+{
+    std::mt19937 g(seed);
+    std::vector<uint8_t> a = rand_desc(g, n1), b;
+    std::vector<uint8_t> base = rand_desc(g, n2);
+    b = base;
+    if (n1 && n2) {
+        std::vector<uint8_t> na;
+        noisy(g, a, na);
+        for (int i = 0; i < std::min(n1, n2) / 2; ++i) std::copy(&na[(size_t)i * 32], &na[(size_t)i * 32 + 32], &b[(size_t)i * 32]);
+    }
+    StVO::DescMat d1(a.data(), n1), d2(b.data(), n2);
+    StVO::bestLRMatches() = mutual;
+    std::vector<int> m12;
+    const int n = StVO::match(d1, d2, nnr, m12);
+    std::vector<int32_t> ref((size_t)n1);
+    const int nref = plo_match(a.data(), n1, b.data(), n2, nnr, mutual ? 1 : 0, ref.data());
+    EXPECT(n == nref);
+    EXPECT((int)m12.size() == n1);
+    for (int i = 0; i < n1; ++i) EXPECT(m12[i] == ref[i]);
+    // the caller-side contract of src/mapHandler.cpp:280-283
+    int cnt = 0;
+    for (int i1 = 0; i1 < (int)m12.size(); ++i1) {
+        const int i2 = m12[i1];
+        if (i2 < 0) continue;
+        EXPECT(i2 < n2);
+        ++cnt;
+    }
+    EXPECT(cnt == n);
+}
+
+int main()
+{
+    // --- StVO::match drop-in -------------------------------------------------------------
+    match_case(1500, 1500, 0.75f, true, 1);
+    match_case(200, 200, 0.9f, true, 2);
+    match_case(777, 301, 0.75f, false, 3);
+    match_case(5, 1, 0.9f, true, 4);      // n2 < 2: defined as "no match"
+    match_case(0, 10, 0.9f, true, 5);
+    match_case(10, 0, 0.9f, true, 6);
+
+    // error behaviour: exceptions, like the reference (std::runtime_error)
+    {
+        StVO::DescMat bad(reinterpret_cast<const uint8_t*>("x"), 3);
+        bad.cols = 16;
+        std::vector<int> m;
+        bool threw = false;
+        try { StVO::match(bad, bad, 0.9f, m); } catch (const std::runtime_error&) { threw = true; }
+        EXPECT(threw);
+    }
+
+    // concurrent callers (VO thread, local mapping, loop closure): one context per thread
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < 3; ++t) th.emplace_back([t] { for (int k = 0; k < 4; ++k) match_case(400 + 37 * t, 390, 0.75f, true, 100 + 10 * t + k); });
+        for (auto& x : th) x.join();
+    }
+
+    // batch of jobs
+    {
+        std::mt19937 g(77);
+        std::vector<std::vector<uint8_t>> store;
+        std::vector<StVO::MatchJob> jobs;
+        const int sizes[][2] = {{300, 280}, {0, 5}, {64, 64}, {1, 2}, {129, 1000}};
+        for (auto& s : sizes) {
+            store.push_back(rand_desc(g, s[0]));
+            store.push_back(rand_desc(g, s[1]));
+        }
+        for (size_t b = 0; b < 5; ++b)
+            jobs.push_back({StVO::DescMat(store[2 * b].data(), sizes[b][0]), StVO::DescMat(store[2 * b + 1].data(), sizes[b][1])});
+        StVO::bestLRMatches() = true;
+        std::vector<std::vector<int>> out;
+        std::vector<int> counts = StVO::matchBatch(jobs, 0.9f, out);
+        for (size_t b = 0; b < 5; ++b) {
+            std::vector<int32_t> ref((size_t)sizes[b][0]);
+            const int nref = plo_match(store[2 * b].data(), sizes[b][0], store[2 * b + 1].data(), sizes[b][1], 0.9f, 1, ref.data());
+            EXPECT(counts[b] == nref);
+            for (int i = 0; i < sizes[b][0]; ++i) EXPECT(out[b][i] == ref[i]);
+        }
+    }
+
+    // --- LBA normal equations through the row builder -------------------------------------
+    {
+        plslam_ctx* ctx = nullptr;
+        EXPECT(plslam_ctx_create(0, &ctx) == PLSLAM_OK);
+        plslam_cam cam{458.654, 457.296, 367.215, 248.375, 0.11, 752, 480};
+        plo_cam ocam{458.654, 457.296, 367.215, 248.375, 0.11, 752, 480};
+        std::mt19937 g(5);
+        std::uniform_real_distribution<double> U(-1.0, 1.0);
+        PLSLAM::LbaProblem p;
+        const int nslots = 4, Npt = 60, Nls = 20;
+        p.Nkf = 3;  // slot 0 = KF 0 (never optimised, kf_loc = -1), slots 1..3 -> kf_loc 0..2
+        for (int k = 0; k < nslots; ++k) {
+            double x[6] = {0.02 * U(g), 0.02 * U(g), 0.25 * k, 0.01 * U(g), 0.01 * U(g), 0.01 * U(g)}, T[16];
+            plo_expmap_se3(x, T);
+            p.poses_T_kf_w.insert(p.poses_T_kf_w.end(), T, T + 16);
+        }
+        for (int i = 0; i < Npt; ++i) { p.points.push_back(3 * U(g)); p.points.push_back(2 * U(g)); p.points.push_back(8 + 4 * U(g)); }
+        for (int i = 0; i < Nls; ++i) for (int e = 0; e < 2; ++e) { p.lines.push_back(3 * U(g)); p.lines.push_back(2 * U(g)); p.lines.push_back(8 + 4 * U(g)); }
+        for (int i = 0; i < Npt; ++i)
+            for (int s = 0; s < 3; ++s) {
+                const int slot = (i + s) % nslots;
+                p.pt_obs_list.push_back({i, i, s, slot, slot - 1, 1});
+                p.pt_pose_slot.push_back(slot);
+                p.pt_obs.push_back(367 + 150 * U(g)); p.pt_obs.push_back(248 + 100 * U(g));
+            }
+        for (int i = 0; i < Nls; ++i)
+            for (int s = 0; s < 2; ++s) {
+                const int slot = (i + 2 * s) % nslots;
+                p.ls_obs_list.push_back({i, i, s, slot, slot - 1, 1});
+                p.ls_pose_slot.push_back(slot);
+                const double a = U(g), b = U(g), nn = std::sqrt(a * a + b * b) + 1e-3;
+                p.ls_obs.push_back(a / nn); p.ls_obs.push_back(b / nn); p.ls_obs.push_back(-300 * U(g));
+            }
+        PLSLAM::LbaRowBuilder rb(ctx, cam, 1e-7);
+        for (int pass = 0; pass < 2; ++pass) {
+            std::vector<double> H, gv;
+            double err = 0;
+            rb.buildNormalEquations(p, pass == 1, H, gv, err);
+            // oracle: same rows + same accumulation
+            const int N = 6 * p.Nkf + 3 * Npt + 6 * Nls;
+            std::vector<double> Ho((size_t)N * N, 0.0), go((size_t)N, 0.0);
+            double erro = 0;
+            const int np = (int)p.pt_obs_list.size(), nl = (int)p.ls_obs_list.size();
+            std::vector<int32_t> lm(np), kfl(np), lml(nl), kfll(nl);
+            for (int o = 0; o < np; ++o) { lm[o] = p.pt_obs_list[o][1]; kfl[o] = p.pt_obs_list[o][4]; }
+            for (int o = 0; o < nl; ++o) { lml[o] = p.ls_obs_list[o][1]; kfll[o] = p.ls_obs_list[o][4]; }
+            std::vector<double> Jp((size_t)np * 6), Jl((size_t)np * 3), r(np), w(np);
+            plo_lba_point_rows(&ocam, 1e-7, p.poses_T_kf_w.data(), p.points.data(), p.pt_obs.data(), lm.data(), p.pt_pose_slot.data(), np, Jp.data(), Jl.data(), r.data(), w.data());
+            plo_lba_accumulate_points(p.Nkf, Npt, Nls, lm.data(), kfl.data(), np, Jp.data(), Jl.data(), r.data(), w.data(), Ho.data(), go.data(), &erro);
+            std::vector<double> Jp2((size_t)nl * 6), Jl2((size_t)nl * 6), r2(nl), w2(nl);
+            plo_lba_line_rows(&ocam, 1e-7, pass, p.poses_T_kf_w.data(), p.lines.data(), p.ls_obs.data(), lml.data(), p.ls_pose_slot.data(), nl, Jp2.data(), Jl2.data(), r2.data(), w2.data());
+            plo_lba_accumulate_lines(p.Nkf, Npt, Nls, lml.data(), kfll.data(), nl, Jp2.data(), Jl2.data(), r2.data(), w2.data(), Ho.data(), go.data(), &erro);
+            double worst = 0;
+            for (size_t i = 0; i < H.size(); ++i) worst = std::fmax(worst, std::fabs(H[i] - Ho[i]) / std::fmax(1e-300, std::fabs(Ho[i])));
+            for (size_t i = 0; i < gv.size(); ++i) worst = std::fmax(worst, std::fabs(gv[i] - go[i]) / std::fmax(1e-300, std::fabs(go[i])));
+            EXPECT(worst <= 1e-6);            // the contract (north_star)
+            EXPECT(std::fabs(err - erro) <= 1e-6 * std::fabs(erro));
+            std::printf("LBA normal equations pass %d: N=%d max rel diff vs oracle %.3g\n", pass, N, worst);
+        }
+        plslam_ctx_destroy(ctx);
+    }
+    std::printf(g_fail ? "HOST SHIM: %d FAILURES\n" : "HOST SHIM: all checks passed\n", g_fail);
+    return g_fail ? 1 : 0;
+}

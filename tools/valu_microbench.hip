@@ -58,6 +58,24 @@
 #define I_CMP(r)      "v_cmp_lt_u32 vcc, " #r ", %8\n"
 #define I_READLANE(r) "v_readlane_b32 s20, " #r ", 5\n"
 
+#define I_XOR_E64S(r) "v_xor_b32_e64 " #r ", " #r ", %9\n"
+#define I_BITOP3_S(r) "v_bitop3_b32 " #r ", " #r ", %9, %9 bitop3:0x66\n"
+#define I_BITOP3_S2(r) "v_bitop3_b32 " #r ", %9, " #r ", " #r " bitop3:0x3c\n"
+#define I_ADD_S(r)    "v_add_u32 " #r ", %9, " #r "\n"
+#define I_MOV_S(r)    "v_mov_b32 " #r ", %9\n"
+#define I_XNOR_S(r)   "v_xnor_b32 " #r ", %9, " #r "\n"
+#define I_AND_S(r)    "v_and_b32 " #r ", %9, " #r "\n"
+#define I_XOR_LIT(r)  "v_xor_b32 " #r ", 0x12345678, " #r "\n"
+#define I_XOR_INL(r)  "v_xor_b32 " #r ", 15, " #r "\n"
+DEFINE_KERNEL(xor_e64_sgpr, I_XOR_E64S)
+DEFINE_KERNEL(bitop3_sgpr_src12, I_BITOP3_S)
+DEFINE_KERNEL(bitop3_sgpr_src0, I_BITOP3_S2)
+DEFINE_KERNEL(add_u32_sgpr, I_ADD_S)
+DEFINE_KERNEL(mov_from_sgpr, I_MOV_S)
+DEFINE_KERNEL(xnor_sgpr, I_XNOR_S)
+DEFINE_KERNEL(and_sgpr, I_AND_S)
+DEFINE_KERNEL(xor_literal, I_XOR_LIT)
+DEFINE_KERNEL(xor_inline_const, I_XOR_INL)
 DEFINE_KERNEL(xor, I_XOR)
 DEFINE_KERNEL(xor_sgpr, I_XOR_S)
 DEFINE_KERNEL(bcnt, I_BCNT)
@@ -132,6 +150,78 @@ __global__ void __launch_bounds__(256) k_lds_w16(uint32_t* out, uint32_t s, int 
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// symmetric row-mode mix, train row from SGPRs (current kernel): 8 xor(s) + 8 bcnt + 3 + ds_write_b16
+__global__ void __launch_bounds__(256) k_mix_sym_sgpr(uint32_t* out, uint32_t s, int iters)
+{
+    __shared__ uint16_t tile[4][64 * 72];
+    uint16_t* wr = tile[threadIdx.x >> 6] + (threadIdx.x & 63);
+    uint32_t q0 = threadIdx.x, q1 = q0 * 3, q2 = q0 * 5, q3 = q0 * 7, q4 = q0 * 11, q5 = q0 * 13,
+             q6 = q0 * 17, q7 = q0 * 19;
+    uint32_t b0 = ~0u, b1 = ~0u;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            uint32_t t0, t1, t2, t3, t4, t5, t6, t7, d;
+            asm volatile(
+                "v_xor_b32 %0, %19, %10\n v_xor_b32 %1, %19, %11\n v_xor_b32 %2, %19, %12\n"
+                "v_xor_b32 %3, %19, %13\n v_xor_b32 %4, %19, %14\n v_xor_b32 %5, %19, %15\n"
+                "v_xor_b32 %6, %19, %16\n v_xor_b32 %7, %19, %17\n"
+                "v_bcnt_u32_b32 %8, %0, 0\n v_bcnt_u32_b32 %8, %1, %8\n v_bcnt_u32_b32 %8, %2, %8\n"
+                "v_bcnt_u32_b32 %8, %3, %8\n v_bcnt_u32_b32 %8, %4, %8\n v_bcnt_u32_b32 %8, %5, %8\n"
+                "v_bcnt_u32_b32 %8, %6, %8\n v_bcnt_u32_b32 %8, %7, %8\n"
+                : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7),
+                  "=&v"(d), "+v"(b0)
+                : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7), "v"(b1), "s"(s + i + u));
+            wr[((i * 4 + u) & 63) * 72] = (uint16_t)d;
+            uint32_t key, nb1;
+            asm volatile("v_lshl_or_b32 %0, %1, 23, %2\n" : "=v"(key) : "v"(d), "s"(s + i));
+            asm volatile("v_med3_u32 %0, %1, %2, %3\n" : "=v"(nb1) : "v"(b0), "v"(b1), "v"(key));
+            asm volatile("v_min_u32 %0, %0, %1\n" : "+v"(b0) : "v"(key));
+            b1 = nb1;
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = b0 ^ b1;
+}
+
+// same, train row broadcast-read from LDS into VGPRs: 2 ds_read_b128 + 8 xor(v,v) + 8 bcnt + 3 + ds_write_b16
+__global__ void __launch_bounds__(256) k_mix_sym_lds(uint32_t* out, uint32_t s, int iters)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t tile[4][64 * 72];
+    __shared__ __attribute__((aligned(16))) uint32_t brow[64 * 8];
+    for (int i = threadIdx.x; i < 64 * 8; i += 256) brow[i] = i * 2654435761u + s;
+    __syncthreads();
+    uint16_t* wr = tile[threadIdx.x >> 6] + (threadIdx.x & 63);
+    uint32_t q0 = threadIdx.x, q1 = q0 * 3, q2 = q0 * 5, q3 = q0 * 7, q4 = q0 * 11, q5 = q0 * 13,
+             q6 = q0 * 17, q7 = q0 * 19;
+    uint32_t b0 = ~0u, b1 = ~0u;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint4* rp = reinterpret_cast<const uint4*>(brow + (((i * 4 + u) & 63) * 8));
+            const uint4 ta = rp[0], tb = rp[1];
+            uint32_t t0, t1, t2, t3, t4, t5, t6, t7, d;
+            asm volatile(
+                "v_xor_b32 %0, %19, %10\n v_xor_b32 %1, %20, %11\n v_xor_b32 %2, %21, %12\n"
+                "v_xor_b32 %3, %22, %13\n v_xor_b32 %4, %23, %14\n v_xor_b32 %5, %24, %15\n"
+                "v_xor_b32 %6, %25, %16\n v_xor_b32 %7, %26, %17\n"
+                "v_bcnt_u32_b32 %8, %0, 0\n v_bcnt_u32_b32 %8, %1, %8\n v_bcnt_u32_b32 %8, %2, %8\n"
+                "v_bcnt_u32_b32 %8, %3, %8\n v_bcnt_u32_b32 %8, %4, %8\n v_bcnt_u32_b32 %8, %5, %8\n"
+                "v_bcnt_u32_b32 %8, %6, %8\n v_bcnt_u32_b32 %8, %7, %8\n"
+                : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7),
+                  "=&v"(d), "+v"(b0)
+                : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7), "v"(b1),
+                  "v"(ta.x), "v"(ta.y), "v"(ta.z), "v"(ta.w), "v"(tb.x), "v"(tb.y), "v"(tb.z), "v"(tb.w));
+            wr[((i * 4 + u) & 63) * 72] = (uint16_t)d;
+            uint32_t key, nb1;
+            asm volatile("v_lshl_or_b32 %0, %1, 23, %2\n" : "=v"(key) : "v"(d), "s"(s + i));
+            asm volatile("v_med3_u32 %0, %1, %2, %3\n" : "=v"(nb1) : "v"(b0), "v"(b1), "v"(key));
+            asm volatile("v_min_u32 %0, %0, %1\n" : "+v"(b0) : "v"(key));
+            b1 = nb1;
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = b0 ^ b1;
+}
+
 typedef void (*kern_t)(uint32_t*, uint32_t, int);
 struct Entry { const char* name; kern_t k; double ops_per_iter; };
 
@@ -150,7 +240,11 @@ int main(int argc, char** argv)
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
 #define E(NAME) {#NAME, k_##NAME, 64.0}
-    Entry es[] = {E(xor), E(xor_sgpr), E(bcnt), E(min_u32), E(med3_u32), E(min3_u32), E(lshl_or),
+    Entry es[] = {E(xor_e64_sgpr), E(bitop3_sgpr_src12), E(bitop3_sgpr_src0), E(add_u32_sgpr), E(mov_from_sgpr),
+                  E(xnor_sgpr), E(and_sgpr), E(xor_literal), E(xor_inline_const),
+                  {"mix_sym_sgpr (19 valu + ds_write_b16)", k_mix_sym_sgpr, 76.0},
+                  {"mix_sym_lds (2 ds_read_b128 bcast + 19 valu + ds_write_b16)", k_mix_sym_lds, 76.0},
+                  E(xor), E(xor_sgpr), E(bcnt), E(min_u32), E(med3_u32), E(min3_u32), E(lshl_or),
                   E(lshl_or_sgpr), E(add_u32), E(add3_u32), E(and_or), E(bfe_u32), E(perm_b32), E(mov),
                   E(lshlrev), E(cndmask), E(fma_f32), E(bitop3), E(pk_add_u16), E(pk_min_u16), E(sad_u8),
                   E(dot4_u32_u8), E(mad_u32_u24), E(min_dpp_quad), E(min_dpp_row_ror),
@@ -172,7 +266,7 @@ int main(int argc, char** argv)
         }
         const double wave_instr = (double)blocks * 4 * iters * e.ops_per_iter;  // 4 waves per block
         const double cyc = best * 1e-3 * clk * (cus * 4.0) / wave_instr;
-        printf("%-40s %8.3f ms  %6.2f cyc/wave-instr/SIMD @maxclk  %7.2f T lane-ops/s\n", e.name, best,
+        printf("%-62s %8.3f ms  %6.2f cyc/wave-instr/SIMD @maxclk  %7.2f T lane-ops/s\n", e.name, best,
                cyc, wave_instr * 64 / (best * 1e-3) / 1e12);
     }
     return 0;
