@@ -15,8 +15,9 @@
  *
  * Pointer conventions: entry points WITHOUT a _dev suffix take HOST pointers and do their
  * own H2D/D2H on the context's stream; *_dev entry points and match plans take DEVICE
- * pointers and a hipStream_t (passed as void*; NULL = the context's own stream) and are
- * asynchronous with respect to the host.
+ * pointers and a hipStream_t (passed as void*) and are asynchronous with respect to the host.
+ * A NULL stream means "the context's own (non-blocking) stream", NOT HIP's legacy default stream:
+ * callers that need ordering against their own work must pass a real stream handle.
  *
  * Threading: the reference calls StVO::match() concurrently from the VO thread, the local
  * mapping thread and the loop-closure thread (app/plslam_dataset.cpp:127,

@@ -78,10 +78,18 @@ class StereoBatchMatcher:
             probs.append((ll + row_l * i, self.n_lbd, ll + row_l * (i + 1), self.n_lbd, nnr_l, mutual,
                           t_i + 4 * sl["lbd_pc"].start, c_i + 12))
         self.plan = ctx.plan(probs)
+        # A real (non-NULL) HIP stream: the C ABI reads a NULL stream as "the context's own stream",
+        # and torch's legacy default stream has handle 0.
+        self.stream = torch.cuda.Stream(device=dev)
 
     def run(self):
-        """Enqueue one pass over the batch on torch's current stream."""
-        self.plan.run(self.torch.cuda.current_stream(self.dev).cuda_stream)
+        """Enqueue one pass over the batch.  The kernels run on this object's stream, fenced on both
+        sides against torch's current stream so that whatever the caller enqueues next (e.g. the
+        RCCL gather of the table) is ordered after them."""
+        cur = self.torch.cuda.current_stream(self.dev)
+        self.stream.wait_stream(cur)
+        self.plan.run(self.stream.cuda_stream)
+        cur.wait_stream(self.stream)
         return self.table
 
     def close(self):

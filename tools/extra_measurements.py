@@ -21,16 +21,20 @@ from plslam_amd import synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
+STREAM = None   # a real (non-NULL) HIP stream: the ABI reads NULL as "the context's own stream"
+
+
 def ev_time(fn, iters=50, warm=5):
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
+    with torch.cuda.stream(STREAM):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(STREAM)
+        for _ in range(iters):
+            fn()
+        e1.record(STREAM)
+        torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters   # ms
 
 
@@ -38,7 +42,10 @@ def main():
     out = {}
     ctx = plslam_amd.Context(0)
     dev = torch.device("cuda", 0)
-    st = torch.cuda.current_stream(dev).cuda_stream
+    global STREAM
+    STREAM = torch.cuda.Stream(device=dev)
+    st = STREAM.cuda_stream
+    assert st != 0
 
     # ---- PCIe-inclusive: host-pointer API on 128 C2 pairs --------------------------------------
     B = 128
