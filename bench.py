@@ -83,7 +83,10 @@ def main():
     ap.add_argument("--nnr-l", type=float, default=0.75)
     ap.add_argument("--scan-variant", type=int, default=0)
     ap.add_argument("--scan-block", type=int, default=0)
+    ap.add_argument("--sym-rows", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="create the NCCL(RCCL) process group and run the table gather even with one rank")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -109,8 +112,10 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.pairs_per_gpu
@@ -123,19 +128,21 @@ def main():
         ctx.set_option("scan_variant", args.scan_variant)
     if args.scan_block:
         ctx.set_option("scan_block", args.scan_block)
+    if args.sym_rows:
+        ctx.set_option("sym_rows", args.sym_rows)
     bm = frontend.StereoBatchMatcher(ctx, stream, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev)
     info = bm.plan.info()
     devinfo = ctx.device_info()
 
     def step():
         tab = bm.run()
-        if world > 1:
-            return frontend.gather_tables(tab, world, rank, root=0)
+        if use_dist:
+            return frontend.gather_tables(tab, world, rank, root=0, force=True)
         return tab
 
     def sync():
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -156,7 +163,7 @@ def main():
     note(f"timed {args.steps} steps in {elapsed:.4f}s; scan {scan_ms / max(runs, 1):.3f} ms/launch")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -176,6 +183,18 @@ def main():
         scan_s = scan_ms / 1e3 / max(runs, 1)           # average launch duration of the dominant kernel
         achieved_gbs = info["algorithmic_bytes"] / scan_s / 1e9
         valu_peak = devinfo["cu_count"] * VALU_LANES_PER_CLK_PER_CU * devinfo["clock_khz"] * 1e3
+        # HBM bytes of the dominant kernel per launch: PMC counters cannot be read from inside this
+        # process, so the figure comes from the committed rocprofv3 passes of this same command
+        # (profiles/pmc_traffic.json) and is reported only for the configuration they were taken on.
+        traffic = None
+        wkey = f"C2:{args.n_orb}+{args.n_lbd}:pairs{B}:sym{ctx.get_option('sym_rows')}"
+        try:
+            with open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")) as f:
+                pm = json.load(f)
+            if pm.get("workload_key") == wkey and info["scan_variant"] == 3:
+                traffic = pm["traffic_bytes_per_launch"]
+        except OSError:
+            pass
         out = {
             "metric": "stereo pairs/sec (1500 ORB + 200 LBD BF-match)",
             "value": pairs_total / elapsed,
@@ -199,7 +218,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": "k_scan (Hamming kNN-2)", "kernel_ms": 1e3 * scan_s,
                 "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
                 "note": "compulsory-byte model 32(Q+T)+16Q per directed scan; the kernel is VALU "
@@ -224,7 +243,7 @@ def main():
 
     bm.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

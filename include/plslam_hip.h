@@ -82,7 +82,8 @@ int plslam_abi_version(void);
  * scratch pools.  Replaces nothing in the reference (it has no device state). */
 int plslam_ctx_create(int device_ordinal, plslam_ctx** out);
 void plslam_ctx_destroy(plslam_ctx* ctx);
-/* options: "scan_variant" (PLSLAM_SCAN_*), "scan_block" (queries per workgroup: 256|512|1024) */
+/* options: "scan_variant" (PLSLAM_SCAN_*), "scan_block" (queries per workgroup of the directed
+ * scan: 256|512|1024), "sym_rows" (rows of d1 per lane in the symmetric scan: 1|4, default 1) */
 int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value);
 int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value);
 /* device facts for reports: CU count, max clock (kHz), LDS bytes per workgroup */

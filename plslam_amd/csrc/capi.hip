@@ -67,9 +67,13 @@ struct plslam_match_plan {
     plslam_ctx* ctx = nullptr;
     int variant = 0, block_threads = 0;
     int32_t nprob = 0, nscan = 0, nscan_blocks = 0, nfin_blocks = 0, ncounts = 0;
-    int32_t nsym = 0, nsym_blocks = 0, nmerge_blocks = 0;
-    DevBuf keys, scans, probs, scan_blocks, fin_blocks, counts, count_dst;
-    DevBuf syms, sym_blocks, merge_blocks, partials;
+    int32_t nsym = 0, nsym_blocks = 0, nmerge_blocks = 0, sym_rows = 1;
+    DevBuf keys, counts, partials;
+    DevBuf tables;                     // all launch tables, packed, uploaded with ONE copy
+    std::vector<char> staging;         // host image of `tables` (kept alive: the copy is async)
+    ScanDesc* d_scans = nullptr; SymDesc* d_syms = nullptr; ProblemDesc* d_probs = nullptr;
+    BlockDesc *d_scan_blocks = nullptr, *d_sym_blocks = nullptr, *d_merge_blocks = nullptr, *d_fin_blocks = nullptr;
+    int32_t** d_count_dst = nullptr;
     int32_t* d_counts_zero = nullptr;  // contiguous int32 counters zeroed by the first scan kernel
     bool scatter_counts = false;       // user n_matches pointers are not one contiguous array
     plslam_plan_info info{};
@@ -81,9 +85,7 @@ struct plslam_match_plan {
     int64_t acc_runs = 0;
     void free_all()
     {
-        keys.release(); scans.release(); probs.release();
-        scan_blocks.release(); fin_blocks.release(); counts.release(); count_dst.release();
-        syms.release(); sym_blocks.release(); merge_blocks.release(); partials.release();
+        keys.release(); counts.release(); partials.release(); tables.release();
         for (auto& e : evs) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2); }
         evs.clear();
     }
@@ -99,10 +101,21 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
 
     // AUTO: mutual problems take the symmetric scan (one distance feeds both directions), the
     // others the directed lane-per-query scan.  A forced variant applies to every problem.
-    const bool allow_sym = ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_SYMMETRIC;
-    PLSLAM_REQUIRE(ctx->scan_variant != PLSLAM_SCAN_WAVE_PER_QUERY, PLSLAM_ENOTSUP);
+    // A plan too small to put one wave on every SIMD under those (e.g. ONE StVO::match call of the
+    // SLAM loop) takes the wave-per-query scan instead: 16 queries per workgroup, train tile in LDS.
+    int64_t thr_waves = 0;
+    for (int32_t i = 0; i < nprob; ++i)
+        thr_waves += (probs[i].n1 + 63) / 64 + (probs[i].mutual ? 0 : 0);
+    const int64_t simds = (int64_t)ctx->prop.multiProcessorCount * 4;
+    const bool use_wpq = ctx->scan_variant == PLSLAM_SCAN_WAVE_PER_QUERY ||
+                         (ctx->scan_variant == PLSLAM_SCAN_AUTO && thr_waves < simds);
+    const bool allow_sym = !use_wpq &&
+                           (ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_SYMMETRIC);
     auto is_sym = [&](const plslam_match_problem& p) { return allow_sym && p.mutual && p.n1 > 0 && p.n2 > 0; };
 
+    P->sym_rows = ctx->sym_rows;
+    const int rpp = sym_rows_per_partial(P->sym_rows);   // a-rows per column partial
+    const int rps = sym_rows_per_block(P->sym_rows);     // a-rows per workgroup of the symmetric scan
     int64_t rows = 0, part_rows = 0;
     for (int32_t i = 0; i < nprob; ++i) {
         const plslam_match_problem& p = probs[i];
@@ -115,13 +128,15 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         PLSLAM_REQUIRE(p.n2 <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
         PLSLAM_REQUIRE(!p.mutual || p.n1 <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
         rows += p.n1 + (p.mutual ? p.n2 : 0);
-        if (is_sym(p)) part_rows += (int64_t)((p.n1 + 63) / 64) * p.n2;
+        if (is_sym(p)) part_rows += (int64_t)((p.n1 + rpp - 1) / rpp) * p.n2;
     }
     PLSLAM_REQUIRE(rows < (int64_t(1) << 31), PLSLAM_ERANGE);
 
-    P->variant = allow_sym ? PLSLAM_SCAN_SYMMETRIC : PLSLAM_SCAN_LANE_PER_QUERY;
-    P->block_threads = ctx->scan_block ? ctx->scan_block : 256;
-    const int rpb = scan_rows_per_block(PLSLAM_SCAN_LANE_PER_QUERY, P->block_threads);
+    P->variant = use_wpq ? PLSLAM_SCAN_WAVE_PER_QUERY
+                         : (allow_sym ? PLSLAM_SCAN_SYMMETRIC : PLSLAM_SCAN_LANE_PER_QUERY);
+    P->block_threads = use_wpq ? 256 : (ctx->scan_block ? ctx->scan_block : 256);
+    const int directed_variant = use_wpq ? PLSLAM_SCAN_WAVE_PER_QUERY : PLSLAM_SCAN_LANE_PER_QUERY;
+    const int rpb = scan_rows_per_block(directed_variant, P->block_threads);
 
     int r = P->keys.reserve(sizeof(uint32_t) * 2 * (size_t)(rows > 0 ? rows : 1));
     if (r) return r;
@@ -173,9 +188,9 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             SymDesc y{};
             y.a = p.d1; y.b = p.d2; y.keys12 = k12; y.keys21 = k21;
             y.part21 = d_part + 2 * part_row;
-            y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = (p.n1 + 63) / 64;
+            y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = (p.n1 + rpp - 1) / rpp;
             part_row += (int64_t)y.n_iblk * p.n2;
-            for (int32_t r0 = 0; r0 < p.n1; r0 += 256) yblocks.push_back({(int32_t)syms.size(), r0});
+            for (int32_t r0 = 0; r0 < p.n1; r0 += rps) yblocks.push_back({(int32_t)syms.size(), r0});
             for (int32_t c0 = 0; c0 < p.n2; c0 += 256) mblocks.push_back({(int32_t)syms.size(), c0});
             syms.push_back(y);
             evals += (int64_t)p.n1 * p.n2;
@@ -212,26 +227,39 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->info.algorithmic_bytes = abytes;  // 32(Q+T)+16Q per DIRECTED scan, however executed
     P->info.n_scans = P->nscan + 2 * P->nsym;
     P->info.scan_blocks = P->nscan_blocks + P->nsym_blocks;
-    P->info.scan_variant = P->nsym ? PLSLAM_SCAN_SYMMETRIC : PLSLAM_SCAN_LANE_PER_QUERY;
-    P->info.scan_block_threads = P->nsym ? 256 : P->block_threads;
+    P->info.scan_variant = P->nsym ? PLSLAM_SCAN_SYMMETRIC : directed_variant;
+    P->info.scan_block_threads = P->nsym ? (P->sym_rows == 4 ? 64 : 256) : P->block_threads;
 
-    auto upload = [&](DevBuf& b, const void* src, size_t bytes) -> int {
-        int rr = b.reserve(bytes ? bytes : 16);
-        if (rr) return rr;
-        if (bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
-        return PLSLAM_OK;
-    };
-    if ((r = upload(P->scans, scans.data(), scans.size() * sizeof(ScanDesc)))) return r;
-    if ((r = upload(P->syms, syms.data(), syms.size() * sizeof(SymDesc)))) return r;
-    if ((r = upload(P->probs, pds.data(), pds.size() * sizeof(ProblemDesc)))) return r;
-    if ((r = upload(P->scan_blocks, sblocks.data(), sblocks.size() * sizeof(BlockDesc)))) return r;
-    if ((r = upload(P->sym_blocks, yblocks.data(), yblocks.size() * sizeof(BlockDesc)))) return r;
-    if ((r = upload(P->merge_blocks, mblocks.data(), mblocks.size() * sizeof(BlockDesc)))) return r;
-    if ((r = upload(P->fin_blocks, fblocks.data(), fblocks.size() * sizeof(BlockDesc)))) return r;
-    if (P->scatter_counts)
-        if ((r = upload(P->count_dst, user_counts.data(), user_counts.size() * sizeof(int32_t*)))) return r;
-    // the staging vectors die at scope exit: make the uploads complete first
-    PLSLAM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // pack every launch table into one host image and upload it with a single copy
+    struct Piece { const void* src; size_t bytes; size_t off; };
+    Piece pc[8] = {{scans.data(), scans.size() * sizeof(ScanDesc), 0},
+                   {syms.data(), syms.size() * sizeof(SymDesc), 0},
+                   {pds.data(), pds.size() * sizeof(ProblemDesc), 0},
+                   {sblocks.data(), sblocks.size() * sizeof(BlockDesc), 0},
+                   {yblocks.data(), yblocks.size() * sizeof(BlockDesc), 0},
+                   {mblocks.data(), mblocks.size() * sizeof(BlockDesc), 0},
+                   {fblocks.data(), fblocks.size() * sizeof(BlockDesc), 0},
+                   {user_counts.data(), P->scatter_counts ? user_counts.size() * sizeof(int32_t*) : 0, 0}};
+    size_t total = 0;
+    for (Piece& x : pc) { x.off = total; total += (x.bytes + 255) & ~size_t(255); }
+    if (total == 0) total = 256;
+    P->staging.resize(total);
+    for (const Piece& x : pc)
+        if (x.bytes) memcpy(P->staging.data() + x.off, x.src, x.bytes);
+    if ((r = P->tables.reserve(total))) return r;
+    char* base = P->tables.as<char>();
+    P->d_scans = reinterpret_cast<ScanDesc*>(base + pc[0].off);
+    P->d_syms = reinterpret_cast<SymDesc*>(base + pc[1].off);
+    P->d_probs = reinterpret_cast<ProblemDesc*>(base + pc[2].off);
+    P->d_scan_blocks = reinterpret_cast<BlockDesc*>(base + pc[3].off);
+    P->d_sym_blocks = reinterpret_cast<BlockDesc*>(base + pc[4].off);
+    P->d_merge_blocks = reinterpret_cast<BlockDesc*>(base + pc[5].off);
+    P->d_fin_blocks = reinterpret_cast<BlockDesc*>(base + pc[6].off);
+    P->d_count_dst = reinterpret_cast<int32_t**>(base + pc[7].off);
+    // P->staging outlives the copy (it is a member), so no synchronisation is needed here; the
+    // copy is ordered before the kernels of plan_run when they use the same stream, and the public
+    // plan_create synchronises once so that any stream may be used afterwards.
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(base, P->staging.data(), total, hipMemcpyHostToDevice, ctx->stream));
     return PLSLAM_OK;
 }
 
@@ -253,24 +281,26 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
     int r;
     const bool sym_first = P->nsym_blocks > 0;
     if (sym_first) {
-        r = launch_scan_sym(P->syms.as<SymDesc>(), P->sym_blocks.as<BlockDesc>(), P->nsym_blocks,
-                            P->d_counts_zero, P->ncounts, s);
+        r = launch_scan_sym(P->sym_rows, P->d_syms, P->d_sym_blocks,
+                            P->nsym_blocks, P->d_counts_zero, P->ncounts, s);
         if (r) return r;
     }
     if (P->nscan_blocks > 0 || !sym_first) {
-        r = launch_scan(P->ctx, PLSLAM_SCAN_LANE_PER_QUERY, P->block_threads, P->scans.as<ScanDesc>(),
-                        P->scan_blocks.as<BlockDesc>(), P->nscan_blocks, P->d_counts_zero,
+        r = launch_scan(P->ctx, P->variant == PLSLAM_SCAN_WAVE_PER_QUERY ? PLSLAM_SCAN_WAVE_PER_QUERY
+                                                                         : PLSLAM_SCAN_LANE_PER_QUERY,
+                        P->block_threads, P->d_scans,
+                        P->d_scan_blocks, P->nscan_blocks, P->d_counts_zero,
                         sym_first ? 0 : P->ncounts, s);
         if (r) return r;
     }
-    r = launch_merge_partials(P->syms.as<SymDesc>(), P->merge_blocks.as<BlockDesc>(), P->nmerge_blocks, s);
+    r = launch_merge_partials(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s);
     if (r) return r;
     if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e1, s));
-    r = launch_finalize(P->probs.as<ProblemDesc>(), P->fin_blocks.as<BlockDesc>(), P->nfin_blocks, s);
+    r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, s);
     if (r) return r;
     if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e2, s));
     if (P->scatter_counts)
-        return launch_scatter_counts(P->d_counts_zero, P->count_dst.as<int32_t*>(), P->nprob, s);
+        return launch_scatter_counts(P->d_counts_zero, P->d_count_dst, P->nprob, s);
     return PLSLAM_OK;
 }
 
@@ -337,6 +367,10 @@ void plslam_ctx_destroy(plslam_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->in_a.release(); ctx->in_b.release(); ctx->out_a.release(); ctx->out_b.release();
     ctx->misc_a.release(); ctx->misc_b.release(); ctx->misc_c.release();
+    if (ctx->host_plan) {
+        ctx->host_plan->free_all();
+        delete ctx->host_plan;
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -354,6 +388,11 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         ctx->scan_block = value;
         return PLSLAM_OK;
     }
+    if (!strcmp(key, "sym_rows")) {
+        PLSLAM_REQUIRE(value == 1 || value == 4, PLSLAM_EINVAL);
+        ctx->sym_rows = value;
+        return PLSLAM_OK;
+    }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }
@@ -363,6 +402,7 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     PLSLAM_REQUIRE(ctx && key && value, PLSLAM_EINVAL);
     if (!strcmp(key, "scan_variant")) { *value = ctx->scan_variant; return PLSLAM_OK; }
     if (!strcmp(key, "scan_block")) { *value = ctx->scan_block; return PLSLAM_OK; }
+    if (!strcmp(key, "sym_rows")) { *value = ctx->sym_rows; return PLSLAM_OK; }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }
@@ -389,7 +429,11 @@ int plslam_match_plan_create(plslam_ctx* ctx, const plslam_match_problem* probs,
     DeviceGuard g(ctx->device);
     plslam_match_plan* P = new (std::nothrow) plslam_match_plan();
     PLSLAM_REQUIRE(P != nullptr, PLSLAM_ENOMEM);
-    const int r = plan_build(ctx, probs, nprob, P);
+    int r = plan_build(ctx, probs, nprob, P);
+    if (!r && hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        set_last_error("hipStreamSynchronize failed after the plan upload");
+        r = PLSLAM_EHIP;
+    }
     if (r) {
         P->free_all();
         delete P;
@@ -490,7 +534,11 @@ int plslam_match_batched(plslam_ctx* ctx, const uint8_t* d1, const int32_t* off1
         p.matches_12 = ctx->out_a.as<int32_t>() + off1[b];
         p.n_matches = ctx->out_b.as<int32_t>() + b;
     }
-    plslam_match_plan P;
+    // the context keeps ONE plan object for the host-pointer path: its device buffers only grow, so
+    // a call in the SLAM loop does no hipMalloc/hipFree
+    if (!ctx->host_plan) ctx->host_plan = new (std::nothrow) plslam_match_plan();
+    PLSLAM_REQUIRE(ctx->host_plan != nullptr, PLSLAM_ENOMEM);
+    plslam_match_plan& P = *ctx->host_plan;
     r = plan_build(ctx, probs.data(), B, &P);
     if (!r) r = plan_run(&P, ctx->stream);
     if (!r) {
@@ -506,7 +554,6 @@ int plslam_match_batched(plslam_ctx* ctx, const uint8_t* d1, const int32_t* off1
     } else {
         (void)hipStreamSynchronize(ctx->stream);
     }
-    P.free_all();
     return r;
 }
 
@@ -531,9 +578,11 @@ int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const 
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     int r;
-    const int variant = ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_SYMMETRIC
-                            ? PLSLAM_SCAN_LANE_PER_QUERY : ctx->scan_variant;
-    const int bt = ctx->scan_block ? ctx->scan_block : 256;
+    const bool small = (nq + 63) / 64 < ctx->prop.multiProcessorCount * 4;
+    const int variant = ctx->scan_variant == PLSLAM_SCAN_WAVE_PER_QUERY ||
+                                (ctx->scan_variant == PLSLAM_SCAN_AUTO && small)
+                            ? PLSLAM_SCAN_WAVE_PER_QUERY : PLSLAM_SCAN_LANE_PER_QUERY;
+    const int bt = variant == PLSLAM_SCAN_WAVE_PER_QUERY ? 256 : (ctx->scan_block ? ctx->scan_block : 256);
     const int rpb = scan_rows_per_block(variant, bt);
     if ((r = ctx->in_a.reserve((size_t)nq * 32))) return r;
     if ((r = ctx->in_b.reserve((size_t)nt * 32 + 16))) return r;

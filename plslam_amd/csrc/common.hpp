@@ -51,8 +51,10 @@ struct plslam_ctx {
     hipDeviceProp_t prop;
     int scan_variant = PLSLAM_SCAN_AUTO;
     int scan_block = 0;  // 0 = variant default
+    int sym_rows = 1;    // rows of d1 per lane in the symmetric scan (1 or 4); see DESIGN.md section 5
     std::mutex mu;       // serialises the host-pointer entry points
     plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
+    struct plslam_match_plan* host_plan = nullptr;  // reused by the host-pointer match entry points
 };
 
 namespace plslam {
@@ -104,8 +106,12 @@ struct SymDesc {
     int32_t n_iblk;
     int32_t pad;
 };
-int launch_scan_sym(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
-                    int nzero, hipStream_t s);
+// rows_per_lane: 1 (K1b: 256-thread workgroups, 64 a-rows per wave) or 4 (K1b': 64-thread
+// workgroups, 256 a-rows per wave).  sym_rows_per_block() = a-rows covered by one BlockDesc.
+int sym_rows_per_block(int rows_per_lane);
+int sym_rows_per_partial(int rows_per_lane);
+int launch_scan_sym(int rows_per_lane, const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks,
+                    int32_t* d_zero, int nzero, hipStream_t s);
 int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s);
 
 int scan_rows_per_block(int variant, int block_threads);

@@ -151,6 +151,83 @@ k_scan_lane_per_query(const ScanDesc* __restrict__ scans, const BlockDesc* __res
 }
 
 // ---------------------------------------------------------------------------------------------
+// K1d  wave-per-query scan: the LATENCY variant for plans too small to give every SIMD a wave under
+// K1a/K1b (one StVO::match call in the SLAM loop: 1500 queries are 6 workgroups there, 94 here).
+// A 256-thread workgroup stages a tile of train rows in LDS (16-byte slots XOR-swizzled with bit 3
+// of the row so that the per-lane 32-byte row reads are conflict-free ds_read_b128); each wave
+// takes 4 queries into SGPRs (s_load_dwordx8), every lane scans the tile rows lane, lane+64, ...
+// (19 VALU ops per distance, the train row is read once for the 4 queries), and a 6-step
+// cross-lane butterfly merges the lanes' best-2 keys per query.  Same keys, same order as K1a.
+// ---------------------------------------------------------------------------------------------
+constexpr int WPQ_TILE_ROWS = 1536;                // 48 KB of LDS: 3 workgroups per CU
+constexpr int WPQ_QUERIES_PER_WAVE = 4;
+constexpr int WPQ_QUERIES_PER_BLOCK = 4 * WPQ_QUERIES_PER_WAVE;
+
+__device__ __forceinline__ uint32_t wpq_slot(uint32_t row, uint32_t half)
+{
+    return ((2u * row + half) ^ ((row >> 3) & 1u));  // index of a 16-byte slot
+}
+
+__global__ void __launch_bounds__(256)
+k_scan_wave_per_query(const ScanDesc* __restrict__ scans, const BlockDesc* __restrict__ blocks,
+                      int32_t* __restrict__ zero, int nzero)
+{
+    __shared__ __attribute__((aligned(16))) uint4 tile[WPQ_TILE_ROWS * 2];
+
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+
+    const BlockDesc bd = blocks[blockIdx.x];
+    const ScanDesc sc = scans[bd.item];
+    const int nq = sc.nq, nt = sc.nt;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int q0 = bd.row0 + WPQ_QUERIES_PER_WAVE * wave;
+
+    // this wave's 4 queries, wave-uniform -> SGPRs
+    sptr_t qp = (sptr_t)(uintptr_t)sc.q;
+    uint32_t q[WPQ_QUERIES_PER_WAVE][8];
+#pragma unroll
+    for (int k = 0; k < WPQ_QUERIES_PER_WAVE; ++k) {
+        const int qi = q0 + k < nq ? q0 + k : nq - 1;
+        sptr_t p = qp + (size_t)qi * 8;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[k][i] = p[i];
+    }
+    uint32_t b[WPQ_QUERIES_PER_WAVE][2];
+#pragma unroll
+    for (int k = 0; k < WPQ_QUERIES_PER_WAVE; ++k) b[k][0] = b[k][1] = KEY_NONE;
+
+    const uint4* tg = reinterpret_cast<const uint4*>(sc.t);
+    for (int t0 = 0; t0 < nt; t0 += WPQ_TILE_ROWS) {
+        const int rows = nt - t0 < WPQ_TILE_ROWS ? nt - t0 : WPQ_TILE_ROWS;
+        if (t0) __syncthreads();                       // previous tile fully consumed
+        for (int c = threadIdx.x; c < 2 * rows; c += 256)   // 16-byte chunks, coalesced
+            tile[wpq_slot((uint32_t)c >> 1, (uint32_t)c & 1u)] = tg[(size_t)2 * t0 + c];
+        __syncthreads();
+        for (int r = lane; r < rows; r += 64) {
+            const uint4 ta = tile[wpq_slot((uint32_t)r, 0)], tb = tile[wpq_slot((uint32_t)r, 1)];
+            const uint32_t t[8] = {ta.x, ta.y, ta.z, ta.w, tb.x, tb.y, tb.z, tb.w};
+            const uint32_t j = (uint32_t)(t0 + r);
+#pragma unroll
+            for (int k = 0; k < WPQ_QUERIES_PER_WAVE; ++k) {
+                const uint32_t d = PLSLAM_DIST8(t, q[k]);
+                best2_push(b[k][0], b[k][1], (d << KEY_IDX_BITS) | j);
+            }
+        }
+    }
+    // wave-level best-2 reduce (keys are unique per lane: distinct train indices)
+#pragma unroll
+    for (int k = 0; k < WPQ_QUERIES_PER_WAVE; ++k) {
+        uint32_t k0 = b[k][0], k1 = b[k][1];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1)
+            best2_merge(k0, k1, (uint32_t)__shfl_xor((int)k0, m), (uint32_t)__shfl_xor((int)k1, m));
+        if (lane == 0 && q0 + k < nq) reinterpret_cast<uint2*>(sc.keys)[q0 + k] = make_uint2(k0, k1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K1b  symmetric scan for mutual problems: ONE distance d(i,j) serves both directions.
 //
 // A wave owns 64 rows of `a` (one per lane, 8 VGPRs) and streams every row of `b` (SGPRs).
@@ -302,6 +379,138 @@ k_scan_symmetric(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__
     if (row < n1) reinterpret_cast<uint2*>(sd.keys12)[row] = make_uint2(rb0, rb1);
 }
 
+// ---------------------------------------------------------------------------------------------
+// K1b'  symmetric scan, FOUR rows of `a` per lane (option sym_rows = 4; not the default).  Any VALU op with an SGPR source
+// issues at the slow rate on gfx950 (4.1 vs 2.4 cycles, profiles/r1_valu_microbench.txt), and the
+// train row lives in SGPRs.  With rows q0..q3 in one lane,  q_r ^ t = (q0 ^ t) ^ (q0 ^ q_r):  only
+// the first XOR touches the SGPRs, the other three use a per-lane constant c_r = q0 ^ q_r and run
+// at the fast VGPR-only rate.  A wave (= a 64-thread workgroup, no barriers) owns 256 rows of `a`:
+// lane l holds rows i0 + 64 r + l.  The transposed LDS tile keeps its 9216 bytes: 16 rows of `b`
+// x 4 row-blocks x 144 B.  In column mode lane l reduces row-block (l >> 4) of column (l & 15)
+// with the packed 16-bit keys, the four row-blocks are combined across lanes, and ONE partial per
+// 256 rows of `a` is written (4x fewer partials than K1b).
+// MEASURED (profiles/r1_valu_microbench.txt, "alt xor(v,v)/bcnt"): a fast op alternating with a slow
+// one issues at the slow rate, so the compiler-interleaved stream gains nothing over K1b (341k vs
+// 343k pairs/s at 2048 pairs/step) and the 4x coarser work units lose to tail quantisation at 512
+// pairs/step.  Kept selectable for the 4x smaller partial table.
+// ---------------------------------------------------------------------------------------------
+constexpr int SYM4_SUBTILE_U16 = 16 * SYM_TILE_ROW_U16;      // 16 b-rows x 144 B = 2304 B per row-block
+
+__global__ void __launch_bounds__(64)
+k_scan_symmetric_r4(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
+                    int32_t* __restrict__ zero, int nzero)
+{
+    __shared__ __attribute__((aligned(16))) uint16_t tile[4 * SYM4_SUBTILE_U16];
+
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nzero; i += 64) zero[i] = 0;
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const BlockDesc bd = blocks[wg];
+    const SymDesc sd = syms[bd.item];
+    const int n1 = sd.n1, n2 = sd.n2;
+    const int lane = threadIdx.x;
+    const int i0 = bd.row0;                        // first of this wave's 256 a-rows
+    const int iblk = i0 >> 8;
+
+    uint32_t q0[8], c1[8], c2[8], c3[8];
+    uint32_t bias[4];
+    {
+        uint32_t qr[4][8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = i0 + 64 * r + lane;
+            bias[r] = row < n1 ? 0u : SYM_INVALID_BIAS;
+            const int rrow = row < n1 ? row : n1 - 1;
+            const u32x4* qp = reinterpret_cast<const u32x4*>(sd.a + (size_t)rrow * 32);
+            const u32x4 a = qp[0], b = qp[1];
+            qr[r][0] = a.x; qr[r][1] = a.y; qr[r][2] = a.z; qr[r][3] = a.w;
+            qr[r][4] = b.x; qr[r][5] = b.y; qr[r][6] = b.z; qr[r][7] = b.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            q0[k] = qr[0][k];
+            c1[k] = qr[0][k] ^ qr[1][k];
+            c2[k] = qr[0][k] ^ qr[2][k];
+            c3[k] = qr[0][k] ^ qr[3][k];
+        }
+    }
+    uint16_t* wr = tile + lane;                                          // tile[r][jj][lane]
+    const uint16_t* col = tile + (lane >> 4) * SYM4_SUBTILE_U16 + (lane & 15) * SYM_TILE_ROW_U16;
+    const uint32_t col_i_base = (uint32_t)(i0 + 64 * (lane >> 4));
+    uint2* part = reinterpret_cast<uint2*>(sd.part21) + (size_t)iblk * n2;
+    sptr_t tp = (sptr_t)(uintptr_t)sd.b;
+
+    uint32_t rb[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rb[r][0] = rb[r][1] = KEY_NONE;
+
+#define PLSLAM_SYM4_ROW(T, JJ)                                                                    \
+    {                                                                                             \
+        uint32_t x[8];                                                                            \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) x[k] = q0[k] ^ (T)[k];                      \
+        const uint32_t e0 = bcnt_acc(x[7], bcnt_acc(x[6], bcnt_acc(x[5], bcnt_acc(x[4],           \
+                            bcnt_acc(x[3], bcnt_acc(x[2], bcnt_acc(x[1], bcnt_acc(x[0], bias[0]))))))));  \
+        const uint32_t e1 = bcnt_acc(x[7] ^ c1[7], bcnt_acc(x[6] ^ c1[6], bcnt_acc(x[5] ^ c1[5],  \
+                            bcnt_acc(x[4] ^ c1[4], bcnt_acc(x[3] ^ c1[3], bcnt_acc(x[2] ^ c1[2],  \
+                            bcnt_acc(x[1] ^ c1[1], bcnt_acc(x[0] ^ c1[0], bias[1]))))))));        \
+        const uint32_t e2 = bcnt_acc(x[7] ^ c2[7], bcnt_acc(x[6] ^ c2[6], bcnt_acc(x[5] ^ c2[5],  \
+                            bcnt_acc(x[4] ^ c2[4], bcnt_acc(x[3] ^ c2[3], bcnt_acc(x[2] ^ c2[2],  \
+                            bcnt_acc(x[1] ^ c2[1], bcnt_acc(x[0] ^ c2[0], bias[2]))))))));        \
+        const uint32_t e3 = bcnt_acc(x[7] ^ c3[7], bcnt_acc(x[6] ^ c3[6], bcnt_acc(x[5] ^ c3[5],  \
+                            bcnt_acc(x[4] ^ c3[4], bcnt_acc(x[3] ^ c3[3], bcnt_acc(x[2] ^ c3[2],  \
+                            bcnt_acc(x[1] ^ c3[1], bcnt_acc(x[0] ^ c3[0], bias[3]))))))));        \
+        wr[0 * SYM4_SUBTILE_U16 + (JJ) * SYM_TILE_ROW_U16] = (uint16_t)e0;                        \
+        wr[1 * SYM4_SUBTILE_U16 + (JJ) * SYM_TILE_ROW_U16] = (uint16_t)e1;                        \
+        wr[2 * SYM4_SUBTILE_U16 + (JJ) * SYM_TILE_ROW_U16] = (uint16_t)e2;                        \
+        wr[3 * SYM4_SUBTILE_U16 + (JJ) * SYM_TILE_ROW_U16] = (uint16_t)e3;                        \
+        const uint32_t jkey = (uint32_t)(j0 + (JJ));                                              \
+        best2_push(rb[0][0], rb[0][1], make_key_s(e0, jkey));                                     \
+        best2_push(rb[1][0], rb[1][1], make_key_s(e1, jkey));                                     \
+        best2_push(rb[2][0], rb[2][1], make_key_s(e2, jkey));                                     \
+        best2_push(rb[3][0], rb[3][1], make_key_s(e3, jkey));                                     \
+    }
+
+    for (int j0 = 0; j0 < n2; j0 += 16) {
+        const int jc = n2 - j0 < 16 ? n2 - j0 : 16;
+        // ---- row mode --------------------------------------------------------------------------
+        int jj = 0;
+        for (; jj + 4 <= jc; jj += 4) {
+            sptr_t t = tp + (size_t)(j0 + jj) * 8;
+            PLSLAM_SYM4_ROW(t, jj + 0)
+            PLSLAM_SYM4_ROW(t + 8, jj + 1)
+            PLSLAM_SYM4_ROW(t + 16, jj + 2)
+            PLSLAM_SYM4_ROW(t + 24, jj + 3)
+        }
+        for (; jj < jc; ++jj) {
+            sptr_t t = tp + (size_t)(j0 + jj) * 8;
+            PLSLAM_SYM4_ROW(t, jj)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- column mode: lane = (column j0 + (lane & 15), row-block lane >> 4) -----------------
+        uint32_t c0p, c1p;
+        sym_column_reduce(col, c0p, c1p);
+        const uint32_t ev0 = c0p & 0xFFFFu, od0 = c0p >> 16, ev1 = c1p & 0xFFFFu, od1 = c1p >> 16;
+        uint32_t k0 = key16_to_32(umin(ev0, od0), col_i_base);
+        uint32_t k1 = key16_to_32(umin(umax(ev0, od0), umin(ev1, od1)), col_i_base);
+        // combine the four row-blocks of a column: lanes l, l^16, l^32, l^48
+        best2_merge(k0, k1, (uint32_t)__shfl_xor((int)k0, 16), (uint32_t)__shfl_xor((int)k1, 16));
+        best2_merge(k0, k1, (uint32_t)__shfl_xor((int)k0, 32), (uint32_t)__shfl_xor((int)k1, 32));
+        if (lane < jc) part[j0 + lane] = make_uint2(k0, k1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#undef PLSLAM_SYM4_ROW
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = i0 + 64 * r + lane;
+        if (row < n1) reinterpret_cast<uint2*>(sd.keys12)[row] = make_uint2(rb[r][0], rb[r][1]);
+    }
+}
+
 // K1c  merge the per-block column partials of K1b: keys21[j] = best-2 over iblk of part21[iblk][j]
 __global__ void __launch_bounds__(256)
 k_merge_partials(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks)
@@ -378,8 +587,7 @@ k_unpack_keys(const uint32_t* __restrict__ keys, int32_t n, int32_t* __restrict_
 // ---------------------------------------------------------------------------------------------
 int scan_rows_per_block(int variant, int block_threads)
 {
-    (void)variant;
-    return block_threads;
+    return variant == PLSLAM_SCAN_WAVE_PER_QUERY ? WPQ_QUERIES_PER_BLOCK : block_threads;
 }
 
 int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const ScanDesc* d_scans,
@@ -388,6 +596,12 @@ int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const Sca
     (void)ctx;
     if (nblocks <= 0) {
         if (nzero > 0) PLSLAM_HIP_CHECK(hipMemsetAsync(d_zero, 0, sizeof(int32_t) * nzero, s));
+        return PLSLAM_OK;
+    }
+    if (variant == PLSLAM_SCAN_WAVE_PER_QUERY) {
+        hipLaunchKernelGGL(k_scan_wave_per_query, dim3(nblocks), dim3(256), 0, s, d_scans, d_blocks, d_zero,
+                           nzero);
+        PLSLAM_HIP_CHECK(hipGetLastError());
         return PLSLAM_OK;
     }
     PLSLAM_REQUIRE(variant == PLSLAM_SCAN_LANE_PER_QUERY, PLSLAM_EINVAL);
@@ -411,11 +625,17 @@ int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const Sca
     return PLSLAM_OK;
 }
 
-int launch_scan_sym(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
-                    int nzero, hipStream_t s)
+int sym_rows_per_block(int rows_per_lane) { return 256; (void)rows_per_lane; }
+int sym_rows_per_partial(int rows_per_lane) { return rows_per_lane == 4 ? 256 : 64; }
+
+int launch_scan_sym(int rows_per_lane, const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks,
+                    int32_t* d_zero, int nzero, hipStream_t s)
 {
     if (nblocks <= 0) return PLSLAM_OK;
-    hipLaunchKernelGGL(k_scan_symmetric, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
+    if (rows_per_lane == 4)
+        hipLaunchKernelGGL(k_scan_symmetric_r4, dim3(nblocks), dim3(64), 0, s, d_sym, d_blocks, d_zero, nzero);
+    else
+        hipLaunchKernelGGL(k_scan_symmetric, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

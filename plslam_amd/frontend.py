@@ -96,12 +96,12 @@ class StereoBatchMatcher:
         self.plan.close()
 
 
-def gather_tables(local, world: int, rank: int, root: int = 0, group=None):
+def gather_tables(local, world: int, rank: int, root: int = 0, group=None, force: bool = False):
     """Gather fixed-stride per-pair match tables to `root` (torch.distributed: backend 'nccl' is
     RCCL over xGMI on MI355X, 'gloo' on CPU).  Returns the (world*B, stride) tensor on root."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:
         return local
     bufs = [torch.empty_like(local) for _ in range(world)] if rank == root else None
     dist.gather(local, gather_list=bufs, dst=root, group=group)

@@ -41,7 +41,8 @@ def test_golden_vectors(ctx):
 
 @pytest.mark.parametrize("nq,nt", [(0, 5), (5, 0), (3, 1), (3, 2), (1, 1), (64, 64), (65, 129), (255, 3),
                                    (256, 256), (257, 511), (1000, 4), (7, 1025)])
-def test_knn2_and_match_edge_sizes(ctx, oracle, nq, nt):
+def test_knn2_and_match_edge_sizes(vctx, oracle, nq, nt):
+    ctx = vctx
     r = _rng(nq * 4099 + nt)
     q, t = synth.random_desc(r, nq), synth.random_desc(r, nt)
     idx, dist = ctx.knn2(q, t)
@@ -68,7 +69,8 @@ def test_tie_stress_bit_exact(ctx, oracle, seed):
 
 
 @pytest.mark.parametrize("n1,n2", [(1, 2), (2, 1), (63, 65), (64, 64), (65, 63), (129, 1), (200, 200), (1500, 1500),
-                                   (333, 1027), (1027, 333), (2, 2), (70, 3)])
+                                   (333, 1027), (1027, 333), (2, 2), (70, 3), (255, 17), (256, 16), (257, 15), (513, 31),
+                                   (1, 1), (300, 5), (40, 1537), (1600, 3100), (17, 4000)])
 def test_symmetric_and_directed_variants_agree(ctx, oracle, n1, n2):
     """Mutual problems default to the symmetric scan (one distance feeds both directions); forcing
     the directed lane-per-query scan must give the same tables, and both must equal the oracle."""
@@ -81,12 +83,16 @@ def test_symmetric_and_directed_variants_agree(ctx, oracle, n1, n2):
             d2[:k] = d1[:k] ^ np.packbits(r.random((k, 256)) < 0.06, axis=1)
         em, en = oracle.match(d1, d2, 0.9, True)
         try:
-            for variant in (plslam_amd.SCAN_SYMMETRIC, plslam_amd.SCAN_LANE_PER_QUERY, plslam_amd.SCAN_AUTO):
+            for variant, sym_rows in ((plslam_amd.SCAN_SYMMETRIC, 4), (plslam_amd.SCAN_SYMMETRIC, 1),
+                                      (plslam_amd.SCAN_LANE_PER_QUERY, 1), (plslam_amd.SCAN_WAVE_PER_QUERY, 1),
+                                      (plslam_amd.SCAN_AUTO, 1)):
                 ctx.set_option("scan_variant", variant)
+                ctx.set_option("sym_rows", sym_rows)
                 m, n = ctx.match(d1, d2, 0.9, True)
-                assert np.array_equal(m, em) and n == en, (variant, gen.__name__)
+                assert np.array_equal(m, em) and n == en, (variant, sym_rows, gen.__name__)
         finally:
             ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+            ctx.set_option("sym_rows", 1)
 
 
 def test_all_scan_block_sizes(ctx, oracle):
@@ -106,8 +112,21 @@ def test_all_scan_block_sizes(ctx, oracle):
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
 
 
-def test_c2_full_size_pair_bit_exact(ctx, oracle):
+@pytest.fixture(params=["auto", "lane_per_query", "wave_per_query", "symmetric"])
+def vctx(ctx, request):
+    """The context with each scan variant forced in turn (AUTO picks wave-per-query for plans too
+    small to fill the chip, the symmetric scan for mutual problems otherwise)."""
+    import plslam_amd
+    v = {"auto": plslam_amd.SCAN_AUTO, "lane_per_query": plslam_amd.SCAN_LANE_PER_QUERY,
+         "wave_per_query": plslam_amd.SCAN_WAVE_PER_QUERY, "symmetric": plslam_amd.SCAN_SYMMETRIC}[request.param]
+    ctx.set_option("scan_variant", v)
+    yield ctx
+    ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+
+
+def test_c2_full_size_pair_bit_exact(vctx, oracle):
     """BASELINE config 2: 1500 ORB + 200 LBD, L<->R and prev<->curr, mutual + ratio."""
+    ctx = vctx
     s = synth.stereo_stream(2, 1500, 200, seed=synth.SEED0)
     for i in range(2):
         for name, d1, d2 in frontend.pair_problems(s["orb_l"], s["orb_r"], s["lbd_l"], s["lbd_r"], i):
@@ -119,8 +138,9 @@ def test_c2_full_size_pair_bit_exact(ctx, oracle):
                 assert n > 0.4 * len(m)         # the planted true matches are found
 
 
-def test_c3_map_to_frame_sizes_bit_exact(ctx, oracle):
+def test_c3_map_to_frame_sizes_bit_exact(vctx, oracle):
     """BASELINE config 3 matching half: 10k map points x 1500 frame rows, 2k lines x 200."""
+    ctx = vctx
     r = _rng(31)
     frame_p = synth.random_desc(r, 1500)
     map_p = np.concatenate([synth.noisy_copy(r, frame_p)[0], synth.random_desc(r, 8500)])
@@ -157,7 +177,8 @@ def test_c5_dense_size_properties(ctx, oracle):
     assert np.array_equal(m12, em) and n12 == en
 
 
-def test_batched_ragged_problems(ctx, oracle):
+def test_batched_ragged_problems(vctx, oracle):
+    ctx = vctx
     r = _rng(9)
     sizes1 = [30, 0, 17, 64, 300, 1, 2, 513]
     sizes2 = [25, 10, 0, 70, 299, 5, 1, 255]
@@ -183,14 +204,19 @@ def test_error_codes(ctx):
         ctx.match_batched(np.zeros((5, 32), np.uint8), off, np.zeros((5, 32), np.uint8), off, 0.9, True)
 
 
-def test_device_resident_plan_matches_oracle(ctx, oracle):
+def test_device_resident_plan_matches_oracle(vctx, oracle):
     """The throughput path: StereoBatchMatcher (device-resident, one plan, torch's stream)."""
     import torch
+    import plslam_amd
+    ctx = vctx
     s = synth.stereo_stream(3, 320, 70, seed=5)
     bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.75, nnr_l=0.9, mutual=True)
     info = bm.plan.info()
     assert info["n_scans"] == 3 * 8 and info["directed_evals"] == 3 * 4 * (320 * 320 + 70 * 70)
-    assert info["distance_evals"] == info["directed_evals"] // 2     # symmetric scan: half the distances
+    if info["scan_variant"] == plslam_amd.SCAN_SYMMETRIC:
+        assert info["distance_evals"] == info["directed_evals"] // 2   # half the distances
+    else:
+        assert info["distance_evals"] == info["directed_evals"]
     for _ in range(2):                        # re-running a plan is idempotent
         tab = bm.run()
         torch.cuda.synchronize()

@@ -222,6 +222,57 @@ __global__ void __launch_bounds__(256) k_mix_sym_lds(uint32_t* out, uint32_t s, 
     out[blockIdx.x * 256 + threadIdx.x] = b0 ^ b1;
 }
 
+// how do fast (xor v,v) and slow (bcnt) ops mix?  alternating vs blocked, 8 independent chains
+#define I_XB_ALT(r)   "v_xor_b32 " #r ", %8, " #r "\n v_bcnt_u32_b32 " #r ", %10, " #r "\n"
+__global__ void __launch_bounds__(256) k_alt_xor_bcnt(uint32_t* out, uint32_t s, int iters)
+{
+    uint32_t a0 = threadIdx.x, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19;
+    uint32_t b = a0 ^ 0x5a5a5a5a, c = a0 * 977 + 1;
+    for (int i = 0; i < iters; ++i) { REP8(BODY(I_XB_ALT)) }
+    out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+// xor into a temp then bcnt of the temp accumulating into the chain (the real dependency shape)
+__global__ void __launch_bounds__(256) k_dep_xor_bcnt(uint32_t* out, uint32_t s, int iters)
+{
+    uint32_t q0 = threadIdx.x, q1 = q0 * 3, q2 = q0 * 5, q3 = q0 * 7, q4 = q0 * 11, q5 = q0 * 13, q6 = q0 * 17, q7 = q0 * 19;
+    uint32_t t = q0 ^ 0x5a5a5a5a, acc = 0;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            uint32_t x0, x1, x2, x3, x4, x5, x6, x7;
+            asm volatile(
+                "v_xor_b32 %0, %17, %9\n v_xor_b32 %1, %17, %10\n v_xor_b32 %2, %17, %11\n v_xor_b32 %3, %17, %12\n"
+                "v_xor_b32 %4, %17, %13\n v_xor_b32 %5, %17, %14\n v_xor_b32 %6, %17, %15\n v_xor_b32 %7, %17, %16\n"
+                "v_bcnt_u32_b32 %8, %0, %8\n v_bcnt_u32_b32 %8, %1, %8\n v_bcnt_u32_b32 %8, %2, %8\n v_bcnt_u32_b32 %8, %3, %8\n"
+                "v_bcnt_u32_b32 %8, %4, %8\n v_bcnt_u32_b32 %8, %5, %8\n v_bcnt_u32_b32 %8, %6, %8\n v_bcnt_u32_b32 %8, %7, %8\n"
+                : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7), "+v"(acc)
+                : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7), "v"(t));
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+// same with 4 independent accumulators interleaved (xor block of 8, then 8 bcnt on 4 chains)
+__global__ void __launch_bounds__(256) k_dep4_xor_bcnt(uint32_t* out, uint32_t s, int iters)
+{
+    uint32_t q0 = threadIdx.x, q1 = q0 * 3, q2 = q0 * 5, q3 = q0 * 7, q4 = q0 * 11, q5 = q0 * 13, q6 = q0 * 17, q7 = q0 * 19;
+    uint32_t t = q0 ^ 0x5a5a5a5a, acc0 = 0, acc1 = 1, acc2 = 2, acc3 = 3;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            uint32_t x0, x1, x2, x3, x4, x5, x6, x7;
+            asm volatile(
+                "v_xor_b32 %0, %20, %12\n v_xor_b32 %1, %20, %13\n v_xor_b32 %2, %20, %14\n v_xor_b32 %3, %20, %15\n"
+                "v_xor_b32 %4, %20, %16\n v_xor_b32 %5, %20, %17\n v_xor_b32 %6, %20, %18\n v_xor_b32 %7, %20, %19\n"
+                "v_bcnt_u32_b32 %8, %0, %8\n v_bcnt_u32_b32 %9, %1, %9\n v_bcnt_u32_b32 %10, %2, %10\n v_bcnt_u32_b32 %11, %3, %11\n"
+                "v_bcnt_u32_b32 %8, %4, %8\n v_bcnt_u32_b32 %9, %5, %9\n v_bcnt_u32_b32 %10, %6, %10\n v_bcnt_u32_b32 %11, %7, %11\n"
+                : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3), "=&v"(x4), "=&v"(x5), "=&v"(x6), "=&v"(x7),
+                  "+v"(acc0), "+v"(acc1), "+v"(acc2), "+v"(acc3)
+                : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(q4), "v"(q5), "v"(q6), "v"(q7), "v"(t));
+        }
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = acc0 ^ acc1 ^ acc2 ^ acc3;
+}
+
 typedef void (*kern_t)(uint32_t*, uint32_t, int);
 struct Entry { const char* name; kern_t k; double ops_per_iter; };
 
@@ -233,14 +284,19 @@ int main(int argc, char** argv)
     const int cus = prop.multiProcessorCount;
     const double clk = prop.clockRate * 1e3;
     printf("device %s %s CUs=%d maxclk=%.0f MHz\n", prop.name, prop.gcnArchName, cus, clk / 1e6);
-    const int blocks = cus * 8;  // 8 waves per SIMD
+    const int wps = argc > 2 ? atoi(argv[2]) : 8;
+    const int blocks = cus * wps;  // wps waves per SIMD (256-thread blocks, one wave per SIMD each)
+    printf("waves per SIMD: %d\n", wps);
     uint32_t* out;
     CHECK(hipMalloc(&out, sizeof(uint32_t) * blocks * 256));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
 #define E(NAME) {#NAME, k_##NAME, 64.0}
-    Entry es[] = {E(xor_e64_sgpr), E(bitop3_sgpr_src12), E(bitop3_sgpr_src0), E(add_u32_sgpr), E(mov_from_sgpr),
+    Entry es[] = {{"alt xor(v,v)/bcnt, 8 indep chains", k_alt_xor_bcnt, 128.0},
+                  {"8 xor(v,v) then 8 bcnt on ONE chain", k_dep_xor_bcnt, 128.0},
+                  {"8 xor(v,v) then 8 bcnt on FOUR chains", k_dep4_xor_bcnt, 128.0},
+                  E(xor_e64_sgpr), E(bitop3_sgpr_src12), E(bitop3_sgpr_src0), E(add_u32_sgpr), E(mov_from_sgpr),
                   E(xnor_sgpr), E(and_sgpr), E(xor_literal), E(xor_inline_const),
                   {"mix_sym_sgpr (19 valu + ds_write_b16)", k_mix_sym_sgpr, 76.0},
                   {"mix_sym_lds (2 ds_read_b128 bcast + 19 valu + ds_write_b16)", k_mix_sym_lds, 76.0},
