@@ -273,6 +273,28 @@ __global__ void __launch_bounds__(256) k_dep4_xor_bcnt(uint32_t* out, uint32_t s
     out[blockIdx.x * 256 + threadIdx.x] = acc0 ^ acc1 ^ acc2 ^ acc3;
 }
 
+// runs of N independent fast xors followed by N slow bcnts (8 rotating chains): does run length matter?
+template <int N>
+__global__ void __launch_bounds__(256) k_runs(uint32_t* out, uint32_t s, int iters)
+{
+    uint32_t a[8], c[8];
+    for (int k = 0; k < 8; ++k) { a[k] = threadIdx.x * (2 * k + 3); c[k] = k; }
+    const uint32_t b = threadIdx.x ^ 0x5a5a5a5a;
+    const int reps = 64 / N;   // 64 fast + 64 slow per iteration in total
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int r = 0; r < reps; ++r) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a[k & 7]) : "v"(b));
+#pragma unroll
+            for (int k = 0; k < N; ++k) asm volatile("v_bcnt_u32_b32 %0, %1, %0" : "+v"(c[k & 7]) : "v"(a[k & 7]));
+        }
+    }
+    uint32_t o = 0;
+    for (int k = 0; k < 8; ++k) o ^= a[k] ^ c[k];
+    out[blockIdx.x * 256 + threadIdx.x] = o;
+}
+
 typedef void (*kern_t)(uint32_t*, uint32_t, int);
 struct Entry { const char* name; kern_t k; double ops_per_iter; };
 
@@ -293,7 +315,11 @@ int main(int argc, char** argv)
     CHECK(hipEventCreate(&e0));
     CHECK(hipEventCreate(&e1));
 #define E(NAME) {#NAME, k_##NAME, 64.0}
-    Entry es[] = {{"alt xor(v,v)/bcnt, 8 indep chains", k_alt_xor_bcnt, 128.0},
+    Entry es[] = {{"runs: 1 fast / 1 slow", k_runs<1>, 128.0}, {"runs: 2 fast / 2 slow", k_runs<2>, 128.0},
+                  {"runs: 4 fast / 4 slow", k_runs<4>, 128.0}, {"runs: 8 fast / 8 slow", k_runs<8>, 128.0},
+                  {"runs: 16 fast / 16 slow", k_runs<16>, 128.0}, {"runs: 32 fast / 32 slow", k_runs<32>, 128.0},
+                  {"runs: 64 fast / 64 slow", k_runs<64>, 128.0},
+                  {"alt xor(v,v)/bcnt, 8 indep chains", k_alt_xor_bcnt, 128.0},
                   {"8 xor(v,v) then 8 bcnt on ONE chain", k_dep_xor_bcnt, 128.0},
                   {"8 xor(v,v) then 8 bcnt on FOUR chains", k_dep4_xor_bcnt, 128.0},
                   E(xor_e64_sgpr), E(bitop3_sgpr_src12), E(bitop3_sgpr_src0), E(add_u32_sgpr), E(mov_from_sgpr),
