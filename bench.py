@@ -90,6 +90,12 @@ def main():
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE JSON line; libraries (e.g. RCCL's version banner, flushed at
+    # exit) also write to fd 1.  Keep the real stdout aside and point fd 1 at stderr meanwhile.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     T0 = time.perf_counter()
 
     def note(msg):                                      # progress on stderr (stdout carries the JSON)
@@ -130,17 +136,25 @@ def main():
         ctx.set_option("scan_block", args.scan_block)
     if args.sym_rows:
         ctx.set_option("sym_rows", args.sym_rows)
-    bm = frontend.StereoBatchMatcher(ctx, stream, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev)
+    bm = frontend.StereoBatchMatcher(ctx, stream, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev,
+                                     n_buffers=2 if use_dist else 1)
     info = bm.plan.info()
     devinfo = ctx.device_info()
+    # N > 1: the table of step k is gathered to rank 0 over RCCL on a communication stream while
+    # step k+1 computes into the other table buffer (steps are independent batches of a stream).
+    pg = frontend.PipelinedGather(bm, world, rank, root=0) if use_dist else None
+    step_no = [0]
 
     def step():
-        tab = bm.run()
-        if use_dist:
-            return frontend.gather_tables(tab, world, rank, root=0, force=True)
-        return tab
+        if pg is not None:
+            pg.step(step_no[0])
+            step_no[0] += 1
+        else:
+            bm.run()
 
     def sync():
+        if pg is not None:
+            pg.finish()
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
@@ -151,15 +165,20 @@ def main():
         step()
     sync()
     note("warmup done")
-    bm.plan.set_profiling(True)
-    bm.plan.elapsed()                         # reset the accumulators
+    for p_ in bm.plans:
+        p_.set_profiling(True)
+        p_.elapsed()                          # reset the accumulators
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
-    scan_ms, fin_ms, runs = bm.plan.elapsed()
-    bm.plan.set_profiling(False)
+    scan_ms = fin_ms = 0.0
+    runs = 0
+    for p_ in bm.plans:
+        a_, b_, n_ = p_.elapsed()
+        scan_ms, fin_ms, runs = scan_ms + a_, fin_ms + b_, runs + n_
+        p_.set_profiling(False)
     note(f"timed {args.steps} steps in {elapsed:.4f}s; scan {scan_ms / max(runs, 1):.3f} ms/launch")
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -167,16 +186,24 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # self-check of the timed output against the oracle on one pair (the checker, not the product)
+    # self-check of the timed output against the oracle (the checker, not the product): pair 0 of
+    # EVERY rank's table as it arrived on rank 0 (N > 1: through the RCCL gather, both buffers)
     if rank == 0:
         from oracle import oracle as O
-        tab = bm.table[0].cpu().numpy()
         sl = frontend.table_slices(args.n_orb, args.n_lbd)
-        for name, d1, d2 in frontend.pair_problems(stream["orb_l"], stream["orb_r"], stream["lbd_l"],
-                                                   stream["lbd_r"], 0):
-            em, _ = O.match(d1, d2, args.nnr_p if name.startswith("orb") else args.nnr_l, True)
-            if not np.array_equal(tab[sl[name]], em):
-                raise SystemExit(f"bench output differs from the oracle on pair 0 / {name}")
+        bufs = range(len(bm.tables)) if pg is not None and args.steps + args.warmup >= 2 else [0]
+        for b_ in bufs:
+            full = (pg.gathered(b_) if pg is not None else bm.tables[b_]).cpu().numpy()
+            for r_ in range(world if pg is not None else 1):
+                st_r = stream if r_ == 0 else synth.stereo_stream(1, args.n_orb, args.n_lbd, seed=synth.SEED0,
+                                                                  first_pair=r_ * B)
+                tab = full[r_ * B]
+                for name, d1, d2 in frontend.pair_problems(st_r["orb_l"], st_r["orb_r"], st_r["lbd_l"],
+                                                           st_r["lbd_r"], 0):
+                    em, _ = O.match(d1, d2, args.nnr_p if name.startswith("orb") else args.nnr_l, True)
+                    if not np.array_equal(tab[sl[name]], em):
+                        raise SystemExit(f"bench output differs from the oracle: rank {r_} buffer {b_} pair 0 / {name}")
+        note(f"output verified against the oracle for {world if pg is not None else 1} rank(s)")
 
     if rank == 0:
         pairs_total = B * world * args.steps
@@ -213,8 +240,8 @@ def main():
                             "ORB+LBD L<->R and prev<->curr, mutual + ratio (StVO::match), device-resident",
                 "pairs_per_gpu_per_step": B, "nnr_p": args.nnr_p, "nnr_l": args.nnr_l, "mutual": True,
                 "scan_variant": info["scan_variant"], "scan_block_threads": info["scan_block_threads"],
-                "parallelism": f"pairs sharded over {world} rank(s); table gather to rank 0" if world > 1
-                               else "single GPU",
+                "parallelism": f"pairs sharded over {world} rank(s); per-step RCCL gather of the match tables "
+                               "to rank 0, overlapped with the next step" if use_dist else "single GPU",
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -239,7 +266,7 @@ def main():
             note("cpu baseline ...")
             out["cpu_baseline"] = cpu_baseline(stream, args.n_orb, args.n_lbd, args.nnr_p, args.nnr_l,
                                                args.cpu_budget_s)
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
     bm.close()
     ctx.close()

@@ -45,9 +45,12 @@ def pair_problems(orb_l, orb_r, lbd_l, lbd_r, i):
 
 
 class StereoBatchMatcher:
-    """Device-resident batch of `B` stereo pairs -> (B, stride) int32 match table."""
+    """Device-resident batch of `B` stereo pairs -> (B, stride) int32 match table.
 
-    def __init__(self, ctx, stream_np: dict, nnr_p=0.75, nnr_l=0.75, mutual=True, device=None):
+    `n_buffers` output tables (and plans) over the same descriptors let step k+1 compute while the
+    table of step k is still being gathered (bench.py, N > 1)."""
+
+    def __init__(self, ctx, stream_np: dict, nnr_p=0.75, nnr_l=0.75, mutual=True, device=None, n_buffers=1):
         import torch
         self.torch = torch
         self.ctx = ctx
@@ -58,42 +61,97 @@ class StereoBatchMatcher:
         self.n_lbd = stream_np["lbd_l"].shape[1]
         self.stride = table_stride(self.n_orb, self.n_lbd)
         self.d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in stream_np.items()}
-        self.table = torch.full((self.B, self.stride), -2, dtype=torch.int32, device=dev)
-        self.counts = torch.zeros((self.B, 4), dtype=torch.int32, device=dev)
         sl = table_slices(self.n_orb, self.n_lbd)
-        probs = []
-        tb, cb = self.table.data_ptr(), self.counts.data_ptr()
         row_o, row_l = self.n_orb * 32, self.n_lbd * 32
         ol, orr = self.d["orb_l"].data_ptr(), self.d["orb_r"].data_ptr()
         ll, lr = self.d["lbd_l"].data_ptr(), self.d["lbd_r"].data_ptr()
-        for i in range(self.B):
-            t_i = tb + 4 * self.stride * i
-            c_i = cb + 16 * i
-            probs.append((ol + row_o * (i + 1), self.n_orb, orr + row_o * (i + 1), self.n_orb, nnr_p, mutual,
-                          t_i + 4 * sl["orb_lr"].start, c_i))
-            probs.append((ol + row_o * i, self.n_orb, ol + row_o * (i + 1), self.n_orb, nnr_p, mutual,
-                          t_i + 4 * sl["orb_pc"].start, c_i + 4))
-            probs.append((ll + row_l * (i + 1), self.n_lbd, lr + row_l * (i + 1), self.n_lbd, nnr_l, mutual,
-                          t_i + 4 * sl["lbd_lr"].start, c_i + 8))
-            probs.append((ll + row_l * i, self.n_lbd, ll + row_l * (i + 1), self.n_lbd, nnr_l, mutual,
-                          t_i + 4 * sl["lbd_pc"].start, c_i + 12))
-        self.plan = ctx.plan(probs)
+        self.tables, self.count_bufs, self.plans = [], [], []
+        for _ in range(n_buffers):
+            table = torch.full((self.B, self.stride), -2, dtype=torch.int32, device=dev)
+            counts = torch.zeros((self.B, 4), dtype=torch.int32, device=dev)
+            tb, cb = table.data_ptr(), counts.data_ptr()
+            probs = []
+            for i in range(self.B):
+                t_i = tb + 4 * self.stride * i
+                c_i = cb + 16 * i
+                probs.append((ol + row_o * (i + 1), self.n_orb, orr + row_o * (i + 1), self.n_orb, nnr_p, mutual,
+                              t_i + 4 * sl["orb_lr"].start, c_i))
+                probs.append((ol + row_o * i, self.n_orb, ol + row_o * (i + 1), self.n_orb, nnr_p, mutual,
+                              t_i + 4 * sl["orb_pc"].start, c_i + 4))
+                probs.append((ll + row_l * (i + 1), self.n_lbd, lr + row_l * (i + 1), self.n_lbd, nnr_l, mutual,
+                              t_i + 4 * sl["lbd_lr"].start, c_i + 8))
+                probs.append((ll + row_l * i, self.n_lbd, ll + row_l * (i + 1), self.n_lbd, nnr_l, mutual,
+                              t_i + 4 * sl["lbd_pc"].start, c_i + 12))
+            self.tables.append(table)
+            self.count_bufs.append(counts)
+            self.plans.append(ctx.plan(probs))
+        self.table, self.counts, self.plan = self.tables[0], self.count_bufs[0], self.plans[0]
         # A real (non-NULL) HIP stream: the C ABI reads a NULL stream as "the context's own stream",
         # and torch's legacy default stream has handle 0.
         self.stream = torch.cuda.Stream(device=dev)
 
-    def run(self):
-        """Enqueue one pass over the batch.  The kernels run on this object's stream, fenced on both
-        sides against torch's current stream so that whatever the caller enqueues next (e.g. the
-        RCCL gather of the table) is ordered after them."""
+    def run(self, buf: int = 0):
+        """Enqueue one pass over the batch into table `buf`.  The kernels run on this object's stream,
+        fenced on both sides against torch's current stream so that whatever the caller enqueues next
+        is ordered after them."""
         cur = self.torch.cuda.current_stream(self.dev)
         self.stream.wait_stream(cur)
-        self.plan.run(self.stream.cuda_stream)
+        self.plans[buf].run(self.stream.cuda_stream)
         cur.wait_stream(self.stream)
-        return self.table
+        return self.tables[buf]
+
+    def run_async(self, buf: int = 0):
+        """Enqueue one pass on this object's stream only; returns an event recorded after it."""
+        self.plans[buf].run(self.stream.cuda_stream)
+        ev = self.torch.cuda.Event()
+        ev.record(self.stream)
+        return ev
 
     def close(self):
-        self.plan.close()
+        for p in self.plans:
+            p.close()
+
+
+class PipelinedGather:
+    """Gathers the per-step match tables of all ranks to `root` on a communication stream while the
+    next step computes.  Fixed-stride tables are received straight into one preallocated
+    (world, B, stride) buffer per in-flight step (no concatenation)."""
+
+    def __init__(self, bm: StereoBatchMatcher, world: int, rank: int, root: int = 0, group=None):
+        import torch
+        self.torch, self.bm, self.world, self.rank, self.root, self.group = torch, bm, world, rank, root, group
+        self.comm = torch.cuda.Stream(device=bm.dev)
+        self.nbuf = len(bm.tables)
+        self.recv = [torch.empty((world, bm.B, bm.stride), dtype=torch.int32, device=bm.dev)
+                     for _ in range(self.nbuf)] if rank == root else [None] * self.nbuf
+        self.works = [None] * self.nbuf      # outstanding gather per buffer
+        self.done_ev = [None] * self.nbuf    # recorded on the comm stream after that gather
+
+    def step(self, k: int):
+        """Compute step k into buffer k % nbuf and start gathering it."""
+        import torch.distributed as dist
+        b = k % self.nbuf
+        if self.done_ev[b] is not None:                    # buffer b is being re-used: its previous gather
+            self.bm.stream.wait_event(self.done_ev[b])     # must have read the table before we overwrite it
+        ev = self.bm.run_async(b)
+        with self.torch.cuda.stream(self.comm):
+            self.comm.wait_event(ev)
+            glist = list(self.recv[b].unbind(0)) if self.rank == self.root else None
+            w = dist.gather(self.bm.tables[b], gather_list=glist, dst=self.root, group=self.group, async_op=True)
+            w.wait()                                        # stream-level wait (comm stream), not a host block
+            done = self.torch.cuda.Event()
+            done.record(self.comm)
+        self.works[b], self.done_ev[b] = w, done
+        return b
+
+    def finish(self):
+        for ev in self.done_ev:
+            if ev is not None:
+                ev.synchronize()
+        self.torch.cuda.synchronize(self.bm.dev)
+
+    def gathered(self, b: int):
+        return self.recv[b].reshape(self.world * self.bm.B, self.bm.stride) if self.rank == self.root else None
 
 
 def gather_tables(local, world: int, rank: int, root: int = 0, group=None, force: bool = False):
