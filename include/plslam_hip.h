@@ -212,6 +212,30 @@ int plslam_map_point_visible(plslam_ctx* ctx, const plslam_cam* K, const double*
 int plslam_map_line_visible(plslam_ctx* ctx, const plslam_cam* K, const double* Twf,
                             const double* Lw, int32_t n, uint8_t* vis);
 
+/* ---- the map <-> keyframe association drivers, fused ---------------------------------------- */
+/* Replaces the compute of MapHandler::matchMap2KFPoints (src/mapHandler.cpp:532-632), brute-force
+ * path (fast_matching == false); the map mutation (:614-626) stays with the caller.
+ *   candidate[i] != 0  <=>  the reference's  pt != nullptr && pt->local && pt->kf_obs_list.back() != kf2_idx (:547)
+ *   Xw n_map*3 = pt->point3D, med_desc n_map*32 = pt->med_desc (:555)
+ *   kf_desc n_kf*32 = pdesc_l, kf_pl n_kf*2 = stereo_pt[i]->pl, kf_idx[i] = stereo_pt[i]->idx (-1 = unmatched, :565)
+ *   min_matches = SlamConfig::minPointMatches() (:594-596), max_epip = SlamConfig::maxKFEpipP() (:613)
+ * On the device: projection + inside-image test (:549-551), Q/T matrix construction (:555, :567),
+ * StVO::match (:597), epipolar gate (:610-613).  map_to_kf[n_map] receives, per map landmark, the
+ * ORIGINAL keyframe feature index it is associated with, or -1; *n_matches the return value. */
+int plslam_map2kf_match_points(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* Xw,
+                               const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                               const uint8_t* kf_desc, const double* kf_pl, const int32_t* kf_idx,
+                               int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
+                               int32_t* map_to_kf, int32_t* n_matches);
+/* MapHandler::matchMap2KFLines (src/mapHandler.cpp:634-752): Lw n_map*6 = ls->line3D, kf_le n_kf*3 =
+ * stereo_ls[i]->le; both endpoints must project inside (:654-655); signed gate (:727-729);
+ * min_matches = SlamConfig::minLineMatches() (:709-711). */
+int plslam_map2kf_match_lines(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* Lw,
+                              const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                              const uint8_t* kf_desc, const double* kf_le, const int32_t* kf_idx,
+                              int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
+                              int32_t* map_to_kf, int32_t* n_matches);
+
 /* ---- multi-GPU: gather of per-frame match tables over RCCL/xGMI -------------------------- */
 /* No reference counterpart (the reference is single-process).  `comm` is an ncclComm_t the
  * host created (one rank per GPU); `local` is this rank's n_local int32 match-table entries

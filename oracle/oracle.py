@@ -73,6 +73,10 @@ def _bind(lib: C.CDLL) -> C.CDLL:
         f.argtypes = [C.POINTER(Cam), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p,
                       C.c_double, C.c_void_p]
         f.restype = C.c_int32
+    for f in (lib.plo_map2kf_match_points, lib.plo_map2kf_match_lines):
+        f.argtypes = [C.POINTER(Cam)] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 + \
+            [C.c_int32, C.c_float, C.c_int, C.c_double, C.c_int32, C.c_void_p]
+        f.restype = C.c_int32
     for f in (lib.plo_map_point_visible, lib.plo_map_line_visible):
         f.argtypes = [C.POINTER(Cam), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         f.restype = None
@@ -282,6 +286,22 @@ def map_line_visible(cam, Twf, Lw):
     vis = np.empty(Lw.shape[0], np.uint8)
     lib().plo_map_line_visible(C.byref(cam), _p(Twf), _p(Lw), Lw.shape[0], _p(vis))
     return vis
+
+
+def map2kf_match(kind, cam, Twf, LM, med_desc, candidate, kf_desc, kf_feat, kf_idx, nnr, mutual, max_epip,
+                 min_matches):
+    """MapHandler::matchMap2KFPoints / Lines (src/mapHandler.cpp:532-752), BF path."""
+    lw, fw = (3, 2) if kind == "points" else (6, 3)
+    Twf = _c(Twf, np.float64).reshape(16)
+    LM = _c(LM, np.float64).reshape(-1, lw)
+    md, cand = _desc(med_desc), _c(candidate, np.uint8)
+    kd, kf = _desc(kf_desc), _c(kf_feat, np.float64).reshape(-1, fw)
+    ki = _c(kf_idx, np.int32)
+    out = np.empty(LM.shape[0], np.int32)
+    f = lib().plo_map2kf_match_points if kind == "points" else lib().plo_map2kf_match_lines
+    n = f(C.byref(cam), _p(Twf), _p(LM), _p(md), _p(cand), LM.shape[0], _p(kd), _p(kf), _p(ki), kd.shape[0],
+          float(nnr), int(bool(mutual)), float(max_epip), int(min_matches), _p(out))
+    return out, int(n)
 
 
 # ------------------------------------------------------------------------------------------

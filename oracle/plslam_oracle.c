@@ -570,3 +570,68 @@ void plo_map_line_visible(const plo_cam* K, const double Twf[16], const double* 
         vis[i] = (uint8_t)(inside(K, sP) && inside(K, eP));
     }
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* map <-> keyframe drivers: src/mapHandler.cpp:532-632 (points), :634-752 (lines)        */
+/* ------------------------------------------------------------------------------------ */
+static int32_t map2kf_driver(int lines, const plo_cam* K, const double Twf[16], const double* LM,
+                             const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                             const uint8_t* kf_desc, const double* kf_feat, const int32_t* kf_idx,
+                             int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
+                             int32_t* map_to_kf)
+{
+    const int lw = lines ? 6 : 3, fw = lines ? 3 : 2;
+    for (int32_t i = 0; i < n_map; ++i) map_to_kf[i] = -1;
+    uint8_t* vis = (uint8_t*)malloc((size_t)(n_map > 0 ? n_map : 1));
+    if (lines) plo_map_line_visible(K, Twf, LM, n_map, vis); else plo_map_point_visible(K, Twf, LM, n_map, vis);
+    int32_t* qi = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_map > 0 ? n_map : 1));
+    int32_t* ti = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_kf > 0 ? n_kf : 1));
+    int32_t nq = 0, nt = 0;
+    for (int32_t i = 0; i < n_map; ++i) if (candidate[i] && vis[i]) qi[nq++] = i;      /* :545-558 */
+    for (int32_t i = 0; i < n_kf; ++i) if (kf_idx[i] == -1) ti[nt++] = i;              /* :563-569 */
+    int32_t matches = 0;
+    if (nq > 0 && nt > 0 && nq > min_matches) {                                         /* :571, :594-597 */
+        uint8_t* Q = (uint8_t*)malloc((size_t)nq * 32);
+        uint8_t* T = (uint8_t*)malloc((size_t)nt * 32);
+        double* QL = (double*)malloc(sizeof(double) * (size_t)nq * lw);
+        double* TF = (double*)malloc(sizeof(double) * (size_t)nt * fw);
+        for (int32_t a = 0; a < nq; ++a) {
+            memcpy(Q + (size_t)a * 32, med_desc + (size_t)qi[a] * 32, 32);
+            memcpy(QL + (size_t)a * lw, LM + (size_t)qi[a] * lw, sizeof(double) * lw);
+        }
+        for (int32_t b = 0; b < nt; ++b) {
+            memcpy(T + (size_t)b * 32, kf_desc + (size_t)ti[b] * 32, 32);
+            memcpy(TF + (size_t)b * fw, kf_feat + (size_t)ti[b] * fw, sizeof(double) * fw);
+        }
+        int32_t* m12 = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
+        uint8_t* mask = (uint8_t*)malloc((size_t)nq);
+        plo_match(Q, nq, T, nt, nnr, mutual, m12);
+        matches = lines ? plo_map2kf_line_gate(K, Twf, QL, m12, nq, TF, max_epip, mask)
+                        : plo_map2kf_point_gate(K, Twf, QL, m12, nq, TF, max_epip, mask);
+        for (int32_t a = 0; a < nq; ++a)
+            if (mask[a]) map_to_kf[qi[a]] = ti[m12[a]];
+        free(mask); free(m12); free(TF); free(QL); free(T); free(Q);
+    }
+    free(ti); free(qi); free(vis);
+    return matches;
+}
+
+int32_t plo_map2kf_match_points(const plo_cam* K, const double Twf[16], const double* Xw,
+                                const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                                const uint8_t* kf_desc, const double* kf_pl, const int32_t* kf_idx,
+                                int32_t n_kf, float nnr, int mutual, double max_epip,
+                                int32_t min_matches, int32_t* map_to_kf)
+{
+    return map2kf_driver(0, K, Twf, Xw, med_desc, candidate, n_map, kf_desc, kf_pl, kf_idx, n_kf, nnr,
+                         mutual, max_epip, min_matches, map_to_kf);
+}
+
+int32_t plo_map2kf_match_lines(const plo_cam* K, const double Twf[16], const double* Lw,
+                               const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                               const uint8_t* kf_desc, const double* kf_le, const int32_t* kf_idx,
+                               int32_t n_kf, float nnr, int mutual, double max_epip,
+                               int32_t min_matches, int32_t* map_to_kf)
+{
+    return map2kf_driver(1, K, Twf, Lw, med_desc, candidate, n_map, kf_desc, kf_le, kf_idx, n_kf, nnr,
+                         mutual, max_epip, min_matches, map_to_kf);
+}

@@ -124,6 +124,26 @@ void plo_map_point_visible(const plo_cam* K, const double Twf[16], const double*
 void plo_map_line_visible(const plo_cam* K, const double Twf[16], const double* Lw, int32_t n,
                           uint8_t* vis);
 
+/* ---- map <-> keyframe drivers (BF path, fast_matching == false) -------------------------- */
+/* MapHandler::matchMap2KFPoints, src/mapHandler.cpp:532-632 without the map mutation:
+ *  Q = med_desc rows of candidate[i] landmarks that project inside the image (:545-558);
+ *  T = kf_desc rows whose kf_idx == -1 (:563-569); if either is empty -> 0 (:571);
+ *  match() only if |Q| > min_matches (:594-597, matchGrid absent => matches == 0 before);
+ *  accept i1->i2 iff || proj(Twf X) - pl || < max_epip (:610-613), else --matches (:628).
+ * map_to_kf[n_map] receives the ORIGINAL kf feature index or -1.  Returns #accepted. */
+int32_t plo_map2kf_match_points(const plo_cam* K, const double Twf[16], const double* Xw,
+                                const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                                const uint8_t* kf_desc, const double* kf_pl, const int32_t* kf_idx,
+                                int32_t n_kf, float nnr, int mutual, double max_epip,
+                                int32_t min_matches, int32_t* map_to_kf);
+/* MapHandler::matchMap2KFLines, src/mapHandler.cpp:634-752 (both endpoints visible :654-655,
+ * signed gate :727-729, min_matches = SlamConfig::minLineMatches :709-712). */
+int32_t plo_map2kf_match_lines(const plo_cam* K, const double Twf[16], const double* Lw,
+                               const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                               const uint8_t* kf_desc, const double* kf_le, const int32_t* kf_idx,
+                               int32_t n_kf, float nnr, int mutual, double max_epip,
+                               int32_t min_matches, int32_t* map_to_kf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "plslam_lba_point_rows", "plslam_lba_line_rows", "plslam_lba_point_rows_dev",
     "plslam_lba_line_rows_dev",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
-    "plslam_map_line_visible",
+    "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
     "plslam_gather_match_tables",
 )
 
@@ -110,6 +110,9 @@ def load() -> C.CDLL:
         f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, i32, vp, i32, f64, vp, C.POINTER(i32)]
     for f in (L.plslam_map_point_visible, L.plslam_map_line_visible):
         f.argtypes = [vp, C.POINTER(Cam), vp, vp, i32, vp]
+    for f in (L.plslam_map2kf_match_points, L.plslam_map2kf_match_lines):
+        f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_float, C.c_int, f64, i32, vp,
+                      C.POINTER(i32)]
     L.plslam_gather_match_tables.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
@@ -282,6 +285,23 @@ class Context:
         _check(self._L.plslam_map_line_visible(self._h, C.byref(cam), _p(Twf), _p(Lw), Lw.shape[0], _p(vis)),
                "plslam_map_line_visible")
         return vis
+
+    def map2kf_match(self, kind, cam, Twf, LM, med_desc, candidate, kf_desc, kf_feat, kf_idx, nnr, mutual,
+                     max_epip, min_matches):
+        """MapHandler::matchMap2KFPoints / matchMap2KFLines (compute part) -> (map_to_kf, n_matches)."""
+        lw, fw = (3, 2) if kind == "points" else (6, 3)
+        Twf = _arr(Twf, np.float64, (16,))
+        LM = _arr(LM, np.float64, (-1, lw))
+        md, cand = _arr(med_desc, np.uint8, (-1, 32)), _arr(candidate, np.uint8)
+        kd, kf = _arr(kf_desc, np.uint8, (-1, 32)), _arr(kf_feat, np.float64, (-1, fw))
+        ki = _arr(kf_idx, np.int32)
+        out = np.empty(LM.shape[0], np.int32)
+        n = C.c_int32()
+        fn = self._L.plslam_map2kf_match_points if kind == "points" else self._L.plslam_map2kf_match_lines
+        _check(fn(self._h, C.byref(cam), _p(Twf), _p(LM), _p(md), _p(cand), LM.shape[0], _p(kd), _p(kf), _p(ki),
+                  kd.shape[0], float(nnr), int(bool(mutual)), float(max_epip), int(min_matches), _p(out),
+                  C.byref(n)), "plslam_map2kf_match_" + kind)
+        return out, n.value
 
     # ---- device-pointer calls ----------------------------------------------------------------
     def lba_point_rows_dev(self, cam, homog_th, T, Xw, uv, lm, kf, nobs, Jp, Jl, r, w, stream=0):

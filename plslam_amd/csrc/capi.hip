@@ -304,6 +304,16 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
     return PLSLAM_OK;
 }
 
+namespace plslam {
+int match_problems_on_ctx_stream(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob)
+{
+    if (!ctx->host_plan) ctx->host_plan = new (std::nothrow) plslam_match_plan();
+    PLSLAM_REQUIRE(ctx->host_plan != nullptr, PLSLAM_ENOMEM);
+    const int r = plan_build(ctx, probs, nprob, ctx->host_plan);
+    return r ? r : plan_run(ctx->host_plan, ctx->stream);
+}
+}  // namespace plslam
+
 // ---------------------------------------------------------------------------------------------
 // extern "C"
 // ---------------------------------------------------------------------------------------------

@@ -116,6 +116,13 @@ int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int n
 
 int scan_rows_per_block(int variant, int block_threads);
 
+// builds the plan for `probs` (DEVICE pointers) into the context's persistent host-path plan and
+// enqueues it on the context stream; no synchronisation.  Caller holds ctx->mu.  (capi.hip)
+int match_problems_on_ctx_stream(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob);
+// dst[i] = src[idx[i]] for rows of row_bytes (a multiple of 8) bytes  (map2kf.hip)
+int launch_gather_rows(const void* src, const int32_t* idx, int32_t n, int32_t row_bytes, void* dst,
+                       hipStream_t s);
+
 // --- LBA rows + gates (lba.hip) --------------------------------------------------------------
 int launch_point_rows(const plslam_cam& K, double th, const double* T, const double* Xw,
                       const double* uv, const int32_t* lm, const int32_t* kf, int32_t nobs,
