@@ -191,6 +191,26 @@ int plslam_lba_line_rows_dev(plslam_ctx* ctx, const plslam_cam* K, double homog_
                              int32_t nobs, double* J_pose, double* J_lm, double* r, double* w,
                              void* stream);
 
+/* ---- K7-K10: normal equations of the local BA in block form ------------------------------- */
+/* Replaces the accumulation into the dense H / g of levMarquardtOptimizationLBA
+ * (src/mapHandler.cpp:1410-1429 points, :1519-1538 lines) by its block structure:
+ *   g       N = 6*nkf + 3*npt + 6*nls      (the layout of the reference's X / g)
+ *   H_pose  nkf * 6x6   H.block(idx,idx,6,6)          H_pt  npt * 3x3   H.block(jdx,jdx,3,3)
+ *   H_ls    nls * 6x6   H.block(jdx,jdx,6,6)
+ *   W_pt    n_pt_obs * 3x6   the observation's Haux = H.block(jdx,idx,3,6) contribution (:1424-1426)
+ *   W_ls    n_ls_obs * 6x6   (:1533-1535); zero when kf_loc == -1 (keyframe not optimised, :1413)
+ *   err     sum r^2 w (:1416,1423,1525,1532)
+ * Inputs are the rows of plslam_lba_*_rows plus the Vector6i columns lm_loc (1) and kf_loc (4)
+ * (:1259,1263).  Every block entry is the sequential sum over the observations in list order
+ * (points, then lines), i.e. the dense accumulation's own order; all blocks row-major. */
+int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, int32_t nls,
+                        const int32_t* pt_lm_loc, const int32_t* pt_kf_loc, int32_t n_pt_obs,
+                        const double* pt_J_pose, const double* pt_J_lm, const double* pt_r,
+                        const double* pt_w, const int32_t* ls_lm_loc, const int32_t* ls_kf_loc,
+                        int32_t n_ls_obs, const double* ls_J_pose, const double* ls_J_lm,
+                        const double* ls_r, const double* ls_w, double* g, double* H_pose,
+                        double* H_pt, double* H_ls, double* W_pt, double* W_ls, double* err);
+
 /* ---- K5/K6: map <-> keyframe geometric gates (the inlier masks) -------------------------- */
 /* Points: src/mapHandler.cpp:601-613.  mask[i] = 1 iff matches_12[i] >= 0 and
  * || proj(Twf * Xw[i]) - pl[matches_12[i]] ||_2 < max_epip.  Twf: 16 doubles row-major.

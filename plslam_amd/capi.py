@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "plslam_match_plan_create", "plslam_match_plan_run", "plslam_match_plan_set_profiling",
     "plslam_match_plan_elapsed", "plslam_match_plan_info", "plslam_match_plan_destroy",
     "plslam_lba_point_rows", "plslam_lba_line_rows", "plslam_lba_point_rows_dev",
-    "plslam_lba_line_rows_dev",
+    "plslam_lba_line_rows_dev", "plslam_lba_assemble",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
     "plslam_gather_match_tables",
@@ -106,6 +106,8 @@ def load() -> C.CDLL:
                                             vp, vp, vp, vp, vp]
     L.plslam_lba_line_rows_dev.argtypes = [vp, C.POINTER(Cam), f64, C.c_int, vp, vp, vp, vp, vp, i32,
                                            vp, vp, vp, vp, vp]
+    L.plslam_lba_assemble.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp,
+                                      vp, vp, vp, vp, vp, vp, vp]
     for f in (L.plslam_map2kf_point_gate, L.plslam_map2kf_line_gate):
         f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, i32, vp, i32, f64, vp, C.POINTER(i32)]
     for f in (L.plslam_map_point_visible, L.plslam_map_line_visible):
@@ -250,6 +252,24 @@ class Context:
                                             Lw.shape[0], _p(lo), _p(lm), _p(kf), n, _p(Jp), _p(Jl),
                                             _p(r), _p(w)), "plslam_lba_line_rows")
         return Jp, Jl, r, w
+
+    def lba_assemble(self, nkf, npt, nls, pt_lm, pt_kf_loc, pt_rows, ls_lm, ls_kf_loc, ls_rows):
+        """Block-form normal equations from point rows (Jp, Jl, r, w) and line rows."""
+        plm, pkf = _arr(pt_lm, np.int32), _arr(pt_kf_loc, np.int32)
+        llm, lkf = _arr(ls_lm, np.int32), _arr(ls_kf_loc, np.int32)
+        pr = [_arr(x, np.float64) for x in pt_rows]
+        lr = [_arr(x, np.float64) for x in ls_rows]
+        npo, nlo = plm.shape[0], llm.shape[0]
+        N = 6 * nkf + 3 * npt + 6 * nls
+        g, Hp = np.empty(N), np.empty((nkf, 6, 6))
+        Hpt, Hls = np.empty((npt, 3, 3)), np.empty((nls, 6, 6))
+        Wp, Wl = np.empty((npo, 3, 6)), np.empty((nlo, 6, 6))
+        err = np.empty(1)
+        _check(self._L.plslam_lba_assemble(self._h, nkf, npt, nls, _p(plm), _p(pkf), npo, _p(pr[0]), _p(pr[1]),
+                                           _p(pr[2]), _p(pr[3]), _p(llm), _p(lkf), nlo, _p(lr[0]), _p(lr[1]),
+                                           _p(lr[2]), _p(lr[3]), _p(g), _p(Hp), _p(Hpt), _p(Hls), _p(Wp), _p(Wl),
+                                           _p(err)), "plslam_lba_assemble")
+        return dict(g=g, H_pose=Hp, H_pt=Hpt, H_ls=Hls, W_pt=Wp, W_ls=Wl, err=float(err[0]))
 
     def _gate(self, fn, name, cam, Twf, LM, lw, m12, feat, fw, th):
         Twf = _arr(Twf, np.float64, (16,))

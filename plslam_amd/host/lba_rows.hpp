@@ -115,6 +115,35 @@ public:
         accumulate(p.ls_obs_list, rows, 6, 6 * p.Nkf + 3 * Npt, N, H, g, err);
     }
 
+    // Block (Schur-ready) form of the same normal equations, assembled on the device
+    // (plslam_lba_assemble): H.block(idx,idx,6,6) per keyframe, H.block(jdx,jdx,.,.) per landmark,
+    // one Haux (:1424, :1533) per observation.  Entries are bit-identical to the dense accumulation.
+    struct BlockNormalEquations {
+        std::vector<double> g, H_pose, H_pt, H_ls, W_pt, W_ls;
+        double err = 0.0;
+        int Nkf = 0, Npt = 0, Nls = 0;
+    };
+    void buildBlockNormalEquations(const LbaProblem& p, bool iteration_pass, BlockNormalEquations& out) const
+    {
+        out.Nkf = p.Nkf; out.Npt = (int)(p.points.size() / 3); out.Nls = (int)(p.lines.size() / 6);
+        LbaRows rp, rl;
+        pointRows(p, rp);
+        lineRows(p, iteration_pass, rl);
+        const int32_t np = (int32_t)p.pt_obs_list.size(), nl = (int32_t)p.ls_obs_list.size();
+        std::vector<int32_t> plm(np), pkf(np), llm(nl), lkf(nl);
+        for (int32_t o = 0; o < np; ++o) { plm[o] = p.pt_obs_list[o][1]; pkf[o] = p.pt_obs_list[o][4]; }
+        for (int32_t o = 0; o < nl; ++o) { llm[o] = p.ls_obs_list[o][1]; lkf[o] = p.ls_obs_list[o][4]; }
+        out.g.assign((size_t)(6 * out.Nkf + 3 * out.Npt + 6 * out.Nls), 0.0);
+        out.H_pose.assign((size_t)out.Nkf * 36, 0.0); out.H_pt.assign((size_t)out.Npt * 9, 0.0);
+        out.H_ls.assign((size_t)out.Nls * 36, 0.0); out.W_pt.assign((size_t)np * 18, 0.0);
+        out.W_ls.assign((size_t)nl * 36, 0.0);
+        check(plslam_lba_assemble(ctx_, out.Nkf, out.Npt, out.Nls, plm.data(), pkf.data(), np, rp.J_pose.data(),
+                                  rp.J_lm.data(), rp.r.data(), rp.w.data(), llm.data(), lkf.data(), nl,
+                                  rl.J_pose.data(), rl.J_lm.data(), rl.r.data(), rl.w.data(), out.g.data(),
+                                  out.H_pose.data(), out.H_pt.data(), out.H_ls.data(), out.W_pt.data(),
+                                  out.W_ls.data(), &out.err), "plslam_lba_assemble");
+    }
+
 private:
     static void check(int rc, const char* fn)
     {

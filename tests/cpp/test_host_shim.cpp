@@ -170,6 +170,29 @@ int main()
             EXPECT(worst <= 1e-6);            // the contract (north_star)
             EXPECT(std::fabs(err - erro) <= 1e-6 * std::fabs(erro));
             std::printf("LBA normal equations pass %d: N=%d max rel diff vs oracle %.3g\n", pass, N, worst);
+            // block form (device assembly) == the dense accumulation, entry for entry
+            PLSLAM::LbaRowBuilder::BlockNormalEquations B;
+            rb.buildBlockNormalEquations(p, pass == 1, B);
+            int bad = 0;
+            for (int i = 0; i < N; ++i) bad += B.g[i] != gv[i];
+            for (int k = 0; k < p.Nkf; ++k)
+                for (int a = 0; a < 6; ++a)
+                    for (int b = 0; b < 6; ++b) bad += B.H_pose[(size_t)k * 36 + a * 6 + b] != H[(size_t)(6 * k + a) * N + 6 * k + b];
+            for (int l = 0; l < Npt; ++l)
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 3; ++b) {
+                        const int j = 6 * p.Nkf + 3 * l;
+                        bad += B.H_pt[(size_t)l * 9 + a * 3 + b] != H[(size_t)(j + a) * N + j + b];
+                    }
+            for (int o = 0; o < np; ++o) {
+                const int kf = p.pt_obs_list[o][4];
+                if (kf < 0) continue;
+                const int j = 6 * p.Nkf + 3 * p.pt_obs_list[o][1], i0 = 6 * kf;
+                for (int a = 0; a < 3; ++a)
+                    for (int b = 0; b < 6; ++b) bad += B.W_pt[(size_t)o * 18 + a * 6 + b] != H[(size_t)(j + a) * N + i0 + b];
+            }
+            EXPECT(bad == 0);
+            EXPECT(std::fabs(B.err - err) <= 1e-12 * std::fabs(err));
         }
         plslam_ctx_destroy(ctx);
     }

@@ -107,3 +107,80 @@ def test_gates_and_visibility_bit_exact(ctx, oracle):
     mask, cnt = ctx.map2kf_line_gate(cam, Twf, Lw, m12l, le, 1.0)
     emask, ecnt = oracle.map2kf_line_gate(ocam, Twf, Lw, m12l, le, 1.0)
     assert np.array_equal(mask, emask) and cnt == ecnt
+
+
+def _expand_blocks(B, nkf, npt, nls, pt_lm, pt_kf, ls_lm, ls_kf):
+    """Scatter the block form back into the reference's dense H (src/mapHandler.cpp:1410-1429, :1519-1538)."""
+    N = 6 * nkf + 3 * npt + 6 * nls
+    H = np.zeros((N, N))
+    for k in range(nkf):
+        H[6 * k:6 * k + 6, 6 * k:6 * k + 6] = B["H_pose"][k]
+    for l in range(npt):
+        j = 6 * nkf + 3 * l
+        H[j:j + 3, j:j + 3] = B["H_pt"][l]
+    for l in range(nls):
+        j = 6 * nkf + 3 * npt + 6 * l
+        H[j:j + 6, j:j + 6] = B["H_ls"][l]
+    for o in range(len(pt_lm)):
+        if pt_kf[o] >= 0:
+            j, i = 6 * nkf + 3 * pt_lm[o], 6 * pt_kf[o]
+            H[j:j + 3, i:i + 6] += B["W_pt"][o]
+            H[i:i + 6, j:j + 3] += B["W_pt"][o].T
+    for o in range(len(ls_lm)):
+        if ls_kf[o] >= 0:
+            j, i = 6 * nkf + 3 * npt + 6 * ls_lm[o], 6 * ls_kf[o]
+            H[j:j + 6, i:i + 6] += B["W_ls"][o]
+            H[i:i + 6, j:j + 6] += B["W_ls"][o].T
+    return H
+
+
+@pytest.mark.parametrize("n_kf,n_pt,n_ls,obs", [(4, 60, 20, 3), (8, 300, 90, 5), (3, 10, 0, 2), (3, 0, 7, 3)])
+def test_block_assembly_equals_dense_accumulation(ctx, oracle, n_kf, n_pt, n_ls, obs):
+    """K7-K10: the block-form normal equations, expanded, equal the reference's dense H and g
+    accumulation bit for bit (same summation order); err to 1e-12 (tree vs sequential sum)."""
+    lm = synth.local_map(n_kf=n_kf, n_pt=n_pt, n_ls=n_ls, obs_per_lm=obs, seed=n_pt + 1)
+    cam, ocam = _cams()
+    nkf = n_kf - 1                                 # keyframe 0 is never optimised (:1231): kf_loc = slot - 1
+    pt_kf_loc, ls_kf_loc = lm["pt_kf"] - 1, lm["ls_kf"] - 1
+    rows_p = oracle.lba_point_rows(ocam, 1e-7, lm["T_kf_w"], lm["Xw"], lm["obs_uv"], lm["pt_lm"], lm["pt_kf"])
+    rows_l = oracle.lba_line_rows(ocam, 1e-7, lm["T_kf_w"], lm["Lw"], lm["l_obs"], lm["ls_lm"], lm["ls_kf"])
+    H, g, e1 = oracle.lba_accumulate("points", nkf, n_pt, n_ls, lm["pt_lm"], pt_kf_loc, *rows_p)
+    H, g, e2 = oracle.lba_accumulate("lines", nkf, n_pt, n_ls, lm["ls_lm"], ls_kf_loc, *rows_l, H=H, g=g)
+    B = ctx.lba_assemble(nkf, n_pt, n_ls, lm["pt_lm"], pt_kf_loc, rows_p, lm["ls_lm"], ls_kf_loc, rows_l)
+    Hd = _expand_blocks(B, nkf, n_pt, n_ls, lm["pt_lm"], pt_kf_loc, lm["ls_lm"], ls_kf_loc)
+    assert np.array_equal(B["g"], g)
+    assert np.array_equal(Hd, H)
+    assert abs(B["err"] - (e1 + e2)) <= 1e-12 * abs(e1 + e2)
+    if n_pt:
+        with pytest.raises(plslam_amd.PlslamError):    # out-of-range keyframe slots are rejected, not read
+            ctx.lba_assemble(nkf, n_pt, n_ls, lm["pt_lm"], pt_kf_loc + 100, rows_p, lm["ls_lm"], ls_kf_loc, rows_l)
+
+
+def test_block_assembly_c3_size(ctx, oracle):
+    """C3 scale (N = 42 054): the dense H of the reference would be 14 GB; check the blocks against
+    per-block numpy sums instead."""
+    lm = synth.local_map()
+    cam, ocam = _cams()
+    nkf, npt, nls = 9, 10000, 2000
+    pkf, lkf = lm["pt_kf"] - 1, lm["ls_kf"] - 1
+    rows_p = ctx.lba_point_rows(cam, 1e-7, lm["T_kf_w"], lm["Xw"], lm["obs_uv"], lm["pt_lm"], lm["pt_kf"])
+    rows_l = ctx.lba_line_rows(cam, 1e-7, lm["T_kf_w"], lm["Lw"], lm["l_obs"], lm["ls_lm"], lm["ls_kf"])
+    B = ctx.lba_assemble(nkf, npt, nls, lm["pt_lm"], pkf, rows_p, lm["ls_lm"], lkf, rows_l)
+    Jp, Jl, r, w = rows_p
+    Hpt = np.zeros((npt, 3, 3))
+    np.add.at(Hpt, lm["pt_lm"], Jl[:, :, None] * Jl[:, None, :] * w[:, None, None])
+    assert np.allclose(B["H_pt"], Hpt, rtol=1e-12, atol=1e-300)
+    Hp = np.zeros((nkf, 6, 6))
+    sel = pkf >= 0
+    np.add.at(Hp, pkf[sel], (Jp[:, :, None] * Jp[:, None, :] * w[:, None, None])[sel])
+    Jp2, Jl2, r2, w2 = rows_l
+    sel2 = lkf >= 0
+    np.add.at(Hp, lkf[sel2], (Jp2[:, :, None] * Jp2[:, None, :] * w2[:, None, None])[sel2])
+    assert np.allclose(B["H_pose"], Hp, rtol=1e-9)
+    assert np.allclose(B["W_ls"][sel2], (Jl2[:, :, None] * Jp2[:, None, :] * w2[:, None, None])[sel2], rtol=1e-13)
+    assert (B["W_ls"][~sel2] == 0).all()
+    assert np.isclose(B["err"], (r * r * w).sum() + (r2 * r2 * w2).sum(), rtol=1e-12)
+    gp = np.zeros(6 * nkf + 3 * npt + 6 * nls)
+    np.add.at(gp, (6 * nkf + 3 * lm["pt_lm"][:, None] + np.arange(3)).ravel(), (Jl * (r * w)[:, None]).ravel())
+    seg = slice(6 * nkf, 6 * nkf + 3 * npt)    # sums with cancellation: bound relative to the segment's scale
+    assert np.max(np.abs(B["g"][seg] - gp[seg])) <= 1e-12 * np.max(np.abs(gp[seg]))
