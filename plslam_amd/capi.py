@@ -65,6 +65,31 @@ class PlslamError(RuntimeError):
 _lib = None
 
 
+def _preload_shared_hip_runtime() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.  A process must run ONE HIP runtime: if
+    this library pulled in /opt/rocm's copy first and torch initialised its own afterwards, torch
+    would find no GPU.  When torch is installed, load ITS runtime first (without importing torch) so
+    that the dynamic loader resolves our DT_NEEDED libamdhip64 to the same copy."""
+    import glob
+    import importlib.util
+    if "torch" in __import__("sys").modules:
+        return                                   # torch already brought its runtime in
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+    for name in ("libamdhip64.so", "libamdhip64.so.*"):
+        for path in sorted(glob.glob(os.path.join(libdir, name))):
+            try:
+                C.CDLL(path, mode=C.RTLD_GLOBAL)
+                return
+            except OSError:
+                continue
+
+
 def load() -> C.CDLL:
     """dlopen libplslam_hip.so and declare prototypes.  Fails loudly if it was not built."""
     global _lib
@@ -74,6 +99,7 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _preload_shared_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, i32, f64 = C.c_void_p, C.c_int32, C.c_double
     L.plslam_strerror.restype = C.c_char_p

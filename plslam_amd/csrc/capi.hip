@@ -4,6 +4,7 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 
 #include "common.hpp"
@@ -216,6 +217,36 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         }
         pds.push_back(pd);
     }
+    // Longest-first scheduling.  The scan kernels walk the block table through xcd_remap(): XCD x
+    // owns one contiguous range of the table and dispatches it in order.  Deal the blocks out by
+    // descending train-stream length (round-robin over the 8 ranges) so that every XCD runs its
+    // long blocks (ORB) first and the short ones (LBD) fill the drain phase of the launch.
+    auto longest_first = [](std::vector<BlockDesc>& blocks, auto cost_of) {
+        const size_t n = blocks.size();
+        if (n < 16) return;
+        std::vector<size_t> order(n);
+        for (size_t i = 0; i < n; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(),
+                         [&](size_t a, size_t b) { return cost_of(blocks[a]) > cost_of(blocks[b]); });
+        const size_t q = n / 8, r = n % 8;                 // range of XCD x: as in xcd_remap()
+        std::vector<BlockDesc> out(n);
+        size_t fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        size_t x = 0;
+        for (size_t k = 0; k < n; ++k) {
+            // next XCD (round-robin) that still has room in its range
+            for (size_t tries = 0; tries < 8; ++tries, x = (x + 1) & 7) {
+                const size_t len = q + (x < r ? 1 : 0);
+                if (fill[x] < len) break;
+            }
+            const size_t base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+            out[base + fill[x]++] = blocks[order[k]];
+            x = (x + 1) & 7;
+        }
+        blocks.swap(out);
+    };
+    longest_first(yblocks, [&](const BlockDesc& b) { return (int64_t)syms[b.item].n2; });
+    if (!use_wpq) longest_first(sblocks, [&](const BlockDesc& b) { return (int64_t)scans[b.item].nt; });
+
     P->nscan = (int32_t)scans.size();
     P->nscan_blocks = (int32_t)sblocks.size();
     P->nfin_blocks = (int32_t)fblocks.size();
