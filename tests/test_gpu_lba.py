@@ -184,3 +184,31 @@ def test_block_assembly_c3_size(ctx, oracle):
     np.add.at(gp, (6 * nkf + 3 * lm["pt_lm"][:, None] + np.arange(3)).ravel(), (Jl * (r * w)[:, None]).ravel())
     seg = slice(6 * nkf, 6 * nkf + 3 * npt)    # sums with cancellation: bound relative to the segment's scale
     assert np.max(np.abs(B["g"][seg] - gp[seg])) <= 1e-12 * np.max(np.abs(gp[seg]))
+
+
+def test_committed_lba_goldens(ctx):
+    """GPU vs the committed fixtures tests/golden/lba_golden.npz (no oracle involved at run time)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lba_golden.npz"))
+    cam, _ = _cams()
+    lm = {k[4:]: g[k] for k in g.files if k.startswith("map/")}
+    got = ctx.lba_point_rows(cam, 1e-7, lm["T_kf_w"], lm["Xw"], lm["obs_uv"], lm["pt_lm"], lm["pt_kf"])
+    for nm, a in zip(("J_pose", "J_lm", "r", "w"), got):
+        assert _close(a, g[f"rows/pt/{nm}"], RTOL) and _close(a, g[f"rows/pt/{nm}"], 1e-12)
+    got_l = ctx.lba_line_rows(cam, 1e-7, lm["T_kf_w"], lm["Lw"], lm["l_obs"], lm["ls_lm"], lm["ls_kf"])
+    for nm, a in zip(("J_pose", "J_lm", "r", "w"), got_l):
+        assert _close(a, g[f"rows/ls/{nm}"], 1e-12)
+    got_c = ctx.lba_line_rows(cam, 1e-3, lm["T_kf_w"], lm["Lw"], lm["l_obs"], lm["ls_lm"], lm["ls_kf"], compat_iter_pass=True)
+    for nm, a in zip(("J_pose", "J_lm", "r", "w"), got_c):
+        assert _close(a, g[f"rows/ls_compat/{nm}"], 1e-12)
+    B = ctx.lba_assemble(4, 120, 40, lm["pt_lm"], lm["pt_kf"] - 1, [g[f"rows/pt/{n}"] for n in ("J_pose", "J_lm", "r", "w")],
+                         lm["ls_lm"], lm["ls_kf"] - 1, [g[f"rows/ls/{n}"] for n in ("J_pose", "J_lm", "r", "w")])
+    Hd = _expand_blocks(B, 4, 120, 40, lm["pt_lm"], lm["pt_kf"] - 1, lm["ls_lm"], lm["ls_kf"] - 1)
+    assert np.array_equal(Hd, g["acc/H"]) and np.array_equal(B["g"], g["acc/g"])
+    for kind in ("points", "lines"):
+        s = {k.split("/")[2]: g[k] for k in g.files if k.startswith(f"drv/{kind}/")}
+        m, n = ctx.map2kf_match(kind, cam, s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"], s["kf_idx"],
+                                0.9, True, 1.0, 10)
+        assert np.array_equal(m, s["map_to_kf"]) and n == int(s["n"][0])
+        vis = (ctx.map_line_visible if kind == "lines" else ctx.map_point_visible)(cam, s["Twf"], s["LM"])
+        assert np.array_equal(vis, s["visible"])

@@ -234,3 +234,23 @@ def test_device_resident_plan_matches_oracle(vctx, oracle):
     scan_ms, fin_ms, runs = bm.plan.elapsed()
     assert runs == 1 and scan_ms > 0 and fin_ms > 0
     bm.close()
+
+
+def test_large_train_set_index_bits(vctx, oracle):
+    """Train indices beyond 16 bits (the composite key keeps 23 index bits): 70 000 train rows,
+    planted best/second-best at the far end, plus exact duplicates to force index tie-breaks."""
+    ctx = vctx
+    r = _rng(123)
+    q = synth.random_desc(r, 130)
+    t = synth.random_desc(r, 70000)
+    t[69990] = q[0]                       # exact hit at a > 16-bit index
+    t[69999] = q[0] ^ np.packbits(np.arange(256) < 3)
+    t[66000] = q[1]
+    t[66001] = q[1]                       # duplicate: lower index must win
+    idx, dist = ctx.knn2(q, t)
+    eidx, edist = oracle.knn2(q, t)
+    assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+    assert list(idx[0]) == [69990, 69999] and list(idx[1]) == [66000, 66001]
+    m, n = ctx.match(q, t, 0.75, True)
+    em, en = oracle.match(q, t, 0.75, True)
+    assert np.array_equal(m, em) and n == en

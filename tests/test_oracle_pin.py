@@ -395,3 +395,25 @@ def test_gates_against_numpy():
     e = ok & (e0 < 1.0) & (e1 < 1.0)
     assert np.array_equal(mask.astype(bool), e) and n == e.sum()
     assert (e & ((e0 < -5) | (e1 < -5))).any()   # the signed quirk is exercised
+
+
+# ---------------------------------------------------------------- committed LBA goldens -----
+LBA_GOLD = os.path.join(os.path.dirname(__file__), "golden", "lba_golden.npz")
+
+
+def test_lba_golden_matches_oracle():
+    """The committed fixtures (tests/golden/make_lba_golden.py) are what the oracle produces today."""
+    g = np.load(LBA_GOLD)
+    cam = O.make_cam(**synth.EUROC)
+    lm = {k[4:]: g[k] for k in g.files if k.startswith("map/")}
+    rows = O.lba_point_rows(cam, 1e-7, lm["T_kf_w"], lm["Xw"], lm["obs_uv"], lm["pt_lm"], lm["pt_kf"])
+    for nm, a in zip(("J_pose", "J_lm", "r", "w"), rows):
+        assert np.array_equal(a, g[f"rows/pt/{nm}"])
+    rows = O.lba_line_rows(cam, 1e-3, lm["T_kf_w"], lm["Lw"], lm["l_obs"], lm["ls_lm"], lm["ls_kf"], compat_iter_pass=True)
+    for nm, a in zip(("J_pose", "J_lm", "r", "w"), rows):
+        assert np.array_equal(a, g[f"rows/ls_compat/{nm}"])
+    for kind in ("points", "lines"):
+        s = {k.split("/")[2]: g[k] for k in g.files if k.startswith(f"drv/{kind}/")}
+        m, n = O.map2kf_match(kind, cam, s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"], s["kf_idx"],
+                              0.9, True, 1.0, 10)
+        assert np.array_equal(m, s["map_to_kf"]) and n == int(s["n"][0])
