@@ -55,12 +55,32 @@ __device__ __forceinline__ void jac6(double a, double b, double k, const double 
     J[5] = +k * (b * gx * gz - a * gy * gz);
 }
 
-__device__ __forceinline__ void store6(double* __restrict__ dst, const double v[6])
+// Coalesced row store: every lane holds NW doubles of its own output row (row-major [obs][NW]).
+// Written straight to global memory, one instruction touches 16 B out of every 8*NW B; instead the
+// wave drops its 64 rows into a private LDS slab and streams the slab out linearly, 16 B per lane
+// per instruction (1 KB contiguous per instruction).  `valid` = rows of this wave inside nobs.
+template <int NW>
+__device__ __forceinline__ void wave_store_rows(double* __restrict__ gbase /* row 0 of this wave */,
+                                                const double (&v)[NW], double* __restrict__ slab, int lane,
+                                                int valid)
 {
-    double2* d = reinterpret_cast<double2*>(dst);  // rows are 48 B: 16-byte aligned
-    d[0] = make_double2(v[0], v[1]);
-    d[1] = make_double2(v[2], v[3]);
-    d[2] = make_double2(v[4], v[5]);
+#pragma unroll
+    for (int c = 0; c < NW; ++c) slab[lane * NW + c] = v[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int total2 = valid * NW / 2;                      // number of double2 chunks (NW*valid is even
+    const double2* s2 = reinterpret_cast<const double2*>(slab);   //  unless NW and valid are odd)
+    double2* g2 = reinterpret_cast<double2*>(gbase);
+#pragma unroll
+    for (int k = 0; k < (NW + 1) / 2; ++k) {
+        const int i = k * 64 + lane;
+        if (i < total2) g2[i] = s2[i];
+    }
+    if ((valid * NW) & 1) {                                  // odd tail double
+        if (lane == 0) gbase[valid * NW - 1] = slab[valid * NW - 1];
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 // K3: point rows
@@ -70,14 +90,19 @@ k_point_rows(CamD K, double th, const double* __restrict__ T, const double* __re
              const int32_t* __restrict__ kf, int32_t nobs, double* __restrict__ Jp,
              double* __restrict__ Jl, double* __restrict__ r, double* __restrict__ w)
 {
+    __shared__ __attribute__((aligned(16))) double slabs[4][64 * 6];
     const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= nobs) return;
-    double R[9], t[3], G[3], Jc[6], out6[6];
-    inv_pose(T + 16 * (size_t)kf[o], R, t);
-    xform(R, t, Xw + 3 * (size_t)lm[o], G);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int o0 = o - lane;                                 // first observation of this wave
+    if (o0 >= nobs) return;                                  // whole wave out of range (wave-uniform)
+    const int valid = nobs - o0 < 64 ? nobs - o0 : 64;
+    const int oc = o < nobs ? o : nobs - 1;                  // clamp: tail lanes recompute the last row
+    double R[9], t[3], G[3], Jc[6], out6[6], out3[3];
+    inv_pose(T + 16 * (size_t)kf[oc], R, t);
+    xform(R, t, Xw + 3 * (size_t)lm[oc], G);
     double pu, pv;
     project(K, G, pu, pv);
-    const double2 ob = reinterpret_cast<const double2*>(uv)[o];
+    const double2 ob = reinterpret_cast<const double2*>(uv)[oc];
     const double dx = ob.x - pu, dy = ob.y - pv;
     const double nrm = sqrt(dx * dx + dy * dy);
     const double k = 1.0 / dmax(th, G[2] * G[2]);
@@ -86,12 +111,14 @@ k_point_rows(CamD K, double th, const double* __restrict__ T, const double* __re
     const double den = dmax(th, nrm);
 #pragma unroll
     for (int c = 0; c < 6; ++c) out6[c] = Jc[c] / den;
-    store6(Jp + 6 * (size_t)o, out6);
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-        Jl[3 * (size_t)o + j] = (Jc[0] * R[j] + Jc[1] * R[3 + j] + Jc[2] * R[6 + j]) / den;
-    r[o] = nrm;
-    w[o] = 1.0 / (1.0 + nrm * nrm);
+    for (int j = 0; j < 3; ++j) out3[j] = (Jc[0] * R[j] + Jc[1] * R[3 + j] + Jc[2] * R[6 + j]) / den;
+    wave_store_rows<6>(Jp + 6 * (size_t)o0, out6, slabs[wave], lane, valid);
+    wave_store_rows<3>(Jl + 3 * (size_t)o0, out3, slabs[wave], lane, valid);
+    if (o < nobs) {
+        r[o] = nrm;
+        w[o] = 1.0 / (1.0 + nrm * nrm);
+    }
 }
 
 // K4: line rows
@@ -102,19 +129,24 @@ k_line_rows(CamD K, double th, int compat, const double* __restrict__ T,
             double* __restrict__ Jp, double* __restrict__ Jl, double* __restrict__ r,
             double* __restrict__ w)
 {
+    __shared__ __attribute__((aligned(16))) double slabs[4][64 * 6];
     const int o = blockIdx.x * 256 + threadIdx.x;
-    if (o >= nobs) return;
-    double R[9], t[3], P[3], Q[3], JP[6], JQ[6], out6[6];
-    const size_t l0 = (size_t)lm[o];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int o0 = o - lane;
+    if (o0 >= nobs) return;
+    const int valid = nobs - o0 < 64 ? nobs - o0 : 64;
+    const int oc = o < nobs ? o : nobs - 1;
+    double R[9], t[3], P[3], Q[3], JP[6], JQ[6], outl[6], outp[6];
+    const size_t l0 = (size_t)lm[oc];
     const double* Pw = compat ? Lw + 3 * l0 : Lw + 6 * l0;
     const double* Qw = compat ? Lw + 3 * l0 : Lw + 6 * l0 + 3;
-    inv_pose(T + 16 * (size_t)kf[o], R, t);
+    inv_pose(T + 16 * (size_t)kf[oc], R, t);
     xform(R, t, Pw, P);
     xform(R, t, Qw, Q);
     double pu, pv, qu, qv;
     project(K, P, pu, pv);
     project(K, Q, qu, qv);
-    const double lx = lobs[3 * (size_t)o], ly = lobs[3 * (size_t)o + 1], lz = lobs[3 * (size_t)o + 2];
+    const double lx = lobs[3 * (size_t)oc], ly = lobs[3 * (size_t)oc + 1], lz = lobs[3 * (size_t)oc + 2];
     const double e0 = lx * pu + ly * pv + lz;
     const double e1 = lx * qu + ly * qv + lz;
     const double nrm = sqrt(e0 * e0 + e1 * e1);
@@ -128,15 +160,17 @@ k_line_rows(CamD K, double th, int compat, const double* __restrict__ T,
     for (int j = 0; j < 3; ++j) {
         const double vp = JP[0] * R[j] + JP[1] * R[3 + j] + JP[2] * R[6 + j];
         const double vq = JQ[0] * R[j] + JQ[1] * R[3 + j] + JQ[2] * R[6 + j];
-        out6[j] = vp * e0 / den;
-        out6[3 + j] = vq * e1 / den;
+        outl[j] = vp * e0 / den;
+        outl[3 + j] = vq * e1 / den;
     }
-    store6(Jl + 6 * (size_t)o, out6);
 #pragma unroll
-    for (int c = 0; c < 6; ++c) out6[c] = (JP[c] * e0 + JQ[c] * e1) / den;
-    store6(Jp + 6 * (size_t)o, out6);
-    r[o] = nrm;
-    w[o] = 1.0 / (1.0 + nrm * nrm);
+    for (int c = 0; c < 6; ++c) outp[c] = (JP[c] * e0 + JQ[c] * e1) / den;
+    wave_store_rows<6>(Jl + 6 * (size_t)o0, outl, slabs[wave], lane, valid);
+    wave_store_rows<6>(Jp + 6 * (size_t)o0, outp, slabs[wave], lane, valid);
+    if (o < nobs) {
+        r[o] = nrm;
+        w[o] = 1.0 / (1.0 + nrm * nrm);
+    }
 }
 
 struct Pose12 { double m[12]; };  // rows 0..2 of the row-major 4x4

@@ -145,6 +145,19 @@ def main():
     out["lba_point_rows_streaming"] = {"rows": nbig, "kernel_us": 1e3 * ms_big,
                                        "GBps_algorithmic": nbig * 152 / (ms_big * 1e-3) / 1e9,
                                        "frac_of_8TBps": nbig * 152 / (ms_big * 1e-3) / 8e12}
+    bigl = {k: torch.cat([v] * reps) for k, v in g.items() if k in ("l_obs", "ls_lm", "ls_kf")}
+    nbl = nls * reps
+    JpL = torch.empty((nbl, 6), dtype=torch.float64, device=dev)
+    JlL = torch.empty((nbl, 6), dtype=torch.float64, device=dev)
+    rL = torch.empty(nbl, dtype=torch.float64, device=dev)
+    wL = torch.empty(nbl, dtype=torch.float64, device=dev)
+    ms_bigl = ev_time(lambda: ctx.lba_line_rows_dev(cam, 1e-7, False, g["T_kf_w"].data_ptr(), g["Lw"].data_ptr(),
+                                                    bigl["l_obs"].data_ptr(), bigl["ls_lm"].data_ptr(),
+                                                    bigl["ls_kf"].data_ptr(), nbl, JpL.data_ptr(), JlL.data_ptr(),
+                                                    rL.data_ptr(), wL.data_ptr(), st), iters=50, warm=5)
+    out["lba_line_rows_streaming"] = {"rows": nbl, "kernel_us": 1e3 * ms_bigl,
+                                      "GBps_algorithmic": nbl * 208 / (ms_bigl * 1e-3) / 1e9,
+                                      "frac_of_8TBps": nbl * 208 / (ms_bigl * 1e-3) / 8e12}
     ctx.close()
     print(json.dumps(out))
 
