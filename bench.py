@@ -76,7 +76,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-gpu", type=int, default=512)
+    ap.add_argument("--pairs-per-gpu", type=int, default=4096,
+                    help="stereo pairs per GPU per step: the device-resident batch (BASELINE config 4: 4096)")
     ap.add_argument("--n-orb", type=int, default=1500)
     ap.add_argument("--n-lbd", type=int, default=200)
     ap.add_argument("--nnr-p", type=float, default=0.75)
@@ -84,6 +85,7 @@ def main():
     ap.add_argument("--scan-variant", type=int, default=0)
     ap.add_argument("--scan-block", type=int, default=0)
     ap.add_argument("--sym-rows", type=int, default=0)
+    ap.add_argument("--group-cap", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the NCCL(RCCL) process group and run the table gather even with one rank")
@@ -136,6 +138,8 @@ def main():
         ctx.set_option("scan_block", args.scan_block)
     if args.sym_rows:
         ctx.set_option("sym_rows", args.sym_rows)
+    if args.group_cap:
+        ctx.set_option("group_cap", args.group_cap)
     bm = frontend.StereoBatchMatcher(ctx, stream, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev,
                                      n_buffers=2 if use_dist else 1)
     info = bm.plan.info()
@@ -214,7 +218,8 @@ def main():
         # process, so the figure comes from the committed rocprofv3 passes of this same command
         # (profiles/pmc_traffic.json) and is reported only for the configuration they were taken on.
         traffic = None
-        wkey = f"C2:{args.n_orb}+{args.n_lbd}:pairs{B}:sym{ctx.get_option('sym_rows')}"
+        wkey = f"C2:{args.n_orb}+{args.n_lbd}:pairs{B}:sym{ctx.get_option('sym_rows')}:cap{ctx.get_option('group_cap')}"
+        # (sym_rows 0 = auto: resolved per plan, reported in config.scan_block_threads: 64 => 4 rows/lane)
         try:
             with open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")) as f:
                 pm = json.load(f)
@@ -246,7 +251,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": "k_scan (Hamming kNN-2)", "kernel_ms": 1e3 * scan_s,
+                "kernel": {3: "k_scan_symmetric" + ("_r4" if info["scan_block_threads"] == 64 else ""),
+                           2: "k_scan_wave_per_query", 1: "k_scan_lane_per_query"}.get(info["scan_variant"], "k_scan"),
+                "kernel_ms": 1e3 * scan_s,
                 "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
                 "note": "compulsory-byte model 32(Q+T)+16Q per directed scan; the kernel is VALU "
                         "(xor+popcount) bound, see valu_roofline",
@@ -259,7 +266,7 @@ def main():
                         "distances the reference evaluates; peak = CUs x 128 lanes/clk x max clock",
                 "evals_per_launch": info["directed_evals"], "executed_evals_per_launch": info["distance_evals"],
             },
-            "kernel_ms": {"scan": scan_ms / max(runs, 1), "finalize": fin_ms / max(runs, 1)},
+            "kernel_ms": {"scan": scan_ms / max(runs, 1), "merge+finalize": fin_ms / max(runs, 1)},
             "device": devinfo["name"],
         }
         if world == 1 and not args.no_cpu_baseline:

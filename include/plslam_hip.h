@@ -83,7 +83,8 @@ int plslam_abi_version(void);
 int plslam_ctx_create(int device_ordinal, plslam_ctx** out);
 void plslam_ctx_destroy(plslam_ctx* ctx);
 /* options: "scan_variant" (PLSLAM_SCAN_*), "scan_block" (queries per workgroup of the directed
- * scan: 256|512|1024), "sym_rows" (rows of d1 per lane in the symmetric scan: 1|4, default 1) */
+ * scan: 256|512|1024), "sym_rows" (rows of d1 per lane in the symmetric scan: 0 = auto (default) | 1 | 4),
+ * "group_cap" (workgroups of one problem co-scheduled on one XCD: 0 = auto (default) | 1..64) */
 int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value);
 int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value);
 /* device facts for reports: CU count, max clock (kHz), LDS bytes per workgroup */
@@ -152,7 +153,8 @@ int plslam_match_plan_run(plslam_match_plan* plan, void* stream);
 /* With profiling on, every run brackets each kernel with HIP events on the launch stream. */
 int plslam_match_plan_set_profiling(plslam_match_plan* plan, int enable);
 /* Synchronises the recorded events and returns accumulated kernel milliseconds since the
- * last call (then resets): scan kernel(s), finalize kernel, number of profiled runs. */
+ * last call (then resets): the scan kernel(s) alone, then everything after them (merge of the
+ * symmetric scan's column partials + finalize), and the number of profiled runs. */
 int plslam_match_plan_elapsed(plslam_match_plan* plan, double* scan_ms, double* finalize_ms,
                               int64_t* runs);
 int plslam_match_plan_info(plslam_match_plan* plan, plslam_plan_info* info);

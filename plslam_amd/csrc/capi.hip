@@ -114,7 +114,17 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
                            (ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_SYMMETRIC);
     auto is_sym = [&](const plslam_match_problem& p) { return allow_sym && p.mutual && p.n1 > 0 && p.n2 > 0; };
 
+    // sym_rows 0 = auto: 4 rows of d1 per lane (4x fewer column partials, slightly faster) once the
+    // plan has enough 256-row waves for >= 6 full rounds of the chip (17 single-wave workgroups fit a
+    // CU's LDS); below that the 4x coarser work units lose more to tail quantisation than they gain
+    // (measured: 266k vs 320k pairs/s at 512 pairs, 347k vs 344k at 2048, 364k vs 347k at 4096).
     P->sym_rows = ctx->sym_rows;
+    if (P->sym_rows == 0) {
+        int64_t waves4 = 0;
+        for (int32_t i = 0; i < nprob; ++i)
+            if (is_sym(probs[i])) waves4 += (probs[i].n1 + 255) / 256;
+        P->sym_rows = waves4 >= 6 * 17 * (int64_t)ctx->prop.multiProcessorCount ? 4 : 1;
+    }
     const int rpp = sym_rows_per_partial(P->sym_rows);   // a-rows per column partial
     const int rps = sym_rows_per_block(P->sym_rows);     // a-rows per workgroup of the symmetric scan
     int64_t rows = 0, part_rows = 0;
@@ -166,6 +176,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->ncounts = nprob;
 
     std::vector<ScanDesc> scans;
+    std::vector<int32_t> scan_problem;   // scans[k] belongs to problem scan_problem[k]
     std::vector<SymDesc> syms;
     std::vector<ProblemDesc> pds;
     std::vector<BlockDesc> sblocks, fblocks, yblocks, mblocks;
@@ -202,6 +213,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
                 ScanDesc sc{p.d1, p.d2, k12, p.n1, p.n2};
                 for (int32_t r0 = 0; r0 < p.n1; r0 += rpb) sblocks.push_back({(int32_t)scans.size(), r0});
                 scans.push_back(sc);
+                scan_problem.push_back(i);
                 evals += (int64_t)p.n1 * p.n2;
                 devals += (int64_t)p.n1 * p.n2;
                 abytes += 32LL * (p.n1 + p.n2) + 16LL * p.n1;
@@ -210,6 +222,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
                 ScanDesc sc{p.d2, p.d1, k21, p.n2, p.n1};
                 for (int32_t r0 = 0; r0 < p.n2; r0 += rpb) sblocks.push_back({(int32_t)scans.size(), r0});
                 scans.push_back(sc);
+                scan_problem.push_back(i);
                 evals += (int64_t)p.n1 * p.n2;
                 devals += (int64_t)p.n1 * p.n2;
                 abytes += 32LL * (p.n1 + p.n2) + 16LL * p.n2;
@@ -217,35 +230,57 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         }
         pds.push_back(pd);
     }
-    // Longest-first scheduling.  The scan kernels walk the block table through xcd_remap(): XCD x
-    // owns one contiguous range of the table and dispatches it in order.  Deal the blocks out by
-    // descending train-stream length (round-robin over the 8 ranges) so that every XCD runs its
-    // long blocks (ORB) first and the short ones (LBD) fill the drain phase of the launch.
-    auto longest_first = [](std::vector<BlockDesc>& blocks, auto cost_of) {
-        const size_t n = blocks.size();
-        if (n < 16) return;
-        std::vector<size_t> order(n);
-        for (size_t i = 0; i < n; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(),
-                         [&](size_t a, size_t b) { return cost_of(blocks[a]) > cost_of(blocks[b]); });
-        const size_t q = n / 8, r = n % 8;                 // range of XCD x: as in xcd_remap()
-        std::vector<BlockDesc> out(n);
-        size_t fill[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // XCD-striped, longest-first block tables.  Hardware places workgroup b on XCD b % 8 and
+    // dispatches in increasing b, and the scan kernels read table entry (b % 8) * L + b / 8, so row x
+    // of the table (L entries) is XCD x's work in dispatch order.  Blocks are dealt out in GROUPS
+    // (the blocks of one problem, at most 8: they stream the same descriptor sets, so they should
+    // share one XCD's L2 at the same time), groups in descending train-stream length so that every
+    // XCD runs its long blocks (ORB) first and the short ones (LBD) fill the drain phase.  Rows are
+    // padded to equal length with no-op entries (item = -1).
+    struct Group { int64_t cost; int32_t first, count; };
+    auto stripe = [](std::vector<BlockDesc>& blocks, std::vector<Group> groups) {
+        std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.cost > b.cost; });
+        std::vector<BlockDesc> rows[8];
         size_t x = 0;
-        for (size_t k = 0; k < n; ++k) {
-            // next XCD (round-robin) that still has room in its range
-            for (size_t tries = 0; tries < 8; ++tries, x = (x + 1) & 7) {
-                const size_t len = q + (x < r ? 1 : 0);
-                if (fill[x] < len) break;
+        for (const Group& g : groups) {
+            // next XCD round-robin, but prefer the currently shortest row among the next candidates
+            size_t best = x;
+            for (size_t t = 0; t < 8; ++t) {
+                const size_t c = (x + t) & 7;
+                if (rows[c].size() < rows[best].size()) best = c;
             }
-            const size_t base = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
-            out[base + fill[x]++] = blocks[order[k]];
-            x = (x + 1) & 7;
+            for (int32_t k = 0; k < g.count; ++k) rows[best].push_back(blocks[(size_t)g.first + k]);
+            x = (best + 1) & 7;
         }
+        size_t L = 0;
+        for (auto& r : rows) L = std::max(L, r.size());
+        std::vector<BlockDesc> out(8 * L, BlockDesc{-1, 0});
+        for (size_t c = 0; c < 8; ++c)
+            for (size_t k = 0; k < rows[c].size(); ++k) out[c * L + k] = rows[c][k];
         blocks.swap(out);
     };
-    longest_first(yblocks, [&](const BlockDesc& b) { return (int64_t)syms[b.item].n2; });
-    if (!use_wpq) longest_first(sblocks, [&](const BlockDesc& b) { return (int64_t)scans[b.item].nt; });
+    // group_cap: measured on MI355X (512 / 2048 pairs per step): 1 -> 321k / 343k pairs/s with 2.55 GB of
+    // HBM reads per 2048-pair launch; 2 -> 317k / 343k; >= 3 -> 310k / 335k (many waves streaming the same
+    // rows at the same moment contend for the same cache lines) with 0.67 GB of reads.  Default 2.
+    // For the 4-rows-per-lane kernel the cap is speed-neutral (364.7k / 364.9k / 364.4k / 365.9k pairs/s at
+    // cap 1 / 2 / 3 / 6), so its groups keep a whole problem together.  0 = auto.
+    const size_t group_cap = ctx->group_cap > 0 ? (size_t)ctx->group_cap : (P->sym_rows == 4 ? 8 : 2);
+    auto groups_of = [group_cap](const std::vector<BlockDesc>& blocks, auto key_of, auto cost_of) {
+        std::vector<Group> gs;
+        for (size_t i = 0; i < blocks.size();) {
+            size_t j = i;
+            while (j < blocks.size() && j - i < group_cap && key_of(blocks[j]) == key_of(blocks[i])) ++j;
+            gs.push_back({cost_of(blocks[i]), (int32_t)i, (int32_t)(j - i)});
+            i = j;
+        }
+        return gs;
+    };
+    if (!yblocks.empty())
+        stripe(yblocks, groups_of(yblocks, [](const BlockDesc& b) { return b.item; },
+                                  [&](const BlockDesc& b) { return (int64_t)syms[b.item].n2; }));
+    if (!use_wpq && !sblocks.empty())   // the two directed scans of a mutual problem are adjacent: same group key
+        stripe(sblocks, groups_of(sblocks, [&](const BlockDesc& b) { return scan_problem[b.item]; },
+                                  [&](const BlockDesc& b) { return (int64_t)scans[b.item].nt; }));
 
     P->nscan = (int32_t)scans.size();
     P->nscan_blocks = (int32_t)sblocks.size();
@@ -324,9 +359,9 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
                         sym_first ? 0 : P->ncounts, s);
         if (r) return r;
     }
+    if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e1, s));   // e0..e1 = the scan kernel(s) alone
     r = launch_merge_partials(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s);
     if (r) return r;
-    if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e1, s));
     r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, s);
     if (r) return r;
     if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e2, s));
@@ -430,8 +465,13 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         return PLSLAM_OK;
     }
     if (!strcmp(key, "sym_rows")) {
-        PLSLAM_REQUIRE(value == 1 || value == 4, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(value == 0 || value == 1 || value == 4, PLSLAM_EINVAL);
         ctx->sym_rows = value;
+        return PLSLAM_OK;
+    }
+    if (!strcmp(key, "group_cap")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= 64, PLSLAM_EINVAL);
+        ctx->group_cap = value;
         return PLSLAM_OK;
     }
     set_last_error("unknown option '%s'", key);
@@ -444,6 +484,7 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "scan_variant")) { *value = ctx->scan_variant; return PLSLAM_OK; }
     if (!strcmp(key, "scan_block")) { *value = ctx->scan_block; return PLSLAM_OK; }
     if (!strcmp(key, "sym_rows")) { *value = ctx->sym_rows; return PLSLAM_OK; }
+    if (!strcmp(key, "group_cap")) { *value = ctx->group_cap; return PLSLAM_OK; }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }
@@ -632,6 +673,12 @@ int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const 
     if ((r = ctx->out_b.reserve((size_t)nq * 8))) return r;                  // dist
     std::vector<BlockDesc> blocks;
     for (int32_t r0 = 0; r0 < nq; r0 += rpb) blocks.push_back({0, r0});
+    if (variant == PLSLAM_SCAN_LANE_PER_QUERY) {   // the kernel reads the XCD-striped layout (8 rows of L)
+        const size_t n = blocks.size(), L = (n + 7) / 8;
+        std::vector<BlockDesc> striped(8 * L, BlockDesc{-1, 0});
+        for (size_t i = 0; i < n; ++i) striped[(i & 7) * L + (i >> 3)] = blocks[i];
+        blocks.swap(striped);
+    }
     if ((r = ctx->misc_b.reserve(sizeof(ScanDesc) + 16))) return r;
     if ((r = ctx->misc_c.reserve(blocks.size() * sizeof(BlockDesc)))) return r;
     ScanDesc sd{ctx->in_a.as<uint8_t>(), ctx->in_b.as<uint8_t>(), ctx->misc_a.as<uint32_t>(), nq, nt};

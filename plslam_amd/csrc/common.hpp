@@ -51,7 +51,8 @@ struct plslam_ctx {
     hipDeviceProp_t prop;
     int scan_variant = PLSLAM_SCAN_AUTO;
     int scan_block = 0;  // 0 = variant default
-    int sym_rows = 1;    // rows of d1 per lane in the symmetric scan (1 or 4); see DESIGN.md section 5
+    int group_cap = 0;   // blocks of one problem kept together on one XCD; 0 = auto (capi.hip, `stripe`)
+    int sym_rows = 0;    // rows of d1 per lane in the symmetric scan: 0 = auto, 1, 4
     std::mutex mu;       // serialises the host-pointer entry points
     plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
     struct plslam_match_plan* host_plan = nullptr;  // reused by the host-pointer match entry points

@@ -84,15 +84,13 @@ __device__ __forceinline__ void best2_merge(uint32_t& a0, uint32_t& a1, uint32_t
               bcnt_acc(q[2] ^ (tp)[2],                                                           \
                 bcnt_acc(q[1] ^ (tp)[1], bcnt_acc(q[0] ^ (tp)[0], bias))))))))
 
-// XCD-aware workgroup remap (bijective for any grid size): hardware places block b on XCD b % 8;
-// give each XCD a contiguous range of work items so that the workgroups of one scan -- which
-// stream the same train set -- share one XCD's L2.
+// XCD-striped block tables: hardware places workgroup b on XCD b % 8 and dispatches in increasing
+// b; the host lays the table out as 8 rows of L = gridDim.x / 8 entries, row x = the work of XCD x in
+// dispatch order (capi.hip, `stripe`), so the blocks of one problem -- which stream the same
+// descriptor sets -- sit on one XCD's L2 at the same time.  Rows are padded with item = -1.
 __device__ __forceinline__ int xcd_remap(int orig, int nwg)
 {
-    const int xcd = orig & 7;
-    const int q = nwg >> 3, r = nwg & 7;
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + (orig >> 3);
+    return (orig & 7) * (nwg >> 3) + (orig >> 3);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -112,6 +110,7 @@ k_scan_lane_per_query(const ScanDesc* __restrict__ scans, const BlockDesc* __res
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const BlockDesc bd = blocks[wg];
+    if (bd.item < 0) return;                       // padding entry of the XCD-striped table
     const ScanDesc sc = scans[bd.item];
     const int nq = sc.nq, nt = sc.nt;
     const int row = bd.row0 + (int)threadIdx.x;
@@ -307,6 +306,7 @@ k_scan_symmetric(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const BlockDesc bd = blocks[wg];
+    if (bd.item < 0) return;                       // padding entry of the XCD-striped table
     const SymDesc sd = syms[bd.item];
     const int n1 = sd.n1, n2 = sd.n2;
     const int lane = threadIdx.x & 63;
@@ -380,7 +380,7 @@ k_scan_symmetric(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// K1b'  symmetric scan, FOUR rows of `a` per lane (option sym_rows = 4; not the default).  Any VALU op with an SGPR source
+// K1b'  symmetric scan, FOUR rows of `a` per lane (sym_rows = 4; chosen automatically for large plans).  Any VALU op with an SGPR source
 // issues at the slow rate on gfx950 (4.1 vs 2.4 cycles, profiles/r1_valu_microbench.txt), and the
 // train row lives in SGPRs.  With rows q0..q3 in one lane,  q_r ^ t = (q0 ^ t) ^ (q0 ^ q_r):  only
 // the first XOR touches the SGPRs, the other three use a per-lane constant c_r = q0 ^ q_r and run
@@ -390,9 +390,9 @@ k_scan_symmetric(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__
 // with the packed 16-bit keys, the four row-blocks are combined across lanes, and ONE partial per
 // 256 rows of `a` is written (4x fewer partials than K1b).
 // MEASURED (profiles/r1_valu_microbench.txt, "alt xor(v,v)/bcnt"): a fast op alternating with a slow
-// one issues at the slow rate, so the compiler-interleaved stream gains nothing over K1b (341k vs
-// 343k pairs/s at 2048 pairs/step) and the 4x coarser work units lose to tail quantisation at 512
-// pairs/step.  Kept selectable for the 4x smaller partial table.
+// one issues at nearly the slow rate, so the VALU gain is small; what pays is the 4x smaller partial
+// table and merge: 364k vs 347k pairs/s at 4096 pairs/step, 347k vs 344k at 2048 -- but 266k vs 320k
+// at 512, where the 4x coarser work units lose to tail quantisation.  The plan picks (capi.hip).
 // ---------------------------------------------------------------------------------------------
 constexpr int SYM4_SUBTILE_U16 = 16 * SYM_TILE_ROW_U16;      // 16 b-rows x 144 B = 2304 B per row-block
 
@@ -407,6 +407,7 @@ k_scan_symmetric_r4(const SymDesc* __restrict__ syms, const BlockDesc* __restric
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const BlockDesc bd = blocks[wg];
+    if (bd.item < 0) return;                       // padding entry of the XCD-striped table
     const SymDesc sd = syms[bd.item];
     const int n1 = sd.n1, n2 = sd.n2;
     const int lane = threadIdx.x;

@@ -92,7 +92,7 @@ def test_symmetric_and_directed_variants_agree(ctx, oracle, n1, n2):
                 assert np.array_equal(m, em) and n == en, (variant, sym_rows, gen.__name__)
         finally:
             ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
-            ctx.set_option("sym_rows", 1)
+            ctx.set_option("sym_rows", 0)
 
 
 def test_all_scan_block_sizes(ctx, oracle):
