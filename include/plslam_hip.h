@@ -213,6 +213,27 @@ int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, int32_t nls,
                         const double* ls_r, const double* ls_w, double* g, double* H_pose,
                         double* H_pt, double* H_ls, double* W_pt, double* W_ls, double* err);
 
+/* LBA plan: levMarquardtOptimizationLBA rebuilds rows + H/g once (:1358-1540) and then up to
+ * max_iters_lba = 15 times (:1587-1772) while only X changes.  The plan uploads what is constant --
+ * the Vector6i columns lm_loc (1) / kf_loc (4), the pose slot of each observation, the observations
+ * themselves -- once; iterate() uploads poses (n_pose_slots*16, e.g. expmap_se3 of X, :1600-1603) and
+ * landmarks (X.block(6Nkf..), :1597, :1678), runs K3/K4 and K7-K10 on the device and returns the
+ * block-form normal equations (layout as plslam_lba_assemble). */
+typedef struct plslam_lba_plan plslam_lba_plan;
+int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, double homog_th, int32_t n_pose_slots,
+                           int32_t nkf, int32_t npt, int32_t nls, const int32_t* pt_lm_loc,
+                           const int32_t* pt_pose_slot, const int32_t* pt_kf_loc, const double* pt_obs_uv,
+                           int32_t n_pt_obs, const int32_t* ls_lm_loc, const int32_t* ls_pose_slot,
+                           const int32_t* ls_kf_loc, const double* ls_l_obs, int32_t n_ls_obs,
+                           plslam_lba_plan** out);
+int plslam_lba_plan_iterate(plslam_lba_plan* plan, const double* T_kf_w, const double* Xw, const double* Lw,
+                            int compat_iter_pass, double* g, double* H_pose, double* H_pt, double* H_ls,
+                            double* W_pt, double* W_ls, double* err);
+/* rows of the last iterate() (any pointer may be NULL), e.g. for the write-back logic of :1822-1855 */
+int plslam_lba_plan_rows(plslam_lba_plan* plan, double* pt_J_pose, double* pt_J_lm, double* pt_r, double* pt_w,
+                         double* ls_J_pose, double* ls_J_lm, double* ls_r, double* ls_w);
+void plslam_lba_plan_destroy(plslam_lba_plan* plan);
+
 /* ---- K5/K6: map <-> keyframe geometric gates (the inlier masks) -------------------------- */
 /* Points: src/mapHandler.cpp:601-613.  mask[i] = 1 iff matches_12[i] >= 0 and
  * || proj(Twf * Xw[i]) - pl[matches_12[i]] ||_2 < max_epip.  Twf: 16 doubles row-major.

@@ -28,7 +28,8 @@ ABI_SYMBOLS = (
     "plslam_match_plan_create", "plslam_match_plan_run", "plslam_match_plan_set_profiling",
     "plslam_match_plan_elapsed", "plslam_match_plan_info", "plslam_match_plan_destroy",
     "plslam_lba_point_rows", "plslam_lba_line_rows", "plslam_lba_point_rows_dev",
-    "plslam_lba_line_rows_dev", "plslam_lba_assemble",
+    "plslam_lba_line_rows_dev", "plslam_lba_assemble", "plslam_lba_plan_create", "plslam_lba_plan_iterate",
+    "plslam_lba_plan_rows", "plslam_lba_plan_destroy",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
     "plslam_gather_match_tables",
@@ -134,6 +135,12 @@ def load() -> C.CDLL:
                                            vp, vp, vp, vp, vp]
     L.plslam_lba_assemble.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp,
                                       vp, vp, vp, vp, vp, vp, vp]
+    L.plslam_lba_plan_create.argtypes = [vp, C.POINTER(Cam), f64, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp,
+                                         i32, C.POINTER(vp)]
+    L.plslam_lba_plan_iterate.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    L.plslam_lba_plan_rows.argtypes = [vp] * 9
+    L.plslam_lba_plan_destroy.argtypes = [vp]
+    L.plslam_lba_plan_destroy.restype = None
     for f in (L.plslam_map2kf_point_gate, L.plslam_map2kf_line_gate):
         f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, i32, vp, i32, f64, vp, C.POINTER(i32)]
     for f in (L.plslam_map_point_visible, L.plslam_map_line_visible):
@@ -145,7 +152,7 @@ def load() -> C.CDLL:
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if name not in ("plslam_strerror", "plslam_last_error", "plslam_ctx_destroy",
-                        "plslam_match_plan_destroy"):
+                        "plslam_match_plan_destroy", "plslam_lba_plan_destroy"):
             f.restype = C.c_int
     _lib = L
     return L
@@ -362,6 +369,57 @@ class Context:
 
     def plan(self, problems) -> "MatchPlan":
         return MatchPlan(self, problems)
+
+
+class LbaPlan:
+    """plslam_lba_plan: observation lists uploaded once, iterate(T_kf_w, Xw, Lw) per LM iteration."""
+
+    def __init__(self, ctx: Context, cam: Cam, homog_th, n_pose_slots, nkf, npt, nls, pt_lm, pt_slot, pt_kf_loc,
+                 pt_obs_uv, ls_lm, ls_slot, ls_kf_loc, ls_l_obs):
+        self._L = ctx._L
+        self._ctx = ctx
+        a = [_arr(x, np.int32) for x in (pt_lm, pt_slot, pt_kf_loc)]
+        b = [_arr(x, np.int32) for x in (ls_lm, ls_slot, ls_kf_loc)]
+        uv, lo = _arr(pt_obs_uv, np.float64, (-1, 2)), _arr(ls_l_obs, np.float64, (-1, 3))
+        self.dims = (int(nkf), int(npt), int(nls), uv.shape[0], lo.shape[0], int(n_pose_slots))
+        h = C.c_void_p()
+        _check(self._L.plslam_lba_plan_create(ctx.handle, C.byref(cam), float(homog_th), int(n_pose_slots), int(nkf),
+                                              int(npt), int(nls), _p(a[0]), _p(a[1]), _p(a[2]), _p(uv), uv.shape[0],
+                                              _p(b[0]), _p(b[1]), _p(b[2]), _p(lo), lo.shape[0], C.byref(h)),
+               "plslam_lba_plan_create")
+        self._h = h
+
+    def iterate(self, T_kf_w, Xw, Lw, compat_iter_pass=False):
+        nkf, npt, nls, npo, nlo, nslot = self.dims
+        T = _arr(T_kf_w, np.float64, (-1, 16))
+        X, Lm = _arr(Xw, np.float64, (-1, 3)), _arr(Lw, np.float64, (-1, 6))
+        assert T.shape[0] == nslot and X.shape[0] == npt and Lm.shape[0] == nls
+        N = 6 * nkf + 3 * npt + 6 * nls
+        g, Hp = np.empty(N), np.empty((nkf, 6, 6))
+        Hpt, Hls = np.empty((npt, 3, 3)), np.empty((nls, 6, 6))
+        Wp, Wl = np.empty((npo, 3, 6)), np.empty((nlo, 6, 6))
+        err = np.empty(1)
+        _check(self._L.plslam_lba_plan_iterate(self._h, _p(T), _p(X), _p(Lm), int(bool(compat_iter_pass)), _p(g), _p(Hp),
+                                               _p(Hpt), _p(Hls), _p(Wp), _p(Wl), _p(err)), "plslam_lba_plan_iterate")
+        return dict(g=g, H_pose=Hp, H_pt=Hpt, H_ls=Hls, W_pt=Wp, W_ls=Wl, err=float(err[0]))
+
+    def rows(self):
+        nkf, npt, nls, npo, nlo, _ = self.dims
+        pr = [np.empty((npo, 6)), np.empty((npo, 3)), np.empty(npo), np.empty(npo)]
+        lr = [np.empty((nlo, 6)), np.empty((nlo, 6)), np.empty(nlo), np.empty(nlo)]
+        _check(self._L.plslam_lba_plan_rows(self._h, *[_p(x) for x in pr + lr]), "plslam_lba_plan_rows")
+        return pr, lr
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.plslam_lba_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class MatchPlan:

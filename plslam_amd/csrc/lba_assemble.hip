@@ -4,14 +4,19 @@
 // (src/mapHandler.cpp:1410-1429 for points, :1519-1538 for lines) and then takes H.sparseView()
 // (:1555).  H has a fixed block structure -- one 6x6 block per optimised keyframe, one 3x3 / 6x6
 // block per landmark, one 3x6 / 6x6 cross block per observation -- so this file produces exactly
-// those blocks (the Schur-complement-ready layout) and g, with the reference's accumulation ORDER:
-// each entry is the sequential sum over the observations in list order, so the blocks are bit-exact
-// against the dense accumulation.  No atomics (they would make the sums order-dependent).
+// those blocks (the Schur-complement-ready layout) and g.  Landmark and cross blocks keep the
+// reference's accumulation ORDER (sequential over the landmark's observations in list order), so
+// they are bit-exact against the dense accumulation; the keyframe blocks, which sum thousands of
+// observations, use a fixed-shape two-level sum (deterministic, equal up to rounding).  No atomics
+// (they would make the sums depend on scheduling).
 //   K7  k_landmark_blocks<DL>   one lane per landmark: H_ll (DLxDL), g_l (DL) over its observations
 //   K8  k_cross_blocks<DL>      one lane per observation: W = J_lm * J_pose^T * w (DLx6)
-//   K9  k_pose_blocks           one lane per (keyframe, entry): H_pp (6x6) and g_p (6) over the
-//                                keyframe's observations (points first, then lines, list order)
+//   K9  k_pose_partials/_blocks one lane per (keyframe, chunk, entry) then per (keyframe, entry):
+//                                H_pp (6x6) and g_p (6) over the keyframe's observations (points
+//                                first, then lines, list order; 128-observation chunks)
 //   K10 k_weighted_error        err = sum r^2 w (fixed-shape tree: deterministic, not sequential)
+#include <algorithm>
+#include <new>
 #include <vector>
 
 #include "common.hpp"
@@ -70,18 +75,27 @@ k_cross_blocks(const int32_t* __restrict__ kf_loc, int32_t nobs, const double* _
     }
 }
 
-// entry e of keyframe k: e < 36 -> H_pp[k][e/6][e%6]; e >= 36 -> g_p[k][e-36]
+// entry e of keyframe k: e < 36 -> H_pp[k][e/6][e%6]; e >= 36 -> g_p[k][e-36].
+// Two-level, fixed-shape (deterministic) summation: chunk c of keyframe k sums observations
+// [c*POSE_CHUNK, (c+1)*POSE_CHUNK) of the keyframe's list sequentially in list order, then the chunk
+// partials are summed sequentially in chunk order.  (A single sequential chain over the ~6700
+// observations of a C3 keyframe is bit-identical to the reference's dense accumulation but takes
+// 1.9 ms on 9 workgroups; this takes microseconds and differs from it by rounding only.)
+constexpr int POSE_CHUNK = 128;
+
 __global__ void __launch_bounds__(64)
-k_pose_blocks(const int32_t* __restrict__ kf_ptr, const int32_t* __restrict__ kf_obs, int32_t n_pt_obs,
-              const double* __restrict__ Jp_pt, const double* __restrict__ r_pt, const double* __restrict__ w_pt,
-              const double* __restrict__ Jp_ls, const double* __restrict__ r_ls, const double* __restrict__ w_ls,
-              double* __restrict__ Hpp, double* __restrict__ gp)
+k_pose_partials(const int32_t* __restrict__ kf_ptr, const int32_t* __restrict__ kf_obs, int32_t n_pt_obs,
+                const double* __restrict__ Jp_pt, const double* __restrict__ r_pt, const double* __restrict__ w_pt,
+                const double* __restrict__ Jp_ls, const double* __restrict__ r_ls, const double* __restrict__ w_ls,
+                int32_t max_chunks, double* __restrict__ part /* [nkf][max_chunks][42] */)
 {
-    const int k = blockIdx.x, e = threadIdx.x;
+    const int k = blockIdx.x, c = blockIdx.y, e = threadIdx.x;
     if (e >= 42) return;
+    const int beg = kf_ptr[k] + c * POSE_CHUNK;
+    const int end = beg + POSE_CHUNK < kf_ptr[k + 1] ? beg + POSE_CHUNK : kf_ptr[k + 1];
     const int a = e < 36 ? e / 6 : e - 36, b = e < 36 ? e % 6 : 0;
     double acc = 0.0;
-    for (int i = kf_ptr[k]; i < kf_ptr[k + 1]; ++i) {
+    for (int i = beg; i < end; ++i) {
         const int o = kf_obs[i];       // global observation id: points [0, n_pt_obs), then lines
         const bool pt = o < n_pt_obs;
         const int oo = pt ? o : o - n_pt_obs;
@@ -90,8 +104,20 @@ k_pose_blocks(const int32_t* __restrict__ kf_ptr, const int32_t* __restrict__ kf
         if (e < 36) acc += J[a] * J[b] * ww;
         else acc += J[a] * (pt ? r_pt : r_ls)[oo] * ww;
     }
+    part[((size_t)k * max_chunks + c) * 42 + e] = acc;   // empty chunks write 0
+}
+
+__global__ void __launch_bounds__(64)
+k_pose_blocks(const int32_t* __restrict__ kf_ptr, int32_t max_chunks, const double* __restrict__ part,
+              double* __restrict__ Hpp, double* __restrict__ gp)
+{
+    const int k = blockIdx.x, e = threadIdx.x;
+    if (e >= 42) return;
+    const int nchunks = (kf_ptr[k + 1] - kf_ptr[k] + POSE_CHUNK - 1) / POSE_CHUNK;
+    double acc = 0.0;
+    for (int c = 0; c < nchunks; ++c) acc += part[((size_t)k * max_chunks + c) * 42 + e];
     if (e < 36) Hpp[(size_t)k * 36 + e] = acc;
-    else gp[(size_t)k * 6 + a] = acc;
+    else gp[(size_t)k * 6 + (e - 36)] = acc;
 }
 
 __global__ void __launch_bounds__(256)
@@ -120,7 +146,252 @@ struct Carve {
 }  // namespace
 }  // namespace plslam
 
+namespace plslam {
+
+// all pointers on the device; CSR lists as built by build_csr().  Asynchronous on `s`.
+struct AssembleDev {
+    const int32_t *pt_kf_loc, *ls_kf_loc, *pt_ptr, *pt_ids, *ls_ptr, *ls_ids, *kf_ptr, *kf_ids;
+    const double *pt_Jp, *pt_Jl, *pt_r, *pt_w, *ls_Jp, *ls_Jl, *ls_r, *ls_w;
+    double *g, *H_pose, *H_pt, *H_ls, *W_pt, *W_ls, *err;
+    double* pose_part;      // [nkf][max_chunks][42] scratch
+    int32_t max_chunks;     // max over keyframes of ceil(#observations / POSE_CHUNK)
+};
+
+static int assemble_on_device(const AssembleDev& a, int32_t nkf, int32_t npt, int32_t nls, int32_t n_pt_obs,
+                              int32_t n_ls_obs, hipStream_t s)
+{
+    // g layout = the reference's X layout: [6*nkf poses | 3*npt points | 6*nls lines]
+    if (npt)
+        hipLaunchKernelGGL(k_landmark_blocks<3>, dim3((npt + 255) / 256), dim3(256), 0, s, a.pt_ptr, a.pt_ids, npt,
+                           a.pt_Jl, a.pt_r, a.pt_w, a.H_pt, a.g + 6 * (size_t)nkf);
+    if (nls)
+        hipLaunchKernelGGL(k_landmark_blocks<6>, dim3((nls + 255) / 256), dim3(256), 0, s, a.ls_ptr, a.ls_ids, nls,
+                           a.ls_Jl, a.ls_r, a.ls_w, a.H_ls, a.g + 6 * (size_t)nkf + 3 * (size_t)npt);
+    if (n_pt_obs)
+        hipLaunchKernelGGL(k_cross_blocks<3>, dim3((n_pt_obs + 255) / 256), dim3(256), 0, s, a.pt_kf_loc, n_pt_obs,
+                           a.pt_Jp, a.pt_Jl, a.pt_w, a.W_pt);
+    if (n_ls_obs)
+        hipLaunchKernelGGL(k_cross_blocks<6>, dim3((n_ls_obs + 255) / 256), dim3(256), 0, s, a.ls_kf_loc, n_ls_obs,
+                           a.ls_Jp, a.ls_Jl, a.ls_w, a.W_ls);
+    if (nkf) {
+        if (a.max_chunks > 0)
+            hipLaunchKernelGGL(k_pose_partials, dim3(nkf, a.max_chunks), dim3(64), 0, s, a.kf_ptr, a.kf_ids, n_pt_obs,
+                               a.pt_Jp, a.pt_r, a.pt_w, a.ls_Jp, a.ls_r, a.ls_w, a.max_chunks, a.pose_part);
+        hipLaunchKernelGGL(k_pose_blocks, dim3(nkf), dim3(64), 0, s, a.kf_ptr, a.max_chunks, a.pose_part, a.H_pose, a.g);
+    }
+    hipLaunchKernelGGL(k_weighted_error, dim3(1), dim3(256), 0, s, a.pt_r, a.pt_w, n_pt_obs, a.ls_r, a.ls_w, n_ls_obs,
+                       a.err);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+// stable CSR lists (host, O(nobs)): observations per landmark and per keyframe, list order; keyframe
+// lists hold points first, then lines (global ids: points [0, n_pt_obs), lines n_pt_obs + o)
+struct CsrLists { std::vector<int32_t> ptp, pti, lsp, lsi, kfp, kfi; };
+static void build_csr(const int32_t* pt_lm, const int32_t* pt_kf, int32_t np, const int32_t* ls_lm,
+                      const int32_t* ls_kf, int32_t nl, int32_t nkf, int32_t npt, int32_t nls, CsrLists& c)
+{
+    auto by = [](const int32_t* key, int32_t n, int32_t nkeys, std::vector<int32_t>& ptr, std::vector<int32_t>& ids) {
+        ptr.assign((size_t)nkeys + 1, 0);
+        for (int32_t o = 0; o < n; ++o) ++ptr[key[o] + 1];
+        for (int32_t k = 0; k < nkeys; ++k) ptr[k + 1] += ptr[k];
+        ids.assign((size_t)ptr[nkeys], 0);
+        std::vector<int32_t> pos(ptr.begin(), ptr.end() - 1);
+        for (int32_t o = 0; o < n; ++o) ids[pos[key[o]]++] = o;
+    };
+    by(pt_lm, np, npt, c.ptp, c.pti);
+    by(ls_lm, nl, nls, c.lsp, c.lsi);
+    c.kfp.assign((size_t)nkf + 1, 0);
+    for (int32_t o = 0; o < np; ++o) if (pt_kf[o] >= 0) ++c.kfp[pt_kf[o] + 1];
+    for (int32_t o = 0; o < nl; ++o) if (ls_kf[o] >= 0) ++c.kfp[ls_kf[o] + 1];
+    for (int32_t k = 0; k < nkf; ++k) c.kfp[k + 1] += c.kfp[k];
+    c.kfi.assign((size_t)c.kfp[nkf], 0);
+    std::vector<int32_t> pos(c.kfp.begin(), c.kfp.end() - 1);
+    for (int32_t o = 0; o < np; ++o) if (pt_kf[o] >= 0) c.kfi[pos[pt_kf[o]]++] = o;
+    for (int32_t o = 0; o < nl; ++o) if (ls_kf[o] >= 0) c.kfi[pos[ls_kf[o]]++] = np + o;
+}
+
+static int32_t pose_max_chunks(const std::vector<int32_t>& kfp)
+{
+    int32_t m = 0;
+    for (size_t k = 0; k + 1 < kfp.size(); ++k) m = std::max(m, (kfp[k + 1] - kfp[k] + POSE_CHUNK - 1) / POSE_CHUNK);
+    return m;
+}
+
+}  // namespace plslam
+
 using namespace plslam;
+
+// ---------------------------------------------------------------------------------------------
+// LBA plan: the LM loop of levMarquardtOptimizationLBA rebuilds rows + H/g up to max_iters_lba = 15
+// times per call (src/mapHandler.cpp:1358-1540 once, :1587-1772 per iteration) while only X (poses,
+// landmarks) changes.  The plan uploads the observation lists, the observations and the CSR lists
+// once; iterate() uploads X, runs K3/K4 and K7-K10 device-resident and downloads the blocks.
+// ---------------------------------------------------------------------------------------------
+struct plslam_lba_plan {
+    plslam_ctx* ctx = nullptr;
+    plslam_cam cam{};
+    double th = 0;
+    int32_t n_slots = 0, nkf = 0, npt = 0, nls = 0, np = 0, nl = 0;
+    DevBuf stat, dyn, rows, out;   // static lists / X / row arrays / blocks
+    // offsets
+    size_t oPlm = 0, oPslot = 0, oPkf = 0, oPuv = 0, oLlm = 0, oLslot = 0, oLkf = 0, oLobs = 0, oPtp = 0, oPti = 0,
+           oLsp = 0, oLsi = 0, oKfp = 0, oKfi = 0;
+    size_t oT = 0, oX = 0, oL = 0;
+    size_t oPJp = 0, oPJl = 0, oPr = 0, oPw = 0, oLJp = 0, oLJl = 0, oLr = 0, oLw = 0;
+    size_t oG = 0, oHp = 0, oHpt = 0, oHls = 0, oWp = 0, oWl = 0, oErr = 0, oPart = 0;
+    int32_t max_chunks = 0;
+};
+
+extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, double homog_th, int32_t n_pose_slots,
+                                      int32_t nkf, int32_t npt, int32_t nls, const int32_t* pt_lm_loc,
+                                      const int32_t* pt_pose_slot, const int32_t* pt_kf_loc, const double* pt_obs_uv,
+                                      int32_t n_pt_obs, const int32_t* ls_lm_loc, const int32_t* ls_pose_slot,
+                                      const int32_t* ls_kf_loc, const double* ls_l_obs, int32_t n_ls_obs,
+                                      plslam_lba_plan** out)
+{
+    PLSLAM_REQUIRE(ctx && K && out && n_pose_slots >= 0 && nkf >= 0 && npt >= 0 && nls >= 0, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(n_pt_obs >= 0 && n_ls_obs >= 0, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(n_pt_obs == 0 || (pt_lm_loc && pt_pose_slot && pt_kf_loc && pt_obs_uv), PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(n_ls_obs == 0 || (ls_lm_loc && ls_pose_slot && ls_kf_loc && ls_l_obs), PLSLAM_EINVAL);
+    *out = nullptr;
+    for (int32_t o = 0; o < n_pt_obs; ++o)
+        PLSLAM_REQUIRE(pt_lm_loc[o] >= 0 && pt_lm_loc[o] < npt && pt_kf_loc[o] >= -1 && pt_kf_loc[o] < nkf &&
+                       pt_pose_slot[o] >= 0 && pt_pose_slot[o] < n_pose_slots, PLSLAM_EINVAL);
+    for (int32_t o = 0; o < n_ls_obs; ++o)
+        PLSLAM_REQUIRE(ls_lm_loc[o] >= 0 && ls_lm_loc[o] < nls && ls_kf_loc[o] >= -1 && ls_kf_loc[o] < nkf &&
+                       ls_pose_slot[o] >= 0 && ls_pose_slot[o] < n_pose_slots, PLSLAM_EINVAL);
+    plslam_lba_plan* P = new (std::nothrow) plslam_lba_plan();
+    PLSLAM_REQUIRE(P != nullptr, PLSLAM_ENOMEM);
+    P->ctx = ctx; P->cam = *K; P->th = homog_th; P->n_slots = n_pose_slots; P->nkf = nkf; P->npt = npt; P->nls = nls;
+    P->np = n_pt_obs; P->nl = n_ls_obs;
+    CsrLists c;
+    build_csr(pt_lm_loc, pt_kf_loc, n_pt_obs, ls_lm_loc, ls_kf_loc, n_ls_obs, nkf, npt, nls, c);
+    const size_t np = (size_t)n_pt_obs, nl = (size_t)n_ls_obs;
+    Carve cs;
+    P->oPlm = cs.take(np * 4); P->oPslot = cs.take(np * 4); P->oPkf = cs.take(np * 4); P->oPuv = cs.take(np * 16);
+    P->oLlm = cs.take(nl * 4); P->oLslot = cs.take(nl * 4); P->oLkf = cs.take(nl * 4); P->oLobs = cs.take(nl * 24);
+    P->oPtp = cs.take(c.ptp.size() * 4); P->oPti = cs.take(c.pti.size() * 4 + 4); P->oLsp = cs.take(c.lsp.size() * 4);
+    P->oLsi = cs.take(c.lsi.size() * 4 + 4); P->oKfp = cs.take(c.kfp.size() * 4); P->oKfi = cs.take(c.kfi.size() * 4 + 4);
+    Carve cd;
+    P->oT = cd.take((size_t)n_pose_slots * 128 + 8); P->oX = cd.take((size_t)npt * 24 + 8); P->oL = cd.take((size_t)nls * 48 + 8);
+    Carve cr;
+    P->oPJp = cr.take(np * 48 + 8); P->oPJl = cr.take(np * 24 + 8); P->oPr = cr.take(np * 8 + 8); P->oPw = cr.take(np * 8 + 8);
+    P->oLJp = cr.take(nl * 48 + 8); P->oLJl = cr.take(nl * 48 + 8); P->oLr = cr.take(nl * 8 + 8); P->oLw = cr.take(nl * 8 + 8);
+    const size_t N = 6 * (size_t)nkf + 3 * (size_t)npt + 6 * (size_t)nls;
+    Carve co;
+    P->oG = co.take(N * 8 + 8); P->oHp = co.take((size_t)nkf * 288 + 8); P->oHpt = co.take((size_t)npt * 72 + 8);
+    P->oHls = co.take((size_t)nls * 288 + 8); P->oWp = co.take(np * 144 + 8); P->oWl = co.take(nl * 288 + 8);
+    P->oErr = co.take(8);
+    P->max_chunks = pose_max_chunks(c.kfp);
+    P->oPart = co.take((size_t)nkf * (size_t)P->max_chunks * 42 * 8 + 8);
+    int rc;
+    if ((rc = P->stat.reserve(cs.off + 256)) || (rc = P->dyn.reserve(cd.off + 256)) ||
+        (rc = P->rows.reserve(cr.off + 256)) || (rc = P->out.reserve(co.off + 256))) {
+        P->stat.release(); P->dyn.release(); P->rows.release(); P->out.release();
+        delete P;
+        return rc;
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipStream_t s = ctx->stream;
+    char* d = P->stat.as<char>();
+    auto up = [&](size_t off, const void* src, size_t bytes) -> int {
+        if (bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(d + off, src, bytes, hipMemcpyHostToDevice, s));
+        return PLSLAM_OK;
+    };
+    if ((rc = up(P->oPlm, pt_lm_loc, np * 4)) || (rc = up(P->oPslot, pt_pose_slot, np * 4)) ||
+        (rc = up(P->oPkf, pt_kf_loc, np * 4)) || (rc = up(P->oPuv, pt_obs_uv, np * 16)) ||
+        (rc = up(P->oLlm, ls_lm_loc, nl * 4)) || (rc = up(P->oLslot, ls_pose_slot, nl * 4)) ||
+        (rc = up(P->oLkf, ls_kf_loc, nl * 4)) || (rc = up(P->oLobs, ls_l_obs, nl * 24)) ||
+        (rc = up(P->oPtp, c.ptp.data(), c.ptp.size() * 4)) || (rc = up(P->oPti, c.pti.data(), c.pti.size() * 4)) ||
+        (rc = up(P->oLsp, c.lsp.data(), c.lsp.size() * 4)) || (rc = up(P->oLsi, c.lsi.data(), c.lsi.size() * 4)) ||
+        (rc = up(P->oKfp, c.kfp.data(), c.kfp.size() * 4)) || (rc = up(P->oKfi, c.kfi.data(), c.kfi.size() * 4)) ||
+        (hipStreamSynchronize(s) != hipSuccess && (rc = PLSLAM_EHIP))) {   // the staging vectors die here
+        (void)hipStreamSynchronize(s);
+        P->stat.release(); P->dyn.release(); P->rows.release(); P->out.release();
+        delete P;
+        return rc;
+    }
+    *out = P;
+    return PLSLAM_OK;
+}
+
+extern "C" int plslam_lba_plan_iterate(plslam_lba_plan* P, const double* T_kf_w, const double* Xw, const double* Lw,
+                                       int compat_iter_pass, double* g, double* H_pose, double* H_pt, double* H_ls,
+                                       double* W_pt, double* W_ls, double* err)
+{
+    PLSLAM_REQUIRE(P && g && err, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE((P->n_slots == 0 || T_kf_w) && (P->npt == 0 || (Xw && H_pt)) && (P->nls == 0 || (Lw && H_ls)), PLSLAM_EINVAL);
+    PLSLAM_REQUIRE((P->nkf == 0 || H_pose) && (P->np == 0 || W_pt) && (P->nl == 0 || W_ls), PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipStream_t s = ctx->stream;
+    char *ds = P->stat.as<char>(), *dd = P->dyn.as<char>(), *dr = P->rows.as<char>(), *dout = P->out.as<char>();
+    if (P->n_slots) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd + P->oT, T_kf_w, (size_t)P->n_slots * 128, hipMemcpyHostToDevice, s));
+    if (P->npt) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd + P->oX, Xw, (size_t)P->npt * 24, hipMemcpyHostToDevice, s));
+    if (P->nls) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd + P->oL, Lw, (size_t)P->nls * 48, hipMemcpyHostToDevice, s));
+    int rc;
+    if ((rc = launch_point_rows(P->cam, P->th, (double*)(dd + P->oT), (double*)(dd + P->oX), (double*)(ds + P->oPuv),
+                                (int32_t*)(ds + P->oPlm), (int32_t*)(ds + P->oPslot), P->np, (double*)(dr + P->oPJp),
+                                (double*)(dr + P->oPJl), (double*)(dr + P->oPr), (double*)(dr + P->oPw), s)))
+        return rc;
+    if ((rc = launch_line_rows(P->cam, P->th, compat_iter_pass ? 1 : 0, (double*)(dd + P->oT), (double*)(dd + P->oL),
+                               (double*)(ds + P->oLobs), (int32_t*)(ds + P->oLlm), (int32_t*)(ds + P->oLslot), P->nl,
+                               (double*)(dr + P->oLJp), (double*)(dr + P->oLJl), (double*)(dr + P->oLr),
+                               (double*)(dr + P->oLw), s)))
+        return rc;
+    AssembleDev a{(int32_t*)(ds + P->oPkf), (int32_t*)(ds + P->oLkf), (int32_t*)(ds + P->oPtp), (int32_t*)(ds + P->oPti),
+                  (int32_t*)(ds + P->oLsp), (int32_t*)(ds + P->oLsi), (int32_t*)(ds + P->oKfp), (int32_t*)(ds + P->oKfi),
+                  (double*)(dr + P->oPJp), (double*)(dr + P->oPJl), (double*)(dr + P->oPr), (double*)(dr + P->oPw),
+                  (double*)(dr + P->oLJp), (double*)(dr + P->oLJl), (double*)(dr + P->oLr), (double*)(dr + P->oLw),
+                  (double*)(dout + P->oG), (double*)(dout + P->oHp), (double*)(dout + P->oHpt), (double*)(dout + P->oHls),
+                  (double*)(dout + P->oWp), (double*)(dout + P->oWl), (double*)(dout + P->oErr),
+                  (double*)(dout + P->oPart), P->max_chunks};
+    if ((rc = assemble_on_device(a, P->nkf, P->npt, P->nls, P->np, P->nl, s))) return rc;
+    const size_t N = 6 * (size_t)P->nkf + 3 * (size_t)P->npt + 6 * (size_t)P->nls;
+    auto down = [&](void* dst, size_t off, size_t bytes) -> int {
+        if (bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(dst, dout + off, bytes, hipMemcpyDeviceToHost, s));
+        return PLSLAM_OK;
+    };
+    if ((rc = down(g, P->oG, N * 8)) || (rc = down(H_pose, P->oHp, (size_t)P->nkf * 288)) ||
+        (rc = down(H_pt, P->oHpt, (size_t)P->npt * 72)) || (rc = down(H_ls, P->oHls, (size_t)P->nls * 288)) ||
+        (rc = down(W_pt, P->oWp, (size_t)P->np * 144)) || (rc = down(W_ls, P->oWl, (size_t)P->nl * 288)) ||
+        (rc = down(err, P->oErr, 8)))
+        return rc;
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return PLSLAM_OK;
+}
+
+// the rows of the last iterate() (device -> host), e.g. for the outlier logic of :1831-1846
+extern "C" int plslam_lba_plan_rows(plslam_lba_plan* P, double* pt_J_pose, double* pt_J_lm, double* pt_r, double* pt_w,
+                                    double* ls_J_pose, double* ls_J_lm, double* ls_r, double* ls_w)
+{
+    PLSLAM_REQUIRE(P != nullptr, PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    hipStream_t s = ctx->stream;
+    char* dr = P->rows.as<char>();
+    const size_t np = (size_t)P->np, nl = (size_t)P->nl;
+    auto down = [&](void* dst, size_t off, size_t bytes) -> int {
+        if (dst && bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(dst, dr + off, bytes, hipMemcpyDeviceToHost, s));
+        return PLSLAM_OK;
+    };
+    int rc;
+    if ((rc = down(pt_J_pose, P->oPJp, np * 48)) || (rc = down(pt_J_lm, P->oPJl, np * 24)) || (rc = down(pt_r, P->oPr, np * 8)) ||
+        (rc = down(pt_w, P->oPw, np * 8)) || (rc = down(ls_J_pose, P->oLJp, nl * 48)) || (rc = down(ls_J_lm, P->oLJl, nl * 48)) ||
+        (rc = down(ls_r, P->oLr, nl * 8)) || (rc = down(ls_w, P->oLw, nl * 8)))
+        return rc;
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return PLSLAM_OK;
+}
+
+extern "C" void plslam_lba_plan_destroy(plslam_lba_plan* P)
+{
+    if (!P) return;
+    (void)hipStreamSynchronize(P->ctx->stream);
+    P->stat.release(); P->dyn.release(); P->rows.release(); P->out.release();
+    delete P;
+}
 
 extern "C" int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, int32_t nls,
                                    const int32_t* pt_lm_loc, const int32_t* pt_kf_loc, int32_t n_pt_obs,
@@ -139,34 +410,9 @@ extern "C" int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, in
     for (int32_t o = 0; o < n_ls_obs; ++o)
         PLSLAM_REQUIRE(ls_lm_loc[o] >= 0 && ls_lm_loc[o] < nls && ls_kf_loc[o] >= -1 && ls_kf_loc[o] < nkf, PLSLAM_EINVAL);
 
-    // ---- stable CSR lists (host, O(nobs)): observations per landmark and per keyframe, list order
-    auto csr = [](const int32_t* key, int32_t n, int32_t nkeys, int32_t id0, std::vector<int32_t>& ptr,
-                  std::vector<int32_t>& ids, bool append) {
-        if (!append) ptr.assign((size_t)nkeys + 1, 0);
-        std::vector<int32_t> cnt((size_t)nkeys, 0);
-        for (int32_t o = 0; o < n; ++o) if (key[o] >= 0) ++cnt[key[o]];
-        if (!append) {
-            for (int32_t k = 0; k < nkeys; ++k) ptr[k + 1] = ptr[k] + cnt[k];
-            ids.assign((size_t)ptr[nkeys], 0);
-            std::vector<int32_t> pos(ptr.begin(), ptr.end() - 1);
-            for (int32_t o = 0; o < n; ++o) if (key[o] >= 0) ids[pos[key[o]]++] = id0 + o;
-        }
-    };
-    std::vector<int32_t> ptp, pti, lsp, lsi;
-    csr(pt_lm_loc, n_pt_obs, npt, 0, ptp, pti, false);
-    csr(ls_lm_loc, n_ls_obs, nls, 0, lsp, lsi, false);
-    // keyframes: points first, then lines (the reference runs the point loop before the line loop)
-    std::vector<int32_t> kfp((size_t)nkf + 1, 0), kfi;
-    {
-        std::vector<int32_t> cnt((size_t)nkf, 0);
-        for (int32_t o = 0; o < n_pt_obs; ++o) if (pt_kf_loc[o] >= 0) ++cnt[pt_kf_loc[o]];
-        for (int32_t o = 0; o < n_ls_obs; ++o) if (ls_kf_loc[o] >= 0) ++cnt[ls_kf_loc[o]];
-        for (int32_t k = 0; k < nkf; ++k) kfp[k + 1] = kfp[k] + cnt[k];
-        kfi.assign((size_t)kfp[nkf], 0);
-        std::vector<int32_t> pos(kfp.begin(), kfp.end() - 1);
-        for (int32_t o = 0; o < n_pt_obs; ++o) if (pt_kf_loc[o] >= 0) kfi[pos[pt_kf_loc[o]]++] = o;
-        for (int32_t o = 0; o < n_ls_obs; ++o) if (ls_kf_loc[o] >= 0) kfi[pos[ls_kf_loc[o]]++] = n_pt_obs + o;
-    }
+    CsrLists L;
+    build_csr(pt_lm_loc, pt_kf_loc, n_pt_obs, ls_lm_loc, ls_kf_loc, n_ls_obs, nkf, npt, nls, L);
+    std::vector<int32_t>&ptp = L.ptp, &pti = L.pti, &lsp = L.lsp, &lsi = L.lsi, &kfp = L.kfp, &kfi = L.kfi;
 
     std::lock_guard<std::mutex> lk(ctx->mu);
     hipStream_t s = ctx->stream;
@@ -182,6 +428,8 @@ extern "C" int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, in
     const size_t oG = co.take(N * 8 + 8), oHp = co.take((size_t)nkf * 288 + 8), oHpt = co.take((size_t)npt * 72 + 8),
                  oHls = co.take((size_t)nls * 288 + 8), oWp = co.take(np * 144 + 8), oWl = co.take(nl * 288 + 8),
                  oErr = co.take(8);
+    const int32_t max_chunks = pose_max_chunks(kfp);
+    const size_t oPart = co.take((size_t)nkf * (size_t)max_chunks * 42 * 8 + 8);
     int rc;
     if ((rc = ctx->in_a.reserve(c.off + 256))) return rc;
     if ((rc = ctx->out_a.reserve(co.off + 256))) return rc;
@@ -199,29 +447,14 @@ extern "C" int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, in
         (rc = up(oLsi, lsi.data(), lsi.size() * 4)) || (rc = up(oKfp, kfp.data(), kfp.size() * 4)) ||
         (rc = up(oKfi, kfi.data(), kfi.size() * 4)))
         return rc;
-    double* dG = (double*)(dout + oG);
-    // g layout = the reference's X layout: [6*nkf poses | 3*npt points | 6*nls lines]
-    if (npt)
-        hipLaunchKernelGGL(k_landmark_blocks<3>, dim3((npt + 255) / 256), dim3(256), 0, s, (int32_t*)(di + oPtp),
-                           (int32_t*)(di + oPti), npt, (double*)(di + oPJl), (double*)(di + oPr), (double*)(di + oPw),
-                           (double*)(dout + oHpt), dG + 6 * (size_t)nkf);
-    if (nls)
-        hipLaunchKernelGGL(k_landmark_blocks<6>, dim3((nls + 255) / 256), dim3(256), 0, s, (int32_t*)(di + oLsp),
-                           (int32_t*)(di + oLsi), nls, (double*)(di + oLJl), (double*)(di + oLr), (double*)(di + oLw),
-                           (double*)(dout + oHls), dG + 6 * (size_t)nkf + 3 * (size_t)npt);
-    if (n_pt_obs)
-        hipLaunchKernelGGL(k_cross_blocks<3>, dim3((n_pt_obs + 255) / 256), dim3(256), 0, s, (int32_t*)(di + oPk),
-                           n_pt_obs, (double*)(di + oPJp), (double*)(di + oPJl), (double*)(di + oPw), (double*)(dout + oWp));
-    if (n_ls_obs)
-        hipLaunchKernelGGL(k_cross_blocks<6>, dim3((n_ls_obs + 255) / 256), dim3(256), 0, s, (int32_t*)(di + oLk),
-                           n_ls_obs, (double*)(di + oLJp), (double*)(di + oLJl), (double*)(di + oLw), (double*)(dout + oWl));
-    if (nkf)
-        hipLaunchKernelGGL(k_pose_blocks, dim3(nkf), dim3(64), 0, s, (int32_t*)(di + oKfp), (int32_t*)(di + oKfi), n_pt_obs,
-                           (double*)(di + oPJp), (double*)(di + oPr), (double*)(di + oPw), (double*)(di + oLJp),
-                           (double*)(di + oLr), (double*)(di + oLw), (double*)(dout + oHp), dG);
-    hipLaunchKernelGGL(k_weighted_error, dim3(1), dim3(256), 0, s, (double*)(di + oPr), (double*)(di + oPw), n_pt_obs,
-                       (double*)(di + oLr), (double*)(di + oLw), n_ls_obs, (double*)(dout + oErr));
-    PLSLAM_HIP_CHECK(hipGetLastError());
+    AssembleDev a{(int32_t*)(di + oPk), (int32_t*)(di + oLk), (int32_t*)(di + oPtp), (int32_t*)(di + oPti),
+                  (int32_t*)(di + oLsp), (int32_t*)(di + oLsi), (int32_t*)(di + oKfp), (int32_t*)(di + oKfi),
+                  (double*)(di + oPJp), (double*)(di + oPJl), (double*)(di + oPr), (double*)(di + oPw),
+                  (double*)(di + oLJp), (double*)(di + oLJl), (double*)(di + oLr), (double*)(di + oLw),
+                  (double*)(dout + oG), (double*)(dout + oHp), (double*)(dout + oHpt), (double*)(dout + oHls),
+                  (double*)(dout + oWp), (double*)(dout + oWl), (double*)(dout + oErr), (double*)(dout + oPart),
+                  max_chunks};
+    if ((rc = assemble_on_device(a, nkf, npt, nls, n_pt_obs, n_ls_obs, s))) return rc;
     auto down = [&](void* dst, size_t off, size_t bytes) -> int {
         if (bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(dst, dout + off, bytes, hipMemcpyDeviceToHost, s));
         return PLSLAM_OK;

@@ -174,10 +174,19 @@ int main()
             PLSLAM::LbaRowBuilder::BlockNormalEquations B;
             rb.buildBlockNormalEquations(p, pass == 1, B);
             int bad = 0;
-            for (int i = 0; i < N; ++i) bad += B.g[i] != gv[i];
+            double pose_scale = 0, pose_diff = 0;   // keyframe blocks: two-level sum, equal to rounding
+            for (int i = 6 * p.Nkf; i < N; ++i) bad += B.g[i] != gv[i];
+            for (int i = 0; i < 6 * p.Nkf; ++i) { pose_scale = std::fmax(pose_scale, std::fabs(gv[i])); pose_diff = std::fmax(pose_diff, std::fabs(B.g[i] - gv[i])); }
+            EXPECT(pose_diff <= 1e-13 * pose_scale);
+            pose_scale = pose_diff = 0;
             for (int k = 0; k < p.Nkf; ++k)
                 for (int a = 0; a < 6; ++a)
-                    for (int b = 0; b < 6; ++b) bad += B.H_pose[(size_t)k * 36 + a * 6 + b] != H[(size_t)(6 * k + a) * N + 6 * k + b];
+                    for (int b = 0; b < 6; ++b) {
+                        const double ref = H[(size_t)(6 * k + a) * N + 6 * k + b];
+                        pose_scale = std::fmax(pose_scale, std::fabs(ref));
+                        pose_diff = std::fmax(pose_diff, std::fabs(B.H_pose[(size_t)k * 36 + a * 6 + b] - ref));
+                    }
+            EXPECT(pose_diff <= 1e-13 * pose_scale);
             for (int l = 0; l < Npt; ++l)
                 for (int a = 0; a < 3; ++a)
                     for (int b = 0; b < 3; ++b) {

@@ -109,6 +109,20 @@ def test_gates_and_visibility_bit_exact(ctx, oracle):
     assert np.array_equal(mask, emask) and cnt == ecnt
 
 
+def _assert_blocks_match_dense(B, H, g, nkf, npt, nls, pt_lm, pt_kf, ls_lm, ls_kf):
+    """Landmark and cross blocks (and the landmark part of g) are bit-identical to the dense
+    accumulation; the keyframe blocks / pose part of g are a fixed-shape two-level sum: equal to
+    1e-13 of the block's scale."""
+    Hd = _expand_blocks(B, nkf, npt, nls, pt_lm, pt_kf, ls_lm, ls_kf)
+    p6 = 6 * nkf
+    assert np.array_equal(Hd[p6:, :], H[p6:, :]) and np.array_equal(Hd[:, p6:], H[:, p6:])
+    assert np.array_equal(B["g"][p6:], g[p6:])
+    if nkf:
+        scale = max(np.abs(H[:p6, :p6]).max(), 1e-300)
+        assert np.abs(Hd[:p6, :p6] - H[:p6, :p6]).max() <= 1e-13 * scale
+        assert np.abs(B["g"][:p6] - g[:p6]).max() <= 1e-13 * max(np.abs(g[:p6]).max(), 1e-300)
+
+
 def _expand_blocks(B, nkf, npt, nls, pt_lm, pt_kf, ls_lm, ls_kf):
     """Scatter the block form back into the reference's dense H (src/mapHandler.cpp:1410-1429, :1519-1538)."""
     N = 6 * nkf + 3 * npt + 6 * nls
@@ -137,7 +151,8 @@ def _expand_blocks(B, nkf, npt, nls, pt_lm, pt_kf, ls_lm, ls_kf):
 @pytest.mark.parametrize("n_kf,n_pt,n_ls,obs", [(4, 60, 20, 3), (8, 300, 90, 5), (3, 10, 0, 2), (3, 0, 7, 3)])
 def test_block_assembly_equals_dense_accumulation(ctx, oracle, n_kf, n_pt, n_ls, obs):
     """K7-K10: the block-form normal equations, expanded, equal the reference's dense H and g
-    accumulation bit for bit (same summation order); err to 1e-12 (tree vs sequential sum)."""
+    accumulation: landmark + cross blocks bit for bit (same summation order), keyframe blocks and err
+    to rounding (fixed-shape two-level / tree sums)."""
     lm = synth.local_map(n_kf=n_kf, n_pt=n_pt, n_ls=n_ls, obs_per_lm=obs, seed=n_pt + 1)
     cam, ocam = _cams()
     nkf = n_kf - 1                                 # keyframe 0 is never optimised (:1231): kf_loc = slot - 1
@@ -147,9 +162,7 @@ def test_block_assembly_equals_dense_accumulation(ctx, oracle, n_kf, n_pt, n_ls,
     H, g, e1 = oracle.lba_accumulate("points", nkf, n_pt, n_ls, lm["pt_lm"], pt_kf_loc, *rows_p)
     H, g, e2 = oracle.lba_accumulate("lines", nkf, n_pt, n_ls, lm["ls_lm"], ls_kf_loc, *rows_l, H=H, g=g)
     B = ctx.lba_assemble(nkf, n_pt, n_ls, lm["pt_lm"], pt_kf_loc, rows_p, lm["ls_lm"], ls_kf_loc, rows_l)
-    Hd = _expand_blocks(B, nkf, n_pt, n_ls, lm["pt_lm"], pt_kf_loc, lm["ls_lm"], ls_kf_loc)
-    assert np.array_equal(B["g"], g)
-    assert np.array_equal(Hd, H)
+    _assert_blocks_match_dense(B, H, g, nkf, n_pt, n_ls, lm["pt_lm"], pt_kf_loc, lm["ls_lm"], ls_kf_loc)
     assert abs(B["err"] - (e1 + e2)) <= 1e-12 * abs(e1 + e2)
     if n_pt:
         with pytest.raises(plslam_amd.PlslamError):    # out-of-range keyframe slots are rejected, not read
@@ -203,8 +216,8 @@ def test_committed_lba_goldens(ctx):
         assert _close(a, g[f"rows/ls_compat/{nm}"], 1e-12)
     B = ctx.lba_assemble(4, 120, 40, lm["pt_lm"], lm["pt_kf"] - 1, [g[f"rows/pt/{n}"] for n in ("J_pose", "J_lm", "r", "w")],
                          lm["ls_lm"], lm["ls_kf"] - 1, [g[f"rows/ls/{n}"] for n in ("J_pose", "J_lm", "r", "w")])
-    Hd = _expand_blocks(B, 4, 120, 40, lm["pt_lm"], lm["pt_kf"] - 1, lm["ls_lm"], lm["ls_kf"] - 1)
-    assert np.array_equal(Hd, g["acc/H"]) and np.array_equal(B["g"], g["acc/g"])
+    _assert_blocks_match_dense(B, g["acc/H"], g["acc/g"], 4, 120, 40, lm["pt_lm"], lm["pt_kf"] - 1, lm["ls_lm"],
+                               lm["ls_kf"] - 1)
     for kind in ("points", "lines"):
         s = {k.split("/")[2]: g[k] for k in g.files if k.startswith(f"drv/{kind}/")}
         m, n = ctx.map2kf_match(kind, cam, s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"], s["kf_idx"],
@@ -212,3 +225,41 @@ def test_committed_lba_goldens(ctx):
         assert np.array_equal(m, s["map_to_kf"]) and n == int(s["n"][0])
         vis = (ctx.map_line_visible if kind == "lines" else ctx.map_point_visible)(cam, s["Twf"], s["LM"])
         assert np.array_equal(vis, s["visible"])
+
+
+def test_lba_plan_iterations_match_oracle(ctx, oracle):
+    """plslam_lba_plan: lists uploaded once, iterate() per LM iteration with changed poses/landmarks;
+    blocks and rows equal the oracle's rows + dense accumulation (bit-exact), first pass and
+    iteration-pass (compat) line behaviour."""
+    lm = synth.local_map(n_kf=6, n_pt=400, n_ls=120, obs_per_lm=4, seed=3)
+    cam, ocam = _cams()
+    nkf, npt, nls = 5, 400, 120
+    pkf, lkf = lm["pt_kf"] - 1, lm["ls_kf"] - 1
+    plan = plslam_amd.LbaPlan(ctx, cam, 1e-7, 6, nkf, npt, nls, lm["pt_lm"], lm["pt_kf"], pkf, lm["obs_uv"],
+                              lm["ls_lm"], lm["ls_kf"], lkf, lm["l_obs"])
+    r = np.random.Generator(np.random.PCG64(77))
+    T, X, L = lm["T_kf_w"].copy(), lm["Xw"].copy(), lm["Lw"].copy()
+    for it in range(3):
+        compat = it > 0                                   # iterations after the first pass (:1668-1748)
+        B = plan.iterate(T, X, L, compat_iter_pass=compat)
+        rp = oracle.lba_point_rows(ocam, 1e-7, T, X, lm["obs_uv"], lm["pt_lm"], lm["pt_kf"])
+        rl = oracle.lba_line_rows(ocam, 1e-7, T, L, lm["l_obs"], lm["ls_lm"], lm["ls_kf"], compat_iter_pass=compat)
+        H, g, e1 = oracle.lba_accumulate("points", nkf, npt, nls, lm["pt_lm"], pkf, *rp)
+        H, g, e2 = oracle.lba_accumulate("lines", nkf, npt, nls, lm["ls_lm"], lkf, *rl, H=H, g=g)
+        gp, gl = plan.rows()
+        for a, b in zip(gp + gl, list(rp) + list(rl)):
+            assert _close(a, b, 1e-12)
+        if all(np.array_equal(a, b) for a, b in zip(gp + gl, list(rp) + list(rl))):   # rows bit-equal => blocks too
+            _assert_blocks_match_dense(B, H, g, nkf, npt, nls, lm["pt_lm"], pkf, lm["ls_lm"], lkf)
+        else:
+            assert np.allclose(B["g"], g, rtol=1e-9, atol=1e-9 * np.abs(g).max())
+        assert abs(B["err"] - (e1 + e2)) <= 1e-12 * abs(e1 + e2)
+        # an "LM step": perturb landmarks and the optimised poses
+        X = X + 1e-3 * r.standard_normal(X.shape)
+        L = L + 1e-3 * r.standard_normal(L.shape)
+        for k in range(1, 6):
+            T[k] = (T[k].reshape(4, 4) @ np.linalg.inv(synth.se3_exp(1e-3 * r.standard_normal(6)))).reshape(16)
+    plan.close()
+    with pytest.raises(plslam_amd.PlslamError):
+        plslam_amd.LbaPlan(ctx, cam, 1e-7, 6, nkf, npt, nls, lm["pt_lm"], lm["pt_kf"] + 9, pkf, lm["obs_uv"],
+                           lm["ls_lm"], lm["ls_kf"], lkf, lm["l_obs"])

@@ -158,6 +158,19 @@ def main():
     out["lba_line_rows_streaming"] = {"rows": nbl, "kernel_us": 1e3 * ms_bigl,
                                       "GBps_algorithmic": nbl * 208 / (ms_bigl * 1e-3) / 1e9,
                                       "frac_of_8TBps": nbl * 208 / (ms_bigl * 1e-3) / 8e12}
+    # ---- one LM iteration at C3 through the LBA plan (upload X, rows, block assembly, download) ----
+    plan = plslam_amd.LbaPlan(ctx, cam, 1e-7, 10, 9, 10000, 2000, lm["pt_lm"], lm["pt_kf"], lm["pt_kf"] - 1, lm["obs_uv"],
+                              lm["ls_lm"], lm["ls_kf"], lm["ls_kf"] - 1, lm["l_obs"])
+    plan.iterate(lm["T_kf_w"], lm["Xw"], lm["Lw"])
+    t0 = time.perf_counter()
+    for _ in range(20):
+        plan.iterate(lm["T_kf_w"], lm["Xw"], lm["Lw"])
+    out["c3_lba_plan_iteration"] = {"ms_per_iteration_host_to_host": 1e3 * (time.perf_counter() - t0) / 20,
+                                    "N": 6 * 9 + 3 * 10000 + 6 * 2000,
+                                    "note": "upload poses+landmarks (0.34 MB), K3/K4 rows, K7-K10 block assembly, download "
+                                            "g + blocks (11.5 MB) to pageable host memory; the reference's dense H at this "
+                                            "size would be 14 GB"}
+    plan.close()
     ctx.close()
     print(json.dumps(out))
 
