@@ -254,3 +254,29 @@ def test_large_train_set_index_bits(vctx, oracle):
     m, n = ctx.match(q, t, 0.75, True)
     em, en = oracle.match(q, t, 0.75, True)
     assert np.array_equal(m, em) and n == en
+
+
+def test_fuzz_all_variants_vs_oracle(ctx, oracle):
+    """Randomised sizes / ties / thresholds / variants against the oracle (fixed seeds)."""
+    import plslam_amd
+    r = _rng(2024)
+    variants = (plslam_amd.SCAN_AUTO, plslam_amd.SCAN_LANE_PER_QUERY, plslam_amd.SCAN_WAVE_PER_QUERY,
+                plslam_amd.SCAN_SYMMETRIC)
+    try:
+        for case in range(160):
+            n1, n2 = int(r.integers(0, 420)), int(r.integers(0, 420))
+            gen = synth.tie_stress_desc if case % 3 == 0 else synth.random_desc
+            d1, d2 = gen(r, n1), gen(r, n2)
+            if gen is synth.random_desc and min(n1, n2) > 4:
+                k = int(r.integers(1, min(n1, n2)))
+                d2[:k] = d1[:k] ^ np.packbits(r.random((k, 256)) < 0.07, axis=1)
+            nnr = float(r.choice([0.6, 0.75, 0.8, 0.9]))
+            mutual = bool(case % 2)
+            ctx.set_option("scan_variant", variants[case % 4])
+            ctx.set_option("sym_rows", [0, 1, 4][case % 3])
+            m, n = ctx.match(d1, d2, nnr, mutual)
+            em, en = oracle.match(d1, d2, nnr, mutual)
+            assert np.array_equal(m, em) and n == en, (case, n1, n2, nnr, mutual)
+    finally:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+        ctx.set_option("sym_rows", 0)
