@@ -27,12 +27,37 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_LANES_PER_CLK_PER_CU = 128  # 4 SIMD-32 per CU
 
 
+def usable_cpus() -> int:
+    """CPUs this process may actually use: scheduler affinity capped by the cgroup CPU quota
+    (containers: os.cpu_count() reports the host's CPUs, not the quota)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", None)):
+        try:
+            txt = open(path).read().strip()
+            if parse:
+                quota, period = parse(txt)
+                if quota != "max":
+                    n = min(n, max(1, int(int(quota) / int(period))))
+            else:
+                period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if int(txt) > 0:
+                    n = min(n, max(1, int(int(txt) / period)))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(stream, n_orb, n_lbd, nnr_p, nnr_l, budget_s=15.0):
     """The CPU restatement of the reference path (oracle, -O3 -march=native, popcnt) timed on this
     host's cores on a bounded sample of the SAME workload.  kind = "port"."""
     from oracle import oracle as O
     L = O.native_lib()
-    cores = os.cpu_count() or 1
+    cores = usable_cpus()      # threads actually used = CPUs the container may use (cgroup quota)
 
     def pack(lst, n):
         return np.ascontiguousarray(np.concatenate(lst)), np.arange(0, (len(lst) + 1) * n, n, dtype=np.int32)
@@ -66,6 +91,7 @@ def cpu_baseline(stream, n_orb, n_lbd, nnr_p, nnr_l, budget_s=15.0):
         t_mt += run(full, cores)
         reps += 1
     return {"value": B * reps / t_mt, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
+            "host_logical_cpus": os.cpu_count(),
             "sample": f"{reps} pass(es) over the same {B}-pair batch on {cores} threads ({t_mt:.1f} s); "
                       f"1 thread: {reps_1} pass(es) over {n_1} pairs ({t_1:.1f} s)",
             "value_1thread": n_1 * reps_1 / t_1}
