@@ -89,6 +89,19 @@ class StereoBatchMatcher:
         # A real (non-NULL) HIP stream: the C ABI reads a NULL stream as "the context's own stream",
         # and torch's legacy default stream has handle 0.
         self.stream = torch.cuda.Stream(device=dev)
+        self.streams = [self.stream] + [torch.cuda.Stream(device=dev) for _ in range(n_buffers - 1)]
+
+    def run_overlapped(self, k: int):
+        """Step k of a stream of independent batches: buffer k % n_buffers on its own HIP stream, so
+        that the ramp-up of step k+1 overlaps the drain / merge / finalize of step k.  Steps that
+        share a buffer are ordered by their stream.  Call synchronize_all() before reading."""
+        b = k % len(self.plans)
+        self.plans[b].run(self.streams[b].cuda_stream)
+        return b
+
+    def synchronize_all(self):
+        for s in self.streams:
+            s.synchronize()
 
     def run(self, buf: int = 0):
         """Enqueue one pass over the batch into table `buf`.  The kernels run on this object's stream,
@@ -101,10 +114,12 @@ class StereoBatchMatcher:
         return self.tables[buf]
 
     def run_async(self, buf: int = 0):
-        """Enqueue one pass on this object's stream only; returns an event recorded after it."""
-        self.plans[buf].run(self.stream.cuda_stream)
+        """Enqueue one pass into table `buf` on that buffer's own stream; returns an event recorded
+        after it (consecutive steps use different buffers/streams and may overlap)."""
+        st = self.streams[buf]
+        self.plans[buf].run(st.cuda_stream)
         ev = self.torch.cuda.Event()
-        ev.record(self.stream)
+        ev.record(st)
         return ev
 
     def close(self):
@@ -132,7 +147,7 @@ class PipelinedGather:
         import torch.distributed as dist
         b = k % self.nbuf
         if self.done_ev[b] is not None:                    # buffer b is being re-used: its previous gather
-            self.bm.stream.wait_event(self.done_ev[b])     # must have read the table before we overwrite it
+            self.bm.streams[b].wait_event(self.done_ev[b])  # must have read the table before we overwrite it
         ev = self.bm.run_async(b)
         with self.torch.cuda.stream(self.comm):
             self.comm.wait_event(ev)
