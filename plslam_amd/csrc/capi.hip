@@ -104,9 +104,8 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     // others the directed lane-per-query scan.  A forced variant applies to every problem.
     // A plan too small to put one wave on every SIMD under those (e.g. ONE StVO::match call of the
     // SLAM loop) takes the wave-per-query scan instead: 16 queries per workgroup, train tile in LDS.
-    int64_t thr_waves = 0;
-    for (int32_t i = 0; i < nprob; ++i)
-        thr_waves += (probs[i].n1 + 63) / 64 + (probs[i].mutual ? 0 : 0);
+    int64_t thr_waves = 0;   // waves the throughput kernels would launch: one per 64 rows of d1
+    for (int32_t i = 0; i < nprob; ++i) thr_waves += (probs[i].n1 + 63) / 64;
     const int64_t simds = (int64_t)ctx->prop.multiProcessorCount * 4;
     const bool use_wpq = ctx->scan_variant == PLSLAM_SCAN_WAVE_PER_QUERY ||
                          (ctx->scan_variant == PLSLAM_SCAN_AUTO && thr_waves < simds);
