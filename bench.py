@@ -241,6 +241,12 @@ def main():
         excl_scan_ms, excl_fin_ms = a_ / max(n_, 1), b_ / max(n_, 1)
         note(f"exclusive kernel times: scan {excl_scan_ms:.3f} ms, merge+finalize {excl_fin_ms:.3f} ms")
 
+    # full-size determinism check: every output buffer was computed from the same inputs (under
+    # overlap / contention), so whole tables and count arrays must be bit-identical
+    for b_ in range(1, len(bm.tables)):
+        if args.steps + args.warmup >= 2 and not (torch.equal(bm.tables[0], bm.tables[b_]) and
+                                                  torch.equal(bm.count_bufs[0], bm.count_bufs[b_])):
+            raise SystemExit(f"rank {rank}: output buffers 0 and {b_} differ (nondeterministic result)")
     # self-check of the timed output against the oracle (the checker, not the product): pair 0 of
     # EVERY rank's table as it arrived on rank 0 (N > 1: through the RCCL gather, both buffers)
     if rank == 0:
