@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--scan-block", type=int, default=0)
     ap.add_argument("--sym-rows", type=int, default=0)
     ap.add_argument("--group-cap", type=int, default=0)
+    ap.add_argument("--step-streams", type=int, default=2, help="output buffers / HIP streams the steps alternate over")
     ap.add_argument("--no-overlap", action="store_true",
                     help="single GPU: run the steps strictly one after another on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -170,7 +171,7 @@ def main():
         ctx.set_option("group_cap", args.group_cap)
     overlap = not use_dist and not args.no_overlap
     bm = frontend.StereoBatchMatcher(ctx, stream, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev,
-                                     n_buffers=2 if (use_dist or overlap) else 1)
+                                     n_buffers=max(2, args.step_streams) if (use_dist or overlap) else 1)
     info = bm.plan.info()
     devinfo = ctx.device_info()
     # N > 1: the table of step k is gathered to rank 0 over RCCL on a communication stream while
@@ -277,6 +278,7 @@ def main():
         # process, so the figure comes from the committed rocprofv3 passes of this same command
         # (profiles/pmc_traffic.json) and is reported only for the configuration they were taken on.
         traffic = None
+        executed = None
         wkey = f"C2:{args.n_orb}+{args.n_lbd}:pairs{B}:sym{ctx.get_option('sym_rows')}:cap{ctx.get_option('group_cap')}"
         # (sym_rows 0 = auto: resolved per plan, reported in config.scan_block_threads: 64 => 4 rows/lane)
         try:
@@ -284,6 +286,12 @@ def main():
                 pm = json.load(f)
             if pm.get("workload_key") == wkey and info["scan_variant"] == 3:
                 traffic = pm["traffic_bytes_per_launch"]
+                lane_ops = pm["sq_insts_valu_per_launch"] * 64 / (excl_scan_ms / 1e3)
+                executed = {"lane_ops_per_s": lane_ops, "sq_insts_valu_per_launch": pm["sq_insts_valu_per_launch"],
+                            "measured_ceiling_lane_ops_per_s": pm["measured_int_valu_ceiling_lane_ops_per_s"],
+                            "frac_of_measured_ceiling": lane_ops / pm["measured_int_valu_ceiling_lane_ops_per_s"],
+                            "note": "executed wave64 VALU instructions (PMC, profiles/pmc_traffic.json) x 64 / exclusive scan "
+                                    "time, against the issue rate measured for this instruction mix (16 lanes/clk/SIMD)"}
         except OSError:
             pass
         out = {
@@ -330,6 +338,7 @@ def main():
                 "note": "16 algorithmic lane-ops (8 xor + 8 bcnt) per 256-bit distance x directed "
                         "distances the reference evaluates; peak = CUs x 128 lanes/clk x max clock",
                 "evals_per_launch": info["directed_evals"], "executed_evals_per_launch": info["distance_evals"],
+                "executed": executed,
             },
             "kernel_ms": {"scan": excl_scan_ms, "merge+finalize": excl_fin_ms,
                           "scan_in_timed_region": scan_ms / max(runs, 1),
