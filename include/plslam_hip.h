@@ -279,6 +279,21 @@ int plslam_map2kf_match_lines(plslam_ctx* ctx, const plslam_cam* K, const double
                               int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
                               int32_t* map_to_kf, int32_t* n_matches);
 
+/* ---- LBD float -> 256-bit binary line descriptor (producer of the matcher's LBD rows) ----- */
+/* Replaces the "fill current row with binary descriptor" loop of BinaryDescriptor::computeImpl,
+ * 3rdparty/line_descriptor/src/binary_descriptor_custom.cpp:653-668, with
+ * binaryConversion (:401-412: bit i of a byte set iff f1[i] > f2[i]) over the 32 band pairs of
+ * combinations[32][2] (:74-107); NUM_OF_BANDS 9 (:57) x 8 floats = 72 floats per line.
+ *   lbd_f32  n x 72 float32, row-major contiguous (the ScaleLines' `descriptor` vectors, packed)
+ *   desc_u8  n x 32 uint8: the cv::Mat(n,32,CV_8UC1) rows StVO::match consumes for lines
+ * Comparisons with a NaN operand leave the bit clear, as in the reference.  The _dev form takes
+ * device pointers (both 16-byte aligned) and enqueues on `stream`
+ * (NULL = the context's stream) without synchronising. */
+#define PLSLAM_LBD_FLOATS 72
+int plslam_lbd_binarise(plslam_ctx* ctx, const float* lbd_f32, int32_t n, uint8_t* desc_u8);
+int plslam_lbd_binarise_dev(plslam_ctx* ctx, const float* lbd_f32, int32_t n, uint8_t* desc_u8,
+                            void* stream);
+
 /* ---- multi-GPU: gather of per-frame match tables over RCCL/xGMI -------------------------- */
 /* No reference counterpart (the reference is single-process).  `comm` is an ncclComm_t the
  * host created (one rank per GPU); `local` is this rank's n_local int32 match-table entries

@@ -80,6 +80,10 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     for f in (lib.plo_map_point_visible, lib.plo_map_line_visible):
         f.argtypes = [C.POINTER(Cam), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         f.restype = None
+    lib.plo_lbd_binarise.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.plo_lbd_binarise.restype = None
+    lib.plo_lbd_binary_conversion.argtypes = [C.c_void_p, C.c_void_p]
+    lib.plo_lbd_binary_conversion.restype = C.c_uint8
     return lib
 
 
@@ -302,6 +306,28 @@ def map2kf_match(kind, cam, Twf, LM, med_desc, candidate, kf_desc, kf_feat, kf_i
     n = f(C.byref(cam), _p(Twf), _p(LM), _p(md), _p(cand), LM.shape[0], _p(kd), _p(kf), _p(ki), kd.shape[0],
           float(nnr), int(bool(mutual)), float(max_epip), int(min_matches), _p(out))
     return out, int(n)
+
+
+def lbd_pairs():
+    """combinations[32][2] (binary_descriptor_custom.cpp:74-107) as a (32, 2) int array."""
+    arr = (C.c_int * 64).in_dll(lib(), "plo_lbd_pairs")
+    return np.array(list(arr), np.int32).reshape(32, 2)
+
+
+def lbd_binarise(lbd_f32):
+    """computeImpl's binary conversion (binary_descriptor_custom.cpp:653-668): n x 72 f32 -> n x 32 u8."""
+    f = _c(lbd_f32, np.float32).reshape(-1, 72)
+    out = np.empty((f.shape[0], 32), np.uint8)
+    lib().plo_lbd_binarise(_p(f), f.shape[0], _p(out))
+    return out
+
+
+def np_lbd_binarise(lbd_f32):
+    """numpy mirror of lbd_binarise (different formulation: whole-array compare + packbits)."""
+    f = _c(lbd_f32, np.float32).reshape(-1, 9, 8)
+    pr = lbd_pairs()
+    bits = f[:, pr[:, 0], :] > f[:, pr[:, 1], :]                 # n x 32 x 8, bit i = element i
+    return np.packbits(bits, axis=2, bitorder="little").reshape(-1, 32)
 
 
 # ------------------------------------------------------------------------------------------

@@ -635,3 +635,36 @@ int32_t plo_map2kf_match_lines(const plo_cam* K, const double Twf[16], const dou
     return map2kf_driver(1, K, Twf, Lw, med_desc, candidate, n_map, kf_desc, kf_le, kf_idx, n_kf, nnr,
                          mutual, max_epip, min_matches, map_to_kf);
 }
+
+/* ---- LBD float -> binary line descriptor -------------------------------------------------- */
+/* binary_descriptor_custom.cpp:74-107 -- band index pairs of the 32 output bytes */
+const int plo_lbd_pairs[32][2] = {
+    {0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6},
+    {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6},
+    {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7}, {2, 8},
+    {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8},
+    {4, 5}, {4, 6}, {4, 7}, {4, 8},
+    {5, 6}, {5, 7}, {5, 8},
+    {6, 7}, {6, 8},
+    {7, 8}};
+
+/* binary_descriptor_custom.cpp:401-412 (get2Pow(i) = 2^i for 0<=i<=7, :338-341) */
+uint8_t plo_lbd_binary_conversion(const float* f1, const float* f2)
+{
+    uint8_t result = 0;
+    for (int i = 0; i < 8; ++i)
+        if (f1[i] > f2[i]) result = (uint8_t)(result + (1u << i));
+    return result;
+}
+
+/* binary_descriptor_custom.cpp:653-668 */
+void plo_lbd_binarise(const float* lbd, int32_t n, uint8_t* desc)
+{
+    for (int32_t l = 0; l < n; ++l) {
+        const float* v = lbd + (size_t)l * PLO_LBD_FLOATS;
+        uint8_t* row = desc + (size_t)l * 32;
+        for (int comb = 0; comb < 32; ++comb)
+            row[comb] = plo_lbd_binary_conversion(&v[8 * plo_lbd_pairs[comb][0]],
+                                                  &v[8 * plo_lbd_pairs[comb][1]]);
+    }
+}

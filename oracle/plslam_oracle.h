@@ -144,6 +144,16 @@ int32_t plo_map2kf_match_lines(const plo_cam* K, const double Twf[16], const dou
                                int32_t n_kf, float nnr, int mutual, double max_epip,
                                int32_t min_matches, int32_t* map_to_kf);
 
+/* ---- LBD float -> binary line descriptor ---------------------------------------------------
+ * 3rdparty/line_descriptor/src/binary_descriptor_custom.cpp: the 32 band pairs of
+ * combinations[32][2] (:74-107), binaryConversion (:401-412; bit i set iff f1[i] > f2[i]) and the
+ * row fill loop of computeImpl (:653-668).  lbd: n x 72 f32, desc: n x 32 u8.
+ * Pinned: tests/test_oracle_pin.py parses the pair table out of the reference source text. */
+#define PLO_LBD_FLOATS 72
+extern const int plo_lbd_pairs[32][2];
+uint8_t plo_lbd_binary_conversion(const float* f1, const float* f2);
+void plo_lbd_binarise(const float* lbd, int32_t n, uint8_t* desc);
+
 #ifdef __cplusplus
 }
 #endif

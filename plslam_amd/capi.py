@@ -32,6 +32,7 @@ ABI_SYMBOLS = (
     "plslam_lba_plan_rows", "plslam_lba_plan_destroy",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
+    "plslam_lbd_binarise", "plslam_lbd_binarise_dev",
     "plslam_gather_match_tables",
 )
 
@@ -338,6 +339,20 @@ class Context:
         _check(self._L.plslam_map_line_visible(self._h, C.byref(cam), _p(Twf), _p(Lw), Lw.shape[0], _p(vis)),
                "plslam_map_line_visible")
         return vis
+
+    def lbd_binarise(self, lbd_f32):
+        """BinaryDescriptor::computeImpl's binary conversion (binary_descriptor_custom.cpp:653-668):
+        n x 72 float32 LBD -> n x 32 uint8 rows."""
+        f = _arr(lbd_f32, np.float32, (-1, 72))
+        out = np.empty((f.shape[0], 32), np.uint8)
+        _check(self._L.plslam_lbd_binarise(self._h, _p(f), f.shape[0], _p(out)), "plslam_lbd_binarise")
+        return out
+
+    def lbd_binarise_dev(self, d_lbd_ptr, n, d_desc_ptr, stream=None):
+        """Device-pointer form; enqueues on `stream` (None = the context's stream), no sync."""
+        _check(self._L.plslam_lbd_binarise_dev(self._h, C.c_void_p(d_lbd_ptr), int(n),
+                                               C.c_void_p(d_desc_ptr), C.c_void_p(stream or 0)),
+               "plslam_lbd_binarise_dev")
 
     def map2kf_match(self, kind, cam, Twf, LM, med_desc, candidate, kf_desc, kf_feat, kf_idx, nnr, mutual,
                      max_epip, min_matches):

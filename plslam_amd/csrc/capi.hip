@@ -891,6 +891,40 @@ int plslam_map_line_visible(plslam_ctx* ctx, const plslam_cam* K, const double* 
     return visible_host(ctx, K, Twf, Lw, n, 1, vis);
 }
 
+// ---- LBD binarisation ------------------------------------------------------------------------
+int plslam_lbd_binarise_dev(plslam_ctx* ctx, const float* lbd_f32, int32_t n, uint8_t* desc_u8,
+                            void* stream)
+{
+    PLSLAM_REQUIRE(ctx && n >= 0, PLSLAM_EINVAL);
+    if (n == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(lbd_f32 && desc_u8, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(((uintptr_t)lbd_f32 & 15) == 0 && ((uintptr_t)desc_u8 & 15) == 0, PLSLAM_EINVAL);
+    DeviceGuard g(ctx->device);
+    return launch_lbd_binarise(lbd_f32, n, desc_u8,
+                               stream ? static_cast<hipStream_t>(stream) : ctx->stream);
+}
+
+int plslam_lbd_binarise(plslam_ctx* ctx, const float* lbd_f32, int32_t n, uint8_t* desc_u8)
+{
+    PLSLAM_REQUIRE(ctx && n >= 0, PLSLAM_EINVAL);
+    if (n == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(lbd_f32 && desc_u8, PLSLAM_EINVAL);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    Carver c;
+    const size_t oF = c.take((size_t)n * PLSLAM_LBD_FLOATS * 4), oC = c.take((size_t)n * 32);
+    int rc;
+    if ((rc = ctx->in_a.reserve(c.off))) return rc;
+    char* d = ctx->in_a.as<char>();
+    hipStream_t s = ctx->stream;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oF, lbd_f32, (size_t)n * PLSLAM_LBD_FLOATS * 4,
+                                    hipMemcpyHostToDevice, s));
+    if ((rc = launch_lbd_binarise((const float*)(d + oF), n, (uint8_t*)(d + oC), s))) return rc;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(desc_u8, d + oC, (size_t)n * 32, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return PLSLAM_OK;
+}
+
 // ---- RCCL gather -----------------------------------------------------------------------------
 namespace {
 typedef int (*nccl_group_fn)(void);

@@ -140,4 +140,8 @@ int launch_line_gate(const plslam_cam& K, const double* Twf16, const double* Lw,
 int launch_visible(const plslam_cam& K, const double* Twf16, const double* X, int32_t n, int lines,
                    uint8_t* vis, hipStream_t s);
 
+// --- LBD float -> binary line descriptor (lbd.hip) ---------------------------------------------
+// lbd: n x 72 f32, codes: n x 32 u8 (both 16-byte aligned)
+int launch_lbd_binarise(const float* lbd, int32_t n, uint8_t* codes, hipStream_t s);
+
 }  // namespace plslam

@@ -40,6 +40,18 @@ def tie_stress_desc(rng, n, entropy_bits=5):
     return np.ascontiguousarray(pats[rng.integers(0, pats.shape[0], size=n)])
 
 
+def lbd_float(rng, n, levels=0):
+    """n x 72 float32 rows shaped like LBD output (binary_descriptor_custom.cpp computeLBD: per band 4
+    means + 4 std-devs, unit-normalised, clipped): non-negative, <= 0.4.  levels > 0 quantises to that
+    many distinct values so that f1[i] == f2[i] ties (strict '>' in binaryConversion) are frequent."""
+    f = np.abs(rng.standard_normal((n, 72))).astype(np.float32)
+    f /= np.maximum(np.linalg.norm(f, axis=1, keepdims=True), np.float32(1e-12))
+    f = np.minimum(f, np.float32(0.4))
+    if levels > 0:
+        f = np.round(f * np.float32(levels / 0.4)).astype(np.float32) * np.float32(0.4 / levels)
+    return np.ascontiguousarray(f, np.float32)
+
+
 def stereo_stream(n_pairs, n_orb=1500, n_lbd=200, seed=SEED0, first_pair=0, tie_stress=False):
     """A stream of stereo pairs.  Returns dict of uint8 arrays:
          orb_l, orb_r : (n_pairs+1, n_orb, 32)   index 0 is the HALO = left image of the pair before

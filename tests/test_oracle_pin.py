@@ -417,3 +417,66 @@ def test_lba_golden_matches_oracle():
         m, n = O.map2kf_match(kind, cam, s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"], s["kf_idx"],
                               0.9, True, 1.0, 10)
         assert np.array_equal(m, s["map_to_kf"]) and n == int(s["n"][0])
+
+
+# ---------------------------------------------------------------- LBD binarisation ---------
+REF_LBD_SRC = "/root/reference/3rdparty/line_descriptor/src/binary_descriptor_custom.cpp"
+LBD_GOLD = os.path.join(os.path.dirname(__file__), "golden", "lbd_golden.npz")
+
+
+def test_lbd_pair_table_structure():
+    pr = O.lbd_pairs()
+    assert pr.shape == (32, 2)
+    rule = [(a, b) for a in range(9) for b in range(a + 1, 9) if not (a <= 1 and b >= 7)]
+    assert [tuple(x) for x in pr.tolist()] == rule
+
+
+def test_lbd_pair_table_pinned_to_reference_source():
+    """Parses combinations[32][2] out of the reference's own source text (this container only)."""
+    if not os.path.exists(REF_LBD_SRC):
+        pytest.skip("/root/reference not present")
+    import re
+    txt = open(REF_LBD_SRC).read()
+    m = re.search(r"combinations\[32\]\[2\]\s*=\s*\{(.*?)\};", txt, re.S)
+    assert m, "combinations table not found"
+    ref = [(int(a), int(b)) for a, b in re.findall(r"\{\s*(\d+)\s*,\s*(\d+)\s*\}", m.group(1))]
+    assert len(ref) == 32
+    assert ref == [tuple(x) for x in O.lbd_pairs().tolist()]
+    # the conversion itself: strict '>' and weight 2^i, as the source states
+    body = re.search(r"BinaryDescriptor::binaryConversion\(.*?\)\s*\{(.*?)return result", txt, re.S).group(1)
+    assert "f1[i] > f2[i]" in body and "get2Pow( i )" in body
+    assert "NUM_OF_BANDS 9" in txt
+
+
+def test_lbd_binary_conversion_known_answers():
+    f1 = np.array([1, 0, 1, 0, 1, 0, 1, 0], np.float32)
+    f0 = np.zeros(8, np.float32)
+    bc = lambda a, b: int(O.lib().plo_lbd_binary_conversion(a.ctypes.data, b.ctypes.data))
+    assert bc(f1, f0) == 0b01010101
+    assert bc(f0, f1) == 0
+    assert bc(1 - f1, f1) == 0b10101010
+    assert bc(f1, f1) == 0                                   # equality is not '>'
+    e = np.zeros(8, np.float32)
+    e[7] = 1
+    assert bc(e, f0) == 128
+    nan = np.full(8, np.nan, np.float32)
+    assert bc(nan, f0) == 0 and bc(f0, nan) == 0             # unordered compares are false
+    assert bc(np.full(8, np.inf, np.float32), np.full(8, 3.0e38, np.float32)) == 255
+    assert bc(np.zeros(8, np.float32), np.full(8, -0.0, np.float32)) == 0   # +0 > -0 is false
+
+
+@pytest.mark.parametrize("n,levels", [(0, 0), (1, 0), (31, 4), (32, 0), (33, 16), (1000, 8)])
+def test_lbd_binarise_c_vs_numpy(n, levels):
+    f = synth.lbd_float(_rng(40 + n), n, levels)
+    got = O.lbd_binarise(f)
+    assert got.shape == (n, 32)
+    np.testing.assert_array_equal(got, O.np_lbd_binarise(f))
+    if n >= 1000 and levels:
+        # quantised rows really exercise the tie rule
+        assert (f.reshape(n, 9, 8)[:, 0] == f.reshape(n, 9, 8)[:, 1]).any()
+
+
+def test_lbd_golden_matches_oracle():
+    g = np.load(LBD_GOLD)
+    np.testing.assert_array_equal(O.lbd_binarise(g["lbd_f32"]), g["desc_u8"])
+    np.testing.assert_array_equal(O.np_lbd_binarise(g["lbd_f32"]), g["desc_u8"])

@@ -170,6 +170,19 @@ def main():
                                     "note": "upload poses+landmarks (0.34 MB), K3/K4 rows, K7-K10 block assembly, download "
                                             "g + blocks (11.5 MB) to pageable host memory; the reference's dense H at this "
                                             "size would be 14 GB"}
+    # ---- K11: LBD float -> binary rows (288 B read + 32 B written per line) ----
+    for tag, nlines in (("frame", 200), ("c2_step", 4096 * 2 * 200), ("stream", 8 << 20)):
+        f = torch.rand((nlines, 72), dtype=torch.float32, device=dev)
+        codes = torch.empty((nlines, 32), dtype=torch.uint8, device=dev)
+        ms_k = ev_time(lambda: ctx.lbd_binarise_dev(f.data_ptr(), nlines, codes.data_ptr(), st), iters=50, warm=5)
+        out["lbd_binarise_" + tag] = {"lines": nlines, "kernel_us": 1e3 * ms_k,
+                                      "GBps_algorithmic": nlines * 320 / (ms_k * 1e-3) / 1e9,
+                                      "frac_of_8TBps": nlines * 320 / (ms_k * 1e-3) / 8e12}
+        del f, codes
+    fh = synth.lbd_float(np.random.Generator(np.random.PCG64(1)), 1 << 18)
+    t0 = time.perf_counter()
+    O.lbd_binarise(fh)
+    out["lbd_binarise_cpu_oracle_1thread_lines_per_s"] = (1 << 18) / (time.perf_counter() - t0)
     plan.close()
     ctx.close()
     print(json.dumps(out))
