@@ -279,6 +279,27 @@ int plslam_map2kf_match_lines(plslam_ctx* ctx, const plslam_cam* K, const double
                               int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
                               int32_t* map_to_kf, int32_t* n_matches);
 
+/* ---- representative ("median") descriptor of every landmark, batched ------------------------ */
+/* Replaces the descriptor part of MapPoint::updateAverageDescDir (src/mapFeatures.cpp:51-84) and of
+ * MapLine::updateAverageDescDir (:121-157), which the reference runs per landmark whenever an
+ * observation is added (:47, :118): per landmark, the observation whose row of the pairwise
+ * Hamming matrix has the smallest element int(1+0.5*(n-1)) after sorting (:77), first row winning
+ * ties (strict '<' :78).  All landmarks in one call, observation lists concatenated:
+ *   desc_lists  total x 32 uint8  landmark l owns rows offsets[l] .. offsets[l+1]-1 (desc_list order)
+ *   offsets     n_lm+1 int32, offsets[0] = 0, non-decreasing; every list shorter than 2^23 rows
+ *   med_idx     n_lm int32: winner's position within its own list (0 for a single observation --
+ *               the constructors :28-38 -- and -1 for an empty list, which the reference never has)
+ *   med_desc    n_lm x 32 uint8 = desc_list[med_idx] (zeros for an empty list); may be NULL.  These
+ *               rows are the `med_desc` argument of plslam_map2kf_match_points/_lines.
+ * The direction average (:86-91) accumulates into an uninitialised vector upstream and is not
+ * reproduced.  The _dev form takes device pointers (4-byte aligned) plus the total row count and
+ * enqueues on `stream` (NULL = the context's stream) without synchronising. */
+int plslam_median_desc_batched(plslam_ctx* ctx, const uint8_t* desc_lists, const int32_t* offsets,
+                               int32_t n_lm, int32_t* med_idx, uint8_t* med_desc);
+int plslam_median_desc_batched_dev(plslam_ctx* ctx, const uint8_t* desc_lists, const int32_t* offsets,
+                                   int32_t n_lm, int32_t total, int32_t* med_idx, uint8_t* med_desc,
+                                   void* stream);
+
 /* ---- LBD float -> 256-bit binary line descriptor (producer of the matcher's LBD rows) ----- */
 /* Replaces the "fill current row with binary descriptor" loop of BinaryDescriptor::computeImpl,
  * 3rdparty/line_descriptor/src/binary_descriptor_custom.cpp:653-668, with

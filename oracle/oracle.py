@@ -80,6 +80,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     for f in (lib.plo_map_point_visible, lib.plo_map_line_visible):
         f.argtypes = [C.POINTER(Cam), C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         f.restype = None
+    lib.plo_median_desc_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.plo_median_desc_batched.restype = None
     lib.plo_lbd_binarise.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.plo_lbd_binarise.restype = None
     lib.plo_lbd_binary_conversion.argtypes = [C.c_void_p, C.c_void_p]
@@ -191,6 +193,27 @@ def match_batched(d1, off1, d2, off2, nnr, mutual=True, nthreads=1, L=None):
 def median_desc(descs) -> int:
     d = _desc(descs)
     return int(lib().plo_median_desc(_p(d), d.shape[0]))
+
+
+def median_desc_batched(desc_lists, offsets):
+    """updateAverageDescDir (src/mapFeatures.cpp:51-84) for every landmark -> (med_idx, med_desc)."""
+    d, off = _desc(desc_lists), _c(offsets, np.int32)
+    n_lm = off.shape[0] - 1
+    idx = np.empty(n_lm, np.int32)
+    md = np.empty((n_lm, 32), np.uint8)
+    lib().plo_median_desc_batched(_p(d), _p(off), n_lm, _p(idx), _p(md))
+    return idx, md
+
+
+def np_median_desc(descs) -> int:
+    """numpy mirror of median_desc: full matrix, np.sort rows, literal index expression, argmin
+    (first minimum)."""
+    d = _desc(descs)
+    n = d.shape[0]
+    if n <= 1:
+        return 0
+    D = np.sort(np_dist_matrix(d, d), axis=1)
+    return int(np.argmin(D[:, int(1 + 0.5 * (n - 1))]))
 
 
 def inverse_se3(T):

@@ -238,6 +238,20 @@ int32_t plo_median_desc(const uint8_t* descs, int32_t n)
     return max_idx;
 }
 
+void plo_median_desc_batched(const uint8_t* descs, const int32_t* off, int32_t n_lm, int32_t* med_idx,
+                             uint8_t* med_desc)
+{
+    for (int32_t l = 0; l < n_lm; ++l) {
+        const int32_t n = off[l + 1] - off[l];
+        const uint8_t* list = descs + (size_t)off[l] * 32;
+        med_idx[l] = n > 0 ? plo_median_desc(list, n) : -1;
+        if (med_desc) {
+            if (n > 0) memcpy(med_desc + (size_t)l * 32, list + (size_t)med_idx[l] * 32, 32); /* :84 */
+            else memset(med_desc + (size_t)l * 32, 0, 32);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------ */
 /* SE(3) helpers (stvo-pl auxiliar.cpp [RECALL]); 4x4 row-major                          */
 /* ------------------------------------------------------------------------------------ */

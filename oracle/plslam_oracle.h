@@ -69,6 +69,10 @@ void plo_match_batched_mt(const uint8_t* d1, const int32_t* off1, const uint8_t*
 /* returns the index of the observation whose median Hamming distance to all
  * observations (itself included, d=0) is smallest; first minimum wins. */
 int32_t plo_median_desc(const uint8_t* descs, int32_t n);
+/* the same for every landmark of a map: lists concatenated, landmark l = rows off[l]..off[l+1]-1.
+ * med_idx[l] = plo_median_desc of its list (-1 for an empty list), med_desc (optional) = that row. */
+void plo_median_desc_batched(const uint8_t* descs, const int32_t* off, int32_t n_lm, int32_t* med_idx,
+                             uint8_t* med_desc);
 
 /* ---- SE(3) helpers (stvo-pl auxiliar.cpp, [RECALL]) -------------------------------- */
 void plo_inverse_se3(const double T[16], double Tinv[16]);      /* [R^T, -R^T t] */

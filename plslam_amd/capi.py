@@ -33,6 +33,7 @@ ABI_SYMBOLS = (
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
     "plslam_lbd_binarise", "plslam_lbd_binarise_dev",
+    "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
     "plslam_gather_match_tables",
 )
 
@@ -339,6 +340,26 @@ class Context:
         _check(self._L.plslam_map_line_visible(self._h, C.byref(cam), _p(Twf), _p(Lw), Lw.shape[0], _p(vis)),
                "plslam_map_line_visible")
         return vis
+
+    def median_desc_batched(self, desc_lists, offsets, want_desc=True):
+        """MapPoint/MapLine::updateAverageDescDir (src/mapFeatures.cpp:51-84, :121-157) for all landmarks
+        -> (med_idx[n_lm], med_desc[n_lm, 32] or None)."""
+        d = _arr(desc_lists, np.uint8, (-1, 32))
+        off = _arr(offsets, np.int32)
+        n_lm = off.shape[0] - 1
+        idx = np.empty(max(n_lm, 0), np.int32)
+        md = np.empty((max(n_lm, 0), 32), np.uint8) if want_desc else None
+        _check(self._L.plslam_median_desc_batched(self._h, _p(d), _p(off), n_lm, _p(idx),
+                                                  _p(md) if want_desc else C.c_void_p(None)),
+               "plslam_median_desc_batched")
+        return idx, md
+
+    def median_desc_batched_dev(self, d_desc_ptr, d_off_ptr, n_lm, total, d_idx_ptr, d_med_ptr=0, stream=None):
+        """Device-pointer form; enqueues on `stream` (None = the context's stream), no sync."""
+        _check(self._L.plslam_median_desc_batched_dev(self._h, C.c_void_p(d_desc_ptr), C.c_void_p(d_off_ptr),
+                                                      int(n_lm), int(total), C.c_void_p(d_idx_ptr),
+                                                      C.c_void_p(d_med_ptr or None), C.c_void_p(stream or 0)),
+               "plslam_median_desc_batched_dev")
 
     def lbd_binarise(self, lbd_f32):
         """BinaryDescriptor::computeImpl's binary conversion (binary_descriptor_custom.cpp:653-668):

@@ -891,6 +891,52 @@ int plslam_map_line_visible(plslam_ctx* ctx, const plslam_cam* K, const double* 
     return visible_host(ctx, K, Twf, Lw, n, 1, vis);
 }
 
+// ---- representative descriptors ---------------------------------------------------------------
+int plslam_median_desc_batched_dev(plslam_ctx* ctx, const uint8_t* desc_lists, const int32_t* offsets,
+                                   int32_t n_lm, int32_t total, int32_t* med_idx, uint8_t* med_desc,
+                                   void* stream)
+{
+    PLSLAM_REQUIRE(ctx && n_lm >= 0 && total >= 0, PLSLAM_EINVAL);
+    if (n_lm == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(offsets && med_idx && (total == 0 || desc_lists), PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(((uintptr_t)desc_lists & 3) == 0 && ((uintptr_t)med_desc & 3) == 0, PLSLAM_EINVAL);
+    DeviceGuard g(ctx->device);
+    return launch_median_desc(desc_lists, offsets, n_lm, total, med_idx, med_desc,
+                              stream ? static_cast<hipStream_t>(stream) : ctx->stream);
+}
+
+int plslam_median_desc_batched(plslam_ctx* ctx, const uint8_t* desc_lists, const int32_t* offsets,
+                               int32_t n_lm, int32_t* med_idx, uint8_t* med_desc)
+{
+    PLSLAM_REQUIRE(ctx && n_lm >= 0, PLSLAM_EINVAL);
+    if (n_lm == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(offsets && med_idx && offsets[0] == 0, PLSLAM_EINVAL);
+    for (int32_t l = 0; l < n_lm; ++l) {
+        const int64_t n = (int64_t)offsets[l + 1] - offsets[l];
+        PLSLAM_REQUIRE(n >= 0 && n < (1 << 23), PLSLAM_EINVAL);
+    }
+    const int32_t total = offsets[n_lm];
+    PLSLAM_REQUIRE(total == 0 || desc_lists, PLSLAM_EINVAL);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    Carver c;
+    const size_t oD = c.take((size_t)total * 32), oO = c.take((size_t)(n_lm + 1) * 4),
+                 oI = c.take((size_t)n_lm * 4), oM = c.take((size_t)n_lm * 32);
+    int rc;
+    if ((rc = ctx->in_a.reserve(c.off))) return rc;
+    char* d = ctx->in_a.as<char>();
+    hipStream_t s = ctx->stream;
+    if (total) PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oD, desc_lists, (size_t)total * 32, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oO, offsets, (size_t)(n_lm + 1) * 4, hipMemcpyHostToDevice, s));
+    if ((rc = launch_median_desc((const uint8_t*)(d + oD), (const int32_t*)(d + oO), n_lm, total,
+                                 (int32_t*)(d + oI), med_desc ? (uint8_t*)(d + oM) : nullptr, s)))
+        return rc;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(med_idx, d + oI, (size_t)n_lm * 4, hipMemcpyDeviceToHost, s));
+    if (med_desc) PLSLAM_HIP_CHECK(hipMemcpyAsync(med_desc, d + oM, (size_t)n_lm * 32, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return PLSLAM_OK;
+}
+
 // ---- LBD binarisation ------------------------------------------------------------------------
 int plslam_lbd_binarise_dev(plslam_ctx* ctx, const float* lbd_f32, int32_t n, uint8_t* desc_u8,
                             void* stream)

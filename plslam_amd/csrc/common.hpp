@@ -140,6 +140,12 @@ int launch_line_gate(const plslam_cam& K, const double* Twf16, const double* Lw,
 int launch_visible(const plslam_cam& K, const double* Twf16, const double* X, int32_t n, int lines,
                    uint8_t* vis, hipStream_t s);
 
+// --- representative descriptor per landmark (median_desc.hip) ---------------------------------
+// desc: total x 32 u8 (4-byte aligned), off: n_lm+1 CSR offsets (device), med_idx: n_lm, med_desc:
+// n_lm x 32 or nullptr.  memset + 2 kernels on s.
+int launch_median_desc(const uint8_t* desc, const int32_t* off, int32_t n_lm, int32_t total,
+                       int32_t* med_idx, uint8_t* med_desc, hipStream_t s);
+
 // --- LBD float -> binary line descriptor (lbd.hip) ---------------------------------------------
 // lbd: n x 72 f32, codes: n x 32 u8 (both 16-byte aligned)
 int launch_lbd_binarise(const float* lbd, int32_t n, uint8_t* codes, hipStream_t s);

@@ -40,6 +40,26 @@ def tie_stress_desc(rng, n, entropy_bits=5):
     return np.ascontiguousarray(pats[rng.integers(0, pats.shape[0], size=n)])
 
 
+def landmark_desc_lists(rng, n_lm, max_obs=8, flip=0.08, empty_frac=0.0, ties=False):
+    """Observation descriptor lists of n_lm landmarks (MapPoint::desc_list), concatenated.
+    Each list = noisy copies of one base row (flip = per-bit flip probability); list lengths are
+    uniform in [1, max_obs]; a fraction may be empty.  ties=True draws the noise from few patterns so
+    that equal medians between rows are common.  Returns (desc[total,32] u8, offsets[n_lm+1] i32)."""
+    lens = rng.integers(1, max_obs + 1, size=n_lm)
+    if empty_frac > 0:
+        lens[rng.random(n_lm) < empty_frac] = 0
+    off = np.zeros(n_lm + 1, np.int32)
+    np.cumsum(lens, out=off[1:])
+    total = int(off[-1])
+    base = np.repeat(random_desc(rng, n_lm), lens, axis=0) if total else np.zeros((0, 32), np.uint8)
+    if ties:
+        pats = np.packbits(rng.random((4, 256)) < flip, axis=1)
+        noise = pats[rng.integers(0, 4, size=total)]
+    else:
+        noise = np.packbits(rng.random((total, 256)) < flip, axis=1)
+    return np.ascontiguousarray(base ^ noise), off
+
+
 def lbd_float(rng, n, levels=0):
     """n x 72 float32 rows shaped like LBD output (binary_descriptor_custom.cpp computeLBD: per band 4
     means + 4 std-devs, unit-normalised, clipped): non-negative, <= 0.4.  levels > 0 quantises to that

@@ -207,6 +207,22 @@ def test_median_descriptor_restatement():
     assert O.median_desc(synth.random_desc(r, 1)) == 0
 
 
+@pytest.mark.parametrize("seed,max_obs,ties", [(0, 8, False), (1, 8, True), (2, 40, False), (3, 3, True)])
+def test_median_descriptor_batched_vs_numpy(seed, max_obs, ties):
+    d, off = synth.landmark_desc_lists(_rng(60 + seed), 300, max_obs=max_obs, empty_frac=0.05, ties=ties)
+    idx, md = O.median_desc_batched(d, off)
+    for l in range(300):
+        lst = d[off[l]:off[l + 1]]
+        if lst.shape[0] == 0:
+            assert idx[l] == -1 and not md[l].any()
+            continue
+        assert idx[l] == O.np_median_desc(lst) == O.median_desc(lst)
+        np.testing.assert_array_equal(md[l], lst[idx[l]])
+    if ties:
+        # tie stress really produces rows with equal medians (first row must win)
+        assert any(len(set(map(bytes, d[off[l]:off[l + 1]]))) < off[l + 1] - off[l] for l in range(300))
+
+
 # ---------------------------------------------------------------- SE(3) --------------------
 def test_se3_helpers():
     r = _rng(4)

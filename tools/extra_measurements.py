@@ -183,6 +183,24 @@ def main():
     t0 = time.perf_counter()
     O.lbd_binarise(fh)
     out["lbd_binarise_cpu_oracle_1thread_lines_per_s"] = (1 << 18) / (time.perf_counter() - t0)
+    # ---- K12/K13: representative descriptor of every landmark (C3 map: 10 000 x 5 + 2 000 x 5) ----
+    rr = np.random.Generator(np.random.PCG64(2))
+    for tag, n_lm, n_obs in (("c3_map", 12000, 5), ("big_map", 1 << 20, 8)):
+        lists = synth.random_desc(rr, n_lm * n_obs)
+        off = (np.arange(n_lm + 1) * n_obs).astype(np.int32)
+        dl, do = torch.from_numpy(lists).to(dev), torch.from_numpy(off).to(dev)
+        di = torch.empty(n_lm, dtype=torch.int32, device=dev)
+        dm = torch.empty((n_lm, 32), dtype=torch.uint8, device=dev)
+        ms_m = ev_time(lambda: ctx.median_desc_batched_dev(dl.data_ptr(), do.data_ptr(), n_lm, n_lm * n_obs,
+                                                           di.data_ptr(), dm.data_ptr(), st), iters=30, warm=3)
+        t0 = time.perf_counter()
+        nsub = min(n_lm, 50000)
+        O.median_desc_batched(lists[:nsub * n_obs], off[:nsub + 1])
+        cpu_ms = 1e3 * (time.perf_counter() - t0) * n_lm / nsub
+        out["median_desc_" + tag] = {"landmarks": n_lm, "obs_per_landmark": n_obs, "gpu_us": 1e3 * ms_m,
+                                     "landmarks_per_s": n_lm / (ms_m * 1e-3), "cpu_oracle_1thread_ms": cpu_ms,
+                                     "GBps_compulsory": (n_lm * n_obs * 32 + n_lm * 36) / (ms_m * 1e-3) / 1e9}
+        del dl, do, di, dm
     plan.close()
     ctx.close()
     print(json.dumps(out))
