@@ -25,6 +25,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_LANES_PER_CLK_PER_CU = 128  # 4 SIMD-32 per CU
+I8_MFMA_OPS_PER_CLK_PER_SIMD = 2048  # v_mfma_i32_32x32x32_i8: 65536 ops in 8 passes of 4 clk
 
 
 def usable_cpus() -> int:
@@ -279,21 +280,56 @@ def main():
         # (profiles/pmc_traffic.json) and is reported only for the configuration they were taken on.
         traffic = None
         executed = None
-        wkey = f"C2:{args.n_orb}+{args.n_lbd}:pairs{B}:sym{ctx.get_option('sym_rows')}:cap{ctx.get_option('group_cap')}"
+        mfma = info["scan_variant"] == 4
+        wkey = (f"C2:{args.n_orb}+{args.n_lbd}:pairs{B}:v{info['scan_variant']}:sym{ctx.get_option('sym_rows')}"
+                f":cap{ctx.get_option('group_cap')}")
         # (sym_rows 0 = auto: resolved per plan, reported in config.scan_block_threads: 64 => 4 rows/lane)
+        pm = None
         try:
             with open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")) as f:
-                pm = json.load(f)
-            if pm.get("workload_key") == wkey and info["scan_variant"] == 3:
-                traffic = pm["traffic_bytes_per_launch"]
-                lane_ops = pm["sq_insts_valu_per_launch"] * 64 / (excl_scan_ms / 1e3)
-                executed = {"lane_ops_per_s": lane_ops, "sq_insts_valu_per_launch": pm["sq_insts_valu_per_launch"],
-                            "measured_ceiling_lane_ops_per_s": pm["measured_int_valu_ceiling_lane_ops_per_s"],
-                            "frac_of_measured_ceiling": lane_ops / pm["measured_int_valu_ceiling_lane_ops_per_s"],
-                            "note": "executed wave64 VALU instructions (PMC, profiles/pmc_traffic.json) x 64 / exclusive scan "
-                                    "time, against the issue rate measured for this instruction mix (16 lanes/clk/SIMD)"}
+                pm = json.load(f).get("entries", {}).get(wkey)
         except OSError:
             pass
+        if pm:
+            traffic = pm["traffic_bytes_per_launch"]
+            valu_insts = pm["sq_insts_valu_per_launch"] - pm.get("sq_insts_mfma_per_launch", 0)
+            lane_ops = valu_insts * 64 / (excl_scan_ms / 1e3)
+            executed = {"lane_ops_per_s": lane_ops, "sq_insts_valu_per_launch": valu_insts,
+                        "sq_insts_mfma_per_launch": pm.get("sq_insts_mfma_per_launch", 0),
+                        "measured_ceiling_lane_ops_per_s": pm["measured_int_valu_ceiling_lane_ops_per_s"],
+                        "frac_of_measured_ceiling": lane_ops / pm["measured_int_valu_ceiling_lane_ops_per_s"],
+                        "note": "executed wave64 VALU instructions, MFMAs excluded (PMC, profiles/pmc_traffic.json) x 64 / "
+                                "exclusive scan time, against the issue rate measured for this integer instruction mix "
+                                "(16 lanes/clk/SIMD)"}
+        kernel_name = {4: "k_scan_sym_mfma", 3: "k_scan_symmetric" + ("_r4" if info["scan_block_threads"] == 64 else ""),
+                       2: "k_scan_wave_per_query", 1: "k_scan_lane_per_query"}.get(info["scan_variant"], "k_scan")
+        timing_note = ("kernel_ms = exclusive duration (5 serial launches after the timed region, HIP events on the launch "
+                       "stream); in the timed region consecutive steps overlap on two streams, so start-to-end times there "
+                       "include the other step's share of the GPU")
+        hbm_roofline = {
+            "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel_name,
+            "kernel_ms": 1e3 * scan_s, "kernel_ms_in_timed_region": scan_ms / max(runs, 1), "timing": timing_note,
+            "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
+            "note": "compulsory-byte model 32(Q+T)+16Q per directed scan; at ~17 k distance evaluations per compulsory "
+                    "kilobyte the path is compute-bound on any formulation, so this fraction is small by construction",
+        }
+        if mfma:
+            # K1e: distances come from v_mfma_i32_32x32x32_i8; 256 multiply-accumulates = 512 ops per executed distance
+            i8_peak = devinfo["cu_count"] * 4 * I8_MFMA_OPS_PER_CLK_PER_SIMD * devinfo["clock_khz"] * 1e3
+            mfma_ops = info["distance_evals"] * 512
+            roofline = {
+                "bound": "mfma", "achieved": mfma_ops / scan_s / 1e12, "peak": i8_peak / 1e12, "unit": "TFLOP/s",
+                "frac": mfma_ops / scan_s / i8_peak, "traffic": traffic, "kernel": kernel_name,
+                "kernel_ms": 1e3 * scan_s, "kernel_ms_in_timed_region": scan_ms / max(runs, 1), "timing": timing_note,
+                "algorithmic_ops_per_launch": mfma_ops,
+                "note": "integer ops (i8 multiply-accumulate = 2 ops), dense i8 MFMA peak = CUs x 4 SIMDs x 2048 ops/clk x "
+                        "max clock (MI355X_MICROARCH.md measures 4404 T for the 32x32 shape); 512 ops per executed 256-bit "
+                        "distance (each serves both match directions).  The kernel is co-limited by the VALU best-2 "
+                        "bookkeeping that consumes the accumulators: see valu_roofline.executed",
+            }
+        else:
+            roofline = hbm_roofline
         out = {
             "metric": "stereo pairs/sec (1500 ORB + 200 LBD BF-match)",
             "value": pairs_total / elapsed,
@@ -305,7 +341,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32",
+            "dtype": "i8" if mfma else "u32",
             "data": "synthetic",
             "config": {
                 "workload": f"C2: synthetic 752x480 stereo stream, {args.n_orb} ORB + {args.n_lbd} LBD per image, "
@@ -317,26 +353,15 @@ def main():
                                ("single GPU; consecutive steps alternate two output buffers / HIP streams" if overlap
                                 else "single GPU"),
             },
-            "roofline": {
-                "bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": {3: "k_scan_symmetric" + ("_r4" if info["scan_block_threads"] == 64 else ""),
-                           2: "k_scan_wave_per_query", 1: "k_scan_lane_per_query"}.get(info["scan_variant"], "k_scan"),
-                "kernel_ms": 1e3 * scan_s,
-                "kernel_ms_in_timed_region": scan_ms / max(runs, 1),
-                "timing": "kernel_ms = exclusive duration (5 serial launches after the timed region, HIP events on "
-                          "the launch stream); in the timed region consecutive steps overlap on two streams, so "
-                          "start-to-end times there include the other step's share of the GPU",
-                "algorithmic_bytes_per_launch": info["algorithmic_bytes"],
-                "note": "compulsory-byte model 32(Q+T)+16Q per directed scan; the kernel is VALU "
-                        "(xor+popcount) bound, see valu_roofline",
-            },
+            "roofline": roofline,
+            "hbm_roofline": hbm_roofline,
             "valu_roofline": {
                 "bound": "valu-int", "achieved": info["directed_evals"] * 16 / scan_s / 1e12,
                 "peak": valu_peak / 1e12, "unit": "T lane-ops/s",
                 "frac": info["directed_evals"] * 16 / scan_s / valu_peak,
-                "note": "16 algorithmic lane-ops (8 xor + 8 bcnt) per 256-bit distance x directed "
-                        "distances the reference evaluates; peak = CUs x 128 lanes/clk x max clock",
+                "note": "16 algorithmic lane-ops (8 xor + 8 bcnt) per 256-bit distance x directed distances the "
+                        "reference evaluates, priced as if done on the VALU; peak = CUs x 128 lanes/clk x max clock "
+                        "(frac > 1 is possible when the distances come from the matrix cores)",
                 "evals_per_launch": info["directed_evals"], "executed_evals_per_launch": info["distance_evals"],
                 "executed": executed,
             },

@@ -9,7 +9,7 @@ device-memory handling through torch, sharding over ranks); the C++ host shim th
 the reference's ``StVO::match`` signature lives in plslam_amd/host.
 """
 from .capi import (Cam, Context, MatchPlan, LbaPlan, PlslamError, LIB_PATH, ABI_SYMBOLS, make_cam, load,
-                   SCAN_AUTO, SCAN_LANE_PER_QUERY, SCAN_WAVE_PER_QUERY, SCAN_SYMMETRIC)
+                   SCAN_AUTO, SCAN_LANE_PER_QUERY, SCAN_WAVE_PER_QUERY, SCAN_SYMMETRIC, SCAN_MFMA)
 
 __all__ = ["Cam", "Context", "MatchPlan", "LbaPlan", "PlslamError", "LIB_PATH", "ABI_SYMBOLS", "make_cam", "load",
-           "SCAN_AUTO", "SCAN_LANE_PER_QUERY", "SCAN_WAVE_PER_QUERY", "SCAN_SYMMETRIC"]
+           "SCAN_AUTO", "SCAN_LANE_PER_QUERY", "SCAN_WAVE_PER_QUERY", "SCAN_SYMMETRIC", "SCAN_MFMA"]

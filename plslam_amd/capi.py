@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libplslam_hip.so")
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ERANGE, ENOTSUP = 0, -1, -2, -3, -4, -5, -6
-SCAN_AUTO, SCAN_LANE_PER_QUERY, SCAN_WAVE_PER_QUERY, SCAN_SYMMETRIC = 0, 1, 2, 3
+SCAN_AUTO, SCAN_LANE_PER_QUERY, SCAN_WAVE_PER_QUERY, SCAN_SYMMETRIC, SCAN_MFMA = 0, 1, 2, 3, 4
 MAX_TRAIN_ROWS = 1 << 23
 
 # every symbol include/plslam_hip.h declares (tests check the .so exports all of them)

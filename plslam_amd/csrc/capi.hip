@@ -69,6 +69,7 @@ struct plslam_match_plan {
     int variant = 0, block_threads = 0;
     int32_t nprob = 0, nscan = 0, nscan_blocks = 0, nfin_blocks = 0, ncounts = 0;
     int32_t nsym = 0, nsym_blocks = 0, nmerge_blocks = 0, sym_rows = 1;
+    bool sym_mfma = false;             // symmetric problems run on K1e (matrix cores)
     DevBuf keys, counts, partials;
     DevBuf tables;                     // all launch tables, packed, uploaded with ONE copy
     std::vector<char> staging;         // host image of `tables` (kept alive: the copy is async)
@@ -100,8 +101,11 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->ctx = ctx;
     P->nprob = nprob;
 
-    // AUTO: mutual problems take the symmetric scan (one distance feeds both directions), the
-    // others the directed lane-per-query scan.  A forced variant applies to every problem.
+    // AUTO: mutual problems take the symmetric scan (one distance feeds both directions) -- on the
+    // matrix cores (K1e) when every such problem has n2 <= 2048, else as XOR+popcount (K1b/K1b') -- and
+    // the others the directed lane-per-query scan.  A forced variant applies to every problem
+    // (SYMMETRIC = the XOR+popcount form).  Measured, scan time per launch, C2 batches of 64 / 256 / 1024 /
+    // 4096 pairs: K1e 0.12 / 0.45 / 1.69 / 6.0 ms, K1b(') 0.24 / 0.78 / 2.85 / 10.9 ms.
     // A plan too small to put one wave on every SIMD under those (e.g. ONE StVO::match call of the
     // SLAM loop) takes the wave-per-query scan instead: 16 queries per workgroup, train tile in LDS.
     int64_t thr_waves = 0;   // waves the throughput kernels would launch: one per 64 rows of d1
@@ -110,14 +114,20 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     const bool use_wpq = ctx->scan_variant == PLSLAM_SCAN_WAVE_PER_QUERY ||
                          (ctx->scan_variant == PLSLAM_SCAN_AUTO && thr_waves < simds);
     const bool allow_sym = !use_wpq &&
-                           (ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_SYMMETRIC);
+                           (ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_SYMMETRIC ||
+                            ctx->scan_variant == PLSLAM_SCAN_MFMA);
     auto is_sym = [&](const plslam_match_problem& p) { return allow_sym && p.mutual && p.n1 > 0 && p.n2 > 0; };
 
     // sym_rows 0 = auto: 4 rows of d1 per lane (4x fewer column partials, slightly faster) once the
     // plan has enough 256-row waves for >= 6 full rounds of the chip (17 single-wave workgroups fit a
     // CU's LDS); below that the 4x coarser work units lose more to tail quantisation than they gain
     // (measured: 266k vs 320k pairs/s at 512 pairs, 347k vs 344k at 2048, 364k vs 347k at 4096).
-    P->sym_rows = ctx->sym_rows;
+    // K1e keeps its row state as 16-bit (distance, tile) keys: 64 tiles of 32 columns.  A plan with a
+    // longer mutual problem takes the XOR+popcount symmetric scan instead.
+    P->sym_mfma = allow_sym && (ctx->scan_variant == PLSLAM_SCAN_MFMA || ctx->scan_variant == PLSLAM_SCAN_AUTO);
+    for (int32_t i = 0; i < nprob && P->sym_mfma; ++i)
+        if (is_sym(probs[i]) && probs[i].n2 > 2048) P->sym_mfma = false;
+    P->sym_rows = P->sym_mfma ? 4 : ctx->sym_rows;      // K1e uses the 256-row tables of K1b'
     if (P->sym_rows == 0) {
         int64_t waves4 = 0;
         for (int32_t i = 0; i < nprob; ++i)
@@ -292,8 +302,8 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->info.algorithmic_bytes = abytes;  // 32(Q+T)+16Q per DIRECTED scan, however executed
     P->info.n_scans = P->nscan + 2 * P->nsym;
     P->info.scan_blocks = P->nscan_blocks + P->nsym_blocks;
-    P->info.scan_variant = P->nsym ? PLSLAM_SCAN_SYMMETRIC : directed_variant;
-    P->info.scan_block_threads = P->nsym ? (P->sym_rows == 4 ? 64 : 256) : P->block_threads;
+    P->info.scan_variant = P->nsym ? (P->sym_mfma ? PLSLAM_SCAN_MFMA : PLSLAM_SCAN_SYMMETRIC) : directed_variant;
+    P->info.scan_block_threads = P->nsym ? (P->sym_rows == 4 && !P->sym_mfma ? 64 : 256) : P->block_threads;
 
     // pack every launch table into one host image and upload it with a single copy
     struct Piece { const void* src; size_t bytes; size_t off; };
@@ -346,8 +356,10 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
     int r;
     const bool sym_first = P->nsym_blocks > 0;
     if (sym_first) {
-        r = launch_scan_sym(P->sym_rows, P->d_syms, P->d_sym_blocks,
-                            P->nsym_blocks, P->d_counts_zero, P->ncounts, s);
+        r = P->sym_mfma ? launch_scan_sym_mfma(P->d_syms, P->d_sym_blocks, P->nsym_blocks, P->d_counts_zero,
+                                               P->ncounts, s)
+                        : launch_scan_sym(P->sym_rows, P->d_syms, P->d_sym_blocks,
+                                          P->nsym_blocks, P->d_counts_zero, P->ncounts, s);
         if (r) return r;
     }
     if (P->nscan_blocks > 0 || !sym_first) {
@@ -454,7 +466,7 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
 {
     PLSLAM_REQUIRE(ctx && key, PLSLAM_EINVAL);
     if (!strcmp(key, "scan_variant")) {
-        PLSLAM_REQUIRE(value >= PLSLAM_SCAN_AUTO && value <= PLSLAM_SCAN_SYMMETRIC, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(value >= PLSLAM_SCAN_AUTO && value <= PLSLAM_SCAN_MFMA, PLSLAM_EINVAL);
         ctx->scan_variant = value;
         return PLSLAM_OK;
     }

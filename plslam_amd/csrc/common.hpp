@@ -113,6 +113,10 @@ int sym_rows_per_block(int rows_per_lane);
 int sym_rows_per_partial(int rows_per_lane);
 int launch_scan_sym(int rows_per_lane, const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks,
                     int32_t* d_zero, int nzero, hipStream_t s);
+// K1e: the symmetric scan on the matrix cores (hamming_mfma.hip); block tables / partials as for
+// launch_scan_sym(rows_per_lane = 4): 256 a-rows per workgroup and per column partial
+int launch_scan_sym_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
+                         int nzero, hipStream_t s);
 int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s);
 
 int scan_rows_per_block(int variant, int block_threads);

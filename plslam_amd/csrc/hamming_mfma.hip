@@ -1,0 +1,360 @@
+// hamming_mfma.hip -- K1e: symmetric 256-bit Hamming kNN-2 scan on the matrix cores (gfx950).
+//
+// Same contract as K1b/K1b' (hamming.hip): for a mutual problem (a: n1 rows, b: n2 rows) produce
+// keys12[i] = best-2 over j and the column partials part21[i-block][j] = best-2 over the block's i,
+// keys = (distance << 23) | index, i.e. cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) order in both
+// directions (reference call sites src/mapHandler.cpp:277,424,597,712,3223,3249).
+//
+// The Hamming distance of two bit rows IS a contraction: with s(x) = 1 - 2x in {+1,-1},
+//     sum_k s(a_k) s(b_k) = 256 - 2 d(a,b).
+// A rows are expanded to bytes -s(a) (0xFF / 0x01), B rows to bytes s(b) (0x01 / 0xFF), the accumulator
+// starts at 256, and v_mfma_i32_32x32x32_i8 (8 K-steps) leaves acc = 2 d -- exact integers, so the
+// keys, and with them every match table, are bit-identical to the XOR+popcount kernels.
+// Per 32x32 tile a wave issues 8 MFMAs (the matrix pipe) instead of 16 x 16 VALU ops per lane; what
+// stays on the VALU is the best-2 bookkeeping: 3 ops per element and direction.
+//
+// Work decomposition = K1b': one workgroup per 256 rows of `a` (same block tables, same partial
+// table, same merge + finalize kernels).  4 waves; wave w keeps its 64 rows (2 M-tiles) expanded in
+// 64 VGPRs for the whole scan.  `b` is streamed in tiles of 32 rows: the 256 lanes expand one raw
+// dword each (32 bits -> 32 bytes: v_bfe, v_mul_u32_u24, v_and, v_perm per 4 bytes) into a
+// double-buffered LDS tile whose 272-byte row stride makes the ds_read_b128 operand reads
+// conflict-free.  Only the lane->k mapping shared by the A and the B operand matters for a
+// contraction over all k, so no assumption about the instruction's internal k order is made.
+// C/D layout (dtype-independent): col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+//   row direction : lane keeps best-2 per (M-tile, reg) over the columns it sees (j = lane & 31 mod 32);
+//                   one 5-step butterfly at the end of the scan completes them.
+//   column direction: best-2 over the lane's 32 accumulators (local row index as an inline constant),
+//                   halves combined by one cross-lane step, the four waves through LDS, one partial
+//                   per 256 rows of `a`, as K1b'.
+#include "common.hpp"
+
+#include <type_traits>
+
+// build-time experiments for tools/scan_time.py (results are WRONG with any of them on):
+//   1 = no workgroup barrier, 2 = no epilogue, 3 = no MFMA
+#ifndef PLSLAM_MF_EXPERIMENT
+#define PLSLAM_MF_EXPERIMENT 0
+#endif
+
+namespace plslam {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4), aligned(4)));   // descriptor rows are only 4-byte aligned
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int MF_TILE_N = 32;                 // b rows per tile
+constexpr int MF_ROW_STRIDE = 272;            // bytes per expanded b row in LDS (256 + 16: 4-bank skew)
+constexpr int MF_TILE_BYTES = MF_TILE_N * MF_ROW_STRIDE;
+constexpr uint32_t LUT_A = 0x000001FFu;       // v_perm source: selector 0 -> 0xFF (-1), 1 -> 0x01 (+1)
+constexpr uint32_t LUT_B = 0x0000FF01u;       //                selector 0 -> 0x01 (+1), 1 -> 0xFF (-1)
+
+__device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t med3_(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ void push2(uint32_t& b0, uint32_t& b1, uint32_t key)
+{
+    const uint32_t nb1 = med3_(b0, b1, key);
+    b0 = umin_(b0, key);
+    b1 = nb1;
+}
+__device__ __forceinline__ void merge2(uint32_t& a0, uint32_t& a1, uint32_t c0, uint32_t c1)
+{
+    const uint32_t lo = umin_(a0, c0);
+    const uint32_t hi = umin_(umax_(a0, c0), umin_(a1, c1));
+    a0 = lo;
+    a1 = hi;
+}
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// two sorted streams of 16-bit keys, one per half of the register
+__device__ __forceinline__ void pk_push2(uint32_t& b0, uint32_t& b1, uint32_t key)
+{
+    b1 = pk_min16(b1, pk_max16(b0, key));
+    b0 = pk_min16(b0, key);
+}
+// accumulators of the two M-tiles (acc = 2 d <= 512) side by side: hi << 16 | lo
+__device__ __forceinline__ uint32_t pack_acc(int lo, int hi)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(r) : "v"(hi), "v"(lo));
+    return r;
+}
+// both halves -> 16-bit keys (d << 6) | tag6:  (2 d) << 5 leaves six free low bits per half
+__device__ __forceinline__ uint32_t pk_key_s(uint32_t packed, uint32_t tagpair_uniform)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, 5, %2" : "=v"(r) : "v"(packed), "s"(tagpair_uniform));
+    return r;
+}
+constexpr uint32_t KEY16_NONE = 0xFFFFu;      // real keys are <= (256 << 6) | 63 = 0x403F
+__device__ __forceinline__ uint32_t key16_to_key32(uint32_t k16, uint32_t idx_base, uint32_t idx_scale)
+{
+    return k16 > 0x7FFFu ? KEY_NONE : (((k16 >> 6) << KEY_IDX_BITS) | (idx_base + (k16 & 63u) * idx_scale));
+}
+// (acc << 22) | idx : acc = 2 d, so this is (d << 23) | idx.  One v_lshl_or_b32 each (the compiler
+// would otherwise share the shift between the row key and the column key: 3 ops for 2 keys).
+__device__ __forceinline__ uint32_t key_of(int acc2d, uint32_t idx)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, 22, %2" : "=v"(r) : "v"(acc2d), "v"(idx));
+    return r;
+}
+template <int LOC>      // idx = compile-time local row index (an inline constant, 0..63)
+__device__ __forceinline__ uint32_t key_of_loc(int acc2d)
+{
+    static_assert(LOC >= 0 && LOC <= 63, "inline constant range");
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, 22, %2" : "=v"(r) : "v"(acc2d), "n"(LOC));
+    return r;
+}
+static_assert(KEY_IDX_BITS == 23, "key_of hard-codes the shift");
+// 4 bits (bit k -> byte k) through the +-1 table
+__device__ __forceinline__ uint32_t expand4(uint32_t word, int first_bit, uint32_t lut)
+{
+    const uint32_t nib = __builtin_amdgcn_ubfe(word, first_bit, 4);
+    const uint32_t sel = __umul24(nib, 0x00204081u) & 0x01010101u;
+    return __builtin_amdgcn_perm(0u, lut, sel);
+}
+__device__ __forceinline__ i32x4 expand16(uint32_t word, int first_bit, uint32_t lut)
+{
+    i32x4 v;
+    v.x = (int)expand4(word, first_bit, lut);
+    v.y = (int)expand4(word, first_bit + 4, lut);
+    v.z = (int)expand4(word, first_bit + 8, lut);
+    v.w = (int)expand4(word, first_bit + 12, lut);
+    return v;
+}
+__device__ __forceinline__ int xcd_remap_(int orig, int nwg) { return (orig & 7) * (nwg >> 3) + (orig >> 3); }
+
+}  // namespace
+
+__global__ void __launch_bounds__(256, 2)      // 2 waves per SIMD: <= 256 unified VGPRs
+k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
+                int32_t* __restrict__ zero, int nzero)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t btile[2 * MF_TILE_BYTES];      // 17 408 B
+    __shared__ uint2 colbuf[2][4][MF_TILE_N];                                      //  2 048 B
+
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+
+    const int wg = xcd_remap_(blockIdx.x, gridDim.x);
+    const BlockDesc bd = blocks[wg];
+    if (bd.item < 0) return;                       // padding entry of the XCD-striped table
+    const SymDesc sd = syms[bd.item];
+    const int n1 = sd.n1, n2 = sd.n2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, g = lane >> 5;
+    const int i0 = bd.row0;                        // first of this workgroup's 256 a-rows
+    const int iw = i0 + 64 * w;                    // first of this wave's 64
+    const uint32_t* araw = reinterpret_cast<const uint32_t*>(sd.a);
+    const uint32_t* braw = reinterpret_cast<const uint32_t*>(sd.b);
+
+    // ---- A operands: rows iw + 32 mt + c, bits [32 kk + 16 g, +16) of each, as -s(a) bytes ---------
+    i32x4 afrag[2][8];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = iw + 32 * mt + c;
+        const int rrow = row < n1 ? row : n1 - 1;                 // clamped; masked in the epilogue
+        const u32x4_t* p = reinterpret_cast<const u32x4_t*>(araw + (size_t)rrow * 8);
+        const u32x4_t lo = p[0], hi = p[1];
+        const uint32_t wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) afrag[mt][kk] = expand16(wd[kk] >> (16 * g), 0, LUT_A);
+    }
+    i32x16 cinit;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cinit[r] = 256;
+
+    // row-direction state: per accumulator register r, the best two 16-bit keys (d << 6 | tile) of the
+    // lane's column class, M-tile 0 in the low halves and M-tile 1 in the high halves
+    uint32_t rb[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rb[r][0] = rb[r][1] = 0xFFFFFFFFu;
+
+    const bool rows_ragged = iw + 64 > n1;         // wave-uniform: some of this wave's rows do not exist
+    const uint32_t ibase = (uint32_t)(iw + 4 * g); // + local index = a-row of an accumulator
+    uint2* part = reinterpret_cast<uint2*>(sd.part21) + (size_t)(i0 >> 8) * n2;
+
+    // expansion duty of this lane: b row (tid >> 3) of the tile, dword (tid & 7) of it
+    const int ej = tid >> 3, ewd = tid & 7;
+    const int ntiles = (n2 + MF_TILE_N - 1) / MF_TILE_N;
+    auto load_raw = [&](int t) __attribute__((always_inline)) -> uint32_t {
+        int j = t * MF_TILE_N + ej;
+        j = j < n2 ? j : n2 - 1;
+        return braw[(size_t)j * 8 + ewd];
+    };
+    auto expand_store = [&](uint32_t raw, int buf) __attribute__((always_inline)) {
+        uint8_t* dst = btile + buf * MF_TILE_BYTES + ej * MF_ROW_STRIDE + ewd * 32;
+        *reinterpret_cast<i32x4*>(dst) = expand16(raw, 0, LUT_B);
+        *reinterpret_cast<i32x4*>(dst + 16) = expand16(raw, 16, LUT_B);
+    };
+    auto flush_columns = [&](int t) __attribute__((always_inline)) {              // lanes 0..31 of ONE wave: combine the 4 waves' partials of tile t
+        if (lane < MF_TILE_N) {
+            uint2 k = colbuf[t & 1][0][lane];
+#pragma unroll
+            for (int ww = 1; ww < 4; ++ww) {
+                const uint2 o = colbuf[t & 1][ww][lane];
+                merge2(k.x, k.y, o.x, o.y);
+            }
+            const int j = t * MF_TILE_N + lane;
+            if (j < n2) part[j] = k;
+        }
+    };
+
+    // Epilogue of one accumulator register pair (rows LOC and LOC + 32 of the wave, column j0 + c).
+    // MASKED = false is the steady state (every row of this wave and every column of the tile exists);
+    // the ragged cases are separate instantiations OUTSIDE the steady-state loop.
+    // 9 VALU ops for the two distances: pack, row key, 3 to push it, column key, 3 to push it.
+#define PLSLAM_MF_EPI_ROW(R)                                                                       \
+    {                                                                                              \
+        constexpr uint32_t LOC = ((R) & 3) + 8 * ((R) >> 2);                                       \
+        const uint32_t pk = pack_acc(acc0[R], acc1[R]);                                            \
+        uint32_t kr = pk_key_s(pk, tpair);                                                         \
+        uint32_t kc = pk_key_s(pk, LOC | ((LOC + 32u) << 16));                                     \
+        if (MASKED) {                                                                              \
+            kr = col_ok ? kr : 0xFFFFFFFFu;                                                        \
+            kc |= ((int)(ibase + LOC) < n1 ? 0u : 0x0000FFFFu) |                                   \
+                  ((int)(ibase + LOC + 32u) < n1 ? 0u : 0xFFFF0000u);                              \
+        }                                                                                          \
+        pk_push2(rb[R][0], rb[R][1], kr);                                                          \
+        pk_push2(cb0, cb1, kc);                                                                    \
+    }
+    // One pipeline step = M(t) fused with E(t-1):
+    //   M(t): barrier, then the 16 MFMAs of tile t into (n0, n1); the raw dwords of tile t+2 are requested
+    //         and tile t+1 (requested one step earlier: its latency is off the critical path) is expanded;
+    //   E(t-1): best-2 bookkeeping of tile t-1 from ITS accumulators (p0, p1).
+    // E(t-1) does not depend on M(t), and both sit in one basic block with an explicit interleave
+    // (1 LDS operand read, 2 MFMAs, 24 VALU ops, eight times), so the matrix pipe and the VALU of this
+    // wave work at the same time.
+    uint32_t raw1 = ntiles > 1 ? load_raw(1) : 0u;         // tile t+1 of the coming step
+    // column best-2 of a finished tile: the two halves of (cb0, cb1) are sorted streams over disjoint rows
+    // of the same column -> best 2 of the lane, local row -> a-row, then the other 32 rows (lane ^ 32)
+    auto finish_columns = [&](int t, uint32_t cb0, uint32_t cb1) __attribute__((always_inline)) {
+        const uint32_t e0 = cb0 & 0xFFFFu, o0 = cb0 >> 16, e1 = cb1 & 0xFFFFu, o1 = cb1 >> 16;
+        uint32_t k0 = key16_to_key32(umin_(e0, o0), ibase, 1u);
+        uint32_t k1 = key16_to_key32(umin_(umax_(e0, o0), umin_(e1, o1)), ibase, 1u);
+        merge2(k0, k1, (uint32_t)__shfl_xor((int)k0, 32), (uint32_t)__shfl_xor((int)k1, 32));
+        if (lane < MF_TILE_N) colbuf[t & 1][w][lane] = make_uint2(k0, k1);
+    };
+    // E(t) on its own (the last tile has no following M step to hide under)
+    auto epilogue = [&](int t, const i32x16& acc0, const i32x16& acc1, auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const bool col_ok = t * MF_TILE_N + c < n2;
+        const uint32_t tpair = (uint32_t)t * 0x00010001u;            // tile number in both halves (t < 64)
+        uint32_t cb0 = 0xFFFFFFFFu, cb1 = 0xFFFFFFFFu;
+        PLSLAM_MF_EPI_ROW(0) PLSLAM_MF_EPI_ROW(1) PLSLAM_MF_EPI_ROW(2) PLSLAM_MF_EPI_ROW(3)
+        PLSLAM_MF_EPI_ROW(4) PLSLAM_MF_EPI_ROW(5) PLSLAM_MF_EPI_ROW(6) PLSLAM_MF_EPI_ROW(7)
+        PLSLAM_MF_EPI_ROW(8) PLSLAM_MF_EPI_ROW(9) PLSLAM_MF_EPI_ROW(10) PLSLAM_MF_EPI_ROW(11)
+        PLSLAM_MF_EPI_ROW(12) PLSLAM_MF_EPI_ROW(13) PLSLAM_MF_EPI_ROW(14) PLSLAM_MF_EPI_ROW(15)
+        finish_columns(t, cb0, cb1);
+    };
+    // One pipeline step = M(t) fused with E(t-1):
+    //   M(t): barrier, then the 16 MFMAs of tile t into (m0, m1); the raw dwords of tile t+2 are requested
+    //         and tile t+1 (requested one step earlier: its latency is off the critical path) is expanded;
+    //   E(t-1): best-2 bookkeeping of tile t-1 from ITS accumulators (acc0, acc1).
+    // E(t-1) does not depend on M(t); both sit in one basic block and the scheduler is asked for an
+    // interleave (B operand reads two K-steps ahead, 2 MFMAs, ~22 VALU ops, eight times), so the matrix
+    // pipe works under the bookkeeping.  (A hand-fenced program-order interleave measured 4 % slower.)
+    auto step = [&](int t, i32x16& m0, i32x16& m1, const i32x16& acc0, const i32x16& acc1, bool with_prev,
+                    auto masked_tag) __attribute__((always_inline)) {
+        const uint32_t raw2 = t + 2 < ntiles ? load_raw(t + 2) : 0u;
+        if (PLSLAM_MF_EXPERIMENT != 1) __syncthreads();   // tile t expanded; colbuf of tile t-2 complete
+        if (t > 1 && w == (t & 3)) flush_columns(t - 2);            // the waves take turns
+        const uint8_t* bt = btile + (t & 1) * MF_TILE_BYTES + c * MF_ROW_STRIDE + 16 * g;
+        m0 = cinit;
+        m1 = cinit;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const i32x4 bf = *reinterpret_cast<const i32x4*>(bt + 32 * kk);
+            if (PLSLAM_MF_EXPERIMENT == 3) { m0[kk] += bf.x; m1[kk] += bf.y; continue; }
+            m0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[0][kk], bf, m0, 0, 0, 0);
+            m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[1][kk], bf, m1, 0, 0, 0);
+        }
+        expand_store(raw1, (t + 1) & 1);           // past the last tile: a harmless rewrite of the idle buffer
+        raw1 = raw2;
+        if (PLSLAM_MF_EXPERIMENT == 2) asm volatile("" ::"v"(m0), "v"(m1));
+        if (with_prev && PLSLAM_MF_EXPERIMENT != 2) epilogue(t - 1, acc0, acc1, masked_tag);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // LDS reads kk = 0, 1
+        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);         // VALU while they are in flight
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
+            if (kk < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // LDS read kk + 2
+            __builtin_amdgcn_sched_group_barrier(0x002, 22, 0);     // 22 VALU
+        }
+    };
+    // S(0) | S(1)+E(0) | S(2)+E(1) | ... | E(ntiles-1).  Two accumulator sets alternate (unrolled by two:
+    // no accumulator is ever copied).  Only the last tile can lack columns.
+    auto pipeline = [&](auto steady_tag) __attribute__((always_inline)) {
+        i32x16 A0, A1, B0, B1;
+        const bool last_partial = (n2 % MF_TILE_N) != 0;
+        step(0, A0, A1, A0, A1, false, steady_tag);
+        int t = 1;
+        for (; t + 1 < ntiles; t += 2) {
+            step(t, B0, B1, A0, A1, true, steady_tag);
+            step(t + 1, A0, A1, B0, B1, true, steady_tag);
+        }
+        if (t < ntiles) {                          // t == ntiles - 1: one more tile, into set B
+            step(t, B0, B1, A0, A1, true, steady_tag);
+            if (last_partial) epilogue(t, B0, B1, std::true_type{}); else epilogue(t, B0, B1, steady_tag);
+        } else {                                   // tile ntiles - 1 is in set A
+            if (last_partial) epilogue(t - 1, A0, A1, std::true_type{}); else epilogue(t - 1, A0, A1, steady_tag);
+        }
+    };
+
+    expand_store(load_raw(0), 0);
+    if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
+    // the last two tiles' column partials are still in LDS
+    __syncthreads();
+    if (ntiles > 1 && w == (ntiles & 3)) flush_columns(ntiles - 2);
+    if (w == ((ntiles + 1) & 3)) flush_columns(ntiles - 1);
+#undef PLSLAM_MF_EPI_ROW
+
+    // ---- row results: 16-bit (d, tile) -> 32-bit (d, j = 32 tile + c), then combine the 32 column
+    // classes with a butterfly; lane c keeps (reg = c & 15) ----------------------------------------------
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t h0 = mt ? rb[r][0] >> 16 : rb[r][0] & 0xFFFFu;
+            const uint32_t h1 = mt ? rb[r][1] >> 16 : rb[r][1] & 0xFFFFu;
+            uint32_t k0 = key16_to_key32(h0, (uint32_t)c, (uint32_t)MF_TILE_N);
+            uint32_t k1 = key16_to_key32(h1, (uint32_t)c, (uint32_t)MF_TILE_N);
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1)
+                merge2(k0, k1, (uint32_t)__shfl_xor((int)k0, m), (uint32_t)__shfl_xor((int)k1, m));
+            const int row = iw + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (c == r && row < n1) reinterpret_cast<uint2*>(sd.keys12)[row] = make_uint2(k0, k1);
+        }
+    }
+}
+
+int launch_scan_sym_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
+                         int nzero, hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_scan_sym_mfma, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+}  // namespace plslam

@@ -83,7 +83,7 @@ def test_symmetric_and_directed_variants_agree(ctx, oracle, n1, n2):
             d2[:k] = d1[:k] ^ np.packbits(r.random((k, 256)) < 0.06, axis=1)
         em, en = oracle.match(d1, d2, 0.9, True)
         try:
-            for variant, sym_rows in ((plslam_amd.SCAN_SYMMETRIC, 4), (plslam_amd.SCAN_SYMMETRIC, 1),
+            for variant, sym_rows in ((plslam_amd.SCAN_MFMA, 0), (plslam_amd.SCAN_SYMMETRIC, 4), (plslam_amd.SCAN_SYMMETRIC, 1),
                                       (plslam_amd.SCAN_LANE_PER_QUERY, 1), (plslam_amd.SCAN_WAVE_PER_QUERY, 1),
                                       (plslam_amd.SCAN_AUTO, 1)):
                 ctx.set_option("scan_variant", variant)
@@ -112,13 +112,14 @@ def test_all_scan_block_sizes(ctx, oracle):
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
 
 
-@pytest.fixture(params=["auto", "lane_per_query", "wave_per_query", "symmetric"])
+@pytest.fixture(params=["auto", "lane_per_query", "wave_per_query", "symmetric", "mfma"])
 def vctx(ctx, request):
     """The context with each scan variant forced in turn (AUTO picks wave-per-query for plans too
     small to fill the chip, the symmetric scan for mutual problems otherwise)."""
     import plslam_amd
     v = {"auto": plslam_amd.SCAN_AUTO, "lane_per_query": plslam_amd.SCAN_LANE_PER_QUERY,
-         "wave_per_query": plslam_amd.SCAN_WAVE_PER_QUERY, "symmetric": plslam_amd.SCAN_SYMMETRIC}[request.param]
+         "wave_per_query": plslam_amd.SCAN_WAVE_PER_QUERY, "symmetric": plslam_amd.SCAN_SYMMETRIC,
+         "mfma": plslam_amd.SCAN_MFMA}[request.param]
     ctx.set_option("scan_variant", v)
     yield ctx
     ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
@@ -213,7 +214,7 @@ def test_device_resident_plan_matches_oracle(vctx, oracle):
     bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.75, nnr_l=0.9, mutual=True)
     info = bm.plan.info()
     assert info["n_scans"] == 3 * 8 and info["directed_evals"] == 3 * 4 * (320 * 320 + 70 * 70)
-    if info["scan_variant"] == plslam_amd.SCAN_SYMMETRIC:
+    if info["scan_variant"] in (plslam_amd.SCAN_SYMMETRIC, plslam_amd.SCAN_MFMA):
         assert info["distance_evals"] == info["directed_evals"] // 2   # half the distances
     else:
         assert info["distance_evals"] == info["directed_evals"]
