@@ -3,9 +3,10 @@
 // Replaces cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) + stvo-pl matchNNR()/match()
 // (reached from src/mapHandler.cpp:277,424,597,712,3223,3249 of the reference).
 //
-// Integer XOR + popcount work: there is no dense contraction here, so no MFMA.  A 256-bit
-// distance costs 8 v_xor_b32 + 8 v_bcnt_u32_b32 (the bcnt accumulates for free); the scan is
-// VALU-issue bound, HBM sees each descriptor once.
+// The XOR + popcount forms of the scan: a 256-bit distance costs 8 v_xor_b32 + 8 v_bcnt_u32_b32 (the
+// bcnt accumulates for free); these kernels are VALU-issue bound, HBM sees each descriptor once.
+// (The default scan for mutual problems is the matrix-core form K1e in hamming_mfma.hip; the kernels
+// here serve directed problems, single small problems, n2 > 2048, and forced scan variants.)
 //
 // Result order == OpenCV batchDistance(K=2): lexicographic (distance, trainIdx).  It is encoded
 // as an unsigned min over composite keys  key = (distance << 23) | trainIdx  so that every

@@ -16,7 +16,7 @@
 // Work decomposition = K1b': one workgroup per 256 rows of `a` (same block tables, same partial
 // table, same merge + finalize kernels).  4 waves; wave w keeps its 64 rows (2 M-tiles) expanded in
 // 64 VGPRs for the whole scan.  `b` is streamed in tiles of 32 rows: the 256 lanes expand one raw
-// dword each (32 bits -> 32 bytes: v_bfe, v_mul_u32_u24, v_and, v_perm per 4 bytes) into a
+// dword each (32 bits -> 32 bytes, through a 256-entry byte -> 8-byte table in LDS) into a
 // double-buffered LDS tile whose 272-byte row stride makes the ds_read_b128 operand reads
 // conflict-free.  Only the lane->k mapping shared by the A and the B operand matters for a
 // contraction over all k, so no assumption about the instruction's internal k order is made.
@@ -151,6 +151,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
 {
     __shared__ __attribute__((aligned(16))) uint8_t btile[2 * MF_TILE_BYTES];      // 17 408 B
     __shared__ uint2 colbuf[2][4][MF_TILE_N];                                      //  2 048 B
+    __shared__ uint2 blut[256];                   // byte of a b row -> its 8 s(b) bytes      2 048 B
 
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
@@ -202,10 +203,19 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         j = j < n2 ? j : n2 - 1;
         return braw[(size_t)j * 8 + ewd];
     };
+    // b-side expansion goes through a 256-entry table in LDS (4 ds_read_b64 + ~8 VALU per raw dword
+    // instead of 32 VALU: the VALU is the busy unit of this kernel, the LDS is not)
+    blut[tid] = make_uint2(expand4((uint32_t)tid, 0, LUT_B), expand4((uint32_t)tid, 4, LUT_B));
+    __syncthreads();
     auto expand_store = [&](uint32_t raw, int buf) __attribute__((always_inline)) {
         uint8_t* dst = btile + buf * MF_TILE_BYTES + ej * MF_ROW_STRIDE + ewd * 32;
-        *reinterpret_cast<i32x4*>(dst) = expand16(raw, 0, LUT_B);
-        *reinterpret_cast<i32x4*>(dst + 16) = expand16(raw, 16, LUT_B);
+        const uint2 q0 = blut[raw & 0xFFu], q1 = blut[(raw >> 8) & 0xFFu];
+        const uint2 q2 = blut[(raw >> 16) & 0xFFu], q3 = blut[raw >> 24];
+        i32x4 lo, hi;
+        lo.x = (int)q0.x; lo.y = (int)q0.y; lo.z = (int)q1.x; lo.w = (int)q1.y;
+        hi.x = (int)q2.x; hi.y = (int)q2.y; hi.z = (int)q3.x; hi.w = (int)q3.y;
+        *reinterpret_cast<i32x4*>(dst) = lo;
+        *reinterpret_cast<i32x4*>(dst + 16) = hi;
     };
     auto flush_columns = [&](int t) __attribute__((always_inline)) {              // lanes 0..31 of ONE wave: combine the 4 waves' partials of tile t
         if (lane < MF_TILE_N) {

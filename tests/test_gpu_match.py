@@ -237,6 +237,57 @@ def test_device_resident_plan_matches_oracle(vctx, oracle):
     bm.close()
 
 
+@pytest.mark.parametrize("n_orb,n_lbd,expect", [(2048, 33, "mfma"), (2049, 33, "popcount"), (1999, 1, "mfma"),
+                                                  (96, 2048, "mfma"), (31, 32, "mfma")])
+def test_matrix_core_scan_limits(ctx, oracle, n_orb, n_lbd, expect):
+    """K1e keeps 16-bit (distance, tile) row keys: 64 tiles of 32 columns.  At n2 = 2048 every tile number
+    is used; one row more and the plan falls back to the XOR+popcount symmetric scan.  Tie-stress data
+    (many equal distances) on both sides of the limit, all four problems of every pair against the oracle."""
+    import torch
+    import plslam_amd
+    s = synth.stereo_stream(2, n_orb, n_lbd, seed=77, tie_stress=True)
+    ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)      # (AUTO would pick wave-per-query for 2 pairs)
+    try:
+        bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.8, nnr_l=0.9, mutual=True)
+    finally:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+    used = bm.plan.info()["scan_variant"]
+    assert used == (plslam_amd.SCAN_MFMA if expect == "mfma" else plslam_amd.SCAN_SYMMETRIC)
+    tab = bm.run()
+    torch.cuda.synchronize()
+    tab = tab.cpu().numpy()
+    sl = frontend.table_slices(n_orb, n_lbd)
+    for i in range(2):
+        for name, d1, d2 in frontend.pair_problems(s["orb_l"], s["orb_r"], s["lbd_l"], s["lbd_r"], i):
+            em, _ = oracle.match(d1, d2, 0.8 if name.startswith("orb") else 0.9, True)
+            assert np.array_equal(tab[i, sl[name]], em), (i, name)
+    bm.close()
+
+
+def test_matrix_core_scan_extreme_distances(ctx, oracle):
+    """Distances 0 and 256 (exact complements) and rows of all zeros / all ones: the +-1 byte contraction
+    must give exactly 2 d in [0, 512] and the keys must not wrap."""
+    import plslam_amd
+    r = _rng(5)
+    a = synth.random_desc(r, 300)
+    b = a.copy()[::-1].copy()
+    b[:40] = ~a[:40]                        # complements: distance 256 to their source row
+    a[7] = 0
+    a[8] = 255
+    b[100] = 0
+    b[101] = 255
+    try:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)
+        for nnr in (0.6, 1.0, 1.5):
+            m, n = ctx.match(a, b, nnr, True)
+            em, en = oracle.match(a, b, nnr, True)
+            assert np.array_equal(m, em) and n == en
+        ctx.set_option("scan_variant", plslam_amd.SCAN_LANE_PER_QUERY)
+        assert np.array_equal(ctx.match(a, b, 1.0, True)[0], oracle.match(a, b, 1.0, True)[0])
+    finally:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+
+
 def test_large_train_set_index_bits(vctx, oracle):
     """Train indices beyond 16 bits (the composite key keeps 23 index bits): 70 000 train rows,
     planted best/second-best at the far end, plus exact duplicates to force index tie-breaks."""
@@ -262,7 +313,7 @@ def test_fuzz_all_variants_vs_oracle(ctx, oracle):
     import plslam_amd
     r = _rng(2024)
     variants = (plslam_amd.SCAN_AUTO, plslam_amd.SCAN_LANE_PER_QUERY, plslam_amd.SCAN_WAVE_PER_QUERY,
-                plslam_amd.SCAN_SYMMETRIC)
+                plslam_amd.SCAN_SYMMETRIC, plslam_amd.SCAN_MFMA)
     try:
         for case in range(160):
             n1, n2 = int(r.integers(0, 420)), int(r.integers(0, 420))

@@ -66,10 +66,10 @@ int main(int argc, char** argv)
     int* d; CHECK(hipMalloc(&d, sizeof(int) * 256 * cus * 4));
     for (int wps = 1; wps <= 2; ++wps) {
         run<1, 0>("mfma only (16)", cus, clk, wps, iters, d);
-        run<0, 6>("valu only (192)", cus, clk, wps, iters, d);
-        run<1, 6>("mfma 16 + valu 192 interleaved", cus, clk, wps, iters, d);
-        run<0, 13>("valu only (416)", cus, clk, wps, iters, d);
-        run<1, 13>("mfma 16 + valu 416 interleaved", cus, clk, wps, iters, d);
+        run<0, 6>("valu only (96)", cus, clk, wps, iters, d);
+        run<1, 6>("mfma 16 + valu 96 interleaved", cus, clk, wps, iters, d);
+        run<0, 13>("valu only (208)", cus, clk, wps, iters, d);
+        run<1, 13>("mfma 16 + valu 208 interleaved", cus, clk, wps, iters, d);
     }
     return 0;
 }
