@@ -7,11 +7,12 @@
 //
 // The Hamming distance of two bit rows IS a contraction: with s(x) = 1 - 2x in {+1,-1},
 //     sum_k s(a_k) s(b_k) = 256 - 2 d(a,b).
-// A rows are expanded to bytes -s(a) (0xFF / 0x01), B rows to bytes s(b) (0x01 / 0xFF), the accumulator
-// starts at 256, and v_mfma_i32_32x32x32_i8 (8 K-steps) leaves acc = 2 d -- exact integers, so the
+// A rows are expanded to bytes -64 s(a) (0xC0 / 0x40), B rows to bytes s(b) (0x01 / 0xFF), the accumulator
+// starts at 16384 + tag, and v_mfma_i32_32x32x32_i8 (8 K-steps) leaves acc = 128 d + tag -- exact integers:
+// the 16-bit key (d << 7 | tag) comes out of the matrix core ready-made, and the
 // keys, and with them every match table, are bit-identical to the XOR+popcount kernels.
 // Per 32x32 tile a wave issues 8 MFMAs (the matrix pipe) instead of 16 x 16 VALU ops per lane; what
-// stays on the VALU is the best-2 bookkeeping: 3 ops per element and direction.
+// stays on the VALU is the best-2 bookkeeping: 8 packed 16-bit ops per 2 elements for both directions.
 //
 // Work decomposition = K1b': one workgroup per 256 rows of `a` (same block tables, same partial
 // table, same merge + finalize kernels).  4 waves; wave w keeps its 64 rows (2 M-tiles) expanded in
@@ -47,7 +48,7 @@ namespace {
 constexpr int MF_TILE_N = 32;                 // b rows per tile
 constexpr int MF_ROW_STRIDE = 272;            // bytes per expanded b row in LDS (256 + 16: 4-bank skew)
 constexpr int MF_TILE_BYTES = MF_TILE_N * MF_ROW_STRIDE;
-constexpr uint32_t LUT_A = 0x000001FFu;       // v_perm source: selector 0 -> 0xFF (-1), 1 -> 0x01 (+1)
+constexpr uint32_t LUT_A = 0x000040C0u;       // v_perm source: selector 0 -> 0xC0 (-64), 1 -> 0x40 (+64)
 constexpr uint32_t LUT_B = 0x0000FF01u;       //                selector 0 -> 0x01 (+1), 1 -> 0xFF (-1)
 
 __device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
@@ -71,6 +72,9 @@ __device__ __forceinline__ void merge2(uint32_t& a0, uint32_t& a1, uint32_t c0, 
     a0 = lo;
     a1 = hi;
 }
+// packed 16-bit min / max.  Inline asm on purpose: written with the vector builtins the compiler sinks
+// the row-direction pushes out of the MFMA block into a block of their own (96 VALU ops with no MFMA to
+// hide under, 6 spilled VGPRs; measured 6.10 ms vs 5.85 ms).
 __device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b)
 {
     uint32_t r;
@@ -89,42 +93,22 @@ __device__ __forceinline__ void pk_push2(uint32_t& b0, uint32_t& b1, uint32_t ke
     b1 = pk_min16(b1, pk_max16(b0, key));
     b0 = pk_min16(b0, key);
 }
-// accumulators of the two M-tiles (acc = 2 d <= 512) side by side: hi << 16 | lo
+// accumulators of the two M-tiles (acc = 128 d + tag <= 0x807F) side by side: hi << 16 | lo
 __device__ __forceinline__ uint32_t pack_acc(int lo, int hi)
 {
     uint32_t r;
     asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(r) : "v"(hi), "v"(lo));
     return r;
 }
-// both halves -> 16-bit keys (d << 6) | tag6:  (2 d) << 5 leaves six free low bits per half
-__device__ __forceinline__ uint32_t pk_key_s(uint32_t packed, uint32_t tagpair_uniform)
+// 16-bit keys are (d << 7) | tag7: the A bytes are -64 s(a), so with C = 16384 + tag the accumulator
+// itself is 128 d + tag (<= (256 << 7) + 127 = 0x807F); anything above is "none"
+constexpr uint32_t KEY16_MAX = 0x807Fu;
+__device__ __forceinline__ uint32_t key16_to_key32(uint32_t k16, uint32_t tag_bias, uint32_t idx_base,
+                                                   uint32_t idx_scale)
 {
-    uint32_t r;
-    asm("v_lshl_or_b32 %0, %1, 5, %2" : "=v"(r) : "v"(packed), "s"(tagpair_uniform));
-    return r;
+    return k16 > KEY16_MAX ? KEY_NONE
+                           : (((k16 >> 7) << KEY_IDX_BITS) | (idx_base + ((k16 & 127u) - tag_bias) * idx_scale));
 }
-constexpr uint32_t KEY16_NONE = 0xFFFFu;      // real keys are <= (256 << 6) | 63 = 0x403F
-__device__ __forceinline__ uint32_t key16_to_key32(uint32_t k16, uint32_t idx_base, uint32_t idx_scale)
-{
-    return k16 > 0x7FFFu ? KEY_NONE : (((k16 >> 6) << KEY_IDX_BITS) | (idx_base + (k16 & 63u) * idx_scale));
-}
-// (acc << 22) | idx : acc = 2 d, so this is (d << 23) | idx.  One v_lshl_or_b32 each (the compiler
-// would otherwise share the shift between the row key and the column key: 3 ops for 2 keys).
-__device__ __forceinline__ uint32_t key_of(int acc2d, uint32_t idx)
-{
-    uint32_t r;
-    asm("v_lshl_or_b32 %0, %1, 22, %2" : "=v"(r) : "v"(acc2d), "v"(idx));
-    return r;
-}
-template <int LOC>      // idx = compile-time local row index (an inline constant, 0..63)
-__device__ __forceinline__ uint32_t key_of_loc(int acc2d)
-{
-    static_assert(LOC >= 0 && LOC <= 63, "inline constant range");
-    uint32_t r;
-    asm("v_lshl_or_b32 %0, %1, 22, %2" : "=v"(r) : "v"(acc2d), "n"(LOC));
-    return r;
-}
-static_assert(KEY_IDX_BITS == 23, "key_of hard-codes the shift");
 // 4 bits (bit k -> byte k) through the +-1 table
 __device__ __forceinline__ uint32_t expand4(uint32_t word, int first_bit, uint32_t lut)
 {
@@ -181,9 +165,11 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
 #pragma unroll
         for (int kk = 0; kk < 8; ++kk) afrag[mt][kk] = expand16(wd[kk] >> (16 * g), 0, LUT_A);
     }
+    // accumulator start: 16384 + LOC(reg), so that acc = 128 d + LOC -- the COLUMN key of the element with
+    // no VALU op (LOC = (reg & 3) + 8 (reg >> 2) is the element's local row within the half-tile)
     i32x16 cinit;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cinit[r] = 256;
+    for (int r = 0; r < 16; ++r) cinit[r] = 16384 + (r & 3) + 8 * (r >> 2);
 
     // row-direction state: per accumulator register r, the best two 16-bit keys (d << 6 | tile) of the
     // lane's column class, M-tile 0 in the low halves and M-tile 1 in the high halves
@@ -233,13 +219,13 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     // Epilogue of one accumulator register pair (rows LOC and LOC + 32 of the wave, column j0 + c).
     // MASKED = false is the steady state (every row of this wave and every column of the tile exists);
     // the ragged cases are separate instantiations OUTSIDE the steady-state loop.
-    // 9 VALU ops for the two distances: pack, row key, 3 to push it, column key, 3 to push it.
+    // 8 VALU ops for the two distances: pack (= the column keys), + tile (= the row keys; every candidate
+    // of rb[R] carries the same LOC, so (d, tile + LOC) orders like (d, tile)), 3 + 3 to push them.
 #define PLSLAM_MF_EPI_ROW(R)                                                                       \
     {                                                                                              \
         constexpr uint32_t LOC = ((R) & 3) + 8 * ((R) >> 2);                                       \
-        const uint32_t pk = pack_acc(acc0[R], acc1[R]);                                            \
-        uint32_t kr = pk_key_s(pk, tpair);                                                         \
-        uint32_t kc = pk_key_s(pk, LOC | ((LOC + 32u) << 16));                                     \
+        uint32_t kc = pack_acc(acc0[R], acc1[R]);                                                  \
+        uint32_t kr = kc + tpair;                                                                  \
         if (MASKED) {                                                                              \
             kr = col_ok ? kr : 0xFFFFFFFFu;                                                        \
             kc |= ((int)(ibase + LOC) < n1 ? 0u : 0x0000FFFFu) |                                   \
@@ -248,20 +234,14 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         pk_push2(rb[R][0], rb[R][1], kr);                                                          \
         pk_push2(cb0, cb1, kc);                                                                    \
     }
-    // One pipeline step = M(t) fused with E(t-1):
-    //   M(t): barrier, then the 16 MFMAs of tile t into (n0, n1); the raw dwords of tile t+2 are requested
-    //         and tile t+1 (requested one step earlier: its latency is off the critical path) is expanded;
-    //   E(t-1): best-2 bookkeeping of tile t-1 from ITS accumulators (p0, p1).
-    // E(t-1) does not depend on M(t), and both sit in one basic block with an explicit interleave
-    // (1 LDS operand read, 2 MFMAs, 24 VALU ops, eight times), so the matrix pipe and the VALU of this
-    // wave work at the same time.
-    uint32_t raw1 = ntiles > 1 ? load_raw(1) : 0u;         // tile t+1 of the coming step
+    uint32_t raw1 = ntiles > 1 ? load_raw(1) : 0u;         // raw b dword of tile t+1 of the coming step
     // column best-2 of a finished tile: the two halves of (cb0, cb1) are sorted streams over disjoint rows
-    // of the same column -> best 2 of the lane, local row -> a-row, then the other 32 rows (lane ^ 32)
+    // of the same column -> 32-bit keys with the a-row, best 2 of the lane, then the other 32 rows (lane ^ 32)
     auto finish_columns = [&](int t, uint32_t cb0, uint32_t cb1) __attribute__((always_inline)) {
-        const uint32_t e0 = cb0 & 0xFFFFu, o0 = cb0 >> 16, e1 = cb1 & 0xFFFFu, o1 = cb1 >> 16;
-        uint32_t k0 = key16_to_key32(umin_(e0, o0), ibase, 1u);
-        uint32_t k1 = key16_to_key32(umin_(umax_(e0, o0), umin_(e1, o1)), ibase, 1u);
+        // low halves: rows ibase + LOC (M-tile 0), high halves: rows ibase + 32 + LOC (M-tile 1)
+        uint32_t k0 = key16_to_key32(cb0 & 0xFFFFu, 0u, ibase, 1u);
+        uint32_t k1 = key16_to_key32(cb1 & 0xFFFFu, 0u, ibase, 1u);
+        merge2(k0, k1, key16_to_key32(cb0 >> 16, 0u, ibase + 32u, 1u), key16_to_key32(cb1 >> 16, 0u, ibase + 32u, 1u));
         merge2(k0, k1, (uint32_t)__shfl_xor((int)k0, 32), (uint32_t)__shfl_xor((int)k1, 32));
         if (lane < MF_TILE_N) colbuf[t & 1][w][lane] = make_uint2(k0, k1);
     };
@@ -347,8 +327,9 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         for (int r = 0; r < 16; ++r) {
             const uint32_t h0 = mt ? rb[r][0] >> 16 : rb[r][0] & 0xFFFFu;
             const uint32_t h1 = mt ? rb[r][1] >> 16 : rb[r][1] & 0xFFFFu;
-            uint32_t k0 = key16_to_key32(h0, (uint32_t)c, (uint32_t)MF_TILE_N);
-            uint32_t k1 = key16_to_key32(h1, (uint32_t)c, (uint32_t)MF_TILE_N);
+            const uint32_t loc = (uint32_t)((r & 3) + 8 * (r >> 2));     // the tag is tile + LOC
+            uint32_t k0 = key16_to_key32(h0, loc, (uint32_t)c, (uint32_t)MF_TILE_N);
+            uint32_t k1 = key16_to_key32(h1, loc, (uint32_t)c, (uint32_t)MF_TILE_N);
 #pragma unroll
             for (int m = 16; m >= 1; m >>= 1)
                 merge2(k0, k1, (uint32_t)__shfl_xor((int)k0, m), (uint32_t)__shfl_xor((int)k1, m));
