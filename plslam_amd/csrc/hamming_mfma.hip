@@ -261,9 +261,11 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     //   M(t): barrier, then the 16 MFMAs of tile t into (m0, m1); the raw dwords of tile t+2 are requested
     //         and tile t+1 (requested one step earlier: its latency is off the critical path) is expanded;
     //   E(t-1): best-2 bookkeeping of tile t-1 from ITS accumulators (acc0, acc1).
-    // E(t-1) does not depend on M(t); both sit in one basic block and the scheduler is asked for an
-    // interleave (B operand reads two K-steps ahead, 2 MFMAs, ~22 VALU ops, eight times), so the matrix
-    // pipe works under the bookkeeping.  (A hand-fenced program-order interleave measured 4 % slower.)
+    // E(t-1) does not depend on M(t) and both sit in one basic block, so the scheduler interleaves the
+    // MFMAs with the bookkeeping.  Measured alternatives, all within 5.8-5.9 ms or worse: sched_group_barrier
+    // patterns (2 MFMA : 22 / 30 VALU, 1 : 11); all eight B operands prefetched before the first MFMA;
+    // co-resident workgroups started half a step apart; a hand-fenced program-order interleave (+4 %); LDS
+    // round trips (operand reads, lane exchange) issued a quarter-epilogue ahead of their use (+8 %).
     auto step = [&](int t, i32x16& m0, i32x16& m1, const i32x16& acc0, const i32x16& acc1, bool with_prev,
                     auto masked_tag) __attribute__((always_inline)) {
         const uint32_t raw2 = t + 2 < ntiles ? load_raw(t + 2) : 0u;
@@ -283,14 +285,6 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         raw1 = raw2;
         if (PLSLAM_MF_EXPERIMENT == 2) asm volatile("" ::"v"(m0), "v"(m1));
         if (with_prev && PLSLAM_MF_EXPERIMENT != 2) epilogue(t - 1, acc0, acc1, masked_tag);
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // LDS reads kk = 0, 1
-        __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);         // VALU while they are in flight
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // 2 MFMA
-            if (kk < 6) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // LDS read kk + 2
-            __builtin_amdgcn_sched_group_barrier(0x002, 22, 0);     // 22 VALU
-        }
     };
     // S(0) | S(1)+E(0) | S(2)+E(1) | ... | E(ntiles-1).  Two accumulator sets alternate (unrolled by two:
     // no accumulator is ever copied).  Only the last tile can lack columns.
