@@ -260,31 +260,50 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     // One pipeline step = M(t) fused with E(t-1):
     //   M(t): barrier, then the 16 MFMAs of tile t into (m0, m1); the raw dwords of tile t+2 are requested
     //         and tile t+1 (requested one step earlier: its latency is off the critical path) is expanded;
-    //   E(t-1): best-2 bookkeeping of tile t-1 from ITS accumulators (acc0, acc1).
-    // E(t-1) does not depend on M(t) and both sit in one basic block, so the scheduler interleaves the
-    // MFMAs with the bookkeeping.  Measured alternatives, all within 5.8-5.9 ms or worse: sched_group_barrier
-    // patterns (2 MFMA : 22 / 30 VALU, 1 : 11); all eight B operands prefetched before the first MFMA;
-    // co-resident workgroups started half a step apart; a hand-fenced program-order interleave (+4 %); LDS
-    // round trips (operand reads, lane exchange) issued a quarter-epilogue ahead of their use (+8 %).
+    //   E(t-1): best-2 bookkeeping of tile t-1 from ITS accumulators (acc0, acc1) -- independent of M(t).
+    // Measured alternatives to the order below, all 5.8-5.9 ms or worse (this one: 5.78 ms): MFMAs in pairs
+    // with the scheduler placing the VALU work, with or without sched_group_barrier patterns (2 MFMA : 22 / 30
+    // VALU, 1 : 11); all eight B operands prefetched before the first MFMA; co-resident workgroups started
+    // half a step apart; pairs of MFMAs hand-fenced with two register pairs of E (+4 %); LDS round trips
+    // (operand reads, lane exchange) issued a quarter-epilogue ahead of their use (+8 %).
     auto step = [&](int t, i32x16& m0, i32x16& m1, const i32x16& acc0, const i32x16& acc1, bool with_prev,
                     auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const uint32_t raw2 = t + 2 < ntiles ? load_raw(t + 2) : 0u;
         if (PLSLAM_MF_EXPERIMENT != 1) __syncthreads();   // tile t expanded; colbuf of tile t-2 complete
         if (t > 1 && w == (t & 3)) flush_columns(t - 2);            // the waves take turns
         const uint8_t* bt = btile + (t & 1) * MF_TILE_BYTES + c * MF_ROW_STRIDE + 16 * g;
-        m0 = cinit;
-        m1 = cinit;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const i32x4 bf = *reinterpret_cast<const i32x4*>(bt + 32 * kk);
-            if (PLSLAM_MF_EXPERIMENT == 3) { m0[kk] += bf.x; m1[kk] += bf.y; continue; }
-            m0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[0][kk], bf, m0, 0, 0, 0);
-            m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[1][kk], bf, m1, 0, 0, 0);
+        const bool col_ok = (t - 1) * MF_TILE_N + c < n2;
+        const uint32_t tpair = (uint32_t)(t - 1) * 0x00010001u;      // tile number in both halves (t < 64)
+        uint32_t cb0 = 0xFFFFFFFFu, cb1 = 0xFFFFFFFFu;
+        i32x4 bf = *reinterpret_cast<const i32x4*>(bt);
+        // program order, fenced: [MFMA] [one accumulator register pair of E(t-1): 8 VALU ~ one MFMA's 32
+        // matrix-pipe cycles] [MFMA] [8 VALU] ... -- single MFMAs, evenly spaced, so that this wave is never
+        // stalled at the issue of the second MFMA of a pair while the pipe is busy with the first
+#define PLSLAM_MF_KSTEP(KK, CIN0, CIN1)                                                            \
+        {                                                                                          \
+            const i32x4 bcur = bf;                                                                 \
+            if ((KK) < 7) bf = *reinterpret_cast<const i32x4*>(bt + 32 * ((KK) + 1));               \
+            if (PLSLAM_MF_EXPERIMENT != 3) m0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[0][KK], bcur, CIN0, 0, 0, 0); \
+            else m0[KK] = bcur.x;                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            if (with_prev && PLSLAM_MF_EXPERIMENT != 2) { PLSLAM_MF_EPI_ROW(2 * (KK)) }             \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            if (PLSLAM_MF_EXPERIMENT != 3) m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[1][KK], bcur, CIN1, 0, 0, 0); \
+            else m1[KK] = bcur.y;                                                                  \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            if (with_prev && PLSLAM_MF_EXPERIMENT != 2) { PLSLAM_MF_EPI_ROW(2 * (KK) + 1) }         \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
         }
+        PLSLAM_MF_KSTEP(0, cinit, cinit)
+        PLSLAM_MF_KSTEP(1, m0, m1) PLSLAM_MF_KSTEP(2, m0, m1) PLSLAM_MF_KSTEP(3, m0, m1)
+        PLSLAM_MF_KSTEP(4, m0, m1) PLSLAM_MF_KSTEP(5, m0, m1) PLSLAM_MF_KSTEP(6, m0, m1)
+        PLSLAM_MF_KSTEP(7, m0, m1)
+#undef PLSLAM_MF_KSTEP
         expand_store(raw1, (t + 1) & 1);           // past the last tile: a harmless rewrite of the idle buffer
         raw1 = raw2;
         if (PLSLAM_MF_EXPERIMENT == 2) asm volatile("" ::"v"(m0), "v"(m1));
-        if (with_prev && PLSLAM_MF_EXPERIMENT != 2) epilogue(t - 1, acc0, acc1, masked_tag);
+        if (with_prev && PLSLAM_MF_EXPERIMENT != 2) finish_columns(t - 1, cb0, cb1);
     };
     // S(0) | S(1)+E(0) | S(2)+E(1) | ... | E(ntiles-1).  Two accumulator sets alternate (unrolled by two:
     // no accumulator is ever copied).  Only the last tile can lack columns.
