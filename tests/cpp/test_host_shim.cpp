@@ -10,6 +10,7 @@
 
 #include "../../oracle/plslam_oracle.h"
 #include "../../plslam_amd/host/lba_rows.hpp"
+#include "../../plslam_amd/host/map_features.hpp"
 #include "../../plslam_amd/host/stvo_match.hpp"
 
 static int g_fail = 0;
@@ -110,6 +111,50 @@ int main()
             EXPECT(counts[b] == nref);
             for (int i = 0; i < sizes[b][0]; ++i) EXPECT(out[b][i] == ref[i]);
         }
+    }
+
+    // --- representative descriptors of a local map + LBD binary rows (map_features.hpp) -----
+    {
+        std::mt19937 g(91);
+        const int n_lm = 257;
+        std::vector<std::vector<uint8_t>> obs;          // every observation row
+        std::vector<std::vector<const uint8_t*>> ptrs(n_lm);
+        std::vector<int> lens(n_lm);
+        for (int l = 0; l < n_lm; ++l) lens[l] = (int)(g() % 9);   // 0..8 observations (0: never in the reference)
+        for (int l = 0; l < n_lm; ++l) {
+            std::vector<uint8_t> base = rand_desc(g, 1);
+            for (int k = 0; k < lens[l]; ++k) {
+                std::vector<uint8_t> d;
+                noisy(g, base, d);
+                if (l % 5 == 0 && k) d = obs.back();                // exact duplicates: ties, first row must win
+                obs.push_back(d);
+            }
+        }
+        size_t o = 0;
+        for (int l = 0; l < n_lm; ++l)
+            for (int k = 0; k < lens[l]; ++k) ptrs[l].push_back(obs[o++].data());
+        std::vector<PLSLAM::DescList> lms(n_lm);
+        for (int l = 0; l < n_lm; ++l) { lms[l].rows = ptrs[l].data(); lms[l].n = lens[l]; }
+        std::vector<int> med_idx;
+        std::vector<uint8_t> med_desc;
+        PLSLAM::updateAverageDescriptors(lms, med_idx, &med_desc);
+        EXPECT((int)med_idx.size() == n_lm);
+        for (int l = 0; l < n_lm; ++l) {
+            std::vector<uint8_t> flat;
+            for (int k = 0; k < lens[l]; ++k) flat.insert(flat.end(), ptrs[l][k], ptrs[l][k] + 32);
+            const int ref = lens[l] ? plo_median_desc(flat.data(), lens[l]) : -1;
+            EXPECT(med_idx[l] == ref);
+            for (int b = 0; b < 32; ++b) EXPECT(med_desc[(size_t)l * 32 + b] == (lens[l] ? ptrs[l][ref][b] : 0));
+        }
+        // LBD rows
+        const int nl = 203;
+        std::vector<float> lbd((size_t)nl * 72);
+        std::uniform_int_distribution<int> q(0, 7);
+        for (auto& f : lbd) f = 0.05f * (float)q(g);               // coarse levels: many exact ties
+        std::vector<uint8_t> rows((size_t)nl * 32), ref((size_t)nl * 32);
+        PLSLAM::binaryDescriptorRows(lbd.data(), nl, rows.data());
+        plo_lbd_binarise(lbd.data(), nl, ref.data());
+        for (size_t i = 0; i < rows.size(); ++i) EXPECT(rows[i] == ref[i]);
     }
 
     // --- LBA normal equations through the row builder -------------------------------------
