@@ -25,7 +25,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
 VALU_LANES_PER_CLK_PER_CU = 128  # 4 SIMD-32 per CU
-I8_MFMA_OPS_PER_CLK_PER_SIMD = 2048  # v_mfma_i32_32x32x32_i8: 65536 ops in 8 passes of 4 clk
+FP4_MFMA_OPS_PER_CLK_PER_SIMD = 4096  # v_mfma_scale_f32_32x32x64_f8f6f4 with fp4 operands: 131072 ops in 8 passes of 4 clk
 
 
 def usable_cpus() -> int:
@@ -315,18 +315,20 @@ def main():
                     "kilobyte the path is compute-bound on any formulation, so this fraction is small by construction",
         }
         if mfma:
-            # K1e: distances come from v_mfma_i32_32x32x32_i8; 256 multiply-accumulates = 512 ops per executed distance
-            i8_peak = devinfo["cu_count"] * 4 * I8_MFMA_OPS_PER_CLK_PER_SIMD * devinfo["clock_khz"] * 1e3
+            # K1e: distances come from v_mfma_scale_f32_32x32x64_f8f6f4 over fp4 +-1 codes; 256 multiply-accumulates =
+            # 512 ops per executed distance
+            mx_peak = devinfo["cu_count"] * 4 * FP4_MFMA_OPS_PER_CLK_PER_SIMD * devinfo["clock_khz"] * 1e3
             mfma_ops = info["distance_evals"] * 512
             roofline = {
-                "bound": "mfma", "achieved": mfma_ops / scan_s / 1e12, "peak": i8_peak / 1e12, "unit": "TFLOP/s",
-                "frac": mfma_ops / scan_s / i8_peak, "traffic": traffic, "kernel": kernel_name,
+                "bound": "mfma", "achieved": mfma_ops / scan_s / 1e12, "peak": mx_peak / 1e12, "unit": "TFLOP/s",
+                "frac": mfma_ops / scan_s / mx_peak, "traffic": traffic, "kernel": kernel_name,
                 "kernel_ms": 1e3 * scan_s, "kernel_ms_in_timed_region": scan_ms / max(runs, 1), "timing": timing_note,
                 "algorithmic_ops_per_launch": mfma_ops,
-                "note": "integer ops (i8 multiply-accumulate = 2 ops), dense i8 MFMA peak = CUs x 4 SIMDs x 2048 ops/clk x "
-                        "max clock (MI355X_MICROARCH.md measures 4404 T for the 32x32 shape); 512 ops per executed 256-bit "
-                        "distance (each serves both match directions).  The kernel is co-limited by the VALU best-2 "
-                        "bookkeeping that consumes the accumulators: see valu_roofline.executed",
+                "note": "block-scaled fp4 MFMA (operands are the e2m1 codes of +-1, fp32 accumulation of integers below "
+                        "2^24: exact); dense MX-fp4 peak = CUs x 4 SIMDs x 4096 ops/clk x max clock (MI355X_MICROARCH.md "
+                        "measures 9099 T for the 32x32x64 shape); 512 ops per executed 256-bit distance (each serves both "
+                        "match directions).  The kernel is co-limited by the VALU best-2 bookkeeping that consumes the "
+                        "accumulators: see valu_roofline.executed",
             }
         else:
             roofline = hbm_roofline
@@ -341,7 +343,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "i8" if mfma else "u32",
+            "dtype": "fp4" if mfma else "u32",
             "data": "synthetic",
             "config": {
                 "workload": f"C2: synthetic 752x480 stereo stream, {args.n_orb} ORB + {args.n_lbd} LBD per image, "

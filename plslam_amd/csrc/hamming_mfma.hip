@@ -7,18 +7,20 @@
 //
 // The Hamming distance of two bit rows IS a contraction: with s(x) = 1 - 2x in {+1,-1},
 //     sum_k s(a_k) s(b_k) = 256 - 2 d(a,b).
-// A rows are expanded to bytes -64 s(a) (0xC0 / 0x40), B rows to bytes s(b) (0x01 / 0xFF), the accumulator
-// starts at 16384 + tag, and v_mfma_i32_32x32x32_i8 (8 K-steps) leaves acc = 128 d + tag -- exact integers:
-// the 16-bit key (d << 7 | tag) comes out of the matrix core ready-made, and the
-// keys, and with them every match table, are bit-identical to the XOR+popcount kernels.
-// Per 32x32 tile a wave issues 8 MFMAs (the matrix pipe) instead of 16 x 16 VALU ops per lane; what
+// Both sides are expanded to fp4 (e2m1) codes of +-1 -- A rows to -s(a) with the block scale 2^6, B rows to
+// s(b) -- the accumulator starts at 2^23 + 16384 + tag, and four v_mfma_scale_f32_32x32x64_f8f6f4 (K = 64
+// each) leave 2^23 + 128 d + tag: every partial sum is an integer below 2^24, so the fp32 accumulation is
+// exact, the low 16 bits of the float ARE the 16-bit key (d << 7 | tag), and the match tables are
+// bit-identical to the XOR+popcount kernels.  (The first version used v_mfma_i32_32x32x32_i8 over +-1 bytes:
+// twice the MFMAs, twice the LDS operand reads -- which measured 19 % of the kernel -- and 32 more VGPRs.)
+// Per 32x32 tile a wave issues 4 MFMAs (the matrix pipe) instead of 16 x 16 VALU ops per lane; what
 // stays on the VALU is the best-2 bookkeeping: 8 packed 16-bit ops per 2 elements for both directions.
 //
 // Work decomposition = K1b': one workgroup per 256 rows of `a` (same block tables, same partial
 // table, same merge + finalize kernels).  4 waves; wave w keeps its 64 rows (2 M-tiles) expanded in
-// 64 VGPRs for the whole scan.  `b` is streamed in tiles of 32 rows: the 256 lanes expand one raw
-// dword each (32 bits -> 32 bytes, through a 256-entry byte -> 8-byte table in LDS) into a
-// double-buffered LDS tile whose 272-byte row stride makes the ds_read_b128 operand reads
+// 32 VGPRs for the whole scan.  `b` is streamed in tiles of 32 rows: the 256 lanes expand one raw
+// dword each (32 bits -> 32 fp4 codes, through a 256-entry byte -> 8-code table in LDS) into a
+// double-buffered LDS tile whose 144-byte row stride makes the ds_read_b128 operand reads
 // conflict-free.  Only the lane->k mapping shared by the A and the B operand matters for a
 // contraction over all k, so no assumption about the instruction's internal k order is made.
 // C/D layout (dtype-independent): col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
@@ -41,15 +43,20 @@ namespace plslam {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4), aligned(4)));   // descriptor rows are only 4-byte aligned
-typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
 constexpr int MF_TILE_N = 32;                 // b rows per tile
-constexpr int MF_ROW_STRIDE = 272;            // bytes per expanded b row in LDS (256 + 16: 4-bank skew)
+constexpr int MF_KSTEPS = 4;                  // 256 bits = 4 x K 64
+constexpr int MF_ROW_STRIDE = 144;            // bytes per expanded b row in LDS (128 + 16: 4-bank skew)
 constexpr int MF_TILE_BYTES = MF_TILE_N * MF_ROW_STRIDE;
-constexpr uint32_t LUT_A = 0x000040C0u;       // v_perm source: selector 0 -> 0xC0 (-64), 1 -> 0x40 (+64)
-constexpr uint32_t LUT_B = 0x0000FF01u;       //                selector 0 -> 0x01 (+1), 1 -> 0xFF (-1)
+// fp4 (e2m1) codes: +1.0 = 0x2, -1.0 = 0xA.  b side: bit 0 -> +1, bit 1 -> -1 = s(b); the a side is the b code
+// XOR 0x8 per nibble (= -s(a)) and carries the block scale 2^6 (E8M0 133), the b side 2^0 (E8M0 127).
+constexpr uint32_t FP4_NEG = 0x88888888u;
+constexpr int SCALE_A = 133, SCALE_B = 127;
+constexpr float ACC_MAGIC = 8388608.0f;       // 2^23: float bits = 0x4B000000 + integer part
 
 __device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -93,11 +100,11 @@ __device__ __forceinline__ void pk_push2(uint32_t& b0, uint32_t& b1, uint32_t ke
     b1 = pk_min16(b1, pk_max16(b0, key));
     b0 = pk_min16(b0, key);
 }
-// accumulators of the two M-tiles (acc = 128 d + tag <= 0x807F) side by side: hi << 16 | lo
-__device__ __forceinline__ uint32_t pack_acc(int lo, int hi)
+// accumulators of the two M-tiles (2^23 + 128 d + tag, tag <= 127) side by side: hi.lo16 << 16 | lo.lo16
+__device__ __forceinline__ uint32_t pack_acc(float lo, float hi, uint32_t sel_uniform /* 0x05040100 */)
 {
-    uint32_t r;
-    asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(r) : "v"(hi), "v"(lo));
+    uint32_t r;     // low 16 bits of each float's bit pattern (= its integer part, see ACC_MAGIC)
+    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(sel_uniform));
     return r;
 }
 // 16-bit keys are (d << 7) | tag7: the A bytes are -64 s(a), so with C = 16384 + tag the accumulator
@@ -109,33 +116,25 @@ __device__ __forceinline__ uint32_t key16_to_key32(uint32_t k16, uint32_t tag_bi
     return k16 > KEY16_MAX ? KEY_NONE
                            : (((k16 >> 7) << KEY_IDX_BITS) | (idx_base + ((k16 & 127u) - tag_bias) * idx_scale));
 }
-// 4 bits (bit k -> byte k) through the +-1 table
-__device__ __forceinline__ uint32_t expand4(uint32_t word, int first_bit, uint32_t lut)
+// one byte of a descriptor -> 8 fp4 codes of s(bit): bit k -> nibble k = 0x2 | (bit << 3)
+__device__ __forceinline__ uint32_t expand_byte_fp4(uint32_t byte)
 {
-    const uint32_t nib = __builtin_amdgcn_ubfe(word, first_bit, 4);
-    const uint32_t sel = __umul24(nib, 0x00204081u) & 0x01010101u;
-    return __builtin_amdgcn_perm(0u, lut, sel);
-}
-__device__ __forceinline__ i32x4 expand16(uint32_t word, int first_bit, uint32_t lut)
-{
-    i32x4 v;
-    v.x = (int)expand4(word, first_bit, lut);
-    v.y = (int)expand4(word, first_bit + 4, lut);
-    v.z = (int)expand4(word, first_bit + 8, lut);
-    v.w = (int)expand4(word, first_bit + 12, lut);
-    return v;
+    uint32_t x = (byte | (byte << 12)) & 0x000F000Fu;      // 4 + 4 bits
+    x = (x | (x << 6)) & 0x03030303u;                      // 2 bits per byte
+    x = (x | (x << 3)) & 0x11111111u;                      // 1 bit per nibble (at bit 0)
+    return (x << 3) | 0x22222222u;
 }
 __device__ __forceinline__ int xcd_remap_(int orig, int nwg) { return (orig & 7) * (nwg >> 3) + (orig >> 3); }
 
 }  // namespace
 
-__global__ void __launch_bounds__(256, 2)      // 2 waves per SIMD: <= 256 unified VGPRs
+__global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
 k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
                 int32_t* __restrict__ zero, int nzero)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t btile[2 * MF_TILE_BYTES];      // 17 408 B
+    __shared__ __attribute__((aligned(16))) uint8_t btile[2 * MF_TILE_BYTES];      //  9 216 B
     __shared__ uint2 colbuf[2][4][MF_TILE_N];                                      //  2 048 B
-    __shared__ uint2 blut[256];                   // byte of a b row -> its 8 s(b) bytes      2 048 B
+    __shared__ uint32_t blut[256];                // byte of a b row -> its 8 s(b) fp4 codes  1 024 B
 
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
@@ -153,8 +152,12 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     const uint32_t* araw = reinterpret_cast<const uint32_t*>(sd.a);
     const uint32_t* braw = reinterpret_cast<const uint32_t*>(sd.b);
 
-    // ---- A operands: rows iw + 32 mt + c, bits [32 kk + 16 g, +16) of each, as -s(a) bytes ---------
-    i32x4 afrag[2][8];
+    // expansion table first (the A operands use it too)
+    blut[tid] = expand_byte_fp4((uint32_t)tid);
+    __syncthreads();
+    // ---- A operands: rows iw + 32 mt + c, bits [64 ks + 32 g, +32) of each = raw dword 2 ks + g, as
+    // fp4 codes of -s(a) (the b code with the sign nibble-bit flipped); the factor 64 is the block scale ----
+    i32x4 afrag[2][MF_KSTEPS];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int row = iw + 32 * mt + c;
@@ -163,13 +166,22 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         const u32x4_t lo = p[0], hi = p[1];
         const uint32_t wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
 #pragma unroll
-        for (int kk = 0; kk < 8; ++kk) afrag[mt][kk] = expand16(wd[kk] >> (16 * g), 0, LUT_A);
+        for (int ks = 0; ks < MF_KSTEPS; ++ks) {
+            const uint32_t raw = g ? wd[2 * ks + 1] : wd[2 * ks];
+            afrag[mt][ks].x = (int)(blut[raw & 0xFFu] ^ FP4_NEG);
+            afrag[mt][ks].y = (int)(blut[(raw >> 8) & 0xFFu] ^ FP4_NEG);
+            afrag[mt][ks].z = (int)(blut[(raw >> 16) & 0xFFu] ^ FP4_NEG);
+            afrag[mt][ks].w = (int)(blut[raw >> 24] ^ FP4_NEG);
+        }
     }
-    // accumulator start: 16384 + LOC(reg), so that acc = 128 d + LOC -- the COLUMN key of the element with
-    // no VALU op (LOC = (reg & 3) + 8 (reg >> 2) is the element's local row within the half-tile)
-    i32x16 cinit;
+    // accumulator start: 2^23 + 16384 + LOC(reg): the sum is 2^23 + 128 d + LOC, every partial sum an
+    // integer below 2^24, so fp32 accumulation is exact and the float's low 16 bits ARE the column key
+    // (d << 7 | LOC) of the element (LOC = (reg & 3) + 8 (reg >> 2) = its local row within the half-tile)
+    f32x16 cinit;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cinit[r] = 16384 + (r & 3) + 8 * (r >> 2);
+    for (int r = 0; r < 16; ++r) cinit[r] = ACC_MAGIC + 16384.0f + (float)((r & 3) + 8 * (r >> 2));
+    const int scale_a = SCALE_A, scale_b = SCALE_B;
+    const uint32_t pack_sel = 0x05040100u;
 
     // row-direction state: per accumulator register r, the best two 16-bit keys (d << 6 | tile) of the
     // lane's column class, M-tile 0 in the low halves and M-tile 1 in the high halves
@@ -189,19 +201,15 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         j = j < n2 ? j : n2 - 1;
         return braw[(size_t)j * 8 + ewd];
     };
-    // b-side expansion goes through a 256-entry table in LDS (4 ds_read_b64 + ~8 VALU per raw dword
-    // instead of 32 VALU: the VALU is the busy unit of this kernel, the LDS is not)
-    blut[tid] = make_uint2(expand4((uint32_t)tid, 0, LUT_B), expand4((uint32_t)tid, 4, LUT_B));
-    __syncthreads();
+    // b-side expansion goes through the table: 4 ds_read_b32 + one ds_write_b128 per raw dword
     auto expand_store = [&](uint32_t raw, int buf) __attribute__((always_inline)) {
-        uint8_t* dst = btile + buf * MF_TILE_BYTES + ej * MF_ROW_STRIDE + ewd * 32;
-        const uint2 q0 = blut[raw & 0xFFu], q1 = blut[(raw >> 8) & 0xFFu];
-        const uint2 q2 = blut[(raw >> 16) & 0xFFu], q3 = blut[raw >> 24];
-        i32x4 lo, hi;
-        lo.x = (int)q0.x; lo.y = (int)q0.y; lo.z = (int)q1.x; lo.w = (int)q1.y;
-        hi.x = (int)q2.x; hi.y = (int)q2.y; hi.z = (int)q3.x; hi.w = (int)q3.y;
-        *reinterpret_cast<i32x4*>(dst) = lo;
-        *reinterpret_cast<i32x4*>(dst + 16) = hi;
+        uint8_t* dst = btile + buf * MF_TILE_BYTES + ej * MF_ROW_STRIDE + ewd * 16;
+        i32x4 v;
+        v.x = (int)blut[raw & 0xFFu];
+        v.y = (int)blut[(raw >> 8) & 0xFFu];
+        v.z = (int)blut[(raw >> 16) & 0xFFu];
+        v.w = (int)blut[raw >> 24];
+        *reinterpret_cast<i32x4*>(dst) = v;
     };
     auto flush_columns = [&](int t) __attribute__((always_inline)) {              // lanes 0..31 of ONE wave: combine the 4 waves' partials of tile t
         if (lane < MF_TILE_N) {
@@ -224,7 +232,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
 #define PLSLAM_MF_EPI_ROW(R)                                                                       \
     {                                                                                              \
         constexpr uint32_t LOC = ((R) & 3) + 8 * ((R) >> 2);                                       \
-        uint32_t kc = pack_acc(acc0[R], acc1[R]);                                                  \
+        uint32_t kc = pack_acc(acc0[R], acc1[R], pack_sel);                                        \
         uint32_t kr = kc + tpair;                                                                  \
         if (MASKED) {                                                                              \
             kr = col_ok ? kr : 0xFFFFFFFFu;                                                        \
@@ -246,7 +254,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         if (lane < MF_TILE_N) colbuf[t & 1][w][lane] = make_uint2(k0, k1);
     };
     // E(t) on its own (the last tile has no following M step to hide under)
-    auto epilogue = [&](int t, const i32x16& acc0, const i32x16& acc1, auto masked_tag) __attribute__((always_inline)) {
+    auto epilogue = [&](int t, const f32x16& acc0, const f32x16& acc1, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const bool col_ok = t * MF_TILE_N + c < n2;
         const uint32_t tpair = (uint32_t)t * 0x00010001u;            // tile number in both halves (t < 64)
@@ -266,7 +274,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     // VALU, 1 : 11); all eight B operands prefetched before the first MFMA; co-resident workgroups started
     // half a step apart; pairs of MFMAs hand-fenced with two register pairs of E (+4 %); LDS round trips
     // (operand reads, lane exchange) issued a quarter-epilogue ahead of their use (+8 %).
-    auto step = [&](int t, i32x16& m0, i32x16& m1, const i32x16& acc0, const i32x16& acc1, bool with_prev,
+    auto step = [&](int t, f32x16& m0, f32x16& m1, const f32x16& acc0, const f32x16& acc1, bool with_prev,
                     auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const uint32_t raw2 = t + 2 < ntiles ? load_raw(t + 2) : 0u;
@@ -277,29 +285,34 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         const uint32_t tpair = (uint32_t)(t - 1) * 0x00010001u;      // tile number in both halves (t < 64)
         uint32_t cb0 = 0xFFFFFFFFu, cb1 = 0xFFFFFFFFu;
         i32x4 bf = *reinterpret_cast<const i32x4*>(bt);
-        // program order, fenced: [MFMA] [one accumulator register pair of E(t-1): 8 VALU ~ one MFMA's 32
-        // matrix-pipe cycles] [MFMA] [8 VALU] ... -- single MFMAs, evenly spaced, so that this wave is never
-        // stalled at the issue of the second MFMA of a pair while the pipe is busy with the first
-#define PLSLAM_MF_KSTEP(KK, CIN0, CIN1)                                                            \
+        // program order, fenced: [MFMA] [two accumulator register pairs of E(t-1): 16 VALU] [MFMA] [16 VALU]
+        // ... -- single MFMAs, evenly spaced, so that this wave is never stalled at the issue of the second
+        // MFMA of a pair while the matrix pipe is busy with the first
+#define PLSLAM_MF_MMA(ACC, MT, KS, CIN)                                                            \
+        {                                                                                          \
+            const i32x8 a8 = {afrag[MT][KS].x, afrag[MT][KS].y, afrag[MT][KS].z, afrag[MT][KS].w, 0, 0, 0, 0}; \
+            const i32x8 b8 = {bcur.x, bcur.y, bcur.z, bcur.w, 0, 0, 0, 0};                         \
+            if (PLSLAM_MF_EXPERIMENT != 3)                                                         \
+                ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, CIN, 4, 4, 0, scale_a, 0, scale_b); \
+            else ACC[KS] = __builtin_bit_cast(float, bcur.x);                                      \
+        }
+#define PLSLAM_MF_KSTEP(KS, CIN0, CIN1)                                                            \
         {                                                                                          \
             const i32x4 bcur = bf;                                                                 \
-            if ((KK) < 7) bf = *reinterpret_cast<const i32x4*>(bt + 32 * ((KK) + 1));               \
-            if (PLSLAM_MF_EXPERIMENT != 3) m0 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[0][KK], bcur, CIN0, 0, 0, 0); \
-            else m0[KK] = bcur.x;                                                                  \
+            if ((KS) < MF_KSTEPS - 1) bf = *reinterpret_cast<const i32x4*>(bt + 32 * ((KS) + 1));   \
+            PLSLAM_MF_MMA(m0, 0, KS, CIN0)                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                     \
-            if (with_prev && PLSLAM_MF_EXPERIMENT != 2) { PLSLAM_MF_EPI_ROW(2 * (KK)) }             \
+            if (with_prev && PLSLAM_MF_EXPERIMENT != 2) { PLSLAM_MF_EPI_ROW(4 * (KS)) PLSLAM_MF_EPI_ROW(4 * (KS) + 1) } \
             __builtin_amdgcn_sched_barrier(0);                                                     \
-            if (PLSLAM_MF_EXPERIMENT != 3) m1 = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[1][KK], bcur, CIN1, 0, 0, 0); \
-            else m1[KK] = bcur.y;                                                                  \
+            PLSLAM_MF_MMA(m1, 1, KS, CIN1)                                                         \
             __builtin_amdgcn_sched_barrier(0);                                                     \
-            if (with_prev && PLSLAM_MF_EXPERIMENT != 2) { PLSLAM_MF_EPI_ROW(2 * (KK) + 1) }         \
+            if (with_prev && PLSLAM_MF_EXPERIMENT != 2) { PLSLAM_MF_EPI_ROW(4 * (KS) + 2) PLSLAM_MF_EPI_ROW(4 * (KS) + 3) } \
             __builtin_amdgcn_sched_barrier(0);                                                     \
         }
         PLSLAM_MF_KSTEP(0, cinit, cinit)
         PLSLAM_MF_KSTEP(1, m0, m1) PLSLAM_MF_KSTEP(2, m0, m1) PLSLAM_MF_KSTEP(3, m0, m1)
-        PLSLAM_MF_KSTEP(4, m0, m1) PLSLAM_MF_KSTEP(5, m0, m1) PLSLAM_MF_KSTEP(6, m0, m1)
-        PLSLAM_MF_KSTEP(7, m0, m1)
 #undef PLSLAM_MF_KSTEP
+#undef PLSLAM_MF_MMA
         expand_store(raw1, (t + 1) & 1);           // past the last tile: a harmless rewrite of the idle buffer
         raw1 = raw2;
         if (PLSLAM_MF_EXPERIMENT == 2) asm volatile("" ::"v"(m0), "v"(m1));
@@ -308,7 +321,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     // S(0) | S(1)+E(0) | S(2)+E(1) | ... | E(ntiles-1).  Two accumulator sets alternate (unrolled by two:
     // no accumulator is ever copied).  Only the last tile can lack columns.
     auto pipeline = [&](auto steady_tag) __attribute__((always_inline)) {
-        i32x16 A0, A1, B0, B1;
+        f32x16 A0, A1, B0, B1;
         const bool last_partial = (n2 % MF_TILE_N) != 0;
         step(0, A0, A1, A0, A1, false, steady_tag);
         int t = 1;
