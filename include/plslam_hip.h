@@ -59,8 +59,8 @@ enum {
     PLSLAM_SCAN_LANE_PER_QUERY = 1, /* query in VGPRs, train rows streamed as SGPRs        */
     PLSLAM_SCAN_WAVE_PER_QUERY = 2, /* train tile in LDS, query in SGPRs, wave best-2 reduce */
     PLSLAM_SCAN_SYMMETRIC = 3,      /* mutual problems: one distance serves both directions */
-    PLSLAM_SCAN_MFMA = 4            /* symmetric scan with the distances from v_mfma_i32_32x32x32_i8:
-                                       d = (256 - <s(a),s(b)>)/2 over +-1 bytes, exact; non-mutual
+    PLSLAM_SCAN_MFMA = 4            /* symmetric scan with the distances from the matrix cores:
+                                       d = (256 - <s(a),s(b)>)/2 over +-1 fp4 codes, exact; non-mutual
                                        problems of the plan take LANE_PER_QUERY                      */
 };
 
