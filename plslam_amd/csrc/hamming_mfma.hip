@@ -132,7 +132,11 @@ __global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unifi
 k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
                 int32_t* __restrict__ zero, int nzero)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t btile[2 * MF_TILE_BYTES];      //  9 216 B
+    // one buffer, two lives: the double-buffered b tile during the scan (9 216 B), the row-result transpose
+    // [wave][row 0..63][33] after it (33 792 B)
+    constexpr int ROWX_STRIDE = 33;               // dwords per row: lane = row reads are conflict-free
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * 64 * ROWX_STRIDE * 4];
+    uint8_t* const btile = smem;
     __shared__ uint2 colbuf[2][4][MF_TILE_N];                                      //  2 048 B
     __shared__ uint32_t blut[256];                // byte of a b row -> its 8 s(b) fp4 codes  1 024 B
 
@@ -345,23 +349,40 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     if (w == ((ntiles + 1) & 3)) flush_columns(ntiles - 1);
 #undef PLSLAM_MF_EPI_ROW
 
-    // ---- row results: 16-bit (d, tile) -> 32-bit (d, j = 32 tile + c), then combine the 32 column
-    // classes with a butterfly; lane c keeps (reg = c & 15) ----------------------------------------------
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    // ---- row results.  Every lane holds, per accumulator register, the best two 16-bit keys (d, tile + LOC)
+    // of ITS column class for two rows.  Transpose through LDS so that one lane owns one row: lane l reads
+    // the 32 class entries of row l in class order, widens them to (key16 << 16 | class) -- which orders
+    // like (d, j = 32 tile + class) because every entry of a row carries the same LOC -- and keeps the best
+    // two; only those two are converted to (d << 23 | j).  (A 5-step cross-lane butterfly per register cost
+    // ~860 VALU ops + 320 ds_bpermute per wave; this is ~250 + 64.)  All waves are past their last operand
+    // read of `smem` (barrier above), and the region used here is private to the wave. ---------------------
+    {
+        uint32_t* rowx = reinterpret_cast<uint32_t*>(smem) + w * (64 * ROWX_STRIDE);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const uint32_t h0 = mt ? rb[r][0] >> 16 : rb[r][0] & 0xFFFFu;
-            const uint32_t h1 = mt ? rb[r][1] >> 16 : rb[r][1] & 0xFFFFu;
-            const uint32_t loc = (uint32_t)((r & 3) + 8 * (r >> 2));     // the tag is tile + LOC
-            uint32_t k0 = key16_to_key32(h0, loc, (uint32_t)c, (uint32_t)MF_TILE_N);
-            uint32_t k1 = key16_to_key32(h1, loc, (uint32_t)c, (uint32_t)MF_TILE_N);
-#pragma unroll
-            for (int m = 16; m >= 1; m >>= 1)
-                merge2(k0, k1, (uint32_t)__shfl_xor((int)k0, m), (uint32_t)__shfl_xor((int)k1, m));
-            const int row = iw + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * g;
-            if (c == r && row < n1) reinterpret_cast<uint2*>(sd.keys12)[row] = make_uint2(k0, k1);
+            const int lrow = (r & 3) + 8 * (r >> 2) + 4 * g;
+            // (best | second << 16) of M-tile 0 (low halves) and of M-tile 1 (high halves)
+            rowx[lrow * ROWX_STRIDE + c] = (rb[r][0] & 0xFFFFu) | (rb[r][1] << 16);
+            rowx[(32 + lrow) * ROWX_STRIDE + c] = (rb[r][0] >> 16) | (rb[r][1] & 0xFFFF0000u);
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+        const uint32_t* mine = rowx + lane * ROWX_STRIDE;
+#pragma unroll 8
+        for (int cls = 0; cls < 32; ++cls) {
+            const uint32_t e = mine[cls];
+            merge2(k0, k1, (e << 16) | (uint32_t)cls, (e & 0xFFFF0000u) | (uint32_t)cls);
+        }
+        // (key16 << 16 | class) -> (d << 23 | 32 (tag - LOC) + class); LOC of local row l: l without bit 2 (= g)
+        const uint32_t loc = (uint32_t)(lane & 31 & ~4);
+        auto widen = [&](uint32_t k) -> uint32_t {
+            const uint32_t k16 = k >> 16, cls = k & 0xFFFFu;
+            return key16_to_key32(k16, loc, cls, (uint32_t)MF_TILE_N);
+        };
+        const int row = iw + lane;
+        if (row < n1) reinterpret_cast<uint2*>(sd.keys12)[row] = make_uint2(widen(k0), widen(k1));
     }
 }
 
