@@ -166,12 +166,10 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     for (int mt = 0; mt < 2; ++mt) {
         const int row = iw + 32 * mt + c;
         const int rrow = row < n1 ? row : n1 - 1;                 // clamped; masked in the epilogue
-        const u32x4_t* p = reinterpret_cast<const u32x4_t*>(araw + (size_t)rrow * 8);
-        const u32x4_t lo = p[0], hi = p[1];
-        const uint32_t wd[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+        const uint32_t* p = araw + (size_t)rrow * 8 + g;         // this lane's dword of each K-step: 2 ks + g
 #pragma unroll
         for (int ks = 0; ks < MF_KSTEPS; ++ks) {
-            const uint32_t raw = g ? wd[2 * ks + 1] : wd[2 * ks];
+            const uint32_t raw = p[2 * ks];
             afrag[mt][ks].x = (int)(blut[raw & 0xFFu] ^ FP4_NEG);
             afrag[mt][ks].y = (int)(blut[(raw >> 8) & 0xFFu] ^ FP4_NEG);
             afrag[mt][ks].z = (int)(blut[(raw >> 16) & 0xFFu] ^ FP4_NEG);
