@@ -70,7 +70,8 @@ def test_tie_stress_bit_exact(ctx, oracle, seed):
 
 @pytest.mark.parametrize("n1,n2", [(1, 2), (2, 1), (63, 65), (64, 64), (65, 63), (129, 1), (200, 200), (1500, 1500),
                                    (333, 1027), (1027, 333), (2, 2), (70, 3), (255, 17), (256, 16), (257, 15), (513, 31),
-                                   (1, 1), (300, 5), (40, 1537), (1600, 3100), (17, 4000)])
+                                   (1, 1), (300, 5), (40, 1537), (1600, 3100), (17, 4000), (5000, 1999), (3000, 2048),
+                                   (2048, 31), (257, 2047)])
 def test_symmetric_and_directed_variants_agree(ctx, oracle, n1, n2):
     """Mutual problems default to the symmetric scan (one distance feeds both directions); forcing
     the directed lane-per-query scan must give the same tables, and both must equal the oracle."""
