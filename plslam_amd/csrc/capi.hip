@@ -70,6 +70,7 @@ struct plslam_match_plan {
     int32_t nprob = 0, nscan = 0, nscan_blocks = 0, nfin_blocks = 0, ncounts = 0;
     int32_t nsym = 0, nsym_blocks = 0, nmerge_blocks = 0, sym_rows = 1;
     bool sym_mfma = false;             // symmetric problems run on K1e (matrix cores)
+    bool sym_mfma_multi = false;       // ... and some of them have n2 > 2048 (multi-window instantiation)
     DevBuf keys, counts, partials;
     DevBuf tables;                     // all launch tables, packed, uploaded with ONE copy
     std::vector<char> staging;         // host image of `tables` (kept alive: the copy is async)
@@ -102,7 +103,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->nprob = nprob;
 
     // AUTO: mutual problems take the symmetric scan (one distance feeds both directions) -- on the
-    // matrix cores (K1e) when every such problem has n2 <= 2048, else as XOR+popcount (K1b/K1b') -- and
+    // matrix cores (K1e) -- and
     // the others the directed lane-per-query scan.  A forced variant applies to every problem
     // (SYMMETRIC = the XOR+popcount form).  Measured, scan time per launch, C2 batches of 64 / 256 / 1024 /
     // 4096 pairs: K1e 0.12 / 0.45 / 1.69 / 6.0 ms, K1b(') 0.24 / 0.78 / 2.85 / 10.9 ms.
@@ -122,11 +123,10 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     // plan has enough 256-row waves for >= 6 full rounds of the chip (17 single-wave workgroups fit a
     // CU's LDS); below that the 4x coarser work units lose more to tail quantisation than they gain
     // (measured: 266k vs 320k pairs/s at 512 pairs, 347k vs 344k at 2048, 364k vs 347k at 4096).
-    // K1e keeps its row state as 16-bit (distance, tile) keys: 64 tiles of 32 columns.  A plan with a
-    // longer mutual problem takes the XOR+popcount symmetric scan instead.
     P->sym_mfma = allow_sym && (ctx->scan_variant == PLSLAM_SCAN_MFMA || ctx->scan_variant == PLSLAM_SCAN_AUTO);
+    P->sym_mfma_multi = false;
     for (int32_t i = 0; i < nprob && P->sym_mfma; ++i)
-        if (is_sym(probs[i]) && probs[i].n2 > 2048) P->sym_mfma = false;
+        if (is_sym(probs[i]) && probs[i].n2 > 2048) P->sym_mfma_multi = true;
     P->sym_rows = P->sym_mfma ? 4 : ctx->sym_rows;      // K1e uses the 256-row tables of K1b'
     if (P->sym_rows == 0) {
         int64_t waves4 = 0;
@@ -357,7 +357,7 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
     const bool sym_first = P->nsym_blocks > 0;
     if (sym_first) {
         r = P->sym_mfma ? launch_scan_sym_mfma(P->d_syms, P->d_sym_blocks, P->nsym_blocks, P->d_counts_zero,
-                                               P->ncounts, s)
+                                               P->ncounts, P->sym_mfma_multi, s)
                         : launch_scan_sym(P->sym_rows, P->d_syms, P->d_sym_blocks,
                                           P->nsym_blocks, P->d_counts_zero, P->ncounts, s);
         if (r) return r;

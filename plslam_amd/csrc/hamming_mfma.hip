@@ -128,6 +128,10 @@ __device__ __forceinline__ int xcd_remap_(int orig, int nwg) { return (orig & 7)
 
 }  // namespace
 
+// MULTI = false: every problem of the launch has n2 <= 2048 (one window of 64 tiles; the window bounds are
+// compile-time facts).  MULTI = true: any n2 (the extra live state costs ~2 % through register pressure,
+// which is why the common case has its own instantiation; capi.hip picks per plan).
+template <bool MULTI>
 __global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
 k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
                 int32_t* __restrict__ zero, int nzero)
@@ -244,7 +248,15 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         pk_push2(rb[R][0], rb[R][1], kr);                                                          \
         pk_push2(cb0, cb1, kc);                                                                    \
     }
-    uint32_t raw1 = ntiles > 1 ? load_raw(1) : 0u;         // raw b dword of tile t+1 of the coming step
+    {
+#define WT0 (MULTI ? wt0v : 0)
+#define WT1 (MULTI ? wt1v : ntiles)
+    // The 16-bit row keys hold 64 tile numbers, so the scan runs in WINDOWS of 64 tiles (2048 columns): after
+    // each window the row state is reduced and merged into keys12, then restarted.  WT0 = first tile of the
+    // current window, WT1 = one past its last.  In the MULTI = false instantiation both are
+    // compile-time facts (0 and ntiles): no extra live registers.
+    int wt0v = 0, wt1v = ntiles < 64 ? ntiles : 64;
+    uint32_t raw1 = 0u;                                    // raw b dword of tile t+1 of the coming step
     // column best-2 of a finished tile: the two halves of (cb0, cb1) are sorted streams over disjoint rows
     // of the same column -> 32-bit keys with the a-row, best 2 of the lane, then the other 32 rows (lane ^ 32)
     auto finish_columns = [&](int t, uint32_t cb0, uint32_t cb1) __attribute__((always_inline)) {
@@ -259,7 +271,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     auto epilogue = [&](int t, const f32x16& acc0, const f32x16& acc1, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const bool col_ok = t * MF_TILE_N + c < n2;
-        const uint32_t tpair = (uint32_t)t * 0x00010001u;            // tile number in both halves (t < 64)
+        const uint32_t tpair = (uint32_t)(t - WT0) * 0x00010001u;    // tile number within the window, both halves
         uint32_t cb0 = 0xFFFFFFFFu, cb1 = 0xFFFFFFFFu;
         PLSLAM_MF_EPI_ROW(0) PLSLAM_MF_EPI_ROW(1) PLSLAM_MF_EPI_ROW(2) PLSLAM_MF_EPI_ROW(3)
         PLSLAM_MF_EPI_ROW(4) PLSLAM_MF_EPI_ROW(5) PLSLAM_MF_EPI_ROW(6) PLSLAM_MF_EPI_ROW(7)
@@ -279,12 +291,12 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     auto step = [&](int t, f32x16& m0, f32x16& m1, const f32x16& acc0, const f32x16& acc1, bool with_prev,
                     auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const uint32_t raw2 = t + 2 < ntiles ? load_raw(t + 2) : 0u;
+        const uint32_t raw2 = t + 2 < WT1 ? load_raw(t + 2) : 0u;
         if (PLSLAM_MF_EXPERIMENT != 1) __syncthreads();   // tile t expanded; colbuf of tile t-2 complete
-        if (t > 1 && w == (t & 3)) flush_columns(t - 2);            // the waves take turns
+        if (t - WT0 > 1 && w == (t & 3)) flush_columns(t - 2);      // the waves take turns
         const uint8_t* bt = btile + (t & 1) * MF_TILE_BYTES + c * MF_ROW_STRIDE + 16 * g;
         const bool col_ok = (t - 1) * MF_TILE_N + c < n2;
-        const uint32_t tpair = (uint32_t)(t - 1) * 0x00010001u;      // tile number in both halves (t < 64)
+        const uint32_t tpair = (uint32_t)(t - 1 - WT0) * 0x00010001u; // tile number within the window, both halves
         uint32_t cb0 = 0xFFFFFFFFu, cb1 = 0xFFFFFFFFu;
         i32x4 bf = *reinterpret_cast<const i32x4*>(bt);
         // program order, fenced: [MFMA] [two accumulator register pairs of E(t-1): 16 VALU] [MFMA] [16 VALU]
@@ -320,41 +332,33 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         if (PLSLAM_MF_EXPERIMENT == 2) asm volatile("" ::"v"(m0), "v"(m1));
         if (with_prev && PLSLAM_MF_EXPERIMENT != 2) finish_columns(t - 1, cb0, cb1);
     };
-    // S(0) | S(1)+E(0) | S(2)+E(1) | ... | E(ntiles-1).  Two accumulator sets alternate (unrolled by two:
-    // no accumulator is ever copied).  Only the last tile can lack columns.
+    // One window: S(WT0) | S(WT0+1)+E(WT0) | S(WT0+2)+E(WT0+1) | ... | E(WT1-1).  Two accumulator sets
+    // alternate (unrolled by two: no accumulator is ever copied).  Only the last tile of the scan can lack
+    // columns.
     auto pipeline = [&](auto steady_tag) __attribute__((always_inline)) {
         f32x16 A0, A1, B0, B1;
-        const bool last_partial = (n2 % MF_TILE_N) != 0;
-        step(0, A0, A1, A0, A1, false, steady_tag);
-        int t = 1;
-        for (; t + 1 < ntiles; t += 2) {
+        const bool last_partial = WT1 == ntiles && (n2 % MF_TILE_N) != 0;
+        step(WT0, A0, A1, A0, A1, false, steady_tag);
+        int t = WT0 + 1;
+        for (; t + 1 < WT1; t += 2) {
             step(t, B0, B1, A0, A1, true, steady_tag);
             step(t + 1, A0, A1, B0, B1, true, steady_tag);
         }
-        if (t < ntiles) {                          // t == ntiles - 1: one more tile, into set B
+        if (t < WT1) {                             // t == WT1 - 1: one more tile, into set B
             step(t, B0, B1, A0, A1, true, steady_tag);
             if (last_partial) epilogue(t, B0, B1, std::true_type{}); else epilogue(t, B0, B1, steady_tag);
-        } else {                                   // tile ntiles - 1 is in set A
+        } else {                                   // tile WT1 - 1 is in set A
             if (last_partial) epilogue(t - 1, A0, A1, std::true_type{}); else epilogue(t - 1, A0, A1, steady_tag);
         }
     };
-
-    expand_store(load_raw(0), 0);
-    if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
-    // the last two tiles' column partials are still in LDS
-    __syncthreads();
-    if (ntiles > 1 && w == (ntiles & 3)) flush_columns(ntiles - 2);
-    if (w == ((ntiles + 1) & 3)) flush_columns(ntiles - 1);
-#undef PLSLAM_MF_EPI_ROW
-
-    // ---- row results.  Every lane holds, per accumulator register, the best two 16-bit keys (d, tile + LOC)
-    // of ITS column class for two rows.  Transpose through LDS so that one lane owns one row: lane l reads
-    // the 32 class entries of row l in class order, widens them to (key16 << 16 | class) -- which orders
-    // like (d, j = 32 tile + class) because every entry of a row carries the same LOC -- and keeps the best
-    // two; only those two are converted to (d << 23 | j).  (A 5-step cross-lane butterfly per register cost
-    // ~860 VALU ops + 320 ds_bpermute per wave; this is ~250 + 64.)  All waves are past their last operand
-    // read of `smem` (barrier above), and the region used here is private to the wave. ---------------------
-    {
+    // Row results of a window.  Every lane holds, per accumulator register, the best two 16-bit keys
+    // (d, tile + LOC) of ITS column class for two rows.  Transpose through LDS so that one lane owns one row:
+    // lane l reads the 32 class entries of row l in class order, widens them to (key16 << 16 | class) -- which
+    // orders like (d, j = 32 tile + class) because every entry of a row carries the same LOC -- and keeps the
+    // best two; only those two are converted to (d << 23 | j).  (A 5-step cross-lane butterfly per register
+    // cost ~860 VALU ops + 320 ds_bpermute per wave; this is ~250 + 64.)  Callers guarantee that all waves
+    // are past their last operand read of `smem`; the region used here is private to the wave.
+    auto finish_rows = [&]() __attribute__((always_inline)) {
         uint32_t* rowx = reinterpret_cast<uint32_t*>(smem) + w * (64 * ROWX_STRIDE);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -362,6 +366,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
             // (best | second << 16) of M-tile 0 (low halves) and of M-tile 1 (high halves)
             rowx[lrow * ROWX_STRIDE + c] = (rb[r][0] & 0xFFFFu) | (rb[r][1] << 16);
             rowx[(32 + lrow) * ROWX_STRIDE + c] = (rb[r][0] >> 16) | (rb[r][1] & 0xFFFF0000u);
+            rb[r][0] = rb[r][1] = 0xFFFFFFFFu;                  // restart for the next window
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -373,22 +378,54 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
             const uint32_t e = mine[cls];
             merge2(k0, k1, (e << 16) | (uint32_t)cls, (e & 0xFFFF0000u) | (uint32_t)cls);
         }
-        // (key16 << 16 | class) -> (d << 23 | 32 (tag - LOC) + class); LOC of local row l: l without bit 2 (= g)
+        // (key16 << 16 | class) -> (d << 23 | 32 (WT0 + tag - LOC) + class); LOC of local row l: l without bit 2 (= g)
         const uint32_t loc = (uint32_t)(lane & 31 & ~4);
         auto widen = [&](uint32_t k) -> uint32_t {
             const uint32_t k16 = k >> 16, cls = k & 0xFFFFu;
-            return key16_to_key32(k16, loc, cls, (uint32_t)MF_TILE_N);
+            return key16_to_key32(k16, loc, cls + (uint32_t)(WT0 * MF_TILE_N), (uint32_t)MF_TILE_N);
         };
         const int row = iw + lane;
-        if (row < n1) reinterpret_cast<uint2*>(sd.keys12)[row] = make_uint2(widen(k0), widen(k1));
+        if (row < n1) {
+            uint2* out = reinterpret_cast<uint2*>(sd.keys12) + row;
+            uint32_t r0 = widen(k0), r1 = widen(k1);
+            if (WT0 > 0) {                                  // later windows: merge with the windows before
+                const uint2 prev = *out;
+                merge2(r0, r1, prev.x, prev.y);
+            }
+            *out = make_uint2(r0, r1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (;;) {
+        expand_store(load_raw(WT0), 0);            // WT0 is a multiple of 64: buffer parity restarts at 0
+        raw1 = WT0 + 1 < WT1 ? load_raw(WT0 + 1) : 0u;
+        if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
+        // the last two tiles' column partials of the window are still in LDS
+        __syncthreads();
+        if (WT1 - WT0 > 1 && w == (WT1 & 3)) flush_columns(WT1 - 2);
+        if (w == ((WT1 + 1) & 3)) flush_columns(WT1 - 1);
+        finish_rows();
+        if (!MULTI || wt1v == ntiles) break;
+        __syncthreads();                           // smem becomes the b tile again; colbuf is free
+        wt0v = wt1v;
+        wt1v = ntiles < wt0v + 64 ? ntiles : wt0v + 64;
     }
+#undef WT0
+#undef WT1
+    }
+#undef PLSLAM_MF_EPI_ROW
 }
 
 int launch_scan_sym_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
-                         int nzero, hipStream_t s)
+                         int nzero, bool multi_window, hipStream_t s)
 {
     if (nblocks <= 0) return PLSLAM_OK;
-    hipLaunchKernelGGL(k_scan_sym_mfma, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
+    if (multi_window)
+        hipLaunchKernelGGL(k_scan_sym_mfma<true>, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
+    else
+        hipLaunchKernelGGL(k_scan_sym_mfma<false>, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

@@ -238,12 +238,13 @@ def test_device_resident_plan_matches_oracle(vctx, oracle):
     bm.close()
 
 
-@pytest.mark.parametrize("n_orb,n_lbd,expect", [(2048, 33, "mfma"), (2049, 33, "popcount"), (1999, 1, "mfma"),
-                                                  (96, 2048, "mfma"), (31, 32, "mfma")])
+@pytest.mark.parametrize("n_orb,n_lbd,expect", [(2048, 33, "mfma"), (2049, 33, "mfma"), (1999, 1, "mfma"),
+                                                  (96, 2048, "mfma"), (31, 32, "mfma"), (4130, 65, "mfma")])
 def test_matrix_core_scan_limits(ctx, oracle, n_orb, n_lbd, expect):
-    """K1e keeps 16-bit (distance, tile) row keys: 64 tiles of 32 columns.  At n2 = 2048 every tile number
-    is used; one row more and the plan falls back to the XOR+popcount symmetric scan.  Tie-stress data
-    (many equal distances) on both sides of the limit, all four problems of every pair against the oracle."""
+    """K1e keeps 16-bit (distance, tile) row keys, so it scans in windows of 64 tiles (2048 columns) and merges
+    the row results of successive windows.  At n2 = 2048 every tile number of one window is used; 2049 starts a
+    second window with a single column; 4130 needs three.  Tie-stress data (many equal distances, so that
+    equal keys meet across window borders), all four problems of every pair against the oracle."""
     import torch
     import plslam_amd
     s = synth.stereo_stream(2, n_orb, n_lbd, seed=77, tie_stress=True)
