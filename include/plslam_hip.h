@@ -61,7 +61,7 @@ enum {
     PLSLAM_SCAN_SYMMETRIC = 3,      /* mutual problems: one distance serves both directions */
     PLSLAM_SCAN_MFMA = 4            /* symmetric scan with the distances from the matrix cores:
                                        d = (256 - <s(a),s(b)>)/2 over +-1 fp4 codes, exact; non-mutual
-                                       problems of the plan take LANE_PER_QUERY                      */
+                                       problems take its directed form                               */
 };
 
 typedef struct plslam_ctx plslam_ctx;

@@ -71,6 +71,9 @@ struct plslam_match_plan {
     int32_t nsym = 0, nsym_blocks = 0, nmerge_blocks = 0, sym_rows = 1;
     bool sym_mfma = false;             // symmetric problems run on K1e (matrix cores)
     bool sym_mfma_multi = false;       // ... and some of them have n2 > 2048 (multi-window instantiation)
+    int32_t ndir = 0, ndir_blocks = 0; // non-mutual problems on the directed form of K1e
+    bool dir_multi = false;
+    SymDesc* d_dirs = nullptr; BlockDesc* d_dir_blocks = nullptr;
     DevBuf keys, counts, partials;
     DevBuf tables;                     // all launch tables, packed, uploaded with ONE copy
     std::vector<char> staging;         // host image of `tables` (kept alive: the copy is async)
@@ -104,7 +107,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
 
     // AUTO: mutual problems take the symmetric scan (one distance feeds both directions) -- on the
     // matrix cores (K1e) -- and
-    // the others the directed lane-per-query scan.  A forced variant applies to every problem
+    // the others its directed form (row direction only).  A forced variant applies to every problem
     // (SYMMETRIC = the XOR+popcount form).  Measured, scan time per launch, C2 batches of 64 / 256 / 1024 /
     // 4096 pairs: K1e 0.12 / 0.45 / 1.69 / 6.0 ms, K1b(') 0.24 / 0.78 / 2.85 / 10.9 ms.
     // A plan too small to put one wave on every SIMD under those (e.g. ONE StVO::match call of the
@@ -125,6 +128,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     // (measured: 266k vs 320k pairs/s at 512 pairs, 347k vs 344k at 2048, 364k vs 347k at 4096).
     P->sym_mfma = allow_sym && (ctx->scan_variant == PLSLAM_SCAN_MFMA || ctx->scan_variant == PLSLAM_SCAN_AUTO);
     P->sym_mfma_multi = false;
+    P->dir_multi = false;
     for (int32_t i = 0; i < nprob && P->sym_mfma; ++i)
         if (is_sym(probs[i]) && probs[i].n2 > 2048) P->sym_mfma_multi = true;
     P->sym_rows = P->sym_mfma ? 4 : ctx->sym_rows;      // K1e uses the 256-row tables of K1b'
@@ -186,9 +190,9 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
 
     std::vector<ScanDesc> scans;
     std::vector<int32_t> scan_problem;   // scans[k] belongs to problem scan_problem[k]
-    std::vector<SymDesc> syms;
+    std::vector<SymDesc> syms, dirs;
     std::vector<ProblemDesc> pds;
-    std::vector<BlockDesc> sblocks, fblocks, yblocks, mblocks;
+    std::vector<BlockDesc> sblocks, fblocks, yblocks, mblocks, dblocks;
     int64_t key_row = 0, part_row = 0, evals = 0, devals = 0, abytes = 0;
     std::vector<int32_t*> user_counts((size_t)nprob, nullptr);
     for (int32_t i = 0; i < nprob; ++i) {
@@ -217,6 +221,17 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             evals += (int64_t)p.n1 * p.n2;
             devals += 2LL * p.n1 * p.n2;
             abytes += 2 * 32LL * (p.n1 + p.n2) + 16LL * (p.n1 + p.n2);
+        } else if (P->sym_mfma && !p.mutual && p.n1 > 0 && p.n2 > 0) {
+            // non-mutual problem on the matrix cores: the directed form of K1e (row direction only)
+            SymDesc y{};
+            y.a = p.d1; y.b = p.d2; y.keys12 = k12; y.keys21 = nullptr; y.part21 = nullptr;
+            y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = 0;
+            for (int32_t r0 = 0; r0 < p.n1; r0 += 256) dblocks.push_back({(int32_t)dirs.size(), r0});
+            if (p.n2 > 2048) P->dir_multi = true;
+            dirs.push_back(y);
+            evals += (int64_t)p.n1 * p.n2;
+            devals += (int64_t)p.n1 * p.n2;
+            abytes += 32LL * (p.n1 + p.n2) + 16LL * p.n1;
         } else {
             if (p.n1 > 0) {
                 ScanDesc sc{p.d1, p.d2, k12, p.n1, p.n2};
@@ -287,6 +302,9 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     if (!yblocks.empty())
         stripe(yblocks, groups_of(yblocks, [](const BlockDesc& b) { return b.item; },
                                   [&](const BlockDesc& b) { return (int64_t)syms[b.item].n2; }));
+    if (!dblocks.empty())
+        stripe(dblocks, groups_of(dblocks, [](const BlockDesc& b) { return b.item; },
+                                  [&](const BlockDesc& b) { return (int64_t)dirs[b.item].n2; }));
     if (!use_wpq && !sblocks.empty())   // the two directed scans of a mutual problem are adjacent: same group key
         stripe(sblocks, groups_of(sblocks, [&](const BlockDesc& b) { return scan_problem[b.item]; },
                                   [&](const BlockDesc& b) { return (int64_t)scans[b.item].nt; }));
@@ -296,25 +314,31 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->nfin_blocks = (int32_t)fblocks.size();
     P->nsym = (int32_t)syms.size();
     P->nsym_blocks = (int32_t)yblocks.size();
+    P->ndir = (int32_t)dirs.size();
+    P->ndir_blocks = (int32_t)dblocks.size();
     P->nmerge_blocks = (int32_t)mblocks.size();
     P->info.distance_evals = evals;      // executed
     P->info.directed_evals = devals;     // what two directed knnMatch calls per mutual problem evaluate
     P->info.algorithmic_bytes = abytes;  // 32(Q+T)+16Q per DIRECTED scan, however executed
-    P->info.n_scans = P->nscan + 2 * P->nsym;
-    P->info.scan_blocks = P->nscan_blocks + P->nsym_blocks;
-    P->info.scan_variant = P->nsym ? (P->sym_mfma ? PLSLAM_SCAN_MFMA : PLSLAM_SCAN_SYMMETRIC) : directed_variant;
-    P->info.scan_block_threads = P->nsym ? (P->sym_rows == 4 && !P->sym_mfma ? 64 : 256) : P->block_threads;
+    P->info.n_scans = P->nscan + 2 * P->nsym + P->ndir;
+    P->info.scan_blocks = P->nscan_blocks + P->nsym_blocks + P->ndir_blocks;
+    P->info.scan_variant = P->nsym ? (P->sym_mfma ? PLSLAM_SCAN_MFMA : PLSLAM_SCAN_SYMMETRIC)
+                                   : (P->ndir ? PLSLAM_SCAN_MFMA : directed_variant);
+    P->info.scan_block_threads = P->nsym ? (P->sym_rows == 4 && !P->sym_mfma ? 64 : 256)
+                                         : (P->ndir ? 256 : P->block_threads);
 
     // pack every launch table into one host image and upload it with a single copy
     struct Piece { const void* src; size_t bytes; size_t off; };
-    Piece pc[8] = {{scans.data(), scans.size() * sizeof(ScanDesc), 0},
+    Piece pc[10] = {{scans.data(), scans.size() * sizeof(ScanDesc), 0},
                    {syms.data(), syms.size() * sizeof(SymDesc), 0},
                    {pds.data(), pds.size() * sizeof(ProblemDesc), 0},
                    {sblocks.data(), sblocks.size() * sizeof(BlockDesc), 0},
                    {yblocks.data(), yblocks.size() * sizeof(BlockDesc), 0},
                    {mblocks.data(), mblocks.size() * sizeof(BlockDesc), 0},
                    {fblocks.data(), fblocks.size() * sizeof(BlockDesc), 0},
-                   {user_counts.data(), P->scatter_counts ? user_counts.size() * sizeof(int32_t*) : 0, 0}};
+                   {user_counts.data(), P->scatter_counts ? user_counts.size() * sizeof(int32_t*) : 0, 0},
+                   {dirs.data(), dirs.size() * sizeof(SymDesc), 0},
+                   {dblocks.data(), dblocks.size() * sizeof(BlockDesc), 0}};
     size_t total = 0;
     for (Piece& x : pc) { x.off = total; total += (x.bytes + 255) & ~size_t(255); }
     if (total == 0) total = 256;
@@ -331,6 +355,8 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->d_merge_blocks = reinterpret_cast<BlockDesc*>(base + pc[5].off);
     P->d_fin_blocks = reinterpret_cast<BlockDesc*>(base + pc[6].off);
     P->d_count_dst = reinterpret_cast<int32_t**>(base + pc[7].off);
+    P->d_dirs = reinterpret_cast<SymDesc*>(base + pc[8].off);
+    P->d_dir_blocks = reinterpret_cast<BlockDesc*>(base + pc[9].off);
     // P->staging outlives the copy (it is a member), so no synchronisation is needed here; the
     // copy is ordered before the kernels of plan_run when they use the same stream, and the public
     // plan_create synchronises once so that any stream may be used afterwards.
@@ -354,20 +380,27 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
     }
     // the first scan kernel that runs zeroes the #matches counters
     int r;
-    const bool sym_first = P->nsym_blocks > 0;
-    if (sym_first) {
+    bool zeroed = false;               // the first scan kernel that runs zeroes the #matches counters
+    if (P->nsym_blocks > 0) {
         r = P->sym_mfma ? launch_scan_sym_mfma(P->d_syms, P->d_sym_blocks, P->nsym_blocks, P->d_counts_zero,
-                                               P->ncounts, P->sym_mfma_multi, s)
+                                               P->ncounts, P->sym_mfma_multi, false, s)
                         : launch_scan_sym(P->sym_rows, P->d_syms, P->d_sym_blocks,
                                           P->nsym_blocks, P->d_counts_zero, P->ncounts, s);
         if (r) return r;
+        zeroed = true;
     }
-    if (P->nscan_blocks > 0 || !sym_first) {
+    if (P->ndir_blocks > 0) {
+        r = launch_scan_sym_mfma(P->d_dirs, P->d_dir_blocks, P->ndir_blocks, P->d_counts_zero,
+                                 zeroed ? 0 : P->ncounts, P->dir_multi, true, s);
+        if (r) return r;
+        zeroed = true;
+    }
+    if (P->nscan_blocks > 0 || !zeroed) {
         r = launch_scan(P->ctx, P->variant == PLSLAM_SCAN_WAVE_PER_QUERY ? PLSLAM_SCAN_WAVE_PER_QUERY
                                                                          : PLSLAM_SCAN_LANE_PER_QUERY,
                         P->block_threads, P->d_scans,
                         P->d_scan_blocks, P->nscan_blocks, P->d_counts_zero,
-                        sym_first ? 0 : P->ncounts, s);
+                        zeroed ? 0 : P->ncounts, s);
         if (r) return r;
     }
     if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e1, s));   // e0..e1 = the scan kernel(s) alone
@@ -672,6 +705,38 @@ int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const 
     DeviceGuard g(ctx->device);
     int r;
     const bool small = (nq + 63) / 64 < ctx->prop.multiProcessorCount * 4;
+    // large query sets (or a forced variant): the directed form of K1e, distances from the matrix cores
+    if (nt > 0 && (ctx->scan_variant == PLSLAM_SCAN_MFMA || (ctx->scan_variant == PLSLAM_SCAN_AUTO && !small))) {
+        if ((r = ctx->in_a.reserve((size_t)nq * 32))) return r;
+        if ((r = ctx->in_b.reserve((size_t)nt * 32 + 16))) return r;
+        if ((r = ctx->misc_a.reserve((size_t)nq * 8))) return r;                 // keys
+        if ((r = ctx->out_a.reserve((size_t)nq * 8))) return r;                  // idx
+        if ((r = ctx->out_b.reserve((size_t)nq * 8))) return r;                  // dist
+        std::vector<BlockDesc> blocks;
+        for (int32_t r0 = 0; r0 < nq; r0 += 256) blocks.push_back({0, r0});
+        const size_t n = blocks.size(), L = (n + 7) / 8;                          // XCD-striped layout
+        std::vector<BlockDesc> striped(8 * L, BlockDesc{-1, 0});
+        for (size_t i = 0; i < n; ++i) striped[(i & 7) * L + (i >> 3)] = blocks[i];
+        if ((r = ctx->misc_b.reserve(sizeof(SymDesc) + 16))) return r;
+        if ((r = ctx->misc_c.reserve(striped.size() * sizeof(BlockDesc)))) return r;
+        SymDesc y{};
+        y.a = ctx->in_a.as<uint8_t>(); y.b = ctx->in_b.as<uint8_t>(); y.keys12 = ctx->misc_a.as<uint32_t>();
+        y.n1 = nq; y.n2 = nt;
+        hipStream_t s = ctx->stream;
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_a.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_b.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->misc_b.p, &y, sizeof(y), hipMemcpyHostToDevice, s));
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->misc_c.p, striped.data(), striped.size() * sizeof(BlockDesc),
+                                        hipMemcpyHostToDevice, s));
+        if ((r = launch_scan_sym_mfma(ctx->misc_b.as<SymDesc>(), ctx->misc_c.as<BlockDesc>(), (int)striped.size(),
+                                      nullptr, 0, nt > 2048, true, s))) return r;
+        if ((r = launch_unpack_keys(ctx->misc_a.as<uint32_t>(), nq * 2, ctx->out_a.as<int32_t>(),
+                                    ctx->out_b.as<int32_t>(), s))) return r;
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(idx, ctx->out_a.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(dist, ctx->out_b.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        return PLSLAM_OK;
+    }
     const int variant = ctx->scan_variant == PLSLAM_SCAN_WAVE_PER_QUERY ||
                                 (ctx->scan_variant == PLSLAM_SCAN_AUTO && small)
                             ? PLSLAM_SCAN_WAVE_PER_QUERY : PLSLAM_SCAN_LANE_PER_QUERY;

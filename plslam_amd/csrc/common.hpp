@@ -116,8 +116,9 @@ int launch_scan_sym(int rows_per_lane, const SymDesc* d_sym, const BlockDesc* d_
 // K1e: the symmetric scan on the matrix cores (hamming_mfma.hip); block tables / partials as for
 // launch_scan_sym(rows_per_lane = 4): 256 a-rows per workgroup and per column partial
 // multi_window: some problem of the launch has n2 > 2048 (row keys hold 64 tiles of 32 columns per window)
+// directed: only keys12 of every SymDesc is produced (keys21 / part21 unused): non-mutual problems, knnMatch
 int launch_scan_sym_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
-                         int nzero, bool multi_window, hipStream_t s);
+                         int nzero, bool multi_window, bool directed, hipStream_t s);
 int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s);
 
 int scan_rows_per_block(int variant, int block_threads);

@@ -131,7 +131,9 @@ __device__ __forceinline__ int xcd_remap_(int orig, int nwg) { return (orig & 7)
 // MULTI = false: every problem of the launch has n2 <= 2048 (one window of 64 tiles; the window bounds are
 // compile-time facts).  MULTI = true: any n2 (the extra live state costs ~2 % through register pressure,
 // which is why the common case has its own instantiation; capi.hip picks per plan).
-template <bool MULTI>
+// DIRECTED = true: only keys12 (row direction) is produced -- non-mutual problems and plain knnMatch(k=2):
+// no column keys, no column partials, 5 VALU ops per 2 distances.
+template <bool MULTI, bool DIRECTED>
 __global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
 k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
                 int32_t* __restrict__ zero, int nzero)
@@ -218,7 +220,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         *reinterpret_cast<i32x4*>(dst) = v;
     };
     auto flush_columns = [&](int t) __attribute__((always_inline)) {              // lanes 0..31 of ONE wave: combine the 4 waves' partials of tile t
-        if (lane < MF_TILE_N) {
+        if (!DIRECTED && lane < MF_TILE_N) {
             uint2 k = colbuf[t & 1][0][lane];
 #pragma unroll
             for (int ww = 1; ww < 4; ++ww) {
@@ -246,7 +248,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
                   ((int)(ibase + LOC + 32u) < n1 ? 0u : 0xFFFF0000u);                              \
         }                                                                                          \
         pk_push2(rb[R][0], rb[R][1], kr);                                                          \
-        pk_push2(cb0, cb1, kc);                                                                    \
+        if (!DIRECTED) pk_push2(cb0, cb1, kc);                                                     \
     }
     {
 #define WT0 (MULTI ? wt0v : 0)
@@ -260,6 +262,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     // column best-2 of a finished tile: the two halves of (cb0, cb1) are sorted streams over disjoint rows
     // of the same column -> 32-bit keys with the a-row, best 2 of the lane, then the other 32 rows (lane ^ 32)
     auto finish_columns = [&](int t, uint32_t cb0, uint32_t cb1) __attribute__((always_inline)) {
+        if (DIRECTED) return;
         // low halves: rows ibase + LOC (M-tile 0), high halves: rows ibase + 32 + LOC (M-tile 1)
         uint32_t k0 = key16_to_key32(cb0 & 0xFFFFu, 0u, ibase, 1u);
         uint32_t k1 = key16_to_key32(cb1 & 0xFFFFu, 0u, ibase, 1u);
@@ -419,13 +422,14 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
 }
 
 int launch_scan_sym_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
-                         int nzero, bool multi_window, hipStream_t s)
+                         int nzero, bool multi_window, bool directed, hipStream_t s)
 {
     if (nblocks <= 0) return PLSLAM_OK;
-    if (multi_window)
-        hipLaunchKernelGGL(k_scan_sym_mfma<true>, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
-    else
-        hipLaunchKernelGGL(k_scan_sym_mfma<false>, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
+#define PLSLAM_MF_LAUNCH(M, D) \
+    hipLaunchKernelGGL((k_scan_sym_mfma<M, D>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero)
+    if (multi_window) { if (directed) PLSLAM_MF_LAUNCH(true, true); else PLSLAM_MF_LAUNCH(true, false); }
+    else              { if (directed) PLSLAM_MF_LAUNCH(false, true); else PLSLAM_MF_LAUNCH(false, false); }
+#undef PLSLAM_MF_LAUNCH
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

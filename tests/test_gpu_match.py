@@ -290,6 +290,43 @@ def test_matrix_core_scan_extreme_distances(ctx, oracle):
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
 
 
+def test_directed_matrix_core_paths(ctx, oracle):
+    """Non-mutual problems and plain knnMatch(k=2) on the directed form of K1e: a large query set under AUTO
+    (66 000 queries -> past the latency-kernel threshold), a multi-window train set, ties, and a batched
+    non-mutual plan next to mutual problems."""
+    import plslam_amd
+    r = _rng(31)
+    q = synth.tie_stress_desc(r, 66000)
+    t = synth.tie_stress_desc(r, 300)
+    idx, dist = ctx.knn2(q, t)                               # AUTO
+    eidx, edist = oracle.knn2(q, t)
+    assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+    try:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)
+        q2, t2 = synth.random_desc(r, 700), synth.tie_stress_desc(r, 5000)      # 157 tiles: 3 windows
+        idx, dist = ctx.knn2(q2, t2)
+        eidx, edist = oracle.knn2(q2, t2)
+        assert np.array_equal(idx, eidx) and np.array_equal(dist, edist)
+        for n1, n2 in ((1, 1), (1, 2), (300, 1), (257, 33), (1000, 2049)):
+            a, b = synth.random_desc(r, n1), synth.tie_stress_desc(r, n2)
+            m, n = ctx.match(a, b, 0.9, False)
+            em, en = oracle.match(a, b, 0.9, False)
+            assert np.array_equal(m, em) and n == en, (n1, n2)
+        # mixed batch: problems 0, 2 mutual (symmetric K1e), 1, 3 would be separate calls in the reference;
+        # match_batched applies one mutual flag per call, so run both flags over the same ragged batch
+        sizes1, sizes2 = [300, 0, 513, 64], [280, 7, 100, 2500]
+        d1 = synth.random_desc(r, sum(sizes1)); d2 = synth.random_desc(r, sum(sizes2))
+        off1 = np.concatenate([[0], np.cumsum(sizes1)]).astype(np.int32)
+        off2 = np.concatenate([[0], np.cumsum(sizes2)]).astype(np.int32)
+        for mutual in (False, True):
+            m, cnt = ctx.match_batched(d1, off1, d2, off2, 0.8, mutual)
+            for b_ in range(4):
+                em, en = oracle.match(d1[off1[b_]:off1[b_ + 1]], d2[off2[b_]:off2[b_ + 1]], 0.8, mutual)
+                assert np.array_equal(m[off1[b_]:off1[b_ + 1]], em) and cnt[b_] == en, (mutual, b_)
+    finally:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+
+
 def test_large_train_set_index_bits(vctx, oracle):
     """Train indices beyond 16 bits (the composite key keeps 23 index bits): 70 000 train rows,
     planted best/second-best at the far end, plus exact duplicates to force index tie-breaks."""
