@@ -43,6 +43,28 @@ void DevBuf::release()
     cap = 0;
 }
 
+int HostBuf::reserve(size_t bytes)
+{
+    if (bytes <= cap) return PLSLAM_OK;
+    if (p) {
+        (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    size_t want = bytes + (bytes >> 2);
+    want = (want + 4095) & ~size_t(4095);
+    PLSLAM_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
+    cap = want;
+    return PLSLAM_OK;
+}
+
+void HostBuf::release()
+{
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
 struct DeviceGuard {  // every entry point runs on the context's device
     int prev = -1;
     explicit DeviceGuard(int dev)
@@ -77,6 +99,8 @@ struct plslam_match_plan {
     DevBuf keys, counts, partials;
     DevBuf tables;                     // all launch tables, packed, uploaded with ONE copy
     std::vector<char> staging;         // host image of `tables` (kept alive: the copy is async)
+    HostBuf staging_pin;               // ... in pinned memory when pin_tables (the context's host-path plan)
+    bool pin_tables = false;
     ScanDesc* d_scans = nullptr; SymDesc* d_syms = nullptr; ProblemDesc* d_probs = nullptr;
     BlockDesc *d_scan_blocks = nullptr, *d_sym_blocks = nullptr, *d_merge_blocks = nullptr, *d_fin_blocks = nullptr;
     int32_t** d_count_dst = nullptr;
@@ -91,7 +115,7 @@ struct plslam_match_plan {
     int64_t acc_runs = 0;
     void free_all()
     {
-        keys.release(); counts.release(); partials.release(); tables.release();
+        keys.release(); counts.release(); partials.release(); tables.release(); staging_pin.release();
         for (auto& e : evs) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2); }
         evs.clear();
     }
@@ -342,9 +366,16 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     size_t total = 0;
     for (Piece& x : pc) { x.off = total; total += (x.bytes + 255) & ~size_t(255); }
     if (total == 0) total = 256;
-    P->staging.resize(total);
+    char* stg = nullptr;
+    if (P->pin_tables && total <= (size_t(1) << 20)) {
+        if ((r = P->staging_pin.reserve(total))) return r;
+        stg = P->staging_pin.as<char>();
+    } else {
+        P->staging.resize(total);
+        stg = P->staging.data();
+    }
     for (const Piece& x : pc)
-        if (x.bytes) memcpy(P->staging.data() + x.off, x.src, x.bytes);
+        if (x.bytes) memcpy(stg + x.off, x.src, x.bytes);
     if ((r = P->tables.reserve(total))) return r;
     char* base = P->tables.as<char>();
     P->d_scans = reinterpret_cast<ScanDesc*>(base + pc[0].off);
@@ -360,7 +391,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     // P->staging outlives the copy (it is a member), so no synchronisation is needed here; the
     // copy is ordered before the kernels of plan_run when they use the same stream, and the public
     // plan_create synchronises once so that any stream may be used afterwards.
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(base, P->staging.data(), total, hipMemcpyHostToDevice, ctx->stream));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(base, stg, total, hipMemcpyHostToDevice, ctx->stream));
     return PLSLAM_OK;
 }
 
@@ -487,6 +518,8 @@ void plslam_ctx_destroy(plslam_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     ctx->in_a.release(); ctx->in_b.release(); ctx->out_a.release(); ctx->out_b.release();
     ctx->misc_a.release(); ctx->misc_b.release(); ctx->misc_c.release();
+    ctx->pin_in.release();
+    ctx->pin_out.release();
     if (ctx->host_plan) {
         ctx->host_plan->free_all();
         delete ctx->host_plan;
@@ -645,8 +678,23 @@ int plslam_match_batched(plslam_ctx* ctx, const uint8_t* d1, const int32_t* off1
     if ((r = ctx->in_b.reserve((size_t)r2 * 32 + 16))) return r;
     if ((r = ctx->out_a.reserve((size_t)r1 * 4 + 16))) return r;
     if ((r = ctx->out_b.reserve((size_t)B * 4))) return r;
-    if (r1) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_a.p, d1, (size_t)r1 * 32, hipMemcpyHostToDevice, ctx->stream));
-    if (r2) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_b.p, d2, (size_t)r2 * 32, hipMemcpyHostToDevice, ctx->stream));
+    // Latency path (one StVO::match of the SLAM loop, a frame's handful of problems): stage through the
+    // context's pinned buffers -- the CPU copies ~100 kB in a few microseconds and every hipMemcpyAsync
+    // becomes a plain DMA enqueue instead of the runtime's pageable-memory path.
+    const size_t in1 = (size_t)r1 * 32, in2 = (size_t)r2 * 32, out1 = (size_t)r1 * 4, out2 = (size_t)B * 4;
+    const bool pinned = in1 + in2 <= (size_t(1) << 20);
+    const size_t in2_off = (in1 + 255) & ~size_t(255), out2_off = (out1 + 255) & ~size_t(255);
+    const uint8_t *src1 = d1, *src2 = d2;
+    if (pinned) {
+        if ((r = ctx->pin_in.reserve(in2_off + in2 + 256))) return r;
+        if ((r = ctx->pin_out.reserve(out2_off + out2 + 256))) return r;
+        if (in1) memcpy(ctx->pin_in.as<char>(), d1, in1);
+        if (in2) memcpy(ctx->pin_in.as<char>() + in2_off, d2, in2);
+        src1 = ctx->pin_in.as<uint8_t>();
+        src2 = ctx->pin_in.as<uint8_t>() + in2_off;
+    }
+    if (r1) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_a.p, src1, in1, hipMemcpyHostToDevice, ctx->stream));
+    if (r2) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_b.p, src2, in2, hipMemcpyHostToDevice, ctx->stream));
 
     std::vector<plslam_match_problem> probs((size_t)B);
     for (int32_t b = 0; b < B; ++b) {
@@ -665,14 +713,21 @@ int plslam_match_batched(plslam_ctx* ctx, const uint8_t* d1, const int32_t* off1
     if (!ctx->host_plan) ctx->host_plan = new (std::nothrow) plslam_match_plan();
     PLSLAM_REQUIRE(ctx->host_plan != nullptr, PLSLAM_ENOMEM);
     plslam_match_plan& P = *ctx->host_plan;
+    P.pin_tables = true;
     r = plan_build(ctx, probs.data(), B, &P);
     if (!r) r = plan_run(&P, ctx->stream);
     if (!r) {
         hipError_t e = hipSuccess;
-        if (r1) e = hipMemcpyAsync(matches_12, ctx->out_a.p, (size_t)r1 * 4, hipMemcpyDeviceToHost, ctx->stream);
+        void* dst1 = pinned ? ctx->pin_out.p : (void*)matches_12;
+        void* dst2 = pinned ? (void*)(ctx->pin_out.as<char>() + out2_off) : (void*)n_matches;
+        if (r1) e = hipMemcpyAsync(dst1, ctx->out_a.p, out1, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess && n_matches)
-            e = hipMemcpyAsync(n_matches, ctx->out_b.p, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream);
+            e = hipMemcpyAsync(dst2, ctx->out_b.p, out2, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && pinned) {
+            if (r1) memcpy(matches_12, dst1, out1);
+            if (n_matches) memcpy(n_matches, dst2, out2);
+        }
         if (e != hipSuccess) {
             set_last_error("%s:%d: D2H of match tables -> %s", __FILE__, __LINE__, hipGetErrorString(e));
             r = PLSLAM_EHIP;

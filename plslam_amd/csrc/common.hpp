@@ -42,6 +42,15 @@ struct DevBuf {
     void release();
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
+// pinned host memory (hipHostMalloc), grow-only: staging for the latency path of the host-pointer entry
+// points -- copies from/to pinned memory are plain DMA enqueues, copies from pageable memory are not
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes);
+    void release();
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
 
 }  // namespace plslam
 
@@ -55,6 +64,7 @@ struct plslam_ctx {
     int sym_rows = 0;    // rows of d1 per lane in the symmetric scan: 0 = auto, 1, 4
     std::mutex mu;       // serialises the host-pointer entry points
     plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
+    plslam::HostBuf pin_in, pin_out;                // pinned staging of small host-pointer calls
     struct plslam_match_plan* host_plan = nullptr;  // reused by the host-pointer match entry points
 };
 
