@@ -143,7 +143,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     constexpr int ROWX_STRIDE = 33;               // dwords per row: lane = row reads are conflict-free
     __shared__ __attribute__((aligned(16))) uint8_t smem[4 * 64 * ROWX_STRIDE * 4];
     uint8_t* const btile = smem;
-    __shared__ uint2 colbuf[2][4][MF_TILE_N];                                      //  2 048 B
+    __shared__ uint32_t colbuf[2][4][MF_TILE_N];  // [tile & 1][wave][column] = best | second << 16    1 024 B
     __shared__ uint32_t blut[256];                // byte of a b row -> its 8 s(b) fp4 codes  1 024 B
 
     if (blockIdx.x == 0)
@@ -199,6 +199,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
 
     const bool rows_ragged = iw + 64 > n1;         // wave-uniform: some of this wave's rows do not exist
     const uint32_t ibase = (uint32_t)(iw + 4 * g); // + local index = a-row of an accumulator
+    const uint32_t ghtag = (uint32_t)(4 * g) | ((uint32_t)(4 * g + 32) << 16);   // see finish_columns
     uint2* part = reinterpret_cast<uint2*>(sd.part21) + (size_t)(i0 >> 8) * n2;
 
     // expansion duty of this lane: b row (tid >> 3) of the tile, dword (tid & 7) of it
@@ -219,16 +220,19 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         v.w = (int)blut[raw >> 24];
         *reinterpret_cast<i32x4*>(dst) = v;
     };
-    auto flush_columns = [&](int t) __attribute__((always_inline)) {              // lanes 0..31 of ONE wave: combine the 4 waves' partials of tile t
+    // lanes 0..31 of ONE wave: widen the 4 waves' 16-bit column results of tile t (tag = row within the wave)
+    // to (d << 23 | a-row), combine, and write the workgroup's partial
+    auto flush_columns = [&](int t) __attribute__((always_inline)) {
         if (!DIRECTED && lane < MF_TILE_N) {
-            uint2 k = colbuf[t & 1][0][lane];
+            uint32_t k0 = KEY_NONE, k1 = KEY_NONE;
 #pragma unroll
-            for (int ww = 1; ww < 4; ++ww) {
-                const uint2 o = colbuf[t & 1][ww][lane];
-                merge2(k.x, k.y, o.x, o.y);
+            for (int ww = 0; ww < 4; ++ww) {
+                const uint32_t e = colbuf[t & 1][ww][lane];
+                merge2(k0, k1, key16_to_key32(e & 0xFFFFu, 0u, (uint32_t)(i0 + 64 * ww), 1u),
+                       key16_to_key32(e >> 16, 0u, (uint32_t)(i0 + 64 * ww), 1u));
             }
             const int j = t * MF_TILE_N + lane;
-            if (j < n2) part[j] = k;
+            if (j < n2) part[j] = make_uint2(k0, k1);
         }
     };
 
@@ -260,15 +264,19 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     int wt0v = 0, wt1v = ntiles < 64 ? ntiles : 64;
     uint32_t raw1 = 0u;                                    // raw b dword of tile t+1 of the coming step
     // column best-2 of a finished tile: the two halves of (cb0, cb1) are sorted streams over disjoint rows
-    // of the same column -> 32-bit keys with the a-row, best 2 of the lane, then the other 32 rows (lane ^ 32)
+    // of the same column -> best 2 of the lane, then of the wave (lane ^ 32), as 16-bit keys
     auto finish_columns = [&](int t, uint32_t cb0, uint32_t cb1) __attribute__((always_inline)) {
         if (DIRECTED) return;
-        // low halves: rows ibase + LOC (M-tile 0), high halves: rows ibase + 32 + LOC (M-tile 1)
-        uint32_t k0 = key16_to_key32(cb0 & 0xFFFFu, 0u, ibase, 1u);
-        uint32_t k1 = key16_to_key32(cb1 & 0xFFFFu, 0u, ibase, 1u);
-        merge2(k0, k1, key16_to_key32(cb0 >> 16, 0u, ibase + 32u, 1u), key16_to_key32(cb1 >> 16, 0u, ibase + 32u, 1u));
-        merge2(k0, k1, (uint32_t)__shfl_xor((int)k0, 32), (uint32_t)__shfl_xor((int)k1, 32));
-        if (lane < MF_TILE_N) colbuf[t & 1][w][lane] = make_uint2(k0, k1);
+        // Stay in the 16-bit domain: the tag of a column key is LOC (bits 0,1,3,4 of the row within the wave);
+        // OR-ing in bit 2 (= g) and bit 5 (= M-tile, the high halves) makes it the full row within the wave,
+        // so keys of the two halves and of lane ^ 32 compare directly (0xFFFF stays 0xFFFF).
+        cb0 |= ghtag;
+        cb1 |= ghtag;
+        const uint32_t e0 = cb0 & 0xFFFFu, o0 = cb0 >> 16, e1 = cb1 & 0xFFFFu, o1 = cb1 >> 16;
+        uint32_t m0 = umin_(e0, o0), m1 = umin_(umax_(e0, o0), umin_(e1, o1));
+        const uint32_t other = (uint32_t)__shfl_xor((int)(m0 | (m1 << 16)), 32);
+        merge2(m0, m1, other & 0xFFFFu, other >> 16);
+        if (lane < MF_TILE_N) colbuf[t & 1][w][lane] = m0 | (m1 << 16);
     };
     // E(t) on its own (the last tile has no following M step to hide under)
     auto epilogue = [&](int t, const f32x16& acc0, const f32x16& acc1, auto masked_tag) __attribute__((always_inline)) {
