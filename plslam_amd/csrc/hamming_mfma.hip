@@ -24,11 +24,12 @@
 // conflict-free.  Only the lane->k mapping shared by the A and the B operand matters for a
 // contraction over all k, so no assumption about the instruction's internal k order is made.
 // C/D layout (dtype-independent): col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
-//   row direction : lane keeps best-2 per (M-tile, reg) over the columns it sees (j = lane & 31 mod 32);
-//                   one 5-step butterfly at the end of the scan completes them.
-//   column direction: best-2 over the lane's 32 accumulators (local row index as an inline constant),
-//                   halves combined by one cross-lane step, the four waves through LDS, one partial
-//                   per 256 rows of `a`, as K1b'.
+//   row direction : lane keeps best-2 per (M-tile, reg) over the columns it sees (j = lane & 31 mod 32) as
+//                   packed 16-bit keys (d << 7 | tile + LOC); per window of 64 tiles the 32 column classes of
+//                   a row are combined through an LDS transpose (one lane per row) and merged into keys12.
+//   column direction: best-2 over the lane's 32 accumulators (the key comes out of the MFMA: tag = local
+//                   row), halves and lane ^ 32 combined in the 16-bit domain, the four waves through LDS,
+//                   one partial per 256 rows of `a`, as K1b'.  Not built in the DIRECTED instantiation.
 #include "common.hpp"
 
 #include <type_traits>
