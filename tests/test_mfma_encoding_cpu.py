@@ -1,0 +1,75 @@
+"""CPU check of the arithmetic behind K1e (plslam_amd/csrc/hamming_mfma.hip): the Hamming distance as a
+contraction over fp4 (e2m1) codes of +-1 with fp32 accumulation started at 2^23 + 16384 + tag.  The test
+emulates the operand expansion, the block scale and the accumulation in float32 -- in several summation
+orders, since the instruction's internal order is not specified -- and checks that the low 16 bits of the
+resulting float are exactly (d << 7 | tag).  (The kernel itself is tested bit-exact on the GPU.)"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from plslam_amd import synth
+
+E2M1 = {0x2: 1.0, 0xA: -1.0}          # the only two codes the kernel produces
+
+
+def expand_byte_fp4(byte):
+    """hamming_mfma.hip::expand_byte_fp4: bit k -> nibble k = 0x2 | (bit << 3)."""
+    x = (byte | (byte << 12)) & 0x000F000F
+    x = (x | (x << 6)) & 0x03030303
+    x = (x | (x << 3)) & 0x11111111
+    return ((x << 3) | 0x22222222) & 0xFFFFFFFF
+
+
+def values_of_row(row_u8, a_side):
+    out = []
+    for byte in row_u8:
+        w = expand_byte_fp4(int(byte))
+        if a_side:
+            w ^= 0x88888888           # -s(a)
+        out += [E2M1[(w >> (4 * k)) & 0xF] for k in range(8)]
+    return np.array(out, np.float32)
+
+
+def test_expansion_table():
+    for byte in range(256):
+        w = expand_byte_fp4(byte)
+        for k in range(8):
+            assert (w >> (4 * k)) & 0xF == (0xA if (byte >> k) & 1 else 0x2)
+
+
+@pytest.mark.parametrize("order", ["forward", "reverse", "pairwise", "random"])
+def test_accumulation_is_exact_in_fp32(order):
+    r = np.random.Generator(np.random.PCG64(11))
+    a = synth.random_desc(r, 10)
+    b = np.concatenate([synth.random_desc(r, 8), a[:2], ~a[2:4]])       # incl. distance 0 and 256
+    va = [values_of_row(x, True) * np.float32(64.0) for x in a]          # block scale 2^6 on the a side
+    vb = [values_of_row(x, False) for x in b]
+    for tag in (0, 27, 90, 127):
+        for i in range(a.shape[0]):
+            for j in range(b.shape[0]):
+                prod = (va[i] * vb[j]).astype(np.float32)                # +-64 exactly
+                acc = np.float32(8388608.0 + 16384.0 + tag)
+                if order == "pairwise":                                  # tree sum of each K = 64 block, chained
+                    for blk in range(4):
+                        p = prod[64 * blk:64 * blk + 64].copy()
+                        while p.size > 1:
+                            p = (p[0::2] + p[1::2]).astype(np.float32)
+                        acc = np.float32(acc + p[0])
+                else:
+                    idx = {"forward": np.arange(256), "reverse": np.arange(255, -1, -1),
+                           "random": r.permutation(256)}[order]
+                    for k in idx:
+                        acc = np.float32(acc + prod[k])
+                        assert abs(float(acc)) < 2 ** 24
+                d = O.hamming256(a[i], b[j])
+                bits = int(np.array([acc], np.float32).view(np.uint32)[0])
+                assert bits == 0x4B000000 + 128 * d + tag                # 2^23 + 128 d + tag
+                assert ((bits & 0xFFFF) >> 7) == d and (bits & 0x7F) == tag
+
+
+def test_key_orders_like_distance_then_index():
+    """(d << 7 | tile + LOC) within one row state: LOC is constant, so keys order like (d, tile)."""
+    loc = 27
+    keys = [((d << 7) | (t + loc), d, t) for d in (0, 1, 128, 256) for t in (0, 1, 63)]
+    assert [k[1:] for k in sorted(keys)] == sorted(k[1:] for k in keys)
+    assert max(k[0] for k in keys) <= 0x807F
