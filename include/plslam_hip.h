@@ -163,6 +163,76 @@ int plslam_match_plan_elapsed(plslam_match_plan* plan, double* scan_ms, double* 
 int plslam_match_plan_info(plslam_match_plan* plan, plslam_plan_info* info);
 void plslam_match_plan_destroy(plslam_match_plan* plan);
 
+/* ---- K14: StVO::matchGrid, the windowed ("fast_matching") matcher ------------------------------ */
+/* Replaces  int StVO::matchGrid(const std::vector<point_2d>& points1, const cv::Mat& desc1,
+ *                               const GridStructure& grid, const cv::Mat& desc2, const GridWindow& w,
+ *                               std::vector<int>& matches_12)                       (points) and
+ *           int StVO::matchGrid(const std::vector<line_2d>& lines1, const cv::Mat& desc1,
+ *                               const GridStructure& grid, const cv::Mat& desc2,
+ *                               const std::vector<std::pair<double,double>>& directions2,
+ *                               const GridWindow& w, std::vector<int>& matches_12)  (lines)
+ * of stvo-pl matching.h (un-vendored, [RECALL]); call sites src/mapHandler.cpp:271 (KF<->KF points), :418
+ * (KF<->KF lines), :591 (map points <-> KF), :706 (map lines <-> KF).  This is the matcher the shipped
+ * configurations use first (fast_matching: true); the callers fall back to StVO::match when it finds fewer than
+ * min_*_matches (:274-278, :421-426, :594-598, :709-713).
+ *   centres1   n1 x n_centres x 2 int32: the grid cells (x, y) whose windows supply row i1's candidates --
+ *              n_centres = 1: points1[i1] (a point_2d = pair<int,int>); n_centres = 2: start and end point of
+ *              lines1[i1].  Any int32 value is legal (GridStructure::get clamps the window to the grid).
+ *   grid       the GridStructure the caller filled (:258-264, :395-411) in CSR form: cell (x, y), 0 <= x <
+ *              grid_cols, 0 <= y < grid_rows, has id x*grid_rows + y and owns cell_items[cell_start[id] ..
+ *              cell_start[id+1]-1]; items outside [0, n2) are ignored as upstream does.  GRID_COLS x GRID_ROWS
+ *              is 64 x 48 upstream.
+ *   window     {width.first, width.second, height.first, height.second} of the GridWindow (>= 0): cells
+ *              x - window[0] .. x + window[1], y - window[2] .. y + window[3].
+ *   dir1/dir2  line overload only (else NULL): unit directions of the query lines (what upstream computes from
+ *              lines1[i1] with normalize()) and `directions2`; a candidate is skipped when |dot| < sim_th
+ *              (Config::lineSimTh()).  A NaN direction (zero-length segment) never skips, as upstream.
+ *   nnr        Config::minRatio12P(), used by BOTH overloads upstream; the test is `best_d < best_d2 * nnr` in
+ *              fp64 with best_d2 = INT_MAX when there is no second candidate (a lone candidate is accepted).
+ *   mutual     Config::bestLRMatches(): upstream's sequential `if (d < distances[i2]) {...} else continue;`
+ *              (a candidate only counts for row i1 if it strictly beats every EARLIER row's distance to the
+ *              same i2) followed by the matches_21[i2] == i1 check; reproduced exactly, order-free.
+ *   matches_12 n1 entries (i2 or -1); *n_matches (may be NULL) the return value.
+ * One deliberate definition: among several candidates at the same best distance upstream keeps the one its
+ * std::unordered_set<int> happens to visit first (implementation-defined); here the lowest i2 wins, the
+ * brute-force matcher's rule.  Limits: n1 < 2^22, n2 <= PLSLAM_MAX_TRAIN_ROWS. */
+#define PLSLAM_MAX_GRID_ROWS (1 << 22)
+int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centres, const uint8_t* d1,
+                      int32_t n1, const int32_t* cell_start, const int32_t* cell_items, int32_t grid_cols,
+                      int32_t grid_rows, const uint8_t* d2, int32_t n2, const double* dir1,
+                      const double* dir2, double sim_th, const int32_t window[4], double nnr, int mutual,
+                      int32_t* matches_12, int32_t* n_matches);
+
+/* Device-resident form: a batch of matchGrid problems in ONE kernel launch (one workgroup per problem).
+ * Every pointer of a problem is a DEVICE pointer.  pair_capacity bounds the number of (row, candidate)
+ * pairs of the problem, duplicates included (sum over rows and centres of the window's item count); a
+ * problem that exceeds it matches nothing, gets n_matches = -1 and is counted by plslam_grid_plan_overflows. */
+typedef struct plslam_grid_problem {
+    const uint8_t* d1;
+    const uint8_t* d2;
+    const int32_t* centres1;
+    const int32_t* cell_start;
+    const int32_t* cell_items;
+    const double* dir1;
+    const double* dir2;
+    int32_t n1, n2, n_centres, grid_cols, grid_rows;
+    int32_t window[4];
+    double sim_th, nnr;
+    int32_t mutual;
+    int32_t pair_capacity;
+    int32_t* matches_12;
+    int32_t* n_matches; /* device pointer to one int32, or NULL */
+} plslam_grid_problem;
+typedef struct plslam_grid_plan plslam_grid_plan;
+/* uploads the problem table and allocates the scratch (column lists, keys); runs no kernel */
+int plslam_grid_plan_create(plslam_ctx* ctx, const plslam_grid_problem* probs, int32_t nprob,
+                            plslam_grid_plan** out);
+/* enqueues the kernel on `stream` (hipStream_t; NULL = the context's stream); asynchronous */
+int plslam_grid_plan_run(plslam_grid_plan* plan, void* stream);
+/* synchronises `stream` and returns the number of pair-list overflows since the last call */
+int plslam_grid_plan_overflows(plslam_grid_plan* plan, void* stream, int32_t* n_overflows);
+void plslam_grid_plan_destroy(plslam_grid_plan* plan);
+
 /* ---- K3/K4: local-BA residual + Jacobian rows ------------------------------------------- */
 /* Point rows: the per-observation body of MapHandler::levMarquardtOptimizationLBA,
  * src/mapHandler.cpp:1358-1407 (first pass) == :1587-1642 (iteration pass; the caller

@@ -86,6 +86,16 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.plo_lbd_binarise.restype = None
     lib.plo_lbd_binary_conversion.argtypes = [C.c_void_p, C.c_void_p]
     lib.plo_lbd_binary_conversion.restype = C.c_uint8
+    lib.plo_match_grid.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                   C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
+                                   C.c_void_p, C.c_double, C.c_int, C.c_void_p]
+    lib.plo_match_grid.restype = C.c_int32
+    lib.plo_grid_fill_points.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.plo_grid_fill_points.restype = None
+    lib.plo_get_line_coords.argtypes = [C.c_double] * 4 + [C.c_void_p, C.c_int32]
+    lib.plo_get_line_coords.restype = C.c_int32
+    lib.plo_normalize2.argtypes = [C.c_void_p]
+    lib.plo_normalize2.restype = None
     return lib
 
 
@@ -352,6 +362,119 @@ def np_lbd_binarise(lbd_f32):
     bits = f[:, pr[:, 0], :] > f[:, pr[:, 1], :]                 # n x 32 x 8, bit i = element i
     return np.packbits(bits, axis=2, bitorder="little").reshape(-1, 32)
 
+
+
+# ------------------------------------------------------------------------------------------
+# matchGrid (stvo-pl matching.cpp, [RECALL]; call sites src/mapHandler.cpp:271,418,591,706)
+# ------------------------------------------------------------------------------------------
+def grid_fill_points(xy, cols, rows):
+    """grid.at(x, y).push_back(idx) for idx ascending (src/mapHandler.cpp:258-264) -> CSR (cell_start, cell_items)."""
+    xy = _c(xy, np.int32).reshape(-1, 2)
+    cs = np.empty(cols * rows + 1, np.int32)
+    items = np.empty(max(xy.shape[0], 1), np.int32)
+    lib().plo_grid_fill_points(_p(xy), xy.shape[0], cols, rows, _p(cs), _p(items))
+    return cs, items[:cs[-1]].copy()
+
+
+def get_line_coords(x1, y1, x2, y2):
+    n = lib().plo_get_line_coords(float(x1), float(y1), float(x2), float(y2), None, 0)
+    out = np.empty((max(n, 1), 2), np.int32)
+    lib().plo_get_line_coords(float(x1), float(y1), float(x2), float(y2), _p(out), n)
+    return out[:n]
+
+
+def grid_fill_lines(seg, cols, rows):
+    """Callers' line grid (src/mapHandler.cpp:395-411): every Bresenham cell of segment idx gets idx, idx ascending.
+    seg: n x 4 real-valued (x1, y1, x2, y2) in grid units.  -> CSR (cell_start, cell_items)."""
+    seg = _c(seg, np.float64).reshape(-1, 4)
+    cells = [[] for _ in range(cols * rows)]
+    for idx, (x1, y1, x2, y2) in enumerate(seg):
+        for x, y in get_line_coords(x1, y1, x2, y2):
+            if 0 <= x < cols and 0 <= y < rows:
+                cells[int(x) * rows + int(y)].append(idx)
+    cs = np.zeros(cols * rows + 1, np.int32)
+    cs[1:] = np.cumsum([len(c) for c in cells])
+    items = np.array([i for c in cells for i in c], np.int32)
+    return cs, items
+
+
+def normalize2(v):
+    v = _c(v, np.float64).reshape(-1, 2).copy()
+    for row in v:
+        lib().plo_normalize2(_p(row))
+    return v
+
+
+def match_grid(centres, d1, cell_start, cell_items, cols, rows, d2, window, nnr, mutual=True, dir1=None, dir2=None,
+               sim_th=0.0):
+    d1, d2 = _desc(d1), _desc(d2)
+    n1 = d1.shape[0]
+    centres = _c(centres, np.int32).reshape(n1, -1, 2) if n1 else np.zeros((0, 1, 2), np.int32)
+    cs, items = _c(cell_start, np.int32), _c(cell_items, np.int32)
+    w = _c(window, np.int32)
+    a = _c(dir1, np.float64) if dir1 is not None else None
+    b = _c(dir2, np.float64) if dir2 is not None else None
+    m12 = np.empty(n1, np.int32)
+    n = lib().plo_match_grid(_p(centres), centres.shape[1], _p(d1), n1, _p(cs), _p(items), cols, rows, _p(d2),
+                             d2.shape[0], _p(a) if a is not None else None, _p(b) if b is not None else None,
+                             float(sim_th), _p(w), float(nnr), int(bool(mutual)), _p(m12))
+    return m12, int(n)
+
+
+def np_match_grid(centres, d1, cell_start, cell_items, cols, rows, d2, window, nnr, mutual=True, dir1=None,
+                  dir2=None, sim_th=0.0):
+    """Independent formulation of matchGrid -- the order-free one the device uses.  The sequential
+    `if (d < distances[i2]) ... else continue` of upstream makes candidate (i1, i2) take part in row i1's
+    best/second-best iff d(i1,i2) is a strict prefix minimum of column i2 in row order, i.e. iff
+        i1 == min{ i1' : i2 in C(i1'), d(i1', i2) <= d(i1, i2) };
+    matches_21[i2] is the lexicographic minimum (d, i1) of the column."""
+    d1, d2 = _desc(d1), _desc(d2)
+    n1, n2 = d1.shape[0], d2.shape[0]
+    centres = _c(centres, np.int32).reshape(n1, -1, 2) if n1 else np.zeros((0, 1, 2), np.int32)
+    cs, items = _c(cell_start, np.int32), _c(cell_items, np.int32)
+    w = [int(v) for v in window]
+    pairs = set()
+    for i1 in range(n1):
+        for x, y in centres[i1]:
+            x, y = int(x), int(y)
+            for x_ in range(max(0, x - w[0]), min(cols, x + w[1] + 1)):
+                lo, hi = max(0, y - w[2]), min(rows, y + w[3] + 1)
+                if lo < hi:
+                    for i2 in items[cs[x_ * rows + lo]:cs[x_ * rows + hi]]:
+                        if 0 <= i2 < n2:
+                            pairs.add((i1, int(i2)))
+    if not pairs:
+        return np.full(n1, -1, np.int32), 0
+    P = np.array(sorted(pairs), np.int64)
+    if dir1 is not None and dir2 is not None:
+        a, b = _c(dir1, np.float64).reshape(-1, 2), _c(dir2, np.float64).reshape(-1, 2)
+        dot = a[P[:, 0], 0] * b[P[:, 1], 0] + a[P[:, 0], 1] * b[P[:, 1], 1]
+        P = P[~(np.abs(dot) < sim_th)]
+    D = np.bitwise_count(d1[P[:, 0]] ^ d2[P[:, 1]]).sum(axis=1).astype(np.int64)
+    live = np.ones(len(P), bool)
+    m21 = np.full(n2, -1, np.int64)
+    if mutual:
+        for i2 in np.unique(P[:, 1]):
+            sel = np.nonzero(P[:, 1] == i2)[0]
+            i1s, ds = P[sel, 0], D[sel]
+            first = np.array([i1s[ds <= d].min() for d in ds])
+            live[sel] = first == i1s
+            m21[i2] = i1s[np.lexsort((i1s, ds))[0]]
+    m12 = np.full(n1, -1, np.int32)
+    imax = np.iinfo(np.int32).max
+    for i1 in np.unique(P[:, 0]):
+        sel = np.nonzero((P[:, 0] == i1) & live)[0]
+        if not len(sel):
+            continue
+        order = np.lexsort((P[sel, 1], D[sel]))
+        best_d, best_idx = D[sel][order[0]], P[sel, 1][order[0]]
+        best_d2 = D[sel][order[1]] if len(sel) > 1 else imax
+        if float(best_d) < float(best_d2) * float(nnr):
+            m12[i1] = best_idx
+    if mutual:
+        good = m12 >= 0
+        m12 = np.where(good & (m21[np.clip(m12, 0, None)] == np.arange(n1)), m12, -1).astype(np.int32)
+    return m12, int((m12 >= 0).sum())
 
 # ------------------------------------------------------------------------------------------
 # independent numpy mirror (different formulation: full distance matrix + stable sort)

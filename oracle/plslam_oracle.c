@@ -650,6 +650,157 @@ int32_t plo_map2kf_match_lines(const plo_cam* K, const double Twf[16], const dou
                          mutual, max_epip, min_matches, map_to_kf);
 }
 
+/* ------------------------------------------------------------------------------------ */
+/* stvo-pl matchGrid (matching.cpp) + GridStructure (gridStructure.cpp) -- [RECALL]       */
+/* call sites: src/mapHandler.cpp:271, :418, :591, :706                                   */
+/* ------------------------------------------------------------------------------------ */
+static void grid_get(int32_t x, int32_t y, const int32_t w[4], const int32_t* cell_start,
+                     const int32_t* cell_items, int32_t cols, int32_t rows, int32_t** cand, size_t* n,
+                     size_t* cap)
+{
+    /* GridStructure::get(x, y, w, indices) */
+    const int64_t min_x = (int64_t)x - w[0] > 0 ? (int64_t)x - w[0] : 0;
+    const int64_t max_x = (int64_t)x + w[1] + 1 < cols ? (int64_t)x + w[1] + 1 : cols;
+    const int64_t min_y = (int64_t)y - w[2] > 0 ? (int64_t)y - w[2] : 0;
+    const int64_t max_y = (int64_t)y + w[3] + 1 < rows ? (int64_t)y + w[3] + 1 : rows;
+    for (int64_t x_ = min_x; x_ < max_x; ++x_)
+        for (int64_t y_ = min_y; y_ < max_y; ++y_) {
+            const int64_t id = x_ * rows + y_;
+            for (int32_t k = cell_start[id]; k < cell_start[id + 1]; ++k) {
+                if (*n == *cap) {
+                    *cap = *cap ? *cap * 2 : 64;
+                    *cand = (int32_t*)realloc(*cand, *cap * sizeof(int32_t));
+                }
+                (*cand)[(*n)++] = cell_items[k];
+            }
+        }
+}
+
+int32_t plo_match_grid(const int32_t* centres, int32_t n_centres, const uint8_t* d1, int32_t n1,
+                       const int32_t* cell_start, const int32_t* cell_items, int32_t cols, int32_t rows,
+                       const uint8_t* d2, int32_t n2, const double* dir1, const double* dir2,
+                       double sim_th, const int32_t w[4], double nnr, int mutual, int32_t* m12)
+{
+    int32_t matches = 0;
+    for (int32_t i = 0; i < n1; ++i) m12[i] = -1;                 /* matches_12.resize(desc1.rows, -1) */
+    int32_t* m21 = NULL;
+    int* distances = NULL;
+    if (mutual) {
+        m21 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
+        distances = (int*)malloc(sizeof(int) * (size_t)(n2 > 0 ? n2 : 1));
+        for (int32_t j = 0; j < n2; ++j) { m21[j] = -1; distances[j] = INT_MAX; }
+    }
+    int32_t* cand = NULL;
+    size_t cap = 0;
+    for (int32_t i1 = 0; i1 < n1; ++i1) {
+        int best_d = INT_MAX, best_d2 = INT_MAX;
+        int32_t best_idx = -1;
+        size_t nc = 0;
+        for (int32_t c = 0; c < n_centres; ++c) {
+            const int32_t* p = centres + ((size_t)i1 * (size_t)n_centres + (size_t)c) * 2;
+            grid_get(p[0], p[1], w, cell_start, cell_items, cols, rows, &cand, &nc, &cap);
+        }
+        if (nc == 0) continue;                                      /* candidates.empty() */
+        /* the unordered_set: unique values; visiting order defined here as ascending */
+        qsort(cand, nc, sizeof(int32_t), cmp_int);
+        size_t nu = 0;
+        for (size_t k = 0; k < nc; ++k)
+            if (nu == 0 || cand[nu - 1] != cand[k]) cand[nu++] = cand[k];
+        for (size_t k = 0; k < nu; ++k) {
+            const int32_t i2 = cand[k];
+            if (i2 < 0 || i2 >= n2) continue;
+            if (dir1 && dir2) {
+                const double dot = dir1[2 * i1] * dir2[2 * i2] + dir1[2 * i1 + 1] * dir2[2 * i2 + 1];
+                if (fabs(dot) < sim_th) continue;
+            }
+            const int d = plo_hamming256(d1 + (size_t)i1 * PLO_DESC_BYTES, d2 + (size_t)i2 * PLO_DESC_BYTES);
+            if (mutual) {
+                if (d < distances[i2]) {
+                    distances[i2] = d;
+                    m21[i2] = i1;
+                } else
+                    continue;
+            }
+            if (d < best_d) {
+                best_d2 = best_d;
+                best_d = d;
+                best_idx = i2;
+            } else if (d < best_d2)
+                best_d2 = d;
+        }
+        if ((double)best_d < (double)best_d2 * nnr) {
+            m12[i1] = best_idx;
+            ++matches;
+        }
+    }
+    if (mutual) {
+        for (int32_t i1 = 0; i1 < n1; ++i1) {
+            const int32_t i2 = m12[i1];
+            if (i2 >= 0 && m21[i2] != i1) {
+                m12[i1] = -1;
+                --matches;
+            }
+        }
+    }
+    free(cand); free(distances); free(m21);
+    return matches;
+}
+
+void plo_grid_fill_points(const int32_t* xy, int32_t n, int32_t cols, int32_t rows, int32_t* cell_start,
+                          int32_t* cell_items)
+{
+    const int64_t ncell = (int64_t)cols * rows;
+    for (int64_t c = 0; c <= ncell; ++c) cell_start[c] = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        const int32_t x = xy[2 * i], y = xy[2 * i + 1];
+        if (x >= 0 && x < cols && y >= 0 && y < rows) ++cell_start[(int64_t)x * rows + y + 1];
+    }
+    for (int64_t c = 0; c < ncell; ++c) cell_start[c + 1] += cell_start[c];
+    int32_t* fill = (int32_t*)malloc(sizeof(int32_t) * (size_t)(ncell > 0 ? ncell : 1));
+    for (int64_t c = 0; c < ncell; ++c) fill[c] = cell_start[c];
+    for (int32_t i = 0; i < n; ++i) {                               /* push_back order = ascending idx */
+        const int32_t x = xy[2 * i], y = xy[2 * i + 1];
+        if (x >= 0 && x < cols && y >= 0 && y < rows) cell_items[fill[(int64_t)x * rows + y]++] = i;
+    }
+    free(fill);
+}
+
+int32_t plo_get_line_coords(double x1, double y1, double x2, double y2, int32_t* out_xy, int32_t cap)
+{
+    /* Bresenham as in stvo-pl gridStructure.cpp::getLineCoords */
+    const int steep = fabs(y2 - y1) > fabs(x2 - x1);
+    double t;
+    if (steep) { t = x1; x1 = y1; y1 = t; t = x2; x2 = y2; y2 = t; }
+    if (x1 > x2) { t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; }
+    const double dx = x2 - x1;
+    const double dy = fabs(y2 - y1);
+    double error = dx / 2.0;
+    const int ystep = (y1 < y2) ? 1 : -1;
+    int y = (int)y1;
+    const int maxX = (int)x2;
+    int32_t n = 0;
+    for (int x = (int)x1; x < maxX; x++) {
+        if (n < cap) {
+            out_xy[2 * n] = steep ? y : x;
+            out_xy[2 * n + 1] = steep ? x : y;
+        }
+        ++n;
+        error -= dy;
+        if (error < 0) {
+            y += ystep;
+            error += dx;
+        }
+    }
+    return n;
+}
+
+void plo_normalize2(double v[2])
+{
+    const double magnitude = sqrt(v[0] * v[0] + v[1] * v[1]);
+    v[0] /= magnitude;
+    v[1] /= magnitude;
+}
+
 /* ---- LBD float -> binary line descriptor -------------------------------------------------- */
 /* binary_descriptor_custom.cpp:74-107 -- band index pairs of the 32 output bytes */
 const int plo_lbd_pairs[32][2] = {

@@ -148,6 +148,49 @@ int32_t plo_map2kf_match_lines(const plo_cam* K, const double Twf[16], const dou
                                int32_t n_kf, float nnr, int mutual, double max_epip,
                                int32_t min_matches, int32_t* map_to_kf);
 
+/* ---- stvo-pl matchGrid: the windowed ("fast_matching") matcher ------------------------------
+ * Call sites in the reference: src/mapHandler.cpp:271 (points, KF<->KF), :418 (lines), :591 (map points
+ * <-> KF), :706 (map lines <-> KF); the grid is filled by the callers at :258-264, :395-411, :580-584,
+ * :683-699 and the window comes from SlamConfig::matchingF2FWs() (:266-269).  The function itself lives
+ * in the un-vendored stvo-pl (matching.cpp, gridStructure.cpp; no pinned version) => [RECALL], parity
+ * UNPINNED.  Restated literally from the published source:
+ *   for i1 = 0 .. n1-1 (in order):
+ *     candidates = set union over the query's window centres c of grid.get(c.x, c.y, w)
+ *         get(): x_ in [max(0, x - w.width.first), min(cols, x + w.width.second + 1)),
+ *                y_ in [max(0, y - w.height.first), min(rows, y + w.height.second + 1)): all of grid[x_][y_]
+ *     for i2 in candidates:   skip if i2 < 0 || i2 >= n2
+ *         lines only: skip if |dot(dir1[i1], dir2[i2])| < sim_th          (Config::lineSimTh())
+ *         d = hamming(desc1[i1], desc2[i2])
+ *         if mutual (Config::bestLRMatches()):  if d < distances[i2] { distances[i2] = d; matches_21[i2] = i1 }
+ *                                               else skip this candidate
+ *         if d < best_d { best_d2 = best_d; best_d = d; best_idx = i2 } else if d < best_d2 { best_d2 = d }
+ *     if best_d < best_d2 * nnr (int * double, best_d2 = INT_MAX when absent): matches_12[i1] = best_idx
+ *   if mutual: drop i1 -> i2 when matches_21[i2] != i1.
+ * Points have one centre (points1[i1], a point_2d = pair<int,int>), lines two (start and end point of
+ * lines1[i1]).  Upstream iterates a std::unordered_set<int>: the visiting order -- and with it WHICH of
+ * several equally distant best candidates becomes best_idx -- is implementation-defined.  This
+ * restatement (and the device path) visits candidates in ascending index order: lowest i2 wins a tie,
+ * the same rule as the brute-force matcher.  Nothing else depends on the order.
+ * Grid in CSR form: cell (x, y), 0 <= x < cols, 0 <= y < rows, has id x*rows + y and owns
+ * cell_items[cell_start[id] .. cell_start[id+1]-1] (the list's push_back order).
+ * centres: n1 * n_centres * 2 int32 (x, y).  dir1 (n1*2) / dir2 (n2*2) may be NULL (points).
+ * w = {width.first, width.second, height.first, height.second}.  Returns #matches. */
+int32_t plo_match_grid(const int32_t* centres, int32_t n_centres, const uint8_t* d1, int32_t n1,
+                       const int32_t* cell_start, const int32_t* cell_items, int32_t cols, int32_t rows,
+                       const uint8_t* d2, int32_t n2, const double* dir1, const double* dir2,
+                       double sim_th, const int32_t w[4], double nnr, int mutual, int32_t* m12);
+/* GridStructure fill as the reference's callers do it: grid.at(x, y).push_back(idx) for idx ascending;
+ * at() with an out-of-range cell appends to a dummy list (the item is never returned by get()).
+ * xy: n*2 int32 cells.  cell_start: cols*rows+1, cell_items: n (entries past cell_start[cols*rows] unused). */
+void plo_grid_fill_points(const int32_t* xy, int32_t n, int32_t cols, int32_t rows, int32_t* cell_start,
+                          int32_t* cell_items);
+/* getLineCoords (stvo-pl gridStructure.cpp, [RECALL]): Bresenham cells of the segment (x1,y1)-(x2,y2) given
+ * in (real-valued) grid units; writes up to `cap` (x, y) pairs, returns the number of cells. */
+int32_t plo_get_line_coords(double x1, double y1, double x2, double y2, int32_t* out_xy, int32_t cap);
+/* normalize(std::pair<double,double>&) of stvo-pl ([RECALL]): v /= sqrt(v.v); a zero vector becomes NaN,
+ * and |dot| < th is then false, i.e. the direction test passes. */
+void plo_normalize2(double v[2]);
+
 /* ---- LBD float -> binary line descriptor ---------------------------------------------------
  * 3rdparty/line_descriptor/src/binary_descriptor_custom.cpp: the 32 band pairs of
  * combinations[32][2] (:74-107), binaryConversion (:401-412; bit i set iff f1[i] > f2[i]) and the

@@ -34,6 +34,8 @@ ABI_SYMBOLS = (
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
     "plslam_lbd_binarise", "plslam_lbd_binarise_dev",
     "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
+    "plslam_match_grid", "plslam_grid_plan_create", "plslam_grid_plan_run", "plslam_grid_plan_overflows",
+    "plslam_grid_plan_destroy",
     "plslam_gather_match_tables",
 )
 
@@ -48,6 +50,16 @@ class MatchProblem(C.Structure):
     """plslam_match_problem (device pointers)"""
     _fields_ = [("d1", C.c_void_p), ("d2", C.c_void_p), ("n1", C.c_int32), ("n2", C.c_int32),
                 ("nnr", C.c_float), ("mutual", C.c_int32), ("matches_12", C.c_void_p),
+                ("n_matches", C.c_void_p)]
+
+
+class GridProblem(C.Structure):
+    """plslam_grid_problem (device pointers)"""
+    _fields_ = [("d1", C.c_void_p), ("d2", C.c_void_p), ("centres1", C.c_void_p), ("cell_start", C.c_void_p),
+                ("cell_items", C.c_void_p), ("dir1", C.c_void_p), ("dir2", C.c_void_p),
+                ("n1", C.c_int32), ("n2", C.c_int32), ("n_centres", C.c_int32), ("grid_cols", C.c_int32),
+                ("grid_rows", C.c_int32), ("window", C.c_int32 * 4), ("sim_th", C.c_double), ("nnr", C.c_double),
+                ("mutual", C.c_int32), ("pair_capacity", C.c_int32), ("matches_12", C.c_void_p),
                 ("n_matches", C.c_void_p)]
 
 
@@ -150,11 +162,18 @@ def load() -> C.CDLL:
     for f in (L.plslam_map2kf_match_points, L.plslam_map2kf_match_lines):
         f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_float, C.c_int, f64, i32, vp,
                       C.POINTER(i32)]
+    L.plslam_match_grid.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, vp, vp, f64, vp, f64, C.c_int, vp,
+                                    C.POINTER(i32)]
+    L.plslam_grid_plan_create.argtypes = [vp, C.POINTER(GridProblem), i32, C.POINTER(vp)]
+    L.plslam_grid_plan_run.argtypes = [vp, vp]
+    L.plslam_grid_plan_overflows.argtypes = [vp, vp, C.POINTER(i32)]
+    L.plslam_grid_plan_destroy.argtypes = [vp]
+    L.plslam_grid_plan_destroy.restype = None
     L.plslam_gather_match_tables.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if name not in ("plslam_strerror", "plslam_last_error", "plslam_ctx_destroy",
-                        "plslam_match_plan_destroy", "plslam_lba_plan_destroy"):
+                        "plslam_match_plan_destroy", "plslam_lba_plan_destroy", "plslam_grid_plan_destroy"):
             f.restype = C.c_int
     _lib = L
     return L
@@ -248,6 +267,25 @@ class Context:
         n = C.c_int32()
         _check(self._L.plslam_match(self._h, _p(d1), d1.shape[0], _p(d2), d2.shape[0], float(nnr),
                                     int(bool(mutual)), _p(m12), C.byref(n)), "plslam_match")
+        return m12, n.value
+
+    def match_grid(self, centres, d1, cell_start, cell_items, cols, rows, d2, window, nnr, mutual=True, dir1=None,
+                   dir2=None, sim_th=0.0):
+        """StVO::matchGrid (points: one window centre per row; lines: two + directions) -> (matches_12, n)."""
+        d1 = _arr(d1, np.uint8, (-1, 32))
+        d2 = _arr(d2, np.uint8, (-1, 32))
+        n1 = d1.shape[0]
+        cen = _arr(centres, np.int32).reshape(n1, -1, 2) if n1 else np.zeros((0, 1, 2), np.int32)
+        cs, items = _arr(cell_start, np.int32), _arr(cell_items, np.int32)
+        w = _arr(window, np.int32, (4,))
+        a = _arr(dir1, np.float64, (-1, 2)) if dir1 is not None else None
+        b = _arr(dir2, np.float64, (-1, 2)) if dir2 is not None else None
+        m12 = np.empty(n1, np.int32)
+        n = C.c_int32()
+        _check(self._L.plslam_match_grid(self._h, _p(cen), cen.shape[1], _p(d1), n1, _p(cs), _p(items), int(cols),
+                                         int(rows), _p(d2), d2.shape[0], _p(a) if a is not None else None,
+                                         _p(b) if b is not None else None, float(sim_th), _p(w), float(nnr),
+                                         int(bool(mutual)), _p(m12), C.byref(n)), "plslam_match_grid")
         return m12, n.value
 
     def match_batched(self, d1, off1, d2, off2, nnr: float, mutual: bool = True):
@@ -498,6 +536,50 @@ class MatchPlan:
     def close(self):
         if getattr(self, "_h", None):
             self._L.plslam_match_plan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class GridPlan:
+    """plslam_grid_plan over device pointers: a batch of StVO::matchGrid problems, one kernel launch.
+
+    problems: iterable of dicts with the fields of plslam_grid_problem (pointers as ints; window a 4-sequence).
+    """
+
+    def __init__(self, ctx: Context, problems):
+        self._ctx = ctx
+        self._L = ctx._L
+        problems = list(problems)
+        arr = (GridProblem * max(len(problems), 1))()
+        for i, q in enumerate(problems):
+            g = GridProblem()
+            for k in ("d1", "d2", "centres1", "cell_start", "cell_items", "dir1", "dir2", "matches_12", "n_matches"):
+                setattr(g, k, q.get(k) or None)
+            for k in ("n1", "n2", "n_centres", "grid_cols", "grid_rows", "pair_capacity"):
+                setattr(g, k, int(q[k]))
+            g.window = (C.c_int32 * 4)(*[int(v) for v in q["window"]])
+            g.sim_th, g.nnr, g.mutual = float(q.get("sim_th", 0.0)), float(q["nnr"]), int(bool(q.get("mutual", True)))
+            arr[i] = g
+        h = C.c_void_p()
+        _check(self._L.plslam_grid_plan_create(ctx.handle, arr, len(problems), C.byref(h)), "plslam_grid_plan_create")
+        self._h = h
+
+    def run(self, stream: int = 0) -> None:
+        _check(self._L.plslam_grid_plan_run(self._h, stream or None), "plslam_grid_plan_run")
+
+    def overflows(self, stream: int = 0) -> int:
+        n = C.c_int32()
+        _check(self._L.plslam_grid_plan_overflows(self._h, stream or None, C.byref(n)), "plslam_grid_plan_overflows")
+        return n.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.plslam_grid_plan_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -65,20 +65,6 @@ void HostBuf::release()
     cap = 0;
 }
 
-struct DeviceGuard {  // every entry point runs on the context's device
-    int prev = -1;
-    explicit DeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) (void)hipSetDevice(dev);
-        else prev = -1;
-    }
-    ~DeviceGuard()
-    {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
 }  // namespace plslam
 
 using namespace plslam;
@@ -858,13 +844,6 @@ int plslam_lba_line_rows_dev(plslam_ctx* ctx, const plslam_cam* K, double homog_
                             stream ? static_cast<hipStream_t>(stream) : ctx->stream);
 }
 
-namespace {
-// carve several arrays out of one scratch DevBuf (256-byte aligned slices)
-struct Carver {
-    size_t off = 0;
-    size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~size_t(255); return o; }
-};
-}  // namespace
 
 static int lba_rows_host(plslam_ctx* ctx, const plslam_cam* K, double th, int lines, int compat,
                          const double* T, int32_t nkf, const double* LM, int64_t n_lm_doubles,

@@ -52,6 +52,26 @@ struct HostBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+struct DeviceGuard {  // every entry point runs on the context's device
+    int prev = -1;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// carve several arrays out of one scratch buffer (256-byte aligned slices)
+struct Carver {
+    size_t off = 0;
+    size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~size_t(255); return o; }
+};
+
 }  // namespace plslam
 
 struct plslam_ctx {
@@ -161,6 +181,27 @@ int launch_visible(const plslam_cam& K, const double* Twf16, const double* X, in
 // n_lm x 32 or nullptr.  memset + 2 kernels on s.
 int launch_median_desc(const uint8_t* desc, const int32_t* off, int32_t n_lm, int32_t total,
                        int32_t* med_idx, uint8_t* med_desc, hipStream_t s);
+
+// --- StVO::matchGrid, the windowed matcher (match_grid.hip) --------------------------------------
+struct GridDesc {              // one matchGrid problem; every pointer is a device pointer
+    const uint8_t* d1;         // n1 x 32
+    const uint8_t* d2;         // n2 x 32
+    const int32_t* centres;    // n1 x n_centres x 2 window centres (x, y)
+    const int32_t* cell_start; // cols*rows + 1   GridStructure in CSR form, cell id = x*rows + y
+    const int32_t* cell_items;
+    const double* dir1;        // n1 x 2 or nullptr (points)
+    const double* dir2;        // n2 x 2 or nullptr
+    int32_t* matches_12;       // n1
+    int32_t* n_matches;        // 1 or nullptr
+    uint32_t* scratch;         // grid_scratch_words() words
+    int32_t* status;           // incremented when the pair list does not fit pair_cap; may be nullptr
+    double sim_th, nnr;
+    int32_t n1, n2, n_centres, cols, rows, mutual;
+    int32_t w[4];              // width.first, width.second, height.first, height.second
+    int32_t pair_cap;
+};
+size_t grid_scratch_words(int32_t n1, int32_t n2, int32_t pair_cap);
+int launch_match_grid(const GridDesc* d_probs, int32_t nprob, hipStream_t s);
 
 // --- LBD float -> binary line descriptor (lbd.hip) ---------------------------------------------
 // lbd: n x 72 f32, codes: n x 32 u8 (both 16-byte aligned)

@@ -173,3 +173,36 @@ def local_map(n_kf=10, n_pt=10000, n_ls=2000, obs_per_lm=5, cam=EUROC, seed=7, n
         l_obs[sel] = l
     return dict(T_kf_w=T_kf_w.reshape(n_kf, 16), Xw=Xw, obs_uv=uv, pt_lm=lm_pt, pt_kf=kf_pt,
                 Lw=Lw, l_obs=l_obs, ls_lm=lm_ls, ls_kf=kf_ls)
+
+
+def grid_frame_pair(rng, n1, n2, width=752, height=480, keep_frac=0.7, flip_p=0.08, shift_px=12.0, ties=False,
+                    lines=False):
+    """Two frames for the windowed matcher (StVO::matchGrid; src/mapHandler.cpp:252-271 / :381-418): n1 features of
+    the previous keyframe projected into the current image (some fall outside it) and n2 features of the current
+    one, `keep_frac` of which descend from previous ones (descriptor bit flips with prob. flip_p, position moved by
+    N(0, shift_px)); the rest are fresh.  ties=True draws descriptors from few patterns.
+    points: px1 (n1,2), px2 (n2,2) pixel positions; lines: seg1 (n1,4), seg2 (n2,4) pixel segments (x1,y1,x2,y2)."""
+    mk = (lambda n: tie_stress_desc(rng, n)) if ties else (lambda n: random_desc(rng, n))
+    d1 = mk(n1)
+    p1 = np.stack([rng.uniform(-0.05 * width, 1.05 * width, n1), rng.uniform(-0.05 * height, 1.05 * height, n1)], 1)
+    src = rng.integers(0, max(n1, 1), size=n2)
+    keep = (rng.random(n2) < keep_frac) & (n1 > 0)
+    flips = np.packbits(rng.random((n2, 256), dtype=np.float32) < flip_p, axis=1)
+    d2 = np.where(keep[:, None], (d1[src] if n1 else mk(n2)) ^ flips, mk(n2))
+    fresh = np.stack([rng.uniform(0, width, n2), rng.uniform(0, height, n2)], 1)
+    p2 = np.where(keep[:, None], (p1[src] if n1 else fresh) + rng.normal(0, shift_px, (n2, 2)), fresh)
+    out = dict(d1=np.ascontiguousarray(d1), d2=np.ascontiguousarray(d2), width=width, height=height)
+    if not lines:
+        out.update(px1=p1, px2=p2)
+        return out
+    def seg(p, n):
+        ang = rng.uniform(0, np.pi, n)
+        ln = rng.uniform(0, 0.25 * width, n) * (rng.random(n) > 0.05)      # a few zero-length segments
+        v = np.stack([np.cos(ang), np.sin(ang)], 1) * ln[:, None]
+        return np.concatenate([p, p + v], 1)
+    s1 = seg(p1, n1)
+    s2 = seg(p2, n2)
+    if n1:
+        s2 = np.where(keep[:, None], s1[src] + np.tile(p2 - p1[src], 2) + rng.normal(0, 1.0, (n2, 4)), s2)
+    out.update(seg1=s1, seg2=s2)
+    return out

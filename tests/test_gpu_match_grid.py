@@ -1,0 +1,174 @@
+"""GPU parity tests for K14, the windowed matcher StVO::matchGrid (plslam_match_grid / plslam_grid_plan_*; call sites
+src/mapHandler.cpp:271,418,591,706): match tables bit-exact against the oracle's literal sequential restatement --
+points and lines, with and without Config::bestLRMatches(), tie-heavy descriptors, degenerate grids."""
+import numpy as np
+import pytest
+
+import plslam_amd
+from plslam_amd import grid as G
+from plslam_amd import synth
+from test_match_grid_cpu import line_case, point_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _same(ctx, oracle, c, w, nnr, mutual):
+    got = ctx.match_grid(window=w, nnr=nnr, mutual=mutual, **c)
+    ref = oracle.match_grid(window=w, nnr=nnr, mutual=mutual, **c)
+    np.testing.assert_array_equal(got[0], ref[0])
+    assert got[1] == ref[1] == int((ref[0] >= 0).sum())
+    return ref
+
+
+@pytest.mark.parametrize("mutual", [False, True])
+@pytest.mark.parametrize("ties", [False, True])
+@pytest.mark.parametrize("kind", ["points", "lines"])
+def test_random_scenes_vs_oracle(ctx, oracle, kind, ties, mutual):
+    mk = point_case if kind == "points" else line_case
+    total = 0
+    for seed, (n1, n2, cols, rows, w) in enumerate([(1500, 1500, 64, 48, (3, 3, 3, 3)), (800, 900, 64, 48, (5, 0, 0, 0)),
+                                                    (300, 280, 16, 12, (2, 2, 2, 2)), (200, 150, 8, 6, (3, 0, 1, 0)),
+                                                    (50, 40, 2, 2, (1, 1, 1, 1)), (2000, 3, 4, 4, (4, 4, 4, 4)),
+                                                    (1, 1, 64, 48, (64, 64, 48, 48))]):
+        c = mk(100 + seed + 10 * ties, n1, n2, cols, rows, ties)
+        for nnr in (0.75, 0.9):
+            total += _same(ctx, oracle, c, w, nnr, mutual)[1]
+    assert total > 0
+
+
+def test_c2_frame_pair_finds_the_true_matches(ctx, oracle):
+    """BASELINE config 2 shape: 1500 ORB rows per image, 64 x 48 grid, matching_f2f_ws = 3
+    (config/config/config_kitti.yaml:59)."""
+    c = point_case(7, 1500, 1500, G.GRID_COLS, G.GRID_ROWS)
+    m, n = _same(ctx, oracle, c, (3, 3, 3, 3), 0.75, True)
+    assert n > 300                                                   # ~70 % of the rows have a true match nearby
+    # every reported match is inside the window of its row
+    x2 = {int(i): k // G.GRID_ROWS for k in range(G.GRID_COLS * G.GRID_ROWS)
+          for i in c["cell_items"][c["cell_start"][k]:c["cell_start"][k + 1]]}
+    for i1 in np.nonzero(m >= 0)[0]:
+        assert abs(x2[int(m[i1])] - int(c["centres"][i1][0])) <= 3
+
+
+def test_everything_in_one_cell_long_column_lists(ctx, oracle):
+    """All rows and all items share one cell: every column list has n1 entries (> one wave), the prefix-minimum
+    bins see every distance value; this is brute force restricted by the sequential rule."""
+    for ties in (False, True):
+        f = synth.grid_frame_pair(_rng(21 + ties), 700, 300, ties=ties)
+        cs, items = G.fill_points(np.zeros((300, 2), np.int32), 3, 3)
+        c = dict(centres=np.ones((700, 1, 2), np.int32), d1=f["d1"], cell_start=cs, cell_items=items, cols=3, rows=3,
+                 d2=f["d2"])
+        for mutual in (False, True):
+            _same(ctx, oracle, c, (1, 1, 1, 1), 0.9, mutual)
+
+
+def test_extreme_distances_and_lone_candidates(ctx, oracle):
+    z = np.zeros((4, 32), np.uint8)
+    o = np.full((4, 32), 0xFF, np.uint8)
+    cs, items = G.fill_points([[0, 0], [0, 0], [1, 1], [1, 1]], 2, 2)
+    for d1, d2 in ((z, o), (o, z), (z, z), (o, o)):                  # distances 256 / 0 only
+        for mutual in (False, True):
+            for nnr in (0.75, 2.0):
+                _same(ctx, oracle, dict(centres=[[0, 0], [1, 1], [0, 1], [5, 5]], d1=d1, cell_start=cs, cell_items=items,
+                                        cols=2, rows=2, d2=d2), (0, 0, 0, 0), nnr, mutual)
+    # a lone candidate passes the ratio test (best_d2 = INT_MAX)
+    r = _rng(3)
+    d2 = synth.random_desc(r, 1)
+    d1 = synth.random_desc(r, 1)
+    cs, items = G.fill_points([[2, 2]], 4, 4)
+    m, n = ctx.match_grid([[2, 2]], d1, cs, items, 4, 4, d2, (0, 0, 0, 0), 0.75, True)
+    assert m.tolist() == [0] and n == 1
+
+
+def test_sequential_rule_examples(ctx, oracle):
+    z = np.zeros((1, 32), np.uint8)
+    d2 = np.concatenate([z, z]); d2[1, 0] = 0xFF
+    d1 = np.zeros((2, 32), np.uint8); d1[0, 1] = 0x01
+    cs, items = G.fill_points([[0, 0], [0, 0]], 1, 1)
+    c1 = np.zeros((2, 1, 2), np.int32)
+    assert ctx.match_grid(c1, d1, cs, items, 1, 1, d2, (0, 0, 0, 0), 0.75, True)[0].tolist() == [-1, 0]
+    assert ctx.match_grid(c1, d1[::-1].copy(), cs, items, 1, 1, d2, (0, 0, 0, 0), 0.75, True)[0].tolist() == [0, -1]
+    assert ctx.match_grid(c1, d1, cs, items, 1, 1, d2, (0, 0, 0, 0), 0.75, False)[0].tolist() == [0, 0]
+
+
+def test_empty_and_out_of_range_inputs(ctx, oracle):
+    r = _rng(5)
+    d1, d2 = synth.random_desc(r, 5), synth.random_desc(r, 4)
+    cs0 = np.zeros(13, np.int32)
+    none = np.zeros(0, np.int32)
+    m, n = ctx.match_grid(np.zeros((5, 1, 2), np.int32), d1, cs0, none, 4, 3, d2, (1, 1, 1, 1), 0.75, True)
+    assert (m == -1).all() and n == 0                                # empty grid
+    m, n = ctx.match_grid(np.zeros((0, 1, 2), np.int32), d1[:0], cs0, none, 4, 3, d2, (1, 1, 1, 1), 0.75, True)
+    assert m.shape == (0,) and n == 0                                # no rows
+    cs, items = G.fill_points([[0, 0], [1, 1], [2, 2], [3, 2]], 4, 3)
+    m, n = ctx.match_grid(np.zeros((5, 1, 2), np.int32), d1, cs, items, 4, 3, d2[:0], (1, 1, 1, 1), 0.75, True)
+    assert (m == -1).all() and n == 0                                # desc2 empty: every item is out of range
+    # items outside [0, n2) are skipped (`if (i2 < 0 || i2 >= desc2.rows) continue;`); far-away and negative centres
+    items2 = np.array([0, 7, -3, 3], np.int32)
+    cen = np.array([[0, 0], [1, 1], [-2147483648, 2147483647], [2147483647, -2147483648], [3, 2]], np.int32)
+    c = dict(centres=cen, d1=d1, cell_start=cs, cell_items=items2, cols=4, rows=3, d2=d2)
+    for w in ((1, 1, 1, 1), (0, 0, 0, 0), (2147483647, 2147483647, 2147483647, 2147483647)):
+        _same(ctx, oracle, c, w, 0.9, True)
+
+
+def test_bad_arguments_are_refused(ctx):
+    r = _rng(6)
+    d = synth.random_desc(r, 4)
+    cs, items = G.fill_points([[0, 0]] * 4, 2, 2)
+    ok = dict(centres=np.zeros((4, 1, 2), np.int32), d1=d, cell_start=cs, cell_items=items, cols=2, rows=2, d2=d,
+              nnr=0.75)
+    with pytest.raises(plslam_amd.PlslamError):
+        ctx.match_grid(window=(1, -1, 0, 0), **ok)
+    bad = dict(ok, cell_start=cs[::-1].copy())
+    with pytest.raises(plslam_amd.PlslamError):
+        ctx.match_grid(window=(1, 1, 1, 1), **bad)
+    with pytest.raises(plslam_amd.PlslamError):
+        ctx.match_grid(window=(1, 1, 1, 1), **dict(ok, cols=0))
+
+
+def test_plan_batch_device_resident_and_overflow(ctx, oracle):
+    """64 problems of mixed kind in ONE launch through plslam_grid_plan_*; a problem whose pair_capacity is too
+    small reports an overflow, matches nothing and leaves the others intact."""
+    import torch
+    dev = torch.device("cuda", ctx.device)
+    keep, probs, refs = [], [], []
+
+    def up(a, dt):
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+        keep.append(t)
+        return t
+
+    for b in range(64):
+        lines = b % 3 == 0
+        n1, n2 = 50 + 37 * (b % 7), 40 + 29 * (b % 5)
+        c = (line_case if lines else point_case)(500 + b, n1, n2, 16, 12, ties=b % 2 == 1)
+        w = (2, 2, 2, 2) if b % 4 else (4, 0, 0, 0)
+        mutual = b % 5 != 0
+        refs.append(oracle.match_grid(window=w, nnr=0.8, mutual=mutual, **c))
+        cen = np.asarray(c["centres"], np.int32).reshape(n1, -1, 2)
+        cap = G.pair_count(cen.reshape(-1, 2), c["cell_start"], 16, 12, w)
+        out, cnt = torch.full((n1,), -7, dtype=torch.int32, device=dev), torch.full((1,), -7, dtype=torch.int32, device=dev)
+        keep += [out, cnt]
+        q = dict(d1=up(c["d1"], np.uint8).data_ptr(), d2=up(c["d2"], np.uint8).data_ptr(),
+                 centres1=up(cen, np.int32).data_ptr(), cell_start=up(c["cell_start"], np.int32).data_ptr(),
+                 cell_items=up(c["cell_items"] if len(c["cell_items"]) else np.zeros(1), np.int32).data_ptr(),
+                 n1=n1, n2=n2, n_centres=cen.shape[1], grid_cols=16, grid_rows=12, window=w, nnr=0.8, mutual=mutual,
+                 pair_capacity=cap if b != 9 else max(cap - 1, 0), matches_12=out.data_ptr(), n_matches=cnt.data_ptr())
+        if lines:
+            q.update(dir1=up(c["dir1"], np.float64).data_ptr(), dir2=up(c["dir2"], np.float64).data_ptr(), sim_th=c["sim_th"])
+        probs.append((q, out, cnt))
+    plan = plslam_amd.GridPlan(ctx, [p[0] for p in probs])
+    stream = torch.cuda.Stream(device=dev)
+    for rep in range(2):                                             # a plan is re-runnable
+        plan.run(stream.cuda_stream)
+        assert plan.overflows(stream.cuda_stream) == 1
+        for b, ((q, out, cnt), ref) in enumerate(zip(probs, refs)):
+            if b == 9:
+                assert (out.cpu().numpy() == -1).all() and int(cnt.item()) == -1
+                continue
+            np.testing.assert_array_equal(out.cpu().numpy(), ref[0], err_msg=f"problem {b}")
+            assert int(cnt.item()) == ref[1]
+    plan.close()
