@@ -204,9 +204,11 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
                       int32_t* matches_12, int32_t* n_matches);
 
 /* Device-resident form: a batch of matchGrid problems in ONE kernel launch (one workgroup per problem).
- * Every pointer of a problem is a DEVICE pointer.  pair_capacity bounds the number of (row, candidate)
- * pairs of the problem, duplicates included (sum over rows and centres of the window's item count); a
- * problem that exceeds it matches nothing, gets n_matches = -1 and is counted by plslam_grid_plan_overflows. */
+ * Every pointer of a problem is a DEVICE pointer; d1 / d2 must be 16-byte aligned.  pair_capacity sizes the
+ * kernel's candidate store (mutual problems only; 0 otherwise): rows are handled in blocks of 1024 and a block
+ * needs 1024 x (the number of grid items -- duplicates and out-of-range items included -- inside the windows of
+ * its fullest row) entries of 4 bytes.  A problem that exceeds it matches nothing, gets n_matches = -1 and is
+ * counted by plslam_grid_plan_overflows. */
 typedef struct plslam_grid_problem {
     const uint8_t* d1;
     const uint8_t* d2;
@@ -216,6 +218,7 @@ typedef struct plslam_grid_problem {
     const double* dir1;
     const double* dir2;
     int32_t n1, n2, n_centres, grid_cols, grid_rows;
+    int32_t n_items; /* entries of cell_items: cell_start[grid_cols*grid_rows] must not exceed it (else: overflow) */
     int32_t window[4];
     double sim_th, nnr;
     int32_t mutual;

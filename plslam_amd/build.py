@@ -36,7 +36,9 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc_path()] + FLAGS + ["-I" + os.path.join(_ROOT, "include")] + \
+    # PLSLAM_HIPCC_EXTRA: extra flags for experiment builds (e.g. -DPLSLAM_GRID_TIMING); never set by the product
+    extra = os.environ.get("PLSLAM_HIPCC_EXTRA", "").split()
+    cmd = [hipcc_path()] + FLAGS + extra + ["-I" + os.path.join(_ROOT, "include")] + \
           [os.path.join(CSRC, s) for s in SOURCES] + ["-o", OUT, "-ldl"]
     if verbose:
         print(" ".join(cmd))

@@ -58,7 +58,7 @@ class GridProblem(C.Structure):
     _fields_ = [("d1", C.c_void_p), ("d2", C.c_void_p), ("centres1", C.c_void_p), ("cell_start", C.c_void_p),
                 ("cell_items", C.c_void_p), ("dir1", C.c_void_p), ("dir2", C.c_void_p),
                 ("n1", C.c_int32), ("n2", C.c_int32), ("n_centres", C.c_int32), ("grid_cols", C.c_int32),
-                ("grid_rows", C.c_int32), ("window", C.c_int32 * 4), ("sim_th", C.c_double), ("nnr", C.c_double),
+                ("grid_rows", C.c_int32), ("n_items", C.c_int32), ("window", C.c_int32 * 4), ("sim_th", C.c_double), ("nnr", C.c_double),
                 ("mutual", C.c_int32), ("pair_capacity", C.c_int32), ("matches_12", C.c_void_p),
                 ("n_matches", C.c_void_p)]
 
@@ -560,7 +560,7 @@ class GridPlan:
             g = GridProblem()
             for k in ("d1", "d2", "centres1", "cell_start", "cell_items", "dir1", "dir2", "matches_12", "n_matches"):
                 setattr(g, k, q.get(k) or None)
-            for k in ("n1", "n2", "n_centres", "grid_cols", "grid_rows", "pair_capacity"):
+            for k in ("n1", "n2", "n_centres", "grid_cols", "grid_rows", "n_items", "pair_capacity"):
                 setattr(g, k, int(q[k]))
             g.window = (C.c_int32 * 4)(*[int(v) for v in q["window"]])
             g.sim_th, g.nnr, g.mutual = float(q.get("sim_th", 0.0)), float(q["nnr"]), int(bool(q.get("mutual", True)))

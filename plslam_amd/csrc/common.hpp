@@ -193,15 +193,21 @@ struct GridDesc {              // one matchGrid problem; every pointer is a devi
     const double* dir2;        // n2 x 2 or nullptr
     int32_t* matches_12;       // n1
     int32_t* n_matches;        // 1 or nullptr
-    uint32_t* scratch;         // grid_scratch_words() words
+    uint32_t* scratch;         // grid_scratch_words() words: [tables when they do not fit LDS |] pair list
     int32_t* status;           // incremented when the pair list does not fit pair_cap; may be nullptr
     double sim_th, nnr;
     int32_t n1, n2, n_centres, cols, rows, mutual;
     int32_t w[4];              // width.first, width.second, height.first, height.second
     int32_t pair_cap;
+    int32_t n_items;           // entries of cell_items the caller declared (cell_start[cols*rows] must not exceed it)
 };
-size_t grid_scratch_words(int32_t n1, int32_t n2, int32_t pair_cap);
-int launch_match_grid(const GridDesc* d_probs, int32_t nprob, hipStream_t s);
+size_t grid_fixed_words(int32_t n1, int32_t n2, int64_t ncell);   // tables kept in LDS when they fit
+bool grid_fits_lds(int32_t n1, int32_t n2, int64_t ncell);
+size_t grid_lds_bytes(int mode, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items);
+int grid_mode(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items);   // 2: all in LDS, 1: tables in LDS, 0: global
+size_t grid_scratch_words(int32_t n1, int32_t n2, int64_t ncell, int32_t pair_cap);
+// table order: the n[2] problems of mode 2, then the n[1] of mode 1, then the n[0] of mode 0
+int launch_match_grid(const GridDesc* d_probs, const int32_t n[3], const size_t lds_bytes[3], hipStream_t s);
 
 // --- LBD float -> binary line descriptor (lbd.hip) ---------------------------------------------
 // lbd: n x 72 f32, codes: n x 32 u8 (both 16-byte aligned)

@@ -9,26 +9,34 @@
 // strictly below the smallest distance any earlier row had to i2 (`if (d < distances[i2]) {...} else continue;`),
 // and matches_21[i2] follows the rows that lowered distances[i2].  That loop-carried dependence has an order-free
 // form, which is what runs here:
-//     (i1, i2) takes part in row i1's best / second best   <=>   i1 == min{ i1' : i2 in C(i1'), d(i1',i2) <= d(i1,i2) }
-//     matches_21[i2] = the row of the lexicographic minimum (d, i1) of column i2
-// (the tests check this form against a literal restatement of the sequential loop).  Ties between equally distant best candidates go to the lowest i2 (upstream: the
-// iteration order of a std::unordered_set<int>, implementation-defined).
+//     (i1, i2) takes part in row i1's best / second best   <=>   no row i1' < i1 has d(i1', i2) <= d(i1, i2),
+// i.e. the live entries of a column are its strict prefix minima in row order (its "records": rows ascending,
+// distances strictly descending, ending in the column's lexicographic minimum (d, i1) = matches_21[i2]).  The
+// tests check this form against a literal restatement of the sequential loop.  Ties between equally distant best
+// candidates go to the lowest i2 (upstream: the iteration order of a std::unordered_set<int>, implementation-
+// defined).
 //
-// One workgroup of 1024 lanes per problem, phases separated by workgroup barriers; every cross-lane combination is
-// a min of composite keys or an integer count, so the result does not depend on scheduling:
-//   P1 (lane per row)     count the candidates of every column i2 (the direction test of the line overload applied)
-//   P2                    exclusive scan of the counts -> column lists in CSR form (workgroup scan through LDS)
-//   P3 (lane per row)     d = popcount(desc1[i1] ^ desc2[i2]); append (d << 22 | i1) to column i2's list (unordered;
-//                         nothing below depends on the order); atomicMin the column's (d, i1) key
-//   P4 (wave per column)  first[d] = min i1 of the entries at distance d (257 bins in LDS, ds_min_u32), prefix-min over
-//                         d; an entry is live iff that prefix minimum is its own row; live entries fold (d << 23 | i2)
-//                         into the row's best key with atomicMin and keep a flag bit in the list
-//   P5 (wave per column)  live entries other than the row's best fold into the row's second-best key
-//   P6 (lane per row)     ratio test `best_d < best_d2 * nnr` in fp64 (int * double upstream; best_d2 = INT_MAX when
-//                         absent, so a single live candidate passes), mutual check, count
-// A row's window is 7x7 cells at the shipped configuration (matching_f2f_ws = 3), a few dozen candidates, so a
-// problem is ~10^4..10^5 distances: latency-bound.  Duplicated candidates (an item sitting in several cells of the
-// window, the two windows of a line overlapping) appear several times in the lists; every use is idempotent.
+// One workgroup of 1024 lanes per problem; a lane owns rows tid, tid + 1024, ... and keeps their best / second
+// best keys to itself, so the only shared state is one word per column.  A problem is a few 10^4 distances: what
+// costs is the length of dependent memory chains and the address rate of scattered loads, so the grid's
+// cell_start, its items, the desc2 rows and the per-column / per-row words live in LDS whenever they fit
+// (64 x 48 cells, 1500 + 1500 rows: 90 KB); the same code runs on global scratch when they do not.
+//   PA  per row: candidates in batches of 4, d = popcount(desc1[i1] ^ desc2[i2]).  Without bestLRMatches the
+//       best two (d << 23 | i2) keys are folded on the spot.  With it the candidates (one word each) go to the
+//       lane's slots of a transposed store -- slot k of lane t at [k][t], every access coalesced.
+//   PB  record passes (bestLRMatches only; the first one's proposals are made by PA as it goes).  state[i2] = the
+//       column's newest record (i1 << 9 | d), none at first.  When the stored candidates fit the LDS that the items
+//       and desc2 rows no longer need, they are first moved there (compact, one run per row).
+//       Each pass streams a row's remaining candidates once: a candidate that IS its column's state was installed by
+//       the previous pass -- it is live and joins the row's best two; a candidate below the state's distance proposes
+//       itself with an LDS atomic min of (i1 << 9 | d) (the smallest ROW below the last record's distance is the
+//       next record) and is kept, the others are dropped from the store.  A sweep over the columns then installs the
+//       proposals.  The loop ends when a sweep installs nothing: about ln(candidates per column) + 2 passes over
+//       geometrically shrinking lists.  The final state is the column's lexicographic minimum (d, i1) = matches_21.
+//   PC  per row: ratio test `best_d < best_d2 * nnr` in fp64 (int * double upstream; best_d2 = INT_MAX when absent,
+//       so a lone live candidate passes), mutual check against the column's final state, count.
+// Duplicated candidates (an item sitting in several cells of the window, the two windows of a line overlapping) are
+// harmless: the atomic min and the best-two fold are idempotent.
 #include <cstring>
 #include <new>
 
@@ -37,53 +45,105 @@
 namespace plslam {
 namespace {
 
-constexpr int GRID_THREADS = 1024, GRID_WAVES = GRID_THREADS / 64;
-constexpr uint32_t ROW_BITS = 22, ROW_MASK = (1u << ROW_BITS) - 1u;   // pair entry: live << 31 | d << 22 | i1
-constexpr uint32_t LIVE_BIT = 0x80000000u;
-constexpr int NBINS = 320;                                             // 257 distance values, 5 per lane
+constexpr int GRID_THREADS = 1024;
+constexpr uint32_t REC_D_BITS = 9, REC_D_MASK = 511u;                  // column state: i1 << 9 | d
+constexpr int CB = 4;                                                  // candidates per batch
+constexpr int PB_BATCH = 8;                                            // stored candidates per batch of a record pass
+constexpr size_t GRID_LDS_MAX_BYTES = 152 * 1024;                      // dynamic LDS of the LDS instantiations
+constexpr size_t GRID_LDS_FIXED_MAX_BYTES = 144 * 1024;                // tables that MUST fit for MODE 1
 
-__device__ __forceinline__ void wave_sync()
+// Pointers read out of the problem table are generic to the compiler (it would emit FLAT instructions and, for the
+// mode-dependent ones, could not tell LDS from global memory): every pointer below carries its address space.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a builtin vector (HIP's uint4 class cannot live behind an address space)
+#define PLSLAM_AS_GLOBAL __attribute__((address_space(1)))
+#define PLSLAM_AS_LDS __attribute__((address_space(3)))
+template <class T, bool IN_LDS> struct as_ptr { using type = PLSLAM_AS_GLOBAL T*; };
+template <class T> struct as_ptr<T, true> { using type = PLSLAM_AS_LDS T*; };
+
+template <int MODE>   // 0: every table in global scratch; 1: cell_start + column / row words in LDS; 2: items and desc2 rows too
+struct GridPtrs {
+    typename as_ptr<const uint32_t, (MODE >= 1)>::type cs;      // cell_start
+    typename as_ptr<const int32_t, (MODE == 2)>::type items;    // cell_items
+    typename as_ptr<const u32x4, (MODE == 2)>::type d2;         // desc2 rows, 2 x 16 bytes
+    typename as_ptr<uint32_t, (MODE >= 1)>::type state, next, row_k1, row_k2;
+    PLSLAM_AS_GLOBAL const int32_t* centres;
+    PLSLAM_AS_GLOBAL const double* dir1;
+    PLSLAM_AS_GLOBAL const double* dir2;
+};
+
+__device__ __forceinline__ void best2_fold(uint32_t& k1, uint32_t& k2, uint32_t key)
+{   // idempotent insertion into the two smallest distinct keys (k1 <= k2); value selects only -- a branchy form makes
+    // the compiler address k1 / k2 through private memory
+    const uint32_t lo = key < k1 ? key : k1, hi = key < k1 ? k1 : key;
+    k2 = key == k1 ? k2 : (hi < k2 ? hi : k2);
+    k1 = lo;
+}
+
+struct RowWindows {     // GridStructure::get ranges of one window centre (clamped to the grid: they fit 32 bits)
+    int32_t min_x, max_x, min_y, max_y;
+};
+__device__ __forceinline__ RowWindows window_of(const GridDesc& g, PLSLAM_AS_GLOBAL const int32_t* p)
 {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int64_t x = p[0], y = p[1];
+    RowWindows r;   // the sums in 64 bits: centres and windows may be any int32
+    r.min_x = (int32_t)(x - g.w[0] > 0 ? (x - g.w[0] < g.cols ? x - g.w[0] : g.cols) : 0);
+    r.max_x = (int32_t)(x + g.w[1] + 1 < g.cols ? (x + g.w[1] + 1 > 0 ? x + g.w[1] + 1 : 0) : g.cols);
+    r.min_y = (int32_t)(y - g.w[2] > 0 ? (y - g.w[2] < g.rows ? y - g.w[2] : g.rows) : 0);
+    r.max_y = (int32_t)(y + g.w[3] + 1 < g.rows ? (y + g.w[3] + 1 > 0 ? y + g.w[3] + 1 : 0) : g.rows);
+    return r;
 }
 
-__device__ __forceinline__ uint32_t ld_coherent(const uint32_t* p)
-{   // values other lanes produced with atomics earlier in this kernel
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// number of grid items inside row i1's windows (duplicates, out-of-range items and candidates the direction test
+// will drop included): the upper bound its slots in the candidate store are sized by
+template <int MODE>
+__device__ __forceinline__ uint32_t count_items(const GridDesc& g, const GridPtrs<MODE>& P, int32_t i1)
+{
+    uint32_t n = 0;
+    for (int32_t c = 0; c < g.n_centres; ++c) {
+        const RowWindows r = window_of(g, P.centres + ((int64_t)i1 * g.n_centres + c) * 2);
+        if (r.min_y >= r.max_y) continue;
+        for (int32_t x_ = r.min_x; x_ < r.max_x; ++x_) n += P.cs[x_ * g.rows + r.max_y] - P.cs[x_ * g.rows + r.min_y];
+    }
+    return n;
 }
 
-__device__ __forceinline__ uint32_t umin32(uint32_t a, uint32_t b) { return a < b ? a : b; }
-
-// GridStructure::get over every window centre of row i1; f(i2) for each candidate that survives the range check
-// (`if (i2 < 0 || i2 >= desc2.rows) continue;`) and the direction test of the line overload
-template <class F>
-__device__ __forceinline__ void for_candidates(const GridDesc& g, int32_t i1, F&& f)
+// GridStructure::get over every window centre of row i1, in batches: f(i2[CB]) with i2[j] = -1 for the slots
+// that are empty or fail `if (i2 < 0 || i2 >= desc2.rows) continue;` / the direction test of the line overload
+template <int MODE, class F>
+__device__ __forceinline__ void for_candidates(const GridDesc& g, const GridPtrs<MODE>& P, int32_t i1, F&& f)
 {
     double a0 = 0.0, a1 = 0.0;
     const bool dirs = g.dir1 != nullptr && g.dir2 != nullptr;
     if (dirs) {
-        a0 = g.dir1[2 * (int64_t)i1];
-        a1 = g.dir1[2 * (int64_t)i1 + 1];
+        a0 = P.dir1[2 * (int64_t)i1];
+        a1 = P.dir1[2 * (int64_t)i1 + 1];
     }
     for (int32_t c = 0; c < g.n_centres; ++c) {
-        const int32_t* p = g.centres + ((int64_t)i1 * g.n_centres + c) * 2;
-        const int64_t x = p[0], y = p[1];
-        const int64_t min_x = x - g.w[0] > 0 ? x - g.w[0] : 0;
-        const int64_t max_x = x + g.w[1] + 1 < g.cols ? x + g.w[1] + 1 : g.cols;
-        const int64_t min_y = y - g.w[2] > 0 ? y - g.w[2] : 0;
-        const int64_t max_y = y + g.w[3] + 1 < g.rows ? y + g.w[3] + 1 : g.rows;
-        if (min_y >= max_y) continue;
-        for (int64_t x_ = min_x; x_ < max_x; ++x_) {
+        const RowWindows r = window_of(g, P.centres + ((int64_t)i1 * g.n_centres + c) * 2);
+        if (r.min_y >= r.max_y) continue;
+        for (int32_t x_ = r.min_x; x_ < r.max_x; ++x_) {
             // cells (x_, min_y .. max_y-1) are adjacent in the CSR order (id = x*rows + y)
-            const int32_t s = g.cell_start[x_ * g.rows + min_y], e = g.cell_start[x_ * g.rows + max_y];
-            for (int32_t k = s; k < e; ++k) {
-                const int32_t i2 = g.cell_items[k];
-                if ((uint32_t)i2 >= (uint32_t)g.n2) continue;
+            const int32_t s = (int32_t)P.cs[x_ * g.rows + r.min_y], e = (int32_t)P.cs[x_ * g.rows + r.max_y];
+            for (int32_t k = s; k < e; k += CB) {
+                int32_t i2[CB];
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {
+                    i2[j] = k + j < e ? P.items[k + j] : -1;
+                    if ((uint32_t)i2[j] >= (uint32_t)g.n2) i2[j] = -1;
+                }
                 if (dirs) {
-                    const double dot = a0 * g.dir2[2 * (int64_t)i2] + a1 * g.dir2[2 * (int64_t)i2 + 1];
-                    if (fabs(dot) < g.sim_th) continue;       // NaN (zero-length direction) compares false: kept
+                    double b0[CB], b1[CB];
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) {
+                        const int64_t t = i2[j] < 0 ? 0 : i2[j];
+                        b0[j] = P.dir2[2 * t];
+                        b1[j] = P.dir2[2 * t + 1];
+                    }
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) {
+                        const double dot = a0 * b0[j] + a1 * b1[j];
+                        if (fabs(dot) < g.sim_th) i2[j] = -1;     // NaN (zero-length direction) compares false: kept
+                    }
                 }
                 f(i2);
             }
@@ -91,173 +151,319 @@ __device__ __forceinline__ void for_candidates(const GridDesc& g, int32_t i1, F&
     }
 }
 
-__global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __restrict__ probs)
+template <int MODE>
+__global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __restrict__ probs, uint32_t lds_words)
 {
+    constexpr bool LDS = MODE >= 1;
+    extern __shared__ u32x4 s_dyn4[];
     __shared__ uint32_t s_part[GRID_THREADS];
-    __shared__ uint32_t s_wave[GRID_WAVES];
-    __shared__ uint32_t s_bins[GRID_WAVES][NBINS];
-    __shared__ uint32_t s_total;
+    __shared__ uint32_t s_max2[2];
+    PLSLAM_AS_LDS uint32_t* s_dyn = (PLSLAM_AS_LDS uint32_t*)reinterpret_cast<uint32_t*>(s_dyn4);
 
     const GridDesc g = probs[blockIdx.x];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
     const int32_t n1 = g.n1, n2 = g.n2;
-    uint32_t* col_start = g.scratch;                     // n2 + 1 (counts during P1)
-    uint32_t* col_fill = col_start + (n2 + 1);           // n2
-    uint32_t* col_best = col_fill + n2;                  // n2   (d << 22 | i1) lexicographic column minimum
-    uint32_t* row_k1 = col_best + n2;                    // n1   (d << 23 | i2) best live candidate
-    uint32_t* row_k2 = row_k1 + n1;                      // n1   second best
-    uint32_t* pairs = row_k2 + n1;                       // pair_cap
+    const int32_t ncell = g.cols * g.rows;
+    const int32_t n_rounds = (n1 + GRID_THREADS - 1) / GRID_THREADS;
+#ifdef PLSLAM_GRID_TIMING   // experiment builds only: phase boundaries in 10 ns ticks, printed by one lane
+    uint64_t ts[6];
+    int nts = 0, npass = 0;
+#define GRID_STAMP() do { if (nts < 6) ts[nts++] = wall_clock64(); } while (0)
+#else
+#define GRID_STAMP() do { } while (0)
+#endif
+    GRID_STAMP();
+    PLSLAM_AS_GLOBAL uint32_t* gscratch = (PLSLAM_AS_GLOBAL uint32_t*)g.scratch;
+    PLSLAM_AS_GLOBAL const int32_t* g_cell_start = (PLSLAM_AS_GLOBAL const int32_t*)g.cell_start;
+    PLSLAM_AS_GLOBAL const int32_t* g_items = (PLSLAM_AS_GLOBAL const int32_t*)g.cell_items;
+    PLSLAM_AS_GLOBAL const u32x4* g_d1 = (PLSLAM_AS_GLOBAL const u32x4*)g.d1;
+    PLSLAM_AS_GLOBAL const u32x4* g_d2 = (PLSLAM_AS_GLOBAL const u32x4*)g.d2;
+    PLSLAM_AS_GLOBAL int32_t* g_matches = (PLSLAM_AS_GLOBAL int32_t*)g.matches_12;
+    // tables: [cell_start copy (LDS only)] | state n2 | next n2 | row_k1 n1 | row_k2 n1
+    const uint32_t fixed_words = (uint32_t)(LDS ? ncell + 1 : 0) + 2u * (uint32_t)n2 + 2u * (uint32_t)n1;
+    // MODE 2: items at the next 16-byte boundary behind the tables, desc2 rows behind them (launcher guarantees the fit)
+    const uint32_t items_off = (fixed_words + 3u) & ~3u, d2_off = (items_off + (uint32_t)g.n_items + 3u) & ~3u;
+    GridPtrs<MODE> P;
+    P.centres = (PLSLAM_AS_GLOBAL const int32_t*)g.centres;
+    P.dir1 = (PLSLAM_AS_GLOBAL const double*)g.dir1;
+    P.dir2 = (PLSLAM_AS_GLOBAL const double*)g.dir2;
+    if constexpr (LDS) {
+        P.cs = s_dyn;
+        P.state = s_dyn + (ncell + 1);
+    } else {
+        P.cs = (PLSLAM_AS_GLOBAL const uint32_t*)g.cell_start;
+        P.state = gscratch;
+    }
+    P.next = P.state + n2;                                  // this pass's proposals; state = newest record i1 << 9 | d
+    P.row_k1 = P.next + n2;                                 // (d << 23 | i2) best live candidate of the row
+    P.row_k2 = P.row_k1 + n1;                               // second best
+    if constexpr (MODE == 2) {
+        P.items = (PLSLAM_AS_LDS const int32_t*)(s_dyn + items_off);
+        P.d2 = (PLSLAM_AS_LDS const u32x4*)(s_dyn + d2_off);
+    } else {
+        P.items = g_items;
+        P.d2 = g_d2;
+    }
+    // global scratch behind the tables: per-row slot counts, per-round slot depth, the candidate store (x 2)
+    PLSLAM_AS_GLOBAL uint32_t* rcnt = gscratch + (LDS ? 0u : fixed_words);   // n1
+    PLSLAM_AS_GLOBAL uint32_t* round_k = rcnt + n1;                          // n_rounds
+    PLSLAM_AS_GLOBAL uint32_t* store = round_k + n_rounds;  // 2 x pair_cap words; round r at 1024 * sum_{r' < r} round_k
 
-    // ---- P0 ----
-    for (int32_t j = tid; j <= n2; j += GRID_THREADS) col_start[j] = 0u;
-    for (int32_t j = tid; j < n2; j += GRID_THREADS) col_best[j] = KEY_NONE;
+    // ---- P0: tables ----
+    if constexpr (LDS) {
+        for (int32_t j = tid; j <= ncell; j += GRID_THREADS) s_dyn[j] = (uint32_t)g_cell_start[j];
+    }
+    if constexpr (MODE == 2) {
+        PLSLAM_AS_LDS int32_t* li = (PLSLAM_AS_LDS int32_t*)(s_dyn + items_off);
+        for (int32_t j = tid; j < g.n_items; j += GRID_THREADS) li[j] = g_items[j];
+        PLSLAM_AS_LDS u32x4* lt = (PLSLAM_AS_LDS u32x4*)(s_dyn + d2_off);
+        for (int32_t j = tid; j < 2 * n2; j += GRID_THREADS) lt[j] = g_d2[j];
+    }
+    for (int32_t j = tid; j < n2; j += GRID_THREADS) {
+        P.state[j] = KEY_NONE;
+        P.next[j] = KEY_NONE;
+    }
     for (int32_t i = tid; i < n1; i += GRID_THREADS) {
-        row_k1[i] = KEY_NONE;
-        row_k2[i] = KEY_NONE;
+        P.row_k1[i] = KEY_NONE;
+        P.row_k2[i] = KEY_NONE;
     }
-    __threadfence();
     __syncthreads();
-
-    // ---- P1: column counts ----
-    for (int32_t i1 = tid; i1 < n1; i1 += GRID_THREADS)
-        for_candidates(g, i1, [&](int32_t i2) { atomicAdd(&col_start[i2], 1u); });
-    __threadfence();
-    __syncthreads();
-
-    // ---- P2: exclusive scan of col_start[0..n2) in place; col_start[n2] = total ----
-    {
-        const int32_t per = (n2 + GRID_THREADS - 1) / GRID_THREADS;
-        const int32_t b = tid * per < n2 ? tid * per : n2, e = b + per < n2 ? b + per : n2;
-        uint32_t sum = 0;
-        for (int32_t j = b; j < e; ++j) sum += ld_coherent(&col_start[j]);
-        uint32_t incl = sum;                                        // wave inclusive scan
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint32_t base = 0;
-        for (int w = 0; w < wave; ++w) base += s_wave[w];
-        uint32_t run = base + incl - sum;
-        for (int32_t j = b; j < e; ++j) {
-            const uint32_t c = ld_coherent(&col_start[j]);
-            col_start[j] = run;
-            col_fill[j] = run;
-            run += c;
-        }
-        if (tid == GRID_THREADS - 1) {
-            col_start[n2] = run;
-            s_total = run;
-        }
-        __threadfence();
-        __syncthreads();
-    }
-    if (s_total > (uint32_t)g.pair_cap) {                           // list does not fit: report, match nothing
-        for (int32_t i = tid; i < n1; i += GRID_THREADS) g.matches_12[i] = -1;
+    if ((uint32_t)P.cs[ncell] > (uint32_t)g.n_items) {      // the grid holds more items than the caller declared
+        for (int32_t i = tid; i < n1; i += GRID_THREADS) g_matches[i] = -1;
         if (tid == 0) {
             if (g.n_matches) *g.n_matches = -1;
             if (g.status) atomicAdd(g.status, 1);
         }
         return;
     }
+    GRID_STAMP();
 
-    // ---- P3: distances; column lists; column minima ----
-    for (int32_t i1 = tid; i1 < n1; i1 += GRID_THREADS) {
-        uint32_t q[8];
-        const uint32_t* qa = reinterpret_cast<const uint32_t*>(g.d1) + (int64_t)i1 * 8;
+    // ---- PA: distances ----
+    uint32_t store_words = 0;        // slots claimed so far (uniform)
+    for (int32_t r = 0; r < n_rounds; ++r) {
+        const int32_t i1 = r * GRID_THREADS + tid;
+        uint32_t depth = 0;
+        if (g.mutual) {              // slot depth of this round = the largest item count of one of its rows
+            uint32_t c = i1 < n1 ? count_items(g, P, i1) : 0u;
 #pragma unroll
-        for (int w = 0; w < 8; ++w) q[w] = qa[w];
-        for_candidates(g, i1, [&](int32_t i2) {
-            const uint32_t* t = reinterpret_cast<const uint32_t*>(g.d2) + (int64_t)i2 * 8;
-            uint32_t d = 0;
+            for (int off = 32; off > 0; off >>= 1) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)c, off);
+                c = c > o ? c : o;
+            }
+            uint32_t& s_max = s_max2[r & 1];     // alternating slots: no barrier needed after the read below
+            if (tid == 0) s_max = 0u;
+            __syncthreads();
+            if (lane == 0) atomicMax(&s_max, c);
+            __syncthreads();
+            depth = s_max;
+            if (tid == 0) round_k[r] = depth;
+            if ((uint64_t)store_words + (uint64_t)depth * GRID_THREADS > (uint64_t)(uint32_t)g.pair_cap) {
+                // the store does not fit: report, match nothing
+                for (int32_t i = tid; i < n1; i += GRID_THREADS) g_matches[i] = -1;
+                if (tid == 0) {
+                    if (g.n_matches) *g.n_matches = -1;
+                    if (g.status) atomicAdd(g.status, 1);
+                }
+                return;
+            }
+        }
+        if (i1 < n1) {
+            const u32x4 qa = g_d1[2 * (int64_t)i1], qb = g_d1[2 * (int64_t)i1 + 1];
+            uint32_t k1 = KEY_NONE, k2 = KEY_NONE, kout = 0;
+            PLSLAM_AS_GLOBAL uint32_t* slot = store + store_words + tid;
+            for_candidates(g, P, i1, [&](const int32_t (&i2)[CB]) {
+                u32x4 ta[CB], tb[CB];
 #pragma unroll
-            for (int w = 0; w < 8; ++w) d += (uint32_t)__popc(q[w] ^ t[w]);
-            const uint32_t key = (d << ROW_BITS) | (uint32_t)i1;
-            const uint32_t pos = atomicAdd(&col_fill[i2], 1u);
-            pairs[pos] = key;
-            if (g.mutual) atomicMin(&col_best[i2], key);
-        });
+                for (int j = 0; j < CB; ++j) {
+                    const int64_t t = i2[j] < 0 ? 0 : i2[j];
+                    ta[j] = P.d2[2 * t];
+                    tb[j] = P.d2[2 * t + 1];
+                }
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {
+                    const uint32_t d = (uint32_t)(__popc(qa.x ^ ta[j].x) + __popc(qa.y ^ ta[j].y) + __popc(qa.z ^ ta[j].z) +
+                                                  __popc(qa.w ^ ta[j].w) + __popc(qb.x ^ tb[j].x) + __popc(qb.y ^ tb[j].y) +
+                                                  __popc(qb.z ^ tb[j].z) + __popc(qb.w ^ tb[j].w));
+                    const uint32_t key = (d << KEY_IDX_BITS) | (uint32_t)i2[j];
+                    if (i2[j] >= 0) {
+                        if (g.mutual) {
+                            // the first record pass, fused: no column has a record yet, so every candidate proposes
+                            atomicMin((uint32_t*)&P.next[i2[j]], ((uint32_t)i1 << REC_D_BITS) | d);
+                            slot[(size_t)kout * GRID_THREADS] = key;
+                            ++kout;
+                        } else
+                            best2_fold(k1, k2, key);
+                    }
+                }
+            });
+            if (g.mutual)
+                rcnt[i1] = kout;
+            else {
+                P.row_k1[i1] = k1;
+                P.row_k2[i1] = k2;
+            }
+        }
+        store_words += depth * GRID_THREADS;
     }
     __threadfence();
     __syncthreads();
+    GRID_STAMP();
 
-    // ---- P4: live entries -> row best ----
-    uint32_t* bins = s_bins[wave];
-    for (int32_t i2 = wave; i2 < n2; i2 += GRID_WAVES) {
-        const uint32_t s = col_start[i2], e = col_start[i2 + 1];
-        if (s == e) continue;
-        const bool need_bins = g.mutual && e - s > 1;               // a single entry is its own prefix minimum
-        if (need_bins) {
+    // ---- PB: record passes ----
+    if (g.mutual) {
+        // one row's share of a pass: stream its remaining candidates from `slot` (stride apart), keep the survivors
+        // in `out`; returns how many
+        auto pass_row = [&](int32_t i1, auto slot, auto out, uint32_t stride, uint32_t cnt) -> uint32_t {
+            uint32_t k1 = P.row_k1[i1], k2 = P.row_k2[i1], kout = 0;
+            for (uint32_t k0 = 0; k0 < cnt; k0 += PB_BATCH) {         // PB_BATCH independent loads in flight
+                uint32_t key[PB_BATCH], st[PB_BATCH];
 #pragma unroll
-            for (int k = 0; k < NBINS / 64; ++k) bins[lane + 64 * k] = KEY_NONE;
-            wave_sync();
-            for (uint32_t p = s + lane; p < e; p += 64) {
-                const uint32_t key = pairs[p];
-                atomicMin(&bins[key >> ROW_BITS], key & ROW_MASK);
+                for (int j = 0; j < PB_BATCH; ++j) key[j] = k0 + j < cnt ? slot[(size_t)(k0 + j) * stride] : KEY_NONE;
+#pragma unroll
+                for (int j = 0; j < PB_BATCH; ++j) st[j] = P.state[key[j] == KEY_NONE ? 0u : key[j] & KEY_IDX_MASK];
+#pragma unroll
+                for (int j = 0; j < PB_BATCH; ++j) {
+                    const uint32_t i2 = key[j] & KEY_IDX_MASK, d = key[j] >> KEY_IDX_BITS;
+                    const uint32_t me = ((uint32_t)i1 << REC_D_BITS) | d;
+                    // installed by the previous sweep: live
+                    if (key[j] != KEY_NONE && st[j] == me) best2_fold(k1, k2, key[j]);
+                    const uint32_t cur = st[j] == KEY_NONE ? 512u : st[j] & REC_D_MASK;
+                    if (key[j] != KEY_NONE && d < cur) {             // still below the newest record: propose, keep
+                        atomicMin((uint32_t*)&P.next[i2], me);
+                        out[(size_t)kout * stride] = key[j];
+                        ++kout;
+                    }
+                }
             }
-            wave_sync();
-            // prefix minimum over the distance value: lane l owns bins 5l .. 5l+4
-            uint32_t v[5];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) v[k] = bins[5 * lane + k];
-#pragma unroll
-            for (int k = 1; k < 5; ++k) v[k] = umin32(v[k], v[k - 1]);
-            uint32_t incl = v[4];
+            P.row_k1[i1] = k1;
+            P.row_k2[i1] = k2;
+            return kout;
+        };
+        auto sweep = [&]() -> int {       // install the proposals; workgroup-wide "anything new?"
+            if (!LDS) __threadfence();
+            __syncthreads();
+            int any = 0;
+            for (int32_t i2 = tid; i2 < n2; i2 += GRID_THREADS) {
+                const uint32_t nx = P.next[i2];
+                if (nx != KEY_NONE) {
+                    P.state[i2] = nx;
+                    P.next[i2] = KEY_NONE;
+                    any = 1;
+                }
+            }
+            if (!LDS) __threadfence();
+#ifdef PLSLAM_GRID_TIMING
+            ++npass;
+#endif
+            return __syncthreads_or(any);
+        };
+
+        int more = sweep();               // installs the proposals PA made: every column's first record
+        bool in_lds = false;
+        if constexpr (MODE == 2) {
+            // cell_start's tail neighbours -- the items and the desc2 rows -- are dead now: if the candidates fit
+            // there (compact: row i1 at row_off[i1]), the passes run on LDS alone
+            PLSLAM_AS_LDS uint32_t* row_off = s_dyn + items_off;      // n1 + 1
+            PLSLAM_AS_LDS uint32_t* lcnt = row_off + (n1 + 1);        // n1
+            PLSLAM_AS_LDS uint32_t* lstore = lcnt + n1;
+            const uint32_t room = lds_words > items_off + 2u * (uint32_t)n1 + 1u ? lds_words - (items_off + 2u * (uint32_t)n1 + 1u) : 0u;
+            // exclusive scan of the row counts (s_part as scratch)
+            const int32_t per = (n1 + GRID_THREADS - 1) / GRID_THREADS;
+            const int32_t b = tid * per < n1 ? tid * per : n1, e = b + per < n1 ? b + per : n1;
+            uint32_t sum = 0;
+            for (int32_t i = b; i < e; ++i) sum += rcnt[i];
+            uint32_t incl = sum;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_up((int)incl, off);
-                if (lane >= off) incl = umin32(incl, o);
+                const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
+                if (lane >= off) incl += v;
             }
-            uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
-            if (lane == 0) excl = KEY_NONE;
+            if (lane == 63) s_part[tid >> 6] = incl;
+            __syncthreads();                                          // also: every PA read of items / desc2 is done
+            uint32_t pre = 0, total = 0;
+            for (int w = 0; w < GRID_THREADS / 64; ++w) {
+                const uint32_t v = s_part[w];
+                pre += w < (tid >> 6) ? v : 0u;
+                total += v;
+            }
+            in_lds = total <= room;                                   // uniform
+            if (in_lds) {
+                uint32_t run = pre + incl - sum;
+                for (int32_t i = b; i < e; ++i) {
+                    const uint32_t c = rcnt[i];
+                    row_off[i] = run;
+                    lcnt[i] = c;
+                    run += c;
+                }
+                __syncthreads();
+                uint32_t off = 0;
+                for (int32_t r = 0; r < n_rounds; ++r) {              // transposed global slots -> compact LDS rows
+                    const int32_t i1 = r * GRID_THREADS + tid;
+                    if (i1 < n1) {
+                        const uint32_t cnt = lcnt[i1];
+                        PLSLAM_AS_GLOBAL const uint32_t* slot = store + off + tid;
+                        PLSLAM_AS_LDS uint32_t* dstp = lstore + row_off[i1];
+                        for (uint32_t k0 = 0; k0 < cnt; k0 += PB_BATCH) {
+                            uint32_t key[PB_BATCH];
 #pragma unroll
-            for (int k = 0; k < 5; ++k) bins[5 * lane + k] = umin32(v[k], excl);
-            wave_sync();
-        }
-        for (uint32_t p = s + lane; p < e; p += 64) {
-            const uint32_t key = pairs[p];
-            const uint32_t d = key >> ROW_BITS, i1 = key & ROW_MASK;
-            const bool live = !need_bins || bins[d] == i1;
-            if (live) {
-                pairs[p] = key | LIVE_BIT;
-                atomicMin(&row_k1[i1], (d << KEY_IDX_BITS) | (uint32_t)i2);
+                            for (int j = 0; j < PB_BATCH; ++j) key[j] = k0 + j < cnt ? slot[(size_t)(k0 + j) * GRID_THREADS] : 0u;
+#pragma unroll
+                            for (int j = 0; j < PB_BATCH; ++j)
+                                if (k0 + j < cnt) dstp[k0 + j] = key[j];
+                        }
+                    }
+                    off += round_k[r] * GRID_THREADS;
+                }
+                __syncthreads();
+                while (more) {
+                    for (int32_t i1 = tid; i1 < n1; i1 += GRID_THREADS) {
+                        const uint32_t cnt = lcnt[i1];
+                        if (cnt) {
+                            PLSLAM_AS_LDS uint32_t* rowp = lstore + row_off[i1];
+                            lcnt[i1] = pass_row(i1, rowp, rowp, 1u, cnt);   // in place: survivors land at or before their source
+                        }
+                    }
+                    more = sweep();
+                }
             }
         }
-        wave_sync();                                                // bins are reused by the next column
-    }
-    __threadfence();
-    __syncthreads();
-
-    // ---- P5: live entries other than the row's best -> row second best ----
-    for (int32_t i2 = wave; i2 < n2; i2 += GRID_WAVES) {
-        const uint32_t s = col_start[i2], e = col_start[i2 + 1];
-        for (uint32_t p = s + lane; p < e; p += 64) {
-            const uint32_t key = pairs[p];
-            if (!(key & LIVE_BIT)) continue;
-            const uint32_t d = (key & ~LIVE_BIT) >> ROW_BITS, i1 = key & ROW_MASK;
-            const uint32_t rk = (d << KEY_IDX_BITS) | (uint32_t)i2;
-            if (rk != ld_coherent(&row_k1[i1])) atomicMin(&row_k2[i1], rk);
+        if (!in_lds) {
+            int flip = 0;
+            while (more) {
+                // survivors of a pass go to the other half of the store: reads and writes never alias, so a batch's
+                // loads do not wait for the previous batch's stores
+                PLSLAM_AS_GLOBAL const uint32_t* __restrict__ src = store + (flip ? (uint32_t)g.pair_cap : 0u);
+                PLSLAM_AS_GLOBAL uint32_t* __restrict__ dst = store + (flip ? 0u : (uint32_t)g.pair_cap);
+                flip ^= 1;
+                uint32_t off = 0;
+                for (int32_t r = 0; r < n_rounds; ++r) {
+                    const int32_t i1 = r * GRID_THREADS + tid;
+                    if (i1 < n1) {
+                        const uint32_t cnt = rcnt[i1];
+                        if (cnt) rcnt[i1] = pass_row(i1, src + off + tid, dst + off + tid, (uint32_t)GRID_THREADS, cnt);
+                    }
+                    off += round_k[r] * GRID_THREADS;
+                }
+                more = sweep();
+            }
         }
     }
-    __threadfence();
-    __syncthreads();
+    GRID_STAMP();
 
-    // ---- P6: ratio test, mutual check, count ----
+    // ---- PC: ratio test, mutual check, count ----
     uint32_t cnt = 0;
     for (int32_t i1 = tid; i1 < n1; i1 += GRID_THREADS) {
-        const uint32_t k1 = ld_coherent(&row_k1[i1]), k2 = ld_coherent(&row_k2[i1]);
+        const uint32_t k1 = P.row_k1[i1], k2 = P.row_k2[i1];
         int32_t m = -1;
         if (k1 != KEY_NONE) {
             const double best_d = (double)(int32_t)(k1 >> KEY_IDX_BITS);
             const double best_d2 = k2 == KEY_NONE ? 2147483647.0 : (double)(int32_t)(k2 >> KEY_IDX_BITS);
             if (best_d < best_d2 * g.nnr) {
                 const int32_t i2 = (int32_t)(k1 & KEY_IDX_MASK);
-                if (!g.mutual || (ld_coherent(&col_best[i2]) & ROW_MASK) == (uint32_t)i1) m = i2;
+                if (!g.mutual || (P.state[i2] >> REC_D_BITS) == (uint32_t)i1) m = i2;
             }
         }
-        g.matches_12[i1] = m;
+        g_matches[i1] = m;
         cnt += m >= 0;
     }
     s_part[tid] = cnt;
@@ -267,21 +473,79 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
         __syncthreads();
     }
     if (tid == 0 && g.n_matches) *g.n_matches = (int32_t)s_part[0];
+    GRID_STAMP();
+#ifdef PLSLAM_GRID_TIMING
+    if (tid == 0 && blockIdx.x == 0)
+        printf("[k_match_grid n1=%d n2=%d] P0 %d PA %d PB %d (%d passes) PC %d (x10 ns)\n", n1, n2, (int)(ts[1] - ts[0]),
+               (int)(ts[2] - ts[1]), (int)(ts[3] - ts[2]), npass, (int)(ts[4] - ts[3]));
+#endif
+#undef GRID_STAMP
 }
 
 }  // namespace
 
-size_t grid_scratch_words(int32_t n1, int32_t n2, int32_t pair_cap)
+// words of the tables that live in LDS when they fit (cell_start copy + column / row words)
+size_t grid_fixed_words(int32_t n1, int32_t n2, int64_t ncell)
 {
-    return (size_t)(n2 + 1) + 2 * (size_t)n2 + 2 * (size_t)n1 + (size_t)pair_cap;
+    return (size_t)(ncell + 1) + 2 * (size_t)n2 + 2 * (size_t)n1;
+}
+bool grid_fits_lds(int32_t n1, int32_t n2, int64_t ncell)
+{
+    return grid_fixed_words(n1, n2, ncell) * 4 <= GRID_LDS_FIXED_MAX_BYTES;
+}
+// global scratch of one problem: [tables when they do not fit LDS |] slot counts | round depths | candidate store x 2
+size_t grid_scratch_words(int32_t n1, int32_t n2, int64_t ncell, int32_t pair_cap)
+{
+    return (grid_fits_lds(n1, n2, ncell) ? 0 : 2 * (size_t)n2 + 2 * (size_t)n1) + (size_t)n1 +
+           (size_t)((n1 + GRID_THREADS - 1) / GRID_THREADS) + 2 * (size_t)pair_cap;
 }
 
-int launch_match_grid(const GridDesc* d_probs, int32_t nprob, hipStream_t s)
+// LDS bytes of a problem in each mode (MODE 2: tables, items at a 16-byte boundary, desc2 rows)
+size_t grid_lds_bytes(int mode, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items)
 {
-    if (nprob <= 0) return PLSLAM_OK;
-    hipLaunchKernelGGL(k_match_grid, dim3((unsigned)nprob), dim3(GRID_THREADS), 0, s, d_probs);
+    if (mode == 0) return 0;
+    size_t w = grid_fixed_words(n1, n2, ncell);
+    if (mode == 2) {
+        w = (w + 3) & ~size_t(3);
+        w = (w + (size_t)n_items + 3) & ~size_t(3);
+        w += 8 * (size_t)n2;
+    }
+    return w * 4;
+}
+int grid_mode(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items)
+{
+    if (grid_lds_bytes(2, n1, n2, ncell, n_items) <= GRID_LDS_MAX_BYTES) return 2;
+    return grid_fits_lds(n1, n2, ncell) ? 1 : 0;
+}
+
+template <int MODE>
+static int launch_mode(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hipStream_t s)
+{
+    if (n <= 0) return PLSLAM_OK;
+    if (MODE > 0) {
+        static std::once_flag once;
+        static hipError_t attr = hipSuccess;
+        std::call_once(once, [] {
+            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_grid<MODE>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRID_LDS_MAX_BYTES);
+        });
+        PLSLAM_HIP_CHECK(attr);
+    }
+    if (MODE == 2) lds_bytes = GRID_LDS_MAX_BYTES;   // one workgroup per CU either way: the spare LDS holds the candidates
+    hipLaunchKernelGGL(k_match_grid<MODE>, dim3((unsigned)n), dim3(GRID_THREADS), lds_bytes, s, d_probs,
+                       (uint32_t)(lds_bytes / 4));
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
+}
+
+// d_probs: the n[2] problems of mode 2 first, then the n[1] of mode 1, then the n[0] of mode 0; lds_bytes[m] = the
+// largest grid_lds_bytes() of a problem of mode m
+int launch_match_grid(const GridDesc* d_probs, const int32_t n[3], const size_t lds_bytes[3], hipStream_t s)
+{
+    int rc;
+    if ((rc = launch_mode<2>(d_probs, n[2], lds_bytes[2], s))) return rc;
+    if ((rc = launch_mode<1>(d_probs + n[2], n[1], lds_bytes[1], s))) return rc;
+    return launch_mode<0>(d_probs + n[2] + n[1], n[0], 0, s);
 }
 
 }  // namespace plslam
@@ -294,8 +558,15 @@ using namespace plslam;
 struct plslam_grid_plan {
     plslam_ctx* ctx = nullptr;
     int32_t nprob = 0;
+    int32_t n_mode[3] = {0, 0, 0};     // the table holds the problems of mode 2 first, then mode 1, then mode 0
+    size_t lds_bytes[3] = {0, 0, 0};   // largest LDS footprint of a problem of each mode
     DevBuf table, scratch, status;
 };
+
+static size_t grid_prob_scratch(const plslam_grid_problem& q)
+{
+    return (grid_scratch_words(q.n1, q.n2, (int64_t)q.grid_cols * q.grid_rows, q.pair_capacity) + 63) & ~size_t(63);
+}
 
 static int grid_check_problem(const plslam_grid_problem& q)
 {
@@ -305,11 +576,11 @@ static int grid_check_problem(const plslam_grid_problem& q)
     PLSLAM_REQUIRE(q.n1 < PLSLAM_MAX_GRID_ROWS && q.n2 <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
     PLSLAM_REQUIRE(q.window[0] >= 0 && q.window[1] >= 0 && q.window[2] >= 0 && q.window[3] >= 0,
                    PLSLAM_EINVAL);
-    PLSLAM_REQUIRE(q.pair_capacity >= 0, PLSLAM_EINVAL);
-    PLSLAM_REQUIRE(q.cell_start != nullptr, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(q.pair_capacity >= 0 && q.n_items >= 0, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(q.cell_start != nullptr && (q.n_items == 0 || q.cell_items != nullptr), PLSLAM_EINVAL);
     PLSLAM_REQUIRE(q.n1 == 0 || (q.d1 && q.centres1 && q.matches_12), PLSLAM_EINVAL);
     PLSLAM_REQUIRE(q.n2 == 0 || q.d2, PLSLAM_EINVAL);
-    PLSLAM_REQUIRE(((uintptr_t)q.d1 & 3) == 0 && ((uintptr_t)q.d2 & 3) == 0, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(((uintptr_t)q.d1 & 15) == 0 && ((uintptr_t)q.d2 & 15) == 0, PLSLAM_EINVAL);
     PLSLAM_REQUIRE((q.dir1 == nullptr) == (q.dir2 == nullptr) || q.n1 == 0 || q.n2 == 0, PLSLAM_EINVAL);
     return PLSLAM_OK;
 }
@@ -326,6 +597,7 @@ static void grid_fill_desc(const plslam_grid_problem& q, uint32_t* scratch, int3
     d->mutual = q.mutual ? 1 : 0;
     for (int k = 0; k < 4; ++k) d->w[k] = q.window[k];
     d->pair_cap = q.pair_capacity;
+    d->n_items = q.n_items;
 }
 
 extern "C" {
@@ -339,7 +611,7 @@ int plslam_grid_plan_create(plslam_ctx* ctx, const plslam_grid_problem* probs, i
     size_t words = 0;
     for (int32_t b = 0; b < nprob; ++b) {
         if ((rc = grid_check_problem(probs[b]))) return rc;
-        words += (grid_scratch_words(probs[b].n1, probs[b].n2, probs[b].pair_capacity) + 63) & ~size_t(63);
+        words += grid_prob_scratch(probs[b]);
     }
     DeviceGuard g(ctx->device);
     plslam_grid_plan* P = new (std::nothrow) plslam_grid_plan();
@@ -352,10 +624,17 @@ int plslam_grid_plan_create(plslam_ctx* ctx, const plslam_grid_problem* probs, i
     if ((rc = P->status.reserve(256))) return fail(rc);
     std::vector<GridDesc> tab((size_t)nprob);
     size_t off = 0;
-    for (int32_t b = 0; b < nprob; ++b) {
-        grid_fill_desc(probs[b], P->scratch.as<uint32_t>() + off, P->status.as<int32_t>(), &tab[b]);
-        off += (grid_scratch_words(probs[b].n1, probs[b].n2, probs[b].pair_capacity) + 63) & ~size_t(63);
-    }
+    int32_t slot = 0;
+    for (int mode = 2; mode >= 0; --mode)
+        for (int32_t b = 0; b < nprob; ++b) {
+            const int64_t ncell = (int64_t)probs[b].grid_cols * probs[b].grid_rows;
+            if (grid_mode(probs[b].n1, probs[b].n2, ncell, probs[b].n_items) != mode) continue;
+            const size_t lb = grid_lds_bytes(mode, probs[b].n1, probs[b].n2, ncell, probs[b].n_items);
+            if (lb > P->lds_bytes[mode]) P->lds_bytes[mode] = lb;
+            ++P->n_mode[mode];
+            grid_fill_desc(probs[b], P->scratch.as<uint32_t>() + off, P->status.as<int32_t>(), &tab[slot++]);
+            off += grid_prob_scratch(probs[b]);
+        }
     if (hipMemset(P->status.p, 0, 256) != hipSuccess ||
         (nprob && hipMemcpy(P->table.p, tab.data(), sizeof(GridDesc) * (size_t)nprob, hipMemcpyHostToDevice) !=
                       hipSuccess)) {
@@ -370,7 +649,7 @@ int plslam_grid_plan_run(plslam_grid_plan* plan, void* stream)
 {
     PLSLAM_REQUIRE(plan != nullptr, PLSLAM_EINVAL);
     DeviceGuard g(plan->ctx->device);
-    return launch_match_grid(plan->table.as<GridDesc>(), plan->nprob,
+    return launch_match_grid(plan->table.as<GridDesc>(), plan->n_mode, plan->lds_bytes,
                              stream ? static_cast<hipStream_t>(stream) : plan->ctx->stream);
 }
 
@@ -409,6 +688,7 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     q.d1 = d1; q.d2 = d2; q.centres1 = centres1; q.cell_start = cell_start; q.cell_items = cell_items;
     q.dir1 = dir1; q.dir2 = dir2;
     q.n1 = n1; q.n2 = n2; q.n_centres = n_centres; q.grid_cols = grid_cols; q.grid_rows = grid_rows;
+    q.n_items = 0;   // validated and set below
     for (int k = 0; k < 4; ++k) q.window[k] = window[k];
     q.sim_th = sim_th; q.nnr = nnr; q.mutual = mutual;
     q.matches_12 = matches_12;
@@ -420,16 +700,31 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     for (int64_t c = 0; c < ncell; ++c) PLSLAM_REQUIRE(cell_start[c + 1] >= cell_start[c], PLSLAM_EINVAL);
     const int32_t n_items = cell_start[ncell];
     PLSLAM_REQUIRE(n_items == 0 || cell_items, PLSLAM_EINVAL);
+    q.n_items = n_items;
+    // capacity of the candidate store: rows go in blocks of 1024, a block needs 1024 slots per candidate of its
+    // fullest row (mutual only; without it nothing is stored)
     int64_t pairs = 0;
-    for (int64_t k = 0; k < (int64_t)n1 * n_centres; ++k) {
-        const int64_t x = centres1[2 * k], y = centres1[2 * k + 1];
-        const int64_t min_x = x - window[0] > 0 ? x - window[0] : 0;
-        const int64_t max_x = x + window[1] + 1 < grid_cols ? x + window[1] + 1 : grid_cols;
-        const int64_t min_y = y - window[2] > 0 ? y - window[2] : 0;
-        const int64_t max_y = y + window[3] + 1 < grid_rows ? y + window[3] + 1 : grid_rows;
-        if (min_y >= max_y) continue;
-        for (int64_t x_ = min_x; x_ < max_x; ++x_)
-            pairs += cell_start[x_ * grid_rows + max_y] - cell_start[x_ * grid_rows + min_y];
+    if (mutual) {
+        int64_t depth = 0;
+        for (int32_t i1 = 0; i1 < n1; ++i1) {
+            int64_t cnt = 0;
+            for (int32_t c = 0; c < n_centres; ++c) {
+                const int64_t k = (int64_t)i1 * n_centres + c;
+                const int64_t x = centres1[2 * k], y = centres1[2 * k + 1];
+                const int64_t min_x = x - window[0] > 0 ? x - window[0] : 0;
+                const int64_t max_x = x + window[1] + 1 < grid_cols ? x + window[1] + 1 : grid_cols;
+                const int64_t min_y = y - window[2] > 0 ? y - window[2] : 0;
+                const int64_t max_y = y + window[3] + 1 < grid_rows ? y + window[3] + 1 : grid_rows;
+                if (min_y >= max_y) continue;
+                for (int64_t x_ = min_x; x_ < max_x; ++x_)
+                    cnt += cell_start[x_ * grid_rows + max_y] - cell_start[x_ * grid_rows + min_y];
+            }
+            if (cnt > depth) depth = cnt;
+            if ((i1 & 1023) == 1023 || i1 == n1 - 1) {
+                pairs += depth * 1024;
+                depth = 0;
+            }
+        }
     }
     PLSLAM_REQUIRE(pairs < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
     q.pair_capacity = (int32_t)pairs;
@@ -449,7 +744,7 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     if ((rc = ctx->in_a.reserve(ci.off))) return rc;
     if ((rc = ctx->pin_out.reserve(co.off))) return rc;
     if ((rc = ctx->out_a.reserve(co.off))) return rc;
-    if ((rc = ctx->misc_a.reserve(grid_scratch_words(n1, n2, q.pair_capacity) * 4))) return rc;
+    if ((rc = ctx->misc_a.reserve(grid_scratch_words(n1, n2, ncell, q.pair_capacity) * 4 + 256))) return rc;
     char* h = ctx->pin_in.as<char>();
     char* d = ctx->in_a.as<char>();
     char* dout = ctx->out_a.as<char>();
@@ -476,12 +771,17 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     hipStream_t s = ctx->stream;
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, ci.off, hipMemcpyHostToDevice, s));
     PLSLAM_HIP_CHECK(hipMemsetAsync(dout + oN, 0, 8, s));
-    if ((rc = launch_match_grid((const GridDesc*)(d + oT), 1, s))) return rc;
+    const int mode = grid_mode(n1, n2, ncell, n_items);
+    int32_t n_mode[3] = {0, 0, 0};
+    size_t lds_bytes[3] = {0, 0, 0};
+    n_mode[mode] = 1;
+    lds_bytes[mode] = grid_lds_bytes(mode, n1, n2, ncell, n_items);
+    if ((rc = launch_match_grid((const GridDesc*)(d + oT), n_mode, lds_bytes, s))) return rc;
     PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, dout, co.off, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     const int32_t* res = (const int32_t*)(ctx->pin_out.as<char>() + oN);
     if (res[1] != 0) {   // cannot happen: the capacity above is exact
-        set_last_error("%s:%d: matchGrid pair list overflow (%d pairs counted)", __FILE__, __LINE__, (int)pairs);
+        set_last_error("%s:%d: matchGrid candidate store overflow (%d slots provided)", __FILE__, __LINE__, (int)pairs);
         return PLSLAM_ERANGE;
     }
     memcpy(matches_12, ctx->pin_out.as<char>() + oM, (size_t)n1 * 4);

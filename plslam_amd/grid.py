@@ -74,17 +74,32 @@ def directions(segments):
         return v / np.sqrt(v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1])[:, None]
 
 
-def pair_count(centres, cell_start, cols, rows, window):
-    """(row, candidate) pairs a problem generates, duplicates included = plslam_grid_problem.pair_capacity."""
-    c = np.asarray(centres, np.int64).reshape(-1, 2)
+def row_item_counts(centres, cell_start, cols, rows, window):
+    """Grid items inside the window(s) of every row (duplicates / out-of-range items included). centres: n1 x c x 2."""
+    c = np.asarray(centres, np.int64)
+    c = c.reshape(c.shape[0], -1, 2)
     cs = np.asarray(cell_start, np.int64)
     w = [int(v) for v in window]
-    total = 0
-    for dx in range(-w[0], w[1] + 1):
-        x = c[:, 0] + dx
-        lo = np.clip(c[:, 1] - w[2], 0, rows)
-        hi = np.clip(c[:, 1] + w[3] + 1, 0, rows)
+    cnt = np.zeros(c.shape[0], np.int64)
+    lo = np.clip(c[:, :, 1] - w[2], 0, rows)
+    hi = np.clip(c[:, :, 1] + w[3] + 1, 0, rows)
+    for dx in range(-min(w[0], cols), min(w[1], cols) + 1):
+        x = c[:, :, 0] + dx
         ok = (x >= 0) & (x < cols) & (lo < hi)
         xs = np.where(ok, x, 0)
-        total += int(np.where(ok, cs[xs * rows + hi] - cs[xs * rows + lo], 0).sum())
-    return total
+        cnt += np.where(ok, cs[xs * rows + hi] - cs[xs * rows + lo], 0).sum(axis=1)
+    return cnt
+
+
+def pair_count(centres, cell_start, cols, rows, window):
+    """(row, candidate) pairs of a problem, duplicates included."""
+    return int(row_item_counts(centres, cell_start, cols, rows, window).sum())
+
+
+def store_capacity(centres, cell_start, cols, rows, window, mutual=True):
+    """plslam_grid_problem.pair_capacity: rows go in blocks of 1024; a block needs 1024 slots per candidate of its
+    fullest row (only mutual problems store candidates)."""
+    if not mutual:
+        return 0
+    cnt = row_item_counts(centres, cell_start, cols, rows, window)
+    return int(sum(1024 * int(cnt[b:b + 1024].max()) for b in range(0, len(cnt), 1024)))

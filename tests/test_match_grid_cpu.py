@@ -117,3 +117,4 @@ def test_pair_count_is_the_candidate_enumeration(oracle):
                 if lo < hi:
                     n += cs[x_ * 12 + hi] - cs[x_ * 12 + lo]
         assert G.pair_count(c["centres"], cs, 16, 12, w) == n
+        assert G.store_capacity(c["centres"], cs, 16, 12, w) >= n and G.store_capacity(c["centres"], cs, 16, 12, w, False) == 0

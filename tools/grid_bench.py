@@ -68,7 +68,8 @@ def main():
             cen = np.asarray(c["centres"], np.int32).reshape(c["d1"].shape[0], -1, 2)
             u = dict(d1=up(c["d1"], np.uint8), d2=up(c["d2"], np.uint8), cen=up(cen, np.int32),
                      cs=up(c["cell_start"], np.int32), it=up(c["cell_items"], np.int32), nc=cen.shape[1],
-                     cap=G.pair_count(cen.reshape(-1, 2), c["cell_start"], G.GRID_COLS, G.GRID_ROWS, W), lines=lines)
+                     cap=G.store_capacity(cen, c["cell_start"], G.GRID_COLS, G.GRID_ROWS, W),
+                     pairs=G.pair_count(cen, c["cell_start"], G.GRID_COLS, G.GRID_ROWS, W), lines=lines)
             if lines:
                 u.update(a=up(c["dir1"], np.float64), b=up(c["dir2"], np.float64))
             ups.append(u)
@@ -80,12 +81,12 @@ def main():
                 keep += [o, cnt]
                 q = dict(d1=u["d1"].data_ptr(), d2=u["d2"].data_ptr(), centres1=u["cen"].data_ptr(),
                          cell_start=u["cs"].data_ptr(), cell_items=u["it"].data_ptr(), n1=n1, n2=n2, n_centres=u["nc"],
-                         grid_cols=G.GRID_COLS, grid_rows=G.GRID_ROWS, window=W, nnr=0.75, mutual=True,
+                         grid_cols=G.GRID_COLS, grid_rows=G.GRID_ROWS, n_items=u["it"].shape[0], window=W, nnr=0.75, mutual=True,
                          pair_capacity=u["cap"], matches_12=o.data_ptr(), n_matches=cnt.data_ptr())
                 if u["lines"]:
                     q.update(dir1=u["a"].data_ptr(), dir2=u["b"].data_ptr(), sim_th=0.75)
                 probs.append(q)
-                pairs += u["cap"]
+                pairs += u["pairs"]
         plan = plslam_amd.GridPlan(ctx, probs)
         s = torch.cuda.Stream(device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
