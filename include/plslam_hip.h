@@ -355,6 +355,36 @@ int plslam_map2kf_match_lines(plslam_ctx* ctx, const plslam_cam* K, const double
                               int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
                               int32_t* map_to_kf, int32_t* n_matches);
 
+/* The same drivers with SlamConfig::fastMatching() (`fast_matching: true`, the shipped configurations):
+ * src/mapHandler.cpp:578-592 (points) / :681-707 (lines).  The candidates' projections become grid cells
+ * (pj_points / pj_lines: pixels * inv_width / inv_height truncated to int) on the device, the unmatched
+ * keyframe features fill the GridStructure (points: their cell, :581-584; lines: the Bresenham cells of
+ * (spl, epl) and their directions, :686-698), StVO::matchGrid runs with a window of `ws` cells and the
+ * ratio nnr_grid (Config::minRatio12P() for BOTH kinds); then, exactly as in the plain drivers,
+ * StVO::match(nnr) replaces its result when |Q| > min_matches && matches < min_matches (:594-598,
+ * :709-713).  *used_match (may be NULL) reports whether that happened.  fm == NULL or !fm->enabled is the
+ * plain driver.  kf_seg: n_kf x 4 doubles = stereo_ls[i]->spl, ->epl (lines only). */
+typedef struct plslam_fast_matching {
+    int32_t enabled;              /* SlamConfig::fastMatching() */
+    int32_t grid_cols, grid_rows; /* GRID_COLS (64), GRID_ROWS (48) */
+    int32_t ws;                   /* SlamConfig::matchingF2FWs() */
+    double inv_width, inv_height; /* StereoFrame::inv_width / inv_height (GRID_COLS / width, GRID_ROWS / height) */
+    double nnr_grid;              /* Config::minRatio12P() */
+    double line_sim_th;           /* Config::lineSimTh() */
+} plslam_fast_matching;
+int plslam_map2kf_match_points_fast(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* Xw,
+                                    const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                                    const uint8_t* kf_desc, const double* kf_pl, const int32_t* kf_idx,
+                                    int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
+                                    const plslam_fast_matching* fm, int32_t* map_to_kf, int32_t* n_matches,
+                                    int32_t* used_match);
+int plslam_map2kf_match_lines_fast(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* Lw,
+                                   const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                                   const uint8_t* kf_desc, const double* kf_le, const double* kf_seg,
+                                   const int32_t* kf_idx, int32_t n_kf, float nnr, int mutual, double max_epip,
+                                   int32_t min_matches, const plslam_fast_matching* fm, int32_t* map_to_kf,
+                                   int32_t* n_matches, int32_t* used_match);
+
 /* ---- representative ("median") descriptor of every landmark, batched ------------------------ */
 /* Replaces the descriptor part of MapPoint::updateAverageDescDir (src/mapFeatures.cpp:51-84) and of
  * MapLine::updateAverageDescDir (:121-157), which the reference runs per landmark whenever an

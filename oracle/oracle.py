@@ -22,6 +22,13 @@ _u8p = C.POINTER(C.c_uint8)
 _f64p = C.POINTER(C.c_double)
 
 
+class FastMatching(C.Structure):
+    """plo_fast_matching"""
+    _fields_ = [("enabled", C.c_int32), ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("ws", C.c_int32),
+                ("inv_width", C.c_double), ("inv_height", C.c_double), ("nnr_grid", C.c_double),
+                ("line_sim_th", C.c_double)]
+
+
 class Cam(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("b", C.c_double), ("width", C.c_int32), ("height", C.c_int32)]
@@ -86,6 +93,12 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.plo_lbd_binarise.restype = None
     lib.plo_lbd_binary_conversion.argtypes = [C.c_void_p, C.c_void_p]
     lib.plo_lbd_binary_conversion.restype = C.c_uint8
+    lib.plo_map2kf_match_points_fast.argtypes = [C.POINTER(Cam)] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 + \
+        [C.c_int32, C.c_float, C.c_int, C.c_double, C.c_int32, C.POINTER(FastMatching), C.c_void_p, C.POINTER(C.c_int32)]
+    lib.plo_map2kf_match_points_fast.restype = C.c_int32
+    lib.plo_map2kf_match_lines_fast.argtypes = [C.POINTER(Cam)] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 4 + \
+        [C.c_int32, C.c_float, C.c_int, C.c_double, C.c_int32, C.POINTER(FastMatching), C.c_void_p, C.POINTER(C.c_int32)]
+    lib.plo_map2kf_match_lines_fast.restype = C.c_int32
     lib.plo_match_grid.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
                                    C.c_void_p, C.c_double, C.c_int, C.c_void_p]
@@ -339,6 +352,32 @@ def map2kf_match(kind, cam, Twf, LM, med_desc, candidate, kf_desc, kf_feat, kf_i
     n = f(C.byref(cam), _p(Twf), _p(LM), _p(md), _p(cand), LM.shape[0], _p(kd), _p(kf), _p(ki), kd.shape[0],
           float(nnr), int(bool(mutual)), float(max_epip), int(min_matches), _p(out))
     return out, int(n)
+
+
+def map2kf_match_fast(kind, cam, Twf, LM, med_desc, candidate, kf_desc, kf_feat, kf_idx, nnr, mutual, max_epip,
+                      min_matches, fm, kf_seg=None):
+    """The drivers with SlamConfig::fastMatching() (src/mapHandler.cpp:578-598, :681-713) -> (map_to_kf, n, used_match).
+    fm: dict(enabled, grid_cols, grid_rows, ws, inv_width, inv_height, nnr_grid, line_sim_th)."""
+    lw, fw = (3, 2) if kind == "points" else (6, 3)
+    Twf = _c(Twf, np.float64).reshape(16)
+    LM = _c(LM, np.float64).reshape(-1, lw)
+    md, cand = _desc(med_desc), _c(candidate, np.uint8)
+    kd, kf = _desc(kf_desc), _c(kf_feat, np.float64).reshape(-1, fw)
+    ki = _c(kf_idx, np.int32)
+    out = np.empty(LM.shape[0], np.int32)
+    F = FastMatching(int(fm["enabled"]), int(fm["grid_cols"]), int(fm["grid_rows"]), int(fm["ws"]), float(fm["inv_width"]),
+                     float(fm["inv_height"]), float(fm["nnr_grid"]), float(fm.get("line_sim_th", 0.75)))
+    used = C.c_int32()
+    if kind == "points":
+        n = lib().plo_map2kf_match_points_fast(C.byref(cam), _p(Twf), _p(LM), _p(md), _p(cand), LM.shape[0], _p(kd), _p(kf),
+                                               _p(ki), kd.shape[0], float(nnr), int(bool(mutual)), float(max_epip),
+                                               int(min_matches), C.byref(F), _p(out), C.byref(used))
+    else:
+        sg = _c(kf_seg, np.float64).reshape(-1, 4)
+        n = lib().plo_map2kf_match_lines_fast(C.byref(cam), _p(Twf), _p(LM), _p(md), _p(cand), LM.shape[0], _p(kd), _p(kf),
+                                              _p(sg), _p(ki), kd.shape[0], float(nnr), int(bool(mutual)), float(max_epip),
+                                              int(min_matches), C.byref(F), _p(out), C.byref(used))
+    return out, int(n), int(used.value)
 
 
 def lbd_pairs():

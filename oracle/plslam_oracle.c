@@ -590,21 +590,23 @@ void plo_map_line_visible(const plo_cam* K, const double Twf[16], const double* 
 /* ------------------------------------------------------------------------------------ */
 static int32_t map2kf_driver(int lines, const plo_cam* K, const double Twf[16], const double* LM,
                              const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
-                             const uint8_t* kf_desc, const double* kf_feat, const int32_t* kf_idx,
-                             int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
-                             int32_t* map_to_kf)
+                             const uint8_t* kf_desc, const double* kf_feat, const double* kf_seg,
+                             const int32_t* kf_idx, int32_t n_kf, float nnr, int mutual, double max_epip,
+                             int32_t min_matches, const plo_fast_matching* fm, int32_t* map_to_kf,
+                             int32_t* used_match)
 {
     const int lw = lines ? 6 : 3, fw = lines ? 3 : 2;
     for (int32_t i = 0; i < n_map; ++i) map_to_kf[i] = -1;
+    if (used_match) *used_match = 0;
     uint8_t* vis = (uint8_t*)malloc((size_t)(n_map > 0 ? n_map : 1));
     if (lines) plo_map_line_visible(K, Twf, LM, n_map, vis); else plo_map_point_visible(K, Twf, LM, n_map, vis);
     int32_t* qi = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_map > 0 ? n_map : 1));
     int32_t* ti = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_kf > 0 ? n_kf : 1));
     int32_t nq = 0, nt = 0;
-    for (int32_t i = 0; i < n_map; ++i) if (candidate[i] && vis[i]) qi[nq++] = i;      /* :545-558 */
-    for (int32_t i = 0; i < n_kf; ++i) if (kf_idx[i] == -1) ti[nt++] = i;              /* :563-569 */
+    for (int32_t i = 0; i < n_map; ++i) if (candidate[i] && vis[i]) qi[nq++] = i;      /* :545-558 / :647-663 */
+    for (int32_t i = 0; i < n_kf; ++i) if (kf_idx[i] == -1) ti[nt++] = i;              /* :563-569 / :668-674 */
     int32_t matches = 0;
-    if (nq > 0 && nt > 0 && nq > min_matches) {                                         /* :571, :594-597 */
+    if (nq > 0 && nt > 0) {                                                             /* :571 / :676 */
         uint8_t* Q = (uint8_t*)malloc((size_t)nq * 32);
         uint8_t* T = (uint8_t*)malloc((size_t)nt * 32);
         double* QL = (double*)malloc(sizeof(double) * (size_t)nq * lw);
@@ -618,13 +620,95 @@ static int32_t map2kf_driver(int lines, const plo_cam* K, const double Twf[16], 
             memcpy(TF + (size_t)b * fw, kf_feat + (size_t)ti[b] * fw, sizeof(double) * fw);
         }
         int32_t* m12 = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
-        uint8_t* mask = (uint8_t*)malloc((size_t)nq);
-        plo_match(Q, nq, T, nt, nnr, mutual, m12);
-        matches = lines ? plo_map2kf_line_gate(K, Twf, QL, m12, nq, TF, max_epip, mask)
-                        : plo_map2kf_point_gate(K, Twf, QL, m12, nq, TF, max_epip, mask);
-        for (int32_t a = 0; a < nq; ++a)
-            if (mask[a]) map_to_kf[qi[a]] = ti[m12[a]];
-        free(mask); free(m12); free(TF); free(QL); free(T); free(Q);
+        int32_t n_m12 = 0;                         /* matches_12.size(): 0 until a matcher ran */
+        if (fm && fm->enabled) {                   /* :578-592 / :681-707 */
+            const int32_t cols = fm->grid_cols, rows = fm->grid_rows;
+            const int32_t w[4] = {fm->ws, fm->ws, fm->ws, fm->ws};
+            const int nc = lines ? 2 : 1;
+            int32_t* cen = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq * 2 * nc);
+            double* dir1 = lines ? (double*)malloc(sizeof(double) * (size_t)nq * 2) : NULL;
+            double* dir2 = lines ? (double*)malloc(sizeof(double) * (size_t)nt * 2) : NULL;
+            int32_t* cs = (int32_t*)malloc(sizeof(int32_t) * ((size_t)cols * rows + 1));
+            int32_t* items = NULL;
+            for (int32_t a = 0; a < nq; ++a)       /* pj_points / pj_lines: make_pair<int,int>(double, double) */
+                for (int c = 0; c < nc; ++c) {
+                    double Pf[3], pf[2];
+                    xform44(Twf, QL + (size_t)a * lw + 3 * c, Pf);
+                    project(K, Pf, pf);
+                    cen[((size_t)a * nc + c) * 2] = (int32_t)(pf[0] * fm->inv_width);
+                    cen[((size_t)a * nc + c) * 2 + 1] = (int32_t)(pf[1] * fm->inv_height);
+                }
+            if (!lines) {
+                int32_t* xy = (int32_t*)malloc(sizeof(int32_t) * (size_t)nt * 2);
+                for (int32_t b = 0; b < nt; ++b) {                                     /* :581-584 */
+                    xy[2 * b] = (int32_t)(TF[2 * (size_t)b] * fm->inv_width);
+                    xy[2 * b + 1] = (int32_t)(TF[2 * (size_t)b + 1] * fm->inv_height);
+                }
+                items = (int32_t*)malloc(sizeof(int32_t) * (size_t)nt);
+                plo_grid_fill_points(xy, nt, cols, rows, cs, items);
+                free(xy);
+            } else {
+                /* :686-699: directions + Bresenham cells of every unmatched keyframe line */
+                int32_t** cell_of = (int32_t**)malloc(sizeof(int32_t*) * (size_t)nt);
+                int32_t* ncell_of = (int32_t*)malloc(sizeof(int32_t) * (size_t)nt);
+                size_t total = 0;
+                for (size_t c = 0; c <= (size_t)cols * rows; ++c) cs[c] = 0;
+                for (int32_t b = 0; b < nt; ++b) {
+                    const double* sg = kf_seg + 4 * (size_t)ti[b];
+                    double v[2] = {(sg[2] - sg[0]) * fm->inv_width, (sg[3] - sg[1]) * fm->inv_height};
+                    plo_normalize2(v);
+                    dir2[2 * b] = v[0];
+                    dir2[2 * b + 1] = v[1];
+                    const double x1 = sg[0] * fm->inv_width, y1 = sg[1] * fm->inv_height, x2 = sg[2] * fm->inv_width,
+                                 y2 = sg[3] * fm->inv_height;
+                    const int32_t n = plo_get_line_coords(x1, y1, x2, y2, NULL, 0);
+                    cell_of[b] = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(n > 0 ? n : 1));
+                    plo_get_line_coords(x1, y1, x2, y2, cell_of[b], n);
+                    ncell_of[b] = n;
+                    for (int32_t k = 0; k < n; ++k) {
+                        const int32_t x = cell_of[b][2 * k], y = cell_of[b][2 * k + 1];
+                        if (x >= 0 && x < cols && y >= 0 && y < rows) { ++cs[(size_t)x * rows + y + 1]; ++total; }
+                    }
+                }
+                for (size_t c = 0; c < (size_t)cols * rows; ++c) cs[c + 1] += cs[c];
+                items = (int32_t*)malloc(sizeof(int32_t) * (total > 0 ? total : 1));
+                int32_t* fill = (int32_t*)malloc(sizeof(int32_t) * (size_t)cols * rows);
+                for (size_t c = 0; c < (size_t)cols * rows; ++c) fill[c] = cs[c];
+                for (int32_t b = 0; b < nt; ++b) {                                     /* push_back order: idx ascending */
+                    for (int32_t k = 0; k < ncell_of[b]; ++k) {
+                        const int32_t x = cell_of[b][2 * k], y = cell_of[b][2 * k + 1];
+                        if (x >= 0 && x < cols && y >= 0 && y < rows) items[fill[(size_t)x * rows + y]++] = b;
+                    }
+                    free(cell_of[b]);
+                }
+                free(fill); free(ncell_of); free(cell_of);
+                for (int32_t a = 0; a < nq; ++a) { /* matchGrid derives the query direction from the integer end points */
+                    double v[2] = {(double)(cen[4 * (size_t)a + 2] - cen[4 * (size_t)a]),
+                                   (double)(cen[4 * (size_t)a + 3] - cen[4 * (size_t)a + 1])};
+                    plo_normalize2(v);
+                    dir1[2 * a] = v[0];
+                    dir1[2 * a + 1] = v[1];
+                }
+            }
+            matches = plo_match_grid(cen, nc, Q, nq, cs, items, cols, rows, T, nt, dir1, dir2, fm->line_sim_th, w,
+                                     fm->nnr_grid, mutual, m12);
+            n_m12 = nq;
+            free(items); free(cs); free(dir2); free(dir1); free(cen);
+        }
+        if (nq > min_matches && matches < min_matches) {                               /* :594-598 / :709-713 */
+            matches = plo_match(Q, nq, T, nt, nnr, mutual, m12);
+            n_m12 = nq;
+            if (used_match) *used_match = 1;
+        }
+        if (n_m12) {
+            uint8_t* mask = (uint8_t*)malloc((size_t)nq);
+            matches = lines ? plo_map2kf_line_gate(K, Twf, QL, m12, nq, TF, max_epip, mask)
+                            : plo_map2kf_point_gate(K, Twf, QL, m12, nq, TF, max_epip, mask);
+            for (int32_t a = 0; a < nq; ++a)
+                if (mask[a]) map_to_kf[qi[a]] = ti[m12[a]];
+            free(mask);
+        }
+        free(m12); free(TF); free(QL); free(T); free(Q);
     }
     free(ti); free(qi); free(vis);
     return matches;
@@ -636,8 +720,8 @@ int32_t plo_map2kf_match_points(const plo_cam* K, const double Twf[16], const do
                                 int32_t n_kf, float nnr, int mutual, double max_epip,
                                 int32_t min_matches, int32_t* map_to_kf)
 {
-    return map2kf_driver(0, K, Twf, Xw, med_desc, candidate, n_map, kf_desc, kf_pl, kf_idx, n_kf, nnr,
-                         mutual, max_epip, min_matches, map_to_kf);
+    return map2kf_driver(0, K, Twf, Xw, med_desc, candidate, n_map, kf_desc, kf_pl, NULL, kf_idx, n_kf, nnr,
+                         mutual, max_epip, min_matches, NULL, map_to_kf, NULL);
 }
 
 int32_t plo_map2kf_match_lines(const plo_cam* K, const double Twf[16], const double* Lw,
@@ -646,8 +730,29 @@ int32_t plo_map2kf_match_lines(const plo_cam* K, const double Twf[16], const dou
                                int32_t n_kf, float nnr, int mutual, double max_epip,
                                int32_t min_matches, int32_t* map_to_kf)
 {
-    return map2kf_driver(1, K, Twf, Lw, med_desc, candidate, n_map, kf_desc, kf_le, kf_idx, n_kf, nnr,
-                         mutual, max_epip, min_matches, map_to_kf);
+    return map2kf_driver(1, K, Twf, Lw, med_desc, candidate, n_map, kf_desc, kf_le, NULL, kf_idx, n_kf, nnr,
+                         mutual, max_epip, min_matches, NULL, map_to_kf, NULL);
+}
+
+int32_t plo_map2kf_match_points_fast(const plo_cam* K, const double Twf[16], const double* Xw,
+                                     const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                                     const uint8_t* kf_desc, const double* kf_pl, const int32_t* kf_idx,
+                                     int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
+                                     const plo_fast_matching* fm, int32_t* map_to_kf, int32_t* used_match)
+{
+    return map2kf_driver(0, K, Twf, Xw, med_desc, candidate, n_map, kf_desc, kf_pl, NULL, kf_idx, n_kf, nnr,
+                         mutual, max_epip, min_matches, fm, map_to_kf, used_match);
+}
+
+int32_t plo_map2kf_match_lines_fast(const plo_cam* K, const double Twf[16], const double* Lw,
+                                    const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                                    const uint8_t* kf_desc, const double* kf_le, const double* kf_seg,
+                                    const int32_t* kf_idx, int32_t n_kf, float nnr, int mutual, double max_epip,
+                                    int32_t min_matches, const plo_fast_matching* fm, int32_t* map_to_kf,
+                                    int32_t* used_match)
+{
+    return map2kf_driver(1, K, Twf, Lw, med_desc, candidate, n_map, kf_desc, kf_le, kf_seg, kf_idx, n_kf, nnr,
+                         mutual, max_epip, min_matches, fm, map_to_kf, used_match);
 }
 
 /* ------------------------------------------------------------------------------------ */

@@ -148,6 +148,34 @@ int32_t plo_map2kf_match_lines(const plo_cam* K, const double Twf[16], const dou
                                int32_t n_kf, float nnr, int mutual, double max_epip,
                                int32_t min_matches, int32_t* map_to_kf);
 
+/* ---- the same drivers with SlamConfig::fastMatching() (the shipped configurations) ----------
+ * src/mapHandler.cpp:578-592 (points) / :681-707 (lines): project the candidates into the keyframe
+ * (pj_points / pj_lines in grid units, truncated to int by make_pair<int,int>), fill a GridStructure with
+ * the unmatched keyframe features (points: their cell; lines: their Bresenham cells + directions), window
+ * of matching_f2f_ws cells, matchGrid (ratio Config::minRatio12P() for BOTH kinds); then, as in the plain
+ * drivers, StVO::match replaces the result when `|Q| > min_matches && matches < min_matches` (:594-598,
+ * :709-713; lines use minRatio12L there).  *used_match (may be NULL) tells whether that happened.
+ * kf_seg: n_kf x 4 = (spl, epl) pixel end points of the keyframe lines (only lines, only when enabled). */
+typedef struct {
+    int32_t enabled;              /* SlamConfig::fastMatching() */
+    int32_t grid_cols, grid_rows; /* GRID_COLS, GRID_ROWS */
+    int32_t ws;                   /* SlamConfig::matchingF2FWs() */
+    double inv_width, inv_height; /* StereoFrame::inv_width / inv_height = GRID_COLS / width, GRID_ROWS / height */
+    double nnr_grid;              /* Config::minRatio12P() */
+    double line_sim_th;           /* Config::lineSimTh() */
+} plo_fast_matching;
+int32_t plo_map2kf_match_points_fast(const plo_cam* K, const double Twf[16], const double* Xw,
+                                     const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                                     const uint8_t* kf_desc, const double* kf_pl, const int32_t* kf_idx,
+                                     int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
+                                     const plo_fast_matching* fm, int32_t* map_to_kf, int32_t* used_match);
+int32_t plo_map2kf_match_lines_fast(const plo_cam* K, const double Twf[16], const double* Lw,
+                                    const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                                    const uint8_t* kf_desc, const double* kf_le, const double* kf_seg,
+                                    const int32_t* kf_idx, int32_t n_kf, float nnr, int mutual, double max_epip,
+                                    int32_t min_matches, const plo_fast_matching* fm, int32_t* map_to_kf,
+                                    int32_t* used_match);
+
 /* ---- stvo-pl matchGrid: the windowed ("fast_matching") matcher ------------------------------
  * Call sites in the reference: src/mapHandler.cpp:271 (points, KF<->KF), :418 (lines), :591 (map points
  * <-> KF), :706 (map lines <-> KF); the grid is filled by the callers at :258-264, :395-411, :580-584,

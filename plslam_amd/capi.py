@@ -32,6 +32,7 @@ ABI_SYMBOLS = (
     "plslam_lba_plan_rows", "plslam_lba_plan_destroy",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
+    "plslam_map2kf_match_points_fast", "plslam_map2kf_match_lines_fast",
     "plslam_lbd_binarise", "plslam_lbd_binarise_dev",
     "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
     "plslam_match_grid", "plslam_grid_plan_create", "plslam_grid_plan_run", "plslam_grid_plan_overflows",
@@ -61,6 +62,13 @@ class GridProblem(C.Structure):
                 ("grid_rows", C.c_int32), ("n_items", C.c_int32), ("window", C.c_int32 * 4), ("sim_th", C.c_double), ("nnr", C.c_double),
                 ("mutual", C.c_int32), ("pair_capacity", C.c_int32), ("matches_12", C.c_void_p),
                 ("n_matches", C.c_void_p)]
+
+
+class FastMatching(C.Structure):
+    """plslam_fast_matching"""
+    _fields_ = [("enabled", C.c_int32), ("grid_cols", C.c_int32), ("grid_rows", C.c_int32), ("ws", C.c_int32),
+                ("inv_width", C.c_double), ("inv_height", C.c_double), ("nnr_grid", C.c_double),
+                ("line_sim_th", C.c_double)]
 
 
 class PlanInfo(C.Structure):
@@ -162,6 +170,12 @@ def load() -> C.CDLL:
     for f in (L.plslam_map2kf_match_points, L.plslam_map2kf_match_lines):
         f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_float, C.c_int, f64, i32, vp,
                       C.POINTER(i32)]
+    L.plslam_map2kf_match_points_fast.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, vp, i32, vp, vp, vp, i32, C.c_float,
+                                                  C.c_int, f64, i32, C.POINTER(FastMatching), vp, C.POINTER(i32),
+                                                  C.POINTER(i32)]
+    L.plslam_map2kf_match_lines_fast.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, C.c_float,
+                                                 C.c_int, f64, i32, C.POINTER(FastMatching), vp, C.POINTER(i32),
+                                                 C.POINTER(i32)]
     L.plslam_match_grid.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, vp, vp, f64, vp, f64, C.c_int, vp,
                                     C.POINTER(i32)]
     L.plslam_grid_plan_create.argtypes = [vp, C.POINTER(GridProblem), i32, C.POINTER(vp)]
@@ -429,6 +443,36 @@ class Context:
                   kd.shape[0], float(nnr), int(bool(mutual)), float(max_epip), int(min_matches), _p(out),
                   C.byref(n)), "plslam_map2kf_match_" + kind)
         return out, n.value
+
+    def map2kf_match_fast(self, kind, cam, Twf, LM, med_desc, candidate, kf_desc, kf_feat, kf_idx, nnr, mutual,
+                          max_epip, min_matches, fm, kf_seg=None):
+        """The drivers with SlamConfig::fastMatching() (matchGrid first, StVO::match when it finds too little)
+        -> (map_to_kf, n_matches, used_match).  fm: dict with the fields of plslam_fast_matching."""
+        lw, fw = (3, 2) if kind == "points" else (6, 3)
+        Twf = _arr(Twf, np.float64, (16,))
+        LM = _arr(LM, np.float64, (-1, lw))
+        md, cand = _arr(med_desc, np.uint8, (-1, 32)), _arr(candidate, np.uint8)
+        kd, kf = _arr(kf_desc, np.uint8, (-1, 32)), _arr(kf_feat, np.float64, (-1, fw))
+        ki = _arr(kf_idx, np.int32)
+        out = np.empty(LM.shape[0], np.int32)
+        F = FastMatching(int(fm["enabled"]), int(fm["grid_cols"]), int(fm["grid_rows"]), int(fm["ws"]),
+                         float(fm["inv_width"]), float(fm["inv_height"]), float(fm["nnr_grid"]),
+                         float(fm.get("line_sim_th", 0.75)))
+        n, used = C.c_int32(), C.c_int32()
+        if kind == "points":
+            _check(self._L.plslam_map2kf_match_points_fast(self._h, C.byref(cam), _p(Twf), _p(LM), _p(md), _p(cand),
+                                                           LM.shape[0], _p(kd), _p(kf), _p(ki), kd.shape[0], float(nnr),
+                                                           int(bool(mutual)), float(max_epip), int(min_matches),
+                                                           C.byref(F), _p(out), C.byref(n), C.byref(used)),
+                   "plslam_map2kf_match_points_fast")
+        else:
+            sg = _arr(kf_seg, np.float64, (-1, 4))
+            _check(self._L.plslam_map2kf_match_lines_fast(self._h, C.byref(cam), _p(Twf), _p(LM), _p(md), _p(cand),
+                                                          LM.shape[0], _p(kd), _p(kf), _p(sg), _p(ki), kd.shape[0],
+                                                          float(nnr), int(bool(mutual)), float(max_epip),
+                                                          int(min_matches), C.byref(F), _p(out), C.byref(n),
+                                                          C.byref(used)), "plslam_map2kf_match_lines_fast")
+        return out, n.value, used.value
 
     # ---- device-pointer calls ----------------------------------------------------------------
     def lba_point_rows_dev(self, cam, homog_th, T, Xw, uv, lm, kf, nobs, Jp, Jl, r, w, stream=0):

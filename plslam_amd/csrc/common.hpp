@@ -175,6 +175,9 @@ int launch_line_gate(const plslam_cam& K, const double* Twf16, const double* Lw,
                      hipStream_t s);
 int launch_visible(const plslam_cam& K, const double* Twf16, const double* X, int32_t n, int lines,
                    uint8_t* vis, hipStream_t s);
+// cells (n x [1|2] x 2 int32) of the projected landmarks in grid units; lines: also dir1 (n x 2)
+int launch_project_cells(const plslam_cam& K, const double* Twf16, const double* X, int32_t n, int lines, double inv_w,
+                         double inv_h, int32_t* cells, double* dir1, hipStream_t s);
 
 // --- representative descriptor per landmark (median_desc.hip) ---------------------------------
 // desc: total x 32 u8 (4-byte aligned), off: n_lm+1 CSR offsets (device), med_idx: n_lm, med_desc:
@@ -206,6 +209,11 @@ bool grid_fits_lds(int32_t n1, int32_t n2, int64_t ncell);
 size_t grid_lds_bytes(int mode, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items);
 int grid_mode(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items);   // 2: all in LDS, 1: tables in LDS, 0: global
 size_t grid_scratch_words(int32_t n1, int32_t n2, int64_t ncell, int32_t pair_cap);
+int64_t grid_store_capacity_host(const int32_t* centres, int32_t n1, int32_t n_centres, const int32_t* cell_start,
+                                 int32_t cols, int32_t rows, const int32_t window[4], int mutual);
+// one problem with DEVICE pointers on `s` (scratch: grid_scratch_words() words; status: one zeroed int32)
+int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* d_desc_slot,
+                          GridDesc* h_desc_slot, hipStream_t s);
 // table order: the n[2] problems of mode 2, then the n[1] of mode 1, then the n[0] of mode 0
 int launch_match_grid(const GridDesc* d_probs, const int32_t n[3], const size_t lds_bytes[3], hipStream_t s);
 

@@ -330,4 +330,42 @@ int launch_visible(const plslam_cam& K, const double* Twf16, const double* X, in
     return PLSLAM_OK;
 }
 
+// pj_points / pj_lines of the fast_matching drivers (:553-555, :656-661): projection of the (already gathered)
+// candidate landmarks in grid units, truncated toward zero as std::make_pair<int,int>(double, double) does; for
+// lines also the unit direction matchGrid derives from the two INTEGER end points (zero vector -> NaN)
+__global__ void __launch_bounds__(256)
+k_project_cells(CamD K, Pose12 Twf, const double* __restrict__ X, int32_t n, int lines, double inv_w, double inv_h,
+                int32_t* __restrict__ cells, double* __restrict__ dir1)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int nc = lines ? 2 : 1;
+    int32_t c[4];
+    for (int e = 0; e < nc; ++e) {
+        double P[3], u, v;
+        xform44(Twf, X + (size_t)i * 3 * nc + 3 * e, P);
+        project(K, P, u, v);
+        c[2 * e] = (int32_t)(u * inv_w);
+        c[2 * e + 1] = (int32_t)(v * inv_h);
+        cells[((size_t)i * nc + e) * 2] = c[2 * e];
+        cells[((size_t)i * nc + e) * 2 + 1] = c[2 * e + 1];
+    }
+    if (lines) {
+        const double vx = (double)(c[2] - c[0]), vy = (double)(c[3] - c[1]);
+        const double magnitude = sqrt(vx * vx + vy * vy);
+        dir1[2 * (size_t)i] = vx / magnitude;
+        dir1[2 * (size_t)i + 1] = vy / magnitude;
+    }
+}
+
+int launch_project_cells(const plslam_cam& K, const double* Twf16, const double* X, int32_t n, int lines, double inv_w,
+                         double inv_h, int32_t* cells, double* dir1, hipStream_t s)
+{
+    if (n <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_project_cells, dim3((n + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), X, n, lines,
+                       inv_w, inv_h, cells, dir1);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
 }  // namespace plslam

@@ -1,9 +1,13 @@
 // map2kf.hip -- the map <-> keyframe association drivers of the reference as fused entry points:
-// MapHandler::matchMap2KFPoints (src/mapHandler.cpp:532-632) and matchMap2KFLines (:634-752), brute
-// force path (fast_matching == false), without the map mutation (that bookkeeping stays with the
-// caller).  Projection / visibility pre-filter, Q/T descriptor matrix construction, the StVO::match
-// itself and the epipolar inlier gate all run on the MI355X; the host only turns the visibility
-// mask into index lists (one small D2H), exactly the role of the reference's std::vector building.
+// MapHandler::matchMap2KFPoints (src/mapHandler.cpp:532-632) and matchMap2KFLines (:634-752), with and
+// without SlamConfig::fastMatching(), without the map mutation (that bookkeeping stays with the
+// caller).  Projection / visibility pre-filter, Q/T descriptor matrix construction, the projection of
+// the candidates into grid cells, StVO::matchGrid / StVO::match and the epipolar inlier gate all run on
+// the MI355X; the host turns the visibility mask into index lists and fills the GridStructure (cell
+// lists of the unmatched keyframe features, :580-584 / :683-699) -- the list building the reference's
+// callers do with std::vector / std::list.
+#include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "common.hpp"
@@ -39,13 +43,55 @@ struct Carve {
     size_t take(size_t bytes) { const size_t o = off; off += (bytes + 255) & ~size_t(255); return o; }
 };
 
+// getLineCoords of stvo-pl ([RECALL]; the callers' grid fill :693-697): Bresenham cells, the last x excluded
+void line_cells(double x1, double y1, double x2, double y2, std::vector<int32_t>& xy)
+{
+    xy.clear();
+    const bool steep = std::fabs(y2 - y1) > std::fabs(x2 - x1);
+    if (steep) { std::swap(x1, y1); std::swap(x2, y2); }
+    if (x1 > x2) { std::swap(x1, x2); std::swap(y1, y2); }
+    const double dx = x2 - x1, dy = std::fabs(y2 - y1);
+    double error = dx / 2.0;
+    const int ystep = (y1 < y2) ? 1 : -1;
+    int y = (int)y1;
+    const int maxX = (int)x2;
+    for (int x = (int)x1; x < maxX; x++) {
+        xy.push_back(steep ? y : x);
+        xy.push_back(steep ? x : y);
+        error -= dy;
+        if (error < 0) { y += ystep; error += dx; }
+    }
+}
+
+// GridStructure fill in CSR form: `cells` lists (item, x, y) in push_back order
+void csr_fill(const std::vector<int32_t>& item, const std::vector<int32_t>& cx, const std::vector<int32_t>& cy,
+              int32_t cols, int32_t rows, std::vector<int32_t>& cs, std::vector<int32_t>& items)
+{
+    cs.assign((size_t)cols * rows + 1, 0);
+    for (size_t k = 0; k < item.size(); ++k)
+        if (cx[k] >= 0 && cx[k] < cols && cy[k] >= 0 && cy[k] < rows) ++cs[(size_t)cx[k] * rows + cy[k] + 1];
+    for (size_t c = 0; c < (size_t)cols * rows; ++c) cs[c + 1] += cs[c];
+    items.assign((size_t)cs.back() + 1, 0);
+    std::vector<int32_t> fill(cs.begin(), cs.end() - 1);
+    for (size_t k = 0; k < item.size(); ++k)
+        if (cx[k] >= 0 && cx[k] < cols && cy[k] >= 0 && cy[k] < rows) items[(size_t)fill[(size_t)cx[k] * rows + cy[k]]++] = item[k];
+}
+
 int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* Twf, const double* LM,
                   const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map, const uint8_t* kf_desc,
-                  const double* kf_feat, const int32_t* kf_idx, int32_t n_kf, float nnr, int mutual,
-                  double max_epip, int32_t min_matches, int32_t* map_to_kf, int32_t* n_matches)
+                  const double* kf_feat, const double* kf_seg, const int32_t* kf_idx, int32_t n_kf, float nnr,
+                  int mutual, double max_epip, int32_t min_matches, const plslam_fast_matching* fm,
+                  int32_t* map_to_kf, int32_t* n_matches, int32_t* used_match)
 {
     PLSLAM_REQUIRE(ctx && K && Twf && n_map >= 0 && n_kf >= 0, PLSLAM_EINVAL);
+    const bool fast = fm && fm->enabled;
+    if (fast) {
+        PLSLAM_REQUIRE(fm->grid_cols >= 1 && fm->grid_rows >= 1 && fm->ws >= 0, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE((int64_t)fm->grid_cols * fm->grid_rows < (int64_t(1) << 30), PLSLAM_ERANGE);
+        PLSLAM_REQUIRE(!lines || kf_seg || n_kf == 0, PLSLAM_EINVAL);
+    }
     if (n_matches) *n_matches = 0;
+    if (used_match) *used_match = 0;
     if (n_map == 0) return PLSLAM_OK;
     PLSLAM_REQUIRE(LM && med_desc && candidate && map_to_kf, PLSLAM_EINVAL);
     PLSLAM_REQUIRE(n_kf == 0 || (kf_desc && kf_feat && kf_idx), PLSLAM_EINVAL);
@@ -85,7 +131,7 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     for (int32_t i = 0; i < n_map; ++i)
         if (candidate[i] && vis[i]) qi.push_back(i);
     const int32_t nq = (int32_t)qi.size();
-    if (nq == 0 || nq <= min_matches) return PLSLAM_OK;                   // :571, :594-596 / :709-711
+    if (nq == 0) return PLSLAM_OK;                                        // :571 / :676
 
     // ---- build the Q / T matrices on the device, match, gate ----------------------------------
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oQi, qi.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
@@ -94,10 +140,88 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     if ((rc = launch_gather_rows(d + oKD, (int32_t*)(d + oTi), nt, 32, d + oT, s))) return rc;
     if ((rc = launch_gather_rows(d + oLM, (int32_t*)(d + oQi), nq, lw * 8, d + oQL, s))) return rc;
     if ((rc = launch_gather_rows(d + oKF, (int32_t*)(d + oTi), nt, fw * 8, d + oTF, s))) return rc;
-    plslam_match_problem p{};
-    p.d1 = (uint8_t*)(d + oQ); p.n1 = nq; p.d2 = (uint8_t*)(d + oT); p.n2 = nt;
-    p.nnr = nnr; p.mutual = mutual ? 1 : 0; p.matches_12 = (int32_t*)(d + oM); p.n_matches = nullptr;
-    if ((rc = match_problems_on_ctx_stream(ctx, &p, 1))) return rc;       // :597 / :712
+    int32_t matches = 0;
+    bool have_m12 = false;                       // matches_12.size() != 0: a matcher ran
+    if (fast) {                                  // :578-592 / :681-707
+        const int nc = lines ? 2 : 1;
+        const int32_t cols = fm->grid_cols, rows = fm->grid_rows;
+        const int32_t win[4] = {fm->ws, fm->ws, fm->ws, fm->ws};
+        // pj_points / pj_lines: the candidates' projections in grid cells, computed on the device
+        Carve cf;
+        const size_t oCen = cf.take((size_t)nq * nc * 8), oD1 = cf.take(lines ? (size_t)nq * 16 : 0),
+                     oD2 = cf.take(lines ? (size_t)nt * 16 : 0), oCs = cf.take(((size_t)cols * rows + 1) * 4),
+                     oDesc = cf.take(sizeof(GridDesc)), oSt = cf.take(8);
+        std::vector<int32_t> cen((size_t)nq * nc * 2), cs, items, it, cx, cy, xy;
+        std::vector<double> dir2;
+        // the grid of the unmatched keyframe features (host list building, as in the reference's callers)
+        if (!lines) {
+            for (int32_t b = 0; b < nt; ++b) {                                          // :581-584
+                it.push_back(b);
+                cx.push_back((int32_t)(kf_feat[2 * (size_t)ti[b]] * fm->inv_width));
+                cy.push_back((int32_t)(kf_feat[2 * (size_t)ti[b] + 1] * fm->inv_height));
+            }
+        } else {
+            dir2.resize((size_t)nt * 2);
+            for (int32_t b = 0; b < nt; ++b) {                                          // :686-698
+                const double* sg = kf_seg + 4 * (size_t)ti[b];
+                double vx = (sg[2] - sg[0]) * fm->inv_width, vy = (sg[3] - sg[1]) * fm->inv_height;
+                const double magnitude = std::sqrt(vx * vx + vy * vy);
+                dir2[2 * (size_t)b] = vx / magnitude;
+                dir2[2 * (size_t)b + 1] = vy / magnitude;
+                line_cells(sg[0] * fm->inv_width, sg[1] * fm->inv_height, sg[2] * fm->inv_width, sg[3] * fm->inv_height, xy);
+                for (size_t k = 0; k + 1 < xy.size(); k += 2) {
+                    it.push_back(b);
+                    cx.push_back(xy[k]);
+                    cy.push_back(xy[k + 1]);
+                }
+            }
+        }
+        csr_fill(it, cx, cy, cols, rows, cs, items);
+        const int32_t n_items = cs.back();
+        const size_t oIt = cf.take((size_t)(n_items + 1) * 4);
+        if ((rc = ctx->misc_b.reserve(cf.off))) return rc;
+        char* f = ctx->misc_b.as<char>();
+        if ((rc = launch_project_cells(*K, Twf, (double*)(d + oQL), nq, lines, fm->inv_width, fm->inv_height,
+                                       (int32_t*)(f + oCen), lines ? (double*)(f + oD1) : nullptr, s)))
+            return rc;
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(cen.data(), f + oCen, (size_t)nq * nc * 8, hipMemcpyDeviceToHost, s));
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oCs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, s));
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oIt, items.data(), (size_t)(n_items + 1) * 4, hipMemcpyHostToDevice, s));
+        if (lines) PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oD2, dir2.data(), (size_t)nt * 16, hipMemcpyHostToDevice, s));
+        PLSLAM_HIP_CHECK(hipMemsetAsync(f + oSt, 0, 8, s));
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));                                       // cells on the host: store size
+        const int64_t cap = grid_store_capacity_host(cen.data(), nq, nc, cs.data(), cols, rows, win, mutual);
+        PLSLAM_REQUIRE(cap < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
+        if ((rc = ctx->misc_c.reserve(grid_scratch_words(nq, nt, (int64_t)cols * rows, (int32_t)cap) * 4 + 256))) return rc;
+        plslam_grid_problem q{};
+        q.d1 = (uint8_t*)(d + oQ); q.d2 = (uint8_t*)(d + oT); q.centres1 = (int32_t*)(f + oCen);
+        q.cell_start = (int32_t*)(f + oCs); q.cell_items = (int32_t*)(f + oIt);
+        q.dir1 = lines ? (double*)(f + oD1) : nullptr; q.dir2 = lines ? (double*)(f + oD2) : nullptr;
+        q.n1 = nq; q.n2 = nt; q.n_centres = nc; q.grid_cols = cols; q.grid_rows = rows; q.n_items = n_items;
+        for (int k = 0; k < 4; ++k) q.window[k] = win[k];
+        q.sim_th = fm->line_sim_th; q.nnr = fm->nnr_grid; q.mutual = mutual ? 1 : 0;
+        q.pair_capacity = (int32_t)cap;
+        q.matches_12 = (int32_t*)(d + oM); q.n_matches = (int32_t*)(f + oSt);
+        GridDesc hdesc;
+        if ((rc = launch_match_grid_one(q, ctx->misc_c.as<uint32_t>(), (int32_t*)(f + oSt) + 1, (GridDesc*)(f + oDesc),
+                                        &hdesc, s)))
+            return rc;
+        int32_t res[2] = {0, 0};
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(res, f + oSt, 8, hipMemcpyDeviceToHost, s));
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));                                       // also keeps hdesc alive long enough
+        PLSLAM_REQUIRE(res[1] == 0, PLSLAM_ERANGE);
+        matches = res[0];
+        have_m12 = true;
+    }
+    if (nq > min_matches && matches < min_matches) {                     // :594-598 / :709-713
+        plslam_match_problem p{};
+        p.d1 = (uint8_t*)(d + oQ); p.n1 = nq; p.d2 = (uint8_t*)(d + oT); p.n2 = nt;
+        p.nnr = nnr; p.mutual = mutual ? 1 : 0; p.matches_12 = (int32_t*)(d + oM); p.n_matches = nullptr;
+        if ((rc = match_problems_on_ctx_stream(ctx, &p, 1))) return rc;   // :597 / :712
+        have_m12 = true;
+        if (used_match) *used_match = 1;
+    }
+    if (!have_m12) return PLSLAM_OK;
     rc = lines ? launch_line_gate(*K, Twf, (double*)(d + oQL), (int32_t*)(d + oM), nq, (double*)(d + oTF),
                                   max_epip, (uint8_t*)(d + oMask), (int32_t*)(d + oCnt), s)
                : launch_point_gate(*K, Twf, (double*)(d + oQL), (int32_t*)(d + oM), nq, (double*)(d + oTF),
@@ -126,8 +250,8 @@ int plslam_map2kf_match_points(plslam_ctx* ctx, const plslam_cam* K, const doubl
                                int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
                                int32_t* map_to_kf, int32_t* n_matches)
 {
-    return plslam::map2kf_driver(ctx, 0, K, Twf, Xw, med_desc, candidate, n_map, kf_desc, kf_pl, kf_idx, n_kf,
-                                 nnr, mutual, max_epip, min_matches, map_to_kf, n_matches);
+    return plslam::map2kf_driver(ctx, 0, K, Twf, Xw, med_desc, candidate, n_map, kf_desc, kf_pl, nullptr, kf_idx, n_kf,
+                                 nnr, mutual, max_epip, min_matches, nullptr, map_to_kf, n_matches, nullptr);
 }
 
 int plslam_map2kf_match_lines(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* Lw,
@@ -136,8 +260,30 @@ int plslam_map2kf_match_lines(plslam_ctx* ctx, const plslam_cam* K, const double
                               int32_t n_kf, float nnr, int mutual, double max_epip, int32_t min_matches,
                               int32_t* map_to_kf, int32_t* n_matches)
 {
-    return plslam::map2kf_driver(ctx, 1, K, Twf, Lw, med_desc, candidate, n_map, kf_desc, kf_le, kf_idx, n_kf,
-                                 nnr, mutual, max_epip, min_matches, map_to_kf, n_matches);
+    return plslam::map2kf_driver(ctx, 1, K, Twf, Lw, med_desc, candidate, n_map, kf_desc, kf_le, nullptr, kf_idx, n_kf,
+                                 nnr, mutual, max_epip, min_matches, nullptr, map_to_kf, n_matches, nullptr);
+}
+
+int plslam_map2kf_match_points_fast(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* Xw,
+                                    const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                                    const uint8_t* kf_desc, const double* kf_pl, const int32_t* kf_idx, int32_t n_kf,
+                                    float nnr, int mutual, double max_epip, int32_t min_matches,
+                                    const plslam_fast_matching* fm, int32_t* map_to_kf, int32_t* n_matches,
+                                    int32_t* used_match)
+{
+    return plslam::map2kf_driver(ctx, 0, K, Twf, Xw, med_desc, candidate, n_map, kf_desc, kf_pl, nullptr, kf_idx, n_kf,
+                                 nnr, mutual, max_epip, min_matches, fm, map_to_kf, n_matches, used_match);
+}
+
+int plslam_map2kf_match_lines_fast(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* Lw,
+                                   const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
+                                   const uint8_t* kf_desc, const double* kf_le, const double* kf_seg,
+                                   const int32_t* kf_idx, int32_t n_kf, float nnr, int mutual, double max_epip,
+                                   int32_t min_matches, const plslam_fast_matching* fm, int32_t* map_to_kf,
+                                   int32_t* n_matches, int32_t* used_match)
+{
+    return plslam::map2kf_driver(ctx, 1, K, Twf, Lw, med_desc, candidate, n_map, kf_desc, kf_le, kf_seg, kf_idx, n_kf,
+                                 nnr, mutual, max_epip, min_matches, fm, map_to_kf, n_matches, used_match);
 }
 
 }  // extern "C"

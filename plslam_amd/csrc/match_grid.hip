@@ -538,6 +538,34 @@ static int launch_mode(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hip
     return PLSLAM_OK;
 }
 
+// capacity of the candidate store (host-side data): rows go in blocks of 1024, a block needs 1024 slots per grid item
+// inside the windows of its fullest row (mutual only; without it nothing is stored)
+int64_t grid_store_capacity_host(const int32_t* centres, int32_t n1, int32_t n_centres, const int32_t* cell_start,
+                                 int32_t cols, int32_t rows, const int32_t window[4], int mutual)
+{
+    if (!mutual) return 0;
+    int64_t total = 0, depth = 0;
+    for (int32_t i1 = 0; i1 < n1; ++i1) {
+        int64_t cnt = 0;
+        for (int32_t c = 0; c < n_centres; ++c) {
+            const int64_t k = (int64_t)i1 * n_centres + c;
+            const int64_t x = centres[2 * k], y = centres[2 * k + 1];
+            const int64_t min_x = x - window[0] > 0 ? x - window[0] : 0;
+            const int64_t max_x = x + window[1] + 1 < cols ? x + window[1] + 1 : cols;
+            const int64_t min_y = y - window[2] > 0 ? y - window[2] : 0;
+            const int64_t max_y = y + window[3] + 1 < rows ? y + window[3] + 1 : rows;
+            if (min_y >= max_y) continue;
+            for (int64_t x_ = min_x; x_ < max_x; ++x_) cnt += cell_start[x_ * rows + max_y] - cell_start[x_ * rows + min_y];
+        }
+        if (cnt > depth) depth = cnt;
+        if ((i1 & (GRID_THREADS - 1)) == GRID_THREADS - 1 || i1 == n1 - 1) {
+            total += depth * GRID_THREADS;
+            depth = 0;
+        }
+    }
+    return total;
+}
+
 // d_probs: the n[2] problems of mode 2 first, then the n[1] of mode 1, then the n[0] of mode 0; lds_bytes[m] = the
 // largest grid_lds_bytes() of a problem of mode m
 int launch_match_grid(const GridDesc* d_probs, const int32_t n[3], const size_t lds_bytes[3], hipStream_t s)
@@ -599,6 +627,25 @@ static void grid_fill_desc(const plslam_grid_problem& q, uint32_t* scratch, int3
     d->pair_cap = q.pair_capacity;
     d->n_items = q.n_items;
 }
+
+namespace plslam {
+// h_desc_slot must stay valid until the copy is done (pinned or synchronised by the caller)
+int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* d_desc_slot,
+                          GridDesc* h_desc_slot, hipStream_t s)
+{
+    int rc;
+    if ((rc = grid_check_problem(q))) return rc;
+    grid_fill_desc(q, scratch, status, h_desc_slot);
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d_desc_slot, h_desc_slot, sizeof(GridDesc), hipMemcpyHostToDevice, s));
+    const int64_t ncell = (int64_t)q.grid_cols * q.grid_rows;
+    const int mode = grid_mode(q.n1, q.n2, ncell, q.n_items);
+    int32_t n_mode[3] = {0, 0, 0};
+    size_t lds_bytes[3] = {0, 0, 0};
+    n_mode[mode] = 1;
+    lds_bytes[mode] = grid_lds_bytes(mode, q.n1, q.n2, ncell, q.n_items);
+    return launch_match_grid(d_desc_slot, n_mode, lds_bytes, s);
+}
+}  // namespace plslam
 
 extern "C" {
 
@@ -701,31 +748,8 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     const int32_t n_items = cell_start[ncell];
     PLSLAM_REQUIRE(n_items == 0 || cell_items, PLSLAM_EINVAL);
     q.n_items = n_items;
-    // capacity of the candidate store: rows go in blocks of 1024, a block needs 1024 slots per candidate of its
-    // fullest row (mutual only; without it nothing is stored)
-    int64_t pairs = 0;
-    if (mutual) {
-        int64_t depth = 0;
-        for (int32_t i1 = 0; i1 < n1; ++i1) {
-            int64_t cnt = 0;
-            for (int32_t c = 0; c < n_centres; ++c) {
-                const int64_t k = (int64_t)i1 * n_centres + c;
-                const int64_t x = centres1[2 * k], y = centres1[2 * k + 1];
-                const int64_t min_x = x - window[0] > 0 ? x - window[0] : 0;
-                const int64_t max_x = x + window[1] + 1 < grid_cols ? x + window[1] + 1 : grid_cols;
-                const int64_t min_y = y - window[2] > 0 ? y - window[2] : 0;
-                const int64_t max_y = y + window[3] + 1 < grid_rows ? y + window[3] + 1 : grid_rows;
-                if (min_y >= max_y) continue;
-                for (int64_t x_ = min_x; x_ < max_x; ++x_)
-                    cnt += cell_start[x_ * grid_rows + max_y] - cell_start[x_ * grid_rows + min_y];
-            }
-            if (cnt > depth) depth = cnt;
-            if ((i1 & 1023) == 1023 || i1 == n1 - 1) {
-                pairs += depth * 1024;
-                depth = 0;
-            }
-        }
-    }
+    const int64_t pairs = grid_store_capacity_host(centres1, n1, n_centres, cell_start, grid_cols, grid_rows, window,
+                                                   mutual);
     PLSLAM_REQUIRE(pairs < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
     q.pair_capacity = (int32_t)pairs;
 

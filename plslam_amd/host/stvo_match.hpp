@@ -18,8 +18,11 @@
 
 #include <stdint.h>
 
+#include <cmath>
+#include <list>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "plslam_hip.h"
@@ -109,6 +112,153 @@ inline int match(const Mat1& desc1, const Mat2& desc2, float nnr, std::vector<in
                                matches_12.data(), &n),
                   "StVO::match");
     return n;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The windowed matcher: stvo-pl gridStructure.h / matching.h ([RECALL] -- the dependency is not vendored), as used
+// by src/mapHandler.cpp:252-271 (points), :381-418 (lines), :580-591, :683-706.  Same names, same argument meaning.
+// ---------------------------------------------------------------------------------------------------------------
+#ifndef GRID_ROWS
+#define GRID_ROWS 48
+#endif
+#ifndef GRID_COLS
+#define GRID_COLS 64
+#endif
+
+typedef std::pair<int, int> point_2d;            // a grid cell (x, y); doubles passed to make_pair truncate toward 0
+typedef std::pair<point_2d, point_2d> line_2d;   // start and end cell of a segment
+
+struct GridWindow {
+    std::pair<int, int> width, height;           // cells x - width.first .. x + width.second, y likewise
+};
+
+// Config::lineSimTh() of stvo-pl (`line_sim_th`, config/config/config_kitti.yaml): minimum |cos| between the
+// directions of a query line and a candidate; process-wide like the reference's Config singleton
+inline double& lineSimTh()
+{
+    static double v = 0.75;
+    return v;
+}
+
+inline void normalize(std::pair<double, double>& v)
+{
+    const double magnitude = std::sqrt(v.first * v.first + v.second * v.second);
+    v.first /= magnitude;
+    v.second /= magnitude;
+}
+
+// Bresenham cells of a segment given in (real-valued) grid units; the last x is excluded
+inline void getLineCoords(double x1, double y1, double x2, double y2, std::list<point_2d>& line_coords)
+{
+    line_coords.clear();
+    const bool steep = std::fabs(y2 - y1) > std::fabs(x2 - x1);
+    if (steep) { std::swap(x1, y1); std::swap(x2, y2); }
+    if (x1 > x2) { std::swap(x1, x2); std::swap(y1, y2); }
+    const double dx = x2 - x1, dy = std::fabs(y2 - y1);
+    double error = dx / 2.0;
+    const int ystep = (y1 < y2) ? 1 : -1;
+    int y = (int)y1;
+    const int maxX = (int)x2;
+    for (int x = (int)x1; x < maxX; x++) {
+        if (steep) line_coords.push_back(std::make_pair(y, x));
+        else line_coords.push_back(std::make_pair(x, y));
+        error -= dy;
+        if (error < 0) { y += ystep; error += dx; }
+    }
+}
+
+// grid[x][y], 0 <= x < cols, 0 <= y < rows; at() outside the grid returns a dummy list whose content is never seen
+class GridStructure {
+public:
+    int rows, cols;
+    GridStructure(int rows_, int cols_) : rows(rows_), cols(cols_)
+    {
+        if (rows <= 0 || cols <= 0) throw std::runtime_error("[GridStructure] invalid dimension");
+        grid.resize((size_t)cols, std::vector<std::list<int>>((size_t)rows));
+    }
+    std::list<int>& at(int x, int y)
+    {
+        if (x >= 0 && x < cols && y >= 0 && y < rows) return grid[(size_t)x][(size_t)y];
+        return out_of_bounds;
+    }
+    // CSR form of the C ABI: cell (x, y) -> id x*rows + y, items in push_back order
+    void toCSR(std::vector<int32_t>& cell_start, std::vector<int32_t>& cell_items) const
+    {
+        cell_start.assign((size_t)cols * rows + 1, 0);
+        cell_items.clear();
+        for (int x = 0; x < cols; ++x)
+            for (int y = 0; y < rows; ++y) {
+                for (int i : grid[(size_t)x][(size_t)y]) cell_items.push_back(i);
+                cell_start[(size_t)x * rows + y + 1] = (int32_t)cell_items.size();
+            }
+    }
+private:
+    std::vector<std::vector<std::list<int>>> grid;
+    std::list<int> out_of_bounds;
+};
+
+namespace detail {
+template <class Mat1, class Mat2>
+inline int matchGridCall(const std::vector<int32_t>& centres, int n_centres, const Mat1& desc1, const GridStructure& grid,
+                         const Mat2& desc2, const double* dir1, const double* dir2, const GridWindow& w, float nnr,
+                         std::vector<int>& matches_12, const char* who)
+{
+    matches_12.assign((size_t)desc1.rows, -1);
+    std::vector<int32_t> cs, items;
+    grid.toCSR(cs, items);
+    const int32_t win[4] = {w.width.first, w.width.second, w.height.first, w.height.second};
+    int32_t n = 0;
+    check(plslam_match_grid(ctx(), centres.data(), n_centres, rows_of(desc1, "desc1"), desc1.rows, cs.data(),
+                            items.data(), grid.cols, grid.rows, rows_of(desc2, "desc2"), desc2.rows, dir1, dir2,
+                            lineSimTh(), win, (double)nnr, bestLRMatches() ? 1 : 0, matches_12.data(), &n),
+          who);
+    return n;
+}
+}  // namespace detail
+
+// int matchGrid(points1, desc1, grid, desc2, w, matches_12): nnr is Config::minRatio12P() upstream (a global there;
+// an argument with the same default use here: pass SlamConfig::minRatio12P())
+template <class Mat1, class Mat2>
+inline int matchGrid(const std::vector<point_2d>& points1, const Mat1& desc1, const GridStructure& grid,
+                     const Mat2& desc2, const GridWindow& w, std::vector<int>& matches_12, float nnr = 0.75f)
+{
+    if ((int)points1.size() != desc1.rows)
+        throw std::runtime_error("[matchGrid] Each point needs a corresponding descriptor!");
+    std::vector<int32_t> centres(points1.size() * 2);
+    for (size_t i = 0; i < points1.size(); ++i) {
+        centres[2 * i] = points1[i].first;
+        centres[2 * i + 1] = points1[i].second;
+    }
+    return detail::matchGridCall(centres, 1, desc1, grid, desc2, nullptr, nullptr, w, nnr, matches_12, "StVO::matchGrid");
+}
+
+// line overload: candidates from the windows around both end points, skipped when the directions disagree
+template <class Mat1, class Mat2>
+inline int matchGrid(const std::vector<line_2d>& lines1, const Mat1& desc1, const GridStructure& grid, const Mat2& desc2,
+                     const std::vector<std::pair<double, double>>& directions2, const GridWindow& w,
+                     std::vector<int>& matches_12, float nnr = 0.75f)
+{
+    if ((int)lines1.size() != desc1.rows)
+        throw std::runtime_error("[matchGrid] Each line needs a corresponding descriptor!");
+    if ((int)directions2.size() != desc2.rows)
+        throw std::runtime_error("[matchGrid] Each candidate line needs a direction!");
+    std::vector<int32_t> centres(lines1.size() * 4);
+    std::vector<double> dir1(lines1.size() * 2), dir2(directions2.size() * 2);
+    for (size_t i = 0; i < lines1.size(); ++i) {
+        const point_2d &sp = lines1[i].first, &ep = lines1[i].second;
+        centres[4 * i] = sp.first; centres[4 * i + 1] = sp.second;
+        centres[4 * i + 2] = ep.first; centres[4 * i + 3] = ep.second;
+        std::pair<double, double> v = std::make_pair((double)(ep.first - sp.first), (double)(ep.second - sp.second));
+        normalize(v);                                  // a zero vector becomes NaN: the direction test then never skips
+        dir1[2 * i] = v.first;
+        dir1[2 * i + 1] = v.second;
+    }
+    for (size_t i = 0; i < directions2.size(); ++i) {
+        dir2[2 * i] = directions2[i].first;
+        dir2[2 * i + 1] = directions2[i].second;
+    }
+    return detail::matchGridCall(centres, 2, desc1, grid, desc2, dir1.data(), dir2.data(), w, nnr, matches_12,
+                                 "StVO::matchGrid");
 }
 
 // A batch of independent match() calls in one launch (e.g. the four per-frame problems of

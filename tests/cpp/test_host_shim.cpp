@@ -63,8 +63,106 @@ static void match_case(int n1, int n2, float nnr, bool mutual, unsigned seed)
     EXPECT(cnt == n);
 }
 
+// StVO::matchGrid used exactly as MapHandler::matchKF2KFPoints / matchKF2KFLines do (src/mapHandler.cpp:252-271,
+// :381-418): project, fill the GridStructure, window of matching_f2f_ws cells, match; against the oracle's literal
+// sequential restatement fed with the same grid in CSR form.
+static void grid_case(bool lines, int n1, int n2, bool mutual, unsigned seed)
+{
+    std::mt19937 g(seed);
+    std::uniform_real_distribution<double> ux(-20.0, 772.0), uy(-20.0, 500.0), ul(0.0, 180.0), ua(0.0, 3.14159);
+    const double inv_width = GRID_COLS / 752.0, inv_height = GRID_ROWS / 480.0;
+    std::vector<uint8_t> b = rand_desc(g, n2), a;
+    noisy(g, b, a);
+    a.resize((size_t)n1 * 32);
+    for (size_t k = (size_t)std::min(n1, n2) * 32; k < a.size(); ++k) a[k] = (uint8_t)(g() & 0xFF);
+    StVO::DescMat d1(a.data(), n1), d2(b.data(), n2);
+    StVO::bestLRMatches() = mutual;
+    StVO::GridStructure grid(GRID_ROWS, GRID_COLS);
+    StVO::GridWindow w;
+    w.width = std::make_pair(3, 3);
+    w.height = std::make_pair(3, 3);
+    std::vector<int> m12;
+    int n = 0;
+    std::vector<int32_t> centres;
+    std::vector<double> dir1, dir2;
+    if (!lines) {
+        std::vector<StVO::point_2d> pj_points;
+        std::vector<std::pair<double, double>> px2((size_t)n2);
+        for (int i = 0; i < n2; ++i) {
+            px2[i] = std::make_pair(ux(g), uy(g));
+            grid.at(px2[i].first * inv_width, px2[i].second * inv_height).push_back(i);
+        }
+        for (int i = 0; i < n1; ++i) {
+            const double x = i < n2 ? px2[i].first + 5.0 : ux(g), y = i < n2 ? px2[i].second - 4.0 : uy(g);
+            pj_points.push_back(std::make_pair(x * inv_width, y * inv_height));
+            centres.push_back(pj_points.back().first);
+            centres.push_back(pj_points.back().second);
+        }
+        n = StVO::matchGrid(pj_points, d1, grid, d2, w, m12, 0.8f);
+    } else {
+        std::vector<StVO::line_2d> pj_lines;
+        std::vector<std::pair<double, double>> directions((size_t)n2);
+        std::vector<double> seg((size_t)n2 * 4);
+        std::list<StVO::point_2d> line_coords;
+        for (int i = 0; i < n2; ++i) {
+            const double x = ux(g), y = uy(g), l = ul(g), t = ua(g);
+            seg[4 * i] = x; seg[4 * i + 1] = y; seg[4 * i + 2] = x + l * std::cos(t); seg[4 * i + 3] = y + l * std::sin(t);
+            std::pair<double, double>& v = directions[i];
+            v = std::make_pair((seg[4 * i + 2] - x) * inv_width, (seg[4 * i + 3] - y) * inv_height);
+            StVO::normalize(v);
+            StVO::getLineCoords(x * inv_width, y * inv_height, seg[4 * i + 2] * inv_width, seg[4 * i + 3] * inv_height, line_coords);
+            for (const StVO::point_2d& p : line_coords) grid.at(p.first, p.second).push_back(i);
+            dir2.push_back(v.first);
+            dir2.push_back(v.second);
+        }
+        for (int i = 0; i < n1; ++i) {
+            double s[4];
+            for (int k = 0; k < 4; ++k) s[k] = i < n2 ? seg[4 * i + k] + 3.0 : (k & 1 ? uy(g) : ux(g));
+            pj_lines.push_back(std::make_pair(std::make_pair(s[0] * inv_width, s[1] * inv_height),
+                                              std::make_pair(s[2] * inv_width, s[3] * inv_height)));
+            const StVO::line_2d& L = pj_lines.back();
+            centres.push_back(L.first.first); centres.push_back(L.first.second);
+            centres.push_back(L.second.first); centres.push_back(L.second.second);
+            double v[2] = {(double)(L.second.first - L.first.first), (double)(L.second.second - L.first.second)};
+            plo_normalize2(v);
+            dir1.push_back(v[0]);
+            dir1.push_back(v[1]);
+        }
+        n = StVO::matchGrid(pj_lines, d1, grid, d2, directions, w, m12, 0.8f);
+    }
+    std::vector<int32_t> cs, items, ref((size_t)n1);
+    grid.toCSR(cs, items);
+    const int32_t win[4] = {3, 3, 3, 3};
+    const int nref = plo_match_grid(centres.data(), lines ? 2 : 1, a.data(), n1, cs.data(), items.data(), GRID_COLS, GRID_ROWS,
+                                    b.data(), n2, lines ? dir1.data() : nullptr, lines ? dir2.data() : nullptr,
+                                    StVO::lineSimTh(), win, (double)0.8f, mutual ? 1 : 0, ref.data());
+    EXPECT(n == nref);
+    EXPECT(nref > 0);
+    EXPECT((int)m12.size() == n1);
+    for (int i = 0; i < n1; ++i) EXPECT(m12[i] == ref[i]);
+}
+
 int main()
 {
+    // --- StVO::matchGrid drop-in ------------------------------------------------------------
+    grid_case(false, 1500, 1400, true, 11);
+    grid_case(false, 800, 900, false, 12);
+    grid_case(true, 200, 220, true, 13);
+    grid_case(true, 150, 100, false, 14);
+    {   // getLineCoords against the oracle's restatement
+        std::mt19937 g(5);
+        std::uniform_real_distribution<double> u(-3.0, 70.0);
+        for (int k = 0; k < 200; ++k) {
+            const double x1 = u(g), y1 = u(g), x2 = u(g), y2 = u(g);
+            std::list<StVO::point_2d> lc;
+            StVO::getLineCoords(x1, y1, x2, y2, lc);
+            std::vector<int32_t> out(2 * 256);
+            const int n = plo_get_line_coords(x1, y1, x2, y2, out.data(), 256);
+            EXPECT(n == (int)lc.size());
+            int j = 0;
+            for (const auto& p : lc) { EXPECT(p.first == out[2 * j] && p.second == out[2 * j + 1]); ++j; }
+        }
+    }
     // --- StVO::match drop-in -------------------------------------------------------------
     match_case(1500, 1500, 0.75f, true, 1);
     match_case(200, 200, 0.9f, true, 2);

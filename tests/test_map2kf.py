@@ -40,7 +40,8 @@ def scene(n_map=3000, n_kf=900, lines=False, seed=1, frac_unmatched=0.6):
     nrm = np.sqrt(le[:, 0] ** 2 + le[:, 1] ** 2)
     le = le / np.where(nrm > 0, nrm, 1.0)[:, None]
     le[:, 2] += r.normal(0, 0.7, n_kf)
-    return dict(Twf=Twf, LM=Lw, med=med, cand=cand, kf_desc=kf_desc, kf_feat=le, kf_idx=kf_idx)
+    seg = np.nan_to_num(np.concatenate([p[:, :2], q[:, :2]], 1), posinf=0, neginf=0) + r.normal(0, 0.7, (n_kf, 4))
+    return dict(Twf=Twf, LM=Lw, med=med, cand=cand, kf_desc=kf_desc, kf_feat=le, kf_idx=kf_idx, kf_seg=seg)
 
 
 def test_oracle_driver_semantics(oracle):
@@ -77,7 +78,7 @@ def test_gpu_driver_bit_exact(ctx, oracle, kind, n_map, n_kf):
     import plslam_amd
     cam, ocam = plslam_amd.make_cam(**synth.EUROC), oracle.make_cam(**synth.EUROC)
     s = scene(n_map, n_kf, lines=(kind == "lines"), seed=n_map)
-    for nnr, mutual, th, mm in ((0.75, True, 1.0, 10), (0.9, False, 2.0, 6), (0.9, True, 0.5, 0)):
+    for nnr, mutual, th, mm in ((0.75, True, 1.0, 10), (0.9, False, 2.0, 6), (0.9, True, 0.5, 1), (0.9, True, 0.5, 0)):
         exp, en = oracle.map2kf_match(kind, ocam, s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"],
                                       s["kf_idx"], nnr, mutual, th, mm)
         got, gn = ctx.map2kf_match(kind, cam, s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"],
@@ -101,3 +102,65 @@ def test_gpu_driver_degenerate(ctx, oracle):
     got, gn = ctx.map2kf_match("points", cam, s["Twf"], np.zeros((0, 3)), np.zeros((0, 32), np.uint8),
                                np.zeros(0, np.uint8), s["kf_desc"], s["kf_feat"], s["kf_idx"], 0.9, True, 1.0, 10)
     assert gn == 0 and got.shape == (0,)
+
+
+def fast_cfg(ws=3, nnr_grid=0.75, enabled=1):
+    """The shipped configuration: 64 x 48 grid over the 752 x 480 image, matching_f2f_ws = 3
+    (config/config/config_euroc.yaml / config_kitti.yaml:59)."""
+    K = synth.EUROC
+    return dict(enabled=enabled, grid_cols=64, grid_rows=48, ws=ws, inv_width=64 / K["width"], inv_height=48 / K["height"],
+                nnr_grid=nnr_grid, line_sim_th=0.75)
+
+
+def test_oracle_fast_driver_semantics(oracle):
+    """fast_matching: matchGrid first; StVO::match only replaces it when it found fewer than min_matches."""
+    cam = oracle.make_cam(**synth.EUROC)
+    s = scene(1500, 600)
+    a = (s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"], s["kf_idx"])
+    out, n, used = oracle.map2kf_match_fast("points", cam, *a, 0.9, True, 1.5, 10, fast_cfg())
+    assert n > 20 and used == 0 and n == (out >= 0).sum()
+    # a grid result below min_matches is replaced by brute force: identical to the plain driver then
+    vis = oracle.map_point_visible(cam, s["Twf"], s["LM"]).astype(bool)
+    nq = int((s["cand"].astype(bool) & vis).sum())
+    assert nq > n + 60                                        # room for a min_matches between the two
+    out2, n2, used2 = oracle.map2kf_match_fast("points", cam, *a, 0.9, True, 1.5, n + 50, fast_cfg())
+    ref, nref = oracle.map2kf_match("points", cam, *a, 0.9, True, 1.5, n + 50)
+    assert used2 == 1 and n2 == nref and (out2 == ref).all()
+    # ... but not when the candidate list itself is not larger than min_matches (:594)
+    out2b, n2b, used2b = oracle.map2kf_match_fast("points", cam, *a, 0.9, True, 1.5, nq, fast_cfg())
+    assert used2b == 0 and n2b == n and (out2b == out).all()
+    # disabled == the plain driver
+    out3, n3, used3 = oracle.map2kf_match_fast("points", cam, *a, 0.9, True, 1.5, 10, fast_cfg(enabled=0))
+    ref3, nref3 = oracle.map2kf_match("points", cam, *a, 0.9, True, 1.5, 10)
+    assert used3 == 1 and n3 == nref3 and (out3 == ref3).all()
+    # min_matches = 0: nothing can be "fewer than 0", so the plain driver matches nothing (:594-596) ...
+    assert oracle.map2kf_match("points", cam, *a, 0.9, True, 1.5, 0)[1] == 0
+    # ... while the grid result stands on its own
+    assert oracle.map2kf_match_fast("points", cam, *a, 0.9, True, 1.5, 0, fast_cfg())[1] == n
+    # associations of the windowed matcher lie within the window (3 cells of 11.75 x 10 px) + the gate
+    sl = scene(400, 150, lines=True)
+    outl, nl, usedl = oracle.map2kf_match_fast("lines", cam, sl["Twf"], sl["LM"], sl["med"], sl["cand"], sl["kf_desc"],
+                                               sl["kf_feat"], sl["kf_idx"], 0.9, True, 3.0, 2, fast_cfg(), kf_seg=sl["kf_seg"])
+    assert nl == (outl >= 0).sum()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n_map,n_kf", [("points", 10000, 1500), ("lines", 2000, 200), ("points", 300, 40),
+                                             ("lines", 50, 10)])
+def test_gpu_fast_driver_bit_exact(ctx, oracle, kind, n_map, n_kf):
+    """The shipped fast_matching configuration at BASELINE config 3 sizes: association tables, counts and the
+    fall-back decision equal the oracle's."""
+    import plslam_amd
+    cam, ocam = plslam_amd.make_cam(**synth.EUROC), oracle.make_cam(**synth.EUROC)
+    s = scene(n_map, n_kf, lines=(kind == "lines"), seed=n_map + 1)
+    a = (s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"], s["kf_idx"])
+    seen_used = set()
+    for nnr, mutual, th, mm, fm in ((0.75, True, 1.5, 10, fast_cfg()), (0.9, False, 2.0, 6, fast_cfg(ws=1)),
+                                    (0.9, True, 0.8, 250 if n_map >= 2000 else 12, fast_cfg()), (0.9, True, 1.0, 0, fast_cfg(ws=5, nnr_grid=0.9)),
+                                    (0.8, True, 1.0, 5, fast_cfg(enabled=0))):
+        got = ctx.map2kf_match_fast(kind, cam, *a, nnr, mutual, th, mm, fm, kf_seg=s.get("kf_seg"))
+        ref = oracle.map2kf_match_fast(kind, ocam, *a, nnr, mutual, th, mm, fm, kf_seg=s.get("kf_seg"))
+        np.testing.assert_array_equal(got[0], ref[0])
+        assert got[1] == ref[1] == int((ref[0] >= 0).sum()) and got[2] == ref[2]
+        seen_used.add(ref[2])
+    assert seen_used == {0, 1} or n_map < 100
