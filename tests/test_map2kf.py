@@ -78,7 +78,7 @@ def test_gpu_driver_bit_exact(ctx, oracle, kind, n_map, n_kf):
     import plslam_amd
     cam, ocam = plslam_amd.make_cam(**synth.EUROC), oracle.make_cam(**synth.EUROC)
     s = scene(n_map, n_kf, lines=(kind == "lines"), seed=n_map)
-    for nnr, mutual, th, mm in ((0.75, True, 1.0, 10), (0.9, False, 2.0, 6), (0.9, True, 0.5, 1), (0.9, True, 0.5, 0)):
+    for nnr, mutual, th, mm in ((0.9, True, 0.5, 0), (0.75, True, 1.0, 10), (0.9, False, 2.0, 6), (0.9, True, 0.5, 1)):
         exp, en = oracle.map2kf_match(kind, ocam, s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"],
                                       s["kf_idx"], nnr, mutual, th, mm)
         got, gn = ctx.map2kf_match(kind, cam, s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"],
