@@ -183,3 +183,12 @@ def test_plan_batch_device_resident_and_overflow(ctx, oracle):
             np.testing.assert_array_equal(out.cpu().numpy(), ref[0], err_msg=f"problem {b}")
             assert int(cnt.item()) == ref[1]
     plan.close()
+
+
+def test_committed_grid_goldens(ctx):
+    """GPU vs the committed fixtures tests/golden/grid_golden.npz (no oracle involved at run time)."""
+    from test_match_grid_cpu import golden_cases
+    for c, w, nnr, mutual, want in golden_cases():
+        m, n = ctx.match_grid(window=w, nnr=nnr, mutual=mutual, **c)
+        np.testing.assert_array_equal(m, want)
+        assert n == int((want >= 0).sum())

@@ -118,3 +118,31 @@ def test_pair_count_is_the_candidate_enumeration(oracle):
                     n += cs[x_ * 12 + hi] - cs[x_ * 12 + lo]
         assert G.pair_count(c["centres"], cs, 16, 12, w) == n
         assert G.store_capacity(c["centres"], cs, 16, 12, w) >= n and G.store_capacity(c["centres"], cs, 16, 12, w, False) == 0
+
+
+GRID_GOLD = __import__("os").path.join(__import__("os").path.dirname(__file__), "golden", "grid_golden.npz")
+
+
+def golden_cases():
+    g = np.load(GRID_GOLD)
+    for name in g["names"]:
+        cols, rows, w0, w1, w2, w3, lines = [int(v) for v in g[f"{name}_meta"]]
+        c = dict(centres=g[f"{name}_centres"], d1=g[f"{name}_d1"], cell_start=g[f"{name}_cell_start"],
+                 cell_items=g[f"{name}_cell_items"], cols=cols, rows=rows, d2=g[f"{name}_d2"])
+        if lines:
+            c.update(dir1=g[f"{name}_dir1"], dir2=g[f"{name}_dir2"], sim_th=0.75)
+        for mutual in (0, 1):
+            for nnr in (0.75, 0.9):
+                yield c, (w0, w1, w2, w3), nnr, bool(mutual), g[f"{name}_m{mutual}_r{int(nnr * 100)}"]
+
+
+def test_oracle_reproduces_the_committed_grid_goldens(oracle):
+    """tests/golden/grid_golden.npz (made by the order-free numpy form, tests/golden/make_grid_golden.py) vs the C
+    oracle's literal sequential loop."""
+    k = 0
+    for c, w, nnr, mutual, want in golden_cases():
+        m, n = oracle.match_grid(window=w, nnr=nnr, mutual=mutual, **c)
+        np.testing.assert_array_equal(m, want)
+        assert n == int((want >= 0).sum())
+        k += int((want >= 0).sum())
+    assert k > 300
