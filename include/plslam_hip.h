@@ -236,6 +236,28 @@ int plslam_grid_plan_run(plslam_grid_plan* plan, void* stream);
 int plslam_grid_plan_overflows(plslam_grid_plan* plan, void* stream, int32_t* n_overflows);
 void plslam_grid_plan_destroy(plslam_grid_plan* plan);
 
+/* ---- K15/K16: the stereo L<->R gates of StVO::StereoFrame ---------------------------------------- */
+/* stvo-pl stereoFrame.cpp, matchStereoPoints / matchStereoLines ([RECALL]; the un-vendored dependency): what turns
+ * the match table of (pdesc_l, pdesc_r) / (ldesc_l, ldesc_r) -- from StVO::match or StVO::matchGrid with the window
+ * {matching_s_ws, 0, 0, 0} -- into the frame's stereo features.  Thresholds are the reference's config keys
+ * max_dist_epip, min_disp, line_horiz_th, stereo_overlap_th, ls_min_disp_ratio
+ * (config/config/config_kitti.yaml:25,26,34,31,36).
+ *   points: kp = n x 2 float32 (cv::KeyPoint::pt.x, .y).  Kept iff |pt_l.y - pt_r.y| <= max_dist_epip (float
+ *           subtraction) and disp = pt_l.x - pt_r.x >= min_disp.  disp: n_l doubles (0 where dropped).
+ *   lines:  seg = n x 4 float32 (KeyLine startPointX, startPointY, endPointX, endPointY).  The right end points are
+ *           moved along the right line to the rows of the left end points, disp_s / disp_e are the differences of x
+ *           (both -1 when min/max < ls_min_disp_ratio); kept iff both >= min_disp, neither segment is horizontal
+ *           (|dy| > line_horiz_th) and lineSegmentOverlapStereo of the y ranges > stereo_overlap_th.
+ *           disp_se: n_l x 2 doubles.
+ * stereo_12[i1] = i2 or -1; *n_stereo (may be NULL) = number kept. */
+int plslam_stereo_point_gate(plslam_ctx* ctx, const int32_t* matches_12, int32_t n_l, const float* kp_l,
+                             const float* kp_r, int32_t n_r, double max_dist_epip, double min_disp,
+                             int32_t* stereo_12, double* disp, int32_t* n_stereo);
+int plslam_stereo_line_gate(plslam_ctx* ctx, const int32_t* matches_12, int32_t n_l, const float* seg_l,
+                            const float* seg_r, int32_t n_r, double min_disp, double line_horiz_th,
+                            double stereo_overlap_th, double ls_min_disp_ratio, int32_t* stereo_12,
+                            double* disp_se, int32_t* n_stereo);
+
 /* ---- K3/K4: local-BA residual + Jacobian rows ------------------------------------------- */
 /* Point rows: the per-observation body of MapHandler::levMarquardtOptimizationLBA,
  * src/mapHandler.cpp:1358-1407 (first pass) == :1587-1642 (iteration pass; the caller

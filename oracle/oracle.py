@@ -99,6 +99,14 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.plo_map2kf_match_lines_fast.argtypes = [C.POINTER(Cam)] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 4 + \
         [C.c_int32, C.c_float, C.c_int, C.c_double, C.c_int32, C.POINTER(FastMatching), C.c_void_p, C.POINTER(C.c_int32)]
     lib.plo_map2kf_match_lines_fast.restype = C.c_int32
+    lib.plo_stereo_point_gate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_double,
+                                          C.c_void_p, C.c_void_p]
+    lib.plo_stereo_point_gate.restype = C.c_int32
+    lib.plo_stereo_line_gate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32] + [C.c_double] * 4 + \
+        [C.c_void_p, C.c_void_p]
+    lib.plo_stereo_line_gate.restype = C.c_int32
+    lib.plo_line_segment_overlap_stereo.argtypes = [C.c_double] * 5
+    lib.plo_line_segment_overlap_stereo.restype = C.c_double
     lib.plo_match_grid.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
                                    C.c_void_p, C.c_double, C.c_int, C.c_void_p]
@@ -378,6 +386,26 @@ def map2kf_match_fast(kind, cam, Twf, LM, med_desc, candidate, kf_desc, kf_feat,
                                               _p(sg), _p(ki), kd.shape[0], float(nnr), int(bool(mutual)), float(max_epip),
                                               int(min_matches), C.byref(F), _p(out), C.byref(used))
     return out, int(n), int(used.value)
+
+
+def stereo_point_gate(m12, kp_l, kp_r, max_dist_epip, min_disp):
+    """StereoFrame::matchStereoPoints gates ([RECALL]) -> (stereo_12, disp, n)."""
+    m12 = _c(m12, np.int32)
+    a, b = _c(kp_l, np.float32).reshape(-1, 2), _c(kp_r, np.float32).reshape(-1, 2)
+    out, disp = np.empty(m12.shape[0], np.int32), np.empty(m12.shape[0], np.float64)
+    n = lib().plo_stereo_point_gate(_p(m12), m12.shape[0], _p(a), _p(b), b.shape[0], float(max_dist_epip), float(min_disp),
+                                    _p(out), _p(disp))
+    return out, disp, int(n)
+
+
+def stereo_line_gate(m12, seg_l, seg_r, min_disp, line_horiz_th, stereo_overlap_th, ls_min_disp_ratio):
+    """StereoFrame::matchStereoLines gates ([RECALL]) -> (stereo_12, disp_se[n,2], n)."""
+    m12 = _c(m12, np.int32)
+    a, b = _c(seg_l, np.float32).reshape(-1, 4), _c(seg_r, np.float32).reshape(-1, 4)
+    out, disp = np.empty(m12.shape[0], np.int32), np.empty((m12.shape[0], 2), np.float64)
+    n = lib().plo_stereo_line_gate(_p(m12), m12.shape[0], _p(a), _p(b), b.shape[0], float(min_disp), float(line_horiz_th),
+                                   float(stereo_overlap_th), float(ls_min_disp_ratio), _p(out), _p(disp))
+    return out, disp, int(n)
 
 
 def lbd_pairs():

@@ -756,6 +756,102 @@ int32_t plo_map2kf_match_lines_fast(const plo_cam* K, const double Twf[16], cons
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* stereo gates of StVO::StereoFrame (stvo-pl stereoFrame.cpp) -- [RECALL]                */
+/* ------------------------------------------------------------------------------------ */
+static inline double dmin2(double a, double b) { return b < a ? b : a; }   /* std::min */
+static inline double dmax2(double a, double b) { return a < b ? b : a; }   /* std::max */
+
+double plo_line_segment_overlap_stereo(double spl_obs, double epl_obs, double spl_proj, double epl_proj,
+                                       double line_horiz_th)
+{
+    double overlap = 1.f;
+    if (fabs(epl_obs - spl_obs) > line_horiz_th) {  /* normal lines (verticals included) */
+        const double sln = dmin2(spl_obs, epl_obs);
+        const double eln = dmax2(spl_obs, epl_obs);
+        const double spn = dmin2(spl_proj, epl_proj);
+        const double epn = dmax2(spl_proj, epl_proj);
+        const double length = eln - spn;
+        if ((epn < sln) || (spn > eln))
+            overlap = 0.f;
+        else {
+            if ((epn > eln) && (spn < sln))
+                overlap = eln - sln;
+            else
+                overlap = dmin2(eln, epn) - dmax2(sln, spn);
+        }
+        if (length > 0.01f)
+            overlap = overlap / length;
+        else
+            overlap = 0.f;
+        if (overlap > 1.f) overlap = 1.f;
+    }
+    return overlap;
+}
+
+int32_t plo_stereo_point_gate(const int32_t* m12, int32_t n_l, const float* kp_l, const float* kp_r, int32_t n_r,
+                              double max_dist_epip, double min_disp, int32_t* stereo_12, double* disp)
+{
+    int32_t n = 0;
+    for (int32_t i1 = 0; i1 < n_l; ++i1) {
+        stereo_12[i1] = -1;
+        disp[i1] = 0.0;
+        const int32_t i2 = m12[i1];
+        if (i2 < 0 || i2 >= n_r) continue;
+        const float dy = kp_l[2 * (size_t)i1 + 1] - kp_r[2 * (size_t)i2 + 1];
+        if ((double)fabsf(dy) <= max_dist_epip) {                  /* check stereo epipolar constraint */
+            const float dx = kp_l[2 * (size_t)i1] - kp_r[2 * (size_t)i2];
+            const double disp_ = (double)dx;
+            if (disp_ >= min_disp) {                               /* check minimal disparity */
+                stereo_12[i1] = i2;
+                disp[i1] = disp_;
+                ++n;
+            }
+        }
+    }
+    return n;
+}
+
+int32_t plo_stereo_line_gate(const int32_t* m12, int32_t n_l, const float* seg_l, const float* seg_r, int32_t n_r,
+                             double min_disp, double line_horiz_th, double stereo_overlap_th,
+                             double ls_min_disp_ratio, int32_t* stereo_12, double* disp_se)
+{
+    int32_t n = 0;
+    for (int32_t i1 = 0; i1 < n_l; ++i1) {
+        stereo_12[i1] = -1;
+        disp_se[2 * (size_t)i1] = disp_se[2 * (size_t)i1 + 1] = 0.0;
+        const int32_t i2 = m12[i1];
+        if (i2 < 0 || i2 >= n_r) continue;
+        const double sp_l[2] = {seg_l[4 * (size_t)i1], seg_l[4 * (size_t)i1 + 1]};
+        const double ep_l[2] = {seg_l[4 * (size_t)i1 + 2], seg_l[4 * (size_t)i1 + 3]};
+        double sp_r[2] = {seg_r[4 * (size_t)i2], seg_r[4 * (size_t)i2 + 1]};
+        double ep_r[2] = {seg_r[4 * (size_t)i2 + 2], seg_r[4 * (size_t)i2 + 3]};
+        const double overlap = plo_line_segment_overlap_stereo(sp_l[1], ep_l[1], sp_r[1], ep_r[1], line_horiz_th);
+        /* estimate the disparity of the endpoints: the right end points slide along the right line */
+        const double sx = (sp_r[0] * (sp_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - sp_l[1])) / (sp_r[1] - ep_r[1]);
+        sp_r[0] = sx;
+        sp_r[1] = sp_l[1];
+        const double ex = (sp_r[0] * (ep_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - ep_l[1])) / (sp_r[1] - ep_r[1]);
+        ep_r[0] = ex;
+        ep_r[1] = ep_l[1];
+        /* filterLineSegmentDisparity */
+        double disp_s = sp_l[0] - sp_r[0];
+        double disp_e = ep_l[0] - ep_r[0];
+        if (dmin2(disp_s, disp_e) / dmax2(disp_s, disp_e) < ls_min_disp_ratio) {
+            disp_s = -1.0;
+            disp_e = -1.0;
+        }
+        if (disp_s >= min_disp && disp_e >= min_disp && fabs(sp_l[1] - ep_l[1]) > line_horiz_th &&
+            fabs(sp_r[1] - ep_r[1]) > line_horiz_th && overlap > stereo_overlap_th) {
+            stereo_12[i1] = i2;
+            disp_se[2 * (size_t)i1] = disp_s;
+            disp_se[2 * (size_t)i1 + 1] = disp_e;
+            ++n;
+        }
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* stvo-pl matchGrid (matching.cpp) + GridStructure (gridStructure.cpp) -- [RECALL]       */
 /* call sites: src/mapHandler.cpp:271, :418, :591, :706                                   */
 /* ------------------------------------------------------------------------------------ */

@@ -176,6 +176,28 @@ int32_t plo_map2kf_match_lines_fast(const plo_cam* K, const double Twf[16], cons
                                     int32_t min_matches, const plo_fast_matching* fm, int32_t* map_to_kf,
                                     int32_t* used_match);
 
+/* ---- stereo L<->R gates inside StVO::StereoFrame (stvo-pl stereoFrame.cpp, [RECALL]) -------
+ * Thresholds are the reference's own config keys: max_dist_epip (config/config/config_kitti.yaml:25), min_disp (:26),
+ * stereo_overlap_th (:31), line_horiz_th (:34), ls_min_disp_ratio (:36).  matches_12 is the table StVO::match /
+ * matchGrid produced for (desc_l, desc_r).
+ * Points (matchStereoPoints): keep i1 -> i2 iff  std::abs(pt_l.y - pt_r.y) <= max_dist_epip  (float arithmetic on
+ * cv::KeyPoint::pt, compared against the double threshold)  and  disp = pt_l.x - pt_r.x >= min_disp  (float
+ * subtraction, then double).  kp: n x 2 float32 (pt.x, pt.y).  stereo_12[i1] = i2 or -1, disp[i1] (0 when dropped).
+ * Lines (matchStereoLines): end points as doubles; overlap = lineSegmentOverlapStereo(sp_l.y, ep_l.y, sp_r.y, ep_r.y);
+ * the right end points are moved along the right line to the rows of the left end points (the second one already
+ * reads the overwritten first one, as upstream); disp_s / disp_e = differences of x, both set to -1 when
+ * min/max < ls_min_disp_ratio (filterLineSegmentDisparity); keep iff both >= min_disp, |sp_l.y - ep_l.y| >
+ * line_horiz_th, |sp_r'.y - ep_r'.y| > line_horiz_th, overlap > stereo_overlap_th.
+ * seg: n x 4 float32 (startPointX, startPointY, endPointX, endPointY of the cv::line_descriptor::KeyLine).
+ * disp_se: n_l x 2 (disp_s, disp_e; 0, 0 when dropped).  Both return the number of stereo features. */
+int32_t plo_stereo_point_gate(const int32_t* m12, int32_t n_l, const float* kp_l, const float* kp_r, int32_t n_r,
+                              double max_dist_epip, double min_disp, int32_t* stereo_12, double* disp);
+int32_t plo_stereo_line_gate(const int32_t* m12, int32_t n_l, const float* seg_l, const float* seg_r, int32_t n_r,
+                             double min_disp, double line_horiz_th, double stereo_overlap_th,
+                             double ls_min_disp_ratio, int32_t* stereo_12, double* disp_se);
+double plo_line_segment_overlap_stereo(double spl_obs, double epl_obs, double spl_proj, double epl_proj,
+                                       double line_horiz_th);
+
 /* ---- stvo-pl matchGrid: the windowed ("fast_matching") matcher ------------------------------
  * Call sites in the reference: src/mapHandler.cpp:271 (points, KF<->KF), :418 (lines), :591 (map points
  * <-> KF), :706 (map lines <-> KF); the grid is filled by the callers at :258-264, :395-411, :580-584,

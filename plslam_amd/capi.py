@@ -35,6 +35,7 @@ ABI_SYMBOLS = (
     "plslam_map2kf_match_points_fast", "plslam_map2kf_match_lines_fast",
     "plslam_lbd_binarise", "plslam_lbd_binarise_dev",
     "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
+    "plslam_stereo_point_gate", "plslam_stereo_line_gate",
     "plslam_match_grid", "plslam_grid_plan_create", "plslam_grid_plan_run", "plslam_grid_plan_overflows",
     "plslam_grid_plan_destroy",
     "plslam_gather_match_tables",
@@ -176,6 +177,8 @@ def load() -> C.CDLL:
     L.plslam_map2kf_match_lines_fast.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, C.c_float,
                                                  C.c_int, f64, i32, C.POINTER(FastMatching), vp, C.POINTER(i32),
                                                  C.POINTER(i32)]
+    L.plslam_stereo_point_gate.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, vp, vp, C.POINTER(i32)]
+    L.plslam_stereo_line_gate.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, f64, f64, vp, vp, C.POINTER(i32)]
     L.plslam_match_grid.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, vp, vp, f64, vp, f64, C.c_int, vp,
                                     C.POINTER(i32)]
     L.plslam_grid_plan_create.argtypes = [vp, C.POINTER(GridProblem), i32, C.POINTER(vp)]
@@ -301,6 +304,28 @@ class Context:
                                          _p(b) if b is not None else None, float(sim_th), _p(w), float(nnr),
                                          int(bool(mutual)), _p(m12), C.byref(n)), "plslam_match_grid")
         return m12, n.value
+
+    def stereo_point_gate(self, m12, kp_l, kp_r, max_dist_epip, min_disp):
+        """StereoFrame::matchStereoPoints gates -> (stereo_12, disp, n_stereo)."""
+        m12 = _arr(m12, np.int32)
+        a, b = _arr(kp_l, np.float32, (-1, 2)), _arr(kp_r, np.float32, (-1, 2))
+        out, disp = np.empty(m12.shape[0], np.int32), np.empty(m12.shape[0], np.float64)
+        n = C.c_int32()
+        _check(self._L.plslam_stereo_point_gate(self._h, _p(m12), m12.shape[0], _p(a), _p(b), b.shape[0],
+                                                float(max_dist_epip), float(min_disp), _p(out), _p(disp), C.byref(n)),
+               "plslam_stereo_point_gate")
+        return out, disp, n.value
+
+    def stereo_line_gate(self, m12, seg_l, seg_r, min_disp, line_horiz_th, stereo_overlap_th, ls_min_disp_ratio):
+        """StereoFrame::matchStereoLines gates -> (stereo_12, disp_se[n, 2], n_stereo)."""
+        m12 = _arr(m12, np.int32)
+        a, b = _arr(seg_l, np.float32, (-1, 4)), _arr(seg_r, np.float32, (-1, 4))
+        out, disp = np.empty(m12.shape[0], np.int32), np.empty((m12.shape[0], 2), np.float64)
+        n = C.c_int32()
+        _check(self._L.plslam_stereo_line_gate(self._h, _p(m12), m12.shape[0], _p(a), _p(b), b.shape[0], float(min_disp),
+                                               float(line_horiz_th), float(stereo_overlap_th), float(ls_min_disp_ratio),
+                                               _p(out), _p(disp), C.byref(n)), "plslam_stereo_line_gate")
+        return out, disp, n.value
 
     def match_batched(self, d1, off1, d2, off2, nnr: float, mutual: bool = True):
         d1 = _arr(d1, np.uint8, (-1, 32))
