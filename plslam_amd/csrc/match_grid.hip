@@ -79,6 +79,14 @@ __device__ __forceinline__ void best2_fold(uint32_t& k1, uint32_t& k2, uint32_t 
     k1 = lo;
 }
 
+// Slot k of lane `tid` in the transposed candidate store of a round: row k of a [depth][1024] array, rotated by one
+// wave per row -- a wave's successive slots then fall into different 256-byte channels of L2 / HBM instead of all
+// into the same one (row pitch 4 KB = 16 channels x 256 B)
+__device__ __forceinline__ size_t slot_index(uint32_t k, int tid)
+{
+    return (size_t)k * GRID_THREADS + ((uint32_t)(tid + (k << 6)) & (uint32_t)(GRID_THREADS - 1));
+}
+
 struct RowWindows {     // GridStructure::get ranges of one window centre (clamped to the grid: they fit 32 bits)
     int32_t min_x, max_x, min_y, max_y;
 };
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
         if (i1 < n1) {
             const u32x4 qa = g_d1[2 * (int64_t)i1], qb = g_d1[2 * (int64_t)i1 + 1];
             uint32_t k1 = KEY_NONE, k2 = KEY_NONE, kout = 0;
-            PLSLAM_AS_GLOBAL uint32_t* slot = store + store_words + tid;
+            PLSLAM_AS_GLOBAL uint32_t* slot = store + store_words;
             for_candidates(g, P, i1, [&](const int32_t (&i2)[CB]) {
                 u32x4 ta[CB], tb[CB];
 #pragma unroll
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
                         if (g.mutual) {
                             // the first record pass, fused: no column has a record yet, so every candidate proposes
                             atomicMin((uint32_t*)&P.next[i2[j]], ((uint32_t)i1 << REC_D_BITS) | d);
-                            slot[(size_t)kout * GRID_THREADS] = key;
+                            slot[slot_index(kout, tid)] = key;
                             ++kout;
                         } else
                             best2_fold(k1, k2, key);
@@ -313,12 +321,12 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
     if (g.mutual) {
         // one row's share of a pass: stream its remaining candidates from `slot` (stride apart), keep the survivors
         // in `out`; returns how many
-        auto pass_row = [&](int32_t i1, auto slot, auto out, uint32_t stride, uint32_t cnt) -> uint32_t {
+        auto pass_row = [&](int32_t i1, auto slot, auto out, auto at, uint32_t cnt) -> uint32_t {
             uint32_t k1 = P.row_k1[i1], k2 = P.row_k2[i1], kout = 0;
             for (uint32_t k0 = 0; k0 < cnt; k0 += PB_BATCH) {         // PB_BATCH independent loads in flight
                 uint32_t key[PB_BATCH], st[PB_BATCH];
 #pragma unroll
-                for (int j = 0; j < PB_BATCH; ++j) key[j] = k0 + j < cnt ? slot[(size_t)(k0 + j) * stride] : KEY_NONE;
+                for (int j = 0; j < PB_BATCH; ++j) key[j] = k0 + j < cnt ? slot[at(k0 + j)] : KEY_NONE;
 #pragma unroll
                 for (int j = 0; j < PB_BATCH; ++j) st[j] = P.state[key[j] == KEY_NONE ? 0u : key[j] & KEY_IDX_MASK];
 #pragma unroll
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
                     const uint32_t cur = st[j] == KEY_NONE ? 512u : st[j] & REC_D_MASK;
                     if (key[j] != KEY_NONE && d < cur) {             // still below the newest record: propose, keep
                         atomicMin((uint32_t*)&P.next[i2], me);
-                        out[(size_t)kout * stride] = key[j];
+                        out[at(kout)] = key[j];
                         ++kout;
                     }
                 }
@@ -401,12 +409,12 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
                     const int32_t i1 = r * GRID_THREADS + tid;
                     if (i1 < n1) {
                         const uint32_t cnt = lcnt[i1];
-                        PLSLAM_AS_GLOBAL const uint32_t* slot = store + off + tid;
+                        PLSLAM_AS_GLOBAL const uint32_t* slot = store + off;
                         PLSLAM_AS_LDS uint32_t* dstp = lstore + row_off[i1];
                         for (uint32_t k0 = 0; k0 < cnt; k0 += PB_BATCH) {
                             uint32_t key[PB_BATCH];
 #pragma unroll
-                            for (int j = 0; j < PB_BATCH; ++j) key[j] = k0 + j < cnt ? slot[(size_t)(k0 + j) * GRID_THREADS] : 0u;
+                            for (int j = 0; j < PB_BATCH; ++j) key[j] = k0 + j < cnt ? slot[slot_index(k0 + j, tid)] : 0u;
 #pragma unroll
                             for (int j = 0; j < PB_BATCH; ++j)
                                 if (k0 + j < cnt) dstp[k0 + j] = key[j];
@@ -420,7 +428,8 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
                         const uint32_t cnt = lcnt[i1];
                         if (cnt) {
                             PLSLAM_AS_LDS uint32_t* rowp = lstore + row_off[i1];
-                            lcnt[i1] = pass_row(i1, rowp, rowp, 1u, cnt);   // in place: survivors land at or before their source
+                            // in place: survivors land at or before their source
+                            lcnt[i1] = pass_row(i1, rowp, rowp, [](uint32_t k) { return k; }, cnt);
                         }
                     }
                     more = sweep();
@@ -440,7 +449,8 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
                     const int32_t i1 = r * GRID_THREADS + tid;
                     if (i1 < n1) {
                         const uint32_t cnt = rcnt[i1];
-                        if (cnt) rcnt[i1] = pass_row(i1, src + off + tid, dst + off + tid, (uint32_t)GRID_THREADS, cnt);
+                        if (cnt)
+                            rcnt[i1] = pass_row(i1, src + off, dst + off, [tid](uint32_t k) { return slot_index(k, tid); }, cnt);
                     }
                     off += round_k[r] * GRID_THREADS;
                 }
