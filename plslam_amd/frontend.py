@@ -130,14 +130,23 @@ class StereoBatchMatcher:
 class PipelinedGather:
     """Gathers the per-step match tables of all ranks to `root` on a communication stream while the
     next step computes.  Fixed-stride tables are received straight into one preallocated
-    (world, B, stride) buffer per in-flight step (no concatenation)."""
+    (world, B, stride) buffer per in-flight step (no concatenation).
 
-    def __init__(self, bm: StereoBatchMatcher, world: int, rank: int, root: int = 0, group=None):
+    Wire format: a table entry is a row index of the other image or -1, so with at most 32 767 features per
+    image it travels as int16 (27.8 MB instead of 55.7 MB per rank and step at 4096 pairs of 1500 + 200
+    features): half the bytes on every xGMI link into the root and half the root's HBM writes; `gathered()`
+    widens back to the int32 tables of the C ABI."""
+
+    def __init__(self, bm: StereoBatchMatcher, world: int, rank: int, root: int = 0, group=None, compact=None):
         import torch
         self.torch, self.bm, self.world, self.rank, self.root, self.group = torch, bm, world, rank, root, group
         self.comm = torch.cuda.Stream(device=bm.dev)
         self.nbuf = len(bm.tables)
-        self.recv = [torch.empty((world, bm.B, bm.stride), dtype=torch.int32, device=bm.dev)
+        self.compact = (max(bm.n_orb, bm.n_lbd) <= 32767) if compact is None else bool(compact)
+        self.wire = torch.int16 if self.compact else torch.int32
+        self.send = [torch.empty((bm.B, bm.stride), dtype=self.wire, device=bm.dev) for _ in range(self.nbuf)] \
+            if self.compact else list(bm.tables)
+        self.recv = [torch.empty((world, bm.B, bm.stride), dtype=self.wire, device=bm.dev)
                      for _ in range(self.nbuf)] if rank == root else [None] * self.nbuf
         self.works = [None] * self.nbuf      # outstanding gather per buffer
         self.done_ev = [None] * self.nbuf    # recorded on the comm stream after that gather
@@ -149,10 +158,17 @@ class PipelinedGather:
         if self.done_ev[b] is not None:                    # buffer b is being re-used: its previous gather
             self.bm.streams[b].wait_event(self.done_ev[b])  # must have read the table before we overwrite it
         ev = self.bm.run_async(b)
+        if self.compact:                                    # narrow on the compute stream, right behind the finalize
+            with self.torch.cuda.stream(self.bm.streams[b]):
+                self.send[b].copy_(self.bm.tables[b])
+                ev = self.torch.cuda.Event()
+                ev.record(self.bm.streams[b])
         with self.torch.cuda.stream(self.comm):
             self.comm.wait_event(ev)
-            glist = list(self.recv[b].unbind(0)) if self.rank == self.root else None
-            w = dist.gather(self.bm.tables[b], gather_list=glist, dst=self.root, group=self.group, async_op=True)
+            # RCCL has no 16-bit integer type; a gather moves bytes, so both sides are viewed as uint8
+            glist = list(self.recv[b].view(self.torch.uint8).unbind(0)) if self.rank == self.root else None
+            w = dist.gather(self.send[b].view(self.torch.uint8), gather_list=glist, dst=self.root, group=self.group,
+                            async_op=True)
             w.wait()                                        # stream-level wait (comm stream), not a host block
             done = self.torch.cuda.Event()
             done.record(self.comm)
@@ -166,7 +182,9 @@ class PipelinedGather:
         self.torch.cuda.synchronize(self.bm.dev)
 
     def gathered(self, b: int):
-        return self.recv[b].reshape(self.world * self.bm.B, self.bm.stride) if self.rank == self.root else None
+        if self.rank != self.root:
+            return None
+        return self.recv[b].reshape(self.world * self.bm.B, self.bm.stride).to(self.torch.int32)
 
 
 def gather_tables(local, world: int, rank: int, root: int = 0, group=None, force: bool = False):
