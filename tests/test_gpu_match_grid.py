@@ -192,3 +192,26 @@ def test_committed_grid_goldens(ctx):
         m, n = ctx.match_grid(window=w, nnr=nnr, mutual=mutual, **c)
         np.testing.assert_array_equal(m, want)
         assert n == int((want >= 0).sum())
+
+
+@pytest.mark.parametrize("n1,n2", [(1500, 1500), (4000, 4000)])
+def test_full_window_without_mutual_is_brute_force(ctx, n1, n2):
+    """Size-independent property at BASELINE sizes (C2 / C5 rows), no oracle involved: with a window that covers the
+    whole grid and bestLRMatches off, every row's candidates are ALL items, so matchGrid must return what the
+    brute-force matcher (StVO::match without the mutual check, a different kernel family) returns -- the ratio tests
+    `d0 < d1 * 0.75` agree in fp32 and fp64 for every integer pair."""
+    f = synth.grid_frame_pair(_rng(n1), n1, n2)
+    sc = [G.GRID_COLS / f["width"], G.GRID_ROWS / f["height"]]
+    cells2 = np.clip(G.to_cells(f["px2"] * sc), 0, [G.GRID_COLS - 1, G.GRID_ROWS - 1])   # every item inside the grid
+    cs, items = G.fill_points(cells2)
+    c = dict(centres=G.to_cells(f["px1"] * sc), d1=f["d1"], cell_start=cs, cell_items=items, cols=G.GRID_COLS,
+             rows=G.GRID_ROWS, d2=f["d2"])
+    m, n = ctx.match_grid(window=(G.GRID_COLS + 8, G.GRID_COLS + 8, G.GRID_ROWS + 8, G.GRID_ROWS + 8), nnr=0.75, mutual=False, **c)
+    bf, nbf = ctx.match(f["d1"], f["d2"], 0.75, mutual=False)
+    np.testing.assert_array_equal(m, bf)
+    assert n == nbf > 0.3 * min(n1, n2)
+    # and the mutual result is reproducible call after call (atomics, but only min / count combinations)
+    a = ctx.match_grid(window=(3, 3, 3, 3), nnr=0.75, mutual=True, **c)
+    b = ctx.match_grid(window=(3, 3, 3, 3), nnr=0.75, mutual=True, **c)
+    np.testing.assert_array_equal(a[0], b[0])
+    assert a[1] == b[1] > 0
