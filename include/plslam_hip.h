@@ -407,6 +407,29 @@ int plslam_map2kf_match_lines_fast(plslam_ctx* ctx, const plslam_cam* K, const d
                                    int32_t min_matches, const plslam_fast_matching* fm, int32_t* map_to_kf,
                                    int32_t* n_matches, int32_t* used_match);
 
+/* ---- the keyframe <-> keyframe association drivers ------------------------------------------------ */
+/* Replace the compute of MapHandler::matchKF2KFPoints (src/mapHandler.cpp:234-363; :246-278) and matchKF2KFLines
+ * (:365-530; :378-426); creating the MapPoints / MapLines from matches_12 (:280-363, :428-530) stays with the caller.
+ *   fm enabled: the previous keyframe's stereo features are projected with DT (16 doubles row-major; :254-256,
+ *     :384-394) on the device, the current keyframe's features fill the GridStructure (:259-263 / :397-411), window of
+ *     matching_f2f_ws cells, StVO::matchGrid.  Points: pj_points = projection * inv_width / inv_height.  Lines: pj_lines
+ *     are the projected PIXELS -- upstream does not multiply them by inv_width (:392-393) -- truncated to int like
+ *     everything that goes into a point_2d; a projection that is not a finite int32 becomes INT_MIN (x86 cvttsd2si).
+ *   then StVO::match(prev, curr, nnr) iff n_curr > min_matches && n_prev > min_matches && matches < min_matches
+ *     (:274-278, :421-425).
+ * P_prev n_prev x 3 (stereo_pt[i]->P) / sPeP_prev n_prev x 6 (stereo_ls[i]->sP, ->eP); pl_curr n_curr x 2 /
+ * seg_curr n_curr x 4 (spl, epl).  matches_12: n_prev entries (all -1 when no matcher ran). */
+int plslam_kf2kf_match_points(plslam_ctx* ctx, const plslam_cam* K, const double* DT, const double* P_prev,
+                              const uint8_t* desc_prev, int32_t n_prev, const double* pl_curr,
+                              const uint8_t* desc_curr, int32_t n_curr, float nnr, int mutual, int32_t min_matches,
+                              const plslam_fast_matching* fm, int32_t* matches_12, int32_t* n_matches,
+                              int32_t* used_match);
+int plslam_kf2kf_match_lines(plslam_ctx* ctx, const plslam_cam* K, const double* DT, const double* sPeP_prev,
+                             const uint8_t* desc_prev, int32_t n_prev, const double* seg_curr,
+                             const uint8_t* desc_curr, int32_t n_curr, float nnr, int mutual, int32_t min_matches,
+                             const plslam_fast_matching* fm, int32_t* matches_12, int32_t* n_matches,
+                             int32_t* used_match);
+
 /* ---- representative ("median") descriptor of every landmark, batched ------------------------ */
 /* Replaces the descriptor part of MapPoint::updateAverageDescDir (src/mapFeatures.cpp:51-84) and of
  * MapLine::updateAverageDescDir (:121-157), which the reference runs per landmark whenever an

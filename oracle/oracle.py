@@ -107,6 +107,12 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.plo_stereo_line_gate.restype = C.c_int32
     lib.plo_line_segment_overlap_stereo.argtypes = [C.c_double] * 5
     lib.plo_line_segment_overlap_stereo.restype = C.c_double
+    lib.plo_kf2kf_match_points.argtypes = [C.POINTER(Cam), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                           C.c_int32, C.c_float, C.c_int, C.c_int32, C.POINTER(FastMatching), C.c_void_p,
+                                           C.POINTER(C.c_int32)]
+    lib.plo_kf2kf_match_points.restype = C.c_int32
+    lib.plo_kf2kf_match_lines.argtypes = lib.plo_kf2kf_match_points.argtypes
+    lib.plo_kf2kf_match_lines.restype = C.c_int32
     lib.plo_match_grid.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
                                    C.c_void_p, C.c_double, C.c_int, C.c_void_p]
@@ -385,6 +391,23 @@ def map2kf_match_fast(kind, cam, Twf, LM, med_desc, candidate, kf_desc, kf_feat,
         n = lib().plo_map2kf_match_lines_fast(C.byref(cam), _p(Twf), _p(LM), _p(md), _p(cand), LM.shape[0], _p(kd), _p(kf),
                                               _p(sg), _p(ki), kd.shape[0], float(nnr), int(bool(mutual)), float(max_epip),
                                               int(min_matches), C.byref(F), _p(out), C.byref(used))
+    return out, int(n), int(used.value)
+
+
+def kf2kf_match(kind, cam, DT, X_prev, desc_prev, feat_curr, desc_curr, nnr, mutual, min_matches, fm):
+    """MapHandler::matchKF2KFPoints / Lines compute part (src/mapHandler.cpp:246-278, :378-426) -> (matches_12, n, used_match)."""
+    xw, fw = (3, 2) if kind == "points" else (6, 4)
+    DT = _c(DT, np.float64).reshape(16)
+    X = _c(X_prev, np.float64).reshape(-1, xw)
+    dp, dc = _desc(desc_prev), _desc(desc_curr)
+    fc = _c(feat_curr, np.float64).reshape(-1, fw)
+    out = np.empty(X.shape[0], np.int32)
+    F = FastMatching(int(fm["enabled"]), int(fm["grid_cols"]), int(fm["grid_rows"]), int(fm["ws"]), float(fm["inv_width"]),
+                     float(fm["inv_height"]), float(fm["nnr_grid"]), float(fm.get("line_sim_th", 0.75)))
+    used = C.c_int32()
+    f = lib().plo_kf2kf_match_points if kind == "points" else lib().plo_kf2kf_match_lines
+    n = f(C.byref(cam), _p(DT), _p(X), _p(dp), X.shape[0], _p(fc), _p(dc), fc.shape[0], float(nnr), int(bool(mutual)),
+          int(min_matches), C.byref(F), _p(out), C.byref(used))
     return out, int(n), int(used.value)
 
 

@@ -588,6 +588,144 @@ void plo_map_line_visible(const plo_cam* K, const double Twf[16], const double* 
 /* ------------------------------------------------------------------------------------ */
 /* map <-> keyframe drivers: src/mapHandler.cpp:532-632 (points), :634-752 (lines)        */
 /* ------------------------------------------------------------------------------------ */
+/* double -> int as the reference's x86 build does it (cvttsd2si): truncation toward zero; NaN and values outside
+ * int32 give INT_MIN ("integer indefinite") */
+static inline int32_t cvtt_x86(double v)
+{
+    return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN;
+}
+
+/* grid of keyframe features for matchGrid: points -> their cell; lines -> Bresenham cells + unit directions.
+ * feat: per item 2 (points: pl) or 4 (lines: spl, epl) doubles, item b = feat[sel ? sel[b] : b].
+ * cs: cols*rows+1; returns malloc'ed items (caller frees); dir2: n x 2 or NULL */
+static int32_t* fill_feature_grid(int lines, const double* feat, const int32_t* sel, int32_t n, int32_t cols,
+                                  int32_t rows, double inv_w, double inv_h, int32_t* cs, double* dir2)
+{
+    int32_t* items;
+    if (!lines) {
+        int32_t* xy = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(n > 0 ? n : 1));
+        for (int32_t b = 0; b < n; ++b) {
+            const double* p = feat + 2 * (size_t)(sel ? sel[b] : b);
+            xy[2 * b] = cvtt_x86(p[0] * inv_w);
+            xy[2 * b + 1] = cvtt_x86(p[1] * inv_h);
+        }
+        items = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+        plo_grid_fill_points(xy, n, cols, rows, cs, items);
+        free(xy);
+        return items;
+    }
+    int32_t** cell_of = (int32_t**)malloc(sizeof(int32_t*) * (size_t)(n > 0 ? n : 1));
+    int32_t* ncell_of = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n > 0 ? n : 1));
+    size_t total = 0;
+    for (size_t c = 0; c <= (size_t)cols * rows; ++c) cs[c] = 0;
+    for (int32_t b = 0; b < n; ++b) {
+        const double* sg = feat + 4 * (size_t)(sel ? sel[b] : b);
+        double v[2] = {(sg[2] - sg[0]) * inv_w, (sg[3] - sg[1]) * inv_h};
+        plo_normalize2(v);
+        dir2[2 * b] = v[0];
+        dir2[2 * b + 1] = v[1];
+        const double x1 = sg[0] * inv_w, y1 = sg[1] * inv_h, x2 = sg[2] * inv_w, y2 = sg[3] * inv_h;
+        const int32_t m = plo_get_line_coords(x1, y1, x2, y2, NULL, 0);
+        cell_of[b] = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(m > 0 ? m : 1));
+        plo_get_line_coords(x1, y1, x2, y2, cell_of[b], m);
+        ncell_of[b] = m;
+        for (int32_t k = 0; k < m; ++k) {
+            const int32_t x = cell_of[b][2 * k], y = cell_of[b][2 * k + 1];
+            if (x >= 0 && x < cols && y >= 0 && y < rows) { ++cs[(size_t)x * rows + y + 1]; ++total; }
+        }
+    }
+    for (size_t c = 0; c < (size_t)cols * rows; ++c) cs[c + 1] += cs[c];
+    items = (int32_t*)malloc(sizeof(int32_t) * (total > 0 ? total : 1));
+    int32_t* fill = (int32_t*)malloc(sizeof(int32_t) * (size_t)cols * rows);
+    for (size_t c = 0; c < (size_t)cols * rows; ++c) fill[c] = cs[c];
+    for (int32_t b = 0; b < n; ++b) {                                     /* push_back order: idx ascending */
+        for (int32_t k = 0; k < ncell_of[b]; ++k) {
+            const int32_t x = cell_of[b][2 * k], y = cell_of[b][2 * k + 1];
+            if (x >= 0 && x < cols && y >= 0 && y < rows) items[fill[(size_t)x * rows + y]++] = b;
+        }
+        free(cell_of[b]);
+    }
+    free(fill); free(ncell_of); free(cell_of);
+    return items;
+}
+
+/* matchGrid over projected 3D features: cen = cells of proj(T * X) * (sx, sy), dir1 for lines */
+static int32_t grid_match_projected(int lines, const plo_cam* K, const double T[16], const double* X3, int32_t nq,
+                                    double sx, double sy, const uint8_t* Q, const int32_t* cs, const int32_t* items,
+                                    int32_t cols, int32_t rows, const uint8_t* Tdesc, int32_t nt, const double* dir2,
+                                    const plo_fast_matching* fm, int mutual, int32_t* m12)
+{
+    const int nc = lines ? 2 : 1;
+    const int32_t w[4] = {fm->ws, fm->ws, fm->ws, fm->ws};
+    int32_t* cen = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)nc * (size_t)(nq > 0 ? nq : 1));
+    double* dir1 = lines ? (double*)malloc(sizeof(double) * 2 * (size_t)(nq > 0 ? nq : 1)) : NULL;
+    for (int32_t a = 0; a < nq; ++a) {
+        for (int c = 0; c < nc; ++c) {
+            double Pf[3], pf[2];
+            xform44(T, X3 + (size_t)a * 3 * nc + 3 * c, Pf);
+            project(K, Pf, pf);
+            cen[((size_t)a * nc + c) * 2] = cvtt_x86(pf[0] * sx);
+            cen[((size_t)a * nc + c) * 2 + 1] = cvtt_x86(pf[1] * sy);
+        }
+        if (lines) {   /* matchGrid derives the query direction from the integer end points */
+            double v[2] = {(double)cen[4 * (size_t)a + 2] - (double)cen[4 * (size_t)a],
+                           (double)cen[4 * (size_t)a + 3] - (double)cen[4 * (size_t)a + 1]};
+            plo_normalize2(v);
+            dir1[2 * a] = v[0];
+            dir1[2 * a + 1] = v[1];
+        }
+    }
+    const int32_t n = plo_match_grid(cen, nc, Q, nq, cs, items, cols, rows, Tdesc, nt, dir1, dir2, fm->line_sim_th, w,
+                                     fm->nnr_grid, mutual, m12);
+    free(dir1); free(cen);
+    return n;
+}
+
+static int32_t kf2kf_driver(int lines, const plo_cam* K, const double DT[16], const double* X_prev,
+                            const uint8_t* desc_prev, int32_t n_prev, const double* feat_curr, const uint8_t* desc_curr,
+                            int32_t n_curr, float nnr, int mutual, int32_t min_matches, const plo_fast_matching* fm,
+                            int32_t* m12, int32_t* used_match)
+{
+    for (int32_t i = 0; i < n_prev; ++i) m12[i] = -1;
+    if (used_match) *used_match = 0;
+    if (n_prev <= 0 || n_curr <= 0) return 0;                                         /* :243 / :368 */
+    int32_t matches = 0;
+    if (fm && fm->enabled) {
+        int32_t* cs = (int32_t*)malloc(sizeof(int32_t) * ((size_t)fm->grid_cols * fm->grid_rows + 1));
+        double* dir2 = lines ? (double*)malloc(sizeof(double) * 2 * (size_t)n_curr) : NULL;
+        int32_t* items = fill_feature_grid(lines, feat_curr, NULL, n_curr, fm->grid_cols, fm->grid_rows, fm->inv_width,
+                                           fm->inv_height, cs, dir2);
+        /* points: pixels * inv (:256); lines: the projected pixels themselves (:392-393) */
+        matches = grid_match_projected(lines, K, DT, X_prev, n_prev, lines ? 1.0 : fm->inv_width,
+                                       lines ? 1.0 : fm->inv_height, desc_prev, cs, items, fm->grid_cols, fm->grid_rows,
+                                       desc_curr, n_curr, dir2, fm, mutual, m12);
+        free(items); free(dir2); free(cs);
+    }
+    if (n_curr > min_matches && n_prev > min_matches && matches < min_matches) {    /* :274-278 / :421-425 */
+        matches = plo_match(desc_prev, n_prev, desc_curr, n_curr, nnr, mutual, m12);
+        if (used_match) *used_match = 1;
+    }
+    return matches;
+}
+
+int32_t plo_kf2kf_match_points(const plo_cam* K, const double DT[16], const double* P_prev, const uint8_t* desc_prev,
+                               int32_t n_prev, const double* pl_curr, const uint8_t* desc_curr, int32_t n_curr,
+                               float nnr, int mutual, int32_t min_matches, const plo_fast_matching* fm, int32_t* m12,
+                               int32_t* used_match)
+{
+    return kf2kf_driver(0, K, DT, P_prev, desc_prev, n_prev, pl_curr, desc_curr, n_curr, nnr, mutual, min_matches, fm,
+                        m12, used_match);
+}
+
+int32_t plo_kf2kf_match_lines(const plo_cam* K, const double DT[16], const double* sPeP_prev,
+                              const uint8_t* desc_prev, int32_t n_prev, const double* seg_curr,
+                              const uint8_t* desc_curr, int32_t n_curr, float nnr, int mutual, int32_t min_matches,
+                              const plo_fast_matching* fm, int32_t* m12, int32_t* used_match)
+{
+    return kf2kf_driver(1, K, DT, sPeP_prev, desc_prev, n_prev, seg_curr, desc_curr, n_curr, nnr, mutual, min_matches,
+                        fm, m12, used_match);
+}
+
 static int32_t map2kf_driver(int lines, const plo_cam* K, const double Twf[16], const double* LM,
                              const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map,
                              const uint8_t* kf_desc, const double* kf_feat, const double* kf_seg,
@@ -622,78 +760,16 @@ static int32_t map2kf_driver(int lines, const plo_cam* K, const double Twf[16], 
         int32_t* m12 = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq);
         int32_t n_m12 = 0;                         /* matches_12.size(): 0 until a matcher ran */
         if (fm && fm->enabled) {                   /* :578-592 / :681-707 */
-            const int32_t cols = fm->grid_cols, rows = fm->grid_rows;
-            const int32_t w[4] = {fm->ws, fm->ws, fm->ws, fm->ws};
-            const int nc = lines ? 2 : 1;
-            int32_t* cen = (int32_t*)malloc(sizeof(int32_t) * (size_t)nq * 2 * nc);
-            double* dir1 = lines ? (double*)malloc(sizeof(double) * (size_t)nq * 2) : NULL;
-            double* dir2 = lines ? (double*)malloc(sizeof(double) * (size_t)nt * 2) : NULL;
-            int32_t* cs = (int32_t*)malloc(sizeof(int32_t) * ((size_t)cols * rows + 1));
-            int32_t* items = NULL;
-            for (int32_t a = 0; a < nq; ++a)       /* pj_points / pj_lines: make_pair<int,int>(double, double) */
-                for (int c = 0; c < nc; ++c) {
-                    double Pf[3], pf[2];
-                    xform44(Twf, QL + (size_t)a * lw + 3 * c, Pf);
-                    project(K, Pf, pf);
-                    cen[((size_t)a * nc + c) * 2] = (int32_t)(pf[0] * fm->inv_width);
-                    cen[((size_t)a * nc + c) * 2 + 1] = (int32_t)(pf[1] * fm->inv_height);
-                }
-            if (!lines) {
-                int32_t* xy = (int32_t*)malloc(sizeof(int32_t) * (size_t)nt * 2);
-                for (int32_t b = 0; b < nt; ++b) {                                     /* :581-584 */
-                    xy[2 * b] = (int32_t)(TF[2 * (size_t)b] * fm->inv_width);
-                    xy[2 * b + 1] = (int32_t)(TF[2 * (size_t)b + 1] * fm->inv_height);
-                }
-                items = (int32_t*)malloc(sizeof(int32_t) * (size_t)nt);
-                plo_grid_fill_points(xy, nt, cols, rows, cs, items);
-                free(xy);
-            } else {
-                /* :686-699: directions + Bresenham cells of every unmatched keyframe line */
-                int32_t** cell_of = (int32_t**)malloc(sizeof(int32_t*) * (size_t)nt);
-                int32_t* ncell_of = (int32_t*)malloc(sizeof(int32_t) * (size_t)nt);
-                size_t total = 0;
-                for (size_t c = 0; c <= (size_t)cols * rows; ++c) cs[c] = 0;
-                for (int32_t b = 0; b < nt; ++b) {
-                    const double* sg = kf_seg + 4 * (size_t)ti[b];
-                    double v[2] = {(sg[2] - sg[0]) * fm->inv_width, (sg[3] - sg[1]) * fm->inv_height};
-                    plo_normalize2(v);
-                    dir2[2 * b] = v[0];
-                    dir2[2 * b + 1] = v[1];
-                    const double x1 = sg[0] * fm->inv_width, y1 = sg[1] * fm->inv_height, x2 = sg[2] * fm->inv_width,
-                                 y2 = sg[3] * fm->inv_height;
-                    const int32_t n = plo_get_line_coords(x1, y1, x2, y2, NULL, 0);
-                    cell_of[b] = (int32_t*)malloc(sizeof(int32_t) * 2 * (size_t)(n > 0 ? n : 1));
-                    plo_get_line_coords(x1, y1, x2, y2, cell_of[b], n);
-                    ncell_of[b] = n;
-                    for (int32_t k = 0; k < n; ++k) {
-                        const int32_t x = cell_of[b][2 * k], y = cell_of[b][2 * k + 1];
-                        if (x >= 0 && x < cols && y >= 0 && y < rows) { ++cs[(size_t)x * rows + y + 1]; ++total; }
-                    }
-                }
-                for (size_t c = 0; c < (size_t)cols * rows; ++c) cs[c + 1] += cs[c];
-                items = (int32_t*)malloc(sizeof(int32_t) * (total > 0 ? total : 1));
-                int32_t* fill = (int32_t*)malloc(sizeof(int32_t) * (size_t)cols * rows);
-                for (size_t c = 0; c < (size_t)cols * rows; ++c) fill[c] = cs[c];
-                for (int32_t b = 0; b < nt; ++b) {                                     /* push_back order: idx ascending */
-                    for (int32_t k = 0; k < ncell_of[b]; ++k) {
-                        const int32_t x = cell_of[b][2 * k], y = cell_of[b][2 * k + 1];
-                        if (x >= 0 && x < cols && y >= 0 && y < rows) items[fill[(size_t)x * rows + y]++] = b;
-                    }
-                    free(cell_of[b]);
-                }
-                free(fill); free(ncell_of); free(cell_of);
-                for (int32_t a = 0; a < nq; ++a) { /* matchGrid derives the query direction from the integer end points */
-                    double v[2] = {(double)(cen[4 * (size_t)a + 2] - cen[4 * (size_t)a]),
-                                   (double)(cen[4 * (size_t)a + 3] - cen[4 * (size_t)a + 1])};
-                    plo_normalize2(v);
-                    dir1[2 * a] = v[0];
-                    dir1[2 * a + 1] = v[1];
-                }
-            }
-            matches = plo_match_grid(cen, nc, Q, nq, cs, items, cols, rows, T, nt, dir1, dir2, fm->line_sim_th, w,
-                                     fm->nnr_grid, mutual, m12);
+            int32_t* cs = (int32_t*)malloc(sizeof(int32_t) * ((size_t)fm->grid_cols * fm->grid_rows + 1));
+            double* dir2 = lines ? (double*)malloc(sizeof(double) * 2 * (size_t)nt) : NULL;
+            /* the grid of the unmatched keyframe features: points :581-584, lines :686-698 (kf_seg = spl, epl) */
+            int32_t* items = fill_feature_grid(lines, lines ? kf_seg : kf_feat, ti, nt, fm->grid_cols, fm->grid_rows,
+                                               fm->inv_width, fm->inv_height, cs, dir2);
+            /* pj_points / pj_lines: projections * inv_width / inv_height, make_pair<int,int> (:555, :659) */
+            matches = grid_match_projected(lines, K, Twf, QL, nq, fm->inv_width, fm->inv_height, Q, cs, items,
+                                           fm->grid_cols, fm->grid_rows, T, nt, dir2, fm, mutual, m12);
             n_m12 = nq;
-            free(items); free(cs); free(dir2); free(dir1); free(cen);
+            free(items); free(dir2); free(cs);
         }
         if (nq > min_matches && matches < min_matches) {                               /* :594-598 / :709-713 */
             matches = plo_match(Q, nq, T, nt, nnr, mutual, m12);

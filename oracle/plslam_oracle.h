@@ -176,6 +176,26 @@ int32_t plo_map2kf_match_lines_fast(const plo_cam* K, const double Twf[16], cons
                                     int32_t min_matches, const plo_fast_matching* fm, int32_t* map_to_kf,
                                     int32_t* used_match);
 
+/* ---- keyframe <-> keyframe drivers: MapHandler::matchKF2KFPoints / matchKF2KFLines ----------------
+ * src/mapHandler.cpp:234-363 / :365-530, compute part (:246-278 / :378-426); creating MapPoints / MapLines from the
+ * table (:280-363) stays with the caller.
+ *   if fastMatching: project the previous keyframe's stereo features with DT (:254-256 / :384-394), fill the grid with
+ *       the current keyframe's features (:259-263 / :397-411), window of matchingF2FWs cells, matchGrid;
+ *       points: pj_points = projection * inv_width / inv_height; lines: pj_lines = the projections in PIXELS, not
+ *       multiplied by inv_width (:392-393, as written upstream), both truncated to int by make_pair<int,int>
+ *       (a projection that is not a finite int32 becomes INT_MIN, what x86's cvttsd2si returns);
+ *   if n_curr > min_matches && n_prev > min_matches && matches < min_matches: matches = match(prev, curr, nnr)
+ *       (:274-278 / :421-425).
+ * m12: n_prev entries (all -1 when no matcher ran).  Returns matches.  seg_curr: n_curr x 4 (spl, epl). */
+int32_t plo_kf2kf_match_points(const plo_cam* K, const double DT[16], const double* P_prev, const uint8_t* desc_prev,
+                               int32_t n_prev, const double* pl_curr, const uint8_t* desc_curr, int32_t n_curr,
+                               float nnr, int mutual, int32_t min_matches, const plo_fast_matching* fm, int32_t* m12,
+                               int32_t* used_match);
+int32_t plo_kf2kf_match_lines(const plo_cam* K, const double DT[16], const double* sPeP_prev,
+                              const uint8_t* desc_prev, int32_t n_prev, const double* seg_curr,
+                              const uint8_t* desc_curr, int32_t n_curr, float nnr, int mutual, int32_t min_matches,
+                              const plo_fast_matching* fm, int32_t* m12, int32_t* used_match);
+
 /* ---- stereo L<->R gates inside StVO::StereoFrame (stvo-pl stereoFrame.cpp, [RECALL]) -------
  * Thresholds are the reference's own config keys: max_dist_epip (config/config/config_kitti.yaml:25), min_disp (:26),
  * stereo_overlap_th (:31), line_horiz_th (:34), ls_min_disp_ratio (:36).  matches_12 is the table StVO::match /

@@ -33,6 +33,7 @@ ABI_SYMBOLS = (
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
     "plslam_map2kf_match_points_fast", "plslam_map2kf_match_lines_fast",
+    "plslam_kf2kf_match_points", "plslam_kf2kf_match_lines",
     "plslam_lbd_binarise", "plslam_lbd_binarise_dev",
     "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
     "plslam_stereo_point_gate", "plslam_stereo_line_gate",
@@ -177,6 +178,9 @@ def load() -> C.CDLL:
     L.plslam_map2kf_match_lines_fast.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, C.c_float,
                                                  C.c_int, f64, i32, C.POINTER(FastMatching), vp, C.POINTER(i32),
                                                  C.POINTER(i32)]
+    for f in (L.plslam_kf2kf_match_points, L.plslam_kf2kf_match_lines):
+        f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, i32, vp, vp, i32, C.c_float, C.c_int, i32, C.POINTER(FastMatching), vp,
+                      C.POINTER(i32), C.POINTER(i32)]
     L.plslam_stereo_point_gate.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, vp, vp, C.POINTER(i32)]
     L.plslam_stereo_line_gate.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, f64, f64, vp, vp, C.POINTER(i32)]
     L.plslam_match_grid.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, vp, vp, f64, vp, f64, C.c_int, vp,
@@ -497,6 +501,24 @@ class Context:
                                                           float(nnr), int(bool(mutual)), float(max_epip),
                                                           int(min_matches), C.byref(F), _p(out), C.byref(n),
                                                           C.byref(used)), "plslam_map2kf_match_lines_fast")
+        return out, n.value, used.value
+
+    def kf2kf_match(self, kind, cam, DT, X_prev, desc_prev, feat_curr, desc_curr, nnr, mutual, min_matches, fm):
+        """MapHandler::matchKF2KFPoints / Lines compute part -> (matches_12, n_matches, used_match)."""
+        xw, fw = (3, 2) if kind == "points" else (6, 4)
+        DT = _arr(DT, np.float64, (16,))
+        X = _arr(X_prev, np.float64, (-1, xw))
+        dp, dc = _arr(desc_prev, np.uint8, (-1, 32)), _arr(desc_curr, np.uint8, (-1, 32))
+        fc = _arr(feat_curr, np.float64, (-1, fw))
+        out = np.empty(X.shape[0], np.int32)
+        F = FastMatching(int(fm["enabled"]), int(fm["grid_cols"]), int(fm["grid_rows"]), int(fm["ws"]),
+                         float(fm["inv_width"]), float(fm["inv_height"]), float(fm["nnr_grid"]),
+                         float(fm.get("line_sim_th", 0.75)))
+        n, used = C.c_int32(), C.c_int32()
+        fn = self._L.plslam_kf2kf_match_points if kind == "points" else self._L.plslam_kf2kf_match_lines
+        _check(fn(self._h, C.byref(cam), _p(DT), _p(X), _p(dp), X.shape[0], _p(fc), _p(dc), fc.shape[0], float(nnr),
+                  int(bool(mutual)), int(min_matches), C.byref(F), _p(out), C.byref(n), C.byref(used)),
+               "plslam_kf2kf_match_" + kind)
         return out, n.value, used.value
 
     # ---- device-pointer calls ----------------------------------------------------------------

@@ -341,17 +341,19 @@ k_project_cells(CamD K, Pose12 Twf, const double* __restrict__ X, int32_t n, int
     if (i >= n) return;
     const int nc = lines ? 2 : 1;
     int32_t c[4];
+    // double -> int as the reference's x86 build does it (cvttsd2si): truncation; NaN / out of range -> INT_MIN
+    auto cvtt = [](double v) -> int32_t { return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN; };
     for (int e = 0; e < nc; ++e) {
         double P[3], u, v;
         xform44(Twf, X + (size_t)i * 3 * nc + 3 * e, P);
         project(K, P, u, v);
-        c[2 * e] = (int32_t)(u * inv_w);
-        c[2 * e + 1] = (int32_t)(v * inv_h);
+        c[2 * e] = cvtt(u * inv_w);
+        c[2 * e + 1] = cvtt(v * inv_h);
         cells[((size_t)i * nc + e) * 2] = c[2 * e];
         cells[((size_t)i * nc + e) * 2 + 1] = c[2 * e + 1];
     }
     if (lines) {
-        const double vx = (double)(c[2] - c[0]), vy = (double)(c[3] - c[1]);
+        const double vx = (double)c[2] - (double)c[0], vy = (double)c[3] - (double)c[1];
         const double magnitude = sqrt(vx * vx + vy * vy);
         dir1[2 * (size_t)i] = vx / magnitude;
         dir1[2 * (size_t)i + 1] = vy / magnitude;

@@ -77,6 +77,156 @@ void csr_fill(const std::vector<int32_t>& item, const std::vector<int32_t>& cx, 
         if (cx[k] >= 0 && cx[k] < cols && cy[k] >= 0 && cy[k] < rows) items[(size_t)fill[(size_t)cx[k] * rows + cy[k]]++] = item[k];
 }
 
+inline int32_t cvtt_x86(double v)   // as the reference's x86 build converts (cvttsd2si): NaN / out of range -> INT_MIN
+{
+    return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN;
+}
+
+// StVO::matchGrid over projected 3D features, device-resident except the grid fill:
+//   d_X3 (device): nq x 3 (points) / nq x 6 (lines) features, projected with T16 into cells * (sx, sy) by K16';
+//   feat_curr (HOST): the keyframe features that fill the GridStructure -- item b = feat_curr[sel ? sel[b] : b],
+//   2 doubles (pl) or 4 (spl, epl); d_Q / d_T (device): the descriptor matrices; d_m12 (device): nq entries out.
+// Uses ctx->misc_b (tables) and ctx->misc_c (kernel scratch).  Synchronises the stream (twice).
+int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16, const double* d_X3, int32_t nq, double sx,
+              double sy, const uint8_t* d_Q, const double* feat_curr, const int32_t* sel, int32_t nt, const uint8_t* d_T,
+              const plslam_fast_matching* fm, int mutual, int32_t* d_m12, int32_t* matches)
+{
+    hipStream_t s = ctx->stream;
+    int rc;
+    const int nc = lines ? 2 : 1;
+    const int32_t cols = fm->grid_cols, rows = fm->grid_rows;
+    const int32_t win[4] = {fm->ws, fm->ws, fm->ws, fm->ws};
+    Carve cf;
+    const size_t oCen = cf.take((size_t)nq * nc * 8), oD1 = cf.take(lines ? (size_t)nq * 16 : 0),
+                 oD2 = cf.take(lines ? (size_t)nt * 16 : 0), oCs = cf.take(((size_t)cols * rows + 1) * 4),
+                 oDesc = cf.take(sizeof(GridDesc)), oSt = cf.take(8);
+    std::vector<int32_t> cen((size_t)nq * nc * 2), cs, items, it, cx, cy, xy;
+    std::vector<double> dir2;
+    if (!lines) {
+        for (int32_t b = 0; b < nt; ++b) {
+            const double* p = feat_curr + 2 * (size_t)(sel ? sel[b] : b);
+            it.push_back(b);
+            cx.push_back(cvtt_x86(p[0] * fm->inv_width));
+            cy.push_back(cvtt_x86(p[1] * fm->inv_height));
+        }
+    } else {
+        dir2.resize((size_t)nt * 2);
+        for (int32_t b = 0; b < nt; ++b) {
+            const double* sg = feat_curr + 4 * (size_t)(sel ? sel[b] : b);
+            double vx = (sg[2] - sg[0]) * fm->inv_width, vy = (sg[3] - sg[1]) * fm->inv_height;
+            const double magnitude = std::sqrt(vx * vx + vy * vy);
+            dir2[2 * (size_t)b] = vx / magnitude;
+            dir2[2 * (size_t)b + 1] = vy / magnitude;
+            line_cells(sg[0] * fm->inv_width, sg[1] * fm->inv_height, sg[2] * fm->inv_width, sg[3] * fm->inv_height, xy);
+            for (size_t k = 0; k + 1 < xy.size(); k += 2) {
+                it.push_back(b);
+                cx.push_back(xy[k]);
+                cy.push_back(xy[k + 1]);
+            }
+        }
+    }
+    csr_fill(it, cx, cy, cols, rows, cs, items);
+    const int32_t n_items = cs.back();
+    const size_t oIt = cf.take((size_t)(n_items + 1) * 4);
+    if ((rc = ctx->misc_b.reserve(cf.off))) return rc;
+    char* f = ctx->misc_b.as<char>();
+    if ((rc = launch_project_cells(*K, T16, d_X3, nq, lines, sx, sy, (int32_t*)(f + oCen),
+                                   lines ? (double*)(f + oD1) : nullptr, s)))
+        return rc;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(cen.data(), f + oCen, (size_t)nq * nc * 8, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oCs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oIt, items.data(), (size_t)(n_items + 1) * 4, hipMemcpyHostToDevice, s));
+    if (lines) PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oD2, dir2.data(), (size_t)nt * 16, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemsetAsync(f + oSt, 0, 8, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));                                       // cells on the host: store size
+    const int64_t cap = grid_store_capacity_host(cen.data(), nq, nc, cs.data(), cols, rows, win, mutual);
+    PLSLAM_REQUIRE(cap < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
+    if ((rc = ctx->misc_c.reserve(grid_scratch_words(nq, nt, (int64_t)cols * rows, (int32_t)cap) * 4 + 256))) return rc;
+    plslam_grid_problem q{};
+    q.d1 = d_Q; q.d2 = d_T; q.centres1 = (int32_t*)(f + oCen);
+    q.cell_start = (int32_t*)(f + oCs); q.cell_items = (int32_t*)(f + oIt);
+    q.dir1 = lines ? (double*)(f + oD1) : nullptr; q.dir2 = lines ? (double*)(f + oD2) : nullptr;
+    q.n1 = nq; q.n2 = nt; q.n_centres = nc; q.grid_cols = cols; q.grid_rows = rows; q.n_items = n_items;
+    for (int k = 0; k < 4; ++k) q.window[k] = win[k];
+    q.sim_th = fm->line_sim_th; q.nnr = fm->nnr_grid; q.mutual = mutual ? 1 : 0;
+    q.pair_capacity = (int32_t)cap;
+    q.matches_12 = d_m12; q.n_matches = (int32_t*)(f + oSt);
+    GridDesc hdesc;
+    if ((rc = launch_match_grid_one(q, ctx->misc_c.as<uint32_t>(), (int32_t*)(f + oSt) + 1, (GridDesc*)(f + oDesc), &hdesc, s)))
+        return rc;
+    int32_t res[2] = {0, 0};
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(res, f + oSt, 8, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));                                       // also keeps hdesc alive long enough
+    PLSLAM_REQUIRE(res[1] == 0, PLSLAM_ERANGE);
+    *matches = res[0];
+    return PLSLAM_OK;
+}
+
+bool fast_ok(const plslam_fast_matching* fm)
+{
+    return fm->grid_cols >= 1 && fm->grid_rows >= 1 && fm->ws >= 0 && (int64_t)fm->grid_cols * fm->grid_rows < (int64_t(1) << 30);
+}
+
+// MapHandler::matchKF2KFPoints / matchKF2KFLines, compute part (src/mapHandler.cpp:246-278 / :378-426)
+int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* DT, const double* X_prev,
+                 const uint8_t* desc_prev, int32_t n_prev, const double* feat_curr, const uint8_t* desc_curr,
+                 int32_t n_curr, float nnr, int mutual, int32_t min_matches, const plslam_fast_matching* fm,
+                 int32_t* matches_12, int32_t* n_matches, int32_t* used_match)
+{
+    PLSLAM_REQUIRE(ctx && K && DT && n_prev >= 0 && n_curr >= 0, PLSLAM_EINVAL);
+    const bool fast = fm && fm->enabled;
+    if (fast) PLSLAM_REQUIRE(fast_ok(fm), PLSLAM_EINVAL);
+    if (n_matches) *n_matches = 0;
+    if (used_match) *used_match = 0;
+    if (n_prev == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(matches_12 != nullptr, PLSLAM_EINVAL);
+    for (int32_t i = 0; i < n_prev; ++i) matches_12[i] = -1;
+    if (n_curr == 0) return PLSLAM_OK;                                    // :243 / :368
+    PLSLAM_REQUIRE(X_prev && desc_prev && feat_curr && desc_curr, PLSLAM_EINVAL);
+    const bool bf_possible = n_curr > min_matches && n_prev > min_matches;
+    if (!fast && !(bf_possible && 0 < min_matches)) return PLSLAM_OK;      // no matcher would run
+    const int xw = lines ? 6 : 3;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipStream_t s = ctx->stream;
+    Carve c;
+    const size_t oX = c.take((size_t)n_prev * xw * 8), oQ = c.take((size_t)n_prev * 32), oT = c.take((size_t)n_curr * 32),
+                 oM = c.take((size_t)n_prev * 4);
+    int rc;
+    if ((rc = ctx->misc_a.reserve(c.off))) return rc;
+    char* d = ctx->misc_a.as<char>();
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oX, X_prev, (size_t)n_prev * xw * 8, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oQ, desc_prev, (size_t)n_prev * 32, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oT, desc_curr, (size_t)n_curr * 32, hipMemcpyHostToDevice, s));
+    int32_t matches = 0;
+    bool have = false;
+    if (fast) {
+        // points: pj_points = projection * inv (:256); lines: pj_lines = the projected PIXELS (:392-393, as upstream)
+        if ((rc = grid_path(ctx, lines, K, DT, (const double*)(d + oX), n_prev, lines ? 1.0 : fm->inv_width,
+                            lines ? 1.0 : fm->inv_height, (const uint8_t*)(d + oQ), feat_curr, nullptr, n_curr,
+                            (const uint8_t*)(d + oT), fm, mutual, (int32_t*)(d + oM), &matches)))
+            return rc;
+        have = true;
+    }
+    int32_t* d_cnt = nullptr;
+    if (bf_possible && matches < min_matches) {                            // :274-278 / :421-425
+        if ((rc = ctx->misc_b.reserve(256))) return rc;
+        d_cnt = ctx->misc_b.as<int32_t>();
+        plslam_match_problem p{};
+        p.d1 = (uint8_t*)(d + oQ); p.n1 = n_prev; p.d2 = (uint8_t*)(d + oT); p.n2 = n_curr;
+        p.nnr = nnr; p.mutual = mutual ? 1 : 0; p.matches_12 = (int32_t*)(d + oM); p.n_matches = d_cnt;
+        if ((rc = match_problems_on_ctx_stream(ctx, &p, 1))) return rc;
+        have = true;
+        if (used_match) *used_match = 1;
+    }
+    if (!have) return PLSLAM_OK;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(matches_12, d + oM, (size_t)n_prev * 4, hipMemcpyDeviceToHost, s));
+    if (d_cnt) PLSLAM_HIP_CHECK(hipMemcpyAsync(&matches, d_cnt, 4, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (n_matches) *n_matches = matches;
+    return PLSLAM_OK;
+}
+
 int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* Twf, const double* LM,
                   const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map, const uint8_t* kf_desc,
                   const double* kf_feat, const double* kf_seg, const int32_t* kf_idx, int32_t n_kf, float nnr,
@@ -86,8 +236,7 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     PLSLAM_REQUIRE(ctx && K && Twf && n_map >= 0 && n_kf >= 0, PLSLAM_EINVAL);
     const bool fast = fm && fm->enabled;
     if (fast) {
-        PLSLAM_REQUIRE(fm->grid_cols >= 1 && fm->grid_rows >= 1 && fm->ws >= 0, PLSLAM_EINVAL);
-        PLSLAM_REQUIRE((int64_t)fm->grid_cols * fm->grid_rows < (int64_t(1) << 30), PLSLAM_ERANGE);
+        PLSLAM_REQUIRE(fast_ok(fm), PLSLAM_EINVAL);
         PLSLAM_REQUIRE(!lines || kf_seg || n_kf == 0, PLSLAM_EINVAL);
     }
     if (n_matches) *n_matches = 0;
@@ -143,74 +292,11 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     int32_t matches = 0;
     bool have_m12 = false;                       // matches_12.size() != 0: a matcher ran
     if (fast) {                                  // :578-592 / :681-707
-        const int nc = lines ? 2 : 1;
-        const int32_t cols = fm->grid_cols, rows = fm->grid_rows;
-        const int32_t win[4] = {fm->ws, fm->ws, fm->ws, fm->ws};
-        // pj_points / pj_lines: the candidates' projections in grid cells, computed on the device
-        Carve cf;
-        const size_t oCen = cf.take((size_t)nq * nc * 8), oD1 = cf.take(lines ? (size_t)nq * 16 : 0),
-                     oD2 = cf.take(lines ? (size_t)nt * 16 : 0), oCs = cf.take(((size_t)cols * rows + 1) * 4),
-                     oDesc = cf.take(sizeof(GridDesc)), oSt = cf.take(8);
-        std::vector<int32_t> cen((size_t)nq * nc * 2), cs, items, it, cx, cy, xy;
-        std::vector<double> dir2;
-        // the grid of the unmatched keyframe features (host list building, as in the reference's callers)
-        if (!lines) {
-            for (int32_t b = 0; b < nt; ++b) {                                          // :581-584
-                it.push_back(b);
-                cx.push_back((int32_t)(kf_feat[2 * (size_t)ti[b]] * fm->inv_width));
-                cy.push_back((int32_t)(kf_feat[2 * (size_t)ti[b] + 1] * fm->inv_height));
-            }
-        } else {
-            dir2.resize((size_t)nt * 2);
-            for (int32_t b = 0; b < nt; ++b) {                                          // :686-698
-                const double* sg = kf_seg + 4 * (size_t)ti[b];
-                double vx = (sg[2] - sg[0]) * fm->inv_width, vy = (sg[3] - sg[1]) * fm->inv_height;
-                const double magnitude = std::sqrt(vx * vx + vy * vy);
-                dir2[2 * (size_t)b] = vx / magnitude;
-                dir2[2 * (size_t)b + 1] = vy / magnitude;
-                line_cells(sg[0] * fm->inv_width, sg[1] * fm->inv_height, sg[2] * fm->inv_width, sg[3] * fm->inv_height, xy);
-                for (size_t k = 0; k + 1 < xy.size(); k += 2) {
-                    it.push_back(b);
-                    cx.push_back(xy[k]);
-                    cy.push_back(xy[k + 1]);
-                }
-            }
-        }
-        csr_fill(it, cx, cy, cols, rows, cs, items);
-        const int32_t n_items = cs.back();
-        const size_t oIt = cf.take((size_t)(n_items + 1) * 4);
-        if ((rc = ctx->misc_b.reserve(cf.off))) return rc;
-        char* f = ctx->misc_b.as<char>();
-        if ((rc = launch_project_cells(*K, Twf, (double*)(d + oQL), nq, lines, fm->inv_width, fm->inv_height,
-                                       (int32_t*)(f + oCen), lines ? (double*)(f + oD1) : nullptr, s)))
+        // the grid of the unmatched keyframe features: points :581-584, lines :686-698 (kf_seg = spl, epl)
+        if ((rc = grid_path(ctx, lines, K, Twf, (const double*)(d + oQL), nq, fm->inv_width, fm->inv_height,
+                            (const uint8_t*)(d + oQ), lines ? kf_seg : kf_feat, ti.data(), nt, (const uint8_t*)(d + oT),
+                            fm, mutual, (int32_t*)(d + oM), &matches)))
             return rc;
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(cen.data(), f + oCen, (size_t)nq * nc * 8, hipMemcpyDeviceToHost, s));
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oCs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, s));
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oIt, items.data(), (size_t)(n_items + 1) * 4, hipMemcpyHostToDevice, s));
-        if (lines) PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oD2, dir2.data(), (size_t)nt * 16, hipMemcpyHostToDevice, s));
-        PLSLAM_HIP_CHECK(hipMemsetAsync(f + oSt, 0, 8, s));
-        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));                                       // cells on the host: store size
-        const int64_t cap = grid_store_capacity_host(cen.data(), nq, nc, cs.data(), cols, rows, win, mutual);
-        PLSLAM_REQUIRE(cap < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
-        if ((rc = ctx->misc_c.reserve(grid_scratch_words(nq, nt, (int64_t)cols * rows, (int32_t)cap) * 4 + 256))) return rc;
-        plslam_grid_problem q{};
-        q.d1 = (uint8_t*)(d + oQ); q.d2 = (uint8_t*)(d + oT); q.centres1 = (int32_t*)(f + oCen);
-        q.cell_start = (int32_t*)(f + oCs); q.cell_items = (int32_t*)(f + oIt);
-        q.dir1 = lines ? (double*)(f + oD1) : nullptr; q.dir2 = lines ? (double*)(f + oD2) : nullptr;
-        q.n1 = nq; q.n2 = nt; q.n_centres = nc; q.grid_cols = cols; q.grid_rows = rows; q.n_items = n_items;
-        for (int k = 0; k < 4; ++k) q.window[k] = win[k];
-        q.sim_th = fm->line_sim_th; q.nnr = fm->nnr_grid; q.mutual = mutual ? 1 : 0;
-        q.pair_capacity = (int32_t)cap;
-        q.matches_12 = (int32_t*)(d + oM); q.n_matches = (int32_t*)(f + oSt);
-        GridDesc hdesc;
-        if ((rc = launch_match_grid_one(q, ctx->misc_c.as<uint32_t>(), (int32_t*)(f + oSt) + 1, (GridDesc*)(f + oDesc),
-                                        &hdesc, s)))
-            return rc;
-        int32_t res[2] = {0, 0};
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(res, f + oSt, 8, hipMemcpyDeviceToHost, s));
-        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));                                       // also keeps hdesc alive long enough
-        PLSLAM_REQUIRE(res[1] == 0, PLSLAM_ERANGE);
-        matches = res[0];
         have_m12 = true;
     }
     if (nq > min_matches && matches < min_matches) {                     // :594-598 / :709-713
@@ -284,6 +370,24 @@ int plslam_map2kf_match_lines_fast(plslam_ctx* ctx, const plslam_cam* K, const d
 {
     return plslam::map2kf_driver(ctx, 1, K, Twf, Lw, med_desc, candidate, n_map, kf_desc, kf_le, kf_seg, kf_idx, n_kf,
                                  nnr, mutual, max_epip, min_matches, fm, map_to_kf, n_matches, used_match);
+}
+
+int plslam_kf2kf_match_points(plslam_ctx* ctx, const plslam_cam* K, const double* DT, const double* P_prev,
+                              const uint8_t* desc_prev, int32_t n_prev, const double* pl_curr, const uint8_t* desc_curr,
+                              int32_t n_curr, float nnr, int mutual, int32_t min_matches, const plslam_fast_matching* fm,
+                              int32_t* matches_12, int32_t* n_matches, int32_t* used_match)
+{
+    return plslam::kf2kf_driver(ctx, 0, K, DT, P_prev, desc_prev, n_prev, pl_curr, desc_curr, n_curr, nnr, mutual,
+                                min_matches, fm, matches_12, n_matches, used_match);
+}
+
+int plslam_kf2kf_match_lines(plslam_ctx* ctx, const plslam_cam* K, const double* DT, const double* sPeP_prev,
+                             const uint8_t* desc_prev, int32_t n_prev, const double* seg_curr, const uint8_t* desc_curr,
+                             int32_t n_curr, float nnr, int mutual, int32_t min_matches, const plslam_fast_matching* fm,
+                             int32_t* matches_12, int32_t* n_matches, int32_t* used_match)
+{
+    return plslam::kf2kf_driver(ctx, 1, K, DT, sPeP_prev, desc_prev, n_prev, seg_curr, desc_curr, n_curr, nnr, mutual,
+                                min_matches, fm, matches_12, n_matches, used_match);
 }
 
 }  // extern "C"

@@ -164,3 +164,70 @@ def test_gpu_fast_driver_bit_exact(ctx, oracle, kind, n_map, n_kf):
         assert got[1] == ref[1] == int((ref[0] >= 0).sum()) and got[2] == ref[2]
         seen_used.add(ref[2])
     assert seen_used == {0, 1} or n_map < 100
+
+
+def kf_pair(n_prev=1500, n_curr=1400, lines=False, seed=3):
+    """Two consecutive keyframes: stereo features of the previous one (3D, its camera frame), the relative pose DT and
+    the current one's 2D features = re-observations of a subset (+ noise) and clutter."""
+    r = np.random.Generator(np.random.PCG64(seed))
+    K = synth.EUROC
+    DT = synth.se3_exp([0.15, -0.05, 0.3, 0.01, -0.02, 0.015])
+    z = r.uniform(1.5, 25.0, n_prev)
+    u, v = r.uniform(-30, K["width"] + 30, n_prev), r.uniform(-30, K["height"] + 30, n_prev)
+    P = np.stack([(u - K["cx"]) / K["fx"] * z, (v - K["cy"]) / K["fy"] * z, z], 1)
+    P[r.random(n_prev) < 0.01, 2] = -1.0                       # a few behind the current camera after DT / degenerate
+    proj = lambda X: np.stack([K["cx"] + K["fx"] * X[:, 0] / X[:, 2], K["cy"] + K["fy"] * X[:, 1] / X[:, 2]], 1)
+    d_prev = synth.random_desc(r, n_prev)
+    src = r.integers(0, n_prev, n_curr)
+    d_curr = d_prev[src] ^ np.packbits(r.random((n_curr, 256)) < 0.05, axis=1)
+    clutter = r.random(n_curr) < 0.3
+    d_curr[clutter] = synth.random_desc(r, int(clutter.sum()))
+    with np.errstate(all="ignore"):
+        Pc = P @ DT[:3, :3].T + DT[:3, 3]
+        pl = np.nan_to_num(proj(Pc[src]), posinf=0, neginf=0) + r.normal(0, 1.5, (n_curr, 2))
+        if not lines:
+            return dict(DT=DT, X=P, d_prev=d_prev, feat=pl, d_curr=np.ascontiguousarray(d_curr))
+        E = P + r.uniform(-0.6, 0.6, (n_prev, 3))
+        Ec = E @ DT[:3, :3].T + DT[:3, 3]
+        seg = np.concatenate([pl, np.nan_to_num(proj(Ec[src]), posinf=0, neginf=0) + r.normal(0, 1.5, (n_curr, 2))], 1)
+    return dict(DT=DT, X=np.concatenate([P, E], 1), d_prev=d_prev, feat=seg, d_curr=np.ascontiguousarray(d_curr))
+
+
+def test_oracle_kf2kf_semantics(oracle):
+    cam = oracle.make_cam(**synth.EUROC)
+    s = kf_pair(600, 550)
+    a = (s["DT"], s["X"], s["d_prev"], s["feat"], s["d_curr"])
+    m, n, used = oracle.kf2kf_match("points", cam, *a, 0.75, True, 20, fast_cfg())
+    assert used == 0 and n == (m >= 0).sum() > 100
+    bf, nbf = oracle.match(s["d_prev"], s["d_curr"], 0.75, True)
+    m2, n2, used2 = oracle.kf2kf_match("points", cam, *a, 0.75, True, 20, fast_cfg(enabled=0))
+    assert used2 == 1 and n2 == nbf and (m2 == bf).all()          # fast_matching off: plain StVO::match
+    m3, n3, used3 = oracle.kf2kf_match("points", cam, *a, 0.75, True, n + 10, fast_cfg())
+    assert used3 == 1 and (m3 == bf).all()                        # too few grid matches: replaced by StVO::match
+    m4, n4, used4 = oracle.kf2kf_match("points", cam, *a, 0.75, True, 600, fast_cfg())
+    assert used4 == 0 and (m4 == m).all()                         # ... unless a keyframe has no more than min_matches features
+    # lines: pj_lines are pixels used as cells (:392-393): almost nothing falls into the 64 x 48 grid, the fall-back runs
+    sl = kf_pair(200, 180, lines=True)
+    ml, nl, usedl = oracle.kf2kf_match("lines", cam, sl["DT"], sl["X"], sl["d_prev"], sl["feat"], sl["d_curr"], 0.9, True, 10,
+                                       fast_cfg())
+    assert usedl == 1 and nl == oracle.match(sl["d_prev"], sl["d_curr"], 0.9, True)[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n_prev,n_curr", [("points", 1500, 1400), ("lines", 200, 180), ("points", 60, 50),
+                                                ("lines", 30, 40), ("points", 4000, 4000)])
+def test_gpu_kf2kf_driver_bit_exact(ctx, oracle, kind, n_prev, n_curr):
+    import plslam_amd
+    cam, ocam = plslam_amd.make_cam(**synth.EUROC), oracle.make_cam(**synth.EUROC)
+    s = kf_pair(n_prev, n_curr, lines=(kind == "lines"), seed=n_prev)
+    a = (s["DT"], s["X"], s["d_prev"], s["feat"], s["d_curr"])
+    seen = set()
+    for nnr, mutual, mm, fm in ((0.75, True, 20, fast_cfg()), (0.9, False, 5, fast_cfg(ws=1)), (0.9, True, 10 ** 6, fast_cfg()),
+                                (0.8, True, 10, fast_cfg(enabled=0)), (0.8, True, 0, fast_cfg(enabled=0)),
+                                (0.75, True, max(min(n_prev, n_curr) - 1, 0), fast_cfg(ws=6, nnr_grid=0.9))):
+        got = ctx.kf2kf_match(kind, cam, *a, nnr, mutual, mm, fm)
+        ref = oracle.kf2kf_match(kind, ocam, *a, nnr, mutual, mm, fm)
+        np.testing.assert_array_equal(got[0], ref[0])
+        assert got[1] == ref[1] == int((ref[0] >= 0).sum()) and got[2] == ref[2]
+        seen.add(ref[2])
+    assert seen == {0, 1}
