@@ -192,7 +192,9 @@ void plslam_match_plan_destroy(plslam_match_plan* plan);
  *   mutual     Config::bestLRMatches(): upstream's sequential `if (d < distances[i2]) {...} else continue;`
  *              (a candidate only counts for row i1 if it strictly beats every EARLIER row's distance to the
  *              same i2) followed by the matches_21[i2] == i1 check; reproduced exactly, order-free.
- *   matches_12 n1 entries (i2 or -1); *n_matches (may be NULL) the return value.
+ *   matches_12 n1 entries (i2 or -1); *n_matches (may be NULL) the return value.  (With nnr > 1 -- no shipped
+ *              configuration -- upstream also counts every row that had candidates none of which counted:
+ *              `INT_MAX < INT_MAX * nnr`; reproduced, so there n_matches can exceed the entries >= 0.)
  * One deliberate definition: among several candidates at the same best distance upstream keeps the one its
  * std::unordered_set<int> happens to visit first (implementation-defined); here the lowest i2 wins, the
  * brute-force matcher's rule.  Limits: n1 < 2^22, n2 <= PLSLAM_MAX_TRAIN_ROWS. */

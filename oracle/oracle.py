@@ -524,6 +524,7 @@ def np_match_grid(centres, d1, cell_start, cell_items, cols, rows, d2, window, n
     cs, items = _c(cell_start, np.int32), _c(cell_items, np.int32)
     w = [int(v) for v in window]
     pairs = set()
+    nonempty = np.zeros(n1, bool)          # rows whose candidate SET is not empty (before any per-candidate test)
     for i1 in range(n1):
         for x, y in centres[i1]:
             x, y = int(x), int(y)
@@ -531,10 +532,15 @@ def np_match_grid(centres, d1, cell_start, cell_items, cols, rows, d2, window, n
                 lo, hi = max(0, y - w[2]), min(rows, y + w[3] + 1)
                 if lo < hi:
                     for i2 in items[cs[x_ * rows + lo]:cs[x_ * rows + hi]]:
+                        nonempty[i1] = True
                         if 0 <= i2 < n2:
                             pairs.add((i1, int(i2)))
+    imax = np.iinfo(np.int32).max
+    # upstream quirk: a row with candidates of which none counts keeps best_d = best_d2 = INT_MAX, and
+    # `INT_MAX < INT_MAX * nnr` holds for nnr > 1: it "matches" best_idx = -1 and is counted
+    phantom = float(imax) < float(imax) * float(nnr)
     if not pairs:
-        return np.full(n1, -1, np.int32), 0
+        return np.full(n1, -1, np.int32), int(nonempty.sum()) if phantom else 0
     P = np.array(sorted(pairs), np.int64)
     if dir1 is not None and dir2 is not None:
         a, b = _c(dir1, np.float64).reshape(-1, 2), _c(dir2, np.float64).reshape(-1, 2)
@@ -551,11 +557,12 @@ def np_match_grid(centres, d1, cell_start, cell_items, cols, rows, d2, window, n
             live[sel] = first == i1s
             m21[i2] = i1s[np.lexsort((i1s, ds))[0]]
     m12 = np.full(n1, -1, np.int32)
-    imax = np.iinfo(np.int32).max
+    has_live = np.zeros(n1, bool)
     for i1 in np.unique(P[:, 0]):
         sel = np.nonzero((P[:, 0] == i1) & live)[0]
         if not len(sel):
             continue
+        has_live[i1] = True
         order = np.lexsort((P[sel, 1], D[sel]))
         best_d, best_idx = D[sel][order[0]], P[sel, 1][order[0]]
         best_d2 = D[sel][order[1]] if len(sel) > 1 else imax
@@ -564,7 +571,7 @@ def np_match_grid(centres, d1, cell_start, cell_items, cols, rows, d2, window, n
     if mutual:
         good = m12 >= 0
         m12 = np.where(good & (m21[np.clip(m12, 0, None)] == np.arange(n1)), m12, -1).astype(np.int32)
-    return m12, int((m12 >= 0).sum())
+    return m12, int((m12 >= 0).sum()) + (int((nonempty & ~has_live).sum()) if phantom else 0)
 
 # ------------------------------------------------------------------------------------------
 # independent numpy mirror (different formulation: full distance matrix + stable sort)

@@ -473,6 +473,9 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
                 if (!g.mutual || (P.state[i2] >> REC_D_BITS) == (uint32_t)i1) m = i2;
             }
         }
+        else if (2147483647.0 < 2147483647.0 * g.nnr && count_items(g, P, i1) > 0u)
+            cnt += 1;   // upstream, nnr > 1 only: a row whose candidates all fail keeps best_d = best_d2 = INT_MAX, passes
+                        // `best_d < best_d2 * nnr`, gets matches_12 = best_idx = -1 and is COUNTED
         g_matches[i1] = m;
         cnt += m >= 0;
     }

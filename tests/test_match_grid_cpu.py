@@ -146,3 +146,31 @@ def test_oracle_reproduces_the_committed_grid_goldens(oracle):
         assert n == int((want >= 0).sum())
         k += int((want >= 0).sum())
     assert k > 300
+
+
+def test_hypothesis_sequential_vs_order_free(oracle):
+    """Property-based: arbitrary small grids, windows, centres (also far outside the grid), items (also out of range
+    and repeated across cells), descriptors drawn from 3 patterns (ties everywhere): the literal sequential loop and
+    the order-free form agree."""
+    from hypothesis import given, settings, strategies as st
+
+    pats = np.array([[0] * 32, [0xFF] + [0] * 31, [0x0F] * 32], np.uint8)
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.integers(1, 4), st.integers(1, 4), st.integers(0, 12), st.integers(0, 10), st.integers(1, 2),
+           st.tuples(*[st.integers(0, 3)] * 4), st.booleans(), st.sampled_from([0.5, 0.75, 1.0, 1.5]), st.integers(0, 2 ** 31))
+    def run(cols, rows, n1, n2, nc, w, mutual, nnr, seed):
+        r = _rng(seed)
+        d1, d2 = pats[r.integers(0, 3, n1)], pats[r.integers(0, 3, n2)]
+        cen = np.stack([r.integers(-3, cols + 3, (n1, nc)), r.integers(-3, rows + 3, (n1, nc))], 2).astype(np.int32)
+        # a hand-made CSR grid: every cell gets a random multiset of item ids, some outside [0, n2)
+        lens = r.integers(0, 4, cols * rows)
+        cs = np.zeros(cols * rows + 1, np.int32)
+        np.cumsum(lens, out=cs[1:])
+        items = r.integers(-1, n2 + 2, int(cs[-1])).astype(np.int32)
+        kw = dict(centres=cen, d1=d1.reshape(-1, 32), cell_start=cs, cell_items=items, cols=cols, rows=rows,
+                  d2=d2.reshape(-1, 32), window=w, nnr=nnr, mutual=mutual)
+        a, b = oracle.match_grid(**kw), oracle.np_match_grid(**kw)
+        assert a[1] == b[1] and np.array_equal(a[0], b[0])
+
+    run()
