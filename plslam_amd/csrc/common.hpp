@@ -214,8 +214,11 @@ int64_t grid_store_capacity_host(const int32_t* centres, int32_t n1, int32_t n_c
 // one problem with DEVICE pointers on `s` (scratch: grid_scratch_words() words; status: one zeroed int32)
 int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* d_desc_slot,
                           GridDesc* h_desc_slot, hipStream_t s);
-// table order: the n[2] problems of mode 2, then the n[1] of mode 1, then the n[0] of mode 0
-int launch_match_grid(const GridDesc* d_probs, const int32_t n[3], const size_t lds_bytes[3], hipStream_t s);
+// launch groups: 3 = all in LDS / 256-lane workgroups (n1 <= 256), 2 = all in LDS, 1 = tables in LDS, 0 = global
+int grid_group(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items);
+size_t grid_group_lds_bytes(int group, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items);
+// table order: the n[3] problems of group 3, then n[2], n[1], n[0]
+int launch_match_grid(const GridDesc* d_probs, const int32_t n[4], const size_t lds_bytes[4], hipStream_t s);
 
 // --- LBD float -> binary line descriptor (lbd.hip) ---------------------------------------------
 // lbd: n x 72 f32, codes: n x 32 u8 (both 16-byte aligned)

@@ -79,12 +79,13 @@ __device__ __forceinline__ void best2_fold(uint32_t& k1, uint32_t& k2, uint32_t 
     k1 = lo;
 }
 
-// Slot k of lane `tid` in the transposed candidate store of a round: row k of a [depth][1024] array, rotated by one
+// Slot k of lane `tid` in the transposed candidate store of a round: row k of a [depth][NT] array, rotated by one
 // wave per row -- a wave's successive slots then fall into different 256-byte channels of L2 / HBM instead of all
 // into the same one (row pitch 4 KB = 16 channels x 256 B)
+template <int NT>
 __device__ __forceinline__ size_t slot_index(uint32_t k, int tid)
 {
-    return (size_t)k * GRID_THREADS + ((uint32_t)(tid + (k << 6)) & (uint32_t)(GRID_THREADS - 1));
+    return (size_t)k * NT + ((uint32_t)(tid + (k << 6)) & (uint32_t)(NT - 1));
 }
 
 struct RowWindows {     // GridStructure::get ranges of one window centre (clamped to the grid: they fit 32 bits)
@@ -159,12 +160,14 @@ __device__ __forceinline__ void for_candidates(const GridDesc& g, const GridPtrs
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __restrict__ probs, uint32_t lds_words)
+// NT lanes per workgroup: 1024, or 256 for problems of at most 256 rows (a 200-line problem would leave 12 of 16 waves
+// idle at every barrier -- and, in a batch, occupy a whole CU)
+template <int MODE, int NT>
+__global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ probs, uint32_t lds_words)
 {
     constexpr bool LDS = MODE >= 1;
     extern __shared__ u32x4 s_dyn4[];
-    __shared__ uint32_t s_part[GRID_THREADS];
+    __shared__ uint32_t s_part[NT];
     __shared__ uint32_t s_max2[2];
     PLSLAM_AS_LDS uint32_t* s_dyn = (PLSLAM_AS_LDS uint32_t*)reinterpret_cast<uint32_t*>(s_dyn4);
 
@@ -172,7 +175,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int32_t n1 = g.n1, n2 = g.n2;
     const int32_t ncell = g.cols * g.rows;
-    const int32_t n_rounds = (n1 + GRID_THREADS - 1) / GRID_THREADS;
+    const int32_t n_rounds = (n1 + NT - 1) / NT;
 #ifdef PLSLAM_GRID_TIMING   // experiment builds only: phase boundaries in 10 ns ticks, printed by one lane
     uint64_t ts[6];
     int nts = 0, npass = 0;
@@ -219,25 +222,25 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
 
     // ---- P0: tables ----
     if constexpr (LDS) {
-        for (int32_t j = tid; j <= ncell; j += GRID_THREADS) s_dyn[j] = (uint32_t)g_cell_start[j];
+        for (int32_t j = tid; j <= ncell; j += NT) s_dyn[j] = (uint32_t)g_cell_start[j];
     }
     if constexpr (MODE == 2) {
         PLSLAM_AS_LDS int32_t* li = (PLSLAM_AS_LDS int32_t*)(s_dyn + items_off);
-        for (int32_t j = tid; j < g.n_items; j += GRID_THREADS) li[j] = g_items[j];
+        for (int32_t j = tid; j < g.n_items; j += NT) li[j] = g_items[j];
         PLSLAM_AS_LDS u32x4* lt = (PLSLAM_AS_LDS u32x4*)(s_dyn + d2_off);
-        for (int32_t j = tid; j < 2 * n2; j += GRID_THREADS) lt[j] = g_d2[j];
+        for (int32_t j = tid; j < 2 * n2; j += NT) lt[j] = g_d2[j];
     }
-    for (int32_t j = tid; j < n2; j += GRID_THREADS) {
+    for (int32_t j = tid; j < n2; j += NT) {
         P.state[j] = KEY_NONE;
         P.next[j] = KEY_NONE;
     }
-    for (int32_t i = tid; i < n1; i += GRID_THREADS) {
+    for (int32_t i = tid; i < n1; i += NT) {
         P.row_k1[i] = KEY_NONE;
         P.row_k2[i] = KEY_NONE;
     }
     __syncthreads();
     if ((uint32_t)P.cs[ncell] > (uint32_t)g.n_items) {      // the grid holds more items than the caller declared
-        for (int32_t i = tid; i < n1; i += GRID_THREADS) g_matches[i] = -1;
+        for (int32_t i = tid; i < n1; i += NT) g_matches[i] = -1;
         if (tid == 0) {
             if (g.n_matches) *g.n_matches = -1;
             if (g.status) atomicAdd(g.status, 1);
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
     // ---- PA: distances ----
     uint32_t store_words = 0;        // slots claimed so far (uniform)
     for (int32_t r = 0; r < n_rounds; ++r) {
-        const int32_t i1 = r * GRID_THREADS + tid;
+        const int32_t i1 = r * NT + tid;
         uint32_t depth = 0;
         if (g.mutual) {              // slot depth of this round = the largest item count of one of its rows
             uint32_t c = i1 < n1 ? count_items(g, P, i1) : 0u;
@@ -265,9 +268,9 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
             __syncthreads();
             depth = s_max;
             if (tid == 0) round_k[r] = depth;
-            if ((uint64_t)store_words + (uint64_t)depth * GRID_THREADS > (uint64_t)(uint32_t)g.pair_cap) {
+            if ((uint64_t)store_words + (uint64_t)depth * NT > (uint64_t)(uint32_t)g.pair_cap) {
                 // the store does not fit: report, match nothing
-                for (int32_t i = tid; i < n1; i += GRID_THREADS) g_matches[i] = -1;
+                for (int32_t i = tid; i < n1; i += NT) g_matches[i] = -1;
                 if (tid == 0) {
                     if (g.n_matches) *g.n_matches = -1;
                     if (g.status) atomicAdd(g.status, 1);
@@ -297,7 +300,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
                         if (g.mutual) {
                             // the first record pass, fused: no column has a record yet, so every candidate proposes
                             atomicMin((uint32_t*)&P.next[i2[j]], ((uint32_t)i1 << REC_D_BITS) | d);
-                            slot[slot_index(kout, tid)] = key;
+                            slot[slot_index<NT>(kout, tid)] = key;
                             ++kout;
                         } else
                             best2_fold(k1, k2, key);
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
                 P.row_k2[i1] = k2;
             }
         }
-        store_words += depth * GRID_THREADS;
+        store_words += depth * NT;
     }
     __threadfence();
     __syncthreads();
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
             if (!LDS) __threadfence();
             __syncthreads();
             int any = 0;
-            for (int32_t i2 = tid; i2 < n2; i2 += GRID_THREADS) {
+            for (int32_t i2 = tid; i2 < n2; i2 += NT) {
                 const uint32_t nx = P.next[i2];
                 if (nx != KEY_NONE) {
                     P.state[i2] = nx;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
             PLSLAM_AS_LDS uint32_t* lstore = lcnt + n1;
             const uint32_t room = lds_words > items_off + 2u * (uint32_t)n1 + 1u ? lds_words - (items_off + 2u * (uint32_t)n1 + 1u) : 0u;
             // exclusive scan of the row counts (s_part as scratch)
-            const int32_t per = (n1 + GRID_THREADS - 1) / GRID_THREADS;
+            const int32_t per = (n1 + NT - 1) / NT;
             const int32_t b = tid * per < n1 ? tid * per : n1, e = b + per < n1 ? b + per : n1;
             uint32_t sum = 0;
             for (int32_t i = b; i < e; ++i) sum += rcnt[i];
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
             if (lane == 63) s_part[tid >> 6] = incl;
             __syncthreads();                                          // also: every PA read of items / desc2 is done
             uint32_t pre = 0, total = 0;
-            for (int w = 0; w < GRID_THREADS / 64; ++w) {
+            for (int w = 0; w < NT / 64; ++w) {
                 const uint32_t v = s_part[w];
                 pre += w < (tid >> 6) ? v : 0u;
                 total += v;
@@ -406,7 +409,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
                 __syncthreads();
                 uint32_t off = 0;
                 for (int32_t r = 0; r < n_rounds; ++r) {              // transposed global slots -> compact LDS rows
-                    const int32_t i1 = r * GRID_THREADS + tid;
+                    const int32_t i1 = r * NT + tid;
                     if (i1 < n1) {
                         const uint32_t cnt = lcnt[i1];
                         PLSLAM_AS_GLOBAL const uint32_t* slot = store + off;
@@ -414,17 +417,17 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
                         for (uint32_t k0 = 0; k0 < cnt; k0 += PB_BATCH) {
                             uint32_t key[PB_BATCH];
 #pragma unroll
-                            for (int j = 0; j < PB_BATCH; ++j) key[j] = k0 + j < cnt ? slot[slot_index(k0 + j, tid)] : 0u;
+                            for (int j = 0; j < PB_BATCH; ++j) key[j] = k0 + j < cnt ? slot[slot_index<NT>(k0 + j, tid)] : 0u;
 #pragma unroll
                             for (int j = 0; j < PB_BATCH; ++j)
                                 if (k0 + j < cnt) dstp[k0 + j] = key[j];
                         }
                     }
-                    off += round_k[r] * GRID_THREADS;
+                    off += round_k[r] * NT;
                 }
                 __syncthreads();
                 while (more) {
-                    for (int32_t i1 = tid; i1 < n1; i1 += GRID_THREADS) {
+                    for (int32_t i1 = tid; i1 < n1; i1 += NT) {
                         const uint32_t cnt = lcnt[i1];
                         if (cnt) {
                             PLSLAM_AS_LDS uint32_t* rowp = lstore + row_off[i1];
@@ -446,13 +449,13 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
                 flip ^= 1;
                 uint32_t off = 0;
                 for (int32_t r = 0; r < n_rounds; ++r) {
-                    const int32_t i1 = r * GRID_THREADS + tid;
+                    const int32_t i1 = r * NT + tid;
                     if (i1 < n1) {
                         const uint32_t cnt = rcnt[i1];
                         if (cnt)
-                            rcnt[i1] = pass_row(i1, src + off, dst + off, [tid](uint32_t k) { return slot_index(k, tid); }, cnt);
+                            rcnt[i1] = pass_row(i1, src + off, dst + off, [tid](uint32_t k) { return slot_index<NT>(k, tid); }, cnt);
                     }
-                    off += round_k[r] * GRID_THREADS;
+                    off += round_k[r] * NT;
                 }
                 more = sweep();
             }
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
 
     // ---- PC: ratio test, mutual check, count ----
     uint32_t cnt = 0;
-    for (int32_t i1 = tid; i1 < n1; i1 += GRID_THREADS) {
+    for (int32_t i1 = tid; i1 < n1; i1 += NT) {
         const uint32_t k1 = P.row_k1[i1], k2 = P.row_k2[i1];
         int32_t m = -1;
         if (k1 != KEY_NONE) {
@@ -481,7 +484,7 @@ __global__ __launch_bounds__(GRID_THREADS) void k_match_grid(const GridDesc* __r
     }
     s_part[tid] = cnt;
     __syncthreads();
-    for (int st = GRID_THREADS / 2; st > 0; st >>= 1) {
+    for (int st = NT / 2; st > 0; st >>= 1) {
         if (tid < st) s_part[tid] += s_part[tid + st];
         __syncthreads();
     }
@@ -531,28 +534,9 @@ int grid_mode(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items)
     return grid_fits_lds(n1, n2, ncell) ? 1 : 0;
 }
 
-template <int MODE>
-static int launch_mode(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hipStream_t s)
-{
-    if (n <= 0) return PLSLAM_OK;
-    if (MODE > 0) {
-        static std::once_flag once;
-        static hipError_t attr = hipSuccess;
-        std::call_once(once, [] {
-            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_grid<MODE>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRID_LDS_MAX_BYTES);
-        });
-        PLSLAM_HIP_CHECK(attr);
-    }
-    if (MODE == 2) lds_bytes = GRID_LDS_MAX_BYTES;   // one workgroup per CU either way: the spare LDS holds the candidates
-    hipLaunchKernelGGL(k_match_grid<MODE>, dim3((unsigned)n), dim3(GRID_THREADS), lds_bytes, s, d_probs,
-                       (uint32_t)(lds_bytes / 4));
-    PLSLAM_HIP_CHECK(hipGetLastError());
-    return PLSLAM_OK;
-}
-
 // capacity of the candidate store (host-side data): rows go in blocks of 1024, a block needs 1024 slots per grid item
-// inside the windows of its fullest row (mutual only; without it nothing is stored)
+// inside the windows of its fullest row (mutual only; without it nothing is stored).  (The 256-lane workgroups of small
+// problems use blocks of 256: never more than this.)
 int64_t grid_store_capacity_host(const int32_t* centres, int32_t n1, int32_t n_centres, const int32_t* cell_start,
                                  int32_t cols, int32_t rows, const int32_t window[4], int mutual)
 {
@@ -579,14 +563,57 @@ int64_t grid_store_capacity_host(const int32_t* centres, int32_t n1, int32_t n_c
     return total;
 }
 
-// d_probs: the n[2] problems of mode 2 first, then the n[1] of mode 1, then the n[0] of mode 0; lds_bytes[m] = the
-// largest grid_lds_bytes() of a problem of mode m
-int launch_match_grid(const GridDesc* d_probs, const int32_t n[3], const size_t lds_bytes[3], hipStream_t s)
+constexpr int GRID_SMALL_ROWS = 256;    // problems of at most this many rows run on 256-lane workgroups (MODE 2 only)
+
+// launch groups: 0 = tables in global scratch, 1 = tables in LDS, 2 = everything in LDS / 1024 lanes, 3 = everything in
+// LDS / 256 lanes (n1 <= GRID_SMALL_ROWS)
+int grid_group(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items)
+{
+    const int mode = grid_mode(n1, n2, ncell, n_items);
+    return mode == 2 && n1 <= GRID_SMALL_ROWS ? 3 : mode;
+}
+// dynamic LDS a problem of the group asks for: group 2 takes everything (one workgroup per CU either way: the spare LDS
+// holds the candidates); group 3 adds room for the candidate runs (64 per row) so that several problems share a CU
+size_t grid_group_lds_bytes(int group, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items)
+{
+    if (group == 0) return 0;
+    if (group == 2) return GRID_LDS_MAX_BYTES;
+    size_t b = grid_lds_bytes(group == 3 ? 2 : 1, n1, n2, ncell, n_items);
+    if (group == 3) {
+        b += 4 * (2 * (size_t)n1 + 1 + 64 * (size_t)n1);
+        b = (b + 4095) & ~size_t(4095);
+        if (b > GRID_LDS_MAX_BYTES) b = GRID_LDS_MAX_BYTES;
+    }
+    return b;
+}
+
+template <int MODE, int NT>
+static int launch_group(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hipStream_t s)
+{
+    if (n <= 0) return PLSLAM_OK;
+    if (MODE > 0) {
+        static std::once_flag once;
+        static hipError_t attr = hipSuccess;
+        std::call_once(once, [] {
+            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_grid<MODE, NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRID_LDS_MAX_BYTES);
+        });
+        PLSLAM_HIP_CHECK(attr);
+    }
+    hipLaunchKernelGGL((k_match_grid<MODE, NT>), dim3((unsigned)n), dim3(NT), lds_bytes, s, d_probs,
+                       (uint32_t)(lds_bytes / 4));
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+// d_probs: the problems of group 3 first, then group 2, 1, 0; lds_bytes[g] = the largest grid_group_lds_bytes() in group g
+int launch_match_grid(const GridDesc* d_probs, const int32_t n[4], const size_t lds_bytes[4], hipStream_t s)
 {
     int rc;
-    if ((rc = launch_mode<2>(d_probs, n[2], lds_bytes[2], s))) return rc;
-    if ((rc = launch_mode<1>(d_probs + n[2], n[1], lds_bytes[1], s))) return rc;
-    return launch_mode<0>(d_probs + n[2] + n[1], n[0], 0, s);
+    if ((rc = launch_group<2, 256>(d_probs, n[3], lds_bytes[3], s))) return rc;
+    if ((rc = launch_group<2, 1024>(d_probs + n[3], n[2], lds_bytes[2], s))) return rc;
+    if ((rc = launch_group<1, 1024>(d_probs + n[3] + n[2], n[1], lds_bytes[1], s))) return rc;
+    return launch_group<0, 1024>(d_probs + n[3] + n[2] + n[1], n[0], 0, s);
 }
 
 }  // namespace plslam
@@ -599,8 +626,8 @@ using namespace plslam;
 struct plslam_grid_plan {
     plslam_ctx* ctx = nullptr;
     int32_t nprob = 0;
-    int32_t n_mode[3] = {0, 0, 0};     // the table holds the problems of mode 2 first, then mode 1, then mode 0
-    size_t lds_bytes[3] = {0, 0, 0};   // largest LDS footprint of a problem of each mode
+    int32_t n_mode[4] = {0, 0, 0, 0};  // the table holds the problems of launch group 3 first, then 2, 1, 0
+    size_t lds_bytes[4] = {0, 0, 0, 0};   // largest LDS request of a problem of each group
     DevBuf table, scratch, status;
 };
 
@@ -651,11 +678,11 @@ int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32
     grid_fill_desc(q, scratch, status, h_desc_slot);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d_desc_slot, h_desc_slot, sizeof(GridDesc), hipMemcpyHostToDevice, s));
     const int64_t ncell = (int64_t)q.grid_cols * q.grid_rows;
-    const int mode = grid_mode(q.n1, q.n2, ncell, q.n_items);
-    int32_t n_mode[3] = {0, 0, 0};
-    size_t lds_bytes[3] = {0, 0, 0};
-    n_mode[mode] = 1;
-    lds_bytes[mode] = grid_lds_bytes(mode, q.n1, q.n2, ncell, q.n_items);
+    const int group = grid_group(q.n1, q.n2, ncell, q.n_items);
+    int32_t n_mode[4] = {0, 0, 0, 0};
+    size_t lds_bytes[4] = {0, 0, 0, 0};
+    n_mode[group] = 1;
+    lds_bytes[group] = grid_group_lds_bytes(group, q.n1, q.n2, ncell, q.n_items);
     return launch_match_grid(d_desc_slot, n_mode, lds_bytes, s);
 }
 }  // namespace plslam
@@ -685,11 +712,11 @@ int plslam_grid_plan_create(plslam_ctx* ctx, const plslam_grid_problem* probs, i
     std::vector<GridDesc> tab((size_t)nprob);
     size_t off = 0;
     int32_t slot = 0;
-    for (int mode = 2; mode >= 0; --mode)
+    for (int mode = 3; mode >= 0; --mode)
         for (int32_t b = 0; b < nprob; ++b) {
             const int64_t ncell = (int64_t)probs[b].grid_cols * probs[b].grid_rows;
-            if (grid_mode(probs[b].n1, probs[b].n2, ncell, probs[b].n_items) != mode) continue;
-            const size_t lb = grid_lds_bytes(mode, probs[b].n1, probs[b].n2, ncell, probs[b].n_items);
+            if (grid_group(probs[b].n1, probs[b].n2, ncell, probs[b].n_items) != mode) continue;
+            const size_t lb = grid_group_lds_bytes(mode, probs[b].n1, probs[b].n2, ncell, probs[b].n_items);
             if (lb > P->lds_bytes[mode]) P->lds_bytes[mode] = lb;
             ++P->n_mode[mode];
             grid_fill_desc(probs[b], P->scratch.as<uint32_t>() + off, P->status.as<int32_t>(), &tab[slot++]);
@@ -808,11 +835,11 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     hipStream_t s = ctx->stream;
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, ci.off, hipMemcpyHostToDevice, s));
     PLSLAM_HIP_CHECK(hipMemsetAsync(dout + oN, 0, 8, s));
-    const int mode = grid_mode(n1, n2, ncell, n_items);
-    int32_t n_mode[3] = {0, 0, 0};
-    size_t lds_bytes[3] = {0, 0, 0};
-    n_mode[mode] = 1;
-    lds_bytes[mode] = grid_lds_bytes(mode, n1, n2, ncell, n_items);
+    const int group = grid_group(n1, n2, ncell, n_items);
+    int32_t n_mode[4] = {0, 0, 0, 0};
+    size_t lds_bytes[4] = {0, 0, 0, 0};
+    n_mode[group] = 1;
+    lds_bytes[group] = grid_group_lds_bytes(group, n1, n2, ncell, n_items);
     if ((rc = launch_match_grid((const GridDesc*)(d + oT), n_mode, lds_bytes, s))) return rc;
     PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, dout, co.off, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));

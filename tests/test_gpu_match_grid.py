@@ -168,7 +168,7 @@ def test_plan_batch_device_resident_and_overflow(ctx, oracle):
                  centres1=up(cen, np.int32).data_ptr(), cell_start=up(c["cell_start"], np.int32).data_ptr(),
                  cell_items=up(c["cell_items"] if len(c["cell_items"]) else np.zeros(1), np.int32).data_ptr(),
                  n1=n1, n2=n2, n_centres=cen.shape[1], grid_cols=16, grid_rows=12, n_items=len(c["cell_items"]), window=w, nnr=0.8, mutual=mutual,
-                 pair_capacity=cap if b != 11 else max(cap - 1, 0), matches_12=out.data_ptr(), n_matches=cnt.data_ptr())
+                 pair_capacity=cap if b != 11 else 0, matches_12=out.data_ptr(), n_matches=cnt.data_ptr())
         if lines:
             q.update(dir1=up(c["dir1"], np.float64).data_ptr(), dir2=up(c["dir2"], np.float64).data_ptr(), sim_th=c["sim_th"])
         probs.append((q, out, cnt))
