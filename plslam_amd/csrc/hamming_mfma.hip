@@ -134,8 +134,12 @@ __device__ __forceinline__ int xcd_remap_(int orig, int nwg) { return (orig & 7)
 // which is why the common case has its own instantiation; capi.hip picks per plan).
 // DIRECTED = true: only keys12 (row direction) is produced -- non-mutual problems and plain knnMatch(k=2):
 // no column keys, no column partials, 5 VALU ops per 2 distances.
+// experiment: -DPLSLAM_MF_SINGLE_SET=1 -> one accumulator set, no M(t)/E(t-1) overlap inside a wave, 4 waves per SIMD
+#ifndef PLSLAM_MF_SINGLE_SET
+#define PLSLAM_MF_SINGLE_SET 0
+#endif
 template <bool MULTI, bool DIRECTED>
-__global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
+__global__ void __launch_bounds__(256, PLSLAM_MF_SINGLE_SET ? 4 : 3)      // 3 waves per SIMD: <= 168 unified VGPRs
 k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
                 int32_t* __restrict__ zero, int nzero)
 {
@@ -348,8 +352,16 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     // alternate (unrolled by two: no accumulator is ever copied).  Only the last tile of the scan can lack
     // columns.
     auto pipeline = [&](auto steady_tag) __attribute__((always_inline)) {
-        f32x16 A0, A1, B0, B1;
         const bool last_partial = WT1 == ntiles && (n2 % MF_TILE_N) != 0;
+#if PLSLAM_MF_SINGLE_SET
+        f32x16 A0, A1;
+        for (int t = WT0; t < WT1; ++t) {
+            step(t, A0, A1, A0, A1, false, steady_tag);
+            if (t == WT1 - 1 && last_partial) epilogue(t, A0, A1, std::true_type{}); else epilogue(t, A0, A1, steady_tag);
+        }
+        return;
+#else
+        f32x16 A0, A1, B0, B1;
         step(WT0, A0, A1, A0, A1, false, steady_tag);
         int t = WT0 + 1;
         for (; t + 1 < WT1; t += 2) {
@@ -362,6 +374,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         } else {                                   // tile WT1 - 1 is in set A
             if (last_partial) epilogue(t - 1, A0, A1, std::true_type{}); else epilogue(t - 1, A0, A1, steady_tag);
         }
+#endif
     };
     // Row results of a window.  Every lane holds, per accumulator register, the best two 16-bit keys
     // (d, tile + LOC) of ITS column class for two rows.  Transpose through LDS so that one lane owns one row:
