@@ -334,6 +334,21 @@ int plslam_lba_plan_rows(plslam_lba_plan* plan, double* pt_J_pose, double* pt_J_
                          double* ls_J_pose, double* ls_J_lm, double* ls_r, double* ls_w);
 void plslam_lba_plan_destroy(plslam_lba_plan* plan);
 
+/* ---- K17: pose-only Gauss-Newton system of the loop-closure relative pose ------------------------------- */
+/* The iteration body of MapHandler::computeRelativePoseGN (src/mapHandler.cpp:3324-3424) and of
+ * computeRelativePoseRobustGN (:3588-3689; identical loops): per inlier point / line the reprojection error, the 6-vector
+ * Jacobian wrt the pose increment (note: fx / max(homogTh, z^2) scales BOTH image coordinates, and the line rows use
+ * l_obs(0..1) as multipliers -- unlike the local-BA rows) and the Cauchy weight, accumulated into
+ *   H = H_p + H_l (6 x 6 row-major), g = g_p + g_l, *e = e_p + e_l (BEFORE the division by N_l + N_p of :3421),
+ *   n_obs[0] = N_p, n_obs[1] = N_l (may be NULL).
+ * T_inc: 16 doubles row-major; P npt x 3 (lc_points[i]->P), pl_obs npt x 2, pt_inlier npt bytes; sPeP nls x 6
+ * (lc_lines[i]->sP, ->eP), le_obs nls x 3, ls_inlier nls bytes.  The solve (ColPivHouseholderQR of a 6 x 6, :3426-3428)
+ * and the update T_inc = T_inc * inverse_se3(expmap_se3(x_inc)) stay with the caller. */
+int plslam_pose_gn_accumulate(plslam_ctx* ctx, const plslam_cam* K, double homog_th, const double* T_inc,
+                              const double* P, const double* pl_obs, const uint8_t* pt_inlier, int32_t npt,
+                              const double* sPeP, const double* le_obs, const uint8_t* ls_inlier, int32_t nls,
+                              double* H, double* g, double* e, int32_t* n_obs);
+
 /* ---- K5/K6: map <-> keyframe geometric gates (the inlier masks) -------------------------- */
 /* Points: src/mapHandler.cpp:601-613.  mask[i] = 1 iff matches_12[i] >= 0 and
  * || proj(Twf * Xw[i]) - pl[matches_12[i]] ||_2 < max_epip.  Twf: 16 doubles row-major.

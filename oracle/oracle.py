@@ -113,6 +113,9 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.plo_kf2kf_match_points.restype = C.c_int32
     lib.plo_kf2kf_match_lines.argtypes = lib.plo_kf2kf_match_points.argtypes
     lib.plo_kf2kf_match_lines.restype = C.c_int32
+    lib.plo_pose_gn_accumulate.argtypes = [C.POINTER(Cam), C.c_double] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 + \
+        [C.c_int32] + [C.c_void_p] * 4
+    lib.plo_pose_gn_accumulate.restype = None
     lib.plo_match_grid.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
                                    C.c_void_p, C.c_double, C.c_int, C.c_void_p]
@@ -409,6 +412,18 @@ def kf2kf_match(kind, cam, DT, X_prev, desc_prev, feat_curr, desc_curr, nnr, mut
     n = f(C.byref(cam), _p(DT), _p(X), _p(dp), X.shape[0], _p(fc), _p(dc), fc.shape[0], float(nnr), int(bool(mutual)),
           int(min_matches), C.byref(F), _p(out), C.byref(used))
     return out, int(n), int(used.value)
+
+
+def pose_gn_accumulate(cam, homog_th, T_inc, P, pl_obs, pt_inlier, sPeP, le_obs, ls_inlier):
+    """computeRelativePoseGN iteration body (src/mapHandler.cpp:3324-3424) -> (H[6,6], g[6], e, (N_p, N_l))."""
+    T = _c(T_inc, np.float64).reshape(16)
+    P, po = _c(P, np.float64).reshape(-1, 3), _c(pl_obs, np.float64).reshape(-1, 2)
+    S, lo = _c(sPeP, np.float64).reshape(-1, 6), _c(le_obs, np.float64).reshape(-1, 3)
+    pi, li = _c(pt_inlier, np.uint8), _c(ls_inlier, np.uint8)
+    H, g, e, n = np.empty((6, 6)), np.empty(6), np.empty(1), np.empty(2, np.int32)
+    lib().plo_pose_gn_accumulate(C.byref(cam), float(homog_th), _p(T), _p(P), _p(po), _p(pi), P.shape[0], _p(S), _p(lo),
+                                 _p(li), S.shape[0], _p(H), _p(g), _p(e), _p(n))
+    return H, g, float(e[0]), (int(n[0]), int(n[1]))
 
 
 def stereo_point_gate(m12, kp_l, kp_r, max_dist_epip, min_disp):

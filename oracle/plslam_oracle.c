@@ -588,6 +588,73 @@ void plo_map_line_visible(const plo_cam* K, const double Twf[16], const double* 
 /* ------------------------------------------------------------------------------------ */
 /* map <-> keyframe drivers: src/mapHandler.cpp:532-632 (points), :634-752 (lines)        */
 /* ------------------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------------------ */
+/* pose-only GN of the loop closure: src/mapHandler.cpp:3324-3424                          */
+/* ------------------------------------------------------------------------------------ */
+static void gn_jac6(double fgz2, double a, double b, double gx, double gy, double gz, double J[6])
+{
+    J[0] = +fgz2 * a * gz;
+    J[1] = +fgz2 * b * gz;
+    J[2] = -fgz2 * (gx * a + gy * b);
+    J[3] = -fgz2 * (gx * gy * a + gy * gy * b + gz * gz * b);
+    J[4] = +fgz2 * (gx * gx * a + gz * gz * a + gx * gy * b);
+    J[5] = +fgz2 * (gx * gz * b - gy * gz * a);
+}
+
+void plo_pose_gn_accumulate(const plo_cam* K, double homog_th, const double T_inc[16], const double* P,
+                            const double* pl_obs, const uint8_t* pt_inlier, int32_t npt, const double* sPeP,
+                            const double* le_obs, const uint8_t* ls_inlier, int32_t nls, double* H, double* g, double* e,
+                            int32_t* n_obs)
+{
+    double Hp[36] = {0}, Hl[36] = {0}, gp[6] = {0}, gl[6] = {0}, ep = 0.0, el = 0.0;
+    int32_t Np = 0, Nl = 0;
+    for (int32_t i = 0; i < npt; ++i) {
+        if (!pt_inlier[i]) continue;
+        double G[3], p[2], J[6];
+        xform44(T_inc, P + 3 * (size_t)i, G);
+        project(K, G, p);
+        const double dx = p[0] - pl_obs[2 * (size_t)i], dy = p[1] - pl_obs[2 * (size_t)i + 1];
+        const double r = sqrt(dx * dx + dy * dy);
+        const double fgz2 = K->fx / dmax(homog_th, G[2] * G[2]);
+        gn_jac6(fgz2, dx, dy, G[0], G[1], G[2], J);
+        const double den = dmax(homog_th, r);
+        for (int k = 0; k < 6; ++k) J[k] = J[k] / den;
+        const double w = 1.0 / (1.0 + r * r);                         /* robustWeightCauchy */
+        for (int a = 0; a < 6; ++a) {
+            for (int b = 0; b < 6; ++b) Hp[6 * a + b] += J[a] * J[b] * w;
+            gp[a] += J[a] * r * w;
+        }
+        ep += r * r * w;
+        ++Np;
+    }
+    for (int32_t i = 0; i < nls; ++i) {
+        if (!ls_inlier[i]) continue;
+        double S[3], E[3], ps[2], pe[2], Js[6], Je[6], J[6];
+        xform44(T_inc, sPeP + 6 * (size_t)i, S);
+        project(K, S, ps);
+        xform44(T_inc, sPeP + 6 * (size_t)i + 3, E);
+        project(K, E, pe);
+        const double lx = le_obs[3 * (size_t)i], ly = le_obs[3 * (size_t)i + 1], lz = le_obs[3 * (size_t)i + 2];
+        const double ds = lx * ps[0] + ly * ps[1] + lz, de = lx * pe[0] + ly * pe[1] + lz;
+        const double r = sqrt(ds * ds + de * de);
+        gn_jac6(K->fx / dmax(homog_th, S[2] * S[2]), lx, ly, S[0], S[1], S[2], Js);
+        gn_jac6(K->fx / dmax(homog_th, E[2] * E[2]), lx, ly, E[0], E[1], E[2], Je);
+        const double den = dmax(homog_th, r);
+        for (int k = 0; k < 6; ++k) J[k] = (Js[k] * ds + Je[k] * de) / den;
+        const double w = 1.0 / (1.0 + r * r);
+        for (int a = 0; a < 6; ++a) {
+            for (int b = 0; b < 6; ++b) Hl[6 * a + b] += J[a] * J[b] * w;
+            gl[a] += J[a] * r * w;
+        }
+        el += r * r * w;
+        ++Nl;
+    }
+    for (int k = 0; k < 36; ++k) H[k] = Hp[k] + Hl[k];
+    for (int k = 0; k < 6; ++k) g[k] = gp[k] + gl[k];
+    *e = ep + el;
+    if (n_obs) { n_obs[0] = Np; n_obs[1] = Nl; }
+}
+
 /* double -> int as the reference's x86 build does it (cvttsd2si): truncation toward zero; NaN and values outside
  * int32 give INT_MIN ("integer indefinite") */
 static inline int32_t cvtt_x86(double v)

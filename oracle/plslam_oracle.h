@@ -111,6 +111,15 @@ void plo_lba_accumulate_lines(int32_t nkf_opt, int32_t npt, int32_t nls, const i
                               const double* J_lm, const double* r, const double* w,
                               double* H, double* g, double* err);
 
+/* ---- pose-only GN system of the loop-closure relative pose ---------------------------------------------
+ * MapHandler::computeRelativePoseGN iteration body, src/mapHandler.cpp:3324-3424 (== computeRelativePoseRobustGN
+ * :3588-3689): literal restatement; H (36, row-major) = H_p + H_l, g = g_p + g_l, *e = e_p + e_l (not yet divided by
+ * N_l + N_p); n_obs[0] = N_p, n_obs[1] = N_l. */
+void plo_pose_gn_accumulate(const plo_cam* K, double homog_th, const double T_inc[16], const double* P,
+                            const double* pl_obs, const uint8_t* pt_inlier, int32_t npt, const double* sPeP,
+                            const double* le_obs, const uint8_t* ls_inlier, int32_t nls, double* H, double* g, double* e,
+                            int32_t* n_obs);
+
 /* ---- map<->KF geometric gates (inlier masks) ---------------------------------------- */
 /* src/mapHandler.cpp:605-613: mask[i]=1 iff m12[i]>=0 and ||proj(Twf*X_i) - pl[m12[i]]|| < th.
  * returns #inliers. Twf row-major 4x4; Xw nq*3; pl nt*2. */

@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "plslam_kf2kf_match_points", "plslam_kf2kf_match_lines",
     "plslam_lbd_binarise", "plslam_lbd_binarise_dev",
     "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
-    "plslam_stereo_point_gate", "plslam_stereo_line_gate",
+    "plslam_stereo_point_gate", "plslam_stereo_line_gate", "plslam_pose_gn_accumulate",
     "plslam_match_grid", "plslam_grid_plan_create", "plslam_grid_plan_run", "plslam_grid_plan_overflows",
     "plslam_grid_plan_destroy",
     "plslam_gather_match_tables",
@@ -181,6 +181,7 @@ def load() -> C.CDLL:
     for f in (L.plslam_kf2kf_match_points, L.plslam_kf2kf_match_lines):
         f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, i32, vp, vp, i32, C.c_float, C.c_int, i32, C.POINTER(FastMatching), vp,
                       C.POINTER(i32), C.POINTER(i32)]
+    L.plslam_pose_gn_accumulate.argtypes = [vp, C.POINTER(Cam), f64, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
     L.plslam_stereo_point_gate.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, vp, vp, C.POINTER(i32)]
     L.plslam_stereo_line_gate.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, f64, f64, vp, vp, C.POINTER(i32)]
     L.plslam_match_grid.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, vp, vp, f64, vp, f64, C.c_int, vp,
@@ -308,6 +309,18 @@ class Context:
                                          _p(b) if b is not None else None, float(sim_th), _p(w), float(nnr),
                                          int(bool(mutual)), _p(m12), C.byref(n)), "plslam_match_grid")
         return m12, n.value
+
+    def pose_gn_accumulate(self, cam, homog_th, T_inc, P, pl_obs, pt_inlier, sPeP, le_obs, ls_inlier):
+        """computeRelativePoseGN iteration body -> (H[6,6], g[6], e, (N_p, N_l))."""
+        T = _arr(T_inc, np.float64, (16,))
+        P, po = _arr(P, np.float64, (-1, 3)), _arr(pl_obs, np.float64, (-1, 2))
+        S, lo = _arr(sPeP, np.float64, (-1, 6)), _arr(le_obs, np.float64, (-1, 3))
+        pi, li = _arr(pt_inlier, np.uint8), _arr(ls_inlier, np.uint8)
+        H, g, e, n = np.empty((6, 6)), np.empty(6), np.empty(1), np.empty(2, np.int32)
+        _check(self._L.plslam_pose_gn_accumulate(self._h, C.byref(cam), float(homog_th), _p(T), _p(P), _p(po), _p(pi),
+                                                 P.shape[0], _p(S), _p(lo), _p(li), S.shape[0], _p(H), _p(g), _p(e), _p(n)),
+               "plslam_pose_gn_accumulate")
+        return H, g, float(e[0]), (int(n[0]), int(n[1]))
 
     def stereo_point_gate(self, m12, kp_l, kp_r, max_dist_epip, min_disp):
         """StereoFrame::matchStereoPoints gates -> (stereo_12, disp, n_stereo)."""
