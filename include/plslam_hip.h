@@ -468,6 +468,27 @@ int plslam_median_desc_batched_dev(plslam_ctx* ctx, const uint8_t* desc_lists, c
                                    int32_t n_lm, int32_t total, int32_t* med_idx, uint8_t* med_desc,
                                    void* stream);
 
+/* ---- K18: the LBD float descriptor of a line (producer of the 72 floats K11 binarises) -------------------- */
+/* Replaces BinaryDescriptor::computeLBD, 3rdparty/line_descriptor/src/binary_descriptor_custom.cpp:1026-1372, for the
+ * lines of ONE octave: gradient images dx / dy (int16, width x height, row stride = width: dxImg_vector[octave] /
+ * dyImg_vector[octave], :1095-1101) and, per line, the OctaveSingleLine fields the function reads (numOfPixels,
+ * sPointInOctaveX/Y, ePointInOctaveX/Y, direction).  width_of_band = params.widthOfBand_ (7; 1..7 supported),
+ * NUM_OF_BANDS = 9.  lbd_f32: n x 72 float32 = the lines' `descriptor` vectors -- the input of
+ * plslam_lbd_binarise.  fp32 with the source's sequential summation order and no FMA; the weight tables and
+ * cos / sin(direction) are evaluated on the host with libm as upstream does.
+ * _dev form: dx_img / dy_img / lbd_f32 are DEVICE pointers (the line records stay host data: they are the line
+ * detector's small output); enqueues on `stream` (NULL = the context's stream). */
+typedef struct plslam_lbd_line {
+    int32_t num_pixels;
+    float sx, sy, ex, ey;
+    float direction;
+} plslam_lbd_line;
+int plslam_lbd_compute(plslam_ctx* ctx, const int16_t* dx_img, const int16_t* dy_img, int32_t width, int32_t height,
+                       const plslam_lbd_line* lines, int32_t n, int32_t width_of_band, float* lbd_f32);
+int plslam_lbd_compute_dev(plslam_ctx* ctx, const int16_t* dx_img, const int16_t* dy_img, int32_t width,
+                           int32_t height, const plslam_lbd_line* lines_host, int32_t n, int32_t width_of_band,
+                           float* lbd_f32, void* stream);
+
 /* ---- LBD float -> 256-bit binary line descriptor (producer of the matcher's LBD rows) ----- */
 /* Replaces the "fill current row with binary descriptor" loop of BinaryDescriptor::computeImpl,
  * 3rdparty/line_descriptor/src/binary_descriptor_custom.cpp:653-668, with

@@ -29,6 +29,12 @@ class FastMatching(C.Structure):
                 ("line_sim_th", C.c_double)]
 
 
+class LbdLine(C.Structure):
+    """plo_lbd_line"""
+    _fields_ = [("num_pixels", C.c_int32), ("sx", C.c_float), ("sy", C.c_float), ("ex", C.c_float), ("ey", C.c_float),
+                ("direction", C.c_float)]
+
+
 class Cam(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("b", C.c_double), ("width", C.c_int32), ("height", C.c_int32)]
@@ -116,6 +122,10 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.plo_pose_gn_accumulate.argtypes = [C.POINTER(Cam), C.c_double] + [C.c_void_p] * 4 + [C.c_int32] + [C.c_void_p] * 3 + \
         [C.c_int32] + [C.c_void_p] * 4
     lib.plo_pose_gn_accumulate.restype = None
+    lib.plo_lbd_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+    lib.plo_lbd_compute.restype = None
+    lib.plo_lbd_gauss_tables.argtypes = [C.c_int32, C.c_void_p, C.c_void_p]
+    lib.plo_lbd_gauss_tables.restype = None
     lib.plo_match_grid.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                    C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
                                    C.c_void_p, C.c_double, C.c_int, C.c_void_p]
@@ -444,6 +454,26 @@ def stereo_line_gate(m12, seg_l, seg_r, min_disp, line_horiz_th, stereo_overlap_
     n = lib().plo_stereo_line_gate(_p(m12), m12.shape[0], _p(a), _p(b), b.shape[0], float(min_disp), float(line_horiz_th),
                                    float(stereo_overlap_th), float(ls_min_disp_ratio), _p(out), _p(disp))
     return out, disp, int(n)
+
+
+LBD_LINE_DTYPE = np.dtype([("num_pixels", np.int32), ("sx", np.float32), ("sy", np.float32), ("ex", np.float32),
+                           ("ey", np.float32), ("direction", np.float32)])
+
+
+def lbd_compute(dx_img, dy_img, lines, width_of_band=7):
+    """BinaryDescriptor::computeLBD (binary_descriptor_custom.cpp:1026-1372) for the lines of one octave.
+    dx_img / dy_img: (height, width) int16; lines: structured array LBD_LINE_DTYPE -> (n, 72) float32."""
+    dx, dy = _c(dx_img, np.int16), _c(dy_img, np.int16)
+    ln = np.ascontiguousarray(lines, dtype=LBD_LINE_DTYPE)
+    out = np.empty((ln.shape[0], 72), np.float32)
+    lib().plo_lbd_compute(_p(dx), _p(dy), dx.shape[1], dx.shape[0], _p(ln), ln.shape[0], int(width_of_band), _p(out))
+    return out
+
+
+def lbd_gauss_tables(width_of_band=7):
+    cl, cg = np.empty(3 * width_of_band), np.empty(9 * width_of_band)
+    lib().plo_lbd_gauss_tables(int(width_of_band), _p(cl), _p(cg))
+    return cl, cg
 
 
 def lbd_pairs():

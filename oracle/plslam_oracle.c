@@ -1145,6 +1145,153 @@ void plo_normalize2(double v[2])
     v[1] /= magnitude;
 }
 
+/* ---- LBD float descriptor: binary_descriptor_custom.cpp:1026-1372 ------------------------------------- */
+#define PLO_NUM_OF_BANDS 9
+void plo_lbd_gauss_tables(int32_t w, double* coef_l, double* coef_g)
+{
+    /* :146-176 (the constructor), integer divisions as written */
+    double u = (w * 3 - 1) / 2;
+    double sigma = (w * 2 + 1) / 2;
+    double invsigma2 = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < w * 3; i++) {
+        const double dis = i - u;
+        coef_l[i] = exp(dis * dis * invsigma2);
+    }
+    u = (PLO_NUM_OF_BANDS * w - 1) / 2;
+    sigma = u;
+    invsigma2 = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < PLO_NUM_OF_BANDS * w; i++) {
+        const double dis = i - u;
+        coef_g[i] = exp(dis * dis * invsigma2);
+    }
+}
+
+void plo_lbd_compute(const int16_t* pdxImg, const int16_t* pdyImg, int32_t width, int32_t height, const plo_lbd_line* lines,
+                     int32_t n, int32_t widthOfBand, float* lbd)
+{
+    double* gaussCoefL = (double*)malloc(sizeof(double) * 3 * (size_t)widthOfBand);
+    double* gaussCoefG = (double*)malloc(sizeof(double) * PLO_NUM_OF_BANDS * (size_t)widthOfBand);
+    plo_lbd_gauss_tables(widthOfBand, gaussCoefL, gaussCoefG);
+    const short heightOfLSP = (short)(widthOfBand * PLO_NUM_OF_BANDS);
+    const short descriptor_size = PLO_NUM_OF_BANDS * 8;
+    const short halfHeight = (heightOfLSP - 1) / 2;
+    const short realWidth = (short)width;
+    const short imageWidth = realWidth - 1;
+    const short imageHeight = (short)(height - 1);
+    for (int32_t li = 0; li < n; ++li) {
+        const plo_lbd_line* L = &lines[li];
+        float pgdLBandSum[PLO_NUM_OF_BANDS] = {0}, ngdLBandSum[PLO_NUM_OF_BANDS] = {0}, pgdL2BandSum[PLO_NUM_OF_BANDS] = {0},
+              ngdL2BandSum[PLO_NUM_OF_BANDS] = {0}, pgdOBandSum[PLO_NUM_OF_BANDS] = {0}, ngdOBandSum[PLO_NUM_OF_BANDS] = {0},
+              pgdO2BandSum[PLO_NUM_OF_BANDS] = {0}, ngdO2BandSum[PLO_NUM_OF_BANDS] = {0};
+        const short lengthOfLSP = (short)L->num_pixels;
+        const short halfWidth = (lengthOfLSP - 1) / 2;
+        const float lineMiddlePointX = (float)(0.5 * (L->sx + L->ex));
+        const float lineMiddlePointY = (float)(0.5 * (L->sy + L->ey));
+        float dL[2], dO[2];
+        dL[0] = (float)cos((double)L->direction);
+        dL[1] = (float)sin((double)L->direction);
+        dO[0] = -dL[1];
+        dO[1] = dL[0];
+        float sCorX0 = -dL[0] * halfWidth + dL[1] * halfHeight + lineMiddlePointX;
+        float sCorY0 = -dL[1] * halfWidth - dL[0] * halfHeight + lineMiddlePointY;
+        for (short hID = 0; hID < heightOfLSP; hID++) {
+            float sCorX = sCorX0, sCorY = sCorY0;
+            float pgdLRowSum = 0, ngdLRowSum = 0, pgdORowSum = 0, ngdORowSum = 0;
+            for (short wID = 0; wID < lengthOfLSP; wID++) {
+                short tempCor = (short)round(sCorX);
+                const short xCor = (tempCor < 0) ? 0 : (tempCor > imageWidth) ? imageWidth : tempCor;
+                tempCor = (short)round(sCorY);
+                const short yCor = (tempCor < 0) ? 0 : (tempCor > imageHeight) ? imageHeight : tempCor;
+                const short dx = pdxImg[yCor * realWidth + xCor];
+                const short dy = pdyImg[yCor * realWidth + xCor];
+                const float gDL = dx * dL[0] + dy * dL[1];
+                const float gDO = dx * dO[0] + dy * dO[1];
+                if (gDL > 0) pgdLRowSum += gDL; else ngdLRowSum -= gDL;
+                if (gDO > 0) pgdORowSum += gDO; else ngdORowSum -= gDO;
+                sCorX += dL[0];
+                sCorY += dL[1];
+            }
+            sCorX0 -= dL[1];
+            sCorY0 += dL[0];
+            float coefInGaussion = (float)gaussCoefG[hID];
+            pgdLRowSum = coefInGaussion * pgdLRowSum;
+            ngdLRowSum = coefInGaussion * ngdLRowSum;
+            const float pgdL2RowSum = pgdLRowSum * pgdLRowSum;
+            const float ngdL2RowSum = ngdLRowSum * ngdLRowSum;
+            pgdORowSum = coefInGaussion * pgdORowSum;
+            ngdORowSum = coefInGaussion * ngdORowSum;
+            const float pgdO2RowSum = pgdORowSum * pgdORowSum;
+            const float ngdO2RowSum = ngdORowSum * ngdORowSum;
+            short bandID = (short)(hID / widthOfBand);
+            for (int nb = 0; nb < 3; ++nb) {        /* own band (:1201-1210), the one above (:1215-1227), the one below (:1228-1239) */
+                int b, off;
+                if (nb == 0) { b = bandID; off = widthOfBand; }
+                else if (nb == 1) { b = bandID - 1; off = 2 * widthOfBand; if (b < 0) continue; }
+                else { b = bandID + 1; off = 0; if (b >= PLO_NUM_OF_BANDS) continue; }
+                coefInGaussion = (float)(gaussCoefL[hID % widthOfBand + off]);
+                pgdLBandSum[b] += coefInGaussion * pgdLRowSum;
+                ngdLBandSum[b] += coefInGaussion * ngdLRowSum;
+                pgdL2BandSum[b] += coefInGaussion * coefInGaussion * pgdL2RowSum;
+                ngdL2BandSum[b] += coefInGaussion * coefInGaussion * ngdL2RowSum;
+                pgdOBandSum[b] += coefInGaussion * pgdORowSum;
+                ngdOBandSum[b] += coefInGaussion * ngdORowSum;
+                pgdO2BandSum[b] += coefInGaussion * coefInGaussion * pgdO2RowSum;
+                ngdO2BandSum[b] += coefInGaussion * coefInGaussion * ngdO2RowSum;
+            }
+        }
+        float* desVec = lbd + (size_t)li * descriptor_size;
+        const float invN2 = (float)(1.0 / (widthOfBand * 2.0));
+        const float invN3 = (float)(1.0 / (widthOfBand * 3.0));
+        for (short bandID = 0; bandID < PLO_NUM_OF_BANDS; bandID++) {
+            const float invN = (bandID == 0 || bandID == PLO_NUM_OF_BANDS - 1) ? invN2 : invN3;
+            const short desID = bandID * 8;
+            float temp = pgdLBandSum[bandID] * invN;
+            desVec[desID] = temp;
+            desVec[desID + 4] = sqrtf(pgdL2BandSum[bandID] * invN - temp * temp);
+            temp = ngdLBandSum[bandID] * invN;
+            desVec[desID + 1] = temp;
+            desVec[desID + 5] = sqrtf(ngdL2BandSum[bandID] * invN - temp * temp);
+            temp = pgdOBandSum[bandID] * invN;
+            desVec[desID + 2] = temp;
+            desVec[desID + 6] = sqrtf(pgdO2BandSum[bandID] * invN - temp * temp);
+            temp = ngdOBandSum[bandID] * invN;
+            desVec[desID + 3] = temp;
+            desVec[desID + 7] = sqrtf(ngdO2BandSum[bandID] * invN - temp * temp);
+        }
+        float tempM = 0, tempS = 0;
+        for (int i = 0; i < descriptor_size; i += 8) {
+            tempM += desVec[i] * desVec[i];
+            tempM += desVec[i + 1] * desVec[i + 1];
+            tempM += desVec[i + 2] * desVec[i + 2];
+            tempM += desVec[i + 3] * desVec[i + 3];
+            tempS += desVec[i + 4] * desVec[i + 4];
+            tempS += desVec[i + 5] * desVec[i + 5];
+            tempS += desVec[i + 6] * desVec[i + 6];
+            tempS += desVec[i + 7] * desVec[i + 7];
+        }
+        tempM = 1 / sqrtf(tempM);
+        tempS = 1 / sqrtf(tempS);
+        for (int i = 0; i < descriptor_size; i += 8) {
+            desVec[i] = desVec[i] * tempM;
+            desVec[i + 1] = desVec[i + 1] * tempM;
+            desVec[i + 2] = desVec[i + 2] * tempM;
+            desVec[i + 3] = desVec[i + 3] * tempM;
+            desVec[i + 4] = desVec[i + 4] * tempS;
+            desVec[i + 5] = desVec[i + 5] * tempS;
+            desVec[i + 6] = desVec[i + 6] * tempS;
+            desVec[i + 7] = desVec[i + 7] * tempS;
+        }
+        for (short i = 0; i < descriptor_size; i++)
+            if (desVec[i] > 0.4) desVec[i] = (float)0.4;
+        float temp = 0;
+        for (short i = 0; i < descriptor_size; i++) temp += desVec[i] * desVec[i];
+        temp = 1 / sqrtf(temp);
+        for (short i = 0; i < descriptor_size; i++) desVec[i] = desVec[i] * temp;
+    }
+    free(gaussCoefG);
+    free(gaussCoefL);
+}
+
 /* ---- LBD float -> binary line descriptor -------------------------------------------------- */
 /* binary_descriptor_custom.cpp:74-107 -- band index pairs of the 32 output bytes */
 const int plo_lbd_pairs[32][2] = {

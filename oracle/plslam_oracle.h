@@ -270,6 +270,26 @@ int32_t plo_get_line_coords(double x1, double y1, double x2, double y2, int32_t*
  * and |dot| < th is then false, i.e. the direction test passes. */
 void plo_normalize2(double v[2]);
 
+/* ---- LBD float descriptor of a line: BinaryDescriptor::computeLBD ------------------------------------------
+ * 3rdparty/line_descriptor/src/binary_descriptor_custom.cpp:1026-1372, literal restatement (fp32, the source's
+ * sequential summation order; built without FMA contraction): the line support region of NUM_OF_BANDS (9) bands x
+ * widthOfBand rows, row sums of the gradient projected on the line direction / its normal split by sign (:1140-1187),
+ * the global Gaussian weight per row gaussCoefG_ (:1188-1196), band sums with the local weights gaussCoefL_ of the row's
+ * own band and its two neighbours (:1201-1239), mean / std per band (:1253-1277), the two-part normalisation
+ * (:1279-1312), the 0.4 clamp (:1318-1325) and the re-normalisation (:1327-1338).  Weight tables as the constructor
+ * builds them (:146-176, integer divisions included).
+ *   dx, dy      gradient images of ONE octave, int16, `width` x `height`, row stride = width (dxImg_vector[octave])
+ *   lines       n x plo_lbd_line: the OctaveSingleLine fields computeLBD reads
+ *   lbd         n x 72 float32 (the `descriptor` vector of each line) */
+typedef struct {
+    int32_t num_pixels;          /* numOfPixels: length of the support region */
+    float sx, sy, ex, ey;        /* sPointInOctaveX/Y, ePointInOctaveX/Y */
+    float direction;             /* angle of the line */
+} plo_lbd_line;
+void plo_lbd_compute(const int16_t* dx, const int16_t* dy, int32_t width, int32_t height, const plo_lbd_line* lines,
+                     int32_t n, int32_t width_of_band, float* lbd);
+void plo_lbd_gauss_tables(int32_t width_of_band, double* coef_l /* 3 w */, double* coef_g /* 9 w */);
+
 /* ---- LBD float -> binary line descriptor ---------------------------------------------------
  * 3rdparty/line_descriptor/src/binary_descriptor_custom.cpp: the 32 band pairs of
  * combinations[32][2] (:74-107), binaryConversion (:401-412; bit i set iff f1[i] > f2[i]) and the

@@ -34,7 +34,7 @@ ABI_SYMBOLS = (
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
     "plslam_map2kf_match_points_fast", "plslam_map2kf_match_lines_fast",
     "plslam_kf2kf_match_points", "plslam_kf2kf_match_lines",
-    "plslam_lbd_binarise", "plslam_lbd_binarise_dev",
+    "plslam_lbd_binarise", "plslam_lbd_binarise_dev", "plslam_lbd_compute", "plslam_lbd_compute_dev",
     "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
     "plslam_stereo_point_gate", "plslam_stereo_line_gate", "plslam_pose_gn_accumulate",
     "plslam_match_grid", "plslam_grid_plan_create", "plslam_grid_plan_run", "plslam_grid_plan_overflows",
@@ -79,6 +79,11 @@ class PlanInfo(C.Structure):
                 ("algorithmic_bytes", C.c_int64), ("n_scans", C.c_int32),
                 ("scan_blocks", C.c_int32), ("scan_variant", C.c_int32),
                 ("scan_block_threads", C.c_int32)]
+
+
+# plslam_lbd_line as a numpy record
+LBD_LINE_DTYPE = np.dtype([("num_pixels", np.int32), ("sx", np.float32), ("sy", np.float32), ("ex", np.float32),
+                           ("ey", np.float32), ("direction", np.float32)])
 
 
 class PlslamError(RuntimeError):
@@ -182,6 +187,8 @@ def load() -> C.CDLL:
         f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, i32, vp, vp, i32, C.c_float, C.c_int, i32, C.POINTER(FastMatching), vp,
                       C.POINTER(i32), C.POINTER(i32)]
     L.plslam_pose_gn_accumulate.argtypes = [vp, C.POINTER(Cam), f64, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
+    L.plslam_lbd_compute.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, vp]
+    L.plslam_lbd_compute_dev.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]
     L.plslam_stereo_point_gate.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, vp, vp, C.POINTER(i32)]
     L.plslam_stereo_line_gate.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, f64, f64, vp, vp, C.POINTER(i32)]
     L.plslam_match_grid.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, vp, vp, f64, vp, f64, C.c_int, vp,
@@ -462,6 +469,23 @@ class Context:
         out = np.empty((f.shape[0], 32), np.uint8)
         _check(self._L.plslam_lbd_binarise(self._h, _p(f), f.shape[0], _p(out)), "plslam_lbd_binarise")
         return out
+
+    def lbd_compute(self, dx_img, dy_img, lines, width_of_band=7):
+        """BinaryDescriptor::computeLBD for the lines of one octave: (height, width) int16 gradient images and a
+        structured array of plslam_lbd_line -> (n, 72) float32."""
+        dx, dy = _arr(dx_img, np.int16), _arr(dy_img, np.int16)
+        ln = np.ascontiguousarray(lines, dtype=LBD_LINE_DTYPE)
+        out = np.empty((ln.shape[0], 72), np.float32)
+        _check(self._L.plslam_lbd_compute(self._h, _p(dx), _p(dy), dx.shape[1], dx.shape[0], _p(ln), ln.shape[0],
+                                          int(width_of_band), _p(out)), "plslam_lbd_compute")
+        return out
+
+    def lbd_compute_dev(self, d_dx_ptr, d_dy_ptr, width, height, lines, d_lbd_ptr, width_of_band=7, stream=None):
+        """Device-pointer form (gradient images and the output on the device; the line records are host data)."""
+        ln = np.ascontiguousarray(lines, dtype=LBD_LINE_DTYPE)
+        _check(self._L.plslam_lbd_compute_dev(self._h, C.c_void_p(d_dx_ptr), C.c_void_p(d_dy_ptr), int(width), int(height),
+                                              _p(ln), ln.shape[0], int(width_of_band), C.c_void_p(d_lbd_ptr),
+                                              C.c_void_p(stream or 0)), "plslam_lbd_compute_dev")
 
     def lbd_binarise_dev(self, d_lbd_ptr, n, d_desc_ptr, stream=None):
         """Device-pointer form; enqueues on `stream` (None = the context's stream), no sync."""

@@ -206,3 +206,28 @@ def grid_frame_pair(rng, n1, n2, width=752, height=480, keep_frac=0.7, flip_p=0.
         s2 = np.where(keep[:, None], s1[src] + np.tile(p2 - p1[src], 2) + rng.normal(0, 1.0, (n2, 4)), s2)
     out.update(seg1=s1, seg2=s2)
     return out
+
+
+def gradient_images(rng, width=752, height=480, smooth=3):
+    """Sobel-like int16 gradient images of a random smoothed image (what EDLineDetector / the octave pyramid hand to
+    computeLBD as dxImg / dyImg)."""
+    img = rng.integers(0, 256, size=(height, width)).astype(np.float64)
+    for _ in range(smooth):
+        img = (img + np.roll(img, 1, 0) + np.roll(img, -1, 0) + np.roll(img, 1, 1) + np.roll(img, -1, 1)) / 5.0
+    p = np.pad(img, 1, mode="edge")
+    dx = (p[:-2, 2:] + 2 * p[1:-1, 2:] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[1:-1, :-2] + p[2:, :-2])
+    dy = (p[2:, :-2] + 2 * p[2:, 1:-1] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[:-2, 1:-1] + p[:-2, 2:])
+    return np.rint(dx).astype(np.int16), np.rint(dy).astype(np.int16)
+
+
+def lbd_lines(rng, n, width=752, height=480, min_len=10.0, max_len=250.0, dtype=None):
+    """Random segments as the line detector reports them (OctaveSingleLine fields read by computeLBD); some reach past
+    the image border so that the clamping is exercised."""
+    sx, sy = rng.uniform(-5, width + 5, n), rng.uniform(-5, height + 5, n)
+    ang, ln = rng.uniform(-np.pi, np.pi, n), rng.uniform(min_len, max_len, n)
+    ex, ey = sx + ln * np.cos(ang), sy + ln * np.sin(ang)
+    out = np.zeros(n, dtype=dtype)
+    out["num_pixels"] = np.rint(ln).astype(np.int32)
+    out["sx"], out["sy"], out["ex"], out["ey"] = sx, sy, ex, ey
+    out["direction"] = np.arctan2(ey - sy, ex - sx)
+    return out

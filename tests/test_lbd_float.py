@@ -1,0 +1,158 @@
+"""K18: the LBD float descriptor (BinaryDescriptor::computeLBD, 3rdparty/line_descriptor/src/
+binary_descriptor_custom.cpp:1026-1372).  CPU: the oracle's literal restatement -- weight tables against the
+constructor's formulas parsed from the source text, structural properties, a numpy re-derivation of one line; GPU: the
+HIP kernel against the oracle (same fp32 operation order, no FMA on either side: bit-exact; the contract towards the
+reference binary is 1e-5 relative) and the chain gradient images -> LBD floats -> binary rows -> StVO::match."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from plslam_amd import synth
+
+SRC = "/root/reference/3rdparty/line_descriptor/src/binary_descriptor_custom.cpp"
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def test_gauss_tables_follow_the_constructor(oracle):
+    cl, cg = oracle.lbd_gauss_tables(7)
+    # :146-176 with the integer divisions as written: u = (7*3-1)/2 = 10, sigma = (7*2+1)/2 = 7; u = sigma = (9*7-1)/2 = 31
+    np.testing.assert_array_equal(cl, np.exp((np.arange(21) - 10.0) ** 2 * (-1 / (2 * 7.0 * 7.0))))
+    np.testing.assert_array_equal(cg, np.exp((np.arange(63) - 31.0) ** 2 * (-1 / (2 * 31.0 * 31.0))))
+    if os.path.exists(SRC):          # this container only: the formulas really are what the source says
+        txt = open(SRC).read()
+        assert re.search(r"double u = \( params\.widthOfBand_ \* 3 - 1 \) / 2;", txt)
+        assert re.search(r"double sigma = \( params\.widthOfBand_ \* 2 \+ 1 \) / 2;", txt)
+        assert re.search(r"u = \( NUM_OF_BANDS \* params\.widthOfBand_ - 1 \) / 2;", txt) and "#define NUM_OF_BANDS 9" in txt
+        assert "if( desVec[i] > 0.4 )" in txt and "widthOfBand_ = 7;" in txt
+
+
+def _np_one_line(dx, dy, L, w=7):
+    """Independent (float64, vectorised) derivation of the band statistics of one line, up to the normalisations."""
+    from oracle import oracle as O
+    cl, cg = O.lbd_gauss_tables(w)
+    H, n = 9 * w, int(L["num_pixels"])
+    d0, d1 = np.float32(np.cos(np.float64(L["direction"]))), np.float32(np.sin(np.float64(L["direction"])))
+    mx, my = np.float32(0.5 * (L["sx"] + L["ex"])), np.float32(0.5 * (L["sy"] + L["ey"]))
+    hw, hh = (n - 1) // 2, (H - 1) // 2
+    rows = np.zeros((H, 4))
+    f32 = np.float32
+    # the pixel coordinates are ACCUMULATED in fp32 upstream (row starts and steps along the row): reproduce that, so
+    # that both derivations visit the same pixels; everything after the pixel fetch is float64 here
+    x0s = np.concatenate([[-d0 * f32(hw) + d1 * f32(hh) + mx], np.full(H - 1, -d1, f32)]).astype(f32).cumsum(dtype=f32)
+    y0s = np.concatenate([[-d1 * f32(hw) - d0 * f32(hh) + my], np.full(H - 1, d0, f32)]).astype(f32).cumsum(dtype=f32)
+    rnd = lambda v: (np.sign(v) * np.floor(np.abs(v.astype(np.float64)) + 0.5)).astype(int)       # C round()
+    for h in range(H):
+        xs = np.concatenate([[x0s[h]], np.full(max(n - 1, 0), d0, f32)]).astype(f32).cumsum(dtype=f32)[:n]
+        ys = np.concatenate([[y0s[h]], np.full(max(n - 1, 0), d1, f32)]).astype(f32).cumsum(dtype=f32)[:n]
+        xi = np.clip(rnd(xs), 0, dx.shape[1] - 1)
+        yi = np.clip(rnd(ys), 0, dx.shape[0] - 1)
+        gx, gy = dx[yi, xi].astype(np.float64), dy[yi, xi].astype(np.float64)
+        gl, go = gx * d0 + gy * d1, -gx * d1 + gy * d0
+        rows[h] = [gl[gl > 0].sum(), -gl[gl <= 0].sum(), go[go > 0].sum(), -go[go <= 0].sum()]
+    rows *= cg[:, None]
+    band = np.zeros((9, 8))
+    for h in range(H):
+        b0 = h // w
+        for b, off in ((b0, w), (b0 - 1, 2 * w), (b0 + 1, 0)):
+            if 0 <= b < 9:
+                c = cl[h % w + off]
+                band[b, :4] += c * rows[h]
+                band[b, 4:] += c * c * rows[h] ** 2
+    invn = np.where((np.arange(9) == 0) | (np.arange(9) == 8), 1 / (2.0 * w), 1 / (3.0 * w))[:, None]
+    mean = band[:, :4] * invn
+    std = np.sqrt(np.maximum(band[:, 4:] * invn - mean ** 2, 0))
+    des = np.concatenate([mean, std], 1)                     # [band][pgdL ngdL pgdO ngdO | their stds]
+    des[:, :4] /= np.sqrt((des[:, :4] ** 2).sum())
+    des[:, 4:] /= np.sqrt((des[:, 4:] ** 2).sum())
+    des = np.minimum(des, 0.4).reshape(-1)
+    return des / np.sqrt((des ** 2).sum())
+
+
+def test_oracle_against_an_independent_derivation(oracle):
+    r = _rng(1)
+    dx, dy = synth.gradient_images(r, 320, 240)
+    lines = synth.lbd_lines(r, 12, 320, 240, max_len=120, dtype=oracle.LBD_LINE_DTYPE)
+    lines["sx"], lines["ex"] = np.clip(lines["sx"], 40, 280), np.clip(lines["ex"], 40, 280)   # keep the rounding trivial
+    lines["sy"], lines["ey"] = np.clip(lines["sy"], 40, 200), np.clip(lines["ey"], 40, 200)
+    lines["direction"] = np.arctan2(lines["ey"] - lines["sy"], lines["ex"] - lines["sx"])
+    out = oracle.lbd_compute(dx, dy, lines)
+    assert out.shape == (12, 72) and np.isfinite(out).all()
+    np.testing.assert_allclose((out.astype(np.float64) ** 2).sum(1), 1.0, rtol=1e-5)        # unit vectors
+    assert (out >= 0).all() and out.max() < 0.4 * 1.5
+    for i in range(12):
+        # same pixels, fp32 sequential sums vs float64 vectorised sums
+        np.testing.assert_allclose(out[i], _np_one_line(dx, dy, lines[i]), rtol=0, atol=2e-5)
+
+
+def test_oracle_edge_cases(oracle):
+    r = _rng(2)
+    dx, dy = synth.gradient_images(r, 96, 64)
+    lines = np.zeros(3, oracle.LBD_LINE_DTYPE)
+    lines[0] = (40, 10, 10, 50, 10, 0.0)
+    lines[1] = (0, 30, 30, 30, 30, 1.0)                       # zero-length support region: all sums 0 -> 0 / 0
+    lines[2] = (300, -100, -100, 200, 200, np.pi / 4)         # far outside: every pixel clamps to the border
+    out = oracle.lbd_compute(dx, dy, lines)
+    assert np.isfinite(out[0]).all() and np.isnan(out[1]).all() and np.isfinite(out[2]).all()
+    z = oracle.lbd_compute(np.zeros_like(dx), np.zeros_like(dy), lines[:1])
+    assert np.isnan(z).all()                                  # no gradient at all: 1 / sqrt(0) * 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("width,height,n,w", [(752, 480, 200, 7), (1241, 376, 900, 7), (96, 64, 33, 7), (320, 240, 50, 5),
+                                              (64, 48, 5, 1)])
+def test_gpu_bit_exact_vs_oracle(ctx, oracle, width, height, n, w):
+    r = _rng(width + n)
+    dx, dy = synth.gradient_images(r, width, height)
+    lines = synth.lbd_lines(r, n, width, height, max_len=min(250.0, 0.6 * width), dtype=oracle.LBD_LINE_DTYPE)
+    lines["num_pixels"][:2] = (0, 1)                          # degenerate support regions too
+    got = ctx.lbd_compute(dx, dy, lines, w)
+    ref = oracle.lbd_compute(dx, dy, lines, w)
+    np.testing.assert_array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gpu_chain_images_to_matches(ctx, oracle):
+    """Two views of the same lines (the second image = the first shifted by a few pixels): gradient images -> K18 -> K11
+    -> StVO::match, device-resident between the stages, equals the oracle chain and finds the correspondences."""
+    import torch
+    r = _rng(5)
+    W, Hh, n = 752, 480, 200
+    dx, dy = synth.gradient_images(r, W, Hh, smooth=6)
+    lines = synth.lbd_lines(r, n, W, Hh, min_len=40, max_len=160, dtype=oracle.LBD_LINE_DTYPE)
+    for k in ("sx", "ex"):
+        lines[k] = np.clip(lines[k], 60, W - 60)
+    for k in ("sy", "ey"):
+        lines[k] = np.clip(lines[k], 60, Hh - 60)
+    lines["direction"] = np.arctan2(lines["ey"] - lines["sy"], lines["ex"] - lines["sx"])
+    lines["num_pixels"] = np.rint(np.hypot(lines["ex"] - lines["sx"], lines["ey"] - lines["sy"])).astype(np.int32)
+    dx2, dy2 = np.roll(dx, (2, 3), (0, 1)), np.roll(dy, (2, 3), (0, 1))
+    lines2 = lines.copy()
+    for k, s in (("sx", 3), ("ex", 3), ("sy", 2), ("ey", 2)):
+        lines2[k] += s
+    perm = r.permutation(n)
+    lines2 = lines2[perm]
+    dev = torch.device("cuda", ctx.device)
+    st = torch.cuda.Stream(device=dev)
+    descs = []
+    for gx, gy, ln in ((dx, dy, lines), (dx2, dy2, lines2)):
+        tx, ty = torch.from_numpy(gx).to(dev), torch.from_numpy(gy).to(dev)
+        f = torch.empty((n, 72), dtype=torch.float32, device=dev)
+        b = torch.empty((n, 32), dtype=torch.uint8, device=dev)
+        ctx.lbd_compute_dev(tx.data_ptr(), ty.data_ptr(), W, Hh, ln, f.data_ptr(), 7, st.cuda_stream)
+        ctx.lbd_binarise_dev(f.data_ptr(), n, b.data_ptr(), st.cuda_stream)
+        st.synchronize()
+        ref_f = oracle.lbd_compute(gx, gy, ln)
+        np.testing.assert_array_equal(f.cpu().numpy().view(np.uint32), ref_f.view(np.uint32))
+        np.testing.assert_array_equal(b.cpu().numpy(), oracle.lbd_binarise(ref_f))
+        descs.append(b.cpu().numpy())
+    m, k = ctx.match(descs[0], descs[1], 0.9, True)
+    rm, rk = oracle.match(descs[0], descs[1], 0.9, True)
+    np.testing.assert_array_equal(m, rm)
+    truth = np.argsort(perm)
+    ok = m >= 0
+    assert ok.sum() > 0.8 * n and (m[ok] == truth[ok]).mean() > 0.98
