@@ -1,0 +1,41 @@
+"""Generates tests/golden/lbd_float_golden.npz and pose_gn_golden.npz (run from the repo root:
+python tests/golden/make_k17_k18_golden.py).  Outputs come from the C oracle's literal restatements of
+BinaryDescriptor::computeLBD (binary_descriptor_custom.cpp:1026-1372) and of the computeRelativePoseGN iteration body
+(src/mapHandler.cpp:3324-3424); the LBD case is additionally checked here against the independent float64 numpy
+derivation of tests/test_lbd_float.py before it is written."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle import oracle as O  # noqa: E402
+from plslam_amd import synth  # noqa: E402
+from test_lbd_float import _np_one_line  # noqa: E402
+from test_pose_gn import scene  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    r = np.random.Generator(np.random.PCG64(77))
+    dx, dy = synth.gradient_images(r, 128, 96)
+    lines = synth.lbd_lines(r, 24, 128, 96, min_len=8, max_len=70, dtype=O.LBD_LINE_DTYPE)
+    out = O.lbd_compute(dx, dy, lines)
+    inner = (np.minimum(lines["sx"], lines["ex"]) > 35) & (np.maximum(lines["sx"], lines["ex"]) < 93) & \
+            (np.minimum(lines["sy"], lines["ey"]) > 35) & (np.maximum(lines["sy"], lines["ey"]) < 61)
+    for i in np.nonzero(inner)[0]:
+        np.testing.assert_allclose(out[i], _np_one_line(dx, dy, lines[i]), rtol=0, atol=5e-5)
+    np.savez_compressed(os.path.join(OUT, "lbd_float_golden.npz"), dx=dx, dy=dy, lines=lines, lbd=out,
+                        codes=O.lbd_binarise(out))
+    s = scene(60, 20, seed=31)
+    cam = O.make_cam(**synth.EUROC)
+    H, g, e, n = O.pose_gn_accumulate(cam, 1e-7, s["T"], s["P"], s["pl_obs"], s["pt_in"], s["sPeP"], s["le_obs"], s["ls_in"])
+    np.savez_compressed(os.path.join(OUT, "pose_gn_golden.npz"), H=H, g=g, e=e, n=np.array(n), **s)
+    print("wrote lbd_float_golden.npz, pose_gn_golden.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -156,3 +156,22 @@ def test_gpu_chain_images_to_matches(ctx, oracle):
     truth = np.argsort(perm)
     ok = m >= 0
     assert ok.sum() > 0.8 * n and (m[ok] == truth[ok]).mean() > 0.98
+
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "lbd_float_golden.npz")
+
+
+def test_oracle_reproduces_the_committed_golden(oracle):
+    g = np.load(GOLD)
+    out = oracle.lbd_compute(g["dx"], g["dy"], g["lines"])
+    np.testing.assert_array_equal(out.view(np.uint32), g["lbd"].view(np.uint32))
+    np.testing.assert_array_equal(oracle.lbd_binarise(out), g["codes"])
+
+
+@pytest.mark.gpu
+def test_gpu_committed_golden(ctx):
+    """No oracle at run time: floats and binary rows against tests/golden/lbd_float_golden.npz."""
+    g = np.load(GOLD)
+    out = ctx.lbd_compute(g["dx"], g["dy"], g["lines"])
+    np.testing.assert_array_equal(out.view(np.uint32), g["lbd"].view(np.uint32))
+    np.testing.assert_array_equal(ctx.lbd_binarise(out), g["codes"])

@@ -107,3 +107,17 @@ def test_gpu_gn_iterations_converge_like_the_oracle(ctx, oracle):
         poses.append(T)
     np.testing.assert_allclose(poses[0], poses[1], rtol=0, atol=1e-9)
     assert np.abs(poses[0] - np.eye(4)).max() > 1e-3               # it did move
+
+
+@pytest.mark.gpu
+def test_gpu_committed_golden(ctx):
+    """No oracle at run time: tests/golden/pose_gn_golden.npz (tests/golden/make_k17_k18_golden.py)."""
+    import os
+    import plslam_amd
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "pose_gn_golden.npz"))
+    cam = plslam_amd.make_cam(**synth.EUROC)
+    H, gg, e, n = ctx.pose_gn_accumulate(cam, 1e-7, g["T"], g["P"], g["pl_obs"], g["pt_in"], g["sPeP"], g["le_obs"], g["ls_in"])
+    assert n == tuple(g["n"])
+    np.testing.assert_allclose(H, g["H"], rtol=0, atol=1e-9 * np.abs(g["H"]).max())
+    np.testing.assert_allclose(gg, g["g"], rtol=0, atol=1e-9 * np.abs(g["g"]).max())
+    assert abs(e - float(g["e"])) <= 1e-9 * abs(float(g["e"]))
