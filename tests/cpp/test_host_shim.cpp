@@ -4,6 +4,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 #include <thread>
 #include <vector>
@@ -346,6 +347,93 @@ int main()
             EXPECT(bad == 0);
             EXPECT(std::fabs(B.err - err) <= 1e-12 * std::fabs(err));
         }
+        plslam_ctx_destroy(ctx);
+    }
+    {   // --- the newer C entry points through a C++ translation unit: struct layouts + results vs the oracle ---
+        plslam_ctx* ctx = nullptr;
+        EXPECT(plslam_ctx_create(0, &ctx) == PLSLAM_OK);
+        std::mt19937 g(99);
+        std::uniform_real_distribution<double> U(0.0, 1.0);
+        // stereo point gate
+        const int n = 500;
+        std::vector<float> kl(2 * n), kr(2 * n);
+        std::vector<int32_t> m12(n), s12(n), rs12(n);
+        std::vector<double> disp(n), rdisp(n);
+        for (int i = 0; i < n; ++i) {
+            kl[2 * i] = (float)(752 * U(g)); kl[2 * i + 1] = (float)(480 * U(g));
+            kr[2 * i] = kl[2 * i] - (float)(40 * U(g) - 2); kr[2 * i + 1] = kl[2 * i + 1] + (float)(3 * U(g) - 1.5);
+            m12[i] = U(g) < 0.8 ? i : -1;
+        }
+        int32_t ns = 0;
+        EXPECT(plslam_stereo_point_gate(ctx, m12.data(), n, kl.data(), kr.data(), n, 1.0, 1.0, s12.data(), disp.data(), &ns) == PLSLAM_OK);
+        EXPECT(ns == plo_stereo_point_gate(m12.data(), n, kl.data(), kr.data(), n, 1.0, 1.0, rs12.data(), rdisp.data()));
+        for (int i = 0; i < n; ++i) EXPECT(s12[i] == rs12[i] && disp[i] == rdisp[i]);
+        // LBD float descriptor: plslam_lbd_line and plo_lbd_line share their layout
+        static_assert(sizeof(plslam_lbd_line) == sizeof(plo_lbd_line), "line record layout");
+        const int W = 160, H = 120, nl = 20;
+        std::vector<int16_t> gx((size_t)W * H), gy((size_t)W * H);
+        for (auto& v : gx) v = (int16_t)(int)(600 * U(g) - 300);
+        for (auto& v : gy) v = (int16_t)(int)(600 * U(g) - 300);
+        std::vector<plslam_lbd_line> lines(nl);
+        for (auto& L : lines) {
+            L.sx = (float)(20 + 100 * U(g)); L.sy = (float)(20 + 70 * U(g));
+            const double a = 6.28 * U(g), len = 10 + 50 * U(g);
+            L.ex = L.sx + (float)(len * std::cos(a)); L.ey = L.sy + (float)(len * std::sin(a));
+            L.num_pixels = (int32_t)len;
+            L.direction = (float)std::atan2(L.ey - L.sy, L.ex - L.sx);
+        }
+        std::vector<float> lbd((size_t)nl * 72), rlbd((size_t)nl * 72);
+        EXPECT(plslam_lbd_compute(ctx, gx.data(), gy.data(), W, H, lines.data(), nl, 7, lbd.data()) == PLSLAM_OK);
+        plo_lbd_compute(gx.data(), gy.data(), W, H, reinterpret_cast<const plo_lbd_line*>(lines.data()), nl, 7, rlbd.data());
+        EXPECT(std::memcmp(lbd.data(), rlbd.data(), lbd.size() * 4) == 0);
+        // pose-only GN system
+        plslam_cam K{458.654, 457.296, 367.215, 248.375, 0.11, 752, 480};
+        plo_cam oK{458.654, 457.296, 367.215, 248.375, 0.11, 752, 480};
+        const int np = 120, nls = 30;
+        std::vector<double> P(3 * np), po(2 * np), S(6 * nls), lo(3 * nls);
+        std::vector<uint8_t> pi(np), li(nls);
+        for (int i = 0; i < np; ++i) {
+            P[3 * i] = 4 * U(g) - 2; P[3 * i + 1] = 3 * U(g) - 1.5; P[3 * i + 2] = 3 + 10 * U(g);
+            po[2 * i] = K.cx + K.fx * P[3 * i] / P[3 * i + 2] + 2 * U(g); po[2 * i + 1] = K.cy + K.fy * P[3 * i + 1] / P[3 * i + 2] - 2 * U(g);
+            pi[i] = U(g) < 0.9;
+        }
+        for (int i = 0; i < nls; ++i) {
+            for (int k = 0; k < 2; ++k) { S[6 * i + 3 * k] = 4 * U(g) - 2; S[6 * i + 3 * k + 1] = 3 * U(g) - 1.5; S[6 * i + 3 * k + 2] = 3 + 10 * U(g); }
+            lo[3 * i] = 0.6; lo[3 * i + 1] = 0.8; lo[3 * i + 2] = -400 + 20 * U(g);
+            li[i] = U(g) < 0.9;
+        }
+        const double T[16] = {1, 0, 0, 0.01, 0, 1, 0, -0.02, 0, 0, 1, 0.03, 0, 0, 0, 1};
+        double Hm[36], gv[6], e, rH[36], rg[6], re;
+        int32_t cnt[2], rcnt[2];
+        EXPECT(plslam_pose_gn_accumulate(ctx, &K, 1e-7, T, P.data(), po.data(), pi.data(), np, S.data(), lo.data(), li.data(), nls, Hm, gv, &e, cnt) == PLSLAM_OK);
+        plo_pose_gn_accumulate(&oK, 1e-7, T, P.data(), po.data(), pi.data(), np, S.data(), lo.data(), li.data(), nls, rH, rg, &re, rcnt);
+        EXPECT(cnt[0] == rcnt[0] && cnt[1] == rcnt[1]);
+        double hmax = 0;
+        for (double v : rH) hmax = std::max(hmax, std::fabs(v));
+        for (int k = 0; k < 36; ++k) EXPECT(std::fabs(Hm[k] - rH[k]) <= 1e-9 * hmax);
+        EXPECT(std::fabs(e - re) <= 1e-9 * std::fabs(re));
+        // keyframe <-> keyframe driver with fast_matching (plslam_fast_matching layout == plo_fast_matching)
+        static_assert(sizeof(plslam_fast_matching) == sizeof(plo_fast_matching), "fast-matching record layout");
+        const int n1 = 400, n2 = 380;
+        std::vector<double> Pp(3 * n1), plc(2 * n2);
+        std::vector<uint8_t> dp = rand_desc(g, n1), dc = rand_desc(g, n2);
+        for (int i = 0; i < n1; ++i) { Pp[3 * i + 2] = 2 + 20 * U(g); Pp[3 * i] = (752 * U(g) - K.cx) / K.fx * Pp[3 * i + 2]; Pp[3 * i + 1] = (480 * U(g) - K.cy) / K.fy * Pp[3 * i + 2]; }
+        for (int j = 0; j < n2; ++j) {
+            const int i = j % n1;
+            plc[2 * j] = K.cx + K.fx * Pp[3 * i] / Pp[3 * i + 2] + 3 * U(g); plc[2 * j + 1] = K.cy + K.fy * Pp[3 * i + 1] / Pp[3 * i + 2] + 3 * U(g);
+            std::vector<uint8_t> src(dp.begin() + (size_t)i * 32, dp.begin() + (size_t)i * 32 + 32), dst;
+            noisy(g, src, dst);
+            std::copy(dst.begin(), dst.end(), dc.begin() + (size_t)j * 32);
+        }
+        const double DT[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+        plslam_fast_matching fm{1, GRID_COLS, GRID_ROWS, 3, GRID_COLS / 752.0, GRID_ROWS / 480.0, 0.75, 0.75};
+        plo_fast_matching ofm{1, GRID_COLS, GRID_ROWS, 3, GRID_COLS / 752.0, GRID_ROWS / 480.0, 0.75, 0.75};
+        std::vector<int32_t> km(n1), rkm(n1);
+        int32_t kn = 0, used = 0, rused = 0;
+        EXPECT(plslam_kf2kf_match_points(ctx, &K, DT, Pp.data(), dp.data(), n1, plc.data(), dc.data(), n2, 0.75f, 1, 20, &fm, km.data(), &kn, &used) == PLSLAM_OK);
+        const int rkn = plo_kf2kf_match_points(&oK, DT, Pp.data(), dp.data(), n1, plc.data(), dc.data(), n2, 0.75f, 1, 20, &ofm, rkm.data(), &rused);
+        EXPECT(kn == rkn && used == rused && kn > 100);
+        for (int i = 0; i < n1; ++i) EXPECT(km[i] == rkm[i]);
         plslam_ctx_destroy(ctx);
     }
     std::printf(g_fail ? "HOST SHIM: %d FAILURES\n" : "HOST SHIM: all checks passed\n", g_fail);
