@@ -161,6 +161,14 @@ int plslam_match_plan_set_profiling(plslam_match_plan* plan, int enable);
 int plslam_match_plan_elapsed(plslam_match_plan* plan, double* scan_ms, double* finalize_ms,
                               int64_t* runs);
 int plslam_match_plan_info(plslam_match_plan* plan, plslam_plan_info* info);
+/* Diagnostics (no reference counterpart): after a device-wide synchronise, copies the plan's intermediate key
+ * table (per problem: n1 then n2 rows of two composite keys (distance << 23 | index), the state between the scan
+ * and the finalize kernel) and the symmetric scan's per-workgroup column partials to the host.  Either buffer may be
+ * NULL / too small: the sizes are always returned.  The determinism check (tools/determinism_check.py and its GPU
+ * test) compares these words between repeated runs -- ~10^4 x more sensitive than the match tables, where only a
+ * difference that flips a ratio test shows. */
+int plslam_match_plan_dump(plslam_match_plan* plan, void* keys_out, size_t keys_cap, void* part_out,
+                           size_t part_cap, size_t* keys_bytes, size_t* part_bytes);
 void plslam_match_plan_destroy(plslam_match_plan* plan);
 
 /* ---- K14: StVO::matchGrid, the windowed ("fast_matching") matcher ------------------------------ */

@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "plslam_ctx_device_info",
     "plslam_knn2_hamming256", "plslam_match", "plslam_match_batched",
     "plslam_match_plan_create", "plslam_match_plan_run", "plslam_match_plan_set_profiling",
-    "plslam_match_plan_elapsed", "plslam_match_plan_info", "plslam_match_plan_destroy",
+    "plslam_match_plan_elapsed", "plslam_match_plan_info", "plslam_match_plan_dump", "plslam_match_plan_destroy",
     "plslam_lba_point_rows", "plslam_lba_line_rows", "plslam_lba_point_rows_dev",
     "plslam_lba_line_rows_dev", "plslam_lba_assemble", "plslam_lba_plan_create", "plslam_lba_plan_iterate",
     "plslam_lba_plan_rows", "plslam_lba_plan_destroy",
@@ -152,6 +152,8 @@ def load() -> C.CDLL:
     L.plslam_match_plan_set_profiling.argtypes = [vp, C.c_int]
     L.plslam_match_plan_elapsed.argtypes = [vp, C.POINTER(f64), C.POINTER(f64), C.POINTER(C.c_int64)]
     L.plslam_match_plan_info.argtypes = [vp, C.POINTER(PlanInfo)]
+    L.plslam_match_plan_dump.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t),
+                                         C.POINTER(C.c_size_t)]
     L.plslam_match_plan_destroy.argtypes = [vp]
     L.plslam_match_plan_destroy.restype = None
     L.plslam_lba_point_rows.argtypes = [vp, C.POINTER(Cam), f64, vp, i32, vp, i32, vp, vp, vp, i32,
@@ -660,6 +662,17 @@ class MatchPlan:
         i = PlanInfo()
         _check(self._L.plslam_match_plan_info(self._h, C.byref(i)), "plslam_match_plan_info")
         return {k: getattr(i, k) for k, _ in PlanInfo._fields_}
+
+    def dump(self):
+        """Diagnostics: (keys, column_partials) as uint32 arrays, after a device synchronise."""
+        kb, pb = C.c_size_t(), C.c_size_t()
+        _check(self._L.plslam_match_plan_dump(self._h, None, 0, None, 0, C.byref(kb), C.byref(pb)),
+               "plslam_match_plan_dump")
+        k = np.empty(kb.value // 4, np.uint32)
+        p = np.empty(pb.value // 4, np.uint32)
+        _check(self._L.plslam_match_plan_dump(self._h, k.ctypes.data, k.nbytes, p.ctypes.data, p.nbytes,
+                                              C.byref(kb), C.byref(pb)), "plslam_match_plan_dump")
+        return k, p
 
     def close(self):
         if getattr(self, "_h", None):

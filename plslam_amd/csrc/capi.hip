@@ -633,6 +633,20 @@ int plslam_match_plan_info(plslam_match_plan* plan, plslam_plan_info* info)
     return PLSLAM_OK;
 }
 
+// diagnostics: raw copies of a plan's key table and the symmetric scan's column partials (see the header)
+int plslam_match_plan_dump(plslam_match_plan* plan, void* keys_out, size_t keys_cap, void* part_out, size_t part_cap,
+                           size_t* keys_bytes, size_t* part_bytes)
+{
+    if (!plan || !keys_bytes || !part_bytes) return PLSLAM_EINVAL;
+    DeviceGuard g(plan->ctx->device);
+    (void)hipDeviceSynchronize();
+    *keys_bytes = plan->keys.cap;
+    *part_bytes = plan->partials.cap;
+    if (keys_out && keys_cap >= plan->keys.cap && plan->keys.p) (void)hipMemcpy(keys_out, plan->keys.p, plan->keys.cap, hipMemcpyDeviceToHost);
+    if (part_out && part_cap >= plan->partials.cap && plan->partials.p) (void)hipMemcpy(part_out, plan->partials.p, plan->partials.cap, hipMemcpyDeviceToHost);
+    return PLSLAM_OK;
+}
+
 void plslam_match_plan_destroy(plslam_match_plan* plan)
 {
     if (!plan) return;

@@ -104,9 +104,15 @@ __device__ __forceinline__ void pk_push2(uint32_t& b0, uint32_t& b1, uint32_t ke
 // accumulators of the two M-tiles (2^23 + 128 d + tag, tag <= 127) side by side: hi.lo16 << 16 | lo.lo16
 __device__ __forceinline__ uint32_t pack_acc(float lo, float hi, uint32_t sel_uniform /* 0x05040100 */)
 {
-    uint32_t r;     // low 16 bits of each float's bit pattern (= its integer part, see ACC_MAGIC)
-    asm("v_perm_b32 %0, %1, %2, %3" : "=v"(r) : "v"(hi), "v"(lo), "s"(sel_uniform));
-    return r;
+    // The BUILTIN, not inline asm: this is the one instruction that reads MFMA results directly, and on gfx950 the
+    // wait states between an MFMA and a VALU access to its destination registers are the COMPILER's job (s_nop); its
+    // hazard recognizer does not look inside asm statements.  As `asm("v_perm_b32 ...")` the first two packs of the
+    // unpipelined epilogue issued right behind the last MFMA of the set: accumulators 0 and 1 (tile rows 0, 1, 4, 5)
+    // were read -- and register 0 overwritten -- while still in flight.  Right most of the time, wrong when waves of
+    // co-resident workgroups delayed the matrix pipe: ~1 % of the intermediate keys of a loaded batch differed from
+    // run to run, 1e-6 of the table entries at a 0.9 ratio ("K1e determinism";
+    // tools/determinism_check.py is the instrument).  The v_pk_min/max asm below only ever sees pack_acc's result.
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), sel_uniform);
 }
 // 16-bit keys are (d << 7) | tag7: the A bytes are -64 s(a), so with C = 16384 + tag the accumulator
 // itself is 128 d + tag (<= (256 << 7) + 127 = 0x807F); anything above is "none"
@@ -139,7 +145,10 @@ __device__ __forceinline__ int xcd_remap_(int orig, int nwg) { return (orig & 7)
 #define PLSLAM_MF_SINGLE_SET 0
 #endif
 template <bool MULTI, bool DIRECTED>
-__global__ void __launch_bounds__(256, PLSLAM_MF_SINGLE_SET ? 4 : 3)      // 3 waves per SIMD: <= 168 unified VGPRs
+#ifndef PLSLAM_MF_WAVES
+#define PLSLAM_MF_WAVES 3
+#endif
+__global__ void __launch_bounds__(256, PLSLAM_MF_SINGLE_SET ? 4 : PLSLAM_MF_WAVES)      // 3 waves per SIMD: <= 168 unified VGPRs
 k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
                 int32_t* __restrict__ zero, int nzero)
 {
@@ -357,6 +366,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         f32x16 A0, A1;
         for (int t = WT0; t < WT1; ++t) {
             step(t, A0, A1, A0, A1, false, steady_tag);
+            __syncthreads();                       // the flush of tile t-2 (same colbuf parity as tile t) is done
             if (t == WT1 - 1 && last_partial) epilogue(t, A0, A1, std::true_type{}); else epilogue(t, A0, A1, steady_tag);
         }
         return;
@@ -368,10 +378,17 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
             step(t, B0, B1, A0, A1, true, steady_tag);
             step(t + 1, A0, A1, B0, B1, true, steady_tag);
         }
+        // The trailing epilogue E(WT1-1) writes colbuf[(WT1-1) & 1] -- the buffer the flush of tile WT1-3 READS at the
+        // start of the last step (one wave, right behind that step's barrier).  In the steady state a barrier lies between
+        // a tile's flush and the next write of its buffer; here it must be added, or a wave that races through its last
+        // step can overwrite its slot before a delayed flusher (e.g. an instruction-cache miss in the rarely executed
+        // flush path) has read it: rare wrong column partials (seen as 1 in ~10^6 table entries under load).
         if (t < WT1) {                             // t == WT1 - 1: one more tile, into set B
             step(t, B0, B1, A0, A1, true, steady_tag);
+            __syncthreads();
             if (last_partial) epilogue(t, B0, B1, std::true_type{}); else epilogue(t, B0, B1, steady_tag);
         } else {                                   // tile WT1 - 1 is in set A
+            __syncthreads();
             if (last_partial) epilogue(t - 1, A0, A1, std::true_type{}); else epilogue(t - 1, A0, A1, steady_tag);
         }
 #endif
