@@ -164,8 +164,9 @@ def native_lib() -> C.CDLL:
 
 
 def ref_lib():
-    """oracle/_ref/libplslam_ref.so: the reference's OWN popcount code compiled from
-    /root/reference (bitops_custom.hpp:83-96, FORB.cpp:78-101).  None if never built."""
+    """oracle/_ref/libplslam_ref.so: the reference's OWN code compiled from /root/reference where it lies --
+    the popcounts (bitops_custom.hpp:83-96, FORB.cpp:78-101) and the exact multi-index-hashing kNN search
+    BinaryDescriptorMatcher::knnMatch (binary_descriptor_matcher.cpp:258-335).  None if never built."""
     global _REF
     if _REF is None:
         p = os.path.join(_HERE, "_ref", "libplslam_ref.so")
@@ -179,8 +180,26 @@ def ref_lib():
         r.ref_ld_match.restype = C.c_int
         r.ref_forb_distance.argtypes = [C.c_void_p, C.c_void_p]
         r.ref_forb_distance.restype = C.c_int
+        if hasattr(r, "ref_mih_knn"):        # a prebuilt library from before the MIH wrapper lacks it
+            r.ref_mih_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+            r.ref_mih_knn.restype = C.c_int
         _REF = r
     return _REF
+
+
+def ref_mih_knn(q, t, k):
+    """The reference's in-tree exact kNN (see ref_lib): (idx, dist) of shape (nq, k), or None if unavailable."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_mih_knn"):
+        return None
+    q = np.ascontiguousarray(q, np.uint8)
+    t = np.ascontiguousarray(t, np.uint8)
+    idx = np.empty((len(q), k), np.int32)
+    dist = np.empty((len(q), k), np.int32)
+    rc = r.ref_mih_knn(q.ctypes.data, len(q), t.ctypes.data, len(t), k, idx.ctypes.data, dist.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"ref_mih_knn rc={rc}")
+    return idx, dist
 
 
 def _c(a, dt):

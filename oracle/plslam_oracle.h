@@ -10,7 +10,13 @@
  *   - Hamming-256 distance: PINNED against the reference's own in-tree code
  *     (3rdparty/line_descriptor/src/bitops_custom.hpp:83-96 compiled from where it
  *     lies into oracle/_ref/, and the SWAR form of 3rdparty/DBoW2/src/DBoW2/FORB.cpp:78-101).
- *   - kNN-2 order, ratio test, mutual check: the arithmetic lives in OpenCV 3.x
+ *   - The two nearest DISTANCES of every query: PINNED against the only kNN code that exists in the
+ *     reference tree, the exact multi-index-hashing search BinaryDescriptorMatcher::knnMatch
+ *     (3rdparty/line_descriptor/src/binary_descriptor_matcher.cpp:258-335, compiled from where it lies
+ *     into oracle/_ref/ against the cv:: stand-in oracle/ref_shim/; outputs committed as
+ *     tests/golden/ref_knn_golden.npz).  Its choice among equally distant rows is not repeatable
+ *     between runs, so indices are compared only where distance alone decides.
+ *   - kNN-2 TIE order, ratio test, mutual check: the arithmetic lives in OpenCV 3.x
  *     features2d (cv::BFMatcher::knnMatch) and in the un-vendored stvo-pl
  *     (matching.cpp: match()/matchNNR()) -- neither is under /root/reference, neither
  *     has a pinned version, and the reference holds no tests/golden vectors for it.

@@ -410,3 +410,69 @@ def test_batched_tables_equal_oracle_at_loose_ratio(ctx, oracle):
         for name in sl:
             assert np.array_equal(got[:, sl[name]], exp[:, sl[name]]), name
     bm.close()
+
+
+def test_one_context_shared_by_three_threads(ctx, oracle):
+    """The reference calls match() from the VO thread, the local-mapping thread and the loop-closure thread
+    (src/mapHandler.cpp:1103, :1164 -> :3223; app/plslam_dataset.cpp:127) with no shared matcher state.
+    Here all three share ONE context: the host-pointer entry points serialise on its mutex (ctypes drops the GIL
+    for the call), every result must still be the oracle's."""
+    import threading
+    from test_match_grid_cpu import point_case
+    r = _rng(4242)
+    jobs = []
+    for k in range(6):
+        q, t = synth.random_desc(r, 200 + 61 * k), synth.random_desc(r, 180 + 47 * k)
+        jobs.append((q, t, oracle.match(q, t, 0.9, True), oracle.knn2(q, t)))
+    grid_case = point_case(11, 600, 640, 64, 48)
+    grid_ref = oracle.match_grid(window=(3, 3, 3, 3), nnr=0.8, mutual=True, **grid_case)
+    errors = []
+
+    def matcher(tid):
+        try:
+            for rep in range(5):
+                for q, t, (em, en), _ in jobs[tid::2]:
+                    m, n = ctx.match(q, t, 0.9, True)
+                    assert np.array_equal(m, em) and n == en
+        except Exception as e:                                        # noqa: BLE001 -- reported below
+            errors.append(("match", tid, repr(e)))
+
+    def scanner():
+        try:
+            for rep in range(5):
+                for q, t, _, (ei, ed) in jobs:
+                    i, d = ctx.knn2(q, t)
+                    assert np.array_equal(i, ei) and np.array_equal(d, ed)
+        except Exception as e:                                        # noqa: BLE001
+            errors.append(("knn2", repr(e)))
+
+    def windowed():
+        try:
+            for rep in range(10):
+                m, n = ctx.match_grid(window=(3, 3, 3, 3), nnr=0.8, mutual=True, **grid_case)
+                assert np.array_equal(m, grid_ref[0]) and n == grid_ref[1]
+        except Exception as e:                                        # noqa: BLE001
+            errors.append(("grid", repr(e)))
+
+    th = [threading.Thread(target=matcher, args=(0,)), threading.Thread(target=matcher, args=(1,)),
+          threading.Thread(target=scanner), threading.Thread(target=windowed)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errors, errors
+
+
+def test_knn2_against_the_reference_kNN_outputs(ctx):
+    """tests/golden/ref_knn_golden.npz holds outputs of the reference's own exact kNN search
+    (BinaryDescriptorMatcher::knnMatch, binary_descriptor_matcher.cpp:258-335; generated by
+    tests/golden/make_ref_knn_golden.py): the device's two nearest distances must equal them for every query, the
+    indices wherever distance alone decides."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_knn_golden.npz"))
+    for name in g["names"]:
+        q, t = g[f"{name}/q"], g[f"{name}/t"]
+        idx, dist = ctx.knn2(q, t)
+        assert np.array_equal(dist, g[f"{name}/k2_dist"]), name
+        u = np.all(g[f"{name}/k2_idx"] >= 0, axis=1)      # queries whose three nearest distances are distinct
+        assert u.sum() > 0 or name == "ties"
+        assert np.array_equal(idx[u], g[f"{name}/k2_idx"][u]), name
