@@ -180,11 +180,54 @@ def ref_lib():
         r.ref_ld_match.restype = C.c_int
         r.ref_forb_distance.argtypes = [C.c_void_p, C.c_void_p]
         r.ref_forb_distance.restype = C.c_int
+        if hasattr(r, "ref_lbd_compute"):
+            r.ref_lbd_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+            r.ref_lbd_compute.restype = C.c_int
+            r.ref_lbd_gauss_tables.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+            r.ref_lbd_gauss_tables.restype = C.c_int
+            r.ref_lbd_binary_conversion.argtypes = [C.c_void_p, C.c_void_p]
+            r.ref_lbd_binary_conversion.restype = C.c_int
         if hasattr(r, "ref_mih_knn"):        # a prebuilt library from before the MIH wrapper lacks it
             r.ref_mih_knn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
             r.ref_mih_knn.restype = C.c_int
         _REF = r
     return _REF
+
+
+def ref_lbd_compute(dx_img, dy_img, lines, width_of_band=7):
+    """The reference's OWN BinaryDescriptor::computeLBD (binary_descriptor_custom.cpp:1026-1372, compiled from where
+    it lies into oracle/_ref) on the given gradient images; same arguments as lbd_compute.  None if unavailable."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_lbd_compute"):
+        return None
+    dx, dy = _c(dx_img, np.int16), _c(dy_img, np.int16)
+    ln = np.ascontiguousarray(lines, dtype=LBD_LINE_DTYPE)
+    out = np.empty((ln.shape[0], 72), np.float32)
+    rc = r.ref_lbd_compute(dx.ctypes.data, dy.ctypes.data, dx.shape[1], dx.shape[0], ln.ctypes.data, ln.shape[0],
+                           int(width_of_band), out.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"ref_lbd_compute rc={rc}")
+    return out
+
+
+def ref_lbd_gauss_tables(width_of_band=7):
+    """gaussCoefL_ / gaussCoefG_ as the reference's BinaryDescriptor constructor builds them (:217-259)."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_lbd_compute"):
+        return None
+    cl, cg = np.empty(3 * width_of_band), np.empty(9 * width_of_band)
+    if r.ref_lbd_gauss_tables(int(width_of_band), cl.ctypes.data, cg.ctypes.data) != 0:
+        raise RuntimeError("ref_lbd_gauss_tables")
+    return cl, cg
+
+
+def ref_lbd_binary_conversion(f1, f2):
+    """The reference's BinaryDescriptor::binaryConversion (:401-412) on two 8-float groups."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_lbd_compute"):
+        return None
+    a, b = _c(f1, np.float32), _c(f2, np.float32)
+    return int(r.ref_lbd_binary_conversion(a.ctypes.data, b.ctypes.data))
 
 
 def ref_mih_knn(q, t, k):

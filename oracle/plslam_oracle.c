@@ -1188,8 +1188,13 @@ void plo_lbd_compute(const int16_t* pdxImg, const int16_t* pdyImg, int32_t width
         const float lineMiddlePointX = (float)(0.5 * (L->sx + L->ex));
         const float lineMiddlePointY = (float)(0.5 * (L->sy + L->ey));
         float dL[2], dO[2];
-        dL[0] = (float)cos((double)L->direction);
-        dL[1] = (float)sin((double)L->direction);
+        /* `dL[0] = cos( pSingleLine->direction )` with a float argument: under libstdc++'s <math.h> (GCC >= 6;
+         * bitarray_custom.hpp:52 includes it) the unqualified call binds to the float overload = cosf, which is what
+         * the reference compiled in this image does (oracle/_ref, test_lbd_compute_pinned_to_reference_code).  A
+         * toolchain whose <math.h> is the plain C header evaluates in double and rounds: ~2 % of directions then
+         * differ by one ulp, ~2e-7 in the descriptor. */
+        dL[0] = cosf(L->direction);
+        dL[1] = sinf(L->direction);
         dO[0] = -dL[1];
         dO[1] = dL[0];
         float sCorX0 = -dL[0] * halfWidth + dL[1] * halfHeight + lineMiddlePointX;

@@ -284,6 +284,9 @@ void plo_normalize2(double v[2]);
  * own band and its two neighbours (:1201-1239), mean / std per band (:1253-1277), the two-part normalisation
  * (:1279-1312), the 0.4 clamp (:1318-1325) and the re-normalisation (:1327-1338).  Weight tables as the constructor
  * builds them (:146-176, integer divisions included).
+ * PINNED: oracle/_ref holds the reference's own computeLBD / constructor / binaryConversion compiled from where the
+ * file lies (oracle/ref_wrap_lbd.cpp); tests/test_oracle_pin.py::test_lbd_compute_pinned_to_reference_code requires
+ * every output bit to agree (cos / sin of the direction are the FLOAT overloads, as the reference binds them).
  *   dx, dy      gradient images of ONE octave, int16, `width` x `height`, row stride = width (dxImg_vector[octave])
  *   lines       n x plo_lbd_line: the OctaveSingleLine fields computeLBD reads
  *   lbd         n x 72 float32 (the `descriptor` vector of each line) */

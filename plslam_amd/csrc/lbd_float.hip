@@ -205,8 +205,9 @@ void lbd_lines_dev(const plslam_lbd_line* lines, int32_t n, LbdLineDev* out)
     for (int32_t i = 0; i < n; ++i) {
         out[i].num_pixels = lines[i].num_pixels;
         out[i].sx = lines[i].sx; out[i].sy = lines[i].sy; out[i].ex = lines[i].ex; out[i].ey = lines[i].ey;
-        out[i].dl0 = (float)std::cos((double)lines[i].direction);     // dL[0] = cos(direction), :1117-1118
-        out[i].dl1 = (float)std::sin((double)lines[i].direction);
+        // dL[0] = cos(direction), :1117-1118 -- the FLOAT overload (cosf), as the reference binds it under libstdc++
+        out[i].dl0 = std::cos(lines[i].direction);
+        out[i].dl1 = std::sin(lines[i].direction);
         out[i].pad = 0.f;
     }
 }

@@ -1,8 +1,10 @@
 """Generates tests/golden/lbd_float_golden.npz and pose_gn_golden.npz (run from the repo root:
-python tests/golden/make_k17_k18_golden.py).  Outputs come from the C oracle's literal restatements of
-BinaryDescriptor::computeLBD (binary_descriptor_custom.cpp:1026-1372) and of the computeRelativePoseGN iteration body
-(src/mapHandler.cpp:3324-3424); the LBD case is additionally checked here against the independent float64 numpy
-derivation of tests/test_lbd_float.py before it is written."""
+python tests/golden/make_k17_k18_golden.py, in the build container: needs oracle/_ref built from /root/reference).
+The LBD vectors are OUTPUTS OF THE REFERENCE ITSELF: BinaryDescriptor::computeLBD (binary_descriptor_custom.cpp:1026-1372)
+compiled from where it lies (oracle/ref_wrap_lbd.cpp) and run on the seeded gradient images; the script refuses to
+write them unless the C oracle reproduces them bit for bit and the independent float64 numpy derivation of
+tests/test_lbd_float.py agrees to 2e-5.  The pose-GN vectors come from the C oracle's literal restatement of the
+computeRelativePoseGN iteration body (src/mapHandler.cpp:3324-3424; not compilable here: Eigen / stvo-pl)."""
 import os
 import sys
 
@@ -23,7 +25,10 @@ def main():
     r = np.random.Generator(np.random.PCG64(77))
     dx, dy = synth.gradient_images(r, 128, 96)
     lines = synth.lbd_lines(r, 24, 128, 96, min_len=8, max_len=70, dtype=O.LBD_LINE_DTYPE)
-    out = O.lbd_compute(dx, dy, lines)
+    out = O.ref_lbd_compute(dx, dy, lines)
+    if out is None:
+        raise SystemExit("oracle/_ref lacks ref_lbd_compute: run `make -C oracle ref` with /root/reference present")
+    assert np.array_equal(out.view(np.uint32), O.lbd_compute(dx, dy, lines).view(np.uint32)), "oracle != reference"
     inner = (np.minimum(lines["sx"], lines["ex"]) > 35) & (np.maximum(lines["sx"], lines["ex"]) < 93) & \
             (np.minimum(lines["sy"], lines["ey"]) > 35) & (np.maximum(lines["sy"], lines["ey"]) < 61)
     for i in np.nonzero(inner)[0]:

@@ -555,3 +555,39 @@ def test_lbd_golden_matches_oracle():
     g = np.load(LBD_GOLD)
     np.testing.assert_array_equal(O.lbd_binarise(g["lbd_f32"]), g["desc_u8"])
     np.testing.assert_array_equal(O.np_lbd_binarise(g["lbd_f32"]), g["desc_u8"])
+
+
+# ---------------------------------------------------------------- LBD pinned to reference code ----
+@pytest.mark.parametrize("width,height,n,wob,seed", [(320, 240, 300, 7, 0), (752, 480, 400, 7, 1), (200, 100, 200, 5, 2),
+                                                     (640, 480, 200, 9, 3)])
+def test_lbd_compute_pinned_to_reference_code(width, height, n, wob, seed):
+    """oracle/_ref holds the reference's own BinaryDescriptor::computeLBD (binary_descriptor_custom.cpp:1026-1372,
+    compiled from where it lies; oracle/ref_wrap_lbd.cpp hands it the gradient images computeSobel would have left in
+    dxImg_vector / dyImg_vector).  The oracle's restatement must reproduce its 72 floats per line BIT FOR BIT --
+    segments reaching past the image border (clamping) and three band widths included."""
+    r = _rng(7000 + seed)
+    dx, dy = synth.gradient_images(r, width, height)
+    lines = synth.lbd_lines(r, n, width, height, dtype=O.LBD_LINE_DTYPE)
+    ref = O.ref_lbd_compute(dx, dy, lines, wob)
+    if ref is None:
+        pytest.skip("oracle/_ref not built with the LBD wrapper (needs /root/reference at build time)")
+    got = O.lbd_compute(dx, dy, lines, wob)
+    assert not np.isnan(ref).any()
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    # and the 32-byte binary rows built from them (computeImpl :653-668) follow
+    assert np.array_equal(O.lbd_binarise(got), O.lbd_binarise(ref))
+
+
+def test_lbd_tables_and_binary_conversion_pinned_to_reference_code():
+    """The constructor's Gaussian weight tables (:217-259) and binaryConversion (:401-412) of the compiled reference."""
+    if O.ref_lbd_gauss_tables(7) is None:
+        pytest.skip("oracle/_ref not built with the LBD wrapper (needs /root/reference at build time)")
+    for wob in (3, 5, 7, 9, 12):
+        cl, cg = O.lbd_gauss_tables(wob)
+        rl, rg = O.ref_lbd_gauss_tables(wob)
+        assert np.array_equal(cl, rl) and np.array_equal(cg, rg)
+    r = _rng(7100)
+    for _ in range(500):
+        f1 = r.integers(0, 4, 8).astype(np.float32)          # small integers: plenty of equal pairs (strict >)
+        f2 = r.integers(0, 4, 8).astype(np.float32)
+        assert int(O.lib().plo_lbd_binary_conversion(f1.ctypes.data, f2.ctypes.data)) == O.ref_lbd_binary_conversion(f1, f2)
