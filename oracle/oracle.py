@@ -180,6 +180,10 @@ def ref_lib():
         r.ref_ld_match.restype = C.c_int
         r.ref_forb_distance.argtypes = [C.c_void_p, C.c_void_p]
         r.ref_forb_distance.restype = C.c_int
+        if hasattr(r, "ref_median_desc_point"):
+            for f in (r.ref_median_desc_point, r.ref_median_desc_line):
+                f.argtypes = [C.c_void_p, C.c_int]
+                f.restype = C.c_int
         if hasattr(r, "ref_lbd_compute"):
             r.ref_lbd_compute.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
             r.ref_lbd_compute.restype = C.c_int
@@ -192,6 +196,18 @@ def ref_lib():
             r.ref_mih_knn.restype = C.c_int
         _REF = r
     return _REF
+
+
+def ref_median_desc(descs, kind="point"):
+    """The reference's OWN MapPoint / MapLine::updateAverageDescDir (src/mapFeatures.cpp:51-93 / :121-163, compiled
+    from where it lies into oracle/_ref): the landmark is built from observation 0 and the others are added one by one;
+    returns the index of the observation that ended up as med_desc.  None if unavailable."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_median_desc_point"):
+        return None
+    d = np.ascontiguousarray(descs, np.uint8).reshape(-1, 32)
+    f = r.ref_median_desc_point if kind == "point" else r.ref_median_desc_line
+    return int(f(d.ctypes.data, d.shape[0]))
 
 
 def ref_lbd_compute(dx_img, dy_img, lines, width_of_band=7):

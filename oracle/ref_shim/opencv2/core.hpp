@@ -153,6 +153,14 @@ class _InputArray { public: Mat getMat() const { PLSLAM_SHIM_NOT_IMPLEMENTED("In
 class _OutputArray {};
 enum { COLOR_BGR2GRAY = 6, THRESH_TOZERO = 3, CMP_LT = 3, NORM_HAMMING = 6 };
 using std::max;
+// The one OpenCV routine this stand-in IMPLEMENTS (src/mapFeatures.cpp:63,133 call it): the Hamming norm of two byte
+// rows = bit count of their XOR.  The distance itself is pinned separately against the reference's own popcount code.
+inline double norm(const Mat& a, const Mat& b, int type) {
+    if (type != NORM_HAMMING || a.rows * a.cols != b.rows * b.cols) PLSLAM_SHIM_NOT_IMPLEMENTED("norm (only NORM_HAMMING)");
+    int d = 0;
+    for (int i = 0; i < a.rows * a.cols; ++i) d += __builtin_popcount((unsigned)(a.ptr()[i] ^ b.ptr()[i]));
+    return d;
+}
 // image-processing entry points the reference's detector code mentions: declarations that let it compile; the tests
 // only ever run code that does not reach them
 inline void Sobel(const Mat&, Mat&, int, int, int, int) { PLSLAM_SHIM_NOT_IMPLEMENTED("Sobel"); }

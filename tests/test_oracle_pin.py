@@ -591,3 +591,23 @@ def test_lbd_tables_and_binary_conversion_pinned_to_reference_code():
         f1 = r.integers(0, 4, 8).astype(np.float32)          # small integers: plenty of equal pairs (strict >)
         f2 = r.integers(0, 4, 8).astype(np.float32)
         assert int(O.lib().plo_lbd_binary_conversion(f1.ctypes.data, f2.ctypes.data)) == O.ref_lbd_binary_conversion(f1, f2)
+
+
+# ---------------------------------------------------------------- median descriptor pinned to reference code ----
+def test_median_descriptor_pinned_to_reference_code():
+    """oracle/_ref holds the reference's own MapPoint / MapLine::updateAverageDescDir (src/mapFeatures.cpp:51-93,
+    :121-163; mapFeatures.cpp compiled from where it lies against cv:: / Eigen stand-ins).  The landmark is built the
+    way the map builds it -- first observation through the constructor, the rest through add*Observation -- and the
+    observation that ends up as med_desc must be the one the oracle (and the kernel, test_gpu_median_desc.py) names:
+    1 .. 13 observations, tie-heavy rows, duplicated observations (first minimum wins)."""
+    if O.ref_median_desc(np.zeros((1, 32), np.uint8)) is None:
+        pytest.skip("oracle/_ref not built with the mapFeatures wrapper (needs /root/reference at build time)")
+    for seed in range(400):
+        r = _rng(8000 + seed)
+        n = int(r.integers(1, 14))
+        d = synth.tie_stress_desc(r, n) if seed % 3 == 0 else synth.random_desc(r, n)
+        if seed % 5 == 0 and n > 2:
+            d[int(r.integers(1, n))] = d[0]
+        exp = O.median_desc(d)
+        assert O.ref_median_desc(d, "point") == exp, (seed, n)
+        assert O.ref_median_desc(d, "line") == exp, (seed, n)
