@@ -326,7 +326,13 @@ int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, int32_t nls,
  * the Vector6i columns lm_loc (1) / kf_loc (4), the pose slot of each observation, the observations
  * themselves -- once; iterate() uploads poses (n_pose_slots*16, e.g. expmap_se3 of X, :1600-1603) and
  * landmarks (X.block(6Nkf..), :1597, :1678), runs K3/K4 and K7-K10 on the device and returns the
- * block-form normal equations (layout as plslam_lba_assemble). */
+ * block-form normal equations (layout as plslam_lba_assemble).
+ * Pose slots are per observation and separate for points and lines on purpose: in the iteration pass the reference
+ * gives an optimised key frame's POINT observations the current estimate expmap_se3(X.block(6*kf_loc..)) (:1600-1601)
+ * but its LINE observations the stored map_keyframes[kf]->T_kf_w (:1680) -- a caller that wants the reference's
+ * numbers keeps one slot per key frame with the stored pose for ls_pose_slot and a second set with the current
+ * estimates for pt_pose_slot, and passes compat_iter_pass = 1 (stride-3 end points :1677-1678, literal 1e-7 :1698).
+ * All three quirks are checked against the reference's own source text (oracle/ref_wrap_lba.cpp). */
 typedef struct plslam_lba_plan plslam_lba_plan;
 int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, double homog_th, int32_t n_pose_slots,
                            int32_t nkf, int32_t npt, int32_t nls, const int32_t* pt_lm_loc,

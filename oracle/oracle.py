@@ -180,6 +180,11 @@ def ref_lib():
         r.ref_ld_match.restype = C.c_int
         r.ref_forb_distance.argtypes = [C.c_void_p, C.c_void_p]
         r.ref_forb_distance.restype = C.c_int
+        if hasattr(r, "ref_lba_accumulate"):
+            r.ref_lba_accumulate.argtypes = [C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                             C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_void_p] * 4 + [C.c_int] + \
+                [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3
+            r.ref_lba_accumulate.restype = C.c_int
         if hasattr(r, "ref_median_desc_point"):
             for f in (r.ref_median_desc_point, r.ref_median_desc_line):
                 f.argtypes = [C.c_void_p, C.c_int]
@@ -196,6 +201,34 @@ def ref_lib():
             r.ref_mih_knn.restype = C.c_int
         _REF = r
     return _REF
+
+
+def ref_lba_accumulate(iter_pass, cam, homog_th, nkf, T_map, T_slot, Xw, Lw, pt_lm, pt_kf_map, pt_kf_loc, pt_uv,
+                       ls_lm, ls_kf_map, ls_kf_loc, ls_l):
+    """The reference's OWN local-BA observation loops (src/mapHandler.cpp:1358-1431 + :1436-1540, or with iter_pass the
+    iteration-pass loops :1587-1666 + :1668-1772), compiled textually from where they lie (oracle/ref_wrap_lba.cpp)
+    -> (H, g, err) as they stand after both loops.  Landmark map index == local index; T_map: poses by key-frame map
+    index; T_slot: poses of the nkf optimised slots (what expmap_se3 of X's pose blocks gives in the iteration pass).
+    None if unavailable."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_lba_accumulate"):
+        return None
+    T_map = _c(T_map, np.float64).reshape(-1, 16)
+    T_slot = _c(T_slot, np.float64).reshape(-1, 16)
+    Xw, Lw = _c(Xw, np.float64).reshape(-1, 3), _c(Lw, np.float64).reshape(-1, 6)
+    npt, nls = Xw.shape[0], Lw.shape[0]
+    N = 6 * nkf + 3 * npt + 6 * nls
+    H, g, err = np.zeros((N, N)), np.zeros(N), np.zeros(1)
+    a = [_c(x, np.int32) for x in (pt_lm, pt_kf_map, pt_kf_loc)] + [_c(pt_uv, np.float64)]
+    b = [_c(x, np.int32) for x in (ls_lm, ls_kf_map, ls_kf_loc)] + [_c(ls_l, np.float64)]
+    c4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy])
+    rc = r.ref_lba_accumulate(int(bool(iter_pass)), c4.ctypes.data, float(homog_th), nkf, npt, nls, T_map.ctypes.data,
+                              T_map.shape[0], T_slot.ctypes.data, Xw.ctypes.data, Lw.ctypes.data,
+                              *[x.ctypes.data for x in a], a[0].shape[0], *[x.ctypes.data for x in b], b[0].shape[0],
+                              H.ctypes.data, g.ctypes.data, err.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"ref_lba_accumulate rc={rc}")
+    return H, g, float(err[0])
 
 
 def ref_median_desc(descs, kind="point"):

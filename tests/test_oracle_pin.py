@@ -611,3 +611,53 @@ def test_median_descriptor_pinned_to_reference_code():
         exp = O.median_desc(d)
         assert O.ref_median_desc(d, "point") == exp, (seed, n)
         assert O.ref_median_desc(d, "line") == exp, (seed, n)
+
+
+# ---------------------------------------------------------------- LBA rows + accumulation pinned to the source text ----
+def _lba_oracle_Hg(cam, th, nkf, npt, nls, T, lm, kf_slot_p, kf_slot_l, kf_loc_p, kf_loc_l, compat):
+    rows_p = O.lba_point_rows(cam, th, T, lm["Xw"], lm["obs_uv"], lm["pt_lm"], kf_slot_p)
+    rows_l = O.lba_line_rows(cam, th, T, lm["Lw"], lm["l_obs"], lm["ls_lm"], kf_slot_l, compat_iter_pass=compat)
+    H, g, e1 = O.lba_accumulate("points", nkf, npt, nls, lm["pt_lm"], kf_loc_p, *rows_p)
+    H, g, e2 = O.lba_accumulate("lines", nkf, npt, nls, lm["ls_lm"], kf_loc_l, *rows_l, H=H, g=g)
+    return H, g, e1 + e2
+
+
+@pytest.mark.parametrize("th", [1e-7, 0.3, 30.0])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_lba_rows_and_accumulation_pinned_to_reference_source_text(seed, th):
+    """oracle/_ref compiles the reference's four local-BA observation loops TEXTUALLY (cut out of
+    src/mapHandler.cpp:1358-1431, :1436-1540, :1587-1666, :1668-1772 where the file lies; Eigen spellings served by the
+    plain-loop stand-in oracle/ref_shim/mini_dense.hpp, the un-vendored stvo-pl helpers restated).  H, g and err after
+    the reference's loops must equal the oracle's rows + accumulation: first pass, and the iteration pass with its
+    quirks (line end points both read at stride 3, the literal 1e-7, lines keep the un-updated key-frame pose while
+    points take expmap(X)).  th = 0.3 puts some residual norms, th = 30 some depths (z^2) below the threshold: both std::max(homogTh, .) branches.  Tolerance 1e-11
+    relative: the stand-in is not Eigen, rounding of the 3-term sums may differ in the last bit."""
+    n_kf, npt, nls = 5, 40, 14
+    lm = synth.local_map(n_kf=n_kf, n_pt=npt, n_ls=nls, obs_per_lm=3, seed=70 + seed, noise_px=2.0)
+    cam = O.make_cam(**synth.EUROC)
+    nkf = n_kf - 1                                 # KF 0 is not optimised
+    kf_loc_p, kf_loc_l = lm["pt_kf"] - 1, lm["ls_kf"] - 1
+    T_map = np.asarray(lm["T_kf_w"]).reshape(n_kf, 16)
+    r = _rng(500 + seed)
+    T_slot = np.stack([(synth.se3_exp(r.normal(0, 0.02, 6)) @ T_map[k + 1].reshape(4, 4)).reshape(16) for k in range(nkf)])
+    first = O.ref_lba_accumulate(False, cam, th, nkf, T_map, T_slot, lm["Xw"], lm["Lw"], lm["pt_lm"], lm["pt_kf"], kf_loc_p,
+                                 lm["obs_uv"], lm["ls_lm"], lm["ls_kf"], kf_loc_l, lm["l_obs"])
+    if first is None:
+        pytest.skip("oracle/_ref not built with the LBA harness (needs /root/reference at build time)")
+    H, g, e = _lba_oracle_Hg(cam, th, nkf, npt, nls, T_map, lm, lm["pt_kf"], lm["ls_kf"], kf_loc_p, kf_loc_l, False)
+    scale = np.abs(H).max()
+    assert scale > 0 and np.abs(g).max() > 0
+    np.testing.assert_allclose(first[0], H, rtol=1e-11, atol=1e-11 * scale)
+    np.testing.assert_allclose(first[1], g, rtol=1e-11, atol=1e-11 * np.abs(g).max())
+    assert np.isclose(first[2], e, rtol=1e-12)
+    # iteration pass: points at expmap(X) for optimised slots, lines at the stored pose and with the stride-3 read
+    it = O.ref_lba_accumulate(True, cam, th, nkf, T_map, T_slot, lm["Xw"], lm["Lw"], lm["pt_lm"], lm["pt_kf"], kf_loc_p,
+                              lm["obs_uv"], lm["ls_lm"], lm["ls_kf"], kf_loc_l, lm["l_obs"])
+    T_all = np.concatenate([T_map, T_slot])
+    slot_p = np.where(kf_loc_p >= 0, n_kf + kf_loc_p, lm["pt_kf"]).astype(np.int32)
+    H2, g2, e2 = _lba_oracle_Hg(cam, th, nkf, npt, nls, T_all, lm, slot_p, lm["ls_kf"], kf_loc_p, kf_loc_l, True)
+    scale2 = np.abs(H2).max()
+    np.testing.assert_allclose(it[0], H2, rtol=1e-11, atol=1e-11 * scale2)
+    np.testing.assert_allclose(it[1], g2, rtol=1e-11, atol=1e-11 * np.abs(g2).max())
+    assert np.isclose(it[2], e2, rtol=1e-12)
+    assert not np.allclose(it[0], first[0], rtol=1e-6, atol=1e-6 * scale)       # the two passes really differ
