@@ -185,6 +185,17 @@ def ref_lib():
                                              C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_void_p] * 4 + [C.c_int] + \
                 [C.c_void_p] * 4 + [C.c_int] + [C.c_void_p] * 3
             r.ref_lba_accumulate.restype = C.c_int
+        if hasattr(r, "ref_map_visible"):
+            r.ref_map_visible.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double,
+                                          C.c_void_p, C.c_void_p]
+            r.ref_map_visible.restype = C.c_int
+            r.ref_map2kf_gate.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                          C.c_double, C.c_int, C.c_void_p]
+            r.ref_map2kf_gate.restype = C.c_int
+        if hasattr(r, "ref_pose_gn_accumulate"):
+            r.ref_pose_gn_accumulate.argtypes = [C.c_int, C.c_void_p, C.c_double] + [C.c_void_p] * 4 + [C.c_int] + \
+                [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 4
+            r.ref_pose_gn_accumulate.restype = C.c_int
         if hasattr(r, "ref_median_desc_point"):
             for f in (r.ref_median_desc_point, r.ref_median_desc_line):
                 f.argtypes = [C.c_void_p, C.c_int]
@@ -229,6 +240,70 @@ def ref_lba_accumulate(iter_pass, cam, homog_th, nkf, T_map, T_slot, Xw, Lw, pt_
     if rc != 0:
         raise RuntimeError(f"ref_lba_accumulate rc={rc}")
     return H, g, float(err[0])
+
+
+def _cam6(cam):
+    return np.array([cam.fx, cam.fy, cam.cx, cam.cy, float(cam.width), float(cam.height)])
+
+
+def ref_map_visible(kind, cam, Twf, X, inv_w=1.0, inv_h=1.0):
+    """The reference's OWN visibility pre-filter loop of matchMap2KFPoints (src/mapHandler.cpp:545-558) / Lines
+    (:647-663), compiled textually -> (vis mask, normalised projections of the selected landmarks).  None if unavailable."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_map_visible"):
+        return None
+    lines = kind == "lines"
+    X = _c(X, np.float64).reshape(-1, 6 if lines else 3)
+    T = _c(Twf, np.float64).reshape(16)
+    vis = np.zeros(X.shape[0], np.uint8)
+    pj = np.zeros((X.shape[0], 4 if lines else 2))
+    c6 = _cam6(cam)
+    ns = r.ref_map_visible(int(lines), c6.ctypes.data, T.ctypes.data, X.ctypes.data, X.shape[0], float(inv_w), float(inv_h),
+                           vis.ctypes.data, pj.ctypes.data)
+    if ns < 0:
+        raise RuntimeError(f"ref_map_visible rc={ns}")
+    return vis, pj[:ns]
+
+
+def ref_map2kf_gate(kind, cam, Twf, X, m12, obs, max_epip):
+    """The reference's OWN gate loop of matchMap2KFPoints (src/mapHandler.cpp:601-629) / Lines (:716-749), compiled
+    textually -> (mask of the landmarks that received the observation, final `matches`).  None if unavailable."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_map2kf_gate"):
+        return None
+    lines = kind == "lines"
+    X = _c(X, np.float64).reshape(-1, 6 if lines else 3)
+    obs = _c(obs, np.float64).reshape(-1, 3 if lines else 2)
+    T = _c(Twf, np.float64).reshape(16)
+    m12 = _c(m12, np.int32)
+    mask = np.zeros(X.shape[0], np.uint8)
+    c6 = _cam6(cam)
+    n = r.ref_map2kf_gate(int(lines), c6.ctypes.data, T.ctypes.data, X.ctypes.data, m12.ctypes.data, X.shape[0],
+                          obs.ctypes.data, obs.shape[0], float(max_epip), int((m12 >= 0).sum()), mask.ctypes.data)
+    if n <= -1000000:
+        raise RuntimeError("ref_map2kf_gate failed")
+    return mask, int(n)
+
+
+def ref_pose_gn_accumulate(robust, cam, homog_th, T_inc, P, pl_obs, pt_inlier, sPeP, le_obs, ls_inlier):
+    """The reference's OWN pose-only Gauss-Newton loops (computeRelativePoseGN src/mapHandler.cpp:3331-3426, or with
+    `robust` the first pair of loops of computeRelativePoseRobustGN :3595-3689), compiled textually from where they
+    lie; same arguments and results as pose_gn_accumulate.  None if unavailable."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_pose_gn_accumulate"):
+        return None
+    T = _c(T_inc, np.float64).reshape(16)
+    P, po = _c(P, np.float64).reshape(-1, 3), _c(pl_obs, np.float64).reshape(-1, 2)
+    S, lo = _c(sPeP, np.float64).reshape(-1, 6), _c(le_obs, np.float64).reshape(-1, 3)
+    pi, li = _c(pt_inlier, np.uint8), _c(ls_inlier, np.uint8)
+    H, g, e, n = np.empty((6, 6)), np.empty(6), np.empty(1), np.empty(2, np.int32)
+    c4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy])
+    rc = r.ref_pose_gn_accumulate(int(bool(robust)), c4.ctypes.data, float(homog_th), T.ctypes.data, P.ctypes.data,
+                                  po.ctypes.data, pi.ctypes.data, P.shape[0], S.ctypes.data, lo.ctypes.data, li.ctypes.data,
+                                  S.shape[0], H.ctypes.data, g.ctypes.data, e.ctypes.data, n.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"ref_pose_gn_accumulate rc={rc}")
+    return H, g, float(e[0]), (int(n[0]), int(n[1]))
 
 
 def ref_median_desc(descs, kind="point"):

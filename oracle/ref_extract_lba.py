@@ -7,7 +7,13 @@ oracle/ref_wrap_lba.cpp can compile them textually against the dense-matrix stan
     lba_ls_first.inc   first pass,     line observations                                            (near :1436)
     lba_pt_iter.inc    iteration pass, point observations                                           (near :1587)
     lba_ls_iter.inc    iteration pass, line observations                                            (near :1668)
-The loops are found by their headers inside that function and closed by brace matching, not by line number.
+and the point / line loops of the pose-only Gauss-Newton iterations (K17's checker):
+    gn_pt.inc, gn_ls.inc           MapHandler::computeRelativePoseGN        (near :3330, :3370)
+    gnr_pt.inc, gnr_ls.inc         MapHandler::computeRelativePoseRobustGN  (first pair of loops, near :3594, :3634)
+and the visibility pre-filter / geometric gate loops of the map <-> key-frame matchers:
+    m2kf_pt_vis.inc, m2kf_pt_gate.inc   MapHandler::matchMap2KFPoints  (near :545, :602)
+    m2kf_ls_vis.inc, m2kf_ls_gate.inc   MapHandler::matchMap2KFLines   (near :646, :715)
+The loops are found by their headers inside those functions and closed by brace matching, not by line number.
 usage: ref_extract_lba.py <reference root> <output dir>
 """
 import os
@@ -44,6 +50,32 @@ def main(ref, out):
         for which, start in zip(("first", "iter"), found[key]):
             end = loop_at(src, start)
             name = "lba_%s_%s.inc" % (key, which)
+            with open(os.path.join(out, name), "w") as fh:
+                fh.write("// generated from src/mapHandler.cpp:%d-%d by oracle/ref_extract_lba.py -- not part of the repository\n"
+                         % (start + 1, end + 1))
+                fh.write("\n".join(src[start:end + 1]) + "\n")
+            print("[ref_extract_lba] %s = src/mapHandler.cpp:%d-%d" % (name, start + 1, end + 1))
+    for fn, nxt, tag, vis_hdr in (("MapHandler::matchMap2KFPoints", "MapHandler::matchMap2KFLines", "m2kf_pt", "for (MapPoint* pt : map_points)"),
+                                  ("MapHandler::matchMap2KFLines", "MapHandler::lookForCommonMatches", "m2kf_ls", "for (MapLine* ls : map_lines)")):
+        g0 = next(i for i, l in enumerate(src) if fn + "(" in l.replace(" ", ""))
+        g1 = next(i for i, l in enumerate(src) if i > g0 and nxt in l)
+        for key, hdr in (("vis", vis_hdr), ("gate", "for (int i1 = 0; i1 < matches_12.size(); ++i1)")):
+            start = next(i for i in range(g0, g1) if hdr in src[i])
+            end = loop_at(src, start)
+            name = "%s_%s.inc" % (tag, key)
+            with open(os.path.join(out, name), "w") as fh:
+                fh.write("// generated from src/mapHandler.cpp:%d-%d by oracle/ref_extract_lba.py -- not part of the repository\n"
+                         % (start + 1, end + 1))
+                fh.write("\n".join(src[start:end + 1]) + "\n")
+            print("[ref_extract_lba] %s = src/mapHandler.cpp:%d-%d" % (name, start + 1, end + 1))
+    for fn, nxt, tag in (("MapHandler::computeRelativePoseGN", "MapHandler::computeRelativePoseRobustGN", "gn"),
+                         ("MapHandler::computeRelativePoseRobustGN", "MapHandler::loopClosureOptimizationEssGraphG2O", "gnr")):
+        g0 = next(i for i, l in enumerate(src) if fn + "(" in l.replace(" ", ""))
+        g1 = next(i for i, l in enumerate(src) if i > g0 and nxt in l)
+        for key, hdr in (("pt", "vector<PointFeature*>::iterator pt_it"), ("ls", "vector<LineFeature*>::iterator ls_it")):
+            start = next(i for i in range(g0, g1) if hdr in src[i] and src[i].lstrip().startswith("for"))
+            end = loop_at(src, start)
+            name = "%s_%s.inc" % (tag, key)
             with open(os.path.join(out, name), "w") as fh:
                 fh.write("// generated from src/mapHandler.cpp:%d-%d by oracle/ref_extract_lba.py -- not part of the repository\n"
                          % (start + 1, end + 1))

@@ -1,6 +1,7 @@
 // oracle/ref_shim/mini_dense.hpp -- TEST INFRASTRUCTURE ONLY.
 // A from-scratch dense-matrix stand-in with the Eigen SPELLINGS that the local-BA row loops of
-// /root/reference/src/mapHandler.cpp use (:1358-1431, :1436-1540, :1587-1666, :1668-1772): fixed and dynamic double
+// /root/reference/src/mapHandler.cpp use (:1358-1431, :1436-1540, :1587-1666, :1668-1772; and the pose-only Gauss-Newton
+// loops :3330-3367, :3370-3412 and their twins in computeRelativePoseRobustGN): fixed and dynamic double
 // matrices, (i) / (i,j), block / head / tail as assignable views, transpose, norm, Zero, the comma initialiser,
 // + - * / with matrices and scalars.  It lets those loops be compiled TEXTUALLY from where they lie (oracle/
 // ref_extract_lba.py cuts them into oracle/_ref/*.inc at build time) so that the oracle's restatement of the row
@@ -21,11 +22,13 @@ struct Block {                       // assignable view
     Block& operator=(const Dyn& o);
     Block& operator+=(const Dyn& o);
     Block& operator=(const Block& o);
+    Block head(int n) const { Block b = {m, i0, j0, w == 1 ? n : 1, w == 1 ? 1 : n}; return b; }
 };
 struct Comma {
     Dyn* m;
     int k;
     Comma operator,(double x);
+    Comma operator,(const Dyn& x);
 };
 struct Dyn {
     int r, c;
@@ -45,6 +48,12 @@ struct Dyn {
         Block b = {this, i, j, h, w};
         return b;
     }
+    Block col(int j) { return block(0, j, r, 1); }
+    Dyn& operator+=(const Dyn& o) {
+        if (o.r != r || o.c != c) throw std::invalid_argument("mini::+= : shape");
+        for (size_t k = 0; k < v.size(); ++k) v[k] += o.v[k];
+        return *this;
+    }
     Block head(int n) { return c == 1 ? block(0, 0, n, 1) : block(0, 0, 1, n); }
     Block tail(int n) { return c == 1 ? block(r - n, 0, n, 1) : block(0, c - n, 1, n); }
     Dyn transpose() const {
@@ -59,7 +68,14 @@ struct Dyn {
         return std::sqrt(s);
     }
     Comma operator<<(double x) { v.at(0) = x; Comma cm = {this, 1}; return cm; }
+    Comma operator<<(const Dyn& x) { Comma cm = {this, 0}; return (cm, x); }
+    Dyn normalized() const { Dyn o = *this; const double n = norm(); for (size_t k = 0; k < o.v.size(); ++k) o.v[k] = v[k] / n; return o; }
 };
+inline Comma Comma::operator,(const Dyn& x) {
+    Comma cm = {m, k};
+    for (size_t i = 0; i < x.v.size(); ++i) { m->v.at(cm.k) = x.v[i]; ++cm.k; }
+    return cm;
+}
 inline Comma Comma::operator,(double x) { m->v.at(k) = x; Comma cm = {m, k + 1}; return cm; }
 inline Block& Block::operator=(const Dyn& o) {
     const bool same = o.r == h && o.c == w, flip = o.r == w && o.c == h && (h == 1 || w == 1);

@@ -1,5 +1,6 @@
 // oracle/ref_wrap_lba.cpp -- TEST INFRASTRUCTURE ONLY (built into oracle/_ref/).
-// Compiles the reference's local-BA observation loops TEXTUALLY -- the four `for` loops of
+// Compiles the reference's local-BA observation loops (and, at the end of the file, its pose-only Gauss-Newton loops)
+// TEXTUALLY -- the four `for` loops of
 // MapHandler::levMarquardtOptimizationLBA, /root/reference/src/mapHandler.cpp:1358-1431 (points, first pass),
 // :1436-1540 (lines, first pass), :1587-1666 and :1668-1772 (iteration pass), cut out of the file where it lies by
 // oracle/ref_extract_lba.py into oracle/_ref/*.inc -- inside a harness that supplies the names they use:
@@ -25,6 +26,7 @@ typedef mini::Fixed<2, 1> Vector2d;
 typedef mini::Fixed<3, 1> Vector3d;
 typedef mini::Fixed<6, 1> Vector6d;
 typedef mini::Fixed<4, 4> Matrix4d;
+typedef mini::Fixed<6, 6> Matrix6d;
 typedef mini::MatrixX MatrixXd;
 typedef mini::MatrixX VectorXd;
 typedef mini::Vector6i Vector6i;
@@ -33,6 +35,9 @@ namespace {
 struct MapPoint { Vector3d point3D; vector<Vector2d> obs_list; vector<double> sigma_list; };   // sigma_list: read, unused (:1641)
 struct MapLine { Vector6d line3D; vector<Vector3d> obs_list; };
 struct KeyFrame { Matrix4d T_kf_w; };
+// the stvo-pl feature records, with the members the pose-only GN loops read (src/mapHandler.cpp:3331-3426)
+struct PointFeature { bool inlier; Vector3d P; Vector2d pl_obs; double sigma2; };
+struct LineFeature { bool inlier; Vector3d sP, eP, le_obs; double sigma2; };
 struct Camera {
     double fx, fy, cx, cy;
     Vector2d projection(const Vector3d& P) const {      // stvo-pl PinholeStereoCamera::projection [RECALL]
@@ -134,6 +139,68 @@ extern "C" int ref_lba_accumulate(int iter_pass, const double cam4[4], double ho
         for (size_t k = 0; k < map_keyframes.size(); ++k) delete map_keyframes[k];
         for (size_t k = 0; k < map_points.size(); ++k) delete map_points[k];
         for (size_t k = 0; k < map_lines.size(); ++k) delete map_lines[k];
+        return 0;
+    } catch (const std::exception&) {
+        return -1;
+    }
+}
+
+// The point and line loops of one pose-only Gauss-Newton iteration, MapHandler::computeRelativePoseGN
+// (/root/reference/src/mapHandler.cpp:3331-3368, :3371-3426) or, with robust != 0, the first pair of loops of
+// computeRelativePoseRobustGN (:3595-3630, :3633-3689) -- compiled textually like the loops above.  Outputs as the
+// reference combines them right behind the loops (:3413-3416): H = H_p + H_l, g = g_p + g_l, e = e_p + e_l.
+extern "C" int ref_pose_gn_accumulate(int robust, const double cam4[4], double homog_th, const double* T_inc16,
+                                      const double* P, const double* pl_obs, const uint8_t* pt_inlier, int npt,
+                                      const double* sPeP, const double* le_obs, const uint8_t* ls_inlier, int nls,
+                                      double* H_out, double* g_out, double* e_out, int32_t* n_obs)
+{
+    try {
+        g_homog_th = homog_th;
+        Camera cam_ = {cam4[0], cam4[1], cam4[2], cam4[3]};
+        Camera* cam = &cam_;
+        Matrix4d T_inc;
+        for (int i = 0; i < 16; ++i) T_inc.v[i] = T_inc16[i];
+        vector<PointFeature*> lc_points;
+        vector<LineFeature*> lc_lines;
+        for (int i = 0; i < npt; ++i) {
+            PointFeature* f = new PointFeature;
+            f->inlier = pt_inlier[i] != 0;
+            f->sigma2 = 1.0;
+            for (int k = 0; k < 3; ++k) f->P(k) = P[3 * (size_t)i + k];
+            for (int k = 0; k < 2; ++k) f->pl_obs(k) = pl_obs[2 * (size_t)i + k];
+            lc_points.push_back(f);
+        }
+        for (int i = 0; i < nls; ++i) {
+            LineFeature* f = new LineFeature;
+            f->inlier = ls_inlier[i] != 0;
+            f->sigma2 = 1.0;
+            for (int k = 0; k < 3; ++k) {
+                f->sP(k) = sPeP[6 * (size_t)i + k];
+                f->eP(k) = sPeP[6 * (size_t)i + 3 + k];
+                f->le_obs(k) = le_obs[3 * (size_t)i + k];
+            }
+            lc_lines.push_back(f);
+        }
+        Matrix6d H_p = Matrix6d::Zero(), H_l = Matrix6d::Zero();
+        Vector6d g_p = Vector6d::Zero(), g_l = Vector6d::Zero();
+        double e_p = 0.0, e_l = 0.0;
+        int N_p = 0, N_l = 0;
+        if (!robust) {
+#include "_ref/gn_pt.inc"
+#include "_ref/gn_ls.inc"
+        } else {
+#include "_ref/gnr_pt.inc"
+#include "_ref/gnr_ls.inc"
+        }
+        Matrix6d H = H_p + H_l;
+        Vector6d g = g_p + g_l;
+        memcpy(H_out, H.v.data(), 36 * sizeof(double));
+        memcpy(g_out, g.v.data(), 6 * sizeof(double));
+        *e_out = e_p + e_l;
+        n_obs[0] = N_p;
+        n_obs[1] = N_l;
+        for (size_t k = 0; k < lc_points.size(); ++k) delete lc_points[k];
+        for (size_t k = 0; k < lc_lines.size(); ++k) delete lc_lines[k];
         return 0;
     } catch (const std::exception&) {
         return -1;

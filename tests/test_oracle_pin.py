@@ -661,3 +661,75 @@ def test_lba_rows_and_accumulation_pinned_to_reference_source_text(seed, th):
     np.testing.assert_allclose(it[1], g2, rtol=1e-11, atol=1e-11 * np.abs(g2).max())
     assert np.isclose(it[2], e2, rtol=1e-12)
     assert not np.allclose(it[0], first[0], rtol=1e-6, atol=1e-6 * scale)       # the two passes really differ
+
+
+@pytest.mark.parametrize("robust", [False, True])
+@pytest.mark.parametrize("th", [1e-7, 0.5, 60.0])
+def test_pose_gn_loops_pinned_to_reference_source_text(robust, th):
+    """K17's checker against the reference's own pose-only Gauss-Newton loops, compiled textually from
+    src/mapHandler.cpp:3331-3426 (computeRelativePoseGN) and :3595-3689 (computeRelativePoseRobustGN): H = H_p + H_l,
+    g, e and the inlier counts of one iteration.  th = 0.5 / 60 put residual norms / depths below homogTh."""
+    from test_pose_gn import scene, _args
+    cam = O.make_cam(**synth.EUROC)
+    for seed in (2, 3, 4):
+        sc = scene(120, 40, seed=seed)
+        ref = O.ref_pose_gn_accumulate(robust, cam, th, *_args(sc))
+        if ref is None:
+            pytest.skip("oracle/_ref not built with the LBA / GN harness (needs /root/reference at build time)")
+        H, g, e, n = O.pose_gn_accumulate(cam, th, *_args(sc))
+        assert n == ref[3] and n[0] > 50 and n[1] > 15
+        np.testing.assert_allclose(ref[0], H, rtol=1e-11, atol=1e-11 * np.abs(H).max())
+        np.testing.assert_allclose(ref[1], g, rtol=1e-11, atol=1e-11 * np.abs(g).max())
+        assert np.isclose(ref[2], e, rtol=1e-12)
+
+
+def test_map2kf_visibility_and_gates_pinned_to_reference_source_text():
+    """The loops either side of the descriptor match in matchMap2KFPoints / matchMap2KFLines, compiled textually from
+    src/mapHandler.cpp:545-558, :601-629, :647-663, :716-749: which landmarks the visibility pre-filter selects (and the
+    normalised projections it records for the grid search), which landmarks pass the geometric gate (points: norm of
+    the pixel error; lines: the SIGNED two-end-point test) and the final `matches` count."""
+    K = synth.EUROC
+    cam = O.make_cam(**K)
+    checked = 0
+    for seed in range(4):
+        r = _rng(300 + seed)
+        Twf = np.linalg.inv(synth.se3_exp(r.normal(0, 0.08, 6)))
+        n = 300
+        X = np.stack([r.uniform(-4, 4, n), r.uniform(-3, 3, n), r.uniform(-2, 20, n)], 1)
+        X[0, 2] = -Twf[2, 3] / max(abs(Twf[2, 2]), 1e-9) * np.sign(Twf[2, 2])        # a landmark at (almost) zero depth
+        ref = O.ref_map_visible("points", cam, Twf, X, 1.0 / K["width"], 1.0 / K["height"])
+        if ref is None:
+            pytest.skip("oracle/_ref not built with the map2kf harness (needs /root/reference at build time)")
+        vis = O.map_point_visible(cam, Twf, X)
+        assert np.array_equal(vis, ref[0]) and 20 < vis.sum() < n
+        Xc = X @ Twf[:3, :3].T + Twf[:3, 3]
+        uv = np.stack([K["cx"] + K["fx"] * Xc[:, 0] / Xc[:, 2], K["cy"] + K["fy"] * Xc[:, 1] / Xc[:, 2]], 1)
+        sel = vis.astype(bool)
+        np.testing.assert_allclose(ref[1], uv[sel] * [1.0 / K["width"], 1.0 / K["height"]], rtol=1e-12)
+        Lw = np.concatenate([X, X + r.normal(0, 0.4, X.shape)], 1)
+        refl = O.ref_map_visible("lines", cam, Twf, Lw, 1.0 / K["width"], 1.0 / K["height"])
+        visl = O.map_line_visible(cam, Twf, Lw)
+        assert np.array_equal(visl, refl[0]) and 10 < visl.sum() < n
+        # gates on the visible ones
+        Xv, Lv = X[sel], Lw[visl.astype(bool)]
+        nt = 150
+        m12 = r.integers(-1, nt, len(Xv)).astype(np.int32)
+        pl = np.zeros((nt, 2))
+        ok = m12 >= 0
+        pl[m12[ok]] = uv[sel][ok]
+        pl += r.normal(0, 0.8, pl.shape)
+        for th in (1.0, 2.5):
+            mask, cnt = O.map2kf_point_gate(cam, Twf, Xv, m12, pl, th)
+            rmask, rcnt = O.ref_map2kf_gate("points", cam, Twf, Xv, m12, pl, th)
+            assert np.array_equal(mask, rmask) and cnt == rcnt and 0 < cnt < ok.sum()
+            checked += 1
+        m12l = r.integers(-1, nt, len(Lv)).astype(np.int32)
+        le = r.normal(0, 1, (nt, 3))
+        le /= np.linalg.norm(le[:, :2], axis=1, keepdims=True)
+        le[:, 2] *= 200.0
+        for th in (1.0, 40.0):
+            mask, cnt = O.map2kf_line_gate(cam, Twf, Lv, m12l, le, th)
+            rmask, rcnt = O.ref_map2kf_gate("lines", cam, Twf, Lv, m12l, le, th)
+            assert np.array_equal(mask, rmask) and cnt == rcnt
+            checked += 1
+    assert checked == 16
