@@ -332,7 +332,7 @@ int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, int32_t nls,
  * but its LINE observations the stored map_keyframes[kf]->T_kf_w (:1680) -- a caller that wants the reference's
  * numbers keeps one slot per key frame with the stored pose for ls_pose_slot and a second set with the current
  * estimates for pt_pose_slot, and passes compat_iter_pass = 1 (stride-3 end points :1677-1678, literal 1e-7 :1698).
- * All three quirks are checked against the reference's own source text (oracle/ref_wrap_lba.cpp). */
+ * All three quirks are checked against the reference's own source text by the CPU test suite. */
 typedef struct plslam_lba_plan plslam_lba_plan;
 int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, double homog_th, int32_t n_pose_slots,
                            int32_t nkf, int32_t npt, int32_t nls, const int32_t* pt_lm_loc,
