@@ -217,7 +217,8 @@ def ref_lib():
 def ref_lba_accumulate(iter_pass, cam, homog_th, nkf, T_map, T_slot, Xw, Lw, pt_lm, pt_kf_map, pt_kf_loc, pt_uv,
                        ls_lm, ls_kf_map, ls_kf_loc, ls_l):
     """The reference's OWN local-BA observation loops (src/mapHandler.cpp:1358-1431 + :1436-1540, or with iter_pass the
-    iteration-pass loops :1587-1666 + :1668-1772), compiled textually from where they lie (oracle/ref_wrap_lba.cpp)
+    iteration-pass loops :1587-1666 + :1668-1772; with iter_pass == "gba" the first-pass loops of
+    levMarquardtOptimizationGBA :2124-2228 + :2233-2355), compiled textually from where they lie (oracle/ref_wrap_lba.cpp)
     -> (H, g, err) as they stand after both loops.  Landmark map index == local index; T_map: poses by key-frame map
     index; T_slot: poses of the nkf optimised slots (what expmap_se3 of X's pose blocks gives in the iteration pass).
     None if unavailable."""
@@ -233,7 +234,8 @@ def ref_lba_accumulate(iter_pass, cam, homog_th, nkf, T_map, T_slot, Xw, Lw, pt_
     a = [_c(x, np.int32) for x in (pt_lm, pt_kf_map, pt_kf_loc)] + [_c(pt_uv, np.float64)]
     b = [_c(x, np.int32) for x in (ls_lm, ls_kf_map, ls_kf_loc)] + [_c(ls_l, np.float64)]
     c4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy])
-    rc = r.ref_lba_accumulate(int(bool(iter_pass)), c4.ctypes.data, float(homog_th), nkf, npt, nls, T_map.ctypes.data,
+    mode = 2 if iter_pass == "gba" else int(bool(iter_pass))
+    rc = r.ref_lba_accumulate(mode, c4.ctypes.data, float(homog_th), nkf, npt, nls, T_map.ctypes.data,
                               T_map.shape[0], T_slot.ctypes.data, Xw.ctypes.data, Lw.ctypes.data,
                               *[x.ctypes.data for x in a], a[0].shape[0], *[x.ctypes.data for x in b], b[0].shape[0],
                               H.ctypes.data, g.ctypes.data, err.ctypes.data)

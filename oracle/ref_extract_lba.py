@@ -7,6 +7,7 @@ oracle/ref_wrap_lba.cpp can compile them textually against the dense-matrix stan
     lba_ls_first.inc   first pass,     line observations                                            (near :1436)
     lba_pt_iter.inc    iteration pass, point observations                                           (near :1587)
     lba_ls_iter.inc    iteration pass, line observations                                            (near :1668)
+    gba_pt_first.inc, gba_ls_first.inc   the first-pass loops of levMarquardtOptimizationGBA        (near :2124, :2233)
 and the point / line loops of the pose-only Gauss-Newton iterations (K17's checker):
     gn_pt.inc, gn_ls.inc           MapHandler::computeRelativePoseGN        (near :3330, :3370)
     gnr_pt.inc, gnr_ls.inc         MapHandler::computeRelativePoseRobustGN  (first pair of loops, near :3594, :3634)
@@ -55,6 +56,17 @@ def main(ref, out):
                          % (start + 1, end + 1))
                 fh.write("\n".join(src[start:end + 1]) + "\n")
             print("[ref_extract_lba] %s = src/mapHandler.cpp:%d-%d" % (name, start + 1, end + 1))
+    f2 = next(i for i, l in enumerate(src) if "MapHandler::levMarquardtOptimizationGBA" in l)
+    f3 = next(i for i, l in enumerate(src) if i > f2 and "MapHandler::removeBadMapLandmarks" in l)
+    for key in ("pt", "ls"):
+        start = next(i for i in range(f2, f3) if "vector<Vector6i>::iterator %s_it" % key in src[i] and src[i].lstrip().startswith("for"))
+        end = loop_at(src, start)
+        name = "gba_%s_first.inc" % key
+        with open(os.path.join(out, name), "w") as fh:
+            fh.write("// generated from src/mapHandler.cpp:%d-%d by oracle/ref_extract_lba.py -- not part of the repository\n"
+                     % (start + 1, end + 1))
+            fh.write("\n".join(src[start:end + 1]) + "\n")
+        print("[ref_extract_lba] %s = src/mapHandler.cpp:%d-%d" % (name, start + 1, end + 1))
     for fn, nxt, tag, vis_hdr in (("MapHandler::matchMap2KFPoints", "MapHandler::matchMap2KFLines", "m2kf_pt", "for (MapPoint* pt : map_points)"),
                                   ("MapHandler::matchMap2KFLines", "MapHandler::lookForCommonMatches", "m2kf_ls", "for (MapLine* ls : map_lines)")):
         g0 = next(i for i, l in enumerate(src) if fn + "(" in l.replace(" ", ""))

@@ -136,6 +136,13 @@ struct MatrixX : Dyn {
     static MatrixX Zero(int r_, int c_) { return MatrixX(r_, c_); }
     static MatrixX Zero(int n) { return MatrixX(n, 1); }
 };
+struct SparseLike : Dyn {            // SparseMatrix / SparseVector spelt through coeffRef only; dense underneath
+    SparseLike() {}
+    SparseLike(int r_, int c_) : Dyn(r_, c_) {}
+    explicit SparseLike(int n) : Dyn(n, 1) {}
+    double& coeffRef(int i, int j) { return (*this)(i, j); }
+    double& coeffRef(int i) { return (*this)(i); }
+};
 struct Vector6i {
     int v[6];
     int operator()(int i) const { return v[i]; }

@@ -26,6 +26,7 @@ typedef mini::Fixed<2, 1> Vector2d;
 typedef mini::Fixed<3, 1> Vector3d;
 typedef mini::Fixed<6, 1> Vector6d;
 typedef mini::Fixed<4, 4> Matrix4d;
+typedef mini::Fixed<3, 3> Matrix3d;
 typedef mini::Fixed<6, 6> Matrix6d;
 typedef mini::MatrixX MatrixXd;
 typedef mini::MatrixX VectorXd;
@@ -126,12 +127,26 @@ extern "C" int ref_lba_accumulate(int iter_pass, const double cam4[4], double ho
         for (int i = 0; i < 3 * Npt; ++i) X(6 * Nkf + i) = Xw[i];
         for (int i = 0; i < 6 * Nls; ++i) X(6 * Nkf + 3 * Npt + i) = Lw[i];
         double err = 0.0;
-        if (!iter_pass) {
+        if (iter_pass == 0) {
 #include "_ref/lba_pt_first.inc"
 #include "_ref/lba_ls_first.inc"
-        } else {
+        } else if (iter_pass == 1) {
 #include "_ref/lba_pt_iter.inc"
 #include "_ref/lba_ls_iter.inc"
+        } else {
+            // iter_pass == 2: the first-pass loops of levMarquardtOptimizationGBA (:2124-2228, :2233-2355), which spell the
+            // accumulation through SparseMatrix / SparseVector::coeffRef; the outer H / g are shadowed by such objects
+            mini::SparseLike H(N, N), g(N);
+            int Npt_obs = 0, Nls_obs = 0;
+#include "_ref/gba_pt_first.inc"
+#include "_ref/gba_ls_first.inc"
+            memcpy(H_out, H.v.data(), sizeof(double) * (size_t)N * N);
+            memcpy(g_out, g.v.data(), sizeof(double) * (size_t)N);
+            *err_out = err;
+            for (size_t k = 0; k < map_keyframes.size(); ++k) delete map_keyframes[k];
+            for (size_t k = 0; k < map_points.size(); ++k) delete map_points[k];
+            for (size_t k = 0; k < map_lines.size(); ++k) delete map_lines[k];
+            return 0;
         }
         memcpy(H_out, H.v.data(), sizeof(double) * (size_t)N * N);
         memcpy(g_out, g.v.data(), sizeof(double) * (size_t)N);

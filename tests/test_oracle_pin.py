@@ -733,3 +733,36 @@ def test_map2kf_visibility_and_gates_pinned_to_reference_source_text():
             assert np.array_equal(mask, rmask) and cnt == rcnt
             checked += 1
     assert checked == 16
+
+
+def test_gba_first_pass_is_the_lba_first_pass_except_for_one_transposed_block():
+    """DESIGN.md claims the global-BA rows are the local-BA rows verbatim and only the accumulation is spelt differently
+    (SparseMatrix::coeffRef).  Compiling the reference's own GBA loops (src/mapHandler.cpp:2124-2228, :2233-2355) shows
+    the claim holds for g, err and every block of H -- EXCEPT the pose x line cross blocks, which the GBA code writes
+    transposed (`H.coeffRef(idx+i,jdx+j) += Hij(i,j)` with Hij = J_line J_pose^T, :2341-2352; the local BA puts that
+    product at [line rows, pose columns], :1531-1532).  A caller that wants the reference's GBA numbers therefore
+    transposes the 6 x 6 W blocks of the line observations it gets from plslam_lba_assemble."""
+    n_kf, npt, nls = 5, 40, 14
+    lm = synth.local_map(n_kf=n_kf, n_pt=npt, n_ls=nls, obs_per_lm=3, seed=71, noise_px=2.0)
+    cam = O.make_cam(**synth.EUROC)
+    nkf = n_kf - 1
+    kf_loc_p, kf_loc_l = lm["pt_kf"] - 1, lm["ls_kf"] - 1
+    T_map = np.asarray(lm["T_kf_w"]).reshape(n_kf, 16)
+    args = (cam, 1e-7, nkf, T_map, T_map[1:], lm["Xw"], lm["Lw"], lm["pt_lm"], lm["pt_kf"], kf_loc_p, lm["obs_uv"],
+            lm["ls_lm"], lm["ls_kf"], kf_loc_l, lm["l_obs"])
+    gba = O.ref_lba_accumulate("gba", *args)
+    if gba is None:
+        pytest.skip("oracle/_ref not built with the LBA harness (needs /root/reference at build time)")
+    H, g, e = _lba_oracle_Hg(cam, 1e-7, nkf, npt, nls, T_map, lm, lm["pt_kf"], lm["ls_kf"], kf_loc_p, kf_loc_l, False)
+    tol = 1e-11 * np.abs(H).max()
+    np.testing.assert_allclose(gba[1], g, rtol=1e-11, atol=1e-11 * np.abs(g).max())
+    assert np.isclose(gba[2], e, rtol=1e-12)
+    base = 6 * nkf + 3 * npt
+    exp = H.copy()
+    for k in range(nkf):
+        for l in range(nls):
+            blk = H[base + 6 * l: base + 6 * l + 6, 6 * k: 6 * k + 6]          # [line rows, pose cols] = J_line J_pose^T
+            exp[6 * k: 6 * k + 6, base + 6 * l: base + 6 * l + 6] = blk         # GBA: the same numbers, untransposed
+            exp[base + 6 * l: base + 6 * l + 6, 6 * k: 6 * k + 6] = blk.T
+    np.testing.assert_allclose(gba[0], exp, rtol=1e-11, atol=tol)
+    assert not np.allclose(gba[0], H, rtol=1e-9, atol=1e-9 * np.abs(H).max())   # ... and that is a real difference
