@@ -263,3 +263,29 @@ def test_lba_plan_iterations_match_oracle(ctx, oracle):
     with pytest.raises(plslam_amd.PlslamError):
         plslam_amd.LbaPlan(ctx, cam, 1e-7, 6, nkf, npt, nls, lm["pt_lm"], lm["pt_kf"] + 9, pkf, lm["obs_uv"],
                            lm["ls_lm"], lm["ls_kf"], lkf, lm["l_obs"])
+
+
+def test_lba_plan_against_the_reference_source_text_outputs(ctx):
+    """tests/golden/lba_ref_golden.npz = dense H, g, err produced by the reference's OWN observation loops
+    (src/mapHandler.cpp:1358-1540 first pass, :1587-1772 iteration pass; compiled textually, see
+    tests/golden/make_lba_ref_golden.py).  One device plan, used as INTEGRATION.md says: pose slots 0..n_kf-1 hold the
+    stored key-frame poses, slots n_kf.. the current estimates; point observations of optimised key frames read the
+    estimates, line observations ALWAYS the stored poses (:1680), iteration pass with compat (stride-3 end points,
+    literal 1e-7).  Block-form output, expanded, vs the reference: 1e-10 of the matrix scale."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lba_ref_golden.npz"))
+    n_kf, nkf, npt, nls = (int(x) for x in g["dims"])
+    cam, _ = _cams()
+    kp, kl = g["pt_kf"] - 1, g["ls_kf"] - 1
+    slot_p = np.where(kp >= 0, n_kf + kp, g["pt_kf"]).astype(np.int32)
+    plan = plslam_amd.LbaPlan(ctx, cam, float(g["th"][0]), n_kf + nkf, nkf, npt, nls, g["pt_lm"], slot_p, kp, g["obs_uv"],
+                              g["ls_lm"], g["ls_kf"], kl, g["l_obs"])
+    for name, T_est, compat in (("first", g["T_map"][1:], False), ("iter", g["T_slot"], True)):
+        B = plan.iterate(np.concatenate([g["T_map"], T_est]), g["Xw"], g["Lw"], compat_iter_pass=compat)
+        Hd = _expand_blocks(B, nkf, npt, nls, g["pt_lm"], kp, g["ls_lm"], kl)
+        H, gg = g[f"{name}_H"], g[f"{name}_g"]
+        assert np.abs(Hd - H).max() <= 1e-10 * np.abs(H).max(), name
+        assert np.abs(B["g"] - gg).max() <= 1e-10 * np.abs(gg).max(), name
+        assert abs(B["err"] - float(g[f"{name}_err"][0])) <= 1e-11 * float(g[f"{name}_err"][0]), name
+    assert np.abs(g["iter_H"] - g["first_H"]).max() > 1e-6 * np.abs(g["first_H"]).max()     # the passes differ
+    plan.close()

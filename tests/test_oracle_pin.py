@@ -766,3 +766,24 @@ def test_gba_first_pass_is_the_lba_first_pass_except_for_one_transposed_block():
             exp[base + 6 * l: base + 6 * l + 6, 6 * k: 6 * k + 6] = blk.T
     np.testing.assert_allclose(gba[0], exp, rtol=1e-11, atol=tol)
     assert not np.allclose(gba[0], H, rtol=1e-9, atol=1e-9 * np.abs(H).max())   # ... and that is a real difference
+
+
+def test_lba_against_committed_reference_source_text_outputs():
+    """tests/golden/lba_ref_golden.npz (H, g, err from the reference's own loops, make_lba_ref_golden.py) against the
+    oracle -- runs where oracle/_ref was never built."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lba_ref_golden.npz"))
+    n_kf, nkf, npt, nls = (int(x) for x in g["dims"])
+    cam = O.make_cam(**synth.EUROC)
+    lm = {k: g[k] for k in ("Xw", "Lw", "obs_uv", "l_obs", "pt_lm", "pt_kf", "ls_lm", "ls_kf")}
+    kp, kl = g["pt_kf"] - 1, g["ls_kf"] - 1
+    th = float(g["th"][0])
+    H, gg, e = _lba_oracle_Hg(cam, th, nkf, npt, nls, g["T_map"], lm, g["pt_kf"], g["ls_kf"], kp, kl, False)
+    np.testing.assert_allclose(g["first_H"], H, rtol=1e-11, atol=1e-11 * np.abs(H).max())
+    np.testing.assert_allclose(g["first_g"], gg, rtol=1e-11, atol=1e-11 * np.abs(gg).max())
+    assert np.isclose(float(g["first_err"][0]), e, rtol=1e-12)
+    T_all = np.concatenate([g["T_map"], g["T_slot"]])
+    slot_p = np.where(kp >= 0, n_kf + kp, g["pt_kf"]).astype(np.int32)
+    H, gg, e = _lba_oracle_Hg(cam, th, nkf, npt, nls, T_all, lm, slot_p, g["ls_kf"], kp, kl, True)
+    np.testing.assert_allclose(g["iter_H"], H, rtol=1e-11, atol=1e-11 * np.abs(H).max())
+    np.testing.assert_allclose(g["iter_g"], gg, rtol=1e-11, atol=1e-11 * np.abs(gg).max())
+    assert np.isclose(float(g["iter_err"][0]), e, rtol=1e-12)
