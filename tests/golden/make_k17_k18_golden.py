@@ -3,8 +3,9 @@ python tests/golden/make_k17_k18_golden.py, in the build container: needs oracle
 The LBD vectors are OUTPUTS OF THE REFERENCE ITSELF: BinaryDescriptor::computeLBD (binary_descriptor_custom.cpp:1026-1372)
 compiled from where it lies (oracle/ref_wrap_lbd.cpp) and run on the seeded gradient images; the script refuses to
 write them unless the C oracle reproduces them bit for bit and the independent float64 numpy derivation of
-tests/test_lbd_float.py agrees to 2e-5.  The pose-GN vectors come from the C oracle's literal restatement of the
-computeRelativePoseGN iteration body (src/mapHandler.cpp:3324-3424; not compilable here: Eigen / stvo-pl)."""
+tests/test_lbd_float.py agrees to 2e-5.  The pose-GN vectors are likewise the reference's own: the point and line loops
+of computeRelativePoseGN (src/mapHandler.cpp:3331-3426) compiled textually (oracle/ref_wrap_lba.cpp); written only if the
+C oracle agrees to 1e-11 and the twin loops of computeRelativePoseRobustGN give the same numbers."""
 import os
 import sys
 
@@ -37,7 +38,16 @@ def main():
                         codes=O.lbd_binarise(out))
     s = scene(60, 20, seed=31)
     cam = O.make_cam(**synth.EUROC)
-    H, g, e, n = O.pose_gn_accumulate(cam, 1e-7, s["T"], s["P"], s["pl_obs"], s["pt_in"], s["sPeP"], s["le_obs"], s["ls_in"])
+    a = (cam, 1e-7, s["T"], s["P"], s["pl_obs"], s["pt_in"], s["sPeP"], s["le_obs"], s["ls_in"])
+    ref = O.ref_pose_gn_accumulate(False, *a)          # the reference's own loops, compiled textually (:3331-3426)
+    if ref is None:
+        raise SystemExit("oracle/_ref lacks ref_pose_gn_accumulate: run `make -C oracle ref` with /root/reference present")
+    H, g, e, n = ref
+    Ho, go, eo, no = O.pose_gn_accumulate(*a)
+    assert no == n and np.allclose(Ho, H, rtol=1e-11, atol=1e-11 * np.abs(H).max()) and np.allclose(go, g, rtol=1e-11) \
+        and np.isclose(eo, e, rtol=1e-12), "oracle != reference source text"
+    rr = O.ref_pose_gn_accumulate(True, *a)            # computeRelativePoseRobustGN's twin loops (:3595-3689)
+    assert rr[3] == n and np.allclose(rr[0], H, rtol=1e-13, atol=0) and np.allclose(rr[1], g, rtol=1e-13, atol=0)
     np.savez_compressed(os.path.join(OUT, "pose_gn_golden.npz"), H=H, g=g, e=e, n=np.array(n), **s)
     print("wrote lbd_float_golden.npz, pose_gn_golden.npz")
 
