@@ -289,3 +289,25 @@ def test_lba_plan_against_the_reference_source_text_outputs(ctx):
         assert abs(B["err"] - float(g[f"{name}_err"][0])) <= 1e-11 * float(g[f"{name}_err"][0]), name
     assert np.abs(g["iter_H"] - g["first_H"]).max() > 1e-6 * np.abs(g["first_H"]).max()     # the passes differ
     plan.close()
+
+
+def test_visibility_gates_and_median_descriptor_against_reference_source_text_outputs(ctx):
+    """tests/golden/map2kf_ref_golden.npz = what the reference's OWN loops produce (matchMap2KFPoints / Lines visibility
+    pre-filter and gates, src/mapHandler.cpp:545-558, :601-629, :647-663, :716-749, compiled textually; and
+    updateAverageDescDir, src/mapFeatures.cpp:51-93 compiled as is -- tests/golden/make_map2kf_ref_golden.py).  The
+    device entry points must reproduce every mask, count and index."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "map2kf_ref_golden.npz"))
+    cam, _ = _cams()
+    vp, vl = ctx.map_point_visible(cam, g["Twf"], g["X"]), ctx.map_line_visible(cam, g["Twf"], g["Lw"])
+    assert np.array_equal(vp, g["vis_p"]) and np.array_equal(vl, g["vis_l"])
+    Xv, Lv = g["X"][vp.astype(bool)], g["Lw"][vl.astype(bool)]
+    for k, th in enumerate(g["th_p"]):
+        mask, cnt = ctx.map2kf_point_gate(cam, g["Twf"], Xv, g["m12p"], g["pl"], float(th))
+        assert np.array_equal(mask, g[f"gate_p{k}"]) and cnt == int(g[f"count_p{k}"][0])
+    for k, th in enumerate(g["th_l"]):
+        mask, cnt = ctx.map2kf_line_gate(cam, g["Twf"], Lv, g["m12l"], g["le"], float(th))
+        assert np.array_equal(mask, g[f"gate_l{k}"]) and cnt == int(g[f"count_l{k}"][0])
+    idx, md = ctx.median_desc_batched(g["med_desc_lists"], g["med_offsets"])
+    assert np.array_equal(idx, g["med_idx"])
+    assert np.array_equal(md, g["med_desc_lists"][g["med_offsets"][:-1] + g["med_idx"]])

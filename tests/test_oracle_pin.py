@@ -787,3 +787,21 @@ def test_lba_against_committed_reference_source_text_outputs():
     np.testing.assert_allclose(g["iter_H"], H, rtol=1e-11, atol=1e-11 * np.abs(H).max())
     np.testing.assert_allclose(g["iter_g"], gg, rtol=1e-11, atol=1e-11 * np.abs(gg).max())
     assert np.isclose(float(g["iter_err"][0]), e, rtol=1e-12)
+
+
+def test_visibility_gates_median_against_committed_reference_outputs():
+    """tests/golden/map2kf_ref_golden.npz (outputs of the reference's own loops, make_map2kf_ref_golden.py) against the
+    oracle -- runs where oracle/_ref was never built."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "map2kf_ref_golden.npz"))
+    cam = O.make_cam(**synth.EUROC)
+    vp, vl = O.map_point_visible(cam, g["Twf"], g["X"]), O.map_line_visible(cam, g["Twf"], g["Lw"])
+    assert np.array_equal(vp, g["vis_p"]) and np.array_equal(vl, g["vis_l"])
+    Xv, Lv = g["X"][vp.astype(bool)], g["Lw"][vl.astype(bool)]
+    for k, th in enumerate(g["th_p"]):
+        mask, cnt = O.map2kf_point_gate(cam, g["Twf"], Xv, g["m12p"], g["pl"], float(th))
+        assert np.array_equal(mask, g[f"gate_p{k}"]) and cnt == int(g[f"count_p{k}"][0])
+    for k, th in enumerate(g["th_l"]):
+        mask, cnt = O.map2kf_line_gate(cam, g["Twf"], Lv, g["m12l"], g["le"], float(th))
+        assert np.array_equal(mask, g[f"gate_l{k}"]) and cnt == int(g[f"count_l{k}"][0])
+    idx, md = O.median_desc_batched(g["med_desc_lists"], g["med_offsets"])
+    assert np.array_equal(idx, g["med_idx"])
