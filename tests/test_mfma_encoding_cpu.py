@@ -73,3 +73,25 @@ def test_key_orders_like_distance_then_index():
     keys = [((d << 7) | (t + loc), d, t) for d in (0, 1, 128, 256) for t in (0, 1, 63)]
     assert [k[1:] for k in sorted(keys)] == sorted(k[1:] for k in keys)
     assert max(k[0] for k in keys) <= 0x807F
+
+
+def test_no_inline_asm_reads_mfma_results():
+    """Guard for the K1e determinism bug: the wait states between a v_mfma and a VALU access to
+    its destination registers are inserted by the compiler, which does not look inside asm statements.  pack_acc -- the
+    one consumer of accumulator registers -- must therefore stay a builtin, and no asm statement may take an accumulator
+    element as an operand."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plslam_amd", "csrc",
+                            "hamming_mfma.hip")).read()
+    src = "\n".join(l.split("//")[0] for l in src.split("\n"))          # code only
+    assert "__builtin_amdgcn_perm(" in src
+    assert 'asm("v_perm_b32' not in src and "asm volatile(\"v_perm_b32" not in src
+    for m in re.finditer(r"asm(?:\s+volatile)?\s*\(([^;]*);", src):
+        body = m.group(1)
+        if re.match(r'\s*""', body):                      # an empty template issues no instruction
+            continue
+        assert not re.search(r"\bacc[01]\b|\bm[01]\b\s*[\[\)]|\bA[01]\b|\bB[01]\b", body), body[:120]
+    # the accumulators reach the bookkeeping through pack_acc only
+    uses = [l for l in src.split("\n") if re.search(r"\bacc[01]\[", l)]
+    assert uses and all("pack_acc(" in l for l in uses), uses
