@@ -383,6 +383,12 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         // a tile's flush and the next write of its buffer; here it must be added, or a wave that races through its last
         // step can overwrite its slot before a delayed flusher (e.g. an instruction-cache miss in the rarely executed
         // flush path) has read it: rare wrong column partials (seen as 1 in ~10^6 table entries under load).
+        // Loop exit.  The step that just ended issued MFMAs whose destination registers are dead on some of the paths
+        // below (a window with nothing left to consume them): the allocator reuses those registers at once, and on the
+        // shortest such path tools/check_mfma_hazards.py counts only 8 wait states between the last v_mfma and a VALU
+        // write to one of its destination registers -- fewer than the 11-12 the compiler puts in front of its own
+        // accumulator reads.  Never seen to misbehave; 16 idle cycles once per window make it a non-question.
+        asm volatile("s_nop 7\n\ts_nop 7");
         if (t < WT1) {                             // t == WT1 - 1: one more tile, into set B
             step(t, B0, B1, A0, A1, true, steady_tag);
             __syncthreads();

@@ -95,3 +95,30 @@ def test_no_inline_asm_reads_mfma_results():
     # the accumulators reach the bookkeeping through pack_acc only
     uses = [l for l in src.split("\n") if re.search(r"\bacc[01]\[", l)]
     assert uses and all("pack_acc(" in l for l in uses), uses
+
+
+def test_final_isa_has_no_mfma_destination_hazard(tmp_path):
+    """Compiles hamming_mfma.hip to gfx950 assembly (as build.py does, -S instead of -shared) and runs
+    tools/check_mfma_hazards.py over the FINAL listing, inline-asm bodies included: no non-MFMA instruction may touch a
+    destination register of a v_mfma within 11 wait states on any path (fall-through and taken branches).  The listing
+    of the kernel as it was before the K1e determinism fix has 94 such places; the shipped one must have none."""
+    import importlib.util
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        import pytest
+        pytest.skip("hipcc not available")
+    out = str(tmp_path / "hamming_mfma.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "include"),
+                    "-S", "--cuda-device-only", "-o", out, os.path.join(root, "plslam_amd", "csrc", "hamming_mfma.hip")],
+                   check=True, capture_output=True)
+    spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(root, "tools", "check_mfma_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    text = open(out).read()
+    assert text.count("v_mfma_scale_f32_32x32x64_f8f6f4") >= 128          # the four instantiations are all there
+    findings = mod.check(out, 11)
+    assert not findings, findings[:5]
