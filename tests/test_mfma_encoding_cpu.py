@@ -100,7 +100,7 @@ def test_no_inline_asm_reads_mfma_results():
 def test_final_isa_has_no_mfma_destination_hazard(tmp_path):
     """Compiles hamming_mfma.hip to gfx950 assembly (as build.py does, -S instead of -shared) and runs
     tools/check_mfma_hazards.py over the FINAL listing, inline-asm bodies included: no non-MFMA instruction may touch a
-    destination register of a v_mfma within 11 wait states on any path (fall-through and taken branches).  The listing
+    destination register of a v_mfma within 12 wait states on any path (fall-through and taken branches).  The listing
     of the kernel as it was before the K1e determinism fix has 94 such places; the shipped one must have none."""
     import importlib.util
     import os
@@ -120,5 +120,5 @@ def test_final_isa_has_no_mfma_destination_hazard(tmp_path):
     spec.loader.exec_module(mod)
     text = open(out).read()
     assert text.count("v_mfma_scale_f32_32x32x64_f8f6f4") >= 128          # the four instantiations are all there
-    findings = mod.check(out, 11)
+    findings = mod.check(out, 12)
     assert not findings, findings[:5]

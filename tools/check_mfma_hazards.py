@@ -6,8 +6,8 @@ own instructions but cannot see the operands of inline asm -- this checker reads
 
 Model (conservative): every instruction is one wait state, `s_nop N` is N + 1, an intervening v_mfma also counts as one
 (it really occupies the pipe for its passes, so the true distance is larger).  Paths: fall-through and taken branches are
-both followed until WAIT wait states have passed.  WAIT = 11 for the 8-pass fp4 form of v_mfma_scale_f32_32x32x64_f8f6f4
-(the compiler emits `s_nop 9` / `s_nop 11` in front of its own consumers; 11 is what it uses for the closest pair).
+both followed until WAIT wait states have passed.  WAIT = 12 for the 8-pass fp4 form of v_mfma_scale_f32_32x32x64_f8f6f4:
+the compiler emits `s_nop 11` (= 12 wait states) between such an MFMA and an immediately following read of its result.
 
 usage: check_mfma_hazards.py file.s [wait]      exit code 1 and a report if anything is found
 """
@@ -43,7 +43,7 @@ def parse(path):
     return ins, labels
 
 
-def check(path, wait=11):
+def check(path, wait=12):
     ins, labels = parse(path)
     findings = []
     for i, text in enumerate(ins):
@@ -80,7 +80,7 @@ def check(path, wait=11):
 
 
 if __name__ == "__main__":
-    f = check(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+    f = check(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 12)
     for i, a, j, b, ws in f[:40]:
         print(f"[{i}] {a[:70]}\n    -> [{j}] {b[:90]}   after {ws} wait state(s)")
     print(f"{len(f)} finding(s)")
