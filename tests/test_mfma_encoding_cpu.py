@@ -122,3 +122,18 @@ def test_final_isa_has_no_mfma_destination_hazard(tmp_path):
     assert text.count("v_mfma_scale_f32_32x32x64_f8f6f4") >= 128          # the four instantiations are all there
     findings = mod.check(out, 12)
     assert not findings, findings[:5]
+
+
+def test_unshipped_experiment_patch_still_applies():
+    """tools/experiments/k1e_tile_in_seed.patch is where the next round starts: it must keep applying to the shipped
+    kernel source (dry run; nothing is modified)."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("patch"):
+        import pytest
+        pytest.skip("patch(1) not available")
+    r = subprocess.run(["patch", "--dry-run", "-p1", "-i", os.path.join("tools", "experiments", "k1e_tile_in_seed.patch")],
+                       cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
