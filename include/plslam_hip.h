@@ -87,7 +87,9 @@ int plslam_ctx_create(int device_ordinal, plslam_ctx** out);
 void plslam_ctx_destroy(plslam_ctx* ctx);
 /* options: "scan_variant" (PLSLAM_SCAN_*), "scan_block" (queries per workgroup of the directed
  * scan: 256|512|1024), "sym_rows" (rows of d1 per lane in the symmetric scan: 0 = auto (default) | 1 | 4),
- * "group_cap" (workgroups of one problem co-scheduled on one XCD: 0 = auto (default) | 1..64) */
+ * "group_cap" (workgroups of one problem co-scheduled on one XCD: 0 = auto (default) | 1..64),
+ * "mfma_form" (bookkeeping of the matrix-core scan: 0 = auto (default) | 1 = best-2 push per tile (K1e) |
+ * 2 = group minima + second best by recomputation (K1f); identical results) */
 int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value);
 int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value);
 /* device facts for reports: CU count, max clock (kHz), LDS bytes per workgroup */

@@ -14,6 +14,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libplslam_hip.so")
+# experiment builds of the SAME library (tools/build_exp.py: timing-only variants of one kernel) are loaded through
+# this variable by the tools under tools/; the product, the tests and bench.py never set it
+if os.environ.get("PLSLAM_HIP_LIB_EXPERIMENT"):
+    LIB_PATH = os.path.abspath(os.environ["PLSLAM_HIP_LIB_EXPERIMENT"])
 
 OK, EINVAL, ENODEV, EHIP, ENOMEM, ERANGE, ENOTSUP = 0, -1, -2, -3, -4, -5, -6
 SCAN_AUTO, SCAN_LANE_PER_QUERY, SCAN_WAVE_PER_QUERY, SCAN_SYMMETRIC, SCAN_MFMA = 0, 1, 2, 3, 4

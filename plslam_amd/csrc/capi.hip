@@ -79,6 +79,7 @@ struct plslam_match_plan {
     int32_t nsym = 0, nsym_blocks = 0, nmerge_blocks = 0, sym_rows = 1;
     bool sym_mfma = false;             // symmetric problems run on K1e (matrix cores)
     bool sym_mfma_multi = false;       // ... and some of them have n2 > 2048 (multi-window instantiation)
+    int mfma_form = 0;                 // ctx option "mfma_form" at plan creation (0/2 = K1f, 1 = K1e)
     int32_t ndir = 0, ndir_blocks = 0; // non-mutual problems on the directed form of K1e
     bool dir_multi = false;
     SymDesc* d_dirs = nullptr; BlockDesc* d_dir_blocks = nullptr;
@@ -138,6 +139,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     // (measured: 266k vs 320k pairs/s at 512 pairs, 347k vs 344k at 2048, 364k vs 347k at 4096).
     P->sym_mfma = allow_sym && (ctx->scan_variant == PLSLAM_SCAN_MFMA || ctx->scan_variant == PLSLAM_SCAN_AUTO);
     P->sym_mfma_multi = false;
+    P->mfma_form = ctx->mfma_form;
     P->dir_multi = false;
     for (int32_t i = 0; i < nprob && P->sym_mfma; ++i)
         if (is_sym(probs[i]) && probs[i].n2 > 2048) P->sym_mfma_multi = true;
@@ -399,16 +401,16 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
     int r;
     bool zeroed = false;               // the first scan kernel that runs zeroes the #matches counters
     if (P->nsym_blocks > 0) {
-        r = P->sym_mfma ? launch_scan_sym_mfma(P->d_syms, P->d_sym_blocks, P->nsym_blocks, P->d_counts_zero,
-                                               P->ncounts, P->sym_mfma_multi, false, s)
+        r = P->sym_mfma ? launch_scan_mfma_form(P->mfma_form, P->d_syms, P->d_sym_blocks, P->nsym_blocks, P->d_counts_zero,
+                                                P->ncounts, P->sym_mfma_multi, false, s)
                         : launch_scan_sym(P->sym_rows, P->d_syms, P->d_sym_blocks,
                                           P->nsym_blocks, P->d_counts_zero, P->ncounts, s);
         if (r) return r;
         zeroed = true;
     }
     if (P->ndir_blocks > 0) {
-        r = launch_scan_sym_mfma(P->d_dirs, P->d_dir_blocks, P->ndir_blocks, P->d_counts_zero,
-                                 zeroed ? 0 : P->ncounts, P->dir_multi, true, s);
+        r = launch_scan_mfma_form(P->mfma_form, P->d_dirs, P->d_dir_blocks, P->ndir_blocks, P->d_counts_zero,
+                                  zeroed ? 0 : P->ncounts, P->dir_multi, true, s);
         if (r) return r;
         zeroed = true;
     }
@@ -537,6 +539,11 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         ctx->group_cap = value;
         return PLSLAM_OK;
     }
+    if (!strcmp(key, "mfma_form")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= 2, PLSLAM_EINVAL);
+        ctx->mfma_form = value;
+        return PLSLAM_OK;
+    }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }
@@ -548,6 +555,7 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "scan_block")) { *value = ctx->scan_block; return PLSLAM_OK; }
     if (!strcmp(key, "sym_rows")) { *value = ctx->sym_rows; return PLSLAM_OK; }
     if (!strcmp(key, "group_cap")) { *value = ctx->group_cap; return PLSLAM_OK; }
+    if (!strcmp(key, "mfma_form")) { *value = ctx->mfma_form; return PLSLAM_OK; }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }
@@ -783,8 +791,8 @@ int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const 
         PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->misc_b.p, &y, sizeof(y), hipMemcpyHostToDevice, s));
         PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->misc_c.p, striped.data(), striped.size() * sizeof(BlockDesc),
                                         hipMemcpyHostToDevice, s));
-        if ((r = launch_scan_sym_mfma(ctx->misc_b.as<SymDesc>(), ctx->misc_c.as<BlockDesc>(), (int)striped.size(),
-                                      nullptr, 0, nt > 2048, true, s))) return r;
+        if ((r = launch_scan_mfma_form(ctx->mfma_form, ctx->misc_b.as<SymDesc>(), ctx->misc_c.as<BlockDesc>(),
+                                       (int)striped.size(), nullptr, 0, nt > 2048, true, s))) return r;
         if ((r = launch_unpack_keys(ctx->misc_a.as<uint32_t>(), nq * 2, ctx->out_a.as<int32_t>(),
                                     ctx->out_b.as<int32_t>(), s))) return r;
         PLSLAM_HIP_CHECK(hipMemcpyAsync(idx, ctx->out_a.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));

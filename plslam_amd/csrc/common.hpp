@@ -82,6 +82,7 @@ struct plslam_ctx {
     int scan_block = 0;  // 0 = variant default
     int group_cap = 0;   // blocks of one problem kept together on one XCD; 0 = auto (capi.hip, `stripe`)
     int sym_rows = 0;    // rows of d1 per lane in the symmetric scan: 0 = auto, 1, 4
+    int mfma_form = 0;   // matrix-core scan: 0 = auto (grouped, K1f), 1 = exact push per tile (K1e), 2 = grouped (K1f)
     std::mutex mu;       // serialises the host-pointer entry points
     plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
     plslam::HostBuf pin_in, pin_out;                // pinned staging of small host-pointer calls
@@ -149,6 +150,15 @@ int launch_scan_sym(int rows_per_lane, const SymDesc* d_sym, const BlockDesc* d_
 // directed: only keys12 of every SymDesc is produced (keys21 / part21 unused): non-mutual problems, knnMatch
 int launch_scan_sym_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
                          int nzero, bool multi_window, bool directed, hipStream_t s);
+// K1f (hamming_mfma_g.hip): same contract and tables as K1e; row direction = group minima + second best by recomputation
+int launch_scan_sym_mfma_g(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
+                           int nzero, bool multi_window, bool directed, hipStream_t s);
+inline int launch_scan_mfma_form(int form, const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
+                                 int nzero, bool multi_window, bool directed, hipStream_t s)
+{
+    return form == 1 ? launch_scan_sym_mfma(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, s)
+                     : launch_scan_sym_mfma_g(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, s);
+}
 int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s);
 
 int scan_rows_per_block(int variant, int block_threads);

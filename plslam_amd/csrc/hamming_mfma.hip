@@ -46,6 +46,14 @@ typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4), aligned(4)));   // descriptor rows are only 4-byte aligned
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Pointers read from the launch tables are GENERIC to the compiler, and a generic access is a FLAT instruction, which
+// counts on lgkmcnt as well as vmcnt: the `s_waitcnt lgkmcnt(0)` in front of every workgroup barrier then waits for
+// the raw-row PREFETCH of two tiles ahead (round 2 finding: every tile paid a memory latency).  With the address
+// space spelled out the loads are global_load (vmcnt only) and stay in flight across the barrier.
+#define PLSLAM_GLOBAL __attribute__((address_space(1)))
+typedef const PLSLAM_GLOBAL uint32_t* gcu32_t;
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef PLSLAM_GLOBAL u32x2_t* gu2_t;
 
 namespace {
 
@@ -173,8 +181,8 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     const int c = lane & 31, g = lane >> 5;
     const int i0 = bd.row0;                        // first of this workgroup's 256 a-rows
     const int iw = i0 + 64 * w;                    // first of this wave's 64
-    const uint32_t* araw = reinterpret_cast<const uint32_t*>(sd.a);
-    const uint32_t* braw = reinterpret_cast<const uint32_t*>(sd.b);
+    const gcu32_t araw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.a);
+    const gcu32_t braw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.b);
 
     // expansion table first (the A operands use it too)
     blut[tid] = expand_byte_fp4((uint32_t)tid);
@@ -186,7 +194,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     for (int mt = 0; mt < 2; ++mt) {
         const int row = iw + 32 * mt + c;
         const int rrow = row < n1 ? row : n1 - 1;                 // clamped; masked in the epilogue
-        const uint32_t* p = araw + (size_t)rrow * 8 + g;         // this lane's dword of each K-step: 2 ks + g
+        const gcu32_t p = araw + (size_t)rrow * 8 + g;           // this lane's dword of each K-step: 2 ks + g
 #pragma unroll
         for (int ks = 0; ks < MF_KSTEPS; ++ks) {
             const uint32_t raw = p[2 * ks];
@@ -214,7 +222,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
     const bool rows_ragged = iw + 64 > n1;         // wave-uniform: some of this wave's rows do not exist
     const uint32_t ibase = (uint32_t)(iw + 4 * g); // + local index = a-row of an accumulator
     const uint32_t ghtag = (uint32_t)(4 * g) | ((uint32_t)(4 * g + 32) << 16);   // see finish_columns
-    uint2* part = reinterpret_cast<uint2*>(sd.part21) + (size_t)(i0 >> 8) * n2;
+    const gu2_t part = (gu2_t) reinterpret_cast<u32x2_t*>(sd.part21) + (size_t)(i0 >> 8) * n2;
 
     // expansion duty of this lane: b row (tid >> 3) of the tile, dword (tid & 7) of it
     const int ej = tid >> 3, ewd = tid & 7;
@@ -246,7 +254,7 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
                        key16_to_key32(e >> 16, 0u, (uint32_t)(i0 + 64 * ww), 1u));
             }
             const int j = t * MF_TILE_N + lane;
-            if (j < n2) part[j] = make_uint2(k0, k1);
+            if (j < n2) part[j] = u32x2_t{k0, k1};
         }
     };
 
@@ -434,13 +442,13 @@ k_scan_sym_mfma(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ 
         };
         const int row = iw + lane;
         if (row < n1) {
-            uint2* out = reinterpret_cast<uint2*>(sd.keys12) + row;
+            const gu2_t out = (gu2_t) reinterpret_cast<u32x2_t*>(sd.keys12) + row;
             uint32_t r0 = widen(k0), r1 = widen(k1);
             if (WT0 > 0) {                                  // later windows: merge with the windows before
-                const uint2 prev = *out;
+                const u32x2_t prev = *out;
                 merge2(r0, r1, prev.x, prev.y);
             }
-            *out = make_uint2(r0, r1);
+            *out = u32x2_t{r0, r1};
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -1,0 +1,477 @@
+// hamming_mfma_g.hip -- K1f: the matrix-core symmetric Hamming kNN-2 scan with GROUPED row bookkeeping (gfx950).
+//
+// Contract, work decomposition, block tables, partial table, merge + finalize kernels: exactly those of K1e
+// (hamming_mfma.hip) -- keys12[i] = best-2 over j, part21[i-block][j] = best-2 over the block's i, keys =
+// (distance << 23) | index = cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) order in both directions (reference call
+// sites src/mapHandler.cpp:277,424,597,712,3223,3249).  The distances come out of the same four
+// v_mfma_scale_f32_32x32x64_f8f6f4 per 32x32 tile (fp4 codes of +-1, accumulator = 2^23 + 128 d + tag, exact).
+//
+// What is different: K1e sits on the VALU issue limit of its best-2 bookkeeping (round 1: 455 VALU instructions
+// per two tiles, matrix pipe 24 % busy), and three things take instructions out of that stream here.
+//
+//  1. Row direction: minimum now, second best later.  K1e pushes every packed key pair into a sorted pair
+//     (best, second) per (row, column class): 3 packed ops per 2 distances.  Here a lane keeps only the running
+//     MINIMUM of a group of 8 consecutive tiles per (row, class) -- ONE v_pk_min_u16 per 2 distances -- and pushes
+//     the group minimum into the sorted pair once per 8 tiles.  Best-2 over group minima gives the exact best key
+//     B0, and B1 = the best key outside B0's group; the true second best is min(B1, best key among the OTHER
+//     members of B0's group).  Those are 7 known columns of the same class (j0 +- 32 k), so after the scan one lane
+//     per row recomputes 7 distances with XOR + popcount from the raw rows (L2-resident: the workgroup has just
+//     streamed them) and takes the minimum.  Exact, tie order included: within a class the 16-bit key order
+//     (d, tile) is the (d, j) order.  Per tile 16 + 64/8 = 24 instead of 48 packed ops; per scan ~150 extra.
+//  2. The tile number of a key rides in the accumulator start value (scalar adds on the seeds) instead of one
+//     vector add per packed pair; the column keys of a tile then share the offset and finish_columns takes it
+//     off again (round 1's tile-in-seed experiment).
+//  3. The byte -> fp4 expansion is arithmetic: nibble k of output dword s = 0x2 | bit(4k + s) << 3, i.e.
+//     ((x << (3 - s)) & 0x88888888) | 0x22222222: 3 adds + 4 v_and_or per raw dword, no 256-entry table, no
+//     data-dependent LDS gathers (round 1 measured 1.9e8 bank-conflict cycles per launch in those), one barrier
+//     less at kernel start.  Only the lane -> k map shared by the A and the B operand matters for a contraction
+//     over all k, so the changed bit order changes nothing.
+//
+// The column direction is unchanged (exact best-2 per tile): a column's candidates are complete within the
+// tile, so a deferred second best would have to be recomputed per tile and row block, which costs what it saves.
+#include "common.hpp"
+
+#include <type_traits>
+
+// build-time experiments for tools/scan_time.py / tools/build_exp.py (results are WRONG with any of them on):
+//   1 no workgroup barrier   2 no epilogue (bookkeeping)   3 no MFMA   4 no column flush   5 no second-best fix-up
+//   6 no finish_columns      7 no group push
+#ifndef PLSLAM_MG_EXPERIMENT
+#define PLSLAM_MG_EXPERIMENT 0
+#endif
+
+namespace plslam {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4), aligned(4)));   // descriptor rows are only 4-byte aligned
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// Pointers read from the launch tables are GENERIC to the compiler, and a generic access is a FLAT instruction, which
+// counts on lgkmcnt as well as vmcnt: the `s_waitcnt lgkmcnt(0)` in front of every workgroup barrier then waits for
+// the raw-row PREFETCH of two tiles ahead, i.e. every tile pays a full memory latency.  With the address space spelled
+// out the loads are global_load (vmcnt only) and stay in flight across the barrier.
+#define PLSLAM_GLOBAL __attribute__((address_space(1)))
+typedef const PLSLAM_GLOBAL uint32_t* gcu32_t;
+typedef const PLSLAM_GLOBAL u32x4_t* gcu32x4_t;
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef PLSLAM_GLOBAL u32x2_t* gu2_t;
+
+namespace {
+
+constexpr int MF_TILE_N = 32;                 // b rows per tile
+constexpr int MF_KSTEPS = 4;                  // 256 bits = 4 x K 64
+constexpr int MF_ROW_STRIDE = 144;            // bytes per expanded b row in LDS (128 + 16: 4-bank skew)
+constexpr int MF_TILE_BYTES = MF_TILE_N * MF_ROW_STRIDE;
+constexpr int MF_GROUP = 8;                   // tiles per row-direction group (a window of 64 tiles = 8 groups)
+// fp4 (e2m1) codes: +1.0 = 0x2, -1.0 = 0xA.  b side: bit 0 -> +1, bit 1 -> -1 = s(b); the a side is the b code
+// XOR 0x8 per nibble (= -s(a)) and carries the block scale 2^6 (E8M0 133), the b side 2^0 (E8M0 127).
+constexpr uint32_t FP4_NEG = 0x88888888u;
+constexpr uint32_t FP4_ONE = 0x22222222u;
+constexpr int SCALE_A = 133, SCALE_B = 127;
+constexpr uint32_t ACC_BITS = 0x4B000000u + 16384u;   // float bits of 2^23 + 16384 (+ small integers: + the integer)
+
+__device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ void merge2(uint32_t& a0, uint32_t& a1, uint32_t c0, uint32_t c1)
+{
+    const uint32_t lo = umin_(a0, c0);
+    const uint32_t hi = umin_(umax_(a0, c0), umin_(a1, c1));
+    a0 = lo;
+    a1 = hi;
+}
+// packed 16-bit min / max (inline asm: see hamming_mfma.hip -- the vector builtins get sunk out of the MFMA block)
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void pk_push2(uint32_t& b0, uint32_t& b1, uint32_t key)
+{
+    b1 = pk_min16(b1, pk_max16(b0, key));
+    b0 = pk_min16(b0, key);
+}
+// accumulators of the two M-tiles (2^23 + 128 d + tag, tag <= 127) side by side: hi.lo16 << 16 | lo.lo16.
+// The BUILTIN, never inline asm: this is the one instruction that reads MFMA results, and the wait states between an
+// MFMA and a VALU access to its destination are the compiler's job ("K1e determinism").
+__device__ __forceinline__ uint32_t pack_acc(float lo, float hi, uint32_t sel_uniform /* 0x05040100 */)
+{
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), sel_uniform);
+}
+// 16-bit keys are (d << 7) | tag7 (<= (256 << 7) + 127 = 0x807F); anything above is "none"
+constexpr uint32_t KEY16_MAX = 0x807Fu;
+__device__ __forceinline__ uint32_t key16_to_key32(uint32_t k16, uint32_t tag_bias, uint32_t idx_base,
+                                                   uint32_t idx_scale)
+{
+    return k16 > KEY16_MAX ? KEY_NONE
+                           : (((k16 >> 7) << KEY_IDX_BITS) | (idx_base + ((k16 & 127u) - tag_bias) * idx_scale));
+}
+// 32 bits of a descriptor -> 32 fp4 codes of s(bit): dword s holds bits 4k + s, nibble k = 0x2 | bit << 3
+template <bool A_SIDE>
+__device__ __forceinline__ i32x4 expand_dword_fp4(uint32_t x)
+{
+    const uint32_t x1 = x + x, x2 = x1 + x1, x3 = x2 + x2;
+    i32x4 v;
+    v.x = (int)((x3 & FP4_NEG) | FP4_ONE);      // one v_and_or_b32 each
+    v.y = (int)((x2 & FP4_NEG) | FP4_ONE);
+    v.z = (int)((x1 & FP4_NEG) | FP4_ONE);
+    v.w = (int)((x & FP4_NEG) | FP4_ONE);
+    if (A_SIDE) { v.x ^= (int)FP4_NEG; v.y ^= (int)FP4_NEG; v.z ^= (int)FP4_NEG; v.w ^= (int)FP4_NEG; }
+    return v;
+}
+__device__ __forceinline__ uint32_t bcnt_acc_(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ int xcd_remap_(int orig, int nwg) { return (orig & 7) * (nwg >> 3) + (orig >> 3); }
+
+}  // namespace
+
+// MULTI = false: every problem of the launch has n2 <= 2048 (one window of 64 tiles; the window bounds are
+// compile-time facts).  MULTI = true: any n2.  DIRECTED = true: only keys12 (row direction) is produced.
+template <bool MULTI, bool DIRECTED>
+__global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
+k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
+                  int32_t* __restrict__ zero, int nzero)
+{
+    // one buffer, two lives: the double-buffered b tile during the scan (9 216 B), the row-result transpose
+    // [wave][row 0..63][33] after it (33 792 B)
+    constexpr int ROWX_STRIDE = 33;               // dwords per row: lane = row reads are conflict-free
+    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * 64 * ROWX_STRIDE * 4];
+    uint8_t* const btile = smem;
+    __shared__ uint32_t colbuf[2][4][MF_TILE_N];  // [tile & 1][wave][column] = best | second << 16    1 024 B
+
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+
+    const int wg = xcd_remap_(blockIdx.x, gridDim.x);
+    const BlockDesc bd = blocks[wg];
+    if (bd.item < 0) return;                       // padding entry of the XCD-striped table
+    const SymDesc sd = syms[bd.item];
+    const int n1 = sd.n1, n2 = sd.n2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, g = lane >> 5;
+    const int i0 = bd.row0;                        // first of this workgroup's 256 a-rows
+    const int iw = i0 + 64 * w;                    // first of this wave's 64
+    const gcu32_t araw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.a);
+    const gcu32_t braw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.b);
+
+    // ---- A operands: rows iw + 32 mt + c, raw dword 2 ks + g of each, as fp4 codes of -s(a) (the b code with the
+    // sign nibble-bit flipped); the factor 64 is the block scale ----
+    i32x4 afrag[2][MF_KSTEPS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = iw + 32 * mt + c;
+        const int rrow = row < n1 ? row : n1 - 1;                 // clamped; masked in the epilogue
+        const gcu32_t p = araw + (size_t)rrow * 8 + g;           // this lane's dword of each K-step: 2 ks + g
+#pragma unroll
+        for (int ks = 0; ks < MF_KSTEPS; ++ks) afrag[mt][ks] = expand_dword_fp4<true>(p[2 * ks]);
+    }
+    const int scale_a = SCALE_A, scale_b = SCALE_B;
+    const uint32_t pack_sel = 0x05040100u;
+
+    // row-direction state per accumulator register r (M-tile 0 in the low halves, M-tile 1 in the high halves):
+    //   gm[r]    running minimum of the 16-bit keys (d << 7 | tile + LOC) of the current group of 8 tiles
+    //   rb[r][2] the best two GROUP minima of the lane's column class
+    uint32_t gm[16], rb[16][2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gm[r] = rb[r][0] = rb[r][1] = 0xFFFFFFFFu;
+
+    const bool rows_ragged = iw + 64 > n1;         // wave-uniform: some of this wave's rows do not exist
+    const uint32_t ibase = (uint32_t)(iw + 4 * g); // + local index = a-row of an accumulator
+    const uint32_t ghtag = (uint32_t)(4 * g) | ((uint32_t)(4 * g + 32) << 16);   // see finish_columns
+    const gu2_t part = DIRECTED ? (gu2_t) nullptr : (gu2_t) reinterpret_cast<u32x2_t*>(sd.part21) + (size_t)(i0 >> 8) * n2;
+
+    // expansion duty of this lane: b row (tid >> 3) of the tile, dword (tid & 7) of it
+    const int ej = tid >> 3, ewd = tid & 7;
+    const int ntiles = (n2 + MF_TILE_N - 1) / MF_TILE_N;
+    auto load_raw = [&](int t) __attribute__((always_inline)) -> uint32_t {
+        int j = t * MF_TILE_N + ej;
+        j = j < n2 ? j : n2 - 1;
+        return braw[(size_t)j * 8 + ewd];
+    };
+    auto expand_store = [&](uint32_t raw, int buf) __attribute__((always_inline)) {
+        uint8_t* dst = btile + buf * MF_TILE_BYTES + ej * MF_ROW_STRIDE + ewd * 16;
+        *reinterpret_cast<i32x4*>(dst) = expand_dword_fp4<false>(raw);
+    };
+    // lanes 0..31 of ONE wave: widen the 4 waves' 16-bit column results of tile t (tag = row within the wave)
+    // to (d << 23 | a-row), combine, and write the workgroup's partial
+    auto flush_columns = [&](int t) __attribute__((always_inline)) {
+        if (!DIRECTED && lane < MF_TILE_N && PLSLAM_MG_EXPERIMENT != 4) {
+            uint32_t k0 = KEY_NONE, k1 = KEY_NONE;
+#pragma unroll
+            for (int ww = 0; ww < 4; ++ww) {
+                const uint32_t e = colbuf[t & 1][ww][lane];
+                merge2(k0, k1, key16_to_key32(e & 0xFFFFu, 0u, (uint32_t)(i0 + 64 * ww), 1u),
+                       key16_to_key32(e >> 16, 0u, (uint32_t)(i0 + 64 * ww), 1u));
+            }
+            const int j = t * MF_TILE_N + lane;
+            if (j < n2) part[j] = u32x2_t{k0, k1};
+        }
+    };
+
+    // Epilogue of one accumulator register pair (rows LOC and LOC + 32 of the wave, column j0 + c): pack (= the
+    // keys of both directions: the tile number came in through the accumulator seed), ONE packed min into the
+    // group minimum of the row direction, 3 packed ops for the column best-2: 5 VALU ops per 2 distances.
+    // MASKED = false is the steady state (every row of this wave and every column of the tile exists).
+#define PLSLAM_MG_EPI_ROW(R)                                                                       \
+    {                                                                                              \
+        constexpr uint32_t LOC = ((R) & 3) + 8 * ((R) >> 2);                                       \
+        const float f0 = acc0[R], f1 = acc1[R];                                                    \
+        uint32_t kc = pack_acc(f0, f1, pack_sel);                                                  \
+        uint32_t kr = kc;                                                                          \
+        if (MASKED) {                                                                              \
+            kr = col_ok ? kr : 0xFFFFFFFFu;                                                        \
+            kc |= ((int)(ibase + LOC) < n1 ? 0u : 0x0000FFFFu) |                                   \
+                  ((int)(ibase + LOC + 32u) < n1 ? 0u : 0xFFFF0000u);                              \
+        }                                                                                          \
+        gm[R] = pk_min16(gm[R], kr);                                                               \
+        if (!DIRECTED) pk_push2(cb0, cb1, kc);                                                     \
+    }
+    {
+#define WT0 (MULTI ? wt0v : 0)
+#define WT1 (MULTI ? wt1v : ntiles)
+    // The 16-bit row keys hold 64 tile numbers, so the scan runs in WINDOWS of 64 tiles (2048 columns): after
+    // each window the row state is reduced, completed (second best) and merged into keys12, then restarted.
+    int wt0v = 0, wt1v = ntiles < 64 ? ntiles : 64;
+    uint32_t raw1 = 0u;                                    // raw b dword of tile t+1 of the coming step
+    // the group of 8 tiles is over: its minima go into the sorted pairs, the minima restart
+    auto push_groups = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pk_push2(rb[r][0], rb[r][1], gm[r]);
+            gm[r] = 0xFFFFFFFFu;
+        }
+    };
+    // column best-2 of a finished tile: the two halves of (cb0, cb1) are sorted streams over disjoint rows
+    // of the same column -> best 2 of the lane, then of the wave (lane ^ 32), as 16-bit keys
+    auto finish_columns = [&](int t, uint32_t cb0, uint32_t cb1) __attribute__((always_inline)) {
+        if (DIRECTED || PLSLAM_MG_EXPERIMENT == 6) { asm volatile("" ::"v"(cb0), "v"(cb1)); return; }
+        // every key of this tile carries + tile in its low 7 bits (no borrow: each half is >= tile; a "none" half
+        // 0xFFFF becomes 0xFFFF - tile > KEY16_MAX, still "none" for every later comparison and conversion)
+        const uint32_t tp = (uint32_t)(t - WT0) * 0x00010001u;
+        cb0 -= tp;
+        cb1 -= tp;
+        // Stay in the 16-bit domain: the tag of a column key is LOC (bits 0,1,3,4 of the row within the wave);
+        // OR-ing in bit 2 (= g) and bit 5 (= M-tile, the high halves) makes it the full row within the wave,
+        // so keys of the two halves and of lane ^ 32 compare directly (a "none" stays above KEY16_MAX).
+        cb0 |= ghtag;
+        cb1 |= ghtag;
+        const uint32_t e0 = cb0 & 0xFFFFu, o0 = cb0 >> 16, e1 = cb1 & 0xFFFFu, o1 = cb1 >> 16;
+        uint32_t m0 = umin_(e0, o0), m1 = umin_(umax_(e0, o0), umin_(e1, o1));
+        const uint32_t other = (uint32_t)__shfl_xor((int)(m0 | (m1 << 16)), 32);
+        merge2(m0, m1, other & 0xFFFFu, other >> 16);
+        if (lane < MF_TILE_N) colbuf[t & 1][w][lane] = m0 | (m1 << 16);
+    };
+    // E(t) on its own (the last tile of a window has no following M step to hide under)
+    auto epilogue = [&](int t, const f32x16& acc0, const f32x16& acc1, auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const bool col_ok = t * MF_TILE_N + c < n2;
+        uint32_t cb0 = 0xFFFFFFFFu, cb1 = 0xFFFFFFFFu;
+        PLSLAM_MG_EPI_ROW(0) PLSLAM_MG_EPI_ROW(1) PLSLAM_MG_EPI_ROW(2) PLSLAM_MG_EPI_ROW(3)
+        PLSLAM_MG_EPI_ROW(4) PLSLAM_MG_EPI_ROW(5) PLSLAM_MG_EPI_ROW(6) PLSLAM_MG_EPI_ROW(7)
+        PLSLAM_MG_EPI_ROW(8) PLSLAM_MG_EPI_ROW(9) PLSLAM_MG_EPI_ROW(10) PLSLAM_MG_EPI_ROW(11)
+        PLSLAM_MG_EPI_ROW(12) PLSLAM_MG_EPI_ROW(13) PLSLAM_MG_EPI_ROW(14) PLSLAM_MG_EPI_ROW(15)
+        finish_columns(t, cb0, cb1);
+    };
+    // One pipeline step = M(t) fused with E(t-1):
+    //   M(t): barrier, then the 8 MFMAs of tile t into (m0, m1); the raw dwords of tile t+2 are requested
+    //         and tile t+1 (requested one step earlier: its latency is off the critical path) is expanded;
+    //   E(t-1): bookkeeping of tile t-1 from ITS accumulators (acc0, acc1) -- independent of M(t).
+    auto step = [&](int t, f32x16& m0, f32x16& m1, const f32x16& acc0, const f32x16& acc1, bool with_prev,
+                    auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const uint32_t raw2 = t + 2 < WT1 ? load_raw(t + 2) : 0u;
+        if (PLSLAM_MG_EXPERIMENT != 1) __syncthreads();  // tile t expanded; colbuf of tile t-2 complete
+        if (t - WT0 > 1 && w == (t & 3)) flush_columns(t - 2);      // the waves take turns
+        const uint8_t* bt = btile + (t & 1) * MF_TILE_BYTES + c * MF_ROW_STRIDE + 16 * g;
+        const bool col_ok = (t - 1) * MF_TILE_N + c < n2;
+        uint32_t cb0 = 0xFFFFFFFFu, cb1 = 0xFFFFFFFFu;
+        i32x4 bf = *reinterpret_cast<const i32x4*>(bt);
+        // accumulator start: 2^23 + 16384 + LOC(reg) + tile within the window: the sum is 2^23 + 128 d + LOC + tile,
+        // every partial sum an integer below 2^24, so fp32 accumulation is exact and the float's low 16 bits ARE
+        // the key (d << 7 | LOC + tile).  Wave-uniform integers (scalar adds); built from integers through a scalar
+        // because __builtin_bit_cast applied to a vector ELEMENT is miscompiled by this toolchain (ROCm 7.2).
+        f32x16 cseed;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const uint32_t bits = ACC_BITS + (uint32_t)((r & 3) + 8 * (r >> 2)) + (uint32_t)(t - WT0);
+            const float f = __builtin_bit_cast(float, bits);
+            cseed[r] = f;
+        }
+#define PLSLAM_MG_MMA(ACC, MT, KS, CIN)                                                            \
+        {                                                                                          \
+            const i32x8 a8 = {afrag[MT][KS].x, afrag[MT][KS].y, afrag[MT][KS].z, afrag[MT][KS].w, 0, 0, 0, 0}; \
+            const i32x8 b8 = {bcur.x, bcur.y, bcur.z, bcur.w, 0, 0, 0, 0};                         \
+            if (PLSLAM_MG_EXPERIMENT != 3)                                                         \
+                ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, CIN, 4, 4, 0, scale_a, 0, scale_b); \
+            else { const f32x16 cin_ = CIN; ACC = cin_; ACC[KS] = __builtin_bit_cast(float, bcur.x ^ a8[0]); }               \
+        }
+#define PLSLAM_MG_KSTEP(KS, CIN0, CIN1)                                                            \
+        {                                                                                          \
+            const i32x4 bcur = bf;                                                                 \
+            if ((KS) < MF_KSTEPS - 1) bf = *reinterpret_cast<const i32x4*>(bt + 32 * ((KS) + 1));   \
+            PLSLAM_MG_MMA(m0, 0, KS, CIN0)                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            if (with_prev && PLSLAM_MG_EXPERIMENT != 2) { PLSLAM_MG_EPI_ROW(4 * (KS)) PLSLAM_MG_EPI_ROW(4 * (KS) + 1) } \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            PLSLAM_MG_MMA(m1, 1, KS, CIN1)                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+            if (with_prev && PLSLAM_MG_EXPERIMENT != 2) { PLSLAM_MG_EPI_ROW(4 * (KS) + 2) PLSLAM_MG_EPI_ROW(4 * (KS) + 3) } \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }
+        PLSLAM_MG_KSTEP(0, cseed, cseed)
+        PLSLAM_MG_KSTEP(1, m0, m1) PLSLAM_MG_KSTEP(2, m0, m1) PLSLAM_MG_KSTEP(3, m0, m1)
+#undef PLSLAM_MG_KSTEP
+#undef PLSLAM_MG_MMA
+        expand_store(raw1, (t + 1) & 1);           // past the last tile: a harmless rewrite of the idle buffer
+        raw1 = raw2;
+        if (PLSLAM_MG_EXPERIMENT == 2) asm volatile("" ::"v"(m0), "v"(m1));
+        if (with_prev) {
+            finish_columns(t - 1, cb0, cb1);
+            if (((t - 1 - WT0) & (MF_GROUP - 1)) == MF_GROUP - 1 && PLSLAM_MG_EXPERIMENT != 7) push_groups();   // wave-uniform: tile t-1 closed a group
+        }
+    };
+    // One window: S(WT0) | S(WT0+1)+E(WT0) | S(WT0+2)+E(WT0+1) | ... | E(WT1-1).  Two accumulator sets
+    // alternate (unrolled by two: no accumulator is ever copied).  Only the last tile of the scan can lack columns.
+    auto pipeline = [&](auto steady_tag) __attribute__((always_inline)) {
+        const bool last_partial = WT1 == ntiles && (n2 % MF_TILE_N) != 0;
+        f32x16 A0, A1, B0, B1;
+        step(WT0, A0, A1, A0, A1, false, steady_tag);
+        int t = WT0 + 1;
+        for (; t + 1 < WT1; t += 2) {
+            step(t, B0, B1, A0, A1, true, steady_tag);
+            step(t + 1, A0, A1, B0, B1, true, steady_tag);
+        }
+        // Loop exit: MFMA destination registers that are dead on some of the paths below may be reused at once; 16 idle
+        // cycles keep the distance the compiler itself keeps in front of its accumulator reads (see hamming_mfma.hip).
+        asm volatile("s_nop 7\n\ts_nop 7");
+        // The trailing epilogue writes colbuf[(WT1-1) & 1], which the flush of tile WT1-3 READS at the start of the last
+        // step: a barrier must lie between them (see hamming_mfma.hip).
+        if (t < WT1) {                             // t == WT1 - 1: one more tile, into set B
+            step(t, B0, B1, A0, A1, true, steady_tag);
+            __syncthreads();
+            if (last_partial) epilogue(t, B0, B1, std::true_type{}); else epilogue(t, B0, B1, steady_tag);
+        } else {                                   // tile WT1 - 1 is in set A
+            __syncthreads();
+            if (last_partial) epilogue(t - 1, A0, A1, std::true_type{}); else epilogue(t - 1, A0, A1, steady_tag);
+        }
+        push_groups();                             // the (possibly partial, possibly empty) last group
+    };
+    // Row results of a window.  Every lane holds, per accumulator register, the best two GROUP minima (16-bit keys
+    // (d, tile + LOC)) of ITS column class for two rows.  Transpose through LDS so that one lane owns one row: lane l
+    // reads the 32 class entries of row l in class order, widens them to (key16 << 16 | class) -- which orders like
+    // (d, j = 32 tile + class) because every entry of a row carries the same LOC -- and keeps the best two.  The
+    // first is the row's best key; the second is the best key OUTSIDE the winner's group, so the lane then visits
+    // the other 7 columns of the winner's group (same class, the other tiles of the group) and recomputes their
+    // distances from the raw rows: second best = min of the two.  Callers guarantee that all waves are past their
+    // last operand read of `smem`; the region used here is private to the wave.
+    auto finish_rows = [&]() __attribute__((always_inline)) {
+        uint32_t* rowx = reinterpret_cast<uint32_t*>(smem) + w * (64 * ROWX_STRIDE);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lrow = (r & 3) + 8 * (r >> 2) + 4 * g;
+            // (best | second << 16) of M-tile 0 (low halves) and of M-tile 1 (high halves)
+            rowx[lrow * ROWX_STRIDE + c] = (rb[r][0] & 0xFFFFu) | (rb[r][1] << 16);
+            rowx[(32 + lrow) * ROWX_STRIDE + c] = (rb[r][0] >> 16) | (rb[r][1] & 0xFFFF0000u);
+            rb[r][0] = rb[r][1] = 0xFFFFFFFFu;                  // restart for the next window
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+        const uint32_t* mine = rowx + lane * ROWX_STRIDE;
+#pragma unroll 8
+        for (int cls = 0; cls < 32; ++cls) {
+            const uint32_t e = mine[cls];
+            merge2(k0, k1, (e << 16) | (uint32_t)cls, (e & 0xFFFF0000u) | (uint32_t)cls);
+        }
+        // (key16 << 16 | class) -> (d << 23 | 32 (WT0 + tag - LOC) + class); LOC of local row l: l without bit 2 (= g)
+        const uint32_t loc = (uint32_t)(lane & 31 & ~4);
+        auto widen = [&](uint32_t k) -> uint32_t {
+            const uint32_t k16 = k >> 16, cls = k & 0xFFFFu;
+            return key16_to_key32(k16, loc, cls + (uint32_t)(WT0 * MF_TILE_N), (uint32_t)MF_TILE_N);
+        };
+        const int row = iw + lane;
+        if (row < n1) {
+            const gu2_t out = (gu2_t) reinterpret_cast<u32x2_t*>(sd.keys12) + row;
+            uint32_t r0 = widen(k0), r1 = widen(k1);
+            if ((k0 >> 16) <= KEY16_MAX && PLSLAM_MG_EXPERIMENT != 5) {
+                // the other members of the winner's group: tiles g0 .. g0 + 7 of the window, same class
+                const uint32_t cls0 = k0 & 0xFFFFu;
+                const uint32_t tw = ((k0 >> 16) & 127u) - loc;              // winner's tile within the window
+                const uint32_t g0 = (uint32_t)WT0 + (tw & ~(uint32_t)(MF_GROUP - 1));
+                const gcu32x4_t ap = (gcu32x4_t)(araw + (size_t)row * 8);
+                const u32x4_t a_lo = ap[0], a_hi = ap[1];
+#pragma unroll
+                for (int k = 0; k < MF_GROUP; ++k) {
+                    const uint32_t tile = g0 + (uint32_t)k;
+                    const uint32_t j = tile * MF_TILE_N + cls0;
+                    const bool ok = (uint32_t)k != (tw & (uint32_t)(MF_GROUP - 1)) && tile < (uint32_t)WT1 && j < (uint32_t)n2;
+                    const gcu32x4_t bp = (gcu32x4_t)(braw + (size_t)(ok ? j : 0u) * 8);
+                    const u32x4_t b_lo = bp[0], b_hi = bp[1];
+                    uint32_t d = bcnt_acc_(a_lo.x ^ b_lo.x, 0u);
+                    d = bcnt_acc_(a_lo.y ^ b_lo.y, d);
+                    d = bcnt_acc_(a_lo.z ^ b_lo.z, d);
+                    d = bcnt_acc_(a_lo.w ^ b_lo.w, d);
+                    d = bcnt_acc_(a_hi.x ^ b_hi.x, d);
+                    d = bcnt_acc_(a_hi.y ^ b_hi.y, d);
+                    d = bcnt_acc_(a_hi.z ^ b_hi.z, d);
+                    d = bcnt_acc_(a_hi.w ^ b_hi.w, d);
+                    const uint32_t cand = ok ? ((d << KEY_IDX_BITS) | j) : KEY_NONE;
+                    r1 = umin_(r1, cand);
+                }
+            }
+            if (WT0 > 0) {                                  // later windows: merge with the windows before
+                const u32x2_t prev = *out;
+                merge2(r0, r1, prev.x, prev.y);
+            }
+            *out = u32x2_t{r0, r1};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (;;) {
+        expand_store(load_raw(WT0), 0);            // WT0 is a multiple of 64: buffer parity restarts at 0
+        raw1 = WT0 + 1 < WT1 ? load_raw(WT0 + 1) : 0u;
+        if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
+        // the last two tiles' column partials of the window are still in LDS
+        __syncthreads();
+        if (WT1 - WT0 > 1 && w == (WT1 & 3)) flush_columns(WT1 - 2);
+        if (w == ((WT1 + 1) & 3)) flush_columns(WT1 - 1);
+        finish_rows();
+        if (!MULTI || wt1v == ntiles) break;
+        __syncthreads();                           // smem becomes the b tile again; colbuf is free
+        wt0v = wt1v;
+        wt1v = ntiles < wt0v + 64 ? ntiles : wt0v + 64;
+    }
+#undef WT0
+#undef WT1
+    }
+#undef PLSLAM_MG_EPI_ROW
+}
+
+int launch_scan_sym_mfma_g(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
+                           int nzero, bool multi_window, bool directed, hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+#define PLSLAM_MG_LAUNCH(M, D) \
+    hipLaunchKernelGGL((k_scan_sym_mfma_g<M, D>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero)
+    if (multi_window) { if (directed) PLSLAM_MG_LAUNCH(true, true); else PLSLAM_MG_LAUNCH(true, false); }
+    else              { if (directed) PLSLAM_MG_LAUNCH(false, true); else PLSLAM_MG_LAUNCH(false, false); }
+#undef PLSLAM_MG_LAUNCH
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+}  // namespace plslam

@@ -84,16 +84,20 @@ def test_symmetric_and_directed_variants_agree(ctx, oracle, n1, n2):
             d2[:k] = d1[:k] ^ np.packbits(r.random((k, 256)) < 0.06, axis=1)
         em, en = oracle.match(d1, d2, 0.9, True)
         try:
-            for variant, sym_rows in ((plslam_amd.SCAN_MFMA, 0), (plslam_amd.SCAN_SYMMETRIC, 4), (plslam_amd.SCAN_SYMMETRIC, 1),
-                                      (plslam_amd.SCAN_LANE_PER_QUERY, 1), (plslam_amd.SCAN_WAVE_PER_QUERY, 1),
-                                      (plslam_amd.SCAN_AUTO, 1)):
+            # (variant, sym_rows, mfma_form): mfma_form 2 = K1f (group minima, the default), 1 = K1e (push per tile)
+            for variant, sym_rows, form in ((plslam_amd.SCAN_MFMA, 0, 2), (plslam_amd.SCAN_MFMA, 0, 1),
+                                            (plslam_amd.SCAN_SYMMETRIC, 4, 0), (plslam_amd.SCAN_SYMMETRIC, 1, 0),
+                                            (plslam_amd.SCAN_LANE_PER_QUERY, 1, 0), (plslam_amd.SCAN_WAVE_PER_QUERY, 1, 0),
+                                            (plslam_amd.SCAN_AUTO, 1, 0)):
                 ctx.set_option("scan_variant", variant)
                 ctx.set_option("sym_rows", sym_rows)
+                ctx.set_option("mfma_form", form)
                 m, n = ctx.match(d1, d2, 0.9, True)
-                assert np.array_equal(m, em) and n == en, (variant, sym_rows, gen.__name__)
+                assert np.array_equal(m, em) and n == en, (variant, sym_rows, form, gen.__name__)
         finally:
             ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
             ctx.set_option("sym_rows", 0)
+            ctx.set_option("mfma_form", 0)
 
 
 def test_all_scan_block_sizes(ctx, oracle):
@@ -113,17 +117,28 @@ def test_all_scan_block_sizes(ctx, oracle):
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
 
 
-@pytest.fixture(params=["auto", "lane_per_query", "wave_per_query", "symmetric", "mfma"])
+@pytest.fixture(params=["auto", "lane_per_query", "wave_per_query", "symmetric", "mfma", "mfma_k1e"])
 def vctx(ctx, request):
     """The context with each scan variant forced in turn (AUTO picks wave-per-query for plans too
     small to fill the chip, the symmetric scan for mutual problems otherwise)."""
     import plslam_amd
     v = {"auto": plslam_amd.SCAN_AUTO, "lane_per_query": plslam_amd.SCAN_LANE_PER_QUERY,
          "wave_per_query": plslam_amd.SCAN_WAVE_PER_QUERY, "symmetric": plslam_amd.SCAN_SYMMETRIC,
-         "mfma": plslam_amd.SCAN_MFMA}[request.param]
+         "mfma": plslam_amd.SCAN_MFMA, "mfma_k1e": plslam_amd.SCAN_MFMA}[request.param]
     ctx.set_option("scan_variant", v)
+    ctx.set_option("mfma_form", 1 if request.param == "mfma_k1e" else 0)   # default form = K1f (group minima)
     yield ctx
     ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+    ctx.set_option("mfma_form", 0)
+
+
+@pytest.fixture(params=[2, 1], ids=["k1f", "k1e"])
+def mform(ctx, request):
+    """Both bookkeeping forms of the matrix-core scan: 2 = K1f (group minima + recomputed second best, the default),
+    1 = K1e (best-2 push per tile)."""
+    ctx.set_option("mfma_form", request.param)
+    yield request.param
+    ctx.set_option("mfma_form", 0)
 
 
 def test_c2_full_size_pair_bit_exact(vctx, oracle):
@@ -240,7 +255,7 @@ def test_device_resident_plan_matches_oracle(vctx, oracle):
 
 @pytest.mark.parametrize("n_orb,n_lbd,expect", [(2048, 33, "mfma"), (2049, 33, "mfma"), (1999, 1, "mfma"),
                                                   (96, 2048, "mfma"), (31, 32, "mfma"), (4130, 65, "mfma")])
-def test_matrix_core_scan_limits(ctx, oracle, n_orb, n_lbd, expect):
+def test_matrix_core_scan_limits(ctx, oracle, mform, n_orb, n_lbd, expect):
     """K1e keeps 16-bit (distance, tile) row keys, so it scans in windows of 64 tiles (2048 columns) and merges
     the row results of successive windows.  At n2 = 2048 every tile number of one window is used; 2049 starts a
     second window with a single column; 4130 needs three.  Tie-stress data (many equal distances, so that
@@ -266,7 +281,7 @@ def test_matrix_core_scan_limits(ctx, oracle, n_orb, n_lbd, expect):
     bm.close()
 
 
-def test_matrix_core_scan_extreme_distances(ctx, oracle):
+def test_matrix_core_scan_extreme_distances(ctx, oracle, mform):
     """Distances 0 and 256 (exact complements) and rows of all zeros / all ones: the +-1 byte contraction
     must give exactly 2 d in [0, 512] and the keys must not wrap."""
     import plslam_amd
@@ -290,7 +305,7 @@ def test_matrix_core_scan_extreme_distances(ctx, oracle):
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
 
 
-def test_directed_matrix_core_paths(ctx, oracle):
+def test_directed_matrix_core_paths(ctx, oracle, mform):
     """Non-mutual problems and plain knnMatch(k=2) on the directed form of K1e: a large query set under AUTO
     (66 000 queries -> past the latency-kernel threshold), a multi-window train set, ties, and a batched
     non-mutual plan next to mutual problems."""
@@ -374,7 +389,7 @@ def test_fuzz_all_variants_vs_oracle(ctx, oracle):
 
 
 @pytest.mark.parametrize("n_orb,n_lbd,pairs,mutual", [(256, 256, 128, True), (800, 100, 64, True), (256, 256, 128, False)])
-def test_batched_scan_is_deterministic_under_load(ctx, n_orb, n_lbd, pairs, mutual):
+def test_batched_scan_is_deterministic_under_load(ctx, mform, n_orb, n_lbd, pairs, mutual):
     """Two overlapped plans (several workgroups per CU), repeated: every intermediate key word, column partial
     and table entry must repeat exactly.  Regression for the K1e symmetric scan's exec-masked column store, which
     made ~1 % of the key words differ from run to run while every single-problem parity test
@@ -387,6 +402,41 @@ def test_batched_scan_is_deterministic_under_load(ctx, n_orb, n_lbd, pairs, mutu
     r = mod.check(ctx, n_orb, n_lbd, pairs, rounds=8, nnr=0.9, mutual=mutual)
     assert r["key_words"] > 0
     assert (r["key_diffs"], r["partial_diffs"], r["table_diffs"]) == (0, 0, 0), r
+
+
+@pytest.mark.parametrize("n_orb,n_lbd,pairs,mutual", [(1500, 200, 24, True), (300, 70, 96, True), (2100, 33, 8, True),
+                                                        (257, 4130, 4, True), (777, 130, 32, False), (40, 2500, 16, False)])
+def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs, mutual):
+    """K1f (group minima; the second best of the winner's group recomputed from the raw rows) against K1e (every key
+    pushed): not only the match tables but every intermediate word -- keys12 = (best, second best) per row with the
+    second best's INDEX, and the per-row-block column partials -- must be identical, on tie-heavy data, ragged sizes,
+    several windows (n2 > 2048) and the directed form."""
+    import torch
+    import plslam_amd
+    s = synth.stereo_stream(pairs, n_orb, n_lbd, seed=4242 + n_orb, tie_stress=(n_orb % 2 == 1))
+    got = {}
+    try:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)
+        for form in (1, 2):
+            ctx.set_option("mfma_form", form)
+            bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.85, nnr_l=0.9, mutual=mutual)
+            tab = bm.run()
+            torch.cuda.synchronize()
+            keys, part = bm.plan.dump()
+            got[form] = (keys.copy(), part.copy(), tab.cpu().numpy().copy())
+            bm.close()
+    finally:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+        ctx.set_option("mfma_form", 0)
+    # the dump returns the buffers with their 25 % growth slack: compare the words the kernels write
+    rows = pairs * 2 * ((n_orb + n_lbd) * (2 if mutual else 1))
+    prows = pairs * 2 * (-(-n_orb // 256) * n_orb + -(-n_lbd // 256) * n_lbd) if mutual else 0
+    assert got[1][0].size >= 2 * rows and got[1][1].size >= 2 * prows
+    k1, k2 = got[1][0][:2 * rows], got[2][0][:2 * rows]
+    assert np.array_equal(k1, k2), int((k1 != k2).sum())
+    p1, p2 = got[1][1][:2 * prows], got[2][1][:2 * prows]
+    assert np.array_equal(p1, p2), int((p1 != p2).sum())
+    assert np.array_equal(got[1][2], got[2][2])
 
 
 def test_batched_tables_equal_oracle_at_loose_ratio(ctx, oracle):
