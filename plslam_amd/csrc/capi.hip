@@ -150,6 +150,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             if (is_sym(probs[i])) waves4 += (probs[i].n1 + 255) / 256;
         P->sym_rows = waves4 >= 6 * 17 * (int64_t)ctx->prop.multiProcessorCount ? 4 : 1;
     }
+    const bool k1f = P->sym_mfma && P->mfma_form != 1;   // K1f: column partials per 64-row block, 16-bit keys
     const int rpp = sym_rows_per_partial(P->sym_rows);   // a-rows per column partial
     const int rps = sym_rows_per_block(P->sym_rows);     // a-rows per workgroup of the symmetric scan
     int64_t rows = 0, part_rows = 0;
@@ -164,7 +165,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         PLSLAM_REQUIRE(p.n2 <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
         PLSLAM_REQUIRE(!p.mutual || p.n1 <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
         rows += p.n1 + (p.mutual ? p.n2 : 0);
-        if (is_sym(p)) part_rows += (int64_t)((p.n1 + rpp - 1) / rpp) * p.n2;
+        if (is_sym(p)) part_rows += (int64_t)((p.n1 + rpp - 1) / rpp) * p.n2 * (k1f ? 2 : 1);   // K1f: a dword per 64 rows
     }
     PLSLAM_REQUIRE(rows < (int64_t(1) << 31), PLSLAM_ERANGE);
 
@@ -226,7 +227,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             y.a = p.d1; y.b = p.d2; y.keys12 = k12; y.keys21 = k21;
             y.part21 = d_part + 2 * part_row;
             y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = (p.n1 + rpp - 1) / rpp;
-            part_row += (int64_t)y.n_iblk * p.n2;
+            part_row += (int64_t)y.n_iblk * p.n2 * (k1f ? 2 : 1);
             for (int32_t r0 = 0; r0 < p.n1; r0 += rps) yblocks.push_back({(int32_t)syms.size(), r0});
             for (int32_t c0 = 0; c0 < p.n2; c0 += 256) mblocks.push_back({(int32_t)syms.size(), c0});
             syms.push_back(y);
@@ -423,7 +424,8 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
         if (r) return r;
     }
     if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e1, s));   // e0..e1 = the scan kernel(s) alone
-    r = launch_merge_partials(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s);
+    r = P->sym_mfma && P->mfma_form != 1 ? launch_merge_partials16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s)
+                                         : launch_merge_partials(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s);
     if (r) return r;
     r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, s);
     if (r) return r;

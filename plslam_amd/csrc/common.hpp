@@ -153,6 +153,7 @@ int launch_scan_sym_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nb
 // K1f (hamming_mfma_g.hip): same contract and tables as K1e; row direction = group minima + second best by recomputation
 int launch_scan_sym_mfma_g(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
                            int nzero, bool multi_window, bool directed, hipStream_t s);
+int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s);
 inline int launch_scan_mfma_form(int form, const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
                                  int nzero, bool multi_window, bool directed, hipStream_t s)
 {

@@ -34,7 +34,7 @@
 #include <type_traits>
 
 // build-time experiments for tools/scan_time.py / tools/build_exp.py (results are WRONG with any of them on):
-//   1 no workgroup barrier   2 no epilogue (bookkeeping)   3 no MFMA   4 no column flush   5 no second-best fix-up
+//   1 no workgroup barrier   2 no epilogue (bookkeeping)   3 no MFMA   4 no column store   5 no second-best fix-up
 //   6 no finish_columns      7 no group push
 #ifndef PLSLAM_MG_EXPERIMENT
 #define PLSLAM_MG_EXPERIMENT 0
@@ -55,6 +55,7 @@ typedef const PLSLAM_GLOBAL uint32_t* gcu32_t;
 typedef const PLSLAM_GLOBAL u32x4_t* gcu32x4_t;
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef PLSLAM_GLOBAL u32x2_t* gu2_t;
+typedef PLSLAM_GLOBAL uint32_t* gu32_t;
 
 namespace {
 
@@ -142,12 +143,16 @@ __global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unifi
 k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
                   int32_t* __restrict__ zero, int nzero)
 {
-    // one buffer, two lives: the double-buffered b tile during the scan (9 216 B), the row-result transpose
-    // [wave][row 0..63][33] after it (33 792 B)
+    // one buffer, two lives: during the scan the double-buffered b tile (9 216 B) followed by the PARKED sorted pairs of the
+    // row direction ([wave][reg][lane] x 8 B = 32 768 B: they are touched once per 8 tiles, so they live here and not in
+    // 32 VGPRs); after the scan the row-result transpose [wave][row 0..63][33] (33 792 B) over both
     constexpr int ROWX_STRIDE = 33;               // dwords per row: lane = row reads are conflict-free
-    __shared__ __attribute__((aligned(16))) uint8_t smem[4 * 64 * ROWX_STRIDE * 4];
+    constexpr int PARK_OFF = 2 * MF_TILE_BYTES;
+    constexpr int SMEM_BYTES = PARK_OFF + 4 * 16 * 64 * 8;
+    static_assert(SMEM_BYTES >= 4 * 64 * ROWX_STRIDE * 4, "the transpose must fit");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
     uint8_t* const btile = smem;
-    __shared__ uint32_t colbuf[2][4][MF_TILE_N];  // [tile & 1][wave][column] = best | second << 16    1 024 B
+    u32x2_t* const park = reinterpret_cast<u32x2_t*>(smem + PARK_OFF) + (threadIdx.x >> 6) * (16 * 64) + (threadIdx.x & 63);
 
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
@@ -181,15 +186,19 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 
     // row-direction state per accumulator register r (M-tile 0 in the low halves, M-tile 1 in the high halves):
     //   gm[r]    running minimum of the 16-bit keys (d << 7 | tile + LOC) of the current group of 8 tiles
-    //   rb[r][2] the best two GROUP minima of the lane's column class
-    uint32_t gm[16], rb[16][2];
+    //   park[r]  (LDS) the best two GROUP minima of the lane's column class
+    uint32_t gm[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gm[r] = rb[r][0] = rb[r][1] = 0xFFFFFFFFu;
+    for (int r = 0; r < 16; ++r) gm[r] = 0xFFFFFFFFu;
 
     const bool rows_ragged = iw + 64 > n1;         // wave-uniform: some of this wave's rows do not exist
     const uint32_t ibase = (uint32_t)(iw + 4 * g); // + local index = a-row of an accumulator
     const uint32_t ghtag = (uint32_t)(4 * g) | ((uint32_t)(4 * g + 32) << 16);   // see finish_columns
-    const gu2_t part = DIRECTED ? (gu2_t) nullptr : (gu2_t) reinterpret_cast<u32x2_t*>(sd.part21) + (size_t)(i0 >> 8) * n2;
+    // column partials of THIS WAVE's 64 rows: part16[(row block of 64)][column] = best | second << 16 as 16-bit keys
+    // (d << 7 | row within the block); the merge kernel (k_merge_partials16) widens and combines them.  Every wave writes
+    // its own results straight from registers: no LDS exchange between the waves, no flush step on the tile's critical path.
+    const gu32_t part = DIRECTED ? (gu32_t) nullptr : (gu32_t) sd.part21 + (size_t)(iw >> 6) * n2;
+    const bool wave_has_rows = iw < n1;
 
     // expansion duty of this lane: b row (tid >> 3) of the tile, dword (tid & 7) of it
     const int ej = tid >> 3, ewd = tid & 7;
@@ -203,39 +212,23 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         uint8_t* dst = btile + buf * MF_TILE_BYTES + ej * MF_ROW_STRIDE + ewd * 16;
         *reinterpret_cast<i32x4*>(dst) = expand_dword_fp4<false>(raw);
     };
-    // lanes 0..31 of ONE wave: widen the 4 waves' 16-bit column results of tile t (tag = row within the wave)
-    // to (d << 23 | a-row), combine, and write the workgroup's partial
-    auto flush_columns = [&](int t) __attribute__((always_inline)) {
-        if (!DIRECTED && lane < MF_TILE_N && PLSLAM_MG_EXPERIMENT != 4) {
-            uint32_t k0 = KEY_NONE, k1 = KEY_NONE;
-#pragma unroll
-            for (int ww = 0; ww < 4; ++ww) {
-                const uint32_t e = colbuf[t & 1][ww][lane];
-                merge2(k0, k1, key16_to_key32(e & 0xFFFFu, 0u, (uint32_t)(i0 + 64 * ww), 1u),
-                       key16_to_key32(e >> 16, 0u, (uint32_t)(i0 + 64 * ww), 1u));
-            }
-            const int j = t * MF_TILE_N + lane;
-            if (j < n2) part[j] = u32x2_t{k0, k1};
-        }
-    };
-
-    // Epilogue of one accumulator register pair (rows LOC and LOC + 32 of the wave, column j0 + c): pack (= the
-    // keys of both directions: the tile number came in through the accumulator seed), ONE packed min into the
-    // group minimum of the row direction, 3 packed ops for the column best-2: 5 VALU ops per 2 distances.
-    // MASKED = false is the steady state (every row of this wave and every column of the tile exists).
+    // Bookkeeping of one packed key pair (rows LOC and LOC + 32 of the wave, column j0 + c).  kc[R] was packed from the
+    // accumulators right after the tile's MFMAs (pack_tile) and holds the keys of BOTH directions (the tile number came
+    // in through the accumulator seed): ONE packed min into the group minimum of the row direction, 3 packed ops for the
+    // column best-2: 4 VALU ops per 2 distances (+ the pack).  MASKED = false is the steady state (every row of this
+    // wave and every column of the tile exists).
 #define PLSLAM_MG_EPI_ROW(R)                                                                       \
     {                                                                                              \
         constexpr uint32_t LOC = ((R) & 3) + 8 * ((R) >> 2);                                       \
-        const float f0 = acc0[R], f1 = acc1[R];                                                    \
-        uint32_t kc = pack_acc(f0, f1, pack_sel);                                                  \
-        uint32_t kr = kc;                                                                          \
+        uint32_t kcv = kc[R];                                                                      \
+        uint32_t kr = kcv;                                                                         \
         if (MASKED) {                                                                              \
             kr = col_ok ? kr : 0xFFFFFFFFu;                                                        \
-            kc |= ((int)(ibase + LOC) < n1 ? 0u : 0x0000FFFFu) |                                   \
-                  ((int)(ibase + LOC + 32u) < n1 ? 0u : 0xFFFF0000u);                              \
+            kcv |= ((int)(ibase + LOC) < n1 ? 0u : 0x0000FFFFu) |                                  \
+                   ((int)(ibase + LOC + 32u) < n1 ? 0u : 0xFFFF0000u);                             \
         }                                                                                          \
         gm[R] = pk_min16(gm[R], kr);                                                               \
-        if (!DIRECTED) pk_push2(cb0, cb1, kc);                                                     \
+        if (!DIRECTED) pk_push2(cb0, cb1, kcv);                                                    \
     }
     {
 #define WT0 (MULTI ? wt0v : 0)
@@ -248,7 +241,10 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     auto push_groups = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            pk_push2(rb[r][0], rb[r][1], gm[r]);
+            const u32x2_t v = park[r * 64];
+            uint32_t b0 = v.x, b1 = v.y;
+            pk_push2(b0, b1, gm[r]);
+            park[r * 64] = u32x2_t{b0, b1};
             gm[r] = 0xFFFFFFFFu;
         }
     };
@@ -270,29 +266,22 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         uint32_t m0 = umin_(e0, o0), m1 = umin_(umax_(e0, o0), umin_(e1, o1));
         const uint32_t other = (uint32_t)__shfl_xor((int)(m0 | (m1 << 16)), 32);
         merge2(m0, m1, other & 0xFFFFu, other >> 16);
-        if (lane < MF_TILE_N) colbuf[t & 1][w][lane] = m0 | (m1 << 16);
+        const int j = t * MF_TILE_N + lane;
+        if (lane < MF_TILE_N && j < n2 && wave_has_rows && PLSLAM_MG_EXPERIMENT != 4) part[j] = m0 | (m1 << 16);
     };
-    // E(t) on its own (the last tile of a window has no following M step to hide under)
-    auto epilogue = [&](int t, const f32x16& acc0, const f32x16& acc1, auto masked_tag) __attribute__((always_inline)) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
-        const bool col_ok = t * MF_TILE_N + c < n2;
-        uint32_t cb0 = 0xFFFFFFFFu, cb1 = 0xFFFFFFFFu;
-        PLSLAM_MG_EPI_ROW(0) PLSLAM_MG_EPI_ROW(1) PLSLAM_MG_EPI_ROW(2) PLSLAM_MG_EPI_ROW(3)
-        PLSLAM_MG_EPI_ROW(4) PLSLAM_MG_EPI_ROW(5) PLSLAM_MG_EPI_ROW(6) PLSLAM_MG_EPI_ROW(7)
-        PLSLAM_MG_EPI_ROW(8) PLSLAM_MG_EPI_ROW(9) PLSLAM_MG_EPI_ROW(10) PLSLAM_MG_EPI_ROW(11)
-        PLSLAM_MG_EPI_ROW(12) PLSLAM_MG_EPI_ROW(13) PLSLAM_MG_EPI_ROW(14) PLSLAM_MG_EPI_ROW(15)
-        finish_columns(t, cb0, cb1);
-    };
-    // One pipeline step = M(t) fused with E(t-1):
-    //   M(t): barrier, then the 8 MFMAs of tile t into (m0, m1); the raw dwords of tile t+2 are requested
-    //         and tile t+1 (requested one step earlier: its latency is off the critical path) is expanded;
-    //   E(t-1): bookkeeping of tile t-1 from ITS accumulators (acc0, acc1) -- independent of M(t).
-    auto step = [&](int t, f32x16& m0, f32x16& m1, const f32x16& acc0, const f32x16& acc1, bool with_prev,
-                    auto masked_tag) __attribute__((always_inline)) {
+    // Software pipeline, ONE accumulator set.  A tile's life:  M(t): 8 MFMAs -> P(t): 16 v_perm pack the 32 accumulators
+    // into 16 key pairs kc[] (the accumulator registers are free again) -> E(t): bookkeeping from kc[], issued BETWEEN the
+    // MFMAs of M(t+1).  So a wave has matrix work and VALU work in flight at the same time with 32 + 16 live registers
+    // instead of two accumulator sets (round 1's two-set form collapsed into [8 MFMA][wait][bookkeeping] under the
+    // 168-register budget: nothing overlapped inside a wave, and once the bookkeeping shrank the scan stopped following
+    // the VALU instruction count).  What sits between the last MFMA of M(t) and P(t) -- the expansion of tile t+1, the
+    // column results of tile t-1 -- covers the matrix pipe's latency.
+    //   step(t) = barrier | operand reads | seeds | M(t) x E(t-1) | expand(t+1) | finish_columns(t-1) | P(t)
+    uint32_t kc[16];
+    auto tile_step = [&](int t, bool with_prev, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
         const uint32_t raw2 = t + 2 < WT1 ? load_raw(t + 2) : 0u;
-        if (PLSLAM_MG_EXPERIMENT != 1) __syncthreads();  // tile t expanded; colbuf of tile t-2 complete
-        if (t - WT0 > 1 && w == (t & 3)) flush_columns(t - 2);      // the waves take turns
+        if (PLSLAM_MG_EXPERIMENT != 1) __syncthreads();  // tile t expanded; every wave is past its reads of the other buffer
         const uint8_t* bt = btile + (t & 1) * MF_TILE_BYTES + c * MF_ROW_STRIDE + 16 * g;
         const bool col_ok = (t - 1) * MF_TILE_N + c < n2;
         uint32_t cb0 = 0xFFFFFFFFu, cb1 = 0xFFFFFFFFu;
@@ -301,7 +290,7 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         // every partial sum an integer below 2^24, so fp32 accumulation is exact and the float's low 16 bits ARE
         // the key (d << 7 | LOC + tile).  Wave-uniform integers (scalar adds); built from integers through a scalar
         // because __builtin_bit_cast applied to a vector ELEMENT is miscompiled by this toolchain (ROCm 7.2).
-        f32x16 cseed;
+        f32x16 cseed, m0, m1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const uint32_t bits = ACC_BITS + (uint32_t)((r & 3) + 8 * (r >> 2)) + (uint32_t)(t - WT0);
@@ -314,7 +303,10 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             const i32x8 b8 = {bcur.x, bcur.y, bcur.z, bcur.w, 0, 0, 0, 0};                         \
             if (PLSLAM_MG_EXPERIMENT != 3)                                                         \
                 ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, CIN, 4, 4, 0, scale_a, 0, scale_b); \
-            else { const f32x16 cin_ = CIN; ACC = cin_; ACC[KS] = __builtin_bit_cast(float, bcur.x ^ a8[0]); }               \
+            else { const f32x16 cin_ = CIN; ACC = cin_; ACC[KS] = __builtin_bit_cast(float, bcur.x ^ a8[0]); } \
+            /* an EMPTY asm (no instruction): pins the MFMA here -- without a use in this block the optimizer sinks all */ \
+            /* eight MFMAs of a tile down to the pack, i.e. behind the bookkeeping they are meant to overlap with */ \
+            asm volatile("" : "+v"(ACC));                                                          \
         }
 #define PLSLAM_MG_KSTEP(KS, CIN0, CIN1)                                                            \
         {                                                                                          \
@@ -335,36 +327,35 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #undef PLSLAM_MG_MMA
         expand_store(raw1, (t + 1) & 1);           // past the last tile: a harmless rewrite of the idle buffer
         raw1 = raw2;
-        if (PLSLAM_MG_EXPERIMENT == 2) asm volatile("" ::"v"(m0), "v"(m1));
         if (with_prev) {
             finish_columns(t - 1, cb0, cb1);
             if (((t - 1 - WT0) & (MF_GROUP - 1)) == MF_GROUP - 1 && PLSLAM_MG_EXPERIMENT != 7) push_groups();   // wave-uniform: tile t-1 closed a group
         }
+        // P(t): the key pairs of tile t; the accumulators are dead from here on
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float f0 = m0[r], f1 = m1[r];
+            kc[r] = pack_acc(f0, f1, pack_sel);
+        }
     };
-    // One window: S(WT0) | S(WT0+1)+E(WT0) | S(WT0+2)+E(WT0+1) | ... | E(WT1-1).  Two accumulator sets
-    // alternate (unrolled by two: no accumulator is ever copied).  Only the last tile of the scan can lack columns.
+    // E(t) on its own (the last tile of a window has no following M step to hide under)
+    auto epilogue = [&](int t, auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const bool col_ok = t * MF_TILE_N + c < n2;
+        uint32_t cb0 = 0xFFFFFFFFu, cb1 = 0xFFFFFFFFu;
+        PLSLAM_MG_EPI_ROW(0) PLSLAM_MG_EPI_ROW(1) PLSLAM_MG_EPI_ROW(2) PLSLAM_MG_EPI_ROW(3)
+        PLSLAM_MG_EPI_ROW(4) PLSLAM_MG_EPI_ROW(5) PLSLAM_MG_EPI_ROW(6) PLSLAM_MG_EPI_ROW(7)
+        PLSLAM_MG_EPI_ROW(8) PLSLAM_MG_EPI_ROW(9) PLSLAM_MG_EPI_ROW(10) PLSLAM_MG_EPI_ROW(11)
+        PLSLAM_MG_EPI_ROW(12) PLSLAM_MG_EPI_ROW(13) PLSLAM_MG_EPI_ROW(14) PLSLAM_MG_EPI_ROW(15)
+        finish_columns(t, cb0, cb1);
+    };
+    // One window: M(WT0) P | M(WT0+1) x E(WT0) P | ... | M(WT1-1) x E(WT1-2) P | E(WT1-1).  Only the last tile of the
+    // scan can lack columns.
     auto pipeline = [&](auto steady_tag) __attribute__((always_inline)) {
         const bool last_partial = WT1 == ntiles && (n2 % MF_TILE_N) != 0;
-        f32x16 A0, A1, B0, B1;
-        step(WT0, A0, A1, A0, A1, false, steady_tag);
-        int t = WT0 + 1;
-        for (; t + 1 < WT1; t += 2) {
-            step(t, B0, B1, A0, A1, true, steady_tag);
-            step(t + 1, A0, A1, B0, B1, true, steady_tag);
-        }
-        // Loop exit: MFMA destination registers that are dead on some of the paths below may be reused at once; 16 idle
-        // cycles keep the distance the compiler itself keeps in front of its accumulator reads (see hamming_mfma.hip).
-        asm volatile("s_nop 7\n\ts_nop 7");
-        // The trailing epilogue writes colbuf[(WT1-1) & 1], which the flush of tile WT1-3 READS at the start of the last
-        // step: a barrier must lie between them (see hamming_mfma.hip).
-        if (t < WT1) {                             // t == WT1 - 1: one more tile, into set B
-            step(t, B0, B1, A0, A1, true, steady_tag);
-            __syncthreads();
-            if (last_partial) epilogue(t, B0, B1, std::true_type{}); else epilogue(t, B0, B1, steady_tag);
-        } else {                                   // tile WT1 - 1 is in set A
-            __syncthreads();
-            if (last_partial) epilogue(t - 1, A0, A1, std::true_type{}); else epilogue(t - 1, A0, A1, steady_tag);
-        }
+        tile_step(WT0, false, steady_tag);
+        for (int t = WT0 + 1; t < WT1; ++t) tile_step(t, true, steady_tag);
+        if (last_partial) epilogue(WT1 - 1, std::true_type{}); else epilogue(WT1 - 1, steady_tag);
         push_groups();                             // the (possibly partial, possibly empty) last group
     };
     // Row results of a window.  Every lane holds, per accumulator register, the best two GROUP minima (16-bit keys
@@ -377,13 +368,16 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // last operand read of `smem`; the region used here is private to the wave.
     auto finish_rows = [&]() __attribute__((always_inline)) {
         uint32_t* rowx = reinterpret_cast<uint32_t*>(smem) + w * (64 * ROWX_STRIDE);
+        u32x2_t rb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rb[r] = park[r * 64];
+        __syncthreads();                           // every wave holds its pairs: the transpose may overwrite the parking area
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int lrow = (r & 3) + 8 * (r >> 2) + 4 * g;
             // (best | second << 16) of M-tile 0 (low halves) and of M-tile 1 (high halves)
-            rowx[lrow * ROWX_STRIDE + c] = (rb[r][0] & 0xFFFFu) | (rb[r][1] << 16);
-            rowx[(32 + lrow) * ROWX_STRIDE + c] = (rb[r][0] >> 16) | (rb[r][1] & 0xFFFF0000u);
-            rb[r][0] = rb[r][1] = 0xFFFFFFFFu;                  // restart for the next window
+            rowx[lrow * ROWX_STRIDE + c] = (rb[r].x & 0xFFFFu) | (rb[r].y << 16);
+            rowx[(32 + lrow) * ROWX_STRIDE + c] = (rb[r].x >> 16) | (rb[r].y & 0xFFFF0000u);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -442,16 +436,15 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     };
 
     for (;;) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) park[r * 64] = u32x2_t{0xFFFFFFFFu, 0xFFFFFFFFu};   // wave-private: no barrier needed
         expand_store(load_raw(WT0), 0);            // WT0 is a multiple of 64: buffer parity restarts at 0
         raw1 = WT0 + 1 < WT1 ? load_raw(WT0 + 1) : 0u;
         if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
-        // the last two tiles' column partials of the window are still in LDS
-        __syncthreads();
-        if (WT1 - WT0 > 1 && w == (WT1 & 3)) flush_columns(WT1 - 2);
-        if (w == ((WT1 + 1) & 3)) flush_columns(WT1 - 1);
+        __syncthreads();                           // every wave is past its last operand read of the b tile
         finish_rows();
         if (!MULTI || wt1v == ntiles) break;
-        __syncthreads();                           // smem becomes the b tile again; colbuf is free
+        __syncthreads();                           // smem becomes the b tile (+ parking area) again
         wt0v = wt1v;
         wt1v = ntiles < wt0v + 64 ? ntiles : wt0v + 64;
     }
@@ -459,6 +452,34 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #undef WT1
     }
 #undef PLSLAM_MG_EPI_ROW
+}
+
+// K1c'  merge of K1f's column partials: keys21[j] = best-2 over the 64-row blocks of part16[block][j] (16-bit keys
+// (d << 7 | row within the block), best | second << 16), widened to (d << 23 | row)
+__global__ void __launch_bounds__(256)
+k_merge_partials16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks)
+{
+    const BlockDesc bd = blocks[blockIdx.x];
+    const SymDesc sd = syms[bd.item];
+    const int j = bd.row0 + (int)threadIdx.x;
+    if (j >= sd.n2) return;
+    const gcu32_t part = (gcu32_t) sd.part21;
+    const int nwb = (sd.n1 + 63) >> 6;
+    uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
+    for (int wb = 0; wb < nwb; ++wb) {
+        const uint32_t e = part[(size_t)wb * sd.n2 + j];
+        merge2(b0, b1, key16_to_key32(e & 0xFFFFu, 0u, (uint32_t)(64 * wb), 1u),
+               key16_to_key32(e >> 16, 0u, (uint32_t)(64 * wb), 1u));
+    }
+    ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21))[j] = u32x2_t{b0, b1};
+}
+
+int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_merge_partials16, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
 }
 
 int launch_scan_sym_mfma_g(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,

@@ -409,7 +409,7 @@ def test_batched_scan_is_deterministic_under_load(ctx, mform, n_orb, n_lbd, pair
 def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs, mutual):
     """K1f (group minima; the second best of the winner's group recomputed from the raw rows) against K1e (every key
     pushed): not only the match tables but every intermediate word -- keys12 = (best, second best) per row with the
-    second best's INDEX, and the per-row-block column partials -- must be identical, on tie-heavy data, ragged sizes,
+    second best's INDEX, and keys21, the merged column results -- must be identical, on tie-heavy data, ragged sizes,
     several windows (n2 > 2048) and the directed form."""
     import torch
     import plslam_amd
@@ -428,14 +428,13 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
     finally:
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
         ctx.set_option("mfma_form", 0)
-    # the dump returns the buffers with their 25 % growth slack: compare the words the kernels write
+    # the dump returns the buffers with their 25 % growth slack: compare the words the kernels write.  (The column
+    # PARTIALS are laid out differently -- K1e: 32-bit keys per 256-row block, K1f: 16-bit keys per 64-row block -- so
+    # the column direction is compared after the merge: keys21 is part of the key table.)
     rows = pairs * 2 * ((n_orb + n_lbd) * (2 if mutual else 1))
-    prows = pairs * 2 * (-(-n_orb // 256) * n_orb + -(-n_lbd // 256) * n_lbd) if mutual else 0
-    assert got[1][0].size >= 2 * rows and got[1][1].size >= 2 * prows
+    assert got[1][0].size >= 2 * rows
     k1, k2 = got[1][0][:2 * rows], got[2][0][:2 * rows]
     assert np.array_equal(k1, k2), int((k1 != k2).sum())
-    p1, p2 = got[1][1][:2 * prows], got[2][1][:2 * prows]
-    assert np.array_equal(p1, p2), int((p1 != p2).sum())
     assert np.array_equal(got[1][2], got[2][2])
 
 
