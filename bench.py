@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--sym-rows", type=int, default=0)
     ap.add_argument("--group-cap", type=int, default=0)
     ap.add_argument("--mfma-form", type=int, default=0, help="0 = auto (K1f), 1 = K1e (best-2 push per tile), 2 = K1f (group minima)")
+    ap.add_argument("--fuse", type=int, default=0, help="K1f: 0 = auto, 1 = never, 2 = always one workgroup per problem incl. merge + finalize")
     ap.add_argument("--step-streams", type=int, default=2, help="output buffers / HIP streams the steps alternate over")
     ap.add_argument("--no-overlap", action="store_true",
                     help="single GPU: run the steps strictly one after another on one stream")
@@ -173,6 +174,8 @@ def main():
         ctx.set_option("group_cap", args.group_cap)
     if args.mfma_form:
         ctx.set_option("mfma_form", args.mfma_form)
+    if args.fuse:
+        ctx.set_option("fuse", args.fuse)
     overlap = not use_dist and not args.no_overlap
     bm = frontend.StereoBatchMatcher(ctx, stream, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev,
                                      n_buffers=max(2, args.step_streams) if (use_dist or overlap) else 1)

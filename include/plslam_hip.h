@@ -89,7 +89,9 @@ void plslam_ctx_destroy(plslam_ctx* ctx);
  * scan: 256|512|1024), "sym_rows" (rows of d1 per lane in the symmetric scan: 0 = auto (default) | 1 | 4),
  * "group_cap" (workgroups of one problem co-scheduled on one XCD: 0 = auto (default) | 1..64),
  * "mfma_form" (bookkeeping of the matrix-core scan: 0 = auto (default) | 1 = best-2 push per tile (K1e) |
- * 2 = group minima + second best by recomputation (K1f); identical results) */
+ * 2 = group minima + second best by recomputation (K1f); identical results),
+ * "fuse" (K1f: one workgroup per problem that also merges the column results and applies the ratio test + mutual
+ * check, i.e. one kernel per plan run: 0 = auto (currently: never -- measured no faster) | 1 = never | 2 = always) */
 int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value);
 int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value);
 /* device facts for reports: CU count, max clock (kHz), LDS bytes per workgroup */

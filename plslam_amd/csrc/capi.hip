@@ -80,6 +80,7 @@ struct plslam_match_plan {
     bool sym_mfma = false;             // symmetric problems run on K1e (matrix cores)
     bool sym_mfma_multi = false;       // ... and some of them have n2 > 2048 (multi-window instantiation)
     int mfma_form = 0;                 // ctx option "mfma_form" at plan creation (0/2 = K1f, 1 = K1e)
+    bool fused = false;                // K1f, one workgroup per problem: merge + ratio + mutual inside the scan kernel
     int32_t ndir = 0, ndir_blocks = 0; // non-mutual problems on the directed form of K1e
     bool dir_multi = false;
     SymDesc* d_dirs = nullptr; BlockDesc* d_dir_blocks = nullptr;
@@ -151,6 +152,24 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         P->sym_rows = waves4 >= 6 * 17 * (int64_t)ctx->prop.multiProcessorCount ? 4 : 1;
     }
     const bool k1f = P->sym_mfma && P->mfma_form != 1;   // K1f: column partials per 64-row block, 16-bit keys
+    // Fused form (K1f only): one workgroup per problem walks all row blocks and finishes the problem (column merge, ratio
+    // test, mutual check, count) -- ONE kernel per plan run, no merge / finalize kernels, no keys21 round trip.  Measured
+    // at C2 / 4096 pairs per step: 4.05 ms against 3.48 + 0.52 ms unfused -- the merge's VALU work (+5 %), which the
+    // separate merge kernel hides under its HBM time, and the serial tail of every workgroup cost what the two launches
+    // cost -- so AUTO does not select it; "fuse" = 2 does (it needs many more problems than the chip has workgroup slots,
+    // 3 per CU, or the 6x coarser work units lose to tail quantisation).  Mutual problems keep their merged column keys in
+    // LDS: n2 <= PLSLAM_K1F_FUSED_MAX_N2.
+    {
+        int64_t nmf = 0;
+        bool fits = true;
+        for (int32_t i = 0; i < nprob; ++i) {
+            if (probs[i].n1 <= 0 || probs[i].n2 <= 0) continue;
+            ++nmf;
+            if (probs[i].mutual && probs[i].n2 > PLSLAM_K1F_FUSED_MAX_N2) fits = false;
+        }
+        (void)nmf;
+        P->fused = k1f && fits && ctx->fuse == 2;
+    }
     const int rpp = sym_rows_per_partial(P->sym_rows);   // a-rows per column partial
     const int rps = sym_rows_per_block(P->sym_rows);     // a-rows per workgroup of the symmetric scan
     int64_t rows = 0, part_rows = 0;
@@ -165,7 +184,10 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         PLSLAM_REQUIRE(p.n2 <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
         PLSLAM_REQUIRE(!p.mutual || p.n1 <= PLSLAM_MAX_TRAIN_ROWS, PLSLAM_ERANGE);
         rows += p.n1 + (p.mutual ? p.n2 : 0);
-        if (is_sym(p)) part_rows += (int64_t)((p.n1 + rpp - 1) / rpp) * p.n2 * (k1f ? 2 : 1);   // K1f: a dword per 64 rows
+        // column partials, in units of two words: K1e one (best, second) pair per (256-row block, column); K1f one word
+        // per (64-row block, column) with the rows padded to 256 columns
+        if (is_sym(p)) part_rows += k1f ? (int64_t)((p.n1 + 63) / 64) * ((p.n2 + 255) / 256) * 128
+                                        : (int64_t)((p.n1 + rpp - 1) / rpp) * p.n2;
     }
     PLSLAM_REQUIRE(rows < (int64_t(1) << 31), PLSLAM_ERANGE);
 
@@ -221,15 +243,22 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         if (p.mutual) key_row += p.n2;
         pd.keys12 = k12;
         pd.keys21 = k21;
-        for (int32_t r0 = 0; r0 < p.n1; r0 += 256) fblocks.push_back({i, r0});
+        const bool mf_path = P->sym_mfma && p.n1 > 0 && p.n2 > 0;    // this problem runs on K1e / K1f
+        if (!(P->fused && mf_path))
+            for (int32_t r0 = 0; r0 < p.n1; r0 += 256) fblocks.push_back({i, r0});
         if (is_sym(p)) {
             SymDesc y{};
             y.a = p.d1; y.b = p.d2; y.keys12 = k12; y.keys21 = k21;
             y.part21 = d_part + 2 * part_row;
             y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = (p.n1 + rpp - 1) / rpp;
-            part_row += (int64_t)y.n_iblk * p.n2 * (k1f ? 2 : 1);
-            for (int32_t r0 = 0; r0 < p.n1; r0 += rps) yblocks.push_back({(int32_t)syms.size(), r0});
-            for (int32_t c0 = 0; c0 < p.n2; c0 += 256) mblocks.push_back({(int32_t)syms.size(), c0});
+            part_row += k1f ? (int64_t)((p.n1 + 63) / 64) * ((p.n2 + 255) / 256) * 128 : (int64_t)y.n_iblk * p.n2;
+            if (P->fused) {
+                y.mutual = 1; y.matches_12 = p.matches_12; y.n_matches = pd.n_matches; y.nnr = p.nnr;
+                yblocks.push_back({(int32_t)syms.size(), 0});
+            } else {
+                for (int32_t r0 = 0; r0 < p.n1; r0 += rps) yblocks.push_back({(int32_t)syms.size(), r0});
+                for (int32_t c0 = 0; c0 < p.n2; c0 += 256) mblocks.push_back({(int32_t)syms.size(), c0});
+            }
             syms.push_back(y);
             evals += (int64_t)p.n1 * p.n2;
             devals += 2LL * p.n1 * p.n2;
@@ -239,7 +268,12 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             SymDesc y{};
             y.a = p.d1; y.b = p.d2; y.keys12 = k12; y.keys21 = nullptr; y.part21 = nullptr;
             y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = 0;
-            for (int32_t r0 = 0; r0 < p.n1; r0 += 256) dblocks.push_back({(int32_t)dirs.size(), r0});
+            if (P->fused) {
+                y.mutual = 0; y.matches_12 = p.matches_12; y.n_matches = pd.n_matches; y.nnr = p.nnr;
+                dblocks.push_back({(int32_t)dirs.size(), 0});
+            } else {
+                for (int32_t r0 = 0; r0 < p.n1; r0 += 256) dblocks.push_back({(int32_t)dirs.size(), r0});
+            }
             if (p.n2 > 2048) P->dir_multi = true;
             dirs.push_back(y);
             evals += (int64_t)p.n1 * p.n2;
@@ -312,12 +346,13 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         }
         return gs;
     };
+    // (fused: one entry per problem, so a group is one workgroup and its cost the whole distance matrix)
     if (!yblocks.empty())
         stripe(yblocks, groups_of(yblocks, [](const BlockDesc& b) { return b.item; },
-                                  [&](const BlockDesc& b) { return (int64_t)syms[b.item].n2; }));
+                                  [&](const BlockDesc& b) { return (int64_t)syms[b.item].n2 * (P->fused ? syms[b.item].n1 : 1); }));
     if (!dblocks.empty())
         stripe(dblocks, groups_of(dblocks, [](const BlockDesc& b) { return b.item; },
-                                  [&](const BlockDesc& b) { return (int64_t)dirs[b.item].n2; }));
+                                  [&](const BlockDesc& b) { return (int64_t)dirs[b.item].n2 * (P->fused ? dirs[b.item].n1 : 1); }));
     if (!use_wpq && !sblocks.empty())   // the two directed scans of a mutual problem are adjacent: same group key
         stripe(sblocks, groups_of(sblocks, [&](const BlockDesc& b) { return scan_problem[b.item]; },
                                   [&](const BlockDesc& b) { return (int64_t)scans[b.item].nt; }));
@@ -401,9 +436,15 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
     // the first scan kernel that runs zeroes the #matches counters
     int r;
     bool zeroed = false;               // the first scan kernel that runs zeroes the #matches counters
+    if (P->fused) {
+        // fused problems STORE their counts from inside the scan kernel, so the counters cannot be zeroed by that kernel's
+        // first workgroup: clear them ahead of it (only problems without rows or columns keep the zero)
+        PLSLAM_HIP_CHECK(hipMemsetAsync(P->d_counts_zero, 0, sizeof(int32_t) * (size_t)P->ncounts, s));
+        zeroed = true;
+    }
     if (P->nsym_blocks > 0) {
         r = P->sym_mfma ? launch_scan_mfma_form(P->mfma_form, P->d_syms, P->d_sym_blocks, P->nsym_blocks, P->d_counts_zero,
-                                                P->ncounts, P->sym_mfma_multi, false, s)
+                                                zeroed ? 0 : P->ncounts, P->sym_mfma_multi, false, s, P->fused)
                         : launch_scan_sym(P->sym_rows, P->d_syms, P->d_sym_blocks,
                                           P->nsym_blocks, P->d_counts_zero, P->ncounts, s);
         if (r) return r;
@@ -411,7 +452,7 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
     }
     if (P->ndir_blocks > 0) {
         r = launch_scan_mfma_form(P->mfma_form, P->d_dirs, P->d_dir_blocks, P->ndir_blocks, P->d_counts_zero,
-                                  zeroed ? 0 : P->ncounts, P->dir_multi, true, s);
+                                  zeroed ? 0 : P->ncounts, P->dir_multi, true, s, P->fused);
         if (r) return r;
         zeroed = true;
     }
@@ -546,6 +587,11 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         ctx->mfma_form = value;
         return PLSLAM_OK;
     }
+    if (!strcmp(key, "fuse")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= 2, PLSLAM_EINVAL);
+        ctx->fuse = value;
+        return PLSLAM_OK;
+    }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }
@@ -558,6 +604,7 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "sym_rows")) { *value = ctx->sym_rows; return PLSLAM_OK; }
     if (!strcmp(key, "group_cap")) { *value = ctx->group_cap; return PLSLAM_OK; }
     if (!strcmp(key, "mfma_form")) { *value = ctx->mfma_form; return PLSLAM_OK; }
+    if (!strcmp(key, "fuse")) { *value = ctx->fuse; return PLSLAM_OK; }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }

@@ -83,6 +83,7 @@ struct plslam_ctx {
     int group_cap = 0;   // blocks of one problem kept together on one XCD; 0 = auto (capi.hip, `stripe`)
     int sym_rows = 0;    // rows of d1 per lane in the symmetric scan: 0 = auto, 1, 4
     int mfma_form = 0;   // matrix-core scan: 0 = auto (grouped, K1f), 1 = exact push per tile (K1e), 2 = grouped (K1f)
+    int fuse = 0;        // K1f: 0 = auto (one workgroup per problem incl. merge + finalize when the plan is large), 1 = never, 2 = always
     std::mutex mu;       // serialises the host-pointer entry points
     plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
     plslam::HostBuf pin_in, pin_out;                // pinned staging of small host-pointer calls
@@ -136,6 +137,10 @@ struct SymDesc {
     uint32_t* part21;       // [n_iblk][n2][2] column partials per 64-row block of a
     int32_t n1, n2;
     int32_t n_iblk;
+    int32_t mutual;         // fused form (K1f, one workgroup per problem): ratio + mutual finalize happen in the scan kernel
+    int32_t* matches_12;    //   n1 match-table entries (nullptr: not fused)
+    int32_t* n_matches;     //   one counter, STORED (not accumulated) by the problem's workgroup; may be nullptr
+    float nnr;
     int32_t pad;
 };
 // rows_per_lane: 1 (K1b: 256-thread workgroups, 64 a-rows per wave) or 4 (K1b': 64-thread
@@ -151,14 +156,18 @@ int launch_scan_sym(int rows_per_lane, const SymDesc* d_sym, const BlockDesc* d_
 int launch_scan_sym_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
                          int nzero, bool multi_window, bool directed, hipStream_t s);
 // K1f (hamming_mfma_g.hip): same contract and tables as K1e; row direction = group minima + second best by recomputation
+// fused: one block-table entry per PROBLEM (row0 = 0); the workgroup walks the problem's row blocks itself, then merges the
+// column partials and applies the ratio test + mutual check (SymDesc::matches_12 / n_matches / nnr / mutual): no merge
+// kernel, no finalize kernel, no counter zeroing for these problems.  Mutual problems need n2 <= PLSLAM_K1F_FUSED_MAX_N2.
+constexpr int PLSLAM_K1F_FUSED_MAX_N2 = 4096;
 int launch_scan_sym_mfma_g(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
-                           int nzero, bool multi_window, bool directed, hipStream_t s);
+                           int nzero, bool multi_window, bool directed, bool fused, hipStream_t s);
 int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s);
 inline int launch_scan_mfma_form(int form, const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
-                                 int nzero, bool multi_window, bool directed, hipStream_t s)
+                                 int nzero, bool multi_window, bool directed, hipStream_t s, bool fused = false)
 {
     return form == 1 ? launch_scan_sym_mfma(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, s)
-                     : launch_scan_sym_mfma_g(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, s);
+                     : launch_scan_sym_mfma_g(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, fused, s);
 }
 int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s);
 

@@ -33,12 +33,14 @@
 
 #include <type_traits>
 
-// build-time experiments for tools/scan_time.py / tools/build_exp.py (results are WRONG with any of them on):
-//   1 no workgroup barrier   2 no epilogue (bookkeeping)   3 no MFMA   4 no column store   5 no second-best fix-up
-//   6 no finish_columns      7 no group push
+// build-time experiments for tools/scan_time.py / tools/build_exp.py (results are WRONG with any of them on), a bit mask:
+//   1 no workgroup barrier   2 no bookkeeping rows   4 no MFMA   8 no column store   16 no second-best fix-up
+//   32 no finish_columns     64 no group push        128 no expansion of the b tile (no global load, no LDS write)
+//   256 no operand reads from LDS                    512 no pack
 #ifndef PLSLAM_MG_EXPERIMENT
 #define PLSLAM_MG_EXPERIMENT 0
 #endif
+#define PLSLAM_MG_X(bit) ((PLSLAM_MG_EXPERIMENT & (bit)) != 0)
 
 namespace plslam {
 
@@ -63,7 +65,10 @@ constexpr int MF_TILE_N = 32;                 // b rows per tile
 constexpr int MF_KSTEPS = 4;                  // 256 bits = 4 x K 64
 constexpr int MF_ROW_STRIDE = 144;            // bytes per expanded b row in LDS (128 + 16: 4-bank skew)
 constexpr int MF_TILE_BYTES = MF_TILE_N * MF_ROW_STRIDE;
-constexpr int MF_GROUP = 8;                   // tiles per row-direction group (a window of 64 tiles = 8 groups)
+#ifndef PLSLAM_MG_GROUP
+#define PLSLAM_MG_GROUP 8
+#endif
+constexpr int MF_GROUP = PLSLAM_MG_GROUP;     // tiles per row-direction group (a window of 64 tiles = 8 groups of 8)
 // fp4 (e2m1) codes: +1.0 = 0x2, -1.0 = 0xA.  b side: bit 0 -> +1, bit 1 -> -1 = s(b); the a side is the b code
 // XOR 0x8 per nibble (= -s(a)) and carries the block scale 2^6 (E8M0 133), the b side 2^0 (E8M0 127).
 constexpr uint32_t FP4_NEG = 0x88888888u;
@@ -93,6 +98,12 @@ __device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b)
     asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+__device__ __forceinline__ uint32_t pk_add16_sat(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void pk_push2(uint32_t& b0, uint32_t& b1, uint32_t key)
 {
     b1 = pk_min16(b1, pk_max16(b0, key));
@@ -114,16 +125,23 @@ __device__ __forceinline__ uint32_t key16_to_key32(uint32_t k16, uint32_t tag_bi
                            : (((k16 >> 7) << KEY_IDX_BITS) | (idx_base + ((k16 & 127u) - tag_bias) * idx_scale));
 }
 // 32 bits of a descriptor -> 32 fp4 codes of s(bit): dword s holds bits 4k + s, nibble k = 0x2 | bit << 3
+// 7 VALU ops of the fast class (measured ~2.5 cycles per wave instruction against ~4.2 for shifts and v_and_or): three adds
+// for x << 1, 2, 3 and four v_bitop3 (a & b) | c.  Written with asm / the builtin because the compiler turns x + x back
+// into a shift and (x & m) | c into v_and + v_or.
 template <bool A_SIDE>
 __device__ __forceinline__ i32x4 expand_dword_fp4(uint32_t x)
 {
-    const uint32_t x1 = x + x, x2 = x1 + x1, x3 = x2 + x2;
+    uint32_t x1, x2, x3;
+    asm("v_add_u32 %0, %1, %1" : "=v"(x1) : "v"(x));
+    asm("v_add_u32 %0, %1, %1" : "=v"(x2) : "v"(x1));
+    asm("v_add_u32 %0, %1, %1" : "=v"(x3) : "v"(x2));
+    constexpr uint32_t base = A_SIDE ? (FP4_ONE ^ FP4_NEG) : FP4_ONE;       // a side: sign nibble-bit flipped
+    constexpr unsigned TT = A_SIDE ? 0x6Au : 0xEAu;                         // (a & b) ^ c  |  (a & b) | c
     i32x4 v;
-    v.x = (int)((x3 & FP4_NEG) | FP4_ONE);      // one v_and_or_b32 each
-    v.y = (int)((x2 & FP4_NEG) | FP4_ONE);
-    v.z = (int)((x1 & FP4_NEG) | FP4_ONE);
-    v.w = (int)((x & FP4_NEG) | FP4_ONE);
-    if (A_SIDE) { v.x ^= (int)FP4_NEG; v.y ^= (int)FP4_NEG; v.z ^= (int)FP4_NEG; v.w ^= (int)FP4_NEG; }
+    v.x = (int)__builtin_amdgcn_bitop3_b32(x3, FP4_NEG, base, TT);
+    v.y = (int)__builtin_amdgcn_bitop3_b32(x2, FP4_NEG, base, TT);
+    v.z = (int)__builtin_amdgcn_bitop3_b32(x1, FP4_NEG, base, TT);
+    v.w = (int)__builtin_amdgcn_bitop3_b32(x, FP4_NEG, base, TT);
     return v;
 }
 __device__ __forceinline__ uint32_t bcnt_acc_(uint32_t x, uint32_t acc)
@@ -138,7 +156,10 @@ __device__ __forceinline__ int xcd_remap_(int orig, int nwg) { return (orig & 7)
 
 // MULTI = false: every problem of the launch has n2 <= 2048 (one window of 64 tiles; the window bounds are
 // compile-time facts).  MULTI = true: any n2.  DIRECTED = true: only keys12 (row direction) is produced.
-template <bool MULTI, bool DIRECTED>
+// FUSED = true: one workgroup per PROBLEM.  It walks the problem's row blocks of 256 itself and then finishes the problem:
+// column partials (still in L2 / the Infinity Cache) -> keys21 in LDS -> ratio test + mutual check -> matches_12 and the
+// match count.  No merge kernel, no finalize kernel, no counter zeroing, no keys21 round trip through HBM.
+template <bool MULTI, bool DIRECTED, bool FUSED>
 __global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
 k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks,
                   int32_t* __restrict__ zero, int nzero)
@@ -151,6 +172,12 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     constexpr int SMEM_BYTES = PARK_OFF + 4 * 16 * 64 * 8;
     static_assert(SMEM_BYTES >= 4 * 64 * ROWX_STRIDE * 4, "the transpose must fit");
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
+    // column results of the current group of 8 tiles, per wave [tile in group][column] (1 KB per wave): they leave for
+    // HBM once per group as one 16-byte store per lane.  A global store per tile would sit in the same counter (vmcnt) as
+    // the raw-row prefetch, and with loads AND stores pending the counter is out of order: every wait becomes
+    // vmcnt(0), the prefetch distance collapses to one tile, and a tile then costs a full memory latency (round 2
+    // finding: 2.7 ms of the 3.4 ms scan were there with NO bookkeeping at all in the kernel).
+    __shared__ __attribute__((aligned(16))) uint32_t colstage[4][MF_GROUP * MF_TILE_N];
     uint8_t* const btile = smem;
     u32x2_t* const park = reinterpret_cast<u32x2_t*>(smem + PARK_OFF) + (threadIdx.x >> 6) * (16 * 64) + (threadIdx.x & 63);
 
@@ -162,13 +189,14 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     if (bd.item < 0) return;                       // padding entry of the XCD-striped table
     const SymDesc sd = syms[bd.item];
     const int n1 = sd.n1, n2 = sd.n2;
+    const int n2p = (n2 + 255) & ~255;             // rows of the partial table are padded to 256 columns: whole groups are stored
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, g = lane >> 5;
-    const int i0 = bd.row0;                        // first of this workgroup's 256 a-rows
-    const int iw = i0 + 64 * w;                    // first of this wave's 64
     const gcu32_t araw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.a);
     const gcu32_t braw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.b);
+    for (int i0 = FUSED ? 0 : bd.row0;; i0 += 256) {     // first of the 256 a-rows at hand (not FUSED: the one block of the entry)
+    const int iw = i0 + 64 * w;                    // first of this wave's 64
 
     // ---- A operands: rows iw + 32 mt + c, raw dword 2 ks + g of each, as fp4 codes of -s(a) (the b code with the
     // sign nibble-bit flipped); the factor 64 is the block scale ----
@@ -197,8 +225,10 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // column partials of THIS WAVE's 64 rows: part16[(row block of 64)][column] = best | second << 16 as 16-bit keys
     // (d << 7 | row within the block); the merge kernel (k_merge_partials16) widens and combines them.  Every wave writes
     // its own results straight from registers: no LDS exchange between the waves, no flush step on the tile's critical path.
-    const gu32_t part = DIRECTED ? (gu32_t) nullptr : (gu32_t) sd.part21 + (size_t)(iw >> 6) * n2;
+    const gu32_t part = DIRECTED ? (gu32_t) nullptr : (gu32_t) sd.part21 + (size_t)(iw >> 6) * n2p;
     const bool wave_has_rows = iw < n1;
+    uint32_t* const cstage = colstage[w];
+    *reinterpret_cast<i32x4*>(cstage + 4 * lane) = i32x4{-1, -1, -1, -1};     // wave-private
 
     // expansion duty of this lane: b row (tid >> 3) of the tile, dword (tid & 7) of it
     const int ej = tid >> 3, ewd = tid & 7;
@@ -236,9 +266,18 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // The 16-bit row keys hold 64 tile numbers, so the scan runs in WINDOWS of 64 tiles (2048 columns): after
     // each window the row state is reduced, completed (second best) and merged into keys12, then restarted.
     int wt0v = 0, wt1v = ntiles < 64 ? ntiles : 64;
-    uint32_t raw1 = 0u;                                    // raw b dword of tile t+1 of the coming step
-    // the group of 8 tiles is over: its minima go into the sorted pairs, the minima restart
-    auto push_groups = [&]() __attribute__((always_inline)) {
+    uint32_t raw1 = 0u, raw2 = 0u, raw3 = 0u;              // raw b dwords of tiles t+1, t+2, t+3 of the coming step
+    // the group of 8 tiles that ends with tile `tl` is over: its minima go into the sorted pairs, the minima restart, and
+    // the group's column results go to the partial table (256 columns: 16 bytes per lane)
+    auto push_groups = [&](int tl) __attribute__((always_inline)) {
+        if (!DIRECTED && wave_has_rows && !PLSLAM_MG_X(8)) {
+            const int j0 = (tl & ~(MF_GROUP - 1)) * MF_TILE_N + 4 * lane;       // WT0 is a multiple of 8
+            const i32x4 v = *reinterpret_cast<const i32x4*>(cstage + 4 * lane);
+            if (j0 < n2p) *reinterpret_cast<PLSLAM_GLOBAL i32x4*>(part + j0) = v;
+            // tiles of a partial last group that never ran leave "none" in the padding columns (never read; keeps the
+            // partial table a pure function of the inputs, which tools/determinism_check.py compares word for word)
+            *reinterpret_cast<i32x4*>(cstage + 4 * lane) = i32x4{-1, -1, -1, -1};
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const u32x2_t v = park[r * 64];
@@ -249,25 +288,28 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         }
     };
     // column best-2 of a finished tile: the two halves of (cb0, cb1) are sorted streams over disjoint rows
-    // of the same column -> best 2 of the lane, then of the wave (lane ^ 32), as 16-bit keys
+    // of the same column -> best 2 of the lane, then of the wave (lanes l and l + 32 hold the same column), as 16-bit
+    // keys.  The keys still carry "+ tile within the window" from the accumulator seed; every key of a tile carries
+    // the same offset, so all comparisons here are unaffected and the merge step takes it off (a "none" half 0xFFFF
+    // stays above KEY16_MAX after the subtraction).
     auto finish_columns = [&](int t, uint32_t cb0, uint32_t cb1) __attribute__((always_inline)) {
-        if (DIRECTED || PLSLAM_MG_EXPERIMENT == 6) { asm volatile("" ::"v"(cb0), "v"(cb1)); return; }
-        // every key of this tile carries + tile in its low 7 bits (no borrow: each half is >= tile; a "none" half
-        // 0xFFFF becomes 0xFFFF - tile > KEY16_MAX, still "none" for every later comparison and conversion)
-        const uint32_t tp = (uint32_t)(t - WT0) * 0x00010001u;
-        cb0 -= tp;
-        cb1 -= tp;
-        // Stay in the 16-bit domain: the tag of a column key is LOC (bits 0,1,3,4 of the row within the wave);
-        // OR-ing in bit 2 (= g) and bit 5 (= M-tile, the high halves) makes it the full row within the wave,
-        // so keys of the two halves and of lane ^ 32 compare directly (a "none" stays above KEY16_MAX).
-        cb0 |= ghtag;
-        cb1 |= ghtag;
+        if (DIRECTED || PLSLAM_MG_X(32)) { asm volatile("" ::"v"(cb0), "v"(cb1)); return; }
+        // The tag of a column key is LOC (bits 0,1,3,4 of the row within the wave) [+ tile]; OR-ing in bit 2 (= g) and
+        // bit 5 (= M-tile, the high halves) makes it the full row within the wave [+ tile: LOC + tile < 128 and the
+        // OR-ed bits are clear in LOC but NOT in LOC + tile, so they are ADDED: no carry leaves the 7-bit tag because
+        // row + tile <= 63 + 63; the packed add saturates, so a "none" half (0xFFFF: masked rows) stays 0xFFFF and never
+        // carries into its neighbour], so keys of the two halves and of lane + 32 compare directly.
+        cb0 = pk_add16_sat(cb0, ghtag);
+        cb1 = pk_add16_sat(cb1, ghtag);
         const uint32_t e0 = cb0 & 0xFFFFu, o0 = cb0 >> 16, e1 = cb1 & 0xFFFFu, o1 = cb1 >> 16;
         uint32_t m0 = umin_(e0, o0), m1 = umin_(umax_(e0, o0), umin_(e1, o1));
-        const uint32_t other = (uint32_t)__shfl_xor((int)(m0 | (m1 << 16)), 32);
+        // lanes l < 32 fetch lane l + 32's pair with one VALU swap (gfx950: v_permlane32_swap), no LDS round trip;
+        // lanes >= 32 compute a value nobody stores
+        const uint32_t mine = m0 | (m1 << 16);
+        const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+        const uint32_t other = sw[1];
         merge2(m0, m1, other & 0xFFFFu, other >> 16);
-        const int j = t * MF_TILE_N + lane;
-        if (lane < MF_TILE_N && j < n2 && wave_has_rows && PLSLAM_MG_EXPERIMENT != 4) part[j] = m0 | (m1 << 16);
+        if (lane < MF_TILE_N) cstage[((t - WT0) & (MF_GROUP - 1)) * MF_TILE_N + lane] = m0 | (m1 << 16);
     };
     // Software pipeline, ONE accumulator set.  A tile's life:  M(t): 8 MFMAs -> P(t): 16 v_perm pack the 32 accumulators
     // into 16 key pairs kc[] (the accumulator registers are free again) -> E(t): bookkeeping from kc[], issued BETWEEN the
@@ -280,12 +322,25 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     uint32_t kc[16];
     auto tile_step = [&](int t, bool with_prev, auto masked_tag) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const uint32_t raw2 = t + 2 < WT1 ? load_raw(t + 2) : 0u;
-        if (PLSLAM_MG_EXPERIMENT != 1) __syncthreads();  // tile t expanded; every wave is past its reads of the other buffer
+        if (!PLSLAM_MG_X(1)) __syncthreads();  // tile t expanded; every wave is past its reads of the other buffer
         const uint8_t* bt = btile + (t & 1) * MF_TILE_BYTES + c * MF_ROW_STRIDE + 16 * g;
         const bool col_ok = (t - 1) * MF_TILE_N + c < n2;
         uint32_t cb0 = 0xFFFFFFFFu, cb1 = 0xFFFFFFFFu;
-        i32x4 bf = *reinterpret_cast<const i32x4*>(bt);
+        // all four operand reads of the tile go out at once, right behind the barrier; what follows until the first MFMA
+        // needs one of them (the expansion of tile t+1, whose buffer every wave left before this barrier; the seeds; the
+        // first bookkeeping rows) covers the LDS latency
+        i32x4 bfr[MF_KSTEPS];
+#pragma unroll
+        for (int ks = 0; ks < MF_KSTEPS; ++ks)
+            bfr[ks] = PLSLAM_MG_X(256) ? i32x4{(int)FP4_ONE + t, (int)FP4_ONE, (int)FP4_ONE + ks, (int)FP4_ONE}
+                                       : *reinterpret_cast<const i32x4*>(bt + 32 * ks);
+        if (!PLSLAM_MG_X(128)) expand_store(raw1, (t + 1) & 1);   // past the last tile: a harmless rewrite of the idle buffer
+        // raw-row prefetch, three tiles deep: the request for tile t+4 goes out now, its dword is expanded in step t+3.
+        // Always issued (load_raw clamps the row), so the number of loads in flight is the same on every path and the
+        // waits are exact counts.
+        raw1 = raw2;
+        raw2 = raw3;
+        if (!PLSLAM_MG_X(128)) raw3 = load_raw(t + 4);
         // accumulator start: 2^23 + 16384 + LOC(reg) + tile within the window: the sum is 2^23 + 128 d + LOC + tile,
         // every partial sum an integer below 2^24, so fp32 accumulation is exact and the float's low 16 bits ARE
         // the key (d << 7 | LOC + tile).  Wave-uniform integers (scalar adds); built from integers through a scalar
@@ -300,43 +355,44 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #define PLSLAM_MG_MMA(ACC, MT, KS, CIN)                                                            \
         {                                                                                          \
             const i32x8 a8 = {afrag[MT][KS].x, afrag[MT][KS].y, afrag[MT][KS].z, afrag[MT][KS].w, 0, 0, 0, 0}; \
-            const i32x8 b8 = {bcur.x, bcur.y, bcur.z, bcur.w, 0, 0, 0, 0};                         \
-            if (PLSLAM_MG_EXPERIMENT != 3)                                                         \
+            const i32x8 b8 = {bfr[KS].x, bfr[KS].y, bfr[KS].z, bfr[KS].w, 0, 0, 0, 0};             \
+            if (!PLSLAM_MG_X(4))                                                                   \
                 ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, CIN, 4, 4, 0, scale_a, 0, scale_b); \
-            else { const f32x16 cin_ = CIN; ACC = cin_; ACC[KS] = __builtin_bit_cast(float, bcur.x ^ a8[0]); } \
+            else { const f32x16 cin_ = CIN; ACC = cin_; ACC[KS] = __builtin_bit_cast(float, bfr[KS].x ^ a8[0]); } \
             /* an EMPTY asm (no instruction): pins the MFMA here -- without a use in this block the optimizer sinks all */ \
             /* eight MFMAs of a tile down to the pack, i.e. behind the bookkeeping they are meant to overlap with */ \
             asm volatile("" : "+v"(ACC));                                                          \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
         }
-#define PLSLAM_MG_KSTEP(KS, CIN0, CIN1)                                                            \
+#define PLSLAM_MG_EPI2(R)                                                                          \
         {                                                                                          \
-            const i32x4 bcur = bf;                                                                 \
-            if ((KS) < MF_KSTEPS - 1) bf = *reinterpret_cast<const i32x4*>(bt + 32 * ((KS) + 1));   \
-            PLSLAM_MG_MMA(m0, 0, KS, CIN0)                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                     \
-            if (with_prev && PLSLAM_MG_EXPERIMENT != 2) { PLSLAM_MG_EPI_ROW(4 * (KS)) PLSLAM_MG_EPI_ROW(4 * (KS) + 1) } \
-            __builtin_amdgcn_sched_barrier(0);                                                     \
-            PLSLAM_MG_MMA(m1, 1, KS, CIN1)                                                         \
-            __builtin_amdgcn_sched_barrier(0);                                                     \
-            if (with_prev && PLSLAM_MG_EXPERIMENT != 2) { PLSLAM_MG_EPI_ROW(4 * (KS) + 2) PLSLAM_MG_EPI_ROW(4 * (KS) + 3) } \
+            if (with_prev && !PLSLAM_MG_X(2)) { PLSLAM_MG_EPI_ROW(R) PLSLAM_MG_EPI_ROW((R) + 1) }  \
             __builtin_amdgcn_sched_barrier(0);                                                     \
         }
-        PLSLAM_MG_KSTEP(0, cseed, cseed)
-        PLSLAM_MG_KSTEP(1, m0, m1) PLSLAM_MG_KSTEP(2, m0, m1) PLSLAM_MG_KSTEP(3, m0, m1)
-#undef PLSLAM_MG_KSTEP
+        // program order, fenced: [2 rows] MFMA [2 rows] MFMA ... : single MFMAs, evenly spaced, each followed by VALU work
+        // that does not depend on it
+        __builtin_amdgcn_sched_barrier(0);
+        PLSLAM_MG_EPI2(0)  PLSLAM_MG_MMA(m0, 0, 0, cseed)
+        PLSLAM_MG_EPI2(2)  PLSLAM_MG_MMA(m1, 1, 0, cseed)
+        PLSLAM_MG_EPI2(4)  PLSLAM_MG_MMA(m0, 0, 1, m0)
+        PLSLAM_MG_EPI2(6)  PLSLAM_MG_MMA(m1, 1, 1, m1)
+        PLSLAM_MG_EPI2(8)  PLSLAM_MG_MMA(m0, 0, 2, m0)
+        PLSLAM_MG_EPI2(10) PLSLAM_MG_MMA(m1, 1, 2, m1)
+        PLSLAM_MG_EPI2(12) PLSLAM_MG_MMA(m0, 0, 3, m0)
+        PLSLAM_MG_EPI2(14) PLSLAM_MG_MMA(m1, 1, 3, m1)
+#undef PLSLAM_MG_EPI2
 #undef PLSLAM_MG_MMA
-        expand_store(raw1, (t + 1) & 1);           // past the last tile: a harmless rewrite of the idle buffer
-        raw1 = raw2;
         if (with_prev) {
             finish_columns(t - 1, cb0, cb1);
-            if (((t - 1 - WT0) & (MF_GROUP - 1)) == MF_GROUP - 1 && PLSLAM_MG_EXPERIMENT != 7) push_groups();   // wave-uniform: tile t-1 closed a group
+            if (((t - 1 - WT0) & (MF_GROUP - 1)) == MF_GROUP - 1 && !PLSLAM_MG_X(64)) push_groups(t - 1);   // wave-uniform: tile t-1 closed a group
         }
         // P(t): the key pairs of tile t; the accumulators are dead from here on
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float f0 = m0[r], f1 = m1[r];
-            kc[r] = pack_acc(f0, f1, pack_sel);
+            if (!PLSLAM_MG_X(512)) kc[r] = pack_acc(f0, f1, pack_sel);
         }
+        if (PLSLAM_MG_X(512)) { asm volatile("" ::"v"(m0), "v"(m1)); kc[0] = __builtin_bit_cast(uint32_t, (float)m0[0]); }
     };
     // E(t) on its own (the last tile of a window has no following M step to hide under)
     auto epilogue = [&](int t, auto masked_tag) __attribute__((always_inline)) {
@@ -356,7 +412,7 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         tile_step(WT0, false, steady_tag);
         for (int t = WT0 + 1; t < WT1; ++t) tile_step(t, true, steady_tag);
         if (last_partial) epilogue(WT1 - 1, std::true_type{}); else epilogue(WT1 - 1, steady_tag);
-        push_groups();                             // the (possibly partial, possibly empty) last group
+        push_groups(WT1 - 1);                      // the (possibly partial) last group
     };
     // Row results of a window.  Every lane holds, per accumulator register, the best two GROUP minima (16-bit keys
     // (d, tile + LOC)) of ITS column class for two rows.  Transpose through LDS so that one lane owns one row: lane l
@@ -399,7 +455,7 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         if (row < n1) {
             const gu2_t out = (gu2_t) reinterpret_cast<u32x2_t*>(sd.keys12) + row;
             uint32_t r0 = widen(k0), r1 = widen(k1);
-            if ((k0 >> 16) <= KEY16_MAX && PLSLAM_MG_EXPERIMENT != 5) {
+            if ((k0 >> 16) <= KEY16_MAX && !PLSLAM_MG_X(16)) {
                 // the other members of the winner's group: tiles g0 .. g0 + 7 of the window, same class
                 const uint32_t cls0 = k0 & 0xFFFFu;
                 const uint32_t tw = ((k0 >> 16) & 127u) - loc;              // winner's tile within the window
@@ -439,7 +495,9 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) park[r * 64] = u32x2_t{0xFFFFFFFFu, 0xFFFFFFFFu};   // wave-private: no barrier needed
         expand_store(load_raw(WT0), 0);            // WT0 is a multiple of 64: buffer parity restarts at 0
-        raw1 = WT0 + 1 < WT1 ? load_raw(WT0 + 1) : 0u;
+        raw1 = load_raw(WT0 + 1);
+        raw2 = load_raw(WT0 + 2);
+        raw3 = load_raw(WT0 + 3);
         if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
         __syncthreads();                           // every wave is past its last operand read of the b tile
         finish_rows();
@@ -451,7 +509,65 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #undef WT0
 #undef WT1
     }
+    if (!FUSED || i0 + 256 >= n1) break;
+    __syncthreads();                               // the transpose area becomes b tile + parking area again
+    }   // row blocks
 #undef PLSLAM_MG_EPI_ROW
+    if (!FUSED) return;
+
+    // ---- the problem's tail: merge the column partials, ratio test + mutual check (K1c' + K2 of the unfused path) ----
+    // Every wave waits for its own stores (keys12 rows, partials), then the workgroup meets.  All waves of a workgroup
+    // share one L1 (the kernel is not built for threadgroup-split mode), so after the barrier plain loads see them.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    uint32_t* const k21 = reinterpret_cast<uint32_t*>(smem);           // n2 x (best, second): <= 32 KB (host checks n2)
+    if (!DIRECTED) {
+        const gcu32_t part = (gcu32_t) sd.part21;
+        const int nwb = (n1 + 63) >> 6;
+        const gu2_t k21g = (gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21);
+        for (int j = tid; j < n2; j += 256) {
+            uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
+            const uint32_t tw = ((uint32_t)j >> 5) & 63u;  // the keys still carry + tile within the 64-tile window
+#pragma unroll 8
+            for (int wb = 0; wb < nwb; ++wb) {
+                const uint32_t e = part[(size_t)wb * n2p + j];
+                merge2(b0, b1, key16_to_key32((e & 0xFFFFu) - tw, 0u, (uint32_t)(64 * wb), 1u),
+                       key16_to_key32((e >> 16) - tw, 0u, (uint32_t)(64 * wb), 1u));
+            }
+            k21[2 * j] = b0;
+            k21[2 * j + 1] = b1;
+            if (k21g) k21g[j] = u32x2_t{b0, b1};                      // diagnostics (plslam_match_plan_dump) only
+        }
+        __syncthreads();
+    }
+    // stvo-pl matchNNR: accept iff (float)d0 < (float)d1 * nnr (one fp32 multiply); match(): keep i1 -> i2 iff m21[i2] == i1
+    auto ratio_pick = [&](uint32_t q0, uint32_t q1) -> int {
+        if (q1 == KEY_NONE) return -1;                                 // fewer than two neighbours: "no match"
+        const float d0 = (float)(q0 >> KEY_IDX_BITS);
+        const float d1n = __fmul_rn((float)(q1 >> KEY_IDX_BITS), sd.nnr);
+        return d0 < d1n ? (int)(q0 & KEY_IDX_MASK) : -1;
+    };
+    int found = 0;
+    for (int ib = 0; ib < n1; ib += 256) {
+        const int i1 = ib + tid;
+        int m = -1;
+        if (i1 < n1) {
+            const u32x2_t q = ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys12))[i1];
+            m = ratio_pick(q.x, q.y);
+            if (!DIRECTED && m >= 0 && sd.mutual && ratio_pick(k21[2 * m], k21[2 * m + 1]) != i1) m = -1;
+            ((PLSLAM_GLOBAL int32_t*) sd.matches_12)[i1] = m;
+        }
+        found += (int)__popcll(__ballot(m >= 0));                      // wave-uniform
+    }
+    if (sd.n_matches) {
+        __syncthreads();                                               // k21 is dead: its first words become the counter
+        int* const cnt = reinterpret_cast<int*>(smem);
+        if (tid == 0) *cnt = 0;
+        __syncthreads();
+        if (lane == 0) atomicAdd(cnt, found);
+        __syncthreads();
+        if (tid == 0) *((PLSLAM_GLOBAL int32_t*) sd.n_matches) = *cnt;
+    }
 }
 
 // K1c'  merge of K1f's column partials: keys21[j] = best-2 over the 64-row blocks of part16[block][j] (16-bit keys
@@ -465,11 +581,14 @@ k_merge_partials16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict
     if (j >= sd.n2) return;
     const gcu32_t part = (gcu32_t) sd.part21;
     const int nwb = (sd.n1 + 63) >> 6;
+    const int n2p = (sd.n2 + 255) & ~255;                  // padded row of the partial table
     uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
+    const uint32_t tw = ((uint32_t)j >> 5) & 63u;          // the keys still carry + tile within the 64-tile window
+#pragma unroll 8
     for (int wb = 0; wb < nwb; ++wb) {
-        const uint32_t e = part[(size_t)wb * sd.n2 + j];
-        merge2(b0, b1, key16_to_key32(e & 0xFFFFu, 0u, (uint32_t)(64 * wb), 1u),
-               key16_to_key32(e >> 16, 0u, (uint32_t)(64 * wb), 1u));
+        const uint32_t e = part[(size_t)wb * n2p + j];
+        merge2(b0, b1, key16_to_key32((e & 0xFFFFu) - tw, 0u, (uint32_t)(64 * wb), 1u),
+               key16_to_key32((e >> 16) - tw, 0u, (uint32_t)(64 * wb), 1u));
     }
     ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21))[j] = u32x2_t{b0, b1};
 }
@@ -483,13 +602,15 @@ int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int
 }
 
 int launch_scan_sym_mfma_g(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
-                           int nzero, bool multi_window, bool directed, hipStream_t s)
+                           int nzero, bool multi_window, bool directed, bool fused, hipStream_t s)
 {
     if (nblocks <= 0) return PLSLAM_OK;
-#define PLSLAM_MG_LAUNCH(M, D) \
-    hipLaunchKernelGGL((k_scan_sym_mfma_g<M, D>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero)
-    if (multi_window) { if (directed) PLSLAM_MG_LAUNCH(true, true); else PLSLAM_MG_LAUNCH(true, false); }
-    else              { if (directed) PLSLAM_MG_LAUNCH(false, true); else PLSLAM_MG_LAUNCH(false, false); }
+#define PLSLAM_MG_LAUNCH(M, D, F) \
+    hipLaunchKernelGGL((k_scan_sym_mfma_g<M, D, F>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero)
+#define PLSLAM_MG_LAUNCH2(M, D) { if (fused) PLSLAM_MG_LAUNCH(M, D, true); else PLSLAM_MG_LAUNCH(M, D, false); }
+    if (multi_window) { if (directed) PLSLAM_MG_LAUNCH2(true, true) else PLSLAM_MG_LAUNCH2(true, false) }
+    else              { if (directed) PLSLAM_MG_LAUNCH2(false, true) else PLSLAM_MG_LAUNCH2(false, false) }
+#undef PLSLAM_MG_LAUNCH2
 #undef PLSLAM_MG_LAUNCH
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;

@@ -85,19 +85,21 @@ def test_symmetric_and_directed_variants_agree(ctx, oracle, n1, n2):
         em, en = oracle.match(d1, d2, 0.9, True)
         try:
             # (variant, sym_rows, mfma_form): mfma_form 2 = K1f (group minima, the default), 1 = K1e (push per tile)
-            for variant, sym_rows, form in ((plslam_amd.SCAN_MFMA, 0, 2), (plslam_amd.SCAN_MFMA, 0, 1),
+            for variant, sym_rows, form in ((plslam_amd.SCAN_MFMA, 0, 2), (plslam_amd.SCAN_MFMA, 0, 1), (plslam_amd.SCAN_MFMA, 0, 3),
                                             (plslam_amd.SCAN_SYMMETRIC, 4, 0), (plslam_amd.SCAN_SYMMETRIC, 1, 0),
                                             (plslam_amd.SCAN_LANE_PER_QUERY, 1, 0), (plslam_amd.SCAN_WAVE_PER_QUERY, 1, 0),
                                             (plslam_amd.SCAN_AUTO, 1, 0)):
                 ctx.set_option("scan_variant", variant)
                 ctx.set_option("sym_rows", sym_rows)
-                ctx.set_option("mfma_form", form)
+                ctx.set_option("mfma_form", min(form, 2))
+                ctx.set_option("fuse", 2 if form == 3 else 0)
                 m, n = ctx.match(d1, d2, 0.9, True)
                 assert np.array_equal(m, em) and n == en, (variant, sym_rows, form, gen.__name__)
         finally:
             ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
             ctx.set_option("sym_rows", 0)
             ctx.set_option("mfma_form", 0)
+            ctx.set_option("fuse", 0)
 
 
 def test_all_scan_block_sizes(ctx, oracle):
@@ -117,28 +119,33 @@ def test_all_scan_block_sizes(ctx, oracle):
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
 
 
-@pytest.fixture(params=["auto", "lane_per_query", "wave_per_query", "symmetric", "mfma", "mfma_k1e"])
+@pytest.fixture(params=["auto", "lane_per_query", "wave_per_query", "symmetric", "mfma", "mfma_k1e", "mfma_fused"])
 def vctx(ctx, request):
     """The context with each scan variant forced in turn (AUTO picks wave-per-query for plans too
     small to fill the chip, the symmetric scan for mutual problems otherwise)."""
     import plslam_amd
     v = {"auto": plslam_amd.SCAN_AUTO, "lane_per_query": plslam_amd.SCAN_LANE_PER_QUERY,
          "wave_per_query": plslam_amd.SCAN_WAVE_PER_QUERY, "symmetric": plslam_amd.SCAN_SYMMETRIC,
-         "mfma": plslam_amd.SCAN_MFMA, "mfma_k1e": plslam_amd.SCAN_MFMA}[request.param]
+         "mfma": plslam_amd.SCAN_MFMA, "mfma_k1e": plslam_amd.SCAN_MFMA, "mfma_fused": plslam_amd.SCAN_MFMA}[request.param]
     ctx.set_option("scan_variant", v)
     ctx.set_option("mfma_form", 1 if request.param == "mfma_k1e" else 0)   # default form = K1f (group minima)
+    ctx.set_option("fuse", 2 if request.param == "mfma_fused" else 0)      # one workgroup per problem incl. finalize
     yield ctx
     ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
     ctx.set_option("mfma_form", 0)
+    ctx.set_option("fuse", 0)
 
 
-@pytest.fixture(params=[2, 1], ids=["k1f", "k1e"])
+@pytest.fixture(params=[2, 1, 3], ids=["k1f", "k1e", "k1f_fused"])
 def mform(ctx, request):
-    """Both bookkeeping forms of the matrix-core scan: 2 = K1f (group minima + recomputed second best, the default),
-    1 = K1e (best-2 push per tile)."""
-    ctx.set_option("mfma_form", request.param)
+    """The forms of the matrix-core scan: 2 = K1f (group minima + recomputed second best, the default), 1 = K1e (best-2
+    push per tile), 3 = K1f with one workgroup per problem that also merges the columns and applies ratio + mutual
+    (what AUTO picks for large plans; forced here so that small plans exercise it)."""
+    ctx.set_option("mfma_form", min(request.param, 2))
+    ctx.set_option("fuse", 2 if request.param == 3 else 1)
     yield request.param
     ctx.set_option("mfma_form", 0)
+    ctx.set_option("fuse", 0)
 
 
 def test_c2_full_size_pair_bit_exact(vctx, oracle):
@@ -417,25 +424,30 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
     got = {}
     try:
         ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)
-        for form in (1, 2):
-            ctx.set_option("mfma_form", form)
+        for form in (1, 2, 3):                 # K1e, K1f, K1f fused (one workgroup per problem incl. merge + finalize)
+            ctx.set_option("mfma_form", min(form, 2))
+            ctx.set_option("fuse", 2 if form == 3 else 1)
             bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.85, nnr_l=0.9, mutual=mutual)
             tab = bm.run()
             torch.cuda.synchronize()
             keys, part = bm.plan.dump()
-            got[form] = (keys.copy(), part.copy(), tab.cpu().numpy().copy())
+            got[form] = (keys.copy(), part.copy(), tab.cpu().numpy().copy(), bm.counts.cpu().numpy().copy())
             bm.close()
     finally:
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
         ctx.set_option("mfma_form", 0)
+        ctx.set_option("fuse", 0)
     # the dump returns the buffers with their 25 % growth slack: compare the words the kernels write.  (The column
     # PARTIALS are laid out differently -- K1e: 32-bit keys per 256-row block, K1f: 16-bit keys per 64-row block -- so
     # the column direction is compared after the merge: keys21 is part of the key table.)
     rows = pairs * 2 * ((n_orb + n_lbd) * (2 if mutual else 1))
     assert got[1][0].size >= 2 * rows
-    k1, k2 = got[1][0][:2 * rows], got[2][0][:2 * rows]
-    assert np.array_equal(k1, k2), int((k1 != k2).sum())
-    assert np.array_equal(got[1][2], got[2][2])
+    k1 = got[1][0][:2 * rows]
+    for form in (2, 3):
+        k2 = got[form][0][:2 * rows]
+        assert np.array_equal(k1, k2), (form, int((k1 != k2).sum()))
+        assert np.array_equal(got[1][2], got[form][2]), form
+        assert np.array_equal(got[1][3], got[form][3]), form
 
 
 def test_batched_tables_equal_oracle_at_loose_ratio(ctx, oracle):

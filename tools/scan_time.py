@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times the scan kernel alone on the C2 batch (no verification): a scratch tool for kernel experiments.
-usage: scan_time.py [scan_variant] [pairs] [mutual 0|1] [mfma_form]        (PLSLAM_HIP_LIB_EXPERIMENT selects a build)"""
+usage: scan_time.py [scan_variant] [pairs] [mutual 0|1] [mfma_form] [fuse]        (PLSLAM_HIP_LIB_EXPERIMENT selects a build)"""
 import os
 import sys
 
@@ -16,9 +16,11 @@ variant = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 mutual = bool(int(sys.argv[3])) if len(sys.argv) > 3 else True
 form = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+fuse = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 ctx = plslam_amd.Context(0)
 ctx.set_option("scan_variant", variant)
 ctx.set_option("mfma_form", form)
+ctx.set_option("fuse", fuse)
 s = synth.stereo_stream(64, 1500, 200, seed=synth.SEED0)
 reps = pairs // 64
 big = {k: np.concatenate([v[:1]] + [v[1:]] * reps) for k, v in s.items()}
@@ -33,5 +35,5 @@ for _ in range(5):
     bm.plan.run(st.cuda_stream)
 st.synchronize()
 a, b, n = bm.plan.elapsed()
-print(f"{os.path.basename(os.environ.get('PLSLAM_HIP_LIB_EXPERIMENT', 'shipped')):16s} variant {variant} form {form} pairs {pairs} "
+print(f"{os.path.basename(os.environ.get('PLSLAM_HIP_LIB_EXPERIMENT', 'shipped')):16s} variant {variant} form {form} fuse {fuse} pairs {pairs} "
       f"mutual {int(mutual)}: scan {a / n:.3f} ms  merge+finalize {b / n:.3f} ms")
