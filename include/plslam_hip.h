@@ -272,6 +272,43 @@ int plslam_stereo_line_gate(plslam_ctx* ctx, const int32_t* matches_12, int32_t 
                             double stereo_overlap_th, double ls_min_disp_ratio, int32_t* stereo_12,
                             double* disp_se, int32_t* n_stereo);
 
+/* Device-pointer forms: every pointer is a device pointer (kp / seg rows 8 / 16-byte aligned), the kernel is enqueued on
+ * `stream` (NULL = the context's stream) and NOT synchronised; *n_stereo (device, may be NULL) is zeroed on the stream
+ * first.  matches_12 is normally the device table a match plan or plslam_match_dev wrote. */
+int plslam_stereo_point_gate_dev(plslam_ctx* ctx, const int32_t* matches_12, int32_t n_l, const float* kp_l,
+                                 const float* kp_r, int32_t n_r, double max_dist_epip, double min_disp,
+                                 int32_t* stereo_12, double* disp, int32_t* n_stereo, void* stream);
+int plslam_stereo_line_gate_dev(plslam_ctx* ctx, const int32_t* matches_12, int32_t n_l, const float* seg_l,
+                                const float* seg_r, int32_t n_r, double min_disp, double line_horiz_th,
+                                double stereo_overlap_th, double ls_min_disp_ratio, int32_t* stereo_12,
+                                double* disp_se, int32_t* n_stereo, void* stream);
+
+/* The gate stage of a match plan: StereoFrame::matchStereoPoints / matchStereoLines for a whole batch.  Each gate
+ * problem names the L<->R match table of one frame (usually the matches_12 of one of the plan's problems) and that
+ * frame's key points / segments; after plslam_match_plan_add_stereo_gates, every plslam_match_plan_run ends with ONE
+ * more launch that turns all those tables into stereo associations (stereo_12, disparities, counts).  All pointers are
+ * device pointers and must stay valid for the life of the plan.  n_stereo: either NULL in every problem, or the
+ * problems' counters form one contiguous int32 array (gates[i].n_stereo == gates[0].n_stereo + i).  Calling it again
+ * replaces the stage; ngates = 0 removes it. */
+typedef struct plslam_stereo_gate_problem {
+    const int32_t* matches_12;   /* n_l entries: right index or -1                                    */
+    const float* f_l;            /* n_l x 2 (points: pt.x, pt.y) or n_l x 4 (lines: sx, sy, ex, ey)  */
+    const float* f_r;            /* n_r x 2 / n_r x 4                                                */
+    int32_t n_l, n_r;
+    int32_t lines;               /* 0 = points, 1 = lines                                            */
+    int32_t pad;
+    double max_dist_epip;        /* points  (config_kitti.yaml:25)                                   */
+    double min_disp;             /* both    (:26)                                                    */
+    double line_horiz_th;        /* lines   (:34)                                                    */
+    double stereo_overlap_th;    /* lines   (:31)                                                    */
+    double ls_min_disp_ratio;    /* lines   (:36)                                                    */
+    int32_t* stereo_12;          /* out: n_l entries                                                 */
+    double* disp;                /* out: n_l (points) or 2 n_l (lines: disp_s, disp_e) doubles       */
+    int32_t* n_stereo;           /* out: number kept; may be NULL                                    */
+} plslam_stereo_gate_problem;
+int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_stereo_gate_problem* gates,
+                                       int32_t ngates);
+
 /* ---- K3/K4: local-BA residual + Jacobian rows ------------------------------------------- */
 /* Point rows: the per-observation body of MapHandler::levMarquardtOptimizationLBA,
  * src/mapHandler.cpp:1358-1407 (first pass) == :1587-1642 (iteration pass; the caller

@@ -40,7 +40,8 @@ ABI_SYMBOLS = (
     "plslam_kf2kf_match_points", "plslam_kf2kf_match_lines",
     "plslam_lbd_binarise", "plslam_lbd_binarise_dev", "plslam_lbd_compute", "plslam_lbd_compute_dev",
     "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
-    "plslam_stereo_point_gate", "plslam_stereo_line_gate", "plslam_pose_gn_accumulate",
+    "plslam_stereo_point_gate", "plslam_stereo_line_gate", "plslam_stereo_point_gate_dev", "plslam_stereo_line_gate_dev",
+    "plslam_match_plan_add_stereo_gates", "plslam_pose_gn_accumulate",
     "plslam_match_grid", "plslam_grid_plan_create", "plslam_grid_plan_run", "plslam_grid_plan_overflows",
     "plslam_grid_plan_destroy",
     "plslam_gather_match_tables",
@@ -58,6 +59,15 @@ class MatchProblem(C.Structure):
     _fields_ = [("d1", C.c_void_p), ("d2", C.c_void_p), ("n1", C.c_int32), ("n2", C.c_int32),
                 ("nnr", C.c_float), ("mutual", C.c_int32), ("matches_12", C.c_void_p),
                 ("n_matches", C.c_void_p)]
+
+
+class StereoGateProblem(C.Structure):
+    """plslam_stereo_gate_problem (device pointers)"""
+    _fields_ = [("matches_12", C.c_void_p), ("f_l", C.c_void_p), ("f_r", C.c_void_p), ("n_l", C.c_int32),
+                ("n_r", C.c_int32), ("lines", C.c_int32), ("pad", C.c_int32), ("max_dist_epip", C.c_double),
+                ("min_disp", C.c_double), ("line_horiz_th", C.c_double), ("stereo_overlap_th", C.c_double),
+                ("ls_min_disp_ratio", C.c_double), ("stereo_12", C.c_void_p), ("disp", C.c_void_p),
+                ("n_stereo", C.c_void_p)]
 
 
 class GridProblem(C.Structure):
@@ -197,6 +207,9 @@ def load() -> C.CDLL:
     L.plslam_lbd_compute_dev.argtypes = [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]
     L.plslam_stereo_point_gate.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, vp, vp, C.POINTER(i32)]
     L.plslam_stereo_line_gate.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, f64, f64, vp, vp, C.POINTER(i32)]
+    L.plslam_stereo_point_gate_dev.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, vp, vp, vp, vp]
+    L.plslam_stereo_line_gate_dev.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, f64, f64, vp, vp, vp, vp]
+    L.plslam_match_plan_add_stereo_gates.argtypes = [vp, C.POINTER(StereoGateProblem), i32]
     L.plslam_match_grid.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, vp, vp, f64, vp, f64, C.c_int, vp,
                                     C.POINTER(i32)]
     L.plslam_grid_plan_create.argtypes = [vp, C.POINTER(GridProblem), i32, C.POINTER(vp)]
@@ -651,6 +664,19 @@ class MatchPlan:
 
     def run(self, stream: int = 0) -> None:
         _check(self._L.plslam_match_plan_run(self._h, stream or None), "plslam_match_plan_run")
+
+    def add_stereo_gates(self, gates) -> None:
+        """The gate stage (StereoFrame::matchStereoPoints / matchStereoLines over the batch).  gates: iterable of dicts
+        with the fields of plslam_stereo_gate_problem (device pointers as ints)."""
+        gates = list(gates)
+        arr = (StereoGateProblem * max(len(gates), 1))()
+        for i, g in enumerate(gates):
+            arr[i] = StereoGateProblem(g["matches_12"] or None, g["f_l"] or None, g["f_r"] or None, int(g["n_l"]),
+                                       int(g["n_r"]), int(bool(g["lines"])), 0, float(g.get("max_dist_epip", 0.0)),
+                                       float(g.get("min_disp", 0.0)), float(g.get("line_horiz_th", 0.0)),
+                                       float(g.get("stereo_overlap_th", 0.0)), float(g.get("ls_min_disp_ratio", 0.0)),
+                                       g["stereo_12"] or None, g["disp"] or None, g.get("n_stereo") or None)
+        _check(self._L.plslam_match_plan_add_stereo_gates(self._h, arr, len(gates)), "plslam_match_plan_add_stereo_gates")
 
     def set_profiling(self, on: bool) -> None:
         _check(self._L.plslam_match_plan_set_profiling(self._h, int(bool(on))),

@@ -94,6 +94,13 @@ struct plslam_match_plan {
     int32_t** d_count_dst = nullptr;
     int32_t* d_counts_zero = nullptr;  // contiguous int32 counters zeroed by the first scan kernel
     bool scatter_counts = false;       // user n_matches pointers are not one contiguous array
+    // optional last stage: the stereo gates over the L<->R tables of the batch (plslam_match_plan_add_stereo_gates)
+    DevBuf gate_tables;
+    std::vector<char> gate_staging;
+    plslam_stereo_gate_problem* d_gates = nullptr;
+    BlockDesc* d_gate_blocks = nullptr;
+    int32_t ngate_blocks = 0, ngates = 0;
+    int32_t* d_gate_counts = nullptr;  // contiguous counters of the gate problems (or nullptr)
     plslam_plan_info info{};
     bool profiling = false;
     struct Ev { hipEvent_t e0, e1, e2; };
@@ -104,6 +111,7 @@ struct plslam_match_plan {
     void free_all()
     {
         keys.release(); counts.release(); partials.release(); tables.release(); staging_pin.release();
+        gate_tables.release();
         for (auto& e : evs) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2); }
         evs.clear();
     }
@@ -470,6 +478,11 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
     if (r) return r;
     r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, s);
     if (r) return r;
+    if (P->ngate_blocks > 0) {
+        if (P->d_gate_counts) PLSLAM_HIP_CHECK(hipMemsetAsync(P->d_gate_counts, 0, sizeof(int32_t) * (size_t)P->ngates, s));
+        r = launch_stereo_gates(P->d_gates, P->d_gate_blocks, P->ngate_blocks, s);
+        if (r) return r;
+    }
     if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e2, s));
     if (P->scatter_counts)
         return launch_scatter_counts(P->d_counts_zero, P->d_count_dst, P->nprob, s);
@@ -642,6 +655,42 @@ int plslam_match_plan_create(plslam_ctx* ctx, const plslam_match_problem* probs,
         return r;
     }
     *out = P;
+    return PLSLAM_OK;
+}
+
+int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_stereo_gate_problem* gates, int32_t ngates)
+{
+    PLSLAM_REQUIRE(plan != nullptr && ngates >= 0 && (ngates == 0 || gates != nullptr), PLSLAM_EINVAL);
+    DeviceGuard g(plan->ctx->device);
+    plan->ngate_blocks = 0;
+    plan->ngates = 0;
+    plan->d_gate_counts = nullptr;
+    if (ngates == 0) return PLSLAM_OK;
+    std::vector<BlockDesc> blocks;
+    bool any_cnt = false, all_cnt = true;
+    for (int32_t i = 0; i < ngates; ++i) {
+        const int rc = check_stereo_gate_problem(gates[i]);
+        if (rc) return rc;
+        any_cnt = any_cnt || gates[i].n_stereo != nullptr;
+        all_cnt = all_cnt && gates[i].n_stereo != nullptr && gates[i].n_stereo == gates[0].n_stereo + i;
+        for (int32_t r0 = 0; r0 < gates[i].n_l; r0 += 256) blocks.push_back({i, r0});
+    }
+    PLSLAM_REQUIRE(!any_cnt || all_cnt, PLSLAM_EINVAL);     // counters: none, or one contiguous array
+    const size_t gbytes = ((size_t)ngates * sizeof(plslam_stereo_gate_problem) + 255) & ~size_t(255);
+    const size_t total = gbytes + blocks.size() * sizeof(BlockDesc) + 256;
+    plan->gate_staging.assign(total, 0);
+    memcpy(plan->gate_staging.data(), gates, (size_t)ngates * sizeof(plslam_stereo_gate_problem));
+    if (!blocks.empty()) memcpy(plan->gate_staging.data() + gbytes, blocks.data(), blocks.size() * sizeof(BlockDesc));
+    int r = plan->gate_tables.reserve(total);
+    if (r) return r;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(plan->gate_tables.p, plan->gate_staging.data(), total, hipMemcpyHostToDevice,
+                                    plan->ctx->stream));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(plan->ctx->stream));
+    plan->d_gates = plan->gate_tables.as<plslam_stereo_gate_problem>();
+    plan->d_gate_blocks = reinterpret_cast<BlockDesc*>(plan->gate_tables.as<char>() + gbytes);
+    plan->ngate_blocks = (int32_t)blocks.size();
+    plan->ngates = ngates;
+    plan->d_gate_counts = any_cnt ? gates[0].n_stereo : nullptr;
     return PLSLAM_OK;
 }
 

@@ -199,6 +199,10 @@ int launch_visible(const plslam_cam& K, const double* Twf16, const double* X, in
 int launch_project_cells(const plslam_cam& K, const double* Twf16, const double* X, int32_t n, int lines, double inv_w,
                          double inv_h, int32_t* cells, double* dir1, hipStream_t s);
 
+// --- stereo gates (stereo_gates.hip) -------------------------------------------------------------
+int launch_stereo_gates(const plslam_stereo_gate_problem* d_gates, const BlockDesc* d_blocks, int nblocks, hipStream_t s);
+int check_stereo_gate_problem(const plslam_stereo_gate_problem& q);
+
 // --- representative descriptor per landmark (median_desc.hip) ---------------------------------
 // desc: total x 32 u8 (4-byte aligned), off: n_lm+1 CSR offsets (device), med_idx: n_lm, med_desc:
 // n_lm x 32 or nullptr.  memset + 2 kernels on s.

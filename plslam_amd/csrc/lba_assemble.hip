@@ -293,6 +293,7 @@ extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, doub
         return rc;
     }
     std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);    // every entry point runs on the context's device, whatever the calling thread's current one
     hipStream_t s = ctx->stream;
     char* d = P->stat.as<char>();
     auto up = [&](size_t off, const void* src, size_t bytes) -> int {
@@ -325,6 +326,7 @@ extern "C" int plslam_lba_plan_iterate(plslam_lba_plan* P, const double* T_kf_w,
     PLSLAM_REQUIRE((P->nkf == 0 || H_pose) && (P->np == 0 || W_pt) && (P->nl == 0 || W_ls), PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);    // every entry point runs on the context's device, whatever the calling thread's current one
     hipStream_t s = ctx->stream;
     char *ds = P->stat.as<char>(), *dd = P->dyn.as<char>(), *dr = P->rows.as<char>(), *dout = P->out.as<char>();
     if (P->n_slots) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd + P->oT, T_kf_w, (size_t)P->n_slots * 128, hipMemcpyHostToDevice, s));
@@ -369,6 +371,7 @@ extern "C" int plslam_lba_plan_rows(plslam_lba_plan* P, double* pt_J_pose, doubl
     PLSLAM_REQUIRE(P != nullptr, PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);    // every entry point runs on the context's device, whatever the calling thread's current one
     hipStream_t s = ctx->stream;
     char* dr = P->rows.as<char>();
     const size_t np = (size_t)P->np, nl = (size_t)P->nl;
@@ -415,6 +418,7 @@ extern "C" int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, in
     std::vector<int32_t>&ptp = L.ptp, &pti = L.pti, &lsp = L.lsp, &lsi = L.lsi, &kfp = L.kfp, &kfi = L.kfi;
 
     std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);    // every entry point runs on the context's device, whatever the calling thread's current one
     hipStream_t s = ctx->stream;
     Carve c;
     const size_t np = (size_t)n_pt_obs, nl = (size_t)n_ls_obs;

@@ -255,6 +255,7 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     if (nt == 0) return PLSLAM_OK;                                        // :571 / :676
 
     std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);    // every entry point runs on the context's device, whatever the calling thread's current one
     hipStream_t s = ctx->stream;
     // ---- stage the map and the keyframe on the device, project + visibility test ------------
     Carve c;

@@ -17,32 +17,19 @@
 namespace plslam {
 namespace {
 
-__global__ void __launch_bounds__(256)
-k_stereo_point_gate(const int32_t* __restrict__ m12, int32_t n_l, const float2* __restrict__ kp_l,
-                    const float2* __restrict__ kp_r, int32_t n_r, double max_dist_epip, double min_disp,
-                    int32_t* __restrict__ stereo_12, double* __restrict__ disp, int32_t* __restrict__ count)
+// one left key point: the gate of matchStereoPoints; returns the kept right index or -1, *dsp = its disparity or 0
+__device__ __forceinline__ int32_t point_gate_one(int32_t i2, float2 a, const float2* __restrict__ kp_r, int32_t n_r,
+                                                  double max_dist_epip, double min_disp, double* dsp)
 {
-    const int i1 = blockIdx.x * 256 + threadIdx.x;
-    int ok = 0;
-    if (i1 < n_l) {
-        const int32_t i2 = m12[i1];
-        double dsp = 0.0;
-        if (i2 >= 0 && i2 < n_r) {
-            const float2 a = kp_l[i1], b = kp_r[i2];
-            const float dy = __fsub_rn(a.y, b.y);
-            if ((double)fabsf(dy) <= max_dist_epip) {
-                const double d = (double)__fsub_rn(a.x, b.x);
-                if (d >= min_disp) {
-                    ok = 1;
-                    dsp = d;
-                }
-            }
-        }
-        stereo_12[i1] = ok ? i2 : -1;
-        disp[i1] = dsp;
-    }
-    const unsigned long long bal = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(count, (int)__popcll(bal));
+    *dsp = 0.0;
+    if (i2 < 0 || i2 >= n_r) return -1;
+    const float2 b = kp_r[i2];
+    const float dy = __fsub_rn(a.y, b.y);
+    if (!((double)fabsf(dy) <= max_dist_epip)) return -1;
+    const double d = (double)__fsub_rn(a.x, b.x);
+    if (!(d >= min_disp)) return -1;
+    *dsp = d;
+    return i2;
 }
 
 __device__ __forceinline__ double dmin2(double a, double b) { return b < a ? b : a; }   // std::min
@@ -72,6 +59,57 @@ __device__ __forceinline__ double overlap_stereo(double spl_obs, double epl_obs,
     return overlap;
 }
 
+// one left segment: the gate of matchStereoLines (the second end point reads the already overwritten first one, as the
+// source does); returns the kept right index or -1, ds / de = the end-point disparities or 0
+__device__ __forceinline__ int32_t line_gate_one(int32_t i2, float4 L, const float4* __restrict__ seg_r, int32_t n_r,
+                                                 double min_disp, double line_horiz_th, double stereo_overlap_th,
+                                                 double ls_min_disp_ratio, double* ds, double* de)
+{
+    *ds = 0.0;
+    *de = 0.0;
+    if (i2 < 0 || i2 >= n_r) return -1;
+    const float4 R = seg_r[i2];
+    const double sp_l[2] = {L.x, L.y}, ep_l[2] = {L.z, L.w};
+    double sp_r[2] = {R.x, R.y}, ep_r[2] = {R.z, R.w};
+    const double overlap = overlap_stereo(sp_l[1], ep_l[1], sp_r[1], ep_r[1], line_horiz_th);
+    const double sx = (sp_r[0] * (sp_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - sp_l[1])) / (sp_r[1] - ep_r[1]);
+    sp_r[0] = sx;
+    sp_r[1] = sp_l[1];
+    const double ex = (sp_r[0] * (ep_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - ep_l[1])) / (sp_r[1] - ep_r[1]);
+    ep_r[0] = ex;
+    ep_r[1] = ep_l[1];
+    double disp_s = sp_l[0] - sp_r[0], disp_e = ep_l[0] - ep_r[0];
+    if (dmin2(disp_s, disp_e) / dmax2(disp_s, disp_e) < ls_min_disp_ratio) {
+        disp_s = -1.0;
+        disp_e = -1.0;
+    }
+    if (disp_s >= min_disp && disp_e >= min_disp && fabs(sp_l[1] - ep_l[1]) > line_horiz_th &&
+        fabs(sp_r[1] - ep_r[1]) > line_horiz_th && overlap > stereo_overlap_th) {
+        *ds = disp_s;
+        *de = disp_e;
+        return i2;
+    }
+    return -1;
+}
+
+__global__ void __launch_bounds__(256)
+k_stereo_point_gate(const int32_t* __restrict__ m12, int32_t n_l, const float2* __restrict__ kp_l,
+                    const float2* __restrict__ kp_r, int32_t n_r, double max_dist_epip, double min_disp,
+                    int32_t* __restrict__ stereo_12, double* __restrict__ disp, int32_t* __restrict__ count)
+{
+    const int i1 = blockIdx.x * 256 + threadIdx.x;
+    int ok = 0;
+    if (i1 < n_l) {
+        double dsp;
+        const int32_t k = point_gate_one(m12[i1], kp_l[i1], kp_r, n_r, max_dist_epip, min_disp, &dsp);
+        ok = k >= 0;
+        stereo_12[i1] = k;
+        disp[i1] = dsp;
+    }
+    const unsigned long long bal = __ballot(ok);
+    if (count && (threadIdx.x & 63) == 0 && bal) atomicAdd(count, (int)__popcll(bal));
+}
+
 __global__ void __launch_bounds__(256)
 k_stereo_line_gate(const int32_t* __restrict__ m12, int32_t n_l, const float4* __restrict__ seg_l,
                    const float4* __restrict__ seg_r, int32_t n_r, double min_disp, double line_horiz_th,
@@ -81,37 +119,48 @@ k_stereo_line_gate(const int32_t* __restrict__ m12, int32_t n_l, const float4* _
     const int i1 = blockIdx.x * 256 + threadIdx.x;
     int ok = 0;
     if (i1 < n_l) {
-        const int32_t i2 = m12[i1];
-        double ds = 0.0, de = 0.0;
-        if (i2 >= 0 && i2 < n_r) {
-            const float4 L = seg_l[i1], R = seg_r[i2];
-            const double sp_l[2] = {L.x, L.y}, ep_l[2] = {L.z, L.w};
-            double sp_r[2] = {R.x, R.y}, ep_r[2] = {R.z, R.w};
-            const double overlap = overlap_stereo(sp_l[1], ep_l[1], sp_r[1], ep_r[1], line_horiz_th);
-            const double sx = (sp_r[0] * (sp_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - sp_l[1])) / (sp_r[1] - ep_r[1]);
-            sp_r[0] = sx;
-            sp_r[1] = sp_l[1];
-            const double ex = (sp_r[0] * (ep_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - ep_l[1])) / (sp_r[1] - ep_r[1]);
-            ep_r[0] = ex;
-            ep_r[1] = ep_l[1];
-            double disp_s = sp_l[0] - sp_r[0], disp_e = ep_l[0] - ep_r[0];
-            if (dmin2(disp_s, disp_e) / dmax2(disp_s, disp_e) < ls_min_disp_ratio) {
-                disp_s = -1.0;
-                disp_e = -1.0;
-            }
-            if (disp_s >= min_disp && disp_e >= min_disp && fabs(sp_l[1] - ep_l[1]) > line_horiz_th &&
-                fabs(sp_r[1] - ep_r[1]) > line_horiz_th && overlap > stereo_overlap_th) {
-                ok = 1;
-                ds = disp_s;
-                de = disp_e;
-            }
-        }
-        stereo_12[i1] = ok ? i2 : -1;
+        double ds, de;
+        const int32_t k = line_gate_one(m12[i1], seg_l[i1], seg_r, n_r, min_disp, line_horiz_th, stereo_overlap_th,
+                                        ls_min_disp_ratio, &ds, &de);
+        ok = k >= 0;
+        stereo_12[i1] = k;
         disp_se[2 * (size_t)i1] = ds;
         disp_se[2 * (size_t)i1 + 1] = de;
     }
     const unsigned long long bal = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(count, (int)__popcll(bal));
+    if (count && (threadIdx.x & 63) == 0 && bal) atomicAdd(count, (int)__popcll(bal));
+}
+
+// the gate stage of a match plan: every (gate problem, 256 left features) pair is one workgroup of ONE launch
+__global__ void __launch_bounds__(256)
+k_stereo_gates_batched(const plslam_stereo_gate_problem* __restrict__ gates, const BlockDesc* __restrict__ blocks)
+{
+    const BlockDesc bd = blocks[blockIdx.x];
+    const plslam_stereo_gate_problem q = gates[bd.item];
+    const int i1 = bd.row0 + (int)threadIdx.x;
+    int ok = 0;
+    if (i1 < q.n_l) {
+        const int32_t i2 = q.matches_12[i1];
+        if (q.lines) {
+            double ds, de;
+            const int32_t k = line_gate_one(i2, reinterpret_cast<const float4*>(q.f_l)[i1],
+                                            reinterpret_cast<const float4*>(q.f_r), q.n_r, q.min_disp, q.line_horiz_th,
+                                            q.stereo_overlap_th, q.ls_min_disp_ratio, &ds, &de);
+            ok = k >= 0;
+            q.stereo_12[i1] = k;
+            q.disp[2 * (size_t)i1] = ds;
+            q.disp[2 * (size_t)i1 + 1] = de;
+        } else {
+            double dsp;
+            const int32_t k = point_gate_one(i2, reinterpret_cast<const float2*>(q.f_l)[i1],
+                                             reinterpret_cast<const float2*>(q.f_r), q.n_r, q.max_dist_epip, q.min_disp, &dsp);
+            ok = k >= 0;
+            q.stereo_12[i1] = k;
+            q.disp[i1] = dsp;
+        }
+    }
+    const unsigned long long bal = __ballot(ok);
+    if (q.n_stereo && (threadIdx.x & 63) == 0 && bal) atomicAdd(q.n_stereo, (int)__popcll(bal));
 }
 
 // one host-pointer call: lines != 0 -> segments (4 floats per feature) and two disparities per feature
@@ -163,9 +212,76 @@ int stereo_gate_host(plslam_ctx* ctx, int lines, const int32_t* m12, int32_t n_l
 }
 
 }  // namespace
+
+int launch_stereo_gates(const plslam_stereo_gate_problem* d_gates, const BlockDesc* d_blocks, int nblocks, hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_stereo_gates_batched, dim3(nblocks), dim3(256), 0, s, d_gates, d_blocks);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int check_stereo_gate_problem(const plslam_stereo_gate_problem& q)
+{
+    PLSLAM_REQUIRE(q.n_l >= 0 && q.n_r >= 0, PLSLAM_EINVAL);
+    if (q.n_l == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(q.matches_12 && q.f_l && q.stereo_12 && q.disp && (q.n_r == 0 || q.f_r), PLSLAM_EINVAL);
+    const uintptr_t al = q.lines ? 15 : 7;            // float4 / float2 rows
+    PLSLAM_REQUIRE((reinterpret_cast<uintptr_t>(q.f_l) & al) == 0 && (reinterpret_cast<uintptr_t>(q.f_r) & al) == 0,
+                   PLSLAM_EINVAL);
+    PLSLAM_REQUIRE((reinterpret_cast<uintptr_t>(q.disp) & 7) == 0, PLSLAM_EINVAL);
+    return PLSLAM_OK;
+}
+
+// one gate problem with DEVICE pointers on stream `s` (no synchronisation); *n_stereo is zeroed first when given
+static int stereo_gate_dev(plslam_ctx* ctx, const plslam_stereo_gate_problem& q, hipStream_t s)
+{
+    PLSLAM_REQUIRE(ctx != nullptr, PLSLAM_EINVAL);
+    int rc = check_stereo_gate_problem(q);
+    if (rc) return rc;
+    DeviceGuard g(ctx->device);
+    if (!s) s = ctx->stream;
+    if (q.n_stereo) PLSLAM_HIP_CHECK(hipMemsetAsync(q.n_stereo, 0, 4, s));
+    if (q.n_l == 0) return PLSLAM_OK;
+    const dim3 grid((unsigned)((q.n_l + 255) / 256)), block(256);
+    if (!q.lines)
+        hipLaunchKernelGGL(k_stereo_point_gate, grid, block, 0, s, q.matches_12, q.n_l, (const float2*)q.f_l,
+                           (const float2*)q.f_r, q.n_r, q.max_dist_epip, q.min_disp, q.stereo_12, q.disp, q.n_stereo);
+    else
+        hipLaunchKernelGGL(k_stereo_line_gate, grid, block, 0, s, q.matches_12, q.n_l, (const float4*)q.f_l,
+                           (const float4*)q.f_r, q.n_r, q.min_disp, q.line_horiz_th, q.stereo_overlap_th,
+                           q.ls_min_disp_ratio, q.stereo_12, q.disp, q.n_stereo);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
 }  // namespace plslam
 
 extern "C" {
+
+int plslam_stereo_point_gate_dev(plslam_ctx* ctx, const int32_t* matches_12, int32_t n_l, const float* kp_l,
+                                 const float* kp_r, int32_t n_r, double max_dist_epip, double min_disp,
+                                 int32_t* stereo_12, double* disp, int32_t* n_stereo, void* stream)
+{
+    plslam_stereo_gate_problem q{};
+    q.matches_12 = matches_12; q.f_l = kp_l; q.f_r = kp_r; q.n_l = n_l; q.n_r = n_r; q.lines = 0;
+    q.max_dist_epip = max_dist_epip; q.min_disp = min_disp;
+    q.stereo_12 = stereo_12; q.disp = disp; q.n_stereo = n_stereo;
+    return plslam::stereo_gate_dev(ctx, q, static_cast<hipStream_t>(stream));
+}
+
+int plslam_stereo_line_gate_dev(plslam_ctx* ctx, const int32_t* matches_12, int32_t n_l, const float* seg_l,
+                                const float* seg_r, int32_t n_r, double min_disp, double line_horiz_th,
+                                double stereo_overlap_th, double ls_min_disp_ratio, int32_t* stereo_12,
+                                double* disp_se, int32_t* n_stereo, void* stream)
+{
+    plslam_stereo_gate_problem q{};
+    q.matches_12 = matches_12; q.f_l = seg_l; q.f_r = seg_r; q.n_l = n_l; q.n_r = n_r; q.lines = 1;
+    q.min_disp = min_disp; q.line_horiz_th = line_horiz_th; q.stereo_overlap_th = stereo_overlap_th;
+    q.ls_min_disp_ratio = ls_min_disp_ratio;
+    q.stereo_12 = stereo_12; q.disp = disp_se; q.n_stereo = n_stereo;
+    return plslam::stereo_gate_dev(ctx, q, static_cast<hipStream_t>(stream));
+}
 
 int plslam_stereo_point_gate(plslam_ctx* ctx, const int32_t* matches_12, int32_t n_l, const float* kp_l,
                              const float* kp_r, int32_t n_r, double max_dist_epip, double min_disp,

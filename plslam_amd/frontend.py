@@ -50,7 +50,12 @@ class StereoBatchMatcher:
     `n_buffers` output tables (and plans) over the same descriptors let step k+1 compute while the
     table of step k is still being gathered (bench.py, N > 1)."""
 
-    def __init__(self, ctx, stream_np: dict, nnr_p=0.75, nnr_l=0.75, mutual=True, device=None, n_buffers=1):
+    def __init__(self, ctx, stream_np: dict, nnr_p=0.75, nnr_l=0.75, mutual=True, device=None, n_buffers=1,
+                 geometry: dict | None = None, gates: dict | None = None):
+        """geometry (synth.stereo_geometry: kp_l, kp_r, seg_l, seg_r per frame) + gates (the thresholds max_dist_epip,
+        min_disp, line_horiz_th, stereo_overlap_th, ls_min_disp_ratio) add the gate stage of StereoFrame to every plan:
+        each run then also fills `stereo` (B, n_orb + n_lbd) int32 -- the L<->R associations that survive the epipolar /
+        disparity / overlap gates -- `stereo_disp` (B, n_orb + 2 n_lbd) float64 and `stereo_counts` (B, 2)."""
         import torch
         self.torch = torch
         self.ctx = ctx
@@ -60,12 +65,19 @@ class StereoBatchMatcher:
         self.n_orb = stream_np["orb_l"].shape[1]
         self.n_lbd = stream_np["lbd_l"].shape[1]
         self.stride = table_stride(self.n_orb, self.n_lbd)
-        self.d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in stream_np.items()}
+        self.d = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in stream_np.items()
+                  if k in ("orb_l", "orb_r", "lbd_l", "lbd_r")}
+        self.g = None
+        if geometry is not None:
+            assert gates is not None, "thresholds required (e.g. synth.KITTI_GATES)"
+            self.g = {k: torch.from_numpy(np.ascontiguousarray(geometry[k], np.float32)).to(dev)
+                      for k in ("kp_l", "kp_r", "seg_l", "seg_r")}
         sl = table_slices(self.n_orb, self.n_lbd)
         row_o, row_l = self.n_orb * 32, self.n_lbd * 32
         ol, orr = self.d["orb_l"].data_ptr(), self.d["orb_r"].data_ptr()
         ll, lr = self.d["lbd_l"].data_ptr(), self.d["lbd_r"].data_ptr()
         self.tables, self.count_bufs, self.plans = [], [], []
+        self.stereo_tabs, self.stereo_disps, self.stereo_cnts = [], [], []
         for _ in range(n_buffers):
             table = torch.full((self.B, self.stride), -2, dtype=torch.int32, device=dev)
             counts = torch.zeros((self.B, 4), dtype=torch.int32, device=dev)
@@ -84,8 +96,33 @@ class StereoBatchMatcher:
                               t_i + 4 * sl["lbd_pc"].start, c_i + 12))
             self.tables.append(table)
             self.count_bufs.append(counts)
-            self.plans.append(ctx.plan(probs))
+            plan = ctx.plan(probs)
+            if self.g is not None:
+                # the stereo gates over the L<->R tables of this buffer: points then lines of pair i
+                st = torch.full((self.B, self.n_orb + self.n_lbd), -2, dtype=torch.int32, device=dev)
+                sd = torch.zeros((self.B, self.n_orb + 2 * self.n_lbd), dtype=torch.float64, device=dev)
+                sc = torch.zeros((self.B, 2), dtype=torch.int32, device=dev)
+                kl, kr, gl, gr = (self.g[k].data_ptr() for k in ("kp_l", "kp_r", "seg_l", "seg_r"))
+                glist = []
+                for i in range(self.B):
+                    t_i = tb + 4 * self.stride * i
+                    s_i = st.data_ptr() + 4 * (self.n_orb + self.n_lbd) * i
+                    d_i = sd.data_ptr() + 8 * (self.n_orb + 2 * self.n_lbd) * i
+                    glist.append(dict(matches_12=t_i + 4 * sl["orb_lr"].start, f_l=kl + 8 * self.n_orb * (i + 1),
+                                      f_r=kr + 8 * self.n_orb * (i + 1), n_l=self.n_orb, n_r=self.n_orb, lines=0,
+                                      stereo_12=s_i, disp=d_i, n_stereo=sc.data_ptr() + 8 * i, **gates))
+                    glist.append(dict(matches_12=t_i + 4 * sl["lbd_lr"].start, f_l=gl + 16 * self.n_lbd * (i + 1),
+                                      f_r=gr + 16 * self.n_lbd * (i + 1), n_l=self.n_lbd, n_r=self.n_lbd, lines=1,
+                                      stereo_12=s_i + 4 * self.n_orb, disp=d_i + 8 * self.n_orb,
+                                      n_stereo=sc.data_ptr() + 8 * i + 4, **gates))
+                plan.add_stereo_gates(glist)
+                self.stereo_tabs.append(st)
+                self.stereo_disps.append(sd)
+                self.stereo_cnts.append(sc)
+            self.plans.append(plan)
         self.table, self.counts, self.plan = self.tables[0], self.count_bufs[0], self.plans[0]
+        if self.g is not None:
+            self.stereo, self.stereo_disp, self.stereo_counts = self.stereo_tabs[0], self.stereo_disps[0], self.stereo_cnts[0]
         # A real (non-NULL) HIP stream: the C ABI reads a NULL stream as "the context's own stream",
         # and torch's legacy default stream has handle 0.
         self.stream = torch.cuda.Stream(device=dev)

@@ -81,6 +81,11 @@ def stereo_stream(n_pairs, n_orb=1500, n_lbd=200, seed=SEED0, first_pair=0, tie_
     independently of the others (contiguous shards produce bit-identical data)."""
     out = {k: np.empty((n_pairs + 1, n, 32), np.uint8)
            for k, n in (("orb_l", n_orb), ("orb_r", n_orb), ("lbd_l", n_lbd), ("lbd_r", n_lbd))}
+    # which left row a right row descends from (and whether it is a fresh random row instead): the ground truth
+    # stereo_geometry() places the key points / segments by.  No effect on the descriptors or on the random sequence.
+    for kind, n in (("orb", n_orb), ("lbd", n_lbd)):
+        out[kind + "_rperm"] = np.zeros((n_pairs + 1, n), np.int32)
+        out[kind + "_rfresh"] = np.ones((n_pairs + 1, n), bool)
     f0 = first_pair - 1
     start = (f0 // 64) * 64 if f0 >= 0 else f0  # chain restart boundary at or before f0
     prev = {}
@@ -88,6 +93,7 @@ def stereo_stream(n_pairs, n_orb=1500, n_lbd=200, seed=SEED0, first_pair=0, tie_
         rng = np.random.Generator(np.random.PCG64(seed + 7919 * (f + 1)))
         cur = {}
         for kind, n in (("orb", n_orb), ("lbd", n_lbd)):
+            rperm, rfresh = np.arange(n, dtype=np.int32), np.ones(n, bool)
             if tie_stress:
                 left = tie_stress_desc(rng, n)
                 right = tie_stress_desc(rng, n)
@@ -96,14 +102,62 @@ def stereo_stream(n_pairs, n_orb=1500, n_lbd=200, seed=SEED0, first_pair=0, tie_
                     left = random_desc(rng, n)
                 else:
                     left, _, _ = noisy_copy(rng, prev[kind])
-                right, _, _ = noisy_copy(rng, left)
+                right, rperm, rfresh = noisy_copy(rng, left)
             cur[kind] = left
             i = f - f0
             if i >= 0:
                 out[kind + "_l"][i] = left
                 out[kind + "_r"][i] = right
+                out[kind + "_rperm"][i] = rperm
+                out[kind + "_rfresh"][i] = rfresh
         prev = cur
     return out
+
+
+def stereo_geometry(stream, seed=SEED0 + 1, width=752, height=480, first_pair=0):
+    """Key points and line segments for the frames of a stereo_stream(): float32 arrays kp_l, kp_r (frames, n_orb, 2)
+    and seg_l, seg_r (frames, n_lbd, 4) -- what StereoFrame's detectors would hand to matchStereoPoints / Lines.
+    A right feature that descends from a left one (stream["*_rperm"], not "*_rfresh") sits at the left position minus
+    a disparity, with sub-pixel noise across the epipolar line; fresh ones lie anywhere.  A share of the lines is
+    horizontal, degenerate or only partly overlapping, so that every branch of the gates is taken.  Frame f's
+    geometry depends only on (seed, first_pair + index)."""
+    frames, n_orb = stream["orb_l"].shape[:2]
+    n_lbd = stream["lbd_l"].shape[1]
+    out = {"kp_l": np.empty((frames, n_orb, 2), np.float32), "kp_r": np.empty((frames, n_orb, 2), np.float32),
+           "seg_l": np.empty((frames, n_lbd, 4), np.float32), "seg_r": np.empty((frames, n_lbd, 4), np.float32)}
+    for i in range(frames):
+        r = np.random.Generator(np.random.PCG64(seed + 104729 * (first_pair + i)))
+        # FAST corners sit on integer pixels (level 0); the shipped configuration keeps only pairs on the SAME row
+        # (max_dist_epip: 0.0), so the row noise is quantised: about 60 % of the true pairs stay on their row
+        kp_l = np.floor(np.stack([r.uniform(0, width, n_orb), r.uniform(0, height, n_orb)], 1))
+        src = stream["orb_rperm"][i]
+        kp_r = kp_l[src] - np.stack([np.floor(r.uniform(-3, 60, n_orb)), np.rint(r.normal(0, 0.6, n_orb))], 1)
+        fresh = stream["orb_rfresh"][i]
+        kp_r[fresh] = np.stack([r.uniform(0, width, n_orb), r.uniform(0, height, n_orb)], 1)[fresh]
+        out["kp_l"][i], out["kp_r"][i] = kp_l, kp_r
+        a = np.stack([r.uniform(0, width, n_lbd), r.uniform(0, height, n_lbd)], 1)
+        ang, ln = r.uniform(0, np.pi, n_lbd), r.uniform(5, 150, n_lbd)
+        ln[r.random(n_lbd) < 0.03] = 0.0                                 # zero-length segments
+        ang[r.random(n_lbd) < 0.08] = 0.0                                # horizontal: dy = 0 (division by zero)
+        seg_l = np.concatenate([a, a + np.stack([np.cos(ang), np.sin(ang)], 1) * ln[:, None]], 1)
+        src = stream["lbd_rperm"][i]
+        d0, d1 = r.uniform(-2, 50, n_lbd), r.uniform(0.5, 1.5, n_lbd)
+        seg_r = seg_l[src].copy()
+        seg_r[:, 0] -= d0
+        seg_r[:, 2] -= d0 * d1
+        seg_r += r.normal(0, 0.6, seg_r.shape)
+        cut = r.random(n_lbd) < 0.25                                     # partial vertical overlap
+        seg_r[cut, 2:] = seg_r[cut, :2] + (seg_r[cut, 2:] - seg_r[cut, :2]) * r.uniform(0.1, 0.9, (int(cut.sum()), 1))
+        fresh = stream["lbd_rfresh"][i]
+        rnd = np.concatenate([np.stack([r.uniform(0, width, n_lbd), r.uniform(0, height, n_lbd)], 1),
+                              np.stack([r.uniform(0, width, n_lbd), r.uniform(0, height, n_lbd)], 1)], 1)
+        seg_r[fresh] = rnd[fresh]
+        out["seg_l"][i], out["seg_r"][i] = seg_l, seg_r
+    return out
+
+
+# the stereo-gate thresholds of the reference's shipped configuration (config/config/config_kitti.yaml:25-36)
+KITTI_GATES = dict(max_dist_epip=0.0, min_disp=1.0, line_horiz_th=0.1, stereo_overlap_th=0.75, ls_min_disp_ratio=0.7)
 
 
 def se3_exp(x):

@@ -141,3 +141,90 @@ def test_gpu_stereo_association_end_to_end(ctx, oracle):
     truth = np.argsort(perm)                                           # left i1 <-> right truth[i1]
     kept = got[0] >= 0
     assert kept.sum() > 0.6 * n and (got[0][kept] == truth[kept]).mean() > 0.99
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pairs,n_orb,n_lbd,gates", [
+    (64, 1500, 200, "kitti"),                                          # C2 sizes, the shipped thresholds
+    (96, 300, 70, dict(max_dist_epip=1.0, min_disp=0.0, line_horiz_th=1.0, stereo_overlap_th=0.2, ls_min_disp_ratio=0.3)),
+    (8, 2100, 33, dict(max_dist_epip=2.5, min_disp=-5.0, line_horiz_th=0.0, stereo_overlap_th=0.0, ls_min_disp_ratio=0.0))])
+def test_gate_stage_of_the_batch_plan(ctx, oracle, pairs, n_orb, n_lbd, gates):
+    """SURVEY 8 a4 in the batched path: ONE plslam_match_plan_run yields, for every pair of the batch, the L<->R match
+    tables AND the stereo associations that survive StereoFrame's gates (device-resident tables in, no host round
+    trip).  Every pair is compared with the oracle chain match -> gate bit for bit: table, disparities (as raw 64-bit
+    words: NaN rows of degenerate lines included) and counts."""
+    import torch
+    import plslam_amd
+    from plslam_amd import frontend, synth
+    th = synth.KITTI_GATES if gates == "kitti" else gates
+    s = synth.stereo_stream(pairs, n_orb, n_lbd, seed=991 + n_orb)
+    geo = synth.stereo_geometry(s, seed=17)
+    try:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)
+        bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.75, nnr_l=0.9, mutual=True, geometry=geo, gates=th, n_buffers=2)
+    finally:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+    for k in range(3):                                                  # both buffers, re-run: idempotent
+        bm.run_overlapped(k)
+    bm.synchronize_all()
+    for b in range(2):
+        tab = bm.tables[b].cpu().numpy()
+        st, sd, sc = bm.stereo_tabs[b].cpu().numpy(), bm.stereo_disps[b].cpu().numpy(), bm.stereo_cnts[b].cpu().numpy()
+        sl = frontend.table_slices(n_orb, n_lbd)
+        kept_p = kept_l = 0
+        check = range(pairs) if b == 0 else range(0, pairs, 7)
+        with np.errstate(all="ignore"):
+            for i in check:
+                mp, _ = oracle.match(s["orb_l"][i + 1], s["orb_r"][i + 1], 0.75, True)
+                ml, _ = oracle.match(s["lbd_l"][i + 1], s["lbd_r"][i + 1], 0.9, True)
+                np.testing.assert_array_equal(tab[i, sl["orb_lr"]], mp)
+                np.testing.assert_array_equal(tab[i, sl["lbd_lr"]], ml)
+                ep, dp, cp = oracle.stereo_point_gate(mp, geo["kp_l"][i + 1], geo["kp_r"][i + 1], th["max_dist_epip"],
+                                                      th["min_disp"])
+                el, dl, cl = oracle.stereo_line_gate(ml, geo["seg_l"][i + 1], geo["seg_r"][i + 1], th["min_disp"],
+                                                     th["line_horiz_th"], th["stereo_overlap_th"], th["ls_min_disp_ratio"])
+                np.testing.assert_array_equal(st[i, :n_orb], ep)
+                np.testing.assert_array_equal(st[i, n_orb:], el)
+                np.testing.assert_array_equal(sd[i, :n_orb].view(np.uint64), dp.view(np.uint64))
+                np.testing.assert_array_equal(sd[i, n_orb:].view(np.uint64), dl.reshape(-1).view(np.uint64))
+                assert sc[i].tolist() == [cp, cl]
+                kept_p += cp
+                kept_l += cl
+        assert kept_p > 0 and (kept_l > 0 or n_lbd < 40)
+    bm.close()
+
+
+@pytest.mark.gpu
+def test_device_pointer_gates(ctx, oracle):
+    """plslam_stereo_point_gate_dev / _line_gate_dev: device tables in, device results out, on a caller's stream."""
+    import ctypes as C
+    import torch
+    m12, kp_l, kp_r = stereo_points(3, 1500, 1400)
+    ml, seg_l, seg_r = stereo_lines(4, 200, 210)
+    dev = torch.device("cuda", ctx.device)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)     # noqa: E731
+    d_m, d_a, d_b = t(m12), t(kp_l), t(kp_r)
+    out = torch.empty(1500, dtype=torch.int32, device=dev)
+    disp = torch.empty(1500, dtype=torch.float64, device=dev)
+    cnt = torch.full((2,), 77, dtype=torch.int32, device=dev)
+    st = torch.cuda.Stream(device=dev)
+    L = ctx._L
+    assert L.plslam_stereo_point_gate_dev(ctx.handle, d_m.data_ptr(), 1500, d_a.data_ptr(), d_b.data_ptr(), 1400, 1.0, 1.0,
+                                          out.data_ptr(), disp.data_ptr(), cnt.data_ptr(), st.cuda_stream) == 0
+    e_m, e_a, e_b = t(ml), t(seg_l), t(seg_r)
+    out_l = torch.empty(200, dtype=torch.int32, device=dev)
+    disp_l = torch.empty((200, 2), dtype=torch.float64, device=dev)
+    assert L.plslam_stereo_line_gate_dev(ctx.handle, e_m.data_ptr(), 200, e_a.data_ptr(), e_b.data_ptr(), 210, 1.0, 0.1, 0.75,
+                                         0.7, out_l.data_ptr(), disp_l.data_ptr(), cnt.data_ptr() + 4, st.cuda_stream) == 0
+    st.synchronize()
+    rp = oracle.stereo_point_gate(m12, kp_l, kp_r, 1.0, 1.0)
+    with np.errstate(all="ignore"):
+        rl = oracle.stereo_line_gate(ml, seg_l, seg_r, 1.0, 0.1, 0.75, 0.7)
+    np.testing.assert_array_equal(out.cpu().numpy(), rp[0])
+    np.testing.assert_array_equal(disp.cpu().numpy().view(np.uint64), rp[1].view(np.uint64))
+    np.testing.assert_array_equal(out_l.cpu().numpy(), rl[0])
+    np.testing.assert_array_equal(disp_l.cpu().numpy().view(np.uint64), rl[1].view(np.uint64))
+    assert cnt.cpu().numpy().tolist() == [rp[2], rl[2]]
+    # argument checks: misaligned feature rows, counters that are not one array
+    assert L.plslam_stereo_point_gate_dev(ctx.handle, d_m.data_ptr(), 1500, d_a.data_ptr() + 4, d_b.data_ptr(), 1400, 1.0, 1.0,
+                                          out.data_ptr(), disp.data_ptr(), None, None) == -1
