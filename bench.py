@@ -3,7 +3,8 @@
 
 A "step" is one pass of the hot path over one device-resident batch of synthetic stereo pairs
 (BASELINE.json config 2: 752x480-shaped stream, 1500 ORB + 200 LBD per image; per pair
-ORB L<->R, ORB prev<->curr, LBD L<->R, LBD prev<->curr, each a mutual + ratio StVO::match).
+ORB L<->R, ORB prev<->curr, LBD L<->R, LBD prev<->curr, each a mutual + ratio StVO::match, followed by
+StereoFrame's epipolar / disparity / overlap gates over the two L<->R tables -- SURVEY 8 a1-a5).
 With N > 1 ranks (one per GPU, torch.distributed 'nccl' == RCCL) every rank runs its own shard of
 pairs (weak scaling) and the per-pair match tables are gathered to rank 0 inside the step.
 
@@ -12,6 +13,7 @@ Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -53,9 +55,22 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+def kernel_source_hash() -> str:
+    """Identifies the kernel sources a PMC pass was taken on (profiles/pmc_traffic.json is keyed by it)."""
+    h = hashlib.sha256()
+    d = os.path.join(_ROOT, "plslam_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(stream, n_orb, n_lbd, nnr_p, nnr_l, budget_s=15.0):
     """The CPU restatement of the reference path (oracle, -O3 -march=native, popcnt) timed on this
-    host's cores on a bounded sample of the SAME workload.  kind = "port"."""
+    host's cores on a bounded sample of the SAME workload.  kind = "port".  Also returns the match tables of its first
+    all-cores pass over the WHOLE batch -- (B, 2 n_orb + 2 n_lbd), the layout of the GPU table -- so that the caller can
+    verify every pair of the timed output, not a sample."""
     from oracle import oracle as O
     L = O.native_lib()
     cores = usable_cpus()      # threads actually used = CPUs the container may use (cgroup quota)
@@ -75,27 +90,34 @@ def cpu_baseline(stream, n_orb, n_lbd, nnr_p, nnr_l, budget_s=15.0):
     def run(packed, threads):
         (a, oa), (b, ob), (c, oc), (d, od) = packed
         t0 = time.perf_counter()
-        O.match_batched(a, oa, b, ob, nnr_p, True, nthreads=threads, L=L)
-        O.match_batched(c, oc, d, od, nnr_l, True, nthreads=threads, L=L)
-        return time.perf_counter() - t0
+        mo, _ = O.match_batched(a, oa, b, ob, nnr_p, True, nthreads=threads, L=L)
+        ml, _ = O.match_batched(c, oc, d, od, nnr_l, True, nthreads=threads, L=L)
+        return time.perf_counter() - t0, mo, ml
 
     B = stream["orb_l"].shape[0] - 1
     n_1 = min(B, 8)
     one = problems(list(range(n_1)))
     t_1, reps_1 = 0.0, 0
     while t_1 < 0.25 * budget_s:                        # single-thread leg, bounded by wall clock
-        t_1 += run(one, 1)
+        t_1 += run(one, 1)[0]
         reps_1 += 1
     full = problems(list(range(B)))
-    t_mt, reps = 0.0, 0
+    t_mt, reps, tables = 0.0, 0, None
     while t_mt < 0.75 * budget_s:                       # all-cores leg: whole passes over the batch
-        t_mt += run(full, cores)
+        dt, mo, ml = run(full, cores)
+        t_mt += dt
         reps += 1
-    return {"value": B * reps / t_mt, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
-            "host_logical_cpus": os.cpu_count(),
-            "sample": f"{reps} pass(es) over the same {B}-pair batch on {cores} threads ({t_mt:.1f} s); "
-                      f"1 thread: {reps_1} pass(es) over {n_1} pairs ({t_1:.1f} s)",
-            "value_1thread": n_1 * reps_1 / t_1}
+        if tables is None:                              # (pair, [L->R, prev->curr], row) -> the GPU table's row layout
+            tables = np.concatenate([mo.reshape(B, 2 * n_orb), ml.reshape(B, 2 * n_lbd)], axis=1)
+    rec = {"value": B * reps / t_mt, "unit": "stereo pairs/s", "cores": cores, "kind": "port",
+           "host_logical_cpus": os.cpu_count(),
+           "sample": f"{reps} pass(es) over the same {B}-pair batch on {cores} threads ({t_mt:.1f} s); "
+                     f"1 thread: {reps_1} pass(es) over {n_1} pairs ({t_1:.1f} s)",
+           "value_1thread": n_1 * reps_1 / t_1,
+           "note": "a restatement of the reference path (oracle/plslam_oracle.c: per-query scalar scan with popcnt, no "
+                   "tiling, no AVX-512 vpopcnt), not the reference binary, which cannot be built in this image; a "
+                   "reported baseline -- the GPU/CPU ratio says nothing about kernel quality"}
+    return rec, tables
 
 
 def main():
@@ -115,10 +137,13 @@ def main():
     ap.add_argument("--group-cap", type=int, default=0)
     ap.add_argument("--mfma-form", type=int, default=0, help="0 = auto (K1f), 1 = K1e (best-2 push per tile), 2 = K1f (group minima)")
     ap.add_argument("--fuse", type=int, default=0, help="K1f: 0 = auto, 1 = never, 2 = always one workgroup per problem incl. merge + finalize")
+    ap.add_argument("--no-gates", action="store_true", help="leave the stereo-gate stage out of the step (tables only)")
     ap.add_argument("--step-streams", type=int, default=2, help="output buffers / HIP streams the steps alternate over")
     ap.add_argument("--no-overlap", action="store_true",
                     help="single GPU: run the steps strictly one after another on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary records (tables only, popcount kernels, C5, C3) of the N = 1 line")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the NCCL(RCCL) process group and run the table gather even with one rank")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
@@ -159,66 +184,61 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.pairs_per_gpu
+    n_orb, n_lbd = args.n_orb, args.n_lbd
+    baseline_cfg = {(800, 100): "C1-shaped (KITTI 800 ORB + 100 LBD)", (1500, 200): "C2", (4000, 600): "C5"}
+    cfg_name = baseline_cfg.get((n_orb, n_lbd), "custom")
     # weak scaling: rank r owns pairs [r*B, (r+1)*B) of one global stream (with a one-pair halo)
-    stream = synth.stereo_stream(B, args.n_orb, args.n_lbd, seed=synth.SEED0, first_pair=rank * B)
+    stream = synth.stereo_stream(B, n_orb, n_lbd, seed=synth.SEED0, first_pair=rank * B)
+    gates = None if args.no_gates else dict(synth.KITTI_GATES)
+    geo = None if args.no_gates else synth.stereo_geometry(stream, first_pair=rank * B)
 
     note(f"synthetic stream of {B} pairs generated")
     ctx = plslam_amd.Context(local_rank)     # raises if libplslam_hip.so / a gfx950 device is missing
-    if args.scan_variant:
-        ctx.set_option("scan_variant", args.scan_variant)
-    if args.scan_block:
-        ctx.set_option("scan_block", args.scan_block)
-    if args.sym_rows:
-        ctx.set_option("sym_rows", args.sym_rows)
-    if args.group_cap:
-        ctx.set_option("group_cap", args.group_cap)
-    if args.mfma_form:
-        ctx.set_option("mfma_form", args.mfma_form)
-    if args.fuse:
-        ctx.set_option("fuse", args.fuse)
+    for key, val in (("scan_variant", args.scan_variant), ("scan_block", args.scan_block), ("sym_rows", args.sym_rows),
+                     ("group_cap", args.group_cap), ("mfma_form", args.mfma_form), ("fuse", args.fuse)):
+        if val:
+            ctx.set_option(key, val)
     overlap = not use_dist and not args.no_overlap
+    n_buf = max(2, args.step_streams) if (use_dist or overlap) else 1
     bm = frontend.StereoBatchMatcher(ctx, stream, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev,
-                                     n_buffers=max(2, args.step_streams) if (use_dist or overlap) else 1)
+                                     n_buffers=n_buf, geometry=geo, gates=gates)
     info = bm.plan.info()
     devinfo = ctx.device_info()
     # N > 1: the table of step k is gathered to rank 0 over RCCL on a communication stream while
     # step k+1 computes into the other table buffer (steps are independent batches of a stream).
     pg = frontend.PipelinedGather(bm, world, rank, root=0) if use_dist else None
-    step_no = [0]
 
-    def step():
-        if pg is not None:
-            pg.step(step_no[0])
-        elif overlap:
-            # consecutive steps are independent batches: alternate two output buffers / HIP streams so
-            # the next scan's ramp-up fills the CUs that idle in this step's drain, merge and finalize
-            bm.run_overlapped(step_no[0])
-        else:
-            bm.run()
-        step_no[0] += 1
+    def run_steps(matcher, gather, n, k0=0):
+        for k in range(k0, k0 + n):
+            if gather is not None:
+                gather.step(k)
+            elif overlap:
+                # consecutive steps are independent batches: alternate two output buffers / HIP streams so
+                # the next scan's ramp-up fills the CUs that idle in this step's drain, merge and finalize
+                matcher.run_overlapped(k)
+            else:
+                matcher.run()
 
-    def sync():
-        if pg is not None:
-            pg.finish()
+    def sync(matcher, gather):
+        if gather is not None:
+            gather.finish()
         if overlap:
-            bm.synchronize_all()
+            matcher.synchronize_all()
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
     note(f"plan built: {info}")
-    for _ in range(args.warmup):
-        step()
-    sync()
+    run_steps(bm, pg, args.warmup)
+    sync(bm, pg)
     note("warmup done")
     for p_ in bm.plans:
         p_.set_profiling(True)
         p_.elapsed()                          # reset the accumulators
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
+    run_steps(bm, pg, args.steps, args.warmup)
+    sync(bm, pg)
     elapsed = time.perf_counter() - t0
     scan_ms = fin_ms = 0.0
     runs = 0
@@ -247,68 +267,116 @@ def main():
         a_, b_, n_ = p0.elapsed()
         p0.set_profiling(False)
         excl_scan_ms, excl_fin_ms = a_ / max(n_, 1), b_ / max(n_, 1)
-        note(f"exclusive kernel times: scan {excl_scan_ms:.3f} ms, merge+finalize {excl_fin_ms:.3f} ms")
+        note(f"exclusive kernel times: scan {excl_scan_ms:.3f} ms, post-scan stages {excl_fin_ms:.3f} ms")
 
     # full-size determinism check: every output buffer was computed from the same inputs (under
     # overlap / contention), so whole tables and count arrays must be bit-identical
-    for b_ in range(1, len(bm.tables)):
-        if args.steps + args.warmup >= 2 and not (torch.equal(bm.tables[0], bm.tables[b_]) and
-                                                  torch.equal(bm.count_bufs[0], bm.count_bufs[b_])):
-            raise SystemExit(f"rank {rank}: output buffers 0 and {b_} differ (nondeterministic result)")
-    # self-check of the timed output against the oracle (the checker, not the product): pair 0 of
-    # EVERY rank's table as it arrived on rank 0 (N > 1: through the RCCL gather, both buffers)
+    if args.steps + args.warmup >= 2:
+        for b_ in range(1, len(bm.tables)):
+            same = torch.equal(bm.tables[0], bm.tables[b_]) and torch.equal(bm.count_bufs[0], bm.count_bufs[b_])
+            if gates is not None:
+                same = same and torch.equal(bm.stereo_tabs[0], bm.stereo_tabs[b_]) and \
+                    torch.equal(bm.stereo_disps[0].view(torch.int64), bm.stereo_disps[b_].view(torch.int64)) and \
+                    torch.equal(bm.stereo_cnts[0], bm.stereo_cnts[b_])
+            if not same:
+                raise SystemExit(f"rank {rank}: output buffers 0 and {b_} differ (nondeterministic result)")
+
+    out = None
     if rank == 0:
         from oracle import oracle as O
-        sl = frontend.table_slices(args.n_orb, args.n_lbd)
-        bufs = range(len(bm.tables)) if (pg is not None or overlap) and args.steps + args.warmup >= 2 else [0]
+        sl = frontend.table_slices(n_orb, n_lbd)
+        # ---- CPU baseline (N = 1 only) and, with it, the oracle's tables for the WHOLE batch --------------------------
+        cpu_rec, cpu_tables = None, None
+        if world == 1 and not args.no_cpu_baseline:
+            note("cpu baseline ...")
+            cpu_rec, cpu_tables = cpu_baseline(stream, n_orb, n_lbd, args.nnr_p, args.nnr_l, args.cpu_budget_s)
+        # ---- verification of the timed output against the oracle (the checker, not the product) -----------------------
+        bufs = list(range(len(bm.tables))) if args.steps + args.warmup >= 2 else [0]
+        verified = {"match_tables": None, "stereo_gates": None}
+        if cpu_tables is not None:
+            # every pair, every problem of rank 0's batch: the table the cpu_baseline leg computed anyway
+            for b_ in bufs:
+                got = bm.tables[b_].cpu().numpy()
+                if not np.array_equal(got, cpu_tables):
+                    bad = np.argwhere(got != cpu_tables)
+                    raise SystemExit(f"bench output differs from the oracle: buffer {b_}, {len(bad)} entries, first at "
+                                     f"pair {bad[0][0]} column {bad[0][1]}")
+            verified["match_tables"] = f"all {B} pairs x 4 problems bit-exact vs the oracle ({len(bufs)} buffer(s))"
+        # N > 1 (or no CPU baseline): pair 0 and a spread of pairs of EVERY rank's table as it arrived on rank 0
+        # (through the RCCL gather, both buffers)
+        sample = sorted({0, 1, B // 3, B // 2, B - 1}) if cpu_tables is None else [0]
         for b_ in bufs:
             full = (pg.gathered(b_) if pg is not None else bm.tables[b_]).cpu().numpy()
             for r_ in range(world if pg is not None else 1):
-                st_r = stream if r_ == 0 else synth.stereo_stream(1, args.n_orb, args.n_lbd, seed=synth.SEED0,
-                                                                  first_pair=r_ * B)
-                tab = full[r_ * B]
-                for name, d1, d2 in frontend.pair_problems(st_r["orb_l"], st_r["orb_r"], st_r["lbd_l"],
-                                                           st_r["lbd_r"], 0):
-                    em, _ = O.match(d1, d2, args.nnr_p if name.startswith("orb") else args.nnr_l, True)
-                    if not np.array_equal(tab[sl[name]], em):
-                        raise SystemExit(f"bench output differs from the oracle: rank {r_} buffer {b_} pair 0 / {name}")
-        note(f"output verified against the oracle for {world if pg is not None else 1} rank(s)")
+                for i_ in sample:
+                    st_r = stream if r_ == 0 else synth.stereo_stream(i_ + 1, n_orb, n_lbd, seed=synth.SEED0,
+                                                                      first_pair=r_ * B)
+                    tab = full[r_ * B + i_]
+                    for name, d1, d2 in frontend.pair_problems(st_r["orb_l"], st_r["orb_r"], st_r["lbd_l"],
+                                                               st_r["lbd_r"], i_):
+                        em, _ = O.match(d1, d2, args.nnr_p if name.startswith("orb") else args.nnr_l, True)
+                        if not np.array_equal(tab[sl[name]], em):
+                            raise SystemExit(f"bench output differs from the oracle: rank {r_} buffer {b_} pair {i_} / {name}")
+        if verified["match_tables"] is None:
+            verified["match_tables"] = (f"pairs {sample} x 4 problems of {world if pg is not None else 1} rank(s) bit-exact "
+                                        f"vs the oracle ({len(bufs)} buffer(s))")
+        if gates is not None:
+            gsample = sorted(set(range(0, B, max(1, B // 64))) | {B - 1})
+            ref_tab = cpu_tables if cpu_tables is not None else bm.tables[0].cpu().numpy()
+            st_, sd_, sc_ = (x.cpu().numpy() for x in (bm.stereo_tabs[0], bm.stereo_disps[0], bm.stereo_cnts[0]))
+            with np.errstate(all="ignore"):
+                for i_ in gsample:
+                    ep, dp, cp = O.stereo_point_gate(ref_tab[i_, sl["orb_lr"]], geo["kp_l"][i_ + 1], geo["kp_r"][i_ + 1],
+                                                     gates["max_dist_epip"], gates["min_disp"])
+                    el, dl, cl = O.stereo_line_gate(ref_tab[i_, sl["lbd_lr"]], geo["seg_l"][i_ + 1], geo["seg_r"][i_ + 1],
+                                                    gates["min_disp"], gates["line_horiz_th"], gates["stereo_overlap_th"],
+                                                    gates["ls_min_disp_ratio"])
+                    ok = (np.array_equal(st_[i_, :n_orb], ep) and np.array_equal(st_[i_, n_orb:], el) and
+                          np.array_equal(sd_[i_, :n_orb].view(np.uint64), dp.view(np.uint64)) and
+                          np.array_equal(sd_[i_, n_orb:].view(np.uint64), dl.reshape(-1).view(np.uint64)) and
+                          sc_[i_].tolist() == [cp, cl])
+                    if not ok:
+                        raise SystemExit(f"bench stereo-gate output differs from the oracle: pair {i_}")
+            verified["stereo_gates"] = (f"{len(gsample)} pairs spread over the batch bit-exact vs the oracle (tables, "
+                                        f"disparities as raw words, counts); kept {int(sc_[:, 0].sum())} points + "
+                                        f"{int(sc_[:, 1].sum())} lines of the batch")
+        note(f"output verified: {verified}")
 
-    if rank == 0:
         pairs_total = B * world * args.steps
         # duration of the dominant kernel: exclusive (serial launches) for the roofline; the in-region
         # figure (overlapped with the neighbouring step) is reported next to it
         scan_s = excl_scan_ms / 1e3
         achieved_gbs = info["algorithmic_bytes"] / scan_s / 1e9
-        valu_peak = devinfo["cu_count"] * VALU_LANES_PER_CLK_PER_CU * devinfo["clock_khz"] * 1e3
-        # HBM bytes of the dominant kernel per launch: PMC counters cannot be read from inside this
-        # process, so the figure comes from the committed rocprofv3 passes of this same command
-        # (profiles/pmc_traffic.json) and is reported only for the configuration they were taken on.
-        traffic = None
-        executed = None
         mfma = info["scan_variant"] == 4
-        wkey = (f"C2:{args.n_orb}+{args.n_lbd}:pairs{B}:v{info['scan_variant']}:sym{ctx.get_option('sym_rows')}"
-                f":cap{ctx.get_option('group_cap')}")
-        # (sym_rows 0 = auto: resolved per plan, reported in config.scan_block_threads: 64 => 4 rows/lane)
-        pm = None
+        form = ctx.get_option("mfma_form")
+        kernel_name = {4: ("k_scan_sym_mfma" if form == 1 else "k_scan_sym_mfma_g"),
+                       3: "k_scan_symmetric" + ("_r4" if info["scan_block_threads"] == 64 else ""),
+                       2: "k_scan_wave_per_query", 1: "k_scan_lane_per_query"}.get(info["scan_variant"], "k_scan")
+        # HBM bytes / executed instructions of the dominant kernel per launch: PMC counters cannot be read from inside
+        # this process, so the figures come from the committed rocprofv3 passes of this same command
+        # (profiles/pmc_traffic.json) -- and ONLY when they were taken on these kernel sources (hash) and this workload.
+        src_hash = kernel_source_hash()
+        wkey = f"{n_orb}+{n_lbd}:pairs{B}:{kernel_name}"
+        traffic, executed, pmc_note = None, None, "no PMC entry for these kernel sources / this workload"
         try:
             with open(os.path.join(_ROOT, "profiles", "pmc_traffic.json")) as f:
                 pm = json.load(f).get("entries", {}).get(wkey)
         except OSError:
-            pass
-        if pm:
+            pm = None
+        if pm and pm.get("kernel_source_hash") == src_hash:
             traffic = pm["traffic_bytes_per_launch"]
             valu_insts = pm["sq_insts_valu_per_launch"] - pm.get("sq_insts_mfma_per_launch", 0)
-            lane_ops = valu_insts * 64 / (excl_scan_ms / 1e3)
+            lane_ops = valu_insts * 64 / scan_s
             executed = {"lane_ops_per_s": lane_ops, "sq_insts_valu_per_launch": valu_insts,
                         "sq_insts_mfma_per_launch": pm.get("sq_insts_mfma_per_launch", 0),
                         "measured_ceiling_lane_ops_per_s": pm["measured_int_valu_ceiling_lane_ops_per_s"],
                         "frac_of_measured_ceiling": lane_ops / pm["measured_int_valu_ceiling_lane_ops_per_s"],
-                        "note": "executed wave64 VALU instructions, MFMAs excluded (PMC, profiles/pmc_traffic.json) x 64 / "
-                                "exclusive scan time, against the issue rate measured for this integer instruction mix "
-                                "(16 lanes/clk/SIMD)"}
-        kernel_name = {4: "k_scan_sym_mfma", 3: "k_scan_symmetric" + ("_r4" if info["scan_block_threads"] == 64 else ""),
-                       2: "k_scan_wave_per_query", 1: "k_scan_lane_per_query"}.get(info["scan_variant"], "k_scan")
+                        "source": pm.get("source"),
+                        "note": "executed wave64 VALU instructions, MFMAs excluded (PMC) x 64 / exclusive scan time, against "
+                                "the issue rate measured for this integer instruction class (16 lanes/clk/SIMD)"}
+            pmc_note = pm.get("source")
+        elif pm:
+            pmc_note = "profiles/pmc_traffic.json holds this workload for OTHER kernel sources (stale): not reported"
         timing_note = ("kernel_ms = exclusive duration (5 serial launches after the timed region, HIP events on the launch "
                        "stream); in the timed region consecutive steps overlap on two streams, so start-to-end times there "
                        "include the other step's share of the GPU")
@@ -321,7 +389,7 @@ def main():
                     "kilobyte the path is compute-bound on any formulation, so this fraction is small by construction",
         }
         if mfma:
-            # K1e: distances come from v_mfma_scale_f32_32x32x64_f8f6f4 over fp4 +-1 codes; 256 multiply-accumulates =
+            # distances come from v_mfma_scale_f32_32x32x64_f8f6f4 over fp4 +-1 codes; 256 multiply-accumulates =
             # 512 ops per executed distance
             mx_peak = devinfo["cu_count"] * 4 * FP4_MFMA_OPS_PER_CLK_PER_SIMD * devinfo["clock_khz"] * 1e3
             mfma_ops = info["distance_evals"] * 512
@@ -329,17 +397,21 @@ def main():
                 "bound": "mfma", "achieved": mfma_ops / scan_s / 1e12, "peak": mx_peak / 1e12, "unit": "TFLOP/s",
                 "frac": mfma_ops / scan_s / mx_peak, "traffic": traffic, "kernel": kernel_name,
                 "kernel_ms": 1e3 * scan_s, "kernel_ms_in_timed_region": scan_ms / max(runs, 1), "timing": timing_note,
-                "algorithmic_ops_per_launch": mfma_ops,
+                "algorithmic_ops_per_launch": mfma_ops, "pmc": pmc_note,
                 "note": "block-scaled fp4 MFMA (operands are the e2m1 codes of +-1, fp32 accumulation of integers below "
                         "2^24: exact); dense MX-fp4 peak = CUs x 4 SIMDs x 4096 ops/clk x max clock (MI355X_MICROARCH.md "
                         "measures 9099 T for the 32x32x64 shape); 512 ops per executed 256-bit distance (each serves both "
                         "match directions).  The kernel is co-limited by the VALU best-2 bookkeeping that consumes the "
-                        "accumulators: see valu_roofline.executed",
+                        "accumulators: see valu_executed",
             }
         else:
-            roofline = hbm_roofline
+            roofline = dict(hbm_roofline, pmc=pmc_note)
+        workload = (f"{cfg_name}: synthetic 752x480 stereo stream, {n_orb} ORB + {n_lbd} LBD per image, ORB+LBD L<->R and "
+                    "prev<->curr, mutual + ratio (StVO::match)" +
+                    ("" if gates is None else ", then StereoFrame's gates over the L<->R tables (config_kitti.yaml:25-36)") +
+                    ", device-resident")
         out = {
-            "metric": "stereo pairs/sec (1500 ORB + 200 LBD BF-match)",
+            "metric": f"stereo pairs/sec ({n_orb} ORB + {n_lbd} LBD BF-match)",
             "value": pairs_total / elapsed,
             "unit": "stereo pairs/s",
             "n_gpus": world,
@@ -352,10 +424,11 @@ def main():
             "dtype": "fp4" if mfma else "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"C2: synthetic 752x480 stereo stream, {args.n_orb} ORB + {args.n_lbd} LBD per image, "
-                            "ORB+LBD L<->R and prev<->curr, mutual + ratio (StVO::match), device-resident",
+                "workload": workload,
                 "pairs_per_gpu_per_step": B, "nnr_p": args.nnr_p, "nnr_l": args.nnr_l, "mutual": True,
+                "stereo_gates": gates,
                 "scan_variant": info["scan_variant"], "scan_block_threads": info["scan_block_threads"],
+                "mfma_form": form, "kernel": kernel_name, "kernel_source_hash": src_hash,
                 "parallelism": f"pairs sharded over {world} rank(s); per-step RCCL gather of the match tables "
                                "to rank 0, overlapped with the next step" if use_dist else
                                ("single GPU; consecutive steps alternate two output buffers / HIP streams" if overlap
@@ -363,31 +436,173 @@ def main():
             },
             "roofline": roofline,
             "hbm_roofline": hbm_roofline,
-            "valu_roofline": {
-                "bound": "valu-int", "achieved": info["directed_evals"] * 16 / scan_s / 1e12,
-                "peak": valu_peak / 1e12, "unit": "T lane-ops/s",
-                "frac": info["directed_evals"] * 16 / scan_s / valu_peak,
-                "note": "16 algorithmic lane-ops (8 xor + 8 bcnt) per 256-bit distance x directed distances the "
-                        "reference evaluates, priced as if done on the VALU; peak = CUs x 128 lanes/clk x max clock "
-                        "(frac > 1 is possible when the distances come from the matrix cores)",
-                "evals_per_launch": info["directed_evals"], "executed_evals_per_launch": info["distance_evals"],
-                "executed": executed,
-            },
-            "kernel_ms": {"scan": excl_scan_ms, "merge+finalize": excl_fin_ms,
+            "valu_executed": executed,
+            "kernel_ms": {"scan": excl_scan_ms, "post_scan_stages": excl_fin_ms,
                           "scan_in_timed_region": scan_ms / max(runs, 1),
-                          "merge+finalize_in_timed_region": fin_ms / max(runs, 1)},
+                          "post_scan_stages_in_timed_region": fin_ms / max(runs, 1),
+                          "note": "post-scan stages = column-partial merge + ratio/mutual finalize" +
+                                  ("" if gates is None else " + stereo gates")},
+            "verified": verified,
             "device": devinfo["name"],
         }
-        if world == 1 and not args.no_cpu_baseline:
-            note("cpu baseline ...")
-            out["cpu_baseline"] = cpu_baseline(stream, args.n_orb, args.n_lbd, args.nnr_p, args.nnr_l,
-                                               args.cpu_budget_s)
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        if cpu_rec is not None:
+            out["cpu_baseline"] = cpu_rec
 
     bm.close()
+    # ---- secondary records (N = 1): the other single-GPU configurations, timed by this same command ---------------------
+    if rank == 0 and world == 1 and not args.no_secondary and not use_dist:
+        note("secondary records ...")
+        out["secondary"] = secondary_records(ctx, dev, args, note)
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def secondary_records(ctx, dev, args, note):
+    """Driver-timed numbers for the other BASELINE configurations and kernel forms (they existed only as
+    builder-run files).  Each is a short run: a few hundred ms of GPU time."""
+    import torch
+    import plslam_amd
+    from oracle import oracle as O
+    from plslam_amd import frontend, synth
+    rec = {}
+
+    def timed(bm, steps, warm=2):
+        for k in range(warm):
+            bm.run_overlapped(k)
+        bm.synchronize_all()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            bm.run_overlapped(warm + k)
+        bm.synchronize_all()
+        dt = time.perf_counter() - t0
+        p0 = bm.plans[0]
+        p0.set_profiling(True)
+        p0.elapsed()
+        for _ in range(3):
+            p0.run(bm.streams[0].cuda_stream)
+            bm.streams[0].synchronize()
+        a_, b_, n_ = p0.elapsed()
+        p0.set_profiling(False)
+        return dt, a_ / max(n_, 1), b_ / max(n_, 1)
+
+    def check_pair0(bm, st, n_orb, n_lbd, nnr_p, nnr_l):
+        tab = bm.tables[0][0].cpu().numpy()
+        sl = frontend.table_slices(n_orb, n_lbd)
+        for name, d1, d2 in frontend.pair_problems(st["orb_l"], st["orb_r"], st["lbd_l"], st["lbd_r"], 0):
+            em, _ = O.match(d1, d2, nnr_p if name.startswith("orb") else nnr_l, True)
+            if not np.array_equal(tab[sl[name]], em):
+                raise SystemExit(f"secondary record: output differs from the oracle ({name})")
+
+    def pairs_run(tag, n_orb, n_lbd, pairs, steps, opts, workload):
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        try:
+            st = synth.stereo_stream(pairs, n_orb, n_lbd, seed=synth.SEED0)
+            bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev, n_buffers=2)
+            info = bm.plan.info()
+            dt, scan_ms, post_ms = timed(bm, steps)
+            check_pair0(bm, st, n_orb, n_lbd, args.nnr_p, args.nnr_l)
+            bm.close()
+        finally:
+            for k in opts:
+                ctx.set_option(k, 0)
+        gbs = info["algorithmic_bytes"] / (scan_ms / 1e3) / 1e9
+        rec[tag] = {"metric": f"stereo pairs/sec ({n_orb} ORB + {n_lbd} LBD BF-match)", "value": pairs * steps / dt,
+                    "unit": "stereo pairs/s", "workload": workload, "pairs_per_step": pairs, "steps": steps,
+                    "scan_variant": info["scan_variant"], "scan_kernel_ms": scan_ms, "post_scan_ms": post_ms,
+                    "hbm_roofline_frac": gbs / HBM_PEAK_GBS, "hbm_algorithmic_GBps": gbs,
+                    "verified": "pair 0 x 4 problems bit-exact vs the oracle"}
+        note(f"  {tag}: {rec[tag]['value']:.0f} pairs/s, scan {scan_ms:.3f} ms")
+
+    n_orb, n_lbd, B = args.n_orb, args.n_lbd, args.pairs_per_gpu
+    small = max(64, min(512, B))
+    pairs_run("tables_only", n_orb, n_lbd, B, 6, {}, "the main workload without the stereo-gate stage")
+    pairs_run("popcount_u32_symmetric", n_orb, n_lbd, small, 4, {"scan_variant": plslam_amd.SCAN_SYMMETRIC},
+              "XOR + popcount symmetric scan (K1b/K1b'), no matrix cores")
+    pairs_run("popcount_u32_north_star_literal", n_orb, n_lbd, small, 3, {"scan_variant": plslam_amd.SCAN_WAVE_PER_QUERY},
+              "north_star's literal kernel: train tile in LDS, wavefront-per-query popcount, wave best-2 reduce (K1d)")
+    pairs_run("c5", 4000, 600, 128, 4, {"scan_variant": plslam_amd.SCAN_MFMA},
+              "C5: 4000 ORB + 600 LBD per image (two 2048-column windows per ORB scan)")
+
+    # ---- C3: one map<->frame problem (10 000 x 1500 ORB + 2 000 x 200 LBD, mutual) and the LBA row pass --------------------
+    st_ = torch.cuda.Stream(device=dev)
+    s_ = st_.cuda_stream
+
+    def ev_time(fn, iters, warm=5):
+        with torch.cuda.stream(st_):
+            for _ in range(warm):
+                fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st_)
+            for _ in range(iters):
+                fn()
+            e1.record(st_)
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    r = np.random.Generator(np.random.PCG64(31))
+    frame_p = synth.random_desc(r, 1500)
+    map_p = np.concatenate([synth.noisy_copy(r, frame_p)[0], synth.random_desc(r, 8500)])
+    frame_l = synth.random_desc(r, 200)
+    map_l = np.concatenate([synth.noisy_copy(r, frame_l)[0], synth.random_desc(r, 1800)])
+    t = {k: torch.from_numpy(v).to(dev) for k, v in dict(mp=map_p, fp=frame_p, ml=map_l, fl=frame_l).items()}
+    m_p = torch.empty(10000, dtype=torch.int32, device=dev)
+    m_l = torch.empty(2000, dtype=torch.int32, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    plan = ctx.plan([(t["mp"].data_ptr(), 10000, t["fp"].data_ptr(), 1500, 0.75, True, m_p.data_ptr(), cnt.data_ptr()),
+                     (t["ml"].data_ptr(), 2000, t["fl"].data_ptr(), 200, 0.75, True, m_l.data_ptr(), cnt.data_ptr() + 4)])
+    ms = ev_time(lambda: plan.run(s_), iters=200, warm=10)
+    em, _ = O.match(map_p, frame_p, 0.75, True)
+    el, _ = O.match(map_l, frame_l, 0.75, True)
+    if not (np.array_equal(m_p.cpu().numpy(), em) and np.array_equal(m_l.cpu().numpy(), el)):
+        raise SystemExit("secondary record c3: match tables differ from the oracle")
+    pinfo = plan.info()
+    plan.close()
+    lm = synth.local_map()
+    cam = plslam_amd.make_cam(**synth.EUROC)
+    g = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in lm.items()}
+    npt, nls = lm["pt_lm"].shape[0], lm["ls_lm"].shape[0]
+    reps = 64                                   # many maps in one launch: the row kernels' streaming rate
+
+    def rows(kind, n, nrep):
+        key = ("obs_uv", "pt_lm", "pt_kf") if kind == "pt" else ("l_obs", "ls_lm", "ls_kf")
+        big = {k: torch.cat([g[k]] * nrep) for k in key}
+        nb = n * nrep
+        Jp = torch.empty((nb, 6), dtype=torch.float64, device=dev)
+        Jl = torch.empty((nb, 3 if kind == "pt" else 6), dtype=torch.float64, device=dev)
+        rr = torch.empty(nb, dtype=torch.float64, device=dev)
+        ww = torch.empty(nb, dtype=torch.float64, device=dev)
+        if kind == "pt":
+            fn = lambda: ctx.lba_point_rows_dev(cam, 1e-7, g["T_kf_w"].data_ptr(), g["Xw"].data_ptr(), big["obs_uv"].data_ptr(),  # noqa: E731
+                                                big["pt_lm"].data_ptr(), big["pt_kf"].data_ptr(), nb, Jp.data_ptr(),
+                                                Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), s_)
+        else:
+            fn = lambda: ctx.lba_line_rows_dev(cam, 1e-7, False, g["T_kf_w"].data_ptr(), g["Lw"].data_ptr(),  # noqa: E731
+                                               big["l_obs"].data_ptr(), big["ls_lm"].data_ptr(), big["ls_kf"].data_ptr(), nb,
+                                               Jp.data_ptr(), Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), s_)
+        return ev_time(fn, iters=30 if nrep > 1 else 200, warm=5)
+    ms_p1, ms_l1 = rows("pt", npt, 1), rows("ls", nls, 1)
+    ms_pb, ms_lb = rows("pt", npt, reps), rows("ls", nls, reps)
+    rec["c3"] = {
+        "workload": "C3: one local map against one frame -- 10 000 x 1500 ORB + 2 000 x 200 LBD mutual match "
+                    "(mapHandler.cpp:532-752) and the LBA row pass over 50 000 point + 10 000 line observations (:1358-1540)",
+        "match_us": 1e3 * ms, "match_scan_variant": pinfo["scan_variant"], "match_directed_evals": pinfo["directed_evals"],
+        "match_verified": "both tables bit-exact vs the oracle",
+        "lba_rows_pass_us": 1e3 * (ms_p1 + ms_l1), "lba_rows_pass_bytes": npt * 152 + nls * 208,
+        "lba_point_rows_streaming": {"rows": npt * reps, "GBps_algorithmic": npt * reps * 152 / (ms_pb * 1e-3) / 1e9,
+                                     "frac_of_hbm_peak": npt * reps * 152 / (ms_pb * 1e-3) / (HBM_PEAK_GBS * 1e9)},
+        "lba_line_rows_streaming": {"rows": nls * reps, "GBps_algorithmic": nls * reps * 208 / (ms_lb * 1e-3) / 1e9,
+                                    "frac_of_hbm_peak": nls * reps * 208 / (ms_lb * 1e-3) / (HBM_PEAK_GBS * 1e9)},
+        "note": "one map = one launch of 9.7 MB: launch-bound (replicas only, SURVEY 8e); the streaming figures batch 64 maps "
+                "per launch to show the row kernels' HBM rate (152 B / 208 B algorithmic per row)"}
+    note(f"  c3: match {1e3 * ms:.1f} us, rows {rec['c3']['lba_point_rows_streaming']['GBps_algorithmic']:.0f} / "
+         f"{rec['c3']['lba_line_rows_streaming']['GBps_algorithmic']:.0f} GB/s")
+    return rec
 
 
 if __name__ == "__main__":

@@ -14,9 +14,9 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config", "roofline"}
 
 
-def _run(extra, env=None):
+def _run(extra, env=None, pairs=24, n_orb=192, n_lbd=40):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-           "--pairs-per-gpu", "24", "--n-orb", "192", "--n-lbd", "40"] + extra
+           "--pairs-per-gpu", str(pairs), "--n-orb", str(n_orb), "--n-lbd", str(n_lbd)] + extra
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {}))
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e)
     assert res.returncode == 0, res.stderr[-3000:]
@@ -26,6 +26,8 @@ def _run(extra, env=None):
 
 
 def test_bench_single_gpu_line():
+    """A plan too small for the matrix-core scan (AUTO picks the latency kernel): the HBM branch of the line, with the
+    CPU baseline, the full-batch verification it enables, the stereo-gate stage and the secondary records."""
     d = _run(["--cpu-budget-s", "1"])
     assert REQUIRED <= set(d) and "cpu_baseline" in d
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
@@ -33,7 +35,31 @@ def test_bench_single_gpu_line():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
-    assert "workload" in d["config"]
+    assert "192 ORB + 40 LBD" in d["metric"] and "192 ORB + 40 LBD" in d["config"]["workload"]      # derived, not hard-coded
+    assert d["verified"]["match_tables"].startswith("all 24 pairs") and "bit-exact" in d["verified"]["stereo_gates"]
+    assert d["config"]["stereo_gates"]["max_dist_epip"] == 0.0
+    sec = d["secondary"]
+    assert set(sec) >= {"tables_only", "popcount_u32_symmetric", "popcount_u32_north_star_literal", "c5", "c3"}
+    assert all(sec[k]["value"] > 0 for k in ("tables_only", "popcount_u32_symmetric", "popcount_u32_north_star_literal", "c5"))
+    assert "4000 ORB + 600 LBD" in sec["c5"]["metric"] and sec["c3"]["match_us"] > 0
+    assert 0 < sec["c3"]["lba_point_rows_streaming"]["frac_of_hbm_peak"] < 1
+    assert "valu_roofline" not in d                      # (round 1 printed a "fraction" of 1.86 there)
+
+
+def test_bench_matrix_core_branch_of_the_line():
+    """A plan large enough for AUTO to take the matrix-core scan -- the branch the driver's default run gets: roofline
+    bound "mfma", fp4 operand type, the HBM model beside it, PMC-derived fields absent unless the committed passes were
+    taken on exactly these kernel sources."""
+    d = _run(["--no-cpu-baseline", "--no-secondary"], pairs=160, n_orb=512, n_lbd=64)
+    assert REQUIRED <= set(d) and d["value"] > 0
+    assert d["roofline"]["bound"] == "mfma" and d["dtype"] == "fp4" and d["roofline"]["unit"] == "TFLOP/s"
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel"] == "k_scan_sym_mfma_g"
+    assert d["hbm_roofline"]["bound"] == "hbm" and 0 < d["hbm_roofline"]["frac"] < 1
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"}
+    assert len(d["config"]["kernel_source_hash"]) == 16
+    if d["valu_executed"] is not None:
+        assert 0 < d["valu_executed"]["frac_of_measured_ceiling"] <= 1.0
+    assert "pairs [0, 1," in d["verified"]["match_tables"]
 
 
 def test_bench_forced_rccl_group_one_rank():
