@@ -11,13 +11,13 @@
 //
 //  1. Row direction: minimum now, second best later.  K1e pushes every packed key pair into a sorted pair
 //     (best, second) per (row, column class): 3 packed ops per 2 distances.  Here a lane keeps only the running
-//     MINIMUM of a group of 8 consecutive tiles per (row, class) -- ONE v_pk_min_u16 per 2 distances -- and pushes
-//     the group minimum into the sorted pair once per 8 tiles.  Best-2 over group minima gives the exact best key
+//     MINIMUM of a group of 16 consecutive tiles per (row, class) -- ONE v_pk_min_u16 per 2 distances -- and pushes
+//     the group minimum into the sorted pair once per 16 tiles.  Best-2 over group minima gives the exact best key
 //     B0, and B1 = the best key outside B0's group; the true second best is min(B1, best key among the OTHER
-//     members of B0's group).  Those are 7 known columns of the same class (j0 +- 32 k), so after the scan one lane
-//     per row recomputes 7 distances with XOR + popcount from the raw rows (L2-resident: the workgroup has just
+//     members of B0's group).  Those are 15 known columns of the same class (j0 +- 32 k), so after the scan one lane
+//     per row recomputes 15 distances with XOR + popcount from the raw rows (L2-resident: the workgroup has just
 //     streamed them) and takes the minimum.  Exact, tie order included: within a class the 16-bit key order
-//     (d, tile) is the (d, j) order.  Per tile 16 + 64/8 = 24 instead of 48 packed ops; per scan ~150 extra.
+//     (d, tile) is the (d, j) order.  Per tile 16 + 64/16 = 20 instead of 48 packed ops; per scan ~350 extra.
 //  2. The tile number of a key rides in the accumulator start value (scalar adds on the seeds) instead of one
 //     vector add per packed pair; the column keys of a tile then share the offset and finish_columns takes it
 //     off again (round 1's tile-in-seed experiment).
@@ -66,9 +66,13 @@ constexpr int MF_KSTEPS = 4;                  // 256 bits = 4 x K 64
 constexpr int MF_ROW_STRIDE = 144;            // bytes per expanded b row in LDS (128 + 16: 4-bank skew)
 constexpr int MF_TILE_BYTES = MF_TILE_N * MF_ROW_STRIDE;
 #ifndef PLSLAM_MG_GROUP
-#define PLSLAM_MG_GROUP 8
+#define PLSLAM_MG_GROUP 16
 #endif
-constexpr int MF_GROUP = PLSLAM_MG_GROUP;     // tiles per row-direction group (a window of 64 tiles = 8 groups of 8)
+// tiles per row-direction group (a window of 64 tiles = 4 groups of 16).  A larger group halves the parked-pair pushes
+// (64 VALU + 16 LDS reads + 16 LDS writes each; measured 8 % of the scan at 8 tiles per group) and costs
+// MF_GROUP - 1 recomputed distances per row and window.
+constexpr int MF_GROUP = PLSLAM_MG_GROUP;
+constexpr int MF_CGROUP = 8;                  // tiles whose column results are staged in LDS and stored together (256 columns)
 // fp4 (e2m1) codes: +1.0 = 0x2, -1.0 = 0xA.  b side: bit 0 -> +1, bit 1 -> -1 = s(b); the a side is the b code
 // XOR 0x8 per nibble (= -s(a)) and carries the block scale 2^6 (E8M0 133), the b side 2^0 (E8M0 127).
 constexpr uint32_t FP4_NEG = 0x88888888u;
@@ -165,7 +169,7 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
                   int32_t* __restrict__ zero, int nzero)
 {
     // one buffer, two lives: during the scan the double-buffered b tile (9 216 B) followed by the PARKED sorted pairs of the
-    // row direction ([wave][reg][lane] x 8 B = 32 768 B: they are touched once per 8 tiles, so they live here and not in
+    // row direction ([wave][reg][lane] x 8 B = 32 768 B: they are touched once per group of tiles, so they live here and not in
     // 32 VGPRs); after the scan the row-result transpose [wave][row 0..63][33] (33 792 B) over both
     constexpr int ROWX_STRIDE = 33;               // dwords per row: lane = row reads are conflict-free
     constexpr int PARK_OFF = 2 * MF_TILE_BYTES;
@@ -177,7 +181,7 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // the raw-row prefetch, and with loads AND stores pending the counter is out of order: every wait becomes
     // vmcnt(0), the prefetch distance collapses to one tile, and a tile then costs a full memory latency (round 2
     // finding: 2.7 ms of the 3.4 ms scan were there with NO bookkeeping at all in the kernel).
-    __shared__ __attribute__((aligned(16))) uint32_t colstage[4][MF_GROUP * MF_TILE_N];
+    __shared__ __attribute__((aligned(16))) uint32_t colstage[4][MF_CGROUP * MF_TILE_N];
     uint8_t* const btile = smem;
     u32x2_t* const park = reinterpret_cast<u32x2_t*>(smem + PARK_OFF) + (threadIdx.x >> 6) * (16 * 64) + (threadIdx.x & 63);
 
@@ -213,7 +217,7 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     const uint32_t pack_sel = 0x05040100u;
 
     // row-direction state per accumulator register r (M-tile 0 in the low halves, M-tile 1 in the high halves):
-    //   gm[r]    running minimum of the 16-bit keys (d << 7 | tile + LOC) of the current group of 8 tiles
+    //   gm[r]    running minimum of the 16-bit keys (d << 7 | tile + LOC) of the current group of MF_GROUP tiles
     //   park[r]  (LDS) the best two GROUP minima of the lane's column class
     uint32_t gm[16];
 #pragma unroll
@@ -267,17 +271,20 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // each window the row state is reduced, completed (second best) and merged into keys12, then restarted.
     int wt0v = 0, wt1v = ntiles < 64 ? ntiles : 64;
     uint32_t raw1 = 0u, raw2 = 0u, raw3 = 0u;              // raw b dwords of tiles t+1, t+2, t+3 of the coming step
-    // the group of 8 tiles that ends with tile `tl` is over: its minima go into the sorted pairs, the minima restart, and
-    // the group's column results go to the partial table (256 columns: 16 bytes per lane)
-    auto push_groups = [&](int tl) __attribute__((always_inline)) {
+    // the 8 tiles that end with tile `tl` are over: their column results go to the partial table (256 columns: 16 bytes
+    // per lane)
+    auto store_columns = [&](int tl) __attribute__((always_inline)) {
         if (!DIRECTED && wave_has_rows && !PLSLAM_MG_X(8)) {
-            const int j0 = (tl & ~(MF_GROUP - 1)) * MF_TILE_N + 4 * lane;       // WT0 is a multiple of 8
+            const int j0 = (tl & ~(MF_CGROUP - 1)) * MF_TILE_N + 4 * lane;      // WT0 is a multiple of 8
             const i32x4 v = *reinterpret_cast<const i32x4*>(cstage + 4 * lane);
             if (j0 < n2p) *reinterpret_cast<PLSLAM_GLOBAL i32x4*>(part + j0) = v;
             // tiles of a partial last group that never ran leave "none" in the padding columns (never read; keeps the
             // partial table a pure function of the inputs, which tools/determinism_check.py compares word for word)
             *reinterpret_cast<i32x4*>(cstage + 4 * lane) = i32x4{-1, -1, -1, -1};
         }
+    };
+    // a row group is over: its minima go into the sorted pairs, the minima restart
+    auto push_groups = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const u32x2_t v = park[r * 64];
@@ -309,7 +316,7 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         const auto sw = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
         const uint32_t other = sw[1];
         merge2(m0, m1, other & 0xFFFFu, other >> 16);
-        if (lane < MF_TILE_N) cstage[((t - WT0) & (MF_GROUP - 1)) * MF_TILE_N + lane] = m0 | (m1 << 16);
+        if (lane < MF_TILE_N) cstage[((t - WT0) & (MF_CGROUP - 1)) * MF_TILE_N + lane] = m0 | (m1 << 16);
     };
     // Software pipeline, ONE accumulator set.  A tile's life:  M(t): 8 MFMAs -> P(t): 16 v_perm pack the 32 accumulators
     // into 16 key pairs kc[] (the accumulator registers are free again) -> E(t): bookkeeping from kc[], issued BETWEEN the
@@ -384,7 +391,9 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #undef PLSLAM_MG_MMA
         if (with_prev) {
             finish_columns(t - 1, cb0, cb1);
-            if (((t - 1 - WT0) & (MF_GROUP - 1)) == MF_GROUP - 1 && !PLSLAM_MG_X(64)) push_groups(t - 1);   // wave-uniform: tile t-1 closed a group
+            // wave-uniform: tile t-1 closed a block of 8 tiles / a row group
+            if (((t - 1 - WT0) & (MF_CGROUP - 1)) == MF_CGROUP - 1) store_columns(t - 1);
+            if (((t - 1 - WT0) & (MF_GROUP - 1)) == MF_GROUP - 1 && !PLSLAM_MG_X(64)) push_groups();
         }
         // P(t): the key pairs of tile t; the accumulators are dead from here on
 #pragma unroll
@@ -412,14 +421,15 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         tile_step(WT0, false, steady_tag);
         for (int t = WT0 + 1; t < WT1; ++t) tile_step(t, true, steady_tag);
         if (last_partial) epilogue(WT1 - 1, std::true_type{}); else epilogue(WT1 - 1, steady_tag);
-        push_groups(WT1 - 1);                      // the (possibly partial) last group
+        store_columns(WT1 - 1);                    // the (possibly partial) last block of columns
+        push_groups();                             // ... and row group
     };
     // Row results of a window.  Every lane holds, per accumulator register, the best two GROUP minima (16-bit keys
     // (d, tile + LOC)) of ITS column class for two rows.  Transpose through LDS so that one lane owns one row: lane l
     // reads the 32 class entries of row l in class order, widens them to (key16 << 16 | class) -- which orders like
     // (d, j = 32 tile + class) because every entry of a row carries the same LOC -- and keeps the best two.  The
     // first is the row's best key; the second is the best key OUTSIDE the winner's group, so the lane then visits
-    // the other 7 columns of the winner's group (same class, the other tiles of the group) and recomputes their
+    // the other columns of the winner's group (same class, the other tiles of the group) and recomputes their
     // distances from the raw rows: second best = min of the two.  Callers guarantee that all waves are past their
     // last operand read of `smem`; the region used here is private to the wave.
     auto finish_rows = [&]() __attribute__((always_inline)) {
