@@ -81,6 +81,9 @@ struct plslam_match_plan {
     bool sym_mfma_multi = false;       // ... and some of them have n2 > 2048 (multi-window instantiation)
     int mfma_form = 0;                 // ctx option "mfma_form" at plan creation (0/2 = K1f, 1 = K1e)
     bool fused = false;                // K1f, one workgroup per problem: merge + ratio + mutual inside the scan kernel
+    int merge_parts = 1;               // K1f: lanes per column in the partial merge (tall problems: many row blocks, few columns)
+    bool col_split = false;            // K1f on a FEW LARGE problems: columns cut into ranges scanned as sub-problems
+    DevBuf rowtmp;                     // ... their per-range row results (merged by the finalize kernel)
     int32_t ndir = 0, ndir_blocks = 0; // non-mutual problems on the directed form of K1e
     bool dir_multi = false;
     SymDesc* d_dirs = nullptr; BlockDesc* d_dir_blocks = nullptr;
@@ -111,7 +114,7 @@ struct plslam_match_plan {
     void free_all()
     {
         keys.release(); counts.release(); partials.release(); tables.release(); staging_pin.release();
-        gate_tables.release();
+        gate_tables.release(); rowtmp.release();
         for (auto& e : evs) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2); }
         evs.clear();
     }
@@ -135,8 +138,20 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     int64_t thr_waves = 0;   // waves the throughput kernels would launch: one per 64 rows of d1
     for (int32_t i = 0; i < nprob; ++i) thr_waves += (probs[i].n1 + 63) / 64;
     const int64_t simds = (int64_t)ctx->prop.multiProcessorCount * 4;
+    // A plan of a FEW LARGE problems (C3: one local map against one frame, 10 000 x 1500 + 2 000 x 200, mapHandler.cpp:532-752)
+    // has too few 256-row blocks to fill the chip, but far too much work for the latency kernel (50 us there): the
+    // matrix-core scan takes it with the COLUMNS cut into ranges, one workgroup per (row block, range).
+    int64_t sym_evals = 0;
+    for (int32_t i = 0; i < nprob; ++i)
+        if (probs[i].n1 > 0 && probs[i].n2 > 0) sym_evals += (int64_t)probs[i].n1 * probs[i].n2;
+    const bool small_plan = thr_waves < simds;
+    const bool split_auto = ctx->scan_variant == PLSLAM_SCAN_AUTO && small_plan && sym_evals >= (int64_t(6) << 20) &&
+                            ctx->mfma_form != 1;
+    const bool split_forced = ctx->col_split == 2 && ctx->mfma_form != 1 &&
+                              (ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_MFMA);
+    P->col_split = ctx->col_split != 1 && (split_auto || split_forced);
     const bool use_wpq = ctx->scan_variant == PLSLAM_SCAN_WAVE_PER_QUERY ||
-                         (ctx->scan_variant == PLSLAM_SCAN_AUTO && thr_waves < simds);
+                         (ctx->scan_variant == PLSLAM_SCAN_AUTO && small_plan && !P->col_split);
     const bool allow_sym = !use_wpq &&
                            (ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_SYMMETRIC ||
                             ctx->scan_variant == PLSLAM_SCAN_MFMA);
@@ -150,8 +165,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->sym_mfma_multi = false;
     P->mfma_form = ctx->mfma_form;
     P->dir_multi = false;
-    for (int32_t i = 0; i < nprob && P->sym_mfma; ++i)
-        if (is_sym(probs[i]) && probs[i].n2 > 2048) P->sym_mfma_multi = true;
+    // (set per scanned (sub-)problem while the tables are built)
     P->sym_rows = P->sym_mfma ? 4 : ctx->sym_rows;      // K1e uses the 256-row tables of K1b'
     if (P->sym_rows == 0) {
         int64_t waves4 = 0;
@@ -176,11 +190,42 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             if (probs[i].mutual && probs[i].n2 > PLSLAM_K1F_FUSED_MAX_N2) fits = false;
         }
         (void)nmf;
-        P->fused = k1f && fits && ctx->fuse == 2;
+        P->fused = k1f && fits && ctx->fuse == 2 && !P->col_split;
     }
     const int rpp = sym_rows_per_partial(P->sym_rows);   // a-rows per column partial
     const int rps = sym_rows_per_block(P->sym_rows);     // a-rows per workgroup of the symmetric scan
-    int64_t rows = 0, part_rows = 0;
+    // column split (K1f only): ranges of `cstep` columns per problem so that the launch has about 3 workgroups per CU,
+    // at least 4 tiles (128 columns) per range
+    int64_t mf_row_blocks = 0;
+    for (int32_t i = 0; i < nprob; ++i)
+        if (probs[i].n1 > 0 && probs[i].n2 > 0) mf_row_blocks += (probs[i].n1 + 255) / 256;
+    P->col_split = P->col_split && k1f && mf_row_blocks > 0;
+    auto split_of = [&](const plslam_match_problem& p, int32_t* cstep) -> int32_t {
+        *cstep = 0;
+        if (!P->col_split || p.n1 <= 0 || p.n2 <= 0) return 1;
+        const int64_t target = 3 * (int64_t)ctx->prop.multiProcessorCount;
+        const int64_t want = (target + mf_row_blocks - 1) / mf_row_blocks;
+        const int32_t tiles = (p.n2 + 31) / 32;
+        int32_t per = (int32_t)((tiles + want - 1) / want);
+        if (per < 4) per = 4;
+        const int32_t ns = (tiles + per - 1) / per;
+        if (ns <= 1) return 1;
+        *cstep = per * 32;
+        return ns;
+    };
+    {   // partial merge: share a column among several lanes when the plan has long columns and too few of them
+        int64_t cols = 0;
+        int32_t max_nwb = 0;
+        for (int32_t i = 0; i < nprob; ++i)
+            if (is_sym(probs[i])) { cols += probs[i].n2; max_nwb = std::max(max_nwb, (probs[i].n1 + 63) / 64); }
+        const int64_t lanes = 64 * 4 * (int64_t)ctx->prop.multiProcessorCount * 4;      // ~4 waves per SIMD in flight
+        P->merge_parts = (max_nwb >= 64 && cols * 16 <= lanes) ? 16 : (max_nwb >= 32 && cols * 4 <= lanes) ? 4 : 1;
+    }
+    const int mcols = merge_partials16_cols(P->merge_parts);
+    auto part_units = [&](int32_t n1, int32_t n2) -> int64_t {          // K1f: units of two words
+        return (int64_t)((n1 + 63) / 64) * ((n2 + 255) / 256) * 128;
+    };
+    int64_t rows = 0, part_rows = 0, tmp_rows = 0;
     for (int32_t i = 0; i < nprob; ++i) {
         const plslam_match_problem& p = probs[i];
         PLSLAM_REQUIRE(p.n1 >= 0 && p.n2 >= 0, PLSLAM_EINVAL);
@@ -194,8 +239,21 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         rows += p.n1 + (p.mutual ? p.n2 : 0);
         // column partials, in units of two words: K1e one (best, second) pair per (256-row block, column); K1f one word
         // per (64-row block, column) with the rows padded to 256 columns
-        if (is_sym(p)) part_rows += k1f ? (int64_t)((p.n1 + 63) / 64) * ((p.n2 + 255) / 256) * 128
-                                        : (int64_t)((p.n1 + rpp - 1) / rpp) * p.n2;
+        if (is_sym(p)) {
+            int32_t cstep = 0;
+            const int32_t ns = split_of(p, &cstep);
+            if (ns > 1) {
+                for (int32_t s_ = 0; s_ < ns; ++s_)
+                    part_rows += part_units(p.n1, std::min(cstep, p.n2 - s_ * cstep));
+            } else {
+                part_rows += k1f ? part_units(p.n1, p.n2) : (int64_t)((p.n1 + rpp - 1) / rpp) * p.n2;
+            }
+        }
+        if (P->sym_mfma && p.n1 > 0 && p.n2 > 0) {
+            int32_t cstep = 0;
+            const int32_t ns = split_of(p, &cstep);
+            if (ns > 1) tmp_rows += (int64_t)ns * p.n1;
+        }
     }
     PLSLAM_REQUIRE(rows < (int64_t(1) << 31), PLSLAM_ERANGE);
 
@@ -209,6 +267,8 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     if (r) return r;
     r = P->partials.reserve(sizeof(uint32_t) * 2 * (size_t)(part_rows > 0 ? part_rows : 1));
     if (r) return r;
+    if (tmp_rows > 0 && (r = P->rowtmp.reserve(sizeof(uint32_t) * 2 * (size_t)tmp_rows))) return r;
+    uint32_t* d_tmp = P->rowtmp.as<uint32_t>();
     uint32_t* d_keys = P->keys.as<uint32_t>();
     uint32_t* d_part = P->partials.as<uint32_t>();
     // #matches counters: accumulated with atomics by the finalize kernel, zeroed by the scan
@@ -236,7 +296,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     std::vector<SymDesc> syms, dirs;
     std::vector<ProblemDesc> pds;
     std::vector<BlockDesc> sblocks, fblocks, yblocks, mblocks, dblocks;
-    int64_t key_row = 0, part_row = 0, evals = 0, devals = 0, abytes = 0;
+    int64_t key_row = 0, part_row = 0, tmp_row = 0, evals = 0, devals = 0, abytes = 0;
     std::vector<int32_t*> user_counts((size_t)nprob, nullptr);
     for (int32_t i = 0; i < nprob; ++i) {
         const plslam_match_problem& p = probs[i];
@@ -254,19 +314,49 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         const bool mf_path = P->sym_mfma && p.n1 > 0 && p.n2 > 0;    // this problem runs on K1e / K1f
         if (!(P->fused && mf_path))
             for (int32_t r0 = 0; r0 < p.n1; r0 += 256) fblocks.push_back({i, r0});
-        if (is_sym(p)) {
+        int32_t cstep = 0;
+        const int32_t nsplit = mf_path ? split_of(p, &cstep) : 1;
+        if (nsplit > 1) {
+            // one sub-problem per column range: its own row results (relative column indices, merged by the finalize
+            // kernel), its own partial area, its slice of keys21
+            pd.split_tmp = d_tmp + 2 * tmp_row; pd.keys12_out = k12; pd.nsplit = nsplit; pd.cstep = cstep;
+            std::vector<SymDesc>& dst = p.mutual ? syms : dirs;
+            std::vector<BlockDesc>& dstb = p.mutual ? yblocks : dblocks;
+            for (int32_t s_ = 0; s_ < nsplit; ++s_) {
+                const int32_t c0 = s_ * cstep, n2s = std::min(cstep, p.n2 - c0);
+                SymDesc y{};
+                y.a = p.d1; y.b = p.d2 + (size_t)c0 * 32;
+                y.keys12 = d_tmp + 2 * (tmp_row + (int64_t)s_ * p.n1);
+                y.n1 = p.n1; y.n2 = n2s;
+                if (p.mutual) {
+                    y.keys21 = k21 + 2 * (size_t)c0;
+                    y.part21 = d_part + 2 * part_row;
+                    y.n_iblk = (p.n1 + rpp - 1) / rpp;
+                    part_row += part_units(p.n1, n2s);
+                    for (int32_t j0 = 0; j0 < n2s; j0 += mcols) mblocks.push_back({(int32_t)dst.size(), j0});
+                }
+                for (int32_t r0 = 0; r0 < p.n1; r0 += 256) dstb.push_back({(int32_t)dst.size(), r0});
+                if (n2s > 2048) (p.mutual ? P->sym_mfma_multi : P->dir_multi) = true;
+                dst.push_back(y);
+            }
+            tmp_row += (int64_t)nsplit * p.n1;
+            evals += (int64_t)p.n1 * p.n2;
+            devals += (p.mutual ? 2LL : 1LL) * p.n1 * p.n2;
+            abytes += p.mutual ? 2 * 32LL * (p.n1 + p.n2) + 16LL * (p.n1 + p.n2) : 32LL * (p.n1 + p.n2) + 16LL * p.n1;
+        } else if (is_sym(p)) {
             SymDesc y{};
             y.a = p.d1; y.b = p.d2; y.keys12 = k12; y.keys21 = k21;
             y.part21 = d_part + 2 * part_row;
             y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = (p.n1 + rpp - 1) / rpp;
-            part_row += k1f ? (int64_t)((p.n1 + 63) / 64) * ((p.n2 + 255) / 256) * 128 : (int64_t)y.n_iblk * p.n2;
+            part_row += k1f ? part_units(p.n1, p.n2) : (int64_t)y.n_iblk * p.n2;
             if (P->fused) {
                 y.mutual = 1; y.matches_12 = p.matches_12; y.n_matches = pd.n_matches; y.nnr = p.nnr;
                 yblocks.push_back({(int32_t)syms.size(), 0});
             } else {
                 for (int32_t r0 = 0; r0 < p.n1; r0 += rps) yblocks.push_back({(int32_t)syms.size(), r0});
-                for (int32_t c0 = 0; c0 < p.n2; c0 += 256) mblocks.push_back({(int32_t)syms.size(), c0});
+                for (int32_t c0 = 0; c0 < p.n2; c0 += (k1f ? mcols : 256)) mblocks.push_back({(int32_t)syms.size(), c0});
             }
+            if (P->sym_mfma && p.n2 > 2048) P->sym_mfma_multi = true;
             syms.push_back(y);
             evals += (int64_t)p.n1 * p.n2;
             devals += 2LL * p.n1 * p.n2;
@@ -420,6 +510,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->d_count_dst = reinterpret_cast<int32_t**>(base + pc[7].off);
     P->d_dirs = reinterpret_cast<SymDesc*>(base + pc[8].off);
     P->d_dir_blocks = reinterpret_cast<BlockDesc*>(base + pc[9].off);
+
     // P->staging outlives the copy (it is a member), so no synchronisation is needed here; the
     // copy is ordered before the kernels of plan_run when they use the same stream, and the public
     // plan_create synchronises once so that any stream may be used afterwards.
@@ -473,7 +564,8 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
         if (r) return r;
     }
     if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e1, s));   // e0..e1 = the scan kernel(s) alone
-    r = P->sym_mfma && P->mfma_form != 1 ? launch_merge_partials16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s)
+
+    r = P->sym_mfma && P->mfma_form != 1 ? launch_merge_partials16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, s)
                                          : launch_merge_partials(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s);
     if (r) return r;
     r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, s);
@@ -605,6 +697,11 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         ctx->fuse = value;
         return PLSLAM_OK;
     }
+    if (!strcmp(key, "col_split")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= 2, PLSLAM_EINVAL);
+        ctx->col_split = value;
+        return PLSLAM_OK;
+    }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }
@@ -618,6 +715,7 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "group_cap")) { *value = ctx->group_cap; return PLSLAM_OK; }
     if (!strcmp(key, "mfma_form")) { *value = ctx->mfma_form; return PLSLAM_OK; }
     if (!strcmp(key, "fuse")) { *value = ctx->fuse; return PLSLAM_OK; }
+    if (!strcmp(key, "col_split")) { *value = ctx->col_split; return PLSLAM_OK; }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }

@@ -83,6 +83,7 @@ struct plslam_ctx {
     int group_cap = 0;   // blocks of one problem kept together on one XCD; 0 = auto (capi.hip, `stripe`)
     int sym_rows = 0;    // rows of d1 per lane in the symmetric scan: 0 = auto, 1, 4
     int mfma_form = 0;   // matrix-core scan: 0 = auto (grouped, K1f), 1 = exact push per tile (K1e), 2 = grouped (K1f)
+    int col_split = 0;   // K1f, few large problems: 0 = auto (cut the columns into ranges when the plan cannot fill the chip), 1 = never, 2 = always
     int fuse = 0;        // K1f: 0 = auto (one workgroup per problem incl. merge + finalize when the plan is large), 1 = never, 2 = always
     std::mutex mu;       // serialises the host-pointer entry points
     plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
@@ -113,6 +114,12 @@ struct ProblemDesc {    // one StVO::match problem = scan12 (+ scan21 when mutua
     int32_t n1, n2;
     float nnr;
     int32_t mutual;
+    // column-split problems (K1f, capi.hip): the row results arrive as `nsplit` tables [nsplit][n1][2] with column indices
+    // relative to ranges of `cstep` columns; the finalize kernel merges them on the fly (and stores the merged pair to
+    // keys12_out for diagnostics).  nsplit <= 1: keys12 is final.
+    const uint32_t* split_tmp;
+    uint32_t* keys12_out;
+    int32_t nsplit, cstep;
 };
 
 struct BlockDesc {      // one workgroup's slice of a scan / problem
@@ -162,7 +169,11 @@ int launch_scan_sym_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nb
 constexpr int PLSLAM_K1F_FUSED_MAX_N2 = 4096;
 int launch_scan_sym_mfma_g(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
                            int nzero, bool multi_window, bool directed, bool fused, hipStream_t s);
-int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s);
+// parts: lanes sharing one column (1, 4 or 16); the block table has one entry per merge_partials16_cols(parts) columns
+int merge_partials16_cols(int parts);
+int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, hipStream_t s);
+// (Column split of a large problem, K1f: the columns are cut into ranges scanned as sub-problems of their own -- more
+// workgroups than 256-row blocks alone give; the per-range row results are merged by the finalize kernel: ProblemDesc.)
 inline int launch_scan_mfma_form(int form, const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
                                  int nzero, bool multi_window, bool directed, hipStream_t s, bool fused = false)
 {

@@ -550,7 +550,22 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
     const int i1 = bd.row0 + (int)threadIdx.x;
     int m = -1;
     if (i1 < p.n1) {
-        const uint2 k = reinterpret_cast<const uint2*>(p.keys12)[i1];
+        uint2 k;
+        if (p.nsplit > 1) {
+            // column-split problem: best-2 over the ranges' row results; keys are (d << 23 | j) with j relative to the
+            // range, so its first column is added first -- (d, j) order holds within and across ranges
+            const uint2* tmp = reinterpret_cast<const uint2*>(p.split_tmp);
+            uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
+            for (int s = 0; s < p.nsplit; ++s) {
+                const uint2 q = tmp[(size_t)s * p.n1 + i1];
+                const uint32_t off = (uint32_t)(s * p.cstep);
+                best2_merge(b0, b1, q.x == KEY_NONE ? KEY_NONE : q.x + off, q.y == KEY_NONE ? KEY_NONE : q.y + off);
+            }
+            k = make_uint2(b0, b1);
+            reinterpret_cast<uint2*>(p.keys12_out)[i1] = k;          // diagnostics (plslam_match_plan_dump)
+        } else {
+            k = reinterpret_cast<const uint2*>(p.keys12)[i1];
+        }
         m = ratio_pick(k.x, k.y, p.nnr);
         if (m >= 0 && p.mutual) {
             const uint2 kb = reinterpret_cast<const uint2*>(p.keys21)[m];

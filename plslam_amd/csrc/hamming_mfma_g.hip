@@ -581,32 +581,54 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 }
 
 // K1c'  merge of K1f's column partials: keys21[j] = best-2 over the 64-row blocks of part16[block][j] (16-bit keys
-// (d << 7 | row within the block), best | second << 16), widened to (d << 23 | row)
+// (d << 7 | row within the block), best | second << 16), widened to (d << 23 | row).  PARTS lanes share a column (each
+// takes every PARTS-th row block, then LDS): a batch of 1500-row problems has 24 row blocks per column and thousands of
+// columns (PARTS = 1: HBM-bound), ONE 10 000-row local map has 157 row blocks and 1500 columns -- a serial chain of 157
+// loads per lane on 6 workgroups took longer (13.6 us) than the scan itself.
+template <int PARTS>
 __global__ void __launch_bounds__(256)
 k_merge_partials16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks)
 {
+    constexpr int COLS = 256 / PARTS;
+    __shared__ uint32_t red[PARTS > 1 ? 512 : 2];
     const BlockDesc bd = blocks[blockIdx.x];
     const SymDesc sd = syms[bd.item];
-    const int j = bd.row0 + (int)threadIdx.x;
-    if (j >= sd.n2) return;
+    const int jl = (int)threadIdx.x % COLS, part_id = (int)threadIdx.x / COLS;
+    const int j = bd.row0 + jl;
     const gcu32_t part = (gcu32_t) sd.part21;
     const int nwb = (sd.n1 + 63) >> 6;
     const int n2p = (sd.n2 + 255) & ~255;                  // padded row of the partial table
     uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
     const uint32_t tw = ((uint32_t)j >> 5) & 63u;          // the keys still carry + tile within the 64-tile window
+    if (j < sd.n2) {
 #pragma unroll 8
-    for (int wb = 0; wb < nwb; ++wb) {
-        const uint32_t e = part[(size_t)wb * n2p + j];
-        merge2(b0, b1, key16_to_key32((e & 0xFFFFu) - tw, 0u, (uint32_t)(64 * wb), 1u),
-               key16_to_key32((e >> 16) - tw, 0u, (uint32_t)(64 * wb), 1u));
+        for (int wb = part_id; wb < nwb; wb += PARTS) {
+            const uint32_t e = part[(size_t)wb * n2p + j];
+            merge2(b0, b1, key16_to_key32((e & 0xFFFFu) - tw, 0u, (uint32_t)(64 * wb), 1u),
+                   key16_to_key32((e >> 16) - tw, 0u, (uint32_t)(64 * wb), 1u));
+        }
     }
-    ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21))[j] = u32x2_t{b0, b1};
+    if (PARTS > 1) {
+        red[2 * threadIdx.x] = b0;
+        red[2 * threadIdx.x + 1] = b1;
+        __syncthreads();
+        if (part_id == 0) {
+#pragma unroll
+            for (int q = 1; q < PARTS; ++q) merge2(b0, b1, red[2 * (q * COLS + jl)], red[2 * (q * COLS + jl) + 1]);
+        }
+    }
+    if (part_id == 0 && j < sd.n2) ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21))[j] = u32x2_t{b0, b1};
 }
 
-int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s)
+int merge_partials16_cols(int parts) { return 256 / (parts >= 16 ? 16 : parts >= 4 ? 4 : 1); }
+
+// d_blocks: one entry per (problem, merge_partials16_cols(parts) columns)
+int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, hipStream_t s)
 {
     if (nblocks <= 0) return PLSLAM_OK;
-    hipLaunchKernelGGL(k_merge_partials16, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks);
+    if (parts >= 16) hipLaunchKernelGGL((k_merge_partials16<16>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks);
+    else if (parts >= 4) hipLaunchKernelGGL((k_merge_partials16<4>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks);
+    else hipLaunchKernelGGL((k_merge_partials16<1>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

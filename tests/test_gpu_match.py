@@ -178,6 +178,56 @@ def test_c3_map_to_frame_sizes_bit_exact(vctx, oracle):
     assert np.array_equal(m, em) and n == en
 
 
+@pytest.mark.parametrize("shapes,mutual", [(((10000, 1500), (2000, 200)), True), (((3001, 2049), (700, 129)), True),
+                                            (((517, 4400),), True), (((9000, 1500), (64, 33)), False)])
+def test_column_split_of_few_large_problems(ctx, oracle, shapes, mutual):
+    """C3 (one local map against one frame) in ONE plan: too few 256-row blocks to fill the chip, so the matrix-core
+    scan cuts the columns into ranges (one workgroup per row block and range), merges the per-range row results
+    (k_merge_row_splits) and the column partials of the ranges, then finalizes.  AUTO must pick it for the C3 shape; the
+    tables, counts and every intermediate key word (plan dump: (best, second) incl. the second's index, both directions)
+    must equal the unsplit scan's and the oracle's."""
+    import torch
+    import plslam_amd
+    r = _rng(4711 + shapes[0][0])
+    dev = torch.device("cuda", ctx.device)
+    host, probs, outs = [], [], []
+    cnt = torch.zeros(len(shapes), dtype=torch.int32, device=dev)
+    for k, (n1, n2) in enumerate(shapes):
+        b = synth.tie_stress_desc(r, n2) if k == 1 else synth.random_desc(r, n2)
+        a = np.concatenate([synth.noisy_copy(r, b)[0], synth.random_desc(r, n1)])[:n1]
+        ta, tb = torch.from_numpy(np.ascontiguousarray(a)).to(dev), torch.from_numpy(b).to(dev)
+        m = torch.empty(n1, dtype=torch.int32, device=dev)
+        host.append((a, b, ta, tb))
+        outs.append(m)
+        probs.append((ta.data_ptr(), n1, tb.data_ptr(), n2, 0.8, mutual, m.data_ptr(), cnt.data_ptr() + 4 * k))
+    got = {}
+    try:
+        for tag, variant, split in (("auto", plslam_amd.SCAN_AUTO, 0), ("split", plslam_amd.SCAN_MFMA, 2),
+                                    ("unsplit", plslam_amd.SCAN_MFMA, 1)):
+            ctx.set_option("scan_variant", variant)
+            ctx.set_option("col_split", split)
+            plan = ctx.plan(probs)
+            info = plan.info()
+            plan.run(0)
+            torch.cuda.synchronize()
+            keys, _ = plan.dump()
+            got[tag] = (keys.copy(), [m.cpu().numpy().copy() for m in outs], cnt.cpu().numpy().copy(), info)
+            plan.close()
+    finally:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+        ctx.set_option("col_split", 0)
+    big = sum(n1 * n2 for n1, n2 in shapes) >= 6 << 20
+    assert got["auto"][3]["scan_variant"] == (plslam_amd.SCAN_MFMA if big else plslam_amd.SCAN_WAVE_PER_QUERY)
+    assert got["split"][3]["scan_blocks"] > got["unsplit"][3]["scan_blocks"]          # more workgroups, same work
+    nkeys = 2 * sum(n1 + (n2 if mutual else 0) for n1, n2 in shapes)
+    assert np.array_equal(got["split"][0][:nkeys], got["unsplit"][0][:nkeys])
+    for k, (a, b, _, _) in enumerate(host):
+        em, en = oracle.match(a, b, 0.8, mutual)
+        for tag in ("auto", "split", "unsplit"):
+            assert np.array_equal(got[tag][1][k], em), (tag, k)
+            assert got[tag][2][k] == en, (tag, k)
+
+
 def test_c5_dense_size_properties(ctx, oracle):
     """BASELINE config 5 size (4000 ORB): size-independent properties + oracle spot check."""
     r = _rng(55)
