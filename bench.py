@@ -307,16 +307,11 @@ def main():
         sample = sorted({0, 1, B // 3, B // 2, B - 1}) if cpu_tables is None else [0]
         for b_ in bufs:
             full = (pg.gathered(b_) if pg is not None else bm.tables[b_]).cpu().numpy()
-            for r_ in range(world if pg is not None else 1):
-                for i_ in sample:
-                    st_r = stream if r_ == 0 else synth.stereo_stream(i_ + 1, n_orb, n_lbd, seed=synth.SEED0,
-                                                                      first_pair=r_ * B)
-                    tab = full[r_ * B + i_]
-                    for name, d1, d2 in frontend.pair_problems(st_r["orb_l"], st_r["orb_r"], st_r["lbd_l"],
-                                                               st_r["lbd_r"], i_):
-                        em, _ = O.match(d1, d2, args.nnr_p if name.startswith("orb") else args.nnr_l, True)
-                        if not np.array_equal(tab[sl[name]], em):
-                            raise SystemExit(f"bench output differs from the oracle: rank {r_} buffer {b_} pair {i_} / {name}")
+            bad = frontend.verify_gathered_tables(full, world if pg is not None else 1, B, n_orb, n_lbd, args.nnr_p,
+                                                  args.nnr_l, sample, lambda d1, d2, nnr: O.match(d1, d2, nnr, True)[0],
+                                                  local_stream=stream)
+            if bad:
+                raise SystemExit(f"bench output differs from the oracle: buffer {b_}, (rank, pair, problem) = {bad[:4]}")
         if verified["match_tables"] is None:
             verified["match_tables"] = (f"pairs {sample} x 4 problems of {world if pg is not None else 1} rank(s) bit-exact "
                                         f"vs the oracle ({len(bufs)} buffer(s))")

@@ -164,64 +164,132 @@ class StereoBatchMatcher:
             p.close()
 
 
-class PipelinedGather:
-    """Gathers the per-step match tables of all ranks to `root` on a communication stream while the
-    next step computes.  Fixed-stride tables are received straight into one preallocated
-    (world, B, stride) buffer per in-flight step (no concatenation).
+class TableGatherPipeline:
+    """The backend-agnostic half of the N > 1 path: wire format, receive buffers and the per-buffer ordering of
+    "compute into table b" -> "narrow" -> "gather to root" -> "table b may be overwritten".  It knows nothing about the
+    matcher; `submit()` is handed a finished (or, on a GPU, enqueued) table.  The same code runs over RCCL (CUDA
+    tensors, a communication stream, events) and over gloo (CPU tensors, synchronous): tests/test_dist_cpu.py drives it
+    at world size 2.
 
-    Wire format: a table entry is a row index of the other image or -1, so with at most 32 767 features per
-    image it travels as int16 (27.8 MB instead of 55.7 MB per rank and step at 4096 pairs of 1500 + 200
-    features): half the bytes on every xGMI link into the root and half the root's HBM writes; `gathered()`
-    widens back to the int32 tables of the C ABI."""
+    Wire format: a table entry is a row index of the other image or -1 (or a negative filler), so with at most 32 767
+    features per image it travels as int16 (27.8 MB instead of 55.7 MB per rank and step at 4096 pairs of 1500 + 200
+    features): half the bytes on every xGMI link into the root and half the root's HBM writes; `gathered()` widens
+    back to the int32 tables of the C ABI.  RCCL has no 16-bit integer type and a gather moves bytes, so both sides
+    are viewed as uint8."""
 
-    def __init__(self, bm: StereoBatchMatcher, world: int, rank: int, root: int = 0, group=None, compact=None):
+    def __init__(self, rows: int, stride: int, max_index: int, world: int, rank: int, root: int = 0, nbuf: int = 2,
+                 device=None, group=None, compact=None):
         import torch
-        self.torch, self.bm, self.world, self.rank, self.root, self.group = torch, bm, world, rank, root, group
-        self.comm = torch.cuda.Stream(device=bm.dev)
-        self.nbuf = len(bm.tables)
-        self.compact = (max(bm.n_orb, bm.n_lbd) <= 32767) if compact is None else bool(compact)
+        self.torch, self.world, self.rank, self.root, self.group, self.nbuf = torch, world, rank, root, group, nbuf
+        self.rows, self.stride = rows, stride
+        self.dev = device if device is not None else torch.device("cpu")
+        self.cuda = self.dev.type == "cuda"
+        self.compact = (max_index <= 32767) if compact is None else bool(compact)
         self.wire = torch.int16 if self.compact else torch.int32
-        self.send = [torch.empty((bm.B, bm.stride), dtype=self.wire, device=bm.dev) for _ in range(self.nbuf)] \
-            if self.compact else list(bm.tables)
-        self.recv = [torch.empty((world, bm.B, bm.stride), dtype=self.wire, device=bm.dev)
-                     for _ in range(self.nbuf)] if rank == root else [None] * self.nbuf
-        self.works = [None] * self.nbuf      # outstanding gather per buffer
-        self.done_ev = [None] * self.nbuf    # recorded on the comm stream after that gather
+        self.send = [torch.empty((rows, stride), dtype=self.wire, device=self.dev) for _ in range(nbuf)]
+        self.recv = [torch.empty((world, rows, stride), dtype=self.wire, device=self.dev)
+                     for _ in range(nbuf)] if rank == root else [None] * nbuf
+        self.comm = torch.cuda.Stream(device=self.dev) if self.cuda else None
+        self.done_ev = [None] * nbuf         # CUDA: recorded on the comm stream after buffer b's gather
+        self.works = [None] * nbuf
 
-    def step(self, k: int):
-        """Compute step k into buffer k % nbuf and start gathering it."""
+    def before_overwrite(self, b: int, compute_stream=None):
+        """Call before table b is recomputed: its previous gather must have read the send buffer / table."""
+        if self.cuda:
+            if self.done_ev[b] is not None:
+                (compute_stream or self.torch.cuda.current_stream(self.dev)).wait_event(self.done_ev[b])
+        elif self.works[b] is not None:
+            self.works[b].wait()
+            self.works[b] = None
+
+    def submit(self, b: int, table, compute_stream=None):
+        """Narrow table (rows, stride) int32 into send buffer b and start its gather.  CUDA: `table` was produced on
+        `compute_stream`; the narrowing is enqueued there, the gather on the communication stream behind an event."""
         import torch.distributed as dist
-        b = k % self.nbuf
-        if self.done_ev[b] is not None:                    # buffer b is being re-used: its previous gather
-            self.bm.streams[b].wait_event(self.done_ev[b])  # must have read the table before we overwrite it
-        ev = self.bm.run_async(b)
-        if self.compact:                                    # narrow on the compute stream, right behind the finalize
-            with self.torch.cuda.stream(self.bm.streams[b]):
-                self.send[b].copy_(self.bm.tables[b])
-                ev = self.torch.cuda.Event()
-                ev.record(self.bm.streams[b])
-        with self.torch.cuda.stream(self.comm):
-            self.comm.wait_event(ev)
-            # RCCL has no 16-bit integer type; a gather moves bytes, so both sides are viewed as uint8
-            glist = list(self.recv[b].view(self.torch.uint8).unbind(0)) if self.rank == self.root else None
-            w = dist.gather(self.send[b].view(self.torch.uint8), gather_list=glist, dst=self.root, group=self.group,
-                            async_op=True)
-            w.wait()                                        # stream-level wait (comm stream), not a host block
-            done = self.torch.cuda.Event()
-            done.record(self.comm)
-        self.works[b], self.done_ev[b] = w, done
+        torch = self.torch
+        if self.cuda:
+            st = compute_stream or torch.cuda.current_stream(self.dev)
+            with torch.cuda.stream(st):
+                self.send[b].copy_(table)                  # int32 -> wire type right behind the producer
+                ev = torch.cuda.Event()
+                ev.record(st)
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                glist = list(self.recv[b].view(torch.uint8).unbind(0)) if self.rank == self.root else None
+                w = dist.gather(self.send[b].view(torch.uint8), gather_list=glist, dst=self.root, group=self.group,
+                                async_op=True)
+                w.wait()                                   # stream-level wait (comm stream), not a host block
+                done = torch.cuda.Event()
+                done.record(self.comm)
+            self.works[b], self.done_ev[b] = w, done
+        else:
+            self.send[b].copy_(table)
+            glist = list(self.recv[b].view(torch.uint8).unbind(0)) if self.rank == self.root else None
+            self.works[b] = dist.gather(self.send[b].view(torch.uint8), gather_list=glist, dst=self.root,
+                                        group=self.group, async_op=True)
         return b
 
     def finish(self):
-        for ev in self.done_ev:
-            if ev is not None:
-                ev.synchronize()
-        self.torch.cuda.synchronize(self.bm.dev)
+        if self.cuda:
+            for ev in self.done_ev:
+                if ev is not None:
+                    ev.synchronize()
+            self.torch.cuda.synchronize(self.dev)
+        else:
+            for b, w in enumerate(self.works):
+                if w is not None:
+                    w.wait()
+                    self.works[b] = None
 
     def gathered(self, b: int):
+        """Root: the (world * rows, stride) int32 table of buffer b in rank order; other ranks: None."""
         if self.rank != self.root:
             return None
-        return self.recv[b].reshape(self.world * self.bm.B, self.bm.stride).to(self.torch.int32)
+        return self.recv[b].reshape(self.world * self.rows, self.stride).to(self.torch.int32)
+
+
+class PipelinedGather:
+    """Gathers the per-step match tables of all ranks to `root` on a communication stream while the
+    next step computes: StereoBatchMatcher (compute) + TableGatherPipeline (wire format, buffers, ordering)."""
+
+    def __init__(self, bm: StereoBatchMatcher, world: int, rank: int, root: int = 0, group=None, compact=None):
+        self.bm = bm
+        self.pipe = TableGatherPipeline(bm.B, bm.stride, max(bm.n_orb, bm.n_lbd), world, rank, root,
+                                        nbuf=len(bm.tables), device=bm.dev, group=group, compact=compact)
+
+    def step(self, k: int):
+        """Compute step k into buffer k % nbuf and start gathering it."""
+        b = k % self.pipe.nbuf
+        self.pipe.before_overwrite(b, self.bm.streams[b])
+        self.bm.run_async(b)
+        return self.pipe.submit(b, self.bm.tables[b], self.bm.streams[b])
+
+    def finish(self):
+        self.pipe.finish()
+
+    def gathered(self, b: int):
+        return self.pipe.gathered(b)
+
+
+def verify_gathered_tables(full, world: int, B: int, n_orb: int, n_lbd: int, nnr_p: float, nnr_l: float, sample,
+                           match_fn, seed=None, local_stream=None):
+    """Root-side check of a gathered (world * B, stride) table: pairs `sample` of EVERY rank against `match_fn(d1, d2,
+    nnr) -> matches_12` (the oracle).  Rank r's inputs are regenerated from (seed, first_pair = r * B) -- the weak-scaling
+    shard rule of bench.py -- except rank 0's, which may be passed in.  Returns the list of mismatches (rank, pair,
+    problem); empty = verified."""
+    from . import synth
+    sl = table_slices(n_orb, n_lbd)
+    bad = []
+    for r_ in range(world):
+        for i_ in sample:
+            st = local_stream if (r_ == 0 and local_stream is not None) else \
+                synth.stereo_stream(i_ + 1, n_orb, n_lbd, seed=synth.SEED0 if seed is None else seed, first_pair=r_ * B)
+            tab = full[r_ * B + i_]
+            for name, d1, d2 in pair_problems(st["orb_l"], st["orb_r"], st["lbd_l"], st["lbd_r"], i_):
+                em = match_fn(d1, d2, nnr_p if name.startswith("orb") else nnr_l)
+                if not np.array_equal(np.asarray(tab[sl[name]]), em):
+                    bad.append((r_, i_, name))
+    return bad
 
 
 def gather_tables(local, world: int, rank: int, root: int = 0, group=None, force: bool = False):

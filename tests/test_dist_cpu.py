@@ -66,3 +66,94 @@ def test_gloo_world2_gather_matches_single_process(tmp_path):
     assert np.array_equal(got[:N_PAIRS], full)          # rank order == pair order, halo handled
     assert (got[N_PAIRS:] == -3).all()
     assert (full != -2).all()
+
+
+# ---- the pipelined gather of bench.py's N > 1 path, driven over gloo ------------------------------------------------------
+def _pipeline_worker(rank, world, port, out, compact):
+    """Each rank 'computes' step k's table as its oracle table + k (so that a buffer delivered for the wrong step is
+    visible), through the SAME TableGatherPipeline the RCCL path uses: int16 wire format through uint8 views,
+    widening on the root, two buffers reused by steps k and k + 2."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = frontend.shard_range(N_PAIRS, world, rank)
+    per = -(-N_PAIRS // world)
+    stream = synth.stereo_stream(hi - lo, N_ORB, N_LBD, seed=99, first_pair=lo)
+    tab = _oracle_tables(stream)
+    pad = np.full((per, tab.shape[1]), -3, np.int32)              # ragged tail: filler rows survive the int16 trip
+    pad[: tab.shape[0]] = tab
+    base = torch.from_numpy(pad)
+    pipe = frontend.TableGatherPipeline(per, tab.shape[1], max(N_ORB, N_LBD), world, rank, root=0, nbuf=2, compact=compact)
+    assert pipe.wire == (torch.int16 if compact else torch.int32)
+    tables = [torch.empty_like(base) for _ in range(2)]
+    seen = {}
+    for k in range(5):
+        b = k % 2
+        pipe.before_overwrite(b)                                   # step k - 2's gather has consumed tables[b]
+        tables[b].copy_(torch.where(base >= 0, base + k, base))    # "compute" step k
+        pipe.submit(b, tables[b])
+        if k >= 1:                                                 # while step k is in flight, step k - 1 is complete
+            pipe.before_overwrite((k - 1) % 2)
+            g = pipe.gathered((k - 1) % 2)
+            if rank == 0:
+                seen[k - 1] = g.numpy().copy()
+    pipe.finish()
+    if rank == 0:
+        seen[4] = pipe.gathered(0).numpy().copy()
+        np.savez(out, **{f"step{k}": v for k, v in seen.items()})
+    else:
+        assert pipe.gathered(0) is None
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("compact", [True, False])
+def test_gloo_world2_pipelined_gather(tmp_path, compact):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "pipe.npz")
+    mp.spawn(_pipeline_worker, args=(2, port, out, compact), nprocs=2, join=True)
+    got = np.load(out)
+    full = _oracle_tables(synth.stereo_stream(N_PAIRS, N_ORB, N_LBD, seed=99, first_pair=0))
+    per = -(-N_PAIRS // 2)
+    for k in range(5):
+        g = got[f"step{k}"]
+        assert g.dtype == np.int32 and g.shape == (2 * per, full.shape[1])
+        assert np.array_equal(g[:N_PAIRS], np.where(full >= 0, full + k, full)), k      # the table of step k, rank order
+        assert (g[N_PAIRS:] == -3).all()
+
+
+def _verify_worker(rank, world, port, out):
+    """bench.py's root-side check of a gathered table (frontend.verify_gathered_tables): every rank's shard is regenerated
+    from (seed, first_pair = rank * B) on the root.  One rank's table is corrupted in one entry: exactly that (rank, pair,
+    problem) must be reported."""
+    from oracle import oracle as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    B = 3
+    stream = synth.stereo_stream(B, N_ORB, N_LBD, seed=synth.SEED0, first_pair=rank * B)
+    tab = torch.from_numpy(_oracle_tables(stream))
+    if rank == 1:
+        tab[2, N_ORB + 5] = (tab[2, N_ORB + 5] + 1) % N_ORB        # pair 2 of rank 1, problem orb_pc
+    pipe = frontend.TableGatherPipeline(B, tab.shape[1], max(N_ORB, N_LBD), world, rank, root=0, nbuf=1)
+    pipe.submit(0, tab)
+    pipe.finish()
+    if rank == 0:
+        full = pipe.gathered(0).numpy()
+        match = lambda d1, d2, nnr: O.match(d1, d2, nnr, True)[0]   # noqa: E731
+        bad = frontend.verify_gathered_tables(full, world, B, N_ORB, N_LBD, 0.75, 0.9, [0, 2], match, local_stream=stream)
+        ok = frontend.verify_gathered_tables(full, world, B, N_ORB, N_LBD, 0.75, 0.9, [0, 1], match, local_stream=stream)
+        with open(out, "w") as f:
+            f.write(repr((bad, ok)))
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_root_side_verification(tmp_path):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "verify.txt")
+    mp.spawn(_verify_worker, args=(2, port, out), nprocs=2, join=True)
+    bad, ok = eval(open(out).read())
+    assert bad == [(1, 2, "orb_pc")] and ok == []
