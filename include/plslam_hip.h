@@ -381,9 +381,30 @@ int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, double homog_th
                            int32_t n_pt_obs, const int32_t* ls_lm_loc, const int32_t* ls_pose_slot,
                            const int32_t* ls_kf_loc, const double* ls_l_obs, int32_t n_ls_obs,
                            plslam_lba_plan** out);
+/* compat_flags (a bit mask; 1 keeps its round-1 meaning "compat_iter_pass"):
+ *   PLSLAM_LBA_COMPAT_ITER_PASS  the iteration pass's line quirks (see above)
+ *   PLSLAM_LBA_COMPAT_GBA        levMarquardtOptimizationGBA writes the pose x line cross blocks TRANSPOSED
+ *                                (src/mapHandler.cpp:2341-2352 against :1531-1532; H stays symmetric but the block is
+ *                                J_l J_p^T where J_p J_l^T belongs): W_ls comes out the way the reference's GBA fills it */
+#define PLSLAM_LBA_COMPAT_ITER_PASS 1
+#define PLSLAM_LBA_COMPAT_GBA 2
 int plslam_lba_plan_iterate(plslam_lba_plan* plan, const double* T_kf_w, const double* Xw, const double* Lw,
-                            int compat_iter_pass, double* g, double* H_pose, double* H_pt, double* H_ls,
+                            int compat_flags, double* g, double* H_pose, double* H_pt, double* H_ls,
                             double* W_pt, double* W_ls, double* err);
+/* The same iteration with the blocks LEFT ON THE DEVICE: X goes up (0.34 MB at C3), only *err (and g, N doubles, unless
+ * NULL) comes down -- not the 11.5 MB of blocks that made the host-to-host iteration 2.3 ms for 0.1 ms of kernels.
+ * plslam_lba_plan_device_blocks names the device arrays (valid until the next iterate / destroy; ordered on `stream`, the
+ * context's stream) for a device-side Schur complement / solver; plslam_lba_plan_blocks downloads any of them afterwards
+ * (NULL = skip). */
+int plslam_lba_plan_iterate_dev(plslam_lba_plan* plan, const double* T_kf_w, const double* Xw, const double* Lw,
+                                int compat_flags, double* g, double* err);
+typedef struct plslam_lba_blocks {
+    const double *g, *H_pose, *H_pt, *H_ls, *W_pt, *W_ls, *err;   /* device pointers, layouts as plslam_lba_plan_iterate */
+    void* stream;                                                  /* the HIP stream the blocks were computed on     */
+} plslam_lba_blocks;
+int plslam_lba_plan_device_blocks(plslam_lba_plan* plan, plslam_lba_blocks* out);
+int plslam_lba_plan_blocks(plslam_lba_plan* plan, double* g, double* H_pose, double* H_pt, double* H_ls, double* W_pt,
+                           double* W_ls, double* err);
 /* rows of the last iterate() (any pointer may be NULL), e.g. for the write-back logic of :1822-1855 */
 int plslam_lba_plan_rows(plslam_lba_plan* plan, double* pt_J_pose, double* pt_J_lm, double* pt_r, double* pt_w,
                          double* ls_J_pose, double* ls_J_lm, double* ls_r, double* ls_w);

@@ -33,7 +33,8 @@ ABI_SYMBOLS = (
     "plslam_match_plan_elapsed", "plslam_match_plan_info", "plslam_match_plan_dump", "plslam_match_plan_destroy",
     "plslam_lba_point_rows", "plslam_lba_line_rows", "plslam_lba_point_rows_dev",
     "plslam_lba_line_rows_dev", "plslam_lba_assemble", "plslam_lba_plan_create", "plslam_lba_plan_iterate",
-    "plslam_lba_plan_rows", "plslam_lba_plan_destroy",
+    "plslam_lba_plan_rows", "plslam_lba_plan_destroy", "plslam_lba_plan_iterate_dev", "plslam_lba_plan_device_blocks",
+    "plslam_lba_plan_blocks",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
     "plslam_map2kf_match_points_fast", "plslam_map2kf_match_lines_fast",
@@ -184,6 +185,9 @@ def load() -> C.CDLL:
                                          i32, C.POINTER(vp)]
     L.plslam_lba_plan_iterate.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
     L.plslam_lba_plan_rows.argtypes = [vp] * 9
+    L.plslam_lba_plan_iterate_dev.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
+    L.plslam_lba_plan_device_blocks.argtypes = [vp, vp]
+    L.plslam_lba_plan_blocks.argtypes = [vp] * 8
     L.plslam_lba_plan_destroy.argtypes = [vp]
     L.plslam_lba_plan_destroy.restype = None
     for f in (L.plslam_map2kf_point_gate, L.plslam_map2kf_line_gate):
@@ -610,6 +614,30 @@ class LbaPlan:
                "plslam_lba_plan_create")
         self._h = h
 
+    COMPAT_ITER_PASS, COMPAT_GBA = 1, 2
+
+    def iterate_dev(self, T_kf_w, Xw, Lw, compat_flags=0, want_g=True):
+        """One iteration with the blocks left on the device -> (err, g or None)."""
+        nkf, npt, nls, npo, nlo, nslot = self.dims
+        T = _arr(T_kf_w, np.float64, (-1, 16))
+        X, Lm = _arr(Xw, np.float64, (-1, 3)), _arr(Lw, np.float64, (-1, 6))
+        g = np.empty(6 * nkf + 3 * npt + 6 * nls) if want_g else None
+        err = np.empty(1)
+        _check(self._L.plslam_lba_plan_iterate_dev(self._h, _p(T), _p(X), _p(Lm), int(compat_flags),
+                                                   _p(g) if want_g else None, _p(err)), "plslam_lba_plan_iterate_dev")
+        return float(err[0]), g
+
+    def blocks(self):
+        """Download the blocks of the last iteration (the arrays plslam_lba_plan_device_blocks names)."""
+        nkf, npt, nls, npo, nlo, _ = self.dims
+        g, Hp = np.empty(6 * nkf + 3 * npt + 6 * nls), np.empty((nkf, 6, 6))
+        Hpt, Hls = np.empty((npt, 3, 3)), np.empty((nls, 6, 6))
+        Wp, Wl = np.empty((npo, 3, 6)), np.empty((nlo, 6, 6))
+        err = np.empty(1)
+        _check(self._L.plslam_lba_plan_blocks(self._h, _p(g), _p(Hp), _p(Hpt), _p(Hls), _p(Wp), _p(Wl), _p(err)),
+               "plslam_lba_plan_blocks")
+        return dict(g=g, H_pose=Hp, H_pt=Hpt, H_ls=Hls, W_pt=Wp, W_ls=Wl, err=float(err[0]))
+
     def iterate(self, T_kf_w, Xw, Lw, compat_iter_pass=False):
         nkf, npt, nls, npo, nlo, nslot = self.dims
         T = _arr(T_kf_w, np.float64, (-1, 16))
@@ -620,7 +648,7 @@ class LbaPlan:
         Hpt, Hls = np.empty((npt, 3, 3)), np.empty((nls, 6, 6))
         Wp, Wl = np.empty((npo, 3, 6)), np.empty((nlo, 6, 6))
         err = np.empty(1)
-        _check(self._L.plslam_lba_plan_iterate(self._h, _p(T), _p(X), _p(Lm), int(bool(compat_iter_pass)), _p(g), _p(Hp),
+        _check(self._L.plslam_lba_plan_iterate(self._h, _p(T), _p(X), _p(Lm), int(compat_iter_pass), _p(g), _p(Hp),
                                                _p(Hpt), _p(Hls), _p(Wp), _p(Wl), _p(err)), "plslam_lba_plan_iterate")
         return dict(g=g, H_pose=Hp, H_pt=Hpt, H_ls=Hls, W_pt=Wp, W_ls=Wl, err=float(err[0]))
 

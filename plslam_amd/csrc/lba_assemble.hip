@@ -55,11 +55,15 @@ k_landmark_blocks(const int32_t* __restrict__ lm_ptr, const int32_t* __restrict_
     for (int i = 0; i < DL; ++i) gl[(size_t)l * DL + i] = g[i];
 }
 
-template <int DL>
+// TRANSPOSED (DL == 6 only): element (a, b) receives Jl[b] * Jp[a] * w -- the block as levMarquardtOptimizationGBA writes
+// it for lines (src/mapHandler.cpp:2341-2352 against :1531-1532 of the local BA; a reference defect that callers after
+// the reference's GBA numbers reproduce with PLSLAM_LBA_COMPAT_GBA)
+template <int DL, bool TRANSPOSED = false>
 __global__ void __launch_bounds__(256)
 k_cross_blocks(const int32_t* __restrict__ kf_loc, int32_t nobs, const double* __restrict__ Jp,
                const double* __restrict__ Jl, const double* __restrict__ w, double* __restrict__ W)
 {
+    static_assert(!TRANSPOSED || DL == 6, "only the square line block can be transposed in place");
     const int o = blockIdx.x * 256 + threadIdx.x;
     if (o >= nobs) return;
     const bool opt = kf_loc[o] >= 0;   // kf_loc == -1: the keyframe is not optimised, no cross block
@@ -71,7 +75,7 @@ k_cross_blocks(const int32_t* __restrict__ kf_loc, int32_t nobs, const double* _
     for (int a = 0; a < DL; ++a) {
         const double ja = Jl[(size_t)o * DL + a];
 #pragma unroll
-        for (int b = 0; b < 6; ++b) W[((size_t)o * DL + a) * 6 + b] = opt ? ja * P[b] * ww : 0.0;
+        for (int b = 0; b < 6; ++b) W[TRANSPOSED ? ((size_t)o * 6 + b) * 6 + a : ((size_t)o * DL + a) * 6 + b] = opt ? ja * P[b] * ww : 0.0;
     }
 }
 
@@ -155,6 +159,7 @@ struct AssembleDev {
     double *g, *H_pose, *H_pt, *H_ls, *W_pt, *W_ls, *err;
     double* pose_part;      // [nkf][max_chunks][42] scratch
     int32_t max_chunks;     // max over keyframes of ceil(#observations / POSE_CHUNK)
+    int32_t transpose_ls_cross = 0;   // PLSLAM_LBA_COMPAT_GBA: the pose x line cross blocks as the reference's GBA writes them
 };
 
 static int assemble_on_device(const AssembleDev& a, int32_t nkf, int32_t npt, int32_t nls, int32_t n_pt_obs,
@@ -170,8 +175,11 @@ static int assemble_on_device(const AssembleDev& a, int32_t nkf, int32_t npt, in
     if (n_pt_obs)
         hipLaunchKernelGGL(k_cross_blocks<3>, dim3((n_pt_obs + 255) / 256), dim3(256), 0, s, a.pt_kf_loc, n_pt_obs,
                            a.pt_Jp, a.pt_Jl, a.pt_w, a.W_pt);
-    if (n_ls_obs)
+    if (n_ls_obs && !a.transpose_ls_cross)
         hipLaunchKernelGGL(k_cross_blocks<6>, dim3((n_ls_obs + 255) / 256), dim3(256), 0, s, a.ls_kf_loc, n_ls_obs,
+                           a.ls_Jp, a.ls_Jl, a.ls_w, a.W_ls);
+    if (n_ls_obs && a.transpose_ls_cross)
+        hipLaunchKernelGGL((k_cross_blocks<6, true>), dim3((n_ls_obs + 255) / 256), dim3(256), 0, s, a.ls_kf_loc, n_ls_obs,
                            a.ls_Jp, a.ls_Jl, a.ls_w, a.W_ls);
     if (nkf) {
         if (a.max_chunks > 0)
@@ -317,16 +325,10 @@ extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, doub
     return PLSLAM_OK;
 }
 
-extern "C" int plslam_lba_plan_iterate(plslam_lba_plan* P, const double* T_kf_w, const double* Xw, const double* Lw,
-                                       int compat_iter_pass, double* g, double* H_pose, double* H_pt, double* H_ls,
-                                       double* W_pt, double* W_ls, double* err)
+// upload X, rows (K3/K4), blocks (K7-K10): enqueued on the context's stream, nothing downloaded.  Caller holds ctx->mu.
+static int lba_plan_enqueue(plslam_lba_plan* P, const double* T_kf_w, const double* Xw, const double* Lw, int compat_flags)
 {
-    PLSLAM_REQUIRE(P && g && err, PLSLAM_EINVAL);
-    PLSLAM_REQUIRE((P->n_slots == 0 || T_kf_w) && (P->npt == 0 || (Xw && H_pt)) && (P->nls == 0 || (Lw && H_ls)), PLSLAM_EINVAL);
-    PLSLAM_REQUIRE((P->nkf == 0 || H_pose) && (P->np == 0 || W_pt) && (P->nl == 0 || W_ls), PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    DeviceGuard dg_(ctx->device);    // every entry point runs on the context's device, whatever the calling thread's current one
     hipStream_t s = ctx->stream;
     char *ds = P->stat.as<char>(), *dd = P->dyn.as<char>(), *dr = P->rows.as<char>(), *dout = P->out.as<char>();
     if (P->n_slots) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd + P->oT, T_kf_w, (size_t)P->n_slots * 128, hipMemcpyHostToDevice, s));
@@ -337,10 +339,10 @@ extern "C" int plslam_lba_plan_iterate(plslam_lba_plan* P, const double* T_kf_w,
                                 (int32_t*)(ds + P->oPlm), (int32_t*)(ds + P->oPslot), P->np, (double*)(dr + P->oPJp),
                                 (double*)(dr + P->oPJl), (double*)(dr + P->oPr), (double*)(dr + P->oPw), s)))
         return rc;
-    if ((rc = launch_line_rows(P->cam, P->th, compat_iter_pass ? 1 : 0, (double*)(dd + P->oT), (double*)(dd + P->oL),
-                               (double*)(ds + P->oLobs), (int32_t*)(ds + P->oLlm), (int32_t*)(ds + P->oLslot), P->nl,
-                               (double*)(dr + P->oLJp), (double*)(dr + P->oLJl), (double*)(dr + P->oLr),
-                               (double*)(dr + P->oLw), s)))
+    if ((rc = launch_line_rows(P->cam, P->th, (compat_flags & PLSLAM_LBA_COMPAT_ITER_PASS) ? 1 : 0, (double*)(dd + P->oT),
+                               (double*)(dd + P->oL), (double*)(ds + P->oLobs), (int32_t*)(ds + P->oLlm),
+                               (int32_t*)(ds + P->oLslot), P->nl, (double*)(dr + P->oLJp), (double*)(dr + P->oLJl),
+                               (double*)(dr + P->oLr), (double*)(dr + P->oLw), s)))
         return rc;
     AssembleDev a{(int32_t*)(ds + P->oPkf), (int32_t*)(ds + P->oLkf), (int32_t*)(ds + P->oPtp), (int32_t*)(ds + P->oPti),
                   (int32_t*)(ds + P->oLsp), (int32_t*)(ds + P->oLsi), (int32_t*)(ds + P->oKfp), (int32_t*)(ds + P->oKfi),
@@ -348,20 +350,84 @@ extern "C" int plslam_lba_plan_iterate(plslam_lba_plan* P, const double* T_kf_w,
                   (double*)(dr + P->oLJp), (double*)(dr + P->oLJl), (double*)(dr + P->oLr), (double*)(dr + P->oLw),
                   (double*)(dout + P->oG), (double*)(dout + P->oHp), (double*)(dout + P->oHpt), (double*)(dout + P->oHls),
                   (double*)(dout + P->oWp), (double*)(dout + P->oWl), (double*)(dout + P->oErr),
-                  (double*)(dout + P->oPart), P->max_chunks};
-    if ((rc = assemble_on_device(a, P->nkf, P->npt, P->nls, P->np, P->nl, s))) return rc;
+                  (double*)(dout + P->oPart), P->max_chunks, (compat_flags & PLSLAM_LBA_COMPAT_GBA) ? 1 : 0};
+    return assemble_on_device(a, P->nkf, P->npt, P->nls, P->np, P->nl, s);
+}
+
+// device -> host copies of the blocks of the last iteration (NULL pointers are skipped), then one synchronise
+static int lba_plan_download(plslam_lba_plan* P, double* g, double* H_pose, double* H_pt, double* H_ls, double* W_pt,
+                             double* W_ls, double* err)
+{
+    hipStream_t s = P->ctx->stream;
+    char* dout = P->out.as<char>();
     const size_t N = 6 * (size_t)P->nkf + 3 * (size_t)P->npt + 6 * (size_t)P->nls;
     auto down = [&](void* dst, size_t off, size_t bytes) -> int {
-        if (bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(dst, dout + off, bytes, hipMemcpyDeviceToHost, s));
+        if (dst && bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(dst, dout + off, bytes, hipMemcpyDeviceToHost, s));
         return PLSLAM_OK;
     };
+    int rc;
     if ((rc = down(g, P->oG, N * 8)) || (rc = down(H_pose, P->oHp, (size_t)P->nkf * 288)) ||
         (rc = down(H_pt, P->oHpt, (size_t)P->npt * 72)) || (rc = down(H_ls, P->oHls, (size_t)P->nls * 288)) ||
         (rc = down(W_pt, P->oWp, (size_t)P->np * 144)) || (rc = down(W_ls, P->oWl, (size_t)P->nl * 288)) ||
-        (rc = down(err, P->oErr, 8)))
+        (rc = down(err, P->oErr, 8))) {
+        (void)hipStreamSynchronize(s);
         return rc;
+    }
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     return PLSLAM_OK;
+}
+
+extern "C" int plslam_lba_plan_iterate(plslam_lba_plan* P, const double* T_kf_w, const double* Xw, const double* Lw,
+                                       int compat_flags, double* g, double* H_pose, double* H_pt, double* H_ls,
+                                       double* W_pt, double* W_ls, double* err)
+{
+    PLSLAM_REQUIRE(P && g && err, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE((P->n_slots == 0 || T_kf_w) && (P->npt == 0 || (Xw && H_pt)) && (P->nls == 0 || (Lw && H_ls)), PLSLAM_EINVAL);
+    PLSLAM_REQUIRE((P->nkf == 0 || H_pose) && (P->np == 0 || W_pt) && (P->nl == 0 || W_ls), PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);    // every entry point runs on the context's device, whatever the calling thread's current one
+    int rc = lba_plan_enqueue(P, T_kf_w, Xw, Lw, compat_flags);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    return lba_plan_download(P, g, H_pose, H_pt, H_ls, W_pt, W_ls, err);
+}
+
+// The same iteration with the blocks LEFT ON THE DEVICE: what crosses PCIe is X up (0.34 MB at C3) and err (+ g when
+// asked for) down, not the 11.5 MB of blocks.  plslam_lba_plan_device_blocks names them for a device-side solver;
+// plslam_lba_plan_blocks fetches any of them later.
+extern "C" int plslam_lba_plan_iterate_dev(plslam_lba_plan* P, const double* T_kf_w, const double* Xw, const double* Lw,
+                                           int compat_flags, double* g, double* err)
+{
+    PLSLAM_REQUIRE(P && err, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE((P->n_slots == 0 || T_kf_w) && (P->npt == 0 || Xw) && (P->nls == 0 || Lw), PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
+    int rc = lba_plan_enqueue(P, T_kf_w, Xw, Lw, compat_flags);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    return lba_plan_download(P, g, nullptr, nullptr, nullptr, nullptr, nullptr, err);
+}
+
+extern "C" int plslam_lba_plan_device_blocks(plslam_lba_plan* P, plslam_lba_blocks* out)
+{
+    PLSLAM_REQUIRE(P && out, PLSLAM_EINVAL);
+    char* dout = P->out.as<char>();
+    out->g = (const double*)(dout + P->oG); out->H_pose = (const double*)(dout + P->oHp);
+    out->H_pt = (const double*)(dout + P->oHpt); out->H_ls = (const double*)(dout + P->oHls);
+    out->W_pt = (const double*)(dout + P->oWp); out->W_ls = (const double*)(dout + P->oWl);
+    out->err = (const double*)(dout + P->oErr);
+    out->stream = P->ctx->stream;
+    return PLSLAM_OK;
+}
+
+extern "C" int plslam_lba_plan_blocks(plslam_lba_plan* P, double* g, double* H_pose, double* H_pt, double* H_ls,
+                                      double* W_pt, double* W_ls, double* err)
+{
+    PLSLAM_REQUIRE(P != nullptr, PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
+    return lba_plan_download(P, g, H_pose, H_pt, H_ls, W_pt, W_ls, err);
 }
 
 // the rows of the last iterate() (device -> host), e.g. for the outlier logic of :1831-1846

@@ -291,6 +291,60 @@ def test_lba_plan_against_the_reference_source_text_outputs(ctx):
     plan.close()
 
 
+def test_lba_plan_device_resident_iteration_and_gba_blocks(ctx):
+    """plslam_lba_plan_iterate_dev: the same iteration with the blocks left on the device -- what comes back (err, g) and
+    what plslam_lba_plan_blocks fetches afterwards are bit-identical to plslam_lba_plan_iterate's; at C3 size the
+    host-to-host iteration is several times faster because 11.5 MB of blocks stay put.  PLSLAM_LBA_COMPAT_GBA: the
+    pose x line cross blocks come out TRANSPOSED (how levMarquardtOptimizationGBA writes them, src/mapHandler.cpp:2341-2352
+    vs :1531-1532) and nothing else changes; the goldens of the reference's own loops hold for the _dev form too."""
+    import os
+    import time
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lba_ref_golden.npz"))
+    n_kf, nkf, npt, nls = (int(x) for x in g["dims"])
+    cam, _ = _cams()
+    kp, kl = g["pt_kf"] - 1, g["ls_kf"] - 1
+    slot_p = np.where(kp >= 0, n_kf + kp, g["pt_kf"]).astype(np.int32)
+    plan = plslam_amd.LbaPlan(ctx, cam, float(g["th"][0]), n_kf + nkf, nkf, npt, nls, g["pt_lm"], slot_p, kp, g["obs_uv"],
+                              g["ls_lm"], g["ls_kf"], kl, g["l_obs"])
+    T = np.concatenate([g["T_map"], g["T_slot"]])
+    ref = plan.iterate(T, g["Xw"], g["Lw"], compat_iter_pass=1)
+    err, gg = plan.iterate_dev(T, g["Xw"], g["Lw"], compat_flags=plan.COMPAT_ITER_PASS)
+    got = plan.blocks()
+    assert err == ref["err"] and np.array_equal(gg, ref["g"])
+    for k in ("g", "H_pose", "H_pt", "H_ls", "W_pt", "W_ls"):
+        assert np.array_equal(got[k], ref[k]), k
+    Hd = _expand_blocks(got, nkf, npt, nls, g["pt_lm"], kp, g["ls_lm"], kl)
+    assert np.abs(Hd - g["iter_H"]).max() <= 1e-10 * np.abs(g["iter_H"]).max()
+    # GBA form: only W_ls changes, into the per-observation transposes
+    err2, g2 = plan.iterate_dev(T, g["Xw"], g["Lw"], compat_flags=plan.COMPAT_ITER_PASS | plan.COMPAT_GBA)
+    gba = plan.blocks()
+    assert err2 == err and np.array_equal(g2, gg)
+    for k in ("H_pose", "H_pt", "H_ls", "W_pt"):
+        assert np.array_equal(gba[k], ref[k]), k
+    assert np.array_equal(gba["W_ls"], np.transpose(ref["W_ls"], (0, 2, 1)))
+    assert not np.array_equal(gba["W_ls"], ref["W_ls"])
+    plan.close()
+    # C3 size: host-to-host time of one iteration, blocks downloaded vs left on the device
+    lm = synth.local_map()
+    big = plslam_amd.LbaPlan(ctx, cam, 1e-7, 10, 9, 10000, 2000, lm["pt_lm"], lm["pt_kf"], lm["pt_kf"] - 1, lm["obs_uv"],
+                             lm["ls_lm"], lm["ls_kf"], lm["ls_kf"] - 1, lm["l_obs"])
+    for _ in range(3):
+        big.iterate(lm["T_kf_w"], lm["Xw"], lm["Lw"])
+        big.iterate_dev(lm["T_kf_w"], lm["Xw"], lm["Lw"], want_g=False)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        big.iterate(lm["T_kf_w"], lm["Xw"], lm["Lw"])
+    t_host = (time.perf_counter() - t0) / 10
+    t0 = time.perf_counter()
+    for _ in range(10):
+        e_dev, _ = big.iterate_dev(lm["T_kf_w"], lm["Xw"], lm["Lw"], want_g=False)
+    t_dev = (time.perf_counter() - t0) / 10
+    assert e_dev == big.iterate(lm["T_kf_w"], lm["Xw"], lm["Lw"])["err"]
+    print(f"C3 LBA iteration host-to-host: blocks downloaded {1e3 * t_host:.2f} ms, device-resident {1e3 * t_dev:.2f} ms")
+    assert t_dev < 0.6 * t_host and t_dev < 1.0e-3
+    big.close()
+
+
 def test_visibility_gates_and_median_descriptor_against_reference_source_text_outputs(ctx):
     """tests/golden/map2kf_ref_golden.npz = what the reference's OWN loops produce (matchMap2KFPoints / Lines visibility
     pre-filter and gates, src/mapHandler.cpp:545-558, :601-629, :647-663, :716-749, compiled textually; and
