@@ -523,6 +523,50 @@ def secondary_records(ctx, dev, args, note):
     pairs_run("c5", 4000, 600, 128, 4, {"scan_variant": plslam_amd.SCAN_MFMA},
               "C5: 4000 ORB + 600 LBD per image (two 2048-column windows per ORB scan)")
 
+    # ---- PCIe-inclusive: descriptors in (pinned) host memory, tables wanted in host memory -- never `value` ---------------
+    Bp = max(16, min(256, B))
+    stp = synth.stereo_stream(Bp, n_orb, n_lbd, seed=synth.SEED0)
+    hp = frontend.HostStereoPipeline(ctx, Bp, n_orb, n_lbd, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, depth=3)
+    for slot in range(hp.depth + 1):
+        hp.fill(slot, stp)
+    for k in range(4):
+        hp.submit(k % (hp.depth + 1))
+    hp.wait()
+    nb = 16
+    t0 = time.perf_counter()
+    for k in range(nb):
+        hp.submit(k % (hp.depth + 1))
+    hp.wait()
+    dt = time.perf_counter() - t0
+    # the link itself: the same arena as a bare pinned -> device copy (what any encoding of these bytes is bounded by)
+    pin = torch.empty(hp.arena_bytes, dtype=torch.uint8).pin_memory()
+    dst = torch.empty(hp.arena_bytes, dtype=torch.uint8, device=dev)
+    for _ in range(3):
+        dst.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for _ in range(nb):
+        dst.copy_(pin, non_blocking=True)
+    torch.cuda.synchronize(dev)
+    link = hp.arena_bytes * nb / (time.perf_counter() - t1) / 1e9
+    del pin, dst
+    tab = hp.tables[0].array
+    slh = frontend.table_slices(n_orb, n_lbd)
+    for name, d1, d2 in frontend.pair_problems(stp["orb_l"], stp["orb_r"], stp["lbd_l"], stp["lbd_r"], 0):
+        if not np.array_equal(tab[0, slh[name]], O.match(d1, d2, args.nnr_p if name.startswith("orb") else args.nnr_l, True)[0]):
+            raise SystemExit(f"secondary record pcie_inclusive: output differs from the oracle ({name})")
+    rec["pcie_inclusive"] = {
+        "value": Bp * nb / dt, "unit": "stereo pairs/s", "pairs_per_batch": Bp, "batches": nb, "in_flight": hp.depth,
+        "h2d_GBps": hp.arena_bytes * nb / dt / 1e9, "d2h_GBps": Bp * hp.stride * 4 * nb / dt / 1e9,
+        "h2d_link_GBps_bare_copy": link, "link_bound_pairs_per_s": link * 1e9 / (hp.arena_bytes / Bp),
+        "bytes_up_per_pair": hp.arena_bytes / Bp, "bytes_down_per_pair": hp.stride * 4,
+        "workload": "plslam_match_pipeline: arenas of descriptor rows in pinned host memory -> match tables in pinned host "
+                    "memory; upload of batch k+1 and download of batch k-1 under the kernels of batch k (the host-side "
+                    "fill of the arenas is not in the timed region: the descriptors are taken to be born there)",
+        "verified": "pair 0 x 4 problems bit-exact vs the oracle"}
+    hp.close()
+    note(f"  pcie_inclusive: {rec['pcie_inclusive']['value']:.0f} pairs/s host-to-host, H2D {rec['pcie_inclusive']['h2d_GBps']:.1f} GB/s")
+
     # ---- C3: one map<->frame problem (10 000 x 1500 ORB + 2 000 x 200 LBD, mutual) and the LBA row pass --------------------
     st_ = torch.cuda.Stream(device=dev)
     s_ = st_.cuda_stream

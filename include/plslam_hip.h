@@ -250,6 +250,32 @@ int plslam_grid_plan_run(plslam_grid_plan* plan, void* stream);
 int plslam_grid_plan_overflows(plslam_grid_plan* plan, void* stream, int32_t* n_overflows);
 void plslam_grid_plan_destroy(plslam_grid_plan* plan);
 
+/* ---- host-to-host pipeline: descriptors born on the host, tables wanted on the host -------------------------------- */
+/* plslam_match_batched is strictly serial (H2D -> kernels -> D2H) and uploads every problem's rows separately.  A
+ * pipeline is created ONCE for a batch shape: the host hands over one ARENA of descriptor rows per batch (any layout;
+ * problems name byte offsets into it, so prev<->curr and L<->R problems share the rows of an image instead of carrying
+ * copies: 109 kB per C2 stereo pair instead of 218 kB) and receives one int32 output table.  `depth` (2..8) batches are
+ * in flight: the upload of batch k+1 and the download of batch k-1 run on their own HIP streams under the kernels of
+ * batch k.  submit() returns as soon as the work is enqueued (it first waits for the batch that used the slot `depth`
+ * submits ago); the output of a submit is complete after the submit that re-uses its slot or after wait().  Host
+ * buffers should come from plslam_pinned_alloc (pageable memory works but the runtime then stages every copy itself). */
+typedef struct plslam_arena_problem {
+    int64_t d1_off, d2_off;      /* byte offsets of the two descriptor sets inside the arena (4-byte aligned)  */
+    int32_t n1, n2;
+    float nnr;
+    int32_t mutual;
+    int64_t out_off;             /* first entry of this problem's matches_12 inside the output table (int32 units) */
+} plslam_arena_problem;
+typedef struct plslam_match_pipeline plslam_match_pipeline;
+int plslam_match_pipeline_create(plslam_ctx* ctx, size_t arena_bytes, const plslam_arena_problem* probs, int32_t nprob,
+                                 size_t out_entries, int32_t depth, plslam_match_pipeline** out);
+int plslam_match_pipeline_submit(plslam_match_pipeline* pipe, const void* arena_host, int32_t* out_host,
+                                 int32_t* counts_host /* nprob entries or NULL */);
+int plslam_match_pipeline_wait(plslam_match_pipeline* pipe);
+void plslam_match_pipeline_destroy(plslam_match_pipeline* pipe);
+void* plslam_pinned_alloc(size_t bytes);      /* hipHostMalloc; NULL on failure */
+void plslam_pinned_free(void* p);
+
 /* ---- K15/K16: the stereo L<->R gates of StVO::StereoFrame ---------------------------------------- */
 /* stvo-pl stereoFrame.cpp, matchStereoPoints / matchStereoLines ([RECALL]; the un-vendored dependency): what turns
  * the match table of (pdesc_l, pdesc_r) / (ldesc_l, ldesc_r) -- from StVO::match or StVO::matchGrid with the window

@@ -8,8 +8,8 @@ sources in plslam_amd/csrc).  The Python in this package is plumbing around it (
 device-memory handling through torch, sharding over ranks); the C++ host shim that mirrors
 the reference's ``StVO::match`` signature lives in plslam_amd/host.
 """
-from .capi import (Cam, Context, MatchPlan, LbaPlan, GridPlan, PlslamError, LIB_PATH, ABI_SYMBOLS, make_cam, load,
+from .capi import (Cam, Context, MatchPlan, MatchPipeline, PinnedArray, LbaPlan, GridPlan, PlslamError, LIB_PATH, ABI_SYMBOLS, make_cam, load,
                    SCAN_AUTO, SCAN_LANE_PER_QUERY, SCAN_WAVE_PER_QUERY, SCAN_SYMMETRIC, SCAN_MFMA)
 
-__all__ = ["Cam", "Context", "MatchPlan", "LbaPlan", "GridPlan", "PlslamError", "LIB_PATH", "ABI_SYMBOLS", "make_cam", "load",
+__all__ = ["Cam", "Context", "MatchPlan", "MatchPipeline", "PinnedArray", "LbaPlan", "GridPlan", "PlslamError", "LIB_PATH", "ABI_SYMBOLS", "make_cam", "load",
            "SCAN_AUTO", "SCAN_LANE_PER_QUERY", "SCAN_WAVE_PER_QUERY", "SCAN_SYMMETRIC", "SCAN_MFMA"]

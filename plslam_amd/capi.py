@@ -43,6 +43,8 @@ ABI_SYMBOLS = (
     "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
     "plslam_stereo_point_gate", "plslam_stereo_line_gate", "plslam_stereo_point_gate_dev", "plslam_stereo_line_gate_dev",
     "plslam_match_plan_add_stereo_gates", "plslam_pose_gn_accumulate",
+    "plslam_match_pipeline_create", "plslam_match_pipeline_submit", "plslam_match_pipeline_wait",
+    "plslam_match_pipeline_destroy", "plslam_pinned_alloc", "plslam_pinned_free",
     "plslam_match_grid", "plslam_grid_plan_create", "plslam_grid_plan_run", "plslam_grid_plan_overflows",
     "plslam_grid_plan_destroy",
     "plslam_gather_match_tables",
@@ -69,6 +71,12 @@ class StereoGateProblem(C.Structure):
                 ("min_disp", C.c_double), ("line_horiz_th", C.c_double), ("stereo_overlap_th", C.c_double),
                 ("ls_min_disp_ratio", C.c_double), ("stereo_12", C.c_void_p), ("disp", C.c_void_p),
                 ("n_stereo", C.c_void_p)]
+
+
+class ArenaProblem(C.Structure):
+    """plslam_arena_problem"""
+    _fields_ = [("d1_off", C.c_int64), ("d2_off", C.c_int64), ("n1", C.c_int32), ("n2", C.c_int32), ("nnr", C.c_float),
+                ("mutual", C.c_int32), ("out_off", C.c_int64)]
 
 
 class GridProblem(C.Structure):
@@ -214,6 +222,15 @@ def load() -> C.CDLL:
     L.plslam_stereo_point_gate_dev.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, vp, vp, vp, vp]
     L.plslam_stereo_line_gate_dev.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, f64, f64, vp, vp, vp, vp]
     L.plslam_match_plan_add_stereo_gates.argtypes = [vp, C.POINTER(StereoGateProblem), i32]
+    L.plslam_match_pipeline_create.argtypes = [vp, C.c_size_t, C.POINTER(ArenaProblem), i32, C.c_size_t, i32, C.POINTER(vp)]
+    L.plslam_match_pipeline_submit.argtypes = [vp, vp, vp, vp]
+    L.plslam_match_pipeline_wait.argtypes = [vp]
+    L.plslam_match_pipeline_destroy.argtypes = [vp]
+    L.plslam_match_pipeline_destroy.restype = None
+    L.plslam_pinned_alloc.argtypes = [C.c_size_t]
+    L.plslam_pinned_alloc.restype = vp
+    L.plslam_pinned_free.argtypes = [vp]
+    L.plslam_pinned_free.restype = None
     L.plslam_match_grid.argtypes = [vp, vp, i32, vp, i32, vp, vp, i32, i32, vp, i32, vp, vp, f64, vp, f64, C.c_int, vp,
                                     C.POINTER(i32)]
     L.plslam_grid_plan_create.argtypes = [vp, C.POINTER(GridProblem), i32, C.POINTER(vp)]
@@ -225,7 +242,8 @@ def load() -> C.CDLL:
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if name not in ("plslam_strerror", "plslam_last_error", "plslam_ctx_destroy",
-                        "plslam_match_plan_destroy", "plslam_lba_plan_destroy", "plslam_grid_plan_destroy"):
+                        "plslam_match_plan_destroy", "plslam_lba_plan_destroy", "plslam_grid_plan_destroy",
+                        "plslam_match_pipeline_destroy", "plslam_pinned_alloc", "plslam_pinned_free"):
             f.restype = C.c_int
     _lib = L
     return L
@@ -594,6 +612,68 @@ class Context:
 
     def plan(self, problems) -> "MatchPlan":
         return MatchPlan(self, problems)
+
+
+class PinnedArray:
+    """A numpy view of page-locked host memory (plslam_pinned_alloc): what a host-to-host pipeline should be fed from."""
+
+    def __init__(self, ctx: "Context", shape, dtype):
+        self._L = ctx._L
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._ptr = self._L.plslam_pinned_alloc(max(self.nbytes, 1))
+        if not self._ptr:
+            raise PlslamError("plslam_pinned_alloc failed")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self._ptr))[:self.nbytes] \
+            .view(dtype).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_ptr", None):
+            self.array = None
+            self._L.plslam_pinned_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MatchPipeline:
+    """plslam_match_pipeline: a batch shape fixed at creation, `depth` batches in flight (upload / kernels / download on
+    three streams).  problems: iterable of (d1_off, n1, d2_off, n2, nnr, mutual, out_off)."""
+
+    def __init__(self, ctx: "Context", arena_bytes: int, problems, out_entries: int, depth: int = 3):
+        self._L = ctx._L
+        problems = list(problems)
+        arr = (ArenaProblem * max(len(problems), 1))()
+        for i, (o1, n1, o2, n2, nnr, mutual, oo) in enumerate(problems):
+            arr[i] = ArenaProblem(int(o1), int(o2), int(n1), int(n2), float(nnr), int(bool(mutual)), int(oo))
+        h = C.c_void_p()
+        _check(self._L.plslam_match_pipeline_create(ctx.handle, int(arena_bytes), arr, len(problems), int(out_entries),
+                                                    int(depth), C.byref(h)), "plslam_match_pipeline_create")
+        self._h, self.nprob, self.arena_bytes, self.out_entries = h, len(problems), int(arena_bytes), int(out_entries)
+
+    def submit(self, arena: np.ndarray, out: np.ndarray, counts: np.ndarray | None = None):
+        assert arena.nbytes >= self.arena_bytes and out.dtype == np.int32 and out.size >= self.out_entries
+        assert arena.flags.c_contiguous and out.flags.c_contiguous
+        _check(self._L.plslam_match_pipeline_submit(self._h, arena.ctypes.data, out.ctypes.data,
+                                                    counts.ctypes.data if counts is not None else None),
+               "plslam_match_pipeline_submit")
+
+    def wait(self):
+        _check(self._L.plslam_match_pipeline_wait(self._h), "plslam_match_pipeline_wait")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.plslam_match_pipeline_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class LbaPlan:

@@ -1300,6 +1300,132 @@ int plslam_lbd_binarise(plslam_ctx* ctx, const float* lbd_f32, int32_t n, uint8_
     return PLSLAM_OK;
 }
 
+// ---- host-to-host pipeline ---------------------------------------------------------------------
+struct plslam_match_pipeline {
+    plslam_ctx* ctx = nullptr;
+    size_t arena_bytes = 0, out_entries = 0;
+    int32_t nprob = 0, depth = 0;
+    int64_t submitted = 0;
+    hipStream_t s_up = nullptr, s_down = nullptr;
+    struct Slot {
+        DevBuf arena, out, cnt;
+        plslam_match_plan plan;
+        hipEvent_t up = nullptr, run = nullptr, done = nullptr;   // upload finished / kernels finished / download finished
+        bool used = false;
+    };
+    std::vector<Slot> slots;
+};
+
+int plslam_match_pipeline_create(plslam_ctx* ctx, size_t arena_bytes, const plslam_arena_problem* probs, int32_t nprob,
+                                 size_t out_entries, int32_t depth, plslam_match_pipeline** out)
+{
+    PLSLAM_REQUIRE(ctx && out && probs && nprob > 0 && depth >= 2 && depth <= 8 && arena_bytes > 0, PLSLAM_EINVAL);
+    *out = nullptr;
+    for (int32_t i = 0; i < nprob; ++i) {
+        const plslam_arena_problem& q = probs[i];
+        PLSLAM_REQUIRE(q.n1 >= 0 && q.n2 >= 0 && q.d1_off >= 0 && q.d2_off >= 0 && q.out_off >= 0, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE((q.d1_off & 3) == 0 && (q.d2_off & 3) == 0, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE((size_t)q.d1_off + (size_t)q.n1 * 32 <= arena_bytes && (size_t)q.d2_off + (size_t)q.n2 * 32 <= arena_bytes,
+                       PLSLAM_EINVAL);
+        PLSLAM_REQUIRE((size_t)q.out_off + (size_t)q.n1 <= out_entries, PLSLAM_EINVAL);
+    }
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    plslam_match_pipeline* P = new (std::nothrow) plslam_match_pipeline();
+    PLSLAM_REQUIRE(P != nullptr, PLSLAM_ENOMEM);
+    P->ctx = ctx; P->arena_bytes = arena_bytes; P->out_entries = out_entries; P->nprob = nprob; P->depth = depth;
+    P->slots.resize((size_t)depth);
+    int r = PLSLAM_OK;
+    auto fail = [&](int code) { plslam_match_pipeline_destroy(P); return code; };
+    if (hipStreamCreateWithFlags(&P->s_up, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&P->s_down, hipStreamNonBlocking) != hipSuccess)
+        return fail(PLSLAM_EHIP);
+    std::vector<plslam_match_problem> mp((size_t)nprob);
+    for (auto& sl : P->slots) {
+        if ((r = sl.arena.reserve(arena_bytes + 16)) || (r = sl.out.reserve(out_entries * 4 + 16)) ||
+            (r = sl.cnt.reserve((size_t)nprob * 4)))
+            return fail(r);
+        if (hipEventCreateWithFlags(&sl.up, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sl.run, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess)
+            return fail(PLSLAM_EHIP);
+        for (int32_t i = 0; i < nprob; ++i) {
+            const plslam_arena_problem& q = probs[i];
+            plslam_match_problem& p = mp[(size_t)i];
+            p.d1 = sl.arena.as<uint8_t>() + q.d1_off; p.d2 = sl.arena.as<uint8_t>() + q.d2_off;
+            p.n1 = q.n1; p.n2 = q.n2; p.nnr = q.nnr; p.mutual = q.mutual ? 1 : 0;
+            p.matches_12 = sl.out.as<int32_t>() + q.out_off;
+            p.n_matches = sl.cnt.as<int32_t>() + i;
+        }
+        if ((r = plan_build(ctx, mp.data(), nprob, &sl.plan))) return fail(r);
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(PLSLAM_EHIP);      // the plans' table uploads
+    *out = P;
+    return PLSLAM_OK;
+}
+
+int plslam_match_pipeline_submit(plslam_match_pipeline* P, const void* arena_host, int32_t* out_host, int32_t* counts_host)
+{
+    PLSLAM_REQUIRE(P && arena_host && out_host, PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    plslam_match_pipeline::Slot& sl = P->slots[(size_t)(P->submitted % P->depth)];
+    // the slot's previous batch: its tables must have left the device buffers (its kernels have then finished too)
+    if (sl.used) PLSLAM_HIP_CHECK(hipEventSynchronize(sl.done));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(sl.arena.p, arena_host, P->arena_bytes, hipMemcpyHostToDevice, P->s_up));
+    PLSLAM_HIP_CHECK(hipEventRecord(sl.up, P->s_up));
+    PLSLAM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, sl.up, 0));
+    int r = plan_run(&sl.plan, ctx->stream);
+    if (r) return r;
+    PLSLAM_HIP_CHECK(hipEventRecord(sl.run, ctx->stream));
+    PLSLAM_HIP_CHECK(hipStreamWaitEvent(P->s_down, sl.run, 0));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(out_host, sl.out.p, P->out_entries * 4, hipMemcpyDeviceToHost, P->s_down));
+    if (counts_host)
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(counts_host, sl.cnt.p, (size_t)P->nprob * 4, hipMemcpyDeviceToHost, P->s_down));
+    PLSLAM_HIP_CHECK(hipEventRecord(sl.done, P->s_down));
+    sl.used = true;
+    ++P->submitted;
+    return PLSLAM_OK;
+}
+
+int plslam_match_pipeline_wait(plslam_match_pipeline* P)
+{
+    PLSLAM_REQUIRE(P != nullptr, PLSLAM_EINVAL);
+    DeviceGuard g(P->ctx->device);
+    for (auto& sl : P->slots)
+        if (sl.used) PLSLAM_HIP_CHECK(hipEventSynchronize(sl.done));
+    return PLSLAM_OK;
+}
+
+void plslam_match_pipeline_destroy(plslam_match_pipeline* P)
+{
+    if (!P) return;
+    DeviceGuard g(P->ctx->device);
+    (void)hipDeviceSynchronize();
+    for (auto& sl : P->slots) {
+        sl.arena.release(); sl.out.release(); sl.cnt.release();
+        sl.plan.free_all();
+        if (sl.up) (void)hipEventDestroy(sl.up);
+        if (sl.run) (void)hipEventDestroy(sl.run);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (P->s_up) (void)hipStreamDestroy(P->s_up);
+    if (P->s_down) (void)hipStreamDestroy(P->s_down);
+    delete P;
+}
+
+void* plslam_pinned_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    return hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) == hipSuccess ? p : nullptr;
+}
+
+void plslam_pinned_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 // ---- RCCL gather -----------------------------------------------------------------------------
 namespace {
 typedef int (*nccl_group_fn)(void);

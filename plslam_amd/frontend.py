@@ -164,6 +164,53 @@ class StereoBatchMatcher:
             p.close()
 
 
+class HostStereoPipeline:
+    """Host-to-host form of StereoBatchMatcher: descriptors born on the host (pinned memory), match tables wanted on the
+    host, through plslam_match_pipeline (upload of batch k+1 and download of batch k-1 under the kernels of batch k).
+    One batch = `B` stereo pairs; its arena holds every image's rows ONCE -- left rows of the B pairs and of the pair
+    before the first (the halo), right rows of the B pairs: the prev<->curr and L<->R problems of a pair point into the
+    same rows (109 kB per C2 pair)."""
+
+    def __init__(self, ctx, B: int, n_orb: int, n_lbd: int, nnr_p=0.75, nnr_l=0.75, mutual=True, depth: int = 3):
+        from .capi import MatchPipeline, PinnedArray
+        self.B, self.n_orb, self.n_lbd, self.depth = B, n_orb, n_lbd, depth
+        self.stride = table_stride(n_orb, n_lbd)
+        ro, rl = n_orb * 32, n_lbd * 32
+        self.off = {"orb_l": 0, "orb_r": (B + 1) * ro, "lbd_l": (2 * B + 1) * ro, "lbd_r": (2 * B + 1) * ro + (B + 1) * rl}
+        self.arena_bytes = (2 * B + 1) * (ro + rl)
+        sl = table_slices(n_orb, n_lbd)
+        probs = []
+        for i in range(B):
+            t = self.stride * i
+            probs.append((self.off["orb_l"] + ro * (i + 1), n_orb, self.off["orb_r"] + ro * i, n_orb, nnr_p, mutual, t + sl["orb_lr"].start))
+            probs.append((self.off["orb_l"] + ro * i, n_orb, self.off["orb_l"] + ro * (i + 1), n_orb, nnr_p, mutual, t + sl["orb_pc"].start))
+            probs.append((self.off["lbd_l"] + rl * (i + 1), n_lbd, self.off["lbd_r"] + rl * i, n_lbd, nnr_l, mutual, t + sl["lbd_lr"].start))
+            probs.append((self.off["lbd_l"] + rl * i, n_lbd, self.off["lbd_l"] + rl * (i + 1), n_lbd, nnr_l, mutual, t + sl["lbd_pc"].start))
+        self.pipe = MatchPipeline(ctx, self.arena_bytes, probs, B * self.stride, depth)
+        # `depth` + 1 pinned arena / table pairs: the host fills one while `depth` are in flight
+        self.arenas = [PinnedArray(ctx, (self.arena_bytes,), np.uint8) for _ in range(depth + 1)]
+        self.tables = [PinnedArray(ctx, (B, self.stride), np.int32) for _ in range(depth + 1)]
+
+    def fill(self, slot: int, stream_np: dict, first: int = 0):
+        """Copy pairs [first, first + B) of a synth.stereo_stream (halo at index `first`) into arena `slot`."""
+        a, B = self.arenas[slot].array, self.B
+        for key, n, cnt, lo in (("orb_l", self.n_orb, B + 1, first), ("orb_r", self.n_orb, B, first + 1),
+                                ("lbd_l", self.n_lbd, B + 1, first), ("lbd_r", self.n_lbd, B, first + 1)):
+            o = self.off[key]
+            a[o:o + cnt * n * 32] = stream_np[key][lo:lo + cnt].reshape(-1)
+
+    def submit(self, slot: int):
+        self.pipe.submit(self.arenas[slot].array, self.tables[slot].array)
+
+    def wait(self):
+        self.pipe.wait()
+
+    def close(self):
+        self.pipe.close()
+        for x in self.arenas + self.tables:
+            x.close()
+
+
 class TableGatherPipeline:
     """The backend-agnostic half of the N > 1 path: wire format, receive buffers and the per-buffer ordering of
     "compute into table b" -> "narrow" -> "gather to root" -> "table b may be overwritten".  It knows nothing about the

@@ -228,6 +228,30 @@ def test_column_split_of_few_large_problems(ctx, oracle, shapes, mutual):
             assert got[tag][2][k] == en, (tag, k)
 
 
+def test_host_to_host_pipeline(ctx, oracle):
+    """plslam_match_pipeline: batches from pinned host memory, three in flight (upload / kernels / download on their own
+    streams), problems that SHARE rows inside the arena (prev<->curr reuses the left image of the pair before).  Every
+    table of every batch -- different data per batch -- equals the oracle's; slots are re-used several times."""
+    B, n_orb, n_lbd = 6, 300, 70
+    s = synth.stereo_stream(5 * B, n_orb, n_lbd, seed=606)
+    hp = frontend.HostStereoPipeline(ctx, B, n_orb, n_lbd, nnr_p=0.8, nnr_l=0.9, mutual=True, depth=3)
+    sl = frontend.table_slices(n_orb, n_lbd)
+    got = {}
+    for k in range(5):                                   # host buffers k % 4; device slot k % 3.  Host buffer k % 4 is free:
+        slot = k % (hp.depth + 1)                        # the submit of batch k - 1 waited for batch k - 4's device slot
+        hp.fill(slot, s, first=k * B)
+        hp.submit(slot)
+    hp.wait()
+    for k in range(1, 5):                                # the last four batches are still in the host tables
+        got[k] = hp.tables[k % (hp.depth + 1)].array.copy()
+    for k, tab in got.items():
+        for i in range(B):
+            for name, d1, d2 in frontend.pair_problems(s["orb_l"], s["orb_r"], s["lbd_l"], s["lbd_r"], k * B + i):
+                em, _ = oracle.match(d1, d2, 0.8 if name.startswith("orb") else 0.9, True)
+                assert np.array_equal(tab[i, sl[name]], em), (k, i, name)
+    hp.close()
+
+
 def test_c5_dense_size_properties(ctx, oracle):
     """BASELINE config 5 size (4000 ORB): size-independent properties + oracle spot check."""
     r = _rng(55)
