@@ -257,7 +257,9 @@ void plslam_grid_plan_destroy(plslam_grid_plan* plan);
  * copies: 109 kB per C2 stereo pair instead of 218 kB) and receives one int32 output table.  `depth` (2..8) batches are
  * in flight: the upload of batch k+1 and the download of batch k-1 run on their own HIP streams under the kernels of
  * batch k.  submit() returns as soon as the work is enqueued (it first waits for the batch that used the slot `depth`
- * submits ago); the output of a submit is complete after the submit that re-uses its slot or after wait().  Host
+ * submits ago); the output of a submit is complete after the submit that re-uses its slot or after wait().  Tables in
+ * page-locked memory are written by the GPU itself behind the finalize (a copy-engine download would queue between two
+ * uploads and serialise the pipeline).  Host
  * buffers should come from plslam_pinned_alloc (pageable memory works but the runtime then stages every copy itself). */
 typedef struct plslam_arena_problem {
     int64_t d1_off, d2_off;      /* byte offsets of the two descriptor sets inside the arena (4-byte aligned)  */

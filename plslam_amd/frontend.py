@@ -321,7 +321,7 @@ class PipelinedGather:
 def verify_gathered_tables(full, world: int, B: int, n_orb: int, n_lbd: int, nnr_p: float, nnr_l: float, sample,
                            match_fn, seed=None, local_stream=None):
     """Root-side check of a gathered (world * B, stride) table: pairs `sample` of EVERY rank against `match_fn(d1, d2,
-    nnr) -> matches_12` (the oracle).  Rank r's inputs are regenerated from (seed, first_pair = r * B) -- the weak-scaling
+    nnr) -> matches_12` (the caller's checker).  Rank r's inputs are regenerated from (seed, first_pair = r * B) -- the weak-scaling
     shard rule of bench.py -- except rank 0's, which may be passed in.  Returns the list of mismatches (rank, pair,
     problem); empty = verified."""
     from . import synth

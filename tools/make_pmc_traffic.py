@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 counter summaries of one bench command (tools/pmc_passes.sh -> gpurun_out/<tag>_pmc_{a,fetch,write}.txt)
+into the entry of profiles/pmc_traffic.json that bench.py reports as roofline.traffic / valu_executed -- keyed by workload and
+kernel, and stamped with the hash of the kernel sources the passes were taken on (bench.py ignores an entry whose hash is not
+the tree's).   usage: make_pmc_traffic.py <tag> <n_orb> <n_lbd> <pairs> <kernel substring, e.g. k_scan_sym_mfma_g>"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import kernel_source_hash  # noqa: E402
+
+
+def counters(path, kernel):
+    out = {}
+    for line in open(path):
+        if kernel not in line:
+            continue
+        m = re.search(r"\s([A-Z][A-Z0-9_]+)\s+(\d+)\s+([0-9.]+)\s*$", line)
+        if m:
+            out[m.group(1)] = float(m.group(3))
+    return out
+
+
+def main():
+    tag, n_orb, n_lbd, pairs, kernel = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    g = os.path.join(ROOT, "gpurun_out")
+    a = counters(os.path.join(g, f"{tag}_pmc_a.txt"), kernel)
+    f = counters(os.path.join(g, f"{tag}_pmc_fetch.txt"), kernel)
+    w = counters(os.path.join(g, f"{tag}_pmc_write.txt"), kernel)
+    fetch_kib, write_kib = f["FETCH_SIZE"], w["WRITE_SIZE"]
+    entry = {
+        "kernel": kernel, "kernel_source_hash": kernel_source_hash(),
+        "fetch_size_kib_per_dispatch": fetch_kib, "write_size_kib_per_dispatch": write_kib, "fetch_correction": 2.0,
+        "traffic_bytes_per_launch": int(fetch_kib * 1024 * 2.0 + write_kib * 1024),
+        "sq_insts_valu_per_launch": int(a["SQ_INSTS_VALU"]), "sq_insts_mfma_per_launch": int(a.get("SQ_INSTS_MFMA", 0)),
+        "sq_valu_mfma_busy_cycles_per_launch": int(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)),
+        "sq_active_inst_valu_per_launch": int(a.get("SQ_ACTIVE_INST_VALU", 0)),
+        "sq_wave_cycles_per_launch": int(a.get("SQ_WAVE_CYCLES", 0)),
+        "measured_int_valu_ceiling_lane_ops_per_s": 38500000000000.0,
+        "measured_int_valu_ceiling_source": "profiles/r1_valu_microbench.txt, profiles/r2_valu_microbench2.txt: pk_min / perm / "
+                                            "and_or class ops at 4.1-4.5 cycles per wave64 instruction per SIMD",
+        "note": "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (wide vector loads); SQ_INSTS_VALU counts the "
+                "MFMAs too (bench.py subtracts SQ_INSTS_MFMA)",
+        "source": f"profiles/{tag}_pmc_a.txt, profiles/{tag}_pmc_fetch.txt, profiles/{tag}_pmc_write.txt (rocprofv3 --pmc, "
+                  "separate passes, python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-secondary)"}
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        doc = json.load(open(path))
+    except OSError:
+        doc = {"entries": {}}
+    doc.setdefault("entries", {})[f"{n_orb}+{n_lbd}:pairs{pairs}:{kernel}"] = entry
+    doc["key_format"] = "<n_orb>+<n_lbd>:pairs<pairs per GPU per step>:<scan kernel>; entries carry kernel_source_hash"
+    json.dump(doc, open(path, "w"), indent=1)
+    print(json.dumps(entry, indent=1))
+
+
+if __name__ == "__main__":
+    main()
