@@ -55,14 +55,17 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
+SCAN_KERNEL_SOURCES = ("common.hpp", "hamming.hip", "hamming_mfma.hip", "hamming_mfma_g.hip")
+
+
 def kernel_source_hash() -> str:
-    """Identifies the kernel sources a PMC pass was taken on (profiles/pmc_traffic.json is keyed by it)."""
+    """Identifies the sources of the scan kernels a PMC pass was taken on (profiles/pmc_traffic.json is keyed by it): the
+    files that define K1a-K1f and their shared declarations."""
     h = hashlib.sha256()
     d = os.path.join(_ROOT, "plslam_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".hpp")):
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+    for name in SCAN_KERNEL_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 
