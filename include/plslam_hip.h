@@ -120,6 +120,11 @@ int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const 
 int plslam_match(plslam_ctx* ctx, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2,
                  float nnr, int mutual, int32_t* matches_12, int32_t* n_matches);
 
+/* StVO::match on a matches_12 that already holds n1 entries (in: the earlier table, out: the result); see
+ * plslam_match_problem.keep_prior.  The drop-in header calls this when the caller's vector is not empty. */
+int plslam_match_prior(plslam_ctx* ctx, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2,
+                       float nnr, int mutual, int32_t* matches_12, int32_t* n_matches);
+
 /* B independent match() problems in one launch.  off1/off2 have B+1 row offsets into d1/d2;
  * matches_12 has off1[B] entries (problem b writes rows off1[b]..off1[b+1]); n_matches has B
  * entries (may be NULL).  This is the per-frame work of StereoFrame::extractStereoFeatures +
@@ -139,6 +144,13 @@ typedef struct plslam_match_problem {
     int32_t mutual;
     int32_t* matches_12;
     int32_t* n_matches;
+    /* 0: every row is written (-1 where nothing is accepted) -- StVO::match on a fresh vector.
+     * 1: matches_12 already holds n1 entries and rows the ratio test rejects KEEP theirs; the consistency loop then
+     *    runs over every entry >= 0 and n_matches = (rows accepted) - (entries cleared).  This is StVO::match on the
+     *    vector matchGrid filled, src/mapHandler.cpp:271+277, :418+424, :591+597, :706+712 ([RECALL] stvo-pl matchNNR
+     *    opens with matches_12.resize(desc1.rows, -1)). */
+    int32_t keep_prior;
+    int32_t reserved;
 } plslam_match_problem;
 
 typedef struct plslam_plan_info {

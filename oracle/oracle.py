@@ -63,6 +63,8 @@ def _bind(lib: C.CDLL) -> C.CDLL:
     lib.plo_match_nnr.restype = C.c_int32
     lib.plo_match.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_float, C.c_int, C.c_void_p]
     lib.plo_match.restype = C.c_int32
+    lib.plo_match_prior.argtypes = lib.plo_match.argtypes
+    lib.plo_match_prior.restype = C.c_int32
     lib.plo_match_batched.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_int, C.c_void_p, C.c_void_p]
     lib.plo_match_batched.restype = None
     lib.plo_match_batched_mt.argtypes = [C.c_void_p] * 4 + [C.c_int32, C.c_float, C.c_int, C.c_void_p,
@@ -411,6 +413,16 @@ def match(d1, d2, nnr, mutual=True, L=None):
     d1, d2 = _desc(d1), _desc(d2)
     m12 = np.empty(d1.shape[0], np.int32)
     n = L.plo_match(_p(d1), d1.shape[0], _p(d2), d2.shape[0], float(nnr), int(bool(mutual)), _p(m12))
+    return m12, int(n)
+
+
+def match_prior(d1, d2, nnr, mutual, prior, L=None):
+    """match() on a matches_12 that already holds entries (the fall-back after matchGrid): plo_match_prior."""
+    L = L or lib()
+    d1, d2 = _desc(d1), _desc(d2)
+    m12 = np.array(prior, np.int32, copy=True)
+    assert m12.shape == (d1.shape[0],)
+    n = L.plo_match_prior(_p(d1), d1.shape[0], _p(d2), d2.shape[0], float(nnr), int(bool(mutual)), _p(m12))
     return m12, int(n)
 
 

@@ -112,14 +112,18 @@ void plo_knn2(const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, int32_
 /* ------------------------------------------------------------------------------------ */
 /* stvo-pl matchNNR / match                                                              */
 /* ------------------------------------------------------------------------------------ */
-int32_t plo_match_nnr(const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, float nnr,
-                      int32_t* m12)
+/* keep_prior: [RECALL] stvo-pl matchNNR opens with `matches_12.resize(desc1.rows, -1)` -- a vector that already holds
+ * desc1.rows entries (the matchGrid result of src/mapHandler.cpp:271 handed on to match() at :277, likewise :418/:424,
+ * :591/:597, :706/:712) KEEPS them, and only rows that pass the ratio test are overwritten.  A fresh vector gives the
+ * all -1 start, which is keep_prior = 0. */
+static int32_t match_nnr_impl(const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, float nnr, int32_t* m12,
+                              int keep_prior)
 {
     int32_t matches = 0;
     for (int32_t i = 0; i < nq; ++i) {
         int32_t idx[2], dist[2];
         plo_knn2(q + (size_t)i * PLO_DESC_BYTES, 1, t, nt, idx, dist);
-        m12[i] = -1;
+        if (!keep_prior) m12[i] = -1;
         if (idx[1] < 0) continue;       /* nt < 2: defined as "no match" */
         const volatile float d0 = (float)dist[0];
         const volatile float d1n = (float)dist[1] * nnr; /* one fp32 multiply, then compare */
@@ -131,22 +135,43 @@ int32_t plo_match_nnr(const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt
     return matches;
 }
 
-int32_t plo_match(const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
-                  int mutual, int32_t* m12)
+int32_t plo_match_nnr(const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt, float nnr,
+                      int32_t* m12)
 {
-    int32_t matches = plo_match_nnr(d1, n1, d2, n2, nnr, m12);
+    return match_nnr_impl(q, nq, t, nt, nnr, m12, 0);
+}
+
+static int32_t match_impl(const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
+                          int mutual, int32_t* m12, int keep_prior)
+{
+    int32_t matches = match_nnr_impl(d1, n1, d2, n2, nnr, m12, keep_prior);
     if (!mutual) return matches;
     int32_t* m21 = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n2 > 0 ? n2 : 1));
     plo_match_nnr(d2, n2, d1, n1, nnr, m21);
+    /* the consistency loop runs over EVERY entry >= 0, kept ones included: a kept entry that fails it is cleared and
+     * decrements a count it never incremented (the reference's arithmetic; an entry >= n2 would be an out-of-bounds
+     * read upstream and is defined here as "fails") */
     for (int32_t i1 = 0; i1 < n1; ++i1) {
         const int32_t i2 = m12[i1];
-        if (i2 >= 0 && m21[i2] != i1) {
+        if (i2 >= 0 && (i2 >= n2 || m21[i2] != i1)) {
             m12[i1] = -1;
             --matches;
         }
     }
     free(m21);
     return matches;
+}
+
+int32_t plo_match(const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
+                  int mutual, int32_t* m12)
+{
+    return match_impl(d1, n1, d2, n2, nnr, mutual, m12, 0);
+}
+
+int32_t plo_match_prior(const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2, float nnr,
+                        int mutual, int32_t* m12)
+{
+    return match_impl(d1, n1, d2, n2, nnr, mutual, m12, 1);
 }
 
 void plo_match_batched(const uint8_t* d1, const int32_t* off1, const uint8_t* d2,
@@ -769,7 +794,9 @@ static int32_t kf2kf_driver(int lines, const plo_cam* K, const double DT[16], co
         free(items); free(dir2); free(cs);
     }
     if (n_curr > min_matches && n_prev > min_matches && matches < min_matches) {    /* :274-278 / :421-425 */
-        matches = plo_match(desc_prev, n_prev, desc_curr, n_curr, nnr, mutual, m12);
+        /* the vector matchGrid filled is handed on: its entries survive where the ratio test rejects (plo_match_prior) */
+        matches = (fm && fm->enabled) ? plo_match_prior(desc_prev, n_prev, desc_curr, n_curr, nnr, mutual, m12)
+                                      : plo_match(desc_prev, n_prev, desc_curr, n_curr, nnr, mutual, m12);
         if (used_match) *used_match = 1;
     }
     return matches;
@@ -839,7 +866,8 @@ static int32_t map2kf_driver(int lines, const plo_cam* K, const double Twf[16], 
             free(items); free(dir2); free(cs);
         }
         if (nq > min_matches && matches < min_matches) {                               /* :594-598 / :709-713 */
-            matches = plo_match(Q, nq, T, nt, nnr, mutual, m12);
+            matches = n_m12 ? plo_match_prior(Q, nq, T, nt, nnr, mutual, m12)     /* matchGrid's entries survive */
+                            : plo_match(Q, nq, T, nt, nnr, mutual, m12);
             n_m12 = nq;
             if (used_match) *used_match = 1;
         }

@@ -62,6 +62,11 @@ int32_t plo_match_nnr(const uint8_t* q, int32_t nq, const uint8_t* t, int32_t nt
 /* mutual!=0: run both directions and keep i1->i2 iff m21[i2]==i1 (best_lr_matches). */
 int32_t plo_match(const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2,
                   float nnr, int mutual, int32_t* m12);
+/* the same on a matches_12 that already holds n1 entries: rows the ratio test rejects KEEP theirs ([RECALL] stvo-pl
+ * matchNNR: `matches_12.resize(desc1.rows, -1)`), the mutual loop then runs over every entry >= 0 and the returned count
+ * is (rows accepted) - (entries cleared) -- the fall-back of src/mapHandler.cpp:274-278, :421-425, :594-598, :709-713 */
+int32_t plo_match_prior(const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2,
+                        float nnr, int mutual, int32_t* m12);
 /* B independent problems described by row offsets (B+1 entries each). */
 void plo_match_batched(const uint8_t* d1, const int32_t* off1, const uint8_t* d2,
                        const int32_t* off2, int32_t B, float nnr, int mutual,

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "plslam_strerror", "plslam_last_error", "plslam_abi_version",
     "plslam_ctx_create", "plslam_ctx_destroy", "plslam_ctx_set_option", "plslam_ctx_get_option",
     "plslam_ctx_device_info",
-    "plslam_knn2_hamming256", "plslam_match", "plslam_match_batched",
+    "plslam_knn2_hamming256", "plslam_match", "plslam_match_prior", "plslam_match_batched",
     "plslam_match_plan_create", "plslam_match_plan_run", "plslam_match_plan_set_profiling",
     "plslam_match_plan_elapsed", "plslam_match_plan_info", "plslam_match_plan_dump", "plslam_match_plan_destroy",
     "plslam_lba_point_rows", "plslam_lba_line_rows", "plslam_lba_point_rows_dev",
@@ -61,7 +61,7 @@ class MatchProblem(C.Structure):
     """plslam_match_problem (device pointers)"""
     _fields_ = [("d1", C.c_void_p), ("d2", C.c_void_p), ("n1", C.c_int32), ("n2", C.c_int32),
                 ("nnr", C.c_float), ("mutual", C.c_int32), ("matches_12", C.c_void_p),
-                ("n_matches", C.c_void_p)]
+                ("n_matches", C.c_void_p), ("keep_prior", C.c_int32), ("reserved", C.c_int32)]
 
 
 class StereoGateProblem(C.Structure):
@@ -337,6 +337,18 @@ class Context:
         n = C.c_int32()
         _check(self._L.plslam_match(self._h, _p(d1), d1.shape[0], _p(d2), d2.shape[0], float(nnr),
                                     int(bool(mutual)), _p(m12), C.byref(n)), "plslam_match")
+        return m12, n.value
+
+    def match_prior(self, d1, d2, nnr: float, mutual: bool, prior):
+        """StVO::match on a matches_12 that already holds entries (the fall-back after matchGrid) -> (matches_12, n)."""
+        d1 = _arr(d1, np.uint8, (-1, 32))
+        d2 = _arr(d2, np.uint8, (-1, 32))
+        m12 = np.array(prior, np.int32, copy=True)
+        if m12.shape != (d1.shape[0],):
+            raise ValueError("prior must hold one entry per row of d1")
+        n = C.c_int32()
+        _check(self._L.plslam_match_prior(self._h, _p(d1), d1.shape[0], _p(d2), d2.shape[0], float(nnr),
+                                          int(bool(mutual)), _p(m12), C.byref(n)), "plslam_match_prior")
         return m12, n.value
 
     def match_grid(self, centres, d1, cell_start, cell_items, cols, rows, d2, window, nnr, mutual=True, dir1=None,

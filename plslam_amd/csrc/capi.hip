@@ -188,6 +188,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             if (probs[i].n1 <= 0 || probs[i].n2 <= 0) continue;
             ++nmf;
             if (probs[i].mutual && probs[i].n2 > PLSLAM_K1F_FUSED_MAX_N2) fits = false;
+            if (probs[i].keep_prior) fits = false;          // the in-kernel finalize always writes every row
         }
         (void)nmf;
         P->fused = k1f && fits && ctx->fuse == 2 && !P->col_split;
@@ -302,6 +303,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         const plslam_match_problem& p = probs[i];
         ProblemDesc pd{};
         pd.n1 = p.n1; pd.n2 = p.n2; pd.nnr = p.nnr; pd.mutual = p.mutual ? 1 : 0;
+        pd.keep_prior = p.keep_prior ? 1 : 0;
         pd.matches_12 = p.matches_12;
         pd.n_matches = d_counts + i;
         user_counts[i] = p.n_matches;
@@ -953,6 +955,39 @@ int plslam_match(plslam_ctx* ctx, const uint8_t* d1, int32_t n1, const uint8_t* 
     return r;
 }
 
+int plslam_match_prior(plslam_ctx* ctx, const uint8_t* d1, int32_t n1, const uint8_t* d2, int32_t n2,
+                       float nnr, int mutual, int32_t* matches_12, int32_t* n_matches)
+{
+    PLSLAM_REQUIRE(ctx != nullptr && n1 >= 0 && n2 >= 0, PLSLAM_EINVAL);
+    if (n_matches) *n_matches = 0;
+    if (n1 == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(d1 && matches_12 && (n2 == 0 || d2), PLSLAM_EINVAL);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard g(ctx->device);
+    hipStream_t s = ctx->stream;
+    int r;
+    if ((r = ctx->in_a.reserve((size_t)n1 * 32 + 16))) return r;
+    if ((r = ctx->in_b.reserve((size_t)n2 * 32 + 16))) return r;
+    if ((r = ctx->out_a.reserve((size_t)n1 * 4 + 16))) return r;
+    if ((r = ctx->out_b.reserve(16))) return r;
+    StreamSyncOnError guard(s);
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_a.p, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
+    if (n2) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_b.p, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->out_a.p, matches_12, (size_t)n1 * 4, hipMemcpyHostToDevice, s));
+    plslam_match_problem p{};
+    p.d1 = ctx->in_a.as<uint8_t>(); p.d2 = ctx->in_b.as<uint8_t>(); p.n1 = n1; p.n2 = n2; p.nnr = nnr;
+    p.mutual = mutual ? 1 : 0; p.matches_12 = ctx->out_a.as<int32_t>(); p.n_matches = ctx->out_b.as<int32_t>();
+    p.keep_prior = 1;
+    if ((r = plslam::match_problems_on_ctx_stream(ctx, &p, 1))) return r;
+    int32_t n = 0;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(matches_12, ctx->out_a.p, (size_t)n1 * 4, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(&n, ctx->out_b.p, 4, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    guard.dismiss();
+    if (n_matches) *n_matches = n;
+    return PLSLAM_OK;
+}
+
 int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const uint8_t* t,
                            int32_t nt, int32_t* idx, int32_t* dist)
 {
@@ -963,6 +998,7 @@ int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const 
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     int r;
+    StreamSyncOnError sg(ctx->stream);              // sd / blocks / striped below are locals the copies read
     const bool small = (nq + 63) / 64 < ctx->prop.multiProcessorCount * 4;
     // large query sets (or a forced variant): the directed form of K1e, distances from the matrix cores
     if (nt > 0 && (ctx->scan_variant == PLSLAM_SCAN_MFMA || (ctx->scan_variant == PLSLAM_SCAN_AUTO && !small))) {

@@ -66,6 +66,20 @@ struct DeviceGuard {  // every entry point runs on the context's device
     }
 };
 
+// Host-pointer entry points enqueue copies from stack / local objects and work on the context's shared scratch buffers:
+// whatever way they return (PLSLAM_HIP_CHECK, `return rc`), nothing may still be in flight when the locals die and
+// ctx->mu is released.  On the success path the stream is already idle and the extra synchronise costs a microsecond.
+struct StreamSyncOnError {
+    hipStream_t s;
+    bool armed = true;
+    explicit StreamSyncOnError(hipStream_t st) : s(st) {}
+    void dismiss() { armed = false; }
+    ~StreamSyncOnError()
+    {
+        if (armed) (void)hipStreamSynchronize(s);
+    }
+};
+
 // carve several arrays out of one scratch buffer (256-byte aligned slices)
 struct Carver {
     size_t off = 0;
@@ -120,6 +134,8 @@ struct ProblemDesc {    // one StVO::match problem = scan12 (+ scan21 when mutua
     const uint32_t* split_tmp;
     uint32_t* keys12_out;
     int32_t nsplit, cstep;
+    // plslam_match_problem.keep_prior: rows the ratio test rejects keep what matches_12 holds (stvo-pl's resize())
+    int32_t keep_prior, pad;
 };
 
 struct BlockDesc {      // one workgroup's slice of a scan / problem

@@ -549,6 +549,7 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
     const ProblemDesc p = probs[bd.item];
     const int i1 = bd.row0 + (int)threadIdx.x;
     int m = -1;
+    bool accepted = false, cleared = false;
     if (i1 < p.n1) {
         uint2 k;
         if (p.nsplit > 1) {
@@ -567,15 +568,26 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
             k = reinterpret_cast<const uint2*>(p.keys12)[i1];
         }
         m = ratio_pick(k.x, k.y, p.nnr);
+        accepted = m >= 0;
+        // [RECALL] stvo-pl matchNNR resize()s the table it is given: an entry already there survives a rejected row, then
+        // goes through the consistency loop like any other (an entry outside [0, n2) -- an out-of-bounds read upstream --
+        // is defined as failing it)
+        if (!accepted && p.keep_prior) m = p.matches_12[i1];
         if (m >= 0 && p.mutual) {
-            const uint2 kb = reinterpret_cast<const uint2*>(p.keys21)[m];
-            if (ratio_pick(kb.x, kb.y, p.nnr) != i1) m = -1;
+            bool ok = m < p.n2;
+            if (ok) {
+                const uint2 kb = reinterpret_cast<const uint2*>(p.keys21)[m];
+                ok = ratio_pick(kb.x, kb.y, p.nnr) == i1;
+            }
+            if (!ok) { m = -1; cleared = true; }
         }
         p.matches_12[i1] = m;
     }
     if (p.n_matches) {
-        const unsigned long long b = __ballot(m >= 0);
-        if ((threadIdx.x & 63) == 0 && b) atomicAdd(p.n_matches, (int)__popcll(b));
+        // the reference's arithmetic: +1 per row the ratio test accepts, -1 per entry the consistency loop clears (equal
+        // to the number of entries >= 0 unless kept entries are involved)
+        const int delta = (int)__popcll(__ballot(accepted)) - (int)__popcll(__ballot(cleared));
+        if ((threadIdx.x & 63) == 0 && delta) atomicAdd(p.n_matches, delta);
     }
 }
 

@@ -92,6 +92,7 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
               const plslam_fast_matching* fm, int mutual, int32_t* d_m12, int32_t* matches)
 {
     hipStream_t s = ctx->stream;
+    StreamSyncOnError sg(s);                        // cen / cs / items / dir2 / hdesc are locals the copies read
     int rc;
     const int nc = lines ? 2 : 1;
     const int32_t cols = fm->grid_cols, rows = fm->grid_rows;
@@ -189,6 +190,7 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     hipStream_t s = ctx->stream;
+    StreamSyncOnError sg(s);
     Carve c;
     const size_t oX = c.take((size_t)n_prev * xw * 8), oQ = c.take((size_t)n_prev * 32), oT = c.take((size_t)n_curr * 32),
                  oM = c.take((size_t)n_prev * 4);
@@ -215,6 +217,7 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
         plslam_match_problem p{};
         p.d1 = (uint8_t*)(d + oQ); p.n1 = n_prev; p.d2 = (uint8_t*)(d + oT); p.n2 = n_curr;
         p.nnr = nnr; p.mutual = mutual ? 1 : 0; p.matches_12 = (int32_t*)(d + oM); p.n_matches = d_cnt;
+        p.keep_prior = have ? 1 : 0;             // the vector matchGrid filled is handed on (:271 -> :277, :418 -> :424)
         if ((rc = match_problems_on_ctx_stream(ctx, &p, 1))) return rc;
         have = true;
         if (used_match) *used_match = 1;
@@ -257,6 +260,7 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard dg_(ctx->device);    // every entry point runs on the context's device, whatever the calling thread's current one
     hipStream_t s = ctx->stream;
+    StreamSyncOnError sg(s);
     // ---- stage the map and the keyframe on the device, project + visibility test ------------
     Carve c;
     const size_t oLM = c.take((size_t)n_map * lw * 8), oMD = c.take((size_t)n_map * 32),
@@ -304,6 +308,7 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
         plslam_match_problem p{};
         p.d1 = (uint8_t*)(d + oQ); p.n1 = nq; p.d2 = (uint8_t*)(d + oT); p.n2 = nt;
         p.nnr = nnr; p.mutual = mutual ? 1 : 0; p.matches_12 = (int32_t*)(d + oM); p.n_matches = nullptr;
+        p.keep_prior = have_m12 ? 1 : 0;         // the vector matchGrid filled is handed on (:591 -> :597, :706 -> :712)
         if ((rc = match_problems_on_ctx_stream(ctx, &p, 1))) return rc;   // :597 / :712
         have_m12 = true;
         if (used_match) *used_match = 1;

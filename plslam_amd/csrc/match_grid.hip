@@ -636,7 +636,9 @@ static size_t grid_prob_scratch(const plslam_grid_problem& q)
     return (grid_scratch_words(q.n1, q.n2, (int64_t)q.grid_cols * q.grid_rows, q.pair_capacity) + 63) & ~size_t(63);
 }
 
-static int grid_check_problem(const plslam_grid_problem& q)
+// device_rows: d1 / d2 are the pointers the kernels will read (16-byte vector loads); host rows are staged into aligned
+// device memory first and may sit anywhere
+static int grid_check_problem(const plslam_grid_problem& q, bool device_rows = true)
 {
     PLSLAM_REQUIRE(q.n1 >= 0 && q.n2 >= 0 && q.n_centres >= 1 && q.grid_cols >= 1 && q.grid_rows >= 1,
                    PLSLAM_EINVAL);
@@ -648,7 +650,7 @@ static int grid_check_problem(const plslam_grid_problem& q)
     PLSLAM_REQUIRE(q.cell_start != nullptr && (q.n_items == 0 || q.cell_items != nullptr), PLSLAM_EINVAL);
     PLSLAM_REQUIRE(q.n1 == 0 || (q.d1 && q.centres1 && q.matches_12), PLSLAM_EINVAL);
     PLSLAM_REQUIRE(q.n2 == 0 || q.d2, PLSLAM_EINVAL);
-    PLSLAM_REQUIRE(((uintptr_t)q.d1 & 15) == 0 && ((uintptr_t)q.d2 & 15) == 0, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(!device_rows || (((uintptr_t)q.d1 & 15) == 0 && ((uintptr_t)q.d2 & 15) == 0), PLSLAM_EINVAL);
     PLSLAM_REQUIRE((q.dir1 == nullptr) == (q.dir2 == nullptr) || q.n1 == 0 || q.n2 == 0, PLSLAM_EINVAL);
     return PLSLAM_OK;
 }
@@ -780,13 +782,15 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     q.sim_th = sim_th; q.nnr = nnr; q.mutual = mutual;
     q.matches_12 = matches_12;
     int rc;
-    if ((rc = grid_check_problem(q))) return rc;
-    // the grid is host data here: validate it and count the (row, candidate) pairs exactly
+    if ((rc = grid_check_problem(q, false))) return rc;
+    // the grid is host data here: validate it (offsets monotonic, every entry a row of desc2) and count the
+    // (row, candidate) pairs exactly
     const int64_t ncell = (int64_t)grid_cols * grid_rows;
     PLSLAM_REQUIRE(cell_start[0] == 0, PLSLAM_EINVAL);
     for (int64_t c = 0; c < ncell; ++c) PLSLAM_REQUIRE(cell_start[c + 1] >= cell_start[c], PLSLAM_EINVAL);
     const int32_t n_items = cell_start[ncell];
     PLSLAM_REQUIRE(n_items == 0 || cell_items, PLSLAM_EINVAL);
+    for (int32_t k = 0; k < n_items; ++k) PLSLAM_REQUIRE(cell_items[k] >= 0 && cell_items[k] < n2, PLSLAM_EINVAL);
     q.n_items = n_items;
     const int64_t pairs = grid_store_capacity_host(centres1, n1, n_centres, cell_start, grid_cols, grid_rows, window,
                                                    mutual);
@@ -831,8 +835,10 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     dq.dir2 = dirs ? (const double*)(d + oD2) : nullptr;
     dq.matches_12 = (int32_t*)(dout + oM);
     dq.n_matches = (int32_t*)(dout + oN);
+    if ((rc = grid_check_problem(dq))) return rc;                 // what the kernel reads: the staged, aligned rows
     grid_fill_desc(dq, ctx->misc_a.as<uint32_t>(), (int32_t*)(dout + oN) + 1, (GridDesc*)(h + oT));
     hipStream_t s = ctx->stream;
+    StreamSyncOnError sg(s);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, ci.off, hipMemcpyHostToDevice, s));
     PLSLAM_HIP_CHECK(hipMemsetAsync(dout + oN, 0, 8, s));
     const int group = grid_group(n1, n2, ncell, n_items);

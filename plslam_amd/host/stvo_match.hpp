@@ -20,6 +20,7 @@
 
 #include <cmath>
 #include <list>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -50,9 +51,35 @@ inline bool& bestLRMatches()
 }
 
 namespace detail {
+// One context (stream + scratch buffers) per calling thread, as the reference's threads each own their cv::BFMatcher.
+// Contexts live in a process-wide pool: a thread that ends hands its context back (no HIP call runs in a thread_local
+// destructor -- for the main thread that would be during static destruction, possibly after the HIP runtime is gone),
+// the next new thread re-uses it (a short-lived worker does not pay a context create + destroy).  Nothing is destroyed
+// at process exit; StVO::shutdown() does it explicitly.
+struct CtxPool {
+    std::mutex mu;
+    std::vector<std::pair<int, plslam_ctx*>> idle;   // (device, context) handed back by finished threads
+    std::vector<plslam_ctx*> all;
+    unsigned generation = 0;                         // bumped by shutdown(): handles cached by threads are stale then
+};
+inline CtxPool& pool()
+{
+    static CtxPool* p = new CtxPool();               // deliberately never deleted
+    return *p;
+}
 struct ThreadCtx {
     plslam_ctx* ctx = nullptr;
-    ~ThreadCtx() { if (ctx) plslam_ctx_destroy(ctx); }
+    int device = -1;
+    unsigned generation = 0;
+    void release()
+    {
+        if (!ctx) return;
+        CtxPool& P = pool();
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (generation == P.generation) P.idle.emplace_back(device, ctx);
+        ctx = nullptr;
+    }
+    ~ThreadCtx() { release(); }
 };
 inline int& deviceOrdinal()
 {
@@ -62,11 +89,35 @@ inline int& deviceOrdinal()
 inline plslam_ctx* ctx()
 {
     static thread_local ThreadCtx t;
+    CtxPool& P = pool();
+    const int want = deviceOrdinal();
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (t.ctx && t.generation != P.generation) t.ctx = nullptr;      // destroyed by shutdown()
+    }
+    if (t.ctx && t.device != want) t.release();                          // setDevice() since the last call
     if (!t.ctx) {
-        const int rc = plslam_ctx_create(deviceOrdinal(), &t.ctx);
-        if (rc != PLSLAM_OK)
-            throw std::runtime_error(std::string("[StVO::match] no MI355X context: ") + plslam_strerror(rc) +
-                                     " (" + plslam_last_error() + ")");
+        {
+            std::lock_guard<std::mutex> lk(P.mu);
+            for (size_t k = 0; k < P.idle.size(); ++k)
+                if (P.idle[k].first == want) {
+                    t.ctx = P.idle[k].second;
+                    P.idle.erase(P.idle.begin() + (long)k);
+                    break;
+                }
+            t.generation = P.generation;
+        }
+        if (!t.ctx) {
+            const int rc = plslam_ctx_create(want, &t.ctx);
+            if (rc != PLSLAM_OK) {
+                t.ctx = nullptr;
+                throw std::runtime_error(std::string("[StVO::match] no MI355X context: ") + plslam_strerror(rc) +
+                                         " (" + plslam_last_error() + ")");
+            }
+            std::lock_guard<std::mutex> lk(P.mu);
+            P.all.push_back(t.ctx);
+        }
+        t.device = want;
     }
     return t.ctx;
 }
@@ -85,33 +136,57 @@ inline void check(int rc, const char* fn)
 }
 }  // namespace detail
 
-// select the HIP device used by the calling process (before the first match())
+// select the HIP device used by the calling process (takes effect on each thread's next call)
 inline void setDevice(int ordinal) { detail::deviceOrdinal() = ordinal; }
+
+// Destroys every context the drop-in created (streams, device and page-locked buffers).  Call it when no thread is
+// inside a StVO:: function -- e.g. at the end of main(), before static destruction; without it the contexts are simply
+// left to process exit.  A later StVO:: call creates fresh ones.
+inline void shutdown()
+{
+    detail::CtxPool& P = detail::pool();
+    std::vector<plslam_ctx*> victims;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        victims.swap(P.all);
+        P.idle.clear();
+        ++P.generation;
+    }
+    for (plslam_ctx* c : victims) plslam_ctx_destroy(c);
+}
+
+namespace detail {
+// [RECALL] stvo-pl matchNNR opens with `matches_12.resize(desc1.rows, -1)`: a vector that already holds entries keeps
+// them on rows the ratio test rejects (the fall-back after matchGrid, src/mapHandler.cpp:271+277, :418+424, :591+597,
+// :706+712).  A vector without any entry >= 0 takes the plain path.
+template <class Mat1, class Mat2>
+inline int match_impl(const Mat1& desc1, const Mat2& desc2, float nnr, int mutual, std::vector<int>& matches_12,
+                      const char* fn)
+{
+    static_assert(sizeof(int) == sizeof(int32_t), "matches_12 is std::vector<int> in the reference");
+    matches_12.resize((size_t)desc1.rows, -1);
+    bool prior = false;
+    for (int v : matches_12) prior = prior || v >= 0;
+    int32_t n = 0;
+    check((prior ? plslam_match_prior : plslam_match)(ctx(), rows_of(desc1, "desc1"), desc1.rows, rows_of(desc2, "desc2"),
+                                                      desc2.rows, nnr, mutual, matches_12.data(), &n),
+          fn);
+    return n;
+}
+}  // namespace detail
 
 // stvo-pl matchNNR: one directed kNN-2 + ratio test
 template <class Mat1, class Mat2>
 inline int matchNNR(const Mat1& desc1, const Mat2& desc2, float nnr, std::vector<int>& matches_12)
 {
-    matches_12.assign((size_t)desc1.rows, -1);
-    int32_t n = 0;
-    detail::check(plslam_match(detail::ctx(), detail::rows_of(desc1, "desc1"), desc1.rows,
-                               detail::rows_of(desc2, "desc2"), desc2.rows, nnr, 0, matches_12.data(), &n),
-                  "StVO::matchNNR");
-    return n;
+    return detail::match_impl(desc1, desc2, nnr, 0, matches_12, "StVO::matchNNR");
 }
 
 // stvo-pl match: ratio test both ways + mutual consistency when bestLRMatches()
 template <class Mat1, class Mat2>
 inline int match(const Mat1& desc1, const Mat2& desc2, float nnr, std::vector<int>& matches_12)
 {
-    static_assert(sizeof(int) == sizeof(int32_t), "matches_12 is std::vector<int> in the reference");
-    matches_12.assign((size_t)desc1.rows, -1);
-    int32_t n = 0;
-    detail::check(plslam_match(detail::ctx(), detail::rows_of(desc1, "desc1"), desc1.rows,
-                               detail::rows_of(desc2, "desc2"), desc2.rows, nnr, bestLRMatches() ? 1 : 0,
-                               matches_12.data(), &n),
-                  "StVO::match");
-    return n;
+    return detail::match_impl(desc1, desc2, nnr, bestLRMatches() ? 1 : 0, matches_12, "StVO::match");
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -62,6 +62,17 @@ static void match_case(int n1, int n2, float nnr, bool mutual, unsigned seed)
         ++cnt;
     }
     EXPECT(cnt == n);
+    // the SAME vector handed to match() again, holding an earlier table (what mapHandler.cpp:271+277 does with
+    // matchGrid's result): rows the ratio test rejects keep their entry, stvo-pl's resize() semantics
+    if (n1 > 0 && n2 > 0) {
+        std::vector<int> again((size_t)n1);
+        std::vector<int32_t> ref2((size_t)n1);
+        for (int i = 0; i < n1; ++i) ref2[(size_t)i] = again[(size_t)i] = (i % 3 == 0) ? (int)(g() % (unsigned)n2) : -1;
+        const int n_again = StVO::match(d1, d2, nnr, again);
+        const int nref2 = plo_match_prior(a.data(), n1, b.data(), n2, nnr, mutual ? 1 : 0, ref2.data());
+        EXPECT(n_again == nref2);
+        for (int i = 0; i < n1; ++i) EXPECT(again[(size_t)i] == ref2[(size_t)i]);
+    }
 }
 
 // StVO::matchGrid used exactly as MapHandler::matchKF2KFPoints / matchKF2KFLines do (src/mapHandler.cpp:252-271,
@@ -187,6 +198,13 @@ int main()
         std::vector<std::thread> th;
         for (int t = 0; t < 3; ++t) th.emplace_back([t] { for (int k = 0; k < 4; ++k) match_case(400 + 37 * t, 390, 0.75f, true, 100 + 10 * t + k); });
         for (auto& x : th) x.join();
+        // the finished threads handed their contexts back: a second wave re-uses them, shutdown() destroys all of them
+        // and the next call starts over
+        std::vector<std::thread> th2;
+        for (int t = 0; t < 3; ++t) th2.emplace_back([t] { match_case(300 + t, 310, 0.9f, true, 500 + t); });
+        for (auto& x : th2) x.join();
+        StVO::shutdown();
+        match_case(257, 300, 0.75f, true, 601);
     }
 
     // batch of jobs

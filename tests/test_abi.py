@@ -50,3 +50,20 @@ def test_product_never_imports_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("no CPU fallback", ""), os.path.join(dirpath, f)
     assert "oracle" not in open(os.path.join(ROOT, "include", "plslam_hip.h")).read()
+
+
+def test_every_locked_entry_point_selects_the_context_device():
+    """A host thread starts on device 0 whatever device its context lives on (StVO::setDevice(1), Context(rank > 0) from the
+    local-mapping thread): every entry point that takes the context lock must switch to ctx->device before it allocates,
+    copies or launches.  Structural check of the sources (the run-time check needs two GPUs: test_gpu_match)."""
+    import re
+    n = 0
+    for f in sorted(os.listdir(os.path.join(ROOT, "plslam_amd", "csrc"))):
+        if not f.endswith(".hip"):
+            continue
+        lines = open(os.path.join(ROOT, "plslam_amd", "csrc", f)).read().split("\n")
+        for i, ln in enumerate(lines):
+            if "std::lock_guard<std::mutex>" in ln and "->mu" in ln:
+                n += 1
+                assert re.search(r"\bDeviceGuard\s+\w+\(", lines[i + 1]), f"{f}:{i + 1}: lock without DeviceGuard"
+    assert n >= 20

@@ -611,3 +611,50 @@ def test_knn2_against_the_reference_kNN_outputs(ctx):
         u = np.all(g[f"{name}/k2_idx"] >= 0, axis=1)      # queries whose three nearest distances are distinct
         assert u.sum() > 0 or name == "ties"
         assert np.array_equal(idx[u], g[f"{name}/k2_idx"][u]), name
+
+
+@pytest.mark.parametrize("mutual", [False, True])
+@pytest.mark.parametrize("n1,n2", [(1500, 1400), (200, 37), (3000, 2100), (5, 1)])
+def test_match_on_a_vector_that_already_holds_entries(vctx, oracle, n1, n2, mutual):
+    """plslam_match_prior / plslam_match_problem.keep_prior: the fall-back of src/mapHandler.cpp:274-278 (and :421-425,
+    :594-598, :709-713) runs StVO::match on the vector matchGrid filled -- rejected rows keep their entry, the
+    consistency loop covers them, the count follows the reference's arithmetic.  Every scan form, vs the oracle."""
+    r = np.random.Generator(np.random.PCG64(n1 * 7 + n2))
+    d1 = synth.random_desc(r, n1)
+    d2 = synth.random_desc(r, n2)
+    k = min(n1, n2) // 2
+    d2[:k] = d1[:k] ^ np.packbits(r.random((k, 256)) < 0.04, axis=1)
+    prior = np.where(r.random(n1) < 0.5, r.integers(0, n2, n1), -1).astype(np.int32)
+    got, n = vctx.match_prior(d1, d2, 0.75, mutual, prior)
+    ref, nref = oracle.match_prior(d1, d2, 0.75, mutual, prior)
+    np.testing.assert_array_equal(got, ref)
+    assert n == nref
+    got0, n0 = vctx.match_prior(d1, d2, 0.75, mutual, np.full(n1, -1, np.int32))
+    ref0, nref0 = oracle.match(d1, d2, 0.75, mutual)
+    np.testing.assert_array_equal(got0, ref0)
+    assert n0 == nref0
+
+
+def test_entry_points_run_on_the_context_device_not_the_current_one():
+    """Needs two GPUs (skipped on the 1-GPU test boxes): a context on device 1 driven from a thread whose current device
+    is 0 -- the map<->keyframe drivers, the LBA plan and the matcher allocate and launch on device 1."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one visible GPU")
+    from oracle import oracle as O
+    torch.cuda.set_device(0)
+    ctx = plslam_amd.Context(1)
+    r = np.random.Generator(np.random.PCG64(5))
+    d1, d2 = synth.random_desc(r, 700), synth.random_desc(r, 650)
+    d2[:300] = d1[:300] ^ np.packbits(r.random((300, 256)) < 0.04, axis=1)
+    got = ctx.match(d1, d2, 0.75, True)
+    ref = O.match(d1, d2, 0.75, True)
+    np.testing.assert_array_equal(got[0], ref[0])
+    import test_map2kf as T
+    cam, ocam = plslam_amd.make_cam(**synth.EUROC), O.make_cam(**synth.EUROC)
+    s = T.scene(1200, 500)
+    a = (s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"], s["kf_idx"])
+    g = ctx.map2kf_match_fast("points", cam, *a, 0.9, True, 1.5, 10, T.fast_cfg())
+    e = O.map2kf_match_fast("points", ocam, *a, 0.9, True, 1.5, 10, T.fast_cfg())
+    np.testing.assert_array_equal(g[0], e[0])
+    assert torch.cuda.current_device() == 0

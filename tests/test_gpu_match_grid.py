@@ -139,6 +139,31 @@ def test_bad_arguments_are_refused(ctx):
         ctx.match_grid(window=(1, 1, 1, 1), **bad)
     with pytest.raises(plslam_amd.PlslamError):
         ctx.match_grid(window=(1, 1, 1, 1), **dict(ok, cols=0))
+    # a grid entry that is not a row of desc2 (it would be an out-of-bounds device read)
+    for v in (4, -1):
+        it = items.copy()
+        it[1] = v
+        with pytest.raises(plslam_amd.PlslamError):
+            ctx.match_grid(window=(1, 1, 1, 1), **dict(ok, cell_items=it))
+
+
+def test_host_rows_need_no_alignment(ctx, oracle):
+    """Host descriptor rows are staged into aligned device memory: a view at an odd byte offset (a cv::Mat ROI) is
+    accepted and gives the same table."""
+    c = point_case(77, 300, 260, 16, 12)
+    ref = _same(ctx, oracle, c, (2, 2, 2, 2), 0.8, True)
+
+    def odd(a):
+        buf = np.zeros(a.size + 16, np.uint8)
+        off = 3 + (-buf.ctypes.data) % 16                       # 3 bytes past a 16-byte boundary
+        v = buf[off:off + a.size].reshape(a.shape)
+        v[:] = a
+        assert v.ctypes.data % 16 == 3 and v.flags.c_contiguous
+        return v
+
+    got = ctx.match_grid(window=(2, 2, 2, 2), nnr=0.8, mutual=True, **dict(c, d1=odd(c["d1"]), d2=odd(c["d2"])))
+    np.testing.assert_array_equal(got[0], ref[0])
+    assert got[1] == ref[1]
 
 
 def test_plan_batch_device_resident_and_overflow(ctx, oracle):

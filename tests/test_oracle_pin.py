@@ -221,6 +221,40 @@ def test_mutual_semantics_hand_case():
     assert z.sum() == 0
 
 
+@pytest.mark.parametrize("mutual", [False, True])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_match_on_a_vector_that_already_holds_entries(seed, mutual):
+    """plo_match_prior = [RECALL] stvo-pl matchNNR's `matches_12.resize(desc1.rows, -1)` when the caller's vector is the one
+    matchGrid filled (src/mapHandler.cpp:271 -> :277): restated here step by step from the directed tables."""
+    r = np.random.Generator(np.random.PCG64(seed))
+    n1, n2 = 180, 150
+    d1 = synth.random_desc(r, n1)
+    d2 = synth.random_desc(r, n2)
+    k = 90
+    d2[:k] = d1[:k] ^ np.packbits(r.random((k, 256)) < 0.04, axis=1)         # true correspondences
+    d2[k:k + 20] = d2[:20]                                                    # + duplicates: ratio test fails there
+    prior = np.where(r.random(n1) < 0.5, r.integers(0, n2, n1), -1).astype(np.int32)
+    m12, _ = O.match(d1, d2, 0.75, False)
+    m21, _ = O.match(d2, d1, 0.75, False)
+    exp = np.where(m12 >= 0, m12, prior)
+    cnt = int((m12 >= 0).sum())
+    if mutual:
+        for i1 in range(n1):
+            if exp[i1] >= 0 and m21[exp[i1]] != i1:
+                exp[i1] = -1
+                cnt -= 1
+    got, n = O.match_prior(d1, d2, 0.75, mutual, prior)
+    np.testing.assert_array_equal(got, exp)
+    assert n == cnt
+    assert ((m12 < 0) & (prior >= 0)).sum() > 10                              # kept entries exist in this case
+    if mutual:
+        assert n != (got >= 0).sum() or seed < 0                              # ... and the count is not the number of entries
+    fresh, nf = O.match_prior(d1, d2, 0.75, mutual, np.full(n1, -1, np.int32))
+    ref, nr = O.match(d1, d2, 0.75, mutual)
+    np.testing.assert_array_equal(fresh, ref)                                 # an all -1 vector: plain match()
+    assert nf == nr
+
+
 @settings(max_examples=60, deadline=None)
 @given(st.integers(0, 40), st.integers(0, 40), st.integers(0, 2 ** 31 - 1), st.booleans(),
        st.sampled_from([0.6, 0.75, 0.9]), st.booleans())
