@@ -160,6 +160,12 @@ def load() -> C.CDLL:
     L.plslam_last_error.restype = C.c_char_p
     L.plslam_last_error.argtypes = []
     L.plslam_abi_version.restype = C.c_int
+    L.plslam_abi_version.argtypes = []
+    L.plslam_lbd_binarise.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.plslam_lbd_binarise_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.plslam_median_desc_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    L.plslam_median_desc_batched_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]
     L.plslam_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.plslam_ctx_destroy.argtypes = [vp]
     L.plslam_ctx_destroy.restype = None
@@ -169,6 +175,7 @@ def load() -> C.CDLL:
                                          C.c_char_p, i32]
     L.plslam_knn2_hamming256.argtypes = [vp, vp, i32, vp, i32, vp, vp]
     L.plslam_match.argtypes = [vp, vp, i32, vp, i32, C.c_float, C.c_int, vp, C.POINTER(i32)]
+    L.plslam_match_prior.argtypes = L.plslam_match.argtypes
     L.plslam_match_batched.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, C.c_int, vp, vp]
     L.plslam_match_plan_create.argtypes = [vp, C.POINTER(MatchProblem), i32, C.POINTER(vp)]
     L.plslam_match_plan_run.argtypes = [vp, vp]

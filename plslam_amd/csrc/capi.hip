@@ -658,6 +658,7 @@ void plslam_ctx_destroy(plslam_ctx* ctx)
     ctx->misc_a.release(); ctx->misc_b.release(); ctx->misc_c.release();
     ctx->pin_in.release();
     ctx->pin_out.release();
+    ctx->lbd_ring.release();
     if (ctx->host_plan) {
         ctx->host_plan->free_all();
         delete ctx->host_plan;
@@ -1410,14 +1411,6 @@ __global__ void __launch_bounds__(256) k_store_to_host(const int4* __restrict__ 
     if (blockIdx.x == 0 && (int)threadIdx.x < ntail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
 }
 
-// the device address of page-locked, mapped host memory (hipHostMalloc / hipHostRegister), or nullptr
-static void* mapped_device_pointer(void* host)
-{
-    hipPointerAttribute_t at;
-    if (!host || hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
-    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
-}
-
 int plslam_match_pipeline_submit(plslam_match_pipeline* P, const void* arena_host, int32_t* out_host, int32_t* counts_host)
 {
     PLSLAM_REQUIRE(P && arena_host && out_host, PLSLAM_EINVAL);
@@ -1436,8 +1429,8 @@ int plslam_match_pipeline_submit(plslam_match_pipeline* P, const void* arena_hos
     // a copy-engine download would queue between two uploads, and with the copy engines taking transfers in order the
     // next upload then waits for this batch's kernels -- upload, kernels, download ran strictly one after the other
     // (measured: 1.03 ms per batch of 256 C2 pairs; 0.53 ms = the upload alone once the download is a kernel).
-    void* d_out = mapped_device_pointer(out_host);
-    void* d_cnt = counts_host ? mapped_device_pointer(counts_host) : nullptr;
+    void* d_out = plslam::mapped_device_pointer(out_host);
+    void* d_cnt = counts_host ? plslam::mapped_device_pointer(counts_host) : nullptr;
     if (d_out && (!counts_host || d_cnt) && (P->out_entries % 4) == 0 && P->nprob <= 256 * 1024) {
         const size_t n16 = P->out_entries / 4;
         hipLaunchKernelGGL(k_store_to_host, dim3(64), dim3(256), 0, ctx->stream, sl.out.as<int4>(), (int4*)d_out, n16,

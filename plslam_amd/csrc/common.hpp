@@ -52,6 +52,32 @@ struct HostBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// ring of page-locked slots for small per-call host tables a kernel reads in place (lbd_float.hip: the line records)
+struct LineRing {
+    static constexpr int SLOTS = 4;
+    HostBuf rec[SLOTS];
+    hipEvent_t done[SLOTS] = {nullptr, nullptr, nullptr, nullptr};   // recorded behind the kernel that read the slot
+    bool busy[SLOTS] = {false, false, false, false};
+    int next = 0;
+    void release()
+    {
+        for (int k = 0; k < SLOTS; ++k) {
+            if (done[k]) (void)hipEventDestroy(done[k]);
+            done[k] = nullptr;
+            busy[k] = false;
+            rec[k].release();
+        }
+    }
+};
+
+// the device address of page-locked, mapped host memory (hipHostMalloc / hipHostRegister), or nullptr
+inline void* mapped_device_pointer(void* host)
+{
+    hipPointerAttribute_t at;
+    if (!host || hipPointerGetAttributes(&at, host) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return at.type == hipMemoryTypeHost ? at.devicePointer : nullptr;
+}
+
 struct DeviceGuard {  // every entry point runs on the context's device
     int prev = -1;
     explicit DeviceGuard(int dev)
@@ -102,6 +128,7 @@ struct plslam_ctx {
     std::mutex mu;       // serialises the host-pointer entry points
     plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
     plslam::HostBuf pin_in, pin_out;                // pinned staging of small host-pointer calls
+    plslam::LineRing lbd_ring;                      // line records of the last plslam_lbd_compute* calls
     struct plslam_match_plan* host_plan = nullptr;  // reused by the host-pointer match entry points
 };
 

@@ -783,14 +783,14 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     q.matches_12 = matches_12;
     int rc;
     if ((rc = grid_check_problem(q, false))) return rc;
-    // the grid is host data here: validate it (offsets monotonic, every entry a row of desc2) and count the
-    // (row, candidate) pairs exactly
+    // the grid is host data here: validate the offsets and count the (row, candidate) pairs exactly.  The ENTRIES are
+    // not validated: an entry outside [0, n2) is skipped by the kernel before any read, as upstream's loop skips it
+    // (`if (i2 < 0 || i2 >= desc2.rows) continue;`) -- tests/test_gpu_match_grid.py::test_empty_and_out_of_range_inputs
     const int64_t ncell = (int64_t)grid_cols * grid_rows;
     PLSLAM_REQUIRE(cell_start[0] == 0, PLSLAM_EINVAL);
     for (int64_t c = 0; c < ncell; ++c) PLSLAM_REQUIRE(cell_start[c + 1] >= cell_start[c], PLSLAM_EINVAL);
     const int32_t n_items = cell_start[ncell];
     PLSLAM_REQUIRE(n_items == 0 || cell_items, PLSLAM_EINVAL);
-    for (int32_t k = 0; k < n_items; ++k) PLSLAM_REQUIRE(cell_items[k] >= 0 && cell_items[k] < n2, PLSLAM_EINVAL);
     q.n_items = n_items;
     const int64_t pairs = grid_store_capacity_host(centres1, n1, n_centres, cell_start, grid_cols, grid_rows, window,
                                                    mutual);

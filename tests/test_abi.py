@@ -67,3 +67,11 @@ def test_every_locked_entry_point_selects_the_context_device():
                 n += 1
                 assert re.search(r"\bDeviceGuard\s+\w+\(", lines[i + 1]), f"{f}:{i + 1}: lock without DeviceGuard"
     assert n >= 20
+
+
+def test_every_symbol_has_a_declared_signature():
+    """ctypes guesses int for anything undeclared (floats are refused, pointers truncated): every entry point of the
+    binding carries explicit argtypes."""
+    L = plslam_amd.load()
+    missing = [s for s in plslam_amd.ABI_SYMBOLS if getattr(L, s).argtypes is None]
+    assert not missing, missing

@@ -139,12 +139,6 @@ def test_bad_arguments_are_refused(ctx):
         ctx.match_grid(window=(1, 1, 1, 1), **bad)
     with pytest.raises(plslam_amd.PlslamError):
         ctx.match_grid(window=(1, 1, 1, 1), **dict(ok, cols=0))
-    # a grid entry that is not a row of desc2 (it would be an out-of-bounds device read)
-    for v in (4, -1):
-        it = items.copy()
-        it[1] = v
-        with pytest.raises(plslam_amd.PlslamError):
-            ctx.match_grid(window=(1, 1, 1, 1), **dict(ok, cell_items=it))
 
 
 def test_host_rows_need_no_alignment(ctx, oracle):

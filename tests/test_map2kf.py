@@ -236,6 +236,9 @@ def test_gpu_kf2kf_driver_bit_exact(ctx, oracle, kind, n_prev, n_curr):
         got = ctx.kf2kf_match(kind, cam, *a, nnr, mutual, mm, fm)
         ref = oracle.kf2kf_match(kind, ocam, *a, nnr, mutual, mm, fm)
         np.testing.assert_array_equal(got[0], ref[0])
-        assert got[1] == ref[1] == int((ref[0] >= 0).sum()) and got[2] == ref[2]
+        assert got[1] == ref[1] and got[2] == ref[2]
+        # the count is the number of entries, except after the fall-back ON matchGrid's vector: entries that were kept
+        # were never counted, kept entries that fail the consistency loop are subtracted (the reference's arithmetic)
+        assert ref[1] == int((ref[0] >= 0).sum()) or (ref[2] == 1 and fm["enabled"] and mutual)
         seen.add(ref[2])
     assert seen == {0, 1}
