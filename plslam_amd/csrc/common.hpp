@@ -284,8 +284,8 @@ struct GridDesc {              // one matchGrid problem; every pointer is a devi
 };
 size_t grid_fixed_words(int32_t n1, int32_t n2, int64_t ncell);   // tables kept in LDS when they fit
 bool grid_fits_lds(int32_t n1, int32_t n2, int64_t ncell);
-size_t grid_lds_bytes(int mode, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items);
-int grid_mode(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items);   // 2: all in LDS, 1: tables in LDS, 0: global
+size_t grid_lds_bytes(int mode, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs = false);
+int grid_mode(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs = false);   // 2: all in LDS, 1: tables in LDS, 0: global
 size_t grid_scratch_words(int32_t n1, int32_t n2, int64_t ncell, int32_t pair_cap);
 int64_t grid_store_capacity_host(const int32_t* centres, int32_t n1, int32_t n_centres, const int32_t* cell_start,
                                  int32_t cols, int32_t rows, const int32_t window[4], int mutual);
@@ -293,8 +293,8 @@ int64_t grid_store_capacity_host(const int32_t* centres, int32_t n1, int32_t n_c
 int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* d_desc_slot,
                           GridDesc* h_desc_slot, hipStream_t s);
 // launch groups: 3 = all in LDS / 256-lane workgroups (n1 <= 256), 2 = all in LDS, 1 = tables in LDS, 0 = global
-int grid_group(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items);
-size_t grid_group_lds_bytes(int group, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items);
+int grid_group(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs = false);
+size_t grid_group_lds_bytes(int group, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs = false);
 // table order: the n[3] problems of group 3, then n[2], n[1], n[0]
 int launch_match_grid(const GridDesc* d_probs, const int32_t n[4], const size_t lds_bytes[4], hipStream_t s);
 

@@ -37,6 +37,7 @@
 //       so a lone live candidate passes), mutual check against the column's final state, count.
 // Duplicated candidates (an item sitting in several cells of the window, the two windows of a line overlapping) are
 // harmless: the atomic min and the best-two fold are idempotent.
+#include <algorithm>
 #include <cstring>
 #include <new>
 
@@ -48,6 +49,7 @@ namespace {
 constexpr int GRID_THREADS = 1024;
 constexpr uint32_t REC_D_BITS = 9, REC_D_MASK = 511u;                  // column state: i1 << 9 | d
 constexpr int CB = 4;                                                  // candidates per batch
+constexpr uint32_t GRID_TAIL = 256;                                   // candidates left when one wave finishes the passes alone
 constexpr int PB_BATCH = 8;                                            // stored candidates per batch of a record pass
 constexpr size_t GRID_LDS_MAX_BYTES = 152 * 1024;                      // dynamic LDS of the LDS instantiations
 constexpr size_t GRID_LDS_FIXED_MAX_BYTES = 144 * 1024;                // tables that MUST fit for MODE 1
@@ -68,7 +70,7 @@ struct GridPtrs {
     typename as_ptr<uint32_t, (MODE >= 1)>::type state, next, row_k1, row_k2;
     PLSLAM_AS_GLOBAL const int32_t* centres;
     PLSLAM_AS_GLOBAL const double* dir1;
-    PLSLAM_AS_GLOBAL const double* dir2;
+    typename as_ptr<const double, (MODE == 2)>::type dir2;      // directions of the desc2 lines
 };
 
 __device__ __forceinline__ void best2_fold(uint32_t& k1, uint32_t& k2, uint32_t key)
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     extern __shared__ u32x4 s_dyn4[];
     __shared__ uint32_t s_part[NT];
     __shared__ uint32_t s_max2[2];
+    __shared__ uint32_t s_tail[GRID_TAIL];
     PLSLAM_AS_LDS uint32_t* s_dyn = (PLSLAM_AS_LDS uint32_t*)reinterpret_cast<uint32_t*>(s_dyn4);
 
     const GridDesc g = probs[blockIdx.x];
@@ -177,7 +180,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     const int32_t ncell = g.cols * g.rows;
     const int32_t n_rounds = (n1 + NT - 1) / NT;
 #ifdef PLSLAM_GRID_TIMING   // experiment builds only: phase boundaries in 10 ns ticks, printed by one lane
-    uint64_t ts[6];
+    uint64_t ts[6], t_move = 0;
     int nts = 0, npass = 0;
 #define GRID_STAMP() do { if (nts < 6) ts[nts++] = wall_clock64(); } while (0)
 #else
@@ -190,17 +193,17 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     PLSLAM_AS_GLOBAL const u32x4* g_d1 = (PLSLAM_AS_GLOBAL const u32x4*)g.d1;
     PLSLAM_AS_GLOBAL const u32x4* g_d2 = (PLSLAM_AS_GLOBAL const u32x4*)g.d2;
     PLSLAM_AS_GLOBAL int32_t* g_matches = (PLSLAM_AS_GLOBAL int32_t*)g.matches_12;
-    // tables: [cell_start copy (LDS only)] | state n2 | next n2 | row_k1 n1 | row_k2 n1
+    // tables: state n2 | next n2 | row_k1 n1 | row_k2 n1 | [cell_start copy (LDS only)]
     const uint32_t fixed_words = (uint32_t)(LDS ? ncell + 1 : 0) + 2u * (uint32_t)n2 + 2u * (uint32_t)n1;
     // MODE 2: items at the next 16-byte boundary behind the tables, desc2 rows behind them (launcher guarantees the fit)
     const uint32_t items_off = (fixed_words + 3u) & ~3u, d2_off = (items_off + (uint32_t)g.n_items + 3u) & ~3u;
     GridPtrs<MODE> P;
     P.centres = (PLSLAM_AS_GLOBAL const int32_t*)g.centres;
     P.dir1 = (PLSLAM_AS_GLOBAL const double*)g.dir1;
-    P.dir2 = (PLSLAM_AS_GLOBAL const double*)g.dir2;
-    if constexpr (LDS) {
-        P.cs = s_dyn;
-        P.state = s_dyn + (ncell + 1);
+    const bool has_dirs = g.dir1 != nullptr && g.dir2 != nullptr;
+    if constexpr (LDS) {    // column / row words first: what lies behind them is free once PA is done
+        P.state = s_dyn;
+        P.cs = s_dyn + 2 * (n2 + n1);
     } else {
         P.cs = (PLSLAM_AS_GLOBAL const uint32_t*)g.cell_start;
         P.state = gscratch;
@@ -211,9 +214,11 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     if constexpr (MODE == 2) {
         P.items = (PLSLAM_AS_LDS const int32_t*)(s_dyn + items_off);
         P.d2 = (PLSLAM_AS_LDS const u32x4*)(s_dyn + d2_off);
+        P.dir2 = (PLSLAM_AS_LDS const double*)(s_dyn + d2_off + 8u * (uint32_t)n2);    // 16-byte aligned: d2_off is
     } else {
         P.items = g_items;
         P.d2 = g_d2;
+        P.dir2 = (PLSLAM_AS_GLOBAL const double*)g.dir2;
     }
     // global scratch behind the tables: per-row slot counts, per-round slot depth, the candidate store (x 2)
     PLSLAM_AS_GLOBAL uint32_t* rcnt = gscratch + (LDS ? 0u : fixed_words);   // n1
@@ -222,13 +227,18 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
 
     // ---- P0: tables ----
     if constexpr (LDS) {
-        for (int32_t j = tid; j <= ncell; j += NT) s_dyn[j] = (uint32_t)g_cell_start[j];
+        for (int32_t j = tid; j <= ncell; j += NT) s_dyn[2 * (n2 + n1) + j] = (uint32_t)g_cell_start[j];
     }
     if constexpr (MODE == 2) {
         PLSLAM_AS_LDS int32_t* li = (PLSLAM_AS_LDS int32_t*)(s_dyn + items_off);
         for (int32_t j = tid; j < g.n_items; j += NT) li[j] = g_items[j];
         PLSLAM_AS_LDS u32x4* lt = (PLSLAM_AS_LDS u32x4*)(s_dyn + d2_off);
         for (int32_t j = tid; j < 2 * n2; j += NT) lt[j] = g_d2[j];
+        if (has_dirs) {     // a candidate's direction test sits between its item and its descriptor: not a global round trip
+            PLSLAM_AS_LDS double* ld = (PLSLAM_AS_LDS double*)(s_dyn + d2_off + 8u * (uint32_t)n2);
+            PLSLAM_AS_GLOBAL const double* gd = (PLSLAM_AS_GLOBAL const double*)g.dir2;
+            for (int32_t j = tid; j < 2 * n2; j += NT) ld[j] = gd[j];
+        }
     }
     for (int32_t j = tid; j < n2; j += NT) {
         P.state[j] = KEY_NONE;
@@ -251,11 +261,13 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
 
     // ---- PA: distances ----
     uint32_t store_words = 0;        // slots claimed so far (uniform)
+    uint32_t has_items = 0;          // bit r: this lane's row of round r has grid items inside its windows (mutual only)
     for (int32_t r = 0; r < n_rounds; ++r) {
         const int32_t i1 = r * NT + tid;
         uint32_t depth = 0;
         if (g.mutual) {              // slot depth of this round = the largest item count of one of its rows
             uint32_t c = i1 < n1 ? count_items(g, P, i1) : 0u;
+            if (c && r < 32) has_items |= 1u << r;      // for PC: the cell_start copy may be gone by then
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) {
                 const uint32_t o = (uint32_t)__shfl_xor((int)c, off);
@@ -372,71 +384,160 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         int more = sweep();               // installs the proposals PA made: every column's first record
         bool in_lds = false;
         if constexpr (MODE == 2) {
-            // cell_start's tail neighbours -- the items and the desc2 rows -- are dead now: if the candidates fit
-            // there (compact: row i1 at row_off[i1]), the passes run on LDS alone
-            PLSLAM_AS_LDS uint32_t* row_off = s_dyn + items_off;      // n1 + 1
-            PLSLAM_AS_LDS uint32_t* lcnt = row_off + (n1 + 1);        // n1
-            PLSLAM_AS_LDS uint32_t* lstore = lcnt + n1;
-            const uint32_t room = lds_words > items_off + 2u * (uint32_t)n1 + 1u ? lds_words - (items_off + 2u * (uint32_t)n1 + 1u) : 0u;
-            // exclusive scan of the row counts (s_part as scratch)
-            const int32_t per = (n1 + NT - 1) / NT;
-            const int32_t b = tid * per < n1 ? tid * per : n1, e = b + per < n1 ? b + per : n1;
-            uint32_t sum = 0;
-            for (int32_t i = b; i < e; ++i) sum += rcnt[i];
-            uint32_t incl = sum;
+            // Everything behind the column / row words -- cell_start, the items, the desc2 rows -- is dead now.  If the
+            // stored candidates fit there and row and column numbers fit 11 bits each (a candidate is then ONE word that
+            // names its row: d << 22 | i1 << 11 | i2), the passes run candidate-parallel on LDS alone.
+            const uint32_t tables = 2u * (uint32_t)n2 + 2u * (uint32_t)n1;
+            PLSLAM_AS_LDS uint32_t* lstore = s_dyn + tables;
+            const uint32_t room = lds_words > tables ? lds_words - tables : 0u;
+            // where a lane's rows go in the flat array: exclusive scan of the lanes' candidate counts (any order of the
+            // rows will do)
+            uint32_t mine = 0;
+            for (int32_t r = 0; r < n_rounds; ++r) mine += r * NT + tid < n1 ? rcnt[r * NT + tid] : 0u;
+            uint32_t incl = mine;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
                 if (lane >= off) incl += v;
             }
             if (lane == 63) s_part[tid >> 6] = incl;
-            __syncthreads();                                          // also: every PA read of items / desc2 is done
+            __syncthreads();
             uint32_t pre = 0, total = 0;
             for (int w = 0; w < NT / 64; ++w) {
                 const uint32_t v = s_part[w];
                 pre += w < (tid >> 6) ? v : 0u;
                 total += v;
             }
-            in_lds = total <= room;                                   // uniform
+            in_lds = total <= room && n1 <= 2048 && n2 <= 2048;      // uniform
             if (in_lds) {
-                uint32_t run = pre + incl - sum;
-                for (int32_t i = b; i < e; ++i) {
-                    const uint32_t c = rcnt[i];
-                    row_off[i] = run;
-                    lcnt[i] = c;
-                    run += c;
-                }
-                __syncthreads();
-                uint32_t off = 0;
-                for (int32_t r = 0; r < n_rounds; ++r) {              // transposed global slots -> compact LDS rows
+                uint32_t run = pre + incl - mine, off = 0;
+                for (int32_t r = 0; r < n_rounds; ++r) {              // transposed global slots -> the flat LDS array
                     const int32_t i1 = r * NT + tid;
                     if (i1 < n1) {
-                        const uint32_t cnt = lcnt[i1];
+                        const uint32_t cnt = rcnt[i1];
                         PLSLAM_AS_GLOBAL const uint32_t* slot = store + off;
-                        PLSLAM_AS_LDS uint32_t* dstp = lstore + row_off[i1];
+                        PLSLAM_AS_LDS uint32_t* dstp = lstore + run;
                         for (uint32_t k0 = 0; k0 < cnt; k0 += PB_BATCH) {
                             uint32_t key[PB_BATCH];
 #pragma unroll
                             for (int j = 0; j < PB_BATCH; ++j) key[j] = k0 + j < cnt ? slot[slot_index<NT>(k0 + j, tid)] : 0u;
 #pragma unroll
                             for (int j = 0; j < PB_BATCH; ++j)
-                                if (k0 + j < cnt) dstp[k0 + j] = key[j];
+                                if (k0 + j < cnt)
+                                    dstp[k0 + j] = ((key[j] >> KEY_IDX_BITS) << 22) | ((uint32_t)i1 << 11) | (key[j] & 2047u);
                         }
+                        run += cnt;
                     }
                     off += round_k[r] * NT;
                 }
+                // ---- candidate-parallel passes.  Each wave owns an equal slice of the flat array and compacts the
+                // survivors of a pass in place (ballot + prefix: no other wave touches the slice), so every lane has the
+                // same number of candidates whatever the rows' list lengths.
+                // A column's record carries its pass number in the top bits, newest = smallest:
+                //     rec(t, i1, d) = (0xFFF - t) << 20 | i1 << 9 | d,
+                // pass t reads the records of pass t-1 from one array and proposes with an atomic min into the other: a
+                // proposal of pass t beats whatever pass t-2 left there, so nothing is cleared and nothing is installed --
+                // one barrier per pass.  (Every candidate that survives pass t-1 proposed in it: its column's word in the
+                // array pass t reads IS a pass t-1 record.  A column has at most 257 records: the pass number fits.)
+                // Live candidates join their row's best two with two LDS atomic mins: k1 takes the key, whichever of
+                // (old k1, key) lost goes to k2 -- every key of the row except the final minimum reaches k2 exactly once.
+                for (int32_t i2 = tid; i2 < n2; i2 += NT) {            // the first records: pass 0
+                    const uint32_t v = P.state[i2];
+                    if (v != KEY_NONE) P.state[i2] = 0xFFF00000u | v;
+                }
                 __syncthreads();
-                while (more) {
-                    for (int32_t i1 = tid; i1 < n1; i1 += NT) {
-                        const uint32_t cnt = lcnt[i1];
-                        if (cnt) {
-                            PLSLAM_AS_LDS uint32_t* rowp = lstore + row_off[i1];
-                            // in place: survivors land at or before their source
-                            lcnt[i1] = pass_row(i1, rowp, rowp, [](uint32_t k) { return k; }, cnt);
+#ifdef PLSLAM_GRID_TIMING
+                t_move = wall_clock64();
+#endif
+                constexpr uint32_t NW = NT / 64;
+                constexpr int UN = 4;                                  // chunks of 64 candidates in flight per lane
+                const uint32_t wv = (uint32_t)tid >> 6;
+                const uint32_t seg_b = (uint32_t)((uint64_t)total * wv / NW), seg_e = (uint32_t)((uint64_t)total * (wv + 1) / NW);
+                const uint64_t below = (1ull << lane) - 1ull;
+                // one pass over `alive` candidates at `seg` (in place); returns the survivors
+                auto run_pass = [&](PLSLAM_AS_LDS uint32_t* seg, uint32_t alive, uint32_t t) -> uint32_t {
+                    auto rd = (t & 1) ? P.state : P.next;
+                    auto wr = (t & 1) ? P.next : P.state;
+                    const uint32_t tag_rd = (0xFFFu - (t - 1)) << 20, tag_wr = (0xFFFu - t) << 20;
+                    uint32_t out = 0;
+                    for (uint32_t base = 0; base < alive; base += 64 * UN) {
+                        uint32_t c[UN], rec[UN];
+                        bool keep[UN];
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) c[j] = base + 64 * j + lane < alive ? seg[base + 64 * j + lane] : KEY_NONE;
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) rec[j] = rd[c[j] == KEY_NONE ? 0u : c[j] & 2047u];
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) {
+                            const uint32_t i2 = c[j] & 2047u, i1 = (c[j] >> 11) & 2047u, d = c[j] >> 22;
+                            const uint32_t me = (i1 << REC_D_BITS) | d;
+                            keep[j] = false;
+                            if (c[j] != KEY_NONE) {
+                                if (rec[j] == (tag_rd | me)) {                // the record of the last pass: live
+                                    const uint32_t key = (d << KEY_IDX_BITS) | i2;
+                                    const uint32_t was = atomicMin((uint32_t*)&P.row_k1[i1], key);
+                                    // (a duplicate of the key -- an item in two cells of the window -- changes nothing)
+                                    if (was != key) atomicMin((uint32_t*)&P.row_k2[i1], was > key ? was : key);
+                                } else if (d < (rec[j] & REC_D_MASK)) {       // still below it: propose, stay
+                                    atomicMin((uint32_t*)&wr[i2], tag_wr | me);
+                                    keep[j] = true;
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < UN; ++j) {                       // every read of this step is done: in place
+                            const uint64_t m = __ballot(keep[j]);
+                            if (keep[j]) seg[out + (uint32_t)__popcll(m & below)] = c[j];
+                            out += (uint32_t)__popcll(m);
                         }
                     }
-                    more = sweep();
+                    return out;
+                };
+                uint32_t alive = seg_e - seg_b, t = 1;
+                bool tail = false;
+                while (more) {
+                    alive = run_pass(lstore + seg_b, alive, t);
+                    ++t;
+#ifdef PLSLAM_GRID_TIMING
+                    ++npass;
+#endif
+                    PLSLAM_AS_LDS uint32_t* left_of = (PLSLAM_AS_LDS uint32_t*)s_part + (t & 1u) * NW;   // alternating: one barrier per pass
+                    if (lane == 0) left_of[wv] = alive;
+                    __syncthreads();
+                    uint32_t left = 0;
+                    for (uint32_t w = 0; w < NW; ++w) left += left_of[w];
+                    more = left != 0u;
+                    if (left != 0u && left <= GRID_TAIL) {               // few survivors: no more workgroup barriers
+                        tail = true;
+                        break;
+                    }
                 }
+                if (tail) {
+                    // the last passes of a problem carry a handful of candidates each: wave 0 gathers them and finishes
+                    // alone (its LDS operations are ordered; the other waves wait at the barrier below)
+                    if (wv == 0) {
+                        uint32_t n_tail = 0;
+                        PLSLAM_AS_LDS const uint32_t* left_of = (PLSLAM_AS_LDS const uint32_t*)s_part + (t & 1u) * NW;
+                        for (uint32_t w = 0; w < NW; ++w) {
+                            const uint32_t cw = left_of[w], from = (uint32_t)((uint64_t)total * w / NW);
+                            for (uint32_t k = lane; k < cw; k += 64) s_tail[n_tail + k] = lstore[from + k];
+                            n_tail += cw;
+                        }
+                        while (n_tail) {
+                            n_tail = run_pass((PLSLAM_AS_LDS uint32_t*)s_tail, n_tail, t);
+                            ++t;
+#ifdef PLSLAM_GRID_TIMING
+                            ++npass;
+#endif
+                        }
+                    }
+                    __syncthreads();
+                }
+                for (int32_t i2 = tid; i2 < n2; i2 += NT) {                // the newest record of either array, untagged
+                    const uint32_t a = P.state[i2], b = P.next[i2], v = a < b ? a : b;
+                    P.state[i2] = v == KEY_NONE ? KEY_NONE : v & 0xFFFFFu;
+                }
+                __syncthreads();
             }
         }
         if (!in_lds) {
@@ -476,7 +577,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                 if (!g.mutual || (P.state[i2] >> REC_D_BITS) == (uint32_t)i1) m = i2;
             }
         }
-        else if (2147483647.0 < 2147483647.0 * g.nnr && count_items(g, P, i1) > 0u)
+        else if (2147483647.0 < 2147483647.0 * g.nnr &&
+                 ((g.mutual && i1 / NT < 32) ? ((has_items >> (i1 / NT)) & 1u) != 0u : count_items(g, P, i1) > 0u))
             cnt += 1;   // upstream, nnr > 1 only: a row whose candidates all fail keeps best_d = best_d2 = INT_MAX, passes
                         // `best_d < best_d2 * nnr`, gets matches_12 = best_idx = -1 and is COUNTED
         g_matches[i1] = m;
@@ -492,8 +594,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     GRID_STAMP();
 #ifdef PLSLAM_GRID_TIMING
     if (tid == 0 && blockIdx.x == 0)
-        printf("[k_match_grid n1=%d n2=%d] P0 %d PA %d PB %d (%d passes) PC %d (x10 ns)\n", n1, n2, (int)(ts[1] - ts[0]),
-               (int)(ts[2] - ts[1]), (int)(ts[3] - ts[2]), npass, (int)(ts[4] - ts[3]));
+        printf("[k_match_grid n1=%d n2=%d] P0 %d PA %d PB %d (move %d, %d passes) PC %d (x10 ns)\n", n1, n2, (int)(ts[1] - ts[0]),
+               (int)(ts[2] - ts[1]), (int)(ts[3] - ts[2]), t_move ? (int)(t_move - ts[2]) : -1, npass, (int)(ts[4] - ts[3]));
 #endif
 #undef GRID_STAMP
 }
@@ -517,7 +619,7 @@ size_t grid_scratch_words(int32_t n1, int32_t n2, int64_t ncell, int32_t pair_ca
 }
 
 // LDS bytes of a problem in each mode (MODE 2: tables, items at a 16-byte boundary, desc2 rows)
-size_t grid_lds_bytes(int mode, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items)
+size_t grid_lds_bytes(int mode, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs)
 {
     if (mode == 0) return 0;
     size_t w = grid_fixed_words(n1, n2, ncell);
@@ -525,12 +627,13 @@ size_t grid_lds_bytes(int mode, int32_t n1, int32_t n2, int64_t ncell, int32_t n
         w = (w + 3) & ~size_t(3);
         w = (w + (size_t)n_items + 3) & ~size_t(3);
         w += 8 * (size_t)n2;
+        if (dirs) w += 4 * (size_t)n2;          // the directions of the desc2 lines (2 doubles each)
     }
     return w * 4;
 }
-int grid_mode(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items)
+int grid_mode(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs)
 {
-    if (grid_lds_bytes(2, n1, n2, ncell, n_items) <= GRID_LDS_MAX_BYTES) return 2;
+    if (grid_lds_bytes(2, n1, n2, ncell, n_items, dirs) <= GRID_LDS_MAX_BYTES) return 2;
     return grid_fits_lds(n1, n2, ncell) ? 1 : 0;
 }
 
@@ -567,18 +670,18 @@ constexpr int GRID_SMALL_ROWS = 256;    // problems of at most this many rows ru
 
 // launch groups: 0 = tables in global scratch, 1 = tables in LDS, 2 = everything in LDS / 1024 lanes, 3 = everything in
 // LDS / 256 lanes (n1 <= GRID_SMALL_ROWS)
-int grid_group(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items)
+int grid_group(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs)
 {
-    const int mode = grid_mode(n1, n2, ncell, n_items);
+    const int mode = grid_mode(n1, n2, ncell, n_items, dirs);
     return mode == 2 && n1 <= GRID_SMALL_ROWS ? 3 : mode;
 }
 // dynamic LDS a problem of the group asks for: group 2 takes everything (one workgroup per CU either way: the spare LDS
 // holds the candidates); group 3 adds room for the candidate runs (64 per row) so that several problems share a CU
-size_t grid_group_lds_bytes(int group, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items)
+size_t grid_group_lds_bytes(int group, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs)
 {
     if (group == 0) return 0;
     if (group == 2) return GRID_LDS_MAX_BYTES;
-    size_t b = grid_lds_bytes(group == 3 ? 2 : 1, n1, n2, ncell, n_items);
+    size_t b = grid_lds_bytes(group == 3 ? 2 : 1, n1, n2, ncell, n_items, dirs);
     if (group == 3) {
         b += 4 * (2 * (size_t)n1 + 1 + 64 * (size_t)n1);
         b = (b + 4095) & ~size_t(4095);
@@ -680,11 +783,12 @@ int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32
     grid_fill_desc(q, scratch, status, h_desc_slot);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d_desc_slot, h_desc_slot, sizeof(GridDesc), hipMemcpyHostToDevice, s));
     const int64_t ncell = (int64_t)q.grid_cols * q.grid_rows;
-    const int group = grid_group(q.n1, q.n2, ncell, q.n_items);
+    const bool dirs = q.dir1 != nullptr && q.dir2 != nullptr;
+    const int group = grid_group(q.n1, q.n2, ncell, q.n_items, dirs);
     int32_t n_mode[4] = {0, 0, 0, 0};
     size_t lds_bytes[4] = {0, 0, 0, 0};
     n_mode[group] = 1;
-    lds_bytes[group] = grid_group_lds_bytes(group, q.n1, q.n2, ncell, q.n_items);
+    lds_bytes[group] = grid_group_lds_bytes(group, q.n1, q.n2, ncell, q.n_items, dirs);
     return launch_match_grid(d_desc_slot, n_mode, lds_bytes, s);
 }
 }  // namespace plslam
@@ -717,8 +821,9 @@ int plslam_grid_plan_create(plslam_ctx* ctx, const plslam_grid_problem* probs, i
     for (int mode = 3; mode >= 0; --mode)
         for (int32_t b = 0; b < nprob; ++b) {
             const int64_t ncell = (int64_t)probs[b].grid_cols * probs[b].grid_rows;
-            if (grid_group(probs[b].n1, probs[b].n2, ncell, probs[b].n_items) != mode) continue;
-            const size_t lb = grid_group_lds_bytes(mode, probs[b].n1, probs[b].n2, ncell, probs[b].n_items);
+            const bool dirs = probs[b].dir1 != nullptr && probs[b].dir2 != nullptr;
+            if (grid_group(probs[b].n1, probs[b].n2, ncell, probs[b].n_items, dirs) != mode) continue;
+            const size_t lb = grid_group_lds_bytes(mode, probs[b].n1, probs[b].n2, ncell, probs[b].n_items, dirs);
             if (lb > P->lds_bytes[mode]) P->lds_bytes[mode] = lb;
             ++P->n_mode[mode];
             grid_fill_desc(probs[b], P->scratch.as<uint32_t>() + off, P->status.as<int32_t>(), &tab[slot++]);
@@ -792,8 +897,20 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     const int32_t n_items = cell_start[ncell];
     PLSLAM_REQUIRE(n_items == 0 || cell_items, PLSLAM_EINVAL);
     q.n_items = n_items;
-    const int64_t pairs = grid_store_capacity_host(centres1, n1, n_centres, cell_start, grid_cols, grid_rows, window,
-                                                   mutual);
+    // capacity of the candidate store.  A bound from the grid alone (fullest cell x cells of a window, at most every item,
+    // per window centre; rows in blocks of 1024) costs one pass over cell_start; only when that bound is large is the
+    // exact figure worth a walk over every row's window.
+    int64_t pairs = 0;
+    if (mutual) {
+        int64_t fullest = 0;
+        for (int64_t c = 0; c < ncell; ++c) fullest = std::max<int64_t>(fullest, cell_start[c + 1] - cell_start[c]);
+        const int64_t wx = std::min<int64_t>((int64_t)window[0] + window[1] + 1, grid_cols);
+        const int64_t wy = std::min<int64_t>((int64_t)window[2] + window[3] + 1, grid_rows);
+        const int64_t per_row = std::min<int64_t>(fullest * wx * wy, n_items) * n_centres;
+        pairs = per_row * GRID_THREADS * ((n1 + GRID_THREADS - 1) / GRID_THREADS);
+        if (pairs > (int64_t(1) << 21))
+            pairs = grid_store_capacity_host(centres1, n1, n_centres, cell_start, grid_cols, grid_rows, window, mutual);
+    }
     PLSLAM_REQUIRE(pairs < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
     q.pair_capacity = (int32_t)pairs;
 
@@ -833,24 +950,33 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     dq.d2 = (const uint8_t*)(d + oB);
     dq.dir1 = dirs ? (const double*)(d + oD1) : nullptr;
     dq.dir2 = dirs ? (const double*)(d + oD2) : nullptr;
+    // results: the kernel writes the table, the count and the status word straight into the page-locked block when the
+    // device can address it (one copy-engine command less on the call's critical path)
+    char* hout_dev = static_cast<char*>(mapped_device_pointer(ctx->pin_out.p));
+    int32_t* hres = (int32_t*)(ctx->pin_out.as<char>() + oN);
+    if (hout_dev) {
+        hres[0] = hres[1] = 0;
+        dout = hout_dev;
+    }
     dq.matches_12 = (int32_t*)(dout + oM);
     dq.n_matches = (int32_t*)(dout + oN);
     if ((rc = grid_check_problem(dq))) return rc;                 // what the kernel reads: the staged, aligned rows
-    grid_fill_desc(dq, ctx->misc_a.as<uint32_t>(), (int32_t*)(dout + oN) + 1, (GridDesc*)(h + oT));
+    // (no status word over PCIe -- it is bumped with an atomic; an overflow also shows as a count of -1)
+    grid_fill_desc(dq, ctx->misc_a.as<uint32_t>(), hout_dev ? nullptr : (int32_t*)(dout + oN) + 1, (GridDesc*)(h + oT));
     hipStream_t s = ctx->stream;
     StreamSyncOnError sg(s);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, ci.off, hipMemcpyHostToDevice, s));
-    PLSLAM_HIP_CHECK(hipMemsetAsync(dout + oN, 0, 8, s));
-    const int group = grid_group(n1, n2, ncell, n_items);
+    if (!hout_dev) PLSLAM_HIP_CHECK(hipMemsetAsync(dout + oN, 0, 8, s));
+    const int group = grid_group(n1, n2, ncell, n_items, dirs);
     int32_t n_mode[4] = {0, 0, 0, 0};
     size_t lds_bytes[4] = {0, 0, 0, 0};
     n_mode[group] = 1;
-    lds_bytes[group] = grid_group_lds_bytes(group, n1, n2, ncell, n_items);
+    lds_bytes[group] = grid_group_lds_bytes(group, n1, n2, ncell, n_items, dirs);
     if ((rc = launch_match_grid((const GridDesc*)(d + oT), n_mode, lds_bytes, s))) return rc;
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, dout, co.off, hipMemcpyDeviceToHost, s));
+    if (!hout_dev) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, dout, co.off, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     const int32_t* res = (const int32_t*)(ctx->pin_out.as<char>() + oN);
-    if (res[1] != 0) {   // cannot happen: the capacity above is exact
+    if (res[1] != 0 || res[0] < 0) {   // cannot happen: the capacity above is an upper bound
         set_last_error("%s:%d: matchGrid candidate store overflow (%d slots provided)", __FILE__, __LINE__, (int)pairs);
         return PLSLAM_ERANGE;
     }
