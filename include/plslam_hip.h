@@ -233,8 +233,10 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
  * Every pointer of a problem is a DEVICE pointer; d1 / d2 must be 16-byte aligned.  pair_capacity sizes the
  * kernel's candidate store (mutual problems only; 0 otherwise): rows are handled in blocks of 1024 and a block
  * needs 1024 x (the number of grid items -- duplicates and out-of-range items included -- inside the windows of
- * its fullest row) entries of 4 bytes.  A problem that exceeds it matches nothing, gets n_matches = -1 and is
- * counted by plslam_grid_plan_overflows. */
+ * its fullest row) entries of 4 bytes.  That size is always sufficient.  A problem whose candidates do not fit
+ * matches nothing, gets n_matches = -1 and is counted by plslam_grid_plan_overflows.  (Problems of at most 2048 x 2048
+ * rows whose tables fit the LDS keep their candidates there and use the store only for the excess: they may succeed
+ * with less.) */
 typedef struct plslam_grid_problem {
     const uint8_t* d1;
     const uint8_t* d2;

@@ -16,23 +16,30 @@
 // candidates go to the lowest i2 (upstream: the iteration order of a std::unordered_set<int>, implementation-
 // defined).
 //
-// One workgroup of 1024 lanes per problem; a lane owns rows tid, tid + 1024, ... and keeps their best / second
-// best keys to itself, so the only shared state is one word per column.  A problem is a few 10^4 distances: what
-// costs is the length of dependent memory chains and the address rate of scattered loads, so the grid's
-// cell_start, its items, the desc2 rows and the per-column / per-row words live in LDS whenever they fit
-// (64 x 48 cells, 1500 + 1500 rows: 90 KB); the same code runs on global scratch when they do not.
-//   PA  per row: candidates in batches of 4, d = popcount(desc1[i1] ^ desc2[i2]).  Without bestLRMatches the
-//       best two (d << 23 | i2) keys are folded on the spot.  With it the candidates (one word each) go to the
-//       lane's slots of a transposed store -- slot k of lane t at [k][t], every access coalesced.
-//   PB  record passes (bestLRMatches only; the first one's proposals are made by PA as it goes).  state[i2] = the
-//       column's newest record (i1 << 9 | d), none at first.  When the stored candidates fit the LDS that the items
-//       and desc2 rows no longer need, they are first moved there (compact, one run per row).
-//       Each pass streams a row's remaining candidates once: a candidate that IS its column's state was installed by
-//       the previous pass -- it is live and joins the row's best two; a candidate below the state's distance proposes
-//       itself with an LDS atomic min of (i1 << 9 | d) (the smallest ROW below the last record's distance is the
-//       next record) and is kept, the others are dropped from the store.  A sweep over the columns then installs the
-//       proposals.  The loop ends when a sweep installs nothing: about ln(candidates per column) + 2 passes over
-//       geometrically shrinking lists.  The final state is the column's lexicographic minimum (d, i1) = matches_21.
+// One workgroup of 1024 lanes per problem (256 for problems of at most 256 rows).  A problem is a few 10^4 distances:
+// what costs is the length of dependent memory chains and the address rate of scattered loads, so the grid's cell_start,
+// its items, the desc2 rows (and line directions) and the per-column / per-row words live in LDS whenever they fit
+// (64 x 48 cells, 1500 + 1500 rows: 96 KB); the same code runs on global scratch when they do not.
+//   PA  a lane per row: candidates in batches of 4, d = popcount(desc1[i1] ^ desc2[i2]).  Without bestLRMatches the
+//       best two (d << 23 | i2) keys are folded on the spot.  With it every candidate proposes itself as its column's
+//       first record (atomic min of i1 << 9 | d: the smallest row wins) and is kept for the record passes:
+//       * FLAT mode (everything in LDS, at most 2048 x 2048 rows -- the shipped sizes): a candidate is one word that names
+//         its row, d << 22 | i1 << 11 | i2, appended to the region of the wave that found it in the LDS that is still free
+//         (its share of the global store takes what does not fit).  colbest[i2] = the smallest (d, i1) shown for the column
+//         so far: a candidate that an EARLIER row matches or beats is dead whatever happens later and is never stored.
+//       * otherwise: one word per candidate in the lane's slots of a transposed global store -- slot k of lane t at
+//         [k][t], every access coalesced.
+//   PB  record passes (bestLRMatches only).  A candidate that IS its column's newest record is live: it joins its row's
+//       best two and leaves; one that is still below the record's distance proposes itself as the next record (the
+//       smallest ROW below the last record's distance) and stays; the others are dropped.  About ln(candidates per column)
+//       + 2 passes over geometrically shrinking lists; the last record of a column is its lexicographic minimum
+//       (d, i1) = matches_21.
+//       * FLAT mode: candidate-parallel -- each wave streams its own region and compacts the survivors in place (ballot +
+//         prefix), so the lanes are evenly loaded whatever the rows' list lengths; records carry their pass number in the
+//         top bits and alternate between two arrays, so nothing is cleared or installed between passes (one barrier per
+//         pass); rows' best two via two LDS atomic mins; when at most 256 candidates are left one wave finishes alone.
+//       * otherwise: a lane streams its rows' slots (row-private best two), a sweep over the columns installs the
+//         proposals between passes.
 //   PC  per row: ratio test `best_d < best_d2 * nnr` in fp64 (int * double upstream; best_d2 = INT_MAX when absent,
 //       so a lone live candidate passes), mutual check against the column's final state, count.
 // Duplicated candidates (an item sitting in several cells of the window, the two windows of a line overlapping) are
@@ -172,6 +179,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     __shared__ uint32_t s_part[NT];
     __shared__ uint32_t s_max2[2];
     __shared__ uint32_t s_tail[GRID_TAIL];
+    __shared__ uint32_t s_cur[NT / 64];              // flat mode: candidates appended to each wave's region
     PLSLAM_AS_LDS uint32_t* s_dyn = (PLSLAM_AS_LDS uint32_t*)reinterpret_cast<uint32_t*>(s_dyn4);
 
     const GridDesc g = probs[blockIdx.x];
@@ -180,7 +188,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     const int32_t ncell = g.cols * g.rows;
     const int32_t n_rounds = (n1 + NT - 1) / NT;
 #ifdef PLSLAM_GRID_TIMING   // experiment builds only: phase boundaries in 10 ns ticks, printed by one lane
-    uint64_t ts[6], t_move = 0;
+    uint64_t ts[6], t_move = 0, tp[16];
+    const uint64_t c_start = clock64();
     int nts = 0, npass = 0;
 #define GRID_STAMP() do { if (nts < 6) ts[nts++] = wall_clock64(); } while (0)
 #else
@@ -225,6 +234,33 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     PLSLAM_AS_GLOBAL uint32_t* round_k = rcnt + n1;                          // n_rounds
     PLSLAM_AS_GLOBAL uint32_t* store = round_k + n_rounds;  // 2 x pair_cap words; round r at 1024 * sum_{r' < r} round_k
 
+    // ---- "flat" mode (everything in LDS, bestLRMatches, row and column numbers of at most 11 bits): a candidate is ONE word
+    // that names its row, d << 22 | i1 << 11 | i2; PA appends the candidates of a wave's rows to the wave's own region of the
+    // LDS that is still free (spilling into its share of the global store if it must), the record passes run on those
+    // regions.  colbest[i2] = the smallest (d, i1) any row has shown for the column so far: a candidate that some EARLIER row
+    // matches or beats is dead whatever else happens and is never stored.
+    constexpr uint32_t NW = NT / 64;
+    const uint32_t wv = (uint32_t)tid >> 6;
+    bool flat = false;
+    uint32_t seg_words = 0, tail_cap = 0, reg_off = 0;
+    PLSLAM_AS_LDS uint32_t* colbest = nullptr;
+    if constexpr (MODE == 2) {
+        flat = g.mutual && n1 <= 2048 && n2 <= 2048;
+        const uint32_t pa_end = d2_off + 8u * (uint32_t)n2 + (has_dirs ? 4u * (uint32_t)n2 : 0u);
+        colbest = s_dyn + pa_end;
+        reg_off = pa_end + (uint32_t)n2;
+        seg_words = lds_words > reg_off ? (lds_words - reg_off) / NW : 0u;
+        tail_cap = (uint32_t)g.pair_cap / NW;
+    }
+    // candidate k of wave w: its LDS region first, then its share of the global store
+    auto cand_load = [&](uint32_t w, uint32_t k) -> uint32_t {
+        return k < seg_words ? s_dyn[reg_off + w * seg_words + k] : store[(size_t)w * tail_cap + (k - seg_words)];
+    };
+    auto cand_store = [&](uint32_t w, uint32_t k, uint32_t v) {
+        if (k < seg_words) s_dyn[reg_off + w * seg_words + k] = v;
+        else store[(size_t)w * tail_cap + (k - seg_words)] = v;
+    };
+
     // ---- P0: tables ----
     if constexpr (LDS) {
         for (int32_t j = tid; j <= ncell; j += NT) s_dyn[2 * (n2 + n1) + j] = (uint32_t)g_cell_start[j];
@@ -243,7 +279,9 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     for (int32_t j = tid; j < n2; j += NT) {
         P.state[j] = KEY_NONE;
         P.next[j] = KEY_NONE;
+        if (flat) colbest[j] = KEY_NONE;
     }
+    if (tid < (int)NW) s_cur[tid] = 0u;
     for (int32_t i = tid; i < n1; i += NT) {
         P.row_k1[i] = KEY_NONE;
         P.row_k2[i] = KEY_NONE;
@@ -262,7 +300,66 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     // ---- PA: distances ----
     uint32_t store_words = 0;        // slots claimed so far (uniform)
     uint32_t has_items = 0;          // bit r: this lane's row of round r has grid items inside its windows (mutual only)
-    for (int32_t r = 0; r < n_rounds; ++r) {
+    if (flat) {
+        const bool count_empty = 2147483647.0 < 2147483647.0 * g.nnr;     // PC's nnr > 1 rule needs to know (cell_start is gone by then)
+        for (int32_t r = 0; r < n_rounds; ++r) {
+            const int32_t i1 = r * NT + tid;
+            if (i1 >= n1) continue;
+            if (count_empty && r < 32 && count_items(g, P, i1) > 0u) has_items |= 1u << r;
+            const u32x4 qa = g_d1[2 * (int64_t)i1], qb = g_d1[2 * (int64_t)i1 + 1];
+            for_candidates(g, P, i1, [&](const int32_t (&i2)[CB]) {
+                u32x4 ta[CB], tb[CB];
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {
+                    const int64_t t = i2[j] < 0 ? 0 : i2[j];
+                    ta[j] = P.d2[2 * t];
+                    tb[j] = P.d2[2 * t + 1];
+                }
+                uint32_t d[CB], was[CB];
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+                    d[j] = (uint32_t)(__popc(qa.x ^ ta[j].x) + __popc(qa.y ^ ta[j].y) + __popc(qa.z ^ ta[j].z) +
+                                      __popc(qa.w ^ ta[j].w) + __popc(qb.x ^ tb[j].x) + __popc(qb.y ^ tb[j].y) +
+                                      __popc(qb.z ^ tb[j].z) + __popc(qb.w ^ tb[j].w));
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {                        // the batch's atomics back to back, one wait
+                    was[j] = 0u;                                      // (row 0 at distance 0 beats everything: "dead")
+                    if (i2[j] >= 0) {
+                        // the first record pass, fused: the smallest row of a column is its first record
+                        atomicMin((uint32_t*)&P.next[i2[j]], ((uint32_t)i1 << REC_D_BITS) | d[j]);
+                        was[j] = atomicMin((uint32_t*)&colbest[i2[j]], (d[j] << 11) | (uint32_t)i1);
+                    }
+                }
+                bool keep[CB];
+                uint32_t n_keep = 0;
+#pragma unroll
+                for (int j = 0; j < CB; ++j) {
+                    // stored unless an earlier row is known to match or beat it (or the slot is empty)
+                    keep[j] = i2[j] >= 0 && !((was[j] >> 11) <= d[j] && (was[j] & 2047u) < (uint32_t)i1);
+                    n_keep += keep[j] ? 1u : 0u;
+                }
+                if (n_keep) {
+                    uint32_t pos = atomicAdd(&s_cur[wv], n_keep);     // one claim per batch
+#pragma unroll
+                    for (int j = 0; j < CB; ++j)
+                        if (keep[j]) {
+                            if (pos < seg_words + tail_cap) cand_store(wv, pos, (d[j] << 22) | ((uint32_t)i1 << 11) | (uint32_t)i2[j]);
+                            ++pos;
+                        }
+                }
+            });
+        }
+        __threadfence();
+        if (__syncthreads_or(s_cur[wv] > seg_words + tail_cap)) {       // a wave's share of the store does not fit: report, match nothing
+            for (int32_t i = tid; i < n1; i += NT) g_matches[i] = -1;
+            if (tid == 0) {
+                if (g.n_matches) *g.n_matches = -1;
+                if (g.status) atomicAdd(g.status, 1);
+            }
+            return;
+        }
+    }
+    for (int32_t r = 0; r < (flat ? 0 : n_rounds); ++r) {
         const int32_t i1 = r * NT + tid;
         uint32_t depth = 0;
         if (g.mutual) {              // slot depth of this round = the largest item count of one of its rows
@@ -382,165 +479,127 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         };
 
         int more = sweep();               // installs the proposals PA made: every column's first record
-        bool in_lds = false;
-        if constexpr (MODE == 2) {
-            // Everything behind the column / row words -- cell_start, the items, the desc2 rows -- is dead now.  If the
-            // stored candidates fit there and row and column numbers fit 11 bits each (a candidate is then ONE word that
-            // names its row: d << 22 | i1 << 11 | i2), the passes run candidate-parallel on LDS alone.
-            const uint32_t tables = 2u * (uint32_t)n2 + 2u * (uint32_t)n1;
-            PLSLAM_AS_LDS uint32_t* lstore = s_dyn + tables;
-            const uint32_t room = lds_words > tables ? lds_words - tables : 0u;
-            // where a lane's rows go in the flat array: exclusive scan of the lanes' candidate counts (any order of the
-            // rows will do)
-            uint32_t mine = 0;
-            for (int32_t r = 0; r < n_rounds; ++r) mine += r * NT + tid < n1 ? rcnt[r * NT + tid] : 0u;
-            uint32_t incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t v = (uint32_t)__shfl_up((int)incl, off);
-                if (lane >= off) incl += v;
+        if (flat) {
+            // ---- candidate-parallel passes: each wave works on its own region and compacts the survivors of a pass in
+            // place (ballot + prefix: no other wave touches the region).
+            // A column's record carries its pass number in the top bits, newest = smallest:
+            //     rec(t, i1, d) = (0xFFF - t) << 20 | i1 << 9 | d,
+            // pass t reads the records of pass t-1 from one array and proposes with an atomic min into the other: a proposal
+            // of pass t beats whatever pass t-2 left there, so nothing is cleared and nothing is installed -- one barrier per
+            // pass.  (Every candidate that survives pass t-1 proposed in it: its column's word in the array pass t reads IS
+            // a pass t-1 record.  A column has at most 257 records: the pass number fits.)  Live candidates join their
+            // row's best two with two LDS atomic mins: k1 takes the key, whichever of (old k1, key) lost goes to k2 -- every
+            // key of the row except the final minimum reaches k2 exactly once.
+            for (int32_t i2 = tid; i2 < n2; i2 += NT) {                // the first records: pass 0
+                const uint32_t v = P.state[i2];
+                if (v != KEY_NONE) P.state[i2] = 0xFFF00000u | v;
             }
-            if (lane == 63) s_part[tid >> 6] = incl;
             __syncthreads();
-            uint32_t pre = 0, total = 0;
-            for (int w = 0; w < NT / 64; ++w) {
-                const uint32_t v = s_part[w];
-                pre += w < (tid >> 6) ? v : 0u;
-                total += v;
-            }
-            in_lds = total <= room && n1 <= 2048 && n2 <= 2048;      // uniform
-            if (in_lds) {
-                uint32_t run = pre + incl - mine, off = 0;
-                for (int32_t r = 0; r < n_rounds; ++r) {              // transposed global slots -> the flat LDS array
-                    const int32_t i1 = r * NT + tid;
-                    if (i1 < n1) {
-                        const uint32_t cnt = rcnt[i1];
-                        PLSLAM_AS_GLOBAL const uint32_t* slot = store + off;
-                        PLSLAM_AS_LDS uint32_t* dstp = lstore + run;
-                        for (uint32_t k0 = 0; k0 < cnt; k0 += PB_BATCH) {
-                            uint32_t key[PB_BATCH];
-#pragma unroll
-                            for (int j = 0; j < PB_BATCH; ++j) key[j] = k0 + j < cnt ? slot[slot_index<NT>(k0 + j, tid)] : 0u;
-#pragma unroll
-                            for (int j = 0; j < PB_BATCH; ++j)
-                                if (k0 + j < cnt)
-                                    dstp[k0 + j] = ((key[j] >> KEY_IDX_BITS) << 22) | ((uint32_t)i1 << 11) | (key[j] & 2047u);
-                        }
-                        run += cnt;
-                    }
-                    off += round_k[r] * NT;
-                }
-                // ---- candidate-parallel passes.  Each wave owns an equal slice of the flat array and compacts the
-                // survivors of a pass in place (ballot + prefix: no other wave touches the slice), so every lane has the
-                // same number of candidates whatever the rows' list lengths.
-                // A column's record carries its pass number in the top bits, newest = smallest:
-                //     rec(t, i1, d) = (0xFFF - t) << 20 | i1 << 9 | d,
-                // pass t reads the records of pass t-1 from one array and proposes with an atomic min into the other: a
-                // proposal of pass t beats whatever pass t-2 left there, so nothing is cleared and nothing is installed --
-                // one barrier per pass.  (Every candidate that survives pass t-1 proposed in it: its column's word in the
-                // array pass t reads IS a pass t-1 record.  A column has at most 257 records: the pass number fits.)
-                // Live candidates join their row's best two with two LDS atomic mins: k1 takes the key, whichever of
-                // (old k1, key) lost goes to k2 -- every key of the row except the final minimum reaches k2 exactly once.
-                for (int32_t i2 = tid; i2 < n2; i2 += NT) {            // the first records: pass 0
-                    const uint32_t v = P.state[i2];
-                    if (v != KEY_NONE) P.state[i2] = 0xFFF00000u | v;
-                }
-                __syncthreads();
 #ifdef PLSLAM_GRID_TIMING
-                t_move = wall_clock64();
+            t_move = wall_clock64();
 #endif
-                constexpr uint32_t NW = NT / 64;
-                constexpr int UN = 4;                                  // chunks of 64 candidates in flight per lane
-                const uint32_t wv = (uint32_t)tid >> 6;
-                const uint32_t seg_b = (uint32_t)((uint64_t)total * wv / NW), seg_e = (uint32_t)((uint64_t)total * (wv + 1) / NW);
-                const uint64_t below = (1ull << lane) - 1ull;
-                // one pass over `alive` candidates at `seg` (in place); returns the survivors
-                auto run_pass = [&](PLSLAM_AS_LDS uint32_t* seg, uint32_t alive, uint32_t t) -> uint32_t {
-                    auto rd = (t & 1) ? P.state : P.next;
-                    auto wr = (t & 1) ? P.next : P.state;
-                    const uint32_t tag_rd = (0xFFFu - (t - 1)) << 20, tag_wr = (0xFFFu - t) << 20;
-                    uint32_t out = 0;
-                    for (uint32_t base = 0; base < alive; base += 64 * UN) {
-                        uint32_t c[UN], rec[UN];
-                        bool keep[UN];
+            constexpr int UN = 4;                                      // chunks of 64 candidates in flight per lane
+            const uint64_t below = (1ull << lane) - 1ull;
+            // one pass over the `alive` candidates of wave w's region (s_tail when w == NW); returns the survivors
+            auto run_pass = [&](uint32_t w, uint32_t alive, uint32_t t) -> uint32_t {
+                auto rd = (t & 1) ? P.state : P.next;
+                auto wr = (t & 1) ? P.next : P.state;
+                const uint32_t tag_rd = (0xFFFu - (t - 1)) << 20, tag_wr = (0xFFFu - t) << 20;
+                uint32_t out = 0;
+                for (uint32_t base = 0; base < alive; base += 64 * UN) {
+                    uint32_t c[UN], rec[UN];
+                    bool keep[UN];
+                    // (uniform) the whole step inside the LDS region: plain LDS traffic, all loads in flight together
+                    const bool in_lds = w != NW && base + 64 * UN <= seg_words;
+                    PLSLAM_AS_LDS uint32_t* reg = s_dyn + reg_off + (w == NW ? 0u : w) * seg_words;
 #pragma unroll
-                        for (int j = 0; j < UN; ++j) c[j] = base + 64 * j + lane < alive ? seg[base + 64 * j + lane] : KEY_NONE;
+                    for (int j = 0; j < UN; ++j) {
+                        const uint32_t k = base + 64 * j + lane;
+                        c[j] = k >= alive ? KEY_NONE : in_lds ? reg[k] : w == NW ? s_tail[k] : cand_load(w, k);
+                    }
 #pragma unroll
-                        for (int j = 0; j < UN; ++j) rec[j] = rd[c[j] == KEY_NONE ? 0u : c[j] & 2047u];
+                    for (int j = 0; j < UN; ++j) rec[j] = rd[c[j] == KEY_NONE ? 0u : c[j] & 2047u];
 #pragma unroll
-                        for (int j = 0; j < UN; ++j) {
-                            const uint32_t i2 = c[j] & 2047u, i1 = (c[j] >> 11) & 2047u, d = c[j] >> 22;
-                            const uint32_t me = (i1 << REC_D_BITS) | d;
-                            keep[j] = false;
-                            if (c[j] != KEY_NONE) {
-                                if (rec[j] == (tag_rd | me)) {                // the record of the last pass: live
-                                    const uint32_t key = (d << KEY_IDX_BITS) | i2;
-                                    const uint32_t was = atomicMin((uint32_t*)&P.row_k1[i1], key);
-                                    // (a duplicate of the key -- an item in two cells of the window -- changes nothing)
-                                    if (was != key) atomicMin((uint32_t*)&P.row_k2[i1], was > key ? was : key);
-                                } else if (d < (rec[j] & REC_D_MASK)) {       // still below it: propose, stay
-                                    atomicMin((uint32_t*)&wr[i2], tag_wr | me);
-                                    keep[j] = true;
-                                }
+                    for (int j = 0; j < UN; ++j) {
+                        const uint32_t i2 = c[j] & 2047u, i1 = (c[j] >> 11) & 2047u, d = c[j] >> 22;
+                        const uint32_t me = (i1 << REC_D_BITS) | d;
+                        keep[j] = false;
+                        if (c[j] != KEY_NONE) {
+                            if (rec[j] == (tag_rd | me)) {                    // the record of the last pass: live
+                                const uint32_t key = (d << KEY_IDX_BITS) | i2;
+                                const uint32_t was = atomicMin((uint32_t*)&P.row_k1[i1], key);
+                                // (a duplicate of the key -- an item in two cells of the window -- changes nothing)
+                                if (was != key) atomicMin((uint32_t*)&P.row_k2[i1], was > key ? was : key);
+                            } else if (d < (rec[j] & REC_D_MASK)) {           // still below it: propose, stay
+                                atomicMin((uint32_t*)&wr[i2], tag_wr | me);
+                                keep[j] = true;
                             }
                         }
+                    }
 #pragma unroll
-                        for (int j = 0; j < UN; ++j) {                       // every read of this step is done: in place
-                            const uint64_t m = __ballot(keep[j]);
-                            if (keep[j]) seg[out + (uint32_t)__popcll(m & below)] = c[j];
-                            out += (uint32_t)__popcll(m);
+                    for (int j = 0; j < UN; ++j) {                           // every read of this step is done: in place
+                        const uint64_t m = __ballot(keep[j]);
+                        if (keep[j]) {
+                            const uint32_t k = out + (uint32_t)__popcll(m & below);
+                            if (in_lds) reg[k] = c[j];
+                            else if (w == NW) s_tail[k] = c[j];
+                            else cand_store(w, k, c[j]);
                         }
-                    }
-                    return out;
-                };
-                uint32_t alive = seg_e - seg_b, t = 1;
-                bool tail = false;
-                while (more) {
-                    alive = run_pass(lstore + seg_b, alive, t);
-                    ++t;
-#ifdef PLSLAM_GRID_TIMING
-                    ++npass;
-#endif
-                    PLSLAM_AS_LDS uint32_t* left_of = (PLSLAM_AS_LDS uint32_t*)s_part + (t & 1u) * NW;   // alternating: one barrier per pass
-                    if (lane == 0) left_of[wv] = alive;
-                    __syncthreads();
-                    uint32_t left = 0;
-                    for (uint32_t w = 0; w < NW; ++w) left += left_of[w];
-                    more = left != 0u;
-                    if (left != 0u && left <= GRID_TAIL) {               // few survivors: no more workgroup barriers
-                        tail = true;
-                        break;
+                        out += (uint32_t)__popcll(m);
                     }
                 }
-                if (tail) {
-                    // the last passes of a problem carry a handful of candidates each: wave 0 gathers them and finishes
-                    // alone (its LDS operations are ordered; the other waves wait at the barrier below)
-                    if (wv == 0) {
-                        uint32_t n_tail = 0;
-                        PLSLAM_AS_LDS const uint32_t* left_of = (PLSLAM_AS_LDS const uint32_t*)s_part + (t & 1u) * NW;
-                        for (uint32_t w = 0; w < NW; ++w) {
-                            const uint32_t cw = left_of[w], from = (uint32_t)((uint64_t)total * w / NW);
-                            for (uint32_t k = lane; k < cw; k += 64) s_tail[n_tail + k] = lstore[from + k];
-                            n_tail += cw;
-                        }
-                        while (n_tail) {
-                            n_tail = run_pass((PLSLAM_AS_LDS uint32_t*)s_tail, n_tail, t);
-                            ++t;
+                return out;
+            };
+            uint32_t alive = s_cur[wv], t = 1;
+            bool tail = false;
+            while (more) {
+                alive = run_pass(wv, alive, t);
+                ++t;
 #ifdef PLSLAM_GRID_TIMING
-                            ++npass;
+                if (npass < 16) tp[npass] = wall_clock64();
+                ++npass;
 #endif
-                        }
-                    }
-                    __syncthreads();
+                PLSLAM_AS_LDS uint32_t* left_of = (PLSLAM_AS_LDS uint32_t*)s_part + (t & 1u) * NW;   // alternating: one barrier per pass
+                if (lane == 0) left_of[wv] = alive;
+                if (alive > seg_words) __threadfence();                // survivors in the global share: wave 0 may gather them
+                __syncthreads();
+                uint32_t left = 0;
+                for (uint32_t w = 0; w < NW; ++w) left += left_of[w];
+                more = left != 0u;
+                if (left != 0u && left <= GRID_TAIL) {                   // few survivors: no more workgroup barriers
+                    tail = true;
+                    break;
                 }
-                for (int32_t i2 = tid; i2 < n2; i2 += NT) {                // the newest record of either array, untagged
-                    const uint32_t a = P.state[i2], b = P.next[i2], v = a < b ? a : b;
-                    P.state[i2] = v == KEY_NONE ? KEY_NONE : v & 0xFFFFFu;
+            }
+            if (tail) {
+                // the last passes of a problem carry a handful of candidates each: wave 0 gathers them and finishes alone
+                // (its LDS operations are ordered; the other waves wait at the barrier below)
+                if (wv == 0) {
+                    uint32_t n_tail = 0;
+                    PLSLAM_AS_LDS const uint32_t* left_of = (PLSLAM_AS_LDS const uint32_t*)s_part + (t & 1u) * NW;
+                    for (uint32_t w = 0; w < NW; ++w) {
+                        const uint32_t cw = left_of[w];
+                        for (uint32_t k = lane; k < cw; k += 64) s_tail[n_tail + k] = cand_load(w, k);
+                        n_tail += cw;
+                    }
+                    while (n_tail) {
+                        n_tail = run_pass(NW, n_tail, t);
+                        ++t;
+#ifdef PLSLAM_GRID_TIMING
+                        if (npass < 16) tp[npass] = wall_clock64();
+                        ++npass;
+#endif
+                    }
                 }
                 __syncthreads();
             }
+            for (int32_t i2 = tid; i2 < n2; i2 += NT) {                  // the newest record of either array, untagged
+                const uint32_t a = P.state[i2], b = P.next[i2], v = a < b ? a : b;
+                P.state[i2] = v == KEY_NONE ? KEY_NONE : v & 0xFFFFFu;
+            }
+            __syncthreads();
         }
-        if (!in_lds) {
+        if (!flat) {
             int flip = 0;
             while (more) {
                 // survivors of a pass go to the other half of the store: reads and writes never alias, so a batch's
@@ -593,9 +652,15 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     if (tid == 0 && g.n_matches) *g.n_matches = (int32_t)s_part[0];
     GRID_STAMP();
 #ifdef PLSLAM_GRID_TIMING
-    if (tid == 0 && blockIdx.x == 0)
+    if (tid == 0 && (blockIdx.x == 0 || (blockIdx.x & 1023) == 600))
         printf("[k_match_grid n1=%d n2=%d] P0 %d PA %d PB %d (move %d, %d passes) PC %d (x10 ns)\n", n1, n2, (int)(ts[1] - ts[0]),
                (int)(ts[2] - ts[1]), (int)(ts[3] - ts[2]), t_move ? (int)(t_move - ts[2]) : -1, npass, (int)(ts[4] - ts[3]));
+    if (tid == 0 && (blockIdx.x == 0 || (blockIdx.x & 1023) == 600) && t_move) {
+        printf("   passes:");
+        for (int i = 0; i < npass && i < 16; ++i) printf(" %d", (int)(tp[i] - (i ? tp[i - 1] : t_move)));
+        printf(" | stored %u of wave 0, region %u words | %d shader MHz\n", s_cur[0], seg_words,
+               (int)((clock64() - c_start) / ((wall_clock64() - ts[0]) / 100)));
+    }
 #endif
 #undef GRID_STAMP
 }
@@ -628,6 +693,7 @@ size_t grid_lds_bytes(int mode, int32_t n1, int32_t n2, int64_t ncell, int32_t n
         w = (w + (size_t)n_items + 3) & ~size_t(3);
         w += 8 * (size_t)n2;
         if (dirs) w += 4 * (size_t)n2;          // the directions of the desc2 lines (2 doubles each)
+        w += (size_t)n2;                        // flat mode: the best (d, row) seen per column while PA runs
     }
     return w * 4;
 }
