@@ -429,7 +429,7 @@ def main():
                 "mfma_form": form, "kernel": kernel_name, "kernel_source_hash": src_hash,
                 "parallelism": f"pairs sharded over {world} rank(s); per-step RCCL gather of the match tables "
                                "to rank 0, overlapped with the next step" if use_dist else
-                               ("single GPU; consecutive steps alternate two output buffers / HIP streams" if overlap
+                               ("single GPU; consecutive steps alternate two output buffers; every scan on one HIP stream, the stages behind a scan (merge, finalize, gates) on a second, high-priority one: they run under the next step's scan" if overlap
                                 else "single GPU"),
             },
             "roofline": roofline,

@@ -169,6 +169,12 @@ int plslam_match_plan_create(plslam_ctx* ctx, const plslam_match_problem* probs,
                              plslam_match_plan** out);
 /* Enqueues scan + finalize on `stream` (hipStream_t; NULL = context stream).  Asynchronous. */
 int plslam_match_plan_run(plslam_match_plan* plan, void* stream);
+/* The same with the scan kernel(s) on `scan_stream` and the stages behind them (merge of the column partials, finalize,
+ * stereo gates, count scatter) on `post_stream`: a stream of runs -- of several plans or of this one -- then overlaps
+ * each run's last stages (HBM-bound) with the next run's scan (instruction-issue-bound).  Ordering is the plan's
+ * business: the stages wait for their scan, and the plan's next scan (split or not) waits for them.  Results are
+ * complete when `post_stream` has drained. */
+int plslam_match_plan_run_split(plslam_match_plan* plan, void* scan_stream, void* post_stream);
 /* With profiling on, every run brackets each kernel with HIP events on the launch stream. */
 int plslam_match_plan_set_profiling(plslam_match_plan* plan, int enable);
 /* Synchronises the recorded events and returns accumulated kernel milliseconds since the

@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "plslam_ctx_create", "plslam_ctx_destroy", "plslam_ctx_set_option", "plslam_ctx_get_option",
     "plslam_ctx_device_info",
     "plslam_knn2_hamming256", "plslam_match", "plslam_match_prior", "plslam_match_batched",
-    "plslam_match_plan_create", "plslam_match_plan_run", "plslam_match_plan_set_profiling",
+    "plslam_match_plan_create", "plslam_match_plan_run", "plslam_match_plan_run_split", "plslam_match_plan_set_profiling",
     "plslam_match_plan_elapsed", "plslam_match_plan_info", "plslam_match_plan_dump", "plslam_match_plan_destroy",
     "plslam_lba_point_rows", "plslam_lba_line_rows", "plslam_lba_point_rows_dev",
     "plslam_lba_line_rows_dev", "plslam_lba_assemble", "plslam_lba_plan_create", "plslam_lba_plan_iterate",
@@ -179,6 +179,7 @@ def load() -> C.CDLL:
     L.plslam_match_batched.argtypes = [vp, vp, vp, vp, vp, i32, C.c_float, C.c_int, vp, vp]
     L.plslam_match_plan_create.argtypes = [vp, C.POINTER(MatchProblem), i32, C.POINTER(vp)]
     L.plslam_match_plan_run.argtypes = [vp, vp]
+    L.plslam_match_plan_run_split.argtypes = [vp, vp, vp]
     L.plslam_match_plan_set_profiling.argtypes = [vp, C.c_int]
     L.plslam_match_plan_elapsed.argtypes = [vp, C.POINTER(f64), C.POINTER(f64), C.POINTER(C.c_int64)]
     L.plslam_match_plan_info.argtypes = [vp, C.POINTER(PlanInfo)]
@@ -791,6 +792,11 @@ class MatchPlan:
 
     def run(self, stream: int = 0) -> None:
         _check(self._L.plslam_match_plan_run(self._h, stream or None), "plslam_match_plan_run")
+
+    def run_split(self, scan_stream: int, post_stream: int) -> None:
+        """The scan on one HIP stream, the stages behind it on another (they overlap the next run's scan)."""
+        _check(self._L.plslam_match_plan_run_split(self._h, scan_stream or None, post_stream or None),
+               "plslam_match_plan_run_split")
 
     def add_stereo_gates(self, gates) -> None:
         """The gate stage (StereoFrame::matchStereoPoints / matchStereoLines over the batch).  gates: iterable of dicts

@@ -108,6 +108,9 @@ struct plslam_match_plan {
     bool profiling = false;
     struct Ev { hipEvent_t e0, e1, e2; };
     std::vector<Ev> evs;
+    // split runs (plslam_match_plan_run_split): the scan on one stream, everything behind it on another
+    hipEvent_t scan_done = nullptr, post_done = nullptr;
+    bool post_pending = false;
     size_t ev_used = 0;
     double acc_scan_ms = 0, acc_fin_ms = 0;
     int64_t acc_runs = 0;
@@ -117,6 +120,10 @@ struct plslam_match_plan {
         gate_tables.release(); rowtmp.release();
         for (auto& e : evs) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2); }
         evs.clear();
+        if (scan_done) (void)hipEventDestroy(scan_done);
+        if (post_done) (void)hipEventDestroy(post_done);
+        scan_done = post_done = nullptr;
+        post_pending = false;
     }
 };
 
@@ -520,8 +527,21 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     return PLSLAM_OK;
 }
 
-static int plan_run(plslam_match_plan* P, hipStream_t s)
+// s: the scan kernel(s); sp: the stages behind them (merge of the column partials, finalize, gates, count scatter).  sp == s
+// is the plain run.  With two streams the stages behind the scan of one run overlap the scan of the NEXT run on `s` (another
+// plan, or this one: its next scan waits for this run's last stage, which reads what that scan overwrites): the scan is
+// bound by instruction issue, the stages behind it by HBM, and a workgroup slot the scan frees is taken by either.
+static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
 {
+    const bool split = sp != s;
+    if (split) {
+        if (!P->scan_done) PLSLAM_HIP_CHECK(hipEventCreateWithFlags(&P->scan_done, hipEventDisableTiming));
+        if (!P->post_done) PLSLAM_HIP_CHECK(hipEventCreateWithFlags(&P->post_done, hipEventDisableTiming));
+    }
+    if (P->post_pending) {            // an earlier split run: its last stage must be over before this scan rewrites its input
+        PLSLAM_HIP_CHECK(hipStreamWaitEvent(s, P->post_done, 0));
+        P->post_pending = false;
+    }
     plslam_match_plan::Ev* ev = nullptr;
     if (P->profiling) {
         if (P->ev_used == P->evs.size()) {
@@ -566,6 +586,11 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
         if (r) return r;
     }
     if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e1, s));   // e0..e1 = the scan kernel(s) alone
+    if (split) {
+        PLSLAM_HIP_CHECK(hipEventRecord(P->scan_done, s));
+        PLSLAM_HIP_CHECK(hipStreamWaitEvent(sp, P->scan_done, 0));
+        s = sp;
+    }
 
     r = P->sym_mfma && P->mfma_form != 1 ? launch_merge_partials16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, s)
                                          : launch_merge_partials(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s);
@@ -578,8 +603,11 @@ static int plan_run(plslam_match_plan* P, hipStream_t s)
         if (r) return r;
     }
     if (ev) PLSLAM_HIP_CHECK(hipEventRecord(ev->e2, s));
-    if (P->scatter_counts)
-        return launch_scatter_counts(P->d_counts_zero, P->d_count_dst, P->nprob, s);
+    if (P->scatter_counts && (r = launch_scatter_counts(P->d_counts_zero, P->d_count_dst, P->nprob, s))) return r;
+    if (split) {
+        PLSLAM_HIP_CHECK(hipEventRecord(P->post_done, s));
+        P->post_pending = true;
+    }
     return PLSLAM_OK;
 }
 
@@ -589,7 +617,7 @@ int match_problems_on_ctx_stream(plslam_ctx* ctx, const plslam_match_problem* pr
     if (!ctx->host_plan) ctx->host_plan = new (std::nothrow) plslam_match_plan();
     PLSLAM_REQUIRE(ctx->host_plan != nullptr, PLSLAM_ENOMEM);
     const int r = plan_build(ctx, probs, nprob, ctx->host_plan);
-    return r ? r : plan_run(ctx->host_plan, ctx->stream);
+    return r ? r : plan_run(ctx->host_plan, ctx->stream, ctx->stream);
 }
 }  // namespace plslam
 
@@ -799,7 +827,16 @@ int plslam_match_plan_run(plslam_match_plan* plan, void* stream)
 {
     PLSLAM_REQUIRE(plan != nullptr, PLSLAM_EINVAL);
     DeviceGuard g(plan->ctx->device);
-    return plan_run(plan, stream ? static_cast<hipStream_t>(stream) : plan->ctx->stream);
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : plan->ctx->stream;
+    return plan_run(plan, s, s);
+}
+
+int plslam_match_plan_run_split(plslam_match_plan* plan, void* scan_stream, void* post_stream)
+{
+    PLSLAM_REQUIRE(plan != nullptr, PLSLAM_EINVAL);
+    DeviceGuard g(plan->ctx->device);
+    hipStream_t s = scan_stream ? static_cast<hipStream_t>(scan_stream) : plan->ctx->stream;
+    return plan_run(plan, s, post_stream ? static_cast<hipStream_t>(post_stream) : s);
 }
 
 int plslam_match_plan_set_profiling(plslam_match_plan* plan, int enable)
@@ -922,7 +959,7 @@ int plslam_match_batched(plslam_ctx* ctx, const uint8_t* d1, const int32_t* off1
     plslam_match_plan& P = *ctx->host_plan;
     P.pin_tables = true;
     r = plan_build(ctx, probs.data(), B, &P);
-    if (!r) r = plan_run(&P, ctx->stream);
+    if (!r) r = plan_run(&P, ctx->stream, ctx->stream);
     if (!r) {
         hipError_t e = hipSuccess;
         void* dst1 = pinned ? ctx->pin_out.p : (void*)matches_12;
@@ -1423,7 +1460,7 @@ int plslam_match_pipeline_submit(plslam_match_pipeline* P, const void* arena_hos
     PLSLAM_HIP_CHECK(hipMemcpyAsync(sl.arena.p, arena_host, P->arena_bytes, hipMemcpyHostToDevice, P->s_up));
     PLSLAM_HIP_CHECK(hipEventRecord(sl.up, P->s_up));
     PLSLAM_HIP_CHECK(hipStreamWaitEvent(ctx->stream, sl.up, 0));
-    int r = plan_run(&sl.plan, ctx->stream);
+    int r = plan_run(&sl.plan, ctx->stream, ctx->stream);
     if (r) return r;
     // Results go home.  Page-locked host memory is written by a kernel on the compute stream, right behind the finalize:
     // a copy-engine download would queue between two uploads, and with the copy engines taking transfers in order the

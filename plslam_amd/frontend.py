@@ -126,14 +126,18 @@ class StereoBatchMatcher:
         # A real (non-NULL) HIP stream: the C ABI reads a NULL stream as "the context's own stream",
         # and torch's legacy default stream has handle 0.
         self.stream = torch.cuda.Stream(device=dev)
-        self.streams = [self.stream] + [torch.cuda.Stream(device=dev) for _ in range(n_buffers - 1)]
+        # streams[1] carries the short HBM-bound stages behind a scan in run_overlapped(): high priority, so that they
+        # take the workgroup slots the running scan frees instead of queueing behind its backlog
+        self.streams = [self.stream] + [torch.cuda.Stream(device=dev, priority=-1 if i == 0 else 0)
+                                        for i in range(n_buffers - 1)]
 
     def run_overlapped(self, k: int):
-        """Step k of a stream of independent batches: buffer k % n_buffers on its own HIP stream, so
-        that the ramp-up of step k+1 overlaps the drain / merge / finalize of step k.  Steps that
-        share a buffer are ordered by their stream.  Call synchronize_all() before reading."""
+        """Step k of a stream of independent batches into buffer k % n_buffers: every scan on one HIP stream, the
+        stages behind a scan (merge of the column partials, finalize, gates) on a second one -- they are HBM-bound and
+        run under the NEXT step's scan, which is bound by instruction issue.  The plans order themselves (a plan's
+        scan waits for the last stage of its previous run).  Call synchronize_all() before reading."""
         b = k % len(self.plans)
-        self.plans[b].run(self.streams[b].cuda_stream)
+        self.plans[b].run_split(self.streams[0].cuda_stream, self.streams[min(1, len(self.streams) - 1)].cuda_stream)
         return b
 
     def synchronize_all(self):

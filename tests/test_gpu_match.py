@@ -658,3 +658,27 @@ def test_entry_points_run_on_the_context_device_not_the_current_one():
     e = O.map2kf_match_fast("points", ocam, *a, 0.9, True, 1.5, 10, T.fast_cfg())
     np.testing.assert_array_equal(g[0], e[0])
     assert torch.cuda.current_device() == 0
+
+
+def test_split_runs_order_themselves(ctx, oracle):
+    """plslam_match_plan_run_split: scan on one stream, merge / finalize / gates on another.  The same plan run again
+    (split, then plain, on a third stream) waits for the stages of its previous run; the tables equal the oracle's."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n_orb, n_lbd, pairs = 700, 150, 96
+    stream = synth.stereo_stream(pairs, n_orb, n_lbd, seed=synth.SEED0 + 9, first_pair=0)
+    bm = frontend.StereoBatchMatcher(ctx, stream, nnr_p=0.8, nnr_l=0.8, mutual=True, device=dev, n_buffers=1)
+    s = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    plan = bm.plans[0]
+    for rep in range(4):
+        plan.run_split(s[0].cuda_stream, s[1].cuda_stream)
+        plan.run_split(s[1].cuda_stream, s[0].cuda_stream)        # roles swapped: still ordered by the plan's events
+        plan.run(s[2].cuda_stream)
+    for x in s:
+        x.synchronize()
+    sl = frontend.table_slices(n_orb, n_lbd)
+    got = bm.tables[0].cpu().numpy()
+    for i in range(0, pairs, 7):
+        for name, d1, d2 in frontend.pair_problems(stream["orb_l"], stream["orb_r"], stream["lbd_l"], stream["lbd_r"], i):
+            assert np.array_equal(got[i, sl[name]], oracle.match(d1, d2, 0.8, True)[0]), (i, name)
+    bm.close()
