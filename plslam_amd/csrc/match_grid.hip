@@ -180,6 +180,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     __shared__ uint32_t s_max2[2];
     __shared__ uint32_t s_tail[GRID_TAIL];
     __shared__ uint32_t s_cur[NT / 64];              // flat mode: candidates appended to each wave's region
+    __shared__ uint32_t s_seg[NT / 64 + 1];          // flat mode: first LDS word of each wave's region
     PLSLAM_AS_LDS uint32_t* s_dyn = (PLSLAM_AS_LDS uint32_t*)reinterpret_cast<uint32_t*>(s_dyn4);
 
     const GridDesc g = probs[blockIdx.x];
@@ -249,16 +250,28 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         const uint32_t pa_end = d2_off + 8u * (uint32_t)n2 + (has_dirs ? 4u * (uint32_t)n2 : 0u);
         colbest = s_dyn + pa_end;
         reg_off = pa_end + (uint32_t)n2;
-        seg_words = lds_words > reg_off ? (lds_words - reg_off) / NW : 0u;
         tail_cap = (uint32_t)g.pair_cap / NW;
     }
-    // candidate k of wave w: its LDS region first, then its share of the global store
-    auto cand_load = [&](uint32_t w, uint32_t k) -> uint32_t {
-        return k < seg_words ? s_dyn[reg_off + w * seg_words + k] : store[(size_t)w * tail_cap + (k - seg_words)];
+    // The free LDS is shared out in proportion to the rows a wave owns (row i1 belongs to lane i1 % NT: with 1500 rows on
+    // 1024 lanes waves 0..6 own 128 rows, the last ones 64).  seg_at(w) = first word of wave w's region, seg_at(NW) = end.
+    const uint32_t free_words = flat && lds_words > reg_off ? lds_words - reg_off : 0u;
+    auto seg_at = [&](uint32_t w) -> uint32_t {
+        uint32_t rows_before = 0;
+        for (int32_t r = 0; r < n_rounds; ++r) {
+            const int32_t left = n1 - r * NT;                             // rows of round r
+            rows_before += (uint32_t)(left < (int32_t)(64u * w) ? left : (int32_t)(64u * w));
+        }
+        return reg_off + free_words * rows_before / (uint32_t)(n1 > 0 ? n1 : 1);    // < 2^16 words x <= 2048 rows: 32 bits do
     };
-    auto cand_store = [&](uint32_t w, uint32_t k, uint32_t v) {
-        if (k < seg_words) s_dyn[reg_off + w * seg_words + k] = v;
-        else store[(size_t)w * tail_cap + (k - seg_words)] = v;
+    if (tid <= (int)NW) s_seg[tid] = seg_at((uint32_t)tid);             // (read behind P0's barrier)
+    uint32_t seg_first = 0;
+    // candidate k of this wave: its LDS region first, then its share of the global store
+    auto cand_load = [&](uint32_t k) -> uint32_t {
+        return k < seg_words ? s_dyn[seg_first + k] : store[(size_t)wv * tail_cap + (k - seg_words)];
+    };
+    auto cand_store = [&](uint32_t k, uint32_t v) {
+        if (k < seg_words) s_dyn[seg_first + k] = v;
+        else store[(size_t)wv * tail_cap + (k - seg_words)] = v;
     };
 
     // ---- P0: tables ----
@@ -287,6 +300,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         P.row_k2[i] = KEY_NONE;
     }
     __syncthreads();
+    seg_first = s_seg[wv];
+    seg_words = s_seg[wv + 1] - seg_first;                  // this wave's region
     if ((uint32_t)P.cs[ncell] > (uint32_t)g.n_items) {      // the grid holds more items than the caller declared
         for (int32_t i = tid; i < n1; i += NT) g_matches[i] = -1;
         if (tid == 0) {
@@ -343,7 +358,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
 #pragma unroll
                     for (int j = 0; j < CB; ++j)
                         if (keep[j]) {
-                            if (pos < seg_words + tail_cap) cand_store(wv, pos, (d[j] << 22) | ((uint32_t)i1 << 11) | (uint32_t)i2[j]);
+                            if (pos < seg_words + tail_cap) cand_store(pos, (d[j] << 22) | ((uint32_t)i1 << 11) | (uint32_t)i2[j]);
                             ++pos;
                         }
                 }
@@ -511,11 +526,11 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                     bool keep[UN];
                     // (uniform) the whole step inside the LDS region: plain LDS traffic, all loads in flight together
                     const bool in_lds = w != NW && base + 64 * UN <= seg_words;
-                    PLSLAM_AS_LDS uint32_t* reg = s_dyn + reg_off + (w == NW ? 0u : w) * seg_words;
+                    PLSLAM_AS_LDS uint32_t* reg = s_dyn + seg_first;        // (in_lds: w is this wave)
 #pragma unroll
                     for (int j = 0; j < UN; ++j) {
                         const uint32_t k = base + 64 * j + lane;
-                        c[j] = k >= alive ? KEY_NONE : in_lds ? reg[k] : w == NW ? s_tail[k] : cand_load(w, k);
+                        c[j] = k >= alive ? KEY_NONE : in_lds ? reg[k] : w == NW ? s_tail[k] : cand_load(k);
                     }
 #pragma unroll
                     for (int j = 0; j < UN; ++j) rec[j] = rd[c[j] == KEY_NONE ? 0u : c[j] & 2047u];
@@ -543,7 +558,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                             const uint32_t k = out + (uint32_t)__popcll(m & below);
                             if (in_lds) reg[k] = c[j];
                             else if (w == NW) s_tail[k] = c[j];
-                            else cand_store(w, k, c[j]);
+                            else cand_store(k, c[j]);
                         }
                         out += (uint32_t)__popcll(m);
                     }
@@ -578,8 +593,9 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                     uint32_t n_tail = 0;
                     PLSLAM_AS_LDS const uint32_t* left_of = (PLSLAM_AS_LDS const uint32_t*)s_part + (t & 1u) * NW;
                     for (uint32_t w = 0; w < NW; ++w) {
-                        const uint32_t cw = left_of[w];
-                        for (uint32_t k = lane; k < cw; k += 64) s_tail[n_tail + k] = cand_load(w, k);
+                        const uint32_t cw = left_of[w], first = s_seg[w], words = s_seg[w + 1] - first;
+                        for (uint32_t k = lane; k < cw; k += 64)
+                            s_tail[n_tail + k] = k < words ? s_dyn[first + k] : store[(size_t)w * tail_cap + (k - words)];
                         n_tail += cw;
                     }
                     while (n_tail) {
