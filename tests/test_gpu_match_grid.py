@@ -41,6 +41,21 @@ def test_random_scenes_vs_oracle(ctx, oracle, kind, ties, mutual):
     assert total > 0
 
 
+def test_many_small_random_problems_vs_oracle(ctx, oracle):
+    """Sweep of shapes for the LDS-resident mutual path (candidates filtered and kept per wave, candidate-parallel record
+    passes): coarse grids (long column lists, many duplicates of a line's item across cells), windows from one cell to the
+    whole grid, ties, 1 .. 2048 rows (the packed-candidate limit) on 256- and 1024-lane workgroups."""
+    r = _rng(99)
+    for it in range(48):
+        lines = it % 3 == 0
+        n1 = int(r.choice([1, 2, 63, 64, 65, 255, 256, 257, 700, 1024, 1025, 2048]))
+        n2 = int(r.choice([1, 2, 40, 333, 1500, 2048]))
+        cols, rows = [(1, 1), (2, 3), (7, 5), (16, 12), (64, 48)][it % 5]
+        w = tuple(int(x) for x in r.integers(0, 4, 4)) if it % 4 else (cols, cols, rows, rows)
+        c = (line_case if lines else point_case)(7000 + it, n1, n2, cols, rows, ties=it % 2 == 1)
+        _same(ctx, oracle, c, w, float(r.choice([0.6, 0.75, 0.9, 1.5])), True)
+
+
 @pytest.mark.parametrize("kind", ["points", "lines"])
 def test_tables_too_large_for_lds_run_on_global_scratch(ctx, oracle, kind):
     """A 400 x 100 grid (40 001 cell offsets) or 20 000 rows exceed the LDS budget of a workgroup: same code, tables in
