@@ -601,11 +601,29 @@ k_merge_partials16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict
     uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
     const uint32_t tw = ((uint32_t)j >> 5) & 63u;          // the keys still carry + tile within the 64-tile window
     if (j < sd.n2) {
+        // Only a block's BEST key is widened and merged; the second best overall is either the best of another block (b1)
+        // or the second key of the block that holds the overall best (kept raw in s0, widened once at the end): half the
+        // instructions per entry -- they matter because this kernel runs under the next step's instruction-bound scan.
+        // A "none" half (0xFFFF - tw) widens to a key with d >= 257: it loses every comparison and is mapped to KEY_NONE
+        // at the end.
+        auto wide = [](uint32_t k16, uint32_t wb) -> uint32_t {         // (d << 7 | row in block) -> (d << 23 | row)
+            return ((k16 << 16) & 0xFF800000u) | ((k16 & 63u) + 64u * wb);
+        };
+        const uint32_t tw2 = tw | (tw << 16);
+        uint32_t s0 = 0xFFFFFFFFu;
 #pragma unroll 8
         for (int wb = part_id; wb < nwb; wb += PARTS) {
-            const uint32_t e = part[(size_t)wb * n2p + j];
-            merge2(b0, b1, key16_to_key32((e & 0xFFFFu) - tw, 0u, (uint32_t)(64 * wb), 1u),
-                   key16_to_key32((e >> 16) - tw, 0u, (uint32_t)(64 * wb), 1u));
+            const uint32_t e = part[(size_t)wb * n2p + j] - tw2;          // both halves >= tw: no borrow between them
+            const uint32_t k = wide(e & 0xFFFFu, (uint32_t)wb);
+            s0 = k < b0 ? e : s0;
+            b1 = umin_(b1, umax_(b0, k));
+            b0 = umin_(b0, k);
+        }
+        if (b0 < (257u << KEY_IDX_BITS)) {
+            b1 = umin_(b1, wide(s0 >> 16, (b0 & KEY_IDX_MASK) >> 6));
+            if (b1 >= (257u << KEY_IDX_BITS)) b1 = KEY_NONE;
+        } else {
+            b0 = b1 = KEY_NONE;
         }
     }
     if (PARTS > 1) {
