@@ -507,8 +507,16 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     }
     for (const Piece& x : pc)
         if (x.bytes) memcpy(stg + x.off, x.src, x.bytes);
-    if ((r = P->tables.reserve(total))) return r;
-    char* base = P->tables.as<char>();
+    // Small plans of the host-pointer path: the kernels read their launch tables (a few hundred bytes per workgroup, once)
+    // straight from the page-locked image -- one copy-engine command less in front of the first kernel.  (Those callers
+    // synchronise the stream before the context builds its next plan, so the image is not rewritten under a kernel.)
+    char* base = nullptr;
+    if (stg == P->staging_pin.p && total <= (size_t(1) << 14)) base = static_cast<char*>(mapped_device_pointer(stg));
+    const bool tables_in_place = base != nullptr;
+    if (!tables_in_place) {
+        if ((r = P->tables.reserve(total))) return r;
+        base = P->tables.as<char>();
+    }
     P->d_scans = reinterpret_cast<ScanDesc*>(base + pc[0].off);
     P->d_syms = reinterpret_cast<SymDesc*>(base + pc[1].off);
     P->d_probs = reinterpret_cast<ProblemDesc*>(base + pc[2].off);
@@ -523,7 +531,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     // P->staging outlives the copy (it is a member), so no synchronisation is needed here; the
     // copy is ordered before the kernels of plan_run when they use the same stream, and the public
     // plan_create synchronises once so that any stream may be used afterwards.
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(base, stg, total, hipMemcpyHostToDevice, ctx->stream));
+    if (!tables_in_place) PLSLAM_HIP_CHECK(hipMemcpyAsync(base, stg, total, hipMemcpyHostToDevice, ctx->stream));
     return PLSLAM_OK;
 }
 
@@ -928,28 +936,39 @@ int plslam_match_batched(plslam_ctx* ctx, const uint8_t* d1, const int32_t* off1
     const size_t in1 = (size_t)r1 * 32, in2 = (size_t)r2 * 32, out1 = (size_t)r1 * 4, out2 = (size_t)B * 4;
     const bool pinned = in1 + in2 <= (size_t(1) << 20);
     const size_t in2_off = (in1 + 255) & ~size_t(255), out2_off = (out1 + 255) & ~size_t(255);
-    const uint8_t *src1 = d1, *src2 = d2;
+    const uint8_t *dev1 = ctx->in_a.as<uint8_t>(), *dev2 = ctx->in_b.as<uint8_t>();
+    int32_t* tab_dev = ctx->out_a.as<int32_t>();      // where the kernels write the table
+    bool table_in_place = false;
     if (pinned) {
+        // ONE page-locked image [d1 | d2] -> ONE upload; the table is written by the finalize kernel straight into
+        // page-locked memory (the counts are then the number of entries >= 0: no download at all)
         if ((r = ctx->pin_in.reserve(in2_off + in2 + 256))) return r;
         if ((r = ctx->pin_out.reserve(out2_off + out2 + 256))) return r;
+        if ((r = ctx->in_a.reserve(in2_off + in2 + 256))) return r;
         if (in1) memcpy(ctx->pin_in.as<char>(), d1, in1);
         if (in2) memcpy(ctx->pin_in.as<char>() + in2_off, d2, in2);
-        src1 = ctx->pin_in.as<uint8_t>();
-        src2 = ctx->pin_in.as<uint8_t>() + in2_off;
+        dev1 = ctx->in_a.as<uint8_t>();
+        dev2 = ctx->in_a.as<uint8_t>() + in2_off;
+        if (r1 + r2) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_a.p, ctx->pin_in.p, in2_off + in2, hipMemcpyHostToDevice, ctx->stream));
+        if (void* m = mapped_device_pointer(ctx->pin_out.p)) {
+            tab_dev = static_cast<int32_t*>(m);
+            table_in_place = true;
+        }
+    } else {
+        if (r1) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_a.p, d1, in1, hipMemcpyHostToDevice, ctx->stream));
+        if (r2) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_b.p, d2, in2, hipMemcpyHostToDevice, ctx->stream));
     }
-    if (r1) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_a.p, src1, in1, hipMemcpyHostToDevice, ctx->stream));
-    if (r2) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_b.p, src2, in2, hipMemcpyHostToDevice, ctx->stream));
 
     std::vector<plslam_match_problem> probs((size_t)B);
     for (int32_t b = 0; b < B; ++b) {
         plslam_match_problem& p = probs[b];
-        p.d1 = ctx->in_a.as<uint8_t>() + (size_t)off1[b] * 32;
-        p.d2 = ctx->in_b.as<uint8_t>() + (size_t)off2[b] * 32;
+        p.d1 = dev1 + (size_t)off1[b] * 32;
+        p.d2 = dev2 + (size_t)off2[b] * 32;
         p.n1 = off1[b + 1] - off1[b];
         p.n2 = off2[b + 1] - off2[b];
         p.nnr = nnr;
         p.mutual = mutual ? 1 : 0;
-        p.matches_12 = ctx->out_a.as<int32_t>() + off1[b];
+        p.matches_12 = tab_dev + off1[b];
         p.n_matches = ctx->out_b.as<int32_t>() + b;
     }
     // the context keeps ONE plan object for the host-pointer path: its device buffers only grow, so
@@ -964,13 +983,19 @@ int plslam_match_batched(plslam_ctx* ctx, const uint8_t* d1, const int32_t* off1
         hipError_t e = hipSuccess;
         void* dst1 = pinned ? ctx->pin_out.p : (void*)matches_12;
         void* dst2 = pinned ? (void*)(ctx->pin_out.as<char>() + out2_off) : (void*)n_matches;
-        if (r1) e = hipMemcpyAsync(dst1, ctx->out_a.p, out1, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess && n_matches)
+        if (r1 && !table_in_place) e = hipMemcpyAsync(dst1, ctx->out_a.p, out1, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && n_matches && !table_in_place)
             e = hipMemcpyAsync(dst2, ctx->out_b.p, out2, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e == hipSuccess && pinned) {
             if (r1) memcpy(matches_12, dst1, out1);
-            if (n_matches) memcpy(n_matches, dst2, out2);
+            if (n_matches && !table_in_place) memcpy(n_matches, dst2, out2);
+            if (n_matches && table_in_place)          // StVO::match on a fresh vector: the count IS the number of entries
+                for (int32_t b = 0; b < B; ++b) {
+                    int32_t n = 0;
+                    for (int32_t i = off1[b]; i < off1[b + 1]; ++i) n += matches_12[i] >= 0;
+                    n_matches[b] = n;
+                }
         }
         if (e != hipSuccess) {
             set_last_error("%s:%d: D2H of match tables -> %s", __FILE__, __LINE__, hipGetErrorString(e));
