@@ -6,6 +6,7 @@
 // the MI355X; the host turns the visibility mask into index lists and fills the GridStructure (cell
 // lists of the unmatched keyframe features, :580-584 / :683-699) -- the list building the reference's
 // callers do with std::vector / std::list.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -101,7 +102,7 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     const size_t oCen = cf.take((size_t)nq * nc * 8), oD1 = cf.take(lines ? (size_t)nq * 16 : 0),
                  oD2 = cf.take(lines ? (size_t)nt * 16 : 0), oCs = cf.take(((size_t)cols * rows + 1) * 4),
                  oDesc = cf.take(sizeof(GridDesc)), oSt = cf.take(8);
-    std::vector<int32_t> cen((size_t)nq * nc * 2), cs, items, it, cx, cy, xy;
+    std::vector<int32_t> cs, items, it, cx, cy, xy;
     std::vector<double> dir2;
     if (!lines) {
         for (int32_t b = 0; b < nt; ++b) {
@@ -134,13 +135,19 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     if ((rc = launch_project_cells(*K, T16, d_X3, nq, lines, sx, sy, (int32_t*)(f + oCen),
                                    lines ? (double*)(f + oD1) : nullptr, s)))
         return rc;
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(cen.data(), f + oCen, (size_t)nq * nc * 8, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oCs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, s));
     PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oIt, items.data(), (size_t)(n_items + 1) * 4, hipMemcpyHostToDevice, s));
     if (lines) PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oD2, dir2.data(), (size_t)nt * 16, hipMemcpyHostToDevice, s));
     PLSLAM_HIP_CHECK(hipMemsetAsync(f + oSt, 0, 8, s));
-    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));                                       // cells on the host: store size
-    const int64_t cap = grid_store_capacity_host(cen.data(), nq, nc, cs.data(), cols, rows, win, mutual);
+    // capacity of the candidate store from the grid alone (fullest cell x cells of a window, at most every item, per window
+    // centre; rows in blocks of 1024): the projected cells stay on the device, no round trip before the matcher is launched
+    int64_t cap = 0;
+    if (mutual) {
+        int64_t fullest = 0;
+        for (size_t c = 0; c + 1 < cs.size(); ++c) fullest = std::max<int64_t>(fullest, cs[c + 1] - cs[c]);
+        const int64_t wx = std::min<int64_t>(2 * (int64_t)fm->ws + 1, cols), wy = std::min<int64_t>(2 * (int64_t)fm->ws + 1, rows);
+        cap = std::min<int64_t>(fullest * wx * wy, n_items) * nc * 1024 * ((nq + 1023) / 1024);
+    }
     PLSLAM_REQUIRE(cap < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
     if ((rc = ctx->misc_c.reserve(grid_scratch_words(nq, nt, (int64_t)cols * rows, (int32_t)cap) * 4 + 256))) return rc;
     plslam_grid_problem q{};
