@@ -56,6 +56,7 @@ namespace {
 constexpr int GRID_THREADS = 1024;
 constexpr uint32_t REC_D_BITS = 9, REC_D_MASK = 511u;                  // column state: i1 << 9 | d
 constexpr int CB = 4;                                                  // candidates per batch
+constexpr int GRID_SPLIT = 4;                                          // flat PA: at most this many lanes share a row's window columns
 constexpr uint32_t GRID_TAIL = 256;                                   // candidates left when one wave finishes the passes alone
 constexpr int PB_BATCH = 8;                                            // stored candidates per batch of a record pass
 constexpr size_t GRID_LDS_MAX_BYTES = 152 * 1024;                      // dynamic LDS of the LDS instantiations
@@ -127,8 +128,10 @@ __device__ __forceinline__ uint32_t count_items(const GridDesc& g, const GridPtr
 
 // GridStructure::get over every window centre of row i1, in batches: f(i2[CB]) with i2[j] = -1 for the slots
 // that are empty or fail `if (i2 < 0 || i2 >= desc2.rows) continue;` / the direction test of the line overload
+// (part, split): only the window columns min_x + part, + split, ... -- a row's window shared out over `split` lanes
 template <int MODE, class F>
-__device__ __forceinline__ void for_candidates(const GridDesc& g, const GridPtrs<MODE>& P, int32_t i1, F&& f)
+__device__ __forceinline__ void for_candidates(const GridDesc& g, const GridPtrs<MODE>& P, int32_t i1, F&& f, int32_t part = 0,
+                                               int32_t split = 1)
 {
     double a0 = 0.0, a1 = 0.0;
     const bool dirs = g.dir1 != nullptr && g.dir2 != nullptr;
@@ -139,7 +142,7 @@ __device__ __forceinline__ void for_candidates(const GridDesc& g, const GridPtrs
     for (int32_t c = 0; c < g.n_centres; ++c) {
         const RowWindows r = window_of(g, P.centres + ((int64_t)i1 * g.n_centres + c) * 2);
         if (r.min_y >= r.max_y) continue;
-        for (int32_t x_ = r.min_x; x_ < r.max_x; ++x_) {
+        for (int32_t x_ = r.min_x + part; x_ < r.max_x; x_ += split) {
             // cells (x_, min_y .. max_y-1) are adjacent in the CSR order (id = x*rows + y)
             const int32_t s = (int32_t)P.cs[x_ * g.rows + r.min_y], e = (int32_t)P.cs[x_ * g.rows + r.max_y];
             for (int32_t k = s; k < e; k += CB) {
@@ -252,16 +255,22 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         reg_off = pa_end + (uint32_t)n2;
         tail_cap = (uint32_t)g.pair_cap / NW;
     }
-    // The free LDS is shared out in proportion to the rows a wave owns (row i1 belongs to lane i1 % NT: with 1500 rows on
-    // 1024 lanes waves 0..6 own 128 rows, the last ones 64).  seg_at(w) = first word of wave w's region, seg_at(NW) = end.
+    // The free LDS is shared out in proportion to the (row, window part) tasks a wave owns (task t belongs to lane t % NT).
+    // seg_at(w) = first word of wave w's region, seg_at(NW) = end.
     const uint32_t free_words = flat && lds_words > reg_off ? lds_words - reg_off : 0u;
+    // flat PA: a row's window columns go to 4 lanes (GRID_SPLIT).  Measured against 1 and 2 and against a choice by row count
+    // (1500 x 1500 points: PA 40 -> 47 us but the passes 21 -> 16.5 us, because the stored candidates spread evenly over the
+    // waves' regions; 200 x 200 lines: PA 48 -> 30 us; batched +6 % / +5 %)
+    constexpr int32_t split_log = 2;
+    static_assert((1 << split_log) == GRID_SPLIT, "");
+    const int32_t n_tasks = n1 << split_log;
     auto seg_at = [&](uint32_t w) -> uint32_t {
-        uint32_t rows_before = 0;
-        for (int32_t r = 0; r < n_rounds; ++r) {
-            const int32_t left = n1 - r * NT;                             // rows of round r
-            rows_before += (uint32_t)(left < (int32_t)(64u * w) ? left : (int32_t)(64u * w));
+        uint32_t before = 0;
+        for (int32_t r = 0; r * NT < n_tasks; ++r) {
+            const int32_t left = n_tasks - r * NT;                        // tasks of round r
+            before += (uint32_t)(left < (int32_t)(64u * w) ? left : (int32_t)(64u * w));
         }
-        return reg_off + free_words * rows_before / (uint32_t)(n1 > 0 ? n1 : 1);    // < 2^16 words x <= 2048 rows: 32 bits do
+        return reg_off + free_words * before / (uint32_t)(n_tasks > 0 ? n_tasks : 1);   // < 2^16 words x <= 8192 tasks: 32 bits do
     };
     if (tid <= (int)NW) s_seg[tid] = seg_at((uint32_t)tid);             // (read behind P0's barrier)
     uint32_t seg_first = 0;
@@ -317,10 +326,13 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     uint32_t has_items = 0;          // bit r: this lane's row of round r has grid items inside its windows (mutual only)
     if (flat) {
         const bool count_empty = 2147483647.0 < 2147483647.0 * g.nnr;     // PC's nnr > 1 rule needs to know (cell_start is gone by then)
-        for (int32_t r = 0; r < n_rounds; ++r) {
-            const int32_t i1 = r * NT + tid;
-            if (i1 >= n1) continue;
-            if (count_empty && r < 32 && count_items(g, P, i1) > 0u) has_items |= 1u << r;
+        if (count_empty)
+            for (int32_t r = 0; r < n_rounds && r < 32; ++r)
+                if (r * NT + tid < n1 && count_items(g, P, r * NT + tid) > 0u) has_items |= 1u << r;
+        // a lane per (row, part of the row's window columns): rows differ a lot in their number of candidates, quarters of
+        // rows much less, and there are four times as many of them to even out the lanes of a wave
+        for (int32_t task = tid; task < n_tasks; task += NT) {
+            const int32_t i1 = task >> split_log;
             const u32x4 qa = g_d1[2 * (int64_t)i1], qb = g_d1[2 * (int64_t)i1 + 1];
             for_candidates(g, P, i1, [&](const int32_t (&i2)[CB]) {
                 u32x4 ta[CB], tb[CB];
@@ -362,7 +374,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                             ++pos;
                         }
                 }
-            });
+            }, task & ((1 << split_log) - 1), 1 << split_log);
         }
         __threadfence();
         if (__syncthreads_or(s_cur[wv] > seg_words + tail_cap)) {       // a wave's share of the store does not fit: report, match nothing
@@ -866,7 +878,9 @@ int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d_desc_slot, h_desc_slot, sizeof(GridDesc), hipMemcpyHostToDevice, s));
     const int64_t ncell = (int64_t)q.grid_cols * q.grid_rows;
     const bool dirs = q.dir1 != nullptr && q.dir2 != nullptr;
-    const int group = grid_group(q.n1, q.n2, ncell, q.n_items, dirs);
+    int group = grid_group(q.n1, q.n2, ncell, q.n_items, dirs);
+    // ONE problem: nothing shares the CU, and a mutual problem of <= 256 rows still has up to 1024 (row, window part) tasks
+    if (group == 3 && q.mutual && q.n1 * GRID_SPLIT > GRID_SMALL_ROWS) group = 2;
     int32_t n_mode[4] = {0, 0, 0, 0};
     size_t lds_bytes[4] = {0, 0, 0, 0};
     n_mode[group] = 1;
@@ -1049,7 +1063,8 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     StreamSyncOnError sg(s);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, ci.off, hipMemcpyHostToDevice, s));
     if (!hout_dev) PLSLAM_HIP_CHECK(hipMemsetAsync(dout + oN, 0, 8, s));
-    const int group = grid_group(n1, n2, ncell, n_items, dirs);
+    int group = grid_group(n1, n2, ncell, n_items, dirs);
+    if (group == 3 && mutual && n1 * GRID_SPLIT > GRID_SMALL_ROWS) group = 2;     // one problem: see launch_match_grid_one
     int32_t n_mode[4] = {0, 0, 0, 0};
     size_t lds_bytes[4] = {0, 0, 0, 0};
     n_mode[group] = 1;
