@@ -694,6 +694,7 @@ void plslam_ctx_destroy(plslam_ctx* ctx)
     ctx->misc_a.release(); ctx->misc_b.release(); ctx->misc_c.release();
     ctx->pin_in.release();
     ctx->pin_out.release();
+    ctx->pin_misc.release();
     ctx->lbd_ring.release();
     if (ctx->host_plan) {
         ctx->host_plan->free_all();

@@ -128,6 +128,7 @@ struct plslam_ctx {
     std::mutex mu;       // serialises the host-pointer entry points
     plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
     plslam::HostBuf pin_in, pin_out;                // pinned staging of small host-pointer calls
+    plslam::HostBuf pin_misc;                       // host-built tables of the map-level drivers (map2kf.hip)
     plslam::LineRing lbd_ring;                      // line records of the last plslam_lbd_compute* calls
     struct plslam_match_plan* host_plan = nullptr;  // reused by the host-pointer match entry points
 };
@@ -292,6 +293,9 @@ int64_t grid_store_capacity_host(const int32_t* centres, int32_t n1, int32_t n_c
 // one problem with DEVICE pointers on `s` (scratch: grid_scratch_words() words; status: one zeroed int32)
 int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* d_desc_slot,
                           GridDesc* h_desc_slot, hipStream_t s);
+// the same in two steps (the descriptor inside a larger upload of the caller): host-side check + fill, then the launch
+int grid_prepare_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* h_desc_slot);
+int grid_launch_prepared(const plslam_grid_problem& q, const GridDesc* d_desc_slot, hipStream_t s);
 // launch groups: 3 = all in LDS / 256-lane workgroups (n1 <= 256), 2 = all in LDS, 1 = tables in LDS, 0 = global
 int grid_group(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs = false);
 size_t grid_group_lds_bytes(int group, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs = false);

@@ -86,22 +86,20 @@ inline int32_t cvtt_x86(double v)   // as the reference's x86 build converts (cv
 // StVO::matchGrid over projected 3D features, device-resident except the grid fill:
 //   d_X3 (device): nq x 3 (points) / nq x 6 (lines) features, projected with T16 into cells * (sx, sy) by K16';
 //   feat_curr (HOST): the keyframe features that fill the GridStructure -- item b = feat_curr[sel ? sel[b] : b],
-//   2 doubles (pl) or 4 (spl, epl); d_Q / d_T (device): the descriptor matrices; d_m12 (device): nq entries out.
-// Uses ctx->misc_b (tables) and ctx->misc_c (kernel scratch).  Synchronises the stream (twice).
+//   2 doubles (pl) or 4 (spl, epl); d_Q / d_T (device): the descriptor matrices; d_m12: nq entries out (device memory, or
+//   the device address of page-locked host memory: the caller then has the table without a copy).
+// The host-built tables (cell_start, items, directions) and the problem descriptor travel in ONE page-locked image = one
+// upload; the count comes back through page-locked memory written by the kernel.  Uses ctx->pin_misc, ctx->misc_b (tables)
+// and ctx->misc_c (kernel scratch).  Synchronises the stream once, at the end.
 int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16, const double* d_X3, int32_t nq, double sx,
               double sy, const uint8_t* d_Q, const double* feat_curr, const int32_t* sel, int32_t nt, const uint8_t* d_T,
               const plslam_fast_matching* fm, int mutual, int32_t* d_m12, int32_t* matches)
 {
     hipStream_t s = ctx->stream;
-    StreamSyncOnError sg(s);                        // cen / cs / items / dir2 / hdesc are locals the copies read
+    StreamSyncOnError sg(s);
     int rc;
     const int nc = lines ? 2 : 1;
     const int32_t cols = fm->grid_cols, rows = fm->grid_rows;
-    const int32_t win[4] = {fm->ws, fm->ws, fm->ws, fm->ws};
-    Carve cf;
-    const size_t oCen = cf.take((size_t)nq * nc * 8), oD1 = cf.take(lines ? (size_t)nq * 16 : 0),
-                 oD2 = cf.take(lines ? (size_t)nt * 16 : 0), oCs = cf.take(((size_t)cols * rows + 1) * 4),
-                 oDesc = cf.take(sizeof(GridDesc)), oSt = cf.take(8);
     std::vector<int32_t> cs, items, it, cx, cy, xy;
     std::vector<double> dir2;
     if (!lines) {
@@ -129,16 +127,20 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     }
     csr_fill(it, cx, cy, cols, rows, cs, items);
     const int32_t n_items = cs.back();
-    const size_t oIt = cf.take((size_t)(n_items + 1) * 4);
+    // image (host -> device in one copy): result words | cell_start | items | directions | descriptor; behind it, device only:
+    // the projected cells and the query directions
+    Carve cf;
+    const size_t oSt = cf.take(16), oCs = cf.take(cs.size() * 4), oIt = cf.take((size_t)(n_items + 1) * 4),
+                 oD2 = cf.take(lines ? (size_t)nt * 16 : 0), oDesc = cf.take(sizeof(GridDesc));
+    const size_t image = cf.off;
+    const size_t oCen = cf.take((size_t)nq * nc * 8), oD1 = cf.take(lines ? (size_t)nq * 16 : 0);
+    if ((rc = ctx->pin_misc.reserve(image))) return rc;
     if ((rc = ctx->misc_b.reserve(cf.off))) return rc;
+    char* h = ctx->pin_misc.as<char>();
     char* f = ctx->misc_b.as<char>();
-    if ((rc = launch_project_cells(*K, T16, d_X3, nq, lines, sx, sy, (int32_t*)(f + oCen),
-                                   lines ? (double*)(f + oD1) : nullptr, s)))
-        return rc;
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oCs, cs.data(), cs.size() * 4, hipMemcpyHostToDevice, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oIt, items.data(), (size_t)(n_items + 1) * 4, hipMemcpyHostToDevice, s));
-    if (lines) PLSLAM_HIP_CHECK(hipMemcpyAsync(f + oD2, dir2.data(), (size_t)nt * 16, hipMemcpyHostToDevice, s));
-    PLSLAM_HIP_CHECK(hipMemsetAsync(f + oSt, 0, 8, s));
+    memcpy(h + oCs, cs.data(), cs.size() * 4);
+    memcpy(h + oIt, items.data(), (size_t)(n_items + 1) * 4);
+    if (lines) memcpy(h + oD2, dir2.data(), (size_t)nt * 16);
     // capacity of the candidate store from the grid alone (fullest cell x cells of a window, at most every item, per window
     // centre; rows in blocks of 1024): the projected cells stay on the device, no round trip before the matcher is launched
     int64_t cap = 0;
@@ -150,23 +152,33 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     }
     PLSLAM_REQUIRE(cap < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
     if ((rc = ctx->misc_c.reserve(grid_scratch_words(nq, nt, (int64_t)cols * rows, (int32_t)cap) * 4 + 256))) return rc;
+    // the count: written by the kernel into the page-locked image when the device can address it (no status word then: it
+    // is bumped with an atomic; an overflow also shows as a count of -1)
+    int32_t* res_host = (int32_t*)(h + oSt);
+    int32_t* res_dev = static_cast<int32_t*>(mapped_device_pointer(res_host));
+    const bool in_place = res_dev != nullptr;
+    res_host[0] = res_host[1] = 0;
     plslam_grid_problem q{};
     q.d1 = d_Q; q.d2 = d_T; q.centres1 = (int32_t*)(f + oCen);
     q.cell_start = (int32_t*)(f + oCs); q.cell_items = (int32_t*)(f + oIt);
     q.dir1 = lines ? (double*)(f + oD1) : nullptr; q.dir2 = lines ? (double*)(f + oD2) : nullptr;
     q.n1 = nq; q.n2 = nt; q.n_centres = nc; q.grid_cols = cols; q.grid_rows = rows; q.n_items = n_items;
-    for (int k = 0; k < 4; ++k) q.window[k] = win[k];
+    for (int k = 0; k < 4; ++k) q.window[k] = fm->ws;
     q.sim_th = fm->line_sim_th; q.nnr = fm->nnr_grid; q.mutual = mutual ? 1 : 0;
     q.pair_capacity = (int32_t)cap;
-    q.matches_12 = d_m12; q.n_matches = (int32_t*)(f + oSt);
-    GridDesc hdesc;
-    if ((rc = launch_match_grid_one(q, ctx->misc_c.as<uint32_t>(), (int32_t*)(f + oSt) + 1, (GridDesc*)(f + oDesc), &hdesc, s)))
+    q.matches_12 = d_m12; q.n_matches = in_place ? res_dev : (int32_t*)(f + oSt);
+    if ((rc = grid_prepare_one(q, ctx->misc_c.as<uint32_t>(), in_place ? nullptr : (int32_t*)(f + oSt) + 1, (GridDesc*)(h + oDesc))))
         return rc;
-    int32_t res[2] = {0, 0};
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(res, f + oSt, 8, hipMemcpyDeviceToHost, s));
-    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));                                       // also keeps hdesc alive long enough
-    PLSLAM_REQUIRE(res[1] == 0, PLSLAM_ERANGE);
-    *matches = res[0];
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(f, h, image, hipMemcpyHostToDevice, s));      // (zeroes the device result words too)
+    if ((rc = launch_project_cells(*K, T16, d_X3, nq, lines, sx, sy, (int32_t*)(f + oCen),
+                                   lines ? (double*)(f + oD1) : nullptr, s)))
+        return rc;
+    if ((rc = grid_launch_prepared(q, (const GridDesc*)(f + oDesc), s))) return rc;
+    if (!in_place) PLSLAM_HIP_CHECK(hipMemcpyAsync(res_host, f + oSt, 8, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    sg.dismiss();
+    PLSLAM_REQUIRE(res_host[1] == 0 && res_host[0] >= 0, PLSLAM_ERANGE);
+    *matches = res_host[0];
     return PLSLAM_OK;
 }
 
@@ -198,41 +210,73 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
     DeviceGuard g(ctx->device);
     hipStream_t s = ctx->stream;
     StreamSyncOnError sg(s);
+    // ONE page-locked image [X_prev | desc_prev | desc_curr] -> one upload (X only when the windowed matcher runs); the
+    // match table comes back through page-locked memory the kernels write (no download on the common path)
     Carve c;
-    const size_t oX = c.take((size_t)n_prev * xw * 8), oQ = c.take((size_t)n_prev * 32), oT = c.take((size_t)n_curr * 32),
-                 oM = c.take((size_t)n_prev * 4);
+    const size_t oQ = c.take((size_t)n_prev * 32), oT = c.take((size_t)n_curr * 32), oX = c.take(fast ? (size_t)n_prev * xw * 8 : 0);
+    const size_t image = c.off;
+    const size_t oM = c.take((size_t)n_prev * 4), oCnt = c.take(16);
     int rc;
     if ((rc = ctx->misc_a.reserve(c.off))) return rc;
+    if ((rc = ctx->pin_in.reserve(image))) return rc;
+    if ((rc = ctx->pin_out.reserve((size_t)n_prev * 4 + 256))) return rc;
     char* d = ctx->misc_a.as<char>();
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oX, X_prev, (size_t)n_prev * xw * 8, hipMemcpyHostToDevice, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oQ, desc_prev, (size_t)n_prev * 32, hipMemcpyHostToDevice, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oT, desc_curr, (size_t)n_curr * 32, hipMemcpyHostToDevice, s));
+    char* h = ctx->pin_in.as<char>();
+    memcpy(h + oQ, desc_prev, (size_t)n_prev * 32);
+    memcpy(h + oT, desc_curr, (size_t)n_curr * 32);
+    if (fast) memcpy(h + oX, X_prev, (size_t)n_prev * xw * 8);
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image, hipMemcpyHostToDevice, s));
+    int32_t* tab_host = ctx->pin_out.as<int32_t>();
+    int32_t* tab_mapped = static_cast<int32_t*>(mapped_device_pointer(tab_host));
+    int32_t* tab_dev = (int32_t*)(d + oM);
     int32_t matches = 0;
-    bool have = false;
+    bool have = false, on_host = false;            // on_host: the current table is in tab_host (written by a kernel, synchronised)
     if (fast) {
         // points: pj_points = projection * inv (:256); lines: pj_lines = the projected PIXELS (:392-393, as upstream)
         if ((rc = grid_path(ctx, lines, K, DT, (const double*)(d + oX), n_prev, lines ? 1.0 : fm->inv_width,
                             lines ? 1.0 : fm->inv_height, (const uint8_t*)(d + oQ), feat_curr, nullptr, n_curr,
-                            (const uint8_t*)(d + oT), fm, mutual, (int32_t*)(d + oM), &matches)))
+                            (const uint8_t*)(d + oT), fm, mutual, tab_mapped ? tab_mapped : tab_dev, &matches)))
             return rc;
         have = true;
+        on_host = tab_mapped != nullptr;
     }
-    int32_t* d_cnt = nullptr;
+    bool count_entries = false;
     if (bf_possible && matches < min_matches) {                            // :274-278 / :421-425
-        if ((rc = ctx->misc_b.reserve(256))) return rc;
-        d_cnt = ctx->misc_b.as<int32_t>();
         plslam_match_problem p{};
         p.d1 = (uint8_t*)(d + oQ); p.n1 = n_prev; p.d2 = (uint8_t*)(d + oT); p.n2 = n_curr;
-        p.nnr = nnr; p.mutual = mutual ? 1 : 0; p.matches_12 = (int32_t*)(d + oM); p.n_matches = d_cnt;
+        p.nnr = nnr; p.mutual = mutual ? 1 : 0; p.n_matches = (int32_t*)(d + oCnt);
         p.keep_prior = have ? 1 : 0;             // the vector matchGrid filled is handed on (:271 -> :277, :418 -> :424)
+        if (p.keep_prior) {
+            // (rare) the kernel reads the earlier table as well as writing it: keep it on the device
+            if (on_host) PLSLAM_HIP_CHECK(hipMemcpyAsync(tab_dev, tab_host, (size_t)n_prev * 4, hipMemcpyHostToDevice, s));
+            p.matches_12 = tab_dev;
+            on_host = false;
+        } else {
+            p.matches_12 = tab_mapped ? tab_mapped : tab_dev;
+            on_host = tab_mapped != nullptr;
+            count_entries = on_host;             // StVO::match on a fresh vector: the count is the number of entries
+        }
         if ((rc = match_problems_on_ctx_stream(ctx, &p, 1))) return rc;
+        if (!on_host) {
+            PLSLAM_HIP_CHECK(hipMemcpyAsync(tab_host, tab_dev, (size_t)n_prev * 4, hipMemcpyDeviceToHost, s));
+            PLSLAM_HIP_CHECK(hipMemcpyAsync(&matches, d + oCnt, 4, hipMemcpyDeviceToHost, s));
+        }
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        on_host = true;
         have = true;
         if (used_match) *used_match = 1;
+    } else if (have && !on_host) {
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(tab_host, tab_dev, (size_t)n_prev * 4, hipMemcpyDeviceToHost, s));
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        on_host = true;
     }
+    sg.dismiss();
     if (!have) return PLSLAM_OK;
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(matches_12, d + oM, (size_t)n_prev * 4, hipMemcpyDeviceToHost, s));
-    if (d_cnt) PLSLAM_HIP_CHECK(hipMemcpyAsync(&matches, d_cnt, 4, hipMemcpyDeviceToHost, s));
-    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(matches_12, tab_host, (size_t)n_prev * 4);
+    if (count_entries) {
+        matches = 0;
+        for (int32_t i = 0; i < n_prev; ++i) matches += matches_12[i] >= 0;
+    }
     if (n_matches) *n_matches = matches;
     return PLSLAM_OK;
 }
@@ -268,35 +312,47 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     DeviceGuard dg_(ctx->device);    // every entry point runs on the context's device, whatever the calling thread's current one
     hipStream_t s = ctx->stream;
     StreamSyncOnError sg(s);
-    // ---- stage the map and the keyframe on the device, project + visibility test ------------
+    // ---- stage the map and the keyframe on the device (ONE page-locked image, one upload), project + visibility test ----
     Carve c;
     const size_t oLM = c.take((size_t)n_map * lw * 8), oMD = c.take((size_t)n_map * 32),
-                 oKD = c.take((size_t)n_kf * 32), oKF = c.take((size_t)n_kf * fw * 8), oVis = c.take((size_t)n_map),
-                 oQi = c.take((size_t)n_map * 4), oTi = c.take((size_t)nt * 4), oQ = c.take((size_t)n_map * 32),
-                 oT = c.take((size_t)nt * 32), oQL = c.take((size_t)n_map * lw * 8), oTF = c.take((size_t)nt * fw * 8),
-                 oM = c.take((size_t)n_map * 4), oMask = c.take((size_t)n_map), oCnt = c.take(8);
+                 oKD = c.take((size_t)n_kf * 32), oKF = c.take((size_t)n_kf * fw * 8);
+    const size_t image1 = c.off;
+    const size_t oQi = c.take((size_t)n_map * 4), oTi = c.take((size_t)nt * 4);          // second image: the two lists
+    const size_t image2 = c.off - oQi;
+    const size_t oVis = c.take((size_t)n_map), oQ = c.take((size_t)n_map * 32),
+                 oT = c.take((size_t)nt * 32), oQL = c.take((size_t)n_map * lw * 8), oTF = c.take((size_t)nt * fw * 8);
+    const size_t oM = c.take((size_t)n_map * 4), oMask = c.take((size_t)n_map), oCnt = c.take(8);   // results: one download
+    const size_t results = c.off - oM;
     int rc;
     if ((rc = ctx->misc_a.reserve(c.off))) return rc;
+    if ((rc = ctx->pin_in.reserve(std::max(image1, image2)))) return rc;
+    if ((rc = ctx->pin_out.reserve(std::max(results, (size_t)n_map)))) return rc;
     char* d = ctx->misc_a.as<char>();
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oLM, LM, (size_t)n_map * lw * 8, hipMemcpyHostToDevice, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oMD, med_desc, (size_t)n_map * 32, hipMemcpyHostToDevice, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oKD, kf_desc, (size_t)n_kf * 32, hipMemcpyHostToDevice, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oKF, kf_feat, (size_t)n_kf * fw * 8, hipMemcpyHostToDevice, s));
-    if ((rc = launch_visible(*K, Twf, (double*)(d + oLM), n_map, lines, (uint8_t*)(d + oVis), s))) return rc;
-    std::vector<uint8_t> vis((size_t)n_map);
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(vis.data(), d + oVis, (size_t)n_map, hipMemcpyDeviceToHost, s));
+    char* h = ctx->pin_in.as<char>();
+    char* ho = ctx->pin_out.as<char>();
+    memcpy(h + oLM, LM, (size_t)n_map * lw * 8);
+    memcpy(h + oMD, med_desc, (size_t)n_map * 32);
+    memcpy(h + oKD, kf_desc, (size_t)n_kf * 32);
+    memcpy(h + oKF, kf_feat, (size_t)n_kf * fw * 8);
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image1, hipMemcpyHostToDevice, s));
+    // the visibility flags come back through page-locked memory the kernel writes (no download command)
+    uint8_t* vis_mapped = static_cast<uint8_t*>(mapped_device_pointer(ho));
+    if ((rc = launch_visible(*K, Twf, (double*)(d + oLM), n_map, lines, vis_mapped ? vis_mapped : (uint8_t*)(d + oVis), s))) return rc;
+    if (!vis_mapped) PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oVis, (size_t)n_map, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    const uint8_t* vis = reinterpret_cast<const uint8_t*>(ho);
 
     // ---- Q list: candidate landmarks that project inside the image, :545-558 / :647-663 ------
     std::vector<int32_t> qi;
     for (int32_t i = 0; i < n_map; ++i)
         if (candidate[i] && vis[i]) qi.push_back(i);
     const int32_t nq = (int32_t)qi.size();
-    if (nq == 0) return PLSLAM_OK;                                        // :571 / :676
+    if (nq == 0) { sg.dismiss(); return PLSLAM_OK; }                      // :571 / :676
 
     // ---- build the Q / T matrices on the device, match, gate ----------------------------------
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oQi, qi.data(), (size_t)nq * 4, hipMemcpyHostToDevice, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oTi, ti.data(), (size_t)nt * 4, hipMemcpyHostToDevice, s));
+    memcpy(h, qi.data(), (size_t)nq * 4);                                  // (image 1 is on the device: the buffer is free)
+    memcpy(h + (oTi - oQi), ti.data(), (size_t)nt * 4);
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oQi, h, image2, hipMemcpyHostToDevice, s));
     if ((rc = launch_gather_rows(d + oMD, (int32_t*)(d + oQi), nq, 32, d + oQ, s))) return rc;
     if ((rc = launch_gather_rows(d + oKD, (int32_t*)(d + oTi), nt, 32, d + oT, s))) return rc;
     if ((rc = launch_gather_rows(d + oLM, (int32_t*)(d + oQi), nq, lw * 8, d + oQL, s))) return rc;
@@ -320,22 +376,21 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
         have_m12 = true;
         if (used_match) *used_match = 1;
     }
-    if (!have_m12) return PLSLAM_OK;
+    if (!have_m12) { PLSLAM_HIP_CHECK(hipStreamSynchronize(s)); sg.dismiss(); return PLSLAM_OK; }
     rc = lines ? launch_line_gate(*K, Twf, (double*)(d + oQL), (int32_t*)(d + oM), nq, (double*)(d + oTF),
                                   max_epip, (uint8_t*)(d + oMask), (int32_t*)(d + oCnt), s)
                : launch_point_gate(*K, Twf, (double*)(d + oQL), (int32_t*)(d + oM), nq, (double*)(d + oTF),
                                    max_epip, (uint8_t*)(d + oMask), (int32_t*)(d + oCnt), s);
     if (rc) return rc;
-    std::vector<int32_t> m12((size_t)nq);
-    std::vector<uint8_t> mask((size_t)nq);
-    int32_t cnt = 0;
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(m12.data(), d + oM, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(mask.data(), d + oMask, (size_t)nq, hipMemcpyDeviceToHost, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(&cnt, d + oCnt, 4, hipMemcpyDeviceToHost, s));
+    // table, mask and count lie behind one another: one download
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oM, results, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    sg.dismiss();
+    const int32_t* m12 = reinterpret_cast<const int32_t*>(ho);
+    const uint8_t* mask = reinterpret_cast<const uint8_t*>(ho + (oMask - oM));
     for (int32_t a = 0; a < nq; ++a)
         if (mask[a]) map_to_kf[qi[a]] = ti[m12[a]];                       // :614-619 (the association)
-    if (n_matches) *n_matches = cnt;
+    if (n_matches) *n_matches = *reinterpret_cast<const int32_t*>(ho + (oCnt - oM));
     return PLSLAM_OK;
 }
 }  // namespace

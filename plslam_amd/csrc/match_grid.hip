@@ -868,14 +868,18 @@ static void grid_fill_desc(const plslam_grid_problem& q, uint32_t* scratch, int3
 }
 
 namespace plslam {
-// h_desc_slot must stay valid until the copy is done (pinned or synchronised by the caller)
-int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* d_desc_slot,
-                          GridDesc* h_desc_slot, hipStream_t s)
+// One problem with DEVICE pointers, in two steps so that the descriptor can travel inside a larger upload of the caller:
+// grid_prepare_one checks the problem and writes its GridDesc to h_desc_slot (host); grid_launch_prepared launches it once
+// that descriptor is at d_desc_slot on the device.
+int grid_prepare_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* h_desc_slot)
 {
     int rc;
     if ((rc = grid_check_problem(q))) return rc;
     grid_fill_desc(q, scratch, status, h_desc_slot);
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d_desc_slot, h_desc_slot, sizeof(GridDesc), hipMemcpyHostToDevice, s));
+    return PLSLAM_OK;
+}
+int grid_launch_prepared(const plslam_grid_problem& q, const GridDesc* d_desc_slot, hipStream_t s)
+{
     const int64_t ncell = (int64_t)q.grid_cols * q.grid_rows;
     const bool dirs = q.dir1 != nullptr && q.dir2 != nullptr;
     int group = grid_group(q.n1, q.n2, ncell, q.n_items, dirs);
@@ -886,6 +890,15 @@ int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32
     n_mode[group] = 1;
     lds_bytes[group] = grid_group_lds_bytes(group, q.n1, q.n2, ncell, q.n_items, dirs);
     return launch_match_grid(d_desc_slot, n_mode, lds_bytes, s);
+}
+// h_desc_slot must stay valid until the copy is done (pinned or synchronised by the caller)
+int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* d_desc_slot,
+                          GridDesc* h_desc_slot, hipStream_t s)
+{
+    int rc;
+    if ((rc = grid_prepare_one(q, scratch, status, h_desc_slot))) return rc;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d_desc_slot, h_desc_slot, sizeof(GridDesc), hipMemcpyHostToDevice, s));
+    return grid_launch_prepared(q, d_desc_slot, s);
 }
 }  // namespace plslam
 
