@@ -269,6 +269,14 @@ int plslam_grid_plan_run(plslam_grid_plan* plan, void* stream);
 /* synchronises `stream` and returns the number of pair-list overflows since the last call */
 int plslam_grid_plan_overflows(plslam_grid_plan* plan, void* stream, int32_t* n_overflows);
 void plslam_grid_plan_destroy(plslam_grid_plan* plan);
+/* plslam_grid_problem.pair_capacity from HOST copies of a problem's window centres and cell_start (pure host code, no
+ * device needed).  exact: the documented size (rows in blocks of 1024, 1024 x the item count of a block's fullest row);
+ * bound: an upper bound of it from the grid alone -- fullest cell x cells of a window (at most every item) x n_centres
+ * per row -- for callers whose centres only exist on the device.  Either is sufficient.  0 for non-mutual problems. */
+int64_t plslam_grid_pair_capacity(const int32_t* centres1, int32_t n1, int32_t n_centres, const int32_t* cell_start,
+                                  int32_t grid_cols, int32_t grid_rows, const int32_t window[4], int mutual);
+int64_t plslam_grid_pair_capacity_bound(int32_t n1, int32_t n_centres, const int32_t* cell_start, int32_t grid_cols,
+                                        int32_t grid_rows, const int32_t window[4], int mutual);
 
 /* ---- host-to-host pipeline: descriptors born on the host, tables wanted on the host -------------------------------- */
 /* plslam_match_batched is strictly serial (H2D -> kernels -> D2H) and uploads every problem's rows separately.  A

@@ -46,7 +46,7 @@ ABI_SYMBOLS = (
     "plslam_match_pipeline_create", "plslam_match_pipeline_submit", "plslam_match_pipeline_wait",
     "plslam_match_pipeline_destroy", "plslam_pinned_alloc", "plslam_pinned_free",
     "plslam_match_grid", "plslam_grid_plan_create", "plslam_grid_plan_run", "plslam_grid_plan_overflows",
-    "plslam_grid_plan_destroy",
+    "plslam_grid_plan_destroy", "plslam_grid_pair_capacity", "plslam_grid_pair_capacity_bound",
     "plslam_gather_match_tables",
 )
 
@@ -246,12 +246,17 @@ def load() -> C.CDLL:
     L.plslam_grid_plan_overflows.argtypes = [vp, vp, C.POINTER(i32)]
     L.plslam_grid_plan_destroy.argtypes = [vp]
     L.plslam_grid_plan_destroy.restype = None
+    L.plslam_grid_pair_capacity.argtypes = [vp, i32, i32, vp, i32, i32, vp, C.c_int]
+    L.plslam_grid_pair_capacity.restype = C.c_int64
+    L.plslam_grid_pair_capacity_bound.argtypes = [i32, i32, vp, i32, i32, vp, C.c_int]
+    L.plslam_grid_pair_capacity_bound.restype = C.c_int64
     L.plslam_gather_match_tables.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if name not in ("plslam_strerror", "plslam_last_error", "plslam_ctx_destroy",
                         "plslam_match_plan_destroy", "plslam_lba_plan_destroy", "plslam_grid_plan_destroy",
-                        "plslam_match_pipeline_destroy", "plslam_pinned_alloc", "plslam_pinned_free"):
+                        "plslam_match_pipeline_destroy", "plslam_pinned_alloc", "plslam_pinned_free",
+                        "plslam_grid_pair_capacity", "plslam_grid_pair_capacity_bound"):
             f.restype = C.c_int
     _lib = L
     return L
@@ -274,6 +279,21 @@ def _arr(a, dt, shape=None):
 def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else C.c_void_p(
         a.ctypes.data if a is not None else None)
+
+
+def grid_pair_capacity(centres, cell_start, cols, rows, window, mutual=True, bound=False) -> int:
+    """plslam_grid_problem.pair_capacity (pure host code, no device needed): the documented size, or -- bound=True -- an upper
+    bound of it from the grid alone (centres: only their shape is used then)."""
+    L = load()
+    cen = _arr(centres, np.int32)
+    cen = cen.reshape(cen.shape[0], -1, 2) if cen.size else cen.reshape(0, 1, 2)
+    cs = _arr(cell_start, np.int32)
+    w = _arr(window, np.int32, (4,))
+    if bound:
+        return int(L.plslam_grid_pair_capacity_bound(cen.shape[0], cen.shape[1], _p(cs), int(cols), int(rows), _p(w),
+                                                     int(bool(mutual))))
+    return int(L.plslam_grid_pair_capacity(_p(cen), cen.shape[0], cen.shape[1], _p(cs), int(cols), int(rows), _p(w),
+                                           int(bool(mutual))))
 
 
 def make_cam(fx, fy, cx, cy, b=0.0, width=0, height=0) -> Cam:

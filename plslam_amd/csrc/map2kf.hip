@@ -15,6 +15,10 @@
 
 namespace plslam {
 
+// match_grid.hip: capacity of the windowed matcher's candidate store from the grid alone
+int64_t grid_store_capacity_bound(int32_t n1, int32_t n_centres, const int32_t* cell_start, int32_t cols, int32_t rows,
+                                  const int32_t window[4], int mutual);
+
 __global__ void __launch_bounds__(256)
 k_gather_rows(const uint64_t* __restrict__ src, const int32_t* __restrict__ idx, int32_t n, int32_t words,
               uint64_t* __restrict__ dst)
@@ -143,13 +147,8 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     if (lines) memcpy(h + oD2, dir2.data(), (size_t)nt * 16);
     // capacity of the candidate store from the grid alone (fullest cell x cells of a window, at most every item, per window
     // centre; rows in blocks of 1024): the projected cells stay on the device, no round trip before the matcher is launched
-    int64_t cap = 0;
-    if (mutual) {
-        int64_t fullest = 0;
-        for (size_t c = 0; c + 1 < cs.size(); ++c) fullest = std::max<int64_t>(fullest, cs[c + 1] - cs[c]);
-        const int64_t wx = std::min<int64_t>(2 * (int64_t)fm->ws + 1, cols), wy = std::min<int64_t>(2 * (int64_t)fm->ws + 1, rows);
-        cap = std::min<int64_t>(fullest * wx * wy, n_items) * nc * 1024 * ((nq + 1023) / 1024);
-    }
+    const int32_t win[4] = {fm->ws, fm->ws, fm->ws, fm->ws};
+    const int64_t cap = grid_store_capacity_bound(nq, nc, cs.data(), cols, rows, win, mutual);
     PLSLAM_REQUIRE(cap < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
     if ((rc = ctx->misc_c.reserve(grid_scratch_words(nq, nt, (int64_t)cols * rows, (int32_t)cap) * 4 + 256))) return rc;
     // the count: written by the kernel into the page-locked image when the device can address it (no status word then: it

@@ -760,6 +760,21 @@ int64_t grid_store_capacity_host(const int32_t* centres, int32_t n1, int32_t n_c
     return total;
 }
 
+// upper bound of grid_store_capacity_host() from the grid alone: fullest cell x cells of a window, at most every item, per
+// window centre; rows in blocks of 1024
+int64_t grid_store_capacity_bound(int32_t n1, int32_t n_centres, const int32_t* cell_start, int32_t cols, int32_t rows,
+                                  const int32_t window[4], int mutual)
+{
+    if (!mutual || n1 <= 0) return 0;
+    const int64_t ncell = (int64_t)cols * rows;
+    int64_t fullest = 0;
+    for (int64_t c = 0; c < ncell; ++c) fullest = std::max<int64_t>(fullest, (int64_t)cell_start[c + 1] - cell_start[c]);
+    const int64_t wx = std::min<int64_t>((int64_t)window[0] + window[1] + 1, cols);
+    const int64_t wy = std::min<int64_t>((int64_t)window[2] + window[3] + 1, rows);
+    const int64_t per_row = std::min<int64_t>(fullest * wx * wy, cell_start[ncell]) * n_centres;
+    return per_row * GRID_THREADS * ((n1 + GRID_THREADS - 1) / GRID_THREADS);
+}
+
 constexpr int GRID_SMALL_ROWS = 256;    // problems of at most this many rows run on 256-lane workgroups (MODE 2 only)
 
 // launch groups: 0 = tables in global scratch, 1 = tables in LDS, 2 = everything in LDS / 1024 lanes, 3 = everything in
@@ -1009,17 +1024,9 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     // capacity of the candidate store.  A bound from the grid alone (fullest cell x cells of a window, at most every item,
     // per window centre; rows in blocks of 1024) costs one pass over cell_start; only when that bound is large is the
     // exact figure worth a walk over every row's window.
-    int64_t pairs = 0;
-    if (mutual) {
-        int64_t fullest = 0;
-        for (int64_t c = 0; c < ncell; ++c) fullest = std::max<int64_t>(fullest, cell_start[c + 1] - cell_start[c]);
-        const int64_t wx = std::min<int64_t>((int64_t)window[0] + window[1] + 1, grid_cols);
-        const int64_t wy = std::min<int64_t>((int64_t)window[2] + window[3] + 1, grid_rows);
-        const int64_t per_row = std::min<int64_t>(fullest * wx * wy, n_items) * n_centres;
-        pairs = per_row * GRID_THREADS * ((n1 + GRID_THREADS - 1) / GRID_THREADS);
-        if (pairs > (int64_t(1) << 21))
-            pairs = grid_store_capacity_host(centres1, n1, n_centres, cell_start, grid_cols, grid_rows, window, mutual);
-    }
+    int64_t pairs = grid_store_capacity_bound(n1, n_centres, cell_start, grid_cols, grid_rows, window, mutual);
+    if (pairs > (int64_t(1) << 21))
+        pairs = grid_store_capacity_host(centres1, n1, n_centres, cell_start, grid_cols, grid_rows, window, mutual);
     PLSLAM_REQUIRE(pairs < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
     q.pair_capacity = (int32_t)pairs;
 
@@ -1093,6 +1100,20 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     memcpy(matches_12, ctx->pin_out.as<char>() + oM, (size_t)n1 * 4);
     if (n_matches) *n_matches = res[0];
     return PLSLAM_OK;
+}
+
+int64_t plslam_grid_pair_capacity(const int32_t* centres1, int32_t n1, int32_t n_centres, const int32_t* cell_start,
+                                  int32_t grid_cols, int32_t grid_rows, const int32_t window[4], int mutual)
+{
+    if (!centres1 || !cell_start || !window || n1 < 0 || n_centres < 1 || grid_cols < 1 || grid_rows < 1) return -1;
+    return plslam::grid_store_capacity_host(centres1, n1, n_centres, cell_start, grid_cols, grid_rows, window, mutual);
+}
+
+int64_t plslam_grid_pair_capacity_bound(int32_t n1, int32_t n_centres, const int32_t* cell_start, int32_t grid_cols,
+                                        int32_t grid_rows, const int32_t window[4], int mutual)
+{
+    if (!cell_start || !window || n1 < 0 || n_centres < 1 || grid_cols < 1 || grid_rows < 1) return -1;
+    return plslam::grid_store_capacity_bound(n1, n_centres, cell_start, grid_cols, grid_rows, window, mutual);
 }
 
 }  // extern "C"

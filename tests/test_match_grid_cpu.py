@@ -174,3 +174,23 @@ def test_hypothesis_sequential_vs_order_free(oracle):
         assert a[1] == b[1] and np.array_equal(a[0], b[0])
 
     run()
+
+
+def test_pair_capacity_helpers_of_the_abi():
+    """plslam_grid_pair_capacity = the documented store size (the Python restatement in plslam_amd.grid agrees);
+    plslam_grid_pair_capacity_bound never falls below it.  Pure host code: runs without a device."""
+    from plslam_amd import capi
+    r = _rng(41)
+    for it in range(40):
+        lines = it % 2 == 1
+        n1, n2 = int(r.integers(1, 2600)), int(r.integers(1, 1800))
+        cols, rows = [(1, 1), (3, 2), (16, 12), (64, 48)][it % 4]
+        w = tuple(int(x) for x in r.integers(0, 5, 4)) if it % 5 else (2 ** 31 - 1,) * 4
+        c = (line_case if lines else point_case)(9000 + it, n1, n2, cols, rows)
+        cen = np.asarray(c["centres"], np.int32).reshape(n1, -1, 2)
+        exact = capi.grid_pair_capacity(cen, c["cell_start"], cols, rows, w)
+        assert exact == G.store_capacity(cen, c["cell_start"], cols, rows, w)
+        bound = capi.grid_pair_capacity(cen, c["cell_start"], cols, rows, w, bound=True)
+        assert bound >= exact, (it, bound, exact)
+        assert capi.grid_pair_capacity(cen, c["cell_start"], cols, rows, w, mutual=False) == 0
+        assert capi.grid_pair_capacity(cen, c["cell_start"], cols, rows, w, mutual=False, bound=True) == 0
