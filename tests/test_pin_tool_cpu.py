@@ -7,6 +7,8 @@ import types
 
 import numpy as np
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _tool():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -44,3 +46,53 @@ def test_replay_logic_reproduces_the_goldens(oracle):
 def test_replay_reports_a_different_tie_order(oracle):
     _, bad = _tool().replay_match_golden(_fake_cv2(oracle, flip_ties=True))
     assert any("tie order" in b[1] for b in bad)
+
+
+def _export(tmp_path):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("export_cases", os.path.join(ROOT, "tools", "pin_stvo", "export_cases.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = str(tmp_path / "cases")
+    mod.main(out)
+    return mod, out
+
+
+def test_stvo_harness_export_round_trip(tmp_path):
+    """tools/pin_stvo/export_cases.py: every exported array reads back as the golden it came from."""
+    mod, out = _export(tmp_path)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "grid_golden.npz"))
+    assert np.array_equal(mod.read_array(os.path.join(out, "grid_c2_dir2.bin")), g["c2_dir2"])
+    assert np.array_equal(mod.read_array(os.path.join(out, "grid_c0_m1_r75.bin")), g["c0_m1_r75"])
+    m = np.load(os.path.join(ROOT, "tests", "golden", "match_golden.npz"))
+    assert np.array_equal(mod.read_array(os.path.join(out, "match_planted_q.bin")), m["planted/q"])
+    s = np.load(os.path.join(ROOT, "tests", "golden", "stereo_gates_golden.npz"))
+    assert np.array_equal(mod.read_array(os.path.join(out, "gate_l0_t0_d.bin")).view(np.uint32), s["l0_t0_disp"].view(np.uint32))
+    kinds = [ln.split()[0] for ln in open(os.path.join(out, "manifest.txt"))]
+    assert kinds.count("kind=match") >= 12 and kinds.count("kind=grid_lines") == 8 and kinds.count("kind=gate_lines") == 9
+
+
+def test_stvo_harness_runs_against_stand_ins(tmp_path):
+    """The C++ harness (tools/pin_stvo/pin_stvo.cpp) built against stand-in stvo-pl / OpenCV headers whose StVO:: functions
+    forward to the CPU restatement: every replayable case passes, a corrupted expectation is reported.  This checks the
+    HARNESS (file format, grid reconstruction, window / ratio plumbing) -- the day a stvo-pl checkout exists the same binary,
+    linked against the real sources, checks the restatement."""
+    import subprocess
+    _, out = _export(tmp_path)
+    exe = str(tmp_path / "pin_stvo_selftest")
+    standin = os.path.join(ROOT, "tests", "cpp", "stvo_standin")
+    cmd = ["g++", "-O1", "-std=c++14", "-I" + standin, "-I" + os.path.join(ROOT, "oracle"),
+           os.path.join(ROOT, "tools", "pin_stvo", "pin_stvo.cpp"), os.path.join(standin, "standin.cpp"), "-o", exe,
+           "-L" + os.path.join(ROOT, "oracle"), "-lplslam_oracle", "-Wl,-rpath," + os.path.join(ROOT, "oracle")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe, out], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "98 cases replayed, 0 differ; 18 stereo-gate cases listed" in r.stdout
+    # corrupt one expectation: the harness must say which table differs
+    p = os.path.join(out, "grid_c0_m1_r75.bin")
+    raw = bytearray(open(p, "rb").read())
+    raw[-4:] = (12345).to_bytes(4, "little")
+    open(p, "wb").write(bytes(raw))
+    r = subprocess.run([exe, out], capture_output=True, text=True)
+    assert r.returncode == 1 and "FAIL grid_points c0 nnr 0.75 mutual 1" in r.stdout and "1 differ" in r.stdout

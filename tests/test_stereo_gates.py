@@ -228,3 +228,36 @@ def test_device_pointer_gates(ctx, oracle):
     # argument checks: misaligned feature rows, counters that are not one array
     assert L.plslam_stereo_point_gate_dev(ctx.handle, d_m.data_ptr(), 1500, d_a.data_ptr() + 4, d_b.data_ptr(), 1400, 1.0, 1.0,
                                           out.data_ptr(), disp.data_ptr(), None, None) == -1
+
+
+def golden_gate_cases():
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stereo_gates_golden.npz"))
+    for c in range(3):
+        for t, th in enumerate(g["point_thresholds"]):
+            yield ("points", (g[f"p{c}_m12"], g[f"p{c}_kp_l"], g[f"p{c}_kp_r"]), tuple(th),
+                   (g[f"p{c}_t{t}_stereo"], g[f"p{c}_t{t}_disp"], int(g[f"p{c}_t{t}_n"])))
+        for t, th in enumerate(g["line_thresholds"]):
+            yield ("lines", (g[f"l{c}_m12"], g[f"l{c}_seg_l"], g[f"l{c}_seg_r"]), tuple(th),
+                   (g[f"l{c}_t{t}_stereo"], g[f"l{c}_t{t}_disp"], int(g[f"l{c}_t{t}_n"])))
+
+
+def _same_gate(got, want):
+    np.testing.assert_array_equal(got[0], want[0])
+    assert np.array_equal(np.asarray(got[1], np.float32).view(np.uint32), np.asarray(want[1], np.float32).view(np.uint32))
+    assert got[2] == want[2]
+
+
+def test_oracle_reproduces_the_committed_gate_golden(oracle):
+    with np.errstate(all="ignore"):
+        for kind, inp, th, want in golden_gate_cases():
+            got = (oracle.stereo_point_gate if kind == "points" else oracle.stereo_line_gate)(*inp, *th)
+            _same_gate(got, want)
+
+
+@pytest.mark.gpu
+def test_gpu_committed_gate_golden(ctx):
+    """GPU vs the committed fixture tests/golden/stereo_gates_golden.npz (no oracle involved at run time)."""
+    for kind, inp, th, want in golden_gate_cases():
+        got = (ctx.stereo_point_gate if kind == "points" else ctx.stereo_line_gate)(*inp, *th)
+        _same_gate(got, want)

@@ -9,10 +9,12 @@ What it checks with `cv2` alone (pip opencv-python is enough):
   * the ratio test and the mutual check exactly as stvo-pl's matchNNR / match are recalled (accept iff
     matches[i][0].distance < matches[i][1].distance * nnr in float; keep i1 -> i2 iff matches_21[i2] == i1), computed from
     cv2's OWN knn results, against the stored m12 tables for nnr in (0.6, 0.75, 0.9) x mutual in (0, 1).
-What needs a stvo-pl build (python bindings do not exist upstream; build its `matching.cpp` + `gridStructure.cpp` into a
-small extension and expose match / matchGrid / StereoFrame's gates as `stvo` with the signatures below):
-  * tests/golden/grid_golden.npz through StVO::matchGrid, the stereo-gate cases of tests/test_stereo_gates.py through
-    StereoFrame::matchStereoPoints / matchStereoLines.  The hook is `--stvo-module NAME`.
+What needs a stvo-pl checkout: tools/pin_stvo/ -- `export_cases.py` writes the goldens (match, grid, stereo gates) as flat
+binary arrays + a manifest, `pin_stvo.cpp` (Makefile beside it: STVO_PL_DIR + pkg-config OpenCV) links stvo-pl's own
+matching.cpp / gridStructure.cpp / config.cpp and replays every match and grid case through StVO::match and both
+StVO::matchGrid overloads; the stereo-gate cases (tests/golden/stereo_gates_golden.npz) are exported with inputs, thresholds
+and expected tables for a comparison inside StereoFrame::matchStereoPoints / matchStereoLines, which cannot be called on
+their own.  (A Python module exposing match / matchGrid can be plugged in here instead: `--stvo-module NAME`.)
 
 Exit code 0 = every replayed vector agrees (or nothing could be replayed: no cv2 -- says so), 1 = differences (listed).
 This container has neither OpenCV nor stvo-pl: here the script only reports that.  It never touches the product.
