@@ -42,6 +42,10 @@
 //         proposals between passes.
 //   PC  per row: ratio test `best_d < best_d2 * nnr` in fp64 (int * double upstream; best_d2 = INT_MAX when absent,
 //       so a lone live candidate passes), mutual check against the column's final state, count.
+// Fences: every exchange through global memory in this kernel (candidate store, the scratch tables of the modes that do not
+// fit LDS) is between lanes of ONE workgroup, so the fences are workgroup-scope (__threadfence_block).  A device-scope fence
+// is an L2 write-back + invalidate on this chip (buffer_wbl2 / buffer_inv), whose cost grows with what every OTHER workgroup
+// on the die has written: with it a problem took 107 us among 127 others against 66 us alone.
 // Duplicated candidates (an item sitting in several cells of the window, the two windows of a line overlapping) are
 // harmless: the atomic min and the best-two fold are idempotent.
 #include <algorithm>
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                 }
             }, task & ((1 << split_log) - 1), 1 << split_log);
         }
-        __threadfence();
+        __threadfence_block();
         if (__syncthreads_or(s_cur[wv] > seg_words + tail_cap)) {       // a wave's share of the store does not fit: report, match nothing
             for (int32_t i = tid; i < n1; i += NT) g_matches[i] = -1;
             if (tid == 0) {
@@ -452,7 +456,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         }
         store_words += depth * NT;
     }
-    __threadfence();
+    __threadfence_block();
     __syncthreads();
     GRID_STAMP();
 
@@ -487,7 +491,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
             return kout;
         };
         auto sweep = [&]() -> int {       // install the proposals; workgroup-wide "anything new?"
-            if (!LDS) __threadfence();
+            if (!LDS) __threadfence_block();
             __syncthreads();
             int any = 0;
             for (int32_t i2 = tid; i2 < n2; i2 += NT) {
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                     any = 1;
                 }
             }
-            if (!LDS) __threadfence();
+            if (!LDS) __threadfence_block();
 #ifdef PLSLAM_GRID_TIMING
             ++npass;
 #endif
@@ -588,7 +592,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
 #endif
                 PLSLAM_AS_LDS uint32_t* left_of = (PLSLAM_AS_LDS uint32_t*)s_part + (t & 1u) * NW;   // alternating: one barrier per pass
                 if (lane == 0) left_of[wv] = alive;
-                if (alive > seg_words) __threadfence();                // survivors in the global share: wave 0 may gather them
+                if (alive > seg_words) __threadfence_block();                // survivors in the global share: wave 0 may gather them
                 __syncthreads();
                 uint32_t left = 0;
                 for (uint32_t w = 0; w < NW; ++w) left += left_of[w];

@@ -21,7 +21,10 @@ def main():
     dev = torch.device("cuda", 0)
     W = (3, 3, 3, 3)
     out = {}
-    for kind, mk, n in (("points", point_case, 1500), ("lines", line_case, 200)):
+    # GRID_POINTS_N / GRID_BATCHES: other point-problem sizes / launch sizes for experiments (e.g. "1000", "1,128,256")
+    n_points = int(os.environ.get("GRID_POINTS_N", "1500"))
+    batches = tuple(int(x) for x in os.environ.get("GRID_BATCHES", "128,256,1024,4096").split(","))
+    for kind, mk, n in (("points", point_case, n_points), ("lines", line_case, 200)):
         keep = []
 
         def up(a, dt):
@@ -41,7 +44,7 @@ def main():
             if "dir1" in c:
                 u.update(a=up(c["dir1"], np.float64), b=up(c["dir2"], np.float64))
             ups.append(u)
-        for B in (128, 256, 1024, 4096):
+        for B in batches:
             probs, outs = [], []
             for b in range(B):
                 u = ups[b % NV]
