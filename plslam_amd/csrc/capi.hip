@@ -1062,74 +1062,70 @@ int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const 
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard g(ctx->device);
     int r;
-    StreamSyncOnError sg(ctx->stream);              // sd / blocks / striped below are locals the copies read
+    hipStream_t s = ctx->stream;
+    StreamSyncOnError sg(s);
     const bool small = (nq + 63) / 64 < ctx->prop.multiProcessorCount * 4;
-    // large query sets (or a forced variant): the directed form of K1e, distances from the matrix cores
-    if (nt > 0 && (ctx->scan_variant == PLSLAM_SCAN_MFMA || (ctx->scan_variant == PLSLAM_SCAN_AUTO && !small))) {
-        if ((r = ctx->in_a.reserve((size_t)nq * 32))) return r;
-        if ((r = ctx->in_b.reserve((size_t)nt * 32 + 16))) return r;
-        if ((r = ctx->misc_a.reserve((size_t)nq * 8))) return r;                 // keys
-        if ((r = ctx->out_a.reserve((size_t)nq * 8))) return r;                  // idx
-        if ((r = ctx->out_b.reserve((size_t)nq * 8))) return r;                  // dist
-        std::vector<BlockDesc> blocks;
-        for (int32_t r0 = 0; r0 < nq; r0 += 256) blocks.push_back({0, r0});
-        const size_t n = blocks.size(), L = (n + 7) / 8;                          // XCD-striped layout
-        std::vector<BlockDesc> striped(8 * L, BlockDesc{-1, 0});
-        for (size_t i = 0; i < n; ++i) striped[(i & 7) * L + (i >> 3)] = blocks[i];
-        if ((r = ctx->misc_b.reserve(sizeof(SymDesc) + 16))) return r;
-        if ((r = ctx->misc_c.reserve(striped.size() * sizeof(BlockDesc)))) return r;
-        SymDesc y{};
-        y.a = ctx->in_a.as<uint8_t>(); y.b = ctx->in_b.as<uint8_t>(); y.keys12 = ctx->misc_a.as<uint32_t>();
-        y.n1 = nq; y.n2 = nt;
-        hipStream_t s = ctx->stream;
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_a.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_b.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->misc_b.p, &y, sizeof(y), hipMemcpyHostToDevice, s));
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->misc_c.p, striped.data(), striped.size() * sizeof(BlockDesc),
-                                        hipMemcpyHostToDevice, s));
-        if ((r = launch_scan_mfma_form(ctx->mfma_form, ctx->misc_b.as<SymDesc>(), ctx->misc_c.as<BlockDesc>(),
-                                       (int)striped.size(), nullptr, 0, nt > 2048, true, s))) return r;
-        if ((r = launch_unpack_keys(ctx->misc_a.as<uint32_t>(), nq * 2, ctx->out_a.as<int32_t>(),
-                                    ctx->out_b.as<int32_t>(), s))) return r;
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(idx, ctx->out_a.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(dist, ctx->out_b.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
-        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
-        return PLSLAM_OK;
-    }
-    const int variant = ctx->scan_variant == PLSLAM_SCAN_WAVE_PER_QUERY ||
-                                (ctx->scan_variant == PLSLAM_SCAN_AUTO && small)
+    // large query sets (or a forced variant): the directed form of the matrix-core scan; otherwise the popcount kernels
+    const bool mfma = nt > 0 && (ctx->scan_variant == PLSLAM_SCAN_MFMA || (ctx->scan_variant == PLSLAM_SCAN_AUTO && !small));
+    const int variant = ctx->scan_variant == PLSLAM_SCAN_WAVE_PER_QUERY || (ctx->scan_variant == PLSLAM_SCAN_AUTO && small)
                             ? PLSLAM_SCAN_WAVE_PER_QUERY : PLSLAM_SCAN_LANE_PER_QUERY;
     const int bt = variant == PLSLAM_SCAN_WAVE_PER_QUERY ? 256 : (ctx->scan_block ? ctx->scan_block : 256);
-    const int rpb = scan_rows_per_block(variant, bt);
-    if ((r = ctx->in_a.reserve((size_t)nq * 32))) return r;
-    if ((r = ctx->in_b.reserve((size_t)nt * 32 + 16))) return r;
-    if ((r = ctx->misc_a.reserve((size_t)nq * 8))) return r;                 // keys
-    if ((r = ctx->out_a.reserve((size_t)nq * 8))) return r;                  // idx
-    if ((r = ctx->out_b.reserve((size_t)nq * 8))) return r;                  // dist
+    const int rpb = mfma ? 256 : scan_rows_per_block(variant, bt);
     std::vector<BlockDesc> blocks;
     for (int32_t r0 = 0; r0 < nq; r0 += rpb) blocks.push_back({0, r0});
-    if (variant == PLSLAM_SCAN_LANE_PER_QUERY) {   // the kernel reads the XCD-striped layout (8 rows of L)
+    if (mfma || variant == PLSLAM_SCAN_LANE_PER_QUERY) {   // these kernels read the XCD-striped layout (8 rows of L)
         const size_t n = blocks.size(), L = (n + 7) / 8;
         std::vector<BlockDesc> striped(8 * L, BlockDesc{-1, 0});
         for (size_t i = 0; i < n; ++i) striped[(i & 7) * L + (i >> 3)] = blocks[i];
         blocks.swap(striped);
     }
-    if ((r = ctx->misc_b.reserve(sizeof(ScanDesc) + 16))) return r;
-    if ((r = ctx->misc_c.reserve(blocks.size() * sizeof(BlockDesc)))) return r;
-    ScanDesc sd{ctx->in_a.as<uint8_t>(), ctx->in_b.as<uint8_t>(), ctx->misc_a.as<uint32_t>(), nq, nt};
-    hipStream_t s = ctx->stream;
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_a.p, q, (size_t)nq * 32, hipMemcpyHostToDevice, s));
-    if (nt) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->in_b.p, t, (size_t)nt * 32, hipMemcpyHostToDevice, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->misc_b.p, &sd, sizeof(sd), hipMemcpyHostToDevice, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->misc_c.p, blocks.data(), blocks.size() * sizeof(BlockDesc),
-                                    hipMemcpyHostToDevice, s));
-    if ((r = launch_scan(ctx, variant, bt, ctx->misc_b.as<ScanDesc>(), ctx->misc_c.as<BlockDesc>(),
-                         (int)blocks.size(), nullptr, 0, s))) return r;
-    if ((r = launch_unpack_keys(ctx->misc_a.as<uint32_t>(), nq * 2, ctx->out_a.as<int32_t>(),
-                                ctx->out_b.as<int32_t>(), s))) return r;
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(idx, ctx->out_a.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(dist, ctx->out_b.p, (size_t)nq * 8, hipMemcpyDeviceToHost, s));
+    // one image [q | t | scan descriptor | block table] -- page-locked and uploaded with ONE copy when it is small --, the
+    // (idx, dist) pairs written by the unpack kernel straight into page-locked memory when the device can address it
+    const size_t qb = (size_t)nq * 32, tb = (size_t)nt * 32, bb = blocks.size() * sizeof(BlockDesc);
+    Carver c;
+    const size_t oQ = c.take(qb), oT = c.take(tb + 16), oD = c.take(std::max(sizeof(SymDesc), sizeof(ScanDesc))), oB = c.take(bb);
+    const size_t ob = ((size_t)nq * 8 + 255) & ~size_t(255);
+    if ((r = ctx->in_a.reserve(c.off))) return r;
+    if ((r = ctx->misc_a.reserve((size_t)nq * 8))) return r;                 // keys
+    if ((r = ctx->out_a.reserve(2 * ob))) return r;                          // idx | dist
+    if ((r = ctx->pin_out.reserve(2 * ob))) return r;
+    char* d = ctx->in_a.as<char>();
+    SymDesc y{};
+    y.a = (const uint8_t*)(d + oQ); y.b = (const uint8_t*)(d + oT); y.keys12 = ctx->misc_a.as<uint32_t>();
+    y.n1 = nq; y.n2 = nt;
+    const ScanDesc sd{(const uint8_t*)(d + oQ), (const uint8_t*)(d + oT), ctx->misc_a.as<uint32_t>(), nq, nt};
+    const void* desc = mfma ? (const void*)&y : (const void*)&sd;
+    const size_t desc_bytes = mfma ? sizeof(y) : sizeof(sd);
+    if (c.off <= (size_t(1) << 20)) {
+        if ((r = ctx->pin_in.reserve(c.off))) return r;
+        char* h = ctx->pin_in.as<char>();
+        memcpy(h + oQ, q, qb);
+        if (tb) memcpy(h + oT, t, tb);
+        memcpy(h + oD, desc, desc_bytes);
+        memcpy(h + oB, blocks.data(), bb);
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, c.off, hipMemcpyHostToDevice, s));
+    } else {
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oQ, q, qb, hipMemcpyHostToDevice, s));
+        if (tb) PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oT, t, tb, hipMemcpyHostToDevice, s));
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oD, desc, desc_bytes, hipMemcpyHostToDevice, s));
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oB, blocks.data(), bb, hipMemcpyHostToDevice, s));
+    }
+    if (mfma)
+        r = launch_scan_mfma_form(ctx->mfma_form, (const SymDesc*)(d + oD), (const BlockDesc*)(d + oB), (int)blocks.size(), nullptr,
+                                  0, nt > 2048, true, s);
+    else
+        r = launch_scan(ctx, variant, bt, (const ScanDesc*)(d + oD), (const BlockDesc*)(d + oB), (int)blocks.size(), nullptr, 0, s);
+    if (r) return r;
+    char* ho = ctx->pin_out.as<char>();
+    char* out_dev = static_cast<char*>(mapped_device_pointer(ho));
+    const bool in_place = out_dev != nullptr;
+    if (!in_place) out_dev = ctx->out_a.as<char>();
+    if ((r = launch_unpack_keys(ctx->misc_a.as<uint32_t>(), nq * 2, (int32_t*)out_dev, (int32_t*)(out_dev + ob), s))) return r;
+    if (!in_place) PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, out_dev, 2 * ob, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    sg.dismiss();
+    memcpy(idx, ho, (size_t)nq * 8);
+    memcpy(dist, ho + ob, (size_t)nq * 8);
     return PLSLAM_OK;
 }
 
