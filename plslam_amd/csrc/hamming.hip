@@ -542,6 +542,9 @@ __device__ __forceinline__ int ratio_pick(uint32_t k0, uint32_t k1, float nnr)
     return d0 < d1n ? (int)(k0 & KEY_IDX_MASK) : -1;
 }
 
+#ifndef PLSLAM_NT_FINALIZE
+#define PLSLAM_NT_FINALIZE 1
+#endif
 __global__ void __launch_bounds__(256)
 k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ blocks)
 {
@@ -565,7 +568,10 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
             k = make_uint2(b0, b1);
             reinterpret_cast<uint2*>(p.keys12_out)[i1] = k;          // diagnostics (plslam_match_plan_dump)
         } else {
-            k = reinterpret_cast<const uint2*>(p.keys12)[i1];
+            // (read once: non-temporal, like the table written below -- they must not push the scan's rows out of L2)
+            k = PLSLAM_NT_FINALIZE ? make_uint2(__builtin_nontemporal_load(p.keys12 + 2 * (size_t)i1),
+                                                __builtin_nontemporal_load(p.keys12 + 2 * (size_t)i1 + 1))
+                                   : reinterpret_cast<const uint2*>(p.keys12)[i1];
         }
         m = ratio_pick(k.x, k.y, p.nnr);
         accepted = m >= 0;
@@ -581,7 +587,8 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
             }
             if (!ok) { m = -1; cleared = true; }
         }
-        p.matches_12[i1] = m;
+        if (PLSLAM_NT_FINALIZE) __builtin_nontemporal_store(m, p.matches_12 + i1);
+        else p.matches_12[i1] = m;
     }
     if (p.n_matches) {
         // the reference's arithmetic: +1 per row the ratio test accepts, -1 per entry the consistency loop clears (equal

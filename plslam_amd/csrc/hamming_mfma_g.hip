@@ -65,6 +65,11 @@ constexpr int MF_TILE_N = 32;                 // b rows per tile
 constexpr int MF_KSTEPS = 4;                  // 256 bits = 4 x K 64
 constexpr int MF_ROW_STRIDE = 144;            // bytes per expanded b row in LDS (128 + 16: 4-bank skew)
 constexpr int MF_TILE_BYTES = MF_TILE_N * MF_ROW_STRIDE;
+// Streaming accesses (the column partials: written once by the scan, read once by the merge) carry the non-temporal hint, so
+// that they do not evict the b rows the scan re-reads from L2 -- of this scan or, in the split stepping, of the next one
+#ifndef PLSLAM_NT_STREAMS
+#define PLSLAM_NT_STREAMS 1
+#endif
 #ifndef PLSLAM_MG_GROUP
 #define PLSLAM_MG_GROUP 16
 #endif
@@ -277,7 +282,10 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         if (!DIRECTED && wave_has_rows && !PLSLAM_MG_X(8)) {
             const int j0 = (tl & ~(MF_CGROUP - 1)) * MF_TILE_N + 4 * lane;      // WT0 is a multiple of 8
             const i32x4 v = *reinterpret_cast<const i32x4*>(cstage + 4 * lane);
-            if (j0 < n2p) *reinterpret_cast<PLSLAM_GLOBAL i32x4*>(part + j0) = v;
+            if (j0 < n2p) {
+                if (PLSLAM_NT_STREAMS) __builtin_nontemporal_store(v, reinterpret_cast<PLSLAM_GLOBAL i32x4*>(part + j0));
+                else *reinterpret_cast<PLSLAM_GLOBAL i32x4*>(part + j0) = v;
+            }
             // tiles of a partial last group that never ran leave "none" in the padding columns (never read; keeps the
             // partial table a pure function of the inputs, which tools/determinism_check.py compares word for word)
             *reinterpret_cast<i32x4*>(cstage + 4 * lane) = i32x4{-1, -1, -1, -1};
@@ -613,7 +621,8 @@ k_merge_partials16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict
         uint32_t s0 = 0xFFFFFFFFu;
 #pragma unroll 8
         for (int wb = part_id; wb < nwb; wb += PARTS) {
-            const uint32_t e = part[(size_t)wb * n2p + j] - tw2;          // both halves >= tw: no borrow between them
+            const uint32_t e = (PLSLAM_NT_STREAMS ? __builtin_nontemporal_load(&part[(size_t)wb * n2p + j])
+                                                  : part[(size_t)wb * n2p + j]) - tw2;    // both halves >= tw: no borrow between them
             const uint32_t k = wide(e & 0xFFFFu, (uint32_t)wb);
             s0 = k < b0 ? e : s0;
             b1 = umin_(b1, umax_(b0, k));
