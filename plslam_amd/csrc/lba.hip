@@ -69,13 +69,14 @@ __device__ __forceinline__ void wave_store_rows(double* __restrict__ gbase /* ro
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
     const int total2 = valid * NW / 2;                      // number of double2 chunks (NW*valid is even
-    const double2* s2 = reinterpret_cast<const double2*>(slab);   //  unless NW and valid are odd)
-    double2* g2 = reinterpret_cast<double2*>(gbase);
+    const f64x2* s2 = reinterpret_cast<const f64x2*>(slab);      //  unless NW and valid are odd)
+    f64x2* g2 = reinterpret_cast<f64x2*>(gbase);
 #pragma unroll
     for (int k = 0; k < (NW + 1) / 2; ++k) {
         const int i = k * 64 + lane;
-        if (i < total2) g2[i] = s2[i];
+        if (i < total2) __builtin_nontemporal_store(s2[i], g2 + i);     // rows are written once and read by a later kernel
     }
     if ((valid * NW) & 1) {                                  // odd tail double
         if (lane == 0) gbase[valid * NW - 1] = slab[valid * NW - 1];
