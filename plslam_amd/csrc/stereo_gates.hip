@@ -140,23 +140,23 @@ k_stereo_gates_batched(const plslam_stereo_gate_problem* __restrict__ gates, con
     const int i1 = bd.row0 + (int)threadIdx.x;
     int ok = 0;
     if (i1 < q.n_l) {
-        const int32_t i2 = q.matches_12[i1];
+        const int32_t i2 = __builtin_nontemporal_load(q.matches_12 + i1);   // (tables and outputs stream through once)
         if (q.lines) {
             double ds, de;
             const int32_t k = line_gate_one(i2, reinterpret_cast<const float4*>(q.f_l)[i1],
                                             reinterpret_cast<const float4*>(q.f_r), q.n_r, q.min_disp, q.line_horiz_th,
                                             q.stereo_overlap_th, q.ls_min_disp_ratio, &ds, &de);
             ok = k >= 0;
-            q.stereo_12[i1] = k;
-            q.disp[2 * (size_t)i1] = ds;
-            q.disp[2 * (size_t)i1 + 1] = de;
+            __builtin_nontemporal_store(k, q.stereo_12 + i1);
+            __builtin_nontemporal_store(ds, q.disp + 2 * (size_t)i1);
+            __builtin_nontemporal_store(de, q.disp + 2 * (size_t)i1 + 1);
         } else {
             double dsp;
             const int32_t k = point_gate_one(i2, reinterpret_cast<const float2*>(q.f_l)[i1],
                                              reinterpret_cast<const float2*>(q.f_r), q.n_r, q.max_dist_epip, q.min_disp, &dsp);
             ok = k >= 0;
-            q.stereo_12[i1] = k;
-            q.disp[i1] = dsp;
+            __builtin_nontemporal_store(k, q.stereo_12 + i1);
+            __builtin_nontemporal_store(dsp, q.disp + i1);
         }
     }
     const unsigned long long bal = __ballot(ok);
