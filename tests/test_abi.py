@@ -75,3 +75,18 @@ def test_every_symbol_has_a_declared_signature():
     L = plslam_amd.load()
     missing = [s for s in plslam_amd.ABI_SYMBOLS if getattr(L, s).argtypes is None]
     assert not missing, missing
+
+
+def test_no_device_scope_fence_in_any_kernel():
+    """A device-scope fence is an L2 write-back + invalidate on gfx950 (buffer_wbl2 / buffer_inv) whose cost grows with what the
+    rest of the chip has written (it doubled the windowed matcher's time per problem under load): every exchange through
+    memory inside these kernels is between lanes of one workgroup.  Checked in the ISA of every kernel source."""
+    import subprocess
+    from plslam_amd import build as B
+    csrc = os.path.join(ROOT, "plslam_amd", "csrc")
+    for src in B.SOURCES:
+        r = subprocess.run([B.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                            "-I" + os.path.join(ROOT, "include"), "-S", "--cuda-device-only", os.path.join(csrc, src), "-o", "-"],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-1500:]
+        assert "buffer_wbl2" not in r.stdout and "buffer_inv" not in r.stdout, src
