@@ -31,6 +31,7 @@
 #ifndef PLSLAM_HIP_H
 #define PLSLAM_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus

@@ -90,3 +90,14 @@ def test_no_device_scope_fence_in_any_kernel():
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1500:]
         assert "buffer_wbl2" not in r.stdout and "buffer_inv" not in r.stdout, src
+
+
+def test_header_is_plain_c(tmp_path):
+    """The drop-in boundary is a C ABI: include/plslam_hip.h compiles on its own as C99 (and as C++11), pedantic, no warnings."""
+    import subprocess
+    src = tmp_path / "abi.c"
+    src.write_text('#include "plslam_hip.h"\nint main(void) { return 0; }\n')
+    for cmd in (["gcc", "-std=c99"], ["g++", "-std=c++11", "-x", "c++"]):
+        r = subprocess.run(cmd + ["-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-fsyntax-only",
+                                  str(src)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
