@@ -311,9 +311,13 @@ class PipelinedGather:
     def step(self, k: int):
         """Compute step k into buffer k % nbuf and start gathering it."""
         b = k % self.pipe.nbuf
-        self.pipe.before_overwrite(b, self.bm.streams[b])
-        self.bm.run_async(b)
-        return self.pipe.submit(b, self.bm.tables[b], self.bm.streams[b])
+        # as run_overlapped(): every scan on streams[0], the stages behind it -- which write table b -- on the
+        # high-priority streams[1]; that stream therefore waits for the previous gather of buffer b, and the narrowing
+        # copy + the gather's event go behind the stages on it
+        scan, post = self.bm.streams[0], self.bm.streams[min(1, len(self.bm.streams) - 1)]
+        self.pipe.before_overwrite(b, post)
+        self.bm.plans[b].run_split(scan.cuda_stream, post.cuda_stream)
+        return self.pipe.submit(b, self.bm.tables[b], post)
 
     def finish(self):
         self.pipe.finish()
