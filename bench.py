@@ -55,7 +55,7 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
-SCAN_KERNEL_SOURCES = ("common.hpp", "hamming.hip", "hamming_mfma.hip", "hamming_mfma_g.hip")
+SCAN_KERNEL_SOURCES = ("common.hpp", "hamming.hip", "hamming_mfma.hip", "hamming_mfma_g.hip", "hamming_mfma_h.hip", "hamming_mfma_d.hip")
 
 
 def kernel_source_hash() -> str:
@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--scan-block", type=int, default=0)
     ap.add_argument("--sym-rows", type=int, default=0)
     ap.add_argument("--group-cap", type=int, default=0)
-    ap.add_argument("--mfma-form", type=int, default=0, help="0 = auto (K1f), 1 = K1e (best-2 push per tile), 2 = K1f (group minima)")
+    ap.add_argument("--mfma-form", type=int, default=0, help="0 = auto (K1h), 1 = K1e (best-2 push per tile), 2 = K1f (group minima, rows), 3 = K1g (two directed scans per mutual problem), 4 = K1h (group minima both ways)")
     ap.add_argument("--fuse", type=int, default=0, help="K1f: 0 = auto, 1 = never, 2 = always one workgroup per problem incl. merge + finalize")
     ap.add_argument("--no-gates", action="store_true", help="leave the stereo-gate stage out of the step (tables only)")
     ap.add_argument("--step-streams", type=int, default=2, help="output buffers / HIP streams the steps alternate over")
@@ -347,7 +347,7 @@ def main():
         achieved_gbs = info["algorithmic_bytes"] / scan_s / 1e9
         mfma = info["scan_variant"] == 4
         form = ctx.get_option("mfma_form")
-        kernel_name = {4: ("k_scan_sym_mfma" if form == 1 else "k_scan_sym_mfma_g"),
+        kernel_name = {4: {1: "k_scan_sym_mfma", 2: "k_scan_sym_mfma_g", 3: "k_scan_dir_mfma"}.get(form, "k_scan_sym_mfma_h"),
                        3: "k_scan_symmetric" + ("_r4" if info["scan_block_threads"] == 64 else ""),
                        2: "k_scan_wave_per_query", 1: "k_scan_lane_per_query"}.get(info["scan_variant"], "k_scan")
         # HBM bytes / executed instructions of the dominant kernel per launch: PMC counters cannot be read from inside

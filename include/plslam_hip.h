@@ -38,7 +38,9 @@
 extern "C" {
 #endif
 
-#define PLSLAM_ABI_VERSION 1
+/* 2: plslam_match_problem grew (keep_prior, reserved: 56 bytes), plslam_lba_plan_iterate's flags became a bit mask, options
+ * "mfma_form" 3/4 and "exact_second".  Clients compare plslam_abi_version() with the value they were compiled against. */
+#define PLSLAM_ABI_VERSION 2
 #define PLSLAM_DESC_BYTES 32
 /* largest train set of one directed scan: the composite (distance,index) key keeps 23
  * index bits beside the 9 distance bits */
@@ -89,8 +91,12 @@ void plslam_ctx_destroy(plslam_ctx* ctx);
 /* options: "scan_variant" (PLSLAM_SCAN_*), "scan_block" (queries per workgroup of the directed
  * scan: 256|512|1024), "sym_rows" (rows of d1 per lane in the symmetric scan: 0 = auto (default) | 1 | 4),
  * "group_cap" (workgroups of one problem co-scheduled on one XCD: 0 = auto (default) | 1..64),
- * "mfma_form" (bookkeeping of the matrix-core scan: 0 = auto (default) | 1 = best-2 push per tile (K1e) |
- * 2 = group minima + second best by recomputation (K1f); identical results),
+ * "mfma_form" (bookkeeping of the matrix-core scan: 0 = auto (default; = 4) | 1 = best-2 push per tile (K1e) |
+ * 2 = group minima in the row direction + second best by recomputation (K1f) | 3 = two directed scans per mutual problem
+ * (K1g) | 4 = group minima in both directions, class-major layouts (K1h); identical match tables),
+ * "exact_second" (K1h: 0 (default) = the index of a row's SECOND neighbour in the internal key tables is exact only where
+ * it is an output (plslam_knn2_hamming256) and the column keys are completed lazily by the finalize stage | 1 = every key
+ * of plslam_match_plan_dump is exact; match tables are identical either way),
  * "fuse" (K1f: one workgroup per problem that also merges the column results and applies the ratio test + mutual
  * check, i.e. one kernel per plan run: 0 = auto (currently: never -- measured no faster) | 1 = never | 2 = always) */
 int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value);

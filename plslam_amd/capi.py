@@ -24,6 +24,7 @@ SCAN_AUTO, SCAN_LANE_PER_QUERY, SCAN_WAVE_PER_QUERY, SCAN_SYMMETRIC, SCAN_MFMA =
 MAX_TRAIN_ROWS = 1 << 23
 
 # every symbol include/plslam_hip.h declares (tests check the .so exports all of them)
+ABI_VERSION = 2          # include/plslam_hip.h: PLSLAM_ABI_VERSION
 ABI_SYMBOLS = (
     "plslam_strerror", "plslam_last_error", "plslam_abi_version",
     "plslam_ctx_create", "plslam_ctx_destroy", "plslam_ctx_set_option", "plslam_ctx_get_option",
@@ -161,6 +162,9 @@ def load() -> C.CDLL:
     L.plslam_last_error.argtypes = []
     L.plslam_abi_version.restype = C.c_int
     L.plslam_abi_version.argtypes = []
+    if L.plslam_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"libplslam_hip.so has ABI version {L.plslam_abi_version()}, these bindings were written for {ABI_VERSION} "
+                           "(struct layouts differ: rebuild with plslam_amd/build.py)")
     L.plslam_lbd_binarise.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.plslam_lbd_binarise_dev.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
     L.plslam_median_desc_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]

@@ -80,6 +80,7 @@ struct plslam_match_plan {
     bool sym_mfma = false;             // symmetric problems run on K1e (matrix cores)
     bool sym_mfma_multi = false;       // ... and some of them have n2 > 2048 (multi-window instantiation)
     int mfma_form = 0;                 // ctx option "mfma_form" at plan creation (0/2 = K1f, 1 = K1e)
+    bool exact_second = false;         // K1h: exact key tables (ctx option at plan creation); else the finalize kernel completes keys21 lazily
     bool fused = false;                // K1f, one workgroup per problem: merge + ratio + mutual inside the scan kernel
     int merge_parts = 1;               // K1f: lanes per column in the partial merge (tall problems: many row blocks, few columns)
     bool col_split = false;            // K1f on a FEW LARGE problems: columns cut into ranges scanned as sub-problems
@@ -162,7 +163,11 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     const bool allow_sym = !use_wpq &&
                            (ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_SYMMETRIC ||
                             ctx->scan_variant == PLSLAM_SCAN_MFMA);
-    auto is_sym = [&](const plslam_match_problem& p) { return allow_sym && p.mutual && p.n1 > 0 && p.n2 > 0; };
+    // mfma_form 3: a mutual problem runs as TWO DIRECTED matrix-core scans (d1 -> d2 and d2 -> d1; what the reference's two
+    // knnMatch calls evaluate) -- no column direction, no partial table, no merge kernel
+    const bool dpair = allow_sym && ctx->mfma_form == 3 &&
+                       (ctx->scan_variant == PLSLAM_SCAN_MFMA || ctx->scan_variant == PLSLAM_SCAN_AUTO);
+    auto is_sym = [&](const plslam_match_problem& p) { return allow_sym && !dpair && p.mutual && p.n1 > 0 && p.n2 > 0; };
 
     // sym_rows 0 = auto: 4 rows of d1 per lane (4x fewer column partials, slightly faster) once the
     // plan has enough 256-row waves for >= 6 full rounds of the chip (17 single-wave workgroups fit a
@@ -171,6 +176,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->sym_mfma = allow_sym && (ctx->scan_variant == PLSLAM_SCAN_MFMA || ctx->scan_variant == PLSLAM_SCAN_AUTO);
     P->sym_mfma_multi = false;
     P->mfma_form = ctx->mfma_form;
+    P->exact_second = ctx->exact_second != 0;
     P->dir_multi = false;
     // (set per scanned (sub-)problem while the tables are built)
     P->sym_rows = P->sym_mfma ? 4 : ctx->sym_rows;      // K1e uses the 256-row tables of K1b'
@@ -198,7 +204,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             if (probs[i].keep_prior) fits = false;          // the in-kernel finalize always writes every row
         }
         (void)nmf;
-        P->fused = k1f && fits && ctx->fuse == 2 && !P->col_split;
+        P->fused = k1f && fits && ctx->fuse == 2 && !P->col_split && !dpair;
     }
     const int rpp = sym_rows_per_partial(P->sym_rows);   // a-rows per column partial
     const int rps = sym_rows_per_block(P->sym_rows);     // a-rows per workgroup of the symmetric scan
@@ -207,7 +213,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     int64_t mf_row_blocks = 0;
     for (int32_t i = 0; i < nprob; ++i)
         if (probs[i].n1 > 0 && probs[i].n2 > 0) mf_row_blocks += (probs[i].n1 + 255) / 256;
-    P->col_split = P->col_split && k1f && mf_row_blocks > 0;
+    P->col_split = P->col_split && k1f && mf_row_blocks > 0 && !dpair;
     auto split_of = [&](const plslam_match_problem& p, int32_t* cstep) -> int32_t {
         *cstep = 0;
         if (!P->col_split || p.n1 <= 0 || p.n2 <= 0) return 1;
@@ -320,6 +326,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         if (p.mutual) key_row += p.n2;
         pd.keys12 = k12;
         pd.keys21 = k21;
+        pd.d1 = p.d1; pd.d2 = p.d2;
         const bool mf_path = P->sym_mfma && p.n1 > 0 && p.n2 > 0;    // this problem runs on K1e / K1f
         if (!(P->fused && mf_path))
             for (int32_t r0 = 0; r0 < p.n1; r0 += 256) fblocks.push_back({i, r0});
@@ -329,11 +336,13 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             // one sub-problem per column range: its own row results (relative column indices, merged by the finalize
             // kernel), its own partial area, its slice of keys21
             pd.split_tmp = d_tmp + 2 * tmp_row; pd.keys12_out = k12; pd.nsplit = nsplit; pd.cstep = cstep;
+            pd.lazy21 = p.mutual && P->sym_mfma && mfma_form_is_h(P->mfma_form) && !P->fused && !P->exact_second;
             std::vector<SymDesc>& dst = p.mutual ? syms : dirs;
             std::vector<BlockDesc>& dstb = p.mutual ? yblocks : dblocks;
             for (int32_t s_ = 0; s_ < nsplit; ++s_) {
                 const int32_t c0 = s_ * cstep, n2s = std::min(cstep, p.n2 - c0);
                 SymDesc y{};
+                y.flags = ctx->exact_second ? 1 : 0;
                 y.a = p.d1; y.b = p.d2 + (size_t)c0 * 32;
                 y.keys12 = d_tmp + 2 * (tmp_row + (int64_t)s_ * p.n1);
                 y.n1 = p.n1; y.n2 = n2s;
@@ -353,7 +362,9 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             devals += (p.mutual ? 2LL : 1LL) * p.n1 * p.n2;
             abytes += p.mutual ? 2 * 32LL * (p.n1 + p.n2) + 16LL * (p.n1 + p.n2) : 32LL * (p.n1 + p.n2) + 16LL * p.n1;
         } else if (is_sym(p)) {
+            pd.lazy21 = P->sym_mfma && mfma_form_is_h(P->mfma_form) && !P->fused && !P->exact_second;
             SymDesc y{};
+            y.flags = ctx->exact_second ? 1 : 0;
             y.a = p.d1; y.b = p.d2; y.keys12 = k12; y.keys21 = k21;
             y.part21 = d_part + 2 * part_row;
             y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = (p.n1 + rpp - 1) / rpp;
@@ -370,22 +381,26 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             evals += (int64_t)p.n1 * p.n2;
             devals += 2LL * p.n1 * p.n2;
             abytes += 2 * 32LL * (p.n1 + p.n2) + 16LL * (p.n1 + p.n2);
-        } else if (P->sym_mfma && !p.mutual && p.n1 > 0 && p.n2 > 0) {
-            // non-mutual problem on the matrix cores: the directed form of K1e (row direction only)
-            SymDesc y{};
-            y.a = p.d1; y.b = p.d2; y.keys12 = k12; y.keys21 = nullptr; y.part21 = nullptr;
-            y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = 0;
-            if (P->fused) {
-                y.mutual = 0; y.matches_12 = p.matches_12; y.n_matches = pd.n_matches; y.nnr = p.nnr;
-                dblocks.push_back({(int32_t)dirs.size(), 0});
-            } else {
-                for (int32_t r0 = 0; r0 < p.n1; r0 += 256) dblocks.push_back({(int32_t)dirs.size(), r0});
+        } else if (P->sym_mfma && (!p.mutual || dpair) && p.n1 > 0 && p.n2 > 0) {
+            // non-mutual problem on the matrix cores: the directed form of K1e (row direction only); mfma_form 3: also the two
+            // directions of a mutual problem
+            for (int dir = 0; dir < (p.mutual ? 2 : 1); ++dir) {
+                SymDesc y{};
+                y.flags = ctx->exact_second ? 1 : 0;
+                y.a = dir ? p.d2 : p.d1; y.b = dir ? p.d1 : p.d2; y.keys12 = dir ? k21 : k12; y.keys21 = nullptr; y.part21 = nullptr;
+                y.n1 = dir ? p.n2 : p.n1; y.n2 = dir ? p.n1 : p.n2; y.n_iblk = 0;
+                if (P->fused && !p.mutual) {
+                    y.mutual = 0; y.matches_12 = p.matches_12; y.n_matches = pd.n_matches; y.nnr = p.nnr;
+                    dblocks.push_back({(int32_t)dirs.size(), 0});
+                } else {
+                    for (int32_t r0 = 0; r0 < y.n1; r0 += 256) dblocks.push_back({(int32_t)dirs.size(), r0});
+                }
+                if (y.n2 > 2048) P->dir_multi = true;
+                dirs.push_back(y);
+                evals += (int64_t)p.n1 * p.n2;
+                devals += (int64_t)p.n1 * p.n2;
+                abytes += 32LL * (p.n1 + p.n2) + 16LL * y.n1;
             }
-            if (p.n2 > 2048) P->dir_multi = true;
-            dirs.push_back(y);
-            evals += (int64_t)p.n1 * p.n2;
-            devals += (int64_t)p.n1 * p.n2;
-            abytes += 32LL * (p.n1 + p.n2) + 16LL * p.n1;
         } else {
             if (p.n1 > 0) {
                 ScanDesc sc{p.d1, p.d2, k12, p.n1, p.n2};
@@ -600,8 +615,10 @@ static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
         s = sp;
     }
 
-    r = P->sym_mfma && P->mfma_form != 1 ? launch_merge_partials16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, s)
-                                         : launch_merge_partials(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s);
+    r = P->sym_mfma && mfma_form_is_h(P->mfma_form) && !P->fused
+            ? launch_merge_fix16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, P->exact_second, s)
+            : P->sym_mfma && P->mfma_form != 1 ? launch_merge_partials16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, s)
+                                               : launch_merge_partials(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s);
     if (r) return r;
     r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, s);
     if (r) return r;
@@ -728,13 +745,18 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         return PLSLAM_OK;
     }
     if (!strcmp(key, "mfma_form")) {
-        PLSLAM_REQUIRE(value >= 0 && value <= 2, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(value >= 0 && value <= 4, PLSLAM_EINVAL);
         ctx->mfma_form = value;
         return PLSLAM_OK;
     }
     if (!strcmp(key, "fuse")) {
         PLSLAM_REQUIRE(value >= 0 && value <= 2, PLSLAM_EINVAL);
         ctx->fuse = value;
+        return PLSLAM_OK;
+    }
+    if (!strcmp(key, "exact_second")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= 1, PLSLAM_EINVAL);
+        ctx->exact_second = value;
         return PLSLAM_OK;
     }
     if (!strcmp(key, "col_split")) {
@@ -756,6 +778,7 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "mfma_form")) { *value = ctx->mfma_form; return PLSLAM_OK; }
     if (!strcmp(key, "fuse")) { *value = ctx->fuse; return PLSLAM_OK; }
     if (!strcmp(key, "col_split")) { *value = ctx->col_split; return PLSLAM_OK; }
+    if (!strcmp(key, "exact_second")) { *value = ctx->exact_second; return PLSLAM_OK; }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }
@@ -1093,6 +1116,7 @@ int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const 
     SymDesc y{};
     y.a = (const uint8_t*)(d + oQ); y.b = (const uint8_t*)(d + oT); y.keys12 = ctx->misc_a.as<uint32_t>();
     y.n1 = nq; y.n2 = nt;
+    y.flags = 1;                                   // knnMatch returns the second neighbour's index
     const ScanDesc sd{(const uint8_t*)(d + oQ), (const uint8_t*)(d + oT), ctx->misc_a.as<uint32_t>(), nq, nt};
     const void* desc = mfma ? (const void*)&y : (const void*)&sd;
     const size_t desc_bytes = mfma ? sizeof(y) : sizeof(sd);

@@ -122,8 +122,9 @@ struct plslam_ctx {
     int scan_block = 0;  // 0 = variant default
     int group_cap = 0;   // blocks of one problem kept together on one XCD; 0 = auto (capi.hip, `stripe`)
     int sym_rows = 0;    // rows of d1 per lane in the symmetric scan: 0 = auto, 1, 4
-    int mfma_form = 0;   // matrix-core scan: 0 = auto (grouped, K1f), 1 = exact push per tile (K1e), 2 = grouped (K1f)
+    int mfma_form = 0;   // matrix-core scan: 0 = auto (= 4), 1 = exact push per tile (K1e), 2 = grouped rows (K1f), 3 = directed pairs (K1g), 4 = grouped both ways (K1h)
     int col_split = 0;   // K1f, few large problems: 0 = auto (cut the columns into ranges when the plan cannot fill the chip), 1 = never, 2 = always
+    int exact_second = 0; // K1h: 1 = the index of every second-best row key is exact (0: only where it is an output -- knnMatch)
     int fuse = 0;        // K1f: 0 = auto (one workgroup per problem incl. merge + finalize when the plan is large), 1 = never, 2 = always
     std::mutex mu;       // serialises the host-pointer entry points
     plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
@@ -163,7 +164,12 @@ struct ProblemDesc {    // one StVO::match problem = scan12 (+ scan21 when mutua
     uint32_t* keys12_out;
     int32_t nsplit, cstep;
     // plslam_match_problem.keep_prior: rows the ratio test rejects keep what matches_12 holds (stvo-pl's resize())
-    int32_t keep_prior, pad;
+    int32_t keep_prior;
+    // K1h plans: keys21[j] = (best row, best row OUTSIDE the best row's aligned group of 16 rows of d1): the exact second best
+    // is recomputed here, and only for the columns a row actually points at (15 XOR + popcount distances from d1 / d2)
+    int32_t lazy21;
+    const uint8_t* d1;
+    const uint8_t* d2;
 };
 
 struct BlockDesc {      // one workgroup's slice of a scan / problem
@@ -192,7 +198,7 @@ struct SymDesc {
     int32_t* matches_12;    //   n1 match-table entries (nullptr: not fused)
     int32_t* n_matches;     //   one counter, STORED (not accumulated) by the problem's workgroup; may be nullptr
     float nnr;
-    int32_t pad;
+    int32_t flags;          // bit 0 (K1h): the INDEX of the second-best row key must be exact too (knnMatch output, key dumps)
 };
 // rows_per_lane: 1 (K1b: 256-thread workgroups, 64 a-rows per wave) or 4 (K1b': 64-thread
 // workgroups, 256 a-rows per wave).  sym_rows_per_block() = a-rows covered by one BlockDesc.
@@ -218,9 +224,20 @@ int merge_partials16_cols(int parts);
 int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, hipStream_t s);
 // (Column split of a large problem, K1f: the columns are cut into ranges scanned as sub-problems of their own -- more
 // workgroups than 256-row blocks alone give; the per-range row results are merged by the finalize kernel: ProblemDesc.)
+// K1h (hamming_mfma_h.hip): K1f's contract and partial table; minimum-only bookkeeping in both directions, class-major layouts;
+// its partials need launch_merge_fix16 (merge + second-best recomputation), same block table as launch_merge_partials16
+inline bool mfma_form_is_h(int form) { return form == 0 || form == 4; }      // 0 = auto
+int launch_scan_sym_mfma_h(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
+                           bool directed, hipStream_t s);
+int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, bool fix, hipStream_t s);
+int mh_slot_of_column(int n2, int j);
+// K1g (hamming_mfma_d.hip): the directed scan, one item per (directed scan, 256-row block of a); any n2 (windows inside)
+int launch_scan_dir_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero, hipStream_t s);
 inline int launch_scan_mfma_form(int form, const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
                                  int nzero, bool multi_window, bool directed, hipStream_t s, bool fused = false)
 {
+    if (form == 3 && directed && !fused) return launch_scan_dir_mfma(d_sym, d_blocks, nblocks, d_zero, nzero, s);
+    if (mfma_form_is_h(form) && !fused) return launch_scan_sym_mfma_h(d_sym, d_blocks, nblocks, d_zero, nzero, directed, s);
     return form == 1 ? launch_scan_sym_mfma(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, s)
                      : launch_scan_sym_mfma_g(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, fused, s);
 }

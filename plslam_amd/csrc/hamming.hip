@@ -553,8 +553,10 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
     const int i1 = bd.row0 + (int)threadIdx.x;
     int m = -1;
     bool accepted = false, cleared = false;
+    uint2 k = make_uint2(KEY_NONE, KEY_NONE);            // this row's scan result (rows past n1: none)
+    uint2 kb = make_uint2(KEY_NONE, KEY_NONE);           // the candidate column's keys21 pair
+    bool check = false;                                  // this row has a candidate whose consistency must be checked
     if (i1 < p.n1) {
-        uint2 k;
         if (p.nsplit > 1) {
             // column-split problem: best-2 over the ranges' row results; keys are (d << 23 | j) with j relative to the
             // range, so its first column is added first -- (d, j) order holds within and across ranges
@@ -580,13 +582,69 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
         // is defined as failing it)
         if (!accepted && p.keep_prior) m = p.matches_12[i1];
         if (m >= 0 && p.mutual) {
-            bool ok = m < p.n2;
-            if (ok) {
-                const uint2 kb = reinterpret_cast<const uint2*>(p.keys21)[m];
-                ok = ratio_pick(kb.x, kb.y, p.nnr) == i1;
-            }
-            if (!ok) { m = -1; cleared = true; }
+            check = m < p.n2;
+            if (check) kb = reinterpret_cast<const uint2*>(p.keys21)[m];
+            else { m = -1; cleared = true; }
         }
+    }
+    bool ok = true;
+    if (!p.lazy21) {
+        if (check) ok = ratio_pick(kb.x, kb.y, p.nnr) == i1;
+    } else {
+        // K1h plans.  kb.x = column m's best row (exact); kb.y = its best row OUTSIDE kb.x's aligned group of 16 rows of d1: an
+        // upper bound of the true second best.  The consistency check can only hold if the best row is THIS row; then the
+        // other 15 rows of this row's group are what kb.y has not seen.  Row r's own scan result bounds its distance to
+        // column m from below: it IS r's best distance if m is r's best column, and it is at least r's second-best distance
+        // otherwise.  Those results sit in the neighbouring lanes (a group = 16 aligned lanes: DPP row rotation).  With the
+        // lower bound lo = min(kb.y's distance, the 15 bounds) and the upper bound hi = kb.y's distance on the same side of
+        // the ratio threshold the test is decided; only between them are the 15 distances recomputed (XOR + popcount).
+        const uint32_t mm = check ? (uint32_t)m : 0xFFFFFFFFu;
+        uint32_t lb = 0xFFFFFFFFu;                       // min over the other rows of the group of their bound (a distance)
+#define PLSLAM_FIN_ROT(S)                                                                           \
+        {                                                                                          \
+            const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k.x, 0x120 + (S), 0xf, 0xf, false); \
+            const uint32_t py = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)k.y, 0x120 + (S), 0xf, 0xf, false); \
+            const uint32_t b = (px != KEY_NONE && (px & KEY_IDX_MASK) == mm) ? (px >> KEY_IDX_BITS)  \
+                                                                           : (py == KEY_NONE ? 0xFFFFFFFFu : (py >> KEY_IDX_BITS)); \
+            lb = lb < b ? lb : b;                                                                  \
+        }
+        PLSLAM_FIN_ROT(1) PLSLAM_FIN_ROT(2) PLSLAM_FIN_ROT(3) PLSLAM_FIN_ROT(4) PLSLAM_FIN_ROT(5)
+        PLSLAM_FIN_ROT(6) PLSLAM_FIN_ROT(7) PLSLAM_FIN_ROT(8) PLSLAM_FIN_ROT(9) PLSLAM_FIN_ROT(10)
+        PLSLAM_FIN_ROT(11) PLSLAM_FIN_ROT(12) PLSLAM_FIN_ROT(13) PLSLAM_FIN_ROT(14) PLSLAM_FIN_ROT(15)
+#undef PLSLAM_FIN_ROT
+        if (check) {
+            ok = kb.x != KEY_NONE && (int)(kb.x & KEY_IDX_MASK) == i1;
+            if (ok) {
+                const float d0 = (float)(kb.x >> KEY_IDX_BITS);
+                const uint32_t hi = kb.y == KEY_NONE ? 0xFFFFFFFFu : (kb.y >> KEY_IDX_BITS);
+                const uint32_t lo = hi < lb ? hi : lb;
+                if (hi != 0xFFFFFFFFu && !(d0 < __fmul_rn((float)hi, p.nnr))) {
+                    ok = false;                                      // fails even against the upper bound
+                } else if (lo != 0xFFFFFFFFu && d0 < __fmul_rn((float)lo, p.nnr)) {
+                    ok = true;                                       // holds even against the lower bound (a second row exists)
+                } else {
+                    uint32_t second = kb.y;
+                    const uint4* b = reinterpret_cast<const uint4*>(p.d2 + (size_t)m * 32);
+                    const uint4 b_lo = __ldg(b), b_hi = __ldg(b + 1);
+                    const int base = i1 & ~15;
+                    for (int q = 0; q < 16; ++q) {
+                        const int i = base + q;
+                        const bool use = i != i1 && i < p.n1;
+                        const uint4* a = reinterpret_cast<const uint4*>(p.d1 + (size_t)(use ? i : i1) * 32);
+                        const uint4 a_lo = __ldg(a), a_hi = __ldg(a + 1);
+                        const uint32_t d = __popc(a_lo.x ^ b_lo.x) + __popc(a_lo.y ^ b_lo.y) + __popc(a_lo.z ^ b_lo.z) +
+                                           __popc(a_lo.w ^ b_lo.w) + __popc(a_hi.x ^ b_hi.x) + __popc(a_hi.y ^ b_hi.y) +
+                                           __popc(a_hi.z ^ b_hi.z) + __popc(a_hi.w ^ b_hi.w);
+                        const uint32_t cand = use ? ((d << KEY_IDX_BITS) | (uint32_t)i) : KEY_NONE;
+                        second = second < cand ? second : cand;
+                    }
+                    ok = ratio_pick(kb.x, second, p.nnr) == i1;
+                }
+            }
+        }
+    }
+    if (check && !ok) { m = -1; cleared = true; }
+    if (i1 < p.n1) {
         if (PLSLAM_NT_FINALIZE) __builtin_nontemporal_store(m, p.matches_12 + i1);
         else p.matches_12[i1] = m;
     }

@@ -1,0 +1,670 @@
+// hamming_mfma_h.hip -- K1h: the matrix-core symmetric Hamming kNN-2 scan with MINIMUM-ONLY bookkeeping in BOTH
+// directions (gfx950).  Round 3; the default.
+//
+// Contract, work decomposition, block tables, partial table: those of K1f (hamming_mfma_g.hip) -- keys12[i] = best-2 over j,
+// part21[64-row block of a][column slot] = (best | second << 16) as 16-bit keys, keys = (distance << 23) | index =
+// cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) order in both directions (reference call sites src/mapHandler.cpp:277,424,597,
+// 712,3223,3249).  The distances come out of the same four v_mfma_scale_f32_32x32x64_f8f6f4 per 32 x 32 tile (fp4 codes of
+// +-1, accumulator = 2^23 + 128 d + tag, exact).
+//
+// K1f was bound by VALU issue: 153 VALU instructions per 8 MFMAs (round 2 PMC), of which 48 were the exact best-2 push of
+// the column direction, 16 the per-tile tile-number tags in the accumulator seeds, ~20 the per-tile column finish.  Here:
+//
+//  1. Column direction = "minimum now, second best later" too.  A lane's 16 accumulator registers of an M-tile are a GROUP of
+//     16 rows of a; per tile one packed min chain over the registers gives the group minima (16 v_pk_min_u16 instead of 48),
+//     a wave's 4 groups per column (2 M-tiles x 2 lane halves) give B0 = the best and B1 = the best OUTSIDE B0's group, and
+//     that pair is the column partial.  The merge kernel (k_merge_fix16) combines the 64-row blocks the same way -- K0 = best
+//     key, K1 = best key outside K0's 16-row group -- and then recomputes the 15 other members of K0's group with XOR +
+//     popcount from the raw rows: second best = min(K1, best of those).  Exact, tie order included.
+//  2. WHICH row of a sits in (M-tile, MFMA row) is free, so a lane's 16 registers hold 16 CONSECUTIVE rows of a
+//     (local row = 16 (2 mt + g) + r): the recomputation reads 512 contiguous bytes, and the register number IS the row
+//     within the group -- the tag rides in the accumulator seed as a per-register CONSTANT (no per-tile seed updates).
+//  3. WHICH row of b sits in (tile, lane) is free too: inside a group of 16 tiles the mapping is class-major,
+//     j = 512 G + S class + tile-in-group (S = 16; in the ragged last group S = ceil(rest / 32) and the group has S tiles), so
+//     the row direction's second-best recomputation -- all members of the winner's (group, class) -- reads S consecutive
+//     rows of b (K1f: 16 cache lines per row of a, 10 x the b stream itself).  No tile number in the row keys: the
+//     recomputation finds the exact column.  Columns that do not exist (ragged group only) get zero codes (distance 128) and
+//     a per-lane penalty in the seed: no masking instructions in any tile.
+//
+// The index of the SECOND best row key is exact only on request (SymDesc::flags bit 0: one more recomputation, used by
+// plslam_knn2_hamming256 and the key-dump tests): StVO::match needs the second best's DISTANCE only (ratio test).
+#include "common.hpp"
+
+#include <type_traits>
+
+// build-time experiments (tools/build_exp.py; results are WRONG with any of them on), a bit mask:
+//   1 no workgroup barrier   2 no bookkeeping rows   4 no MFMA   8 no column store   16 no second-best fix-up
+//   32 no finish_columns     64 no group push        128 no expansion of the b tile   256 no operand reads from LDS
+//   512 no pack              1024 no finish_rows
+#ifndef PLSLAM_MH_EXPERIMENT
+#define PLSLAM_MH_EXPERIMENT 0
+#endif
+#define PLSLAM_MH_X(bit) ((PLSLAM_MH_EXPERIMENT & (bit)) != 0)
+
+namespace plslam {
+
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4), aligned(4)));   // descriptor rows are only 4-byte aligned
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+#define PLSLAM_GLOBAL __attribute__((address_space(1)))
+typedef const PLSLAM_GLOBAL uint32_t* gcu32_t;
+typedef const PLSLAM_GLOBAL u32x4_t* gcu32x4_t;
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef PLSLAM_GLOBAL u32x2_t* gu2_t;
+typedef PLSLAM_GLOBAL uint32_t* gu32_t;
+
+namespace {
+
+constexpr int MH_TILE_N = 32;                 // b rows per tile
+constexpr int MH_KSTEPS = 4;                  // 256 bits = 4 x K 64
+constexpr int MH_ROW_STRIDE = 144;            // bytes per expanded b row in LDS (128 + 16: 4-bank skew)
+constexpr int MH_TILE_BYTES = MH_TILE_N * MH_ROW_STRIDE;
+constexpr int MH_GROUP = 16;                  // tiles per group of the row direction (512 b rows)
+constexpr int MH_GROUP_ROWS = MH_GROUP * MH_TILE_N;
+constexpr int MH_WINDOW = 64;                 // tiles per window: the row keys' tag holds the group within the window (2 bits)
+constexpr int MH_CGROUP = 8;                  // tiles whose column results are staged in LDS and stored together (256 slots)
+#ifndef PLSLAM_NT_STREAMS
+#define PLSLAM_NT_STREAMS 1
+#endif
+constexpr uint32_t FP4_NEG = 0x88888888u;
+constexpr uint32_t FP4_ONE = 0x22222222u;
+constexpr int SCALE_A = 133, SCALE_B = 127;   // E8M0: 2^6 on the a side, 2^0 on the b side
+constexpr uint32_t ACC_BITS = 0x4B000000u + 16384u;   // float bits of 2^23 + 16384
+constexpr uint32_t KEY16_MAX = 0x807Fu;       // 16-bit keys are (d << 7) | tag7; anything above is "none"
+// a column that does not exist: zero codes (the contraction contributes nothing: "distance 128") + this in the seed
+// = key 0xBF80 + tag: above KEY16_MAX, below the 16-bit wrap
+constexpr uint32_t COL_PENALTY = 0x7F80u;
+
+__device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ void merge2(uint32_t& a0, uint32_t& a1, uint32_t c0, uint32_t c1)
+{
+    const uint32_t lo = umin_(a0, c0);
+    const uint32_t hi = umin_(umax_(a0, c0), umin_(a1, c1));
+    a0 = lo;
+    a1 = hi;
+}
+__device__ __forceinline__ uint32_t pk_min16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_add16_sat(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_add_u16 %0, %1, %2 clamp" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void pk_push2(uint32_t& b0, uint32_t& b1, uint32_t key)
+{
+    b1 = pk_min16(b1, pk_max16(b0, key));
+    b0 = pk_min16(b0, key);
+}
+// accumulators of the two M-tiles side by side: hi.lo16 << 16 | lo.lo16.  The BUILTIN, never inline asm: this is the one
+// instruction that reads MFMA results ("K1e determinism")
+__device__ __forceinline__ uint32_t pack_acc(float lo, float hi)
+{
+    return __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, hi), __builtin_bit_cast(uint32_t, lo), 0x05040100u);
+}
+// 32 bits of a descriptor -> 32 fp4 codes of s(bit): dword s holds bits 4k + s, nibble k = 0x2 | bit << 3 (see K1f)
+template <bool A_SIDE>
+__device__ __forceinline__ i32x4 expand_dword_fp4(uint32_t x)
+{
+    uint32_t x1, x2, x3;
+    asm("v_add_u32 %0, %1, %1" : "=v"(x1) : "v"(x));
+    asm("v_add_u32 %0, %1, %1" : "=v"(x2) : "v"(x1));
+    asm("v_add_u32 %0, %1, %1" : "=v"(x3) : "v"(x2));
+    constexpr uint32_t base = A_SIDE ? (FP4_ONE ^ FP4_NEG) : FP4_ONE;       // a side: sign nibble-bit flipped
+    constexpr unsigned TT = A_SIDE ? 0x6Au : 0xEAu;                         // (a & b) ^ c  |  (a & b) | c
+    i32x4 v;
+    v.x = (int)__builtin_amdgcn_bitop3_b32(x3, FP4_NEG, base, TT);
+    v.y = (int)__builtin_amdgcn_bitop3_b32(x2, FP4_NEG, base, TT);
+    v.z = (int)__builtin_amdgcn_bitop3_b32(x1, FP4_NEG, base, TT);
+    v.w = (int)__builtin_amdgcn_bitop3_b32(x, FP4_NEG, base, TT);
+    return v;
+}
+__device__ __forceinline__ uint32_t bcnt_acc_(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t hamming256(u32x4_t a_lo, u32x4_t a_hi, u32x4_t b_lo, u32x4_t b_hi)
+{
+    uint32_t d = bcnt_acc_(a_lo.x ^ b_lo.x, 0u);
+    d = bcnt_acc_(a_lo.y ^ b_lo.y, d);
+    d = bcnt_acc_(a_lo.z ^ b_lo.z, d);
+    d = bcnt_acc_(a_lo.w ^ b_lo.w, d);
+    d = bcnt_acc_(a_hi.x ^ b_hi.x, d);
+    d = bcnt_acc_(a_hi.y ^ b_hi.y, d);
+    d = bcnt_acc_(a_hi.z ^ b_hi.z, d);
+    d = bcnt_acc_(a_hi.w ^ b_hi.w, d);
+    return d;
+}
+__device__ __forceinline__ int xcd_remap_(int orig, int nwg) { return (orig & 7) * (nwg >> 3) + (orig >> 3); }
+
+}  // namespace
+
+// ---- the layout of b over (tile, class): class-major inside groups of 16 tiles (see the file header) -------------------
+// full groups: 512 rows each; the ragged rest (n2 mod 512 rows) is one more group of S = ceil(rest / 32) tiles with S rows per
+// class.  Column slot of the partial table = 32 tile + class.
+struct MhLayout {
+    int n2, nfull, ntiles, rag_s;       // nfull: tiles of full groups (a multiple of 16); rag_s: tiles (= rows per class) of the ragged group
+    __host__ __device__ explicit MhLayout(int n2_) : n2(n2_)
+    {
+        const int full = n2_ / MH_GROUP_ROWS, rest = n2_ - full * MH_GROUP_ROWS;
+        nfull = full * MH_GROUP;
+        rag_s = (rest + MH_TILE_N - 1) / MH_TILE_N;
+        ntiles = nfull + rag_s;
+    }
+    __host__ __device__ int stride(int t) const { return t < nfull ? MH_GROUP : rag_s; }
+    __host__ __device__ int row_of(int t, int cls) const { return (t >> 4) * MH_GROUP_ROWS + stride(t) * cls + (t & 15); }   // may be >= n2
+    __host__ __device__ int slot_of(int j) const
+    {
+        const int G = j >> 9, off = j & (MH_GROUP_ROWS - 1);
+        const int s = G * MH_GROUP < nfull ? MH_GROUP : rag_s;
+        const int cls = off / s, tt = off - cls * s;
+        return MH_TILE_N * (G * MH_GROUP + tt) + cls;
+    }
+};
+int mh_slot_of_column(int n2, int j) { return MhLayout(n2).slot_of(j); }     // for tests / tools (plslam_match_plan_dump readers)
+// local row (within a wave's 64 rows of a) held by M-tile mt, MFMA row m: 16 (2 mt + g) + r with m = (r & 3) + 8 (r >> 2) + 4 g
+__host__ __device__ inline int mh_local_row(int mt, int m) { return 16 * (2 * mt + ((m >> 2) & 1)) + (m & 3) + 4 * (m >> 3); }
+
+// DIRECTED = true: only keys12 (row direction) is produced.
+template <bool DIRECTED>
+__global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
+k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks, int32_t* __restrict__ zero, int nzero)
+{
+    // one buffer, two lives: during the scan the double-buffered b tile (9 216 B) followed by the PARKED sorted pairs of the
+    // row direction ([wave][reg][lane] x 8 B = 32 768 B); after the scan the row-result transpose [wave][row 0..63][33]
+    constexpr int ROWX_STRIDE = 33;               // dwords per row: lane = row reads are conflict-free
+    constexpr int PARK_OFF = 2 * MH_TILE_BYTES;
+    constexpr int SMEM_BYTES = PARK_OFF + 4 * 16 * 64 * 8;
+    static_assert(SMEM_BYTES >= 4 * 64 * ROWX_STRIDE * 4, "the transpose must fit");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
+    // column minima of the current 8 tiles, per wave [tile in block][lane] (2 KB per wave): every lane parks its two group
+    // minima per tile (one LDS store, no cross-lane step on the tile's path); once per 8 tiles a lane combines the four
+    // groups of 4 columns and stores 16 bytes (a store per tile would share vmcnt with the raw-row prefetch: see K1f)
+    __shared__ __attribute__((aligned(16))) uint32_t colstage[4][MH_CGROUP * 64];
+    uint8_t* const btile = smem;
+    u32x2_t* const park = reinterpret_cast<u32x2_t*>(smem + PARK_OFF) + (threadIdx.x >> 6) * (16 * 64) + (threadIdx.x & 63);
+
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+
+    const int wg = xcd_remap_(blockIdx.x, gridDim.x);
+    const BlockDesc bd = blocks[wg];
+    if (bd.item < 0) return;                       // padding entry of the XCD-striped table
+    const SymDesc sd = syms[bd.item];
+    const int n1 = sd.n1, n2 = sd.n2;
+    const MhLayout L(n2);
+    const int ntiles = L.ntiles, nfull = L.nfull, rag_s = L.rag_s;
+    const int n2p = (MH_TILE_N * ntiles + 255) & ~255;            // slots per row of the partial table (= n2 rounded up to 256)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, g = lane >> 5;
+    const gcu32_t araw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.a);
+    const int iw = bd.row0 + 64 * w;               // first of this wave's 64 rows of a
+
+    // ---- A operands: MFMA row c of M-tile mt = local row mh_local_row(mt, c); raw dword 2 ks + g of each, as fp4 codes of
+    // -s(a); the factor 64 is the block scale.  Rows past n1 are clamped duplicates (masked / dropped below) ----
+    i32x4 afrag[2][MH_KSTEPS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = iw + mh_local_row(mt, c);
+        const int rrow = row < n1 ? row : n1 - 1;
+        const gcu32_t p = araw + (size_t)rrow * 8 + g;
+#pragma unroll
+        for (int ks = 0; ks < MH_KSTEPS; ++ks) afrag[mt][ks] = expand_dword_fp4<true>(p[2 * ks]);
+    }
+    const int scale_a = SCALE_A, scale_b = SCALE_B;
+
+    // row-direction state per accumulator register r (M-tile 0 in the low halves, M-tile 1 in the high halves):
+    //   gm[r]    running minimum of the 16-bit keys (d << 7 | 16 g + r) of the current group of 16 tiles, column class c
+    //   park[r]  (LDS) the best two GROUP minima (d << 7 | group in window << 5 | 16 g + r) of the lane's column class
+    uint32_t gm[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gm[r] = 0xFFFFFFFFu;
+
+    // accumulator start: 2^23 + 16384 + 16 g + r (the row within its M-tile's 32 rows: constant per register and lane) [+ the
+    // penalty of a lane whose column does not exist].  In VECTOR registers on purpose (asm volatile: opaque to the compiler, which would keep
+    // wave-uniform values in SGPRs and copy them into both accumulators every tile)
+    u32x16 seed;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) seed[r] = ACC_BITS + (uint32_t)(16 * g + r);   // tag = the row within its M-tile's 32
+    asm volatile("" : "+v"(seed));
+    // ragged group: this lane's class has `lim` tiles with a column (0 .. rag_s); from tile-in-group == lim on it has none
+    const int rest = n2 - (nfull >> 4) * MH_GROUP_ROWS;
+    // (recomputed where it is needed -- twice per scan -- instead of living in a register through the tile loop)
+    auto lane_lim = [&]() __attribute__((always_inline)) -> int {
+        const int cc = (int)(threadIdx.x & 31u), v = rest - rag_s * cc;
+        return rag_s == 0 ? 0 : (v < 0 ? 0 : (v > rag_s ? rag_s : v));
+    };
+    const int lim_part = rag_s ? rest % rag_s : 0;                 // the one class that is cut (wave-uniform): its lim, 0 = none is
+
+    const bool rows_ragged = iw + 64 > n1;         // wave-uniform: some of this wave's rows do not exist
+    // rows of this lane's two groups that exist: register r of M-tile mt holds local row 16 (2 mt + g) + r
+#define PLSLAM_MH_NV_LO (n1 - iw - 16 * (int)((threadIdx.x >> 5) & 1u))
+    const gu32_t part = DIRECTED ? (gu32_t) nullptr : (gu32_t) sd.part21 + (size_t)(iw >> 6) * n2p;
+    const bool wave_has_rows = iw < n1;
+    uint32_t* const cstage = colstage[w];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) *reinterpret_cast<i32x4*>(cstage + 256 * k + 4 * lane) = i32x4{-1, -1, -1, -1};   // wave-private
+
+    // expansion duty of this lane: the b row of class (tid >> 3) of the tile, dword (tid & 7) of it.  Byte offset of that
+    // dword = [group, tile in group: scalar] + [class x stride: per lane, one value for full groups, one for the ragged one]
+    const int ej = tid >> 3, ewd4 = (tid & 7) * 4;
+    const PLSLAM_GLOBAL char* const bbytes = (const PLSLAM_GLOBAL char*) sd.b;
+    auto load_raw = [&](int t) __attribute__((always_inline)) -> uint32_t {
+        // everything wave-uniform is scalar: the group's base goes into the scalar address, the lane adds (class x stride +
+        // tile in group) rows, clamped to the last row of b (rows past the end are duplicates that get zero codes)
+        const int tc = t < ntiles ? t : ntiles - 1;
+        const int gbase = (tc >> 4) * MH_GROUP_ROWS;
+        const uint32_t s = tc < nfull ? (uint32_t)MH_GROUP : (uint32_t)rag_s;
+        uint32_t row = __umul24((uint32_t)ej, s) + (uint32_t)(tc & 15);      // v_mad_u32_u24: full rate (v_mul_lo_u32 is not)
+        const uint32_t last = (uint32_t)(n2 - 1 - gbase);
+        row = row < last ? row : last;
+        return *reinterpret_cast<gcu32_t>(bbytes + (size_t)gbase * 32 + (row * 32u + (uint32_t)ewd4));
+    };
+    // tile `tn` (the next one) into buffer `buf`; in the ragged group the rows that do not exist get zero codes
+    auto expand_store = [&](uint32_t raw, int buf, int tn) __attribute__((always_inline)) {
+        uint8_t* dst = btile + buf * MH_TILE_BYTES + ej * MH_ROW_STRIDE + ewd4 * 4;
+        i32x4 v = expand_dword_fp4<false>(raw);
+        if (tn >= nfull) {                                          // wave-uniform
+            const int vm = (int)(__umul24((uint32_t)rag_s, (uint32_t)ej) + (uint32_t)(tn & 15)) < rest ? -1 : 0;
+            v &= i32x4{vm, vm, vm, vm};
+        }
+        *reinterpret_cast<i32x4*>(dst) = v;
+    };
+
+    int wt0 = 0, wt1 = ntiles < MH_WINDOW ? ntiles : MH_WINDOW;      // the current window of tiles
+    // raw b dwords in flight: tile t's dword sits in rr[t & 3].  The tile loop is unrolled by four so that the ring index is a
+    // compile-time fact: a ring rotated with register moves makes every step wait for the load it has just issued (the move
+    // reads the newest register: s_waitcnt vmcnt(0) -- K1f's loop did exactly that, a full memory latency per tile)
+    uint32_t rr[4] = {0u, 0u, 0u, 0u};
+
+    // the 8 tiles that end with tile `tl` are over.  cstage[tile][lane] = that lane's two group minima of column class
+    // lane & 31 as (d << 7 | row within the M-tile): M-tile 0 low, M-tile 1 high; lanes l and l + 32 hold the two halves of
+    // the rows.  Lane L combines slots 4 L .. 4 L + 3 of the block (tile L >> 3, classes 4 (L & 7) ..): B0 = the best of a
+    // column's 4 groups as (d << 7 | row within the wave's 64), B1 = the best of the other three; 16 bytes per lane leave.
+    const uint32_t* const cst_src = cstage + (lane >> 3) * 64 + 4 * (lane & 7);
+    const PLSLAM_GLOBAL char* const part_bytes = (const PLSLAM_GLOBAL char*) part;
+    auto store_columns = [&](int tl) __attribute__((always_inline)) {
+        if (!DIRECTED && wave_has_rows && !PLSLAM_MH_X(8)) {
+            const int blk = (tl & ~(MH_CGROUP - 1)) * MH_TILE_N;       // first slot of the block (scalar); n2p is a multiple of 256
+            const i32x4 x = *reinterpret_cast<const i32x4*>(cst_src), y = *reinterpret_cast<const i32x4*>(cst_src + 32);
+            i32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t xq = pk_add16_sat((uint32_t)x[q], 0x00200000u), yq = pk_add16_sat((uint32_t)y[q], 0x00200000u);   // M-tile 1: rows + 32
+                const uint32_t a = pk_min16(xq, yq), b = pk_max16(xq, yq);
+                const uint32_t m0 = umin_(a & 0xFFFFu, a >> 16);
+                const uint32_t m1 = umin_(umax_(a & 0xFFFFu, a >> 16), umin_(b & 0xFFFFu, b >> 16));
+                v[q] = (int)(m0 | (m1 << 16));
+            }
+            if (PLSLAM_MH_X(32)) v = x;
+            if (blk < n2p) {
+                PLSLAM_GLOBAL i32x4* dst = (PLSLAM_GLOBAL i32x4*)(const_cast<PLSLAM_GLOBAL char*>(part_bytes) + (size_t)blk * 4 + (uint32_t)(16 * lane));
+                if (PLSLAM_NT_STREAMS) __builtin_nontemporal_store(v, dst);
+                else *dst = v;
+            }
+            // (slots of tiles of a last, partial block that never ran hold the block before's values: never read, and a function
+            // of the inputs like everything else in the table)
+        }
+    };
+    // a row group is over: its minima get the group number and go into the parked sorted pairs; the minima restart
+    auto push_groups = [&](int t) __attribute__((always_inline)) {
+        if (PLSLAM_MH_X(64)) return;
+        const uint32_t gtag = (uint32_t)(((t - wt0) >> 4) << 5) * 0x00010001u;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const u32x2_t v = park[r * 64];
+            uint32_t b0 = v.x, b1 = v.y;
+            pk_push2(b0, b1, pk_add16_sat(gm[r], gtag));
+            park[r * 64] = u32x2_t{b0, b1};
+            gm[r] = 0xFFFFFFFFu;
+        }
+    };
+    // column minima of a finished tile: parked as they are (the seeds made the tags), combined in store_columns
+    auto finish_columns = [&](int t, uint32_t cm) __attribute__((always_inline)) {
+        if (DIRECTED || PLSLAM_MH_X(32)) { asm volatile("" ::"v"(cm)); return; }
+        cstage[(t & (MH_CGROUP - 1)) * 64 + lane] = cm;
+    };
+
+    // Bookkeeping of one packed key pair kc[R] (rows r of the lane's two groups, column class c): ONE packed min into the
+    // row direction's group minimum, ONE into the column direction's group minimum.  MASKED: rows of a that do not exist
+    // must not win a column.
+    // (two column chains, even / odd registers: a packed op that reads the result of the packed op two slots earlier costs
+    // an s_nop -- round 2 counted 19 of them per tile)
+#define PLSLAM_MH_EPI_ROW(R)                                                                       \
+    {                                                                                              \
+        uint32_t kcv = kc[R];                                                                      \
+        gm[R] = pk_min16(gm[R], kcv);                                                              \
+        if (!DIRECTED) {                                                                           \
+            if (MASKED) kcv |= ((R) < PLSLAM_MH_NV_LO ? 0u : 0x0000FFFFu) | ((R) < PLSLAM_MH_NV_LO - 32 ? 0u : 0xFFFF0000u); \
+            if ((R) & 1) cm1 = pk_min16(cm1, kcv); else cm = pk_min16(cm, kcv);                    \
+        }                                                                                          \
+    }
+    // Software pipeline, ONE accumulator set (as K1f):  M(t): 8 MFMAs -> P(t): 16 v_perm pack the 32 accumulators into 16
+    // key pairs kc[] -> E(t): bookkeeping from kc[], issued BETWEEN the MFMAs of M(t+1).
+    //   step(t) = barrier | operand reads | M(t) x E(t-1) | expand(t+1) | finish_columns(t-1) | P(t)
+    uint32_t kc[16];
+    auto tile_step = [&](int t, auto u_tag, bool with_prev, auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr int U = decltype(u_tag)::value;                      // t & 3
+        if (!PLSLAM_MH_X(1)) __syncthreads();  // tile t expanded; every wave is past its reads of the other buffer
+        const uint8_t* bt = btile + (U & 1) * MH_TILE_BYTES + c * MH_ROW_STRIDE + 16 * g;
+        uint32_t cm = 0xFFFFFFFFu, cm1 = 0xFFFFFFFFu;
+        // operand reads: K-steps 0 and 1 now, 2 and 3 behind the MFMAs of steps 0 and 1 (their registers): 8 live registers, not 16
+        auto read_b = [&](int ks) __attribute__((always_inline)) -> i32x4 {
+            return PLSLAM_MH_X(256) ? i32x4{(int)FP4_ONE + t, (int)FP4_ONE, (int)FP4_ONE + ks, (int)FP4_ONE}
+                                    : *reinterpret_cast<const i32x4*>(bt + 32 * ks);
+        };
+        i32x4 bfr[MH_KSTEPS];
+        bfr[0] = read_b(0);
+        bfr[1] = read_b(1);
+        // ragged group: lanes whose class has run out of columns take the penalty from this tile on (at most two tiles of a
+        // scan change anything: the group's first -- classes without any column -- and the one where the cut class ends)
+        if (t >= nfull && ((t & 15) == 0 || (t & 15) == lim_part)) {
+            const uint32_t pen = lane_lim() == (t & 15) ? COL_PENALTY : 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) seed[r] += pen;
+            asm volatile("" : "+v"(seed));
+        }
+        const f32x16 cseed = __builtin_bit_cast(f32x16, seed);
+        f32x16 m0, m1;
+#define PLSLAM_MH_MMA(ACC, MT, KS, CIN)                                                            \
+        {                                                                                          \
+            const i32x8 a8 = {afrag[MT][KS].x, afrag[MT][KS].y, afrag[MT][KS].z, afrag[MT][KS].w, 0, 0, 0, 0}; \
+            const i32x8 b8 = {bfr[KS].x, bfr[KS].y, bfr[KS].z, bfr[KS].w, 0, 0, 0, 0};             \
+            if (!PLSLAM_MH_X(4))                                                                   \
+                ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, CIN, 4, 4, 0, scale_a, 0, scale_b); \
+            else { const f32x16 cin_ = CIN; ACC = cin_; ACC[KS] = __builtin_bit_cast(float, bfr[KS].x ^ a8[0]); } \
+            asm volatile("" : "+v"(ACC));    /* pins the MFMA here (no instruction) */              \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }
+#define PLSLAM_MH_EPI2(R)                                                                          \
+        {                                                                                          \
+            if (!PLSLAM_MH_X(2)) { PLSLAM_MH_EPI_ROW(R) PLSLAM_MH_EPI_ROW((R) + 1) }               \
+            __builtin_amdgcn_sched_barrier(0);                                                     \
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        PLSLAM_MH_EPI2(0)  PLSLAM_MH_MMA(m0, 0, 0, cseed)
+        PLSLAM_MH_EPI2(2)  PLSLAM_MH_MMA(m1, 1, 0, cseed)
+        bfr[2] = read_b(2);
+        PLSLAM_MH_EPI2(4)  PLSLAM_MH_MMA(m0, 0, 1, m0)
+        PLSLAM_MH_EPI2(6)  PLSLAM_MH_MMA(m1, 1, 1, m1)
+        bfr[3] = read_b(3);
+        PLSLAM_MH_EPI2(8)  PLSLAM_MH_MMA(m0, 0, 2, m0)
+        PLSLAM_MH_EPI2(10) PLSLAM_MH_MMA(m1, 1, 2, m1)
+        PLSLAM_MH_EPI2(12) PLSLAM_MH_MMA(m0, 0, 3, m0)
+        PLSLAM_MH_EPI2(14) PLSLAM_MH_MMA(m1, 1, 3, m1)
+#undef PLSLAM_MH_EPI2
+#undef PLSLAM_MH_MMA
+        // behind the last MFMA, in front of the pack that needs its result: the expansion of the next tile (its buffer was
+        // read for the last time before this step's barrier) and the prefetch -- independent work that covers the matrix
+        // pipe's latency (measured: the 16 packs cost as much time as the 33 bookkeeping ops while they sat right behind it)
+        if (!PLSLAM_MH_X(128)) {
+            expand_store(rr[(U + 1) & 3], (U + 1) & 1, t + 1);        // past the last tile: a harmless rewrite of the idle buffer
+            rr[(U + 1) & 3] = load_raw(t + 5);                        // four tiles ahead of its use
+        }
+        if (with_prev) {
+            finish_columns(t - 1, pk_min16(cm, cm1));
+            // wave-uniform: tile t-1 closed a block of 8 tiles / a row group
+            if (U == 0 && ((t - 1) & (MH_CGROUP - 1)) == MH_CGROUP - 1) store_columns(t - 1);
+            if (U == 0 && ((t - 1) & (MH_GROUP - 1)) == MH_GROUP - 1) push_groups(t - 1);
+        }
+        // P(t): the key pairs of tile t; the accumulators are dead from here on
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float f0 = m0[r], f1 = m1[r];
+            if (!PLSLAM_MH_X(512)) kc[r] = pack_acc(f0, f1);
+        }
+        if (PLSLAM_MH_X(512)) { asm volatile("" ::"v"(m0), "v"(m1)); kc[0] = __builtin_bit_cast(uint32_t, (float)m0[0]); }
+    };
+    // E(t) on its own (the last tile of a window has no following M step to hide under)
+    auto epilogue = [&](int t, auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        uint32_t cm = 0xFFFFFFFFu, cm1 = 0xFFFFFFFFu;
+        PLSLAM_MH_EPI_ROW(0) PLSLAM_MH_EPI_ROW(1) PLSLAM_MH_EPI_ROW(2) PLSLAM_MH_EPI_ROW(3)
+        PLSLAM_MH_EPI_ROW(4) PLSLAM_MH_EPI_ROW(5) PLSLAM_MH_EPI_ROW(6) PLSLAM_MH_EPI_ROW(7)
+        PLSLAM_MH_EPI_ROW(8) PLSLAM_MH_EPI_ROW(9) PLSLAM_MH_EPI_ROW(10) PLSLAM_MH_EPI_ROW(11)
+        PLSLAM_MH_EPI_ROW(12) PLSLAM_MH_EPI_ROW(13) PLSLAM_MH_EPI_ROW(14) PLSLAM_MH_EPI_ROW(15)
+        finish_columns(t, pk_min16(cm, cm1));
+    };
+    auto pipeline = [&](auto masked_tag) __attribute__((always_inline)) {
+        // (wt0 is a multiple of 64: t & 3 of the unrolled steps is static.  The first step has no previous tile: its
+        // bookkeeping runs on "none" keys, its column / group actions are skipped)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) kc[r] = 0xFFFFFFFFu;
+        for (int tb = wt0; tb < wt1; tb += 4) {
+            tile_step(tb, std::integral_constant<int, 0>{}, tb != wt0, masked_tag);
+            if (tb + 1 < wt1) tile_step(tb + 1, std::integral_constant<int, 1>{}, true, masked_tag);
+            if (tb + 2 < wt1) tile_step(tb + 2, std::integral_constant<int, 2>{}, true, masked_tag);
+            if (tb + 3 < wt1) tile_step(tb + 3, std::integral_constant<int, 3>{}, true, masked_tag);
+        }
+        epilogue(wt1 - 1, masked_tag);
+        store_columns(wt1 - 1);                    // the (possibly partial) last block of columns
+        push_groups(wt1 - 1);                      // ... and row group
+    };
+#undef PLSLAM_MH_EPI_ROW
+
+    // Row results of a window.  Every lane holds, per packed register, the best two GROUP minima (16-bit keys
+    // (d, group in window, r)) of ITS column class for two rows.  Transpose through LDS so that one lane owns one row:
+    // lane l reads the 32 class entries of local row l in class order and widens them to (key16 << 16 | class), which
+    // orders like (d, j) between DIFFERENT (group, class) pairs: j = 512 G + S class + tile, and every entry of a row
+    // carries the same r.  The best entry names the (group, class) that holds the best column; the lane recomputes ALL
+    // members of it from the raw rows (S consecutive rows of b): the first minimum is the best key, the others compete with
+    // the second entry (the best key outside that (group, class)) for second best.
+    auto finish_rows = [&]() __attribute__((always_inline)) {
+        uint32_t* rowx = reinterpret_cast<uint32_t*>(smem) + w * (64 * ROWX_STRIDE);
+        u32x2_t rb[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rb[r] = park[r * 64];
+        __syncthreads();                           // every wave holds its pairs: the transpose may overwrite the parking area
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int lrow = 16 * g + r;           // M-tile 0; M-tile 1: + 32
+            rowx[lrow * ROWX_STRIDE + c] = __builtin_amdgcn_perm(rb[r].y, rb[r].x, 0x05040100u);          // (x.lo | y.lo << 16)
+            rowx[(32 + lrow) * ROWX_STRIDE + c] = __builtin_amdgcn_perm(rb[r].y, rb[r].x, 0x07060302u);   // (x.hi | y.hi << 16)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+        const uint32_t* mine = rowx + lane * ROWX_STRIDE;
+#pragma unroll 8
+        for (int cls = 0; cls < 32; ++cls) {
+            const uint32_t e = mine[cls];
+            merge2(k0, k1, (e << 16) | (uint32_t)cls, (e & 0xFFFF0000u) | (uint32_t)cls);
+        }
+        const int row = iw + lane;
+        if (row < n1) {
+            const gu2_t out = (gu2_t) reinterpret_cast<u32x2_t*>(sd.keys12) + row;
+            const gcu32x4_t ap = (gcu32x4_t)(araw + (size_t)row * 8);
+            const u32x4_t a_lo = ap[0], a_hi = ap[1];
+            // (key16 << 16 | class) -> first row of the (group, class), its stride count, the distance
+            auto group_of = [&](uint32_t k, uint32_t& jbase, uint32_t& cnt) {
+                const uint32_t t0 = (uint32_t)wt0 + (((k >> 21) & 3u) << 4);              // first tile of the group
+                const uint32_t s = t0 < (uint32_t)nfull ? (uint32_t)MH_GROUP : (uint32_t)rag_s;
+                jbase = (t0 >> 4) * MH_GROUP_ROWS + s * (k & 0xFFFFu);
+                cnt = s;
+            };
+            // all members of a (group, class): the smallest (d << 23 | j) and the second smallest
+            auto rescan = [&](uint32_t jbase, uint32_t cnt, uint32_t& best, uint32_t& second) {
+                best = second = KEY_NONE;
+#pragma unroll
+                for (int k = 0; k < MH_GROUP; ++k) {
+                    const uint32_t j = jbase + (uint32_t)k;
+                    const bool ok = (uint32_t)k < cnt && j < (uint32_t)n2;
+                    const gcu32x4_t bp = (gcu32x4_t)(bbytes + (uint32_t)((ok ? j : jbase) * 32u));
+                    const u32x4_t b_lo = bp[0], b_hi = bp[1];
+                    const uint32_t d = hamming256(a_lo, a_hi, b_lo, b_hi);
+                    const uint32_t cand = ok ? ((d << KEY_IDX_BITS) | j) : KEY_NONE;
+                    second = umin_(second, umax_(best, cand));
+                    best = umin_(best, cand);
+                }
+            };
+            uint32_t r0 = KEY_NONE, r1 = KEY_NONE;
+            if ((k0 >> 16) <= KEY16_MAX && !PLSLAM_MH_X(16)) {
+                uint32_t jb, cnt, in2;
+                group_of(k0, jb, cnt);
+                rescan(jb, cnt, r0, in2);
+                if ((k1 >> 16) <= KEY16_MAX) {
+                    // the best key outside the winner's (group, class): its distance is exact, its column is the first of
+                    // its (group, class) unless the exact index was asked for and it IS the second best
+                    uint32_t jb1, cnt1;
+                    group_of(k1, jb1, cnt1);
+                    uint32_t o1 = ((k1 >> 23) << KEY_IDX_BITS) | jb1;
+                    if ((sd.flags & 1) && (o1 >> KEY_IDX_BITS) <= (in2 >> KEY_IDX_BITS)) {
+                        uint32_t b1, s1;
+                        rescan(jb1, cnt1, b1, s1);
+                        o1 = b1;
+                    }
+                    r1 = umin_(in2, o1);
+                } else {
+                    r1 = in2;
+                }
+            } else if (PLSLAM_MH_X(16)) {
+                r0 = k0; r1 = k1;
+            }
+            if (wt0 > 0) {                                  // later windows: merge with the windows before
+                const u32x2_t prev = *out;
+                merge2(r0, r1, prev.x, prev.y);
+            }
+            *out = u32x2_t{r0, r1};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (;;) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) park[r * 64] = u32x2_t{0xFFFFFFFFu, 0xFFFFFFFFu};   // wave-private: no barrier needed
+        expand_store(load_raw(wt0), 0, wt0);       // wt0 is a multiple of 128: buffer parity restarts at 0
+        rr[1] = load_raw(wt0 + 1);
+        rr[2] = load_raw(wt0 + 2);
+        rr[3] = load_raw(wt0 + 3);
+        rr[0] = load_raw(wt0 + 4);
+        if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
+        __syncthreads();                           // every wave is past its last operand read of the b tile
+        if (!PLSLAM_MH_X(1024)) finish_rows();
+        if (wt1 == ntiles) break;
+        __syncthreads();                           // smem becomes the b tile (+ parking area) again
+        wt0 = wt1;
+        wt1 = ntiles < wt0 + MH_WINDOW ? ntiles : wt0 + MH_WINDOW;
+    }
+}
+
+// K1c''  merge of K1h's column partials + the second-best recomputation: keys21[j] = best-2 over all rows of a.
+// part16[64-row block][slot] = (B0 | B1 << 16), 16-bit keys (d << 7 | row within the block): B0 = the block's best row, B1 =
+// its best row OUTSIDE B0's aligned group of 16 rows.  Over the blocks: K0 = the best B0, K1 = the best of (every other
+// block's B0, the winner block's B1) = the best row outside K0's group of 16; the 15 other rows of that group are
+// recomputed from the raw rows (512 contiguous bytes of a).  PARTS lanes share a column (tall problems: see K1f).
+// FIX = false: keys21[j] = (K0, K1) as they are -- the finalize kernel completes the second best for the columns it needs
+// (ProblemDesc::lazy21); FIX = true (exact key tables asked for): the recomputation happens here for every column.
+template <int PARTS, bool FIX>
+__global__ void __launch_bounds__(256)
+k_merge_fix16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks)
+{
+    constexpr int COLS = 256 / PARTS;
+    __shared__ uint32_t red[PARTS > 1 ? 512 : 2];
+    const BlockDesc bd = blocks[blockIdx.x];
+    const SymDesc sd = syms[bd.item];
+    // lanes walk the partial table in SLOT order (coalesced reads of every block's row); the slot's column is where the result goes
+    const int jl = (int)threadIdx.x % COLS, part_id = (int)threadIdx.x / COLS;
+    const int slot = bd.row0 + jl;
+    const MhLayout L(sd.n2);
+    const int j = slot < MH_TILE_N * L.ntiles ? L.row_of(slot >> 5, slot & 31) : sd.n2;     // >= n2: the slot holds no column
+    const gcu32_t part = (gcu32_t) sd.part21;
+    const int nwb = (sd.n1 + 63) >> 6;
+    const int n2p = (MH_TILE_N * L.ntiles + 255) & ~255;
+    uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
+    if (j < sd.n2) {
+        auto wide = [](uint32_t k16, uint32_t wb) -> uint32_t {         // (d << 7 | row in block) -> (d << 23 | row)
+            return ((k16 << 16) & 0xFF800000u) | ((k16 & 63u) + 64u * wb);
+        };
+        // only a block's BEST key is widened and merged per entry; the winner block's second key (kept raw in s0) joins at the end
+        uint32_t s0 = 0xFFFFFFFFu;
+#pragma unroll 8
+        for (int wb = part_id; wb < nwb; wb += PARTS) {
+            const uint32_t e = PLSLAM_NT_STREAMS ? __builtin_nontemporal_load(&part[(size_t)wb * n2p + slot])
+                                                 : part[(size_t)wb * n2p + slot];
+            const uint32_t k = wide(e & 0xFFFFu, (uint32_t)wb);
+            s0 = k < b0 ? e : s0;
+            b1 = umin_(b1, umax_(b0, k));
+            b0 = umin_(b0, k);
+        }
+        if (b0 < (257u << KEY_IDX_BITS)) {
+            b1 = umin_(b1, wide(s0 >> 16, (b0 & KEY_IDX_MASK) >> 6));
+            if (b1 >= (257u << KEY_IDX_BITS)) b1 = KEY_NONE;
+        } else {
+            b0 = b1 = KEY_NONE;
+        }
+    }
+    if (PARTS > 1) {
+        // the parts' pairs: each is (best of its blocks, best outside THAT best's group): the overall best's pair partner is
+        // still "outside its group", and any other part's best is outside it too (another block, or the same block's
+        // other group only if it came as a B1 -- which is also outside) -- merge2 keeps exactly that
+        red[2 * threadIdx.x] = b0;
+        red[2 * threadIdx.x + 1] = b1;
+        __syncthreads();
+        if (part_id == 0) {
+#pragma unroll
+            for (int q = 1; q < PARTS; ++q) merge2(b0, b1, red[2 * (q * COLS + jl)], red[2 * (q * COLS + jl) + 1]);
+        }
+    }
+    if (part_id == 0 && j < sd.n2) {
+        if (FIX && b0 != KEY_NONE) {
+            const gcu32_t araw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.a);
+            const gcu32x4_t bp = (gcu32x4_t)((gcu32_t) reinterpret_cast<const uint32_t*>(sd.b) + (size_t)j * 8);
+            const u32x4_t b_lo = bp[0], b_hi = bp[1];
+            const uint32_t i0 = b0 & KEY_IDX_MASK, ibase = i0 & ~15u;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t i = ibase + (uint32_t)k;
+                const bool ok = i != i0 && i < (uint32_t)sd.n1;
+                const gcu32x4_t ap = (gcu32x4_t)(araw + (size_t)(ok ? i : i0) * 8);
+                const u32x4_t a_lo = ap[0], a_hi = ap[1];
+                const uint32_t d = hamming256(a_lo, a_hi, b_lo, b_hi);
+                b1 = umin_(b1, ok ? ((d << KEY_IDX_BITS) | i) : KEY_NONE);
+            }
+        }
+        ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21))[j] = u32x2_t{b0, b1};
+    }
+}
+
+int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, bool fix, hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+#define PLSLAM_MH_MERGE(P) { if (fix) hipLaunchKernelGGL((k_merge_fix16<P, true>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks); \
+                             else hipLaunchKernelGGL((k_merge_fix16<P, false>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks); }
+    if (parts >= 16) PLSLAM_MH_MERGE(16)
+    else if (parts >= 4) PLSLAM_MH_MERGE(4)
+    else PLSLAM_MH_MERGE(1)
+#undef PLSLAM_MH_MERGE
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int launch_scan_sym_mfma_h(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
+                           bool directed, hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+    if (directed) hipLaunchKernelGGL((k_scan_sym_mfma_h<true>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
+    else hipLaunchKernelGGL((k_scan_sym_mfma_h<false>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+}  // namespace plslam

@@ -108,6 +108,10 @@ inline plslam_ctx* ctx()
             t.generation = P.generation;
         }
         if (!t.ctx) {
+            // a library built from another revision of the header reads plslam_match_problem arrays with another stride
+            if (plslam_abi_version() != PLSLAM_ABI_VERSION)
+                throw std::runtime_error("[StVO::match] libplslam_hip.so has ABI version " + std::to_string(plslam_abi_version()) +
+                                         ", this translation unit was compiled against " + std::to_string(PLSLAM_ABI_VERSION));
             const int rc = plslam_ctx_create(want, &t.ctx);
             if (rc != PLSLAM_OK) {
                 t.ctx = nullptr;

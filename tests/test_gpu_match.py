@@ -86,12 +86,13 @@ def test_symmetric_and_directed_variants_agree(ctx, oracle, n1, n2):
         try:
             # (variant, sym_rows, mfma_form): mfma_form 2 = K1f (group minima, the default), 1 = K1e (push per tile)
             for variant, sym_rows, form in ((plslam_amd.SCAN_MFMA, 0, 2), (plslam_amd.SCAN_MFMA, 0, 1), (plslam_amd.SCAN_MFMA, 0, 3),
+                                            (plslam_amd.SCAN_MFMA, 0, 4), (plslam_amd.SCAN_MFMA, 0, 5),
                                             (plslam_amd.SCAN_SYMMETRIC, 4, 0), (plslam_amd.SCAN_SYMMETRIC, 1, 0),
                                             (plslam_amd.SCAN_LANE_PER_QUERY, 1, 0), (plslam_amd.SCAN_WAVE_PER_QUERY, 1, 0),
                                             (plslam_amd.SCAN_AUTO, 1, 0)):
                 ctx.set_option("scan_variant", variant)
                 ctx.set_option("sym_rows", sym_rows)
-                ctx.set_option("mfma_form", min(form, 2))
+                ctx.set_option("mfma_form", {4: 3, 5: 4}.get(form, min(form, 2)))   # 4 = K1g (two directed scans per mutual problem), 5 = K1h
                 ctx.set_option("fuse", 2 if form == 3 else 0)
                 m, n = ctx.match(d1, d2, 0.9, True)
                 assert np.array_equal(m, em) and n == en, (variant, sym_rows, form, gen.__name__)
@@ -119,16 +120,17 @@ def test_all_scan_block_sizes(ctx, oracle):
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
 
 
-@pytest.fixture(params=["auto", "lane_per_query", "wave_per_query", "symmetric", "mfma", "mfma_k1e", "mfma_fused"])
+@pytest.fixture(params=["auto", "lane_per_query", "wave_per_query", "symmetric", "mfma", "mfma_k1e", "mfma_fused", "mfma_k1g", "mfma_k1h"])
 def vctx(ctx, request):
     """The context with each scan variant forced in turn (AUTO picks wave-per-query for plans too
     small to fill the chip, the symmetric scan for mutual problems otherwise)."""
     import plslam_amd
     v = {"auto": plslam_amd.SCAN_AUTO, "lane_per_query": plslam_amd.SCAN_LANE_PER_QUERY,
          "wave_per_query": plslam_amd.SCAN_WAVE_PER_QUERY, "symmetric": plslam_amd.SCAN_SYMMETRIC,
-         "mfma": plslam_amd.SCAN_MFMA, "mfma_k1e": plslam_amd.SCAN_MFMA, "mfma_fused": plslam_amd.SCAN_MFMA}[request.param]
+         "mfma": plslam_amd.SCAN_MFMA, "mfma_k1e": plslam_amd.SCAN_MFMA, "mfma_fused": plslam_amd.SCAN_MFMA,
+         "mfma_k1g": plslam_amd.SCAN_MFMA, "mfma_k1h": plslam_amd.SCAN_MFMA}[request.param]
     ctx.set_option("scan_variant", v)
-    ctx.set_option("mfma_form", 1 if request.param == "mfma_k1e" else 0)   # default form = K1f (group minima)
+    ctx.set_option("mfma_form", {"mfma_k1e": 1, "mfma_k1g": 3, "mfma_k1h": 4}.get(request.param, 0))   # default form = K1f (group minima)
     ctx.set_option("fuse", 2 if request.param == "mfma_fused" else 0)      # one workgroup per problem incl. finalize
     yield ctx
     ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
@@ -136,12 +138,12 @@ def vctx(ctx, request):
     ctx.set_option("fuse", 0)
 
 
-@pytest.fixture(params=[2, 1, 3], ids=["k1f", "k1e", "k1f_fused"])
+@pytest.fixture(params=[2, 1, 3, 4, 5], ids=["k1f", "k1e", "k1f_fused", "k1g_directed", "k1h"])
 def mform(ctx, request):
     """The forms of the matrix-core scan: 2 = K1f (group minima + recomputed second best, the default), 1 = K1e (best-2
     push per tile), 3 = K1f with one workgroup per problem that also merges the columns and applies ratio + mutual
     (what AUTO picks for large plans; forced here so that small plans exercise it)."""
-    ctx.set_option("mfma_form", min(request.param, 2))
+    ctx.set_option("mfma_form", {4: 3, 5: 4}.get(request.param, min(request.param, 2)))
     ctx.set_option("fuse", 2 if request.param == 3 else 1)
     yield request.param
     ctx.set_option("mfma_form", 0)
@@ -206,6 +208,7 @@ def test_column_split_of_few_large_problems(ctx, oracle, shapes, mutual):
                                     ("unsplit", plslam_amd.SCAN_MFMA, 1)):
             ctx.set_option("scan_variant", variant)
             ctx.set_option("col_split", split)
+            ctx.set_option("exact_second", 1)          # the key tables are compared word for word below
             plan = ctx.plan(probs)
             info = plan.info()
             plan.run(0)
@@ -216,6 +219,7 @@ def test_column_split_of_few_large_problems(ctx, oracle, shapes, mutual):
     finally:
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
         ctx.set_option("col_split", 0)
+        ctx.set_option("exact_second", 0)
     big = sum(n1 * n2 for n1, n2 in shapes) >= 6 << 20
     assert got["auto"][3]["scan_variant"] == (plslam_amd.SCAN_MFMA if big else plslam_amd.SCAN_WAVE_PER_QUERY)
     assert got["split"][3]["scan_blocks"] > got["unsplit"][3]["scan_blocks"]          # more workgroups, same work
@@ -311,8 +315,8 @@ def test_device_resident_plan_matches_oracle(vctx, oracle):
     bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.75, nnr_l=0.9, mutual=True)
     info = bm.plan.info()
     assert info["n_scans"] == 3 * 8 and info["directed_evals"] == 3 * 4 * (320 * 320 + 70 * 70)
-    if info["scan_variant"] in (plslam_amd.SCAN_SYMMETRIC, plslam_amd.SCAN_MFMA):
-        assert info["distance_evals"] == info["directed_evals"] // 2   # half the distances
+    if info["scan_variant"] in (plslam_amd.SCAN_SYMMETRIC, plslam_amd.SCAN_MFMA) and ctx.get_option("mfma_form") != 3:
+        assert info["distance_evals"] == info["directed_evals"] // 2   # half the distances (K1g executes both directions)
     else:
         assert info["distance_evals"] == info["directed_evals"]
     for _ in range(2):                        # re-running a plan is idempotent
@@ -498,8 +502,12 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
     got = {}
     try:
         ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)
-        for form in (1, 2, 3):                 # K1e, K1f, K1f fused (one workgroup per problem incl. merge + finalize)
-            ctx.set_option("mfma_form", min(form, 2))
+        # K1e, K1f, K1f fused (one workgroup per problem incl. merge + finalize), K1g (two directed scans per mutual
+        # problem), K1h with exact key tables ("exact_second": by default K1h leaves the second neighbour's INDEX and the
+        # columns' second key to the stages that need them -- the match tables below are compared in that default too)
+        for form in (1, 2, 3, 4, 5, 6):
+            ctx.set_option("mfma_form", {4: 3, 5: 4, 6: 4}.get(form, min(form, 2)))
+            ctx.set_option("exact_second", 1 if form in (4, 5) else 0)
             ctx.set_option("fuse", 2 if form == 3 else 1)
             bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.85, nnr_l=0.9, mutual=mutual)
             tab = bm.run()
@@ -511,15 +519,21 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
         ctx.set_option("mfma_form", 0)
         ctx.set_option("fuse", 0)
+        ctx.set_option("exact_second", 0)
     # the dump returns the buffers with their 25 % growth slack: compare the words the kernels write.  (The column
     # PARTIALS are laid out differently -- K1e: 32-bit keys per 256-row block, K1f: 16-bit keys per 64-row block -- so
     # the column direction is compared after the merge: keys21 is part of the key table.)
     rows = pairs * 2 * ((n_orb + n_lbd) * (2 if mutual else 1))
     assert got[1][0].size >= 2 * rows
     k1 = got[1][0][:2 * rows]
-    for form in (2, 3):
+    for form in (2, 3, 4, 5, 6):
         k2 = got[form][0][:2 * rows]
-        assert np.array_equal(k1, k2), (form, int((k1 != k2).sum()))
+        if form != 6:
+            assert np.array_equal(k1, k2), (form, int((k1 != k2).sum()))
+        else:
+            # default K1h: every best key is exact, and so is every row's second-best DISTANCE
+            a, b = k1.reshape(-1, 2), k2.reshape(-1, 2)
+            assert np.array_equal(a[:, 0], b[:, 0]), (form, int((a[:, 0] != b[:, 0]).sum()))
         assert np.array_equal(got[1][2], got[form][2]), form
         assert np.array_equal(got[1][3], got[form][3]), form
 
