@@ -351,7 +351,8 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
                     y.part21 = d_part + 2 * part_row;
                     y.n_iblk = (p.n1 + rpp - 1) / rpp;
                     part_row += part_units(p.n1, n2s);
-                    for (int32_t j0 = 0; j0 < n2s; j0 += mcols) mblocks.push_back({(int32_t)dst.size(), j0});
+                    // (K1h's merge walks column SLOTS, 32 per tile: the table covers n2 rounded up to a tile)
+                    for (int32_t j0 = 0; j0 < ((n2s + 31) & ~31); j0 += mcols) mblocks.push_back({(int32_t)dst.size(), j0});
                 }
                 for (int32_t r0 = 0; r0 < p.n1; r0 += 256) dstb.push_back({(int32_t)dst.size(), r0});
                 if (n2s > 2048) (p.mutual ? P->sym_mfma_multi : P->dir_multi) = true;
@@ -374,7 +375,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
                 yblocks.push_back({(int32_t)syms.size(), 0});
             } else {
                 for (int32_t r0 = 0; r0 < p.n1; r0 += rps) yblocks.push_back({(int32_t)syms.size(), r0});
-                for (int32_t c0 = 0; c0 < p.n2; c0 += (k1f ? mcols : 256)) mblocks.push_back({(int32_t)syms.size(), c0});
+                for (int32_t c0 = 0; c0 < (k1f ? (p.n2 + 31) & ~31 : p.n2); c0 += (k1f ? mcols : 256)) mblocks.push_back({(int32_t)syms.size(), c0});
             }
             if (P->sym_mfma && p.n2 > 2048) P->sym_mfma_multi = true;
             syms.push_back(y);

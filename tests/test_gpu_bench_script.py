@@ -53,7 +53,7 @@ def test_bench_matrix_core_branch_of_the_line():
     d = _run(["--no-cpu-baseline", "--no-secondary"], pairs=160, n_orb=512, n_lbd=64)
     assert REQUIRED <= set(d) and d["value"] > 0
     assert d["roofline"]["bound"] == "mfma" and d["dtype"] == "fp4" and d["roofline"]["unit"] == "TFLOP/s"
-    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel"] == "k_scan_sym_mfma_g"
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel"] == "k_scan_sym_mfma_h"
     assert d["hbm_roofline"]["bound"] == "hbm" and 0 < d["hbm_roofline"]["frac"] < 1
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"}
     assert len(d["config"]["kernel_source_hash"]) == 16
