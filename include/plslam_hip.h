@@ -180,7 +180,9 @@ int plslam_match_plan_run(plslam_match_plan* plan, void* stream);
  * stereo gates, count scatter) on `post_stream`: a stream of runs -- of several plans or of this one -- then overlaps
  * each run's last stages (HBM-bound) with the next run's scan (instruction-issue-bound).  Ordering is the plan's
  * business: the stages wait for their scan, and the plan's next scan (split or not) waits for them.  Results are
- * complete when `post_stream` has drained. */
+ * complete when `post_stream` has drained.  A plan created with option "fuse" = 2 has no stage behind its scan (the scan
+ * kernel writes the tables itself): it is not split, all of it runs on `scan_stream` and its results are complete when
+ * THAT stream has drained. */
 int plslam_match_plan_run_split(plslam_match_plan* plan, void* scan_stream, void* post_stream);
 /* With profiling on, every run brackets each kernel with HIP events on the launch stream. */
 int plslam_match_plan_set_profiling(plslam_match_plan* plan, int enable);
@@ -306,6 +308,8 @@ typedef struct plslam_arena_problem {
 typedef struct plslam_match_pipeline plslam_match_pipeline;
 int plslam_match_pipeline_create(plslam_ctx* ctx, size_t arena_bytes, const plslam_arena_problem* probs, int32_t nprob,
                                  size_t out_entries, int32_t depth, plslam_match_pipeline** out);
+/* out_host / counts_host: page-locked AND 16-byte aligned buffers are written by a kernel straight from the compute
+ * stream; anything else (pageable memory, an offset slice of a pinned buffer) takes a copy-engine download. */
 int plslam_match_pipeline_submit(plslam_match_pipeline* pipe, const void* arena_host, int32_t* out_host,
                                  int32_t* counts_host /* nprob entries or NULL */);
 int plslam_match_pipeline_wait(plslam_match_pipeline* pipe);
@@ -369,6 +373,8 @@ typedef struct plslam_stereo_gate_problem {
     double* disp;                /* out: n_l (points) or 2 n_l (lines: disp_s, disp_e) doubles       */
     int32_t* n_stereo;           /* out: number kept; may be NULL                                    */
 } plslam_stereo_gate_problem;
+/* (Calling it again replaces the stage: the call then waits for the device, so that no run still in flight reads tables
+ * that are being replaced.) */
 int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_stereo_gate_problem* gates,
                                        int32_t ngates);
 

@@ -824,6 +824,9 @@ int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_ste
 {
     PLSLAM_REQUIRE(plan != nullptr && ngates >= 0 && (ngates == 0 || gates != nullptr), PLSLAM_EINVAL);
     DeviceGuard g(plan->ctx->device);
+    // replacing the stage frees / rewrites the tables a run still in flight (on whatever stream the caller used) reads: the
+    // call is rare, so it simply waits for the device
+    if (plan->ngate_blocks > 0 || plan->gate_tables.p) PLSLAM_HIP_CHECK(hipDeviceSynchronize());
     plan->ngate_blocks = 0;
     plan->ngates = 0;
     plan->d_gate_counts = nullptr;
@@ -869,6 +872,10 @@ int plslam_match_plan_run_split(plslam_match_plan* plan, void* scan_stream, void
     PLSLAM_REQUIRE(plan != nullptr, PLSLAM_EINVAL);
     DeviceGuard g(plan->ctx->device);
     hipStream_t s = scan_stream ? static_cast<hipStream_t>(scan_stream) : plan->ctx->stream;
+    // A fused plan (option "fuse" = 2) writes matches_12 and the counts from inside its scan kernel: there is no stage behind
+    // the scan whose completion could order the caller's consumers against the plan's NEXT scan, so such a plan is not
+    // split -- everything goes to the scan stream, where stream order does it.
+    if (plan->fused) return plan_run(plan, s, s);
     return plan_run(plan, s, post_stream ? static_cast<hipStream_t>(post_stream) : s);
 }
 
@@ -1466,6 +1473,11 @@ int plslam_match_pipeline_create(plslam_ctx* ctx, size_t arena_bytes, const plsl
         if ((r = sl.arena.reserve(arena_bytes + 16)) || (r = sl.out.reserve(out_entries * 4 + 16)) ||
             (r = sl.cnt.reserve((size_t)nprob * 4)))
             return fail(r);
+        // entries no problem covers (stride padding between tables) are copied to the host with every batch: the same in
+        // every slot (-1), not whatever the allocation held
+        if (hipMemsetAsync(sl.out.p, 0xFF, out_entries * 4 + 16, ctx->stream) != hipSuccess ||
+            hipMemsetAsync(sl.cnt.p, 0, (size_t)nprob * 4, ctx->stream) != hipSuccess)
+            return fail(PLSLAM_EHIP);
         if (hipEventCreateWithFlags(&sl.up, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&sl.run, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess)
@@ -1515,7 +1527,9 @@ int plslam_match_pipeline_submit(plslam_match_pipeline* P, const void* arena_hos
     // (measured: 1.03 ms per batch of 256 C2 pairs; 0.53 ms = the upload alone once the download is a kernel).
     void* d_out = plslam::mapped_device_pointer(out_host);
     void* d_cnt = counts_host ? plslam::mapped_device_pointer(counts_host) : nullptr;
-    if (d_out && (!counts_host || d_cnt) && (P->out_entries % 4) == 0 && P->nprob <= 256 * 1024) {
+    // (the kernel stores 16 bytes at a time: a page-locked but offset pointer -- a slice of a pinned buffer -- takes the copy path)
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_cnt)) & 15) == 0;
+    if (d_out && (!counts_host || d_cnt) && aligned16 && (P->out_entries % 4) == 0 && P->nprob <= 256 * 1024) {
         const size_t n16 = P->out_entries / 4;
         hipLaunchKernelGGL(k_store_to_host, dim3(64), dim3(256), 0, ctx->stream, sl.out.as<int4>(), (int4*)d_out, n16,
                            (const int32_t*)nullptr, (int32_t*)nullptr, 0);

@@ -69,18 +69,6 @@ constexpr float ACC_MAGIC = 8388608.0f;       // 2^23: float bits = 0x4B000000 +
 
 __device__ __forceinline__ uint32_t umin_(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t umax_(uint32_t a, uint32_t b) { return a > b ? a : b; }
-__device__ __forceinline__ uint32_t med3_(uint32_t a, uint32_t b, uint32_t c)
-{
-    uint32_t r;
-    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-__device__ __forceinline__ void push2(uint32_t& b0, uint32_t& b1, uint32_t key)
-{
-    const uint32_t nb1 = med3_(b0, b1, key);
-    b0 = umin_(b0, key);
-    b1 = nb1;
-}
 __device__ __forceinline__ void merge2(uint32_t& a0, uint32_t& a1, uint32_t c0, uint32_t c1)
 {
     const uint32_t lo = umin_(a0, c0);

@@ -22,6 +22,7 @@
 #include <list>
 #include <mutex>
 #include <stdexcept>
+#include <atomic>
 #include <string>
 #include <utility>
 #include <vector>
@@ -81,16 +82,17 @@ struct ThreadCtx {
     }
     ~ThreadCtx() { release(); }
 };
-inline int& deviceOrdinal()
+// read by every matching thread (the reference calls match() from three: src/mapHandler.cpp:1042-1057), written by setDevice()
+inline std::atomic<int>& deviceOrdinal()
 {
-    static int d = 0;
+    static std::atomic<int> d{0};
     return d;
 }
 inline plslam_ctx* ctx()
 {
     static thread_local ThreadCtx t;
     CtxPool& P = pool();
-    const int want = deviceOrdinal();
+    const int want = deviceOrdinal().load(std::memory_order_relaxed);
     {
         std::lock_guard<std::mutex> lk(P.mu);
         if (t.ctx && t.generation != P.generation) t.ctx = nullptr;      // destroyed by shutdown()
@@ -141,7 +143,7 @@ inline void check(int rc, const char* fn)
 }  // namespace detail
 
 // select the HIP device used by the calling process (takes effect on each thread's next call)
-inline void setDevice(int ordinal) { detail::deviceOrdinal() = ordinal; }
+inline void setDevice(int ordinal) { detail::deviceOrdinal().store(ordinal, std::memory_order_relaxed); }
 
 // Destroys every context the drop-in created (streams, device and page-locked buffers).  Call it when no thread is
 // inside a StVO:: function -- e.g. at the end of main(), before static destruction; without it the contexts are simply
