@@ -101,6 +101,8 @@ struct plslam_match_plan {
     // optional last stage: the stereo gates over the L<->R tables of the batch (plslam_match_plan_add_stereo_gates)
     DevBuf gate_tables;
     std::vector<char> gate_staging;
+    std::vector<ProblemDesc> h_probs;  // host image of d_probs (the gate stage patches ProblemDesc::gate)
+    bool probs_in_place = false;       // d_probs IS the page-locked image
     plslam_stereo_gate_problem* d_gates = nullptr;
     BlockDesc* d_gate_blocks = nullptr;
     int32_t ngate_blocks = 0, ngates = 0;
@@ -327,6 +329,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         pd.keys12 = k12;
         pd.keys21 = k21;
         pd.d1 = p.d1; pd.d2 = p.d2;
+        pd.gate = -1;
         const bool mf_path = P->sym_mfma && p.n1 > 0 && p.n2 > 0;    // this problem runs on K1e / K1f
         if (!(P->fused && mf_path))
             for (int32_t r0 = 0; r0 < p.n1; r0 += 256) fblocks.push_back({i, r0});
@@ -543,6 +546,10 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->d_count_dst = reinterpret_cast<int32_t**>(base + pc[7].off);
     P->d_dirs = reinterpret_cast<SymDesc*>(base + pc[8].off);
     P->d_dir_blocks = reinterpret_cast<BlockDesc*>(base + pc[9].off);
+    P->h_probs = pds;
+    P->probs_in_place = tables_in_place;
+    P->ngate_blocks = 0;                 // a rebuilt plan (the context's host-path plan) starts without a gate stage
+    P->ngates = 0;
 
     // P->staging outlives the copy (it is a member), so no synchronisation is needed here; the
     // copy is ordered before the kernels of plan_run when they use the same stream, and the public
@@ -621,10 +628,11 @@ static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
             : P->sym_mfma && P->mfma_form != 1 ? launch_merge_partials16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, s)
                                                : launch_merge_partials(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s);
     if (r) return r;
-    r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, s);
+    // the gate stage: its counters are cleared first; gates over the plan's own tables run inside the finalize kernel
+    if (P->ngates > 0 && P->d_gate_counts) PLSLAM_HIP_CHECK(hipMemsetAsync(P->d_gate_counts, 0, sizeof(int32_t) * (size_t)P->ngates, s));
+    r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, P->ngates > 0 ? P->d_gates : nullptr, s);
     if (r) return r;
     if (P->ngate_blocks > 0) {
-        if (P->d_gate_counts) PLSLAM_HIP_CHECK(hipMemsetAsync(P->d_gate_counts, 0, sizeof(int32_t) * (size_t)P->ngates, s));
         r = launch_stereo_gates(P->d_gates, P->d_gate_blocks, P->ngate_blocks, s);
         if (r) return r;
     }
@@ -830,15 +838,37 @@ int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_ste
     plan->ngate_blocks = 0;
     plan->ngates = 0;
     plan->d_gate_counts = nullptr;
-    if (ngates == 0) return PLSLAM_OK;
+    if (ngates == 0) {
+        bool any = false;
+        for (ProblemDesc& pd : plan->h_probs) { any = any || pd.gate >= 0; pd.gate = -1; }
+        if (any) {
+            PLSLAM_HIP_CHECK(hipMemcpyAsync(plan->d_probs, plan->h_probs.data(), plan->h_probs.size() * sizeof(ProblemDesc),
+                                            plan->probs_in_place ? hipMemcpyHostToHost : hipMemcpyHostToDevice, plan->ctx->stream));
+            PLSLAM_HIP_CHECK(hipStreamSynchronize(plan->ctx->stream));
+        }
+        return PLSLAM_OK;
+    }
     std::vector<BlockDesc> blocks;
     bool any_cnt = false, all_cnt = true;
+    // a gate whose input table is the matches_12 of one of the plan's problems (the usual case: the L<->R tables of the
+    // batch) is applied by the finalize kernel itself, row by row, the moment the entry is decided (ProblemDesc::gate);
+    // any other gate -- and every gate of a fused plan, which has no finalize kernel -- keeps its own workgroups
+    for (ProblemDesc& pd : plan->h_probs) pd.gate = -1;
     for (int32_t i = 0; i < ngates; ++i) {
         const int rc = check_stereo_gate_problem(gates[i]);
         if (rc) return rc;
         any_cnt = any_cnt || gates[i].n_stereo != nullptr;
         all_cnt = all_cnt && gates[i].n_stereo != nullptr && gates[i].n_stereo == gates[0].n_stereo + i;
-        for (int32_t r0 = 0; r0 < gates[i].n_l; r0 += 256) blocks.push_back({i, r0});
+        bool fused_into_finalize = false;
+        if (!plan->fused && gates[i].n_l > 0)
+            for (ProblemDesc& pd : plan->h_probs)
+                if (pd.matches_12 == gates[i].matches_12 && pd.n1 == gates[i].n_l && pd.gate < 0) {
+                    pd.gate = i;
+                    fused_into_finalize = true;
+                    break;
+                }
+        if (!fused_into_finalize)
+            for (int32_t r0 = 0; r0 < gates[i].n_l; r0 += 256) blocks.push_back({i, r0});
     }
     PLSLAM_REQUIRE(!any_cnt || all_cnt, PLSLAM_EINVAL);     // counters: none, or one contiguous array
     const size_t gbytes = ((size_t)ngates * sizeof(plslam_stereo_gate_problem) + 255) & ~size_t(255);
@@ -850,6 +880,10 @@ int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_ste
     if (r) return r;
     PLSLAM_HIP_CHECK(hipMemcpyAsync(plan->gate_tables.p, plan->gate_staging.data(), total, hipMemcpyHostToDevice,
                                     plan->ctx->stream));
+    // the problem table with its gate indices (the page-locked image is the table itself when the kernels read it in place)
+    if (!plan->h_probs.empty())
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(plan->d_probs, plan->h_probs.data(), plan->h_probs.size() * sizeof(ProblemDesc),
+                                        plan->probs_in_place ? hipMemcpyHostToHost : hipMemcpyHostToDevice, plan->ctx->stream));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(plan->ctx->stream));
     plan->d_gates = plan->gate_tables.as<plslam_stereo_gate_problem>();
     plan->d_gate_blocks = reinterpret_cast<BlockDesc*>(plan->gate_tables.as<char>() + gbytes);

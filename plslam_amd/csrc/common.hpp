@@ -136,6 +136,20 @@ struct plslam_ctx {
 
 namespace plslam {
 
+// Pointers read from launch tables are GENERIC to the compiler, and a generic access is a FLAT instruction (it counts on
+// lgkmcnt as well as vmcnt, and cannot take a scalar base).  Kernels spell the address space out at the point of use:
+// g_(p)[i] is a global_load / global_store.  (tests/test_abi.py: no flat_* instruction in any kernel's ISA.)
+#if defined(__HIPCC__)
+#define PLSLAM_AS1 __attribute__((address_space(1)))
+#define g_(p) ((PLSLAM_AS1 __typeof__(*(p))*)(p))          /* keeps the pointee's typedef (alignment attributes included) */
+typedef uint32_t gvec2_t __attribute__((ext_vector_type(2)));   // native vectors: HIP's uint2 / uint4 structs cannot be copied
+typedef uint32_t gvec4_t __attribute__((ext_vector_type(4)));   // out of / into another address space
+template <class T> __device__ __forceinline__ int atomic_add_global(T* p, int v)
+{
+    return __hip_atomic_fetch_add((PLSLAM_AS1 int*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+
 // --- Hamming scan (hamming.hip) ------------------------------------------------------------
 // composite key: (distance << 23) | trainIdx; 0xFFFFFFFF = "no neighbour"
 constexpr uint32_t KEY_IDX_BITS = 23;
@@ -170,6 +184,9 @@ struct ProblemDesc {    // one StVO::match problem = scan12 (+ scan21 when mutua
     int32_t lazy21;
     const uint8_t* d1;
     const uint8_t* d2;
+    // index of the stereo-gate problem that consumes this table (plslam_match_plan_add_stereo_gates), or -1: the finalize
+    // kernel applies the gate to a row's match the moment it is decided -- no second launch, no second pass over the table
+    int32_t gate, pad2;
 };
 
 struct BlockDesc {      // one workgroup's slice of a scan / problem
@@ -181,7 +198,7 @@ struct BlockDesc {      // one workgroup's slice of a scan / problem
 int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const ScanDesc* d_scans,
                 const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero, hipStream_t s);
 int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int nblocks,
-                    hipStream_t s);
+                    const plslam_stereo_gate_problem* d_gates, hipStream_t s);
 int launch_scatter_counts(const int32_t* d_src, int32_t* const* d_dst, int32_t n, hipStream_t s);
 int launch_unpack_keys(const uint32_t* d_keys, int32_t n, int32_t* d_idx, int32_t* d_dist,
                        hipStream_t s);

@@ -12,6 +12,7 @@
 // as an unsigned min over composite keys  key = (distance << 23) | trainIdx  so that every
 // merge (per lane, across lanes, across workgroups) is associative and tie-exact.
 #include "common.hpp"
+#include "stereo_gates_dev.hpp"
 
 namespace plslam {
 
@@ -107,7 +108,7 @@ k_scan_lane_per_query(const ScanDesc* __restrict__ scans, const BlockDesc* __res
                       int32_t* __restrict__ zero, int nzero)
 {
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < nzero; i += BLOCK) zero[i] = 0;
+        for (int i = threadIdx.x; i < nzero; i += BLOCK) g_(zero)[i] = 0;
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const BlockDesc bd = blocks[wg];
@@ -119,7 +120,7 @@ k_scan_lane_per_query(const ScanDesc* __restrict__ scans, const BlockDesc* __res
 
     uint32_t q[8];
     {
-        const u32x4* qp = reinterpret_cast<const u32x4*>(sc.q + (size_t)rrow * 32);
+        const auto qp = g_(reinterpret_cast<const u32x4*>(sc.q + (size_t)rrow * 32));
         const u32x4 a = qp[0], b = qp[1];
         q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
         q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
@@ -147,7 +148,7 @@ k_scan_lane_per_query(const ScanDesc* __restrict__ scans, const BlockDesc* __res
         best2_push(b0, b1, make_key_s(d, (uint32_t)j));
     }
 
-    if (row < nq) reinterpret_cast<uint2*>(sc.keys)[row] = make_uint2(b0, b1);
+    if (row < nq) g_(reinterpret_cast<gvec2_t*>(sc.keys))[row] = gvec2_t{b0, b1};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -175,7 +176,7 @@ k_scan_wave_per_query(const ScanDesc* __restrict__ scans, const BlockDesc* __res
     __shared__ __attribute__((aligned(16))) uint4 tile[WPQ_TILE_ROWS * 2];
 
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+        for (int i = threadIdx.x; i < nzero; i += 256) g_(zero)[i] = 0;
 
     const BlockDesc bd = blocks[blockIdx.x];
     const ScanDesc sc = scans[bd.item];
@@ -198,12 +199,12 @@ k_scan_wave_per_query(const ScanDesc* __restrict__ scans, const BlockDesc* __res
 #pragma unroll
     for (int k = 0; k < WPQ_QUERIES_PER_WAVE; ++k) b[k][0] = b[k][1] = KEY_NONE;
 
-    const uint4* tg = reinterpret_cast<const uint4*>(sc.t);
+    const auto tg = g_(reinterpret_cast<const u32x4*>(sc.t));
     for (int t0 = 0; t0 < nt; t0 += WPQ_TILE_ROWS) {
         const int rows = nt - t0 < WPQ_TILE_ROWS ? nt - t0 : WPQ_TILE_ROWS;
         if (t0) __syncthreads();                       // previous tile fully consumed
         for (int c = threadIdx.x; c < 2 * rows; c += 256)   // 16-byte chunks, coalesced
-            tile[wpq_slot((uint32_t)c >> 1, (uint32_t)c & 1u)] = tg[(size_t)2 * t0 + c];
+            { const u32x4 v = tg[(size_t)2 * t0 + c]; tile[wpq_slot((uint32_t)c >> 1, (uint32_t)c & 1u)] = make_uint4(v.x, v.y, v.z, v.w); }
         __syncthreads();
         for (int r = lane; r < rows; r += 64) {
             const uint4 ta = tile[wpq_slot((uint32_t)r, 0)], tb = tile[wpq_slot((uint32_t)r, 1)];
@@ -223,7 +224,7 @@ k_scan_wave_per_query(const ScanDesc* __restrict__ scans, const BlockDesc* __res
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1)
             best2_merge(k0, k1, (uint32_t)__shfl_xor((int)k0, m), (uint32_t)__shfl_xor((int)k1, m));
-        if (lane == 0 && q0 + k < nq) reinterpret_cast<uint2*>(sc.keys)[q0 + k] = make_uint2(k0, k1);
+        if (lane == 0 && q0 + k < nq) g_(reinterpret_cast<gvec2_t*>(sc.keys))[q0 + k] = gvec2_t{k0, k1};
     }
 }
 
@@ -303,7 +304,7 @@ k_scan_symmetric(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__
     __shared__ __attribute__((aligned(16))) uint16_t lds[4 * SYM_TILE_U16];
 
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+        for (int i = threadIdx.x; i < nzero; i += 256) g_(zero)[i] = 0;
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const BlockDesc bd = blocks[wg];
@@ -321,7 +322,7 @@ k_scan_symmetric(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__
 
     uint32_t q[8];
     {
-        const u32x4* qp = reinterpret_cast<const u32x4*>(sd.a + (size_t)rrow * 32);
+        const auto qp = g_(reinterpret_cast<const u32x4*>(sd.a + (size_t)rrow * 32));
         const u32x4 a = qp[0], b = qp[1];
         q[0] = a.x; q[1] = a.y; q[2] = a.z; q[3] = a.w;
         q[4] = b.x; q[5] = b.y; q[6] = b.z; q[7] = b.w;
@@ -329,7 +330,7 @@ k_scan_symmetric(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__
     uint16_t* tile = lds + wave * SYM_TILE_U16;
     uint16_t* wr = tile + lane;                                  // tile[jj][lane]
     const uint16_t* col = tile + lane * SYM_TILE_ROW_U16;        // tile[lane][0..63]
-    uint2* part = reinterpret_cast<uint2*>(sd.part21) + (size_t)iblk * n2;
+    const auto part = g_(reinterpret_cast<gvec2_t*>(sd.part21)) + (size_t)iblk * n2;
     sptr_t tp = (sptr_t)(uintptr_t)sd.b;
 
     uint32_t rb0 = KEY_NONE, rb1 = KEY_NONE;
@@ -371,13 +372,13 @@ k_scan_symmetric(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__
             const uint32_t m0 = umin(e0, o0);
             const uint32_t m1 = umin(umax(e0, o0), umin(e1, o1));
             if (lane < jc)
-                part[j0 + lane] = make_uint2(key16_to_32(m0, (uint32_t)i0), key16_to_32(m1, (uint32_t)i0));
+                part[j0 + lane] = gvec2_t{key16_to_32(m0, (uint32_t)i0), key16_to_32(m1, (uint32_t)i0)};
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if (row < n1) reinterpret_cast<uint2*>(sd.keys12)[row] = make_uint2(rb0, rb1);
+    if (row < n1) g_(reinterpret_cast<gvec2_t*>(sd.keys12))[row] = gvec2_t{rb0, rb1};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -404,7 +405,7 @@ k_scan_symmetric_r4(const SymDesc* __restrict__ syms, const BlockDesc* __restric
     __shared__ __attribute__((aligned(16))) uint16_t tile[4 * SYM4_SUBTILE_U16];
 
     if (blockIdx.x == 0)
-        for (int i = threadIdx.x; i < nzero; i += 64) zero[i] = 0;
+        for (int i = threadIdx.x; i < nzero; i += 64) g_(zero)[i] = 0;
 
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const BlockDesc bd = blocks[wg];
@@ -424,7 +425,7 @@ k_scan_symmetric_r4(const SymDesc* __restrict__ syms, const BlockDesc* __restric
             const int row = i0 + 64 * r + lane;
             bias[r] = row < n1 ? 0u : SYM_INVALID_BIAS;
             const int rrow = row < n1 ? row : n1 - 1;
-            const u32x4* qp = reinterpret_cast<const u32x4*>(sd.a + (size_t)rrow * 32);
+            const auto qp = g_(reinterpret_cast<const u32x4*>(sd.a + (size_t)rrow * 32));
             const u32x4 a = qp[0], b = qp[1];
             qr[r][0] = a.x; qr[r][1] = a.y; qr[r][2] = a.z; qr[r][3] = a.w;
             qr[r][4] = b.x; qr[r][5] = b.y; qr[r][6] = b.z; qr[r][7] = b.w;
@@ -440,7 +441,7 @@ k_scan_symmetric_r4(const SymDesc* __restrict__ syms, const BlockDesc* __restric
     uint16_t* wr = tile + lane;                                          // tile[r][jj][lane]
     const uint16_t* col = tile + (lane >> 4) * SYM4_SUBTILE_U16 + (lane & 15) * SYM_TILE_ROW_U16;
     const uint32_t col_i_base = (uint32_t)(i0 + 64 * (lane >> 4));
-    uint2* part = reinterpret_cast<uint2*>(sd.part21) + (size_t)iblk * n2;
+    const auto part = g_(reinterpret_cast<gvec2_t*>(sd.part21)) + (size_t)iblk * n2;
     sptr_t tp = (sptr_t)(uintptr_t)sd.b;
 
     uint32_t rb[4][2];
@@ -500,7 +501,7 @@ k_scan_symmetric_r4(const SymDesc* __restrict__ syms, const BlockDesc* __restric
         // combine the four row-blocks of a column: lanes l, l^16, l^32, l^48
         best2_merge(k0, k1, (uint32_t)__shfl_xor((int)k0, 16), (uint32_t)__shfl_xor((int)k1, 16));
         best2_merge(k0, k1, (uint32_t)__shfl_xor((int)k0, 32), (uint32_t)__shfl_xor((int)k1, 32));
-        if (lane < jc) part[j0 + lane] = make_uint2(k0, k1);
+        if (lane < jc) part[j0 + lane] = gvec2_t{k0, k1};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -509,7 +510,7 @@ k_scan_symmetric_r4(const SymDesc* __restrict__ syms, const BlockDesc* __restric
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = i0 + 64 * r + lane;
-        if (row < n1) reinterpret_cast<uint2*>(sd.keys12)[row] = make_uint2(rb[r][0], rb[r][1]);
+        if (row < n1) g_(reinterpret_cast<gvec2_t*>(sd.keys12))[row] = gvec2_t{rb[r][0], rb[r][1]};
     }
 }
 
@@ -521,13 +522,13 @@ k_merge_partials(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__
     const SymDesc sd = syms[bd.item];
     const int j = bd.row0 + (int)threadIdx.x;
     if (j >= sd.n2) return;
-    const uint2* part = reinterpret_cast<const uint2*>(sd.part21);
+    const auto part = g_(reinterpret_cast<const gvec2_t*>(sd.part21));
     uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
     for (int ib = 0; ib < sd.n_iblk; ++ib) {
-        const uint2 p = part[(size_t)ib * sd.n2 + j];
+        const gvec2_t p = part[(size_t)ib * sd.n2 + j];
         best2_merge(b0, b1, p.x, p.y);
     }
-    reinterpret_cast<uint2*>(sd.keys21)[j] = make_uint2(b0, b1);
+    g_(reinterpret_cast<gvec2_t*>(sd.keys21))[j] = gvec2_t{b0, b1};
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -546,7 +547,8 @@ __device__ __forceinline__ int ratio_pick(uint32_t k0, uint32_t k1, float nnr)
 #define PLSLAM_NT_FINALIZE 1
 #endif
 __global__ void __launch_bounds__(256)
-k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ blocks)
+k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ blocks,
+           const plslam_stereo_gate_problem* __restrict__ gates)
 {
     const BlockDesc bd = blocks[blockIdx.x];
     const ProblemDesc p = probs[bd.item];
@@ -560,30 +562,30 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
         if (p.nsplit > 1) {
             // column-split problem: best-2 over the ranges' row results; keys are (d << 23 | j) with j relative to the
             // range, so its first column is added first -- (d, j) order holds within and across ranges
-            const uint2* tmp = reinterpret_cast<const uint2*>(p.split_tmp);
+            const auto tmp = g_(reinterpret_cast<const gvec2_t*>(p.split_tmp));
             uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
             for (int s = 0; s < p.nsplit; ++s) {
-                const uint2 q = tmp[(size_t)s * p.n1 + i1];
+                const gvec2_t q = tmp[(size_t)s * p.n1 + i1];
                 const uint32_t off = (uint32_t)(s * p.cstep);
                 best2_merge(b0, b1, q.x == KEY_NONE ? KEY_NONE : q.x + off, q.y == KEY_NONE ? KEY_NONE : q.y + off);
             }
             k = make_uint2(b0, b1);
-            reinterpret_cast<uint2*>(p.keys12_out)[i1] = k;          // diagnostics (plslam_match_plan_dump)
+            g_(reinterpret_cast<gvec2_t*>(p.keys12_out))[i1] = gvec2_t{k.x, k.y};          // diagnostics (plslam_match_plan_dump)
         } else {
             // (read once: non-temporal, like the table written below -- they must not push the scan's rows out of L2)
-            k = PLSLAM_NT_FINALIZE ? make_uint2(__builtin_nontemporal_load(p.keys12 + 2 * (size_t)i1),
-                                                __builtin_nontemporal_load(p.keys12 + 2 * (size_t)i1 + 1))
-                                   : reinterpret_cast<const uint2*>(p.keys12)[i1];
+            const gvec2_t kv = PLSLAM_NT_FINALIZE ? __builtin_nontemporal_load(g_(reinterpret_cast<const gvec2_t*>(p.keys12)) + i1)
+                                                  : g_(reinterpret_cast<const gvec2_t*>(p.keys12))[i1];
+            k = make_uint2(kv.x, kv.y);
         }
         m = ratio_pick(k.x, k.y, p.nnr);
         accepted = m >= 0;
         // [RECALL] stvo-pl matchNNR resize()s the table it is given: an entry already there survives a rejected row, then
         // goes through the consistency loop like any other (an entry outside [0, n2) -- an out-of-bounds read upstream --
         // is defined as failing it)
-        if (!accepted && p.keep_prior) m = p.matches_12[i1];
+        if (!accepted && p.keep_prior) m = g_(p.matches_12)[i1];
         if (m >= 0 && p.mutual) {
             check = m < p.n2;
-            if (check) kb = reinterpret_cast<const uint2*>(p.keys21)[m];
+            if (check) { const gvec2_t kv = g_(reinterpret_cast<const gvec2_t*>(p.keys21))[m]; kb = make_uint2(kv.x, kv.y); }
             else { m = -1; cleared = true; }
         }
     }
@@ -624,14 +626,14 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
                     ok = true;                                       // holds even against the lower bound (a second row exists)
                 } else {
                     uint32_t second = kb.y;
-                    const uint4* b = reinterpret_cast<const uint4*>(p.d2 + (size_t)m * 32);
-                    const uint4 b_lo = __ldg(b), b_hi = __ldg(b + 1);
+                    const auto b = g_(reinterpret_cast<const u32x4*>(p.d2 + (size_t)m * 32));
+                    const u32x4 b_lo = b[0], b_hi = b[1];
                     const int base = i1 & ~15;
                     for (int q = 0; q < 16; ++q) {
                         const int i = base + q;
                         const bool use = i != i1 && i < p.n1;
-                        const uint4* a = reinterpret_cast<const uint4*>(p.d1 + (size_t)(use ? i : i1) * 32);
-                        const uint4 a_lo = __ldg(a), a_hi = __ldg(a + 1);
+                        const auto a = g_(reinterpret_cast<const u32x4*>(p.d1 + (size_t)(use ? i : i1) * 32));
+                        const u32x4 a_lo = a[0], a_hi = a[1];
                         const uint32_t d = __popc(a_lo.x ^ b_lo.x) + __popc(a_lo.y ^ b_lo.y) + __popc(a_lo.z ^ b_lo.z) +
                                            __popc(a_lo.w ^ b_lo.w) + __popc(a_hi.x ^ b_hi.x) + __popc(a_hi.y ^ b_hi.y) +
                                            __popc(a_hi.z ^ b_hi.z) + __popc(a_hi.w ^ b_hi.w);
@@ -645,14 +647,21 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
     }
     if (check && !ok) { m = -1; cleared = true; }
     if (i1 < p.n1) {
-        if (PLSLAM_NT_FINALIZE) __builtin_nontemporal_store(m, p.matches_12 + i1);
-        else p.matches_12[i1] = m;
+        if (PLSLAM_NT_FINALIZE) __builtin_nontemporal_store(m, g_(p.matches_12) + i1);
+        else g_(p.matches_12)[i1] = m;
     }
     if (p.n_matches) {
         // the reference's arithmetic: +1 per row the ratio test accepts, -1 per entry the consistency loop clears (equal
         // to the number of entries >= 0 unless kept entries are involved)
         const int delta = (int)__popcll(__ballot(accepted)) - (int)__popcll(__ballot(cleared));
-        if ((threadIdx.x & 63) == 0 && delta) atomicAdd(p.n_matches, delta);
+        if ((threadIdx.x & 63) == 0 && delta) (void)atomic_add_global(p.n_matches, delta);
+    }
+    if (p.gate >= 0) {
+        // StereoFrame's gate over this L<->R table (stereo_gates_dev.hpp), on the entry just decided
+        const plslam_stereo_gate_problem q = gates[p.gate];
+        const int kept = i1 < p.n1 ? stereo_gate_row(q, i1, m) : 0;
+        const unsigned long long bal = __ballot(kept);
+        if (q.n_stereo && (threadIdx.x & 63) == 0 && bal) (void)atomic_add_global(q.n_stereo, (int)__popcll(bal));
     }
 }
 
@@ -661,7 +670,7 @@ __global__ void __launch_bounds__(256)
 k_scatter_counts(const int32_t* __restrict__ src, int32_t* const* __restrict__ dst, int32_t n)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && dst[i]) *dst[i] = src[i];
+    if (i < n && g_(dst)[i]) *g_(g_(dst)[i]) = g_(src)[i];
 }
 
 // keys -> (idx, dist) pairs of the knnMatch ABI
@@ -671,7 +680,7 @@ k_unpack_keys(const uint32_t* __restrict__ keys, int32_t n, int32_t* __restrict_
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const uint32_t k = keys[i];
+    const uint32_t k = g_(keys)[i];
     idx[i] = k == KEY_NONE ? -1 : (int32_t)(k & KEY_IDX_MASK);
     dist[i] = k == KEY_NONE ? INT32_MAX : (int32_t)(k >> KEY_IDX_BITS);
 }
@@ -743,10 +752,10 @@ int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int n
 }
 
 int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int nblocks,
-                    hipStream_t s)
+                    const plslam_stereo_gate_problem* d_gates, hipStream_t s)
 {
     if (nblocks <= 0) return PLSLAM_OK;
-    hipLaunchKernelGGL(k_finalize, dim3(nblocks), dim3(256), 0, s, d_probs, d_blocks);
+    hipLaunchKernelGGL(k_finalize, dim3(nblocks), dim3(256), 0, s, d_probs, d_blocks, d_gates);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

@@ -318,8 +318,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     if ((uint32_t)P.cs[ncell] > (uint32_t)g.n_items) {      // the grid holds more items than the caller declared
         for (int32_t i = tid; i < n1; i += NT) g_matches[i] = -1;
         if (tid == 0) {
-            if (g.n_matches) *g.n_matches = -1;
-            if (g.status) atomicAdd(g.status, 1);
+            if (g.n_matches) *g_(g.n_matches) = -1;
+            if (g.status) (void)atomic_add_global(g.status, 1);
         }
         return;
     }
@@ -384,8 +384,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         if (__syncthreads_or(s_cur[wv] > seg_words + tail_cap)) {       // a wave's share of the store does not fit: report, match nothing
             for (int32_t i = tid; i < n1; i += NT) g_matches[i] = -1;
             if (tid == 0) {
-                if (g.n_matches) *g.n_matches = -1;
-                if (g.status) atomicAdd(g.status, 1);
+                if (g.n_matches) *g_(g.n_matches) = -1;
+                if (g.status) (void)atomic_add_global(g.status, 1);
             }
             return;
         }
@@ -412,8 +412,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                 // the store does not fit: report, match nothing
                 for (int32_t i = tid; i < n1; i += NT) g_matches[i] = -1;
                 if (tid == 0) {
-                    if (g.n_matches) *g.n_matches = -1;
-                    if (g.status) atomicAdd(g.status, 1);
+                    if (g.n_matches) *g_(g.n_matches) = -1;
+                    if (g.status) (void)atomic_add_global(g.status, 1);
                 }
                 return;
             }
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         if (tid < st) s_part[tid] += s_part[tid + st];
         __syncthreads();
     }
-    if (tid == 0 && g.n_matches) *g.n_matches = (int32_t)s_part[0];
+    if (tid == 0 && g.n_matches) *g_(g.n_matches) = (int32_t)s_part[0];
     GRID_STAMP();
 #ifdef PLSLAM_GRID_TIMING
     if (tid == 0 && (blockIdx.x == 0 || (blockIdx.x & 1023) == 600))

@@ -13,84 +13,10 @@
 #include <cstring>
 
 #include "common.hpp"
+#include "stereo_gates_dev.hpp"
 
 namespace plslam {
 namespace {
-
-// one left key point: the gate of matchStereoPoints; returns the kept right index or -1, *dsp = its disparity or 0
-__device__ __forceinline__ int32_t point_gate_one(int32_t i2, float2 a, const float2* __restrict__ kp_r, int32_t n_r,
-                                                  double max_dist_epip, double min_disp, double* dsp)
-{
-    *dsp = 0.0;
-    if (i2 < 0 || i2 >= n_r) return -1;
-    const float2 b = kp_r[i2];
-    const float dy = __fsub_rn(a.y, b.y);
-    if (!((double)fabsf(dy) <= max_dist_epip)) return -1;
-    const double d = (double)__fsub_rn(a.x, b.x);
-    if (!(d >= min_disp)) return -1;
-    *dsp = d;
-    return i2;
-}
-
-__device__ __forceinline__ double dmin2(double a, double b) { return b < a ? b : a; }   // std::min
-__device__ __forceinline__ double dmax2(double a, double b) { return a < b ? b : a; }   // std::max
-
-// StereoFrame::lineSegmentOverlapStereo
-__device__ __forceinline__ double overlap_stereo(double spl_obs, double epl_obs, double spl_proj, double epl_proj,
-                                                 double line_horiz_th)
-{
-    double overlap = 1.f;
-    if (fabs(epl_obs - spl_obs) > line_horiz_th) {
-        const double sln = dmin2(spl_obs, epl_obs), eln = dmax2(spl_obs, epl_obs);
-        const double spn = dmin2(spl_proj, epl_proj), epn = dmax2(spl_proj, epl_proj);
-        const double length = eln - spn;
-        if ((epn < sln) || (spn > eln))
-            overlap = 0.f;
-        else if ((epn > eln) && (spn < sln))
-            overlap = eln - sln;
-        else
-            overlap = dmin2(eln, epn) - dmax2(sln, spn);
-        if (length > 0.01f)
-            overlap = overlap / length;
-        else
-            overlap = 0.f;
-        if (overlap > 1.f) overlap = 1.f;
-    }
-    return overlap;
-}
-
-// one left segment: the gate of matchStereoLines (the second end point reads the already overwritten first one, as the
-// source does); returns the kept right index or -1, ds / de = the end-point disparities or 0
-__device__ __forceinline__ int32_t line_gate_one(int32_t i2, float4 L, const float4* __restrict__ seg_r, int32_t n_r,
-                                                 double min_disp, double line_horiz_th, double stereo_overlap_th,
-                                                 double ls_min_disp_ratio, double* ds, double* de)
-{
-    *ds = 0.0;
-    *de = 0.0;
-    if (i2 < 0 || i2 >= n_r) return -1;
-    const float4 R = seg_r[i2];
-    const double sp_l[2] = {L.x, L.y}, ep_l[2] = {L.z, L.w};
-    double sp_r[2] = {R.x, R.y}, ep_r[2] = {R.z, R.w};
-    const double overlap = overlap_stereo(sp_l[1], ep_l[1], sp_r[1], ep_r[1], line_horiz_th);
-    const double sx = (sp_r[0] * (sp_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - sp_l[1])) / (sp_r[1] - ep_r[1]);
-    sp_r[0] = sx;
-    sp_r[1] = sp_l[1];
-    const double ex = (sp_r[0] * (ep_l[1] - ep_r[1]) + ep_r[0] * (sp_r[1] - ep_l[1])) / (sp_r[1] - ep_r[1]);
-    ep_r[0] = ex;
-    ep_r[1] = ep_l[1];
-    double disp_s = sp_l[0] - sp_r[0], disp_e = ep_l[0] - ep_r[0];
-    if (dmin2(disp_s, disp_e) / dmax2(disp_s, disp_e) < ls_min_disp_ratio) {
-        disp_s = -1.0;
-        disp_e = -1.0;
-    }
-    if (disp_s >= min_disp && disp_e >= min_disp && fabs(sp_l[1] - ep_l[1]) > line_horiz_th &&
-        fabs(sp_r[1] - ep_r[1]) > line_horiz_th && overlap > stereo_overlap_th) {
-        *ds = disp_s;
-        *de = disp_e;
-        return i2;
-    }
-    return -1;
-}
 
 __global__ void __launch_bounds__(256)
 k_stereo_point_gate(const int32_t* __restrict__ m12, int32_t n_l, const float2* __restrict__ kp_l,
@@ -101,13 +27,14 @@ k_stereo_point_gate(const int32_t* __restrict__ m12, int32_t n_l, const float2* 
     int ok = 0;
     if (i1 < n_l) {
         double dsp;
-        const int32_t k = point_gate_one(m12[i1], kp_l[i1], kp_r, n_r, max_dist_epip, min_disp, &dsp);
+        const gfvec2_t a = g_(reinterpret_cast<const gfvec2_t*>(kp_l))[i1];
+        const int32_t k = point_gate_one(g_(m12)[i1], make_float2(a.x, a.y), g_(kp_r), n_r, max_dist_epip, min_disp, &dsp);
         ok = k >= 0;
-        stereo_12[i1] = k;
-        disp[i1] = dsp;
+        g_(stereo_12)[i1] = k;
+        g_(disp)[i1] = dsp;
     }
     const unsigned long long bal = __ballot(ok);
-    if (count && (threadIdx.x & 63) == 0 && bal) atomicAdd(count, (int)__popcll(bal));
+    if (count && (threadIdx.x & 63) == 0 && bal) (void)atomic_add_global(count, (int)__popcll(bal));
 }
 
 __global__ void __launch_bounds__(256)
@@ -120,15 +47,16 @@ k_stereo_line_gate(const int32_t* __restrict__ m12, int32_t n_l, const float4* _
     int ok = 0;
     if (i1 < n_l) {
         double ds, de;
-        const int32_t k = line_gate_one(m12[i1], seg_l[i1], seg_r, n_r, min_disp, line_horiz_th, stereo_overlap_th,
-                                        ls_min_disp_ratio, &ds, &de);
+        const gfvec4_t a = g_(reinterpret_cast<const gfvec4_t*>(seg_l))[i1];
+        const int32_t k = line_gate_one(g_(m12)[i1], make_float4(a.x, a.y, a.z, a.w), g_(seg_r), n_r, min_disp, line_horiz_th,
+                                        stereo_overlap_th, ls_min_disp_ratio, &ds, &de);
         ok = k >= 0;
-        stereo_12[i1] = k;
-        disp_se[2 * (size_t)i1] = ds;
-        disp_se[2 * (size_t)i1 + 1] = de;
+        g_(stereo_12)[i1] = k;
+        g_(disp_se)[2 * (size_t)i1] = ds;
+        g_(disp_se)[2 * (size_t)i1 + 1] = de;
     }
     const unsigned long long bal = __ballot(ok);
-    if (count && (threadIdx.x & 63) == 0 && bal) atomicAdd(count, (int)__popcll(bal));
+    if (count && (threadIdx.x & 63) == 0 && bal) (void)atomic_add_global(count, (int)__popcll(bal));
 }
 
 // the gate stage of a match plan: every (gate problem, 256 left features) pair is one workgroup of ONE launch
@@ -140,27 +68,11 @@ k_stereo_gates_batched(const plslam_stereo_gate_problem* __restrict__ gates, con
     const int i1 = bd.row0 + (int)threadIdx.x;
     int ok = 0;
     if (i1 < q.n_l) {
-        const int32_t i2 = __builtin_nontemporal_load(q.matches_12 + i1);   // (tables and outputs stream through once)
-        if (q.lines) {
-            double ds, de;
-            const int32_t k = line_gate_one(i2, reinterpret_cast<const float4*>(q.f_l)[i1],
-                                            reinterpret_cast<const float4*>(q.f_r), q.n_r, q.min_disp, q.line_horiz_th,
-                                            q.stereo_overlap_th, q.ls_min_disp_ratio, &ds, &de);
-            ok = k >= 0;
-            __builtin_nontemporal_store(k, q.stereo_12 + i1);
-            __builtin_nontemporal_store(ds, q.disp + 2 * (size_t)i1);
-            __builtin_nontemporal_store(de, q.disp + 2 * (size_t)i1 + 1);
-        } else {
-            double dsp;
-            const int32_t k = point_gate_one(i2, reinterpret_cast<const float2*>(q.f_l)[i1],
-                                             reinterpret_cast<const float2*>(q.f_r), q.n_r, q.max_dist_epip, q.min_disp, &dsp);
-            ok = k >= 0;
-            __builtin_nontemporal_store(k, q.stereo_12 + i1);
-            __builtin_nontemporal_store(dsp, q.disp + i1);
-        }
+        const int32_t i2 = __builtin_nontemporal_load(g_(q.matches_12) + i1);   // (tables and outputs stream through once)
+        ok = stereo_gate_row(q, i1, i2);
     }
     const unsigned long long bal = __ballot(ok);
-    if (q.n_stereo && (threadIdx.x & 63) == 0 && bal) atomicAdd(q.n_stereo, (int)__popcll(bal));
+    if (q.n_stereo && (threadIdx.x & 63) == 0 && bal) (void)atomic_add_global(q.n_stereo, (int)__popcll(bal));
 }
 
 // one host-pointer call: lines != 0 -> segments (4 floats per feature) and two disparities per feature

@@ -77,10 +77,14 @@ def test_every_symbol_has_a_declared_signature():
     assert not missing, missing
 
 
-def test_no_device_scope_fence_in_any_kernel():
+def test_no_device_scope_fence_and_no_flat_access_in_any_kernel():
     """A device-scope fence is an L2 write-back + invalidate on gfx950 (buffer_wbl2 / buffer_inv) whose cost grows with what the
     rest of the chip has written (it doubled the windowed matcher's time per problem under load): every exchange through
-    memory inside these kernels is between lanes of one workgroup.  Checked in the ISA of every kernel source."""
+    memory inside these kernels is between lanes of one workgroup.  Checked in the ISA of every kernel source.
+    Also: no FLAT memory instruction.  A pointer read from a launch table is generic to the compiler, and a generic access
+    counts on lgkmcnt as well as vmcnt (every LDS wait then also waits for it) and cannot take a scalar base; the kernels
+    spell the global address space out where they dereference (common.hpp: g_())."""
+    import re
     import subprocess
     from plslam_amd import build as B
     csrc = os.path.join(ROOT, "plslam_amd", "csrc")
@@ -90,6 +94,8 @@ def test_no_device_scope_fence_in_any_kernel():
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-1500:]
         assert "buffer_wbl2" not in r.stdout and "buffer_inv" not in r.stdout, src
+        flat = re.findall(r"^\s+(flat_(?:load|store|atomic)\w*)", r.stdout, flags=re.M)
+        assert not flat, (src, len(flat), flat[:3])
 
 
 def test_header_is_plain_c(tmp_path):
