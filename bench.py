@@ -69,6 +69,30 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+def oracle_tables(stream, n_orb, n_lbd, nnr_p, nnr_l, threads=None):
+    """The oracle's match tables of a WHOLE batch, (B, 2 n_orb + 2 n_lbd) in the GPU table's row layout, on all usable cores:
+    the checker of a timed output (every pair, not a sample).  Returns (tables, seconds)."""
+    from oracle import oracle as O
+    L = O.native_lib()
+    B = stream["orb_l"].shape[0] - 1
+    threads = threads or usable_cpus()
+
+    def pack(lst, n):
+        return np.ascontiguousarray(np.concatenate(lst)), np.arange(0, (len(lst) + 1) * n, n, dtype=np.int32)
+    d1o, d2o, d1l, d2l = [], [], [], []
+    for i in range(B):
+        d1o += [stream["orb_l"][i + 1], stream["orb_l"][i]]
+        d2o += [stream["orb_r"][i + 1], stream["orb_l"][i + 1]]
+        d1l += [stream["lbd_l"][i + 1], stream["lbd_l"][i]]
+        d2l += [stream["lbd_r"][i + 1], stream["lbd_l"][i + 1]]
+    (a, oa), (b, ob), (c, oc), (d, od) = pack(d1o, n_orb), pack(d2o, n_orb), pack(d1l, n_lbd), pack(d2l, n_lbd)
+    t0 = time.perf_counter()
+    mo, _ = O.match_batched(a, oa, b, ob, nnr_p, True, nthreads=threads, L=L)
+    ml, _ = O.match_batched(c, oc, d, od, nnr_l, True, nthreads=threads, L=L)
+    dt = time.perf_counter() - t0
+    return np.concatenate([mo.reshape(B, 2 * n_orb), ml.reshape(B, 2 * n_lbd)], axis=1), dt
+
+
 def cpu_baseline(stream, n_orb, n_lbd, nnr_p, nnr_l, budget_s=15.0):
     """The CPU restatement of the reference path (oracle, -O3 -march=native, popcnt) timed on this
     host's cores on a bounded sample of the SAME workload.  kind = "port".  Also returns the match tables of its first
@@ -144,6 +168,11 @@ def main():
     ap.add_argument("--step-streams", type=int, default=2, help="output buffers / HIP streams the steps alternate over")
     ap.add_argument("--no-overlap", action="store_true",
                     help="single GPU: run the steps strictly one after another on one stream")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --pairs-per-gpu pairs on EVERY rank per step (default); strong: --pairs-per-gpu is the TOTAL per step, "
+                         "sharded contiguously over the ranks (BASELINE config 4: 4096 pairs -> 512 per GPU at N = 8)")
+    ap.add_argument("--batches", type=int, default=3,
+                    help="N = 1: distinct input batches rotated through the timed loop (1 = the same batch every step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary records (tables only, popcount kernels, C5, C3) of the N = 1 line")
@@ -186,15 +215,33 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    B = args.pairs_per_gpu
     n_orb, n_lbd = args.n_orb, args.n_lbd
+    if args.scaling == "strong":
+        # BASELINE config 4 as written: ONE batch of --pairs-per-gpu pairs per step, contiguous shards of total / N pairs
+        if args.pairs_per_gpu % world:
+            raise SystemExit(f"--scaling strong: {args.pairs_per_gpu} pairs do not divide over {world} ranks")
+        first_pair, hi_ = frontend.shard_range(args.pairs_per_gpu, world, rank)
+        B = hi_ - first_pair
+    else:
+        B = args.pairs_per_gpu                   # weak scaling: rank r owns pairs [r*B, (r+1)*B) of one global stream
+        first_pair = rank * B
     baseline_cfg = {(800, 100): "C1-shaped (KITTI 800 ORB + 100 LBD)", (1500, 200): "C2", (4000, 600): "C5"}
     cfg_name = baseline_cfg.get((n_orb, n_lbd), "custom")
-    # weak scaling: rank r owns pairs [r*B, (r+1)*B) of one global stream (with a one-pair halo)
-    stream = synth.stereo_stream(B, n_orb, n_lbd, seed=synth.SEED0, first_pair=rank * B)
+    # every shard carries a one-pair halo (the left descriptors of the pair before its first)
+    stream = synth.stereo_stream(B, n_orb, n_lbd, seed=synth.SEED0, first_pair=first_pair)
     gates = None if args.no_gates else dict(synth.KITTI_GATES)
-    geo = None if args.no_gates else synth.stereo_geometry(stream, first_pair=rank * B)
+    geo = None if args.no_gates else synth.stereo_geometry(stream, first_pair=first_pair)
 
+    # N > 1: every rank must sit on its own GPU (a launcher that maps two ranks to one device would still "scale")
+    ranks_seen = None
+    if use_dist:
+        props = torch.cuda.get_device_properties(dev)
+        ident = str(getattr(props, "uuid", "")) or f"{props.name}:{getattr(props, 'pci_bus_id', local_rank)}:{local_rank}"
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        ranks_seen = {"world_size": dist.get_world_size(), "distinct_devices": len(set(idents))}
+        if rank == 0 and ranks_seen["distinct_devices"] != world:
+            raise SystemExit(f"{world} ranks on {ranks_seen['distinct_devices']} distinct devices: {idents}")
     note(f"synthetic stream of {B} pairs generated")
     ctx = plslam_amd.Context(local_rank)     # raises if libplslam_hip.so / a gfx950 device is missing
     for key, val in (("scan_variant", args.scan_variant), ("scan_block", args.scan_block), ("sym_rows", args.sym_rows),
@@ -207,20 +254,37 @@ def main():
                                      n_buffers=n_buf, geometry=geo, gates=gates)
     info = bm.plan.info()
     devinfo = ctx.device_info()
+    # N = 1: consecutive steps are DIFFERENT batches (round 2 alternated two plans over one batch, whose LBD sets and tables
+    # fit the 256 MB Infinity Cache): `--batches` matchers with their own descriptors, tables and plans step through the
+    # same pair of streams in rotation.  (N > 1 keeps one batch per rank: the gather pipeline owns the table buffers.)
+    nbatch = max(1, args.batches) if (overlap and not use_dist) else 1
+    extra_streams, extra_bms = [], []
+    for k_ in range(1, nbatch):
+        st_k = synth.stereo_stream(B, n_orb, n_lbd, seed=synth.SEED0 + 7919 * k_, first_pair=first_pair)
+        geo_k = None if args.no_gates else synth.stereo_geometry(st_k, first_pair=first_pair)
+        extra_streams.append(st_k)
+        extra_bms.append(frontend.StereoBatchMatcher(ctx, st_k, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev,
+                                                     n_buffers=1, geometry=geo_k, gates=gates, streams=bm.streams))
+    rotation = [bm.plans[0]] + [e.plans[0] for e in extra_bms]
     # N > 1: the table of step k is gathered to rank 0 over RCCL on a communication stream while
     # step k+1 computes into the other table buffer (steps are independent batches of a stream).
     pg = frontend.PipelinedGather(bm, world, rank, root=0) if use_dist else None
+    scan_stream, stage_stream = bm.streams[0], bm.stage_stream
 
-    def run_steps(matcher, gather, n, k0=0):
+    def run_steps(matcher, gather, n, k0=0, events=None, rotate=True):
         for k in range(k0, k0 + n):
             if gather is not None:
                 gather.step(k)
+            elif overlap and rotate and nbatch > 1:
+                rotation[k % nbatch].run_split(scan_stream.cuda_stream, stage_stream.cuda_stream)
             elif overlap:
-                # consecutive steps are independent batches: alternate two output buffers / HIP streams so
-                # the next scan's ramp-up fills the CUs that idle in this step's drain, merge and finalize
+                # consecutive steps are independent batches: every scan on one HIP stream, the stages behind a scan on a
+                # second one (they run under the next step's scan)
                 matcher.run_overlapped(k)
             else:
                 matcher.run()
+            if events is not None:
+                events[k - k0 + 1].record(stage_stream if (overlap or gather is not None) else matcher.stream)
 
     def sync(matcher, gather):
         if gather is not None:
@@ -232,24 +296,41 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    note(f"plan built: {info}")
+    note(f"plan built: {info}; {nbatch} distinct batch(es) in rotation")
     run_steps(bm, pg, args.warmup)
     sync(bm, pg)
     note("warmup done")
-    for p_ in bm.plans:
+    all_plans = list(bm.plans) + [e.plans[0] for e in extra_bms]
+    for p_ in all_plans:
         p_.set_profiling(True)
         p_.elapsed()                          # reset the accumulators
+    # per-step completion events on the stream the step's last stage runs on: steady-state step times (median, p10, p90)
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    step_events[0].record(stage_stream if (overlap or pg is not None) else bm.stream)
     t0 = time.perf_counter()
-    run_steps(bm, pg, args.steps, args.warmup)
+    run_steps(bm, pg, args.steps, args.warmup, events=step_events)
     sync(bm, pg)
     elapsed = time.perf_counter() - t0
+    step_ms = np.array([step_events[i].elapsed_time(step_events[i + 1]) for i in range(args.steps)])
     scan_ms = fin_ms = 0.0
     runs = 0
-    for p_ in bm.plans:
+    for p_ in all_plans:
         a_, b_, n_ = p_.elapsed()
         scan_ms, fin_ms, runs = scan_ms + a_, fin_ms + b_, runs + n_
         p_.set_profiling(False)
     note(f"timed {args.steps} steps in {elapsed:.4f}s; scan {scan_ms / max(runs, 1):.3f} ms/launch")
+    # the same K steps over ONE repeated batch (round 2's stepping): how much of the number is cache residency
+    repeated = None
+    if nbatch > 1:
+        run_steps(bm, pg, 2, 0, rotate=False)
+        sync(bm, pg)
+        t1 = time.perf_counter()
+        run_steps(bm, pg, args.steps, 0, rotate=False)
+        sync(bm, pg)
+        dt1 = time.perf_counter() - t1
+        repeated = {"value": B * args.steps / dt1, "unit": "stereo pairs/s", "ms_per_step": 1e3 * dt1 / args.steps,
+                    "note": "the same plan pair over one batch every step (round 2's timed loop); the headline rotates "
+                            f"{nbatch} distinct batches"}
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
@@ -338,6 +419,23 @@ def main():
             verified["stereo_gates"] = (f"{len(gsample)} pairs spread over the batch bit-exact vs the oracle (tables, "
                                         f"disparities as raw words, counts); kept {int(sc_[:, 0].sum())} points + "
                                         f"{int(sc_[:, 1].sum())} lines of the batch")
+        # the other batches of the rotation: whole batches when the CPU leg runs anyway, a spread of pairs otherwise
+        for k_, (eb, st_k) in enumerate(zip(extra_bms, extra_streams), start=1):
+            got = eb.tables[0].cpu().numpy()
+            if cpu_tables is not None:
+                ref_k, _ = oracle_tables(st_k, n_orb, n_lbd, args.nnr_p, args.nnr_l)
+                if not np.array_equal(got, ref_k):
+                    bad = np.argwhere(got != ref_k)
+                    raise SystemExit(f"bench output differs from the oracle: batch {k_}, {len(bad)} entries, first at pair {bad[0][0]}")
+            else:
+                bad = frontend.verify_gathered_tables(got, 1, B, n_orb, n_lbd, args.nnr_p, args.nnr_l,
+                                                      sorted({0, 1, B // 3, B // 2, B - 1}),
+                                                      lambda d1, d2, nnr: O.match(d1, d2, nnr, True)[0], local_stream=st_k)
+                if bad:
+                    raise SystemExit(f"bench output differs from the oracle: batch {k_}, (rank, pair, problem) = {bad[:4]}")
+        if extra_bms:
+            verified["match_tables"] += (f"; the {len(extra_bms)} other batch(es) of the rotation: " +
+                                         ("every pair" if cpu_tables is not None else "the same spread of pairs"))
         note(f"output verified: {verified}")
 
         pairs_total = B * world * args.steps
@@ -417,13 +515,20 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
+            "ms_per_step_distribution": {"median": float(np.median(step_ms)), "p10": float(np.percentile(step_ms, 10)),
+                                         "p90": float(np.percentile(step_ms, 90)), "min": float(step_ms.min()),
+                                         "max": float(step_ms.max()), "n": int(step_ms.size),
+                                         "how": "HIP events on the stream of each step's last stage, rank 0; an interval is the "
+                                                "time between the completions of consecutive steps (steady state: the steps "
+                                                "overlap), the first one includes the pipeline fill"},
             "vs_baseline": None,
             "dtype": "fp4" if mfma else "u32",
             "data": "synthetic",
             "config": {
                 "workload": workload,
-                "pairs_per_gpu_per_step": B, "nnr_p": args.nnr_p, "nnr_l": args.nnr_l, "mutual": True,
+                "pairs_per_gpu_per_step": B, "pairs_per_step_all_gpus": B * world, "nnr_p": args.nnr_p, "nnr_l": args.nnr_l,
+                "mutual": True, "distinct_batches_in_rotation": nbatch, "rccl_ranks_seen": ranks_seen,
                 "stereo_gates": gates,
                 "scan_variant": info["scan_variant"], "scan_block_threads": info["scan_block_threads"],
                 "mfma_form": form, "kernel": kernel_name, "kernel_source_hash": src_hash,
@@ -445,12 +550,17 @@ def main():
         }
         if cpu_rec is not None:
             out["cpu_baseline"] = cpu_rec
+        if repeated is not None:
+            repeated["rotating_over_repeated"] = out["value"] / repeated["value"]
+            out["one_repeated_batch"] = repeated
 
+    for eb in extra_bms:
+        eb.close()
     bm.close()
     # ---- secondary records (N = 1): the other single-GPU configurations, timed by this same command ---------------------
     if rank == 0 and world == 1 and not args.no_secondary and not use_dist:
         note("secondary records ...")
-        out["secondary"] = secondary_records(ctx, dev, args, note)
+        out["secondary"] = secondary_records(ctx, dev, args, note, cpu_tables if out is not None else None)
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
@@ -459,7 +569,7 @@ def main():
         dist.destroy_process_group()
 
 
-def secondary_records(ctx, dev, args, note):
+def secondary_records(ctx, dev, args, note, main_tables=None):
     """Driver-timed numbers for the other BASELINE configurations and kernel forms (they existed only as
     builder-run files).  Each is a short run: a few hundred ms of GPU time."""
     import torch
@@ -487,23 +597,31 @@ def secondary_records(ctx, dev, args, note):
         p0.set_profiling(False)
         return dt, a_ / max(n_, 1), b_ / max(n_, 1)
 
-    def check_pair0(bm, st, n_orb, n_lbd, nnr_p, nnr_l):
-        tab = bm.tables[0][0].cpu().numpy()
-        sl = frontend.table_slices(n_orb, n_lbd)
-        for name, d1, d2 in frontend.pair_problems(st["orb_l"], st["orb_r"], st["lbd_l"], st["lbd_r"], 0):
-            em, _ = O.match(d1, d2, nnr_p if name.startswith("orb") else nnr_l, True)
-            if not np.array_equal(tab[sl[name]], em):
-                raise SystemExit(f"secondary record: output differs from the oracle ({name})")
+    def check_all(bm, st, n_orb, n_lbd, nnr_p, nnr_l, ref=None):
+        """EVERY pair of the batch, both output buffers, against the oracle (all usable cores)."""
+        if ref is None:
+            ref, _ = oracle_tables(st, n_orb, n_lbd, nnr_p, nnr_l)
+        for b_, tab in enumerate(bm.tables):
+            got = tab.cpu().numpy()
+            if not np.array_equal(got, ref):
+                bad = np.argwhere(got != ref)
+                raise SystemExit(f"secondary record: buffer {b_} differs from the oracle in {len(bad)} entries, first at pair {bad[0][0]}")
+        return ref
 
-    def pairs_run(tag, n_orb, n_lbd, pairs, steps, opts, workload):
+    def pairs_run(tag, n_orb, n_lbd, pairs, steps, opts, workload, nnr_l=None, ref=None, with_gates=False, cpu_rate=False):
+        nnr_l = args.nnr_l if nnr_l is None else nnr_l
         for k, v in opts.items():
             ctx.set_option(k, v)
         try:
             st = synth.stereo_stream(pairs, n_orb, n_lbd, seed=synth.SEED0)
-            bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev, n_buffers=2)
+            geo_ = synth.stereo_geometry(st, first_pair=0) if with_gates else None
+            bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=args.nnr_p, nnr_l=nnr_l, mutual=True, device=dev, n_buffers=2,
+                                             geometry=geo_, gates=dict(synth.KITTI_GATES) if with_gates else None)
             info = bm.plan.info()
             dt, scan_ms, post_ms = timed(bm, steps)
-            check_pair0(bm, st, n_orb, n_lbd, args.nnr_p, args.nnr_l)
+            t0 = time.perf_counter()
+            check_all(bm, st, n_orb, n_lbd, args.nnr_p, nnr_l, ref)
+            cpu_dt = time.perf_counter() - t0
             bm.close()
         finally:
             for k in opts:
@@ -513,12 +631,21 @@ def secondary_records(ctx, dev, args, note):
                     "unit": "stereo pairs/s", "workload": workload, "pairs_per_step": pairs, "steps": steps,
                     "scan_variant": info["scan_variant"], "scan_kernel_ms": scan_ms, "post_scan_ms": post_ms,
                     "hbm_roofline_frac": gbs / HBM_PEAK_GBS, "hbm_algorithmic_GBps": gbs,
-                    "verified": "pair 0 x 4 problems bit-exact vs the oracle"}
+                    "verified": f"all {pairs} pairs x 4 problems, both output buffers, bit-exact vs the oracle"}
+        if cpu_rate and ref is None:
+            rec[tag]["cpu_oracle_all_cores_pairs_per_s"] = pairs / cpu_dt     # (includes packing the inputs: a lower bound)
+            rec[tag]["cpu_cores"] = usable_cpus()
         note(f"  {tag}: {rec[tag]['value']:.0f} pairs/s, scan {scan_ms:.3f} ms")
 
     n_orb, n_lbd, B = args.n_orb, args.n_lbd, args.pairs_per_gpu
     small = max(64, min(512, B))
-    pairs_run("tables_only", n_orb, n_lbd, B, 6, {}, "the main workload without the stereo-gate stage")
+    pairs_run("tables_only", n_orb, n_lbd, B, 6, {}, "the main workload without the stereo-gate stage (one repeated batch)",
+              ref=main_tables)
+    pairs_run("strong_512", n_orb, n_lbd, 512, 12, {}, "the per-GPU shard of BASELINE config 4 (4096 pairs over 8 GPUs = 512 per GPU "
+              "per step), gate stage included: the single-GPU rate at that step size", with_gates=True)
+    pairs_run("c1_substitute", 800, 100, min(B, 4096), 6, {}, "C1 substitute (SURVEY 8d): KITTI-00-shaped descriptor-level replay, "
+              "800 ORB + 100 LBD per image (config_kitti.yaml:62,71), nnr_p 0.75, nnr_l 0.9, mutual; the reference's own "
+              "plslam_dataset run cannot be built in this image", nnr_l=0.9, cpu_rate=True)
     pairs_run("popcount_u32_symmetric", n_orb, n_lbd, small, 4, {"scan_variant": plslam_amd.SCAN_SYMMETRIC},
               "XOR + popcount symmetric scan (K1b/K1b'), no matrix cores")
     pairs_run("popcount_u32_north_star_literal", n_orb, n_lbd, small, 3, {"scan_variant": plslam_amd.SCAN_WAVE_PER_QUERY},
@@ -662,6 +789,14 @@ def secondary_records(ctx, dev, args, note):
                 "profiles/r3_*_lba_* hold the rocprofv3 kernel trace and FETCH_SIZE / WRITE_SIZE passes of the same launches"}
     note(f"  c3: match {1e3 * ms:.1f} us, rows {rec['c3']['lba_point_rows_streaming']['GBps_moved']:.0f} / "
          f"{rec['c3']['lba_line_rows_streaming']['GBps_moved']:.0f} GB/s moved")
+    # ---- the other section-8 rows (plslam_amd/bench_rows.py): each verified over everything it produced -----------------
+    from plslam_amd import bench_rows as R
+    for tag, fn in (("grid", lambda: R.grid(ctx, dev, torch, O, st_)), ("drivers", lambda: R.drivers(ctx, O)),
+                    ("lba_plan_iterate_dev", lambda: R.lba_iterate(ctx, O)), ("lbd", lambda: R.lbd(ctx, dev, torch, O, st_)),
+                    ("median_desc", lambda: R.median_desc(ctx, dev, torch, O, st_))):
+        t0 = time.perf_counter()
+        rec[tag] = fn()
+        note(f"  {tag}: done in {time.perf_counter() - t0:.1f} s")
     return rec
 
 

@@ -51,7 +51,7 @@ class StereoBatchMatcher:
     table of step k is still being gathered (bench.py, N > 1)."""
 
     def __init__(self, ctx, stream_np: dict, nnr_p=0.75, nnr_l=0.75, mutual=True, device=None, n_buffers=1,
-                 geometry: dict | None = None, gates: dict | None = None):
+                 geometry: dict | None = None, gates: dict | None = None, streams=None):
         """geometry (synth.stereo_geometry: kp_l, kp_r, seg_l, seg_r per frame) + gates (the thresholds max_dist_epip,
         min_disp, line_horiz_th, stereo_overlap_th, ls_min_disp_ratio) add the gate stage of StereoFrame to every plan:
         each run then also fills `stereo` (B, n_orb + n_lbd) int32 -- the L<->R associations that survive the epipolar /
@@ -125,11 +125,12 @@ class StereoBatchMatcher:
             self.stereo, self.stereo_disp, self.stereo_counts = self.stereo_tabs[0], self.stereo_disps[0], self.stereo_cnts[0]
         # A real (non-NULL) HIP stream: the C ABI reads a NULL stream as "the context's own stream",
         # and torch's legacy default stream has handle 0.
-        self.stream = torch.cuda.Stream(device=dev)
+        # (`streams`: share another matcher's [scan stream, stage stream]: several batches stepping through one pipeline)
+        self.stream = torch.cuda.Stream(device=dev) if streams is None else streams[0]
         # streams[1] carries the short HBM-bound stages behind a scan in run_overlapped(): high priority, so that they
         # take the workgroup slots the running scan frees instead of queueing behind its backlog
-        self.streams = [self.stream] + [torch.cuda.Stream(device=dev, priority=-1 if i == 0 else 0)
-                                        for i in range(n_buffers - 1)]
+        self.streams = list(streams) if streams is not None else \
+            [self.stream] + [torch.cuda.Stream(device=dev, priority=-1 if i == 0 else 0) for i in range(n_buffers - 1)]
 
     def run_overlapped(self, k: int):
         """Step k of a stream of independent batches into buffer k % n_buffers: every scan on one HIP stream, the
@@ -139,6 +140,11 @@ class StereoBatchMatcher:
         b = k % len(self.plans)
         self.plans[b].run_split(self.streams[0].cuda_stream, self.streams[min(1, len(self.streams) - 1)].cuda_stream)
         return b
+
+    @property
+    def stage_stream(self):
+        """The stream the stages behind a scan run on in run_overlapped() (== the scan stream with one buffer)."""
+        return self.streams[min(1, len(self.streams) - 1)]
 
     def synchronize_all(self):
         for s in self.streams:

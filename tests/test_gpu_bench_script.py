@@ -42,8 +42,19 @@ def test_bench_single_gpu_line():
     assert set(sec) >= {"tables_only", "popcount_u32_symmetric", "popcount_u32_north_star_literal", "c5", "c3"}
     assert all(sec[k]["value"] > 0 for k in ("tables_only", "popcount_u32_symmetric", "popcount_u32_north_star_literal", "c5"))
     assert "4000 ORB + 600 LBD" in sec["c5"]["metric"] and sec["c3"]["match_us"] > 0
-    assert 0 < sec["c3"]["lba_point_rows_streaming"]["frac_of_hbm_peak"] < 1
+    for k in ("lba_point_rows_streaming", "lba_line_rows_streaming"):        # (round 2 printed 1.008 of the HBM peak here)
+        assert 0 < sec["c3"][k]["frac_of_hbm_peak"] < 1 and sec["c3"][k]["bytes_per_row_moved"] < sec["c3"][k]["bytes_per_row_survey_model"]
     assert "valu_roofline" not in d                      # (round 1 printed a "fraction" of 1.86 there)
+    # every section-8 row has a driver-timed record, each verified over everything it produced
+    assert set(sec) >= {"strong_512", "c1_substitute", "grid", "drivers", "lba_plan_iterate_dev", "lbd", "median_desc"}
+    assert sec["c1_substitute"]["value"] > 0 and "800 ORB + 100 LBD" in sec["c1_substitute"]["metric"]
+    assert all("all " in sec[k]["verified"] for k in ("tables_only", "strong_512", "c1_substitute", "c5"))
+    assert sec["grid"]["plan_1024_frame_pairs"]["problems"] == 2048 and len([k for k in sec["drivers"] if k != "workload"]) == 8
+    # the rotation of distinct batches, the step-time distribution and the one-batch comparison
+    assert d["config"]["distinct_batches_in_rotation"] == 3 and d["one_repeated_batch"]["value"] > 0
+    dist_ = d["ms_per_step_distribution"]
+    assert dist_["n"] == 3 and dist_["p10"] <= dist_["median"] <= dist_["p90"]
+    assert "the 2 other batch(es) of the rotation: every pair" in d["verified"]["match_tables"]
 
 
 def test_bench_matrix_core_branch_of_the_line():
@@ -66,3 +77,11 @@ def test_bench_forced_rccl_group_one_rank():
     d = _run(["--no-cpu-baseline", "--force-dist"], env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29611"})
     assert REQUIRED <= set(d) and d["value"] > 0
     assert "RCCL gather" in d["config"]["parallelism"]
+    assert d["config"]["rccl_ranks_seen"] == {"world_size": 1, "distinct_devices": 1}
+
+
+def test_bench_strong_scaling_flag_at_one_rank():
+    """--scaling strong: --pairs-per-gpu is the TOTAL per step, sharded over the ranks (BASELINE config 4); at one rank the
+    shard is the whole batch and the line says so."""
+    d = _run(["--no-cpu-baseline", "--no-secondary", "--scaling", "strong"], pairs=32)
+    assert d["scaling"] == "strong" and d["config"]["pairs_per_gpu_per_step"] == 32 and d["config"]["pairs_per_step_all_gpus"] == 32
