@@ -157,3 +157,46 @@ def test_gloo_world2_root_side_verification(tmp_path):
     mp.spawn(_verify_worker, args=(2, port, out), nprocs=2, join=True)
     bad, ok = eval(open(out).read())
     assert bad == [(1, 2, "orb_pc")] and ok == []
+
+
+# ---- bench.py --scaling strong: ONE batch per step, contiguous shards of total / N pairs (BASELINE config 4) ----------------
+def _strong_worker(rank, world, port, out, total):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = frontend.shard_range(total, world, rank)              # bench.py's rule: first_pair = lo, B = hi - lo
+    B = hi - lo
+    stream = synth.stereo_stream(B, N_ORB, N_LBD, seed=synth.SEED0, first_pair=lo)   # carries the halo: pair lo - 1's left rows
+    tab = torch.from_numpy(_oracle_tables(stream))
+    pipe = frontend.TableGatherPipeline(B, tab.shape[1], max(N_ORB, N_LBD), world, rank, root=0, nbuf=2)
+    for k in range(3):                                             # three steps through two buffers
+        pipe.before_overwrite(k % 2)
+        pipe.submit(k % 2, tab)
+    pipe.finish()
+    if rank == 0:
+        np.save(out, pipe.gathered(0).numpy())
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_strong_scaling_shards(tmp_path):
+    """The strong-scaling partition of bench.py (--scaling strong): 6 pairs over 2 ranks = shards [0, 3) and [3, 6).  Pair 3's
+    prev <-> curr problems need pair 2's LEFT descriptors -- the halo rank 1 regenerates locally -- so the gathered table must
+    equal the unsharded stream's, and bench.py's root-side verification (which regenerates rank r's shard from first_pair =
+    r * B) must accept it."""
+    from oracle import oracle as O
+    total = 6
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "strong.npy")
+    mp.spawn(_strong_worker, args=(2, port, out, total), nprocs=2, join=True)
+    got = np.load(out)
+    full = _oracle_tables(synth.stereo_stream(total, N_ORB, N_LBD, seed=synth.SEED0, first_pair=0))
+    assert got.dtype == np.int32 and np.array_equal(got, full)
+    bad = frontend.verify_gathered_tables(got, 2, total // 2, N_ORB, N_LBD, 0.75, 0.9, [0, 1, 2],
+                                          lambda d1, d2, nnr: O.match(d1, d2, nnr, True)[0])
+    assert bad == []
+    got[3, 5] ^= 1                                                 # the first pair of rank 1's shard (the halo consumer)
+    bad = frontend.verify_gathered_tables(got, 2, total // 2, N_ORB, N_LBD, 0.75, 0.9, [0, 1, 2],
+                                          lambda d1, d2, nnr: O.match(d1, d2, nnr, True)[0])
+    assert [b[:2] for b in bad] == [(1, 0)]
