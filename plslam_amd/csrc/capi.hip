@@ -216,6 +216,10 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     for (int32_t i = 0; i < nprob; ++i)
         if (probs[i].n1 > 0 && probs[i].n2 > 0) mf_row_blocks += (probs[i].n1 + 255) / 256;
     P->col_split = P->col_split && k1f && mf_row_blocks > 0 && !dpair;
+    // AUTO form: K1h for throughput plans; a column-split plan (a few large problems, e.g. C3's one map against one frame) is
+    // latency-bound -- 4-5 tiles per workgroup -- and K1f's lighter per-workgroup prologue / row finish wins there
+    // (measured at C3: 22.4 us per run against 27.4 us)
+    if (ctx->mfma_form == 0 && P->col_split) P->mfma_form = 2;
     auto split_of = [&](const plslam_match_problem& p, int32_t* cstep) -> int32_t {
         *cstep = 0;
         if (!P->col_split || p.n1 <= 0 || p.n2 <= 0) return 1;

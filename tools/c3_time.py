@@ -13,9 +13,11 @@ from plslam_amd import synth
 
 split = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+form = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 ctx = plslam_amd.Context(0)
 ctx.set_option("col_split", split)
 ctx.set_option("scan_variant", variant)
+ctx.set_option("mfma_form", form)
 dev = torch.device("cuda", 0)
 r = np.random.Generator(np.random.PCG64(31))
 frame_p = synth.random_desc(r, 1500)
@@ -45,5 +47,5 @@ for _ in range(20):
     plan.run(st.cuda_stream)
     st.synchronize()
 a, b, n = plan.elapsed()
-print(f"col_split {split} variant {variant}: {1e3 * e0.elapsed_time(e1) / 200:.1f} us per back-to-back run; serial runs: scan "
+print(f"col_split {split} variant {variant} form {form}: {1e3 * e0.elapsed_time(e1) / 200:.1f} us per back-to-back run; serial runs: scan "
       f"{1e3 * a / n:.1f} us, post-scan {1e3 * b / n:.1f} us; info {plan.info()}")
