@@ -196,6 +196,9 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // minima per tile (one LDS store, no cross-lane step on the tile's path); once per 8 tiles a lane combines the four
     // groups of 4 columns and stores 16 bytes (a store per tile would share vmcnt with the raw-row prefetch: see K1f)
     __shared__ __attribute__((aligned(16))) uint32_t colstage[4][MH_CGROUP * 64];
+    // raw b dwords in flight: tile t's 256 dwords (one per lane: its expansion duty) in rawring[t % 3], written by LDS-DMA
+    // (global_load_lds_dword: no VGPR destination) and read back by the lane that asked for them
+    __shared__ __attribute__((aligned(16))) uint32_t rawring[3][256];      // (3 slots: with 4 the workgroup's LDS passes 160 KB / 3)
     uint8_t* const btile = smem;
     u32x2_t* const park = reinterpret_cast<u32x2_t*>(smem + PARK_OFF) + (threadIdx.x >> 6) * (16 * 64) + (threadIdx.x & 63);
 
@@ -276,6 +279,34 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         row = row < last ? row : last;
         return *reinterpret_cast<gcu32_t>(bbytes + (size_t)gbase * 32 + (row * 32u + (uint32_t)ewd4));
     };
+    // The same load for the steady loop as LDS-DMA, issued through inline asm, with the matching wait issued by hand.
+    // Why by hand: the compiler's wait-count pass gives up at the loop's back edge and behind the loop's rare paths (stores
+    // of column results, the ragged group's branches) and inserts s_waitcnt vmcnt(0) once per unrolled iteration -- a wait
+    // for the load it has JUST issued, i.e. a memory latency every four tiles.  Why LDS-DMA: an asm load into a VGPR counts
+    // as written when the statement ends, and the compiler is free to copy that register before the data lands (it did:
+    // a first version with VGPR destinations produced different tables from run to run).  Loads return in order, a tile's
+    // dword is used three steps after its request and two younger requests are then in flight: vmcnt(2) is exact, and
+    // anything else the loop sends to memory in between (a store of column results at most) only makes it stricter.
+    // Every lane reads back the dword its own request wrote: no barrier between the wait and the ds_read.
+    auto load_raw_async = [&](int t, int slot) __attribute__((always_inline)) {
+        const int tc = t < ntiles ? t : ntiles - 1;
+        const int gbase = (tc >> 4) * MH_GROUP_ROWS;
+        const uint32_t s = tc < nfull ? (uint32_t)MH_GROUP : (uint32_t)rag_s;
+        uint32_t row = __umul24((uint32_t)ej, s) + (uint32_t)(tc & 15);
+        const uint32_t last = (uint32_t)(n2 - 1 - gbase);
+        row = row < last ? row : last;
+        const uint32_t voff = row * 32u + (uint32_t)ewd4;
+        const PLSLAM_GLOBAL char* sbase = bbytes + (size_t)gbase * 32;
+        // M0 = the wave's 256 bytes of the slot (the hardware adds lane x 4); M0 is compiler-reserved: saved and restored here
+        const uint32_t lds_dst = (uint32_t)(uintptr_t)(&rawring[slot][64 * w]);
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+    };
+    auto take_raw = [&](int slot) __attribute__((always_inline)) -> uint32_t {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        return rawring[slot][tid];
+    };
     // tile `tn` (the next one) into buffer `buf`; in the ragged group the rows that do not exist get zero codes
     auto expand_store = [&](uint32_t raw, int buf, int tn) __attribute__((always_inline)) {
         uint8_t* dst = btile + buf * MH_TILE_BYTES + ej * MH_ROW_STRIDE + ewd4 * 4;
@@ -288,20 +319,30 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     };
 
     int wt0 = 0, wt1 = ntiles < MH_WINDOW ? ntiles : MH_WINDOW;      // the current window of tiles
-    // raw b dwords in flight: tile t's dword sits in rr[t & 3].  The tile loop is unrolled by four so that the ring index is a
-    // compile-time fact: a ring rotated with register moves makes every step wait for the load it has just issued (the move
-    // reads the newest register: s_waitcnt vmcnt(0) -- K1f's loop did exactly that, a full memory latency per tile)
-    uint32_t rr[4] = {0u, 0u, 0u, 0u};
+    // (The tile loop is unrolled by four so that the ring slot and the b-tile buffer of a step are compile-time facts.  K1f
+    // rotated a three-deep register ring with moves: the move reads the newest register, so every tile waited for the load it
+    // had just issued -- s_waitcnt vmcnt(0), a full memory latency per tile.)
 
     // the 8 tiles that end with tile `tl` are over.  cstage[tile][lane] = that lane's two group minima of column class
     // lane & 31 as (d << 7 | row within the M-tile): M-tile 0 low, M-tile 1 high; lanes l and l + 32 hold the two halves of
     // the rows.  Lane L combines slots 4 L .. 4 L + 3 of the block (tile L >> 3, classes 4 (L & 7) ..): B0 = the best of a
     // column's 4 groups as (d << 7 | row within the wave's 64), B1 = the best of the other three; 16 bytes per lane leave.
-    const uint32_t* const cst_src = cstage + (lane >> 3) * 64 + 4 * (lane & 7);
-    const PLSLAM_GLOBAL char* const part_bytes = (const PLSLAM_GLOBAL char*) part;
+    // the wave's row of the partial table as a SCALAR base (the wave number came from readfirstlane, but a pointer computed
+    // from it is a vector value to the compiler -- and then a spilled one)
+    const uint64_t part_u = (uint64_t)(uintptr_t)part;
+    const uint64_t part_s = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(part_u >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)part_u);
     auto store_columns = [&](int tl) __attribute__((always_inline)) {
         if (!DIRECTED && wave_has_rows && !PLSLAM_MH_X(8)) {
             const int blk = (tl & ~(MH_CGROUP - 1)) * MH_TILE_N;       // first slot of the block (scalar); n2p is a multiple of 256
+            // (addresses recomputed from the lane number: a pointer kept across the tile loop ends up spilled, and its reload's
+            // s_waitcnt vmcnt(0) also waits for the raw-row prefetch)
+            // the lane number from mbcnt, not from threadIdx: two instructions here instead of a value kept (and spilled) across
+            // the tile loop, whose reload would wait on vmcnt(0) -- i.e. on the raw-row prefetch
+            // (asm volatile: the builtin form is loop-invariant, gets hoisted -- and spilled all the same)
+            uint32_t l_;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l_));
+            const uint32_t* const cst_src = colstage[w] + (l_ >> 3) * 64 + 4 * (l_ & 7);
             const i32x4 x = *reinterpret_cast<const i32x4*>(cst_src), y = *reinterpret_cast<const i32x4*>(cst_src + 32);
             i32x4 v;
 #pragma unroll
@@ -314,7 +355,7 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             }
             if (PLSLAM_MH_X(32)) v = x;
             if (blk < n2p) {
-                PLSLAM_GLOBAL i32x4* dst = (PLSLAM_GLOBAL i32x4*)(const_cast<PLSLAM_GLOBAL char*>(part_bytes) + (size_t)blk * 4 + (uint32_t)(16 * lane));
+                PLSLAM_GLOBAL i32x4* dst = (PLSLAM_GLOBAL i32x4*)((PLSLAM_GLOBAL char*)(uintptr_t)(part_s + (uint64_t)blk * 4) + (uint32_t)(16 * l_));
                 if (PLSLAM_NT_STREAMS) __builtin_nontemporal_store(v, dst);
                 else *dst = v;
             }
@@ -415,8 +456,9 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         // read for the last time before this step's barrier) and the prefetch -- independent work that covers the matrix
         // pipe's latency (measured: the 16 packs cost as much time as the 33 bookkeeping ops while they sat right behind it)
         if (!PLSLAM_MH_X(128)) {
-            expand_store(rr[(U + 1) & 3], (U + 1) & 1, t + 1);        // past the last tile: a harmless rewrite of the idle buffer
-            rr[(U + 1) & 3] = load_raw(t + 5);                        // four tiles ahead of its use
+            const int slot = (t + 1 - wt0) % 3;                       // (scalar)
+            expand_store(take_raw(slot), (U + 1) & 1, t + 1);         // past the last tile: a harmless rewrite of the idle buffer
+            load_raw_async(t + 4, slot);                              // three tiles ahead of its use, into the slot just read
         }
         if (with_prev) {
             finish_columns(t - 1, pk_min16(cm, cm1));
@@ -564,10 +606,9 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) park[r * 64] = u32x2_t{0xFFFFFFFFu, 0xFFFFFFFFu};   // wave-private: no barrier needed
         expand_store(load_raw(wt0), 0, wt0);       // wt0 is a multiple of 128: buffer parity restarts at 0
-        rr[1] = load_raw(wt0 + 1);
-        rr[2] = load_raw(wt0 + 2);
-        rr[3] = load_raw(wt0 + 3);
-        rr[0] = load_raw(wt0 + 4);
+        load_raw_async(wt0 + 1, 1);
+        load_raw_async(wt0 + 2, 2);
+        load_raw_async(wt0 + 3, 0);
         if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
         __syncthreads();                           // every wave is past its last operand read of the b tile
         if (!PLSLAM_MH_X(1024)) finish_rows();
