@@ -319,6 +319,7 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     };
 
     int wt0 = 0, wt1 = ntiles < MH_WINDOW ? ntiles : MH_WINDOW;      // the current window of tiles
+    int ring_slot = 1;                                               // rawring slot of the NEXT tile
     // (The tile loop is unrolled by four so that the ring slot and the b-tile buffer of a step are compile-time facts.  K1f
     // rotated a three-deep register ring with moves: the move reads the newest register, so every tile waited for the load it
     // had just issued -- s_waitcnt vmcnt(0), a full memory latency per tile.)
@@ -414,6 +415,10 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         i32x4 bfr[MH_KSTEPS];
         bfr[0] = read_b(0);
         bfr[1] = read_b(1);
+        // the next tile's raw dword (requested three steps ago) leaves the ring now, with the operand reads: its LDS latency is
+        // long over when the expansion behind the MFMAs needs it
+        uint32_t raw_next = 0u;
+        if (!PLSLAM_MH_X(128)) raw_next = take_raw(ring_slot);
         // ragged group: lanes whose class has run out of columns take the penalty from this tile on (at most two tiles of a
         // scan change anything: the group's first -- classes without any column -- and the one where the cut class ends)
         if (t >= nfull && ((t & 15) == 0 || (t & 15) == lim_part)) {
@@ -456,9 +461,9 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         // read for the last time before this step's barrier) and the prefetch -- independent work that covers the matrix
         // pipe's latency (measured: the 16 packs cost as much time as the 33 bookkeeping ops while they sat right behind it)
         if (!PLSLAM_MH_X(128)) {
-            const int slot = (t + 1 - wt0) % 3;                       // (scalar)
-            expand_store(take_raw(slot), (U + 1) & 1, t + 1);         // past the last tile: a harmless rewrite of the idle buffer
-            load_raw_async(t + 4, slot);                              // three tiles ahead of its use, into the slot just read
+            expand_store(raw_next, (U + 1) & 1, t + 1);               // past the last tile: a harmless rewrite of the idle buffer
+            load_raw_async(t + 4, ring_slot);                         // three tiles ahead of its use, into the slot just read
+            ring_slot = ring_slot == 2 ? 0 : ring_slot + 1;           // (scalar)
         }
         if (with_prev) {
             finish_columns(t - 1, pk_min16(cm, cm1));
@@ -609,6 +614,7 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         load_raw_async(wt0 + 1, 1);
         load_raw_async(wt0 + 2, 2);
         load_raw_async(wt0 + 3, 0);
+        ring_slot = 1;                             // the slot of tile wt0 + 1
         if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
         __syncthreads();                           // every wave is past its last operand read of the b tile
         if (!PLSLAM_MH_X(1024)) finish_rows();
