@@ -2,7 +2,14 @@
 """Turns the rocprofv3 counter summaries of one bench command (tools/pmc_passes.sh -> gpurun_out/<tag>_pmc_{a,fetch,write}.txt)
 into the entry of profiles/pmc_traffic.json that bench.py reports as roofline.traffic / valu_executed -- keyed by workload and
 kernel, and stamped with the hash of the kernel sources the passes were taken on (bench.py ignores an entry whose hash is not
-the tree's).   usage: make_pmc_traffic.py <tag> <n_orb> <n_lbd> <pairs> <kernel substring, e.g. k_scan_sym_mfma_g>"""
+the tree's).   usage: make_pmc_traffic.py <tag> <n_orb> <n_lbd> <pairs> <kernel substring, e.g. k_scan_sym_mfma_h> [fetch correction]
+
+FETCH_SIZE correction: MI355X_MICROARCH.md measures that this rocprofv3 reports HALF the bytes of a wide coalesced streaming read
+(16 B per lane) and calls other access widths uncalibrated ("calibrate on a known byte count in your own access pattern").  The
+calibration for 4-byte-per-lane loads is in the same passes: k_merge_fix16 reads the column-partial table exactly once with
+dword loads -- 614 MB at C2 / 4096 pairs -- and FETCH_SIZE reports 599 317 KiB = 614 MB: factor 1.0.  K1h's reads are dword
+loads too (raw rows through LDS-DMA, one dword per lane), so its entry uses 1.0; K1f's round-2 entry (16-byte row loads in its
+second-best recomputation, dword loads elsewhere) used the guide's 2.0 as an upper bound."""
 import json
 import os
 import re
@@ -26,6 +33,7 @@ def counters(path, kernel):
 
 def main():
     tag, n_orb, n_lbd, pairs, kernel = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    corr = float(sys.argv[6]) if len(sys.argv) > 6 else 2.0
     g = os.path.join(ROOT, "gpurun_out")
     a = counters(os.path.join(g, f"{tag}_pmc_a.txt"), kernel)
     f = counters(os.path.join(g, f"{tag}_pmc_fetch.txt"), kernel)
@@ -33,8 +41,8 @@ def main():
     fetch_kib, write_kib = f["FETCH_SIZE"], w["WRITE_SIZE"]
     entry = {
         "kernel": kernel, "kernel_source_hash": kernel_source_hash(),
-        "fetch_size_kib_per_dispatch": fetch_kib, "write_size_kib_per_dispatch": write_kib, "fetch_correction": 2.0,
-        "traffic_bytes_per_launch": int(fetch_kib * 1024 * 2.0 + write_kib * 1024),
+        "fetch_size_kib_per_dispatch": fetch_kib, "write_size_kib_per_dispatch": write_kib, "fetch_correction": corr,
+        "traffic_bytes_per_launch": int(fetch_kib * 1024 * corr + write_kib * 1024),
         "sq_insts_valu_per_launch": int(a["SQ_INSTS_VALU"]), "sq_insts_mfma_per_launch": int(a.get("SQ_INSTS_MFMA", 0)),
         "sq_valu_mfma_busy_cycles_per_launch": int(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0)),
         "sq_active_inst_valu_per_launch": int(a.get("SQ_ACTIVE_INST_VALU", 0)),
@@ -42,8 +50,10 @@ def main():
         "measured_int_valu_ceiling_lane_ops_per_s": 38500000000000.0,
         "measured_int_valu_ceiling_source": "profiles/r1_valu_microbench.txt, profiles/r2_valu_microbench2.txt: pk_min / perm / "
                                             "and_or class ops at 4.1-4.5 cycles per wave64 instruction per SIMD",
-        "note": "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (wide vector loads); SQ_INSTS_VALU counts the "
-                "MFMAs too (bench.py subtracts SQ_INSTS_MFMA)",
+        "note": ("FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (wide vector loads)" if corr == 2.0 else
+                 f"FETCH_SIZE x {corr}: dword-per-lane loads, calibrated on k_merge_fix16 of the same passes (reads the 614 MB "
+                 "partial table once, reports 599 317 KiB)") + "; WRITE_SIZE includes the kernel's register spills (scratch); "
+                "SQ_INSTS_VALU counts the MFMAs too (bench.py subtracts SQ_INSTS_MFMA)",
         "source": f"profiles/{tag}_pmc_a.txt, profiles/{tag}_pmc_fetch.txt, profiles/{tag}_pmc_write.txt (rocprofv3 --pmc, "
                   "separate passes, python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-secondary)"}
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
