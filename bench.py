@@ -736,7 +736,8 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
     cam = plslam_amd.make_cam(**synth.EUROC)
     g = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in lm.items()}
     npt, nls = lm["pt_lm"].shape[0], lm["ls_lm"].shape[0]
-    reps = 64                                   # many maps in one launch: the row kernels' streaming rate
+    reps = 256                                  # many maps in one launch: the row kernels' streaming rate (64 maps = an 18 us
+                                                # line-row kernel: the python launch loop, not the kernel, was being timed)
 
     n_pt_lm, n_ls_lm = int(lm["Xw"].shape[0]), int(lm["Lw"].shape[0])
 
@@ -783,7 +784,7 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
         "lba_rows_pass_us": 1e3 * (ms_p1 + ms_l1), "lba_rows_pass_bytes": npt * 152 + nls * 208,
         "lba_point_rows_streaming": stream_rec(npt * reps, ms_pb, moved_pt, 152),
         "lba_line_rows_streaming": stream_rec(nls * reps, ms_lb, moved_ls, 208),
-        "note": "one map = one launch of 9.7 MB: launch-bound (replicas only, SURVEY 8e); the streaming figures batch 64 maps "
+        "note": "one map = one launch of 9.7 MB: launch-bound (replicas only, SURVEY 8e); the streaming figures batch 256 maps "
                 "(each with its own landmark array) per launch to show the row kernels' HBM rate; frac_of_hbm_peak is computed "
                 "from the bytes the kernels move (indices 8 B, not the reference's 24-byte Vector6i; landmarks once), "
                 "profiles/r3_*_lba_* hold the rocprofv3 kernel trace and FETCH_SIZE / WRITE_SIZE passes of the same launches"}
