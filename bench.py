@@ -790,8 +790,8 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
                 "profiles/r3_*_lba_* hold the rocprofv3 kernel trace and FETCH_SIZE / WRITE_SIZE passes of the same launches"}
     note(f"  c3: match {1e3 * ms:.1f} us, rows {rec['c3']['lba_point_rows_streaming']['GBps_moved']:.0f} / "
          f"{rec['c3']['lba_line_rows_streaming']['GBps_moved']:.0f} GB/s moved")
-    # ---- the other section-8 rows (plslam_amd/bench_rows.py): each verified over everything it produced -----------------
-    from plslam_amd import bench_rows as R
+    # ---- the other section-8 rows (bench_rows.py): each verified over everything it produced -----------------
+    import bench_rows as R
     for tag, fn in (("grid", lambda: R.grid(ctx, dev, torch, O, st_)), ("drivers", lambda: R.drivers(ctx, O)),
                     ("lba_plan_iterate_dev", lambda: R.lba_iterate(ctx, O)), ("lbd", lambda: R.lbd(ctx, dev, torch, O, st_)),
                     ("median_desc", lambda: R.median_desc(ctx, dev, torch, O, st_))):
