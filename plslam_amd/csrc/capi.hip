@@ -242,7 +242,11 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         P->merge_parts = (max_nwb >= 64 && cols * 16 <= lanes) ? 16 : (max_nwb >= 32 && cols * 4 <= lanes) ? 4 : 1;
     }
     const int mcols = merge_partials16_cols(P->merge_parts);
-    auto part_units = [&](int32_t n1, int32_t n2) -> int64_t {          // K1f: units of two words
+    // column partials in units of two words.  K1f: one word per (64-row block, column slot), rows padded to 256 slots; K1h:
+    // one word per (256-row block, column slot) -- two with exact key tables
+    const bool h_parts = P->sym_mfma && mfma_form_is_h(P->mfma_form) && !P->fused;
+    auto part_units = [&](int32_t n1, int32_t n2) -> int64_t {
+        if (h_parts) return (int64_t)((n1 + 255) / 256) * ((n2 + 255) / 256) * (P->exact_second ? 256 : 128);
         return (int64_t)((n1 + 63) / 64) * ((n2 + 255) / 256) * 128;
     };
     int64_t rows = 0, part_rows = 0, tmp_rows = 0;

@@ -1,8 +1,10 @@
 // hamming_mfma_h.hip -- K1h: the matrix-core symmetric Hamming kNN-2 scan with MINIMUM-ONLY bookkeeping in BOTH
 // directions (gfx950).  Round 3; the default.
 //
-// Contract, work decomposition, block tables, partial table: those of K1f (hamming_mfma_g.hip) -- keys12[i] = best-2 over j,
-// part21[64-row block of a][column slot] = (best | second << 16) as 16-bit keys, keys = (distance << 23) | index =
+// Contract, work decomposition, block tables: those of K1f (hamming_mfma_g.hip) -- keys12[i] = best-2 over j; the column
+// partials are per WORKGROUP (256 rows of a; K1f: per wave): part21[256-row block of a][column slot] = one word
+// (d0 << 17 | row0 << 9 | d1): the block's best row and the distance of its best row outside that row's group of 16 (two words
+// (d << 8 | row) when exact key tables are asked for); keys = (distance << 23) | index =
 // cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) order in both directions (reference call sites src/mapHandler.cpp:277,424,597,
 // 712,3223,3249).  The distances come out of the same four v_mfma_scale_f32_32x32x64_f8f6f4 per 32 x 32 tile (fp4 codes of
 // +-1, accumulator = 2^23 + 128 d + tag, exact).
@@ -12,13 +14,18 @@
 //
 //  1. Column direction = "minimum now, second best later" too.  A lane's 16 accumulator registers of an M-tile are a GROUP of
 //     16 rows of a; per tile one packed min chain over the registers gives the group minima (16 v_pk_min_u16 instead of 48),
-//     a wave's 4 groups per column (2 M-tiles x 2 lane halves) give B0 = the best and B1 = the best OUTSIDE B0's group, and
-//     that pair is the column partial.  The merge kernel (k_merge_fix16) combines the 64-row blocks the same way -- K0 = best
+//     the workgroup's 16 groups per column (4 waves x 2 M-tiles x 2 lane halves, combined through LDS once per 4 tiles) give
+//     B0 = the best and B1 = the best OUTSIDE B0's group, and that pair is the column partial (a quarter of K1f's partial
+//     table: the table is written once and read once, 1.24 GB each way at C2 / 4096 pairs before).  The merge kernel
+//     (k_merge_fix16) combines the 256-row blocks the same way -- K0 = best
 //     key, K1 = best key outside K0's 16-row group -- and then recomputes the 15 other members of K0's group with XOR +
 //     popcount from the raw rows: second best = min(K1, best of those).  Exact, tie order included.
 //  2. WHICH row of a sits in (M-tile, MFMA row) is free, so a lane's 16 registers hold 16 CONSECUTIVE rows of a
-//     (local row = 16 (2 mt + g) + r): the recomputation reads 512 contiguous bytes, and the register number IS the row
-//     within the group -- the tag rides in the accumulator seed as a per-register CONSTANT (no per-tile seed updates).
+//     (row within the workgroup's 256 = 128 mt + 32 wave + 16 g + r): the recomputation reads 512 contiguous bytes, and the
+//     register number IS the row within the group -- the tag (32 wave + 16 g + r: the row within the M-tile's half of the
+//     block) rides in the accumulator seed as a per-register CONSTANT (no per-tile seed updates).  M-tile 1 = the block's
+//     upper 128 rows: the 16-bit keys of ONE half of a packed register order like (d, row) across all four waves, which is
+//     what lets the workgroup's column minima be combined with packed instructions (combine_columns).
 //  3. WHICH row of b sits in (tile, lane) is free too: inside a group of 16 tiles the mapping is class-major,
 //     j = 512 G + S class + tile-in-group (S = 16; in the ragged last group S = ceil(rest / 32) and the group has S tiles), so
 //     the row direction's second-best recomputation -- all members of the winner's (group, class) -- reads S consecutive
@@ -53,6 +60,7 @@ typedef const PLSLAM_GLOBAL uint32_t* gcu32_t;
 typedef const PLSLAM_GLOBAL u32x4_t* gcu32x4_t;
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef PLSLAM_GLOBAL u32x2_t* gu2_t;
+typedef const PLSLAM_GLOBAL u32x2_t* gu2c_t;
 typedef PLSLAM_GLOBAL uint32_t* gu32_t;
 
 namespace {
@@ -177,8 +185,9 @@ struct MhLayout {
     }
 };
 int mh_slot_of_column(int n2, int j) { return MhLayout(n2).slot_of(j); }     // for tests / tools (plslam_match_plan_dump readers)
-// local row (within a wave's 64 rows of a) held by M-tile mt, MFMA row m: 16 (2 mt + g) + r with m = (r & 3) + 8 (r >> 2) + 4 g
-__host__ __device__ inline int mh_local_row(int mt, int m) { return 16 * (2 * mt + ((m >> 2) & 1)) + (m & 3) + 4 * (m >> 3); }
+// row within the workgroup's 256 rows of a held by wave w, M-tile mt, MFMA row m: 128 mt + 32 w + 16 g + r with
+// m = (r & 3) + 8 (r >> 2) + 4 g
+__host__ __device__ inline int mh_block_row(int w, int mt, int m) { return 128 * mt + 32 * w + 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3); }
 
 // DIRECTED = true: only keys12 (row direction) is produced.
 template <bool DIRECTED>
@@ -192,10 +201,10 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     constexpr int SMEM_BYTES = PARK_OFF + 4 * 16 * 64 * 8;
     static_assert(SMEM_BYTES >= 4 * 64 * ROWX_STRIDE * 4, "the transpose must fit");
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
-    // column minima of the current 8 tiles, per wave [tile in block][lane] (2 KB per wave): every lane parks its two group
-    // minima per tile (one LDS store, no cross-lane step on the tile's path); once per 8 tiles a lane combines the four
-    // groups of 4 columns and stores 16 bytes (a store per tile would share vmcnt with the raw-row prefetch: see K1f)
-    __shared__ __attribute__((aligned(16))) uint32_t colstage[4][MH_CGROUP * 64];
+    // column minima of the last 8 tiles, [tile & 7][wave][lane] (1 KB per tile): every lane parks its two group minima per
+    // tile (one LDS store, no cross-lane step on the tile's path).  Once per 8 tiles the workgroup combines them, a lane
+    // per column: the 4 waves' 2 x 2 group minima of it become ONE word for the workgroup's 256 rows (combine_columns)
+    __shared__ __attribute__((aligned(16))) uint32_t colstage[MH_CGROUP * 256];
     // raw b dwords in flight: tile t's 256 dwords (one per lane: its expansion duty) in rawring[t % 3], written by LDS-DMA
     // (global_load_lds_dword: no VGPR destination) and read back by the lane that asked for them
     __shared__ __attribute__((aligned(16))) uint32_t rawring[3][256];      // (3 slots: with 4 the workgroup's LDS passes 160 KB / 3)
@@ -217,14 +226,14 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 31, g = lane >> 5;
     const gcu32_t araw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.a);
-    const int iw = bd.row0 + 64 * w;               // first of this wave's 64 rows of a
+    const int iw = bd.row0 + 32 * w;               // first of this wave's 32 rows of M-tile 0; M-tile 1: + 128
 
-    // ---- A operands: MFMA row c of M-tile mt = local row mh_local_row(mt, c); raw dword 2 ks + g of each, as fp4 codes of
+    // ---- A operands: MFMA row c of M-tile mt = block row mh_block_row(w, mt, c); raw dword 2 ks + g of each, as fp4 codes of
     // -s(a); the factor 64 is the block scale.  Rows past n1 are clamped duplicates (masked / dropped below) ----
     i32x4 afrag[2][MH_KSTEPS];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int row = iw + mh_local_row(mt, c);
+        const int row = bd.row0 + mh_block_row(w, mt, c);
         const int rrow = row < n1 ? row : n1 - 1;
         const gcu32_t p = araw + (size_t)rrow * 8 + g;
 #pragma unroll
@@ -233,18 +242,18 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     const int scale_a = SCALE_A, scale_b = SCALE_B;
 
     // row-direction state per accumulator register r (M-tile 0 in the low halves, M-tile 1 in the high halves):
-    //   gm[r]    running minimum of the 16-bit keys (d << 7 | 16 g + r) of the current group of 16 tiles, column class c
+    //   gm[r]    running minimum of the 16-bit keys (d << 7 | 32 w + 16 g + r) of the current group of 16 tiles, column class c
     //   park[r]  (LDS) the best two GROUP minima (d << 7 | group in window << 5 | 16 g + r) of the lane's column class
     uint32_t gm[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) gm[r] = 0xFFFFFFFFu;
 
-    // accumulator start: 2^23 + 16384 + 16 g + r (the row within its M-tile's 32 rows: constant per register and lane) [+ the
+    // accumulator start: 2^23 + 16384 + 32 w + 16 g + r (the row within its M-tile's half of the block: constant per register and lane) [+ the
     // penalty of a lane whose column does not exist].  In VECTOR registers on purpose (asm volatile: opaque to the compiler, which would keep
     // wave-uniform values in SGPRs and copy them into both accumulators every tile)
     u32x16 seed;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) seed[r] = ACC_BITS + (uint32_t)(16 * g + r);   // tag = the row within its M-tile's 32
+    for (int r = 0; r < 16; ++r) seed[r] = ACC_BITS + (uint32_t)(32 * w + 16 * g + r);   // tag = the row within its M-tile's 128
     asm volatile("" : "+v"(seed));
     // ragged group: this lane's class has `lim` tiles with a column (0 .. rag_s); from tile-in-group == lim on it has none
     const int rest = n2 - (nfull >> 4) * MH_GROUP_ROWS;
@@ -255,14 +264,15 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     };
     const int lim_part = rag_s ? rest % rag_s : 0;                 // the one class that is cut (wave-uniform): its lim, 0 = none is
 
-    const bool rows_ragged = iw + 64 > n1;         // wave-uniform: some of this wave's rows do not exist
-    // rows of this lane's two groups that exist: register r of M-tile mt holds local row 16 (2 mt + g) + r
+    const bool rows_ragged = iw + 128 + 32 > n1;   // wave-uniform: some of this wave's rows do not exist
+    // rows of this lane's two groups that exist: register r of M-tile mt holds row iw + 128 mt + 16 g + r
 #define PLSLAM_MH_NV_LO (n1 - iw - 16 * (int)((threadIdx.x >> 5) & 1u))
-    const gu32_t part = DIRECTED ? (gu32_t) nullptr : (gu32_t) sd.part21 + (size_t)(iw >> 6) * n2p;
-    const bool wave_has_rows = iw < n1;
-    uint32_t* const cstage = colstage[w];
+    // the workgroup's row of the partial table: n2p words (exact key tables: pairs of words)
+    const bool wide_part = !DIRECTED && (sd.flags & 1);
+    const gu32_t part = DIRECTED ? (gu32_t) nullptr : (gu32_t) sd.part21 + (size_t)(bd.row0 >> 8) * n2p * (wide_part ? 2 : 1);
+    uint32_t* const cstage = colstage + 64 * w;        // + 256 (tile & 7) + lane
 #pragma unroll
-    for (int k = 0; k < 2; ++k) *reinterpret_cast<i32x4*>(cstage + 256 * k + 4 * lane) = i32x4{-1, -1, -1, -1};   // wave-private
+    for (int k = 0; k < 2; ++k) *reinterpret_cast<i32x4*>(colstage + 8 * tid + 4 * k) = i32x4{-1, -1, -1, -1};   // (two barriers before the first use)
 
     // expansion duty of this lane: the b row of class (tid >> 3) of the tile, dword (tid & 7) of it.  Byte offset of that
     // dword = [group, tile in group: scalar] + [class x stride: per lane, one value for full groups, one for the ragged one]
@@ -324,63 +334,81 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // rotated a three-deep register ring with moves: the move reads the newest register, so every tile waited for the load it
     // had just issued -- s_waitcnt vmcnt(0), a full memory latency per tile.)
 
-    // the 8 tiles that end with tile `tl` are over.  cstage[tile][lane] = that lane's two group minima of column class
-    // lane & 31 as (d << 7 | row within the M-tile): M-tile 0 low, M-tile 1 high; lanes l and l + 32 hold the two halves of
-    // the rows.  Lane L combines slots 4 L .. 4 L + 3 of the block (tile L >> 3, classes 4 (L & 7) ..): B0 = the best of a
-    // column's 4 groups as (d << 7 | row within the wave's 64), B1 = the best of the other three; 16 bytes per lane leave.
-    // the wave's row of the partial table as a SCALAR base (the wave number came from readfirstlane, but a pointer computed
-    // from it is a vector value to the compiler -- and then a spilled one)
+    // Block kb of 8 tiles (column slots 256 kb .. 256 kb + 255) is complete in colstage: every wave's stores of it are behind a
+    // workgroup barrier.  A lane per column: the 16 group minima of the column -- 4 waves x 2 lane halves, M-tile 0 in the low
+    // and M-tile 1 in the high halves of the words -- are 8 words whose halves order like (d, row) among themselves (the tag
+    // is the row within the M-tile's 128), so the best two per half come out of a PACKED network (20 instructions for
+    // both halves); widened to (d << 8 | row within the workgroup's 256), the best two of those four: K0 = the best row, K1
+    // = the best row outside K0's group of 16 (every key IS a group minimum).  One word leaves per column: K0 << 9 | K1's
+    // distance; with exact key tables asked for (SymDesc::flags) the pair (K0, K1).  The caller's barrier behind it lets the
+    // slots be rewritten.
+    // (the workgroup's row of the partial table as a SCALAR base: a pointer computed from readfirstlane values is a vector
+    // value to the compiler -- and then a spilled one)
     const uint64_t part_u = (uint64_t)(uintptr_t)part;
     const uint64_t part_s = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(part_u >> 32)) << 32) |
                             (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)part_u);
-    auto store_columns = [&](int tl) __attribute__((always_inline)) {
-        if (!DIRECTED && wave_has_rows && !PLSLAM_MH_X(8)) {
-            const int blk = (tl & ~(MH_CGROUP - 1)) * MH_TILE_N;       // first slot of the block (scalar); n2p is a multiple of 256
-            // (addresses recomputed from the lane number: a pointer kept across the tile loop ends up spilled, and its reload's
-            // s_waitcnt vmcnt(0) also waits for the raw-row prefetch)
-            // the lane number from mbcnt, not from threadIdx: two instructions here instead of a value kept (and spilled) across
-            // the tile loop, whose reload would wait on vmcnt(0) -- i.e. on the raw-row prefetch
-            // (asm volatile: the builtin form is loop-invariant, gets hoisted -- and spilled all the same)
-            uint32_t l_;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l_));
-            const uint32_t* const cst_src = colstage[w] + (l_ >> 3) * 64 + 4 * (l_ & 7);
-            const i32x4 x = *reinterpret_cast<const i32x4*>(cst_src), y = *reinterpret_cast<const i32x4*>(cst_src + 32);
-            i32x4 v;
+    auto combine_columns = [&](int kb) __attribute__((always_inline)) {
+        if (DIRECTED || PLSLAM_MH_X(8)) return;
+        // (the lane number from mbcnt, not from threadIdx: two instructions here instead of a value kept -- and spilled --
+        // across the tile loop, whose reload would wait on vmcnt(0), i.e. on the raw-row prefetch; asm volatile: the
+        // builtin form is loop-invariant, gets hoisted -- and spilled all the same)
+        uint32_t l_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l_));
+        // column slot 64 w + l_ of the block: tile 2 w + (l_ >> 5), class l_ & 31
+        const uint32_t* const src = colstage + 512 * w + (((l_ & 32u) << 3) | (l_ & 31u));
+        uint32_t p[8];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t xq = pk_add16_sat((uint32_t)x[q], 0x00200000u), yq = pk_add16_sat((uint32_t)y[q], 0x00200000u);   // M-tile 1: rows + 32
-                const uint32_t a = pk_min16(xq, yq), b = pk_max16(xq, yq);
-                const uint32_t m0 = umin_(a & 0xFFFFu, a >> 16);
-                const uint32_t m1 = umin_(umax_(a & 0xFFFFu, a >> 16), umin_(b & 0xFFFFu, b >> 16));
-                v[q] = (int)(m0 | (m1 << 16));
-            }
-            if (PLSLAM_MH_X(32)) v = x;
-            if (blk < n2p) {
-                PLSLAM_GLOBAL i32x4* dst = (PLSLAM_GLOBAL i32x4*)((PLSLAM_GLOBAL char*)(uintptr_t)(part_s + (uint64_t)blk * 4) + (uint32_t)(16 * l_));
-                if (PLSLAM_NT_STREAMS) __builtin_nontemporal_store(v, dst);
-                else *dst = v;
-            }
-            // (slots of tiles of a last, partial block that never ran hold the block before's values: never read, and a function
-            // of the inputs like everything else in the table)
+        for (int v = 0; v < 4; ++v) { p[2 * v] = src[64 * v]; p[2 * v + 1] = src[64 * v + 32]; }
+        // best two of 8, both halves at once: 4 sorted pairs, then 3 merges of sorted pairs
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lo[q] = pk_min16(p[2 * q], p[2 * q + 1]); hi[q] = pk_max16(p[2 * q], p[2 * q + 1]); }
+        auto pk_merge = [](uint32_t& a0, uint32_t& a1, uint32_t c0, uint32_t c1) {
+            const uint32_t m = pk_max16(a0, c0);
+            a0 = pk_min16(a0, c0);
+            a1 = pk_min16(m, pk_min16(a1, c1));
+        };
+        pk_merge(lo[0], hi[0], lo[1], hi[1]);
+        pk_merge(lo[2], hi[2], lo[3], hi[3]);
+        pk_merge(lo[0], hi[0], lo[2], hi[2]);
+        // (d << 7 | t) + (d << 7) [+ 128: M-tile 1] = (d << 8 | row in the block); "none" 0xFFFF -> 0x1FF7F / 0x1FFFF: d = 511
+        const uint32_t e0 = lo[0] & 0xFFFFu, e1 = hi[0] & 0xFFFFu, f0 = lo[0] >> 16, f1 = hi[0] >> 16;
+        uint32_t k0 = e0 + (e0 & 0xFF80u), k1 = e1 + (e1 & 0xFF80u);
+        merge2(k0, k1, f0 + (f0 & 0xFF80u) + 128u, f1 + (f1 & 0xFF80u) + 128u);
+        if (PLSLAM_MH_X(32)) k0 = p[0];
+        const uint32_t slot4 = (uint32_t)(256 * kb + 64 * w) * 4u;                             // (scalar) n2p is a multiple of 256
+        if (!wide_part) {
+            const uint32_t e = (k0 << 9) | (k1 >> 8);
+            PLSLAM_GLOBAL uint32_t* dst = (PLSLAM_GLOBAL uint32_t*)((PLSLAM_GLOBAL char*)(uintptr_t)(part_s + slot4) + 4u * l_);
+            if (PLSLAM_NT_STREAMS) __builtin_nontemporal_store(e, dst);
+            else *dst = e;
+        } else {
+            const u32x2_t e = {k0, k1};
+            PLSLAM_GLOBAL u32x2_t* dst = (PLSLAM_GLOBAL u32x2_t*)((PLSLAM_GLOBAL char*)(uintptr_t)(part_s + 2u * slot4) + 8u * l_);
+            if (PLSLAM_NT_STREAMS) __builtin_nontemporal_store(e, dst);
+            else *dst = e;
         }
+        // (slots of tiles of a last, partial block that never ran hold older values: never read, and a function of the
+        // inputs like everything else in the table)
     };
     // a row group is over: its minima get the group number and go into the parked sorted pairs; the minima restart
     auto push_groups = [&](int t) __attribute__((always_inline)) {
         if (PLSLAM_MH_X(64)) return;
-        const uint32_t gtag = (uint32_t)(((t - wt0) >> 4) << 5) * 0x00010001u;
+        // the tag's wave bits become the group number (an XOR: "none" stays above every key, whatever its low bits)
+        const uint32_t gtag = (uint32_t)(((((t - wt0) >> 4) ^ w) & 3) << 5) * 0x00010001u;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const u32x2_t v = park[r * 64];
             uint32_t b0 = v.x, b1 = v.y;
-            pk_push2(b0, b1, pk_add16_sat(gm[r], gtag));
+            pk_push2(b0, b1, gm[r] ^ gtag);
             park[r * 64] = u32x2_t{b0, b1};
             gm[r] = 0xFFFFFFFFu;
         }
     };
-    // column minima of a finished tile: parked as they are (the seeds made the tags), combined in store_columns
+    // column minima of a finished tile: parked as they are (the seeds made the tags), combined in combine_columns
     auto finish_columns = [&](int t, uint32_t cm) __attribute__((always_inline)) {
         if (DIRECTED || PLSLAM_MH_X(32)) { asm volatile("" ::"v"(cm)); return; }
-        cstage[(t & (MH_CGROUP - 1)) * 64 + lane] = cm;
+        cstage[(t & (MH_CGROUP - 1)) * 256 + lane] = cm;
     };
 
     // Bookkeeping of one packed key pair kc[R] (rows r of the lane's two groups, column class c): ONE packed min into the
@@ -393,7 +421,7 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         uint32_t kcv = kc[R];                                                                      \
         gm[R] = pk_min16(gm[R], kcv);                                                              \
         if (!DIRECTED) {                                                                           \
-            if (MASKED) kcv |= ((R) < PLSLAM_MH_NV_LO ? 0u : 0x0000FFFFu) | ((R) < PLSLAM_MH_NV_LO - 32 ? 0u : 0xFFFF0000u); \
+            if (MASKED) kcv |= ((R) < PLSLAM_MH_NV_LO ? 0u : 0x0000FFFFu) | ((R) < PLSLAM_MH_NV_LO - 128 ? 0u : 0xFFFF0000u); \
             if ((R) & 1) cm1 = pk_min16(cm1, kcv); else cm = pk_min16(cm, kcv);                    \
         }                                                                                          \
     }
@@ -466,9 +494,15 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             ring_slot = ring_slot == 2 ? 0 : ring_slot + 1;           // (scalar)
         }
         if (with_prev) {
+            // block (t - 9) / 8 of column results: its last tile was parked in the step before this one, by every wave before
+            // this step's barrier; tile t - 1 is about to take the block's first slot: a second barrier (workgroup-uniform
+            // branch).  (The blocks of the window before were finished behind its loop.)
+            if (!DIRECTED && U == 1 && ((t - 1) & (MH_CGROUP - 1)) == 0 && t - 9 >= wt0) {
+                combine_columns((t - 9) >> 3);
+                if (!PLSLAM_MH_X(1)) __syncthreads();
+            }
             finish_columns(t - 1, pk_min16(cm, cm1));
-            // wave-uniform: tile t-1 closed a block of 8 tiles / a row group
-            if (U == 0 && ((t - 1) & (MH_CGROUP - 1)) == MH_CGROUP - 1) store_columns(t - 1);
+            // wave-uniform: tile t-1 closed a row group
             if (U == 0 && ((t - 1) & (MH_GROUP - 1)) == MH_GROUP - 1) push_groups(t - 1);
         }
         // P(t): the key pairs of tile t; the accumulators are dead from here on
@@ -500,9 +534,15 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             if (tb + 2 < wt1) tile_step(tb + 2, std::integral_constant<int, 2>{}, true, masked_tag);
             if (tb + 3 < wt1) tile_step(tb + 3, std::integral_constant<int, 3>{}, true, masked_tag);
         }
+        // the window's last tile opens a block of columns while the block before it still waits in the slots (the step that
+        // would have combined it does not exist): combine it now
+        if (!DIRECTED && ((wt1 - 1) & (MH_CGROUP - 1)) == 0 && wt1 - 9 >= wt0) {
+            __syncthreads();
+            combine_columns((wt1 - 9) >> 3);
+            __syncthreads();
+        }
         epilogue(wt1 - 1, masked_tag);
-        store_columns(wt1 - 1);                    // the (possibly partial) last block of columns
-        push_groups(wt1 - 1);                      // ... and row group
+        push_groups(wt1 - 1);                      // the (possibly partial) last row group
     };
 #undef PLSLAM_MH_EPI_ROW
 
@@ -535,7 +575,7 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             const uint32_t e = mine[cls];
             merge2(k0, k1, (e << 16) | (uint32_t)cls, (e & 0xFFFF0000u) | (uint32_t)cls);
         }
-        const int row = iw + lane;
+        const int row = iw + lane + (lane & 32) * 3;          // lanes 32..63: M-tile 1's rows, 128 further on
         if (row < n1) {
             const gu2_t out = (gu2_t) reinterpret_cast<u32x2_t*>(sd.keys12) + row;
             const gcu32x4_t ap = (gcu32x4_t)(araw + (size_t)row * 8);
@@ -616,7 +656,9 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         load_raw_async(wt0 + 3, 0);
         ring_slot = 1;                             // the slot of tile wt0 + 1
         if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
-        __syncthreads();                           // every wave is past its last operand read of the b tile
+        __syncthreads();                           // every wave is past its last operand read of the b tile, every column minimum is parked
+        // the window's last block of column results (full or partial)
+        combine_columns((wt1 - 1) >> 3);
         if (!PLSLAM_MH_X(1024)) finish_rows();
         if (wt1 == ntiles) break;
         __syncthreads();                           // smem becomes the b tile (+ parking area) again
@@ -626,12 +668,13 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 }
 
 // K1c''  merge of K1h's column partials + the second-best recomputation: keys21[j] = best-2 over all rows of a.
-// part16[64-row block][slot] = (B0 | B1 << 16), 16-bit keys (d << 7 | row within the block): B0 = the block's best row, B1 =
-// its best row OUTSIDE B0's aligned group of 16 rows.  Over the blocks: K0 = the best B0, K1 = the best of (every other
-// block's B0, the winner block's B1) = the best row outside K0's group of 16; the 15 other rows of that group are
-// recomputed from the raw rows (512 contiguous bytes of a).  PARTS lanes share a column (tall problems: see K1f).
-// FIX = false: keys21[j] = (K0, K1) as they are -- the finalize kernel completes the second best for the columns it needs
-// (ProblemDesc::lazy21); FIX = true (exact key tables asked for): the recomputation happens here for every column.
+// part[256-row block][slot] = (d0 << 17 | row0 << 9 | d1): the block's best row and the distance of its best row OUTSIDE
+// row0's aligned group of 16 rows (FIX: the pair of words (d0 << 8 | row0, d1 << 8 | row1)).  Over the blocks: K0 = the best
+// row, K1 = the best of (every other block's best row, the winner block's second entry) = the best row outside K0's group of 16.
+// FIX = false: keys21[j] = (K0, K1) as they are -- K1's index is not a row then (all ones) -- and the finalize kernel completes
+// the second best for the columns it needs (ProblemDesc::lazy21); FIX = true (exact key tables asked for): the 15 other
+// rows of K0's group are recomputed here for every column (512 contiguous bytes of a).  PARTS lanes share a column (tall
+// problems: see K1f).
 template <int PARTS, bool FIX>
 __global__ void __launch_bounds__(256)
 k_merge_fix16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks)
@@ -646,26 +689,35 @@ k_merge_fix16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ bl
     const MhLayout L(sd.n2);
     const int j = slot < MH_TILE_N * L.ntiles ? L.row_of(slot >> 5, slot & 31) : sd.n2;     // >= n2: the slot holds no column
     const gcu32_t part = (gcu32_t) sd.part21;
-    const int nwb = (sd.n1 + 63) >> 6;
+    const int nwb = (sd.n1 + 255) >> 8;
     const int n2p = (MH_TILE_N * L.ntiles + 255) & ~255;
     uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
     if (j < sd.n2) {
-        auto wide = [](uint32_t k16, uint32_t wb) -> uint32_t {         // (d << 7 | row in block) -> (d << 23 | row)
-            return ((k16 << 16) & 0xFF800000u) | ((k16 & 63u) + 64u * wb);
+        auto wide = [](uint32_t k17, uint32_t wb) -> uint32_t {         // (d << 8 | row in block) -> (d << 23 | row)
+            return ((k17 >> 8) << KEY_IDX_BITS) | ((k17 & 255u) + 256u * wb);
         };
-        // only a block's BEST key is widened and merged per entry; the winner block's second key (kept raw in s0) joins at the end
+        // only a block's BEST key is widened and merged per entry; the winner block's second entry (kept raw in s0) joins at the end
         uint32_t s0 = 0xFFFFFFFFu;
 #pragma unroll 8
         for (int wb = part_id; wb < nwb; wb += PARTS) {
-            const uint32_t e = PLSLAM_NT_STREAMS ? __builtin_nontemporal_load(&part[(size_t)wb * n2p + slot])
-                                                 : part[(size_t)wb * n2p + slot];
-            const uint32_t k = wide(e & 0xFFFFu, (uint32_t)wb);
-            s0 = k < b0 ? e : s0;
+            uint32_t e0, e1;
+            if (FIX) {
+                const gu2c_t pp = (gu2c_t) part + ((size_t)wb * n2p + slot);
+                const u32x2_t e = PLSLAM_NT_STREAMS ? __builtin_nontemporal_load(pp) : *pp;
+                e0 = e.x; e1 = e.y;
+            } else {
+                const uint32_t e = PLSLAM_NT_STREAMS ? __builtin_nontemporal_load(&part[(size_t)wb * n2p + slot])
+                                                     : part[(size_t)wb * n2p + slot];
+                e0 = e >> 9; e1 = ((e & 511u) << 8) | 255u;             // the second entry's row is not in the word
+            }
+            const uint32_t k = wide(e0, (uint32_t)wb);
+            s0 = k < b0 ? e1 : s0;
             b1 = umin_(b1, umax_(b0, k));
             b0 = umin_(b0, k);
         }
         if (b0 < (257u << KEY_IDX_BITS)) {
-            b1 = umin_(b1, wide(s0 >> 16, (b0 & KEY_IDX_MASK) >> 6));
+            const uint32_t k1 = FIX ? wide(s0, (b0 & KEY_IDX_MASK) >> 8) : (((s0 >> 8) << KEY_IDX_BITS) | KEY_IDX_MASK);
+            b1 = umin_(b1, k1);
             if (b1 >= (257u << KEY_IDX_BITS)) b1 = KEY_NONE;
         } else {
             b0 = b1 = KEY_NONE;
