@@ -241,10 +241,11 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         const int64_t lanes = 64 * 4 * (int64_t)ctx->prop.multiProcessorCount * 4;      // ~4 waves per SIMD in flight
         P->merge_parts = (max_nwb >= 64 && cols * 16 <= lanes) ? 16 : (max_nwb >= 32 && cols * 4 <= lanes) ? 4 : 1;
     }
-    const int mcols = merge_partials16_cols(P->merge_parts);
-    // column partials in units of two words.  K1f: one word per (64-row block, column slot), rows padded to 256 slots; K1h:
-    // one word per (256-row block, column slot) -- two with exact key tables
+    // K1h's column partials: one word per (256-row block, column slot) -- two with exact key tables; K1f's: one word per
+    // (64-row block, column slot); rows padded to 256 slots
     const bool h_parts = P->sym_mfma && mfma_form_is_h(P->mfma_form) && !P->fused;
+    const int mcols = h_parts ? merge_fix16_cols(P->merge_parts) : merge_partials16_cols(P->merge_parts);
+    // column partials in units of two words
     auto part_units = [&](int32_t n1, int32_t n2) -> int64_t {
         if (h_parts) return (int64_t)((n1 + 255) / 256) * ((n2 + 255) / 256) * (P->exact_second ? 256 : 128);
         return (int64_t)((n1 + 63) / 64) * ((n2 + 255) / 256) * 128;

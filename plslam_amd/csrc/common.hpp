@@ -246,6 +246,7 @@ int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int
 inline bool mfma_form_is_h(int form) { return form == 0 || form == 4; }      // 0 = auto
 int launch_scan_sym_mfma_h(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
                            bool directed, hipStream_t s);
+int merge_fix16_cols(int parts);      // column slots per block-table entry of launch_merge_fix16
 int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, bool fix, hipStream_t s);
 int mh_slot_of_column(int n2, int j);
 // K1g (hamming_mfma_d.hip): the directed scan, one item per (directed scan, 256-row block of a); any n2 (windows inside)

@@ -72,6 +72,7 @@ constexpr int MH_TILE_BYTES = MH_TILE_N * MH_ROW_STRIDE;
 constexpr int MH_GROUP = 16;                  // tiles per group of the row direction (512 b rows)
 constexpr int MH_GROUP_ROWS = MH_GROUP * MH_TILE_N;
 constexpr int MH_WINDOW = 64;                 // tiles per window: the row keys' tag holds the group within the window (2 bits)
+constexpr int MH_MERGE_SPT = 4;              // slots per lane of the merge kernel (PARTS == 1)
 constexpr int MH_CGROUP = 8;                  // tiles whose column results are staged in LDS and stored together (256 slots)
 #ifndef PLSLAM_NT_STREAMS
 #define PLSLAM_NT_STREAMS 1
@@ -680,81 +681,104 @@ __global__ void __launch_bounds__(256)
 k_merge_fix16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks)
 {
     constexpr int COLS = 256 / PARTS;
+    // PARTS == 1: a lane takes SPT slots, 256 apart (one block-table entry per 1024 slots): the kernel is a chain of dependent
+    // round trips (block entry -> descriptor -> partials -> store) with a few loads at its end, and four slots' loads
+    // share the chain
+    constexpr int SPT = PARTS == 1 ? MH_MERGE_SPT : 1;
     __shared__ uint32_t red[PARTS > 1 ? 512 : 2];
     const BlockDesc bd = blocks[blockIdx.x];
     const SymDesc sd = syms[bd.item];
     // lanes walk the partial table in SLOT order (coalesced reads of every block's row); the slot's column is where the result goes
     const int jl = (int)threadIdx.x % COLS, part_id = (int)threadIdx.x / COLS;
-    const int slot = bd.row0 + jl;
     const MhLayout L(sd.n2);
-    const int j = slot < MH_TILE_N * L.ntiles ? L.row_of(slot >> 5, slot & 31) : sd.n2;     // >= n2: the slot holds no column
     const gcu32_t part = (gcu32_t) sd.part21;
     const int nwb = (sd.n1 + 255) >> 8;
     const int n2p = (MH_TILE_N * L.ntiles + 255) & ~255;
-    uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
-    if (j < sd.n2) {
-        auto wide = [](uint32_t k17, uint32_t wb) -> uint32_t {         // (d << 8 | row in block) -> (d << 23 | row)
-            return ((k17 >> 8) << KEY_IDX_BITS) | ((k17 & 255u) + 256u * wb);
-        };
-        // only a block's BEST key is widened and merged per entry; the winner block's second entry (kept raw in s0) joins at the end
-        uint32_t s0 = 0xFFFFFFFFu;
-#pragma unroll 8
-        for (int wb = part_id; wb < nwb; wb += PARTS) {
-            uint32_t e0, e1;
+    int slot[SPT], j[SPT];
+    uint32_t b0[SPT], b1[SPT], s0[SPT];     // s0: the winner block's second entry, kept raw: it joins at the end
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        slot[q] = bd.row0 + jl + 256 * q;
+        j[q] = slot[q] < MH_TILE_N * L.ntiles ? L.row_of(slot[q] >> 5, slot[q] & 31) : sd.n2;     // >= n2: the slot holds no column
+        if (j[q] >= sd.n2) slot[q] = 0;       // (reads a valid word, drops the result)
+        b0[q] = b1[q] = KEY_NONE;
+        s0[q] = 0xFFFFFFFFu;
+    }
+    auto wide = [](uint32_t k17, uint32_t wb) -> uint32_t {         // (d << 8 | row in block) -> (d << 23 | row)
+        return ((k17 >> 8) << KEY_IDX_BITS) | ((k17 & 255u) + 256u * wb);
+    };
+    // only a block's BEST key is widened and merged per entry
+#pragma unroll 2
+    for (int wb = part_id; wb < nwb; wb += PARTS) {
+        uint32_t e0[SPT], e1[SPT];
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
             if (FIX) {
-                const gu2c_t pp = (gu2c_t) part + ((size_t)wb * n2p + slot);
+                const gu2c_t pp = (gu2c_t) part + ((size_t)wb * n2p + slot[q]);
                 const u32x2_t e = PLSLAM_NT_STREAMS ? __builtin_nontemporal_load(pp) : *pp;
-                e0 = e.x; e1 = e.y;
+                e0[q] = e.x; e1[q] = e.y;
             } else {
-                const uint32_t e = PLSLAM_NT_STREAMS ? __builtin_nontemporal_load(&part[(size_t)wb * n2p + slot])
-                                                     : part[(size_t)wb * n2p + slot];
-                e0 = e >> 9; e1 = ((e & 511u) << 8) | 255u;             // the second entry's row is not in the word
+                const uint32_t e = PLSLAM_NT_STREAMS ? __builtin_nontemporal_load(&part[(size_t)wb * n2p + slot[q]])
+                                                     : part[(size_t)wb * n2p + slot[q]];
+                e0[q] = e >> 9; e1[q] = ((e & 511u) << 8) | 255u;     // the second entry's row is not in the word
             }
-            const uint32_t k = wide(e0, (uint32_t)wb);
-            s0 = k < b0 ? e1 : s0;
-            b1 = umin_(b1, umax_(b0, k));
-            b0 = umin_(b0, k);
         }
-        if (b0 < (257u << KEY_IDX_BITS)) {
-            const uint32_t k1 = FIX ? wide(s0, (b0 & KEY_IDX_MASK) >> 8) : (((s0 >> 8) << KEY_IDX_BITS) | KEY_IDX_MASK);
-            b1 = umin_(b1, k1);
-            if (b1 >= (257u << KEY_IDX_BITS)) b1 = KEY_NONE;
+#pragma unroll
+        for (int q = 0; q < SPT; ++q) {
+            const uint32_t k = wide(e0[q], (uint32_t)wb);
+            s0[q] = k < b0[q] ? e1[q] : s0[q];
+            b1[q] = umin_(b1[q], umax_(b0[q], k));
+            b0[q] = umin_(b0[q], k);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < SPT; ++q) {
+        if (j[q] < sd.n2 && b0[q] < (257u << KEY_IDX_BITS)) {
+            const uint32_t k1 = FIX ? wide(s0[q], (b0[q] & KEY_IDX_MASK) >> 8) : (((s0[q] >> 8) << KEY_IDX_BITS) | KEY_IDX_MASK);
+            b1[q] = umin_(b1[q], k1);
+            if (b1[q] >= (257u << KEY_IDX_BITS)) b1[q] = KEY_NONE;
         } else {
-            b0 = b1 = KEY_NONE;
+            b0[q] = b1[q] = KEY_NONE;
         }
     }
     if (PARTS > 1) {
         // the parts' pairs: each is (best of its blocks, best outside THAT best's group): the overall best's pair partner is
         // still "outside its group", and any other part's best is outside it too (another block, or the same block's
-        // other group only if it came as a B1 -- which is also outside) -- merge2 keeps exactly that
-        red[2 * threadIdx.x] = b0;
-        red[2 * threadIdx.x + 1] = b1;
+        // other group only if it came as a second entry -- which is also outside) -- merge2 keeps exactly that
+        red[2 * threadIdx.x] = b0[0];
+        red[2 * threadIdx.x + 1] = b1[0];
         __syncthreads();
         if (part_id == 0) {
 #pragma unroll
-            for (int q = 1; q < PARTS; ++q) merge2(b0, b1, red[2 * (q * COLS + jl)], red[2 * (q * COLS + jl) + 1]);
+            for (int q = 1; q < PARTS; ++q) merge2(b0[0], b1[0], red[2 * (q * COLS + jl)], red[2 * (q * COLS + jl) + 1]);
         }
     }
-    if (part_id == 0 && j < sd.n2) {
-        if (FIX && b0 != KEY_NONE) {
-            const gcu32_t araw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.a);
-            const gcu32x4_t bp = (gcu32x4_t)((gcu32_t) reinterpret_cast<const uint32_t*>(sd.b) + (size_t)j * 8);
-            const u32x4_t b_lo = bp[0], b_hi = bp[1];
-            const uint32_t i0 = b0 & KEY_IDX_MASK, ibase = i0 & ~15u;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                const uint32_t i = ibase + (uint32_t)k;
-                const bool ok = i != i0 && i < (uint32_t)sd.n1;
-                const gcu32x4_t ap = (gcu32x4_t)(araw + (size_t)(ok ? i : i0) * 8);
-                const u32x4_t a_lo = ap[0], a_hi = ap[1];
-                const uint32_t d = hamming256(a_lo, a_hi, b_lo, b_hi);
-                b1 = umin_(b1, ok ? ((d << KEY_IDX_BITS) | i) : KEY_NONE);
+    for (int q = 0; q < SPT; ++q) {
+        if (part_id == 0 && j[q] < sd.n2) {
+            if (FIX && b0[q] != KEY_NONE) {
+                const gcu32_t araw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.a);
+                const gcu32x4_t bp = (gcu32x4_t)((gcu32_t) reinterpret_cast<const uint32_t*>(sd.b) + (size_t)j[q] * 8);
+                const u32x4_t b_lo = bp[0], b_hi = bp[1];
+                const uint32_t i0 = b0[q] & KEY_IDX_MASK, ibase = i0 & ~15u;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    const uint32_t i = ibase + (uint32_t)k;
+                    const bool ok = i != i0 && i < (uint32_t)sd.n1;
+                    const gcu32x4_t ap = (gcu32x4_t)(araw + (size_t)(ok ? i : i0) * 8);
+                    const u32x4_t a_lo = ap[0], a_hi = ap[1];
+                    const uint32_t d = hamming256(a_lo, a_hi, b_lo, b_hi);
+                    b1[q] = umin_(b1[q], ok ? ((d << KEY_IDX_BITS) | i) : KEY_NONE);
+                }
             }
+            ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21))[j[q]] = u32x2_t{b0[q], b1[q]};
         }
-        ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21))[j] = u32x2_t{b0, b1};
     }
 }
 
+int merge_fix16_cols(int parts) { return parts >= 16 ? 16 : parts >= 4 ? 64 : 256 * MH_MERGE_SPT; }
+
+// d_blocks: one entry per (problem, merge_fix16_cols(parts) column slots)
 int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, bool fix, hipStream_t s)
 {
     if (nblocks <= 0) return PLSLAM_OK;
