@@ -164,6 +164,8 @@ def main():
     ap.add_argument("--group-cap", type=int, default=0)
     ap.add_argument("--mfma-form", type=int, default=0, help="0 = auto (K1h), 1 = K1e (best-2 push per tile), 2 = K1f (group minima, rows), 3 = K1g (two directed scans per mutual problem), 4 = K1h (group minima both ways)")
     ap.add_argument("--fuse", type=int, default=0, help="K1f: 0 = auto, 1 = never, 2 = always one workgroup per problem incl. merge + finalize")
+    ap.add_argument("--post-wgs", type=int, default=0, help="cap on the workgroups of the stages behind a scan when they run beside the next scan (option post_workgroups; 0 = the library's default)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="any other plslam_ctx option, e.g. --opt exact_second=1")
     ap.add_argument("--no-gates", action="store_true", help="leave the stereo-gate stage out of the step (tables only)")
     ap.add_argument("--step-streams", type=int, default=2, help="output buffers / HIP streams the steps alternate over")
     ap.add_argument("--no-overlap", action="store_true",
@@ -245,9 +247,11 @@ def main():
     note(f"synthetic stream of {B} pairs generated")
     ctx = plslam_amd.Context(local_rank)     # raises if libplslam_hip.so / a gfx950 device is missing
     for key, val in (("scan_variant", args.scan_variant), ("scan_block", args.scan_block), ("sym_rows", args.sym_rows),
-                     ("group_cap", args.group_cap), ("mfma_form", args.mfma_form), ("fuse", args.fuse)):
+                     ("group_cap", args.group_cap), ("mfma_form", args.mfma_form), ("fuse", args.fuse), ("post_workgroups", args.post_wgs)):
         if val:
             ctx.set_option(key, val)
+    for kv in args.opt:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     overlap = not use_dist and not args.no_overlap
     n_buf = max(2, args.step_streams) if (use_dist or overlap) else 1
     bm = frontend.StereoBatchMatcher(ctx, stream, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev,

@@ -633,13 +633,13 @@ static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
     }
 
     r = P->sym_mfma && mfma_form_is_h(P->mfma_form) && !P->fused
-            ? launch_merge_fix16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, P->exact_second, s)
+            ? launch_merge_fix16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, P->exact_second, s, split ? P->ctx->post_workgroups : 0)
             : P->sym_mfma && P->mfma_form != 1 ? launch_merge_partials16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, s)
                                                : launch_merge_partials(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s);
     if (r) return r;
     // the gate stage: its counters are cleared first; gates over the plan's own tables run inside the finalize kernel
     if (P->ngates > 0 && P->d_gate_counts) PLSLAM_HIP_CHECK(hipMemsetAsync(P->d_gate_counts, 0, sizeof(int32_t) * (size_t)P->ngates, s));
-    r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, P->ngates > 0 ? P->d_gates : nullptr, s);
+    r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, P->ngates > 0 ? P->d_gates : nullptr, s, split ? P->ctx->post_workgroups : 0);
     if (r) return r;
     if (P->ngate_blocks > 0) {
         r = launch_stereo_gates(P->d_gates, P->d_gate_blocks, P->ngate_blocks, s);
@@ -782,6 +782,11 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         ctx->col_split = value;
         return PLSLAM_OK;
     }
+    if (!strcmp(key, "post_workgroups")) {
+        PLSLAM_REQUIRE(value >= 0, PLSLAM_EINVAL);
+        ctx->post_workgroups = value;
+        return PLSLAM_OK;
+    }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }
@@ -797,6 +802,7 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "fuse")) { *value = ctx->fuse; return PLSLAM_OK; }
     if (!strcmp(key, "col_split")) { *value = ctx->col_split; return PLSLAM_OK; }
     if (!strcmp(key, "exact_second")) { *value = ctx->exact_second; return PLSLAM_OK; }
+    if (!strcmp(key, "post_workgroups")) { *value = ctx->post_workgroups; return PLSLAM_OK; }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }

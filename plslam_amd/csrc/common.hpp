@@ -125,6 +125,7 @@ struct plslam_ctx {
     int mfma_form = 0;   // matrix-core scan: 0 = auto (= 4), 1 = exact push per tile (K1e), 2 = grouped rows (K1f), 3 = directed pairs (K1g), 4 = grouped both ways (K1h)
     int col_split = 0;   // K1f, few large problems: 0 = auto (cut the columns into ranges when the plan cannot fill the chip), 1 = never, 2 = always
     int exact_second = 0; // K1h: 1 = the index of every second-best row key is exact (0: only where it is an output -- knnMatch)
+    int post_workgroups = 0;   // > 0: the stages behind a scan (merge of K1h's partials, finalize) run as at most this many workgroups walking their block tables
     int fuse = 0;        // K1f: 0 = auto (one workgroup per problem incl. merge + finalize when the plan is large), 1 = never, 2 = always
     std::mutex mu;       // serialises the host-pointer entry points
     plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
@@ -163,6 +164,33 @@ struct ScanDesc {       // one directed scan: every query row against every trai
     int32_t nq, nt;
 };
 
+// ---- K1h (hamming_mfma_h.hip): the layout of b over (tile, class): class-major inside groups of 16 tiles of 32 rows ------
+// full groups: 512 rows each; the ragged rest (n2 mod 512 rows) is one more group of S = ceil(rest / 32) tiles with S rows per
+// class.  Column slot of the partial table = 32 tile + class.
+struct MhLayout {
+    int n2, nfull, ntiles, rag_s;       // nfull: tiles of full groups (a multiple of 16); rag_s: tiles (= rows per class) of the ragged group
+    __host__ __device__ explicit MhLayout(int n2_) : n2(n2_)
+    {
+        const int full = n2_ / 512, rest = n2_ - full * 512;
+        nfull = full * 16;
+        rag_s = (rest + 31) / 32;
+        ntiles = nfull + rag_s;
+    }
+    __host__ __device__ int stride(int t) const { return t < nfull ? 16 : rag_s; }
+    __host__ __device__ int row_of(int t, int cls) const { return (t >> 4) * 512 + stride(t) * cls + (t & 15); }   // may be >= n2
+    __host__ __device__ int slot_of(int j) const
+    {
+        const int G = j >> 9, off = j & 511;
+        const int s = G * 16 < nfull ? 16 : rag_s;
+        // off / s for off < 512, 1 <= s <= 16 without a division: floor(off * ceil(2^16 / s) / 2^16), exact while off < 2^16 / s
+        constexpr uint32_t recip[17] = {0, 65536, 32768, 21846, 16384, 13108, 10923, 9363, 8192, 7282, 6554, 5958, 5462, 5042,
+                                        4682, 4370, 4096};
+        const int cls = (int)(((uint32_t)off * recip[s]) >> 16), tt = off - cls * s;
+        return 32 * (G * 16 + tt) + cls;
+    }
+    __host__ __device__ int slots_padded() const { return (32 * ntiles + 255) & ~255; }     // slots per row of the partial table
+};
+
 struct ProblemDesc {    // one StVO::match problem = scan12 (+ scan21 when mutual)
     const uint32_t* keys12;
     const uint32_t* keys21;  // nullptr when !mutual
@@ -198,7 +226,7 @@ struct BlockDesc {      // one workgroup's slice of a scan / problem
 int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const ScanDesc* d_scans,
                 const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero, hipStream_t s);
 int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int nblocks,
-                    const plslam_stereo_gate_problem* d_gates, hipStream_t s);
+                    const plslam_stereo_gate_problem* d_gates, hipStream_t s, int grid_cap = 0);
 int launch_scatter_counts(const int32_t* d_src, int32_t* const* d_dst, int32_t n, hipStream_t s);
 int launch_unpack_keys(const uint32_t* d_keys, int32_t n, int32_t* d_idx, int32_t* d_dist,
                        hipStream_t s);
@@ -247,7 +275,7 @@ inline bool mfma_form_is_h(int form) { return form == 0 || form == 4; }      // 
 int launch_scan_sym_mfma_h(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
                            bool directed, hipStream_t s);
 int merge_fix16_cols(int parts);      // column slots per block-table entry of launch_merge_fix16
-int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, bool fix, hipStream_t s);
+int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, bool fix, hipStream_t s, int grid_cap = 0);
 int mh_slot_of_column(int n2, int j);
 // K1g (hamming_mfma_d.hip): the directed scan, one item per (directed scan, 256-row block of a); any n2 (windows inside)
 int launch_scan_dir_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero, hipStream_t s);

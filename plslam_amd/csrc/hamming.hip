@@ -548,9 +548,11 @@ __device__ __forceinline__ int ratio_pick(uint32_t k0, uint32_t k1, float nnr)
 #endif
 __global__ void __launch_bounds__(256)
 k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ blocks,
-           const plslam_stereo_gate_problem* __restrict__ gates)
+           const plslam_stereo_gate_problem* __restrict__ gates, int nblocks)
 {
-    const BlockDesc bd = blocks[blockIdx.x];
+  // (a capped grid walks the block table: plslam_ctx option "post_workgroups")
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const BlockDesc bd = blocks[blk];
     const ProblemDesc p = probs[bd.item];
     const int i1 = bd.row0 + (int)threadIdx.x;
     int m = -1;
@@ -663,6 +665,7 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
         const unsigned long long bal = __ballot(kept);
         if (q.n_stereo && (threadIdx.x & 63) == 0 && bal) (void)atomic_add_global(q.n_stereo, (int)__popcll(bal));
     }
+  }
 }
 
 // copies the per-problem counters to caller pointers that are not one contiguous array
@@ -752,10 +755,11 @@ int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int n
 }
 
 int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int nblocks,
-                    const plslam_stereo_gate_problem* d_gates, hipStream_t s)
+                    const plslam_stereo_gate_problem* d_gates, hipStream_t s, int grid_cap)
 {
     if (nblocks <= 0) return PLSLAM_OK;
-    hipLaunchKernelGGL(k_finalize, dim3(nblocks), dim3(256), 0, s, d_probs, d_blocks, d_gates);
+    const int grid = grid_cap > 0 && grid_cap < nblocks ? grid_cap : nblocks;
+    hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, d_probs, d_blocks, d_gates, nblocks);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

@@ -163,28 +163,6 @@ __device__ __forceinline__ int xcd_remap_(int orig, int nwg) { return (orig & 7)
 
 }  // namespace
 
-// ---- the layout of b over (tile, class): class-major inside groups of 16 tiles (see the file header) -------------------
-// full groups: 512 rows each; the ragged rest (n2 mod 512 rows) is one more group of S = ceil(rest / 32) tiles with S rows per
-// class.  Column slot of the partial table = 32 tile + class.
-struct MhLayout {
-    int n2, nfull, ntiles, rag_s;       // nfull: tiles of full groups (a multiple of 16); rag_s: tiles (= rows per class) of the ragged group
-    __host__ __device__ explicit MhLayout(int n2_) : n2(n2_)
-    {
-        const int full = n2_ / MH_GROUP_ROWS, rest = n2_ - full * MH_GROUP_ROWS;
-        nfull = full * MH_GROUP;
-        rag_s = (rest + MH_TILE_N - 1) / MH_TILE_N;
-        ntiles = nfull + rag_s;
-    }
-    __host__ __device__ int stride(int t) const { return t < nfull ? MH_GROUP : rag_s; }
-    __host__ __device__ int row_of(int t, int cls) const { return (t >> 4) * MH_GROUP_ROWS + stride(t) * cls + (t & 15); }   // may be >= n2
-    __host__ __device__ int slot_of(int j) const
-    {
-        const int G = j >> 9, off = j & (MH_GROUP_ROWS - 1);
-        const int s = G * MH_GROUP < nfull ? MH_GROUP : rag_s;
-        const int cls = off / s, tt = off - cls * s;
-        return MH_TILE_N * (G * MH_GROUP + tt) + cls;
-    }
-};
 int mh_slot_of_column(int n2, int j) { return MhLayout(n2).slot_of(j); }     // for tests / tools (plslam_match_plan_dump readers)
 // row within the workgroup's 256 rows of a held by wave w, M-tile mt, MFMA row m: 128 mt + 32 w + 16 g + r with
 // m = (r & 3) + 8 (r >> 2) + 4 g
@@ -373,9 +351,9 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         pk_merge(lo[2], hi[2], lo[3], hi[3]);
         pk_merge(lo[0], hi[0], lo[2], hi[2]);
         // (d << 7 | t) + (d << 7) [+ 128: M-tile 1] = (d << 8 | row in the block); "none" 0xFFFF -> 0x1FF7F / 0x1FFFF: d = 511
-        const uint32_t e0 = lo[0] & 0xFFFFu, e1 = hi[0] & 0xFFFFu, f0 = lo[0] >> 16, f1 = hi[0] >> 16;
+        const uint32_t e0 = lo[0] & 0xFFFFu, e1 = hi[0] & 0xFFFFu, u0 = lo[0] >> 16, u1 = hi[0] >> 16;
         uint32_t k0 = e0 + (e0 & 0xFF80u), k1 = e1 + (e1 & 0xFF80u);
-        merge2(k0, k1, f0 + (f0 & 0xFF80u) + 128u, f1 + (f1 & 0xFF80u) + 128u);
+        merge2(k0, k1, u0 + (u0 & 0xFF80u) + 128u, u1 + (u1 & 0xFF80u) + 128u);
         if (PLSLAM_MH_X(32)) k0 = p[0];
         const uint32_t slot4 = (uint32_t)(256 * kb + 64 * w) * 4u;                             // (scalar) n2p is a multiple of 256
         if (!wide_part) {
@@ -678,15 +656,17 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 // problems: see K1f).
 template <int PARTS, bool FIX>
 __global__ void __launch_bounds__(256)
-k_merge_fix16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks)
+k_merge_fix16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks, int nblocks)
 {
+  // (a capped grid walks the block table: plslam_ctx option "post_workgroups")
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     constexpr int COLS = 256 / PARTS;
     // PARTS == 1: a lane takes SPT slots, 256 apart (one block-table entry per 1024 slots): the kernel is a chain of dependent
     // round trips (block entry -> descriptor -> partials -> store) with a few loads at its end, and four slots' loads
     // share the chain
     constexpr int SPT = PARTS == 1 ? MH_MERGE_SPT : 1;
     __shared__ uint32_t red[PARTS > 1 ? 512 : 2];
-    const BlockDesc bd = blocks[blockIdx.x];
+    const BlockDesc bd = blocks[blk];
     const SymDesc sd = syms[bd.item];
     // lanes walk the partial table in SLOT order (coalesced reads of every block's row); the slot's column is where the result goes
     const int jl = (int)threadIdx.x % COLS, part_id = (int)threadIdx.x / COLS;
@@ -745,6 +725,7 @@ k_merge_fix16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ bl
         // the parts' pairs: each is (best of its blocks, best outside THAT best's group): the overall best's pair partner is
         // still "outside its group", and any other part's best is outside it too (another block, or the same block's
         // other group only if it came as a second entry -- which is also outside) -- merge2 keeps exactly that
+        if (blk != (int)blockIdx.x) __syncthreads();          // the entry before: every lane is past its reads of red[]
         red[2 * threadIdx.x] = b0[0];
         red[2 * threadIdx.x + 1] = b1[0];
         __syncthreads();
@@ -774,16 +755,18 @@ k_merge_fix16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ bl
             ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21))[j[q]] = u32x2_t{b0[q], b1[q]};
         }
     }
+  }
 }
 
 int merge_fix16_cols(int parts) { return parts >= 16 ? 16 : parts >= 4 ? 64 : 256 * MH_MERGE_SPT; }
 
 // d_blocks: one entry per (problem, merge_fix16_cols(parts) column slots)
-int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, bool fix, hipStream_t s)
+int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, bool fix, hipStream_t s, int grid_cap)
 {
     if (nblocks <= 0) return PLSLAM_OK;
-#define PLSLAM_MH_MERGE(P) { if (fix) hipLaunchKernelGGL((k_merge_fix16<P, true>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks); \
-                             else hipLaunchKernelGGL((k_merge_fix16<P, false>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks); }
+    const int grid = grid_cap > 0 && grid_cap < nblocks ? grid_cap : nblocks;
+#define PLSLAM_MH_MERGE(P) { if (fix) hipLaunchKernelGGL((k_merge_fix16<P, true>), dim3(grid), dim3(256), 0, s, d_sym, d_blocks, nblocks); \
+                             else hipLaunchKernelGGL((k_merge_fix16<P, false>), dim3(grid), dim3(256), 0, s, d_sym, d_blocks, nblocks); }
     if (parts >= 16) PLSLAM_MH_MERGE(16)
     else if (parts >= 4) PLSLAM_MH_MERGE(4)
     else PLSLAM_MH_MERGE(1)

@@ -531,9 +531,19 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
         if form != 6:
             assert np.array_equal(k1, k2), (form, int((k1 != k2).sum()))
         else:
-            # default K1h: every best key is exact, and so is every row's second-best DISTANCE
+            # default K1h: every row's best key is exact, and so is its second-best DISTANCE; of the merged column keys the
+            # best one (the second one is completed lazily by the finalize kernel: ProblemDesc::lazy21)
             a, b = k1.reshape(-1, 2), k2.reshape(-1, 2)
             assert np.array_equal(a[:, 0], b[:, 0]), (form, int((a[:, 0] != b[:, 0]).sum()))
+            is12 = np.zeros(rows, dtype=bool)                # per problem: n1 rows of keys12, then (mutual) n2 rows of keys21
+            at = 0
+            for _ in range(pairs):
+                for n in (n_orb, n_orb, n_lbd, n_lbd):
+                    is12[at:at + n] = True
+                    at += n * (2 if mutual else 1)
+            assert at == rows
+            assert np.array_equal(a[is12, 0], b[is12, 0]), (form, int((a[is12, 0] != b[is12, 0]).sum()))
+            assert np.array_equal(a[is12, 1] >> 23, b[is12, 1] >> 23), form
         assert np.array_equal(got[1][2], got[form][2]), form
         assert np.array_equal(got[1][3], got[form][3]), form
 
