@@ -6,10 +6,10 @@ the tree's).   usage: make_pmc_traffic.py <tag> <n_orb> <n_lbd> <pairs> <kernel 
 
 FETCH_SIZE correction: MI355X_MICROARCH.md measures that this rocprofv3 reports HALF the bytes of a wide coalesced streaming read
 (16 B per lane) and calls other access widths uncalibrated ("calibrate on a known byte count in your own access pattern").  The
-calibration for 4-byte-per-lane loads is in the same passes: k_merge_fix16 reads the column-partial table exactly once with
-dword loads -- 614 MB at C2 / 4096 pairs -- and FETCH_SIZE reports 599 317 KiB = 614 MB: factor 1.0.  K1h's reads are dword
-loads too (raw rows through LDS-DMA, one dword per lane), so its entry uses 1.0; K1f's round-2 entry (16-byte row loads in its
-second-best recomputation, dword loads elsewhere) used the guide's 2.0 as an upper bound."""
+calibration for 4-byte-per-lane loads is in round 3's passes: k_merge_fix16 reads the column-partial table exactly once with
+dword loads -- in set r3_z 1.24 GB at C2 / 4096 pairs (4096 x (2 x 24 x 1536 + 2 x 4 x 256) words; the scan's WRITE_SIZE agrees)
+-- and FETCH_SIZE reported 599 317 KiB = 0.614 GB: the factor is 2.0 for dword loads as well.  (An earlier reading of the same
+numbers took the table for 614 MB and keyed K1h's entry with 1.0: wrong, corrected here.)"""
 import json
 import os
 import re
@@ -50,9 +50,9 @@ def main():
         "measured_int_valu_ceiling_lane_ops_per_s": 38500000000000.0,
         "measured_int_valu_ceiling_source": "profiles/r1_valu_microbench.txt, profiles/r2_valu_microbench2.txt: pk_min / perm / "
                                             "and_or class ops at 4.1-4.5 cycles per wave64 instruction per SIMD",
-        "note": ("FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (wide vector loads)" if corr == 2.0 else
-                 f"FETCH_SIZE x {corr}: dword-per-lane loads, calibrated on k_merge_fix16 of the same passes (reads the 614 MB "
-                 "partial table once, reports 599 317 KiB)") + "; WRITE_SIZE includes the kernel's register spills (scratch); "
+        "note": ("FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950 (the factor holds for dword-per-lane loads too: "
+                 "k_merge_fix16 reads a table of known size once and reports half of it)" if corr == 2.0 else
+                 f"FETCH_SIZE x {corr}") + "; WRITE_SIZE includes the kernel's register spills (scratch); "
                 "SQ_INSTS_VALU counts the MFMAs too (bench.py subtracts SQ_INSTS_MFMA)",
         "source": f"profiles/{tag}_pmc_a.txt, profiles/{tag}_pmc_fetch.txt, profiles/{tag}_pmc_write.txt (rocprofv3 --pmc, "
                   "separate passes, python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-overlap --no-secondary)"}
