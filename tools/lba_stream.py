@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The LBA row kernels' streaming launches of bench.py's secondary.c3 record on their own (64 maps per launch, each map with
-its own landmark array), for rocprofv3: `rocprofv3 --kernel-trace --stats -- python tools/lba_stream.py` and the FETCH_SIZE /
+"""The LBA row kernels' streaming launches of bench.py's secondary.c3 record on their own (256 point maps / 1024 line maps
+per launch = ~1.5 GB moved, each map with its own landmark array; `lba_stream.py 64 256` = the ~0.4 GB footprint), for rocprofv3: `rocprofv3 --kernel-trace --stats -- python tools/lba_stream.py` and the FETCH_SIZE /
 WRITE_SIZE passes (tools/pmc_passes.sh).  Prints the moved-byte model per launch next to the event-timed rate."""
 import json
 import os
@@ -23,9 +23,11 @@ def main():
     lm = synth.local_map()
     cam = plslam_amd.make_cam(**synth.EUROC)
     g = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in lm.items()}
-    reps, out = 64, {}
+    reps_of = {"point": int(sys.argv[1]) if len(sys.argv) > 1 else 256, "line": int(sys.argv[2]) if len(sys.argv) > 2 else 1024}
+    out = {}
     for kind, n, nlm, lmk, xk, keys, nl in (("point", lm["pt_lm"].shape[0], lm["Xw"].shape[0], "pt_lm", "Xw", ("obs_uv", "pt_kf"), 3),
                                              ("line", lm["ls_lm"].shape[0], lm["Lw"].shape[0], "ls_lm", "Lw", ("l_obs", "ls_kf"), 6)):
+        reps = reps_of[kind]
         big = {k: torch.cat([g[k]] * reps) for k in keys}
         idx = torch.cat([g[lmk] + r * nlm for r in range(reps)])
         X = torch.cat([g[xk]] * reps)
@@ -52,7 +54,7 @@ def main():
         e1.record(st)
         st.synchronize()
         ms = e0.elapsed_time(e1) / 10
-        out[kind] = {"rows_per_launch": nb, "bytes_per_row_moved": moved, "bytes_per_launch_moved": nb * moved, "launches": 13,
+        out[kind] = {"maps_per_launch": reps, "rows_per_launch": nb, "bytes_per_row_moved": moved, "bytes_per_launch_moved": nb * moved, "launches": 13,
                      "ms_per_launch_events": ms, "GBps_moved": nb * moved / (ms * 1e-3) / 1e9}
     print(json.dumps(out))
 
