@@ -97,6 +97,9 @@ void plslam_ctx_destroy(plslam_ctx* ctx);
  * "exact_second" (K1h: 0 (default) = the index of a row's SECOND neighbour in the internal key tables is exact only where
  * it is an output (plslam_knn2_hamming256) and the column keys are completed lazily by the finalize stage | 1 = every key
  * of plslam_match_plan_dump is exact; match tables are identical either way),
+ * "post_workgroups" (0 = default: one workgroup per block-table entry; n > 0: in a split run (plslam_match_plan_run_split) the
+ * stages behind the scan -- K1h's merge of the column partials, the finalize kernel -- run as at most n workgroups that walk
+ * their block tables, i.e. they hold a bounded number of workgroup slots beside the next scan; measured neutral to +1 %),
  * "fuse" (K1f: one workgroup per problem that also merges the column results and applies the ratio test + mutual
  * check, i.e. one kernel per plan run: 0 = auto (currently: never -- measured no faster) | 1 = never | 2 = always) */
 int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value);
