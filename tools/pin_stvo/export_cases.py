@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Exports the committed golden vectors of the matcher path (tests/golden/match_golden.npz, grid_golden.npz,
-stereo_gates_golden.npz) as flat binary arrays + a text manifest that tools/pin_stvo/pin_stvo.cpp reads -- the C++ side then
+stereo_gates_golden.npz) and of the [RECALL] helpers of the LBA rows (se3_helpers_golden.npz) as flat binary arrays + a text manifest that tools/pin_stvo/pin_stvo.cpp reads -- the C++ side then
 needs nothing but OpenCV and a stvo-pl checkout.   usage: export_cases.py <out_dir>
 
 Array file: "PLSA" | dtype char (u = uint8, i = int32, f = float32, d = float64) | int32 ndim | int64 dims[ndim] | data.
@@ -76,6 +76,8 @@ def main(out):
                          f"seg_l={put(f'gate_l{c}_segl', g[f'l{c}_seg_l'])} seg_r={put(f'gate_l{c}_segr', g[f'l{c}_seg_r'])} "
                          f"min_disp={th[0]} line_horiz_th={th[1]} stereo_overlap_th={th[2]} ls_min_disp_ratio={th[3]} "
                          f"expect={put(f'gate_l{c}_t{t}_s', g[f'l{c}_t{t}_stereo'])} expect_disp={put(f'gate_l{c}_t{t}_d', g[f'l{c}_t{t}_disp'])}")
+    g = np.load(os.path.join(GOLD, "se3_helpers_golden.npz"))
+    lines.append("kind=se3 name=helpers " + " ".join(f"{k}={put('se3_' + k, g[k])}" for k in sorted(g.files)))
     with open(os.path.join(out, "manifest.txt"), "w") as f:
         f.write("\n".join(lines) + "\n")
     print(f"{len(lines)} cases -> {out}")

@@ -12,9 +12,13 @@
 //                    int matchGrid(const std::vector<line_2d>&, const cv::Mat&, const GridStructure&, const cv::Mat&,
 //                                  const std::vector<std::pair<double, double>>&, const GridWindow&, std::vector<int>&); }
 //   Config::bestLRMatches(), Config::minRatio12P(), Config::lineSimTh() return references to the singleton's fields.
+// The SE(3) helpers, the pinhole projection and the Cauchy weight (kind=se3; [RECALL] as well) go through se3_adapter.h; they
+// are compared to a relative 1e-12 (stvo-pl may order its floating-point operations differently), not bit for bit.
+// Output: one PASS / FAIL line per case and, at the end, ONE table with a row per golden file.
 // The stereo gates (kind=gate_*) are members of StereoFrame that match and gate in one function: they cannot be called on
 // their own.  Their cases are listed (inputs, thresholds, expected tables and disparities are in the export) for a manual
 // comparison inside StereoFrame::matchStereoPoints / matchStereoLines.
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +35,7 @@
 #include "config.h"
 #include "gridStructure.h"
 #include "matching.h"
+#include "se3_adapter.h"
 
 namespace {
 
@@ -80,6 +85,32 @@ int compare(const std::string& what, const std::vector<int>& got, const Array& w
     return bad ? 1 : 0;
 }
 
+// |got - want| <= tol * max(1, |want|) element-wise; non-finite values must agree exactly (inf with inf, NaN with NaN)
+int compare_f64(const std::string& what, const double* got, const Array& want, double tol)
+{
+    int64_t n = 1;
+    for (int64_t d : want.dims) n *= d;
+    int bad = 0;
+    double worst = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double w = want.as<double>()[i], g = got[i];
+        bool ok;
+        if (std::isnan(w) || std::isnan(g)) ok = std::isnan(w) && std::isnan(g);
+        else if (std::isinf(w) || std::isinf(g)) ok = w == g;
+        else {
+            const double e = std::fabs(g - w) / std::fmax(1.0, std::fabs(w));
+            worst = std::fmax(worst, e);
+            ok = e <= tol;
+        }
+        if (!ok && bad++ < 5) std::printf("  %s: element %lld got %.17g expected %.17g\n", what.c_str(), (long long)i, g, w);
+    }
+    std::printf("%s %s (max relative difference %.3g)%s\n", bad ? "FAIL" : "PASS", what.c_str(), worst,
+                bad ? (" (" + std::to_string(bad) + " elements differ)").c_str() : "");
+    return bad ? 1 : 0;
+}
+
+struct Tally { int ran = 0, failed = 0, listed = 0; };
+
 }  // namespace
 
 int main(int argc, char** argv)
@@ -88,6 +119,7 @@ int main(int argc, char** argv)
     std::ifstream mf(dir + "/manifest.txt");
     if (!mf) { std::fprintf(stderr, "no manifest in %s (run tools/pin_stvo/export_cases.py first)\n", dir.c_str()); return 2; }
     int failed = 0, ran = 0, listed = 0;
+    std::map<std::string, Tally> table;             // one row per golden file
     std::string line;
     while (std::getline(mf, line)) {
         std::map<std::string, std::string> kv;
@@ -100,13 +132,16 @@ int main(int argc, char** argv)
         if (kv.empty()) continue;
         const std::string kind = kv["kind"];
         auto arr = [&](const char* key) { return load(dir + "/" + kv[key]); };
+        Tally& row = table[kind == "match" ? "match_golden.npz" : kind.rfind("grid_", 0) == 0 ? "grid_golden.npz"
+                           : kind == "se3" ? "se3_helpers_golden.npz" : "stereo_gates_golden.npz"];
+        const int failed_before = failed;
         if (kind == "match") {
             Array q = arr("q"), t = arr("t"), want = arr("expect");
             StVO::Config::bestLRMatches() = kv["mutual"] == "1";
             std::vector<int> m12;
             StVO::match(desc_mat(q), desc_mat(t), (float)std::atof(kv["nnr"].c_str()), m12);
             failed += compare("match " + kv["name"] + " nnr " + kv["nnr"] + " mutual " + kv["mutual"], m12, want);
-            ++ran;
+            ++ran; ++row.ran;
         } else if (kind == "grid_points" || kind == "grid_lines") {
             Array cen = arr("centres"), d1 = arr("d1"), d2 = arr("d2"), cs = arr("cell_start"), it = arr("cell_items"),
                   want = arr("expect");
@@ -138,11 +173,35 @@ int main(int argc, char** argv)
                 StVO::matchGrid(lns, desc_mat(d1), grid, desc_mat(d2), dirs, w, m12);
             }
             failed += compare(kind + " " + kv["name"] + " nnr " + kv["nnr"] + " mutual " + kv["mutual"], m12, want);
-            ++ran;
+            ++ran; ++row.ran;
+        } else if (kind == "se3") {
+            const double tol = 1e-12;
+            Array tw = arr("twists"), ex = arr("expmap"), inv = arr("inverse"), lg = arr("logmap"), cam = arr("cam"),
+                  pts = arr("points"), pj = arr("projection"), cr = arr("cauchy_r"), cw = arr("cauchy_w");
+            const int64_t n = tw.rows();
+            std::vector<double> o_ex(16 * n), o_inv(16 * n), o_lg(6 * n), o_pj(2 * pts.rows()), o_cw(cr.rows());
+            for (int64_t i = 0; i < n; ++i) {
+                pin::expmap_se3(tw.as<double>() + 6 * i, o_ex.data() + 16 * i);
+                pin::inverse_se3(ex.as<double>() + 16 * i, o_inv.data() + 16 * i);     // of the EXPECTED pose: the cases stay independent
+                pin::logmap_se3(ex.as<double>() + 16 * i, o_lg.data() + 6 * i);
+            }
+            for (int64_t i = 0; i < pts.rows(); ++i) pin::projection(cam.as<double>(), pts.as<double>() + 3 * i, o_pj.data() + 2 * i);
+            for (int64_t i = 0; i < cr.rows(); ++i) o_cw[i] = pin::cauchy(cr.as<double>()[i]);
+            failed += compare_f64("se3 expmap_se3", o_ex.data(), ex, tol);
+            failed += compare_f64("se3 inverse_se3", o_inv.data(), inv, tol);
+            failed += compare_f64("se3 logmap_se3", o_lg.data(), lg, 1e-9);          // (acos near +-1: conditioning, not convention)
+            failed += compare_f64("se3 projection", o_pj.data(), pj, tol);
+            failed += compare_f64("se3 robustWeightCauchy", o_cw.data(), cw, tol);
+            ran += 5; row.ran += 5;
         } else {
-            ++listed;                                           // gate_points / gate_lines: see the header comment
+            ++listed; ++row.listed;                             // gate_points / gate_lines: see the header comment
         }
+        row.failed += failed - failed_before;
     }
+    std::printf("\n%-28s %8s %6s %6s %s\n", "golden file", "replayed", "PASS", "FAIL", "listed only");
+    for (const auto& kvp : table)
+        std::printf("%-28s %8d %6d %6d %d\n", kvp.first.c_str(), kvp.second.ran, kvp.second.ran - kvp.second.failed, kvp.second.failed,
+                    kvp.second.listed);
     std::printf("%d cases replayed, %d differ; %d stereo-gate cases listed for manual comparison\n", ran, failed, listed);
     return failed ? 1 : 0;
 }

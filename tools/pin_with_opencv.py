@@ -89,6 +89,7 @@ def main():
     print(f"match_golden.npz: {n} cases replayed through cv2.BFMatcher {cv2.__version__}: {len(bad)} difference(s)")
     for b in bad:
         print("  ", b)
+    table = [("match_golden.npz", n, n - len({b[0] for b in bad}), len({b[0] for b in bad}), "cv2.BFMatcher")]
     if a.stvo_module:
         try:
             stvo = importlib.import_module(a.stvo_module)
@@ -104,8 +105,14 @@ def main():
             gbad += int(not np.array_equal(got, g[f"{c}/m12"]))
         print(f"grid_golden.npz: {len(cases)} cases through {a.stvo_module}.matchGrid: {gbad} differ")
         bad += [("grid", gbad)] if gbad else []
+        table.append(("grid_golden.npz", len(cases), len(cases) - gbad, gbad, a.stvo_module))
     else:
-        print("matchGrid / stereo gates: need a stvo-pl build (--stvo-module); not replayed.")
+        print("matchGrid / stereo gates / SE(3) helpers: need a stvo-pl build (make -C tools/pin_stvo check, or --stvo-module); not replayed.")
+        table += [(f, 0, 0, 0, "needs stvo-pl: make -C tools/pin_stvo check STVO_PL_DIR=...")
+                  for f in ("grid_golden.npz", "stereo_gates_golden.npz", "se3_helpers_golden.npz")]
+    print(f"\n{'golden file':28s} {'replayed':>8s} {'PASS':>6s} {'FAIL':>6s}  through")
+    for f, n_, ok, ko, how in table:
+        print(f"{f:28s} {n_:8d} {ok:6d} {ko:6d}  {how}")
     return 1 if bad else 0
 
 
