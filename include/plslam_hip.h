@@ -100,6 +100,9 @@ void plslam_ctx_destroy(plslam_ctx* ctx);
  * "post_workgroups" (0 = default: one workgroup per block-table entry; n > 0: in a split run (plslam_match_plan_run_split) the
  * stages behind the scan -- K1h's merge of the column partials, the finalize kernel -- run as at most n workgroups that walk
  * their block tables, i.e. they hold a bounded number of workgroup slots beside the next scan; measured neutral to +1 %),
+ * "graph" (plslam_match_plan_run as ONE replayed HIP graph -- the run's launches captured on the caller's stream at its first
+ * use: 0 = plans of fewer waves than the chip has SIMDs | 1 = never (default: measured SLOWER on ROCm 7 -- C3's three-kernel
+ * run 26.9 us per back-to-back run against 22.3 us with plain launches) | 2 = always; never while profiling),
  * "fuse" (K1f: one workgroup per problem that also merges the column results and applies the ratio test + mutual
  * check, i.e. one kernel per plan run: 0 = auto (currently: never -- measured no faster) | 1 = never | 2 = always) */
 int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value);

@@ -109,6 +109,12 @@ struct plslam_match_plan {
     int32_t* d_gate_counts = nullptr;  // contiguous counters of the gate problems (or nullptr)
     plslam_plan_info info{};
     bool profiling = false;
+    // a run on one stream, captured once and replayed as a HIP graph (latency plans: a few small kernels whose launch
+    // overheads are the run; option "graph")
+    bool small = false;                // fewer waves than the chip has SIMDs (plan_build)
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_failed = false;
+    void drop_graph() { if (graph_exec) (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; graph_failed = false; }
     struct Ev { hipEvent_t e0, e1, e2; };
     std::vector<Ev> evs;
     // split runs (plslam_match_plan_run_split): the scan on one stream, everything behind it on another
@@ -127,6 +133,7 @@ struct plslam_match_plan {
         if (post_done) (void)hipEventDestroy(post_done);
         scan_done = post_done = nullptr;
         post_pending = false;
+        drop_graph();
     }
 };
 
@@ -155,6 +162,8 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     for (int32_t i = 0; i < nprob; ++i)
         if (probs[i].n1 > 0 && probs[i].n2 > 0) sym_evals += (int64_t)probs[i].n1 * probs[i].n2;
     const bool small_plan = thr_waves < simds;
+    P->small = small_plan;
+    P->drop_graph();                   // (a rebuilt plan launches other tables)
     const bool split_auto = ctx->scan_variant == PLSLAM_SCAN_AUTO && small_plan && sym_evals >= (int64_t(6) << 20) &&
                             ctx->mfma_form != 1;
     const bool split_forced = ctx->col_split == 2 && ctx->mfma_form != 1 &&
@@ -782,6 +791,11 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         ctx->col_split = value;
         return PLSLAM_OK;
     }
+    if (!strcmp(key, "graph")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= 2, PLSLAM_EINVAL);
+        ctx->graph = value;
+        return PLSLAM_OK;
+    }
     if (!strcmp(key, "post_workgroups")) {
         PLSLAM_REQUIRE(value >= 0, PLSLAM_EINVAL);
         ctx->post_workgroups = value;
@@ -803,6 +817,7 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "col_split")) { *value = ctx->col_split; return PLSLAM_OK; }
     if (!strcmp(key, "exact_second")) { *value = ctx->exact_second; return PLSLAM_OK; }
     if (!strcmp(key, "post_workgroups")) { *value = ctx->post_workgroups; return PLSLAM_OK; }
+    if (!strcmp(key, "graph")) { *value = ctx->graph; return PLSLAM_OK; }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
 }
@@ -850,6 +865,7 @@ int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_ste
     // replacing the stage frees / rewrites the tables a run still in flight (on whatever stream the caller used) reads: the
     // call is rare, so it simply waits for the device
     if (plan->ngate_blocks > 0 || plan->gate_tables.p) PLSLAM_HIP_CHECK(hipDeviceSynchronize());
+    if (plan->graph_exec) { PLSLAM_HIP_CHECK(hipDeviceSynchronize()); plan->drop_graph(); }      // the captured run has no gate stage
     plan->ngate_blocks = 0;
     plan->ngates = 0;
     plan->d_gate_counts = nullptr;
@@ -913,6 +929,28 @@ int plslam_match_plan_run(plslam_match_plan* plan, void* stream)
     PLSLAM_REQUIRE(plan != nullptr, PLSLAM_EINVAL);
     DeviceGuard g(plan->ctx->device);
     hipStream_t s = stream ? static_cast<hipStream_t>(stream) : plan->ctx->stream;
+    // Graph replay (option "graph": 0 = plans of fewer waves than the chip has SIMDs, 1 = never, 2 = always): the run's
+    // launches are captured once on the caller's stream and replayed with one hipGraphLaunch.  Not while profiling (the
+    // events belong to the run), not for a plan with a split run pending (its ordering event is not part of the graph).
+    const int gopt = plan->ctx->graph;
+    if (gopt != 1 && (gopt == 2 || plan->small) && !plan->profiling && !plan->post_pending && !plan->graph_failed) {
+        if (!plan->graph_exec) {
+            hipGraph_t gr = nullptr;
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                const int r = plan_run(plan, s, s);
+                const hipError_t e = hipStreamEndCapture(s, &gr);
+                if (r == PLSLAM_OK && e == hipSuccess && gr && hipGraphInstantiate(&plan->graph_exec, gr, nullptr, nullptr, 0) != hipSuccess)
+                    plan->graph_exec = nullptr;
+                if (gr) (void)hipGraphDestroy(gr);
+            }
+            (void)hipGetLastError();
+            if (!plan->graph_exec) plan->graph_failed = true;       // (this device / runtime cannot: plain launches from now on)
+        }
+        if (plan->graph_exec) {
+            PLSLAM_HIP_CHECK(hipGraphLaunch(plan->graph_exec, s));
+            return PLSLAM_OK;
+        }
+    }
     return plan_run(plan, s, s);
 }
 

@@ -205,13 +205,17 @@ def test_column_split_of_few_large_problems(ctx, oracle, shapes, mutual):
     got = {}
     try:
         for tag, variant, split in (("auto", plslam_amd.SCAN_AUTO, 0), ("split", plslam_amd.SCAN_MFMA, 2),
-                                    ("unsplit", plslam_amd.SCAN_MFMA, 1)):
+                                    ("unsplit", plslam_amd.SCAN_MFMA, 1), ("graph", plslam_amd.SCAN_AUTO, 0)):
             ctx.set_option("scan_variant", variant)
             ctx.set_option("col_split", split)
             ctx.set_option("exact_second", 1)          # the key tables are compared word for word below
+            ctx.set_option("graph", 2 if tag == "graph" else 1)     # the run captured once, replayed as a HIP graph
             plan = ctx.plan(probs)
             info = plan.info()
-            plan.run(0)
+            for m in outs:
+                m.fill_(-7)
+            for _ in range(3 if tag == "graph" else 1):            # (capture + two replays)
+                plan.run(0)
             torch.cuda.synchronize()
             keys, _ = plan.dump()
             got[tag] = (keys.copy(), [m.cpu().numpy().copy() for m in outs], cnt.cpu().numpy().copy(), info)
@@ -220,6 +224,7 @@ def test_column_split_of_few_large_problems(ctx, oracle, shapes, mutual):
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
         ctx.set_option("col_split", 0)
         ctx.set_option("exact_second", 0)
+        ctx.set_option("graph", 1)
     big = sum(n1 * n2 for n1, n2 in shapes) >= 6 << 20
     assert got["auto"][3]["scan_variant"] == (plslam_amd.SCAN_MFMA if big else plslam_amd.SCAN_WAVE_PER_QUERY)
     assert got["split"][3]["scan_blocks"] > got["unsplit"][3]["scan_blocks"]          # more workgroups, same work
@@ -227,7 +232,7 @@ def test_column_split_of_few_large_problems(ctx, oracle, shapes, mutual):
     assert np.array_equal(got["split"][0][:nkeys], got["unsplit"][0][:nkeys])
     for k, (a, b, _, _) in enumerate(host):
         em, en = oracle.match(a, b, 0.8, mutual)
-        for tag in ("auto", "split", "unsplit"):
+        for tag in ("auto", "split", "unsplit", "graph"):
             assert np.array_equal(got[tag][1][k], em), (tag, k)
             assert got[tag][2][k] == en, (tag, k)
 
@@ -490,7 +495,8 @@ def test_batched_scan_is_deterministic_under_load(ctx, mform, n_orb, n_lbd, pair
 
 
 @pytest.mark.parametrize("n_orb,n_lbd,pairs,mutual", [(1500, 200, 24, True), (300, 70, 96, True), (2100, 33, 8, True),
-                                                        (257, 4130, 4, True), (777, 130, 32, False), (40, 2500, 16, False)])
+                                                        (257, 4130, 4, True), (777, 130, 32, False), (40, 2500, 16, False),
+                                                        (2060, 513, 3, True)])   # 65 tiles: a second window of ONE tile; 17 tiles
 def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs, mutual):
     """K1f (group minima; the second best of the winner's group recomputed from the raw rows) against K1e (every key
     pushed): not only the match tables but every intermediate word -- keys12 = (best, second best) per row with the

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """C3 (one local map against one frame: 10 000 x 1500 ORB + 2 000 x 200 LBD, mutual) as ONE plan: time per run and the
-scan / post-scan split from the plan's own events.  usage: c3_time.py [col_split 0|1|2] [scan_variant]"""
+scan / post-scan split from the plan's own events.  usage: c3_time.py [col_split 0|1|2] [scan_variant] [mfma_form] [graph 0|1|2]"""
 import os
 import sys
 
@@ -14,10 +14,12 @@ from plslam_amd import synth
 split = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 form = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+graph = int(sys.argv[4]) if len(sys.argv) > 4 else 1
 ctx = plslam_amd.Context(0)
 ctx.set_option("col_split", split)
 ctx.set_option("scan_variant", variant)
 ctx.set_option("mfma_form", form)
+ctx.set_option("graph", graph)
 dev = torch.device("cuda", 0)
 r = np.random.Generator(np.random.PCG64(31))
 frame_p = synth.random_desc(r, 1500)
@@ -34,6 +36,7 @@ st = torch.cuda.Stream(device=dev)
 for _ in range(20):
     plan.run(st.cuda_stream)
 st.synchronize()
+ref_p, ref_l = m_p.clone(), m_l.clone()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 with torch.cuda.stream(st):
     e0.record(st)
@@ -47,5 +50,14 @@ for _ in range(20):
     plan.run(st.cuda_stream)
     st.synchronize()
 a, b, n = plan.elapsed()
+plan.set_profiling(False)
+import time
+t0 = time.perf_counter()
+for _ in range(200):
+    plan.run(st.cuda_stream)
+    st.synchronize()
+wall = (time.perf_counter() - t0) / 200
+assert torch.equal(ref_p, m_p) and torch.equal(ref_l, m_l)
+print(f"graph {graph}: run + synchronize from the host {1e6 * wall:.1f} us; ", end="")
 print(f"col_split {split} variant {variant} form {form}: {1e3 * e0.elapsed_time(e1) / 200:.1f} us per back-to-back run; serial runs: scan "
       f"{1e3 * a / n:.1f} us, post-scan {1e3 * b / n:.1f} us; info {plan.info()}")
