@@ -209,8 +209,11 @@ def main():
                              "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one rank per GPU: LOCAL_RANK is the device index -- unless the launcher masks the devices per process (each then sees one)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if local_rank < ndev else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -238,14 +241,15 @@ def main():
     ranks_seen = None
     if use_dist:
         props = torch.cuda.get_device_properties(dev)
-        ident = str(getattr(props, "uuid", "")) or f"{props.name}:{getattr(props, 'pci_bus_id', local_rank)}:{local_rank}"
+        hw = "|".join(str(getattr(props, k)) for k in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id") if hasattr(props, k))
+        ident = hw or f"unidentified:{rank}"          # (no hardware identifier exposed: the ranks cannot be told apart, nor accused)
         idents = [None] * world
         dist.all_gather_object(idents, ident)
         ranks_seen = {"world_size": dist.get_world_size(), "distinct_devices": len(set(idents))}
         if rank == 0 and ranks_seen["distinct_devices"] != world:
             raise SystemExit(f"{world} ranks on {ranks_seen['distinct_devices']} distinct devices: {idents}")
     note(f"synthetic stream of {B} pairs generated")
-    ctx = plslam_amd.Context(local_rank)     # raises if libplslam_hip.so / a gfx950 device is missing
+    ctx = plslam_amd.Context(dev_index)      # raises if libplslam_hip.so / a gfx950 device is missing
     for key, val in (("scan_variant", args.scan_variant), ("scan_block", args.scan_block), ("sym_rows", args.sym_rows),
                      ("group_cap", args.group_cap), ("mfma_form", args.mfma_form), ("fuse", args.fuse), ("post_workgroups", args.post_wgs)):
         if val:
