@@ -23,8 +23,8 @@
 //   PA  a lane per row: candidates in batches of 4, d = popcount(desc1[i1] ^ desc2[i2]).  Without bestLRMatches the
 //       best two (d << 23 | i2) keys are folded on the spot.  With it every candidate proposes itself as its column's
 //       first record (atomic min of i1 << 9 | d: the smallest row wins) and is kept for the record passes:
-//       * FLAT mode (everything in LDS, at most 2048 x 2048 rows -- the shipped sizes): a candidate is one word that names
-//         its row, d << 22 | i1 << 11 | i2, appended to the region of the wave that found it in the LDS that is still free
+//       * FLAT mode (everything in LDS and row + column numbers of at most 23 bits together -- 4096 x 2048, 8192 x 1024 ..:
+//         the shipped sizes): a candidate is one word that names its row, d << (b1 + b2) | i1 << b2 | i2, appended to the region of the wave that found it in the LDS that is still free
 //         (its share of the global store takes what does not fit).  colbest[i2] = the smallest (d, i1) shown for the column
 //         so far: a candidate that an EARLIER row matches or beats is dead whatever happens later and is never stored.
 //       * otherwise: one word per candidate in the lane's slots of a transposed global store -- slot k of lane t at
@@ -242,18 +242,23 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     PLSLAM_AS_GLOBAL uint32_t* round_k = rcnt + n1;                          // n_rounds
     PLSLAM_AS_GLOBAL uint32_t* store = round_k + n_rounds;  // 2 x pair_cap words; round r at 1024 * sum_{r' < r} round_k
 
-    // ---- "flat" mode (everything in LDS, bestLRMatches, row and column numbers of at most 11 bits): a candidate is ONE word
-    // that names its row, d << 22 | i1 << 11 | i2; PA appends the candidates of a wave's rows to the wave's own region of the
+    // ---- "flat" mode (everything in LDS, bestLRMatches, row and column numbers of at most 23 bits together): a candidate is ONE
+    // word that names its row, d << (fb1 + fb2) | i1 << fb2 | i2 (fb2 = bits of a column number, fb1 = what is left, at most
+    // 14: a column's record needs 9 bits for its pass number above i1 << 9 | d); PA appends the candidates of a wave's rows to the wave's own region of the
     // LDS that is still free (spilling into its share of the global store if it must), the record passes run on those
     // regions.  colbest[i2] = the smallest (d, i1) any row has shown for the column so far: a candidate that some EARLIER row
     // matches or beats is dead whatever else happens and is never stored.
     constexpr uint32_t NW = NT / 64;
     const uint32_t wv = (uint32_t)tid >> 6;
     bool flat = false;
+    uint32_t fb1 = 11, fb2 = 11;                    // bits of a row / column number in the flat words
     uint32_t seg_words = 0, tail_cap = 0, reg_off = 0;
     PLSLAM_AS_LDS uint32_t* colbest = nullptr;
     if constexpr (MODE == 2) {
-        flat = g.mutual && n1 <= 2048 && n2 <= 2048;
+        fb2 = 1;
+        while (fb2 < 22 && (1u << fb2) < (uint32_t)n2) ++fb2;
+        fb1 = 23u - fb2 > 14u ? 14u : 23u - fb2;
+        flat = g.mutual && (uint32_t)n2 <= (1u << fb2) && (uint32_t)n1 <= (1u << fb1);
         const uint32_t pa_end = d2_off + 8u * (uint32_t)n2 + (has_dirs ? 4u * (uint32_t)n2 : 0u);
         colbest = s_dyn + pa_end;
         reg_off = pa_end + (uint32_t)n2;
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                     if (i2[j] >= 0) {
                         // the first record pass, fused: the smallest row of a column is its first record
                         atomicMin((uint32_t*)&P.next[i2[j]], ((uint32_t)i1 << REC_D_BITS) | d[j]);
-                        was[j] = atomicMin((uint32_t*)&colbest[i2[j]], (d[j] << 11) | (uint32_t)i1);
+                        was[j] = atomicMin((uint32_t*)&colbest[i2[j]], (d[j] << fb1) | (uint32_t)i1);
                     }
                 }
                 bool keep[CB];
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < CB; ++j) {
                     // stored unless an earlier row is known to match or beat it (or the slot is empty)
-                    keep[j] = i2[j] >= 0 && !((was[j] >> 11) <= d[j] && (was[j] & 2047u) < (uint32_t)i1);
+                    keep[j] = i2[j] >= 0 && !((was[j] >> fb1) <= d[j] && (was[j] & ((1u << fb1) - 1u)) < (uint32_t)i1);
                     n_keep += keep[j] ? 1u : 0u;
                 }
                 if (n_keep) {
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
 #pragma unroll
                     for (int j = 0; j < CB; ++j)
                         if (keep[j]) {
-                            if (pos < seg_words + tail_cap) cand_store(pos, (d[j] << 22) | ((uint32_t)i1 << 11) | (uint32_t)i2[j]);
+                            if (pos < seg_words + tail_cap) cand_store(pos, (d[j] << (fb1 + fb2)) | ((uint32_t)i1 << fb2) | (uint32_t)i2[j]);
                             ++pos;
                         }
                 }
@@ -514,16 +519,18 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
             // ---- candidate-parallel passes: each wave works on its own region and compacts the survivors of a pass in
             // place (ballot + prefix: no other wave touches the region).
             // A column's record carries its pass number in the top bits, newest = smallest:
-            //     rec(t, i1, d) = (0xFFF - t) << 20 | i1 << 9 | d,
+            //     rec(t, i1, d) = (TMAX - t) << (9 + fb1) | i1 << 9 | d     (TMAX = all ones of the 23 - fb1 >= 9 bits above),
             // pass t reads the records of pass t-1 from one array and proposes with an atomic min into the other: a proposal
             // of pass t beats whatever pass t-2 left there, so nothing is cleared and nothing is installed -- one barrier per
             // pass.  (Every candidate that survives pass t-1 proposed in it: its column's word in the array pass t reads IS
             // a pass t-1 record.  A column has at most 257 records: the pass number fits.)  Live candidates join their
             // row's best two with two LDS atomic mins: k1 takes the key, whichever of (old k1, key) lost goes to k2 -- every
             // key of the row except the final minimum reaches k2 exactly once.
+            const uint32_t t_shift = REC_D_BITS + fb1, t_max = (1u << (32u - t_shift)) - 1u;
+            const uint32_t m1 = (1u << fb1) - 1u, m2 = (1u << fb2) - 1u;
             for (int32_t i2 = tid; i2 < n2; i2 += NT) {                // the first records: pass 0
                 const uint32_t v = P.state[i2];
-                if (v != KEY_NONE) P.state[i2] = 0xFFF00000u | v;
+                if (v != KEY_NONE) P.state[i2] = (t_max << t_shift) | v;
             }
             __syncthreads();
 #ifdef PLSLAM_GRID_TIMING
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
             auto run_pass = [&](uint32_t w, uint32_t alive, uint32_t t) -> uint32_t {
                 auto rd = (t & 1) ? P.state : P.next;
                 auto wr = (t & 1) ? P.next : P.state;
-                const uint32_t tag_rd = (0xFFFu - (t - 1)) << 20, tag_wr = (0xFFFu - t) << 20;
+                const uint32_t tag_rd = (t_max - (t - 1)) << t_shift, tag_wr = (t_max - t) << t_shift;
                 uint32_t out = 0;
                 for (uint32_t base = 0; base < alive; base += 64 * UN) {
                     uint32_t c[UN], rec[UN];
@@ -549,10 +556,10 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                         c[j] = k >= alive ? KEY_NONE : in_lds ? reg[k] : w == NW ? s_tail[k] : cand_load(k);
                     }
 #pragma unroll
-                    for (int j = 0; j < UN; ++j) rec[j] = rd[c[j] == KEY_NONE ? 0u : c[j] & 2047u];
+                    for (int j = 0; j < UN; ++j) rec[j] = rd[c[j] == KEY_NONE ? 0u : c[j] & m2];
 #pragma unroll
                     for (int j = 0; j < UN; ++j) {
-                        const uint32_t i2 = c[j] & 2047u, i1 = (c[j] >> 11) & 2047u, d = c[j] >> 22;
+                        const uint32_t i2 = c[j] & m2, i1 = (c[j] >> fb2) & m1, d = c[j] >> (fb1 + fb2);
                         const uint32_t me = (i1 << REC_D_BITS) | d;
                         keep[j] = false;
                         if (c[j] != KEY_NONE) {
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
             }
             for (int32_t i2 = tid; i2 < n2; i2 += NT) {                  // the newest record of either array, untagged
                 const uint32_t a = P.state[i2], b = P.next[i2], v = a < b ? a : b;
-                P.state[i2] = v == KEY_NONE ? KEY_NONE : v & 0xFFFFFu;
+                P.state[i2] = v == KEY_NONE ? KEY_NONE : v & ((1u << t_shift) - 1u);
             }
             __syncthreads();
         }

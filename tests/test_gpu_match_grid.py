@@ -44,12 +44,13 @@ def test_random_scenes_vs_oracle(ctx, oracle, kind, ties, mutual):
 def test_many_small_random_problems_vs_oracle(ctx, oracle):
     """Sweep of shapes for the LDS-resident mutual path (candidates filtered and kept per wave, candidate-parallel record
     passes): coarse grids (long column lists, many duplicates of a line's item across cells), windows from one cell to the
-    whole grid, ties, 1 .. 2048 rows (the packed-candidate limit) on 256- and 1024-lane workgroups."""
+    whole grid, ties, 1 .. 8192 rows on 256- and 1024-lane workgroups -- on both sides of the packed-candidate limit (row and
+    column numbers of 23 bits together: 4096 x 2048, 8192 x 1024 fit, 4097 x 1025 and 8192 x 1500 do not)."""
     r = _rng(99)
-    for it in range(48):
+    for it in range(60):
         lines = it % 3 == 0
-        n1 = int(r.choice([1, 2, 63, 64, 65, 255, 256, 257, 700, 1024, 1025, 2048]))
-        n2 = int(r.choice([1, 2, 40, 333, 1500, 2048]))
+        n1 = int(r.choice([1, 2, 63, 64, 65, 255, 256, 257, 700, 1024, 1025, 2048, 2049, 4096, 4097, 8192]))
+        n2 = int(r.choice([1, 2, 40, 333, 512, 1024, 1025, 1500, 2048]))
         cols, rows = [(1, 1), (2, 3), (7, 5), (16, 12), (64, 48)][it % 5]
         w = tuple(int(x) for x in r.integers(0, 4, 4)) if it % 4 else (cols, cols, rows, rows)
         c = (line_case if lines else point_case)(7000 + it, n1, n2, cols, rows, ties=it % 2 == 1)
@@ -177,8 +178,9 @@ def test_host_rows_need_no_alignment(ctx, oracle):
 
 def test_plan_batch_device_resident_and_overflow(ctx, oracle):
     """64 problems of mixed kind in ONE launch through plslam_grid_plan_*; a problem whose pair_capacity is too
-    small reports an overflow, matches nothing and leaves the others intact.  (Problem 11 has more than 2048 rows: such a
-    problem keeps its candidates in the global store alone; smaller ones use it only for what the LDS cannot hold.)"""
+    small reports an overflow, matches nothing and leaves the others intact.  (Problem 11 has more rows than the
+    candidate words of the LDS-resident form can name -- row and column numbers of 23 bits together, at most 14 for the row --:
+    such a problem keeps its candidates in the global store alone; smaller ones use it only for what the LDS cannot hold.)"""
     import torch
     dev = torch.device("cuda", ctx.device)
     keep, probs, refs = [], [], []
@@ -192,7 +194,7 @@ def test_plan_batch_device_resident_and_overflow(ctx, oracle):
         lines = b % 3 == 0
         n1, n2 = 50 + 37 * (b % 7), 40 + 29 * (b % 5)
         if b == 11:
-            n1 = 2100
+            n1 = 17000
         c = (line_case if lines else point_case)(500 + b, n1, n2, 16, 12, ties=b % 2 == 1)
         w = (2, 2, 2, 2) if b % 4 else (4, 0, 0, 0)
         mutual = b % 5 != 0
