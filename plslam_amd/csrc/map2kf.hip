@@ -15,6 +15,11 @@
 
 namespace plslam {
 
+// match_grid.hip: one matchGrid problem on `s`, with its scratch (a large mutual problem gets its distances from a
+// many-workgroup launch)
+int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux);
+size_t grid_aux_words(int32_t n2);            // the words the two launches share, prefilled by grid_aux_fill in the upload image
+void grid_aux_fill(void* host_image, int32_t n2);
 // match_grid.hip: capacity of the windowed matcher's candidate store from the grid alone
 int64_t grid_store_capacity_bound(int32_t n1, int32_t n_centres, const int32_t* cell_start, int32_t cols, int32_t rows,
                                   const int32_t window[4], int mutual);
@@ -135,7 +140,7 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     // the projected cells and the query directions
     Carve cf;
     const size_t oSt = cf.take(16), oCs = cf.take(cs.size() * 4), oIt = cf.take((size_t)(n_items + 1) * 4),
-                 oD2 = cf.take(lines ? (size_t)nt * 16 : 0), oDesc = cf.take(sizeof(GridDesc));
+                 oD2 = cf.take(lines ? (size_t)nt * 16 : 0), oDesc = cf.take(sizeof(GridDesc)), oAux = cf.take(grid_aux_words(nt) * 4);
     const size_t image = cf.off;
     const size_t oCen = cf.take((size_t)nq * nc * 8), oD1 = cf.take(lines ? (size_t)nq * 16 : 0);
     if ((rc = ctx->pin_misc.reserve(image))) return rc;
@@ -168,11 +173,12 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     q.matches_12 = d_m12; q.n_matches = in_place ? res_dev : (int32_t*)(f + oSt);
     if ((rc = grid_prepare_one(q, ctx->misc_c.as<uint32_t>(), in_place ? nullptr : (int32_t*)(f + oSt) + 1, (GridDesc*)(h + oDesc))))
         return rc;
+    grid_aux_fill(h + oAux, nt);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(f, h, image, hipMemcpyHostToDevice, s));      // (zeroes the device result words too)
     if ((rc = launch_project_cells(*K, T16, d_X3, nq, lines, sx, sy, (int32_t*)(f + oCen),
                                    lines ? (double*)(f + oD1) : nullptr, s)))
         return rc;
-    if ((rc = grid_launch_prepared(q, (const GridDesc*)(f + oDesc), s))) return rc;
+    if ((rc = grid_launch_single(q, (const GridDesc*)(f + oDesc), s, (uint32_t*)(f + oAux)))) return rc;
     if (!in_place) PLSLAM_HIP_CHECK(hipMemcpyAsync(res_host, f + oSt, 8, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     sg.dismiss();

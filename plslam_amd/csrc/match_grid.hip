@@ -179,8 +179,14 @@ __device__ __forceinline__ void for_candidates(const GridDesc& g, const GridPtrs
 // NT lanes per workgroup: 1024, or 256 for problems of at most 256 rows (a 200-line problem would leave 12 of 16 waves
 // idle at every barrier -- and, in a batch, occupy a whole CU)
 template <int MODE, int NT>
-__global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ probs, uint32_t lds_words)
+__global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ probs, uint32_t lds_words, const uint32_t* __restrict__ pre)
 {
+    // pre != nullptr (one LDS-resident mutual problem alone on the chip, MODE 2): PA's distances were evaluated by
+    // k_grid_candidates on many workgroups -- every candidate word lies in the second half of the problem's candidate store,
+    // pre[0] = their number --, this kernel does the bookkeeping over them (candidate-parallel: first records, the filter of
+    // candidates an earlier row matches or beats, the waves' shares), then runs the record passes and PC.
+    // (The two per-column atomic minima of the bookkeeping as GLOBAL atomics in k_grid_candidates instead: that kernel 10.5 ->
+    // 16.1 us, this one 42.6 -> 39.4 us -- device-scope atomics are slower than one CU's LDS pipe is busy.)
     constexpr bool LDS = MODE >= 1;
     extern __shared__ u32x4 s_dyn4[];
     __shared__ uint32_t s_part[NT];
@@ -259,7 +265,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         while (fb2 < 22 && (1u << fb2) < (uint32_t)n2) ++fb2;
         fb1 = 23u - fb2 > 14u ? 14u : 23u - fb2;
         flat = g.mutual && (uint32_t)n2 <= (1u << fb2) && (uint32_t)n1 <= (1u << fb1);
-        const uint32_t pa_end = d2_off + 8u * (uint32_t)n2 + (has_dirs ? 4u * (uint32_t)n2 : 0u);
+        // (pre: neither the items nor the desc2 rows are needed here -- their LDS goes to the candidates)
+        const uint32_t pa_end = pre ? items_off : d2_off + 8u * (uint32_t)n2 + (has_dirs ? 4u * (uint32_t)n2 : 0u);
         colbest = s_dyn + pa_end;
         reg_off = pa_end + (uint32_t)n2;
         tail_cap = (uint32_t)g.pair_cap / NW;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     if constexpr (LDS) {
         for (int32_t j = tid; j <= ncell; j += NT) s_dyn[2 * (n2 + n1) + j] = (uint32_t)g_cell_start[j];
     }
-    if constexpr (MODE == 2) {
+    if (MODE == 2 && !pre) {
         PLSLAM_AS_LDS int32_t* li = (PLSLAM_AS_LDS int32_t*)(s_dyn + items_off);
         for (int32_t j = tid; j < g.n_items; j += NT) li[j] = g_items[j];
         PLSLAM_AS_LDS u32x4* lt = (PLSLAM_AS_LDS u32x4*)(s_dyn + d2_off);
@@ -338,9 +345,50 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         if (count_empty)
             for (int32_t r = 0; r < n_rounds && r < 32; ++r)
                 if (r * NT + tid < n1 && count_items(g, P, r * NT + tid) > 0u) has_items |= 1u << r;
+        if (pre) {
+            // the candidate words of k_grid_candidates: bookkeeping in two candidate-parallel sweeps.  First every candidate
+            // proposes itself as its column's first record and shows its (d, row) to colbest; then, colbest being final, a
+            // candidate that an earlier row matches or beats is dropped and the others go to the waves' regions, evenly.
+            const uint32_t total = *(PLSLAM_AS_GLOBAL const uint32_t*)pre;
+            PLSLAM_AS_GLOBAL const uint32_t* raw = store + (uint32_t)g.pair_cap;
+            if (total > (uint32_t)g.pair_cap) {                         // (uniform) the list did not fit: report, match nothing
+                for (int32_t i = tid; i < n1; i += NT) g_matches[i] = -1;
+                if (tid == 0) {
+                    if (g.n_matches) *g_(g.n_matches) = -1;
+                    if (g.status) (void)atomic_add_global(g.status, 1);
+                }
+                return;
+            }
+            const uint32_t mk1 = (1u << fb1) - 1u, mk2 = (1u << fb2) - 1u;
+            for (uint32_t k = (uint32_t)tid; k < total; k += NT) {
+                const uint32_t c = raw[k], i2 = c & mk2, i1 = (c >> fb2) & mk1, d = c >> (fb1 + fb2);
+                atomicMin((uint32_t*)&P.next[i2], (i1 << REC_D_BITS) | d);
+                atomicMin((uint32_t*)&colbest[i2], (d << fb1) | i1);
+            }
+            __syncthreads();
+            const uint32_t lo = (uint32_t)((uint64_t)total * wv / NW), hi = (uint32_t)((uint64_t)total * (wv + 1) / NW);
+            const uint64_t below_ = (1ull << lane) - 1ull;
+            uint32_t out = 0;
+            for (uint32_t base = lo; base < hi; base += 64) {
+                const uint32_t k = base + (uint32_t)lane;
+                const uint32_t c = k < hi ? raw[k] : KEY_NONE;
+                bool keep_ = false;
+                if (c != KEY_NONE) {
+                    const uint32_t i2 = c & mk2, i1 = (c >> fb2) & mk1, d = c >> (fb1 + fb2), cb = colbest[i2];
+                    keep_ = !((cb >> fb1) <= d && (cb & mk1) < i1);
+                }
+                const uint64_t m = __ballot(keep_);
+                if (keep_) {
+                    const uint32_t pos = out + (uint32_t)__popcll(m & below_);
+                    if (pos < seg_words + tail_cap) cand_store(pos, c);
+                }
+                out += (uint32_t)__popcll(m);
+            }
+            if (lane == 0) s_cur[wv] = out;
+        }
         // a lane per (row, part of the row's window columns): rows differ a lot in their number of candidates, quarters of
         // rows much less, and there are four times as many of them to even out the lanes of a wave
-        for (int32_t task = tid; task < n_tasks; task += NT) {
+        for (int32_t task = tid; task < (pre ? 0 : n_tasks); task += NT) {
             const int32_t i1 = task >> split_log;
             const u32x4 qa = g_d1[2 * (int64_t)i1], qb = g_d1[2 * (int64_t)i1 + 1];
             for_candidates(g, P, i1, [&](const int32_t (&i2)[CB]) {
@@ -704,6 +752,84 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
 #undef GRID_STAMP
 }
 
+
+// PA of ONE LDS-resident mutual problem spread over the chip (k_match_grid with `pre` does the rest): a lane per (row, window
+// column) -- `split` = the window's width in cells, at most GRID_SPLIT_MAX: a lane's chain of dependent reads is centre -> cell
+// offsets -> items -> desc2 rows, once --, 256 tasks per workgroup, every table read from global memory (the grid and the desc2 rows are
+// a few tens of KB: L2).  A single workgroup spends two thirds of its time here -- a few 10^4 distances behind scattered
+// reads, with the lanes of a wave unevenly loaded -- while 255 CUs idle.  The candidate words (d << (b1 + b2) | i1 << b2 | i2,
+// as in the flat mode) of a workgroup are collected in LDS and appended to the list in the SECOND half of the problem's
+// candidate store (one global atomic per workgroup; aux[0] = the list's length, zero when the kernel starts); their order in the
+// list is whatever the scheduling made it -- nothing downstream depends on it (every combination is a min of keys).
+constexpr uint32_t GRID_CAND_BUF = 6144;            // candidate words a workgroup collects before they go out (24 KB)
+__global__ __launch_bounds__(256) void k_grid_candidates(const GridDesc* __restrict__ probs, uint32_t* __restrict__ aux, int split)
+{
+    __shared__ uint32_t s_buf[GRID_CAND_BUF];
+    __shared__ uint32_t s_n, s_base;
+    const GridDesc g = probs[0];
+    const int tid = (int)threadIdx.x;
+    const int32_t n1 = g.n1, n2 = g.n2;
+    const int32_t ncell = g.cols * g.rows;
+    uint32_t fb2 = 1;
+    while (fb2 < 22 && (1u << fb2) < (uint32_t)n2) ++fb2;
+    const uint32_t fb1 = 23u - fb2 > 14u ? 14u : 23u - fb2;
+    GridPtrs<0> P;
+    P.cs = (PLSLAM_AS_GLOBAL const uint32_t*)g.cell_start;
+    P.items = (PLSLAM_AS_GLOBAL const int32_t*)g.cell_items;
+    P.d2 = (PLSLAM_AS_GLOBAL const u32x4*)g.d2;
+    P.centres = (PLSLAM_AS_GLOBAL const int32_t*)g.centres;
+    P.dir1 = (PLSLAM_AS_GLOBAL const double*)g.dir1;
+    P.dir2 = (PLSLAM_AS_GLOBAL const double*)g.dir2;
+    P.state = P.next = P.row_k1 = P.row_k2 = nullptr;
+    // the scratch layout of k_match_grid<2, 1024>: slot counts n1 | round depths | candidate store 2 x pair_cap
+    PLSLAM_AS_GLOBAL uint32_t* rcnt = (PLSLAM_AS_GLOBAL uint32_t*)g.scratch;
+    PLSLAM_AS_GLOBAL uint32_t* raw = rcnt + n1 + (n1 + GRID_THREADS - 1) / GRID_THREADS + (uint32_t)g.pair_cap;
+    PLSLAM_AS_GLOBAL const u32x4* g_d1 = (PLSLAM_AS_GLOBAL const u32x4*)g.d1;
+    uint32_t* const counter = aux;
+    if (tid == 0) s_n = 0u;
+    __syncthreads();
+    const int64_t task = (int64_t)blockIdx.x * 256 + tid;
+    if (task < (int64_t)n1 * split && (uint32_t)P.cs[ncell] <= (uint32_t)g.n_items) {      // (an inconsistent grid: k_match_grid reports it)
+        const int32_t i1 = (int32_t)(task / split), part = (int32_t)(task - (int64_t)i1 * split);
+        const u32x4 qa = g_d1[2 * (int64_t)i1], qb = g_d1[2 * (int64_t)i1 + 1];
+        for_candidates(g, P, i1, [&](const int32_t (&i2)[CB]) {
+            u32x4 ta[CB], tb[CB];
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const int64_t t = i2[j] < 0 ? 0 : i2[j];
+                ta[j] = P.d2[2 * t];
+                tb[j] = P.d2[2 * t + 1];
+            }
+            uint32_t n_keep = 0;
+#pragma unroll
+            for (int j = 0; j < CB; ++j) n_keep += i2[j] >= 0 ? 1u : 0u;
+            if (n_keep) {
+                uint32_t pos = atomicAdd(&s_n, n_keep);               // one claim per batch
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+                    if (i2[j] >= 0) {
+                        const uint32_t d = (uint32_t)(__popc(qa.x ^ ta[j].x) + __popc(qa.y ^ ta[j].y) + __popc(qa.z ^ ta[j].z) +
+                                                      __popc(qa.w ^ ta[j].w) + __popc(qb.x ^ tb[j].x) + __popc(qb.y ^ tb[j].y) +
+                                                      __popc(qb.z ^ tb[j].z) + __popc(qb.w ^ tb[j].w));
+                        const uint32_t word = (d << (fb1 + fb2)) | ((uint32_t)i1 << fb2) | (uint32_t)i2[j];
+                        if (pos < GRID_CAND_BUF) s_buf[pos] = word;
+                        else {                                        // (a very dense grid) straight to the list
+                            const uint32_t gp = (uint32_t)atomic_add_global(counter, 1);
+                            if (gp < (uint32_t)g.pair_cap) raw[gp] = word;
+                        }
+                        ++pos;
+                    }
+            }
+        }, part, split);
+    }
+    __syncthreads();
+    const uint32_t n = s_n < GRID_CAND_BUF ? s_n : GRID_CAND_BUF;
+    if (tid == 0) s_base = n ? (uint32_t)atomic_add_global(counter, (int)n) : 0u;
+    __syncthreads();
+    for (uint32_t k = (uint32_t)tid; k < n; k += 256u)
+        if (s_base + k < (uint32_t)g.pair_cap) raw[s_base + k] = s_buf[k];
+}
+
 }  // namespace
 
 // words of the tables that live in LDS when they fit (cell_start copy + column / row words)
@@ -786,6 +912,8 @@ int64_t grid_store_capacity_bound(int32_t n1, int32_t n_centres, const int32_t* 
     return per_row * GRID_THREADS * ((n1 + GRID_THREADS - 1) / GRID_THREADS);
 }
 
+constexpr int GRID_SPLIT_MAX = 16;         // ... with at most this many lanes per row (one per window column)
+constexpr int GRID_SPLIT_MIN_ROWS = 512;   // one problem alone: from this many rows on PA runs as its own many-workgroup launch
 constexpr int GRID_SMALL_ROWS = 256;    // problems of at most this many rows run on 256-lane workgroups (MODE 2 only)
 
 // launch groups: 0 = tables in global scratch, 1 = tables in LDS, 2 = everything in LDS / 1024 lanes, 3 = everything in
@@ -811,7 +939,7 @@ size_t grid_group_lds_bytes(int group, int32_t n1, int32_t n2, int64_t ncell, in
 }
 
 template <int MODE, int NT>
-static int launch_group(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hipStream_t s)
+static int launch_group(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hipStream_t s, const uint32_t* pre = nullptr)
 {
     if (n <= 0) return PLSLAM_OK;
     if (MODE > 0) {
@@ -824,9 +952,43 @@ static int launch_group(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hi
         PLSLAM_HIP_CHECK(attr);
     }
     hipLaunchKernelGGL((k_match_grid<MODE, NT>), dim3((unsigned)n), dim3(NT), lds_bytes, s, d_probs,
-                       (uint32_t)(lds_bytes / 4));
+                       (uint32_t)(lds_bytes / 4), pre);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
+}
+
+// ONE problem on `s`: a mutual problem that runs LDS-resident with packed candidate words (what k_match_grid decides for
+// itself: row and column numbers of 23 bits together) and has enough rows to be worth a second launch gets its distances
+// from k_grid_candidates on many workgroups, then k_match_grid<2, 1024> with pre = 1; everything else is one launch.
+// aux = grid_aux_words(n2) device words the two launches share -- [0] the candidate list's length -- holding zero when the
+// launches reach them: callers upload an image anyway and put them there (grid_aux_fill).  Without it (nullptr) the problem is
+// one launch.
+size_t grid_aux_words(int32_t) { return 4; }
+void grid_aux_fill(void* host_image, int32_t n2) { memset(host_image, 0, grid_aux_words(n2) * 4); }
+int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux)
+{
+    const int64_t ncell = (int64_t)q.grid_cols * q.grid_rows;
+    const bool dirs = q.dir1 != nullptr && q.dir2 != nullptr;
+    int group = grid_group(q.n1, q.n2, ncell, q.n_items, dirs);
+    // ONE problem: nothing shares the CU, and a mutual problem of <= 256 rows still has up to 1024 (row, window part) tasks
+    if (group == 3 && q.mutual && q.n1 * GRID_SPLIT > GRID_SMALL_ROWS) group = 2;
+    uint32_t fb2 = 1;
+    while (fb2 < 22 && (1u << fb2) < (uint32_t)q.n2) ++fb2;
+    const uint32_t fb1 = 23u - fb2 > 14u ? 14u : 23u - fb2;
+    const bool flat = q.mutual && (uint32_t)q.n2 <= (1u << fb2) && (uint32_t)q.n1 <= (1u << fb1);
+    if (group == 2 && flat && aux && q.n1 >= GRID_SPLIT_MIN_ROWS && q.n2 > 0 && q.pair_capacity > 0) {
+        const int64_t wx = std::min<int64_t>((int64_t)q.window[0] + q.window[1] + 1, q.grid_cols);
+        const int split = (int)std::max<int64_t>(1, std::min<int64_t>(wx, GRID_SPLIT_MAX));
+        const unsigned nwg = (unsigned)(((int64_t)q.n1 * split + 255) / 256);
+        hipLaunchKernelGGL(k_grid_candidates, dim3(nwg), dim3(256), 0, s, d_desc, aux, split);
+        PLSLAM_HIP_CHECK(hipGetLastError());
+        return launch_group<2, 1024>(d_desc, 1, grid_group_lds_bytes(2, q.n1, q.n2, ncell, q.n_items, dirs), s, aux);
+    }
+    int32_t n_mode[4] = {0, 0, 0, 0};
+    size_t lds_bytes[4] = {0, 0, 0, 0};
+    n_mode[group] = 1;
+    lds_bytes[group] = grid_group_lds_bytes(group, q.n1, q.n2, ncell, q.n_items, dirs);
+    return launch_match_grid(d_desc, n_mode, lds_bytes, s);
 }
 
 // d_probs: the problems of group 3 first, then group 2, 1, 0; lds_bytes[g] = the largest grid_group_lds_bytes() in group g
@@ -906,16 +1068,7 @@ int grid_prepare_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* s
 }
 int grid_launch_prepared(const plslam_grid_problem& q, const GridDesc* d_desc_slot, hipStream_t s)
 {
-    const int64_t ncell = (int64_t)q.grid_cols * q.grid_rows;
-    const bool dirs = q.dir1 != nullptr && q.dir2 != nullptr;
-    int group = grid_group(q.n1, q.n2, ncell, q.n_items, dirs);
-    // ONE problem: nothing shares the CU, and a mutual problem of <= 256 rows still has up to 1024 (row, window part) tasks
-    if (group == 3 && q.mutual && q.n1 * GRID_SPLIT > GRID_SMALL_ROWS) group = 2;
-    int32_t n_mode[4] = {0, 0, 0, 0};
-    size_t lds_bytes[4] = {0, 0, 0, 0};
-    n_mode[group] = 1;
-    lds_bytes[group] = grid_group_lds_bytes(group, q.n1, q.n2, ncell, q.n_items, dirs);
-    return launch_match_grid(d_desc_slot, n_mode, lds_bytes, s);
+    return grid_launch_single(q, d_desc_slot, s, nullptr);       // (no shared words: one launch)
 }
 // h_desc_slot must stay valid until the copy is done (pinned or synchronised by the caller)
 int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* d_desc_slot,
@@ -924,7 +1077,7 @@ int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32
     int rc;
     if ((rc = grid_prepare_one(q, scratch, status, h_desc_slot))) return rc;
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d_desc_slot, h_desc_slot, sizeof(GridDesc), hipMemcpyHostToDevice, s));
-    return grid_launch_prepared(q, d_desc_slot, s);
+    return grid_launch_single(q, d_desc_slot, s, nullptr);
 }
 }  // namespace plslam
 
@@ -1046,7 +1199,7 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     // ONE pinned staging block -> one H2D copy: [GridDesc | centres | cell_start | cell_items | d1 | d2 | dir1 | dir2]
     Carver ci;
     const bool dirs = dir1 && dir2 && n2 > 0;
-    const size_t oT = ci.take(sizeof(GridDesc)), oC = ci.take((size_t)n1 * n_centres * 8),
+    const size_t oT = ci.take(sizeof(GridDesc)), oX = ci.take(grid_aux_words(n2) * 4), oC = ci.take((size_t)n1 * n_centres * 8),
                  oS = ci.take((size_t)(ncell + 1) * 4), oI = ci.take((size_t)n_items * 4),
                  oA = ci.take((size_t)n1 * 32), oB = ci.take((size_t)n2 * 32),
                  oD1 = ci.take(dirs ? (size_t)n1 * 16 : 0), oD2 = ci.take(dirs ? (size_t)n2 * 16 : 0);
@@ -1090,17 +1243,12 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     if ((rc = grid_check_problem(dq))) return rc;                 // what the kernel reads: the staged, aligned rows
     // (no status word over PCIe -- it is bumped with an atomic; an overflow also shows as a count of -1)
     grid_fill_desc(dq, ctx->misc_a.as<uint32_t>(), hout_dev ? nullptr : (int32_t*)(dout + oN) + 1, (GridDesc*)(h + oT));
+    grid_aux_fill(h + oX, n2);
     hipStream_t s = ctx->stream;
     StreamSyncOnError sg(s);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, ci.off, hipMemcpyHostToDevice, s));
     if (!hout_dev) PLSLAM_HIP_CHECK(hipMemsetAsync(dout + oN, 0, 8, s));
-    int group = grid_group(n1, n2, ncell, n_items, dirs);
-    if (group == 3 && mutual && n1 * GRID_SPLIT > GRID_SMALL_ROWS) group = 2;     // one problem: see launch_match_grid_one
-    int32_t n_mode[4] = {0, 0, 0, 0};
-    size_t lds_bytes[4] = {0, 0, 0, 0};
-    n_mode[group] = 1;
-    lds_bytes[group] = grid_group_lds_bytes(group, n1, n2, ncell, n_items, dirs);
-    if ((rc = launch_match_grid((const GridDesc*)(d + oT), n_mode, lds_bytes, s))) return rc;
+    if ((rc = grid_launch_single(dq, (const GridDesc*)(d + oT), s, (uint32_t*)(d + oX)))) return rc;
     if (!hout_dev) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, dout, co.off, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     const int32_t* res = (const int32_t*)(ctx->pin_out.as<char>() + oN);
