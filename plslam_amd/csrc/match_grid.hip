@@ -360,29 +360,46 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                 return;
             }
             const uint32_t mk1 = (1u << fb1) - 1u, mk2 = (1u << fb2) - 1u;
-            for (uint32_t k = (uint32_t)tid; k < total; k += NT) {
-                const uint32_t c = raw[k], i2 = c & mk2, i1 = (c >> fb2) & mk1, d = c >> (fb1 + fb2);
-                atomicMin((uint32_t*)&P.next[i2], (i1 << REC_D_BITS) | d);
-                atomicMin((uint32_t*)&colbest[i2], (d << fb1) | i1);
+            // (the list comes from L2: PRE_UN independent loads in flight per lane -- one load per loop trip made the two sweeps
+            // 18 us of dependent round trips)
+            constexpr int PRE_UN = 8;
+            for (uint32_t k0 = (uint32_t)tid; k0 < total; k0 += NT * PRE_UN) {
+                uint32_t c[PRE_UN];
+#pragma unroll
+                for (int j = 0; j < PRE_UN; ++j) c[j] = k0 + (uint32_t)j * NT < total ? raw[k0 + (uint32_t)j * NT] : KEY_NONE;
+#pragma unroll
+                for (int j = 0; j < PRE_UN; ++j)
+                    if (c[j] != KEY_NONE) {
+                        const uint32_t i2 = c[j] & mk2, i1 = (c[j] >> fb2) & mk1, d = c[j] >> (fb1 + fb2);
+                        atomicMin((uint32_t*)&P.next[i2], (i1 << REC_D_BITS) | d);
+                        atomicMin((uint32_t*)&colbest[i2], (d << fb1) | i1);
+                    }
             }
             __syncthreads();
             const uint32_t lo = (uint32_t)((uint64_t)total * wv / NW), hi = (uint32_t)((uint64_t)total * (wv + 1) / NW);
             const uint64_t below_ = (1ull << lane) - 1ull;
             uint32_t out = 0;
-            for (uint32_t base = lo; base < hi; base += 64) {
-                const uint32_t k = base + (uint32_t)lane;
-                const uint32_t c = k < hi ? raw[k] : KEY_NONE;
-                bool keep_ = false;
-                if (c != KEY_NONE) {
-                    const uint32_t i2 = c & mk2, i1 = (c >> fb2) & mk1, d = c >> (fb1 + fb2), cb = colbest[i2];
-                    keep_ = !((cb >> fb1) <= d && (cb & mk1) < i1);
+            for (uint32_t base = lo; base < hi; base += 64 * PRE_UN) {
+                uint32_t c[PRE_UN];
+#pragma unroll
+                for (int j = 0; j < PRE_UN; ++j) {
+                    const uint32_t k = base + 64u * (uint32_t)j + (uint32_t)lane;
+                    c[j] = k < hi ? raw[k] : KEY_NONE;
                 }
-                const uint64_t m = __ballot(keep_);
-                if (keep_) {
-                    const uint32_t pos = out + (uint32_t)__popcll(m & below_);
-                    if (pos < seg_words + tail_cap) cand_store(pos, c);
+#pragma unroll
+                for (int j = 0; j < PRE_UN; ++j) {
+                    bool keep_ = false;
+                    if (c[j] != KEY_NONE) {
+                        const uint32_t i2 = c[j] & mk2, i1 = (c[j] >> fb2) & mk1, d = c[j] >> (fb1 + fb2), cb = colbest[i2];
+                        keep_ = !((cb >> fb1) <= d && (cb & mk1) < i1);
+                    }
+                    const uint64_t m = __ballot(keep_);
+                    if (keep_) {
+                        const uint32_t pos = out + (uint32_t)__popcll(m & below_);
+                        if (pos < seg_words + tail_cap) cand_store(pos, c[j]);
+                    }
+                    out += (uint32_t)__popcll(m);
                 }
-                out += (uint32_t)__popcll(m);
             }
             if (lane == 0) s_cur[wv] = out;
         }
