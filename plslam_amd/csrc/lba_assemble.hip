@@ -13,8 +13,8 @@
 //   K8  k_cross_blocks<DL>      one lane per observation: W = J_lm * J_pose^T * w (DLx6)
 //   K9  k_pose_partials/_blocks one lane per (keyframe, chunk, entry) then per (keyframe, entry):
 //                                H_pp (6x6) and g_p (6) over the keyframe's observations (points
-//                                first, then lines, list order; 128-observation chunks)
-//   K10 k_weighted_error        err = sum r^2 w (fixed-shape tree: deterministic, not sequential)
+//                                first, then lines, list order; 64-observation chunks)
+//   K10 k_weighted_error_*      err = sum r^2 w (fixed-shape two-level tree: deterministic, not sequential)
 #include <algorithm>
 #include <new>
 #include <vector>
@@ -85,7 +85,7 @@ k_cross_blocks(const int32_t* __restrict__ kf_loc, int32_t nobs, const double* _
 // partials are summed sequentially in chunk order.  (A single sequential chain over the ~6700
 // observations of a C3 keyframe is bit-identical to the reference's dense accumulation but takes
 // 1.9 ms on 9 workgroups; this takes microseconds and differs from it by rounding only.)
-constexpr int POSE_CHUNK = 128;
+constexpr int POSE_CHUNK = 64;
 
 __global__ void __launch_bounds__(64)
 k_pose_partials(const int32_t* __restrict__ kf_ptr, const int32_t* __restrict__ kf_obs, int32_t n_pt_obs,
@@ -99,14 +99,29 @@ k_pose_partials(const int32_t* __restrict__ kf_ptr, const int32_t* __restrict__ 
     const int end = beg + POSE_CHUNK < kf_ptr[k + 1] ? beg + POSE_CHUNK : kf_ptr[k + 1];
     const int a = e < 36 ? e / 6 : e - 36, b = e < 36 ? e % 6 : 0;
     double acc = 0.0;
-    for (int i = beg; i < end; ++i) {
-        const int o = kf_obs[i];       // global observation id: points [0, n_pt_obs), then lines
-        const bool pt = o < n_pt_obs;
-        const int oo = pt ? o : o - n_pt_obs;
-        const double* J = (pt ? Jp_pt : Jp_ls) + (size_t)oo * 6;
-        const double ww = (pt ? w_pt : w_ls)[oo];
-        if (e < 36) acc += J[a] * J[b] * ww;
-        else acc += J[a] * (pt ? r_pt : r_ls)[oo] * ww;
+    // Same terms, same order -- the loads of PB observations are issued together (the loop was a chain of two dependent round
+    // trips per observation: 128 of them = 48 us for work that takes microseconds)
+    constexpr int PB = 16;
+    for (int i0 = beg; i0 < end; i0 += PB) {
+        int oo[PB];
+        bool pt[PB];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const int o = kf_obs[i0 + j < end ? i0 + j : end - 1];      // global observation id: points [0, n_pt_obs), then lines
+            pt[j] = o < n_pt_obs;
+            oo[j] = pt[j] ? o : o - n_pt_obs;
+        }
+        double ja[PB], jb[PB], ww[PB];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) {
+            const double* J = (pt[j] ? Jp_pt : Jp_ls) + (size_t)oo[j] * 6;
+            ja[j] = J[a];
+            jb[j] = e < 36 ? J[b] : (pt[j] ? r_pt : r_ls)[oo[j]];
+            ww[j] = (pt[j] ? w_pt : w_ls)[oo[j]];
+        }
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            if (i0 + j < end) acc += ja[j] * jb[j] * ww[j];
     }
     part[((size_t)k * max_chunks + c) * 42 + e] = acc;   // empty chunks write 0
 }
@@ -119,27 +134,68 @@ k_pose_blocks(const int32_t* __restrict__ kf_ptr, int32_t max_chunks, const doub
     if (e >= 42) return;
     const int nchunks = (kf_ptr[k + 1] - kf_ptr[k] + POSE_CHUNK - 1) / POSE_CHUNK;
     double acc = 0.0;
-    for (int c = 0; c < nchunks; ++c) acc += part[((size_t)k * max_chunks + c) * 42 + e];
+    constexpr int PB = 8;                       // (same order of additions; the loads in batches)
+    for (int c0 = 0; c0 < nchunks; c0 += PB) {
+        double v[PB];
+#pragma unroll
+        for (int j = 0; j < PB; ++j) v[j] = part[((size_t)k * max_chunks + (c0 + j < nchunks ? c0 + j : nchunks - 1)) * 42 + e];
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            if (c0 + j < nchunks) acc += v[j];
+    }
     if (e < 36) Hpp[(size_t)k * 36 + e] = acc;
     else gp[(size_t)k * 6 + (e - 36)] = acc;
 }
 
+// err = sum r^2 w in a fixed shape: ERR_BLOCKS workgroups of 256 lanes -- lane g of all ERR_BLOCKS x 256 sums observations g,
+// g + ERR_BLOCKS x 256, ... (points, then lines) in that order, a tree over the workgroup's lanes -> err[1 + block] -- then one
+// wave's tree over the ERR_BLOCKS partials -> err[0].  (One workgroup alone read the 0.96 MB of a C3 pass at a single CU's
+// 60 GB/s: 58 us with one load per loop trip, 16 us with the loads batched.)
+constexpr int ERR_BLOCKS = 64;
 __global__ void __launch_bounds__(256)
-k_weighted_error(const double* __restrict__ r_pt, const double* __restrict__ w_pt, int32_t n_pt,
-                 const double* __restrict__ r_ls, const double* __restrict__ w_ls, int32_t n_ls,
-                 double* __restrict__ err)
+k_weighted_error_partials(const double* __restrict__ r_pt, const double* __restrict__ w_pt, int32_t n_pt,
+                          const double* __restrict__ r_ls, const double* __restrict__ w_ls, int32_t n_ls,
+                          double* __restrict__ err)
 {
     __shared__ double red[256];
+    constexpr int G = ERR_BLOCKS * 256, PB = 4;
+    const int g = blockIdx.x * 256 + threadIdx.x;
     double acc = 0.0;
-    for (int o = threadIdx.x; o < n_pt; o += 256) acc += r_pt[o] * r_pt[o] * w_pt[o];
-    for (int o = threadIdx.x; o < n_ls; o += 256) acc += r_ls[o] * r_ls[o] * w_ls[o];
+    auto sum = [&](const double* __restrict__ r, const double* __restrict__ w, int32_t n) {
+        for (int o0 = g; o0 < n; o0 += G * PB) {
+            double rr[PB], ww[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int o = o0 + j * G;
+                rr[j] = o < n ? r[o] : 0.0;
+                ww[j] = o < n ? w[o] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j)
+                if (o0 + j * G < n) acc += rr[j] * rr[j] * ww[j];
+        }
+    };
+    sum(r_pt, w_pt, n_pt);
+    sum(r_ls, w_ls, n_ls);
     red[threadIdx.x] = acc;
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
         if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *err = red[0];
+    if (threadIdx.x == 0) err[1 + blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(ERR_BLOCKS)
+k_weighted_error_final(double* __restrict__ err)
+{
+    __shared__ double red[ERR_BLOCKS];
+    red[threadIdx.x] = err[1 + threadIdx.x];
+    __syncthreads();
+    for (int s = ERR_BLOCKS / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) err[0] = red[0];
 }
 
 namespace {
@@ -187,8 +243,9 @@ static int assemble_on_device(const AssembleDev& a, int32_t nkf, int32_t npt, in
                                a.pt_Jp, a.pt_r, a.pt_w, a.ls_Jp, a.ls_r, a.ls_w, a.max_chunks, a.pose_part);
         hipLaunchKernelGGL(k_pose_blocks, dim3(nkf), dim3(64), 0, s, a.kf_ptr, a.max_chunks, a.pose_part, a.H_pose, a.g);
     }
-    hipLaunchKernelGGL(k_weighted_error, dim3(1), dim3(256), 0, s, a.pt_r, a.pt_w, n_pt_obs, a.ls_r, a.ls_w, n_ls_obs,
-                       a.err);
+    hipLaunchKernelGGL(k_weighted_error_partials, dim3(ERR_BLOCKS), dim3(256), 0, s, a.pt_r, a.pt_w, n_pt_obs, a.ls_r, a.ls_w,
+                       n_ls_obs, a.err);
+    hipLaunchKernelGGL(k_weighted_error_final, dim3(1), dim3(ERR_BLOCKS), 0, s, a.err);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
@@ -290,7 +347,7 @@ extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, doub
     Carve co;
     P->oG = co.take(N * 8 + 8); P->oHp = co.take((size_t)nkf * 288 + 8); P->oHpt = co.take((size_t)npt * 72 + 8);
     P->oHls = co.take((size_t)nls * 288 + 8); P->oWp = co.take(np * 144 + 8); P->oWl = co.take(nl * 288 + 8);
-    P->oErr = co.take(8);
+    P->oErr = co.take(8 * (1 + ERR_BLOCKS));      // err, then the workgroups' partial sums
     P->max_chunks = pose_max_chunks(c.kfp);
     P->oPart = co.take((size_t)nkf * (size_t)P->max_chunks * 42 * 8 + 8);
     int rc;
@@ -497,7 +554,7 @@ extern "C" int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, in
     Carve co;
     const size_t oG = co.take(N * 8 + 8), oHp = co.take((size_t)nkf * 288 + 8), oHpt = co.take((size_t)npt * 72 + 8),
                  oHls = co.take((size_t)nls * 288 + 8), oWp = co.take(np * 144 + 8), oWl = co.take(nl * 288 + 8),
-                 oErr = co.take(8);
+                 oErr = co.take(8 * (1 + ERR_BLOCKS));
     const int32_t max_chunks = pose_max_chunks(kfp);
     const size_t oPart = co.take((size_t)nkf * (size_t)max_chunks * 42 * 8 + 8);
     int rc;
