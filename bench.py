@@ -807,7 +807,7 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
          f"{rec['c3']['lba_line_rows_streaming']['GBps_moved']:.0f} GB/s moved")
     # ---- the other section-8 rows (bench_rows.py): each verified over everything it produced -----------------
     import bench_rows as R
-    for tag, fn in (("grid", lambda: R.grid(ctx, dev, torch, O, st_)), ("drivers", lambda: R.drivers(ctx, O)),
+    for tag, fn in (("grid", lambda: R.grid(ctx, dev, torch, O, st_)), ("drivers", lambda: R.drivers(ctx, O, dev)),
                     ("lba_plan_iterate_dev", lambda: R.lba_iterate(ctx, O)), ("lbd", lambda: R.lbd(ctx, dev, torch, O, st_)),
                     ("median_desc", lambda: R.median_desc(ctx, dev, torch, O, st_))):
         t0 = time.perf_counter()

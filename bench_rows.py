@@ -125,7 +125,7 @@ def grid(ctx, dev, torch, O, stream):
     return rec
 
 
-def drivers(ctx, O):
+def drivers(ctx, O, dev_tensors=None):
     import plslam_amd
     from plslam_amd import synth
     TM, _ = _test_helpers()
@@ -147,6 +147,16 @@ def drivers(ctx, O):
             rec[f"map2kf_{kind}_{n_map}x{n_kf}_{name}"] = dict(_pct(_wall(g, 20)), cpu_oracle_1thread_us=cpu,
                                                                associations=int(ref[1]),
                                                                verified="association table + inlier count bit-exact vs the oracle")
+            if dev_tensors is not None:
+                # the same call with the map side resident on the device (plslam_map2kf_match_*_dev)
+                import torch
+                d_lm, d_md, d_cd = (torch.from_numpy(np.ascontiguousarray(s[k_])).to(dev_tensors) for k_ in ("LM", "med", "cand"))
+                gd = lambda: ctx.map2kf_match_dev(kind, cam, s["Twf"], d_lm.data_ptr(), d_md.data_ptr(), d_cd.data_ptr(), n_map,   # noqa: E731
+                                                  s["kf_desc"], s["kf_feat"], s["kf_idx"], 0.9, True, 1.5, 10, fm, kf_seg=s.get("kf_seg"))
+                gotd = gd()
+                if not (np.array_equal(gotd[0], ref[0]) and gotd[1] == ref[1]):
+                    raise SystemExit(f"secondary record drivers/map2kf_{kind}_{name} (map on the device): result differs from the oracle")
+                rec[f"map2kf_{kind}_{n_map}x{n_kf}_{name}"]["map_on_device_us_median"] = _pct(_wall(gd, 20))["us_median"]
     for kind, n in (("points", 1500), ("lines", 200)):
         s = TM.kf_pair(n, n - 100, lines=(kind == "lines"), seed=n)
         a = (s["DT"], s["X"], s["d_prev"], s["feat"], s["d_curr"])

@@ -574,6 +574,24 @@ int plslam_map2kf_match_lines_fast(plslam_ctx* ctx, const plslam_cam* K, const d
                                    const int32_t* kf_idx, int32_t n_kf, float nnr, int mutual, double max_epip,
                                    int32_t min_matches, const plslam_fast_matching* fm, int32_t* map_to_kf,
                                    int32_t* n_matches, int32_t* used_match);
+/* The same drivers with the MAP SIDE DEVICE-RESIDENT: d_Xw / d_Lw, d_med_desc and d_candidate are device pointers (8-byte
+ * aligned) -- a local map lives on the GPU across keyframes (the representative descriptors come from
+ * plslam_median_desc_batched_dev, the landmarks from the LBA plan); the host-pointer forms above stage and upload 0.56 MB of
+ * it per call at C3 sizes (10 000 landmarks), which is a quarter of their time.  The keyframe side (kf_*), the results and the
+ * semantics are those of the _fast forms (fm == NULL or !fm->enabled: the plain driver).  kf_seg: lines only. */
+int plslam_map2kf_match_points_dev(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* d_Xw,
+                                   const uint8_t* d_med_desc, const uint8_t* d_candidate, int32_t n_map,
+                                   const uint8_t* kf_desc, const double* kf_pl, const int32_t* kf_idx, int32_t n_kf,
+                                   float nnr, int mutual, double max_epip, int32_t min_matches,
+                                   const plslam_fast_matching* fm, int32_t* map_to_kf, int32_t* n_matches,
+                                   int32_t* used_match);
+int plslam_map2kf_match_lines_dev(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* d_Lw,
+                                  const uint8_t* d_med_desc, const uint8_t* d_candidate, int32_t n_map,
+                                  const uint8_t* kf_desc, const double* kf_le, const double* kf_seg,
+                                  const int32_t* kf_idx, int32_t n_kf, float nnr, int mutual, double max_epip,
+                                  int32_t min_matches, const plslam_fast_matching* fm, int32_t* map_to_kf,
+                                  int32_t* n_matches, int32_t* used_match);
+
 
 /* ---- the keyframe <-> keyframe association drivers ------------------------------------------------ */
 /* Replace the compute of MapHandler::matchKF2KFPoints (src/mapHandler.cpp:234-363; :246-278) and matchKF2KFLines

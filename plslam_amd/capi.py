@@ -38,7 +38,7 @@ ABI_SYMBOLS = (
     "plslam_lba_plan_blocks",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
-    "plslam_map2kf_match_points_fast", "plslam_map2kf_match_lines_fast",
+    "plslam_map2kf_match_points_fast", "plslam_map2kf_match_lines_fast", "plslam_map2kf_match_points_dev", "plslam_map2kf_match_lines_dev",
     "plslam_kf2kf_match_points", "plslam_kf2kf_match_lines",
     "plslam_lbd_binarise", "plslam_lbd_binarise_dev", "plslam_lbd_compute", "plslam_lbd_compute_dev",
     "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
@@ -223,6 +223,8 @@ def load() -> C.CDLL:
     L.plslam_map2kf_match_lines_fast.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, C.c_float,
                                                  C.c_int, f64, i32, C.POINTER(FastMatching), vp, C.POINTER(i32),
                                                  C.POINTER(i32)]
+    L.plslam_map2kf_match_points_dev.argtypes = L.plslam_map2kf_match_points_fast.argtypes
+    L.plslam_map2kf_match_lines_dev.argtypes = L.plslam_map2kf_match_lines_fast.argtypes
     for f in (L.plslam_kf2kf_match_points, L.plslam_kf2kf_match_lines):
         f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, i32, vp, vp, i32, C.c_float, C.c_int, i32, C.POINTER(FastMatching), vp,
                       C.POINTER(i32), C.POINTER(i32)]
@@ -623,6 +625,34 @@ class Context:
                                                           float(nnr), int(bool(mutual)), float(max_epip),
                                                           int(min_matches), C.byref(F), _p(out), C.byref(n),
                                                           C.byref(used)), "plslam_map2kf_match_lines_fast")
+        return out, n.value, used.value
+
+    def map2kf_match_dev(self, kind, cam, Twf, d_LM, d_med_desc, d_candidate, n_map, kf_desc, kf_feat, kf_idx, nnr, mutual,
+                         max_epip, min_matches, fm, kf_seg=None):
+        """map2kf_match_fast with the MAP SIDE on the device: d_LM (n_map x 3 | 6 float64), d_med_desc (n_map x 32 uint8),
+        d_candidate (n_map uint8) are device addresses (ints); the keyframe side and the results are host arrays."""
+        fw = 2 if kind == "points" else 3
+        Twf = _arr(Twf, np.float64, (16,))
+        kd, kf = _arr(kf_desc, np.uint8, (-1, 32)), _arr(kf_feat, np.float64, (-1, fw))
+        ki = _arr(kf_idx, np.int32)
+        out = np.empty(int(n_map), np.int32)
+        F = FastMatching(int(fm["enabled"]), int(fm["grid_cols"]), int(fm["grid_rows"]), int(fm["ws"]),
+                         float(fm["inv_width"]), float(fm["inv_height"]), float(fm["nnr_grid"]),
+                         float(fm.get("line_sim_th", 0.75)))
+        n, used = C.c_int32(), C.c_int32()
+        if kind == "points":
+            _check(self._L.plslam_map2kf_match_points_dev(self._h, C.byref(cam), _p(Twf), int(d_LM), int(d_med_desc),
+                                                          int(d_candidate), int(n_map), _p(kd), _p(kf), _p(ki), kd.shape[0],
+                                                          float(nnr), int(bool(mutual)), float(max_epip), int(min_matches),
+                                                          C.byref(F), _p(out), C.byref(n), C.byref(used)),
+                   "plslam_map2kf_match_points_dev")
+        else:
+            sg = _arr(kf_seg, np.float64, (-1, 4))
+            _check(self._L.plslam_map2kf_match_lines_dev(self._h, C.byref(cam), _p(Twf), int(d_LM), int(d_med_desc),
+                                                         int(d_candidate), int(n_map), _p(kd), _p(kf), _p(sg), _p(ki),
+                                                         kd.shape[0], float(nnr), int(bool(mutual)), float(max_epip),
+                                                         int(min_matches), C.byref(F), _p(out), C.byref(n), C.byref(used)),
+                   "plslam_map2kf_match_lines_dev")
         return out, n.value, used.value
 
     def kf2kf_match(self, kind, cam, DT, X_prev, desc_prev, feat_curr, desc_curr, nnr, mutual, min_matches, fm):

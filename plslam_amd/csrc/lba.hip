@@ -248,19 +248,20 @@ __device__ __forceinline__ int inside(const CamD& K, const double P[3])
 // candidate pre-filter (:549-551, :650-655)
 __global__ void __launch_bounds__(256)
 k_visible(CamD K, Pose12 Twf, const double* __restrict__ X, int32_t n, int lines,
-          uint8_t* __restrict__ vis)
+          uint8_t* __restrict__ vis, const uint8_t* __restrict__ cand)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const bool c = cand == nullptr || cand[i] != 0;      // (cand: the caller's candidate flags live on the device -- folded in)
     double P[3];
     if (!lines) {
         xform44(Twf, X + 3 * (size_t)i, P);
-        vis[i] = (uint8_t)inside(K, P);
+        vis[i] = (uint8_t)(c && inside(K, P));
     } else {
         double E[3];
         xform44(Twf, X + 6 * (size_t)i, P);
         xform44(Twf, X + 6 * (size_t)i + 3, E);
-        vis[i] = (uint8_t)(inside(K, P) && inside(K, E));
+        vis[i] = (uint8_t)(c && inside(K, P) && inside(K, E));
     }
 }
 
@@ -326,7 +327,17 @@ int launch_visible(const plslam_cam& K, const double* Twf16, const double* X, in
 {
     if (n <= 0) return PLSLAM_OK;
     hipLaunchKernelGGL(k_visible, dim3((n + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), X, n,
-                       lines, vis);
+                       lines, vis, (const uint8_t*)nullptr);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+// ... AND the candidate flags (device): what the drivers with a device-resident map read back
+int launch_visible_cand(const plslam_cam& K, const double* Twf16, const double* X, const uint8_t* cand, int32_t n, int lines,
+                        uint8_t* vis, hipStream_t s)
+{
+    if (n <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_visible, dim3((n + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), X, n,
+                       lines, vis, cand);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

@@ -20,6 +20,9 @@ namespace plslam {
 int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux);
 size_t grid_aux_words(int32_t n2);            // the words the two launches share, prefilled by grid_aux_fill in the upload image
 void grid_aux_fill(void* host_image, int32_t n2);
+// lba.hip: the visibility pre-filter AND the candidate flags, both on the device
+int launch_visible_cand(const plslam_cam& K, const double* Twf16, const double* X, const uint8_t* cand, int32_t n, int lines,
+                        uint8_t* vis, hipStream_t s);
 // match_grid.hip: capacity of the windowed matcher's candidate store from the grid alone
 int64_t grid_store_capacity_bound(int32_t n1, int32_t n_centres, const int32_t* cell_start, int32_t cols, int32_t rows,
                                   const int32_t window[4], int mutual);
@@ -290,8 +293,10 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
                   const uint8_t* med_desc, const uint8_t* candidate, int32_t n_map, const uint8_t* kf_desc,
                   const double* kf_feat, const double* kf_seg, const int32_t* kf_idx, int32_t n_kf, float nnr,
                   int mutual, double max_epip, int32_t min_matches, const plslam_fast_matching* fm,
-                  int32_t* map_to_kf, int32_t* n_matches, int32_t* used_match)
+                  int32_t* map_to_kf, int32_t* n_matches, int32_t* used_match, bool map_dev = false)
 {
+    // map_dev: LM, med_desc and candidate are DEVICE pointers (the local map lives on the GPU across keyframes): nothing of
+    // the map is staged or uploaded, the candidate flags are folded into the visibility kernel
     PLSLAM_REQUIRE(ctx && K && Twf && n_map >= 0 && n_kf >= 0, PLSLAM_EINVAL);
     const bool fast = fm && fm->enabled;
     if (fast) {
@@ -319,7 +324,7 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     StreamSyncOnError sg(s);
     // ---- stage the map and the keyframe on the device (ONE page-locked image, one upload), project + visibility test ----
     Carve c;
-    const size_t oLM = c.take((size_t)n_map * lw * 8), oMD = c.take((size_t)n_map * 32),
+    const size_t oLM = c.take(map_dev ? 0 : (size_t)n_map * lw * 8), oMD = c.take(map_dev ? 0 : (size_t)n_map * 32),
                  oKD = c.take((size_t)n_kf * 32), oKF = c.take((size_t)n_kf * fw * 8);
     const size_t image1 = c.off;
     const size_t oQi = c.take((size_t)n_map * 4), oTi = c.take((size_t)nt * 4);          // second image: the two lists
@@ -335,14 +340,20 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     char* d = ctx->misc_a.as<char>();
     char* h = ctx->pin_in.as<char>();
     char* ho = ctx->pin_out.as<char>();
-    memcpy(h + oLM, LM, (size_t)n_map * lw * 8);
-    memcpy(h + oMD, med_desc, (size_t)n_map * 32);
+    if (!map_dev) {
+        memcpy(h + oLM, LM, (size_t)n_map * lw * 8);
+        memcpy(h + oMD, med_desc, (size_t)n_map * 32);
+    }
+    const char* const d_LM = map_dev ? reinterpret_cast<const char*>(LM) : d + oLM;          // the map on the device
+    const char* const d_MD = map_dev ? reinterpret_cast<const char*>(med_desc) : d + oMD;
     memcpy(h + oKD, kf_desc, (size_t)n_kf * 32);
     memcpy(h + oKF, kf_feat, (size_t)n_kf * fw * 8);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image1, hipMemcpyHostToDevice, s));
     // the visibility flags come back through page-locked memory the kernel writes (no download command)
     uint8_t* vis_mapped = static_cast<uint8_t*>(mapped_device_pointer(ho));
-    if ((rc = launch_visible(*K, Twf, (double*)(d + oLM), n_map, lines, vis_mapped ? vis_mapped : (uint8_t*)(d + oVis), s))) return rc;
+    rc = map_dev ? launch_visible_cand(*K, Twf, (const double*)d_LM, candidate, n_map, lines, vis_mapped ? vis_mapped : (uint8_t*)(d + oVis), s)
+                 : launch_visible(*K, Twf, (const double*)d_LM, n_map, lines, vis_mapped ? vis_mapped : (uint8_t*)(d + oVis), s);
+    if (rc) return rc;
     if (!vis_mapped) PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oVis, (size_t)n_map, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     const uint8_t* vis = reinterpret_cast<const uint8_t*>(ho);
@@ -350,7 +361,7 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     // ---- Q list: candidate landmarks that project inside the image, :545-558 / :647-663 ------
     std::vector<int32_t> qi;
     for (int32_t i = 0; i < n_map; ++i)
-        if (candidate[i] && vis[i]) qi.push_back(i);
+        if ((map_dev || candidate[i]) && vis[i]) qi.push_back(i);        // (map_dev: the kernel folded the flags in)
     const int32_t nq = (int32_t)qi.size();
     if (nq == 0) { sg.dismiss(); return PLSLAM_OK; }                      // :571 / :676
 
@@ -358,9 +369,9 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     memcpy(h, qi.data(), (size_t)nq * 4);                                  // (image 1 is on the device: the buffer is free)
     memcpy(h + (oTi - oQi), ti.data(), (size_t)nt * 4);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d + oQi, h, image2, hipMemcpyHostToDevice, s));
-    if ((rc = launch_gather_rows(d + oMD, (int32_t*)(d + oQi), nq, 32, d + oQ, s))) return rc;
+    if ((rc = launch_gather_rows(d_MD, (int32_t*)(d + oQi), nq, 32, d + oQ, s))) return rc;
     if ((rc = launch_gather_rows(d + oKD, (int32_t*)(d + oTi), nt, 32, d + oT, s))) return rc;
-    if ((rc = launch_gather_rows(d + oLM, (int32_t*)(d + oQi), nq, lw * 8, d + oQL, s))) return rc;
+    if ((rc = launch_gather_rows(d_LM, (int32_t*)(d + oQi), nq, lw * 8, d + oQL, s))) return rc;
     if ((rc = launch_gather_rows(d + oKF, (int32_t*)(d + oTi), nt, fw * 8, d + oTF, s))) return rc;
     int32_t matches = 0;
     bool have_m12 = false;                       // matches_12.size() != 0: a matcher ran
@@ -443,6 +454,30 @@ int plslam_map2kf_match_lines_fast(plslam_ctx* ctx, const plslam_cam* K, const d
 {
     return plslam::map2kf_driver(ctx, 1, K, Twf, Lw, med_desc, candidate, n_map, kf_desc, kf_le, kf_seg, kf_idx, n_kf,
                                  nnr, mutual, max_epip, min_matches, fm, map_to_kf, n_matches, used_match);
+}
+
+int plslam_map2kf_match_points_dev(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* d_Xw,
+                                   const uint8_t* d_med_desc, const uint8_t* d_candidate, int32_t n_map,
+                                   const uint8_t* kf_desc, const double* kf_pl, const int32_t* kf_idx, int32_t n_kf,
+                                   float nnr, int mutual, double max_epip, int32_t min_matches,
+                                   const plslam_fast_matching* fm, int32_t* map_to_kf, int32_t* n_matches,
+                                   int32_t* used_match)
+{
+    PLSLAM_REQUIRE(n_map == 0 || (((uintptr_t)d_Xw & 7) == 0 && ((uintptr_t)d_med_desc & 7) == 0), PLSLAM_EINVAL);
+    return plslam::map2kf_driver(ctx, 0, K, Twf, d_Xw, d_med_desc, d_candidate, n_map, kf_desc, kf_pl, nullptr, kf_idx, n_kf,
+                                 nnr, mutual, max_epip, min_matches, fm, map_to_kf, n_matches, used_match, true);
+}
+
+int plslam_map2kf_match_lines_dev(plslam_ctx* ctx, const plslam_cam* K, const double* Twf, const double* d_Lw,
+                                  const uint8_t* d_med_desc, const uint8_t* d_candidate, int32_t n_map,
+                                  const uint8_t* kf_desc, const double* kf_le, const double* kf_seg,
+                                  const int32_t* kf_idx, int32_t n_kf, float nnr, int mutual, double max_epip,
+                                  int32_t min_matches, const plslam_fast_matching* fm, int32_t* map_to_kf,
+                                  int32_t* n_matches, int32_t* used_match)
+{
+    PLSLAM_REQUIRE(n_map == 0 || (((uintptr_t)d_Lw & 7) == 0 && ((uintptr_t)d_med_desc & 7) == 0), PLSLAM_EINVAL);
+    return plslam::map2kf_driver(ctx, 1, K, Twf, d_Lw, d_med_desc, d_candidate, n_map, kf_desc, kf_le, kf_seg, kf_idx, n_kf,
+                                 nnr, mutual, max_epip, min_matches, fm, map_to_kf, n_matches, used_match, true);
 }
 
 int plslam_kf2kf_match_points(plslam_ctx* ctx, const plslam_cam* K, const double* DT, const double* P_prev,

@@ -172,6 +172,35 @@ def test_gpu_fast_driver_bit_exact(ctx, oracle, kind, n_map, n_kf):
     assert seen_used == {0, 1} or n_map < 100
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,n_map,n_kf", [("points", 10000, 1500), ("lines", 2000, 200), ("points", 300, 40)])
+def test_gpu_driver_with_the_map_on_the_device(ctx, oracle, kind, n_map, n_kf):
+    """plslam_map2kf_match_points_dev / _lines_dev: landmarks, representative descriptors and candidate flags stay on the GPU
+    across calls (here: torch tensors, used by several calls with different keyframe-side settings); results equal the
+    host-pointer drivers' and the oracle's, with fast_matching and without, fall-back taken and not."""
+    import torch
+    import plslam_amd
+    cam, ocam = plslam_amd.make_cam(**synth.EUROC), oracle.make_cam(**synth.EUROC)
+    s = scene(n_map, n_kf, lines=(kind == "lines"), seed=n_map + 7)
+    dev = torch.device("cuda", ctx.device)
+    d_lm = torch.from_numpy(np.ascontiguousarray(s["LM"], np.float64)).to(dev)
+    d_md = torch.from_numpy(np.ascontiguousarray(s["med"], np.uint8)).to(dev)
+    d_cd = torch.from_numpy(np.ascontiguousarray(s["cand"], np.uint8)).to(dev)
+    a = (s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"], s["kf_idx"])
+    seen_used = set()
+    for nnr, mutual, th, mm, fm in ((0.75, True, 1.5, 10, fast_cfg()), (0.9, True, 0.8, 250 if n_map >= 2000 else 12, fast_cfg()),
+                                    (0.8, True, 1.0, 5, fast_cfg(enabled=0)), (0.9, False, 2.0, 6, fast_cfg(ws=1))):
+        got = ctx.map2kf_match_dev(kind, cam, s["Twf"], d_lm.data_ptr(), d_md.data_ptr(), d_cd.data_ptr(), n_map, s["kf_desc"],
+                                   s["kf_feat"], s["kf_idx"], nnr, mutual, th, mm, fm, kf_seg=s.get("kf_seg"))
+        ref = oracle.map2kf_match_fast(kind, ocam, *a, nnr, mutual, th, mm, fm, kf_seg=s.get("kf_seg"))
+        np.testing.assert_array_equal(got[0], ref[0])
+        assert got[1] == ref[1] and got[2] == ref[2]
+        seen_used.add(ref[2])
+    assert seen_used == {0, 1} or n_map < 2000
+    # the device-side inputs are untouched
+    assert np.array_equal(d_md.cpu().numpy(), s["med"]) and np.array_equal(d_cd.cpu().numpy(), s["cand"])
+
+
 def kf_pair(n_prev=1500, n_curr=1400, lines=False, seed=3):
     """Two consecutive keyframes: stereo features of the previous one (3D, its camera frame), the relative pose DT and
     the current one's 2D features = re-observations of a subset (+ noise) and clutter."""
