@@ -188,8 +188,9 @@ __device__ __forceinline__ void xform44(const Pose12& T, const double* X, double
 __global__ void __launch_bounds__(256)
 k_point_gate(CamD K, Pose12 Twf, const double* __restrict__ Xw, const int32_t* __restrict__ m12,
              int32_t nq, const double* __restrict__ pl, double th, uint8_t* __restrict__ mask,
-             int32_t* __restrict__ count)
+             int32_t* __restrict__ count, const int32_t* __restrict__ nq_dev)
 {
+    if (nq_dev) nq = *nq_dev;                  // (the row count lives on the device: the launch covers an upper bound)
     const int i = blockIdx.x * 256 + threadIdx.x;
     int ok = 0;
     if (i < nq) {
@@ -213,8 +214,9 @@ k_point_gate(CamD K, Pose12 Twf, const double* __restrict__ Xw, const int32_t* _
 __global__ void __launch_bounds__(256)
 k_line_gate(CamD K, Pose12 Twf, const double* __restrict__ Lw, const int32_t* __restrict__ m12,
             int32_t nq, const double* __restrict__ le, double th, uint8_t* __restrict__ mask,
-            int32_t* __restrict__ count)
+            int32_t* __restrict__ count, const int32_t* __restrict__ nq_dev)
 {
+    if (nq_dev) nq = *nq_dev;
     const int i = blockIdx.x * 256 + threadIdx.x;
     int ok = 0;
     if (i < nq) {
@@ -305,7 +307,7 @@ int launch_point_gate(const plslam_cam& K, const double* Twf16, const double* Xw
     if (count) PLSLAM_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), s));
     if (nq <= 0) return PLSLAM_OK;
     hipLaunchKernelGGL(k_point_gate, dim3((nq + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16),
-                       Xw, m12, nq, pl, th, mask, count);
+                       Xw, m12, nq, pl, th, mask, count, (const int32_t*)nullptr);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
@@ -317,7 +319,7 @@ int launch_line_gate(const plslam_cam& K, const double* Twf16, const double* Lw,
     if (count) PLSLAM_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), s));
     if (nq <= 0) return PLSLAM_OK;
     hipLaunchKernelGGL(k_line_gate, dim3((nq + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16),
-                       Lw, m12, nq, le, th, mask, count);
+                       Lw, m12, nq, le, th, mask, count, (const int32_t*)nullptr);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
@@ -347,8 +349,9 @@ int launch_visible_cand(const plslam_cam& K, const double* Twf16, const double* 
 // lines also the unit direction matchGrid derives from the two INTEGER end points (zero vector -> NaN)
 __global__ void __launch_bounds__(256)
 k_project_cells(CamD K, Pose12 Twf, const double* __restrict__ X, int32_t n, int lines, double inv_w, double inv_h,
-                int32_t* __restrict__ cells, double* __restrict__ dir1)
+                int32_t* __restrict__ cells, double* __restrict__ dir1, const int32_t* __restrict__ n_dev)
 {
+    if (n_dev) n = *n_dev;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int nc = lines ? 2 : 1;
@@ -377,7 +380,33 @@ int launch_project_cells(const plslam_cam& K, const double* Twf16, const double*
 {
     if (n <= 0) return PLSLAM_OK;
     hipLaunchKernelGGL(k_project_cells, dim3((n + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), X, n, lines,
-                       inv_w, inv_h, cells, dir1);
+                       inv_w, inv_h, cells, dir1, (const int32_t*)nullptr);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+// The same three with the row count ON THE DEVICE (*n_dev <= n_max; the launch covers n_max rows): the drivers' one-synchronisation
+// form builds its candidate list on the device and never learns its length before the results are back.  The gate's counter is
+// NOT cleared here (the caller's image holds the zero).
+int launch_project_cells_n(const plslam_cam& K, const double* Twf16, const double* X, const int32_t* n_dev, int32_t n_max, int lines,
+                           double inv_w, double inv_h, int32_t* cells, double* dir1, hipStream_t s)
+{
+    if (n_max <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_project_cells, dim3((n_max + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), X, n_max, lines,
+                       inv_w, inv_h, cells, dir1, n_dev);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+int launch_gate_n(int lines, const plslam_cam& K, const double* Twf16, const double* LM, const int32_t* m12, const int32_t* n_dev,
+                  int32_t n_max, const double* feat, double th, uint8_t* mask, int32_t* count, hipStream_t s)
+{
+    if (n_max <= 0) return PLSLAM_OK;
+    if (lines)
+        hipLaunchKernelGGL(k_line_gate, dim3((n_max + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), LM, m12, n_max, feat,
+                           th, mask, count, n_dev);
+    else
+        hipLaunchKernelGGL(k_point_gate, dim3((n_max + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), LM, m12, n_max, feat,
+                           th, mask, count, n_dev);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

@@ -17,12 +17,17 @@ namespace plslam {
 
 // match_grid.hip: one matchGrid problem on `s`, with its scratch (a large mutual problem gets its distances from a
 // many-workgroup launch)
-int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux);
+int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux, bool n1_upper_bound);
 size_t grid_aux_words(int32_t n2);            // the words the two launches share, prefilled by grid_aux_fill in the upload image
 void grid_aux_fill(void* host_image, int32_t n2);
 // lba.hip: the visibility pre-filter AND the candidate flags, both on the device
 int launch_visible_cand(const plslam_cam& K, const double* Twf16, const double* X, const uint8_t* cand, int32_t n, int lines,
                         uint8_t* vis, hipStream_t s);
+// lba.hip: projection into grid cells / the epipolar gates with the row count on the device (*n_dev <= n_max)
+int launch_project_cells_n(const plslam_cam& K, const double* Twf16, const double* X, const int32_t* n_dev, int32_t n_max, int lines,
+                           double inv_w, double inv_h, int32_t* cells, double* dir1, hipStream_t s);
+int launch_gate_n(int lines, const plslam_cam& K, const double* Twf16, const double* LM, const int32_t* m12, const int32_t* n_dev,
+                  int32_t n_max, const double* feat, double th, uint8_t* mask, int32_t* count, hipStream_t s);
 // match_grid.hip: capacity of the windowed matcher's candidate store from the grid alone
 int64_t grid_store_capacity_bound(int32_t n1, int32_t n_centres, const int32_t* cell_start, int32_t cols, int32_t rows,
                                   const int32_t window[4], int mutual);
@@ -48,6 +53,63 @@ int launch_gather_rows(const void* src, const int32_t* idx, int32_t n, int32_t r
                        static_cast<const uint64_t*>(src), idx, n, words, static_cast<uint64_t*>(dst));
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
+}
+
+
+// ---- the one-synchronisation form of the map<->keyframe drivers with fast_matching (map2kf_driver below) -------------------
+// stable compaction: idx[0 .. *n_out) = the i with flags[i] != 0, ascending; fill[0 .. n) = -1 (the association table's start).
+// One workgroup: a lane owns a contiguous chunk, a scan over the lanes' counts gives its first slot.
+__global__ void __launch_bounds__(1024)
+k_compact_flags(const uint8_t* __restrict__ flags, int32_t n, int32_t* __restrict__ idx, int32_t* __restrict__ n_out,
+                int32_t* __restrict__ fill)
+{
+    __shared__ int32_t s_sum[1024];
+    const int tid = (int)threadIdx.x;
+    const int32_t chunk = (n + 1023) / 1024, lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    int32_t c = 0;
+    for (int32_t i = lo; i < hi; ++i) {
+        c += flags[i] != 0;
+        fill[i] = -1;
+    }
+    s_sum[tid] = c;
+    __syncthreads();
+    for (int st = 1; st < 1024; st <<= 1) {                      // inclusive scan
+        const int32_t v = tid >= st ? s_sum[tid - st] : 0;
+        __syncthreads();
+        s_sum[tid] += v;
+        __syncthreads();
+    }
+    int32_t k = s_sum[tid] - c;
+    for (int32_t i = lo; i < hi; ++i)
+        if (flags[i] != 0) idx[k++] = i;
+    if (tid == 1023) *n_out = s_sum[1023];
+}
+
+// Q / T matrix construction for the listed landmarks (:555, :567): row a of Q = med_desc[idx[a]] (4 words), of QL = LM[idx[a]]
+// (lw words); *n_dev rows, the launch covers n_max
+__global__ void __launch_bounds__(256)
+k_gather_q(const uint64_t* __restrict__ md, const uint64_t* __restrict__ lm, const int32_t* __restrict__ idx,
+           const int32_t* __restrict__ n_dev, int32_t lw, uint64_t* __restrict__ Q, uint64_t* __restrict__ QL)
+{
+    const int32_t words = 4 + lw;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (int64_t)*n_dev * words) return;
+    const int32_t row = (int32_t)(t / words), w = (int32_t)(t % words);
+    const int64_t src = idx[row];
+    if (w < 4) Q[(int64_t)row * 4 + w] = md[src * 4 + w];
+    else QL[(int64_t)row * lw + (w - 4)] = lm[src * lw + (w - 4)];
+}
+
+// the row count of a matchGrid problem becomes known on the device only: written into its (uploaded) descriptor
+__global__ void k_patch_grid_rows(GridDesc* __restrict__ desc, const int32_t* __restrict__ n_dev) { desc->n1 = *n_dev; }
+
+// :614-619, the association: landmark idx[a] <- keyframe feature ti[m12[a]] where the gate holds (table pre-filled with -1)
+__global__ void __launch_bounds__(256)
+k_associate(const int32_t* __restrict__ idx, const int32_t* __restrict__ n_dev, const int32_t* __restrict__ m12,
+            const uint8_t* __restrict__ mask, const int32_t* __restrict__ ti, int32_t* __restrict__ map_to_kf)
+{
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a < *n_dev && mask[a]) map_to_kf[idx[a]] = ti[m12[a]];
 }
 
 namespace {
@@ -95,25 +157,13 @@ inline int32_t cvtt_x86(double v)   // as the reference's x86 build converts (cv
     return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN;
 }
 
-// StVO::matchGrid over projected 3D features, device-resident except the grid fill:
-//   d_X3 (device): nq x 3 (points) / nq x 6 (lines) features, projected with T16 into cells * (sx, sy) by K16';
-//   feat_curr (HOST): the keyframe features that fill the GridStructure -- item b = feat_curr[sel ? sel[b] : b],
-//   2 doubles (pl) or 4 (spl, epl); d_Q / d_T (device): the descriptor matrices; d_m12: nq entries out (device memory, or
-//   the device address of page-locked host memory: the caller then has the table without a copy).
-// The host-built tables (cell_start, items, directions) and the problem descriptor travel in ONE page-locked image = one
-// upload; the count comes back through page-locked memory written by the kernel.  Uses ctx->pin_misc, ctx->misc_b (tables)
-// and ctx->misc_c (kernel scratch).  Synchronises the stream once, at the end.
-int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16, const double* d_X3, int32_t nq, double sx,
-              double sy, const uint8_t* d_Q, const double* feat_curr, const int32_t* sel, int32_t nt, const uint8_t* d_T,
-              const plslam_fast_matching* fm, int mutual, int32_t* d_m12, int32_t* matches)
+// the GridStructure of the keyframe features feat_curr[sel ? sel[b] : b], b < nt, in CSR form (points: the feature's cell,
+// :581-584; lines: the Bresenham cells of (spl, epl), :686-698) and, for lines, their directions
+void fill_grid_tables(int lines, const double* feat_curr, const int32_t* sel, int32_t nt, const plslam_fast_matching* fm,
+                      std::vector<int32_t>& cs, std::vector<int32_t>& items, std::vector<double>& dir2)
 {
-    hipStream_t s = ctx->stream;
-    StreamSyncOnError sg(s);
-    int rc;
-    const int nc = lines ? 2 : 1;
     const int32_t cols = fm->grid_cols, rows = fm->grid_rows;
-    std::vector<int32_t> cs, items, it, cx, cy, xy;
-    std::vector<double> dir2;
+    std::vector<int32_t> it, cx, cy, xy;
     if (!lines) {
         for (int32_t b = 0; b < nt; ++b) {
             const double* p = feat_curr + 2 * (size_t)(sel ? sel[b] : b);
@@ -138,6 +188,28 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
         }
     }
     csr_fill(it, cx, cy, cols, rows, cs, items);
+}
+
+// StVO::matchGrid over projected 3D features, device-resident except the grid fill:
+//   d_X3 (device): nq x 3 (points) / nq x 6 (lines) features, projected with T16 into cells * (sx, sy) by K16';
+//   feat_curr (HOST): the keyframe features that fill the GridStructure -- item b = feat_curr[sel ? sel[b] : b],
+//   2 doubles (pl) or 4 (spl, epl); d_Q / d_T (device): the descriptor matrices; d_m12: nq entries out (device memory, or
+//   the device address of page-locked host memory: the caller then has the table without a copy).
+// The host-built tables (cell_start, items, directions) and the problem descriptor travel in ONE page-locked image = one
+// upload; the count comes back through page-locked memory written by the kernel.  Uses ctx->pin_misc, ctx->misc_b (tables)
+// and ctx->misc_c (kernel scratch).  Synchronises the stream once, at the end.
+int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16, const double* d_X3, int32_t nq, double sx,
+              double sy, const uint8_t* d_Q, const double* feat_curr, const int32_t* sel, int32_t nt, const uint8_t* d_T,
+              const plslam_fast_matching* fm, int mutual, int32_t* d_m12, int32_t* matches)
+{
+    hipStream_t s = ctx->stream;
+    StreamSyncOnError sg(s);
+    int rc;
+    const int nc = lines ? 2 : 1;
+    const int32_t cols = fm->grid_cols, rows = fm->grid_rows;
+    std::vector<int32_t> cs, items;
+    std::vector<double> dir2;
+    fill_grid_tables(lines, feat_curr, sel, nt, fm, cs, items, dir2);
     const int32_t n_items = cs.back();
     // image (host -> device in one copy): result words | cell_start | items | directions | descriptor; behind it, device only:
     // the projected cells and the query directions
@@ -181,7 +253,7 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     if ((rc = launch_project_cells(*K, T16, d_X3, nq, lines, sx, sy, (int32_t*)(f + oCen),
                                    lines ? (double*)(f + oD1) : nullptr, s)))
         return rc;
-    if ((rc = grid_launch_single(q, (const GridDesc*)(f + oDesc), s, (uint32_t*)(f + oAux)))) return rc;
+    if ((rc = grid_launch_single(q, (const GridDesc*)(f + oDesc), s, (uint32_t*)(f + oAux), false))) return rc;
     if (!in_place) PLSLAM_HIP_CHECK(hipMemcpyAsync(res_host, f + oSt, 8, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     sg.dismiss();
@@ -193,6 +265,117 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
 bool fast_ok(const plslam_fast_matching* fm)
 {
     return fm->grid_cols >= 1 && fm->grid_rows >= 1 && fm->ws >= 0 && (int64_t)fm->grid_cols * fm->grid_rows < (int64_t(1) << 30);
+}
+
+// The map<->keyframe driver with fast_matching as ONE launch sequence and ONE synchronisation: the candidate list is built on
+// the device (visibility [x candidate flags] -> stable compaction), so its length nq stays there -- the gathers, the projection,
+// the gate and the association read it from device memory, matchGrid's descriptor is patched with it behind the upload (its
+// launch geometry follows the upper bound n_map; k_match_grid / k_grid_candidates pick their form from the patched row count)
+// -- and the one host decision of the reference loop that needs it, `|Q| > min && matches < min` (:594-598, :709-713), is taken
+// AFTER the results are back: *redo = 1 then, and the caller runs the step-by-step form (rare: matchGrid found too little).
+// Everything the host knows beforehand travels in ONE upload: [the map, unless it is resident] | T rows | their features | ti |
+// the grid of the unmatched keyframe features | matchGrid's descriptor | zeroed counters.  Caller holds ctx->mu.
+int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* Twf, const double* LM, const uint8_t* med_desc,
+                     const uint8_t* candidate, int32_t n_map, const uint8_t* kf_desc, const double* kf_feat, const double* kf_seg,
+                     const std::vector<int32_t>& ti, float nnr, int mutual, double max_epip, int32_t min_matches,
+                     const plslam_fast_matching* fm, int32_t* map_to_kf, int32_t* n_matches, bool map_dev, int* redo)
+{
+    (void)nnr;
+    *redo = 0;
+    hipStream_t s = ctx->stream;
+    StreamSyncOnError sg(s);
+    int rc;
+    const int32_t nt = (int32_t)ti.size();
+    const int lw = lines ? 6 : 3, fw = lines ? 3 : 2, nc = lines ? 2 : 1;
+    const int32_t cols = fm->grid_cols, rows = fm->grid_rows;
+    std::vector<int32_t> cs, items;
+    std::vector<double> dir2;
+    fill_grid_tables(lines, lines ? kf_seg : kf_feat, ti.data(), nt, fm, cs, items, dir2);
+    const int32_t n_items = cs.back();
+    const int32_t win[4] = {fm->ws, fm->ws, fm->ws, fm->ws};
+    const int64_t cap = grid_store_capacity_bound(n_map, nc, cs.data(), cols, rows, win, mutual);     // (rows: the upper bound)
+    PLSLAM_REQUIRE(cap < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
+    // ---- one image up
+    Carve c;
+    const size_t oLM = c.take(map_dev ? 0 : (size_t)n_map * lw * 8), oMD = c.take(map_dev ? 0 : (size_t)n_map * 32),
+                 oCand = c.take(map_dev ? 0 : (size_t)n_map), oT = c.take((size_t)nt * 32), oTF = c.take((size_t)nt * fw * 8),
+                 oTi = c.take((size_t)nt * 4), oCs = c.take(cs.size() * 4), oIt = c.take((size_t)(n_items + 1) * 4),
+                 oD2 = c.take(lines ? (size_t)nt * 16 : 0), oDesc = c.take(sizeof(GridDesc)), oAux = c.take(grid_aux_words(nt) * 4),
+                 oRes = c.take(16);                                      // gate count | nq | matchGrid's count | -
+    const size_t image = c.off;
+    // ---- device only
+    const size_t oMap = c.take((size_t)n_map * 4);                       // the association table: directly behind the counters' page
+    const size_t oVis = c.take((size_t)n_map), oQi = c.take((size_t)n_map * 4), oQ = c.take((size_t)n_map * 32),
+                 oQL = c.take((size_t)n_map * lw * 8), oCen = c.take((size_t)n_map * nc * 8),
+                 oD1 = c.take(lines ? (size_t)n_map * 16 : 0), oM = c.take((size_t)n_map * 4), oMask = c.take((size_t)n_map);
+    if ((rc = ctx->misc_a.reserve(c.off))) return rc;
+    if ((rc = ctx->pin_in.reserve(image))) return rc;
+    if ((rc = ctx->pin_out.reserve(256 + (size_t)n_map * 4))) return rc;
+    if ((rc = ctx->misc_c.reserve(grid_scratch_words(n_map, nt, (int64_t)cols * rows, (int32_t)cap) * 4 + 256))) return rc;
+    char* d = ctx->misc_a.as<char>();
+    char* h = ctx->pin_in.as<char>();
+    if (!map_dev) {
+        memcpy(h + oLM, LM, (size_t)n_map * lw * 8);
+        memcpy(h + oMD, med_desc, (size_t)n_map * 32);
+        memcpy(h + oCand, candidate, (size_t)n_map);
+    }
+    const char* const d_LM = map_dev ? reinterpret_cast<const char*>(LM) : d + oLM;
+    const char* const d_MD = map_dev ? reinterpret_cast<const char*>(med_desc) : d + oMD;
+    const uint8_t* const d_cand = map_dev ? candidate : (const uint8_t*)(d + oCand);
+    for (int32_t b = 0; b < nt; ++b) {                                   // the T matrix and its features, gathered here (:563-569)
+        memcpy(h + oT + (size_t)b * 32, kf_desc + (size_t)ti[b] * 32, 32);
+        memcpy(h + oTF + (size_t)b * fw * 8, kf_feat + (size_t)ti[b] * fw, (size_t)fw * 8);
+    }
+    memcpy(h + oTi, ti.data(), (size_t)nt * 4);
+    memcpy(h + oCs, cs.data(), cs.size() * 4);
+    memcpy(h + oIt, items.data(), (size_t)(n_items + 1) * 4);
+    if (lines) memcpy(h + oD2, dir2.data(), (size_t)nt * 16);
+    memset(h + oRes, 0, 16);
+    grid_aux_fill(h + oAux, nt);
+    int32_t* const res = (int32_t*)(d + oRes);                           // [0] gate count, [1] nq, [2] matchGrid's count
+    plslam_grid_problem q{};
+    q.d1 = (const uint8_t*)(d + oQ); q.d2 = (const uint8_t*)(d + oT); q.centres1 = (int32_t*)(d + oCen);
+    q.cell_start = (int32_t*)(d + oCs); q.cell_items = (int32_t*)(d + oIt);
+    q.dir1 = lines ? (double*)(d + oD1) : nullptr; q.dir2 = lines ? (double*)(d + oD2) : nullptr;
+    q.n1 = n_map; q.n2 = nt; q.n_centres = nc; q.grid_cols = cols; q.grid_rows = rows; q.n_items = n_items;
+    for (int k = 0; k < 4; ++k) q.window[k] = fm->ws;
+    q.sim_th = fm->line_sim_th; q.nnr = fm->nnr_grid; q.mutual = mutual ? 1 : 0;
+    q.pair_capacity = (int32_t)cap;
+    q.matches_12 = (int32_t*)(d + oM); q.n_matches = res + 2;
+    if ((rc = grid_prepare_one(q, ctx->misc_c.as<uint32_t>(), nullptr, (GridDesc*)(h + oDesc)))) return rc;
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image, hipMemcpyHostToDevice, s));
+    // ---- the launch sequence
+    if ((rc = launch_visible_cand(*K, Twf, (const double*)d_LM, d_cand, n_map, lines, (uint8_t*)(d + oVis), s))) return rc;
+    hipLaunchKernelGGL(k_compact_flags, dim3(1), dim3(1024), 0, s, (const uint8_t*)(d + oVis), n_map, (int32_t*)(d + oQi), res + 1,
+                       (int32_t*)(d + oMap));
+    hipLaunchKernelGGL(k_gather_q, dim3((unsigned)(((int64_t)n_map * (4 + lw) + 255) / 256)), dim3(256), 0, s, (const uint64_t*)d_MD,
+                       (const uint64_t*)d_LM, (const int32_t*)(d + oQi), res + 1, lw, (uint64_t*)(d + oQ), (uint64_t*)(d + oQL));
+    hipLaunchKernelGGL(k_patch_grid_rows, dim3(1), dim3(1), 0, s, (GridDesc*)(d + oDesc), res + 1);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    if ((rc = launch_project_cells_n(*K, Twf, (const double*)(d + oQL), res + 1, n_map, lines, fm->inv_width, fm->inv_height,
+                                     (int32_t*)(d + oCen), lines ? (double*)(d + oD1) : nullptr, s)))
+        return rc;
+    if ((rc = grid_launch_single(q, (const GridDesc*)(d + oDesc), s, (uint32_t*)(d + oAux), true))) return rc;
+    if ((rc = launch_gate_n(lines, *K, Twf, (const double*)(d + oQL), (const int32_t*)(d + oM), res + 1, n_map, (const double*)(d + oTF),
+                            max_epip, (uint8_t*)(d + oMask), res, s)))
+        return rc;
+    hipLaunchKernelGGL(k_associate, dim3((n_map + 255) / 256), dim3(256), 0, s, (const int32_t*)(d + oQi), res + 1,
+                       (const int32_t*)(d + oM), (const uint8_t*)(d + oMask), (const int32_t*)(d + oTi), (int32_t*)(d + oMap));
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    // ---- one download (the counters' page and the table behind it), one synchronisation
+    char* ho = ctx->pin_out.as<char>();
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oRes, (oMap - oRes) + (size_t)n_map * 4, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    sg.dismiss();
+    const int32_t* r = reinterpret_cast<const int32_t*>(ho);
+    PLSLAM_REQUIRE(r[2] >= 0, PLSLAM_ERANGE);                            // (matchGrid's candidate store: the capacity is an upper bound)
+    if (r[1] > min_matches && r[2] < min_matches) {                      // the brute-force matcher replaces matchGrid's table
+        *redo = 1;
+        return PLSLAM_OK;
+    }
+    memcpy(map_to_kf, ho + (oMap - oRes), (size_t)n_map * 4);
+    if (n_matches) *n_matches = r[0];
+    return PLSLAM_OK;
 }
 
 // MapHandler::matchKF2KFPoints / matchKF2KFLines, compute part (src/mapHandler.cpp:246-278 / :378-426)
@@ -320,6 +503,14 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
 
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard dg_(ctx->device);    // every entry point runs on the context's device, whatever the calling thread's current one
+    if (fast) {
+        // one launch sequence, one synchronisation; it asks for the step-by-step form below when the brute-force matcher
+        // has to replace matchGrid's table (which needs the candidate list's length on the host)
+        int redo = 0;
+        const int rc1 = map2kf_fast_once(ctx, lines, K, Twf, LM, med_desc, candidate, n_map, kf_desc, kf_feat, kf_seg, ti, nnr, mutual,
+                                         max_epip, min_matches, fm, map_to_kf, n_matches, map_dev, &redo);
+        if (rc1 || !redo) return rc1;
+    }
     hipStream_t s = ctx->stream;
     StreamSyncOnError sg(s);
     // ---- stage the map and the keyframe on the device (ONE page-locked image, one upload), project + visibility test ----

@@ -179,7 +179,7 @@ __device__ __forceinline__ void for_candidates(const GridDesc& g, const GridPtrs
 // NT lanes per workgroup: 1024, or 256 for problems of at most 256 rows (a 200-line problem would leave 12 of 16 waves
 // idle at every barrier -- and, in a batch, occupy a whole CU)
 template <int MODE, int NT>
-__global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ probs, uint32_t lds_words, const uint32_t* __restrict__ pre)
+__global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ probs, uint32_t lds_words, const uint32_t* __restrict__ pre_arg)
 {
     // pre != nullptr (one LDS-resident mutual problem alone on the chip, MODE 2): PA's distances were evaluated by
     // k_grid_candidates on many workgroups -- every candidate word lies in the second half of the problem's candidate store,
@@ -260,11 +260,15 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     uint32_t fb1 = 11, fb2 = 11;                    // bits of a row / column number in the flat words
     uint32_t seg_words = 0, tail_cap = 0, reg_off = 0;
     PLSLAM_AS_LDS uint32_t* colbest = nullptr;
+    // (the launcher may know an upper bound of n1 only -- the row count then comes from the device, GridDesc::n1 patched behind
+    // the upload --: whether the candidates were listed by k_grid_candidates is decided here, by the same test as there)
+    const uint32_t* pre = pre_arg;
     if constexpr (MODE == 2) {
         fb2 = 1;
         while (fb2 < 22 && (1u << fb2) < (uint32_t)n2) ++fb2;
         fb1 = 23u - fb2 > 14u ? 14u : 23u - fb2;
         flat = g.mutual && (uint32_t)n2 <= (1u << fb2) && (uint32_t)n1 <= (1u << fb1);
+        if (!flat) pre = nullptr;
         // (pre: neither the items nor the desc2 rows are needed here -- their LDS goes to the candidates)
         const uint32_t pa_end = pre ? items_off : d2_off + 8u * (uint32_t)n2 + (has_dirs ? 4u * (uint32_t)n2 : 0u);
         colbest = s_dyn + pa_end;
@@ -803,6 +807,7 @@ __global__ __launch_bounds__(256) void k_grid_candidates(const GridDesc* __restr
     PLSLAM_AS_GLOBAL uint32_t* raw = rcnt + n1 + (n1 + GRID_THREADS - 1) / GRID_THREADS + (uint32_t)g.pair_cap;
     PLSLAM_AS_GLOBAL const u32x4* g_d1 = (PLSLAM_AS_GLOBAL const u32x4*)g.d1;
     uint32_t* const counter = aux;
+    if (!(g.mutual && (uint32_t)n2 <= (1u << fb2) && (uint32_t)n1 <= (1u << fb1))) return;   // (k_match_grid evaluates its own then)
     if (tid == 0) s_n = 0u;
     __syncthreads();
     const int64_t task = (int64_t)blockIdx.x * 256 + tid;
@@ -982,7 +987,9 @@ static int launch_group(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hi
 // one launch.
 size_t grid_aux_words(int32_t) { return 4; }
 void grid_aux_fill(void* host_image, int32_t n2) { memset(host_image, 0, grid_aux_words(n2) * 4); }
-int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux)
+// n1_upper_bound: q.n1 is an upper bound (the descriptor's n1 is patched on the device): both launches go out whenever the
+// problem runs LDS-resident at the bound -- the kernels decide for themselves whether the row count admits the packed words.
+int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux, bool n1_upper_bound)
 {
     const int64_t ncell = (int64_t)q.grid_cols * q.grid_rows;
     const bool dirs = q.dir1 != nullptr && q.dir2 != nullptr;
@@ -993,7 +1000,7 @@ int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hip
     while (fb2 < 22 && (1u << fb2) < (uint32_t)q.n2) ++fb2;
     const uint32_t fb1 = 23u - fb2 > 14u ? 14u : 23u - fb2;
     const bool flat = q.mutual && (uint32_t)q.n2 <= (1u << fb2) && (uint32_t)q.n1 <= (1u << fb1);
-    if (group == 2 && flat && aux && q.n1 >= GRID_SPLIT_MIN_ROWS && q.n2 > 0 && q.pair_capacity > 0) {
+    if (group == 2 && (flat || (n1_upper_bound && q.mutual)) && aux && q.n1 >= GRID_SPLIT_MIN_ROWS && q.n2 > 0 && q.pair_capacity > 0) {
         const int64_t wx = std::min<int64_t>((int64_t)q.window[0] + q.window[1] + 1, q.grid_cols);
         const int split = (int)std::max<int64_t>(1, std::min<int64_t>(wx, GRID_SPLIT_MAX));
         const unsigned nwg = (unsigned)(((int64_t)q.n1 * split + 255) / 256);
@@ -1085,7 +1092,7 @@ int grid_prepare_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* s
 }
 int grid_launch_prepared(const plslam_grid_problem& q, const GridDesc* d_desc_slot, hipStream_t s)
 {
-    return grid_launch_single(q, d_desc_slot, s, nullptr);       // (no shared words: one launch)
+    return grid_launch_single(q, d_desc_slot, s, nullptr, false);       // (no shared words: one launch)
 }
 // h_desc_slot must stay valid until the copy is done (pinned or synchronised by the caller)
 int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* d_desc_slot,
@@ -1094,7 +1101,7 @@ int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32
     int rc;
     if ((rc = grid_prepare_one(q, scratch, status, h_desc_slot))) return rc;
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d_desc_slot, h_desc_slot, sizeof(GridDesc), hipMemcpyHostToDevice, s));
-    return grid_launch_single(q, d_desc_slot, s, nullptr);
+    return grid_launch_single(q, d_desc_slot, s, nullptr, false);
 }
 }  // namespace plslam
 
@@ -1265,7 +1272,7 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     StreamSyncOnError sg(s);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, ci.off, hipMemcpyHostToDevice, s));
     if (!hout_dev) PLSLAM_HIP_CHECK(hipMemsetAsync(dout + oN, 0, 8, s));
-    if ((rc = grid_launch_single(dq, (const GridDesc*)(d + oT), s, (uint32_t*)(d + oX)))) return rc;
+    if ((rc = grid_launch_single(dq, (const GridDesc*)(d + oT), s, (uint32_t*)(d + oX), false))) return rc;
     if (!hout_dev) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, dout, co.off, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     const int32_t* res = (const int32_t*)(ctx->pin_out.as<char>() + oN);
