@@ -132,3 +132,90 @@ def test_final_isa_has_no_mfma_destination_hazard(tmp_path, fname):
     assert text.count("v_mfma_scale_f32_32x32x64_f8f6f4") >= (24 if fname == "hamming_mfma_d.hip" else 128)
     findings = mod.check(out, 12)
     assert not findings, findings[:5]
+
+
+def test_k1h_workgroup_column_combine_model():
+    """K1h's column partial (hamming_mfma_h.hip::combine_columns), modelled in numpy: the 16 group minima of a column --
+    4 waves x 2 lane halves x 2 M-tiles, 16-bit keys (d << 7 | 32 w + 16 g + r), M-tile 0 in the low halves of the 8 parked
+    words and M-tile 1 (the block's upper 128 rows) in the high halves -- go through the packed min / max network, are
+    widened to (d << 8 | row in the block) and merged: K0 must be the column's best row over the workgroup's 256 rows
+    (ties: the lowest row), K1 the best row outside K0's group of 16 -- incl. missing rows (0xFFFF) and penalised columns."""
+    r = np.random.Generator(np.random.PCG64(5))
+
+    def pk(op, a, b):                                      # v_pk_min_u16 / v_pk_max_u16
+        lo, hi = op(a & 0xFFFF, b & 0xFFFF), op(a >> 16, b >> 16)
+        return (hi << 16) | lo
+
+    def pk_merge(a0, a1, c0, c1):
+        m = pk(max, a0, c0)
+        return pk(min, a0, c0), pk(min, m, pk(min, a1, c1))
+
+    def merge2(a0, a1, c0, c1):
+        return min(a0, c0), min(max(a0, c0), min(a1, c1))
+
+    for it in range(4000):
+        ties = it % 3 == 0
+        words, groups = [], []                             # groups: (key widened by hand, group id)
+        for w in range(4):
+            for g in range(2):
+                halves = []
+                for mt in range(2):
+                    kind = r.integers(0, 12)
+                    rr = int(r.integers(0, 16))
+                    if kind == 0:
+                        key = 0xFFFF                       # no row of this group exists
+                    elif kind == 1:
+                        key = 0xBF80 + 32 * w + 16 * g + rr  # a column that does not exist (zero codes + penalty)
+                    else:
+                        d = int(r.integers(0, 4)) if ties else int(r.integers(0, 257))
+                        key = (d << 7) | (32 * w + 16 * g + rr)
+                    halves.append(key)
+                    if key != 0xFFFF:
+                        groups.append((((key >> 7) << 8) | (128 * mt + (key & 0x7F)), (w, g, mt)))
+                words.append((halves[1] << 16) | halves[0])
+        lo = [pk(min, words[2 * q], words[2 * q + 1]) for q in range(4)]
+        hi = [pk(max, words[2 * q], words[2 * q + 1]) for q in range(4)]
+        lo[0], hi[0] = pk_merge(lo[0], hi[0], lo[1], hi[1])
+        lo[2], hi[2] = pk_merge(lo[2], hi[2], lo[3], hi[3])
+        lo[0], hi[0] = pk_merge(lo[0], hi[0], lo[2], hi[2])
+        e0, e1, u0, u1 = lo[0] & 0xFFFF, hi[0] & 0xFFFF, lo[0] >> 16, hi[0] >> 16
+        k0, k1 = merge2(e0 + (e0 & 0xFF80), e1 + (e1 & 0xFF80), u0 + (u0 & 0xFF80) + 128, u1 + (u1 & 0xFF80) + 128)
+        assert k0 <= 0x1FFFF and (k1 >> 8) <= 511           # the one-word partial: K0 << 9 | K1's distance
+        groups.sort()
+        if not groups:
+            assert (k0 >> 8) == 511 and (k1 >> 8) == 511
+            continue
+        assert k0 == groups[0][0], (it, hex(k0), hex(groups[0][0]))
+        assert (k0 & 0xFF) >> 4 == (groups[0][0] & 0xFF) >> 4
+        others = [k for k, gid in groups if gid != groups[0][1]]
+        if others:
+            assert k1 == others[0], (it, hex(k1), hex(others[0]))
+        else:
+            assert (k1 >> 8) == 511
+
+
+def test_k1h_stays_at_three_workgroups_per_cu(tmp_path):
+    """What K1h's 2.8 ms depend on and a careless edit loses silently: 3 workgroups per CU need <= 168 VGPRs and <= 53 248 B of
+    LDS per workgroup (54 272 B measured 2 workgroups per CU and 3.29 ms), and the spilled registers stay outside the
+    tile loop (16 dwords)."""
+    import os
+    import re
+    import subprocess
+    from plslam_amd import build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "plslam_amd", "csrc", "hamming_mfma_h.hip")
+    r = subprocess.run([B.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
+                        "-I" + os.path.join(root, "include"), "-S", "--cuda-device-only", src, "-o", "-"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    seen = 0
+    for blk in r.stdout.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "k_scan_sym_mfma_h" not in name:
+            continue
+        seen += 1
+        lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1))
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+        spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
+        assert lds <= 53248 and vgpr <= 168 and spill <= 16, (name, lds, vgpr, spill)
+    assert seen == 2                                       # the symmetric and the directed instantiation
