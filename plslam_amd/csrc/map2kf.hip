@@ -294,7 +294,11 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
     const int32_t n_items = cs.back();
     const int32_t win[4] = {fm->ws, fm->ws, fm->ws, fm->ws};
     const int64_t cap = grid_store_capacity_bound(n_map, nc, cs.data(), cols, rows, win, mutual);     // (rows: the upper bound)
-    PLSLAM_REQUIRE(cap < (int64_t(1) << 31) - 1, PLSLAM_ERANGE);
+    if (cap >= (int64_t(1) << 28)) {       // a store sized for every landmark of a huge map: the step-by-step form sizes it for the list
+        *redo = 1;
+        sg.dismiss();
+        return PLSLAM_OK;
+    }
     // ---- one image up
     Carve c;
     const size_t oLM = c.take(map_dev ? 0 : (size_t)n_map * lw * 8), oMD = c.take(map_dev ? 0 : (size_t)n_map * 32),
