@@ -188,7 +188,8 @@ __device__ __forceinline__ void xform44(const Pose12& T, const double* X, double
 __global__ void __launch_bounds__(256)
 k_point_gate(CamD K, Pose12 Twf, const double* __restrict__ Xw, const int32_t* __restrict__ m12,
              int32_t nq, const double* __restrict__ pl, double th, uint8_t* __restrict__ mask,
-             int32_t* __restrict__ count, const int32_t* __restrict__ nq_dev)
+             int32_t* __restrict__ count, const int32_t* __restrict__ nq_dev, const int32_t* __restrict__ idx,
+             const int32_t* __restrict__ ti, int32_t* __restrict__ map_to_kf)
 {
     if (nq_dev) nq = *nq_dev;                  // (the row count lives on the device: the launch covers an upper bound)
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -203,6 +204,7 @@ k_point_gate(CamD K, Pose12 Twf, const double* __restrict__ Xw, const int32_t* _
             ok = sqrt(ex * ex + ey * ey) < th;
         }
         mask[i] = (uint8_t)ok;
+        if (ok && map_to_kf) map_to_kf[idx[i]] = ti[i2];          // :614-619, the association (table pre-filled with -1)
     }
     if (count) {
         const unsigned long long b = __ballot(ok);
@@ -214,7 +216,8 @@ k_point_gate(CamD K, Pose12 Twf, const double* __restrict__ Xw, const int32_t* _
 __global__ void __launch_bounds__(256)
 k_line_gate(CamD K, Pose12 Twf, const double* __restrict__ Lw, const int32_t* __restrict__ m12,
             int32_t nq, const double* __restrict__ le, double th, uint8_t* __restrict__ mask,
-            int32_t* __restrict__ count, const int32_t* __restrict__ nq_dev)
+            int32_t* __restrict__ count, const int32_t* __restrict__ nq_dev, const int32_t* __restrict__ idx,
+            const int32_t* __restrict__ ti, int32_t* __restrict__ map_to_kf)
 {
     if (nq_dev) nq = *nq_dev;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -233,6 +236,7 @@ k_line_gate(CamD K, Pose12 Twf, const double* __restrict__ Lw, const int32_t* __
             ok = (e0 < th) && (e1 < th);
         }
         mask[i] = (uint8_t)ok;
+        if (ok && map_to_kf) map_to_kf[idx[i]] = ti[i2];
     }
     if (count) {
         const unsigned long long b = __ballot(ok);
@@ -307,7 +311,8 @@ int launch_point_gate(const plslam_cam& K, const double* Twf16, const double* Xw
     if (count) PLSLAM_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), s));
     if (nq <= 0) return PLSLAM_OK;
     hipLaunchKernelGGL(k_point_gate, dim3((nq + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16),
-                       Xw, m12, nq, pl, th, mask, count, (const int32_t*)nullptr);
+                       Xw, m12, nq, pl, th, mask, count, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr,
+                       (int32_t*)nullptr);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
@@ -319,7 +324,8 @@ int launch_line_gate(const plslam_cam& K, const double* Twf16, const double* Lw,
     if (count) PLSLAM_HIP_CHECK(hipMemsetAsync(count, 0, sizeof(int32_t), s));
     if (nq <= 0) return PLSLAM_OK;
     hipLaunchKernelGGL(k_line_gate, dim3((nq + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16),
-                       Lw, m12, nq, le, th, mask, count, (const int32_t*)nullptr);
+                       Lw, m12, nq, le, th, mask, count, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr,
+                       (int32_t*)nullptr);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
@@ -385,28 +391,124 @@ int launch_project_cells(const plslam_cam& K, const double* Twf16, const double*
     return PLSLAM_OK;
 }
 
-// The same three with the row count ON THE DEVICE (*n_dev <= n_max; the launch covers n_max rows): the drivers' one-synchronisation
+// The gates with the row count ON THE DEVICE (*n_dev <= n_max; the launch covers n_max rows): the drivers' one-synchronisation
 // form builds its candidate list on the device and never learns its length before the results are back.  The gate's counter is
-// NOT cleared here (the caller's image holds the zero).
-int launch_project_cells_n(const plslam_cam& K, const double* Twf16, const double* X, const int32_t* n_dev, int32_t n_max, int lines,
-                           double inv_w, double inv_h, int32_t* cells, double* dir1, hipStream_t s)
-{
-    if (n_max <= 0) return PLSLAM_OK;
-    hipLaunchKernelGGL(k_project_cells, dim3((n_max + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), X, n_max, lines,
-                       inv_w, inv_h, cells, dir1, n_dev);
-    PLSLAM_HIP_CHECK(hipGetLastError());
-    return PLSLAM_OK;
-}
+// NOT cleared here (the caller's image holds the zero); idx / ti / map_to_kf: the association of the rows that pass.
 int launch_gate_n(int lines, const plslam_cam& K, const double* Twf16, const double* LM, const int32_t* m12, const int32_t* n_dev,
-                  int32_t n_max, const double* feat, double th, uint8_t* mask, int32_t* count, hipStream_t s)
+                  int32_t n_max, const double* feat, double th, uint8_t* mask, int32_t* count, const int32_t* idx, const int32_t* ti,
+                  int32_t* map_to_kf, hipStream_t s)
 {
     if (n_max <= 0) return PLSLAM_OK;
     if (lines)
         hipLaunchKernelGGL(k_line_gate, dim3((n_max + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), LM, m12, n_max, feat,
-                           th, mask, count, n_dev);
+                           th, mask, count, n_dev, idx, ti, map_to_kf);
     else
         hipLaunchKernelGGL(k_point_gate, dim3((n_max + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), LM, m12, n_max, feat,
-                           th, mask, count, n_dev);
+                           th, mask, count, n_dev, idx, ti, map_to_kf);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+
+// ---- the map<->keyframe drivers' one-synchronisation form (map2kf.hip): its small kernels fused -- a launch of a
+// microsecond's work costs 4-5 us on the timeline ------------------------------------------------------------------------------
+// candidate pre-filter (:549-551, :650-655) x candidate flags -> the STABLE list of the landmarks that pass (ascending) + its
+// length, the association table's -1 start, and the row count of the matchGrid problem that follows (its uploaded descriptor).
+// One workgroup: a lane owns a contiguous chunk, a scan over the lanes' counts gives its first slot.
+__global__ void __launch_bounds__(1024)
+k_visible_compact(CamD K, Pose12 Twf, const double* __restrict__ X, const uint8_t* __restrict__ cand, int32_t n, int lines,
+                  int32_t* __restrict__ idx, int32_t* __restrict__ n_out, int32_t* __restrict__ fill, GridDesc* __restrict__ desc)
+{
+    __shared__ int32_t s_sum[1024];
+    const int tid = (int)threadIdx.x;
+    const int32_t chunk = (n + 1023) / 1024, lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    auto passes = [&](int32_t i) -> bool {
+        if (cand[i] == 0) return false;
+        double P[3], E[3];
+        if (!lines) {
+            xform44(Twf, X + 3 * (size_t)i, P);
+            return inside(K, P) != 0;
+        }
+        xform44(Twf, X + 6 * (size_t)i, P);
+        xform44(Twf, X + 6 * (size_t)i + 3, E);
+        return inside(K, P) && inside(K, E);
+    };
+    uint32_t bits = 0;                       // (chunks of at most 32 landmarks per lane keep their flags; longer ones re-evaluate)
+    int32_t c = 0;
+    for (int32_t i = lo; i < hi; ++i) {
+        const bool v = passes(i);
+        if (v && i - lo < 32) bits |= 1u << (i - lo);
+        c += v;
+        fill[i] = -1;
+    }
+    s_sum[tid] = c;
+    __syncthreads();
+    for (int st = 1; st < 1024; st <<= 1) {                      // inclusive scan
+        const int32_t v = tid >= st ? s_sum[tid - st] : 0;
+        __syncthreads();
+        s_sum[tid] += v;
+        __syncthreads();
+    }
+    int32_t k = s_sum[tid] - c;
+    for (int32_t i = lo; i < hi; ++i)
+        if (i - lo < 32 ? ((bits >> (i - lo)) & 1u) != 0u : passes(i)) idx[k++] = i;
+    if (tid == 1023) {
+        *n_out = s_sum[1023];
+        if (desc) desc->n1 = s_sum[1023];
+    }
+}
+
+// Q matrix construction (:555, :567) + pj_points / pj_lines (k_project_cells): row a of Q = med_desc[idx[a]], of QL = LM[idx[a]],
+// its window centre(s) from QL; a lane per listed landmark, *n_dev of them
+__global__ void __launch_bounds__(256)
+k_prepare_rows(CamD K, Pose12 Twf, const uint64_t* __restrict__ md, const double* __restrict__ lm, const int32_t* __restrict__ idx,
+               const int32_t* __restrict__ n_dev, int lines, double inv_w, double inv_h, uint64_t* __restrict__ Q,
+               double* __restrict__ QL, int32_t* __restrict__ cells, double* __restrict__ dir1)
+{
+    const int a = blockIdx.x * 256 + threadIdx.x;
+    if (a >= *n_dev) return;
+    const int64_t src = idx[a];
+    const int nc = lines ? 2 : 1, lw = 3 * nc;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) Q[(int64_t)a * 4 + w] = md[src * 4 + w];
+    double X[6];
+    for (int w = 0; w < lw; ++w) {
+        X[w] = lm[src * lw + w];
+        QL[(int64_t)a * lw + w] = X[w];
+    }
+    auto cvtt = [](double v) -> int32_t { return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN; };
+    int32_t c[4];
+    for (int e = 0; e < nc; ++e) {
+        double P[3], u, v;
+        xform44(Twf, X + 3 * e, P);
+        project(K, P, u, v);
+        c[2 * e] = cvtt(u * inv_w);
+        c[2 * e + 1] = cvtt(v * inv_h);
+        cells[((size_t)a * nc + e) * 2] = c[2 * e];
+        cells[((size_t)a * nc + e) * 2 + 1] = c[2 * e + 1];
+    }
+    if (lines) {
+        const double vx = (double)c[2] - (double)c[0], vy = (double)c[3] - (double)c[1];
+        const double magnitude = sqrt(vx * vx + vy * vy);
+        dir1[2 * (size_t)a] = vx / magnitude;
+        dir1[2 * (size_t)a + 1] = vy / magnitude;
+    }
+}
+
+int launch_visible_compact(const plslam_cam& K, const double* Twf16, const double* X, const uint8_t* cand, int32_t n, int lines,
+                           int32_t* idx, int32_t* n_out, int32_t* fill, GridDesc* desc, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_visible_compact, dim3(1), dim3(1024), 0, s, cam_d(K), pose12(Twf16), X, cand, n, lines, idx, n_out, fill, desc);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+int launch_prepare_rows(const plslam_cam& K, const double* Twf16, const void* md, const double* lm, const int32_t* idx,
+                        const int32_t* n_dev, int32_t n_max, int lines, double inv_w, double inv_h, void* Q, double* QL, int32_t* cells,
+                        double* dir1, hipStream_t s)
+{
+    if (n_max <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_prepare_rows, dim3((n_max + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16),
+                       static_cast<const uint64_t*>(md), lm, idx, n_dev, lines, inv_w, inv_h, static_cast<uint64_t*>(Q), QL, cells, dir1);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

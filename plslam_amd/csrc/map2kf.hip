@@ -23,11 +23,17 @@ void grid_aux_fill(void* host_image, int32_t n2);
 // lba.hip: the visibility pre-filter AND the candidate flags, both on the device
 int launch_visible_cand(const plslam_cam& K, const double* Twf16, const double* X, const uint8_t* cand, int32_t n, int lines,
                         uint8_t* vis, hipStream_t s);
-// lba.hip: projection into grid cells / the epipolar gates with the row count on the device (*n_dev <= n_max)
-int launch_project_cells_n(const plslam_cam& K, const double* Twf16, const double* X, const int32_t* n_dev, int32_t n_max, int lines,
-                           double inv_w, double inv_h, int32_t* cells, double* dir1, hipStream_t s);
+// lba.hip: the epipolar gate with the row count on the device (*n_dev <= n_max) and, optionally, the association behind it
 int launch_gate_n(int lines, const plslam_cam& K, const double* Twf16, const double* LM, const int32_t* m12, const int32_t* n_dev,
-                  int32_t n_max, const double* feat, double th, uint8_t* mask, int32_t* count, hipStream_t s);
+                  int32_t n_max, const double* feat, double th, uint8_t* mask, int32_t* count, const int32_t* idx, const int32_t* ti,
+                  int32_t* map_to_kf, hipStream_t s);
+// lba.hip: visibility x candidate flags -> stable list + length (+ -1 fill of the association table, + the row count into a
+// matchGrid descriptor); Q rows + landmarks + window centres of the listed landmarks
+int launch_visible_compact(const plslam_cam& K, const double* Twf16, const double* X, const uint8_t* cand, int32_t n, int lines,
+                           int32_t* idx, int32_t* n_out, int32_t* fill, GridDesc* desc, hipStream_t s);
+int launch_prepare_rows(const plslam_cam& K, const double* Twf16, const void* md, const double* lm, const int32_t* idx,
+                        const int32_t* n_dev, int32_t n_max, int lines, double inv_w, double inv_h, void* Q, double* QL, int32_t* cells,
+                        double* dir1, hipStream_t s);
 // match_grid.hip: capacity of the windowed matcher's candidate store from the grid alone
 int64_t grid_store_capacity_bound(int32_t n1, int32_t n_centres, const int32_t* cell_start, int32_t cols, int32_t rows,
                                   const int32_t window[4], int mutual);
@@ -55,62 +61,6 @@ int launch_gather_rows(const void* src, const int32_t* idx, int32_t n, int32_t r
     return PLSLAM_OK;
 }
 
-
-// ---- the one-synchronisation form of the map<->keyframe drivers with fast_matching (map2kf_driver below) -------------------
-// stable compaction: idx[0 .. *n_out) = the i with flags[i] != 0, ascending; fill[0 .. n) = -1 (the association table's start).
-// One workgroup: a lane owns a contiguous chunk, a scan over the lanes' counts gives its first slot.
-__global__ void __launch_bounds__(1024)
-k_compact_flags(const uint8_t* __restrict__ flags, int32_t n, int32_t* __restrict__ idx, int32_t* __restrict__ n_out,
-                int32_t* __restrict__ fill)
-{
-    __shared__ int32_t s_sum[1024];
-    const int tid = (int)threadIdx.x;
-    const int32_t chunk = (n + 1023) / 1024, lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    int32_t c = 0;
-    for (int32_t i = lo; i < hi; ++i) {
-        c += flags[i] != 0;
-        fill[i] = -1;
-    }
-    s_sum[tid] = c;
-    __syncthreads();
-    for (int st = 1; st < 1024; st <<= 1) {                      // inclusive scan
-        const int32_t v = tid >= st ? s_sum[tid - st] : 0;
-        __syncthreads();
-        s_sum[tid] += v;
-        __syncthreads();
-    }
-    int32_t k = s_sum[tid] - c;
-    for (int32_t i = lo; i < hi; ++i)
-        if (flags[i] != 0) idx[k++] = i;
-    if (tid == 1023) *n_out = s_sum[1023];
-}
-
-// Q / T matrix construction for the listed landmarks (:555, :567): row a of Q = med_desc[idx[a]] (4 words), of QL = LM[idx[a]]
-// (lw words); *n_dev rows, the launch covers n_max
-__global__ void __launch_bounds__(256)
-k_gather_q(const uint64_t* __restrict__ md, const uint64_t* __restrict__ lm, const int32_t* __restrict__ idx,
-           const int32_t* __restrict__ n_dev, int32_t lw, uint64_t* __restrict__ Q, uint64_t* __restrict__ QL)
-{
-    const int32_t words = 4 + lw;
-    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (int64_t)*n_dev * words) return;
-    const int32_t row = (int32_t)(t / words), w = (int32_t)(t % words);
-    const int64_t src = idx[row];
-    if (w < 4) Q[(int64_t)row * 4 + w] = md[src * 4 + w];
-    else QL[(int64_t)row * lw + (w - 4)] = lm[src * lw + (w - 4)];
-}
-
-// the row count of a matchGrid problem becomes known on the device only: written into its (uploaded) descriptor
-__global__ void k_patch_grid_rows(GridDesc* __restrict__ desc, const int32_t* __restrict__ n_dev) { desc->n1 = *n_dev; }
-
-// :614-619, the association: landmark idx[a] <- keyframe feature ti[m12[a]] where the gate holds (table pre-filled with -1)
-__global__ void __launch_bounds__(256)
-k_associate(const int32_t* __restrict__ idx, const int32_t* __restrict__ n_dev, const int32_t* __restrict__ m12,
-            const uint8_t* __restrict__ mask, const int32_t* __restrict__ ti, int32_t* __restrict__ map_to_kf)
-{
-    const int a = blockIdx.x * 256 + threadIdx.x;
-    if (a < *n_dev && mask[a]) map_to_kf[idx[a]] = ti[m12[a]];
-}
 
 namespace {
 struct Carve {
@@ -309,7 +259,7 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
     const size_t image = c.off;
     // ---- device only
     const size_t oMap = c.take((size_t)n_map * 4);                       // the association table: directly behind the counters' page
-    const size_t oVis = c.take((size_t)n_map), oQi = c.take((size_t)n_map * 4), oQ = c.take((size_t)n_map * 32),
+    const size_t oQi = c.take((size_t)n_map * 4), oQ = c.take((size_t)n_map * 32),
                  oQL = c.take((size_t)n_map * lw * 8), oCen = c.take((size_t)n_map * nc * 8),
                  oD1 = c.take(lines ? (size_t)n_map * 16 : 0), oM = c.take((size_t)n_map * 4), oMask = c.take((size_t)n_map);
     if ((rc = ctx->misc_a.reserve(c.off))) return rc;
@@ -348,24 +298,18 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
     q.matches_12 = (int32_t*)(d + oM); q.n_matches = res + 2;
     if ((rc = grid_prepare_one(q, ctx->misc_c.as<uint32_t>(), nullptr, (GridDesc*)(h + oDesc)))) return rc;
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image, hipMemcpyHostToDevice, s));
-    // ---- the launch sequence
-    if ((rc = launch_visible_cand(*K, Twf, (const double*)d_LM, d_cand, n_map, lines, (uint8_t*)(d + oVis), s))) return rc;
-    hipLaunchKernelGGL(k_compact_flags, dim3(1), dim3(1024), 0, s, (const uint8_t*)(d + oVis), n_map, (int32_t*)(d + oQi), res + 1,
-                       (int32_t*)(d + oMap));
-    hipLaunchKernelGGL(k_gather_q, dim3((unsigned)(((int64_t)n_map * (4 + lw) + 255) / 256)), dim3(256), 0, s, (const uint64_t*)d_MD,
-                       (const uint64_t*)d_LM, (const int32_t*)(d + oQi), res + 1, lw, (uint64_t*)(d + oQ), (uint64_t*)(d + oQL));
-    hipLaunchKernelGGL(k_patch_grid_rows, dim3(1), dim3(1), 0, s, (GridDesc*)(d + oDesc), res + 1);
-    PLSLAM_HIP_CHECK(hipGetLastError());
-    if ((rc = launch_project_cells_n(*K, Twf, (const double*)(d + oQL), res + 1, n_map, lines, fm->inv_width, fm->inv_height,
-                                     (int32_t*)(d + oCen), lines ? (double*)(d + oD1) : nullptr, s)))
+    // ---- the launch sequence (five launches: the small steps are fused -- a launch of a microsecond's work costs 4-5 us)
+    if ((rc = launch_visible_compact(*K, Twf, (const double*)d_LM, d_cand, n_map, lines, (int32_t*)(d + oQi), res + 1,
+                                     (int32_t*)(d + oMap), (GridDesc*)(d + oDesc), s)))
+        return rc;
+    if ((rc = launch_prepare_rows(*K, Twf, d_MD, (const double*)d_LM, (const int32_t*)(d + oQi), res + 1, n_map, lines, fm->inv_width,
+                                  fm->inv_height, d + oQ, (double*)(d + oQL), (int32_t*)(d + oCen), lines ? (double*)(d + oD1) : nullptr, s)))
         return rc;
     if ((rc = grid_launch_single(q, (const GridDesc*)(d + oDesc), s, (uint32_t*)(d + oAux), true))) return rc;
     if ((rc = launch_gate_n(lines, *K, Twf, (const double*)(d + oQL), (const int32_t*)(d + oM), res + 1, n_map, (const double*)(d + oTF),
-                            max_epip, (uint8_t*)(d + oMask), res, s)))
+                            max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi), (const int32_t*)(d + oTi),
+                            (int32_t*)(d + oMap), s)))
         return rc;
-    hipLaunchKernelGGL(k_associate, dim3((n_map + 255) / 256), dim3(256), 0, s, (const int32_t*)(d + oQi), res + 1,
-                       (const int32_t*)(d + oM), (const uint8_t*)(d + oMask), (const int32_t*)(d + oTi), (int32_t*)(d + oMap));
-    PLSLAM_HIP_CHECK(hipGetLastError());
     // ---- one download (the counters' page and the table behind it), one synchronisation
     char* ho = ctx->pin_out.as<char>();
     PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oRes, (oMap - oRes) + (size_t)n_map * 4, hipMemcpyDeviceToHost, s));
