@@ -285,3 +285,15 @@ def test_fuzz_small_arbitrary_grids(ctx, oracle):
         assert got[1] == ref[1], seed
         hits += int((ref[0] >= 0).sum())
     assert hits > 500
+
+
+def test_two_launch_path_does_not_depend_on_the_candidate_order(ctx, oracle):
+    """One problem alone on the chip (>= 512 rows, LDS-resident, mutual) gets its distances from k_grid_candidates on many
+    workgroups: the candidate list's order is whatever the scheduling made it.  Every repetition must return the first
+    one's table and count -- which is the oracle's (tie stress: equal distances everywhere)."""
+    c = point_case(11, 1500, 1400, G.GRID_COLS, G.GRID_ROWS, ties=True)
+    ref = oracle.match_grid(window=(3, 3, 3, 3), nnr=0.8, mutual=True, **c)
+    for _ in range(25):
+        m, n = ctx.match_grid(window=(3, 3, 3, 3), nnr=0.8, mutual=True, **c)
+        np.testing.assert_array_equal(m, ref[0])
+        assert n == ref[1]
