@@ -50,6 +50,8 @@ def test_bench_single_gpu_line():
     assert sec["c1_substitute"]["value"] > 0 and "800 ORB + 100 LBD" in sec["c1_substitute"]["metric"]
     assert all("all " in sec[k]["verified"] for k in ("tables_only", "strong_512", "c1_substitute", "c5"))
     assert sec["grid"]["plan_1024_frame_pairs"]["problems"] == 2048 and len([k for k in sec["drivers"] if k != "workload"]) == 8
+    # the map<->keyframe drivers also with the map resident on the device (plslam_map2kf_match_*_dev)
+    assert all(v["map_on_device_us_median"] > 0 for k, v in sec["drivers"].items() if k.startswith("map2kf"))
     # the rotation of distinct batches, the step-time distribution and the one-batch comparison
     assert d["config"]["distinct_batches_in_rotation"] == 3 and d["one_repeated_batch"]["value"] > 0
     dist_ = d["ms_per_step_distribution"]
