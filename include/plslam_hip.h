@@ -91,9 +91,10 @@ void plslam_ctx_destroy(plslam_ctx* ctx);
 /* options: "scan_variant" (PLSLAM_SCAN_*), "scan_block" (queries per workgroup of the directed
  * scan: 256|512|1024), "sym_rows" (rows of d1 per lane in the symmetric scan: 0 = auto (default) | 1 | 4),
  * "group_cap" (workgroups of one problem co-scheduled on one XCD: 0 = auto (default) | 1..64),
- * "mfma_form" (bookkeeping of the matrix-core scan: 0 = auto (default; = 4) | 1 = best-2 push per tile (K1e) |
+ * "mfma_form" (bookkeeping of the matrix-core scan: 0 = auto (default; = 5) | 1 = best-2 push per tile (K1e) |
  * 2 = group minima in the row direction + second best by recomputation (K1f) | 3 = two directed scans per mutual problem
- * (K1g) | 4 = group minima in both directions, class-major layouts (K1h); identical match tables),
+ * (K1g) | 4 = group minima in both directions, class-major layouts (K1h) | 5 = K1h with the two M-tiles of a wave
+ * software-pipelined against each other (K1i); identical match tables),
  * "exact_second" (K1h: 0 (default) = the index of a row's SECOND neighbour in the internal key tables is exact only where
  * it is an output (plslam_knn2_hamming256) and the column keys are completed lazily by the finalize stage | 1 = every key
  * of plslam_match_plan_dump is exact; match tables are identical either way),

@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "lib", "libplslam_hip.so")
-SOURCES = ["hamming.hip", "hamming_mfma.hip", "hamming_mfma_g.hip", "hamming_mfma_d.hip", "hamming_mfma_h.hip", "lba.hip", "lba_assemble.hip", "map2kf.hip", "lbd.hip", "median_desc.hip", "match_grid.hip", "stereo_gates.hip", "pose_gn.hip", "lbd_float.hip", "capi.hip"]
+SOURCES = ["hamming.hip", "hamming_mfma.hip", "hamming_mfma_g.hip", "hamming_mfma_d.hip", "hamming_mfma_h.hip", "hamming_mfma_i.hip", "lba.hip", "lba_assemble.hip", "map2kf.hip", "lbd.hip", "median_desc.hip", "match_grid.hip", "stereo_gates.hip", "pose_gn.hip", "lbd_float.hip", "capi.hip"]
 HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(_ROOT, "include", "plslam_hip.h")]
 # -ffp-contract=off: the fp64 row kernels must execute the reference's operation order
 # (no FMA contraction) so that thresholded masks reproduce the CPU restatement bit for bit.

@@ -772,7 +772,7 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         return PLSLAM_OK;
     }
     if (!strcmp(key, "mfma_form")) {
-        PLSLAM_REQUIRE(value >= 0 && value <= 4, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(value >= 0 && value <= 5, PLSLAM_EINVAL);
         ctx->mfma_form = value;
         return PLSLAM_OK;
     }

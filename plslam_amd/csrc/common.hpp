@@ -122,7 +122,7 @@ struct plslam_ctx {
     int scan_block = 0;  // 0 = variant default
     int group_cap = 0;   // blocks of one problem kept together on one XCD; 0 = auto (capi.hip, `stripe`)
     int sym_rows = 0;    // rows of d1 per lane in the symmetric scan: 0 = auto, 1, 4
-    int mfma_form = 0;   // matrix-core scan: 0 = auto (= 4), 1 = exact push per tile (K1e), 2 = grouped rows (K1f), 3 = directed pairs (K1g), 4 = grouped both ways (K1h)
+    int mfma_form = 0;   // matrix-core scan: 0 = auto (= 5), 1 = exact push per tile (K1e), 2 = grouped rows (K1f), 3 = directed pairs (K1g), 4 = grouped both ways (K1h), 5 = K1h with the M-tiles pipelined against each other (K1i)
     int col_split = 0;   // K1f, few large problems: 0 = auto (cut the columns into ranges when the plan cannot fill the chip), 1 = never, 2 = always
     int exact_second = 0; // K1h: 1 = the index of every second-best row key is exact (0: only where it is an output -- knnMatch)
     int graph = 1;             // plslam_match_plan_run as a replayed HIP graph: 0 = latency plans, 1 = never (default until measured), 2 = always
@@ -272,8 +272,11 @@ int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int
 // workgroups than 256-row blocks alone give; the per-range row results are merged by the finalize kernel: ProblemDesc.)
 // K1h (hamming_mfma_h.hip): K1f's contract and partial table; minimum-only bookkeeping in both directions, class-major layouts;
 // its partials need launch_merge_fix16 (merge + second-best recomputation), same block table as launch_merge_partials16
-inline bool mfma_form_is_h(int form) { return form == 0 || form == 4; }      // 0 = auto
+inline bool mfma_form_is_h(int form) { return form == 0 || form == 4 || form == 5; }      // 0 = auto (= 5); K1h's tables: K1h and K1i
 int launch_scan_sym_mfma_h(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
+                           bool directed, hipStream_t s);
+// K1i (hamming_mfma_i.hip): K1h with the two M-tiles of a wave pipelined against each other; same tables, same merge kernel
+int launch_scan_sym_mfma_i(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
                            bool directed, hipStream_t s);
 int merge_fix16_cols(int parts);      // column slots per block-table entry of launch_merge_fix16
 int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, bool fix, hipStream_t s, int grid_cap = 0);
@@ -284,7 +287,8 @@ inline int launch_scan_mfma_form(int form, const SymDesc* d_sym, const BlockDesc
                                  int nzero, bool multi_window, bool directed, hipStream_t s, bool fused = false)
 {
     if (form == 3 && directed && !fused) return launch_scan_dir_mfma(d_sym, d_blocks, nblocks, d_zero, nzero, s);
-    if (mfma_form_is_h(form) && !fused) return launch_scan_sym_mfma_h(d_sym, d_blocks, nblocks, d_zero, nzero, directed, s);
+    if (form == 4 && !fused) return launch_scan_sym_mfma_h(d_sym, d_blocks, nblocks, d_zero, nzero, directed, s);
+    if (mfma_form_is_h(form) && !fused) return launch_scan_sym_mfma_i(d_sym, d_blocks, nblocks, d_zero, nzero, directed, s);
     return form == 1 ? launch_scan_sym_mfma(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, s)
                      : launch_scan_sym_mfma_g(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, fused, s);
 }

@@ -1,0 +1,638 @@
+// hamming_mfma_i.hip -- K1i: K1h's matrix-core symmetric Hamming kNN-2 scan (minimum-only bookkeeping in both directions,
+// class-major layouts, workgroup-level column partials) with the two M-tiles of a wave software-pipelined AGAINST EACH OTHER
+// (gfx950).  Round 4; the default.
+//
+// Contract, tables, layouts, arithmetic, partial table, merge kernel: those of K1h (hamming_mfma_h.hip): keys12[i] = best-2
+// over j, part21[256-row block of a][column slot] = (d0 << 17 | row0 << 9 | d1), keys = (distance << 23) | index =
+// cv::BFMatcher(NORM_HAMMING).knnMatch(k=2) order (reference call sites src/mapHandler.cpp:277,424,597,712,3223,3249).
+//
+// What changes is WHEN a wave's VALU work can issue.  K1h packs accumulator r of M-tile 0 with accumulator r of M-tile 1 into
+// one register of two 16-bit keys: the pack needs BOTH accumulator sets complete, so a wave's tile is eight MFMAs with four
+// VALU instructions between two of them (17 of 32 matrix-pipe cycles) followed by ~40 VALU instructions with no MFMA in
+// flight (pack, expansion of the next b tile, address work).  Three such waves share a SIMD; whenever two of them are in
+// their MFMA phase they take turns on the matrix pipe and their (in-order) VALU work trickles behind the blocked MFMAs.  PMC
+// (profiles/r3_w_pmc_a.txt): VALU 70 % busy, matrix pipe 37 % -- neither unit is saturated.
+//
+// Here a packed register holds rows q and q + 8 of ONE M-tile's lane group (both from the same accumulator set), so the
+// bookkeeping of a set depends on that set only, and the tile is two half-phases:
+//     phase 1   the 4 MFMAs of M-tile 0 (tile t)   x   pack + bookkeeping of M-tile 1 (tile t-1)
+//     (behind)  expansion of tile t+1, prefetch of tile t+4, column results of tile t-1 parked
+//     phase 2   the 4 MFMAs of M-tile 1 (tile t)   x   pack + bookkeeping of M-tile 0 (tile t)
+// Every MFMA has six independent VALU instructions behind it, no accumulator is read before the four MFMAs after it have been
+// issued, and the packed key registers of K1h (16 VGPRs) disappear: a key pair is consumed the moment it is packed.  The
+// column minima of a 16-row group are now the fold of the two halves of a register (rows 0-7 | rows 8-15: one more packed
+// min with op_sel), parked as the same word K1h parks: everything behind the tile loop is K1h's.
+#include "mfma_h_common.hpp"
+
+#include <type_traits>
+
+// PLSLAM_MI_F16 = 1 (default): the UNSCALED matrix instruction and three-input packed minima.
+//  * fp4 codes of +-4 on both sides and v_mfma_f32_32x32x64_f8f6f4 without block scales: a product is +-16, the accumulator
+//    2^23 + 32 d + tag, the 16-bit key d << 5 | tag with a FIVE-bit tag 16 g + r (the row within the lane pair's 32 rows of a
+//    wave).  The wave's number, which K1h carries in the key, comes back where the workgroup's column minima are combined
+//    (once per 8 tiles); the row direction never needed (g, r) and overwrites the five bits with the group number.  The
+//    scaled instruction costs the VALU port ~11 cycles beside a packed-VALU stream, this one ~7, and the matrix pipe takes
+//    one per 26 instead of 32.6 cycles (tools/issue_mix_microbench.hip, profiles/r4_issue_mix_microbench.txt).
+//  * Every key is below 0x7C00 ("none" = 0x7BFF), i.e. a positive finite half float, and half floats of one sign order like
+//    their bit patterns: gfx950's v_pk_minimum3_f16 is an exact THREE-input packed integer minimum on them, denormals
+//    included (tools/pk_min3_f16_check.hip: 0 of 202 k packed triples wrong; same issue rate as v_pk_min_u16).  Column
+//    direction: the 8 key pairs of an accumulator set in 4 instructions instead of 8.  Row direction: a tile's key pairs are
+//    KEPT on even tiles and folded together with the odd tile's (minimum, kept, new): 8 instructions per two tiles instead of
+//    16.  Per tile and M-tile pair 16 v_perm + 16 minima instead of 16 + 34.
+// 0: K1h's arithmetic (scaled instruction, 7-bit tags, two-input 16-bit minima).
+#ifndef PLSLAM_MI_F16
+#define PLSLAM_MI_F16 1
+#endif
+#define PLSLAM_MI_UNSCALED PLSLAM_MI_F16
+// PLSLAM_MI_ROWLOOK (with PLSLAM_MI_F16): M-tiles whose row direction keeps an even tile's pairs for the odd tile's fold --
+// 0 none, 1 M-tile 1 only (8 more registers), 2 both (16 more)
+#ifndef PLSLAM_MI_ROWLOOK
+#define PLSLAM_MI_ROWLOOK 0
+#endif
+#define PLSLAM_MI_LOOK(MT) (PLSLAM_MI_F16 && ((MT) == 1 ? PLSLAM_MI_ROWLOOK >= 1 : PLSLAM_MI_ROWLOOK >= 2))
+
+namespace plslam {
+
+namespace {
+#if PLSLAM_MI_UNSCALED
+constexpr uint32_t MI_MAG = FP4_FOUR;
+constexpr int MI_DSHIFT = 5;                                  // key16 = d << 5 | tag5
+constexpr uint32_t MI_ACC_BITS = 0x4B000000u + 4096u;         // float bits of 2^23 + 4096: the contraction is 32 d - 4096
+constexpr uint32_t MI_KEY16_MAX = 0x3FFFu;                    // real keys end at 256 << 5 | 31
+constexpr uint32_t MI_COL_PENALTY = 0x4000u;                  // zero codes ("distance 128": 0x1000 + tag) + this: above every real key, below the wrap
+constexpr int MI_SCALE_A = 0, MI_SCALE_B = 0;                 // both zero: the compiler selects the unscaled instruction
+constexpr uint32_t MI_NONE16 = 0x7BFFu;                       // the largest finite half float: above every key and every penalty key
+#else
+constexpr uint32_t MI_MAG = FP4_ONE;
+constexpr int MI_DSHIFT = 7;
+constexpr uint32_t MI_ACC_BITS = ACC_BITS;
+constexpr uint32_t MI_KEY16_MAX = KEY16_MAX;
+constexpr uint32_t MI_COL_PENALTY = COL_PENALTY;
+constexpr int MI_SCALE_A = SCALE_A, MI_SCALE_B = SCALE_B;
+constexpr uint32_t MI_NONE16 = 0xFFFFu;
+#endif
+constexpr uint32_t MI_NONE32 = MI_NONE16 * 0x00010001u;
+__device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+}  // namespace
+
+// DIRECTED = true: only keys12 (row direction) is produced.
+template <bool DIRECTED>
+__global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
+k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks, int32_t* __restrict__ zero, int nzero)
+{
+    // one buffer, two lives: during the scan the double-buffered b tile (9 216 B) followed by the PARKED sorted pairs of the
+    // row direction ([wave][slot][lane] x 8 B = 32 768 B); after the scan the row-result transpose [wave][row 0..63][33]
+    constexpr int ROWX_STRIDE = 33;               // dwords per row: lane = row reads are conflict-free
+    constexpr int PARK_OFF = 2 * MH_TILE_BYTES;
+    constexpr int SMEM_BYTES = PARK_OFF + 4 * 16 * 64 * 8;
+    static_assert(SMEM_BYTES >= 4 * 64 * ROWX_STRIDE * 4, "the transpose must fit");
+    __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
+    // column minima of the last 8 tiles, [tile & 7][wave][lane] (1 KB per tile): see K1h
+    __shared__ __attribute__((aligned(16))) uint32_t colstage[MH_CGROUP * 256];
+    // raw b dwords in flight (LDS-DMA ring, 3 slots): see K1h
+    __shared__ __attribute__((aligned(16))) uint32_t rawring[3][256];
+    uint8_t* const btile = smem;
+    u32x2_t* const park = reinterpret_cast<u32x2_t*>(smem + PARK_OFF) + (threadIdx.x >> 6) * (16 * 64) + (threadIdx.x & 63);
+
+    if (blockIdx.x == 0)
+        for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+
+    const int wg = xcd_remap_(blockIdx.x, gridDim.x);
+    const BlockDesc bd = blocks[wg];
+    if (bd.item < 0) return;                       // padding entry of the XCD-striped table
+    const SymDesc sd = syms[bd.item];
+    const int n1 = sd.n1, n2 = sd.n2;
+    const MhLayout L(n2);
+    const int ntiles = L.ntiles, nfull = L.nfull, rag_s = L.rag_s;
+    const int n2p = (MH_TILE_N * ntiles + 255) & ~255;            // slots per row of the partial table (= n2 rounded up to 256)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, g = lane >> 5;
+    const gcu32_t araw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.a);
+    const int iw = bd.row0 + 32 * w;               // first of this wave's 32 rows of M-tile 0; M-tile 1: + 128
+
+    // ---- A operands: MFMA row c of M-tile mt = block row 128 mt + 32 w + 16 g' + r' (K1h's mh_block_row): a lane's 16
+    // accumulator registers of an M-tile are 16 CONSECUTIVE rows of a ----
+    i32x4 afrag[2][MH_KSTEPS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = bd.row0 + 128 * mt + 32 * w + 16 * ((c >> 2) & 1) + (c & 3) + 4 * (c >> 3);
+        const int rrow = row < n1 ? row : n1 - 1;
+        const gcu32_t p = araw + (size_t)rrow * 8 + g;
+#pragma unroll
+        for (int ks = 0; ks < MH_KSTEPS; ++ks) afrag[mt][ks] = expand_dword_fp4<true, MI_MAG>(p[2 * ks]);
+    }
+
+    // row-direction state per SLOT s = 8 mt + q (low half: row 16 g + q of the lane's group of M-tile mt, high half: row
+    // 16 g + q + 8 of the same group):
+    //   gm[s]    running minimum of the 16-bit keys (d << 5 | 16 g + r; scaled form: d << 7 | 32 w + 16 g + r) of the current
+    //            group of 16 tiles, column class c
+    //   park[s]  (LDS) the best two GROUP minima (d << 5 | group in window; scaled form: d << 7 | group << 5 | 16 g + r) of the
+    //            lane's column class
+    //   kp[s]    (PLSLAM_MI_F16) the key pair of the even tile before, waiting for the odd tile's to be folded in with it
+    uint32_t gm[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) gm[s] = MI_NONE32;
+#if PLSLAM_MI_F16
+    uint32_t kp[16];       // (only the slots of the M-tiles that look back are ever touched)
+#endif
+
+    // accumulator start: 2^23 + 4096 + 16 g + r (scaled form: 2^23 + 16384 + 32 w + 16 g + r), constant per register and lane
+    // (in VECTOR registers: see K1h)
+    u32x16 seed;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) seed[r] = MI_ACC_BITS + (uint32_t)((PLSLAM_MI_UNSCALED ? 0 : 32 * w) + 16 * g + r);
+    asm volatile("" : "+v"(seed));
+    const int rest = n2 - (nfull >> 4) * MH_GROUP_ROWS;
+    auto lane_lim = [&]() __attribute__((always_inline)) -> int {
+        const int cc = (int)(threadIdx.x & 31u), v = rest - rag_s * cc;
+        return rag_s == 0 ? 0 : (v < 0 ? 0 : (v > rag_s ? rag_s : v));
+    };
+    const int lim_part = rag_s ? rest % rag_s : 0;                 // the one class that is cut (wave-uniform): its lim, 0 = none is
+
+    const bool rows_ragged = iw + 128 + 32 > n1;   // wave-uniform: some of this wave's rows do not exist
+    // rows of this lane's group of M-tile 0 that exist (M-tile 1: - 128): register r holds row iw + 128 mt + 16 g + r
+#define PLSLAM_MI_NV (n1 - iw - 16 * (int)((threadIdx.x >> 5) & 1u))
+    const bool wide_part = !DIRECTED && (sd.flags & 1);
+    const gu32_t part = DIRECTED ? (gu32_t) nullptr : (gu32_t) sd.part21 + (size_t)(bd.row0 >> 8) * n2p * (wide_part ? 2 : 1);
+    uint32_t* const cstage = colstage + 64 * w;        // + 256 (tile & 7) + lane
+#pragma unroll
+    for (int k = 0; k < 2; ++k) *reinterpret_cast<i32x4*>(colstage + 8 * tid + 4 * k) = i32x4{-1, -1, -1, -1};   // (two barriers before the first use)
+
+    // expansion duty of this lane: the b row of class (tid >> 3) of the tile, dword (tid & 7) of it (K1h)
+    const int ej = tid >> 3, ewd4 = (tid & 7) * 4;
+    const PLSLAM_GLOBAL char* const bbytes = (const PLSLAM_GLOBAL char*) sd.b;
+    auto load_raw = [&](int t) __attribute__((always_inline)) -> uint32_t {
+        const int tc = t < ntiles ? t : ntiles - 1;
+        const int gbase = (tc >> 4) * MH_GROUP_ROWS;
+        const uint32_t s = tc < nfull ? (uint32_t)MH_GROUP : (uint32_t)rag_s;
+        uint32_t row = __umul24((uint32_t)ej, s) + (uint32_t)(tc & 15);
+        const uint32_t last = (uint32_t)(n2 - 1 - gbase);
+        row = row < last ? row : last;
+        return *reinterpret_cast<gcu32_t>(bbytes + (size_t)gbase * 32 + (row * 32u + (uint32_t)ewd4));
+    };
+    // the steady loop's loads: LDS-DMA through inline asm with the matching wait issued by hand (vmcnt(2): K1h explains why).
+    // The address: ONE scalar base (b) + a 32-bit byte offset per lane (rows of b are below 2^23); M0 -- the LDS destination --
+    // is the compiler's reserved register, which it does not use in this kernel (gfx9 LDS instructions do not need it): it
+    // is declared clobbered instead of being saved and restored (tests/test_abi.py: no other m0 in the kernel's ISA).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+    auto load_raw_async = [&](int t, int slot) __attribute__((always_inline)) {
+        const int tc = t < ntiles ? t : ntiles - 1;
+        const uint32_t s = tc < nfull ? (uint32_t)MH_GROUP : (uint32_t)rag_s;
+        const uint32_t first = ((uint32_t)(tc & ~15) << 5) + (uint32_t)(tc & 15);      // the group's first row + the tile within the group
+        uint32_t row = __umul24((uint32_t)ej, s) + first;
+        const uint32_t last = (uint32_t)(n2 - 1);
+        row = row < last ? row : last;
+        const uint32_t voff = row * 32u + (uint32_t)ewd4;
+        const uint32_t lds_dst = (uint32_t)(uintptr_t)(&rawring[slot][64 * w]);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(bbytes), "s"(lds_dst) : "memory", "m0");
+    };
+#pragma clang diagnostic pop
+    // (the lane's own dword: its index 8 ej + ewd4 / 4 = tid from the two values the expansion keeps anyway -- a register
+    // holding tid through the tile loop is spilled, and the reload waits for vmcnt(0): the whole prefetch)
+    auto take_raw = [&](int slot) __attribute__((always_inline)) -> uint32_t {
+        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(&rawring[slot][0]) + (ej * 32 + ewd4));
+    };
+    auto expand_store = [&](uint32_t raw, int buf, int tn) __attribute__((always_inline)) {
+        uint8_t* dst = btile + buf * MH_TILE_BYTES + ej * MH_ROW_STRIDE + ewd4 * 4;
+        i32x4 v = expand_dword_fp4<false, MI_MAG>(raw);
+        if (tn >= nfull) {                                          // wave-uniform
+            const int vm = (int)(__umul24((uint32_t)rag_s, (uint32_t)ej) + (uint32_t)(tn & 15)) < rest ? -1 : 0;
+            v &= i32x4{vm, vm, vm, vm};
+        }
+        *reinterpret_cast<i32x4*>(dst) = v;
+    };
+
+    int wt0 = 0, wt1 = ntiles < MH_WINDOW ? ntiles : MH_WINDOW;      // the current window of tiles
+    int ring_slot = 1;                                               // rawring slot of the NEXT tile
+
+    // block kb of 8 tiles of column results -> one word per column for the workgroup's 256 rows (K1h's combine_columns)
+    const uint64_t part_u = (uint64_t)(uintptr_t)part;
+    const uint64_t part_s = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(part_u >> 32)) << 32) |
+                            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)part_u);
+    auto combine_columns = [&](int kb) __attribute__((always_inline)) {
+        if (DIRECTED) return;
+        uint32_t l_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=&v"(l_));
+        // column slot 64 w + l_ of the block: tile 2 w + (l_ >> 5), class l_ & 31
+        const uint32_t* const src = colstage + 512 * w + (((l_ & 32u) << 3) | (l_ & 31u));
+        uint32_t p[8];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) { p[2 * v] = src[64 * v]; p[2 * v + 1] = src[64 * v + 32]; }
+        auto pk_merge = [](uint32_t& a0, uint32_t& a1, uint32_t c0, uint32_t c1) {
+            const uint32_t m = pk_max16(a0, c0);
+            a0 = pk_min16(a0, c0);
+            a1 = pk_min16(m, pk_min16(a1, c1));
+        };
+        uint32_t k0, k1;
+#if PLSLAM_MI_UNSCALED
+        // p[2 v + h]: wave v, lane half h; the keys (d << 5 | 16 h + r) of one half-word order like (d, row) WITHIN a wave only.
+        if (!wide_part) {
+            // the waves' sorted pairs (within a wave the keys order like (d, row)) ...
+            uint32_t lo[4], hi[4], enc[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { lo[q] = pk_min16(p[2 * q], p[2 * q + 1]); hi[q] = pk_max16(p[2 * q], p[2 * q + 1]); }
+            // ... the best ROW over the waves: a wave's best key with the wave's number between distance and tag --
+            // (d << 7 | 32 v + 16 h + r), K1h's key: x + 3 (x & ~31) + 32 v (mod 2^16: "none" 0x7BFF becomes 0xEF9F, above every key) ...
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint32_t t;
+                asm("v_pk_add_u16 %0, %1, %2" : "=v"(t) : "v"(lo[q]), "v"((uint32_t)(32 * q) * 0x00010001u));
+                asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(enc[q]) : "v"(lo[q] & 0xFFE0FFE0u), "v"(0x00030003u), "v"(t));
+            }
+            const uint32_t best = pk_min16(pk_min16(enc[0], enc[1]), pk_min16(enc[2], enc[3]));
+            // ... and the second smallest of the 8 group minima as a VALUE: whichever wave it comes from, its distance is that
+            // of the best row outside the best row's group (all that is kept of it)
+            pk_merge(lo[0], hi[0], lo[1], hi[1]);
+            pk_merge(lo[2], hi[2], lo[3], hi[3]);
+            pk_merge(lo[0], hi[0], lo[2], hi[2]);
+            // best: (d << 7 | t) -> (d << 8 | row in the block) as in K1h; second: (d << 5 | t) -> d << 8
+            const uint32_t e0 = best & 0xFFFFu, u0 = best >> 16, e1 = hi[0] & 0xFFE0u, u1 = (hi[0] >> 16) & 0xFFE0u;
+            k0 = e0 + (e0 & 0xFF80u);
+            k1 = e1 << 3;
+            merge2(k0, k1, u0 + (u0 & 0xFF80u) + 128u, u1 << 3);
+        } else {
+            // exact key tables (diagnostics): every word gets its wave first -- (d << 7 | 32 v + 16 h + r), K1h's key -- and K1h's
+            // network orders them
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const uint32_t t = p[q] & 0x001F001Fu;
+                uint32_t sh;
+                asm("v_pk_lshlrev_b16 %0, %1, %2" : "=v"(sh) : "v"(0x00020002u), "v"(p[q] & 0xFFE0FFE0u));
+                p[q] = sh | t | ((uint32_t)(q >> 1) << 5) * 0x00010001u;
+            }
+            uint32_t lo[4], hi[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { lo[q] = pk_min16(p[2 * q], p[2 * q + 1]); hi[q] = pk_max16(p[2 * q], p[2 * q + 1]); }
+            pk_merge(lo[0], hi[0], lo[1], hi[1]);
+            pk_merge(lo[2], hi[2], lo[3], hi[3]);
+            pk_merge(lo[0], hi[0], lo[2], hi[2]);
+            const uint32_t e0 = lo[0] & 0xFFFFu, e1 = hi[0] & 0xFFFFu, u0 = lo[0] >> 16, u1 = hi[0] >> 16;
+            k0 = e0 + (e0 & 0xFF80u); k1 = e1 + (e1 & 0xFF80u);
+            merge2(k0, k1, u0 + (u0 & 0xFF80u) + 128u, u1 + (u1 & 0xFF80u) + 128u);
+        }
+#else
+        uint32_t lo[4], hi[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { lo[q] = pk_min16(p[2 * q], p[2 * q + 1]); hi[q] = pk_max16(p[2 * q], p[2 * q + 1]); }
+        pk_merge(lo[0], hi[0], lo[1], hi[1]);
+        pk_merge(lo[2], hi[2], lo[3], hi[3]);
+        pk_merge(lo[0], hi[0], lo[2], hi[2]);
+        const uint32_t e0 = lo[0] & 0xFFFFu, e1 = hi[0] & 0xFFFFu, u0 = lo[0] >> 16, u1 = hi[0] >> 16;
+        k0 = e0 + (e0 & 0xFF80u); k1 = e1 + (e1 & 0xFF80u);
+        merge2(k0, k1, u0 + (u0 & 0xFF80u) + 128u, u1 + (u1 & 0xFF80u) + 128u);
+#endif
+        const uint32_t slot4 = (uint32_t)(256 * kb + 64 * w) * 4u;                             // (scalar) n2p is a multiple of 256
+        if (!wide_part) {
+            // ("none" and penalty keys widen to distances above 511: the word's fields are 17 + 6 and 9 bits)
+            const uint32_t e = (umin_(k0, 0x1FFFFu) << 9) | umin_(k1 >> 8, 511u);
+            PLSLAM_GLOBAL uint32_t* dst = (PLSLAM_GLOBAL uint32_t*)((PLSLAM_GLOBAL char*)(uintptr_t)(part_s + slot4) + 4u * l_);
+            if (PLSLAM_NT_STREAMS) __builtin_nontemporal_store(e, dst);
+            else *dst = e;
+        } else {
+            const u32x2_t e = {k0, k1};
+            PLSLAM_GLOBAL u32x2_t* dst = (PLSLAM_GLOBAL u32x2_t*)((PLSLAM_GLOBAL char*)(uintptr_t)(part_s + 2u * slot4) + 8u * l_);
+            if (PLSLAM_NT_STREAMS) __builtin_nontemporal_store(e, dst);
+            else *dst = e;
+        }
+    };
+    // a row group is over: its minima get the group number and go into the parked sorted pairs; the minima restart
+    auto push_groups = [&](int t) __attribute__((always_inline)) {
+#if PLSLAM_MI_UNSCALED
+        const uint32_t gtag = (uint32_t)(((t - wt0) >> 4) & 3) * 0x00010001u;        // the group number takes the tag's five bits
+#else
+        const uint32_t gtag = (uint32_t)(((((t - wt0) >> 4) ^ w) & 3) << 5) * 0x00010001u;   // ... the tag's wave bits (an XOR)
+#endif
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const u32x2_t v = park[s * 64];
+            uint32_t b0 = v.x, b1 = v.y;
+            pk_push2(b0, b1, PLSLAM_MI_UNSCALED ? ((gm[s] & 0xFFE0FFE0u) | gtag) : (gm[s] ^ gtag));
+            park[s * 64] = u32x2_t{b0, b1};
+            gm[s] = MI_NONE32;
+        }
+    };
+    // column minima of a finished tile: c0 / c1 = the packed minima (rows 0-7 | rows 8-15 of the lane's group) of M-tile 0 / 1;
+    // parked word = (group minimum of M-tile 0 | group minimum of M-tile 1 << 16), K1h's
+    auto finish_columns = [&](int t, uint32_t c0, uint32_t c1) __attribute__((always_inline)) {
+        if (DIRECTED) { asm volatile("" ::"v"(c0), "v"(c1)); return; }
+        const uint32_t lo = __builtin_amdgcn_perm(c1, c0, 0x05040100u);      // (c0.lo | c1.lo << 16)
+        const uint32_t hi = __builtin_amdgcn_perm(c1, c0, 0x07060302u);      // (c0.hi | c1.hi << 16)
+        cstage[(t & (MH_CGROUP - 1)) * 256 + lane] = pk_min16(lo, hi);
+    };
+
+    // Bookkeeping of slots (MT, Q) and (MT, Q + 1): the accumulators Q and Q + 8 of set ACC become one packed key pair, consumed
+    // at once.  MASKED: rows of a that do not exist must not win a column.  PAR: the tile's parity.
+#if PLSLAM_MI_F16
+    // row direction: even tile -- the pair is kept; odd tile -- minimum, kept pair and new pair in ONE instruction.  Column
+    // direction: both pairs and the running minimum in ONE instruction.
+#define PLSLAM_MI_MASK(MT, Q) (((Q) < PLSLAM_MI_NV - 128 * (MT) ? 0u : MI_NONE16) | ((Q) + 8 < PLSLAM_MI_NV - 128 * (MT) ? 0u : MI_NONE16 << 16))
+#define PLSLAM_MI_EPI2(ACC, MT, Q, PAR)                                                            \
+    {                                                                                              \
+        uint32_t kc0 = pack_acc(ACC[Q], ACC[(Q) + 8]), kc1 = pack_acc(ACC[(Q) + 1], ACC[(Q) + 9]); \
+        if (!PLSLAM_MI_LOOK(MT)) {                                                                 \
+            gm[8 * (MT) + (Q)] = pk_min16(gm[8 * (MT) + (Q)], kc0);                                \
+            gm[8 * (MT) + (Q) + 1] = pk_min16(gm[8 * (MT) + (Q) + 1], kc1);                        \
+        } else if ((PAR) == 0) { kp[8 * (MT) + (Q)] = kc0; kp[8 * (MT) + (Q) + 1] = kc1; }         \
+        else {                                                                                     \
+            gm[8 * (MT) + (Q)] = pk_min3_f16(gm[8 * (MT) + (Q)], kp[8 * (MT) + (Q)], kc0);         \
+            gm[8 * (MT) + (Q) + 1] = pk_min3_f16(gm[8 * (MT) + (Q) + 1], kp[8 * (MT) + (Q) + 1], kc1); \
+        }                                                                                          \
+        if (!DIRECTED) {                                                                           \
+            if (MASKED) { kc0 = pk_max16(kc0, PLSLAM_MI_MASK(MT, Q)); kc1 = pk_max16(kc1, PLSLAM_MI_MASK(MT, (Q) + 1)); } \
+            cma = pk_min3_f16(cma, kc0, kc1);                                                      \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+#else
+    // ONE packed min into the row direction's group minimum, ONE into the column direction's (two chains: a packed op that
+    // reads the result of the packed op two slots earlier costs an s_nop).
+#define PLSLAM_MI_EPI(ACC, MT, Q, CM)                                                              \
+    {                                                                                              \
+        uint32_t kcv = pack_acc(ACC[Q], ACC[(Q) + 8]);                                             \
+        gm[8 * (MT) + (Q)] = pk_min16(gm[8 * (MT) + (Q)], kcv);                                    \
+        if (!DIRECTED) {                                                                           \
+            if (MASKED) kcv |= ((Q) < PLSLAM_MI_NV - 128 * (MT) ? 0u : 0x0000FFFFu) | ((Q) + 8 < PLSLAM_MI_NV - 128 * (MT) ? 0u : 0xFFFF0000u); \
+            CM = pk_min16(CM, kcv);                                                                \
+        }                                                                                          \
+    }
+#define PLSLAM_MI_EPI2(ACC, MT, Q, PAR)                                                            \
+    {                                                                                              \
+        PLSLAM_MI_EPI(ACC, MT, Q, cma) PLSLAM_MI_EPI(ACC, MT, (Q) + 1, cmb)                        \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+#endif
+#define PLSLAM_MI_MMA(ACC, MT, KS, CIN)                                                            \
+    {                                                                                              \
+        const i32x8 a8 = {afrag[MT][KS].x, afrag[MT][KS].y, afrag[MT][KS].z, afrag[MT][KS].w, 0, 0, 0, 0}; \
+        const i32x8 b8 = {bfr[KS].x, bfr[KS].y, bfr[KS].z, bfr[KS].w, 0, 0, 0, 0};                 \
+        ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, CIN, 4, 4, 0, MI_SCALE_A, 0, MI_SCALE_B); \
+        asm volatile("" : "+v"(ACC));    /* pins the MFMA here (no instruction) */                  \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    }
+    // loop-carried: the accumulators of M-tile 1 of the tile before (all "none" at a window's start) and the packed column
+    // minima of its M-tile 0
+    f32x16 m1;
+    uint32_t cm0_prev = MI_NONE32;
+    //   step(t) = barrier | operand reads | M0(t) x E1(t-1) | expand(t+1), prefetch(t+4) | columns(t-1) [| combine | push] | M1(t) x E0(t)
+    auto tile_step = [&](int t, auto u_tag, bool with_prev, auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        constexpr int U = decltype(u_tag)::value;                      // t & 3
+        __syncthreads();                       // tile t expanded; every wave is past its reads of the other buffer
+        const uint8_t* bt = btile + (U & 1) * MH_TILE_BYTES + c * MH_ROW_STRIDE + 16 * g;
+        i32x4 bfr[MH_KSTEPS];
+        bfr[0] = *reinterpret_cast<const i32x4*>(bt);
+        bfr[1] = *reinterpret_cast<const i32x4*>(bt + 32);
+        // ragged group: lanes whose class has run out of columns take the penalty from this tile on (K1h)
+        if (t >= nfull && ((t & 15) == 0 || (t & 15) == lim_part)) {
+            const uint32_t pen = lane_lim() == (t & 15) ? MI_COL_PENALTY : 0u;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) seed[r] += pen;
+            asm volatile("" : "+v"(seed));
+        }
+        const f32x16 cseed = __builtin_bit_cast(f32x16, seed);
+        f32x16 m0;
+        uint32_t cma = MI_NONE32, cmb = MI_NONE32;
+        constexpr int PAR1 = (U + 1) & 1, PAR0 = U & 1;     // the parities of tile t-1 (phase 1) and of tile t (phase 2)
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 1: M-tile 0 of tile t under the bookkeeping of M-tile 1 of tile t-1
+        PLSLAM_MI_EPI2(m1, 1, 0, PAR1) PLSLAM_MI_MMA(m0, 0, 0, cseed)
+        bfr[2] = *reinterpret_cast<const i32x4*>(bt + 64);
+        PLSLAM_MI_EPI2(m1, 1, 2, PAR1) PLSLAM_MI_MMA(m0, 0, 1, m0)
+        bfr[3] = *reinterpret_cast<const i32x4*>(bt + 96);
+        PLSLAM_MI_EPI2(m1, 1, 4, PAR1) PLSLAM_MI_MMA(m0, 0, 2, m0)
+        // the next tile's raw dword (requested three steps ago) leaves the ring: an LDS latency ahead of its expansion
+        const uint32_t raw_next = take_raw(ring_slot);
+        PLSLAM_MI_EPI2(m1, 1, 6, PAR1) PLSLAM_MI_MMA(m0, 0, 3, m0)
+        const uint32_t cm1 = PLSLAM_MI_F16 ? cma : pk_min16(cma, cmb);
+        // behind the chain of M-tile 0: the expansion of the next tile (its buffer was read for the last time before this
+        // step's barrier) and the prefetch -- independent work while the last MFMA of the chain completes
+        expand_store(raw_next, (U + 1) & 1, t + 1);               // past the last tile: a harmless rewrite of the idle buffer
+        load_raw_async(t + 4, ring_slot);                         // three tiles ahead of its use, into the slot just read
+        ring_slot = ring_slot == 2 ? 0 : ring_slot + 1;           // (scalar)
+        if (with_prev) {
+            // block (t - 9) / 8 of column results: its last tile was parked in the step before this one, by every wave before
+            // this step's barrier; tile t - 1 is about to take the block's first slot: a second barrier (workgroup-uniform
+            // branch).  (The blocks of the window before were finished behind its loop.)
+            if (!DIRECTED && U == 1 && ((t - 1) & (MH_CGROUP - 1)) == 0 && t - 9 >= wt0) {
+                combine_columns((t - 9) >> 3);
+                __syncthreads();
+            }
+            finish_columns(t - 1, cm0_prev, cm1);
+            // wave-uniform: tile t-1 closed a row group (both M-tiles of it are in the minima now)
+            if (U == 0 && ((t - 1) & (MH_GROUP - 1)) == MH_GROUP - 1) push_groups(t - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // phase 2: M-tile 1 of tile t under the bookkeeping of M-tile 0 of tile t
+        cma = MI_NONE32; cmb = MI_NONE32;
+#if PLSLAM_MI_UNSCALED
+        // The chain's first MFMA through inline asm with an early-clobber destination: for this loop-carried accumulator set
+        // the compiler picks the tied form (destination = C operand) and copies the 16 seed registers into it every tile (8
+        // v_mov_b64).  What the compiler cannot see is harmless by construction: the result is read next by the chain's second
+        // MFMA (a builtin, six VALU instructions later: any MFMA -> MFMA wait state is long over) and by VALU instructions only
+        // behind the chain's last MFMA, a builtin whose hazards the compiler tracks; the sources are VGPRs the compiler waits
+        // for as for any asm operand.
+        asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %3 cbsz:4 blgp:4" : "=&v"(m1) : "v"(afrag[1][0]), "v"(bfr[0]), "v"(cseed));
+        __builtin_amdgcn_sched_barrier(0);
+#else
+        PLSLAM_MI_MMA(m1, 1, 0, cseed)
+#endif
+        PLSLAM_MI_EPI2(m0, 0, 0, PAR0)
+        PLSLAM_MI_MMA(m1, 1, 1, m1)    PLSLAM_MI_EPI2(m0, 0, 2, PAR0)
+        PLSLAM_MI_MMA(m1, 1, 2, m1)    PLSLAM_MI_EPI2(m0, 0, 4, PAR0)
+        PLSLAM_MI_MMA(m1, 1, 3, m1)    PLSLAM_MI_EPI2(m0, 0, 6, PAR0)
+        cm0_prev = PLSLAM_MI_F16 ? cma : pk_min16(cma, cmb);
+    };
+    // the bookkeeping of M-tile 1 of a window's last tile on its own (no following step to hide under)
+    auto epilogue = [&](int t, auto masked_tag) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        uint32_t cma = MI_NONE32, cmb = MI_NONE32;
+#if PLSLAM_MI_F16
+        if (t & 1) {                               // (wave-uniform) an odd last tile: the even tile's pairs of M-tile 1 are waiting
+            PLSLAM_MI_EPI2(m1, 1, 0, 1) PLSLAM_MI_EPI2(m1, 1, 2, 1) PLSLAM_MI_EPI2(m1, 1, 4, 1) PLSLAM_MI_EPI2(m1, 1, 6, 1)
+        } else {
+            // an even last tile: its pairs go into the minima directly -- M-tile 1's now, M-tile 0's were kept in the last step
+            PLSLAM_MI_EPI2(m1, 1, 0, 0) PLSLAM_MI_EPI2(m1, 1, 2, 0) PLSLAM_MI_EPI2(m1, 1, 4, 0) PLSLAM_MI_EPI2(m1, 1, 6, 0)
+#pragma unroll
+            for (int s = 8; s < 16; ++s) if (PLSLAM_MI_LOOK(1)) gm[s] = pk_min16(gm[s], kp[s]);      // (kept a moment ago)
+            // (M-tile 1's were folded just now -- or never kept)
+#pragma unroll
+            for (int s = 0; s < 8; ++s) if (PLSLAM_MI_LOOK(0)) gm[s] = pk_min16(gm[s], kp[s]);
+        }
+        (void)cmb;
+        finish_columns(t, cm0_prev, cma);
+#else
+        PLSLAM_MI_EPI(m1, 1, 0, cma) PLSLAM_MI_EPI(m1, 1, 1, cmb) PLSLAM_MI_EPI(m1, 1, 2, cma) PLSLAM_MI_EPI(m1, 1, 3, cmb)
+        PLSLAM_MI_EPI(m1, 1, 4, cma) PLSLAM_MI_EPI(m1, 1, 5, cmb) PLSLAM_MI_EPI(m1, 1, 6, cma) PLSLAM_MI_EPI(m1, 1, 7, cmb)
+        finish_columns(t, cm0_prev, pk_min16(cma, cmb));
+#endif
+    };
+    auto pipeline = [&](auto masked_tag) __attribute__((always_inline)) {
+        // (wt0 is a multiple of 64: t & 3 of the unrolled steps is static.  The first step has no previous tile: its
+        // phase 1 runs on "none" accumulators, its column / group actions are skipped)
+        {
+            u32x16 none;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) none[r] = MI_NONE32;     // (the low halves are what the pack takes)
+            asm volatile("" : "+v"(none));
+            m1 = __builtin_bit_cast(f32x16, none);
+#if PLSLAM_MI_F16
+            // the first step folds "the tile before the window" (odd) with whatever is kept: nothing
+#pragma unroll
+            for (int s = 8; s < 16; ++s) if (PLSLAM_MI_LOOK(1)) kp[s] = MI_NONE32;
+#endif
+        }
+        for (int tb = wt0; tb < wt1; tb += 4) {
+            tile_step(tb, std::integral_constant<int, 0>{}, tb != wt0, masked_tag);
+            if (tb + 1 < wt1) tile_step(tb + 1, std::integral_constant<int, 1>{}, true, masked_tag);
+            if (tb + 2 < wt1) tile_step(tb + 2, std::integral_constant<int, 2>{}, true, masked_tag);
+            if (tb + 3 < wt1) tile_step(tb + 3, std::integral_constant<int, 3>{}, true, masked_tag);
+        }
+        // the window's last tile opens a block of columns while the block before it still waits in the slots (the step that
+        // would have combined it does not exist): combine it now
+        if (!DIRECTED && ((wt1 - 1) & (MH_CGROUP - 1)) == 0 && wt1 - 9 >= wt0) {
+            __syncthreads();
+            combine_columns((wt1 - 9) >> 3);
+            __syncthreads();
+        }
+        epilogue(wt1 - 1, masked_tag);
+        push_groups(wt1 - 1);                      // the (possibly partial) last row group
+    };
+#undef PLSLAM_MI_EPI2
+#undef PLSLAM_MI_EPI
+#undef PLSLAM_MI_MASK
+#undef PLSLAM_MI_MMA
+
+    // Row results of a window: K1h's finish_rows with this kernel's slot -> row map (slot 8 mt + q: low half = local row
+    // 32 mt + 16 g + q, high half = local row 32 mt + 16 g + q + 8 of the wave's 64).  One lane per row after the transpose;
+    // the best entry names the (group, class) that holds the best column, whose S members are recomputed from the raw rows.
+    auto finish_rows = [&]() __attribute__((always_inline)) {
+        uint32_t* rowx = reinterpret_cast<uint32_t*>(smem) + w * (64 * ROWX_STRIDE);
+        u32x2_t rb[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) rb[s] = park[s * 64];
+        __syncthreads();                           // every wave holds its pairs: the transpose may overwrite the parking area
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int lrow = 32 * (s >> 3) + 16 * g + (s & 7);
+            rowx[lrow * ROWX_STRIDE + c] = __builtin_amdgcn_perm(rb[s].y, rb[s].x, 0x05040100u);          // (x.lo | y.lo << 16)
+            rowx[(lrow + 8) * ROWX_STRIDE + c] = __builtin_amdgcn_perm(rb[s].y, rb[s].x, 0x07060302u);    // (x.hi | y.hi << 16)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
+        const uint32_t* mine = rowx + lane * ROWX_STRIDE;
+#pragma unroll 8
+        for (int cls = 0; cls < 32; ++cls) {
+            const uint32_t e = mine[cls];
+            merge2(k0, k1, (e << 16) | (uint32_t)cls, (e & 0xFFFF0000u) | (uint32_t)cls);
+        }
+        const int row = iw + lane + (lane & 32) * 3;          // lanes 32..63: M-tile 1's rows, 128 further on
+        if (row < n1) {
+            const gu2_t out = (gu2_t) reinterpret_cast<u32x2_t*>(sd.keys12) + row;
+            const gcu32x4_t ap = (gcu32x4_t)(araw + (size_t)row * 8);
+            const u32x4_t a_lo = ap[0], a_hi = ap[1];
+            // (key16 << 16 | class) -> first row of the (group, class), its stride count, the distance
+            auto group_of = [&](uint32_t k, uint32_t& jbase, uint32_t& cnt) {
+                const uint32_t t0 = (uint32_t)wt0 + (((k >> (PLSLAM_MI_UNSCALED ? 16 : 21)) & 3u) << 4);   // first tile of the group
+                const uint32_t s = t0 < (uint32_t)nfull ? (uint32_t)MH_GROUP : (uint32_t)rag_s;
+                jbase = (t0 >> 4) * MH_GROUP_ROWS + s * (k & 0xFFFFu);
+                cnt = s;
+            };
+            // all members of a (group, class): the smallest (d << 23 | j) and the second smallest (four candidates' rows are
+            // requested together)
+            auto rescan = [&](uint32_t jbase, uint32_t cnt, uint32_t& best, uint32_t& second) {
+                best = second = KEY_NONE;
+                const uint32_t left = (uint32_t)n2 - jbase;                       // >= 1: the class's first column exists
+                const uint32_t nvalid = cnt < left ? cnt : left;
+                const PLSLAM_GLOBAL char* const rbp = bbytes + (size_t)jbase * 32;
+#pragma unroll
+                for (int k0_ = 0; k0_ < MH_GROUP; k0_ += 4) {
+                    u32x4_t bl[4], bh[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t kk = (uint32_t)(k0_ + q) < nvalid ? (uint32_t)(k0_ + q) : nvalid - 1u;   // past the end: a duplicate, masked below
+                        const gcu32x4_t bp = (gcu32x4_t)(rbp + kk * 32u);
+                        bl[q] = bp[0];
+                        bh[q] = bp[1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t d = hamming256(a_lo, a_hi, bl[q], bh[q]);
+                        const uint32_t cand = (uint32_t)(k0_ + q) < nvalid ? ((d << KEY_IDX_BITS) | (jbase + (uint32_t)(k0_ + q))) : KEY_NONE;
+                        second = umin_(second, umax_(best, cand));
+                        best = umin_(best, cand);
+                    }
+                }
+            };
+            uint32_t r0 = KEY_NONE, r1 = KEY_NONE;
+            if ((k0 >> 16) <= MI_KEY16_MAX) {
+                uint32_t jb, cnt, in2;
+                group_of(k0, jb, cnt);
+                rescan(jb, cnt, r0, in2);
+                if ((k1 >> 16) <= MI_KEY16_MAX) {
+                    // the best key outside the winner's (group, class): its distance is exact, its column is the first of
+                    // its (group, class) unless the exact index was asked for and it IS the second best
+                    uint32_t jb1, cnt1;
+                    group_of(k1, jb1, cnt1);
+                    uint32_t o1 = ((k1 >> (16 + MI_DSHIFT)) << KEY_IDX_BITS) | jb1;
+                    if ((sd.flags & 1) && (o1 >> KEY_IDX_BITS) <= (in2 >> KEY_IDX_BITS)) {
+                        uint32_t b1, s1;
+                        rescan(jb1, cnt1, b1, s1);
+                        o1 = b1;
+                    }
+                    r1 = umin_(in2, o1);
+                } else {
+                    r1 = in2;
+                }
+            }
+            if (wt0 > 0) {                                  // later windows: merge with the windows before
+                const u32x2_t prev = *out;
+                merge2(r0, r1, prev.x, prev.y);
+            }
+            *out = u32x2_t{r0, r1};
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    for (;;) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) park[s * 64] = u32x2_t{0xFFFFFFFFu, 0xFFFFFFFFu};   // wave-private: no barrier needed
+        expand_store(load_raw(wt0), 0, wt0);       // wt0 is a multiple of 128: buffer parity restarts at 0
+        load_raw_async(wt0 + 1, 1);
+        load_raw_async(wt0 + 2, 2);
+        load_raw_async(wt0 + 3, 0);
+        ring_slot = 1;                             // the slot of tile wt0 + 1
+        if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
+        __syncthreads();                           // every wave is past its last operand read of the b tile, every column minimum is parked
+        // the window's last block of column results (full or partial)
+        combine_columns((wt1 - 1) >> 3);
+        finish_rows();
+        if (wt1 == ntiles) break;
+        __syncthreads();                           // smem becomes the b tile (+ parking area) again
+        wt0 = wt1;
+        wt1 = ntiles < wt0 + MH_WINDOW ? ntiles : wt0 + MH_WINDOW;
+    }
+#undef PLSLAM_MI_NV
+}
+
+int launch_scan_sym_mfma_i(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
+                           bool directed, hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+    if (directed) hipLaunchKernelGGL((k_scan_sym_mfma_i<true>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
+    else hipLaunchKernelGGL((k_scan_sym_mfma_i<false>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+}  // namespace plslam

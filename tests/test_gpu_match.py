@@ -86,13 +86,13 @@ def test_symmetric_and_directed_variants_agree(ctx, oracle, n1, n2):
         try:
             # (variant, sym_rows, mfma_form): mfma_form 2 = K1f (group minima, the default), 1 = K1e (push per tile)
             for variant, sym_rows, form in ((plslam_amd.SCAN_MFMA, 0, 2), (plslam_amd.SCAN_MFMA, 0, 1), (plslam_amd.SCAN_MFMA, 0, 3),
-                                            (plslam_amd.SCAN_MFMA, 0, 4), (plslam_amd.SCAN_MFMA, 0, 5),
+                                            (plslam_amd.SCAN_MFMA, 0, 4), (plslam_amd.SCAN_MFMA, 0, 5), (plslam_amd.SCAN_MFMA, 0, 6),
                                             (plslam_amd.SCAN_SYMMETRIC, 4, 0), (plslam_amd.SCAN_SYMMETRIC, 1, 0),
                                             (plslam_amd.SCAN_LANE_PER_QUERY, 1, 0), (plslam_amd.SCAN_WAVE_PER_QUERY, 1, 0),
                                             (plslam_amd.SCAN_AUTO, 1, 0)):
                 ctx.set_option("scan_variant", variant)
                 ctx.set_option("sym_rows", sym_rows)
-                ctx.set_option("mfma_form", {4: 3, 5: 4}.get(form, min(form, 2)))   # 4 = K1g (two directed scans per mutual problem), 5 = K1h
+                ctx.set_option("mfma_form", {4: 3, 5: 4, 6: 5}.get(form, min(form, 2)))   # 4 = K1g (two directed scans per mutual problem), 5 = K1h, 6 = K1i
                 ctx.set_option("fuse", 2 if form == 3 else 0)
                 m, n = ctx.match(d1, d2, 0.9, True)
                 assert np.array_equal(m, em) and n == en, (variant, sym_rows, form, gen.__name__)
@@ -120,7 +120,7 @@ def test_all_scan_block_sizes(ctx, oracle):
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
 
 
-@pytest.fixture(params=["auto", "lane_per_query", "wave_per_query", "symmetric", "mfma", "mfma_k1e", "mfma_fused", "mfma_k1g", "mfma_k1h"])
+@pytest.fixture(params=["auto", "lane_per_query", "wave_per_query", "symmetric", "mfma", "mfma_k1e", "mfma_fused", "mfma_k1g", "mfma_k1h", "mfma_k1f"])
 def vctx(ctx, request):
     """The context with each scan variant forced in turn (AUTO picks wave-per-query for plans too
     small to fill the chip, the symmetric scan for mutual problems otherwise)."""
@@ -128,9 +128,10 @@ def vctx(ctx, request):
     v = {"auto": plslam_amd.SCAN_AUTO, "lane_per_query": plslam_amd.SCAN_LANE_PER_QUERY,
          "wave_per_query": plslam_amd.SCAN_WAVE_PER_QUERY, "symmetric": plslam_amd.SCAN_SYMMETRIC,
          "mfma": plslam_amd.SCAN_MFMA, "mfma_k1e": plslam_amd.SCAN_MFMA, "mfma_fused": plslam_amd.SCAN_MFMA,
-         "mfma_k1g": plslam_amd.SCAN_MFMA, "mfma_k1h": plslam_amd.SCAN_MFMA}[request.param]
+         "mfma_k1g": plslam_amd.SCAN_MFMA, "mfma_k1h": plslam_amd.SCAN_MFMA, "mfma_k1f": plslam_amd.SCAN_MFMA}[request.param]
     ctx.set_option("scan_variant", v)
-    ctx.set_option("mfma_form", {"mfma_k1e": 1, "mfma_k1g": 3, "mfma_k1h": 4}.get(request.param, 0))   # default form = K1f (group minima)
+    # "mfma" / "mfma_fused": form 0 = auto = K1i (the default scan; fused plans run K1f)
+    ctx.set_option("mfma_form", {"mfma_k1e": 1, "mfma_k1g": 3, "mfma_k1h": 4, "mfma_k1f": 2}.get(request.param, 0))
     ctx.set_option("fuse", 2 if request.param == "mfma_fused" else 0)      # one workgroup per problem incl. finalize
     yield ctx
     ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
@@ -138,12 +139,12 @@ def vctx(ctx, request):
     ctx.set_option("fuse", 0)
 
 
-@pytest.fixture(params=[2, 1, 3, 4, 5], ids=["k1f", "k1e", "k1f_fused", "k1g_directed", "k1h"])
+@pytest.fixture(params=[2, 1, 3, 4, 5, 6], ids=["k1f", "k1e", "k1f_fused", "k1g_directed", "k1h", "k1i"])
 def mform(ctx, request):
     """The forms of the matrix-core scan: 2 = K1f (group minima + recomputed second best, the default), 1 = K1e (best-2
     push per tile), 3 = K1f with one workgroup per problem that also merges the columns and applies ratio + mutual
     (what AUTO picks for large plans; forced here so that small plans exercise it)."""
-    ctx.set_option("mfma_form", {4: 3, 5: 4}.get(request.param, min(request.param, 2)))
+    ctx.set_option("mfma_form", {4: 3, 5: 4, 6: 5}.get(request.param, min(request.param, 2)))
     ctx.set_option("fuse", 2 if request.param == 3 else 1)
     yield request.param
     ctx.set_option("mfma_form", 0)
@@ -511,9 +512,10 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
         # K1e, K1f, K1f fused (one workgroup per problem incl. merge + finalize), K1g (two directed scans per mutual
         # problem), K1h with exact key tables ("exact_second": by default K1h leaves the second neighbour's INDEX and the
         # columns' second key to the stages that need them -- the match tables below are compared in that default too)
-        for form in (1, 2, 3, 4, 5, 6):
-            ctx.set_option("mfma_form", {4: 3, 5: 4, 6: 4}.get(form, min(form, 2)))
-            ctx.set_option("exact_second", 1 if form in (4, 5) else 0)
+        # 7 / 8: K1i (the default scan) with exact key tables / in its default
+        for form in (1, 2, 3, 4, 5, 6, 7, 8):
+            ctx.set_option("mfma_form", {4: 3, 5: 4, 6: 4, 7: 5, 8: 5}.get(form, min(form, 2)))
+            ctx.set_option("exact_second", 1 if form in (4, 5, 7) else 0)
             ctx.set_option("fuse", 2 if form == 3 else 1)
             bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.85, nnr_l=0.9, mutual=mutual)
             tab = bm.run()
@@ -532,9 +534,9 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
     rows = pairs * 2 * ((n_orb + n_lbd) * (2 if mutual else 1))
     assert got[1][0].size >= 2 * rows
     k1 = got[1][0][:2 * rows]
-    for form in (2, 3, 4, 5, 6):
+    for form in (2, 3, 4, 5, 6, 7, 8):
         k2 = got[form][0][:2 * rows]
-        if form != 6:
+        if form not in (6, 8):
             assert np.array_equal(k1, k2), (form, int((k1 != k2).sum()))
         else:
             # default K1h: every row's best key is exact, and so is its second-best DISTANCE; of the merged column keys the
