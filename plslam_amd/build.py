@@ -14,7 +14,10 @@ HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(_ROOT, "include", "pls
 # -ffp-contract=off: the fp64 row kernels must execute the reference's operation order
 # (no FMA contraction) so that thresholded masks reproduce the CPU restatement bit for bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-         "-Wall", "-Wextra", "-Wno-unused-command-line-argument"]
+         "-Wall", "-Wextra", "-Wno-unused-command-line-argument",
+         # K1i declares M0 clobbered by its LDS-DMA statement (hamming_mfma_i.hip); the pragma form of this does not reach the
+         # diagnostic, which is raised at code generation
+         "-Wno-inline-asm"]
 
 
 def hipcc_path() -> str:

@@ -80,6 +80,14 @@ __device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t
 }
 }  // namespace
 
+// PLSLAM_MI_PROF (experiment builds only, tools/k1i_profile.py): every wave adds the shader cycles (s_memtime) it spends in
+// its prologue, in the tile loops and behind them (column combine, row finish) to g_mi_prof, and its tile count
+#ifdef PLSLAM_MI_PROF
+constexpr int MI_PROF_WGS = 65536;
+__device__ unsigned long long g_mi_prof[MI_PROF_WGS * 4];      // per workgroup (wave 0): prologue, loops, finish, tiles
+#define PLSLAM_MI_TICK() __builtin_readcyclecounter()
+#endif
+
 // DIRECTED = true: only keys12 (row direction) is produced.
 template <bool DIRECTED>
 __global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
@@ -99,6 +107,10 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     uint8_t* const btile = smem;
     u32x2_t* const park = reinterpret_cast<u32x2_t*>(smem + PARK_OFF) + (threadIdx.x >> 6) * (16 * 64) + (threadIdx.x & 63);
 
+#ifdef PLSLAM_MI_PROF
+    const unsigned long long prof_t0 = PLSLAM_MI_TICK();
+    unsigned long long prof_loop = 0, prof_fin = 0, prof_tl = 0;
+#endif
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
 
@@ -116,17 +128,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     const gcu32_t araw = (gcu32_t) reinterpret_cast<const uint32_t*>(sd.a);
     const int iw = bd.row0 + 32 * w;               // first of this wave's 32 rows of M-tile 0; M-tile 1: + 128
 
-    // ---- A operands: MFMA row c of M-tile mt = block row 128 mt + 32 w + 16 g' + r' (K1h's mh_block_row): a lane's 16
-    // accumulator registers of an M-tile are 16 CONSECUTIVE rows of a ----
-    i32x4 afrag[2][MH_KSTEPS];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int row = bd.row0 + 128 * mt + 32 * w + 16 * ((c >> 2) & 1) + (c & 3) + 4 * (c >> 3);
-        const int rrow = row < n1 ? row : n1 - 1;
-        const gcu32_t p = araw + (size_t)rrow * 8 + g;
-#pragma unroll
-        for (int ks = 0; ks < MH_KSTEPS; ++ks) afrag[mt][ks] = expand_dword_fp4<true, MI_MAG>(p[2 * ks]);
-    }
+    i32x4 afrag[2][MH_KSTEPS];            // the A operands (filled behind the first requests for b: see below)
 
     // row-direction state per SLOT s = 8 mt + q (low half: row 16 g + q of the lane's group of M-tile mt, high half: row
     // 16 g + q + 8 of the same group):
@@ -155,9 +157,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     };
     const int lim_part = rag_s ? rest % rag_s : 0;                 // the one class that is cut (wave-uniform): its lim, 0 = none is
 
-    const bool rows_ragged = iw + 128 + 32 > n1;   // wave-uniform: some of this wave's rows do not exist
-    // rows of this lane's group of M-tile 0 that exist (M-tile 1: - 128): register r holds row iw + 128 mt + 16 g + r
-#define PLSLAM_MI_NV (n1 - iw - 16 * (int)((threadIdx.x >> 5) & 1u))
+    const bool block_ragged = bd.row0 + 256 > n1;  // workgroup-uniform: some groups of 16 rows may hold no row of a at all
     const bool wide_part = !DIRECTED && (sd.flags & 1);
     const gu32_t part = DIRECTED ? (gu32_t) nullptr : (gu32_t) sd.part21 + (size_t)(bd.row0 >> 8) * n2p * (wide_part ? 2 : 1);
     uint32_t* const cstage = colstage + 64 * w;        // + 256 (tile & 7) + lane
@@ -180,8 +180,6 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // The address: ONE scalar base (b) + a 32-bit byte offset per lane (rows of b are below 2^23); M0 -- the LDS destination --
     // is the compiler's reserved register, which it does not use in this kernel (gfx9 LDS instructions do not need it): it
     // is declared clobbered instead of being saved and restored (tests/test_abi.py: no other m0 in the kernel's ISA).
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"
     auto load_raw_async = [&](int t, int slot) __attribute__((always_inline)) {
         const int tc = t < ntiles ? t : ntiles - 1;
         const uint32_t s = tc < nfull ? (uint32_t)MH_GROUP : (uint32_t)rag_s;
@@ -193,17 +191,24 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         const uint32_t lds_dst = (uint32_t)(uintptr_t)(&rawring[slot][64 * w]);
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(bbytes), "s"(lds_dst) : "memory", "m0");
     };
-#pragma clang diagnostic pop
     // (the lane's own dword: its index 8 ej + ewd4 / 4 = tid from the two values the expansion keeps anyway -- a register
     // holding tid through the tile loop is spilled, and the reload waits for vmcnt(0): the whole prefetch)
+    // the same inside FULL groups (tile t and the group it lies in: 16 tiles of 32 columns that all exist): no clamps, the lane's
+    // part of the offset is a constant -- one vector instruction
+    auto load_raw_async_full = [&](int t, int slot) __attribute__((always_inline)) {
+        const uint32_t first32 = (((uint32_t)(t & ~15) << 5) + (uint32_t)(t & 15)) * 32u;     // (scalar)
+        const uint32_t voff = (uint32_t)(ej * (MH_GROUP * 32) + ewd4) + first32;
+        const uint32_t lds_dst = (uint32_t)(uintptr_t)(&rawring[slot][64 * w]);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(bbytes), "s"(lds_dst) : "memory", "m0");
+    };
     auto take_raw = [&](int slot) __attribute__((always_inline)) -> uint32_t {
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(&rawring[slot][0]) + (ej * 32 + ewd4));
     };
-    auto expand_store = [&](uint32_t raw, int buf, int tn) __attribute__((always_inline)) {
+    auto expand_store = [&](uint32_t raw, int buf, int tn, bool full = false) __attribute__((always_inline)) {
         uint8_t* dst = btile + buf * MH_TILE_BYTES + ej * MH_ROW_STRIDE + ewd4 * 4;
         i32x4 v = expand_dword_fp4<false, MI_MAG>(raw);
-        if (tn >= nfull) {                                          // wave-uniform
+        if (!full && tn >= nfull) {                                 // wave-uniform
             const int vm = (int)(__umul24((uint32_t)rag_s, (uint32_t)ej) + (uint32_t)(tn & 15)) < rest ? -1 : 0;
             v &= i32x4{vm, vm, vm, vm};
         }
@@ -226,6 +231,16 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         uint32_t p[8];
 #pragma unroll
         for (int v = 0; v < 4; ++v) { p[2 * v] = src[64 * v]; p[2 * v + 1] = src[64 * v + 32]; }
+        if (block_ragged) {
+            // p[2 v + h] = the minima of the groups of rows row0 + 32 v + 16 h .. + 15 (low half) and 128 further on (high half):
+            // a group past the end of a holds duplicates of its last row only
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int base = bd.row0 + 32 * (q >> 1) + 16 * (q & 1);                   // (scalar)
+                const uint32_t strike = (base >= n1 ? MI_NONE16 : 0u) | (base + 128 >= n1 ? MI_NONE16 << 16 : 0u);
+                p[q] = pk_max16(p[q], strike);
+            }
+        }
         auto pk_merge = [](uint32_t& a0, uint32_t& a1, uint32_t c0, uint32_t c1) {
             const uint32_t m = pk_max16(a0, c0);
             a0 = pk_min16(a0, c0);
@@ -329,11 +344,12 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     };
 
     // Bookkeeping of slots (MT, Q) and (MT, Q + 1): the accumulators Q and Q + 8 of set ACC become one packed key pair, consumed
-    // at once.  MASKED: rows of a that do not exist must not win a column.  PAR: the tile's parity.
+    // at once.  PAR: the tile's parity.  (Rows of a that do not exist are clamped duplicates of the last row: inside that
+    // row's own group of 16 they lose every tie to it, and the groups that hold nothing else are struck out where the column
+    // minima are combined -- no masking per tile.)
 #if PLSLAM_MI_F16
     // row direction: even tile -- the pair is kept; odd tile -- minimum, kept pair and new pair in ONE instruction.  Column
     // direction: both pairs and the running minimum in ONE instruction.
-#define PLSLAM_MI_MASK(MT, Q) (((Q) < PLSLAM_MI_NV - 128 * (MT) ? 0u : MI_NONE16) | ((Q) + 8 < PLSLAM_MI_NV - 128 * (MT) ? 0u : MI_NONE16 << 16))
 #define PLSLAM_MI_EPI2(ACC, MT, Q, PAR)                                                            \
     {                                                                                              \
         uint32_t kc0 = pack_acc(ACC[Q], ACC[(Q) + 8]), kc1 = pack_acc(ACC[(Q) + 1], ACC[(Q) + 9]); \
@@ -345,10 +361,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             gm[8 * (MT) + (Q)] = pk_min3_f16(gm[8 * (MT) + (Q)], kp[8 * (MT) + (Q)], kc0);         \
             gm[8 * (MT) + (Q) + 1] = pk_min3_f16(gm[8 * (MT) + (Q) + 1], kp[8 * (MT) + (Q) + 1], kc1); \
         }                                                                                          \
-        if (!DIRECTED) {                                                                           \
-            if (MASKED) { kc0 = pk_max16(kc0, PLSLAM_MI_MASK(MT, Q)); kc1 = pk_max16(kc1, PLSLAM_MI_MASK(MT, (Q) + 1)); } \
-            cma = pk_min3_f16(cma, kc0, kc1);                                                      \
-        }                                                                                          \
+        if (!DIRECTED) cma = pk_min3_f16(cma, kc0, kc1);                                           \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
 #else
@@ -358,10 +371,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     {                                                                                              \
         uint32_t kcv = pack_acc(ACC[Q], ACC[(Q) + 8]);                                             \
         gm[8 * (MT) + (Q)] = pk_min16(gm[8 * (MT) + (Q)], kcv);                                    \
-        if (!DIRECTED) {                                                                           \
-            if (MASKED) kcv |= ((Q) < PLSLAM_MI_NV - 128 * (MT) ? 0u : 0x0000FFFFu) | ((Q) + 8 < PLSLAM_MI_NV - 128 * (MT) ? 0u : 0xFFFF0000u); \
-            CM = pk_min16(CM, kcv);                                                                \
-        }                                                                                          \
+        if (!DIRECTED) CM = pk_min16(CM, kcv);                                                     \
     }
 #define PLSLAM_MI_EPI2(ACC, MT, Q, PAR)                                                            \
     {                                                                                              \
@@ -382,8 +392,9 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     f32x16 m1;
     uint32_t cm0_prev = MI_NONE32;
     //   step(t) = barrier | operand reads | M0(t) x E1(t-1) | expand(t+1), prefetch(t+4) | columns(t-1) [| combine | push] | M1(t) x E0(t)
-    auto tile_step = [&](int t, auto u_tag, bool with_prev, auto masked_tag) __attribute__((always_inline)) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
+    // FULL: tiles t .. t + 4 lie in full groups (no ragged-group tests, the short prefetch address)
+    auto tile_step = [&](int t, auto u_tag, bool with_prev, auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
         constexpr int U = decltype(u_tag)::value;                      // t & 3
         __syncthreads();                       // tile t expanded; every wave is past its reads of the other buffer
         const uint8_t* bt = btile + (U & 1) * MH_TILE_BYTES + c * MH_ROW_STRIDE + 16 * g;
@@ -391,7 +402,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         bfr[0] = *reinterpret_cast<const i32x4*>(bt);
         bfr[1] = *reinterpret_cast<const i32x4*>(bt + 32);
         // ragged group: lanes whose class has run out of columns take the penalty from this tile on (K1h)
-        if (t >= nfull && ((t & 15) == 0 || (t & 15) == lim_part)) {
+        if (!FULL && t >= nfull && ((t & 15) == 0 || (t & 15) == lim_part)) {
             const uint32_t pen = lane_lim() == (t & 15) ? MI_COL_PENALTY : 0u;
 #pragma unroll
             for (int r = 0; r < 16; ++r) seed[r] += pen;
@@ -414,8 +425,9 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         const uint32_t cm1 = PLSLAM_MI_F16 ? cma : pk_min16(cma, cmb);
         // behind the chain of M-tile 0: the expansion of the next tile (its buffer was read for the last time before this
         // step's barrier) and the prefetch -- independent work while the last MFMA of the chain completes
-        expand_store(raw_next, (U + 1) & 1, t + 1);               // past the last tile: a harmless rewrite of the idle buffer
-        load_raw_async(t + 4, ring_slot);                         // three tiles ahead of its use, into the slot just read
+        expand_store(raw_next, (U + 1) & 1, t + 1, FULL);         // past the last tile: a harmless rewrite of the idle buffer
+        if (FULL) load_raw_async_full(t + 4, ring_slot);          // three tiles ahead of its use, into the slot just read
+        else load_raw_async(t + 4, ring_slot);
         ring_slot = ring_slot == 2 ? 0 : ring_slot + 1;           // (scalar)
         if (with_prev) {
             // block (t - 9) / 8 of column results: its last tile was parked in the step before this one, by every wave before
@@ -451,8 +463,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         cm0_prev = PLSLAM_MI_F16 ? cma : pk_min16(cma, cmb);
     };
     // the bookkeeping of M-tile 1 of a window's last tile on its own (no following step to hide under)
-    auto epilogue = [&](int t, auto masked_tag) __attribute__((always_inline)) {
-        constexpr bool MASKED = decltype(masked_tag)::value;
+    auto epilogue = [&](int t) __attribute__((always_inline)) {
         uint32_t cma = MI_NONE32, cmb = MI_NONE32;
 #if PLSLAM_MI_F16
         if (t & 1) {                               // (wave-uniform) an odd last tile: the even tile's pairs of M-tile 1 are waiting
@@ -474,7 +485,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         finish_columns(t, cm0_prev, pk_min16(cma, cmb));
 #endif
     };
-    auto pipeline = [&](auto masked_tag) __attribute__((always_inline)) {
+    auto pipeline = [&]() __attribute__((always_inline)) {
         // (wt0 is a multiple of 64: t & 3 of the unrolled steps is static.  The first step has no previous tile: its
         // phase 1 runs on "none" accumulators, its column / group actions are skipped)
         {
@@ -489,11 +500,22 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             for (int s = 8; s < 16; ++s) if (PLSLAM_MI_LOOK(1)) kp[s] = MI_NONE32;
 #endif
         }
-        for (int tb = wt0; tb < wt1; tb += 4) {
-            tile_step(tb, std::integral_constant<int, 0>{}, tb != wt0, masked_tag);
-            if (tb + 1 < wt1) tile_step(tb + 1, std::integral_constant<int, 1>{}, true, masked_tag);
-            if (tb + 2 < wt1) tile_step(tb + 2, std::integral_constant<int, 2>{}, true, masked_tag);
-            if (tb + 3 < wt1) tile_step(tb + 3, std::integral_constant<int, 3>{}, true, masked_tag);
+        int tb = wt0;
+        {
+            // whole chunks of four tiles whose prefetches (four tiles ahead) stay inside full groups: the lean instantiation
+            const int lim = (wt1 < nfull ? wt1 : nfull) - 7;          // tb + 3 + 4 < nfull and tb + 3 < wt1
+            for (; tb < lim; tb += 4) {
+                tile_step(tb, std::integral_constant<int, 0>{}, tb != wt0, std::true_type{});
+                tile_step(tb + 1, std::integral_constant<int, 1>{}, true, std::true_type{});
+                tile_step(tb + 2, std::integral_constant<int, 2>{}, true, std::true_type{});
+                tile_step(tb + 3, std::integral_constant<int, 3>{}, true, std::true_type{});
+            }
+        }
+        for (; tb < wt1; tb += 4) {
+            tile_step(tb, std::integral_constant<int, 0>{}, tb != wt0, std::false_type{});
+            if (tb + 1 < wt1) tile_step(tb + 1, std::integral_constant<int, 1>{}, true, std::false_type{});
+            if (tb + 2 < wt1) tile_step(tb + 2, std::integral_constant<int, 2>{}, true, std::false_type{});
+            if (tb + 3 < wt1) tile_step(tb + 3, std::integral_constant<int, 3>{}, true, std::false_type{});
         }
         // the window's last tile opens a block of columns while the block before it still waits in the slots (the step that
         // would have combined it does not exist): combine it now
@@ -502,12 +524,11 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             combine_columns((wt1 - 9) >> 3);
             __syncthreads();
         }
-        epilogue(wt1 - 1, masked_tag);
+        epilogue(wt1 - 1);
         push_groups(wt1 - 1);                      // the (possibly partial) last row group
     };
 #undef PLSLAM_MI_EPI2
 #undef PLSLAM_MI_EPI
-#undef PLSLAM_MI_MASK
 #undef PLSLAM_MI_MMA
 
     // Row results of a window: K1h's finish_rows with this kernel's slot -> row map (slot 8 mt + q: low half = local row
@@ -604,26 +625,71 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         __builtin_amdgcn_wave_barrier();
     };
 
+    // the first window's first four tiles of b are requested BEFORE the rows of a: one memory latency for both (a 200 x 200
+    // problem is seven tiles long: its workgroup's time is mostly such latencies)
+    uint32_t raw_first = load_raw(0);
+    load_raw_async(1, 1);
+    load_raw_async(2, 2);
+    load_raw_async(3, 0);
+    // ---- A operands: MFMA row c of M-tile mt = block row 128 mt + 32 w + 16 g' + r' (K1h's mh_block_row): a lane's 16
+    // accumulator registers of an M-tile are 16 CONSECUTIVE rows of a ----
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int row = bd.row0 + 128 * mt + 32 * w + 16 * ((c >> 2) & 1) + (c & 3) + 4 * (c >> 3);
+        const int rrow = row < n1 ? row : n1 - 1;
+        const gcu32_t p = araw + (size_t)rrow * 8 + g;
+#pragma unroll
+        for (int ks = 0; ks < MH_KSTEPS; ++ks) afrag[mt][ks] = expand_dword_fp4<true, MI_MAG>(p[2 * ks]);
+    }
+
+#ifdef PLSLAM_MI_PROF
+    const unsigned long long prof_t1 = PLSLAM_MI_TICK();
+#endif
     for (;;) {
+#ifdef PLSLAM_MI_PROF
+        prof_tl = PLSLAM_MI_TICK();
+#endif
 #pragma unroll
         for (int s = 0; s < 16; ++s) park[s * 64] = u32x2_t{0xFFFFFFFFu, 0xFFFFFFFFu};   // wave-private: no barrier needed
-        expand_store(load_raw(wt0), 0, wt0);       // wt0 is a multiple of 128: buffer parity restarts at 0
-        load_raw_async(wt0 + 1, 1);
-        load_raw_async(wt0 + 2, 2);
-        load_raw_async(wt0 + 3, 0);
+        expand_store(raw_first, 0, wt0);           // wt0 is a multiple of 128: buffer parity restarts at 0
         ring_slot = 1;                             // the slot of tile wt0 + 1
-        if (!rows_ragged) pipeline(std::false_type{}); else pipeline(std::true_type{});
+        pipeline();
+#ifdef PLSLAM_MI_PROF
+        { const unsigned long long t = PLSLAM_MI_TICK(); prof_loop += t - prof_tl; prof_tl = t; }
+#endif
         __syncthreads();                           // every wave is past its last operand read of the b tile, every column minimum is parked
         // the window's last block of column results (full or partial)
         combine_columns((wt1 - 1) >> 3);
         finish_rows();
+#ifdef PLSLAM_MI_PROF
+        prof_fin += PLSLAM_MI_TICK() - prof_tl;
+#endif
         if (wt1 == ntiles) break;
         __syncthreads();                           // smem becomes the b tile (+ parking area) again
         wt0 = wt1;
         wt1 = ntiles < wt0 + MH_WINDOW ? ntiles : wt0 + MH_WINDOW;
+        raw_first = load_raw(wt0);
+        load_raw_async(wt0 + 1, 1);
+        load_raw_async(wt0 + 2, 2);
+        load_raw_async(wt0 + 3, 0);
     }
-#undef PLSLAM_MI_NV
+#ifdef PLSLAM_MI_PROF
+    if (threadIdx.x == 0 && blockIdx.x < MI_PROF_WGS) {
+        g_mi_prof[4 * blockIdx.x + 0] = prof_t1 - prof_t0;
+        g_mi_prof[4 * blockIdx.x + 1] = prof_loop;
+        g_mi_prof[4 * blockIdx.x + 2] = prof_fin;
+        g_mi_prof[4 * blockIdx.x + 3] = ((unsigned long long)ntiles << 40) | (PLSLAM_MI_TICK() - prof_t0);
+    }
+#endif
 }
+
+#ifdef PLSLAM_MI_PROF
+extern "C" int plslam_debug_k1i_profile(unsigned long long* out, int nwg)
+{
+    if (nwg > MI_PROF_WGS) nwg = MI_PROF_WGS;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mi_prof), sizeof(unsigned long long) * 4 * (size_t)nwg) == hipSuccess ? nwg : -1;
+}
+#endif
 
 int launch_scan_sym_mfma_i(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
                            bool directed, hipStream_t s)
