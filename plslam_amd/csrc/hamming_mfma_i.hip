@@ -49,6 +49,11 @@
 #ifndef PLSLAM_MI_ROWLOOK
 #define PLSLAM_MI_ROWLOOK 0
 #endif
+// build-time experiments (tools/build_exp.py; results are WRONG with any of them on): 1 no tile barrier, 2 no operand reads
+// from LDS, 4 no MFMA, 8 no bookkeeping (pack + minima), 16 no expansion / prefetch
+#ifndef PLSLAM_MI_X
+#define PLSLAM_MI_X 0
+#endif
 #define PLSLAM_MI_LOOK(MT) (PLSLAM_MI_F16 && ((MT) == 1 ? PLSLAM_MI_ROWLOOK >= 1 : PLSLAM_MI_ROWLOOK >= 2))
 
 namespace plslam {
@@ -72,6 +77,10 @@ constexpr int MI_SCALE_A = SCALE_A, MI_SCALE_B = SCALE_B;
 constexpr uint32_t MI_NONE16 = 0xFFFFu;
 #endif
 constexpr uint32_t MI_NONE32 = MI_NONE16 * 0x00010001u;
+#ifndef PLSLAM_MI_RESCAN_BATCH
+#define PLSLAM_MI_RESCAN_BATCH 4
+#endif
+constexpr int MI_RESCAN_BATCH = PLSLAM_MI_RESCAN_BATCH;
 __device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t r;
@@ -351,6 +360,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // row direction: even tile -- the pair is kept; odd tile -- minimum, kept pair and new pair in ONE instruction.  Column
     // direction: both pairs and the running minimum in ONE instruction.
 #define PLSLAM_MI_EPI2(ACC, MT, Q, PAR)                                                            \
+    if (PLSLAM_MI_X & 8) { if ((Q) == 0) { asm volatile("" :: "v"(ACC)); cma = __builtin_bit_cast(uint32_t, (float)ACC[0]); } } else \
     {                                                                                              \
         uint32_t kc0 = pack_acc(ACC[Q], ACC[(Q) + 8]), kc1 = pack_acc(ACC[(Q) + 1], ACC[(Q) + 9]); \
         if (!PLSLAM_MI_LOOK(MT)) {                                                                 \
@@ -383,7 +393,8 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     {                                                                                              \
         const i32x8 a8 = {afrag[MT][KS].x, afrag[MT][KS].y, afrag[MT][KS].z, afrag[MT][KS].w, 0, 0, 0, 0}; \
         const i32x8 b8 = {bfr[KS].x, bfr[KS].y, bfr[KS].z, bfr[KS].w, 0, 0, 0, 0};                 \
-        ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, CIN, 4, 4, 0, MI_SCALE_A, 0, MI_SCALE_B); \
+        if (!(PLSLAM_MI_X & 4)) ACC = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, CIN, 4, 4, 0, MI_SCALE_A, 0, MI_SCALE_B); \
+        else { const f32x16 cin_ = CIN; ACC = cin_; ACC[KS] = __builtin_bit_cast(float, b8[0] ^ a8[0]); } \
         asm volatile("" : "+v"(ACC));    /* pins the MFMA here (no instruction) */                  \
         __builtin_amdgcn_sched_barrier(0);                                                         \
     }
@@ -396,11 +407,12 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     auto tile_step = [&](int t, auto u_tag, bool with_prev, auto full_tag) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr int U = decltype(u_tag)::value;                      // t & 3
-        __syncthreads();                       // tile t expanded; every wave is past its reads of the other buffer
+        if (!(PLSLAM_MI_X & 1)) __syncthreads();   // tile t expanded; every wave is past its reads of the other buffer
         const uint8_t* bt = btile + (U & 1) * MH_TILE_BYTES + c * MH_ROW_STRIDE + 16 * g;
         i32x4 bfr[MH_KSTEPS];
-        bfr[0] = *reinterpret_cast<const i32x4*>(bt);
-        bfr[1] = *reinterpret_cast<const i32x4*>(bt + 32);
+#define PLSLAM_MI_READ_B(KS) ((PLSLAM_MI_X & 2) ? i32x4{(int)MI_MAG + t, (int)MI_MAG, (int)MI_MAG + (KS), (int)MI_MAG} : *reinterpret_cast<const i32x4*>(bt + 32 * (KS)))
+        bfr[0] = PLSLAM_MI_READ_B(0);
+        bfr[1] = PLSLAM_MI_READ_B(1);
         // ragged group: lanes whose class has run out of columns take the penalty from this tile on (K1h)
         if (!FULL && t >= nfull && ((t & 15) == 0 || (t & 15) == lim_part)) {
             const uint32_t pen = lane_lim() == (t & 15) ? MI_COL_PENALTY : 0u;
@@ -415,19 +427,21 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         __builtin_amdgcn_sched_barrier(0);
         // phase 1: M-tile 0 of tile t under the bookkeeping of M-tile 1 of tile t-1
         PLSLAM_MI_EPI2(m1, 1, 0, PAR1) PLSLAM_MI_MMA(m0, 0, 0, cseed)
-        bfr[2] = *reinterpret_cast<const i32x4*>(bt + 64);
+        bfr[2] = PLSLAM_MI_READ_B(2);
         PLSLAM_MI_EPI2(m1, 1, 2, PAR1) PLSLAM_MI_MMA(m0, 0, 1, m0)
-        bfr[3] = *reinterpret_cast<const i32x4*>(bt + 96);
+        bfr[3] = PLSLAM_MI_READ_B(3);
         PLSLAM_MI_EPI2(m1, 1, 4, PAR1) PLSLAM_MI_MMA(m0, 0, 2, m0)
         // the next tile's raw dword (requested three steps ago) leaves the ring: an LDS latency ahead of its expansion
-        const uint32_t raw_next = take_raw(ring_slot);
+        const uint32_t raw_next = (PLSLAM_MI_X & 16) ? 0u : take_raw(ring_slot);
         PLSLAM_MI_EPI2(m1, 1, 6, PAR1) PLSLAM_MI_MMA(m0, 0, 3, m0)
         const uint32_t cm1 = PLSLAM_MI_F16 ? cma : pk_min16(cma, cmb);
         // behind the chain of M-tile 0: the expansion of the next tile (its buffer was read for the last time before this
         // step's barrier) and the prefetch -- independent work while the last MFMA of the chain completes
+        if (!(PLSLAM_MI_X & 16)) {
         expand_store(raw_next, (U + 1) & 1, t + 1, FULL);         // past the last tile: a harmless rewrite of the idle buffer
         if (FULL) load_raw_async_full(t + 4, ring_slot);          // three tiles ahead of its use, into the slot just read
         else load_raw_async(t + 4, ring_slot);
+        } else asm volatile("" :: "v"(raw_next));
         ring_slot = ring_slot == 2 ? 0 : ring_slot + 1;           // (scalar)
         if (with_prev) {
             // block (t - 9) / 8 of column results: its last tile was parked in the step before this one, by every wave before
@@ -451,7 +465,8 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         // MFMA (a builtin, six VALU instructions later: any MFMA -> MFMA wait state is long over) and by VALU instructions only
         // behind the chain's last MFMA, a builtin whose hazards the compiler tracks; the sources are VGPRs the compiler waits
         // for as for any asm operand.
-        asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %3 cbsz:4 blgp:4" : "=&v"(m1) : "v"(afrag[1][0]), "v"(bfr[0]), "v"(cseed));
+        if (!(PLSLAM_MI_X & 4)) asm volatile("v_mfma_f32_32x32x64_f8f6f4 %0, %1, %2, %3 cbsz:4 blgp:4" : "=&v"(m1) : "v"(afrag[1][0]), "v"(bfr[0]), "v"(cseed));
+        else { m1 = cseed; m1[0] = __builtin_bit_cast(float, bfr[0].x ^ afrag[1][0].x); asm volatile("" : "+v"(m1)); }
         __builtin_amdgcn_sched_barrier(0);
 #else
         PLSLAM_MI_MMA(m1, 1, 0, cseed)
@@ -530,6 +545,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #undef PLSLAM_MI_EPI2
 #undef PLSLAM_MI_EPI
 #undef PLSLAM_MI_MMA
+#undef PLSLAM_MI_READ_B
 
     // Row results of a window: K1h's finish_rows with this kernel's slot -> row map (slot 8 mt + q: low half = local row
     // 32 mt + 16 g + q, high half = local row 32 mt + 16 g + q + 8 of the wave's 64).  One lane per row after the transpose;
@@ -568,25 +584,25 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
                 jbase = (t0 >> 4) * MH_GROUP_ROWS + s * (k & 0xFFFFu);
                 cnt = s;
             };
-            // all members of a (group, class): the smallest (d << 23 | j) and the second smallest (four candidates' rows are
-            // requested together)
+            // all members of a (group, class): the smallest (d << 23 | j) and the second smallest (MI_RESCAN_BATCH candidates' rows
+            // are requested together: the accumulators are dead here, and the loop is a chain of L2 round trips)
             auto rescan = [&](uint32_t jbase, uint32_t cnt, uint32_t& best, uint32_t& second) {
                 best = second = KEY_NONE;
                 const uint32_t left = (uint32_t)n2 - jbase;                       // >= 1: the class's first column exists
                 const uint32_t nvalid = cnt < left ? cnt : left;
                 const PLSLAM_GLOBAL char* const rbp = bbytes + (size_t)jbase * 32;
 #pragma unroll
-                for (int k0_ = 0; k0_ < MH_GROUP; k0_ += 4) {
-                    u32x4_t bl[4], bh[4];
+                for (int k0_ = 0; k0_ < MH_GROUP; k0_ += MI_RESCAN_BATCH) {
+                    u32x4_t bl[MI_RESCAN_BATCH], bh[MI_RESCAN_BATCH];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < MI_RESCAN_BATCH; ++q) {
                         const uint32_t kk = (uint32_t)(k0_ + q) < nvalid ? (uint32_t)(k0_ + q) : nvalid - 1u;   // past the end: a duplicate, masked below
                         const gcu32x4_t bp = (gcu32x4_t)(rbp + kk * 32u);
                         bl[q] = bp[0];
                         bh[q] = bp[1];
                     }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < MI_RESCAN_BATCH; ++q) {
                         const uint32_t d = hamming256(a_lo, a_hi, bl[q], bh[q]);
                         const uint32_t cand = (uint32_t)(k0_ + q) < nvalid ? ((d << KEY_IDX_BITS) | (jbase + (uint32_t)(k0_ + q))) : KEY_NONE;
                         second = umin_(second, umax_(best, cand));
