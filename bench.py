@@ -55,7 +55,8 @@ def usable_cpus() -> int:
     return max(1, n)
 
 
-SCAN_KERNEL_SOURCES = ("common.hpp", "hamming.hip", "hamming_mfma.hip", "hamming_mfma_g.hip", "hamming_mfma_h.hip", "hamming_mfma_d.hip")
+SCAN_KERNEL_SOURCES = ("common.hpp", "mfma_h_common.hpp", "hamming.hip", "hamming_mfma.hip", "hamming_mfma_g.hip", "hamming_mfma_h.hip",
+                       "hamming_mfma_i.hip", "hamming_mfma_d.hip")
 
 
 def kernel_source_hash() -> str:
@@ -162,7 +163,7 @@ def main():
     ap.add_argument("--scan-block", type=int, default=0)
     ap.add_argument("--sym-rows", type=int, default=0)
     ap.add_argument("--group-cap", type=int, default=0)
-    ap.add_argument("--mfma-form", type=int, default=0, help="0 = auto (K1h), 1 = K1e (best-2 push per tile), 2 = K1f (group minima, rows), 3 = K1g (two directed scans per mutual problem), 4 = K1h (group minima both ways)")
+    ap.add_argument("--mfma-form", type=int, default=0, help="0 = auto (K1i), 1 = K1e (best-2 push per tile), 2 = K1f (group minima, rows), 3 = K1g (two directed scans per mutual problem), 4 = K1h (group minima both ways), 5 = K1i (K1h, M-tiles pipelined against each other, unscaled MFMA, f16 three-input minima)")
     ap.add_argument("--fuse", type=int, default=0, help="K1f: 0 = auto, 1 = never, 2 = always one workgroup per problem incl. merge + finalize")
     ap.add_argument("--post-wgs", type=int, default=0, help="cap on the workgroups of the stages behind a scan when they run beside the next scan (option post_workgroups; 0 = the library's default)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=INT", help="any other plslam_ctx option, e.g. --opt exact_second=1")
@@ -453,7 +454,7 @@ def main():
         achieved_gbs = info["algorithmic_bytes"] / scan_s / 1e9
         mfma = info["scan_variant"] == 4
         form = ctx.get_option("mfma_form")
-        kernel_name = {4: {1: "k_scan_sym_mfma", 2: "k_scan_sym_mfma_g", 3: "k_scan_dir_mfma"}.get(form, "k_scan_sym_mfma_h"),
+        kernel_name = {4: {1: "k_scan_sym_mfma", 2: "k_scan_sym_mfma_g", 3: "k_scan_dir_mfma", 4: "k_scan_sym_mfma_h"}.get(form, "k_scan_sym_mfma_i"),
                        3: "k_scan_symmetric" + ("_r4" if info["scan_block_threads"] == 64 else ""),
                        2: "k_scan_wave_per_query", 1: "k_scan_lane_per_query"}.get(info["scan_variant"], "k_scan")
         # HBM bytes / executed instructions of the dominant kernel per launch: PMC counters cannot be read from inside
@@ -502,11 +503,11 @@ def main():
                 "frac": mfma_ops / scan_s / mx_peak, "traffic": traffic, "kernel": kernel_name,
                 "kernel_ms": 1e3 * scan_s, "kernel_ms_in_timed_region": scan_ms / max(runs, 1), "timing": timing_note,
                 "algorithmic_ops_per_launch": mfma_ops, "pmc": pmc_note,
-                "note": "block-scaled fp4 MFMA (operands are the e2m1 codes of +-1, fp32 accumulation of integers below "
-                        "2^24: exact); dense MX-fp4 peak = CUs x 4 SIMDs x 4096 ops/clk x max clock (MI355X_MICROARCH.md "
-                        "measures 9099 T for the 32x32x64 shape); 512 ops per executed 256-bit distance (each serves both "
-                        "match directions).  The kernel is co-limited by the VALU best-2 bookkeeping that consumes the "
-                        "accumulators: see valu_executed",
+                "note": "fp4 MFMA v_mfma_f32_32x32x64_f8f6f4 (operands are the e2m1 codes of +-4 -- K1i, unscaled -- or of +-1 "
+                        "with a 2^6 block scale -- K1e..K1h; fp32 accumulation of integers below 2^24: exact); dense fp4 peak = "
+                        "CUs x 4 SIMDs x 4096 ops/clk x max clock (MI355X_MICROARCH.md measures 9099 T for the 32x32x64 "
+                        "shape); 512 ops per executed 256-bit distance (each serves both match directions).  The kernel is "
+                        "co-limited by the VALU bookkeeping that consumes the accumulators: see valu_executed",
             }
         else:
             roofline = dict(hbm_roofline, pmc=pmc_note)
@@ -532,6 +533,9 @@ def main():
                                                 "overlap), the first one includes the pipeline fill"},
             "vs_baseline": None,
             "dtype": "fp4" if mfma else "u32",
+            "dtype_note": ("the operand CODE of +-1 values on the matrix cores; every distance is an exact integer (fp32 accumulation "
+                           "of integers below 2^24) and every table of the timed run is compared bit for bit with the oracle's"
+                           if mfma else "exact: XOR + popcount on 32-bit words"),
             "data": "synthetic",
             "config": {
                 "workload": workload,
@@ -645,12 +649,60 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
             rec[tag]["cpu_cores"] = usable_cpus()
         note(f"  {tag}: {rec[tag]['value']:.0f} pairs/s, scan {scan_ms:.3f} ms")
 
+    def gather_1rank(tag, n_orb, n_lbd, pairs, steps):
+        """The strong_512 step as rank 0 of N > 1 runs it: a (forced) one-rank RCCL process group, PipelinedGather around the
+        same matcher -- narrowing copy, gather on the communication stream, widening -- under the next step's scan.  What it
+        shows: the N > 1 step costs what the N = 1 step costs when the link is free (one rank: RCCL copies locally)."""
+        import torch.distributed as dist
+        if dist.is_initialized():
+            return
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29537")
+        try:
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        except Exception as e:                         # (no RCCL in this process: the record says so instead of failing the line)
+            rec[tag] = {"skipped": f"RCCL process group unavailable: {type(e).__name__}"}
+            return
+        try:
+            st = synth.stereo_stream(pairs, n_orb, n_lbd, seed=synth.SEED0)
+            bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev, n_buffers=2,
+                                             geometry=synth.stereo_geometry(st, first_pair=0), gates=dict(synth.KITTI_GATES))
+            pg = frontend.PipelinedGather(bm, 1, 0, root=0)
+            for k in range(2):
+                pg.step(k)
+            pg.finish()
+            bm.synchronize_all()
+            t0 = time.perf_counter()
+            for k in range(steps):
+                pg.step(2 + k)
+            pg.finish()
+            bm.synchronize_all()
+            dt = time.perf_counter() - t0
+            ref, _ = oracle_tables(st, n_orb, n_lbd, args.nnr_p, args.nnr_l)
+            for b_ in range(2):
+                if not np.array_equal(pg.gathered(b_).cpu().numpy(), ref):
+                    raise SystemExit(f"secondary record {tag}: gathered buffer {b_} differs from the oracle")
+            bm.close()
+            rec[tag] = {"metric": f"stereo pairs/sec ({n_orb} ORB + {n_lbd} LBD BF-match)", "value": pairs * steps / dt,
+                        "unit": "stereo pairs/s", "pairs_per_step": pairs, "steps": steps,
+                        "workload": "strong_512 with the N > 1 step around it: one-rank RCCL group, int16 wire format, gather on "
+                                    "the communication stream under the next step's scan, widening to the int32 tables",
+                        "over_strong_512": (pairs * steps / dt) / rec["strong_512"]["value"] if "strong_512" in rec else None,
+                        "verified": f"all {pairs} pairs x 4 problems of both GATHERED buffers bit-exact vs the oracle",
+                        "note": "one rank: what it measures is the step's own overhead (copies, events, the collective's launch), "
+                                "not a link; no 1 -> 8 curve has been measured"}
+            note(f"  {tag}: {rec[tag]['value']:.0f} pairs/s")
+        finally:
+            dist.destroy_process_group()
+
     n_orb, n_lbd, B = args.n_orb, args.n_lbd, args.pairs_per_gpu
     small = max(64, min(512, B))
-    pairs_run("tables_only", n_orb, n_lbd, B, 6, {}, "the main workload without the stereo-gate stage (one repeated batch)",
-              ref=main_tables)
+    # (round 3's "tables_only" record -- the main workload without the gate stage, one repeated batch, six steps incl. the
+    # pipeline fill -- is gone: its stepping was not the headline's, so the two numbers said nothing about the gates' cost;
+    # kernel_ms.post_scan_stages of the main record is the gate-inclusive time of the stages behind the scan)
     pairs_run("strong_512", n_orb, n_lbd, 512, 12, {}, "the per-GPU shard of BASELINE config 4 (4096 pairs over 8 GPUs = 512 per GPU "
               "per step), gate stage included: the single-GPU rate at that step size", with_gates=True)
+    gather_1rank("strong_512_gather_1rank", n_orb, n_lbd, 512, 12)
     pairs_run("c1_substitute", 800, 100, min(B, 4096), 6, {}, "C1 substitute (SURVEY 8d): KITTI-00-shaped descriptor-level replay, "
               "800 ORB + 100 LBD per image (config_kitti.yaml:62,71), nnr_p 0.75, nnr_l 0.9, mutual; the reference's own "
               "plslam_dataset run cannot be built in this image", nnr_l=0.9, cpu_rate=True)
@@ -783,11 +835,17 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
     moved_pt = 8 + 16 + 88 + 24.0 * n_pt_lm / npt
     moved_ls = 8 + 24 + 112 + 48.0 * n_ls_lm / nls
 
-    def stream_rec(nrows, ms_b, moved, model):
-        return {"rows": nrows, "bytes_per_row_moved": moved, "GBps_moved": nrows * moved / (ms_b * 1e-3) / 1e9,
-                "frac_of_hbm_peak": nrows * moved / (ms_b * 1e-3) / (HBM_PEAK_GBS * 1e9),
-                "bytes_per_row_survey_model": model, "GBps_survey_model": nrows * model / (ms_b * 1e-3) / 1e9,
-                "ms_per_launch": ms_b}
+    def stream_rec(nrows, ms_b, moved, model, cache_resident=False):
+        """frac_of_hbm_peak only for the footprint that defeats the 256 MB memory-side cache; SURVEY 8(d)'s per-row MODEL (the
+        reference's 24-byte index records, one landmark read per row) is given as bytes only -- a rate computed from bytes
+        the kernel does not move is not a rate, and could exceed the peak."""
+        d = {"rows": nrows, "bytes_per_row_moved": moved, "GBps_moved": nrows * moved / (ms_b * 1e-3) / 1e9,
+             "bytes_per_row_survey_model": model, "ms_per_launch": ms_b}
+        if cache_resident:
+            d["cache_resident"] = "~0.4 GB per launch: partly absorbed by the memory-side cache -- not an HBM rate, no roofline fraction"
+        else:
+            d["frac_of_hbm_peak"] = nrows * moved / (ms_b * 1e-3) / (HBM_PEAK_GBS * 1e9)
+        return d
     rec["c3"] = {
         "workload": "C3: one local map against one frame -- 10 000 x 1500 ORB + 2 000 x 200 LBD mutual match "
                     "(mapHandler.cpp:532-752) and the LBA row pass over 50 000 point + 10 000 line observations (:1358-1540)",
@@ -795,14 +853,14 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
         "match_verified": "both tables bit-exact vs the oracle",
         "lba_rows_pass_us": 1e3 * (ms_p1 + ms_l1), "lba_rows_pass_bytes": npt * 152 + nls * 208,
         "lba_point_rows_streaming": dict(stream_rec(npt * reps_pt[1], ms_pb, moved_pt, 152),
-                                         at_0p4_GB_per_launch=stream_rec(npt * reps_pt[0], ms_pb0, moved_pt, 152)),
+                                         at_0p4_GB_per_launch=stream_rec(npt * reps_pt[0], ms_pb0, moved_pt, 152, cache_resident=True)),
         "lba_line_rows_streaming": dict(stream_rec(nls * reps_ls[1], ms_lb, moved_ls, 208),
-                                        at_0p4_GB_per_launch=stream_rec(nls * reps_ls[0], ms_lb0, moved_ls, 208)),
+                                        at_0p4_GB_per_launch=stream_rec(nls * reps_ls[0], ms_lb0, moved_ls, 208, cache_resident=True)),
         "note": "one map = one launch of 9.7 MB: launch-bound (replicas only, SURVEY 8e); the streaming figures batch 256 point / "
                 "1024 line maps (each with its own landmark array: ~1.5 GB moved) per launch to show the row kernels' HBM rate, "
                 "and a quarter of that beside it (~0.4 GB: the memory-side cache flatters it); frac_of_hbm_peak is computed "
                 "from the bytes the kernels move (indices 8 B, not the reference's 24-byte Vector6i; landmarks once), "
-                "profiles/r3_*_lba_* hold the rocprofv3 kernel trace and FETCH_SIZE / WRITE_SIZE passes of the same launches"}
+                "profiles/r4_*_lba_* hold the rocprofv3 kernel trace and FETCH_SIZE / WRITE_SIZE passes of the same launches"}
     note(f"  c3: match {1e3 * ms:.1f} us, rows {rec['c3']['lba_point_rows_streaming']['GBps_moved']:.0f} / "
          f"{rec['c3']['lba_line_rows_streaming']['GBps_moved']:.0f} GB/s moved")
     # ---- the other section-8 rows (bench_rows.py): each verified over everything it produced -----------------

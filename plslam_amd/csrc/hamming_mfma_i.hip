@@ -264,12 +264,13 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #pragma unroll
             for (int q = 0; q < 4; ++q) { lo[q] = pk_min16(p[2 * q], p[2 * q + 1]); hi[q] = pk_max16(p[2 * q], p[2 * q + 1]); }
             // ... the best ROW over the waves: a wave's best key with the wave's number between distance and tag --
-            // (d << 7 | 32 v + 16 h + r), K1h's key: x + 3 (x & ~31) + 32 v (mod 2^16: "none" 0x7BFF becomes 0xEF9F, above every key) ...
+            // (d << 7 | 32 v + 16 h + r), K1h's key: x + 3 (x & ~31) + 32 v, SATURATING: "none" (0x7BFF) and the keys of penalised
+            // columns (0x5000 ...) become 0xFFFF, above every key ...
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 uint32_t t;
                 asm("v_pk_add_u16 %0, %1, %2" : "=v"(t) : "v"(lo[q]), "v"((uint32_t)(32 * q) * 0x00010001u));
-                asm("v_pk_mad_u16 %0, %1, %2, %3" : "=v"(enc[q]) : "v"(lo[q] & 0xFFE0FFE0u), "v"(0x00030003u), "v"(t));
+                asm("v_pk_mad_u16 %0, %1, %2, %3 clamp" : "=v"(enc[q]) : "v"(lo[q] & 0xFFE0FFE0u), "v"(0x00030003u), "v"(t));
             }
             const uint32_t best = pk_min16(pk_min16(enc[0], enc[1]), pk_min16(enc[2], enc[3]));
             // ... and the second smallest of the 8 group minima as a VALUE: whichever wave it comes from, its distance is that

@@ -51,7 +51,7 @@ class StereoBatchMatcher:
     table of step k is still being gathered (bench.py, N > 1)."""
 
     def __init__(self, ctx, stream_np: dict, nnr_p=0.75, nnr_l=0.75, mutual=True, device=None, n_buffers=1,
-                 geometry: dict | None = None, gates: dict | None = None, streams=None):
+                 geometry: dict | None = None, gates: dict | None = None, streams=None, scan_streams: int = 1):
         """geometry (synth.stereo_geometry: kp_l, kp_r, seg_l, seg_r per frame) + gates (the thresholds max_dist_epip,
         min_disp, line_horiz_th, stereo_overlap_th, ls_min_disp_ratio) add the gate stage of StereoFrame to every plan:
         each run then also fills `stereo` (B, n_orb + n_lbd) int32 -- the L<->R associations that survive the epipolar /
@@ -131,6 +131,10 @@ class StereoBatchMatcher:
         # take the workgroup slots the running scan frees instead of queueing behind its backlog
         self.streams = list(streams) if streams is not None else \
             [self.stream] + [torch.cuda.Stream(device=dev, priority=-1 if i == 0 else 0) for i in range(n_buffers - 1)]
+        # `scan_streams` = 2: the scans of consecutive steps alternate between two streams, so the first workgroups of step
+        # k+1 fill the slots the last wave of step k's scan leaves idle.  A 512-pair step is 9.3 rounds of the chip's 768
+        # workgroup slots: its last round is a third full, and on one stream the next scan starts only when it is over.
+        self.scan_streams = [self.streams[0]] + [torch.cuda.Stream(device=dev) for _ in range(max(1, scan_streams) - 1)]
 
     def run_overlapped(self, k: int):
         """Step k of a stream of independent batches into buffer k % n_buffers: every scan on one HIP stream, the
@@ -138,8 +142,12 @@ class StereoBatchMatcher:
         run under the NEXT step's scan, which is bound by instruction issue.  The plans order themselves (a plan's
         scan waits for the last stage of its previous run).  Call synchronize_all() before reading."""
         b = k % len(self.plans)
-        self.plans[b].run_split(self.streams[0].cuda_stream, self.streams[min(1, len(self.streams) - 1)].cuda_stream)
+        self.plans[b].run_split(self.scan_stream_of(k).cuda_stream, self.streams[min(1, len(self.streams) - 1)].cuda_stream)
         return b
+
+    def scan_stream_of(self, k: int):
+        """The stream step k's scan runs on."""
+        return self.scan_streams[k % len(self.scan_streams)]
 
     @property
     def stage_stream(self):
@@ -147,7 +155,7 @@ class StereoBatchMatcher:
         return self.streams[min(1, len(self.streams) - 1)]
 
     def synchronize_all(self):
-        for s in self.streams:
+        for s in list(self.streams) + list(self.scan_streams[1:]):
             s.synchronize()
 
     def run(self, buf: int = 0):
@@ -328,7 +336,7 @@ class PipelinedGather:
         # as run_overlapped(): every scan on streams[0], the stages behind it -- which write table b -- on the
         # high-priority streams[1]; that stream therefore waits for the previous gather of buffer b, and the narrowing
         # copy + the gather's event go behind the stages on it
-        scan, post = self.bm.streams[0], self.bm.streams[min(1, len(self.bm.streams) - 1)]
+        scan, post = self.bm.scan_stream_of(k), self.bm.streams[min(1, len(self.bm.streams) - 1)]
         self.pipe.before_overwrite(b, post)
         self.bm.plans[b].run_split(scan.cuda_stream, post.cuda_stream)
         return self.pipe.submit(b, self.bm.tables[b], post)

@@ -39,16 +39,24 @@ def test_bench_single_gpu_line():
     assert d["verified"]["match_tables"].startswith("all 24 pairs") and "bit-exact" in d["verified"]["stereo_gates"]
     assert d["config"]["stereo_gates"]["max_dist_epip"] == 0.0
     sec = d["secondary"]
-    assert set(sec) >= {"tables_only", "popcount_u32_symmetric", "popcount_u32_north_star_literal", "c5", "c3"}
-    assert all(sec[k]["value"] > 0 for k in ("tables_only", "popcount_u32_symmetric", "popcount_u32_north_star_literal", "c5"))
+    assert set(sec) >= {"popcount_u32_symmetric", "popcount_u32_north_star_literal", "c5", "c3"} and "tables_only" not in sec
+    assert all(sec[k]["value"] > 0 for k in ("popcount_u32_symmetric", "popcount_u32_north_star_literal", "c5"))
     assert "4000 ORB + 600 LBD" in sec["c5"]["metric"] and sec["c3"]["match_us"] > 0
     for k in ("lba_point_rows_streaming", "lba_line_rows_streaming"):        # (round 2 printed 1.008 of the HBM peak here)
         assert 0 < sec["c3"][k]["frac_of_hbm_peak"] < 1 and sec["c3"][k]["bytes_per_row_moved"] < sec["c3"][k]["bytes_per_row_survey_model"]
+        # no rate from modelled bytes (round 3 printed 8800 GB/s there), no roofline fraction for the cache-resident footprint
+        assert "GBps_survey_model" not in sec["c3"][k] and "frac_of_hbm_peak" not in sec["c3"][k]["at_0p4_GB_per_launch"]
+        assert "cache_resident" in sec["c3"][k]["at_0p4_GB_per_launch"]
     assert "valu_roofline" not in d                      # (round 1 printed a "fraction" of 1.86 there)
     # every section-8 row has a driver-timed record, each verified over everything it produced
     assert set(sec) >= {"strong_512", "c1_substitute", "grid", "drivers", "lba_plan_iterate_dev", "lbd", "median_desc"}
     assert sec["c1_substitute"]["value"] > 0 and "800 ORB + 100 LBD" in sec["c1_substitute"]["metric"]
-    assert all("all " in sec[k]["verified"] for k in ("tables_only", "strong_512", "c1_substitute", "c5"))
+    assert all("all " in sec[k]["verified"] for k in ("strong_512", "c1_substitute", "c5"))
+    # the N > 1 step around the strong_512 shard, through a forced one-rank RCCL group, every gathered pair verified
+    g1 = sec["strong_512_gather_1rank"]
+    assert "skipped" in g1 or (g1["value"] > 0 and "GATHERED" in g1["verified"] and g1["over_strong_512"] > 0)
+    assert all("binarise_GBps" not in v for k, v in sec["lbd"].items() if isinstance(v, dict))
+    assert d["dtype_note"].startswith("exact") or "exact" in d["dtype_note"]
     assert sec["grid"]["plan_1024_frame_pairs"]["problems"] == 2048 and len([k for k in sec["drivers"] if k != "workload"]) == 8
     # the map<->keyframe drivers also with the map resident on the device (plslam_map2kf_match_*_dev)
     assert all(v["map_on_device_us_median"] > 0 for k, v in sec["drivers"].items() if k.startswith("map2kf"))
@@ -66,7 +74,7 @@ def test_bench_matrix_core_branch_of_the_line():
     d = _run(["--no-cpu-baseline", "--no-secondary"], pairs=160, n_orb=512, n_lbd=64)
     assert REQUIRED <= set(d) and d["value"] > 0
     assert d["roofline"]["bound"] == "mfma" and d["dtype"] == "fp4" and d["roofline"]["unit"] == "TFLOP/s"
-    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel"] == "k_scan_sym_mfma_h"
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel"] == "k_scan_sym_mfma_i"
     assert d["hbm_roofline"]["bound"] == "hbm" and 0 < d["hbm_roofline"]["frac"] < 1
     assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"}
     assert len(d["config"]["kernel_source_hash"]) == 16

@@ -105,7 +105,7 @@ def test_no_inline_asm_reads_mfma_results(fname):
         assert len(re.findall(r"\bf[01]\b", src)) == len(re.findall(r"pack_acc\(f0, f1", src)) * 2 + 2 * len(uses)
 
 
-@pytest.mark.parametrize("fname", ["hamming_mfma.hip", "hamming_mfma_g.hip", "hamming_mfma_h.hip", "hamming_mfma_d.hip"])
+@pytest.mark.parametrize("fname", ["hamming_mfma.hip", "hamming_mfma_g.hip", "hamming_mfma_h.hip", "hamming_mfma_d.hip", "hamming_mfma_i.hip"])
 def test_final_isa_has_no_mfma_destination_hazard(tmp_path, fname):
     """Compiles hamming_mfma.hip to gfx950 assembly (as build.py does, -S instead of -shared) and runs
     tools/check_mfma_hazards.py over the FINAL listing, inline-asm bodies included: no non-MFMA instruction may touch a
@@ -121,7 +121,8 @@ def test_final_isa_has_no_mfma_destination_hazard(tmp_path, fname):
         import pytest
         pytest.skip("hipcc not available")
     out = str(tmp_path / (fname + ".s"))
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(root, "include"),
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm",
+                    "-I" + os.path.join(root, "include"),
                     "-S", "--cuda-device-only", "-o", out, os.path.join(root, "plslam_amd", "csrc", fname)],
                    check=True, capture_output=True)
     spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(root, "tools", "check_mfma_hazards.py"))
@@ -129,7 +130,12 @@ def test_final_isa_has_no_mfma_destination_hazard(tmp_path, fname):
     spec.loader.exec_module(mod)
     text = open(out).read()
     # all instantiations are there (K1h / K1g: one set of MFMAs per unrolled step)
-    assert text.count("v_mfma_scale_f32_32x32x64_f8f6f4") >= (24 if fname == "hamming_mfma_d.hip" else 128)
+    # (K1i issues the UNSCALED instruction -- also through one inline-asm statement per tile, which is why the checker reads
+    # the final listing, asm bodies included)
+    if fname == "hamming_mfma_i.hip":
+        assert text.count("v_mfma_f32_32x32x64_f8f6f4") >= 128 and "v_mfma_scale" not in text
+    else:
+        assert text.count("v_mfma_scale_f32_32x32x64_f8f6f4") >= (24 if fname == "hamming_mfma_d.hip" else 128)
     findings = mod.check(out, 12)
     assert not findings, findings[:5]
 
@@ -219,3 +225,130 @@ def test_k1h_stays_at_three_workgroups_per_cu(tmp_path):
         spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
         assert lds <= 53248 and vgpr <= 168 and spill <= 16, (name, lds, vgpr, spill)
     assert seen == 2                                       # the symmetric and the directed instantiation
+
+
+def test_k1i_inline_asm_touches_accumulators_only_as_an_mfma_destination():
+    """K1i's one exception to "no asm statement takes an accumulator": the first MFMA of the loop-carried chain is an asm
+    statement with an early-clobber DESTINATION (the compiler's tied form would copy 16 seed registers per tile).  Nothing
+    else: the accumulators are read by pack_acc -- a builtin -- only, and no asm statement takes one as an INPUT."""
+    import os
+    import re
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plslam_amd", "csrc", "hamming_mfma_i.hip")).read()
+    src = "\n".join(l.split("//")[0] for l in src.split("\n"))
+    stmts = [m.group(1) for m in re.finditer(r"asm(?:\s+volatile)?\s*\(([^;]*);", src) if not re.match(r'\s*""', m.group(1))]
+    acc = [b for b in stmts if re.search(r"\(m[01]\)", b)]
+    assert len(acc) == 1 and acc[0].lstrip().startswith('"v_mfma_f32_32x32x64_f8f6f4') and '"=&v"(m1)' in acc[0]
+    assert not re.search(r':\s*"v"\(m[01]\)|,\s*"v"\(m[01]\)', acc[0])            # not an input
+    uses = [l for l in src.split("\n") if re.search(r"\bACC\[", l) and "ACC[KS]" not in l and "ACC[0]" not in l]
+    assert uses and all("pack_acc(" in l for l in uses), uses
+
+
+def test_k1i_stays_at_three_workgroups_per_cu_and_owns_m0(tmp_path):
+    """Three workgroups per CU (<= 168 VGPRs, <= 53 248 B of LDS), no spill traffic inside the tile loops (a reload there waits
+    for vmcnt(0), i.e. for the whole LDS-DMA prefetch), and M0 -- declared clobbered, not saved -- written by nothing but the
+    kernel's own LDS-DMA statements."""
+    import os
+    import re
+    import subprocess
+    from plslam_amd import build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "plslam_amd", "csrc", "hamming_mfma_i.hip")
+    r = subprocess.run([B.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm",
+                        "-I" + os.path.join(root, "include"), "-S", "--cuda-device-only", src, "-o", "-"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
+    seen = 0
+    for blk in r.stdout.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "k_scan_sym_mfma_i" not in name:
+            continue
+        seen += 1
+        lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1))
+        vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
+        spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
+        assert lds <= 53248 and vgpr <= 168 and spill <= 8, (name, lds, vgpr, spill)
+    assert seen == 2
+    # per kernel: between the first and the last MFMA lie the tile loops with their rare paths (column combine, group push,
+    # ragged-group penalties): at most a couple of reloads there, none in a stretch between two barriers that is a plain tile
+    # step (8 MFMAs, no store of column results, no parked-pair traffic); and every write of m0 is followed (s_nop apart) by
+    # the LDS-DMA load
+    for body in re.split(r"\n_ZN6plslam17k_scan_sym_mfma_i", r.stdout)[1:]:
+        body = body.split("s_endpgm")[0]
+        first, last = body.index("v_mfma_f32_32x32x64_f8f6f4"), body.rindex("v_mfma_f32_32x32x64_f8f6f4")
+        assert body[first:last].count("scratch_") <= 4, body[first:last].count("scratch_")
+        plain = [seg for seg in body[first:last].split("s_barrier")
+                 if seg.count("v_mfma_f32_32x32x64_f8f6f4") == 8 and "global_store" not in seg and "ds_write2st64_b64" not in seg]
+        assert len(plain) >= 4 and all("scratch_" not in seg for seg in plain), len(plain)
+        lines = [l.strip() for l in body.split("\n") if l.strip() and not l.strip().startswith(";")]
+        for i, l in enumerate(lines):
+            if re.match(r"s_mov_b32 m0,", l):
+                nxt = [x for x in lines[i + 1:i + 4] if not x.startswith("s_nop")]
+                assert nxt and nxt[0].startswith("global_load_lds_dword"), lines[i:i + 4]
+            assert not re.search(r"\bm0\b", l) or l.startswith("s_mov_b32 m0,"), l
+
+
+def test_k1i_workgroup_column_combine_model():
+    """K1i's column combine (hamming_mfma_i.hip::combine_columns, the one-word form), modelled in numpy.  The parked keys are
+    (d << 5 | 16 g + r) -- the unscaled MFMA leaves five bits under the distance --, so keys of DIFFERENT waves do not order
+    like rows: the best row is the minimum of the waves' best keys re-encoded with the wave between distance and tag
+    (x + 3 (x & ~31) + 32 v = d << 7 | 32 v + 16 g + r, saturating), the second entry the second smallest parked VALUE (only its
+    distance is kept).  Must equal the definition: K0 = the column's best row over the workgroup's 256 rows (ties: the lowest
+    row), K1's distance = that of the best row outside K0's group of 16 -- incl. struck-out groups ("none" = 0x7BFF, the
+    largest finite half float), penalised columns and distance ties across waves (the case a value-only network gets wrong)."""
+    r = np.random.Generator(np.random.PCG64(15))
+    NONE = 0x7BFF
+
+    def pk(op, a, b):
+        lo, hi = op(a & 0xFFFF, b & 0xFFFF), op(a >> 16, b >> 16)
+        return (hi << 16) | lo
+
+    def pk_merge(a0, a1, c0, c1):
+        m = pk(max, a0, c0)
+        return pk(min, a0, c0), pk(min, m, pk(min, a1, c1))
+
+    def merge2(a0, a1, c0, c1):
+        return min(a0, c0), min(max(a0, c0), min(a1, c1))
+
+    def enc(x, v):                                         # v_pk_add_u16 + v_pk_mad_u16 ... clamp on one half
+        return min((x & 0xFFE0) * 3 + ((x + 32 * v) & 0xFFFF), 0xFFFF)
+
+    for it in range(6000):
+        ties = it % 3 == 0
+        words, groups = [], []
+        for w in range(4):
+            for g in range(2):
+                halves = []
+                for mt in range(2):
+                    kind = r.integers(0, 12)
+                    rr = int(r.integers(0, 16))
+                    if kind == 0:
+                        key = NONE
+                    elif kind == 1:
+                        key = 0x5000 + 16 * g + rr          # zero codes ("distance 128") + the column penalty
+                    else:
+                        d = int(r.integers(0, 3)) if ties else int(r.integers(0, 257))
+                        key = (d << 5) | (16 * g + rr)
+                    halves.append(key)
+                    if key < 0x4000:
+                        groups.append((((key >> 5) << 8) | (128 * mt + 32 * w + (key & 31)), (w, g, mt)))
+                words.append((halves[1] << 16) | halves[0])
+        lo = [pk(min, words[2 * q], words[2 * q + 1]) for q in range(4)]
+        hi = [pk(max, words[2 * q], words[2 * q + 1]) for q in range(4)]
+        e = [(enc(lo[q] >> 16, q) << 16) | enc(lo[q] & 0xFFFF, q) for q in range(4)]
+        best = pk(min, pk(min, e[0], e[1]), pk(min, e[2], e[3]))
+        lo[0], hi[0] = pk_merge(lo[0], hi[0], lo[1], hi[1])
+        lo[2], hi[2] = pk_merge(lo[2], hi[2], lo[3], hi[3])
+        lo[0], hi[0] = pk_merge(lo[0], hi[0], lo[2], hi[2])
+        e0, u0, e1, u1 = best & 0xFFFF, best >> 16, hi[0] & 0xFFE0, (hi[0] >> 16) & 0xFFE0
+        k0, k1 = merge2(e0 + (e0 & 0xFF80), e1 << 3, u0 + (u0 & 0xFF80) + 128, u1 << 3)
+        k0c, d1 = min(k0, 0x1FFFF), min(k1 >> 8, 511)     # the word's fields
+        groups.sort()
+        if not groups:
+            assert (k0c >> 8) > 256 and d1 > 256
+            continue
+        assert k0c == groups[0][0], (it, hex(k0c), hex(groups[0][0]))
+        others = [k for k, gid in groups if gid != groups[0][1]]
+        if others:
+            assert d1 == others[0] >> 8, (it, d1, others[0] >> 8)
+        else:
+            assert d1 > 256
