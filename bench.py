@@ -590,15 +590,20 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
     from plslam_amd import frontend, synth
     rec = {}
 
-    def timed(bm, steps, warm=2):
+    def timed(bm, steps, warm=2, reps=1):
+        """reps > 1: the median of `reps` timed stretches (short steps: a stretch of a few milliseconds sees the clocks settle)"""
         for k in range(warm):
             bm.run_overlapped(k)
         bm.synchronize_all()
-        t0 = time.perf_counter()
-        for k in range(steps):
-            bm.run_overlapped(warm + k)
-        bm.synchronize_all()
-        dt = time.perf_counter() - t0
+        dts = []
+        for r_ in range(reps):
+            t0 = time.perf_counter()
+            for k in range(steps):
+                bm.run_overlapped(warm + r_ * steps + k)
+            bm.synchronize_all()
+            dts.append(time.perf_counter() - t0)
+        dt = float(np.median(dts))
+        timed.stretches = [steps / d for d in dts]            # steps per second of every stretch
         p0 = bm.plans[0]
         p0.set_profiling(True)
         p0.elapsed()
@@ -620,7 +625,8 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
                 raise SystemExit(f"secondary record: buffer {b_} differs from the oracle in {len(bad)} entries, first at pair {bad[0][0]}")
         return ref
 
-    def pairs_run(tag, n_orb, n_lbd, pairs, steps, opts, workload, nnr_l=None, ref=None, with_gates=False, cpu_rate=False):
+    def pairs_run(tag, n_orb, n_lbd, pairs, steps, opts, workload, nnr_l=None, ref=None, with_gates=False, cpu_rate=False, warm=2,
+                  reps=1):
         nnr_l = args.nnr_l if nnr_l is None else nnr_l
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -630,7 +636,8 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
             bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=args.nnr_p, nnr_l=nnr_l, mutual=True, device=dev, n_buffers=2,
                                              geometry=geo_, gates=dict(synth.KITTI_GATES) if with_gates else None)
             info = bm.plan.info()
-            dt, scan_ms, post_ms = timed(bm, steps)
+            dt, scan_ms, post_ms = timed(bm, steps, warm, reps)
+            stretches = [pairs * x for x in timed.stretches]
             t0 = time.perf_counter()
             check_all(bm, st, n_orb, n_lbd, args.nnr_p, nnr_l, ref)
             cpu_dt = time.perf_counter() - t0
@@ -644,12 +651,15 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
                     "scan_variant": info["scan_variant"], "scan_kernel_ms": scan_ms, "post_scan_ms": post_ms,
                     "hbm_roofline_frac": gbs / HBM_PEAK_GBS, "hbm_algorithmic_GBps": gbs,
                     "verified": f"all {pairs} pairs x 4 problems, both output buffers, bit-exact vs the oracle"}
+        if reps > 1:
+            rec[tag]["stretches_pairs_per_s"] = stretches
+            rec[tag]["how"] = f"median of {reps} stretches of {steps} steps after {warm} warm-up steps"
         if cpu_rate and ref is None:
             rec[tag]["cpu_oracle_all_cores_pairs_per_s"] = pairs / cpu_dt     # (includes packing the inputs: a lower bound)
             rec[tag]["cpu_cores"] = usable_cpus()
         note(f"  {tag}: {rec[tag]['value']:.0f} pairs/s, scan {scan_ms:.3f} ms")
 
-    def gather_1rank(tag, n_orb, n_lbd, pairs, steps):
+    def gather_1rank(tag, n_orb, n_lbd, pairs, steps, warm=2, reps=1):
         """The strong_512 step as rank 0 of N > 1 runs it: a (forced) one-rank RCCL process group, PipelinedGather around the
         same matcher -- narrowing copy, gather on the communication stream, widening -- under the next step's scan.  What it
         shows: the N > 1 step costs what the N = 1 step costs when the link is free (one rank: RCCL copies locally)."""
@@ -668,16 +678,19 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
             bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev, n_buffers=2,
                                              geometry=synth.stereo_geometry(st, first_pair=0), gates=dict(synth.KITTI_GATES))
             pg = frontend.PipelinedGather(bm, 1, 0, root=0)
-            for k in range(2):
+            for k in range(warm):
                 pg.step(k)
             pg.finish()
             bm.synchronize_all()
-            t0 = time.perf_counter()
-            for k in range(steps):
-                pg.step(2 + k)
-            pg.finish()
-            bm.synchronize_all()
-            dt = time.perf_counter() - t0
+            dts = []
+            for r_ in range(reps):
+                t0 = time.perf_counter()
+                for k in range(steps):
+                    pg.step(warm + r_ * steps + k)
+                pg.finish()
+                bm.synchronize_all()
+                dts.append(time.perf_counter() - t0)
+            dt = float(np.median(dts))
             ref, _ = oracle_tables(st, n_orb, n_lbd, args.nnr_p, args.nnr_l)
             for b_ in range(2):
                 if not np.array_equal(pg.gathered(b_).cpu().numpy(), ref):
@@ -688,6 +701,8 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
                         "workload": "strong_512 with the N > 1 step around it: one-rank RCCL group, int16 wire format, gather on "
                                     "the communication stream under the next step's scan, widening to the int32 tables",
                         "over_strong_512": (pairs * steps / dt) / rec["strong_512"]["value"] if "strong_512" in rec else None,
+                        "stretches_pairs_per_s": [pairs * steps / d for d in dts],
+                        "how": f"median of {reps} stretches of {steps} steps after {warm} warm-up steps",
                         "verified": f"all {pairs} pairs x 4 problems of both GATHERED buffers bit-exact vs the oracle",
                         "note": "one rank: what it measures is the step's own overhead (copies, events, the collective's launch), "
                                 "not a link; no 1 -> 8 curve has been measured"}
@@ -700,9 +715,11 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
     # (round 3's "tables_only" record -- the main workload without the gate stage, one repeated batch, six steps incl. the
     # pipeline fill -- is gone: its stepping was not the headline's, so the two numbers said nothing about the gates' cost;
     # kernel_ms.post_scan_stages of the main record is the gate-inclusive time of the stages behind the scan)
-    pairs_run("strong_512", n_orb, n_lbd, 512, 12, {}, "the per-GPU shard of BASELINE config 4 (4096 pairs over 8 GPUs = 512 per GPU "
-              "per step), gate stage included: the single-GPU rate at that step size", with_gates=True)
-    gather_1rank("strong_512_gather_1rank", n_orb, n_lbd, 512, 12)
+    # (round 3 timed 12 steps -- 5 ms -- behind 2 warm-up steps here: mostly the pipeline's fill and the clocks' ramp; a stream of
+    # 512-pair steps settles after a few tens of them)
+    pairs_run("strong_512", n_orb, n_lbd, 512, 150, {}, "the per-GPU shard of BASELINE config 4 (4096 pairs over 8 GPUs = 512 per GPU "
+              "per step), gate stage included: the single-GPU rate at that step size", with_gates=True, warm=10, reps=3)
+    gather_1rank("strong_512_gather_1rank", n_orb, n_lbd, 512, 150, warm=10, reps=3)
     pairs_run("c1_substitute", 800, 100, min(B, 4096), 6, {}, "C1 substitute (SURVEY 8d): KITTI-00-shaped descriptor-level replay, "
               "800 ORB + 100 LBD per image (config_kitti.yaml:62,71), nnr_p 0.75, nnr_l 0.9, mutual; the reference's own "
               "plslam_dataset run cannot be built in this image", nnr_l=0.9, cpu_rate=True)

@@ -39,8 +39,9 @@ extern "C" {
 #endif
 
 /* 2: plslam_match_problem grew (keep_prior, reserved: 56 bytes), plslam_lba_plan_iterate's flags became a bit mask, options
- * "mfma_form" 3/4 and "exact_second".  Clients compare plslam_abi_version() with the value they were compiled against. */
-#define PLSLAM_ABI_VERSION 2
+ * "mfma_form" 3/4 and "exact_second"; 3 (round 4): "mfma_form" 5 (the default), "post_fuse", plslam_match_plan_key_state.
+ * Clients compare plslam_abi_version() with the value they were compiled against. */
+#define PLSLAM_ABI_VERSION 3
 #define PLSLAM_DESC_BYTES 32
 /* largest train set of one directed scan: the composite (distance,index) key keeps 23
  * index bits beside the 9 distance bits */
@@ -95,6 +96,10 @@ void plslam_ctx_destroy(plslam_ctx* ctx);
  * 2 = group minima in the row direction + second best by recomputation (K1f) | 3 = two directed scans per mutual problem
  * (K1g) | 4 = group minima in both directions, class-major layouts (K1h) | 5 = K1h with the two M-tiles of a wave
  * software-pipelined against each other (K1i); identical match tables),
+ * "post_fuse" (K1h / K1i plans: the stages behind the scan -- merge of the column partials, ratio test + mutual check, stereo
+ * gates -- as ONE kernel with a workgroup per problem and the merged column keys in LDS: 0 = auto (default; = never: measured
+ * slower than the separate kernels on MI355X although it moves 0.8 GB less per 4096-pair step) | 1 = never | 2 = whenever the
+ * plan is eligible (every problem mutual, at most 4096 columns and 4096 rows); identical tables),
  * "exact_second" (K1h: 0 (default) = the index of a row's SECOND neighbour in the internal key tables is exact only where
  * it is an output (plslam_knn2_hamming256) and the column keys are completed lazily by the finalize stage | 1 = every key
  * of plslam_match_plan_dump is exact; match tables are identical either way),
@@ -207,6 +212,20 @@ int plslam_match_plan_info(plslam_match_plan* plan, plslam_plan_info* info);
  * difference that flips a ratio test shows. */
 int plslam_match_plan_dump(plslam_match_plan* plan, void* keys_out, size_t keys_cap, void* part_out,
                            size_t part_cap, size_t* keys_bytes, size_t* part_bytes);
+/* What the key table of plslam_match_plan_dump holds for THIS plan (a bit mask; 0 = every word is an exact
+ * (distance << 23 | index) key):
+ *   PLSLAM_KEYS_ROW_SECOND_INDEX_INEXACT   the INDEX of a row's second key is the first column of its (group, class), not
+ *                                          necessarily the second neighbour's (its distance is exact) -- K1h / K1i without
+ *                                          "exact_second";
+ *   PLSLAM_KEYS_COLUMN_SECOND_LAZY         a column's second key is (an upper bound of the second-best distance, index all
+ *                                          ones): the stage behind the scan completes it where a match decision needs it;
+ *   PLSLAM_KEYS_COLUMNS_NOT_IN_MEMORY      the merged column keys never reach memory (the fused stage behind the scan keeps
+ *                                          them in LDS: option "post_fuse"); the table's column rows are unspecified.
+ * Option "exact_second" = 1 at plan creation clears all three. */
+#define PLSLAM_KEYS_ROW_SECOND_INDEX_INEXACT 1
+#define PLSLAM_KEYS_COLUMN_SECOND_LAZY 2
+#define PLSLAM_KEYS_COLUMNS_NOT_IN_MEMORY 4
+int plslam_match_plan_key_state(plslam_match_plan* plan, int32_t* flags);
 void plslam_match_plan_destroy(plslam_match_plan* plan);
 
 /* ---- K14: StVO::matchGrid, the windowed ("fast_matching") matcher ------------------------------ */

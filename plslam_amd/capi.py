@@ -24,14 +24,14 @@ SCAN_AUTO, SCAN_LANE_PER_QUERY, SCAN_WAVE_PER_QUERY, SCAN_SYMMETRIC, SCAN_MFMA =
 MAX_TRAIN_ROWS = 1 << 23
 
 # every symbol include/plslam_hip.h declares (tests check the .so exports all of them)
-ABI_VERSION = 2          # include/plslam_hip.h: PLSLAM_ABI_VERSION
+ABI_VERSION = 3          # include/plslam_hip.h: PLSLAM_ABI_VERSION
 ABI_SYMBOLS = (
     "plslam_strerror", "plslam_last_error", "plslam_abi_version",
     "plslam_ctx_create", "plslam_ctx_destroy", "plslam_ctx_set_option", "plslam_ctx_get_option",
     "plslam_ctx_device_info",
     "plslam_knn2_hamming256", "plslam_match", "plslam_match_prior", "plslam_match_batched",
     "plslam_match_plan_create", "plslam_match_plan_run", "plslam_match_plan_run_split", "plslam_match_plan_set_profiling",
-    "plslam_match_plan_elapsed", "plslam_match_plan_info", "plslam_match_plan_dump", "plslam_match_plan_destroy",
+    "plslam_match_plan_elapsed", "plslam_match_plan_info", "plslam_match_plan_dump", "plslam_match_plan_key_state", "plslam_match_plan_destroy",
     "plslam_lba_point_rows", "plslam_lba_line_rows", "plslam_lba_point_rows_dev",
     "plslam_lba_line_rows_dev", "plslam_lba_assemble", "plslam_lba_plan_create", "plslam_lba_plan_iterate",
     "plslam_lba_plan_rows", "plslam_lba_plan_destroy", "plslam_lba_plan_iterate_dev", "plslam_lba_plan_device_blocks",
@@ -189,6 +189,7 @@ def load() -> C.CDLL:
     L.plslam_match_plan_info.argtypes = [vp, C.POINTER(PlanInfo)]
     L.plslam_match_plan_dump.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.POINTER(C.c_size_t),
                                          C.POINTER(C.c_size_t)]
+    L.plslam_match_plan_key_state.argtypes = [vp, C.POINTER(C.c_int32)]
     L.plslam_match_plan_destroy.argtypes = [vp]
     L.plslam_match_plan_destroy.restype = None
     L.plslam_lba_point_rows.argtypes = [vp, C.POINTER(Cam), f64, vp, i32, vp, i32, vp, vp, vp, i32,
@@ -879,6 +880,13 @@ class MatchPlan:
         i = PlanInfo()
         _check(self._L.plslam_match_plan_info(self._h, C.byref(i)), "plslam_match_plan_info")
         return {k: getattr(i, k) for k, _ in PlanInfo._fields_}
+
+    def key_state(self) -> int:
+        """What dump()'s key table holds: a mask of KEYS_ROW_SECOND_INDEX_INEXACT (1), KEYS_COLUMN_SECOND_LAZY (2),
+        KEYS_COLUMNS_NOT_IN_MEMORY (4); 0 = every word an exact key."""
+        f = C.c_int32()
+        _check(self._L.plslam_match_plan_key_state(self._h, C.byref(f)), "plslam_match_plan_key_state")
+        return f.value
 
     def dump(self):
         """Diagnostics: (keys, column_partials) as uint32 arrays, after a device synchronise."""

@@ -81,6 +81,8 @@ struct plslam_match_plan {
     bool sym_mfma_multi = false;       // ... and some of them have n2 > 2048 (multi-window instantiation)
     int mfma_form = 0;                 // ctx option "mfma_form" at plan creation (0/2 = K1f, 1 = K1e)
     bool exact_second = false;         // K1h: exact key tables (ctx option at plan creation); else the finalize kernel completes keys21 lazily
+    bool post_fused = false;           // K1h / K1i throughput plans: merge + finalize + gates in ONE kernel, a workgroup per problem (k_post_fused)
+    size_t post_lds = 0;               // ... its dynamic LDS: 8 bytes per column of the widest problem
     bool fused = false;                // K1f, one workgroup per problem: merge + ratio + mutual inside the scan kernel
     int merge_parts = 1;               // K1f: lanes per column in the partial merge (tall problems: many row blocks, few columns)
     bool col_split = false;            // K1f on a FEW LARGE problems: columns cut into ranges scanned as sub-problems
@@ -389,6 +391,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             y.flags = ctx->exact_second ? 1 : 0;
             y.a = p.d1; y.b = p.d2; y.keys12 = k12; y.keys21 = k21;
             y.part21 = d_part + 2 * part_row;
+            pd.part21 = y.part21;
             y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = (p.n1 + rpp - 1) / rpp;
             part_row += k1f ? part_units(p.n1, p.n2) : (int64_t)y.n_iblk * p.n2;
             if (P->fused) {
@@ -501,6 +504,27 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         stripe(sblocks, groups_of(sblocks, [&](const BlockDesc& b) { return scan_problem[b.item]; },
                                   [&](const BlockDesc& b) { return (int64_t)scans[b.item].nt; }));
 
+    // The stage behind the scan as ONE kernel (k_post_fused): every problem a mutual one on K1h / K1i with lazy column keys,
+    // few row blocks, columns that fit the workgroup's LDS (option "post_fuse": 0 = auto, 1 = never, 2 = whenever the plan is
+    // eligible).  AUTO does NOT select it: measured at C2 / 4096 pairs it moves 0.8 GB less per step (no merged column table
+    // written and gathered back) but takes 0.335 ms against the separate kernels' 0.276 ms, and the step 2.78 against 2.71 ms --
+    // a workgroup per problem is a chain of round trips (partials -> LDS -> rows -> gates) with 2 048 problems in flight,
+    // where the separate kernels keep 8x as many independent lanes busy; the scan leaves no free registers beside it
+    // (3 x 168 of 512 per lane), so whatever runs behind it displaces scan workgroups one for one and only its own
+    // duration counts.
+    {
+        bool ok = h_parts && !P->exact_second && !P->col_split && ctx->post_fuse != 1 && nprob > 0 && scans.empty() && dirs.empty() &&
+                  (int32_t)syms.size() == nprob;
+        int32_t max_n2 = 0;
+        for (int32_t i = 0; ok && i < nprob; ++i) {
+            ok = pds[i].lazy21 && pds[i].nsplit <= 1 && pds[i].part21 != nullptr && probs[i].n2 <= POST_FUSED_MAX_N2 &&
+                 (probs[i].n1 + 255) / 256 <= POST_FUSED_MAX_ROW_BLOCKS;
+            max_n2 = std::max(max_n2, probs[i].n2);
+        }
+        ok = ok && ctx->post_fuse == 2;
+        P->post_fused = ok;
+        P->post_lds = ok ? sizeof(uint32_t) * 2 * (size_t)((max_n2 + 63) & ~63) : 0;
+    }
     P->nscan = (int32_t)scans.size();
     P->nscan_blocks = (int32_t)sblocks.size();
     P->nfin_blocks = (int32_t)fblocks.size();
@@ -641,6 +665,11 @@ static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
         s = sp;
     }
 
+    if (P->post_fused) {
+        if (P->ngates > 0 && P->d_gate_counts) PLSLAM_HIP_CHECK(hipMemsetAsync(P->d_gate_counts, 0, sizeof(int32_t) * (size_t)P->ngates, s));
+        r = launch_post_fused(P->d_probs, P->nprob, P->ngates > 0 ? P->d_gates : nullptr, P->post_lds, s);
+        if (r) return r;
+    } else {
     r = P->sym_mfma && mfma_form_is_h(P->mfma_form) && !P->fused
             ? launch_merge_fix16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, P->exact_second, s, split ? P->ctx->post_workgroups : 0)
             : P->sym_mfma && P->mfma_form != 1 ? launch_merge_partials16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, s)
@@ -650,6 +679,7 @@ static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
     if (P->ngates > 0 && P->d_gate_counts) PLSLAM_HIP_CHECK(hipMemsetAsync(P->d_gate_counts, 0, sizeof(int32_t) * (size_t)P->ngates, s));
     r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, P->ngates > 0 ? P->d_gates : nullptr, s, split ? P->ctx->post_workgroups : 0);
     if (r) return r;
+    }
     if (P->ngate_blocks > 0) {
         r = launch_stereo_gates(P->d_gates, P->d_gate_blocks, P->ngate_blocks, s);
         if (r) return r;
@@ -781,6 +811,11 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         ctx->fuse = value;
         return PLSLAM_OK;
     }
+    if (!strcmp(key, "post_fuse")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= 2, PLSLAM_EINVAL);
+        ctx->post_fuse = value;
+        return PLSLAM_OK;
+    }
     if (!strcmp(key, "exact_second")) {
         PLSLAM_REQUIRE(value >= 0 && value <= 1, PLSLAM_EINVAL);
         ctx->exact_second = value;
@@ -813,6 +848,7 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "sym_rows")) { *value = ctx->sym_rows; return PLSLAM_OK; }
     if (!strcmp(key, "group_cap")) { *value = ctx->group_cap; return PLSLAM_OK; }
     if (!strcmp(key, "mfma_form")) { *value = ctx->mfma_form; return PLSLAM_OK; }
+    if (!strcmp(key, "post_fuse")) { *value = ctx->post_fuse; return PLSLAM_OK; }
     if (!strcmp(key, "fuse")) { *value = ctx->fuse; return PLSLAM_OK; }
     if (!strcmp(key, "col_split")) { *value = ctx->col_split; return PLSLAM_OK; }
     if (!strcmp(key, "exact_second")) { *value = ctx->exact_second; return PLSLAM_OK; }
@@ -862,46 +898,53 @@ int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_ste
 {
     PLSLAM_REQUIRE(plan != nullptr && ngates >= 0 && (ngates == 0 || gates != nullptr), PLSLAM_EINVAL);
     DeviceGuard g(plan->ctx->device);
-    // replacing the stage frees / rewrites the tables a run still in flight (on whatever stream the caller used) reads: the
-    // call is rare, so it simply waits for the device
-    if (plan->ngate_blocks > 0 || plan->gate_tables.p) PLSLAM_HIP_CHECK(hipDeviceSynchronize());
-    if (plan->graph_exec) { PLSLAM_HIP_CHECK(hipDeviceSynchronize()); plan->drop_graph(); }      // the captured run has no gate stage
-    plan->ngate_blocks = 0;
-    plan->ngates = 0;
-    plan->d_gate_counts = nullptr;
-    if (ngates == 0) {
-        bool any = false;
-        for (ProblemDesc& pd : plan->h_probs) { any = any || pd.gate >= 0; pd.gate = -1; }
-        if (any) {
-            PLSLAM_HIP_CHECK(hipMemcpyAsync(plan->d_probs, plan->h_probs.data(), plan->h_probs.size() * sizeof(ProblemDesc),
-                                            plan->probs_in_place ? hipMemcpyHostToHost : hipMemcpyHostToDevice, plan->ctx->stream));
-            PLSLAM_HIP_CHECK(hipStreamSynchronize(plan->ctx->stream));
-        }
-        return PLSLAM_OK;
-    }
-    std::vector<BlockDesc> blocks;
-    bool any_cnt = false, all_cnt = true;
+    // ---- validation first: nothing of the plan is touched until the whole request is known to be good -----------------
     // a gate whose input table is the matches_12 of one of the plan's problems (the usual case: the L<->R tables of the
     // batch) is applied by the finalize kernel itself, row by row, the moment the entry is decided (ProblemDesc::gate);
     // any other gate -- and every gate of a fused plan, which has no finalize kernel -- keeps its own workgroups
-    for (ProblemDesc& pd : plan->h_probs) pd.gate = -1;
+    std::vector<BlockDesc> blocks;
+    std::vector<int32_t> gate_of(plan->h_probs.size(), -1);
+    bool any_cnt = false, all_cnt = true;
     for (int32_t i = 0; i < ngates; ++i) {
         const int rc = check_stereo_gate_problem(gates[i]);
         if (rc) return rc;
         any_cnt = any_cnt || gates[i].n_stereo != nullptr;
         all_cnt = all_cnt && gates[i].n_stereo != nullptr && gates[i].n_stereo == gates[0].n_stereo + i;
-        bool fused_into_finalize = false;
+        bool in_finalize = false;
         if (!plan->fused && gates[i].n_l > 0)
-            for (ProblemDesc& pd : plan->h_probs)
-                if (pd.matches_12 == gates[i].matches_12 && pd.n1 == gates[i].n_l && pd.gate < 0) {
-                    pd.gate = i;
-                    fused_into_finalize = true;
+            for (size_t k = 0; k < plan->h_probs.size(); ++k) {
+                const ProblemDesc& pd = plan->h_probs[k];
+                if (pd.matches_12 == gates[i].matches_12 && pd.n1 == gates[i].n_l && gate_of[k] < 0) {
+                    gate_of[k] = i;
+                    in_finalize = true;
                     break;
                 }
-        if (!fused_into_finalize)
+            }
+        if (!in_finalize)
             for (int32_t r0 = 0; r0 < gates[i].n_l; r0 += 256) blocks.push_back({i, r0});
     }
     PLSLAM_REQUIRE(!any_cnt || all_cnt, PLSLAM_EINVAL);     // counters: none, or one contiguous array
+    // ---- the stage is replaced: its tables and the problem table (ProblemDesc::gate) are rewritten under whatever run is
+    // still in flight on whatever stream the caller used -- the call is rare, so it simply waits for the device ------------
+    PLSLAM_HIP_CHECK(hipDeviceSynchronize());
+    if (plan->graph_exec) plan->drop_graph();               // the captured run has another gate stage
+    // from here on every exit leaves the plan consistent: first the state "no gate stage" (host image AND device table) ...
+    plan->ngate_blocks = 0;
+    plan->ngates = 0;
+    plan->d_gate_counts = nullptr;
+    plan->d_gates = nullptr;
+    auto upload_probs = [&]() -> int {
+        if (plan->h_probs.empty()) return PLSLAM_OK;
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(plan->d_probs, plan->h_probs.data(), plan->h_probs.size() * sizeof(ProblemDesc),
+                                        plan->probs_in_place ? hipMemcpyHostToHost : hipMemcpyHostToDevice, plan->ctx->stream));
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(plan->ctx->stream));
+        return PLSLAM_OK;
+    };
+    bool had = false;
+    for (ProblemDesc& pd : plan->h_probs) { had = had || pd.gate >= 0; pd.gate = -1; }
+    if (had) { const int rc = upload_probs(); if (rc) return rc; }
+    if (ngates == 0) return PLSLAM_OK;
+    // ... then the new stage: its tables first (a failed allocation returns with the consistent "no gate stage" above) ...
     const size_t gbytes = ((size_t)ngates * sizeof(plslam_stereo_gate_problem) + 255) & ~size_t(255);
     const size_t total = gbytes + blocks.size() * sizeof(BlockDesc) + 256;
     plan->gate_staging.assign(total, 0);
@@ -911,11 +954,16 @@ int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_ste
     if (r) return r;
     PLSLAM_HIP_CHECK(hipMemcpyAsync(plan->gate_tables.p, plan->gate_staging.data(), total, hipMemcpyHostToDevice,
                                     plan->ctx->stream));
-    // the problem table with its gate indices (the page-locked image is the table itself when the kernels read it in place)
-    if (!plan->h_probs.empty())
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(plan->d_probs, plan->h_probs.data(), plan->h_probs.size() * sizeof(ProblemDesc),
-                                        plan->probs_in_place ? hipMemcpyHostToHost : hipMemcpyHostToDevice, plan->ctx->stream));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(plan->ctx->stream));
+    // ... and, last, the gate indices of the problem table together with the counters that make a run use them: a failure of
+    // the upload puts the indices back (the device table then still holds -1 everywhere or is rewritten in full next time)
+    for (size_t k = 0; k < plan->h_probs.size(); ++k) plan->h_probs[k].gate = gate_of[k];
+    r = upload_probs();
+    if (r) {
+        for (ProblemDesc& pd : plan->h_probs) pd.gate = -1;
+        (void)upload_probs();
+        return r;
+    }
     plan->d_gates = plan->gate_tables.as<plslam_stereo_gate_problem>();
     plan->d_gate_blocks = reinterpret_cast<BlockDesc*>(plan->gate_tables.as<char>() + gbytes);
     plan->ngate_blocks = (int32_t)blocks.size();
@@ -1028,6 +1076,15 @@ void plslam_match_plan_destroy(plslam_match_plan* plan)
 }
 
 // ---- host-pointer matching -------------------------------------------------------------------
+int plslam_match_plan_key_state(plslam_match_plan* plan, int32_t* flags)
+{
+    if (!plan || !flags) return PLSLAM_EINVAL;
+    const bool h = plan->sym_mfma && mfma_form_is_h(plan->mfma_form) && !plan->fused;
+    *flags = (h && !plan->exact_second ? PLSLAM_KEYS_ROW_SECOND_INDEX_INEXACT | PLSLAM_KEYS_COLUMN_SECOND_LAZY : 0) |
+             (plan->post_fused ? PLSLAM_KEYS_COLUMNS_NOT_IN_MEMORY : 0);
+    return PLSLAM_OK;
+}
+
 int plslam_match_batched(plslam_ctx* ctx, const uint8_t* d1, const int32_t* off1,
                          const uint8_t* d2, const int32_t* off2, int32_t B, float nnr, int mutual,
                          int32_t* matches_12, int32_t* n_matches)

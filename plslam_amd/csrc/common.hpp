@@ -127,6 +127,7 @@ struct plslam_ctx {
     int exact_second = 0; // K1h: 1 = the index of every second-best row key is exact (0: only where it is an output -- knnMatch)
     int graph = 1;             // plslam_match_plan_run as a replayed HIP graph: 0 = latency plans, 1 = never (default until measured), 2 = always
     int post_workgroups = 0;   // > 0: the stages behind a scan (merge of K1h's partials, finalize) run as at most this many workgroups walking their block tables
+    int post_fuse = 0;   // K1h / K1i plans: merge + finalize + gates behind the scan as ONE kernel: 0 = auto (throughput plans), 1 = never, 2 = whenever eligible
     int fuse = 0;        // K1f: 0 = auto (one workgroup per problem incl. merge + finalize when the plan is large), 1 = never, 2 = always
     std::mutex mu;       // serialises the host-pointer entry points
     plslam::DevBuf in_a, in_b, out_a, out_b, misc_a, misc_b, misc_c;
@@ -216,6 +217,9 @@ struct ProblemDesc {    // one StVO::match problem = scan12 (+ scan21 when mutua
     // index of the stereo-gate problem that consumes this table (plslam_match_plan_add_stereo_gates), or -1: the finalize
     // kernel applies the gate to a row's match the moment it is decided -- no second launch, no second pass over the table
     int32_t gate, pad2;
+    // K1h / K1i plans with the fused stage behind the scan (k_post_fused): the problem's column partials -- [row block][slot]
+    // words, SymDesc::part21 -- or nullptr
+    const uint32_t* part21;
 };
 
 struct BlockDesc {      // one workgroup's slice of a scan / problem
@@ -228,6 +232,12 @@ int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const Sca
                 const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero, hipStream_t s);
 int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int nblocks,
                     const plslam_stereo_gate_problem* d_gates, hipStream_t s, int grid_cap = 0);
+// K2' (hamming.hip): merge of K1h's / K1i's column partials + finalize + gates, one workgroup per problem; lds_bytes = 8 x the
+// largest n2 of the plan
+constexpr int POST_FUSED_MAX_N2 = 4096;
+constexpr int POST_FUSED_MAX_ROW_BLOCKS = 16;
+int launch_post_fused(const ProblemDesc* d_probs, int nprob, const plslam_stereo_gate_problem* d_gates, size_t lds_bytes,
+                      hipStream_t s);
 int launch_scatter_counts(const int32_t* d_src, int32_t* const* d_dst, int32_t n, hipStream_t s);
 int launch_unpack_keys(const uint32_t* d_keys, int32_t n, int32_t* d_idx, int32_t* d_dist,
                        hipStream_t s);

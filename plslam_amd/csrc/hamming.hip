@@ -546,15 +546,14 @@ __device__ __forceinline__ int ratio_pick(uint32_t k0, uint32_t k1, float nnr)
 #ifndef PLSLAM_NT_FINALIZE
 #define PLSLAM_NT_FINALIZE 1
 #endif
-__global__ void __launch_bounds__(256)
-k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ blocks,
-           const plslam_stereo_gate_problem* __restrict__ gates, int nblocks)
+// One row of a problem: ratio test on its scan result, the mutual check against the candidate column's pair kb = fetch_kb(m)
+// (K1h / K1i plans: completed lazily, see below), the table entry, the count and the stereo gate.  EVERY lane of the workgroup
+// calls it (DPP row rotations inside); the workgroup's 256 lanes are 256 consecutive rows starting at a multiple of 16.
+// `pre`: the row's pair of keys12 if the caller has loaded it already (problems that are not column-split), else nullptr.
+template <class FetchKb>
+__device__ __forceinline__ void finalize_row(const ProblemDesc& p, const int i1, const plslam_stereo_gate_problem* __restrict__ gates,
+                                             FetchKb fetch_kb, const gvec2_t* pre = nullptr)
 {
-  // (a capped grid walks the block table: plslam_ctx option "post_workgroups")
-  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
-    const BlockDesc bd = blocks[blk];
-    const ProblemDesc p = probs[bd.item];
-    const int i1 = bd.row0 + (int)threadIdx.x;
     int m = -1;
     bool accepted = false, cleared = false;
     uint2 k = make_uint2(KEY_NONE, KEY_NONE);            // this row's scan result (rows past n1: none)
@@ -573,6 +572,8 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
             }
             k = make_uint2(b0, b1);
             g_(reinterpret_cast<gvec2_t*>(p.keys12_out))[i1] = gvec2_t{k.x, k.y};          // diagnostics (plslam_match_plan_dump)
+        } else if (pre) {
+            k = make_uint2(pre->x, pre->y);
         } else {
             // (read once: non-temporal, like the table written below -- they must not push the scan's rows out of L2)
             const gvec2_t kv = PLSLAM_NT_FINALIZE ? __builtin_nontemporal_load(g_(reinterpret_cast<const gvec2_t*>(p.keys12)) + i1)
@@ -587,7 +588,7 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
         if (!accepted && p.keep_prior) m = g_(p.matches_12)[i1];
         if (m >= 0 && p.mutual) {
             check = m < p.n2;
-            if (check) { const gvec2_t kv = g_(reinterpret_cast<const gvec2_t*>(p.keys21))[m]; kb = make_uint2(kv.x, kv.y); }
+            if (check) kb = fetch_kb(m);
             else { m = -1; cleared = true; }
         }
     }
@@ -658,14 +659,99 @@ k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ 
         const int delta = (int)__popcll(__ballot(accepted)) - (int)__popcll(__ballot(cleared));
         if ((threadIdx.x & 63) == 0 && delta) (void)atomic_add_global(p.n_matches, delta);
     }
-    if (p.gate >= 0) {
+    if (gates && p.gate >= 0) {           // (a plan without a gate stage passes no table: never read through a stale index)
         // StereoFrame's gate over this L<->R table (stereo_gates_dev.hpp), on the entry just decided
         const plslam_stereo_gate_problem q = gates[p.gate];
         const int kept = i1 < p.n1 ? stereo_gate_row(q, i1, m) : 0;
         const unsigned long long bal = __ballot(kept);
         if (q.n_stereo && (threadIdx.x & 63) == 0 && bal) (void)atomic_add_global(q.n_stereo, (int)__popcll(bal));
     }
+}
+
+__global__ void __launch_bounds__(256)
+k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ blocks,
+           const plslam_stereo_gate_problem* __restrict__ gates, int nblocks)
+{
+  // (a capped grid walks the block table: plslam_ctx option "post_workgroups")
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const BlockDesc bd = blocks[blk];
+    const ProblemDesc p = probs[bd.item];
+    finalize_row(p, bd.row0 + (int)threadIdx.x, gates, [&](int m) {
+        const gvec2_t kv = g_(reinterpret_cast<const gvec2_t*>(p.keys21))[m];
+        return make_uint2(kv.x, kv.y);
+    });
   }
+}
+
+// K2'  everything behind a K1h / K1i scan in ONE kernel, one workgroup per problem: the column partials of the problem's <= 16
+// row blocks are merged into LDS (what k_merge_fix16<1, false> writes to keys21: best row, distance of the best row outside
+// its group of 16), then the problem's rows are finalized from there (+ gates).  No merged column table in HBM: the separate
+// kernels write it once (8 B per column) and gather it back through up to six L2s with 8-byte reads (round 3 PMC: 1.0 GB
+// fetched to write 0.16 GB).  Throughput plans only (plan_build: every problem mutual, on K1h / K1i, n2 <= POST_FUSED_MAX_N2,
+// lazy keys): a plan of a few large problems has too few workgroups for this.
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_post_fused(const ProblemDesc* __restrict__ probs, const plslam_stereo_gate_problem* __restrict__ gates, int nprob)
+{
+    extern __shared__ __attribute__((aligned(16))) uint2 kb_lds[];           // [n2]: the merged pair of every column
+    for (int pi = blockIdx.x; pi < nprob; pi += gridDim.x) {
+        const ProblemDesc p = probs[pi];
+        const MhLayout L(p.n2);
+        const int nwb = (p.n1 + 255) >> 8, n2p = L.slots_padded(), nslots = 32 * L.ntiles;
+        const auto part = g_(p.part21);
+        if (pi != (int)blockIdx.x) __syncthreads();        // the problem before: every lane is past its reads of kb_lds
+        // the first 256 rows of keys12 now: their latency passes under the merge
+        const auto k12 = g_(reinterpret_cast<const gvec2_t*>(p.keys12));
+        gvec2_t kcur = gvec2_t{KEY_NONE, KEY_NONE};
+        if ((int)threadIdx.x < p.n1) kcur = __builtin_nontemporal_load(k12 + threadIdx.x);
+        // merge: a lane takes slots 256 apart, PF at a time (their nwb words each are requested together: one round trip)
+        constexpr int PF = NT >= 1024 ? 2 : 4;
+        for (int s0_ = (int)threadIdx.x; s0_ < nslots; s0_ += NT * PF) {
+            uint32_t b0[PF], b1[PF], sx[PF];
+            int j[PF];
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                const int slot = s0_ + NT * q;
+                j[q] = slot < nslots ? L.row_of(slot >> 5, slot & 31) : p.n2;
+                b0[q] = b1[q] = KEY_NONE;
+                sx[q] = 0xFFFFFFFFu;
+            }
+            for (int wb = 0; wb < nwb; ++wb) {
+                uint32_t e[PF];
+#pragma unroll
+                for (int q = 0; q < PF; ++q) e[q] = j[q] < p.n2 ? __builtin_nontemporal_load(&part[(size_t)wb * n2p + s0_ + NT * q]) : 0xFFFFFFFFu;
+#pragma unroll
+                for (int q = 0; q < PF; ++q) {
+                    const uint32_t e0 = e[q] >> 9, e1 = ((e[q] & 511u) << 8) | 255u;     // (d0 << 8 | row0), the second entry's distance
+                    const uint32_t k = ((e0 >> 8) << KEY_IDX_BITS) | ((e0 & 255u) + 256u * (uint32_t)wb);
+                    sx[q] = k < b0[q] ? e1 : sx[q];
+                    b1[q] = umin(b1[q], umax(b0[q], k));
+                    b0[q] = umin(b0[q], k);
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < PF; ++q) {
+                if (j[q] >= p.n2) continue;                // the slot holds no column
+                if (b0[q] < (257u << KEY_IDX_BITS)) {
+                    b1[q] = umin(b1[q], ((sx[q] >> 8) << KEY_IDX_BITS) | KEY_IDX_MASK);
+                    if (b1[q] >= (257u << KEY_IDX_BITS)) b1[q] = KEY_NONE;
+                } else {
+                    b0[q] = b1[q] = KEY_NONE;
+                }
+                kb_lds[j[q]] = make_uint2(b0[q], b1[q]);
+            }
+        }
+        __syncthreads();
+        // rows: the next block's keys are requested before this block's are consumed
+#pragma unroll 1
+        for (int r0 = 0; r0 < p.n1; r0 += NT) {
+            const int inext = r0 + NT + (int)threadIdx.x;
+            gvec2_t knext = gvec2_t{KEY_NONE, KEY_NONE};
+            if (inext < p.n1) knext = __builtin_nontemporal_load(k12 + inext);
+            finalize_row(p, r0 + (int)threadIdx.x, gates, [&](int m) { return kb_lds[m]; }, &kcur);
+            kcur = knext;
+        }
+    }
 }
 
 // copies the per-problem counters to caller pointers that are not one contiguous array
@@ -750,6 +836,21 @@ int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int n
 {
     if (nblocks <= 0) return PLSLAM_OK;
     hipLaunchKernelGGL(k_merge_partials, dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+#ifndef PLSLAM_POST_FUSED_THREADS
+#define PLSLAM_POST_FUSED_THREADS 256
+#endif
+constexpr int POST_FUSED_THREADS = PLSLAM_POST_FUSED_THREADS;
+int launch_post_fused(const ProblemDesc* d_probs, int nprob, const plslam_stereo_gate_problem* d_gates, size_t lds_bytes,
+                      hipStream_t s)
+{
+    if (nprob <= 0) return PLSLAM_OK;
+    // (measured per 16 384-problem step at C2, exclusive: this kernel with 256 lanes per problem 0.335 ms, with 1024 lanes
+    // 0.65 ms, the separate merge + finalize kernels 0.276 ms -- see capi.hip plan_build, option "post_fuse")
+    hipLaunchKernelGGL(k_post_fused<POST_FUSED_THREADS>, dim3(nprob), dim3(POST_FUSED_THREADS), lds_bytes, s, d_probs, d_gates, nprob);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

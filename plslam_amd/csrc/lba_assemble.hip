@@ -16,10 +16,11 @@
 //                                first, then lines, list order; 64-observation chunks)
 //   K10 k_weighted_error_*      err = sum r^2 w (fixed-shape two-level tree: deterministic, not sequential)
 #include <algorithm>
+#include <cstring>
 #include <new>
 #include <vector>
 
-#include "common.hpp"
+#include "lba_rows_dev.hpp"
 
 namespace plslam {
 
@@ -198,6 +199,203 @@ k_weighted_error_final(double* __restrict__ err)
     if (threadIdx.x == 0) err[0] = red[0];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The iteration of an LBA plan in THREE launches (round 4; round 3: ten launches of 4-13 us each, i.e. launch granularity):
+//   F1 k_lba_rows_cross   one lane per observation (points, then lines): the row (K3 / K4), its cross block (K8) from the
+//                         values still in registers, and the workgroup's share of err = sum r^2 w
+//   F2 k_lba_blocks       workgroups [0, nb3): point landmark blocks (K7<3>); [.., +nb6): line landmark blocks (K7<6>); the
+//                         rest: the keyframes' chunk partials (K9, four 64-lane chunks per workgroup)
+//   F3 k_lba_finish       workgroup k < nkf: keyframe k's blocks from its chunk partials (K9); workgroup nkf: err
+// Every block keeps the summation ORDER of the separate kernels (landmark and cross blocks: the reference's, bit for bit;
+// keyframe blocks: chunks of 64 observations in list order, then the chunks in order); err is the sum of the row workgroups'
+// trees in workgroup order -- a fixed shape, deterministic, equal to the reference's sequential sum up to rounding.
+// ---------------------------------------------------------------------------------------------------------------------
+struct LbaIterArgs {
+    CamD K;
+    double th;
+    int32_t compat_iter, transpose_ls_cross;
+    const double *T, *Xw, *Lw, *uv, *lobs;
+    const int32_t *pt_lm, *pt_slot, *pt_kf_loc, *ls_lm, *ls_slot, *ls_kf_loc;
+    int32_t np, nl, nbp, nbl;                 // observations and row workgroups (points, lines)
+    double *pJp, *pJl, *pr, *pw, *lJp, *lJl, *lr, *lw, *Wp, *Wl, *err_part;   // err_part[nbp + nbl]
+};
+
+__global__ void __launch_bounds__(256)
+k_lba_rows_cross(const LbaIterArgs A)
+{
+    __shared__ __attribute__((aligned(16))) double slabs[4][64 * 6];
+    __shared__ double red[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool lines = (int)blockIdx.x >= A.nbp;
+    const int nobs = lines ? A.nl : A.np;
+    const int o = (lines ? (int)blockIdx.x - A.nbp : (int)blockIdx.x) * 256 + (int)threadIdx.x;
+    const int o0 = o - lane;
+    double e2w = 0.0;
+    if (o0 < nobs) {                                         // (wave-uniform)
+        const int valid = nobs - o0 < 64 ? nobs - o0 : 64;
+        const int oc = o < nobs ? o : nobs - 1;              // tail lanes recompute the last row
+        double nrm, wgt;
+        if (!lines) {
+            double out6[6], out3[3];
+            point_row(A.K, A.th, A.T + 16 * (size_t)A.pt_slot[oc], A.Xw + 3 * (size_t)A.pt_lm[oc],
+                      reinterpret_cast<const double2*>(A.uv)[oc], out6, out3, nrm, wgt);
+            wave_store_rows<6>(A.pJp + 6 * (size_t)o0, out6, slabs[wave], lane, valid);
+            wave_store_rows<3>(A.pJl + 3 * (size_t)o0, out3, slabs[wave], lane, valid);
+            if (o < nobs) {
+                A.pr[o] = nrm;
+                A.pw[o] = wgt;
+                const bool opt = A.pt_kf_loc[o] >= 0;          // kf_loc == -1: the keyframe is not optimised, no cross block
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) A.Wp[((size_t)o * 3 + a) * 6 + b] = opt ? out3[a] * out6[b] * wgt : 0.0;
+            }
+        } else {
+            double outl[6], outp[6];
+            const size_t l0 = (size_t)A.ls_lm[oc];
+            const double* Pw = A.compat_iter ? A.Lw + 3 * l0 : A.Lw + 6 * l0;
+            const double* Qw = A.compat_iter ? A.Lw + 3 * l0 : A.Lw + 6 * l0 + 3;
+            line_row(A.K, A.th, A.T + 16 * (size_t)A.ls_slot[oc], Pw, Qw, A.lobs[3 * (size_t)oc], A.lobs[3 * (size_t)oc + 1],
+                     A.lobs[3 * (size_t)oc + 2], outl, outp, nrm, wgt);
+            wave_store_rows<6>(A.lJl + 6 * (size_t)o0, outl, slabs[wave], lane, valid);
+            wave_store_rows<6>(A.lJp + 6 * (size_t)o0, outp, slabs[wave], lane, valid);
+            if (o < nobs) {
+                A.lr[o] = nrm;
+                A.lw[o] = wgt;
+                const bool opt = A.ls_kf_loc[o] >= 0;
+#pragma unroll
+                for (int a = 0; a < 6; ++a)
+#pragma unroll
+                    for (int b = 0; b < 6; ++b)
+                        A.Wl[A.transpose_ls_cross ? ((size_t)o * 6 + b) * 6 + a : ((size_t)o * 6 + a) * 6 + b] = opt ? outl[a] * outp[b] * wgt : 0.0;
+            }
+        }
+        if (o < nobs) e2w = nrm * nrm * wgt;
+    }
+    red[threadIdx.x] = e2w;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) A.err_part[blockIdx.x] = red[0];
+}
+
+template <int DL>
+__device__ __forceinline__ void landmark_block(int l, int32_t nlm, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_obs,
+                                               const double* __restrict__ Jl, const double* __restrict__ r, const double* __restrict__ w,
+                                               double* __restrict__ Hll, double* __restrict__ gl)
+{
+    if (l >= nlm) return;
+    double H[DL * DL], g[DL];
+#pragma unroll
+    for (int i = 0; i < DL * DL; ++i) H[i] = 0.0;
+#pragma unroll
+    for (int i = 0; i < DL; ++i) g[i] = 0.0;
+    for (int k = lm_ptr[l]; k < lm_ptr[l + 1]; ++k) {
+        const int o = lm_obs[k];
+        double J[DL];
+#pragma unroll
+        for (int a = 0; a < DL; ++a) J[a] = Jl[(size_t)o * DL + a];
+        const double rr = r[o], ww = w[o];
+#pragma unroll
+        for (int a = 0; a < DL; ++a) g[a] += J[a] * rr * ww;
+#pragma unroll
+        for (int a = 0; a < DL; ++a)
+#pragma unroll
+            for (int b = 0; b < DL; ++b) H[a * DL + b] += J[a] * J[b] * ww;
+    }
+#pragma unroll
+    for (int i = 0; i < DL * DL; ++i) Hll[(size_t)l * DL * DL + i] = H[i];
+#pragma unroll
+    for (int i = 0; i < DL; ++i) gl[(size_t)l * DL + i] = g[i];
+}
+
+struct LbaBlockArgs {
+    const int32_t *pt_ptr, *pt_ids, *ls_ptr, *ls_ids, *kf_ptr, *kf_ids;
+    const double *pJp, *pJl, *pr, *pw, *lJp, *lJl, *lr, *lw;
+    double *H_pt, *g_pt, *H_ls, *g_ls, *pose_part, *H_pose, *g_pose, *err;
+    const double* err_part;
+    int32_t npt, nls, nkf, np, nb3, nb6, max_chunks, nerr;
+};
+
+__global__ void __launch_bounds__(256)
+k_lba_blocks(const LbaBlockArgs A)
+{
+    const int b = blockIdx.x;
+    if (b < A.nb3) {
+        landmark_block<3>(b * 256 + (int)threadIdx.x, A.npt, A.pt_ptr, A.pt_ids, A.pJl, A.pr, A.pw, A.H_pt, A.g_pt);
+    } else if (b < A.nb3 + A.nb6) {
+        landmark_block<6>((b - A.nb3) * 256 + (int)threadIdx.x, A.nls, A.ls_ptr, A.ls_ids, A.lJl, A.lr, A.lw, A.H_ls, A.g_ls);
+    } else {
+        // chunk partials of the keyframes (K9): item = keyframe * max_chunks + chunk, one wave per item, lane e < 42 an entry
+        const int item = (b - A.nb3 - A.nb6) * 4 + ((int)threadIdx.x >> 6), e = (int)threadIdx.x & 63;
+        if (item >= A.nkf * A.max_chunks || e >= 42) return;
+        const int k = item / A.max_chunks, c = item - k * A.max_chunks;
+        const int beg = A.kf_ptr[k] + c * POSE_CHUNK;
+        const int end = beg + POSE_CHUNK < A.kf_ptr[k + 1] ? beg + POSE_CHUNK : A.kf_ptr[k + 1];
+        const int a = e < 36 ? e / 6 : e - 36, bb = e < 36 ? e % 6 : 0;
+        double acc = 0.0;
+        constexpr int PB = 16;
+        for (int i0 = beg; i0 < end; i0 += PB) {
+            int oo[PB];
+            bool pt[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const int o = A.kf_ids[i0 + j < end ? i0 + j : end - 1];
+                pt[j] = o < A.np;
+                oo[j] = pt[j] ? o : o - A.np;
+            }
+            double ja[PB], jb[PB], ww[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) {
+                const double* J = (pt[j] ? A.pJp : A.lJp) + (size_t)oo[j] * 6;
+                ja[j] = J[a];
+                jb[j] = e < 36 ? J[bb] : (pt[j] ? A.pr : A.lr)[oo[j]];
+                ww[j] = (pt[j] ? A.pw : A.lw)[oo[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < PB; ++j)
+                if (i0 + j < end) acc += ja[j] * jb[j] * ww[j];
+        }
+        A.pose_part[((size_t)k * A.max_chunks + c) * 42 + e] = acc;   // empty chunks write 0
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_lba_finish(const LbaBlockArgs A)
+{
+    const int k = blockIdx.x, e = threadIdx.x;
+    if (k < A.nkf) {
+        if (e >= 42) return;
+        const int nchunks = (A.kf_ptr[k + 1] - A.kf_ptr[k] + POSE_CHUNK - 1) / POSE_CHUNK;
+        double acc = 0.0;
+        constexpr int PB = 8;
+        for (int c0 = 0; c0 < nchunks; c0 += PB) {
+            double v[PB];
+#pragma unroll
+            for (int j = 0; j < PB; ++j) v[j] = A.pose_part[((size_t)k * A.max_chunks + (c0 + j < nchunks ? c0 + j : nchunks - 1)) * 42 + e];
+#pragma unroll
+            for (int j = 0; j < PB; ++j)
+                if (c0 + j < nchunks) acc += v[j];
+        }
+        if (e < 36) A.H_pose[(size_t)k * 36 + e] = acc;
+        else A.g_pose[(size_t)k * 6 + (e - 36)] = acc;
+        return;
+    }
+    // err: lane e sums the row workgroups' partials e, e + 256, ... in that order, then a tree over the lanes
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = e; i < A.nerr; i += 256) acc += A.err_part[i];
+    red[e] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (e < s) red[e] += red[e + s];
+        __syncthreads();
+    }
+    if (e == 0) A.err[0] = red[0];
+}
+
 namespace {
 struct Carve {
     size_t off = 0;
@@ -304,8 +502,12 @@ struct plslam_lba_plan {
            oLsp = 0, oLsi = 0, oKfp = 0, oKfi = 0;
     size_t oT = 0, oX = 0, oL = 0;
     size_t oPJp = 0, oPJl = 0, oPr = 0, oPw = 0, oLJp = 0, oLJl = 0, oLr = 0, oLw = 0;
-    size_t oG = 0, oHp = 0, oHpt = 0, oHls = 0, oWp = 0, oWl = 0, oErr = 0, oPart = 0;
+    size_t oG = 0, oHp = 0, oHpt = 0, oHls = 0, oWp = 0, oWl = 0, oErr = 0, oPart = 0, oErrPart = 0;
     int32_t max_chunks = 0;
+    // one iteration = one upload, three launches, one download: the poses and landmarks are packed into a page-locked image
+    // of `dyn` (ONE copy instead of three from pageable memory), err sits right behind g (ONE copy back)
+    HostBuf pin_in, pin_out;
+    size_t dyn_bytes = 0;
 };
 
 extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, double homog_th, int32_t n_pose_slots,
@@ -347,13 +549,16 @@ extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, doub
     Carve co;
     P->oG = co.take(N * 8 + 8); P->oHp = co.take((size_t)nkf * 288 + 8); P->oHpt = co.take((size_t)npt * 72 + 8);
     P->oHls = co.take((size_t)nls * 288 + 8); P->oWp = co.take(np * 144 + 8); P->oWl = co.take(nl * 288 + 8);
-    P->oErr = co.take(8 * (1 + ERR_BLOCKS));      // err, then the workgroups' partial sums
+    P->oErr = P->oG + N * 8;                      // err: the double right behind g (one copy brings both back)
+    P->oErrPart = co.take(8 * ((np + 255) / 256 + (nl + 255) / 256) + 8);      // the row workgroups' partial sums of err
     P->max_chunks = pose_max_chunks(c.kfp);
     P->oPart = co.take((size_t)nkf * (size_t)P->max_chunks * 42 * 8 + 8);
     int rc;
+    P->dyn_bytes = cd.off;
     if ((rc = P->stat.reserve(cs.off + 256)) || (rc = P->dyn.reserve(cd.off + 256)) ||
-        (rc = P->rows.reserve(cr.off + 256)) || (rc = P->out.reserve(co.off + 256))) {
-        P->stat.release(); P->dyn.release(); P->rows.release(); P->out.release();
+        (rc = P->rows.reserve(cr.off + 256)) || (rc = P->out.reserve(co.off + 256)) ||
+        (rc = P->pin_in.reserve(cd.off + 256)) || (rc = P->pin_out.reserve(N * 8 + 256))) {
+        P->stat.release(); P->dyn.release(); P->rows.release(); P->out.release(); P->pin_in.release(); P->pin_out.release();
         delete P;
         return rc;
     }
@@ -374,7 +579,7 @@ extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, doub
         (rc = up(P->oKfp, c.kfp.data(), c.kfp.size() * 4)) || (rc = up(P->oKfi, c.kfi.data(), c.kfi.size() * 4)) ||
         (hipStreamSynchronize(s) != hipSuccess && (rc = PLSLAM_EHIP))) {   // the staging vectors die here
         (void)hipStreamSynchronize(s);
-        P->stat.release(); P->dyn.release(); P->rows.release(); P->out.release();
+        P->stat.release(); P->dyn.release(); P->rows.release(); P->out.release(); P->pin_in.release(); P->pin_out.release();
         delete P;
         return rc;
     }
@@ -382,33 +587,52 @@ extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, doub
     return PLSLAM_OK;
 }
 
-// upload X, rows (K3/K4), blocks (K7-K10): enqueued on the context's stream, nothing downloaded.  Caller holds ctx->mu.
+// upload X (one copy), rows + cross blocks + err partials (F1), landmark blocks + keyframe chunk partials (F2), keyframe blocks +
+// err (F3): enqueued on the context's stream, nothing downloaded.  Caller holds ctx->mu.
 static int lba_plan_enqueue(plslam_lba_plan* P, const double* T_kf_w, const double* Xw, const double* Lw, int compat_flags)
 {
     plslam_ctx* ctx = P->ctx;
     hipStream_t s = ctx->stream;
     char *ds = P->stat.as<char>(), *dd = P->dyn.as<char>(), *dr = P->rows.as<char>(), *dout = P->out.as<char>();
-    if (P->n_slots) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd + P->oT, T_kf_w, (size_t)P->n_slots * 128, hipMemcpyHostToDevice, s));
-    if (P->npt) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd + P->oX, Xw, (size_t)P->npt * 24, hipMemcpyHostToDevice, s));
-    if (P->nls) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd + P->oL, Lw, (size_t)P->nls * 48, hipMemcpyHostToDevice, s));
-    int rc;
-    if ((rc = launch_point_rows(P->cam, P->th, (double*)(dd + P->oT), (double*)(dd + P->oX), (double*)(ds + P->oPuv),
-                                (int32_t*)(ds + P->oPlm), (int32_t*)(ds + P->oPslot), P->np, (double*)(dr + P->oPJp),
-                                (double*)(dr + P->oPJl), (double*)(dr + P->oPr), (double*)(dr + P->oPw), s)))
-        return rc;
-    if ((rc = launch_line_rows(P->cam, P->th, (compat_flags & PLSLAM_LBA_COMPAT_ITER_PASS) ? 1 : 0, (double*)(dd + P->oT),
-                               (double*)(dd + P->oL), (double*)(ds + P->oLobs), (int32_t*)(ds + P->oLlm),
-                               (int32_t*)(ds + P->oLslot), P->nl, (double*)(dr + P->oLJp), (double*)(dr + P->oLJl),
-                               (double*)(dr + P->oLr), (double*)(dr + P->oLw), s)))
-        return rc;
-    AssembleDev a{(int32_t*)(ds + P->oPkf), (int32_t*)(ds + P->oLkf), (int32_t*)(ds + P->oPtp), (int32_t*)(ds + P->oPti),
-                  (int32_t*)(ds + P->oLsp), (int32_t*)(ds + P->oLsi), (int32_t*)(ds + P->oKfp), (int32_t*)(ds + P->oKfi),
-                  (double*)(dr + P->oPJp), (double*)(dr + P->oPJl), (double*)(dr + P->oPr), (double*)(dr + P->oPw),
-                  (double*)(dr + P->oLJp), (double*)(dr + P->oLJl), (double*)(dr + P->oLr), (double*)(dr + P->oLw),
-                  (double*)(dout + P->oG), (double*)(dout + P->oHp), (double*)(dout + P->oHpt), (double*)(dout + P->oHls),
-                  (double*)(dout + P->oWp), (double*)(dout + P->oWl), (double*)(dout + P->oErr),
-                  (double*)(dout + P->oPart), P->max_chunks, (compat_flags & PLSLAM_LBA_COMPAT_GBA) ? 1 : 0};
-    return assemble_on_device(a, P->nkf, P->npt, P->nls, P->np, P->nl, s);
+    // (the page-locked image is rewritten per call: the previous call's copy has completed -- every caller synchronises the
+    // stream before it returns)
+    char* hi = P->pin_in.as<char>();
+    if (P->n_slots) memcpy(hi + P->oT, T_kf_w, (size_t)P->n_slots * 128);
+    if (P->npt) memcpy(hi + P->oX, Xw, (size_t)P->npt * 24);
+    if (P->nls) memcpy(hi + P->oL, Lw, (size_t)P->nls * 48);
+    if (P->dyn_bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd, hi, P->dyn_bytes, hipMemcpyHostToDevice, s));
+    const int32_t nbp = (P->np + 255) / 256, nbl = (P->nl + 255) / 256;
+    const size_t N6 = 6 * (size_t)P->nkf;
+    LbaIterArgs A{};
+    A.K = CamD{P->cam.fx, P->cam.fy, P->cam.cx, P->cam.cy, (double)P->cam.width, (double)P->cam.height};
+    A.th = P->th;
+    A.compat_iter = (compat_flags & PLSLAM_LBA_COMPAT_ITER_PASS) ? 1 : 0;
+    A.transpose_ls_cross = (compat_flags & PLSLAM_LBA_COMPAT_GBA) ? 1 : 0;
+    A.T = (double*)(dd + P->oT); A.Xw = (double*)(dd + P->oX); A.Lw = (double*)(dd + P->oL);
+    A.uv = (double*)(ds + P->oPuv); A.lobs = (double*)(ds + P->oLobs);
+    A.pt_lm = (int32_t*)(ds + P->oPlm); A.pt_slot = (int32_t*)(ds + P->oPslot); A.pt_kf_loc = (int32_t*)(ds + P->oPkf);
+    A.ls_lm = (int32_t*)(ds + P->oLlm); A.ls_slot = (int32_t*)(ds + P->oLslot); A.ls_kf_loc = (int32_t*)(ds + P->oLkf);
+    A.np = P->np; A.nl = P->nl; A.nbp = nbp; A.nbl = nbl;
+    A.pJp = (double*)(dr + P->oPJp); A.pJl = (double*)(dr + P->oPJl); A.pr = (double*)(dr + P->oPr); A.pw = (double*)(dr + P->oPw);
+    A.lJp = (double*)(dr + P->oLJp); A.lJl = (double*)(dr + P->oLJl); A.lr = (double*)(dr + P->oLr); A.lw = (double*)(dr + P->oLw);
+    A.Wp = (double*)(dout + P->oWp); A.Wl = (double*)(dout + P->oWl); A.err_part = (double*)(dout + P->oErrPart);
+    if (nbp + nbl > 0) hipLaunchKernelGGL(k_lba_rows_cross, dim3(nbp + nbl), dim3(256), 0, s, A);
+    LbaBlockArgs B{};
+    B.pt_ptr = (int32_t*)(ds + P->oPtp); B.pt_ids = (int32_t*)(ds + P->oPti); B.ls_ptr = (int32_t*)(ds + P->oLsp);
+    B.ls_ids = (int32_t*)(ds + P->oLsi); B.kf_ptr = (int32_t*)(ds + P->oKfp); B.kf_ids = (int32_t*)(ds + P->oKfi);
+    B.pJp = A.pJp; B.pJl = A.pJl; B.pr = A.pr; B.pw = A.pw; B.lJp = A.lJp; B.lJl = A.lJl; B.lr = A.lr; B.lw = A.lw;
+    double* g = (double*)(dout + P->oG);
+    B.H_pt = (double*)(dout + P->oHpt); B.g_pt = g + N6; B.H_ls = (double*)(dout + P->oHls); B.g_ls = g + N6 + 3 * (size_t)P->npt;
+    B.pose_part = (double*)(dout + P->oPart); B.H_pose = (double*)(dout + P->oHp); B.g_pose = g;
+    B.err = (double*)(dout + P->oErr); B.err_part = A.err_part;
+    B.npt = P->npt; B.nls = P->nls; B.nkf = P->nkf; B.np = P->np;
+    B.nb3 = (P->npt + 255) / 256; B.nb6 = (P->nls + 255) / 256; B.max_chunks = P->max_chunks; B.nerr = nbp + nbl;
+    const int32_t nchunk_wgs = (P->nkf * P->max_chunks + 3) / 4;
+    if (B.nb3 + B.nb6 + nchunk_wgs > 0)
+        hipLaunchKernelGGL(k_lba_blocks, dim3(B.nb3 + B.nb6 + nchunk_wgs), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(k_lba_finish, dim3(P->nkf + 1), dim3(256), 0, s, B);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
 }
 
 // device -> host copies of the blocks of the last iteration (NULL pointers are skipped), then one synchronise
@@ -423,6 +647,16 @@ static int lba_plan_download(plslam_lba_plan* P, double* g, double* H_pose, doub
         return PLSLAM_OK;
     };
     int rc;
+    if (!H_pose && !H_pt && !H_ls && !W_pt && !W_ls) {
+        // g and err (or err alone): one copy into page-locked memory, then out of it
+        char* ho = P->pin_out.as<char>();
+        const size_t off = g ? P->oG : P->oErr, bytes = g ? N * 8 + 8 : 8;
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, dout + off, bytes, hipMemcpyDeviceToHost, s));
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        if (g) memcpy(g, ho, N * 8);
+        if (err) memcpy(err, ho + bytes - 8, 8);
+        return PLSLAM_OK;
+    }
     if ((rc = down(g, P->oG, N * 8)) || (rc = down(H_pose, P->oHp, (size_t)P->nkf * 288)) ||
         (rc = down(H_pt, P->oHpt, (size_t)P->npt * 72)) || (rc = down(H_ls, P->oHls, (size_t)P->nls * 288)) ||
         (rc = down(W_pt, P->oWp, (size_t)P->np * 144)) || (rc = down(W_ls, P->oWl, (size_t)P->nl * 288)) ||
@@ -515,7 +749,7 @@ extern "C" void plslam_lba_plan_destroy(plslam_lba_plan* P)
 {
     if (!P) return;
     (void)hipStreamSynchronize(P->ctx->stream);
-    P->stat.release(); P->dyn.release(); P->rows.release(); P->out.release();
+    P->stat.release(); P->dyn.release(); P->rows.release(); P->out.release(); P->pin_in.release(); P->pin_out.release();
     delete P;
 }
 

@@ -258,7 +258,9 @@ class TableGatherPipeline:
         # gather (world x 27.8 MB read + 55.7 MB written per step at C4 sizes) -- inside the step, where its cost is timed
         self.wide = [torch.empty((world, rows, stride), dtype=torch.int32, device=self.dev) for _ in range(nbuf)] \
             if (rank == root and self.compact and self.cuda) else None
-        self.comm = torch.cuda.Stream(device=self.dev) if self.cuda else None
+        # high priority: the gather's kernels are short and must take the workgroup slots the running scan frees -- at normal
+        # priority they queue behind the scan's whole backlog, and the step that recomputes this buffer waits for them
+        self.comm = torch.cuda.Stream(device=self.dev, priority=-1) if self.cuda else None
         self.done_ev = [None] * nbuf         # CUDA: recorded on the comm stream after buffer b's gather
         self.works = [None] * nbuf
 

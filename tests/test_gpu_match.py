@@ -517,6 +517,7 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
             ctx.set_option("mfma_form", {4: 3, 5: 4, 6: 4, 7: 5, 8: 5}.get(form, min(form, 2)))
             ctx.set_option("exact_second", 1 if form in (4, 5, 7) else 0)
             ctx.set_option("fuse", 2 if form == 3 else 1)
+            ctx.set_option("post_fuse", 1)         # the merged column keys are compared below: they exist in memory only with the separate kernels
             bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.85, nnr_l=0.9, mutual=mutual)
             tab = bm.run()
             torch.cuda.synchronize()
@@ -528,6 +529,7 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
         ctx.set_option("mfma_form", 0)
         ctx.set_option("fuse", 0)
         ctx.set_option("exact_second", 0)
+        ctx.set_option("post_fuse", 0)
     # the dump returns the buffers with their 25 % growth slack: compare the words the kernels write.  (The column
     # PARTIALS are laid out differently -- K1e: 32-bit keys per 256-row block, K1f: 16-bit keys per 64-row block -- so
     # the column direction is compared after the merge: keys21 is part of the key table.)
@@ -714,3 +716,38 @@ def test_split_runs_order_themselves(ctx, oracle):
         for name, d1, d2 in frontend.pair_problems(stream["orb_l"], stream["orb_r"], stream["lbd_l"], stream["lbd_r"], i):
             assert np.array_equal(got[i, sl[name]], oracle.match(d1, d2, 0.8, True)[0]), (i, name)
     bm.close()
+
+
+@pytest.mark.parametrize("n_orb,n_lbd,pairs", [(1500, 200, 16), (300, 70, 64), (257, 4000, 6), (2100, 33, 6), (40, 17, 200), (513, 1, 24)])
+def test_fused_stage_behind_the_scan_equals_the_separate_kernels(ctx, oracle, n_orb, n_lbd, pairs):
+    """k_post_fused (one workgroup per problem: column merge into LDS, finalize, gates) against k_merge_fix16 + k_finalize on
+    the same plans -- tables, counts, gated associations, disparities -- and against the oracle; tie-heavy data, ragged sizes,
+    several row blocks and column windows, keep_prior-free batch plans.  Forced ("post_fuse" 2: AUTO wants two problems per
+    CU) and refused (1)."""
+    import torch
+    import plslam_amd
+    from plslam_amd import frontend, synth
+    s = synth.stereo_stream(pairs, n_orb, n_lbd, seed=77 + n_orb, tie_stress=(n_orb % 2 == 1))
+    geo = synth.stereo_geometry(s, seed=5)
+    out = {}
+    try:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)
+        for pf in (1, 2):
+            ctx.set_option("post_fuse", pf)
+            bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.8, nnr_l=0.9, mutual=True, geometry=geo, gates=dict(synth.KITTI_GATES), n_buffers=2)
+            for k in range(3):
+                bm.run_overlapped(k)
+            bm.synchronize_all()
+            out[pf] = [x.cpu().numpy().copy() for x in (bm.tables[0], bm.count_bufs[0], bm.stereo_tabs[0], bm.stereo_disps[0].view(torch.int64),
+                                                       bm.stereo_cnts[0], bm.tables[1], bm.stereo_tabs[1])]
+            bm.close()
+    finally:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+        ctx.set_option("post_fuse", 0)
+    for a, b in zip(out[1], out[2]):
+        assert np.array_equal(a, b)
+    sl = frontend.table_slices(n_orb, n_lbd)
+    for i in range(0, pairs, max(1, pairs // 8)):
+        for name, d1, d2 in frontend.pair_problems(s["orb_l"], s["orb_r"], s["lbd_l"], s["lbd_r"], i):
+            em, _ = oracle.match(d1, d2, 0.8 if name.startswith("orb") else 0.9, True)
+            assert np.array_equal(out[2][0][i, sl[name]], em), (i, name)

@@ -195,6 +195,48 @@ def test_gate_stage_of_the_batch_plan(ctx, oracle, pairs, n_orb, n_lbd, gates):
 
 
 @pytest.mark.gpu
+def test_failed_gate_request_leaves_the_plan_usable(ctx, oracle):
+    """a plslam_match_plan_add_stereo_gates call that fails (a gate with a misaligned feature table, counters
+    that are not one array) must leave the plan as it was -- round 3's version had cleared the host image of the problem
+    table first and returned without re-uploading it: the device table kept gate indices, the next run passed no gate table,
+    and the finalize kernel read through a null pointer.  And a plan whose stage is REMOVED (ngates = 0) runs without it."""
+    import torch
+    from plslam_amd import frontend, synth
+    pairs, n_orb, n_lbd = 48, 300, 64
+    s = synth.stereo_stream(pairs, n_orb, n_lbd, seed=5151)
+    geo = synth.stereo_geometry(s, seed=3)
+    th = dict(synth.KITTI_GATES)
+    for post_fuse in (1, 2):                                  # the separate finalize kernel and the fused stage behind the scan
+        ctx.set_option("post_fuse", post_fuse)
+        try:
+            bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.75, nnr_l=0.9, mutual=True, geometry=geo, gates=th)
+        finally:
+            ctx.set_option("post_fuse", 0)
+        bm.run()
+        torch.cuda.synchronize()
+        ref = [x.clone() for x in (bm.table, bm.stereo, bm.stereo_disp.view(torch.int64), bm.stereo_counts)]
+        good = dict(matches_12=bm.table.data_ptr(), f_l=bm.g["kp_l"].data_ptr(), f_r=bm.g["kp_r"].data_ptr(), n_l=n_orb, n_r=n_orb,
+                    lines=0, stereo_12=bm.stereo.data_ptr(), disp=bm.stereo_disp.data_ptr(), n_stereo=bm.stereo_counts.data_ptr(), **th)
+        bad_align = dict(good, f_l=good["f_l"] + 4)                           # float2 rows must be 8-byte aligned
+        bad_count = dict(good, n_stereo=bm.stereo_counts.data_ptr() + 40)     # counters of a request: one contiguous array
+        for request in ([good, bad_align], [good, bad_count]):
+            with pytest.raises(Exception):
+                bm.plan.add_stereo_gates(request)
+            for t in (bm.stereo, bm.stereo_counts):
+                t.fill_(-7)
+            bm.run()
+            torch.cuda.synchronize()
+            got = (bm.table, bm.stereo, bm.stereo_disp.view(torch.int64), bm.stereo_counts)
+            assert all(torch.equal(a, b) for a, b in zip(got, ref)), post_fuse      # the old stage still runs, whole
+        bm.plan.add_stereo_gates([])                                              # stage removed
+        bm.stereo.fill_(-7)
+        bm.run()
+        torch.cuda.synchronize()
+        assert torch.equal(bm.table, ref[0]) and bool((bm.stereo == -7).all())
+        bm.close()
+
+
+@pytest.mark.gpu
 def test_device_pointer_gates(ctx, oracle):
     """plslam_stereo_point_gate_dev / _line_gate_dev: device tables in, device results out, on a caller's stream."""
     import ctypes as C

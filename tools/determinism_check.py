@@ -28,7 +28,14 @@ def check(ctx, n_orb, n_lbd, pairs, rounds, nnr, mutual=True, device=None):
     """-> dict(key_words, key_diffs, partial_diffs, table_diffs) summed over rounds 2..rounds vs round 1."""
     device = device or torch.device("cuda", 0)
     stream = synth.stereo_stream(pairs, n_orb, n_lbd, seed=synth.SEED0, first_pair=0)
-    bm = frontend.StereoBatchMatcher(ctx, stream, nnr_p=nnr, nnr_l=nnr, mutual=mutual, device=device, n_buffers=2)
+    # the merged column keys are part of the dumped key table: they exist in memory only with the separate kernels behind the
+    # scan (the fused stage keeps them in LDS)
+    prev = ctx.get_option("post_fuse")
+    ctx.set_option("post_fuse", 1)
+    try:
+        bm = frontend.StereoBatchMatcher(ctx, stream, nnr_p=nnr, nnr_l=nnr, mutual=mutual, device=device, n_buffers=2)
+    finally:
+        ctx.set_option("post_fuse", prev)
     ref = None
     out = {"key_words": 0, "key_diffs": 0, "partial_diffs": 0, "table_diffs": 0, "rounds": rounds}
     for _ in range(rounds):
