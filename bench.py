@@ -468,7 +468,9 @@ def main():
                 pm = json.load(f).get("entries", {}).get(wkey)
         except OSError:
             pm = None
+        trace_us, trace_file = None, None
         if pm and pm.get("kernel_source_hash") == src_hash:
+            trace_us, trace_file = pm.get("trace_avg_us"), pm.get("trace_file")
             traffic = pm["traffic_bytes_per_launch"]
             valu_insts = pm["sq_insts_valu_per_launch"] - pm.get("sq_insts_mfma_per_launch", 0)
             lane_ops = valu_insts * 64 / scan_s
@@ -503,6 +505,10 @@ def main():
                 "frac": mfma_ops / scan_s / mx_peak, "traffic": traffic, "kernel": kernel_name,
                 "kernel_ms": 1e3 * scan_s, "kernel_ms_in_timed_region": scan_ms / max(runs, 1), "timing": timing_note,
                 "algorithmic_ops_per_launch": mfma_ops, "pmc": pmc_note,
+                # the same fraction from the COMMITTED rocprofv3 kernel trace of this command (another box, another day: boxes
+                # differ by a few per cent), when it was taken on these kernel sources
+                "frac_profiles": (mfma_ops / (trace_us * 1e-6) / mx_peak) if trace_us else None,
+                "frac_profiles_source": trace_file if trace_us else None,
                 "note": "fp4 MFMA v_mfma_f32_32x32x64_f8f6f4 (operands are the e2m1 codes of +-4 -- K1i, unscaled -- or of +-1 "
                         "with a 2^6 block scale -- K1e..K1h; fp32 accumulation of integers below 2^24: exact); dense fp4 peak = "
                         "CUs x 4 SIMDs x 4096 ops/clk x max clock (MI355X_MICROARCH.md measures 9099 T for the 32x32x64 "

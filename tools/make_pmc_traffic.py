@@ -39,8 +39,20 @@ def main():
     f = counters(os.path.join(g, f"{tag}_pmc_fetch.txt"), kernel)
     w = counters(os.path.join(g, f"{tag}_pmc_write.txt"), kernel)
     fetch_kib, write_kib = f["FETCH_SIZE"], w["WRITE_SIZE"]
+    # the same command's kernel trace (no counters: undisturbed durations): the scan kernel's average launch
+    trace_us, trace_calls, trace_file = None, None, f"{tag}_kernel_trace_stats_serial.txt"
+    try:
+        for line in open(os.path.join(g, trace_file)):
+            if kernel in line:
+                m = re.search(r"\s(\d+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s+([0-9.]+)\s*$", line)
+                if m:
+                    trace_calls, trace_us = int(m.group(1)), float(m.group(3))
+                    break
+    except OSError:
+        pass
     entry = {
         "kernel": kernel, "kernel_source_hash": kernel_source_hash(),
+        "trace_avg_us": trace_us, "trace_calls": trace_calls, "trace_file": "profiles/" + trace_file,
         "fetch_size_kib_per_dispatch": fetch_kib, "write_size_kib_per_dispatch": write_kib, "fetch_correction": corr,
         "traffic_bytes_per_launch": int(fetch_kib * 1024 * corr + write_kib * 1024),
         "sq_insts_valu_per_launch": int(a["SQ_INSTS_VALU"]), "sq_insts_mfma_per_launch": int(a.get("SQ_INSTS_MFMA", 0)),
