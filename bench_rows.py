@@ -195,11 +195,20 @@ def lba_iterate(ctx, O):
     if not np.isclose(err, err_ref, rtol=1e-9):
         raise SystemExit("secondary record lba_iterate: the weighted error differs from the oracle's rows")
     ts = _wall(lambda: plan.iterate_dev(lm["T_kf_w"], lm["Xw"], lm["Lw"]), 30)
+    # the same iteration with less crossing the host boundary: err only down (a device-side solver reads g where it is), and
+    # the state resident too (nothing up: the solver updated it in place) -- three launches and an 8-byte download
+    err_only = _pct(_wall(lambda: plan.iterate_dev(lm["T_kf_w"], lm["Xw"], lm["Lw"], want_g=False), 30))["us_median"]
+    if plan.iterate_resident() != err:
+        raise SystemExit("secondary record lba_iterate: the resident iteration's error differs")
+    resident = _pct(_wall(plan.iterate_resident, 30))["us_median"]
     plan.close()
-    return dict(_pct(ts), workload="one Levenberg-Marquardt iteration of MapHandler::levMarquardtOptimizationLBA at C3 sizes "
-                                   "(mapHandler.cpp:1358-1540 rows + :1410-1429, :1519-1538 block assembly; N = 42 054): poses and "
-                                   "landmarks uploaded (0.34 MB), rows, block assembly, the error and g downloaded; the blocks stay "
-                                   "on the device", rows=60000, cpu_oracle_rows_only_1thread_ms=cpu_rows_ms,
+    return dict(_pct(ts), err_only_us_median=err_only, state_resident_us_median=resident,
+                workload="one Levenberg-Marquardt iteration of MapHandler::levMarquardtOptimizationLBA at C3 sizes "
+                         "(mapHandler.cpp:1358-1540 rows + :1410-1429, :1519-1538 block assembly; N = 42 054): poses and landmarks "
+                         "uploaded (0.34 MB, one copy), three launches (rows + cross blocks + error partials | landmark blocks + "
+                         "keyframe chunk partials | keyframe blocks + error), the error and g downloaded (one copy); the blocks stay "
+                         "on the device.  err_only: g stays too; state_resident: nothing uploaded either "
+                         "(plslam_lba_plan_iterate_resident)", rows=60000, cpu_oracle_rows_only_1thread_ms=cpu_rows_ms,
                 verified="all 60 000 rows within 1e-6 relative of the oracle, weighted error within 1e-9")
 
 

@@ -500,6 +500,18 @@ typedef struct plslam_lba_blocks {
 int plslam_lba_plan_device_blocks(plslam_lba_plan* plan, plslam_lba_blocks* out);
 int plslam_lba_plan_blocks(plslam_lba_plan* plan, double* g, double* H_pose, double* H_pt, double* H_ls, double* W_pt,
                            double* W_ls, double* err);
+/* The optimisation state itself on the device (round 4): after one plslam_lba_plan_iterate / _iterate_dev has uploaded it,
+ * plslam_lba_plan_device_state names the device copies of T_kf_w (n_pose_slots x 16), Xw (npt x 3) and Lw (nls x 6) -- a
+ * device-side solver applies its update to them in place (the reference's X <- X + delta, T <- T inv(exp(delta)),
+ * src/mapHandler.cpp:1563-1568), on `stream` -- and plslam_lba_plan_iterate_resident runs the next iteration on them: no
+ * upload, three launches, *err down (8 bytes).  Blocks as after plslam_lba_plan_iterate_dev. */
+typedef struct plslam_lba_state {
+    double *T_kf_w, *Xw, *Lw;                 /* device pointers */
+    int32_t n_pose_slots, npt, nls;
+    void* stream;                              /* the HIP stream the plan's iterations run on */
+} plslam_lba_state;
+int plslam_lba_plan_device_state(plslam_lba_plan* plan, plslam_lba_state* out);
+int plslam_lba_plan_iterate_resident(plslam_lba_plan* plan, int compat_flags, double* err);
 /* rows of the last iterate() (any pointer may be NULL), e.g. for the write-back logic of :1822-1855 */
 int plslam_lba_plan_rows(plslam_lba_plan* plan, double* pt_J_pose, double* pt_J_lm, double* pt_r, double* pt_w,
                          double* ls_J_pose, double* ls_J_lm, double* ls_r, double* ls_w);

@@ -34,7 +34,8 @@ ABI_SYMBOLS = (
     "plslam_match_plan_elapsed", "plslam_match_plan_info", "plslam_match_plan_dump", "plslam_match_plan_key_state", "plslam_match_plan_destroy",
     "plslam_lba_point_rows", "plslam_lba_line_rows", "plslam_lba_point_rows_dev",
     "plslam_lba_line_rows_dev", "plslam_lba_assemble", "plslam_lba_plan_create", "plslam_lba_plan_iterate",
-    "plslam_lba_plan_rows", "plslam_lba_plan_destroy", "plslam_lba_plan_iterate_dev", "plslam_lba_plan_device_blocks",
+    "plslam_lba_plan_rows", "plslam_lba_plan_destroy", "plslam_lba_plan_iterate_dev", "plslam_lba_plan_device_blocks", "plslam_lba_plan_device_state",
+    "plslam_lba_plan_iterate_resident",
     "plslam_lba_plan_blocks",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
@@ -208,6 +209,8 @@ def load() -> C.CDLL:
     L.plslam_lba_plan_rows.argtypes = [vp] * 9
     L.plslam_lba_plan_iterate_dev.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp]
     L.plslam_lba_plan_device_blocks.argtypes = [vp, vp]
+    L.plslam_lba_plan_device_state.argtypes = [vp, vp]
+    L.plslam_lba_plan_iterate_resident.argtypes = [vp, C.c_int, vp]
     L.plslam_lba_plan_blocks.argtypes = [vp] * 8
     L.plslam_lba_plan_destroy.argtypes = [vp]
     L.plslam_lba_plan_destroy.restype = None
@@ -782,6 +785,22 @@ class LbaPlan:
                                                    _p(g) if want_g else None, _p(err)), "plslam_lba_plan_iterate_dev")
         return float(err[0]), g
 
+    def iterate_resident(self, compat_flags=0) -> float:
+        """One iteration on the state already on the device (uploaded by an earlier iterate / iterate_dev, updated in place
+        by a device-side solver: device_state()) -> err."""
+        err = np.empty(1)
+        _check(self._L.plslam_lba_plan_iterate_resident(self._h, int(compat_flags), _p(err)), "plslam_lba_plan_iterate_resident")
+        return float(err[0])
+
+    def device_state(self) -> dict:
+        """Device pointers (ints) of T_kf_w / Xw / Lw, their row counts and the plan's HIP stream."""
+        class _S(C.Structure):
+            _fields_ = [("T_kf_w", C.c_void_p), ("Xw", C.c_void_p), ("Lw", C.c_void_p), ("n_pose_slots", C.c_int32),
+                        ("npt", C.c_int32), ("nls", C.c_int32), ("stream", C.c_void_p)]
+        st = _S()
+        _check(self._L.plslam_lba_plan_device_state(self._h, C.byref(st)), "plslam_lba_plan_device_state")
+        return {k: getattr(st, k) for k, _ in _S._fields_}
+
     def blocks(self):
         """Download the blocks of the last iteration (the arrays plslam_lba_plan_device_blocks names)."""
         nkf, npt, nls, npo, nlo, _ = self.dims
@@ -953,3 +972,11 @@ class GridPlan:
             self.close()
         except Exception:
             pass
+
+
+def _hip_memcpy_dtod(dst: int, src: int, nbytes: int) -> int:
+    """Device-to-device copy through the HIP runtime (tests: an in-place update of a plan's device state)."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    hip.hipMemcpy.restype = C.c_int
+    return hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(src), C.c_size_t(nbytes), 3)      # hipMemcpyDeviceToDevice

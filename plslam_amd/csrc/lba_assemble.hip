@@ -508,6 +508,7 @@ struct plslam_lba_plan {
     // of `dyn` (ONE copy instead of three from pageable memory), err sits right behind g (ONE copy back)
     HostBuf pin_in, pin_out;
     size_t dyn_bytes = 0;
+    bool state_valid = false;      // T / Xw / Lw have been uploaded at least once (iterate_resident needs them)
 };
 
 extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, double homog_th, int32_t n_pose_slots,
@@ -589,18 +590,24 @@ extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, doub
 
 // upload X (one copy), rows + cross blocks + err partials (F1), landmark blocks + keyframe chunk partials (F2), keyframe blocks +
 // err (F3): enqueued on the context's stream, nothing downloaded.  Caller holds ctx->mu.
-static int lba_plan_enqueue(plslam_lba_plan* P, const double* T_kf_w, const double* Xw, const double* Lw, int compat_flags)
+// upload = false: the poses and landmarks already on the device are used (plslam_lba_plan_iterate_resident: a device-side
+// solver has updated them in place)
+static int lba_plan_enqueue(plslam_lba_plan* P, const double* T_kf_w, const double* Xw, const double* Lw, int compat_flags,
+                            bool upload = true)
 {
     plslam_ctx* ctx = P->ctx;
     hipStream_t s = ctx->stream;
     char *ds = P->stat.as<char>(), *dd = P->dyn.as<char>(), *dr = P->rows.as<char>(), *dout = P->out.as<char>();
-    // (the page-locked image is rewritten per call: the previous call's copy has completed -- every caller synchronises the
-    // stream before it returns)
-    char* hi = P->pin_in.as<char>();
-    if (P->n_slots) memcpy(hi + P->oT, T_kf_w, (size_t)P->n_slots * 128);
-    if (P->npt) memcpy(hi + P->oX, Xw, (size_t)P->npt * 24);
-    if (P->nls) memcpy(hi + P->oL, Lw, (size_t)P->nls * 48);
-    if (P->dyn_bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd, hi, P->dyn_bytes, hipMemcpyHostToDevice, s));
+    if (upload) {
+        // (the page-locked image is rewritten per call: the previous call's copy has completed -- every caller synchronises
+        // the stream before it returns)
+        char* hi = P->pin_in.as<char>();
+        if (P->n_slots) memcpy(hi + P->oT, T_kf_w, (size_t)P->n_slots * 128);
+        if (P->npt) memcpy(hi + P->oX, Xw, (size_t)P->npt * 24);
+        if (P->nls) memcpy(hi + P->oL, Lw, (size_t)P->nls * 48);
+        if (P->dyn_bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd, hi, P->dyn_bytes, hipMemcpyHostToDevice, s));
+        P->state_valid = true;
+    }
     const int32_t nbp = (P->np + 255) / 256, nbl = (P->nl + 255) / 256;
     const size_t N6 = 6 * (size_t)P->nkf;
     LbaIterArgs A{};
@@ -697,6 +704,30 @@ extern "C" int plslam_lba_plan_iterate_dev(plslam_lba_plan* P, const double* T_k
     int rc = lba_plan_enqueue(P, T_kf_w, Xw, Lw, compat_flags);
     if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
     return lba_plan_download(P, g, nullptr, nullptr, nullptr, nullptr, nullptr, err);
+}
+
+// The iteration on the state that already lives on the device: nothing goes up, err comes down.  For a device-side solver
+// (plslam_lba_plan_device_state names T / Xw / Lw: it updates them in place on the context's stream between iterations).
+extern "C" int plslam_lba_plan_iterate_resident(plslam_lba_plan* P, int compat_flags, double* err)
+{
+    PLSLAM_REQUIRE(P && err, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(P->state_valid, PLSLAM_EINVAL);         // one plslam_lba_plan_iterate(_dev) first: it uploads the state
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
+    int rc = lba_plan_enqueue(P, nullptr, nullptr, nullptr, compat_flags, false);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    return lba_plan_download(P, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, err);
+}
+
+extern "C" int plslam_lba_plan_device_state(plslam_lba_plan* P, plslam_lba_state* out)
+{
+    PLSLAM_REQUIRE(P && out, PLSLAM_EINVAL);
+    char* dd = P->dyn.as<char>();
+    out->T_kf_w = (double*)(dd + P->oT); out->Xw = (double*)(dd + P->oX); out->Lw = (double*)(dd + P->oL);
+    out->n_pose_slots = P->n_slots; out->npt = P->npt; out->nls = P->nls;
+    out->stream = P->ctx->stream;
+    return PLSLAM_OK;
 }
 
 extern "C" int plslam_lba_plan_device_blocks(plslam_lba_plan* P, plslam_lba_blocks* out)

@@ -342,7 +342,40 @@ def test_lba_plan_device_resident_iteration_and_gba_blocks(ctx):
     assert e_dev == big.iterate(lm["T_kf_w"], lm["Xw"], lm["Lw"])["err"]
     print(f"C3 LBA iteration host-to-host: blocks downloaded {1e3 * t_host:.2f} ms, device-resident {1e3 * t_dev:.2f} ms")
     assert t_dev < 0.6 * t_host and t_dev < 1.0e-3
+    # the state resident too (round 4): no upload -- the same err and the same blocks; after an in-place update of the device
+    # copy of Xw (what a device-side solver does) the iteration equals the uploaded one on the updated landmarks
+    import torch
+    ref_blocks = big.blocks()
+    assert big.iterate_resident() == e_dev
+    again = big.blocks()
+    for k in ("g", "H_pose", "H_pt", "H_ls", "W_pt", "W_ls"):
+        assert np.array_equal(again[k], ref_blocks[k]), k
+    st = big.device_state()
+    assert (st["n_pose_slots"], st["npt"], st["nls"]) == (10, 10000, 2000)
+    X2 = lm["Xw"] + np.random.Generator(np.random.PCG64(3)).normal(0, 1e-3, lm["Xw"].shape)
+    import ctypes
+    torch.cuda.synchronize()
+    dX = torch.from_numpy(X2).to(torch.device("cuda", 0))
+    assert plslam_amd.capi._hip_memcpy_dtod(st["Xw"], dX.data_ptr(), X2.nbytes) == 0
+    e_res = big.iterate_resident()
+    b_res = big.blocks()
+    e_up, _ = big.iterate_dev(lm["T_kf_w"], X2, lm["Lw"], want_g=False)
+    b_up = big.blocks()
+    assert e_res == e_up and e_res != e_dev
+    for k in ("g", "H_pose", "H_pt", "H_ls", "W_pt", "W_ls"):
+        assert np.array_equal(b_res[k], b_up[k]), k
+    t0 = time.perf_counter()
+    for _ in range(20):
+        big.iterate_resident()
+    print(f"state resident: {1e6 * (time.perf_counter() - t0) / 20:.0f} us per iteration")
     big.close()
+    with pytest.raises(plslam_amd.PlslamError):           # no state on the device yet
+        fresh = plslam_amd.LbaPlan(ctx, cam, 1e-7, 10, 9, 10000, 2000, lm["pt_lm"], lm["pt_kf"], lm["pt_kf"] - 1, lm["obs_uv"],
+                                   lm["ls_lm"], lm["ls_kf"], lm["ls_kf"] - 1, lm["l_obs"])
+        try:
+            fresh.iterate_resident()
+        finally:
+            fresh.close()
 
 
 def test_visibility_gates_and_median_descriptor_against_reference_source_text_outputs(ctx):
