@@ -17,7 +17,8 @@ namespace plslam {
 
 // match_grid.hip: one matchGrid problem on `s`, with its scratch (a large mutual problem gets its distances from a
 // many-workgroup launch)
-int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux, bool n1_upper_bound);
+int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux, bool n1_upper_bound,
+                       const GridDesc* h_desc = nullptr);   // h_desc: the host's copy (kernels of a lone problem take it by value)
 size_t grid_aux_words(int32_t n2);            // the words the two launches share, prefilled by grid_aux_fill in the upload image
 void grid_aux_fill(void* host_image, int32_t n2);
 // lba.hip: the visibility pre-filter AND the candidate flags, both on the device
@@ -203,7 +204,7 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     if ((rc = launch_project_cells(*K, T16, d_X3, nq, lines, sx, sy, (int32_t*)(f + oCen),
                                    lines ? (double*)(f + oD1) : nullptr, s)))
         return rc;
-    if ((rc = grid_launch_single(q, (const GridDesc*)(f + oDesc), s, (uint32_t*)(f + oAux), false))) return rc;
+    if ((rc = grid_launch_single(q, (const GridDesc*)(f + oDesc), s, (uint32_t*)(f + oAux), false, (const GridDesc*)(h + oDesc)))) return rc;
     if (!in_place) PLSLAM_HIP_CHECK(hipMemcpyAsync(res_host, f + oSt, 8, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     sg.dismiss();

@@ -63,6 +63,15 @@ constexpr int CB = 4;                                                  // candid
 constexpr int GRID_SPLIT = 4;                                          // flat PA: at most this many lanes share a row's window columns
 constexpr uint32_t GRID_TAIL = 256;                                   // candidates left when one wave finishes the passes alone
 constexpr int PB_BATCH = 8;                                            // stored candidates per batch of a record pass
+#ifndef PLSLAM_GRID_RECORDS
+#define PLSLAM_GRID_RECORDS 1       // 0: experiment builds that list every candidate pair of a lone problem (k_grid_candidates)
+#endif
+#ifndef PLSLAM_GRID_FAST
+#define PLSLAM_GRID_FAST 1          // 0: experiment builds without the shortest bookkeeping of k_grid_records' list
+#endif
+#ifndef PLSLAM_GRID_COLUMNS
+#define PLSLAM_GRID_COLUMNS 1       // 0: experiment builds without the column-bucketed path of a lone problem
+#endif
 constexpr size_t GRID_LDS_MAX_BYTES = 152 * 1024;                      // dynamic LDS of the LDS instantiations
 constexpr size_t GRID_LDS_FIXED_MAX_BYTES = 144 * 1024;                // tables that MUST fit for MODE 1
 
@@ -178,9 +187,14 @@ __device__ __forceinline__ void for_candidates(const GridDesc& g, const GridPtrs
 
 // NT lanes per workgroup: 1024, or 256 for problems of at most 256 rows (a 200-line problem would leave 12 of 16 waves
 // idle at every barrier -- and, in a batch, occupy a whole CU)
-template <int MODE, int NT>
-__global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ probs, uint32_t lds_words, const uint32_t* __restrict__ pre_arg)
+template <int MODE, int NT, bool BYVAL = false>
+__global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ probs, uint32_t lds_words, const uint32_t* __restrict__ pre_arg,
+                                                   uint32_t pre_slots, const GridDesc one)
 {
+    // BYVAL: ONE problem, its descriptor by value in `one` (a dependent round trip less in front of everything; a run-time
+    // choice between the two copies a 152-byte struct through private memory).
+    // pre_slots > 0: the list is k_grid_records': pre_slots words per item of the grid's CSR list (records first, KEY_NONE behind
+    // them), then pre[0] more words; 0: k_grid_candidates' dense list of pre[0] words.
     // pre != nullptr (one LDS-resident mutual problem alone on the chip, MODE 2): PA's distances were evaluated by
     // k_grid_candidates on many workgroups -- every candidate word lies in the second half of the problem's candidate store,
     // pre[0] = their number --, this kernel does the bookkeeping over them (candidate-parallel: first records, the filter of
@@ -196,18 +210,23 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     __shared__ uint32_t s_seg[NT / 64 + 1];          // flat mode: first LDS word of each wave's region
     PLSLAM_AS_LDS uint32_t* s_dyn = (PLSLAM_AS_LDS uint32_t*)reinterpret_cast<uint32_t*>(s_dyn4);
 
-    const GridDesc g = probs[blockIdx.x];
+    const GridDesc g = BYVAL ? one : probs[blockIdx.x];
     const int tid = (int)threadIdx.x, lane = tid & 63;
     const int32_t n1 = g.n1, n2 = g.n2;
     const int32_t ncell = g.cols * g.rows;
     const int32_t n_rounds = (n1 + NT - 1) / NT;
 #ifdef PLSLAM_GRID_TIMING   // experiment builds only: phase boundaries in 10 ns ticks, printed by one lane
-    uint64_t ts[6], t_move = 0, tp[16];
+    uint64_t ts[6], t_move = 0, tp[16], tc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t dbg_total = 0;
+    uint64_t t_cnt = 0;
+    int ntc = 0;
+#define COLS_STAMP() do { if (ntc < 8) tc[ntc++] = wall_clock64(); } while (0)
     const uint64_t c_start = clock64();
     int nts = 0, npass = 0;
 #define GRID_STAMP() do { if (nts < 6) ts[nts++] = wall_clock64(); } while (0)
 #else
 #define GRID_STAMP() do { } while (0)
+#define COLS_STAMP() do { } while (0)
 #endif
     GRID_STAMP();
     PLSLAM_AS_GLOBAL uint32_t* gscratch = (PLSLAM_AS_GLOBAL uint32_t*)g.scratch;
@@ -292,7 +311,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         }
         return reg_off + free_words * before / (uint32_t)(n_tasks > 0 ? n_tasks : 1);   // < 2^16 words x <= 8192 tasks: 32 bits do
     };
-    if (tid <= (int)NW) s_seg[tid] = seg_at((uint32_t)tid);             // (read behind P0's barrier)
+    // (read behind P0's barrier; a listed problem that takes the column-bucketed bookkeeping never needs them -- the loop
+    // and its divisions on 17 lanes would hold the other waves at that barrier --: it fills them in if it falls back)
     uint32_t seg_first = 0;
     // candidate k of this wave: its LDS region first, then its share of the global store
     auto cand_load = [&](uint32_t k) -> uint32_t {
@@ -304,7 +324,26 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     };
 
     // ---- P0: tables ----
-    if constexpr (LDS) {
+    // A listed problem whose PC never counts rows without candidates (nnr <= 1) reads nothing of the grid here: the column-
+    // bucketed bookkeeping below takes the LDS behind the row words, cell_start copy included.  Its list's length, the first
+    // COLS_EARLY words per lane of the list and the grid's item count are requested NOW: one round trip under the table
+    // initialisation instead of three behind it.
+    constexpr uint32_t COLS_HOLD = 32, COLS_EARLY = 12;
+    const bool count_empty = 2147483647.0 < 2147483647.0 * g.nnr;     // PC's nnr > 1 rule
+    const bool cols_maybe = PLSLAM_GRID_COLUMNS && MODE == 2 && NT == 1024 && pre != nullptr && !count_empty;
+    const uint32_t col_off = 2u * (uint32_t)(n2 + n1);
+    uint32_t c_early[COLS_EARLY], total_early = 0, items_end_early = 0;
+    if (cols_maybe) {
+        total_early = ((PLSLAM_AS_GLOBAL const uint32_t*)pre)[0];
+        items_end_early = (uint32_t)g_cell_start[ncell];
+        PLSLAM_AS_GLOBAL const uint32_t* raw = store + (uint32_t)g.pair_cap;
+#pragma unroll
+        for (uint32_t j = 0; j < COLS_EARLY; ++j) {
+            const uint32_t k = (uint32_t)tid + j * NT;
+            c_early[j] = k < (uint32_t)g.pair_cap ? raw[k] : KEY_NONE;      // (words behind the list's end: masked later)
+        }
+    }
+    if (LDS && !cols_maybe) {
         for (int32_t j = tid; j <= ncell; j += NT) s_dyn[2 * (n2 + n1) + j] = (uint32_t)g_cell_start[j];
     }
     if (MODE == 2 && !pre) {
@@ -321,17 +360,22 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     for (int32_t j = tid; j < n2; j += NT) {
         P.state[j] = KEY_NONE;
         P.next[j] = KEY_NONE;
-        if (flat) colbest[j] = KEY_NONE;
+        if (flat && !cols_maybe) colbest[j] = KEY_NONE;
     }
+    if (cols_maybe)
+        for (int32_t j = tid; j <= n2; j += NT) s_dyn[col_off + j] = 0u;          // the columns' counts
     if (tid < (int)NW) s_cur[tid] = 0u;
     for (int32_t i = tid; i < n1; i += NT) {
         P.row_k1[i] = KEY_NONE;
         P.row_k2[i] = KEY_NONE;
     }
+    if (!cols_maybe && tid <= (int)NW) s_seg[tid] = seg_at((uint32_t)tid);
     __syncthreads();
-    seg_first = s_seg[wv];
-    seg_words = s_seg[wv + 1] - seg_first;                  // this wave's region
-    if ((uint32_t)P.cs[ncell] > (uint32_t)g.n_items) {      // the grid holds more items than the caller declared
+    if (!cols_maybe) {
+        seg_first = s_seg[wv];
+        seg_words = s_seg[wv + 1] - seg_first;              // this wave's region
+    }
+    if ((cols_maybe ? items_end_early : (uint32_t)P.cs[ncell]) > (uint32_t)g.n_items) {      // the grid holds more items than the caller declared
         for (int32_t i = tid; i < n1; i += NT) g_matches[i] = -1;
         if (tid == 0) {
             if (g.n_matches) *g_(g.n_matches) = -1;
@@ -344,17 +388,31 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     // ---- PA: distances ----
     uint32_t store_words = 0;        // slots claimed so far (uniform)
     uint32_t has_items = 0;          // bit r: this lane's row of round r has grid items inside its windows (mutual only)
+    bool cols_done = false;          // (uniform) the column-bucketed path has produced the records and the rows' best two
+    bool cols_fast = false;          // (uniform) ... straight from k_grid_records' list: a column's state is d << fb1 | row
     if (flat) {
-        const bool count_empty = 2147483647.0 < 2147483647.0 * g.nnr;     // PC's nnr > 1 rule needs to know (cell_start is gone by then)
-        if (count_empty)
+        if (count_empty)                                                  // PC's nnr > 1 rule needs to know (cell_start is gone by then)
             for (int32_t r = 0; r < n_rounds && r < 32; ++r)
                 if (r * NT + tid < n1 && count_items(g, P, r * NT + tid) > 0u) has_items |= 1u << r;
         if (pre) {
             // the candidate words of k_grid_candidates: bookkeeping in two candidate-parallel sweeps.  First every candidate
             // proposes itself as its column's first record and shows its (d, row) to colbest; then, colbest being final, a
             // candidate that an earlier row matches or beats is dropped and the others go to the waves' regions, evenly.
-            const uint32_t total = *(PLSLAM_AS_GLOBAL const uint32_t*)pre;
+            // (the grid's item count has been checked against the caller's n_items, at most 2^31, by now)
+            const uint32_t n_slots = pre_slots * (cols_maybe ? items_end_early : pre_slots ? (uint32_t)P.cs[ncell] : 0u);
+            const uint64_t total64 = (uint64_t)n_slots + (cols_maybe ? total_early : *(PLSLAM_AS_GLOBAL const uint32_t*)pre);
+            const uint32_t total = total64 > (uint64_t)(uint32_t)g.pair_cap ? (uint32_t)g.pair_cap + 1u : (uint32_t)total64;
+#ifdef PLSLAM_GRID_TIMING
+            dbg_total = total;
+#endif
             PLSLAM_AS_GLOBAL const uint32_t* raw = store + (uint32_t)g.pair_cap;
+#ifdef PLSLAM_GRID_DEBUG_LIST
+            if (tid == 0 && n2 <= 4) {
+                printf("[list] n1 %d n2 %d slots %u total %u pair_cap %d items_end %u overflow %u:", n1, n2, n_slots, total, g.pair_cap, items_end_early, total_early);
+                for (uint32_t k = 0; k < total && k < 40; ++k) printf(" %08x", raw[k]);
+                printf("\n");
+            }
+#endif
             if (total > (uint32_t)g.pair_cap) {                         // (uniform) the list did not fit: report, match nothing
                 for (int32_t i = tid; i < n1; i += NT) g_matches[i] = -1;
                 if (tid == 0) {
@@ -364,10 +422,219 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                 return;
             }
             const uint32_t mk1 = (1u << fb1) - 1u, mk2 = (1u << fb2) - 1u;
+            // ---- the list fits LDS whole (a keyframe pair's ~28 k candidates do; the ~5 k records k_grid_records leaves of them
+            // easily): bucket it by COLUMN and read each column's records off its own segment, no passes over the whole list.
+            // A column's records are, by the definition the passes implement, r_1 = min (i1 << 9 | d) over its candidates,
+            // r_{k+1} = that min over the candidates with d below r_k's; its live candidates are exactly its records (they join
+            // their rows' best two), its final state is the last one.  The counting sort: per-column counts by LDS atomics, an
+            // exclusive scan, a second round of atomics for the places; the list itself is read ONCE, into registers
+            // (COLS_HOLD words per lane).  The segments lie over the cell_start copy's place and everything behind it.
+            // ---- the shortest way: the list is k_grid_records', and no column has two runs (every item of the grid in one
+            // cell: points).  The list then holds each column's records and nothing else -- no liveness to settle: every word
+            // joins its row's best two, a column's state is its smallest (d, row).  Whether a column has two runs shows in the
+            // same sweep (the first word of an item's slots is a record iff the run has any; the counts P0 zeroed take them);
+            // if one has, the tables are wiped and the bucketed bookkeeping below runs.
+            if (PLSLAM_GRID_FAST && cols_maybe && pre_slots > 0u && total <= COLS_EARLY * NT) {
+                PLSLAM_AS_LDS uint32_t* off = s_dyn + col_off;
+                bool dup = false;
+#pragma unroll
+                for (uint32_t j = 0; j < COLS_EARLY; ++j) {
+                    if (j * NT >= total) break;
+                    const uint32_t k = (uint32_t)tid + j * NT;
+                    if (k < total && c_early[j] != KEY_NONE) {
+                        const uint32_t i2 = c_early[j] & mk2, i1 = (c_early[j] >> fb2) & mk1, d = c_early[j] >> (fb1 + fb2);
+                        const uint32_t key = (d << KEY_IDX_BITS) | i2;
+                        if (k < n_slots && (k & (pre_slots - 1u)) == 0u) dup = dup || atomicAdd((uint32_t*)&off[i2], 1u) != 0u;
+                        atomicMin((uint32_t*)&P.state[i2], (d << fb1) | i1);
+                        const uint32_t was = atomicMin((uint32_t*)&P.row_k1[i1], key);
+                        if (was != key) atomicMin((uint32_t*)&P.row_k2[i1], was > key ? was : key);
+                    }
+                }
+                if (__syncthreads_or(dup)) {
+                    for (int32_t j = tid; j < n2; j += NT) P.state[j] = KEY_NONE;
+                    for (int32_t j = tid; j <= n2; j += NT) off[j] = 0u;
+                    for (int32_t i = tid; i < n1; i += NT) {
+                        P.row_k1[i] = KEY_NONE;
+                        P.row_k2[i] = KEY_NONE;
+                    }
+                    __syncthreads();
+                } else {
+                    cols_done = true;
+                    cols_fast = true;
+                }
+            }
+            if (!cols_done && cols_maybe && total <= COLS_HOLD * NT && (uint64_t)col_off + (uint32_t)n2 + 1u + total <= (uint64_t)lds_words) {
+                PLSLAM_AS_LDS uint32_t* off = s_dyn + col_off;              // n2 + 1: counts (zeroed by P0), then the segments' first words
+                PLSLAM_AS_LDS uint32_t* seg = off + n2 + 1;
+                uint32_t c[COLS_HOLD];
+#ifdef PLSLAM_GRID_TIMING
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                const uint32_t nj = (total + NT - 1) / NT;                  // (uniform) words per lane that exist at all: the unrolled
+                COLS_STAMP();                                              // steps behind them are skipped, not predicated away
+#pragma unroll
+                for (uint32_t j = 0; j < COLS_EARLY; ++j) c[j] = (uint32_t)tid + j * NT < total ? c_early[j] : KEY_NONE;
+#pragma unroll
+                for (uint32_t j = COLS_EARLY; j < COLS_HOLD; ++j) c[j] = KEY_NONE;
+                if (total > COLS_EARLY * NT) {
+#pragma unroll
+                    for (uint32_t j = COLS_EARLY; j < COLS_HOLD; ++j) {
+                        const uint32_t k = (uint32_t)tid + j * NT;
+                        c[j] = k < total ? raw[k] : KEY_NONE;
+                    }
+                }
+                COLS_STAMP();
+#pragma unroll
+                for (uint32_t j = 0; j < COLS_HOLD; ++j)
+                    if (j < nj && c[j] != KEY_NONE) atomicAdd((uint32_t*)&off[c[j] & mk2], 1u);
+#ifdef PLSLAM_GRID_TIMING
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                t_cnt = wall_clock64();
+#endif
+                __syncthreads();
+                COLS_STAMP();
+                {   // exclusive scan of the counts: a run of columns per lane, wave scans, the waves' totals through s_part
+                    const int32_t per = (n2 + NT - 1) / NT, b = tid * per, e = b + per < n2 ? b + per : n2;
+                    uint32_t sum = 0;
+                    for (int32_t j = b; j < e; ++j) sum += off[j];
+                    uint32_t incl = sum;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+                        if (lane >= o) incl += t;
+                    }
+                    if (lane == 63) s_part[wv] = incl;
+                    __syncthreads();
+                    uint32_t run = incl - sum;
+                    for (uint32_t w = 0; w < wv; ++w) run += s_part[w];
+                    for (int32_t j = b; j < e; ++j) {
+                        const uint32_t k = off[j];
+                        off[j] = run;
+                        P.next[j] = run;                                  // the column's cursor
+                        run += k;
+                    }
+                    if (tid == NT - 1) off[n2] = run;                     // every word that is not KEY_NONE (lanes behind the last column: all of them)
+                    __syncthreads();
+                }
+                COLS_STAMP();
+#pragma unroll
+                for (uint32_t j = 0; j < COLS_HOLD; ++j)
+                    if (j < nj && c[j] != KEY_NONE) {
+                        const uint32_t i2 = c[j] & mk2, i1 = (c[j] >> fb2) & mk1, d = c[j] >> (fb1 + fb2);
+                        seg[atomicAdd((uint32_t*)&P.next[i2], 1u)] = (i1 << REC_D_BITS) | d;
+                    }
+                __syncthreads();
+                COLS_STAMP();
+                // A lane per column; the segment goes to registers once (REG_N words, chunks of 8 that no lane of the wave
+                // needs are skipped).
+                constexpr int REG_N = 32, CHUNK = 8;
+                for (int32_t base2 = 0; base2 < n2; base2 += NT) {
+                    const int32_t i2 = base2 + tid;
+                    const bool act = i2 < n2;
+                    const uint32_t b = act ? off[i2] : 0u, e = act ? off[i2 + 1] : 0u, len = e - b;
+                    bool need[REG_N / CHUNK];
+#pragma unroll
+                    for (int q = 0; q < REG_N / CHUNK; ++q) need[q] = __any(len > (uint32_t)(q * CHUNK)) != 0;
+                    uint32_t w[REG_N], dd[REG_N];
+#pragma unroll
+                    for (int q = 0; q < REG_N / CHUNK; ++q) {
+                        if (need[q]) {
+#pragma unroll
+                            for (int j = q * CHUNK; j < (q + 1) * CHUNK; ++j) {
+                                const uint32_t v = seg[b + ((uint32_t)j < len ? (uint32_t)j : 0u)];   // (len 0: any word, unused)
+                                w[j] = (uint32_t)j < len ? v : KEY_NONE;
+                                dd[j] = (uint32_t)j < len ? v & REC_D_MASK : REC_D_MASK + 1u;
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = q * CHUNK; j < (q + 1) * CHUNK; ++j) {
+                                w[j] = KEY_NONE;
+                                dd[j] = REC_D_MASK + 1u;
+                            }
+                        }
+                    }
+                    uint32_t last = KEY_NONE;
+                    if (!need[1]) {
+                        // (uniform) segments of at most 8 words -- what k_grid_records leaves: sort them (w = row << 9 | d orders
+                        // by row; 19 compare-exchanges, a min and a max each), then a word is a record iff its distance is below
+                        // every earlier word's.  No sweeps, and the records' atomics go out together: two LDS round trips.
+#define GRID_CE(a, b) do { const uint32_t lo_ = w[a] < w[b] ? w[a] : w[b], hi_ = w[a] < w[b] ? w[b] : w[a]; w[a] = lo_; w[b] = hi_; } while (0)
+                        GRID_CE(0, 1); GRID_CE(2, 3); GRID_CE(4, 5); GRID_CE(6, 7);
+                        GRID_CE(0, 2); GRID_CE(1, 3); GRID_CE(4, 6); GRID_CE(5, 7);
+                        GRID_CE(1, 2); GRID_CE(5, 6);
+                        GRID_CE(0, 4); GRID_CE(1, 5); GRID_CE(2, 6); GRID_CE(3, 7);
+                        GRID_CE(2, 4); GRID_CE(3, 5);
+                        GRID_CE(1, 2); GRID_CE(3, 4); GRID_CE(5, 6);
+#undef GRID_CE
+                        uint32_t run = REC_D_MASK + 1u, was[CHUNK];
+                        bool live[CHUNK];
+#pragma unroll
+                        for (int j = 0; j < CHUNK; ++j) {
+                            const uint32_t dj = w[j] == KEY_NONE ? REC_D_MASK + 1u : w[j] & REC_D_MASK;
+                            live[j] = dj < run;
+                            if (live[j]) last = w[j];                                         // (the last record: the last live word)
+                            run = dj < run ? dj : run;
+                            dd[j] = dj;
+                        }
+#pragma unroll
+                        for (int j = 0; j < CHUNK; ++j) {
+                            const uint32_t key = (dd[j] << KEY_IDX_BITS) | (uint32_t)i2;
+                            was[j] = key;
+                            if (live[j]) was[j] = atomicMin((uint32_t*)&P.row_k1[w[j] >> REC_D_BITS], key);
+                        }
+#pragma unroll
+                        for (int j = 0; j < CHUNK; ++j) {
+                            const uint32_t key = (dd[j] << KEY_IDX_BITS) | (uint32_t)i2;
+                            if (live[j] && was[j] != key) atomicMin((uint32_t*)&P.row_k2[w[j] >> REC_D_BITS], was[j] > key ? was[j] : key);
+                        }
+                    } else {
+                        // a sweep is a compare, a select and a min per word; lanes whose column is done idle until the wave's
+                        // last column is (a column of ~19 candidates has ~3.5 records, the worst of 64 about 8)
+                        uint32_t cur_d = len ? REC_D_MASK + 1u : 0u;
+                        while (__any(cur_d != 0u)) {
+                            uint32_t best = KEY_NONE;
+#pragma unroll
+                            for (int q = 0; q < REG_N / CHUNK; ++q) {
+                                if (need[q]) {
+#pragma unroll
+                                    for (int j = q * CHUNK; j < (q + 1) * CHUNK; ++j) {
+                                        const uint32_t t = dd[j] < cur_d ? w[j] : KEY_NONE;
+                                        best = t < best ? t : best;
+                                    }
+                                }
+                            }
+                            if (len > (uint32_t)REG_N && cur_d)                               // (rare) the rest from LDS
+                                for (uint32_t k = b + REG_N; k < e; ++k) {
+                                    const uint32_t v = seg[k];
+                                    if ((v & REC_D_MASK) < cur_d && v < best) best = v;
+                                }
+                            if (best != KEY_NONE) {
+                                cur_d = best & REC_D_MASK;
+                                last = best;
+                                const uint32_t key = (cur_d << KEY_IDX_BITS) | (uint32_t)i2, i1 = best >> REC_D_BITS;
+                                const uint32_t was = atomicMin((uint32_t*)&P.row_k1[i1], key);
+                                if (was != key) atomicMin((uint32_t*)&P.row_k2[i1], was > key ? was : key);
+                            } else
+                                cur_d = 0u;
+                        }
+                    }
+                    if (act) P.state[i2] = last;
+                }
+                cols_done = true;
+                __syncthreads();
+                COLS_STAMP();
+            } else if (cols_maybe && !cols_done) {                        // (uniform) the passes after all: what P0 left out
+                __syncthreads();
+                for (int32_t j = tid; j < n2; j += NT) colbest[j] = KEY_NONE;
+                if (tid <= (int)NW) s_seg[tid] = seg_at((uint32_t)tid);
+                __syncthreads();
+                seg_first = s_seg[wv];
+                seg_words = s_seg[wv + 1] - seg_first;
+            }
             // (the list comes from L2: PRE_UN independent loads in flight per lane -- one load per loop trip made the two sweeps
             // 18 us of dependent round trips)
             constexpr int PRE_UN = 8;
-            for (uint32_t k0 = (uint32_t)tid; k0 < total; k0 += NT * PRE_UN) {
+            for (uint32_t k0 = (uint32_t)tid; k0 < (cols_done ? 0u : total); k0 += NT * PRE_UN) {
                 uint32_t c[PRE_UN];
 #pragma unroll
                 for (int j = 0; j < PRE_UN; ++j) c[j] = k0 + (uint32_t)j * NT < total ? raw[k0 + (uint32_t)j * NT] : KEY_NONE;
@@ -380,7 +647,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                     }
             }
             __syncthreads();
-            const uint32_t lo = (uint32_t)((uint64_t)total * wv / NW), hi = (uint32_t)((uint64_t)total * (wv + 1) / NW);
+            const uint32_t lo = cols_done ? 0u : (uint32_t)((uint64_t)total * wv / NW);
+            const uint32_t hi = cols_done ? 0u : (uint32_t)((uint64_t)total * (wv + 1) / NW);
             const uint64_t below_ = (1ull << lane) - 1ull;
             uint32_t out = 0;
             for (uint32_t base = lo; base < hi; base += 64 * PRE_UN) {
@@ -535,7 +803,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     GRID_STAMP();
 
     // ---- PB: record passes ----
-    if (g.mutual) {
+    if (g.mutual && !cols_done) {
         // one row's share of a pass: stream its remaining candidates from `slot` (stride apart), keep the survivors
         // in `out`; returns how many
         auto pass_row = [&](int32_t i1, auto slot, auto out, auto at, uint32_t cnt) -> uint32_t {
@@ -741,7 +1009,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
             const double best_d2 = k2 == KEY_NONE ? 2147483647.0 : (double)(int32_t)(k2 >> KEY_IDX_BITS);
             if (best_d < best_d2 * g.nnr) {
                 const int32_t i2 = (int32_t)(k1 & KEY_IDX_MASK);
-                if (!g.mutual || (P.state[i2] >> REC_D_BITS) == (uint32_t)i1) m = i2;
+                if (!g.mutual || (cols_fast ? P.state[i2] & ((1u << fb1) - 1u) : P.state[i2] >> REC_D_BITS) == (uint32_t)i1) m = i2;
             }
         }
         else if (2147483647.0 < 2147483647.0 * g.nnr &&
@@ -751,18 +1019,27 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
         g_matches[i1] = m;
         cnt += m >= 0;
     }
-    s_part[tid] = cnt;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+    __syncthreads();                                         // (s_part may still be read as the scan's wave totals)
+    if (lane == 0) s_part[tid >> 6] = cnt;
     __syncthreads();
-    for (int st = NT / 2; st > 0; st >>= 1) {
-        if (tid < st) s_part[tid] += s_part[tid + st];
-        __syncthreads();
+    if (tid == 0 && g.n_matches) {
+        uint32_t all = 0;
+        for (int w = 0; w < NT / 64; ++w) all += s_part[w];
+        *g_(g.n_matches) = (int32_t)all;
     }
-    if (tid == 0 && g.n_matches) *g_(g.n_matches) = (int32_t)s_part[0];
     GRID_STAMP();
 #ifdef PLSLAM_GRID_TIMING
     if (tid == 0 && (blockIdx.x == 0 || (blockIdx.x & 1023) == 600))
         printf("[k_match_grid n1=%d n2=%d] P0 %d PA %d PB %d (move %d, %d passes) PC %d (x10 ns)\n", n1, n2, (int)(ts[1] - ts[0]),
                (int)(ts[2] - ts[1]), (int)(ts[3] - ts[2]), t_move ? (int)(t_move - ts[2]) : -1, npass, (int)(ts[4] - ts[3]));
+    if (tid == 0 && blockIdx.x == 0 && pre)
+        printf("   columns path %d: %u candidates, lds %u words | load %d count %d scan %d place %d records %d (since PA began: %d)\n",
+               (int)cols_done + (int)cols_fast, dbg_total, lds_words, (int)(tc[1] - tc[0]), (int)(tc[2] - tc[1]), (int)(tc[3] - tc[2]), (int)(tc[4] - tc[3]),
+               (int)(tc[5] - tc[4]), (int)(tc[0] - ts[1]));
+    if (tid == 0 && blockIdx.x == 0 && pre)
+        printf("   count: atomics done %d after the loads' stamp; %d shader MHz\n", (int)(t_cnt - tc[1]), (int)((clock64() - c_start) / ((wall_clock64() - ts[0]) / 100)));
     if (tid == 0 && (blockIdx.x == 0 || (blockIdx.x & 1023) == 600) && t_move) {
         printf("   passes:");
         for (int i = 0; i < npass && i < 16; ++i) printf(" %d", (int)(tp[i] - (i ? tp[i - 1] : t_move)));
@@ -771,6 +1048,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     }
 #endif
 #undef GRID_STAMP
+#undef COLS_STAMP
 }
 
 
@@ -850,6 +1128,227 @@ __global__ __launch_bounds__(256) void k_grid_candidates(const GridDesc* __restr
     __syncthreads();
     for (uint32_t k = (uint32_t)tid; k < n; k += 256u)
         if (s_base + k < (uint32_t)g.pair_cap) raw[s_base + k] = s_buf[k];
+}
+
+
+// The same list, pre-filtered, COLUMN-wise: a workgroup per REC_G vertically adjacent grid cells.  The rows whose windows
+// touch the group come out of one sweep over every row's window centres (a few KB from L2; each wave sweeps a quarter of the
+// rows and compacts its finds IN ROW ORDER, each with the mask of the group's cells its windows hold); a wave then takes a
+// column (an item of one of the cells), evaluates its distance to those rows -- lane j the j-th row -- and a prefix minimum
+// across the lanes says which of them are the column's records (d below every earlier row's): those words alone are kept.  A
+// column of ~19 candidates has ~3 records, so what k_match_grid bookkeeps shrinks from ~28 k to ~4 k words for a keyframe
+// pair, and no lane walks the dependent chain centre -> cell offsets -> items -> desc2 rows of k_grid_candidates.
+// What k_match_grid needs: every live candidate, and candidates only.  A column whose item sits in SEVERAL cells (line
+// segments) gets the records of each cell's row set -- a superset of its records (a record of the union is a record of any
+// subset that holds it), and the bookkeeping downstream drops the rest: a dead candidate has an earlier RECORD at or below its
+// distance, and every record is kept.
+// Where they go: item k of the grid's CSR list (one (cell, column) run) owns words k * REC_SLOT ... + REC_SLOT - 1 of the list,
+// records first, KEY_NONE behind them -- no counter to claim, nothing returns to the wave (a round trip of a global atomic is
+// ~1 us here, and every workgroup of the launch wanted the same word).  The records a run has beyond REC_SLOT (a column in a
+// hundred) are appended behind the last item's words, aux[0] counting them.  The FIRST word of an item's slots is a record
+// exactly when the run has any: k_match_grid counts those per column to see whether a column has one run (the list then holds
+// its records and nothing else) or several.
+// The descriptor comes BY VALUE (kernel arguments): one dependent round trip less in front of everything.
+constexpr int REC_NT = 256;
+constexpr int REC_G = 8;                            // cells per workgroup: same grid column x, consecutive y
+constexpr int REC_ROWS_MAX = 4096;                  // rows of a problem that takes this path (the row lists of a group: 12 KB of LDS)
+constexpr uint32_t REC_SLOT = 8;                    // list words per item of the grid (a power of two)
+static_assert((REC_SLOT & (REC_SLOT - 1)) == 0, "");
+constexpr int64_t REC_GROUPS_MAX = 1 << 16;         // beyond this k_grid_candidates lists the pairs
+__global__ __launch_bounds__(REC_NT) void k_grid_records(const GridDesc g, uint32_t* __restrict__ aux)
+{
+    constexpr int NW = REC_NT / 64, PER_WAVE = REC_ROWS_MAX / NW, SWEEP_UN = 8;
+    static_assert(REC_G <= 8, "a row's cells fit an 8-bit mask");
+    __shared__ uint16_t s_rows[NW][PER_WAVE];         // wave w's finds among rows [w * q, (w + 1) * q), ascending
+    __shared__ uint8_t s_mask[NW][PER_WAVE];
+    __shared__ int32_t s_cs[REC_G + 1];
+    __shared__ uint32_t s_wn[NW];
+#ifdef PLSLAM_GRID_TIMING
+    uint64_t tr[8];
+    int ntr = 0;
+#define REC_STAMP() do { if (ntr < 8) tr[ntr++] = wall_clock64(); } while (0)
+#else
+#define REC_STAMP() do { } while (0)
+#endif
+    REC_STAMP();
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int32_t n1 = g.n1, n2 = g.n2;
+    const int32_t ncell = g.cols * g.rows;
+    const uint32_t fb2 = n2 > 1 ? 32u - (uint32_t)__builtin_clz((uint32_t)n2 - 1u) : 1u;        // bits of a column number (at least 1)
+    const uint32_t fb1 = 23u - fb2 > 14u ? 14u : 23u - fb2;
+    if (!(g.mutual && fb2 <= 22u && (uint32_t)n1 <= (1u << fb1)) || n1 > REC_ROWS_MAX) return;   // (launcher: never)
+    PLSLAM_AS_GLOBAL const int32_t* cs = (PLSLAM_AS_GLOBAL const int32_t*)g.cell_start;
+    PLSLAM_AS_GLOBAL const int32_t* items = (PLSLAM_AS_GLOBAL const int32_t*)g.cell_items;
+    PLSLAM_AS_GLOBAL const int32_t* centres = (PLSLAM_AS_GLOBAL const int32_t*)g.centres;
+    PLSLAM_AS_GLOBAL const u32x4* g_d1 = (PLSLAM_AS_GLOBAL const u32x4*)g.d1;
+    PLSLAM_AS_GLOBAL const u32x4* g_d2 = (PLSLAM_AS_GLOBAL const u32x4*)g.d2;
+    PLSLAM_AS_GLOBAL const double* dir1 = (PLSLAM_AS_GLOBAL const double*)g.dir1;
+    PLSLAM_AS_GLOBAL const double* dir2 = (PLSLAM_AS_GLOBAL const double*)g.dir2;
+    const bool dirs = g.dir1 != nullptr && g.dir2 != nullptr;
+    PLSLAM_AS_GLOBAL uint32_t* rcnt = (PLSLAM_AS_GLOBAL uint32_t*)g.scratch;       // (the layout k_grid_candidates writes)
+    PLSLAM_AS_GLOBAL uint32_t* raw = rcnt + n1 + (n1 + GRID_THREADS - 1) / GRID_THREADS + (uint32_t)g.pair_cap;
+    const int32_t gpc = (g.rows + REC_G - 1) / REC_G;                   // groups per grid column
+    const int32_t cx = (int32_t)blockIdx.x / gpc, cy0 = ((int32_t)blockIdx.x - cx * gpc) * REC_G;
+    if (cx >= g.cols) return;
+    const int32_t ng = g.rows - cy0 < REC_G ? g.rows - cy0 : REC_G, cell0 = cx * g.rows + cy0;
+    // the group's slice of the CSR list and this wave's first rows' centres: requested together
+    const int32_t it_all = cs[ncell], it_begin = cs[cell0], it_end = cs[cell0 + ng];
+    const int32_t my_cs = tid <= ng ? cs[cell0 + tid] : 0;
+    const int32_t q = (n1 + NW - 1) / NW, r_begin = wv * q, r_end = r_begin + q < n1 ? r_begin + q : n1;
+    const bool one_centre = g.n_centres == 1;
+    int32_t cxy[SWEEP_UN][2];
+    if (one_centre) {
+#pragma unroll
+        for (int k = 0; k < SWEEP_UN; ++k) {
+            const int32_t r = r_begin + k * 64 + lane;
+            cxy[k][0] = cxy[k][1] = 0;
+            if (r < r_end) {
+                cxy[k][0] = centres[2 * (int64_t)r];
+                cxy[k][1] = centres[2 * (int64_t)r + 1];
+            }
+        }
+    }
+    if ((uint32_t)it_all > (uint32_t)g.n_items || it_begin >= it_end) return;    // (an inconsistent grid: k_match_grid reports it)
+    if (tid <= ng) s_cs[tid] = my_cs;
+    REC_STAMP();
+    // this wave's first column: its number now, its descriptor as soon as that is here -- both under the sweep below
+    const int32_t k_first = it_begin + wv;
+    const int32_t i2_first = k_first < it_end ? items[k_first] : -1;
+
+    // ---- the rows whose windows touch the group, each with the mask of the cells it reaches ----
+    // (cell (cx, cy) of the grid lies in a centre's clamped window [min, max) exactly when cx - x is in [-w0, w1] and cy - y in
+    // [-w2, w3]: the clamps of window_of only cut what no cell index reaches)
+    auto cells_of = [&](int64_t x, int64_t y) -> uint32_t {
+        const int64_t dx = (int64_t)cx - x;
+        int64_t lo = y - g.w[2], hi = y + g.w[3];
+        lo = lo > cy0 ? lo : cy0;
+        hi = hi < cy0 + ng - 1 ? hi : cy0 + ng - 1;
+        if (dx >= -(int64_t)g.w[0] && dx <= (int64_t)g.w[1] && lo <= hi)
+            return ((2u << (uint32_t)(hi - cy0)) - 1u) & ~((1u << (uint32_t)(lo - cy0)) - 1u);
+        return 0u;
+    };
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t found = 0;                               // (uniform) this wave's finds so far
+    auto keep = [&](int32_t r, uint32_t mask) {
+        const uint64_t b = __ballot(mask != 0u);
+        if (mask) {
+            const uint32_t pos = found + (uint32_t)__popcll(b & below);
+            s_rows[wv][pos] = (uint16_t)r;
+            s_mask[wv][pos] = (uint8_t)mask;
+        }
+        found += (uint32_t)__popcll(b);
+    };
+    if (one_centre) {
+#pragma unroll
+        for (int k = 0; k < SWEEP_UN; ++k) {
+            if (r_begin + k * 64 >= r_end) break;
+            const int32_t r = r_begin + k * 64 + lane;
+            keep(r, r < r_end ? cells_of(cxy[k][0], cxy[k][1]) : 0u);
+        }
+    }
+    for (int32_t r0 = r_begin + (one_centre ? SWEEP_UN * 64 : 0); r0 < r_end; r0 += 64) {      // (many rows, or several centres a row)
+        const int32_t r = r0 + lane;
+        uint32_t mask = 0;
+        if (r < r_end)
+            for (int32_t c = 0; c < g.n_centres; ++c) {
+                PLSLAM_AS_GLOBAL const int32_t* p = centres + ((int64_t)r * g.n_centres + c) * 2;
+                mask |= cells_of(p[0], p[1]);
+            }
+        keep(r, mask);
+    }
+    if (lane == 0) s_wn[wv] = found;
+    REC_STAMP();
+    __syncthreads();
+    REC_STAMP();
+    uint32_t first_of[NW + 1];                        // the waves' finds, concatenated: row j of the group
+    first_of[0] = 0u;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) first_of[w + 1] = first_of[w] + s_wn[w];
+    const uint32_t n_rows = first_of[NW];
+    auto row_at = [&](uint32_t j, uint32_t& row, uint32_t& mk) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int t = 1; t < NW; ++t) w += j >= first_of[t] ? 1u : 0u;
+        uint32_t base = 0;
+#pragma unroll
+        for (int t = 1; t < NW; ++t) base = w == (uint32_t)t ? first_of[t] : base;
+        row = j < n_rows ? s_rows[w][j - base] : 0u;
+        mk = j < n_rows ? s_mask[w][j - base] : 0u;
+    };
+
+    // ---- a wave per column; lane j holds the j-th row (the first 64 rows' descriptors are loaded once) ----
+    uint32_t row_0, mask_0;
+    row_at((uint32_t)lane, row_0, mask_0);
+    const u32x4 qa_0 = g_d1[2 * (int64_t)row_0], qb_0 = g_d1[2 * (int64_t)row_0 + 1];
+    for (int32_t k = k_first; k < it_end; k += NW) {
+        const int32_t i2 = __builtin_amdgcn_readfirstlane(k == k_first ? i2_first : items[k]);
+        PLSLAM_AS_GLOBAL uint32_t* slot = raw + (uint64_t)(uint32_t)k * REC_SLOT;
+        const bool room = ((uint64_t)(uint32_t)k + 1u) * REC_SLOT <= (uint64_t)(uint32_t)g.pair_cap;    // (launcher: always)
+        uint32_t n_rec = 0;                            // (uniform) records of this run so far
+        if ((uint32_t)i2 < (uint32_t)n2) {
+            uint32_t cq = 0;                           // the cell of item k: how many of the group's inner boundaries lie at or below k
+            for (int32_t t = 1; t < ng; ++t) cq += k >= s_cs[t] ? 1u : 0u;
+            const uint32_t bit = 1u << cq;
+            const u32x4 ta = g_d2[2 * (int64_t)i2], tb = g_d2[2 * (int64_t)i2 + 1];
+            double b0 = 0.0, b1 = 0.0;
+            if (dirs) {
+                b0 = dir2[2 * (int64_t)i2];
+                b1 = dir2[2 * (int64_t)i2 + 1];
+            }
+            uint32_t carry = REC_D_MASK + 1u;          // the smallest distance of the rows before this chunk
+            for (uint32_t j0 = 0; j0 < n_rows && carry; j0 += 64) {
+                uint32_t row = row_0, mk = mask_0;
+                u32x4 qa = qa_0, qb = qb_0;
+                if (j0) {
+                    row_at(j0 + (uint32_t)lane, row, mk);
+                    qa = g_d1[2 * (int64_t)row];
+                    qb = g_d1[2 * (int64_t)row + 1];
+                }
+                bool valid = (mk & bit) != 0u;
+                const uint32_t d = (uint32_t)(__popc(qa.x ^ ta.x) + __popc(qa.y ^ ta.y) + __popc(qa.z ^ ta.z) + __popc(qa.w ^ ta.w) +
+                                              __popc(qb.x ^ tb.x) + __popc(qb.y ^ tb.y) + __popc(qb.z ^ tb.z) + __popc(qb.w ^ tb.w));
+                if (dirs) {
+                    const double a0 = dir1[2 * (int64_t)row], a1 = dir1[2 * (int64_t)row + 1];
+                    const double dot = a0 * b0 + a1 * b1;
+                    if (fabs(dot) < g.sim_th) valid = false;     // NaN (zero-length direction) compares false: kept
+                }
+                const uint32_t dm = valid ? d : REC_D_MASK + 1u;
+                uint32_t incl = dm;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+                    if (lane >= o) incl = t < incl ? t : incl;
+                }
+                uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
+                if (lane == 0) excl = REC_D_MASK + 1u;
+                excl = excl < carry ? excl : carry;
+                const bool rec = valid && d < excl;
+                const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                carry = all < carry ? all : carry;
+                const uint64_t m = __ballot(rec);
+                if (rec) {
+                    const uint32_t pos = n_rec + (uint32_t)__popcll(m & below);
+                    const uint32_t word = (d << (fb1 + fb2)) | (row << fb2) | (uint32_t)i2;
+                    if (pos < REC_SLOT) {
+                        if (room) slot[pos] = word;
+                    } else {                                      // beyond the run's own words: behind the last item's
+                        const uint64_t gp = (uint64_t)(uint32_t)it_all * REC_SLOT + (uint32_t)atomic_add_global(aux, 1);
+                        if (gp < (uint64_t)(uint32_t)g.pair_cap) raw[gp] = word;
+                    }
+                }
+                n_rec += (uint32_t)__popcll(m);
+            }
+        }
+        if (room && (uint32_t)lane < REC_SLOT && (uint32_t)lane >= n_rec) slot[lane] = KEY_NONE;
+    }
+    REC_STAMP();
+#ifdef PLSLAM_GRID_TIMING
+    if (tid == 0 && (blockIdx.x % 97) == 5)
+        printf("[k_grid_records group %d: %d items, %u rows] start %llu | args+cs %d sweep %d barrier %d columns %d (x10 ns)\n",
+               (int)blockIdx.x, it_end - it_begin, n_rows, (unsigned long long)(tr[0] % 100000000ull), (int)(tr[1] - tr[0]), (int)(tr[2] - tr[1]),
+               (int)(tr[3] - tr[2]), (int)(tr[4] - tr[3]));
+#endif
+#undef REC_STAMP
 }
 
 }  // namespace
@@ -960,21 +1459,31 @@ size_t grid_group_lds_bytes(int group, int32_t n1, int32_t n2, int64_t ncell, in
     return b;
 }
 
+// one: the descriptor of a lone problem by value (d_probs is not read then); pre / pre_slots: its listed candidates
 template <int MODE, int NT>
-static int launch_group(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hipStream_t s, const uint32_t* pre = nullptr)
+static int launch_group(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hipStream_t s, const uint32_t* pre = nullptr,
+                        uint32_t pre_slots = 0, const GridDesc* one = nullptr)
 {
     if (n <= 0) return PLSLAM_OK;
     if (MODE > 0) {
         static std::once_flag once;
         static hipError_t attr = hipSuccess;
         std::call_once(once, [] {
-            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_grid<MODE, NT>),
+            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_grid<MODE, NT, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRID_LDS_MAX_BYTES);
+            if (attr == hipSuccess && MODE == 2 && NT == 1024)
+                attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_grid<2, 1024, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)GRID_LDS_MAX_BYTES);
         });
         PLSLAM_HIP_CHECK(attr);
     }
-    hipLaunchKernelGGL((k_match_grid<MODE, NT>), dim3((unsigned)n), dim3(NT), lds_bytes, s, d_probs,
-                       (uint32_t)(lds_bytes / 4), pre);
+    static const GridDesc none{};
+    if (one && MODE == 2 && NT == 1024)
+        hipLaunchKernelGGL((k_match_grid<2, 1024, true>), dim3(1), dim3(1024), lds_bytes, s, nullptr, (uint32_t)(lds_bytes / 4), pre,
+                           pre_slots, *one);
+    else
+        hipLaunchKernelGGL((k_match_grid<MODE, NT, false>), dim3((unsigned)n), dim3(NT), lds_bytes, s, d_probs,
+                           (uint32_t)(lds_bytes / 4), pre, pre_slots, none);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
@@ -989,7 +1498,8 @@ size_t grid_aux_words(int32_t) { return 4; }
 void grid_aux_fill(void* host_image, int32_t n2) { memset(host_image, 0, grid_aux_words(n2) * 4); }
 // n1_upper_bound: q.n1 is an upper bound (the descriptor's n1 is patched on the device): both launches go out whenever the
 // problem runs LDS-resident at the bound -- the kernels decide for themselves whether the row count admits the packed words.
-int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux, bool n1_upper_bound)
+int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux, bool n1_upper_bound,
+                       const GridDesc* h_desc)
 {
     const int64_t ncell = (int64_t)q.grid_cols * q.grid_rows;
     const bool dirs = q.dir1 != nullptr && q.dir2 != nullptr;
@@ -1004,9 +1514,19 @@ int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hip
         const int64_t wx = std::min<int64_t>((int64_t)q.window[0] + q.window[1] + 1, q.grid_cols);
         const int split = (int)std::max<int64_t>(1, std::min<int64_t>(wx, GRID_SPLIT_MAX));
         const unsigned nwg = (unsigned)(((int64_t)q.n1 * split + 255) / 256);
+        // the records of each column, found cell by cell (k_grid_records: the descriptor goes by value, so the row count must
+        // be the host's), or every candidate pair (k_grid_candidates)
+        const int64_t n_groups = (int64_t)q.grid_cols * ((q.grid_rows + REC_G - 1) / REC_G);
+        const size_t lds = grid_group_lds_bytes(2, q.n1, q.n2, ncell, q.n_items, dirs);
+        if (PLSLAM_GRID_RECORDS && h_desc && !n1_upper_bound && flat && n_groups <= REC_GROUPS_MAX && q.n1 <= REC_ROWS_MAX &&
+            (int64_t)q.n_items * REC_SLOT <= (int64_t)q.pair_capacity) {
+            hipLaunchKernelGGL(k_grid_records, dim3((unsigned)n_groups), dim3(REC_NT), 0, s, *h_desc, aux);
+            PLSLAM_HIP_CHECK(hipGetLastError());
+            return launch_group<2, 1024>(d_desc, 1, lds, s, aux, REC_SLOT, h_desc);
+        }
         hipLaunchKernelGGL(k_grid_candidates, dim3(nwg), dim3(256), 0, s, d_desc, aux, split);
         PLSLAM_HIP_CHECK(hipGetLastError());
-        return launch_group<2, 1024>(d_desc, 1, grid_group_lds_bytes(2, q.n1, q.n2, ncell, q.n_items, dirs), s, aux);
+        return launch_group<2, 1024>(d_desc, 1, lds, s, aux);
     }
     int32_t n_mode[4] = {0, 0, 0, 0};
     size_t lds_bytes[4] = {0, 0, 0, 0};
@@ -1092,7 +1612,7 @@ int grid_prepare_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* s
 }
 int grid_launch_prepared(const plslam_grid_problem& q, const GridDesc* d_desc_slot, hipStream_t s)
 {
-    return grid_launch_single(q, d_desc_slot, s, nullptr, false);       // (no shared words: one launch)
+    return grid_launch_single(q, d_desc_slot, s, nullptr, false, nullptr);       // (no shared words: one launch)
 }
 // h_desc_slot must stay valid until the copy is done (pinned or synchronised by the caller)
 int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32_t* status, GridDesc* d_desc_slot,
@@ -1101,7 +1621,7 @@ int launch_match_grid_one(const plslam_grid_problem& q, uint32_t* scratch, int32
     int rc;
     if ((rc = grid_prepare_one(q, scratch, status, h_desc_slot))) return rc;
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d_desc_slot, h_desc_slot, sizeof(GridDesc), hipMemcpyHostToDevice, s));
-    return grid_launch_single(q, d_desc_slot, s, nullptr, false);
+    return grid_launch_single(q, d_desc_slot, s, nullptr, false, nullptr);
 }
 }  // namespace plslam
 
@@ -1272,7 +1792,7 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     StreamSyncOnError sg(s);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, ci.off, hipMemcpyHostToDevice, s));
     if (!hout_dev) PLSLAM_HIP_CHECK(hipMemsetAsync(dout + oN, 0, 8, s));
-    if ((rc = grid_launch_single(dq, (const GridDesc*)(d + oT), s, (uint32_t*)(d + oX), false))) return rc;
+    if ((rc = grid_launch_single(dq, (const GridDesc*)(d + oT), s, (uint32_t*)(d + oX), false, (const GridDesc*)(h + oT)))) return rc;
     if (!hout_dev) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, dout, co.off, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     const int32_t* res = (const int32_t*)(ctx->pin_out.as<char>() + oN);
