@@ -72,6 +72,7 @@ constexpr int PB_BATCH = 8;                                            // stored
 #ifndef PLSLAM_GRID_COLUMNS
 #define PLSLAM_GRID_COLUMNS 1       // 0: experiment builds without the column-bucketed path of a lone problem
 #endif
+constexpr uint32_t REC_SLOT = 8;                                       // k_grid_records: list words per item of the grid
 constexpr size_t GRID_LDS_MAX_BYTES = 152 * 1024;                      // dynamic LDS of the LDS instantiations
 constexpr size_t GRID_LDS_FIXED_MAX_BYTES = 144 * 1024;                // tables that MUST fit for MODE 1
 
@@ -332,15 +333,35 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     const bool count_empty = 2147483647.0 < 2147483647.0 * g.nnr;     // PC's nnr > 1 rule
     const bool cols_maybe = PLSLAM_GRID_COLUMNS && MODE == 2 && NT == 1024 && pre != nullptr && !count_empty;
     const uint32_t col_off = 2u * (uint32_t)(n2 + n1);
+    // (k_grid_records' list: the words of item tid and item tid + NT, and the first two words per lane of the records that
+    // did not fit their items' -- those are listed from the END of the store downwards, so their place is known now)
+    constexpr uint32_t ITEMS_EARLY = 2;
     uint32_t c_early[COLS_EARLY], total_early = 0, items_end_early = 0;
+    u32x4 it_early[ITEMS_EARLY][REC_SLOT / 4];
+    uint32_t ov_early[ITEMS_EARLY];
+    const bool slots_early = cols_maybe && pre_slots == REC_SLOT;
     if (cols_maybe) {
         total_early = ((PLSLAM_AS_GLOBAL const uint32_t*)pre)[0];
         items_end_early = (uint32_t)g_cell_start[ncell];
         PLSLAM_AS_GLOBAL const uint32_t* raw = store + (uint32_t)g.pair_cap;
+        if (slots_early) {
 #pragma unroll
-        for (uint32_t j = 0; j < COLS_EARLY; ++j) {
-            const uint32_t k = (uint32_t)tid + j * NT;
-            c_early[j] = k < (uint32_t)g.pair_cap ? raw[k] : KEY_NONE;      // (words behind the list's end: masked later)
+            for (uint32_t j = 0; j < ITEMS_EARLY; ++j) {
+                const uint32_t item = (uint32_t)tid + j * NT;
+                const bool in = ((uint64_t)item + 1u) * REC_SLOT <= (uint64_t)(uint32_t)g.pair_cap;
+#pragma unroll
+                for (uint32_t v = 0; v < REC_SLOT / 4; ++v) {
+                    const u32x4 none4 = {KEY_NONE, KEY_NONE, KEY_NONE, KEY_NONE};
+                    it_early[j][v] = in ? *(PLSLAM_AS_GLOBAL const u32x4*)(raw + (size_t)item * REC_SLOT + 4u * v) : none4;
+                }
+                ov_early[j] = item < (uint32_t)g.pair_cap ? raw[(uint32_t)g.pair_cap - 1u - item] : KEY_NONE;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t j = 0; j < COLS_EARLY; ++j) {
+                const uint32_t k = (uint32_t)tid + j * NT;
+                c_early[j] = k < (uint32_t)g.pair_cap ? raw[k] : KEY_NONE;      // (words behind the list's end: masked later)
+            }
         }
     }
     if (LDS && !cols_maybe) {
@@ -402,14 +423,16 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
             const uint32_t n_slots = pre_slots * (cols_maybe ? items_end_early : pre_slots ? (uint32_t)P.cs[ncell] : 0u);
             const uint64_t total64 = (uint64_t)n_slots + (cols_maybe ? total_early : *(PLSLAM_AS_GLOBAL const uint32_t*)pre);
             const uint32_t total = total64 > (uint64_t)(uint32_t)g.pair_cap ? (uint32_t)g.pair_cap + 1u : (uint32_t)total64;
+            PLSLAM_AS_GLOBAL const uint32_t* raw = store + (uint32_t)g.pair_cap;
+            // word k of the list: the items' words, then (from the end of the store downwards) what did not fit them
+            auto list_at = [&](uint32_t k) -> uint32_t { return k < n_slots || !pre_slots ? raw[k] : raw[(uint32_t)g.pair_cap - 1u - (k - n_slots)]; };
 #ifdef PLSLAM_GRID_TIMING
             dbg_total = total;
 #endif
-            PLSLAM_AS_GLOBAL const uint32_t* raw = store + (uint32_t)g.pair_cap;
 #ifdef PLSLAM_GRID_DEBUG_LIST
             if (tid == 0 && n2 <= 4) {
                 printf("[list] n1 %d n2 %d slots %u total %u pair_cap %d items_end %u overflow %u:", n1, n2, n_slots, total, g.pair_cap, items_end_early, total_early);
-                for (uint32_t k = 0; k < total && k < 40; ++k) printf(" %08x", raw[k]);
+                for (uint32_t k = 0; k < total && k < 40; ++k) printf(" %08x", list_at(k));
                 printf("\n");
             }
 #endif
@@ -431,23 +454,49 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
             // (COLS_HOLD words per lane).  The segments lie over the cell_start copy's place and everything behind it.
             // ---- the shortest way: the list is k_grid_records', and no column has two runs (every item of the grid in one
             // cell: points).  The list then holds each column's records and nothing else -- no liveness to settle: every word
-            // joins its row's best two, a column's state is its smallest (d, row).  Whether a column has two runs shows in the
-            // same sweep (the first word of an item's slots is a record iff the run has any; the counts P0 zeroed take them);
-            // if one has, the tables are wiped and the bucketed bookkeeping below runs.
-            if (PLSLAM_GRID_FAST && cols_maybe && pre_slots > 0u && total <= COLS_EARLY * NT) {
+            // joins its row's best two, a column's state is its smallest (d, row).  A lane takes an item's words (records first:
+            // the first is one iff the run has any -- the counts P0 zeroed take those, and a column counted twice has two runs:
+            // the tables are wiped and the bucketed bookkeeping below runs).  The returning atomics of a lane go out together.
+            const uint32_t n_over = total - n_slots;                    // (total <= pair_cap here)
+            if (PLSLAM_GRID_FAST && slots_early && items_end_early <= ITEMS_EARLY * NT && n_over <= ITEMS_EARLY * NT) {
                 PLSLAM_AS_LDS uint32_t* off = s_dyn + col_off;
                 bool dup = false;
+                auto fold = [&](uint32_t w, bool first, uint32_t& was_) {           // a record word: column state, row's best
+                    const uint32_t i2 = w & mk2, i1 = (w >> fb2) & mk1, d = w >> (fb1 + fb2);
+                    if (first) dup = dup || atomicAdd((uint32_t*)&off[i2], 1u) != 0u;
+                    atomicMin((uint32_t*)&P.state[i2], (d << fb1) | i1);
+                    was_ = atomicMin((uint32_t*)&P.row_k1[i1], (d << KEY_IDX_BITS) | i2);
+                };
+                auto fold2 = [&](uint32_t w, uint32_t was_) {                       // ... whichever lost goes to the second best
+                    const uint32_t i2 = w & mk2, i1 = (w >> fb2) & mk1, d = w >> (fb1 + fb2), key = (d << KEY_IDX_BITS) | i2;
+                    if (was_ != key) atomicMin((uint32_t*)&P.row_k2[i1], was_ > key ? was_ : key);
+                };
 #pragma unroll
-                for (uint32_t j = 0; j < COLS_EARLY; ++j) {
-                    if (j * NT >= total) break;
-                    const uint32_t k = (uint32_t)tid + j * NT;
-                    if (k < total && c_early[j] != KEY_NONE) {
-                        const uint32_t i2 = c_early[j] & mk2, i1 = (c_early[j] >> fb2) & mk1, d = c_early[j] >> (fb1 + fb2);
-                        const uint32_t key = (d << KEY_IDX_BITS) | i2;
-                        if (k < n_slots && (k & (pre_slots - 1u)) == 0u) dup = dup || atomicAdd((uint32_t*)&off[i2], 1u) != 0u;
-                        atomicMin((uint32_t*)&P.state[i2], (d << fb1) | i1);
-                        const uint32_t was = atomicMin((uint32_t*)&P.row_k1[i1], key);
-                        if (was != key) atomicMin((uint32_t*)&P.row_k2[i1], was > key ? was : key);
+                for (uint32_t j = 0; j < ITEMS_EARLY; ++j) {
+                    if (j * NT >= items_end_early) break;
+                    uint32_t w[REC_SLOT], was[REC_SLOT];
+                    const bool mine = (uint32_t)tid + j * NT < items_end_early;
+#pragma unroll
+                    for (uint32_t v = 0; v < REC_SLOT; ++v) w[v] = mine ? it_early[j][v / 4][v % 4] : KEY_NONE;
+#pragma unroll
+                    for (uint32_t v = 0; v < REC_SLOT; ++v) {
+                        if (!__any(w[v] != KEY_NONE)) break;                          // (records first: no lane has a later one either)
+                        was[v] = 0u;
+                        if (w[v] != KEY_NONE) fold(w[v], v == 0u, was[v]);
+                    }
+#pragma unroll
+                    for (uint32_t v = 0; v < REC_SLOT; ++v) {
+                        if (!__any(w[v] != KEY_NONE)) break;
+                        if (w[v] != KEY_NONE) fold2(w[v], was[v]);
+                    }
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < ITEMS_EARLY; ++j) {
+                    if (j * NT >= n_over) break;
+                    if ((uint32_t)tid + j * NT < n_over) {
+                        uint32_t was_ = 0u;
+                        fold(ov_early[j], false, was_);
+                        fold2(ov_early[j], was_);
                     }
                 }
                 if (__syncthreads_or(dup)) {
@@ -463,7 +512,11 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                     cols_fast = true;
                 }
             }
-            if (!cols_done && cols_maybe && total <= COLS_HOLD * NT && (uint64_t)col_off + (uint32_t)n2 + 1u + total <= (uint64_t)lds_words) {
+            // (a lane per column: worth it while the columns are many and short -- 200 columns of 100 candidates each, a map's
+            // lines against a keyframe's, took 107 us this way against ~30 us of record passes)
+            // (k_grid_records' list holds records only: a few per run whatever the windows)
+            if (!cols_done && cols_maybe && total <= COLS_HOLD * NT && (pre_slots > 0u || (uint64_t)total <= 24ull * (uint32_t)n2) &&
+                (uint64_t)col_off + (uint32_t)n2 + 1u + total <= (uint64_t)lds_words) {
                 PLSLAM_AS_LDS uint32_t* off = s_dyn + col_off;              // n2 + 1: counts (zeroed by P0), then the segments' first words
                 PLSLAM_AS_LDS uint32_t* seg = off + n2 + 1;
                 uint32_t c[COLS_HOLD];
@@ -473,14 +526,17 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                 const uint32_t nj = (total + NT - 1) / NT;                  // (uniform) words per lane that exist at all: the unrolled
                 COLS_STAMP();                                              // steps behind them are skipped, not predicated away
 #pragma unroll
-                for (uint32_t j = 0; j < COLS_EARLY; ++j) c[j] = (uint32_t)tid + j * NT < total ? c_early[j] : KEY_NONE;
+                for (uint32_t j = 0; j < COLS_HOLD; ++j) c[j] = KEY_NONE;
+                if (!slots_early) {
 #pragma unroll
-                for (uint32_t j = COLS_EARLY; j < COLS_HOLD; ++j) c[j] = KEY_NONE;
-                if (total > COLS_EARLY * NT) {
+                    for (uint32_t j = 0; j < COLS_EARLY; ++j) c[j] = (uint32_t)tid + j * NT < total ? c_early[j] : KEY_NONE;
+                }
+                if (slots_early || total > COLS_EARLY * NT) {
 #pragma unroll
-                    for (uint32_t j = COLS_EARLY; j < COLS_HOLD; ++j) {
+                    for (uint32_t j = 0; j < COLS_HOLD; ++j) {
+                        if (j * NT >= total) break;
                         const uint32_t k = (uint32_t)tid + j * NT;
-                        c[j] = k < total ? raw[k] : KEY_NONE;
+                        if (slots_early || j >= COLS_EARLY) c[j] = k < total ? list_at(k) : KEY_NONE;
                     }
                 }
                 COLS_STAMP();
@@ -637,7 +693,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
             for (uint32_t k0 = (uint32_t)tid; k0 < (cols_done ? 0u : total); k0 += NT * PRE_UN) {
                 uint32_t c[PRE_UN];
 #pragma unroll
-                for (int j = 0; j < PRE_UN; ++j) c[j] = k0 + (uint32_t)j * NT < total ? raw[k0 + (uint32_t)j * NT] : KEY_NONE;
+                for (int j = 0; j < PRE_UN; ++j) c[j] = k0 + (uint32_t)j * NT < total ? list_at(k0 + (uint32_t)j * NT) : KEY_NONE;
 #pragma unroll
                 for (int j = 0; j < PRE_UN; ++j)
                     if (c[j] != KEY_NONE) {
@@ -656,7 +712,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
 #pragma unroll
                 for (int j = 0; j < PRE_UN; ++j) {
                     const uint32_t k = base + 64u * (uint32_t)j + (uint32_t)lane;
-                    c[j] = k < hi ? raw[k] : KEY_NONE;
+                    c[j] = k < hi ? list_at(k) : KEY_NONE;
                 }
 #pragma unroll
                 for (int j = 0; j < PRE_UN; ++j) {
@@ -1145,15 +1201,13 @@ __global__ __launch_bounds__(256) void k_grid_candidates(const GridDesc* __restr
 // Where they go: item k of the grid's CSR list (one (cell, column) run) owns words k * REC_SLOT ... + REC_SLOT - 1 of the list,
 // records first, KEY_NONE behind them -- no counter to claim, nothing returns to the wave (a round trip of a global atomic is
 // ~1 us here, and every workgroup of the launch wanted the same word).  The records a run has beyond REC_SLOT (a column in a
-// hundred) are appended behind the last item's words, aux[0] counting them.  The FIRST word of an item's slots is a record
+// hundred) are listed from the END of the store downwards, aux[0] counting them (their place does not depend on the grid).  The FIRST word of an item's slots is a record
 // exactly when the run has any: k_match_grid counts those per column to see whether a column has one run (the list then holds
 // its records and nothing else) or several.
 // The descriptor comes BY VALUE (kernel arguments): one dependent round trip less in front of everything.
 constexpr int REC_NT = 256;
 constexpr int REC_G = 8;                            // cells per workgroup: same grid column x, consecutive y
 constexpr int REC_ROWS_MAX = 4096;                  // rows of a problem that takes this path (the row lists of a group: 12 KB of LDS)
-constexpr uint32_t REC_SLOT = 8;                    // list words per item of the grid (a power of two)
-static_assert((REC_SLOT & (REC_SLOT - 1)) == 0, "");
 constexpr int64_t REC_GROUPS_MAX = 1 << 16;         // beyond this k_grid_candidates lists the pairs
 __global__ __launch_bounds__(REC_NT) void k_grid_records(const GridDesc g, uint32_t* __restrict__ aux)
 {
@@ -1211,9 +1265,13 @@ __global__ __launch_bounds__(REC_NT) void k_grid_records(const GridDesc g, uint3
     if ((uint32_t)it_all > (uint32_t)g.n_items || it_begin >= it_end) return;    // (an inconsistent grid: k_match_grid reports it)
     if (tid <= ng) s_cs[tid] = my_cs;
     REC_STAMP();
-    // this wave's first column: its number now, its descriptor as soon as that is here -- both under the sweep below
+    // this wave's first columns: their numbers now (under the sweep below), their descriptors together once those are here --
+    // two round trips for IT_UN columns, not two each (a group holds ~3 items, a wave takes every fourth)
+    constexpr int IT_UN = 4;
     const int32_t k_first = it_begin + wv;
-    const int32_t i2_first = k_first < it_end ? items[k_first] : -1;
+    int32_t i2_un[IT_UN];
+#pragma unroll
+    for (int t = 0; t < IT_UN; ++t) i2_un[t] = k_first + t * NW < it_end ? items[k_first + t * NW] : -1;
 
     // ---- the rows whose windows touch the group, each with the mask of the cells it reaches ----
     // (cell (cx, cy) of the grid lies in a centre's clamped window [min, max) exactly when cx - x is in [-w0, w1] and cy - y in
@@ -1280,8 +1338,7 @@ __global__ __launch_bounds__(REC_NT) void k_grid_records(const GridDesc g, uint3
     uint32_t row_0, mask_0;
     row_at((uint32_t)lane, row_0, mask_0);
     const u32x4 qa_0 = g_d1[2 * (int64_t)row_0], qb_0 = g_d1[2 * (int64_t)row_0 + 1];
-    for (int32_t k = k_first; k < it_end; k += NW) {
-        const int32_t i2 = __builtin_amdgcn_readfirstlane(k == k_first ? i2_first : items[k]);
+    auto run_column = [&](int32_t k, int32_t i2, const u32x4& ta, const u32x4& tb, double b0, double b1) {
         PLSLAM_AS_GLOBAL uint32_t* slot = raw + (uint64_t)(uint32_t)k * REC_SLOT;
         const bool room = ((uint64_t)(uint32_t)k + 1u) * REC_SLOT <= (uint64_t)(uint32_t)g.pair_cap;    // (launcher: always)
         uint32_t n_rec = 0;                            // (uniform) records of this run so far
@@ -1289,12 +1346,6 @@ __global__ __launch_bounds__(REC_NT) void k_grid_records(const GridDesc g, uint3
             uint32_t cq = 0;                           // the cell of item k: how many of the group's inner boundaries lie at or below k
             for (int32_t t = 1; t < ng; ++t) cq += k >= s_cs[t] ? 1u : 0u;
             const uint32_t bit = 1u << cq;
-            const u32x4 ta = g_d2[2 * (int64_t)i2], tb = g_d2[2 * (int64_t)i2 + 1];
-            double b0 = 0.0, b1 = 0.0;
-            if (dirs) {
-                b0 = dir2[2 * (int64_t)i2];
-                b1 = dir2[2 * (int64_t)i2 + 1];
-            }
             uint32_t carry = REC_D_MASK + 1u;          // the smallest distance of the rows before this chunk
             for (uint32_t j0 = 0; j0 < n_rows && carry; j0 += 64) {
                 uint32_t row = row_0, mk = mask_0;
@@ -1331,15 +1382,40 @@ __global__ __launch_bounds__(REC_NT) void k_grid_records(const GridDesc g, uint3
                     const uint32_t word = (d << (fb1 + fb2)) | (row << fb2) | (uint32_t)i2;
                     if (pos < REC_SLOT) {
                         if (room) slot[pos] = word;
-                    } else {                                      // beyond the run's own words: behind the last item's
-                        const uint64_t gp = (uint64_t)(uint32_t)it_all * REC_SLOT + (uint32_t)atomic_add_global(aux, 1);
-                        if (gp < (uint64_t)(uint32_t)g.pair_cap) raw[gp] = word;
+                    } else {                                      // beyond the run's own words: from the store's end downwards
+                        const uint32_t gp = (uint32_t)atomic_add_global(aux, 1);
+                        if ((uint64_t)(uint32_t)it_all * REC_SLOT + gp < (uint64_t)(uint32_t)g.pair_cap)
+                            raw[(uint32_t)g.pair_cap - 1u - gp] = word;
                     }
                 }
                 n_rec += (uint32_t)__popcll(m);
             }
         }
         if (room && (uint32_t)lane < REC_SLOT && (uint32_t)lane >= n_rec) slot[lane] = KEY_NONE;
+    };
+    {
+        u32x4 ta[IT_UN], tb[IT_UN];
+        double b0[IT_UN], b1[IT_UN];
+#pragma unroll
+        for (int t = 0; t < IT_UN; ++t) {
+            const int32_t i2 = __builtin_amdgcn_readfirstlane(i2_un[t]);
+            const int64_t at = (uint32_t)i2 < (uint32_t)n2 ? i2 : 0;
+            ta[t] = g_d2[2 * at];
+            tb[t] = g_d2[2 * at + 1];
+            b0[t] = dirs ? dir2[2 * at] : 0.0;
+            b1[t] = dirs ? dir2[2 * at + 1] : 0.0;
+        }
+#pragma unroll
+        for (int t = 0; t < IT_UN; ++t) {
+            if (k_first + t * NW >= it_end) break;
+            run_column(k_first + t * NW, __builtin_amdgcn_readfirstlane(i2_un[t]), ta[t], tb[t], b0[t], b1[t]);
+        }
+    }
+    for (int32_t k = k_first + IT_UN * NW; k < it_end; k += NW) {       // (a dense group)
+        const int32_t i2 = __builtin_amdgcn_readfirstlane(items[k]);
+        const int64_t at = (uint32_t)i2 < (uint32_t)n2 ? i2 : 0;
+        const u32x4 ta = g_d2[2 * at], tb = g_d2[2 * at + 1];
+        run_column(k, i2, ta, tb, dirs ? dir2[2 * at] : 0.0, dirs ? dir2[2 * at + 1] : 0.0);
     }
     REC_STAMP();
 #ifdef PLSLAM_GRID_TIMING
@@ -1434,7 +1510,10 @@ int64_t grid_store_capacity_bound(int32_t n1, int32_t n_centres, const int32_t* 
 }
 
 constexpr int GRID_SPLIT_MAX = 16;         // ... with at most this many lanes per row (one per window column)
-constexpr int GRID_SPLIT_MIN_ROWS = 512;   // one problem alone: from this many rows on PA runs as its own many-workgroup launch
+#ifndef PLSLAM_GRID_SPLIT_MIN_ROWS
+#define PLSLAM_GRID_SPLIT_MIN_ROWS 128
+#endif
+constexpr int GRID_SPLIT_MIN_ROWS = PLSLAM_GRID_SPLIT_MIN_ROWS;   // one problem alone: from this many rows on PA runs as its own many-workgroup launch
 constexpr int GRID_SMALL_ROWS = 256;    // problems of at most this many rows run on 256-lane workgroups (MODE 2 only)
 
 // launch groups: 0 = tables in global scratch, 1 = tables in LDS, 2 = everything in LDS / 1024 lanes, 3 = everything in
