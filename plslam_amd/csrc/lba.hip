@@ -302,47 +302,75 @@ int launch_gate_n(int lines, const plslam_cam& K, const double* Twf16, const dou
 // microsecond's work costs 4-5 us on the timeline ------------------------------------------------------------------------------
 // candidate pre-filter (:549-551, :650-655) x candidate flags -> the STABLE list of the landmarks that pass (ascending) + its
 // length, the association table's -1 start, and the row count of the matchGrid problem that follows (its uploaded descriptor).
-// One workgroup: a lane owns a contiguous chunk, a scan over the lanes' counts gives its first slot.
+// One workgroup.  Landmark i0 + k * 1024 + tid is lane tid's in round k of a tile of 32 rounds: every load of a round is
+// coalesced and a lane's loads of several rounds are in flight together (a lane with a contiguous chunk of its own walked it
+// one dependent round trip at a time: 28 us for 10 000 landmarks); a round's survivors are counted per wave by ballot, a scan
+// over the (round, wave) counts gives every wave its first slot, and the list comes out ascending.
 __global__ void __launch_bounds__(1024)
 k_visible_compact(CamD K, Pose12 Twf, const double* __restrict__ X, const uint8_t* __restrict__ cand, int32_t n, int lines,
                   int32_t* __restrict__ idx, int32_t* __restrict__ n_out, int32_t* __restrict__ fill, GridDesc* __restrict__ desc)
 {
-    __shared__ int32_t s_sum[1024];
-    const int tid = (int)threadIdx.x;
-    const int32_t chunk = (n + 1023) / 1024, lo = tid * chunk, hi = lo + chunk < n ? lo + chunk : n;
-    auto passes = [&](int32_t i) -> bool {
-        if (cand[i] == 0) return false;
+    constexpr int NT = 1024, NW = NT / 64, TILE_ROUNDS = 32;
+    __shared__ uint32_t s_cnt[TILE_ROUNDS * NW];            // survivors per (round, wave), then their exclusive prefix
+    __shared__ uint32_t s_wt[NW];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint64_t below = (1ull << lane) - 1ull;
+    auto passes = [&](int32_t i) -> bool {                  // (the landmark is read whether it is a candidate or not: one round trip)
+        const uint8_t c = cand[i];
         double P[3], E[3];
         if (!lines) {
             xform44(Twf, X + 3 * (size_t)i, P);
-            return inside(K, P) != 0;
+            return c != 0 && inside(K, P) != 0;
         }
         xform44(Twf, X + 6 * (size_t)i, P);
         xform44(Twf, X + 6 * (size_t)i + 3, E);
-        return inside(K, P) && inside(K, E);
+        return c != 0 && inside(K, P) && inside(K, E);
     };
-    uint32_t bits = 0;                       // (chunks of at most 32 landmarks per lane keep their flags; longer ones re-evaluate)
-    int32_t c = 0;
-    for (int32_t i = lo; i < hi; ++i) {
-        const bool v = passes(i);
-        if (v && i - lo < 32) bits |= 1u << (i - lo);
-        c += v;
-        fill[i] = -1;
-    }
-    s_sum[tid] = c;
-    __syncthreads();
-    for (int st = 1; st < 1024; st <<= 1) {                      // inclusive scan
-        const int32_t v = tid >= st ? s_sum[tid - st] : 0;
+    uint32_t out = 0;                                       // (uniform) listed so far
+    for (int32_t i0 = 0; i0 < n; i0 += TILE_ROUNDS * NT) {
+        const int32_t left = n - i0, rounds = left >= TILE_ROUNDS * NT ? TILE_ROUNDS : (left + NT - 1) / NT;
+        uint32_t bits = 0;                                  // bit k: this lane's landmark of round k passes
+#pragma unroll 4
+        for (int32_t k = 0; k < rounds; ++k) {
+            const int32_t i = i0 + k * NT + tid;
+            if (i < n) {
+                bits |= (passes(i) ? 1u : 0u) << k;
+                fill[i] = -1;
+            }
+        }
+        for (int32_t k = 0; k < rounds; ++k) {
+            const uint64_t b = __ballot((bits >> k) & 1u);
+            if (lane == 0) s_cnt[k * NW + wv] = (uint32_t)__popcll(b);
+        }
         __syncthreads();
-        s_sum[tid] += v;
-        __syncthreads();
+        {   // exclusive prefix over rounds * NW <= 512 counts: one lane each, wave scans, the waves' totals through s_wt
+            const uint32_t v = tid < rounds * NW ? s_cnt[tid] : 0u;
+            uint32_t incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+                if (lane >= o) incl += t;
+            }
+            if (lane == 63) s_wt[wv] = incl;
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+            for (int w = 0; w < NW; ++w) {
+                before += w < wv ? s_wt[w] : 0u;
+                all += s_wt[w];
+            }
+            if (tid < rounds * NW) s_cnt[tid] = before + incl - v;
+            __syncthreads();
+            for (int32_t k = 0; k < rounds; ++k) {
+                const uint64_t b = __ballot((bits >> k) & 1u);
+                if ((bits >> k) & 1u) idx[out + s_cnt[k * NW + wv] + (uint32_t)__popcll(b & below)] = i0 + k * NT + tid;
+            }
+            out += all;
+            __syncthreads();                                // (the counts are the next tile's)
+        }
     }
-    int32_t k = s_sum[tid] - c;
-    for (int32_t i = lo; i < hi; ++i)
-        if (i - lo < 32 ? ((bits >> (i - lo)) & 1u) != 0u : passes(i)) idx[k++] = i;
-    if (tid == 1023) {
-        *n_out = s_sum[1023];
-        if (desc) desc->n1 = s_sum[1023];
+    if (tid == 0) {
+        *n_out = (int32_t)out;
+        if (desc) desc->n1 = (int32_t)out;
     }
 }
 

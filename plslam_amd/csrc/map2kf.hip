@@ -306,7 +306,7 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
     if ((rc = launch_prepare_rows(*K, Twf, d_MD, (const double*)d_LM, (const int32_t*)(d + oQi), res + 1, n_map, lines, fm->inv_width,
                                   fm->inv_height, d + oQ, (double*)(d + oQL), (int32_t*)(d + oCen), lines ? (double*)(d + oD1) : nullptr, s)))
         return rc;
-    if ((rc = grid_launch_single(q, (const GridDesc*)(d + oDesc), s, (uint32_t*)(d + oAux), true))) return rc;
+    if ((rc = grid_launch_single(q, (const GridDesc*)(d + oDesc), s, (uint32_t*)(d + oAux), true, (const GridDesc*)(h + oDesc)))) return rc;
     if ((rc = launch_gate_n(lines, *K, Twf, (const double*)(d + oQL), (const int32_t*)(d + oM), res + 1, n_map, (const double*)(d + oTF),
                             max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi), (const int32_t*)(d + oTi),
                             (int32_t*)(d + oMap), s)))

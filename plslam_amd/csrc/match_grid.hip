@@ -66,6 +66,9 @@ constexpr int PB_BATCH = 8;                                            // stored
 #ifndef PLSLAM_GRID_RECORDS
 #define PLSLAM_GRID_RECORDS 1       // 0: experiment builds that list every candidate pair of a lone problem (k_grid_candidates)
 #endif
+#ifndef PLSLAM_GRID_RUNS_PER_COLUMN
+#define PLSLAM_GRID_RUNS_PER_COLUMN 4   // k_grid_records' list is bucketed by column while a column has at most this many runs on average
+#endif
 #ifndef PLSLAM_GRID_FAST
 #define PLSLAM_GRID_FAST 1          // 0: experiment builds without the shortest bookkeeping of k_grid_records' list
 #endif
@@ -190,10 +193,11 @@ __device__ __forceinline__ void for_candidates(const GridDesc& g, const GridPtrs
 // idle at every barrier -- and, in a batch, occupy a whole CU)
 template <int MODE, int NT, bool BYVAL = false>
 __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ probs, uint32_t lds_words, const uint32_t* __restrict__ pre_arg,
-                                                   uint32_t pre_slots, const GridDesc one)
+                                                   uint32_t pre_slots, const GridDesc one, const int32_t* __restrict__ n1_dev)
 {
     // BYVAL: ONE problem, its descriptor by value in `one` (a dependent round trip less in front of everything; a run-time
-    // choice between the two copies a 152-byte struct through private memory).
+    // choice between the two copies a 152-byte struct through private memory).  n1_dev (BYVAL only): where the row count lives
+    // when a kernel upstream decides it -- one.n1 is then its upper bound, and still what the scratch layout is counted by.
     // pre_slots > 0: the list is k_grid_records': pre_slots words per item of the grid's CSR list (records first, KEY_NONE behind
     // them), then pre[0] more words; 0: k_grid_candidates' dense list of pre[0] words.
     // pre != nullptr (one LDS-resident mutual problem alone on the chip, MODE 2): PA's distances were evaluated by
@@ -211,8 +215,13 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     __shared__ uint32_t s_seg[NT / 64 + 1];          // flat mode: first LDS word of each wave's region
     PLSLAM_AS_LDS uint32_t* s_dyn = (PLSLAM_AS_LDS uint32_t*)reinterpret_cast<uint32_t*>(s_dyn4);
 
-    const GridDesc g = BYVAL ? one : probs[blockIdx.x];
+    GridDesc g = BYVAL ? one : probs[blockIdx.x];
     const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int32_t n1_layout = g.n1;
+    if (BYVAL && n1_dev) {
+        const int32_t n1_now = *(PLSLAM_AS_GLOBAL const int32_t*)n1_dev;
+        g.n1 = n1_now >= 0 && n1_now < n1_layout ? n1_now : n1_layout;
+    }
     const int32_t n1 = g.n1, n2 = g.n2;
     const int32_t ncell = g.cols * g.rows;
     const int32_t n_rounds = (n1 + NT - 1) / NT;
@@ -265,8 +274,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
     }
     // global scratch behind the tables: per-row slot counts, per-round slot depth, the candidate store (x 2)
     PLSLAM_AS_GLOBAL uint32_t* rcnt = gscratch + (LDS ? 0u : fixed_words);   // n1
-    PLSLAM_AS_GLOBAL uint32_t* round_k = rcnt + n1;                          // n_rounds
-    PLSLAM_AS_GLOBAL uint32_t* store = round_k + n_rounds;  // 2 x pair_cap words; round r at 1024 * sum_{r' < r} round_k
+    PLSLAM_AS_GLOBAL uint32_t* round_k = rcnt + n1_layout;                   // n_rounds
+    PLSLAM_AS_GLOBAL uint32_t* store = round_k + (n1_layout + NT - 1) / NT;  // 2 x pair_cap words; round r at 1024 * sum_{r' < r} round_k
 
     // ---- "flat" mode (everything in LDS, bestLRMatches, row and column numbers of at most 23 bits together): a candidate is ONE
     // word that names its row, d << (fb1 + fb2) | i1 << fb2 | i2 (fb2 = bits of a column number, fb1 = what is left, at most
@@ -515,7 +524,8 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
             // (a lane per column: worth it while the columns are many and short -- 200 columns of 100 candidates each, a map's
             // lines against a keyframe's, took 107 us this way against ~30 us of record passes)
             // (k_grid_records' list holds records only: a few per run whatever the windows)
-            if (!cols_done && cols_maybe && total <= COLS_HOLD * NT && (pre_slots > 0u || (uint64_t)total <= 24ull * (uint32_t)n2) &&
+            if (!cols_done && cols_maybe && total <= COLS_HOLD * NT &&
+                (pre_slots > 0u ? (uint64_t)items_end_early <= (uint64_t)PLSLAM_GRID_RUNS_PER_COLUMN * (uint32_t)n2 : (uint64_t)total <= 24ull * (uint32_t)n2) &&
                 (uint64_t)col_off + (uint32_t)n2 + 1u + total <= (uint64_t)lds_words) {
                 PLSLAM_AS_LDS uint32_t* off = s_dyn + col_off;              // n2 + 1: counts (zeroed by P0), then the segments' first words
                 PLSLAM_AS_LDS uint32_t* seg = off + n2 + 1;
@@ -588,29 +598,30 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                     const int32_t i2 = base2 + tid;
                     const bool act = i2 < n2;
                     const uint32_t b = act ? off[i2] : 0u, e = act ? off[i2 + 1] : 0u, len = e - b;
-                    bool need[REG_N / CHUNK];
+                    uint32_t longest = len;                            // (uniform) the wave's longest segment
 #pragma unroll
-                    for (int q = 0; q < REG_N / CHUNK; ++q) need[q] = __any(len > (uint32_t)(q * CHUNK)) != 0;
-                    uint32_t w[REG_N], dd[REG_N];
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const uint32_t t = (uint32_t)__shfl_xor((int)longest, o);
+                        longest = t > longest ? t : longest;
+                    }
+                    longest = (uint32_t)__builtin_amdgcn_readfirstlane((int)longest);
+#define need_chunk(q) (longest > (uint32_t)((q) * CHUNK))
+                    uint32_t w[REG_N];
 #pragma unroll
                     for (int q = 0; q < REG_N / CHUNK; ++q) {
-                        if (need[q]) {
+                        if (need_chunk(q)) {
 #pragma unroll
                             for (int j = q * CHUNK; j < (q + 1) * CHUNK; ++j) {
                                 const uint32_t v = seg[b + ((uint32_t)j < len ? (uint32_t)j : 0u)];   // (len 0: any word, unused)
                                 w[j] = (uint32_t)j < len ? v : KEY_NONE;
-                                dd[j] = (uint32_t)j < len ? v & REC_D_MASK : REC_D_MASK + 1u;
                             }
                         } else {
 #pragma unroll
-                            for (int j = q * CHUNK; j < (q + 1) * CHUNK; ++j) {
-                                w[j] = KEY_NONE;
-                                dd[j] = REC_D_MASK + 1u;
-                            }
+                            for (int j = q * CHUNK; j < (q + 1) * CHUNK; ++j) w[j] = KEY_NONE;
                         }
                     }
                     uint32_t last = KEY_NONE;
-                    if (!need[1]) {
+                    if (!need_chunk(1)) {
                         // (uniform) segments of at most 8 words -- what k_grid_records leaves: sort them (w = row << 9 | d orders
                         // by row; 19 compare-exchanges, a min and a max each), then a word is a record iff its distance is below
                         // every earlier word's.  No sweeps, and the records' atomics go out together: two LDS round trips.
@@ -622,7 +633,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                         GRID_CE(2, 4); GRID_CE(3, 5);
                         GRID_CE(1, 2); GRID_CE(3, 4); GRID_CE(5, 6);
 #undef GRID_CE
-                        uint32_t run = REC_D_MASK + 1u, was[CHUNK];
+                        uint32_t run = REC_D_MASK + 1u, was[CHUNK], dd[CHUNK];
                         bool live[CHUNK];
 #pragma unroll
                         for (int j = 0; j < CHUNK; ++j) {
@@ -644,25 +655,29 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                             if (live[j] && was[j] != key) atomicMin((uint32_t*)&P.row_k2[w[j] >> REC_D_BITS], was[j] > key ? was[j] : key);
                         }
                     } else {
-                        // a sweep is a compare, a select and a min per word; lanes whose column is done idle until the wave's
-                        // last column is (a column of ~19 candidates has ~3.5 records, the worst of 64 about 8)
+                        // a sweep is a mask, a compare, a select and a min per word; lanes whose column is done idle until the
+                        // wave's last column is (a column of ~19 candidates has ~3.5 records, the worst of 64 about 8)
                         uint32_t cur_d = len ? REC_D_MASK + 1u : 0u;
                         while (__any(cur_d != 0u)) {
                             uint32_t best = KEY_NONE;
 #pragma unroll
                             for (int q = 0; q < REG_N / CHUNK; ++q) {
-                                if (need[q]) {
+                                if (need_chunk(q)) {
 #pragma unroll
                                     for (int j = q * CHUNK; j < (q + 1) * CHUNK; ++j) {
-                                        const uint32_t t = dd[j] < cur_d ? w[j] : KEY_NONE;
+                                        const uint32_t t = (w[j] & REC_D_MASK) < cur_d && w[j] != KEY_NONE ? w[j] : KEY_NONE;
                                         best = t < best ? t : best;
                                     }
                                 }
                             }
-                            if (len > (uint32_t)REG_N && cur_d)                               // (rare) the rest from LDS
-                                for (uint32_t k = b + REG_N; k < e; ++k) {
-                                    const uint32_t v = seg[k];
-                                    if ((v & REC_D_MASK) < cur_d && v < best) best = v;
+                            if (len > (uint32_t)REG_N && cur_d)                               // (long columns) the rest from LDS, 8 reads in flight
+                                for (uint32_t k = b + REG_N; k < e; k += CHUNK) {
+                                    uint32_t v[CHUNK];
+#pragma unroll
+                                    for (int j = 0; j < CHUNK; ++j) v[j] = seg[k + j < e ? k + j : b];        // (a repeat changes no minimum)
+#pragma unroll
+                                    for (int j = 0; j < CHUNK; ++j)
+                                        if ((v[j] & REC_D_MASK) < cur_d && v[j] < best) best = v[j];
                                 }
                             if (best != KEY_NONE) {
                                 cur_d = best & REC_D_MASK;
@@ -676,6 +691,7 @@ __global__ __launch_bounds__(NT) void k_match_grid(const GridDesc* __restrict__ 
                     }
                     if (act) P.state[i2] = last;
                 }
+#undef need_chunk
                 cols_done = true;
                 __syncthreads();
                 COLS_STAMP();
@@ -1207,10 +1223,12 @@ __global__ __launch_bounds__(256) void k_grid_candidates(const GridDesc* __restr
 // The descriptor comes BY VALUE (kernel arguments): one dependent round trip less in front of everything.
 constexpr int REC_NT = 256;
 constexpr int REC_G = 8;                            // cells per workgroup: same grid column x, consecutive y
-constexpr int REC_ROWS_MAX = 4096;                  // rows of a problem that takes this path (the row lists of a group: 12 KB of LDS)
+constexpr int REC_ROWS_MAX = 16384;                 // rows of a problem that takes this path (the row lists of a group: 48 KB of LDS)
 constexpr int64_t REC_GROUPS_MAX = 1 << 16;         // beyond this k_grid_candidates lists the pairs
-__global__ __launch_bounds__(REC_NT) void k_grid_records(const GridDesc g, uint32_t* __restrict__ aux)
+__global__ __launch_bounds__(REC_NT) void k_grid_records(const GridDesc g, uint32_t* __restrict__ aux, const int32_t* __restrict__ n1_dev)
 {
+    // n1_dev: where the row count lives when a kernel upstream decides it (g.n1 is then its upper bound, and still what the
+    // scratch layout is counted by)
     constexpr int NW = REC_NT / 64, PER_WAVE = REC_ROWS_MAX / NW, SWEEP_UN = 8;
     static_assert(REC_G <= 8, "a row's cells fit an 8-bit mask");
     __shared__ uint16_t s_rows[NW][PER_WAVE];         // wave w's finds among rows [w * q, (w + 1) * q), ascending
@@ -1226,7 +1244,12 @@ __global__ __launch_bounds__(REC_NT) void k_grid_records(const GridDesc g, uint3
 #endif
     REC_STAMP();
     const int tid = (int)threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int32_t n1 = g.n1, n2 = g.n2;
+    int32_t n1 = g.n1;
+    if (n1_dev) {
+        const int32_t n1_now = *(PLSLAM_AS_GLOBAL const int32_t*)n1_dev;
+        n1 = n1_now >= 0 && n1_now < n1 ? n1_now : n1;
+    }
+    const int32_t n2 = g.n2;
     const int32_t ncell = g.cols * g.rows;
     const uint32_t fb2 = n2 > 1 ? 32u - (uint32_t)__builtin_clz((uint32_t)n2 - 1u) : 1u;        // bits of a column number (at least 1)
     const uint32_t fb1 = 23u - fb2 > 14u ? 14u : 23u - fb2;
@@ -1240,7 +1263,7 @@ __global__ __launch_bounds__(REC_NT) void k_grid_records(const GridDesc g, uint3
     PLSLAM_AS_GLOBAL const double* dir2 = (PLSLAM_AS_GLOBAL const double*)g.dir2;
     const bool dirs = g.dir1 != nullptr && g.dir2 != nullptr;
     PLSLAM_AS_GLOBAL uint32_t* rcnt = (PLSLAM_AS_GLOBAL uint32_t*)g.scratch;       // (the layout k_grid_candidates writes)
-    PLSLAM_AS_GLOBAL uint32_t* raw = rcnt + n1 + (n1 + GRID_THREADS - 1) / GRID_THREADS + (uint32_t)g.pair_cap;
+    PLSLAM_AS_GLOBAL uint32_t* raw = rcnt + g.n1 + (g.n1 + GRID_THREADS - 1) / GRID_THREADS + (uint32_t)g.pair_cap;
     const int32_t gpc = (g.rows + REC_G - 1) / REC_G;                   // groups per grid column
     const int32_t cx = (int32_t)blockIdx.x / gpc, cy0 = ((int32_t)blockIdx.x - cx * gpc) * REC_G;
     if (cx >= g.cols) return;
@@ -1541,7 +1564,7 @@ size_t grid_group_lds_bytes(int group, int32_t n1, int32_t n2, int64_t ncell, in
 // one: the descriptor of a lone problem by value (d_probs is not read then); pre / pre_slots: its listed candidates
 template <int MODE, int NT>
 static int launch_group(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hipStream_t s, const uint32_t* pre = nullptr,
-                        uint32_t pre_slots = 0, const GridDesc* one = nullptr)
+                        uint32_t pre_slots = 0, const GridDesc* one = nullptr, const int32_t* n1_dev = nullptr)
 {
     if (n <= 0) return PLSLAM_OK;
     if (MODE > 0) {
@@ -1559,10 +1582,10 @@ static int launch_group(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hi
     static const GridDesc none{};
     if (one && MODE == 2 && NT == 1024)
         hipLaunchKernelGGL((k_match_grid<2, 1024, true>), dim3(1), dim3(1024), lds_bytes, s, nullptr, (uint32_t)(lds_bytes / 4), pre,
-                           pre_slots, *one);
+                           pre_slots, *one, n1_dev);
     else
         hipLaunchKernelGGL((k_match_grid<MODE, NT, false>), dim3((unsigned)n), dim3(NT), lds_bytes, s, d_probs,
-                           (uint32_t)(lds_bytes / 4), pre, pre_slots, none);
+                           (uint32_t)(lds_bytes / 4), pre, pre_slots, none, nullptr);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
@@ -1597,11 +1620,13 @@ int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hip
         // be the host's), or every candidate pair (k_grid_candidates)
         const int64_t n_groups = (int64_t)q.grid_cols * ((q.grid_rows + REC_G - 1) / REC_G);
         const size_t lds = grid_group_lds_bytes(2, q.n1, q.n2, ncell, q.n_items, dirs);
-        if (PLSLAM_GRID_RECORDS && h_desc && !n1_upper_bound && flat && n_groups <= REC_GROUPS_MAX && q.n1 <= REC_ROWS_MAX &&
+        if (PLSLAM_GRID_RECORDS && h_desc && n_groups <= REC_GROUPS_MAX && q.n1 <= REC_ROWS_MAX &&
             (int64_t)q.n_items * REC_SLOT <= (int64_t)q.pair_capacity) {
-            hipLaunchKernelGGL(k_grid_records, dim3((unsigned)n_groups), dim3(REC_NT), 0, s, *h_desc, aux);
+            // (n1_upper_bound: the row count is the device descriptor's, patched by the caller's kernels)
+            const int32_t* n1_dev = n1_upper_bound ? &d_desc->n1 : nullptr;
+            hipLaunchKernelGGL(k_grid_records, dim3((unsigned)n_groups), dim3(REC_NT), 0, s, *h_desc, aux, n1_dev);
             PLSLAM_HIP_CHECK(hipGetLastError());
-            return launch_group<2, 1024>(d_desc, 1, lds, s, aux, REC_SLOT, h_desc);
+            return launch_group<2, 1024>(d_desc, 1, lds, s, aux, REC_SLOT, h_desc, n1_dev);
         }
         hipLaunchKernelGGL(k_grid_candidates, dim3(nwg), dim3(256), 0, s, d_desc, aux, split);
         PLSLAM_HIP_CHECK(hipGetLastError());
