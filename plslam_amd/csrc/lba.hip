@@ -302,75 +302,63 @@ int launch_gate_n(int lines, const plslam_cam& K, const double* Twf16, const dou
 // microsecond's work costs 4-5 us on the timeline ------------------------------------------------------------------------------
 // candidate pre-filter (:549-551, :650-655) x candidate flags -> the STABLE list of the landmarks that pass (ascending) + its
 // length, the association table's -1 start, and the row count of the matchGrid problem that follows (its uploaded descriptor).
-// One workgroup.  Landmark i0 + k * 1024 + tid is lane tid's in round k of a tile of 32 rounds: every load of a round is
-// coalesced and a lane's loads of several rounds are in flight together (a lane with a contiguous chunk of its own walked it
-// one dependent round trip at a time: 28 us for 10 000 landmarks); a round's survivors are counted per wave by ballot, a scan
-// over the (round, wave) counts gives every wave its first slot, and the list comes out ascending.
-__global__ void __launch_bounds__(1024)
+// A workgroup per 256 landmarks, all of them at once (a single workgroup evaluated 10 000 landmarks in 17 - 28 us: fp64 on one
+// CU); a workgroup's survivors are counted by ballot, the count is published in part[b] with a flag bit, and the workgroup's
+// first slot is the sum of the counts published before it -- it spins on its predecessors' flags (they were dispatched earlier:
+// the chain cannot wait on itself).  The list comes out ascending.  part: (n + 255) / 256 words, ZERO when the kernel starts
+// (the drivers' upload image holds them).
+constexpr int VC_NT = 256;
+constexpr uint32_t VC_FLAG = 0x80000000u;
+__global__ void __launch_bounds__(VC_NT)
 k_visible_compact(CamD K, Pose12 Twf, const double* __restrict__ X, const uint8_t* __restrict__ cand, int32_t n, int lines,
-                  int32_t* __restrict__ idx, int32_t* __restrict__ n_out, int32_t* __restrict__ fill, GridDesc* __restrict__ desc)
+                  int32_t* __restrict__ idx, int32_t* __restrict__ n_out, int32_t* __restrict__ fill, GridDesc* __restrict__ desc,
+                  uint32_t* __restrict__ part)
 {
-    constexpr int NT = 1024, NW = NT / 64, TILE_ROUNDS = 32;
-    __shared__ uint32_t s_cnt[TILE_ROUNDS * NW];            // survivors per (round, wave), then their exclusive prefix
-    __shared__ uint32_t s_wt[NW];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint64_t below = (1ull << lane) - 1ull;
-    auto passes = [&](int32_t i) -> bool {                  // (the landmark is read whether it is a candidate or not: one round trip)
+    constexpr int NW = VC_NT / 64;
+    __shared__ uint32_t s_w[NW], s_before[NW];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6, b = (int)blockIdx.x;
+    const int32_t i = b * VC_NT + tid;
+    bool v = false;
+    if (i < n) {                                            // (the landmark is read whether it is a candidate or not: one round trip)
         const uint8_t c = cand[i];
         double P[3], E[3];
         if (!lines) {
             xform44(Twf, X + 3 * (size_t)i, P);
-            return c != 0 && inside(K, P) != 0;
+            v = c != 0 && inside(K, P) != 0;
+        } else {
+            xform44(Twf, X + 6 * (size_t)i, P);
+            xform44(Twf, X + 6 * (size_t)i + 3, E);
+            v = c != 0 && inside(K, P) && inside(K, E);
         }
-        xform44(Twf, X + 6 * (size_t)i, P);
-        xform44(Twf, X + 6 * (size_t)i + 3, E);
-        return c != 0 && inside(K, P) && inside(K, E);
-    };
-    uint32_t out = 0;                                       // (uniform) listed so far
-    for (int32_t i0 = 0; i0 < n; i0 += TILE_ROUNDS * NT) {
-        const int32_t left = n - i0, rounds = left >= TILE_ROUNDS * NT ? TILE_ROUNDS : (left + NT - 1) / NT;
-        uint32_t bits = 0;                                  // bit k: this lane's landmark of round k passes
-#pragma unroll 4
-        for (int32_t k = 0; k < rounds; ++k) {
-            const int32_t i = i0 + k * NT + tid;
-            if (i < n) {
-                bits |= (passes(i) ? 1u : 0u) << k;
-                fill[i] = -1;
-            }
-        }
-        for (int32_t k = 0; k < rounds; ++k) {
-            const uint64_t b = __ballot((bits >> k) & 1u);
-            if (lane == 0) s_cnt[k * NW + wv] = (uint32_t)__popcll(b);
-        }
-        __syncthreads();
-        {   // exclusive prefix over rounds * NW <= 512 counts: one lane each, wave scans, the waves' totals through s_wt
-            const uint32_t v = tid < rounds * NW ? s_cnt[tid] : 0u;
-            uint32_t incl = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
-                if (lane >= o) incl += t;
-            }
-            if (lane == 63) s_wt[wv] = incl;
-            __syncthreads();
-            uint32_t before = 0, all = 0;
-            for (int w = 0; w < NW; ++w) {
-                before += w < wv ? s_wt[w] : 0u;
-                all += s_wt[w];
-            }
-            if (tid < rounds * NW) s_cnt[tid] = before + incl - v;
-            __syncthreads();
-            for (int32_t k = 0; k < rounds; ++k) {
-                const uint64_t b = __ballot((bits >> k) & 1u);
-                if ((bits >> k) & 1u) idx[out + s_cnt[k * NW + wv] + (uint32_t)__popcll(b & below)] = i0 + k * NT + tid;
-            }
-            out += all;
-            __syncthreads();                                // (the counts are the next tile's)
-        }
+        fill[i] = -1;
     }
-    if (tid == 0) {
-        *n_out = (int32_t)out;
-        if (desc) desc->n1 = (int32_t)out;
+    const uint64_t m = __ballot(v);
+    if (lane == 0) s_w[wv] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t own = 0, inside_wg = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        inside_wg += w < wv ? s_w[w] : 0u;
+        own += s_w[w];
+    }
+    if (tid == 0) __hip_atomic_store(part + b, own | VC_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t before = 0;                                    // the counts of the workgroups in front, a lane each
+    for (int p = tid; p < b; p += VC_NT) {
+        uint32_t x;
+        while (!((x = __hip_atomic_load(part + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & VC_FLAG)) __builtin_amdgcn_s_sleep(1);
+        before += x & ~VC_FLAG;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += (uint32_t)__shfl_xor((int)before, o);
+    if (lane == 0) s_before[wv] = before;
+    __syncthreads();
+    before = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) before += s_before[w];
+    if (v) idx[before + inside_wg + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+    if (b == (int)gridDim.x - 1 && tid == 0) {
+        *n_out = (int32_t)(before + own);
+        if (desc) desc->n1 = (int32_t)(before + own);
     }
 }
 
@@ -411,10 +399,14 @@ k_prepare_rows(CamD K, Pose12 Twf, const uint64_t* __restrict__ md, const double
     }
 }
 
+// part: visible_compact_part_words(n) device words, zero when the kernel starts
+size_t visible_compact_part_words(int32_t n) { return (size_t)(n > 0 ? (n + VC_NT - 1) / VC_NT : 1); }
 int launch_visible_compact(const plslam_cam& K, const double* Twf16, const double* X, const uint8_t* cand, int32_t n, int lines,
-                           int32_t* idx, int32_t* n_out, int32_t* fill, GridDesc* desc, hipStream_t s)
+                           int32_t* idx, int32_t* n_out, int32_t* fill, GridDesc* desc, uint32_t* part, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_visible_compact, dim3(1), dim3(1024), 0, s, cam_d(K), pose12(Twf16), X, cand, n, lines, idx, n_out, fill, desc);
+    const unsigned nb = (unsigned)visible_compact_part_words(n);
+    hipLaunchKernelGGL(k_visible_compact, dim3(nb), dim3(VC_NT), 0, s, cam_d(K), pose12(Twf16), X, cand, n, lines, idx, n_out, fill,
+                       desc, part);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

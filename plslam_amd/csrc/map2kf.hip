@@ -30,8 +30,9 @@ int launch_gate_n(int lines, const plslam_cam& K, const double* Twf16, const dou
                   int32_t* map_to_kf, hipStream_t s);
 // lba.hip: visibility x candidate flags -> stable list + length (+ -1 fill of the association table, + the row count into a
 // matchGrid descriptor); Q rows + landmarks + window centres of the listed landmarks
+size_t visible_compact_part_words(int32_t n);       // zeroed device words the kernel's workgroups chain their counts through
 int launch_visible_compact(const plslam_cam& K, const double* Twf16, const double* X, const uint8_t* cand, int32_t n, int lines,
-                           int32_t* idx, int32_t* n_out, int32_t* fill, GridDesc* desc, hipStream_t s);
+                           int32_t* idx, int32_t* n_out, int32_t* fill, GridDesc* desc, uint32_t* part, hipStream_t s);
 int launch_prepare_rows(const plslam_cam& K, const double* Twf16, const void* md, const double* lm, const int32_t* idx,
                         const int32_t* n_dev, int32_t n_max, int lines, double inv_w, double inv_h, void* Q, double* QL, int32_t* cells,
                         double* dir1, hipStream_t s);
@@ -256,7 +257,8 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
                  oCand = c.take(map_dev ? 0 : (size_t)n_map), oT = c.take((size_t)nt * 32), oTF = c.take((size_t)nt * fw * 8),
                  oTi = c.take((size_t)nt * 4), oCs = c.take(cs.size() * 4), oIt = c.take((size_t)(n_items + 1) * 4),
                  oD2 = c.take(lines ? (size_t)nt * 16 : 0), oDesc = c.take(sizeof(GridDesc)), oAux = c.take(grid_aux_words(nt) * 4),
-                 oRes = c.take(16);                                      // gate count | nq | matchGrid's count | -
+                 oRes = c.take(16),                                      // gate count | nq | matchGrid's count | -
+                 oPart = c.take(visible_compact_part_words(n_map) * 4);  // k_visible_compact's chain (zero)
     const size_t image = c.off;
     // ---- device only
     const size_t oMap = c.take((size_t)n_map * 4);                       // the association table: directly behind the counters' page
@@ -286,6 +288,7 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
     memcpy(h + oIt, items.data(), (size_t)(n_items + 1) * 4);
     if (lines) memcpy(h + oD2, dir2.data(), (size_t)nt * 16);
     memset(h + oRes, 0, 16);
+    memset(h + oPart, 0, visible_compact_part_words(n_map) * 4);
     grid_aux_fill(h + oAux, nt);
     int32_t* const res = (int32_t*)(d + oRes);                           // [0] gate count, [1] nq, [2] matchGrid's count
     plslam_grid_problem q{};
@@ -301,7 +304,7 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image, hipMemcpyHostToDevice, s));
     // ---- the launch sequence (five launches: the small steps are fused -- a launch of a microsecond's work costs 4-5 us)
     if ((rc = launch_visible_compact(*K, Twf, (const double*)d_LM, d_cand, n_map, lines, (int32_t*)(d + oQi), res + 1,
-                                     (int32_t*)(d + oMap), (GridDesc*)(d + oDesc), s)))
+                                     (int32_t*)(d + oMap), (GridDesc*)(d + oDesc), (uint32_t*)(d + oPart), s)))
         return rc;
     if ((rc = launch_prepare_rows(*K, Twf, d_MD, (const double*)d_LM, (const int32_t*)(d + oQi), res + 1, n_map, lines, fm->inv_width,
                                   fm->inv_height, d + oQ, (double*)(d + oQL), (int32_t*)(d + oCen), lines ? (double*)(d + oD1) : nullptr, s)))

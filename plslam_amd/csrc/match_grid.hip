@@ -1229,7 +1229,7 @@ __global__ __launch_bounds__(REC_NT) void k_grid_records(const GridDesc g, uint3
 {
     // n1_dev: where the row count lives when a kernel upstream decides it (g.n1 is then its upper bound, and still what the
     // scratch layout is counted by)
-    constexpr int NW = REC_NT / 64, PER_WAVE = REC_ROWS_MAX / NW, SWEEP_UN = 8;
+    constexpr int NW = REC_NT / 64, PER_WAVE = REC_ROWS_MAX / NW, SWEEP_UN = 16;
     static_assert(REC_G <= 8, "a row's cells fit an 8-bit mask");
     __shared__ uint16_t s_rows[NW][PER_WAVE];         // wave w's finds among rows [w * q, (w + 1) * q), ascending
     __shared__ uint8_t s_mask[NW][PER_WAVE];

@@ -297,3 +297,57 @@ def test_two_launch_path_does_not_depend_on_the_candidate_order(ctx, oracle):
         m, n = ctx.match_grid(window=(3, 3, 3, 3), nnr=0.8, mutual=True, **c)
         np.testing.assert_array_equal(m, ref[0])
         assert n == ref[1]
+
+
+def _regrid(c, edit):
+    """The case's grid with its cell lists edited: edit(lists) gets one Python list per cell."""
+    cs, items = np.asarray(c["cell_start"]), np.asarray(c["cell_items"])
+    lists = [list(items[cs[k]:cs[k + 1]]) for k in range(len(cs) - 1)]
+    edit(lists)
+    out = dict(c)
+    out["cell_start"] = np.concatenate([[0], np.cumsum([len(x) for x in lists])]).astype(np.int32)
+    out["cell_items"] = np.array([i for x in lists for i in x] + [0], np.int32)[:max(1, sum(len(x) for x in lists))]
+    return out
+
+
+def test_lone_problem_records_path_every_branch(ctx, oracle):
+    """One problem alone on the chip (>= 128 rows, mutual, row and column numbers of 23 bits together): k_grid_records lists each
+    (cell, column) run's records in the run's own 8 words, k_match_grid folds them.  The branches: every column with ONE run
+    (points: the list is folded as it stands); an item in two cells or twice in one cell (two runs: the tables are wiped and
+    the list is bucketed by column); item numbers outside [0, n2) and cells that hold only those; runs of more than 8 records
+    (whole-grid windows over 1024+ rows: the words beyond the eighth are listed from the end of the store); a row count that
+    does not fill the last wave's quarter; windows that reach nothing."""
+    r = _rng(4242)
+    c = point_case(31, 1500, 1400, G.GRID_COLS, G.GRID_ROWS)
+    w3 = (3, 3, 3, 3)
+    _same(ctx, oracle, c, w3, 0.75, True)                                      # one run per column
+    ncell = G.GRID_COLS * G.GRID_ROWS
+
+    def dup_across(lists):                                                     # 200 items copied into a neighbouring cell
+        for k in r.choice(ncell - 1, 200, replace=False):
+            if lists[k]:
+                lists[k + 1].append(lists[k][0])
+    _same(ctx, oracle, _regrid(c, dup_across), w3, 0.75, True)
+
+    def dup_within(lists):                                                     # ... and twice in their own
+        for k in r.choice(ncell, 200, replace=False):
+            if lists[k]:
+                lists[k].append(lists[k][-1])
+    _same(ctx, oracle, _regrid(c, dup_within), w3, 0.9, True)
+
+    def strays(lists):                                                         # numbers no desc2 row answers to
+        for k in r.choice(ncell, 300, replace=False):
+            lists[k].insert(0, int(r.choice([-1, -7, 1400, 1401, 2 ** 31 - 1])))
+    _same(ctx, oracle, _regrid(c, strays), w3, 0.75, True)
+
+    # long runs: every row reaches every cell
+    for n1, n2, cols, rows in ((1024, 700, 7, 5), (1531, 300, 16, 12), (2050, 64, 2, 3)):
+        for mk in (point_case, line_case):
+            cc = mk(900 + n1, n1, n2, cols, rows, ties=(n1 % 2 == 0))
+            _same(ctx, oracle, cc, (cols, cols, rows, rows), 0.75, True)
+            _same(ctx, oracle, cc, (0, 0, 0, 0), 0.9, True)                  # one cell each
+    # windows that reach nothing: every centre far outside the grid
+    far = dict(c)
+    far["centres"] = np.asarray(c["centres"]) + 10 ** 6
+    ref = _same(ctx, oracle, far, w3, 0.75, True)
+    assert ref[1] == 0

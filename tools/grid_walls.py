@@ -9,6 +9,6 @@ dev = torch.device("cuda", 0)
 out = {}
 g = bench_rows.grid(ctx, dev, torch, O, torch.cuda.Stream(device=dev))
 out["grid"] = {k: v for k, v in g.items() if k != "workload"}
-d = bench_rows.drivers(ctx, O)
+d = bench_rows.drivers(ctx, O, dev)
 out["drivers"] = {k: (v if not isinstance(v, dict) else {a: b for a, b in v.items() if "us" in a}) for k, v in d.items() if k != "workload"}
 print(json.dumps(out, indent=1))
