@@ -170,6 +170,16 @@ def drivers(ctx, O, dev_tensors=None):
                 raise SystemExit(f"secondary record drivers/kf2kf_{kind}_{name}: result differs from the oracle")
             rec[f"kf2kf_{kind}_{n}_{name}"] = dict(_pct(_wall(g, 20)), cpu_oracle_1thread_us=cpu, matches=int(ref[1]),
                                                    verified="match table + count bit-exact vs the oracle")
+            if dev_tensors is not None:
+                # the same call with the keyframes' rows resident on the device (plslam_kf2kf_match_*_dev)
+                import torch
+                dX, dP, dC = (torch.from_numpy(np.ascontiguousarray(s[k_])).to(dev_tensors) for k_ in ("X", "d_prev", "d_curr"))
+                gd = lambda: ctx.kf2kf_match_dev(kind, cam, s["DT"], dX.data_ptr(), dP.data_ptr(), n, s["feat"], dC.data_ptr(),   # noqa: E731
+                                                 0.75, True, 20, fm)
+                gotd = gd()
+                if not (np.array_equal(gotd[0], ref[0]) and gotd[1] == ref[1]):
+                    raise SystemExit(f"secondary record drivers/kf2kf_{kind}_{name} (rows on the device): result differs from the oracle")
+                rec[f"kf2kf_{kind}_{n}_{name}"]["rows_on_device_us_median"] = _pct(_wall(gd, 20))["us_median"]
     return rec
 
 

@@ -647,6 +647,20 @@ int plslam_kf2kf_match_lines(plslam_ctx* ctx, const plslam_cam* K, const double*
                              const uint8_t* desc_curr, int32_t n_curr, float nnr, int mutual, int32_t min_matches,
                              const plslam_fast_matching* fm, int32_t* matches_12, int32_t* n_matches,
                              int32_t* used_match);
+/* The same with the ROWS ON THE DEVICE: d_P_prev / d_sPeP_prev (n_prev x 3 | 6 doubles), d_desc_prev and d_desc_curr (x 32
+ * bytes, 16-byte aligned) are device pointers -- a keyframe's descriptors and 3D features stay on the GPU from one call to
+ * the next (they are the rows the stereo and frame-to-frame plans already hold); nothing is staged or uploaded but the grid
+ * the host builds from pl_curr / seg_curr (HOST pointers, as above).  Results and semantics are those of the forms above. */
+int plslam_kf2kf_match_points_dev(plslam_ctx* ctx, const plslam_cam* K, const double* DT, const double* d_P_prev,
+                                  const uint8_t* d_desc_prev, int32_t n_prev, const double* pl_curr,
+                                  const uint8_t* d_desc_curr, int32_t n_curr, float nnr, int mutual,
+                                  int32_t min_matches, const plslam_fast_matching* fm, int32_t* matches_12,
+                                  int32_t* n_matches, int32_t* used_match);
+int plslam_kf2kf_match_lines_dev(plslam_ctx* ctx, const plslam_cam* K, const double* DT, const double* d_sPeP_prev,
+                                 const uint8_t* d_desc_prev, int32_t n_prev, const double* seg_curr,
+                                 const uint8_t* d_desc_curr, int32_t n_curr, float nnr, int mutual,
+                                 int32_t min_matches, const plslam_fast_matching* fm, int32_t* matches_12,
+                                 int32_t* n_matches, int32_t* used_match);
 
 /* ---- representative ("median") descriptor of every landmark, batched ------------------------ */
 /* Replaces the descriptor part of MapPoint::updateAverageDescDir (src/mapFeatures.cpp:51-84) and of

@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
     "plslam_map2kf_match_points_fast", "plslam_map2kf_match_lines_fast", "plslam_map2kf_match_points_dev", "plslam_map2kf_match_lines_dev",
-    "plslam_kf2kf_match_points", "plslam_kf2kf_match_lines",
+    "plslam_kf2kf_match_points", "plslam_kf2kf_match_lines", "plslam_kf2kf_match_points_dev", "plslam_kf2kf_match_lines_dev",
     "plslam_lbd_binarise", "plslam_lbd_binarise_dev", "plslam_lbd_compute", "plslam_lbd_compute_dev",
     "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
     "plslam_stereo_point_gate", "plslam_stereo_line_gate", "plslam_stereo_point_gate_dev", "plslam_stereo_line_gate_dev",
@@ -229,7 +229,8 @@ def load() -> C.CDLL:
                                                  C.POINTER(i32)]
     L.plslam_map2kf_match_points_dev.argtypes = L.plslam_map2kf_match_points_fast.argtypes
     L.plslam_map2kf_match_lines_dev.argtypes = L.plslam_map2kf_match_lines_fast.argtypes
-    for f in (L.plslam_kf2kf_match_points, L.plslam_kf2kf_match_lines):
+    for f in (L.plslam_kf2kf_match_points, L.plslam_kf2kf_match_lines, L.plslam_kf2kf_match_points_dev,
+              L.plslam_kf2kf_match_lines_dev):
         f.argtypes = [vp, C.POINTER(Cam), vp, vp, vp, i32, vp, vp, i32, C.c_float, C.c_int, i32, C.POINTER(FastMatching), vp,
                       C.POINTER(i32), C.POINTER(i32)]
     L.plslam_pose_gn_accumulate.argtypes = [vp, C.POINTER(Cam), f64, vp, vp, vp, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
@@ -675,6 +676,23 @@ class Context:
         _check(fn(self._h, C.byref(cam), _p(DT), _p(X), _p(dp), X.shape[0], _p(fc), _p(dc), fc.shape[0], float(nnr),
                   int(bool(mutual)), int(min_matches), C.byref(F), _p(out), C.byref(n), C.byref(used)),
                "plslam_kf2kf_match_" + kind)
+        return out, n.value, used.value
+
+    def kf2kf_match_dev(self, kind, cam, DT, d_X_prev, d_desc_prev, n_prev, feat_curr, d_desc_curr, nnr, mutual, min_matches, fm):
+        """kf2kf_match with the ROWS on the device: d_X_prev (n_prev x 3 | 6 float64), d_desc_prev (n_prev x 32 uint8) and
+        d_desc_curr (len(feat_curr) x 32 uint8) are device addresses (ints); feat_curr and the results are host arrays."""
+        fw = 2 if kind == "points" else 4
+        DT = _arr(DT, np.float64, (16,))
+        fc = _arr(feat_curr, np.float64, (-1, fw))
+        out = np.empty(int(n_prev), np.int32)
+        F = FastMatching(int(fm["enabled"]), int(fm["grid_cols"]), int(fm["grid_rows"]), int(fm["ws"]),
+                         float(fm["inv_width"]), float(fm["inv_height"]), float(fm["nnr_grid"]),
+                         float(fm.get("line_sim_th", 0.75)))
+        n, used = C.c_int32(), C.c_int32()
+        fn = self._L.plslam_kf2kf_match_points_dev if kind == "points" else self._L.plslam_kf2kf_match_lines_dev
+        _check(fn(self._h, C.byref(cam), _p(DT), int(d_X_prev), int(d_desc_prev), int(n_prev), _p(fc), int(d_desc_curr),
+                  fc.shape[0], float(nnr), int(bool(mutual)), int(min_matches), C.byref(F), _p(out), C.byref(n), C.byref(used)),
+               "plslam_kf2kf_match_" + kind + "_dev")
         return out, n.value, used.value
 
     # ---- device-pointer calls ----------------------------------------------------------------

@@ -334,8 +334,10 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
 int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* DT, const double* X_prev,
                  const uint8_t* desc_prev, int32_t n_prev, const double* feat_curr, const uint8_t* desc_curr,
                  int32_t n_curr, float nnr, int mutual, int32_t min_matches, const plslam_fast_matching* fm,
-                 int32_t* matches_12, int32_t* n_matches, int32_t* used_match)
+                 int32_t* matches_12, int32_t* n_matches, int32_t* used_match, bool rows_dev = false)
 {
+    // rows_dev: X_prev, desc_prev and desc_curr are DEVICE pointers (the keyframes' descriptors and the previous keyframe's 3D
+    // features stay on the GPU between calls; 16-byte aligned rows): nothing is staged or uploaded but the grid of feat_curr
     PLSLAM_REQUIRE(ctx && K && DT && n_prev >= 0 && n_curr >= 0, PLSLAM_EINVAL);
     const bool fast = fm && fm->enabled;
     if (fast) PLSLAM_REQUIRE(fast_ok(fm), PLSLAM_EINVAL);
@@ -346,6 +348,10 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
     for (int32_t i = 0; i < n_prev; ++i) matches_12[i] = -1;
     if (n_curr == 0) return PLSLAM_OK;                                    // :243 / :368
     PLSLAM_REQUIRE(X_prev && desc_prev && feat_curr && desc_curr, PLSLAM_EINVAL);
+    if (rows_dev)
+        PLSLAM_REQUIRE((reinterpret_cast<uintptr_t>(desc_prev) & 15) == 0 && (reinterpret_cast<uintptr_t>(desc_curr) & 15) == 0 &&
+                           (reinterpret_cast<uintptr_t>(X_prev) & 7) == 0,
+                       PLSLAM_EINVAL);
     const bool bf_possible = n_curr > min_matches && n_prev > min_matches;
     if (!fast && !(bf_possible && 0 < min_matches)) return PLSLAM_OK;      // no matcher would run
     const int xw = lines ? 6 : 3;
@@ -356,7 +362,8 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
     // ONE page-locked image [X_prev | desc_prev | desc_curr] -> one upload (X only when the windowed matcher runs); the
     // match table comes back through page-locked memory the kernels write (no download on the common path)
     Carve c;
-    const size_t oQ = c.take((size_t)n_prev * 32), oT = c.take((size_t)n_curr * 32), oX = c.take(fast ? (size_t)n_prev * xw * 8 : 0);
+    const size_t oQ = c.take(rows_dev ? 0 : (size_t)n_prev * 32), oT = c.take(rows_dev ? 0 : (size_t)n_curr * 32),
+                 oX = c.take(fast && !rows_dev ? (size_t)n_prev * xw * 8 : 0);
     const size_t image = c.off;
     const size_t oM = c.take((size_t)n_prev * 4), oCnt = c.take(16);
     int rc;
@@ -365,10 +372,15 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
     if ((rc = ctx->pin_out.reserve((size_t)n_prev * 4 + 256))) return rc;
     char* d = ctx->misc_a.as<char>();
     char* h = ctx->pin_in.as<char>();
-    memcpy(h + oQ, desc_prev, (size_t)n_prev * 32);
-    memcpy(h + oT, desc_curr, (size_t)n_curr * 32);
-    if (fast) memcpy(h + oX, X_prev, (size_t)n_prev * xw * 8);
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image, hipMemcpyHostToDevice, s));
+    if (!rows_dev) {
+        memcpy(h + oQ, desc_prev, (size_t)n_prev * 32);
+        memcpy(h + oT, desc_curr, (size_t)n_curr * 32);
+        if (fast) memcpy(h + oX, X_prev, (size_t)n_prev * xw * 8);
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image, hipMemcpyHostToDevice, s));
+    }
+    const uint8_t* const d_Q = rows_dev ? desc_prev : (const uint8_t*)(d + oQ);
+    const uint8_t* const d_T = rows_dev ? desc_curr : (const uint8_t*)(d + oT);
+    const double* const d_X = rows_dev ? X_prev : (const double*)(d + oX);
     int32_t* tab_host = ctx->pin_out.as<int32_t>();
     int32_t* tab_mapped = static_cast<int32_t*>(mapped_device_pointer(tab_host));
     int32_t* tab_dev = (int32_t*)(d + oM);
@@ -376,9 +388,9 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
     bool have = false, on_host = false;            // on_host: the current table is in tab_host (written by a kernel, synchronised)
     if (fast) {
         // points: pj_points = projection * inv (:256); lines: pj_lines = the projected PIXELS (:392-393, as upstream)
-        if ((rc = grid_path(ctx, lines, K, DT, (const double*)(d + oX), n_prev, lines ? 1.0 : fm->inv_width,
-                            lines ? 1.0 : fm->inv_height, (const uint8_t*)(d + oQ), feat_curr, nullptr, n_curr,
-                            (const uint8_t*)(d + oT), fm, mutual, tab_mapped ? tab_mapped : tab_dev, &matches)))
+        if ((rc = grid_path(ctx, lines, K, DT, d_X, n_prev, lines ? 1.0 : fm->inv_width,
+                            lines ? 1.0 : fm->inv_height, d_Q, feat_curr, nullptr, n_curr,
+                            d_T, fm, mutual, tab_mapped ? tab_mapped : tab_dev, &matches)))
             return rc;
         have = true;
         on_host = tab_mapped != nullptr;
@@ -386,7 +398,7 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
     bool count_entries = false;
     if (bf_possible && matches < min_matches) {                            // :274-278 / :421-425
         plslam_match_problem p{};
-        p.d1 = (uint8_t*)(d + oQ); p.n1 = n_prev; p.d2 = (uint8_t*)(d + oT); p.n2 = n_curr;
+        p.d1 = d_Q; p.n1 = n_prev; p.d2 = d_T; p.n2 = n_curr;
         p.nnr = nnr; p.mutual = mutual ? 1 : 0; p.n_matches = (int32_t*)(d + oCnt);
         p.keep_prior = have ? 1 : 0;             // the vector matchGrid filled is handed on (:271 -> :277, :418 -> :424)
         if (p.keep_prior) {
@@ -639,6 +651,24 @@ int plslam_kf2kf_match_lines(plslam_ctx* ctx, const plslam_cam* K, const double*
 {
     return plslam::kf2kf_driver(ctx, 1, K, DT, sPeP_prev, desc_prev, n_prev, seg_curr, desc_curr, n_curr, nnr, mutual,
                                 min_matches, fm, matches_12, n_matches, used_match);
+}
+
+int plslam_kf2kf_match_points_dev(plslam_ctx* ctx, const plslam_cam* K, const double* DT, const double* d_P_prev,
+                                  const uint8_t* d_desc_prev, int32_t n_prev, const double* pl_curr, const uint8_t* d_desc_curr,
+                                  int32_t n_curr, float nnr, int mutual, int32_t min_matches, const plslam_fast_matching* fm,
+                                  int32_t* matches_12, int32_t* n_matches, int32_t* used_match)
+{
+    return plslam::kf2kf_driver(ctx, 0, K, DT, d_P_prev, d_desc_prev, n_prev, pl_curr, d_desc_curr, n_curr, nnr, mutual,
+                                min_matches, fm, matches_12, n_matches, used_match, true);
+}
+
+int plslam_kf2kf_match_lines_dev(plslam_ctx* ctx, const plslam_cam* K, const double* DT, const double* d_sPeP_prev,
+                                 const uint8_t* d_desc_prev, int32_t n_prev, const double* seg_curr, const uint8_t* d_desc_curr,
+                                 int32_t n_curr, float nnr, int mutual, int32_t min_matches, const plslam_fast_matching* fm,
+                                 int32_t* matches_12, int32_t* n_matches, int32_t* used_match)
+{
+    return plslam::kf2kf_driver(ctx, 1, K, DT, d_sPeP_prev, d_desc_prev, n_prev, seg_curr, d_desc_curr, n_curr, nnr, mutual,
+                                min_matches, fm, matches_12, n_matches, used_match, true);
 }
 
 }  // extern "C"

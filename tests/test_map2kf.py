@@ -266,6 +266,12 @@ def test_gpu_kf2kf_driver_bit_exact(ctx, oracle, kind, n_prev, n_curr):
         ref = oracle.kf2kf_match(kind, ocam, *a, nnr, mutual, mm, fm)
         np.testing.assert_array_equal(got[0], ref[0])
         assert got[1] == ref[1] and got[2] == ref[2]
+        # the same with the rows resident on the device (plslam_kf2kf_match_*_dev): nothing but the grid goes up
+        import torch
+        dX, dP, dC = (torch.from_numpy(np.ascontiguousarray(s[k])).cuda() for k in ("X", "d_prev", "d_curr"))
+        gotd = ctx.kf2kf_match_dev(kind, cam, s["DT"], dX.data_ptr(), dP.data_ptr(), n_prev, s["feat"], dC.data_ptr(), nnr, mutual, mm, fm)
+        np.testing.assert_array_equal(gotd[0], ref[0])
+        assert gotd[1] == ref[1] and gotd[2] == ref[2]
         # the count is the number of entries, except after the fall-back ON matchGrid's vector: entries that were kept
         # were never counted, kept entries that fail the consistency loop are subtracted (the reference's arithmetic)
         assert ref[1] == int((ref[0] >= 0).sum()) or (ref[2] == 1 and fm["enabled"] and mutual)
