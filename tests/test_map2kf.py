@@ -277,3 +277,44 @@ def test_gpu_kf2kf_driver_bit_exact(ctx, oracle, kind, n_prev, n_curr):
         assert ref[1] == int((ref[0] >= 0).sum()) or (ref[2] == 1 and fm["enabled"] and mutual)
         seen.add(ref[2])
     assert seen == {0, 1}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["points", "lines"])
+def test_gpu_fast_driver_without_visible_candidates_and_on_a_large_map(ctx, oracle, kind):
+    """The one-launch form of the fast_matching drivers with NOTHING to match -- every candidate flag zero, or every landmark
+    behind the camera: the row count the kernels read from the device is zero, matchGrid's list is empty -- and with a map far
+    larger than one workgroup's share (70 001 landmarks: k_visible_compact's workgroups chain their counts over 274 links, the
+    last one partly filled), through the host-pointer and the device-resident entry points."""
+    import torch
+    import plslam_amd
+    cam, ocam = plslam_amd.make_cam(**synth.EUROC), oracle.make_cam(**synth.EUROC)
+    lines = kind == "lines"
+    dev = torch.device("cuda", ctx.device)
+
+    def both(s, cand, lm, nnr=0.75, mm=10, fm=None):
+        fm = fm or fast_cfg()
+        a = (s["Twf"], lm, s["med"], cand, s["kf_desc"], s["kf_feat"], s["kf_idx"])
+        ref = oracle.map2kf_match_fast(kind, ocam, *a, nnr, True, 1.5, mm, fm, kf_seg=s.get("kf_seg"))
+        got = ctx.map2kf_match_fast(kind, cam, *a, nnr, True, 1.5, mm, fm, kf_seg=s.get("kf_seg"))
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (lm, s["med"], cand)]
+        gotd = ctx.map2kf_match_dev(kind, cam, s["Twf"], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), lm.shape[0], s["kf_desc"],
+                                    s["kf_feat"], s["kf_idx"], nnr, True, 1.5, mm, fm, kf_seg=s.get("kf_seg"))
+        for g in (got, gotd):
+            np.testing.assert_array_equal(g[0], ref[0])
+            assert g[1] == ref[1] and g[2] == ref[2]
+        return ref
+
+    s = scene(3000, 400, lines=lines, seed=77)
+    ref = both(s, np.zeros_like(s["cand"]), s["LM"])                       # no candidate flag set
+    assert ref[1] == 0 and (ref[0] == -1).all()
+    behind = np.array(s["LM"], np.float64)
+    Tfw = np.linalg.inv(s["Twf"])
+    for e in range(2 if lines else 1):                                      # every landmark 50 m behind the camera
+        Xc = np.stack([np.zeros(3000), np.zeros(3000), np.full(3000, -50.0)], 1)
+        behind[:, 3 * e:3 * e + 3] = Xc @ Tfw[:3, :3].T + Tfw[:3, 3]
+    ref = both(s, s["cand"], behind)
+    assert ref[1] == 0 and (ref[0] == -1).all()
+    big = scene(70001, 600, lines=lines, seed=78)
+    ref = both(big, big["cand"], big["LM"], nnr=0.9, mm=5)
+    assert ref[1] > 0
