@@ -751,3 +751,36 @@ def test_fused_stage_behind_the_scan_equals_the_separate_kernels(ctx, oracle, n_
         for name, d1, d2 in frontend.pair_problems(s["orb_l"], s["orb_r"], s["lbd_l"], s["lbd_r"], i):
             em, _ = oracle.match(d1, d2, 0.8 if name.startswith("orb") else 0.9, True)
             assert np.array_equal(out[2][0][i, sl[name]], em), (i, name)
+
+
+@pytest.mark.parametrize("form", [4, 5], ids=["k1h", "k1i"])
+def test_lazy_second_keys_with_prior_entries_column_split_and_a_capped_post_grid(ctx, oracle, form):
+    """The minimum-only scans complete a column's second key lazily in the finalize kernel, from the neighbouring rows' keys
+    (DPP over 16-row groups: finalize blocks start at multiples of 256 rows and every lane runs the sequence).  The option
+    combinations the default tests do not reach: a vector that already holds entries (keep_prior), a forced column split,
+    a capped grid behind the scan (post_workgroups) -- tables and counts against the oracle, exact_second at its default 0."""
+    import plslam_amd
+    r = np.random.Generator(np.random.PCG64(900 + form))
+    try:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)
+        ctx.set_option("mfma_form", form)
+        for n1, n2 in ((1500, 1400), (3000, 2100), (700, 2600)):
+            d1, d2 = synth.random_desc(r, n1), synth.random_desc(r, n2)
+            k = min(n1, n2) // 2
+            d2[:k] = d1[:k] ^ np.packbits(r.random((k, 256)) < 0.04, axis=1)
+            prior = np.where(r.random(n1) < 0.5, r.integers(0, n2, n1), -1).astype(np.int32)
+            ref, nref = oracle.match_prior(d1, d2, 0.75, True, prior)
+            ref0, nref0 = oracle.match(d1, d2, 0.75, True)
+            for split, post in ((0, 0), (2, 0), (0, 3), (2, 5)):
+                ctx.set_option("col_split", split)
+                ctx.set_option("post_workgroups", post)
+                got, n = ctx.match_prior(d1, d2, 0.75, True, prior)
+                np.testing.assert_array_equal(got, ref)
+                assert n == nref
+                got0, n0 = ctx.match(d1, d2, 0.75, True)
+                np.testing.assert_array_equal(got0, ref0)
+                assert n0 == nref0
+    finally:
+        for k in ("col_split", "post_workgroups", "mfma_form"):
+            ctx.set_option(k, 0)
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
