@@ -106,6 +106,15 @@ void plslam_ctx_destroy(plslam_ctx* ctx);
  * "post_workgroups" (0 = default: one workgroup per block-table entry; n > 0: in a split run (plslam_match_plan_run_split) the
  * stages behind the scan -- K1h's merge of the column partials, the finalize kernel -- run as at most n workgroups that walk
  * their block tables, i.e. they hold a bounded number of workgroup slots beside the next scan; measured neutral to +1 %),
+ * "split_post" (column-split plans of mutual problems -- a few LARGE problems, e.g. one local map against one frame: 0 = auto
+ * (default): everything behind the scan is ONE kernel, which merges the column partials and decides the matches from the
+ * column side -- two launches per run | 1 = never: merge kernel + finalize kernel; identical tables and counts),
+ * "post_xcd" (0 = default: the finalize kernel takes its block table in order | 1 = every XCD takes a contiguous run of the
+ * table, so the row blocks of one problem gather the problem's column keys through ONE L2 -- measured SLOWER on MI355X, 0.302
+ * against 0.280 ms per 4096-pair step for the stages behind the scan: the gathers of a problem then queue on one L2 instead of
+ * six; identical tables),
+ * "split_target", "split_min_tiles" (column-split plans: workgroups per CU the split aims at, 0 = 3; tiles of 32 columns per
+ * range at least, 0 = 4),
  * "graph" (plslam_match_plan_run as ONE replayed HIP graph -- the run's launches captured on the caller's stream at its first
  * use: 0 = plans of fewer waves than the chip has SIMDs | 1 = never (default: measured SLOWER on ROCm 7 -- C3's three-kernel
  * run 26.9 us per back-to-back run against 22.3 us with plain launches) | 2 = always; never while profiling),

@@ -87,6 +87,8 @@ struct plslam_match_plan {
     int merge_parts = 1;               // K1f: lanes per column in the partial merge (tall problems: many row blocks, few columns)
     bool col_split = false;            // K1f on a FEW LARGE problems: columns cut into ranges scanned as sub-problems
     DevBuf rowtmp;                     // ... their per-range row results (merged by the finalize kernel)
+    bool split_post = false;           // ... and everything behind the scan in ONE kernel (k_split_post): the run is two launches
+    bool split_post_ok = false;        // (what plan_build found; a gate applied by the finalize kernel switches split_post off)
     int32_t ndir = 0, ndir_blocks = 0; // non-mutual problems on the directed form of K1e
     bool dir_multi = false;
     SymDesc* d_dirs = nullptr; BlockDesc* d_dir_blocks = nullptr;
@@ -234,11 +236,13 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     auto split_of = [&](const plslam_match_problem& p, int32_t* cstep) -> int32_t {
         *cstep = 0;
         if (!P->col_split || p.n1 <= 0 || p.n2 <= 0) return 1;
-        const int64_t target = 3 * (int64_t)ctx->prop.multiProcessorCount;
+        // (options "split_target": workgroups per CU the split aims at, 0 = 3; "split_min_tiles": tiles per range at least, 0 = 4)
+        const int64_t target = (ctx->split_target > 0 ? ctx->split_target : 3) * (int64_t)ctx->prop.multiProcessorCount;
         const int64_t want = (target + mf_row_blocks - 1) / mf_row_blocks;
         const int32_t tiles = (p.n2 + 31) / 32;
         int32_t per = (int32_t)((tiles + want - 1) / want);
-        if (per < 4) per = 4;
+        const int32_t min_tiles = ctx->split_min_tiles > 0 ? ctx->split_min_tiles : 4;
+        if (per < min_tiles) per = min_tiles;
         const int32_t ns = (tiles + per - 1) / per;
         if (ns <= 1) return 1;
         *cstep = per * 32;
@@ -327,6 +331,16 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->d_counts_zero = d_counts;
     P->ncounts = nprob;
 
+    // A column-split plan of mutual K1f problems runs in TWO launches: k_split_post merges the column partials and decides the
+    // matches from the column side (hamming_mfma_g.hip); rows without a match keep the -1 the scan's first column range
+    // writes.  Not with kept entries (keep_prior: a rejected row's old entry goes through the consistency loop) and not with a
+    // stereo gate behind the table (add_stereo_gates switches back to merge + finalize).  Option "split_post": 0 = auto, 1 = never.
+    {
+        bool ok = P->col_split && k1f && !h_parts && !P->fused && ctx->split_post != 1 && nprob > 0;
+        for (int32_t i = 0; ok && i < nprob; ++i)
+            ok = is_sym(probs[i]) && !probs[i].keep_prior;
+        P->split_post = P->split_post_ok = ok;
+    }
     std::vector<ScanDesc> scans;
     std::vector<int32_t> scan_problem;   // scans[k] belongs to problem scan_problem[k]
     std::vector<SymDesc> syms, dirs;
@@ -369,6 +383,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
                 y.a = p.d1; y.b = p.d2 + (size_t)c0 * 32;
                 y.keys12 = d_tmp + 2 * (tmp_row + (int64_t)s_ * p.n1);
                 y.n1 = p.n1; y.n2 = n2s;
+                if (P->split_post) { y.mutual = i + 1; y.matches_12 = s_ == 0 ? p.matches_12 : nullptr; }
                 if (p.mutual) {
                     y.keys21 = k21 + 2 * (size_t)c0;
                     y.part21 = d_part + 2 * part_row;
@@ -394,6 +409,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             pd.part21 = y.part21;
             y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = (p.n1 + rpp - 1) / rpp;
             part_row += k1f ? part_units(p.n1, p.n2) : (int64_t)y.n_iblk * p.n2;
+            if (P->split_post) { y.mutual = i + 1; y.matches_12 = p.matches_12; }     // (a problem of one column range)
             if (P->fused) {
                 y.mutual = 1; y.matches_12 = p.matches_12; y.n_matches = pd.n_matches; y.nnr = p.nnr;
                 yblocks.push_back({(int32_t)syms.size(), 0});
@@ -665,7 +681,10 @@ static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
         s = sp;
     }
 
-    if (P->post_fused) {
+    if (P->split_post) {
+        r = launch_split_post(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, P->d_probs, s);
+        if (r) return r;
+    } else if (P->post_fused) {
         if (P->ngates > 0 && P->d_gate_counts) PLSLAM_HIP_CHECK(hipMemsetAsync(P->d_gate_counts, 0, sizeof(int32_t) * (size_t)P->ngates, s));
         r = launch_post_fused(P->d_probs, P->nprob, P->ngates > 0 ? P->d_gates : nullptr, P->post_lds, s);
         if (r) return r;
@@ -677,7 +696,7 @@ static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
     if (r) return r;
     // the gate stage: its counters are cleared first; gates over the plan's own tables run inside the finalize kernel
     if (P->ngates > 0 && P->d_gate_counts) PLSLAM_HIP_CHECK(hipMemsetAsync(P->d_gate_counts, 0, sizeof(int32_t) * (size_t)P->ngates, s));
-    r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, P->ngates > 0 ? P->d_gates : nullptr, s, split ? P->ctx->post_workgroups : 0);
+    r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, P->ngates > 0 ? P->d_gates : nullptr, s, split ? P->ctx->post_workgroups : 0, P->ctx->post_xcd != 0);
     if (r) return r;
     }
     if (P->ngate_blocks > 0) {
@@ -831,6 +850,26 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         ctx->graph = value;
         return PLSLAM_OK;
     }
+    if (!strcmp(key, "post_xcd")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= 1, PLSLAM_EINVAL);
+        ctx->post_xcd = value;
+        return PLSLAM_OK;
+    }
+    if (!strcmp(key, "split_post")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= 1, PLSLAM_EINVAL);
+        ctx->split_post = value;
+        return PLSLAM_OK;
+    }
+    if (!strcmp(key, "split_target")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= 64, PLSLAM_EINVAL);
+        ctx->split_target = value;
+        return PLSLAM_OK;
+    }
+    if (!strcmp(key, "split_min_tiles")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= 64, PLSLAM_EINVAL);
+        ctx->split_min_tiles = value;
+        return PLSLAM_OK;
+    }
     if (!strcmp(key, "post_workgroups")) {
         PLSLAM_REQUIRE(value >= 0, PLSLAM_EINVAL);
         ctx->post_workgroups = value;
@@ -853,6 +892,10 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "col_split")) { *value = ctx->col_split; return PLSLAM_OK; }
     if (!strcmp(key, "exact_second")) { *value = ctx->exact_second; return PLSLAM_OK; }
     if (!strcmp(key, "post_workgroups")) { *value = ctx->post_workgroups; return PLSLAM_OK; }
+    if (!strcmp(key, "post_xcd")) { *value = ctx->post_xcd; return PLSLAM_OK; }
+    if (!strcmp(key, "split_post")) { *value = ctx->split_post; return PLSLAM_OK; }
+    if (!strcmp(key, "split_target")) { *value = ctx->split_target; return PLSLAM_OK; }
+    if (!strcmp(key, "split_min_tiles")) { *value = ctx->split_min_tiles; return PLSLAM_OK; }
     if (!strcmp(key, "graph")) { *value = ctx->graph; return PLSLAM_OK; }
     set_last_error("unknown option '%s'", key);
     return PLSLAM_EINVAL;
@@ -933,6 +976,7 @@ int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_ste
     plan->ngates = 0;
     plan->d_gate_counts = nullptr;
     plan->d_gates = nullptr;
+    plan->split_post = plan->split_post_ok;
     auto upload_probs = [&]() -> int {
         if (plan->h_probs.empty()) return PLSLAM_OK;
         PLSLAM_HIP_CHECK(hipMemcpyAsync(plan->d_probs, plan->h_probs.data(), plan->h_probs.size() * sizeof(ProblemDesc),
@@ -969,6 +1013,8 @@ int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_ste
     plan->ngate_blocks = (int32_t)blocks.size();
     plan->ngates = ngates;
     plan->d_gate_counts = any_cnt ? gates[0].n_stereo : nullptr;
+    for (int32_t gk : gate_of)
+        if (gk >= 0) plan->split_post = false;              // the finalize kernel applies that gate: merge + finalize it is
     return PLSLAM_OK;
 }
 
@@ -1059,6 +1105,10 @@ int plslam_match_plan_dump(plslam_match_plan* plan, void* keys_out, size_t keys_
     if (!plan || !keys_bytes || !part_bytes) return PLSLAM_EINVAL;
     DeviceGuard g(plan->ctx->device);
     (void)hipDeviceSynchronize();
+    if (plan->split_post) {            // the two-launch form leaves the rows' merged pairs unwritten: complete them here
+        (void)launch_split_rows_dump(plan->d_probs, plan->d_fin_blocks, plan->nfin_blocks, plan->ctx->stream);
+        (void)hipDeviceSynchronize();
+    }
     *keys_bytes = plan->keys.cap;
     *part_bytes = plan->partials.cap;
     if (keys_out && keys_cap >= plan->keys.cap && plan->keys.p) (void)hipMemcpy(keys_out, plan->keys.p, plan->keys.cap, hipMemcpyDeviceToHost);

@@ -127,6 +127,9 @@ struct plslam_ctx {
     int exact_second = 0; // K1h: 1 = the index of every second-best row key is exact (0: only where it is an output -- knnMatch)
     int graph = 1;             // plslam_match_plan_run as a replayed HIP graph: 0 = latency plans, 1 = never (default until measured), 2 = always
     int post_workgroups = 0;   // > 0: the stages behind a scan (merge of K1h's partials, finalize) run as at most this many workgroups walking their block tables
+    int split_target = 0, split_min_tiles = 0;   // column split: workgroups per CU aimed at (0 = 3), tiles per column range at least (0 = 4)
+    int split_post = 0;  // column-split K1f plans: 0 = auto (merge + ratio + mutual behind the scan in ONE kernel: two launches per run), 1 = never
+    int post_xcd = 0;    // finalize: 1 = an XCD takes contiguous entries of the block table (a problem's row blocks share one L2), 0 = table order
     int post_fuse = 0;   // K1h / K1i plans: merge + finalize + gates behind the scan as ONE kernel: 0 = auto (throughput plans), 1 = never, 2 = whenever eligible
     int fuse = 0;        // K1f: 0 = auto (one workgroup per problem incl. merge + finalize when the plan is large), 1 = never, 2 = always
     std::mutex mu;       // serialises the host-pointer entry points
@@ -231,7 +234,7 @@ struct BlockDesc {      // one workgroup's slice of a scan / problem
 int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const ScanDesc* d_scans,
                 const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero, hipStream_t s);
 int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int nblocks,
-                    const plslam_stereo_gate_problem* d_gates, hipStream_t s, int grid_cap = 0);
+                    const plslam_stereo_gate_problem* d_gates, hipStream_t s, int grid_cap = 0, bool xcd_chunks = false);
 // K2' (hamming.hip): merge of K1h's / K1i's column partials + finalize + gates, one workgroup per problem; lds_bytes = 8 x the
 // largest n2 of the plan
 constexpr int POST_FUSED_MAX_N2 = 4096;
@@ -278,6 +281,9 @@ int launch_scan_sym_mfma_g(const SymDesc* d_sym, const BlockDesc* d_blocks, int 
 // parts: lanes sharing one column (1, 4 or 16); the block table has one entry per merge_partials16_cols(parts) columns
 int merge_partials16_cols(int parts);
 int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, hipStream_t s);
+// K1c'' + K2 behind a column-split K1f scan in one kernel (two-launch plan runs); the dump's row completion
+int launch_split_post(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, const ProblemDesc* d_probs, hipStream_t s);
+int launch_split_rows_dump(const ProblemDesc* d_probs, const BlockDesc* d_fin_blocks, int nblocks, hipStream_t s);
 // (Column split of a large problem, K1f: the columns are cut into ranges scanned as sub-problems of their own -- more
 // workgroups than 256-row blocks alone give; the per-range row results are merged by the finalize kernel: ProblemDesc.)
 // K1h (hamming_mfma_h.hip): K1f's contract and partial table; minimum-only bookkeeping in both directions, class-major layouts;

@@ -660,7 +660,9 @@ __device__ __forceinline__ void finalize_row(const ProblemDesc& p, const int i1,
         if ((threadIdx.x & 63) == 0 && delta) (void)atomic_add_global(p.n_matches, delta);
     }
     if (gates && p.gate >= 0) {           // (a plan without a gate stage passes no table: never read through a stale index)
-        // StereoFrame's gate over this L<->R table (stereo_gates_dev.hpp), on the entry just decided
+        // StereoFrame's gate over this L<->R table (stereo_gates_dev.hpp), on the entry just decided.  (Requesting the gate's
+        // descriptor and the row's left feature ahead of the keys -- two links off the chain of dependent accesses -- measured
+        // 2.5 % SLOWER for the stages behind the scan, 0.298 against 0.290 ms per 4096-pair step.)
         const plslam_stereo_gate_problem q = gates[p.gate];
         const int kept = i1 < p.n1 ? stereo_gate_row(q, i1, m) : 0;
         const unsigned long long bal = __ballot(kept);
@@ -670,10 +672,19 @@ __device__ __forceinline__ void finalize_row(const ProblemDesc& p, const int i1,
 
 __global__ void __launch_bounds__(256)
 k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ blocks,
-           const plslam_stereo_gate_problem* __restrict__ gates, int nblocks)
+           const plslam_stereo_gate_problem* __restrict__ gates, int nblocks, int per_xcd)
 {
+  // per_xcd > 0 (option "post_xcd", off by default): workgroup b runs on XCD b % 8, and with per_xcd = ceil(nblocks / 8) XCD x
+  // takes the CONTIGUOUS table entries [x per_xcd, (x + 1) per_xcd), so the (<= 6) row blocks of one problem gather their
+  // column pairs keys21[m] through ONE L2 -- in table order they sit on six XCDs and each fetches the problem's whole column
+  // table (round-4 counters: 0.49 M KiB fetched per 4096-pair step for 0.22 GB of keys).  Measured SLOWER (stages behind the
+  // scan 0.302 against 0.280 ms per step, twice each on one box): the kernel is bound by its chain of dependent accesses, and
+  // a problem's 1500 gathers then queue on one L2's channels instead of six.
   // (a capped grid walks the block table: plslam_ctx option "post_workgroups")
-  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+  const int nslots = per_xcd > 0 ? 8 * per_xcd : nblocks;
+  for (int b = blockIdx.x; b < nslots; b += gridDim.x) {
+    const int blk = per_xcd > 0 ? (b & 7) * per_xcd + (b >> 3) : b;
+    if (blk >= nblocks) continue;                      // (the whole workgroup: finalize_row's DPP rotations see all lanes or none)
     const BlockDesc bd = blocks[blk];
     const ProblemDesc p = probs[bd.item];
     finalize_row(p, bd.row0 + (int)threadIdx.x, gates, [&](int m) {
@@ -856,11 +867,15 @@ int launch_post_fused(const ProblemDesc* d_probs, int nprob, const plslam_stereo
 }
 
 int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int nblocks,
-                    const plslam_stereo_gate_problem* d_gates, hipStream_t s, int grid_cap)
+                    const plslam_stereo_gate_problem* d_gates, hipStream_t s, int grid_cap, bool xcd_chunks)
 {
     if (nblocks <= 0) return PLSLAM_OK;
-    const int grid = grid_cap > 0 && grid_cap < nblocks ? grid_cap : nblocks;
-    hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, d_probs, d_blocks, d_gates, nblocks);
+    // xcd_chunks: contiguous table entries per XCD (k_finalize; option post_xcd, measured slower); pointless below a few entries per XCD
+    const int per_xcd = xcd_chunks && nblocks >= 64 ? (nblocks + 7) / 8 : 0;
+    const int nslots = per_xcd > 0 ? 8 * per_xcd : nblocks;
+    int grid = grid_cap > 0 && grid_cap < nslots ? grid_cap : nslots;
+    if (per_xcd > 0 && grid < nslots) grid = grid >= 8 ? grid & ~7 : 8;   // a walking workgroup stays on its XCD's chunk
+    hipLaunchKernelGGL(k_finalize, dim3(grid), dim3(256), 0, s, d_probs, d_blocks, d_gates, nblocks, per_xcd);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

@@ -504,6 +504,9 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
                 merge2(r0, r1, prev.x, prev.y);
             }
             *out = u32x2_t{r0, r1};
+            // two-launch column-split plans (k_split_post): the sub-problem of a problem's FIRST column range names the match
+            // table, and its workgroups -- one per row block -- clear the rows; the kernel behind the scan writes the matches
+            if (!FUSED && sd.matches_12) ((PLSLAM_GLOBAL int32_t*) sd.matches_12)[row] = -1;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -647,7 +650,130 @@ k_merge_partials16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict
     if (part_id == 0 && j < sd.n2) ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21))[j] = u32x2_t{b0, b1};
 }
 
+// K1c'' + K2 in ONE kernel behind a column-split K1f scan (C3: one local map against one frame; mapHandler.cpp:532-752): the
+// plan run is two launches.  The column side decides.  A workgroup merges the partials of its columns exactly as
+// k_merge_partials16 does; the lane that then holds column j's pair applies the column's ratio test -> i* (the only row that can
+// be consistent with j), merges row i*'s per-range results (the finalize kernel's best2 over `nsplit` tables, column indices
+// relative to ranges of `cstep` columns), applies the row's ratio test -> m, and writes matches_12[i*] = j iff m == j: the set
+// {(i, m) : m21[m] == i} of stvo-pl's match() read from the other side (every row has at most one m, every column at most
+// one i*).  Rows without a match hold the -1 the scan's first column range left there; the count is the number of pairs.
+// Only for mutual problems without keep_prior and without a stereo gate (plan_build / add_stereo_gates decide).
+// SymDesc::mutual - 1 = the problem's index; the range's first column = (sd.b - p.d2) / 32.
+template <int PARTS>
+__global__ void __launch_bounds__(256)
+k_split_post(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks, const ProblemDesc* __restrict__ probs)
+{
+    constexpr int COLS = 256 / PARTS;
+    __shared__ uint32_t red[PARTS > 1 ? 512 : 2];
+    const BlockDesc bd = blocks[blockIdx.x];
+    const SymDesc sd = syms[bd.item];
+    const ProblemDesc p = probs[sd.mutual - 1];
+    const int jl = (int)threadIdx.x % COLS, part_id = (int)threadIdx.x / COLS;
+    const int j = bd.row0 + jl;
+    const gcu32_t part = (gcu32_t) sd.part21;
+    const int nwb = (sd.n1 + 63) >> 6;
+    const int n2p = (sd.n2 + 255) & ~255;
+    uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
+    const uint32_t tw = ((uint32_t)j >> 5) & 63u;
+    if (j < sd.n2) {
+        auto wide = [](uint32_t k16, uint32_t wb) -> uint32_t { return ((k16 << 16) & 0xFF800000u) | ((k16 & 63u) + 64u * wb); };
+        const uint32_t tw2 = tw | (tw << 16);
+        uint32_t s0 = 0xFFFFFFFFu;
+#pragma unroll 8
+        for (int wb = part_id; wb < nwb; wb += PARTS) {
+            const uint32_t e = part[(size_t)wb * n2p + j] - tw2;
+            const uint32_t k = wide(e & 0xFFFFu, (uint32_t)wb);
+            s0 = k < b0 ? e : s0;
+            b1 = umin_(b1, umax_(b0, k));
+            b0 = umin_(b0, k);
+        }
+        if (b0 < (257u << KEY_IDX_BITS)) {
+            b1 = umin_(b1, wide(s0 >> 16, (b0 & KEY_IDX_MASK) >> 6));
+            if (b1 >= (257u << KEY_IDX_BITS)) b1 = KEY_NONE;
+        } else {
+            b0 = b1 = KEY_NONE;
+        }
+    }
+    if (PARTS > 1) {
+        red[2 * threadIdx.x] = b0;
+        red[2 * threadIdx.x + 1] = b1;
+        __syncthreads();
+        if (part_id == 0) {
+#pragma unroll
+            for (int q = 1; q < PARTS; ++q) merge2(b0, b1, red[2 * (q * COLS + jl)], red[2 * (q * COLS + jl) + 1]);
+        }
+    }
+    // stvo-pl matchNNR: accept iff (float)d0 < (float)d1 * nnr (one fp32 multiply); fewer than two neighbours: no match
+    auto ratio_pick = [&](uint32_t q0, uint32_t q1) -> int {
+        if (q1 == KEY_NONE) return -1;
+        const float d0 = (float)(q0 >> KEY_IDX_BITS);
+        const float d1n = __fmul_rn((float)(q1 >> KEY_IDX_BITS), p.nnr);
+        return d0 < d1n ? (int)(q0 & KEY_IDX_MASK) : -1;
+    };
+    bool pair = false;
+    if (part_id == 0 && j < sd.n2) {
+        ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21))[j] = u32x2_t{b0, b1};          // diagnostics (plslam_match_plan_dump)
+        const int istar = ratio_pick(b0, b1);
+        if (istar >= 0) {
+            const int jg = j + (int)((sd.b - p.d2) >> 5);                               // the column within the problem
+            const int ns = p.nsplit > 1 ? p.nsplit : 1;
+            const auto tmp = (const PLSLAM_GLOBAL u32x2_t*) reinterpret_cast<const u32x2_t*>(p.nsplit > 1 ? p.split_tmp : p.keys12);
+            uint32_t r0 = KEY_NONE, r1 = KEY_NONE;
+#pragma unroll 4
+            for (int s = 0; s < ns; ++s) {
+                const u32x2_t q = tmp[(size_t)s * p.n1 + istar];
+                const uint32_t off = (uint32_t)(s * p.cstep);
+                merge2(r0, r1, q.x == KEY_NONE ? KEY_NONE : q.x + off, q.y == KEY_NONE ? KEY_NONE : q.y + off);
+            }
+            pair = ratio_pick(r0, r1) == jg;
+            if (pair) ((PLSLAM_GLOBAL int32_t*) p.matches_12)[istar] = jg;
+        }
+    }
+    if (p.n_matches) {
+        const int found = (int)__popcll(__ballot(pair));
+        if ((threadIdx.x & 63) == 0 && found) (void)atomic_add_global(p.n_matches, found);
+    }
+}
+
+// plslam_match_plan_dump of a two-launch column-split plan: the rows' merged pairs (what the finalize kernel of the three-launch
+// form stores to keys12_out on its way), a lane per row
+__global__ void __launch_bounds__(256)
+k_split_rows_dump(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ blocks)
+{
+    const BlockDesc bd = blocks[blockIdx.x];
+    const ProblemDesc p = probs[bd.item];
+    const int i1 = bd.row0 + (int)threadIdx.x;
+    if (i1 >= p.n1 || p.nsplit <= 1) return;
+    const auto tmp = (const PLSLAM_GLOBAL u32x2_t*) reinterpret_cast<const u32x2_t*>(p.split_tmp);
+    uint32_t r0 = KEY_NONE, r1 = KEY_NONE;
+    for (int s = 0; s < p.nsplit; ++s) {
+        const u32x2_t q = tmp[(size_t)s * p.n1 + i1];
+        const uint32_t off = (uint32_t)(s * p.cstep);
+        merge2(r0, r1, q.x == KEY_NONE ? KEY_NONE : q.x + off, q.y == KEY_NONE ? KEY_NONE : q.y + off);
+    }
+    ((gu2_t) reinterpret_cast<u32x2_t*>(p.keys12_out))[i1] = u32x2_t{r0, r1};
+}
+
 int merge_partials16_cols(int parts) { return 256 / (parts >= 16 ? 16 : parts >= 4 ? 4 : 1); }
+
+// d_blocks: the merge kernel's table, one entry per (sub-problem, merge_partials16_cols(parts) columns)
+int launch_split_post(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, const ProblemDesc* d_probs, hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+    if (parts >= 16) hipLaunchKernelGGL((k_split_post<16>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_probs);
+    else if (parts >= 4) hipLaunchKernelGGL((k_split_post<4>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_probs);
+    else hipLaunchKernelGGL((k_split_post<1>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_probs);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
+
+int launch_split_rows_dump(const ProblemDesc* d_probs, const BlockDesc* d_fin_blocks, int nblocks, hipStream_t s)
+{
+    if (nblocks <= 0) return PLSLAM_OK;
+    hipLaunchKernelGGL(k_split_rows_dump, dim3(nblocks), dim3(256), 0, s, d_probs, d_fin_blocks);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    return PLSLAM_OK;
+}
 
 // d_blocks: one entry per (problem, merge_partials16_cols(parts) columns)
 int launch_merge_partials16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, hipStream_t s)

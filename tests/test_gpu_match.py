@@ -784,3 +784,142 @@ def test_lazy_second_keys_with_prior_entries_column_split_and_a_capped_post_grid
         for k in ("col_split", "post_workgroups", "mfma_form"):
             ctx.set_option(k, 0)
         ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+
+
+@pytest.mark.parametrize("shapes", [((10000, 1500), (2000, 200)), ((3001, 2049), (700, 129)), ((9000, 1500), (64, 33)),
+                                    ((517, 4400),), ((6000, 300), (257, 2)), ((4100, 130), (5000, 1))],
+                         ids=["c3", "multi_window", "with_a_one_range_problem", "wide", "two_columns", "one_column"])
+def test_column_split_plan_in_two_launches(ctx, oracle, shapes):
+    """A column-split plan of mutual problems runs as TWO launches: the scan, then k_split_post, which merges the column
+    partials and decides the matches from the column side (rows without a match keep the -1 the scan's first column range
+    writes).  Tables (pre-filled with garbage), counts and every key word of the dump must equal the three-launch form
+    (merge kernel + finalize kernel, option split_post = 1) and the oracle; repeated runs must not accumulate counts."""
+    import torch
+    import plslam_amd
+    r = _rng(9100 + shapes[0][0])
+    dev = torch.device("cuda", ctx.device)
+    host, probs, outs = [], [], []
+    cnt = torch.zeros(len(shapes), dtype=torch.int32, device=dev)
+    for k, (n1, n2) in enumerate(shapes):
+        b = synth.tie_stress_desc(r, n2) if (k == 1 and n2 > 8) else synth.random_desc(r, n2)
+        a = np.concatenate([synth.noisy_copy(r, b)[0], synth.random_desc(r, n1)])[:n1]
+        a = np.ascontiguousarray(a[r.permutation(n1)])       # the matching rows anywhere in the map, not in its first blocks
+        ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+        m = torch.empty(n1, dtype=torch.int32, device=dev)
+        host.append((a, b, ta, tb))
+        outs.append(m)
+        probs.append((ta.data_ptr(), n1, tb.data_ptr(), n2, 0.8, True, m.data_ptr(), cnt.data_ptr() + 4 * k))
+    got = {}
+    try:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)
+        ctx.set_option("col_split", 2)
+        for sp in (0, 1):
+            ctx.set_option("split_post", sp)
+            plan = ctx.plan(probs)
+            for rep in range(3):
+                for m in outs:
+                    m.fill_(-7 - rep)
+                plan.run(0)
+            torch.cuda.synchronize()
+            keys, _ = plan.dump()
+            got[sp] = (keys.copy(), [m.cpu().numpy().copy() for m in outs], cnt.cpu().numpy().copy(), plan.info())
+            plan.close()
+    finally:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+        ctx.set_option("col_split", 0)
+        ctx.set_option("split_post", 0)
+    nkeys = 2 * sum(n1 + n2 for n1, n2 in shapes)
+    assert np.array_equal(got[0][0][:nkeys], got[1][0][:nkeys])
+    for k, (a, b, _, _) in enumerate(host):
+        em, en = oracle.match(a, b, 0.8, True)
+        for sp in (0, 1):
+            assert np.array_equal(got[sp][1][k], em), (sp, k)
+            assert got[sp][2][k] == en, (sp, k)
+
+
+def test_column_split_plan_with_a_gate_or_prior_entries_keeps_the_finalize_kernel(ctx, oracle):
+    """k_split_post decides matches from the column side: it cannot apply a stereo gate to the row it decides nor keep a
+    rejected row's earlier entry.  A gate added to such a plan switches it back to merge + finalize (and removing the gate
+    switches it forth); keep_prior problems never take it.  Tables, gate outputs and counts against the oracle."""
+    import torch
+    import plslam_amd
+    r = _rng(9191)
+    dev = torch.device("cuda", ctx.device)
+    n1, n2 = 5000, 1400
+    b = synth.random_desc(r, n2)
+    a = np.concatenate([synth.noisy_copy(r, b)[0], synth.random_desc(r, n1)])[:n1]
+    kl = np.ascontiguousarray(r.random((n1, 2)) * [752.0, 480.0], np.float32)
+    kr = np.ascontiguousarray(r.random((n2, 2)) * [752.0, 480.0], np.float32)
+    em, en = oracle.match(a, b, 0.8, True)
+    kr[em[em >= 0]] = kl[em >= 0] - np.array([7.0, 0.25], np.float32)      # most matches pass the gate
+    es, ed, ens = oracle.stereo_point_gate(em, kl, kr, 1.0, 1.0)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in dict(a=a, b=b, kl=kl, kr=kr).items()}
+    m = torch.empty(n1, dtype=torch.int32, device=dev)
+    st = torch.empty(n1, dtype=torch.int32, device=dev)
+    disp = torch.empty(n1, dtype=torch.float64, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int32, device=dev)
+    try:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)
+        ctx.set_option("col_split", 2)
+        plan = ctx.plan([(t["a"].data_ptr(), n1, t["b"].data_ptr(), n2, 0.8, True, m.data_ptr(), cnt.data_ptr())])
+        gate = dict(matches_12=m.data_ptr(), f_l=t["kl"].data_ptr(), f_r=t["kr"].data_ptr(), n_l=n1, n_r=n2, lines=False,
+                    max_dist_epip=1.0, min_disp=1.0, stereo_12=st.data_ptr(), disp=disp.data_ptr(), n_stereo=cnt.data_ptr() + 4)
+        for stage in ("plain", "gated", "plain again"):
+            plan.add_stereo_gates([gate] if stage == "gated" else [])
+            m.fill_(-9); st.fill_(-9)
+            plan.run(0)
+            torch.cuda.synchronize()
+            assert np.array_equal(m.cpu().numpy(), em), stage
+            assert int(cnt[0]) == en, stage
+            if stage == "gated":
+                assert np.array_equal(st.cpu().numpy(), es) and int(cnt[1]) == ens
+                keep = es >= 0
+                assert np.array_equal(disp.cpu().numpy()[keep], ed[keep])
+        plan.close()
+        prior = np.where(r.random(n1) < 0.5, r.integers(0, n2, n1), -1).astype(np.int32)
+        ref, nref = oracle.match_prior(a, b, 0.8, True, prior)
+        got, n = ctx.match_prior(a, b, 0.8, True, prior)
+        assert np.array_equal(got, ref) and n == nref
+    finally:
+        ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
+        ctx.set_option("col_split", 0)
+
+
+def test_finalize_kernel_options(ctx, oracle):
+    """Options of the finalize kernel, schedule-only: post_xcd = 1 hands every XCD a contiguous run of the block table (the row
+    blocks of one problem gather its column keys through one L2; with a capped grid -- post_workgroups -- the walking workgroups
+    stay on their XCD's chunk).  Same tables, counts, gated associations and disparities as the defaults and as the oracle, on
+    a plan whose table has ragged chunks."""
+    import torch
+    pairs, n_orb, n_lbd = 37, 300, 70                        # 37 x (2 x 2 + 2 x 1) = 222 blocks: chunks of 28, the last one short
+    s = synth.stereo_stream(pairs, n_orb, n_lbd, seed=4242)
+    geo = synth.stereo_geometry(s, seed=6)
+    out = {}
+    try:
+        for xcd, cap in ((0, 0), (1, 0), (1, 21), (1, 5), (0, 9)):
+            ctx.set_option("post_xcd", xcd)
+            ctx.set_option("post_workgroups", cap)
+            bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.8, nnr_l=0.9, mutual=True, geometry=geo, gates=dict(synth.KITTI_GATES), n_buffers=2)
+            for k in range(3):                               # (split runs: the capped grid applies to runs beside a scan)
+                bm.run_overlapped(k)
+            bm.synchronize_all()
+            out[(xcd, cap)] = tuple(x.cpu().numpy().copy() for x in (
+                bm.tables[0], bm.count_bufs[0], bm.tables[1], bm.count_bufs[1], bm.stereo_tabs[0], bm.stereo_disps[0].view(torch.int64),
+                bm.stereo_cnts[0], bm.stereo_tabs[1], bm.stereo_disps[1].view(torch.int64), bm.stereo_cnts[1]))
+            bm.close()
+    finally:
+        ctx.set_option("post_xcd", 0)
+        ctx.set_option("post_workgroups", 0)
+    base = out[(0, 0)]
+    for k, v in out.items():
+        for x, y in zip(v, base):
+            assert np.array_equal(x, y), k
+    sl = frontend.table_slices(n_orb, n_lbd)
+    for i in range(0, pairs, 6):
+        for name, d1, d2 in frontend.pair_problems(s["orb_l"], s["orb_r"], s["lbd_l"], s["lbd_r"], i):
+            em, _ = oracle.match(d1, d2, 0.8 if name.startswith("orb") else 0.9, True)
+            assert np.array_equal(base[0][i, sl[name]], em), (i, name)
+    th = synth.KITTI_GATES
+    for i in range(0, pairs, 9):                             # the gated L<->R associations of the default setting vs the oracle
+        es, _, en = oracle.stereo_point_gate(base[0][i, sl["orb_lr"]], geo["kp_l"][i + 1], geo["kp_r"][i + 1], th["max_dist_epip"], th["min_disp"])
+        assert np.array_equal(base[4][i, :n_orb], es) and base[6][i, 0] == en, i

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """C3 (one local map against one frame: 10 000 x 1500 ORB + 2 000 x 200 LBD, mutual) as ONE plan: time per run and the
-scan / post-scan split from the plan's own events.  usage: c3_time.py [col_split 0|1|2] [scan_variant] [mfma_form] [graph 0|1|2]"""
+scan / post-scan split from the plan's own events.  usage: c3_time.py [col_split 0|1|2] [scan_variant] [mfma_form] [graph 0|1|2] [split_post 0|1]"""
 import os
 import sys
 
@@ -15,11 +15,15 @@ split = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 form = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 graph = int(sys.argv[4]) if len(sys.argv) > 4 else 1
+split_post = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 ctx = plslam_amd.Context(0)
 ctx.set_option("col_split", split)
 ctx.set_option("scan_variant", variant)
 ctx.set_option("mfma_form", form)
 ctx.set_option("graph", graph)
+ctx.set_option("split_post", split_post)
+for kv in filter(None, os.environ.get("PLSLAM_OPTS", "").split(",")):      # any other option: PLSLAM_OPTS=split_target=2,split_min_tiles=3
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 dev = torch.device("cuda", 0)
 r = np.random.Generator(np.random.PCG64(31))
 frame_p = synth.random_desc(r, 1500)
@@ -59,5 +63,5 @@ for _ in range(200):
 wall = (time.perf_counter() - t0) / 200
 assert torch.equal(ref_p, m_p) and torch.equal(ref_l, m_l)
 print(f"graph {graph}: run + synchronize from the host {1e6 * wall:.1f} us; ", end="")
-print(f"col_split {split} variant {variant} form {form}: {1e3 * e0.elapsed_time(e1) / 200:.1f} us per back-to-back run; serial runs: scan "
+print(f"[{os.environ.get('PLSLAM_OPTS', '')}] split_post {split_post} col_split {split} variant {variant} form {form}: {1e3 * e0.elapsed_time(e1) / 200:.1f} us per back-to-back run; serial runs: scan "
       f"{1e3 * a / n:.1f} us, post-scan {1e3 * b / n:.1f} us; info {plan.info()}")
