@@ -141,8 +141,11 @@ struct plslam_match_plan {
     }
 };
 
+// n1_dev0 (internal; the map<->keyframe driver's one-synchronisation brute-force form): the row count of problem 0 lives on
+// the device, probs[0].n1 is its upper bound.  Only as a two-launch column-split plan of ONE mutual problem (K1f + k_split_post,
+// which read the count themselves); anything else returns PLSLAM_ENOTSUP and the caller takes its two-synchronisation form.
 static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob,
-                      plslam_match_plan* P)
+                      plslam_match_plan* P, const int32_t* n1_dev0 = nullptr)
 {
     PLSLAM_REQUIRE(nprob >= 0, PLSLAM_EINVAL);
     PLSLAM_REQUIRE(nprob == 0 || probs != nullptr, PLSLAM_EINVAL);
@@ -173,6 +176,13 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     const bool split_forced = ctx->col_split == 2 && ctx->mfma_form != 1 &&
                               (ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_MFMA);
     P->col_split = ctx->col_split != 1 && (split_auto || split_forced);
+    if (n1_dev0) {
+        const bool can = nprob == 1 && probs[0].mutual && !probs[0].keep_prior && probs[0].n1 > 0 && probs[0].n2 > 0 &&
+                         (ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_MFMA) &&
+                         (ctx->mfma_form == 0 || ctx->mfma_form == 2) && ctx->col_split != 1 && ctx->split_post != 1 && ctx->fuse != 2;
+        if (!can) return PLSLAM_ENOTSUP;
+        P->col_split = true;
+    }
     const bool use_wpq = ctx->scan_variant == PLSLAM_SCAN_WAVE_PER_QUERY ||
                          (ctx->scan_variant == PLSLAM_SCAN_AUTO && small_plan && !P->col_split);
     const bool allow_sym = !use_wpq &&
@@ -340,6 +350,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         for (int32_t i = 0; ok && i < nprob; ++i)
             ok = is_sym(probs[i]) && !probs[i].keep_prior;
         P->split_post = P->split_post_ok = ok;
+        if (n1_dev0 && !ok) return PLSLAM_ENOTSUP;
     }
     std::vector<ScanDesc> scans;
     std::vector<int32_t> scan_problem;   // scans[k] belongs to problem scan_problem[k]
@@ -383,7 +394,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
                 y.a = p.d1; y.b = p.d2 + (size_t)c0 * 32;
                 y.keys12 = d_tmp + 2 * (tmp_row + (int64_t)s_ * p.n1);
                 y.n1 = p.n1; y.n2 = n2s;
-                if (P->split_post) { y.mutual = i + 1; y.matches_12 = s_ == 0 ? p.matches_12 : nullptr; }
+                if (P->split_post) { y.mutual = i + 1; y.matches_12 = s_ == 0 ? p.matches_12 : nullptr; y.n1_dev = n1_dev0; }
                 if (p.mutual) {
                     y.keys21 = k21 + 2 * (size_t)c0;
                     y.part21 = d_part + 2 * part_row;
@@ -409,7 +420,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
             pd.part21 = y.part21;
             y.n1 = p.n1; y.n2 = p.n2; y.n_iblk = (p.n1 + rpp - 1) / rpp;
             part_row += k1f ? part_units(p.n1, p.n2) : (int64_t)y.n_iblk * p.n2;
-            if (P->split_post) { y.mutual = i + 1; y.matches_12 = p.matches_12; }     // (a problem of one column range)
+            if (P->split_post) { y.mutual = i + 1; y.matches_12 = p.matches_12; y.n1_dev = n1_dev0; }     // (a problem of one column range)
             if (P->fused) {
                 y.mutual = 1; y.matches_12 = p.matches_12; y.n_matches = pd.n_matches; y.nnr = p.nnr;
                 yblocks.push_back({(int32_t)syms.size(), 0});
@@ -713,11 +724,12 @@ static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
 }
 
 namespace plslam {
-int match_problems_on_ctx_stream(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob)
+int match_problems_on_ctx_stream(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob, const int32_t* n1_dev0)
 {
     if (!ctx->host_plan) ctx->host_plan = new (std::nothrow) plslam_match_plan();
     PLSLAM_REQUIRE(ctx->host_plan != nullptr, PLSLAM_ENOMEM);
-    const int r = plan_build(ctx, probs, nprob, ctx->host_plan);
+    const int r = plan_build(ctx, probs, nprob, ctx->host_plan, n1_dev0);
+    if (r == PLSLAM_ENOTSUP && n1_dev0) return r;            // (not an error: the caller has another form; no message)
     return r ? r : plan_run(ctx->host_plan, ctx->stream, ctx->stream);
 }
 }  // namespace plslam

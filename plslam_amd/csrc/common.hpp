@@ -258,6 +258,9 @@ struct SymDesc {
     int32_t* n_matches;     //   one counter, STORED (not accumulated) by the problem's workgroup; may be nullptr
     float nnr;
     int32_t flags;          // bit 0 (K1h): the INDEX of the second-best row key must be exact too (knnMatch output, key dumps)
+    // K1f, two-launch column-split plans only (the brute-force map<->keyframe driver in one synchronisation, map2kf.hip): the
+    // number of rows of a lives on the DEVICE (*n1_dev <= n1; n1 is the bound the tables and the launch are sized for), or nullptr
+    const int32_t* n1_dev;
 };
 // rows_per_lane: 1 (K1b: 256-thread workgroups, 64 a-rows per wave) or 4 (K1b': 64-thread
 // workgroups, 256 a-rows per wave).  sym_rows_per_block() = a-rows covered by one BlockDesc.
@@ -314,7 +317,8 @@ int scan_rows_per_block(int variant, int block_threads);
 
 // builds the plan for `probs` (DEVICE pointers) into the context's persistent host-path plan and
 // enqueues it on the context stream; no synchronisation.  Caller holds ctx->mu.  (capi.hip)
-int match_problems_on_ctx_stream(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob);
+// n1_dev0: the row count of problem 0 on the device (probs[0].n1 = its bound); PLSLAM_ENOTSUP when the plan cannot take it
+int match_problems_on_ctx_stream(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob, const int32_t* n1_dev0 = nullptr);
 // dst[i] = src[idx[i]] for rows of row_bytes (a multiple of 8) bytes  (map2kf.hip)
 int launch_gather_rows(const void* src, const int32_t* idx, int32_t n, int32_t row_bytes, void* dst,
                        hipStream_t s);

@@ -197,7 +197,11 @@ k_scan_sym_mfma_g(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     const BlockDesc bd = blocks[wg];
     if (bd.item < 0) return;                       // padding entry of the XCD-striped table
     const SymDesc sd = syms[bd.item];
-    const int n1 = sd.n1, n2 = sd.n2;
+    // (the row count may live on the device: the launch and the tables are sized for sd.n1, the rows that exist are the first
+    // *n1_dev; a workgroup whose rows all lie behind them has nothing to do -- its partials are never read)
+    const int n1 = sd.n1_dev ? min(sd.n1, *(const PLSLAM_GLOBAL int32_t*) sd.n1_dev) : sd.n1;
+    const int n2 = sd.n2;
+    if (!FUSED && bd.row0 >= n1) return;
     const int n2p = (n2 + 255) & ~255;             // rows of the partial table are padded to 256 columns: whole groups are stored
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -671,7 +675,8 @@ k_split_post(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blo
     const int jl = (int)threadIdx.x % COLS, part_id = (int)threadIdx.x / COLS;
     const int j = bd.row0 + jl;
     const gcu32_t part = (gcu32_t) sd.part21;
-    const int nwb = (sd.n1 + 63) >> 6;
+    const int n1 = sd.n1_dev ? min(sd.n1, *(const PLSLAM_GLOBAL int32_t*) sd.n1_dev) : sd.n1;   // (the scan wrote the partials of these rows only)
+    const int nwb = (n1 + 63) >> 6;
     const int n2p = (sd.n2 + 255) & ~255;
     uint32_t b0 = KEY_NONE, b1 = KEY_NONE;
     const uint32_t tw = ((uint32_t)j >> 5) & 63u;

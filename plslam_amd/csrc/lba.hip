@@ -380,6 +380,7 @@ k_prepare_rows(CamD K, Pose12 Twf, const uint64_t* __restrict__ md, const double
         X[w] = lm[src * lw + w];
         QL[(int64_t)a * lw + w] = X[w];
     }
+    if (!cells) return;                                     // (the brute-force driver: no window centres)
     auto cvtt = [](double v) -> int32_t { return (v > -2147483649.0 && v < 2147483648.0) ? (int32_t)v : INT32_MIN; };
     int32_t c[4];
     for (int e = 0; e < nc; ++e) {

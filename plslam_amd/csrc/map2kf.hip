@@ -330,6 +330,95 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
     return PLSLAM_OK;
 }
 
+// The map<->keyframe driver WITHOUT fast_matching (:594-598 / :709-713 with an empty matches_12: StVO::match over all of Q) as
+// ONE launch sequence and ONE synchronisation.  As in map2kf_fast_once the candidate list is built on the device and its length
+// nq stays there; the matcher is a two-launch column-split plan sized for the bound n_map whose kernels read the row count from
+// device memory (SymDesc::n1_dev: workgroups behind the last row leave at once), the gate and the association read it too.  The
+// one host decision that needs nq -- match() runs only if |Q| > min_matches -- is applied after the results are back (the
+// matcher's table is then simply not used: every entry of map_to_kf stays -1, as when no matcher ran).  *done = 0: the plan
+// cannot take a device-side row count under the context's options (or the problem is not mutual) -- nothing was enqueued, the
+// caller runs the step-by-step form.  Caller holds ctx->mu.
+int map2kf_bf_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* Twf, const double* LM, const uint8_t* med_desc,
+                   const uint8_t* candidate, int32_t n_map, const uint8_t* kf_desc, const double* kf_feat,
+                   const std::vector<int32_t>& ti, float nnr, int mutual, double max_epip, int32_t min_matches,
+                   int32_t* map_to_kf, int32_t* n_matches, int32_t* used_match, bool map_dev, int* done)
+{
+    *done = 0;
+    if (!mutual || n_map > PLSLAM_MAX_TRAIN_ROWS) return PLSLAM_OK;       // (the plan is sized for the bound n_map, not for |Q|)
+    hipStream_t s = ctx->stream;
+    StreamSyncOnError sg(s);
+    int rc;
+    const int32_t nt = (int32_t)ti.size();
+    const int lw = lines ? 6 : 3, fw = lines ? 3 : 2;
+    // ---- one image up: [the map, unless it is resident] | T rows | their features | ti | zeroed counters
+    Carve c;
+    const size_t oLM = c.take(map_dev ? 0 : (size_t)n_map * lw * 8), oMD = c.take(map_dev ? 0 : (size_t)n_map * 32),
+                 oCand = c.take(map_dev ? 0 : (size_t)n_map), oT = c.take((size_t)nt * 32), oTF = c.take((size_t)nt * fw * 8),
+                 oTi = c.take((size_t)nt * 4),
+                 oRes = c.take(16),                                      // gate count | nq | - | -
+                 oPart = c.take(visible_compact_part_words(n_map) * 4);  // k_visible_compact's chain (zero)
+    const size_t image = c.off;
+    // ---- device only
+    const size_t oMap = c.take((size_t)n_map * 4);                       // the association table: directly behind the counters' page
+    const size_t oQi = c.take((size_t)n_map * 4), oQ = c.take((size_t)n_map * 32), oQL = c.take((size_t)n_map * lw * 8),
+                 oM = c.take((size_t)n_map * 4), oMask = c.take((size_t)n_map);
+    if ((rc = ctx->misc_a.reserve(c.off))) return rc;
+    if ((rc = ctx->pin_in.reserve(image))) return rc;
+    if ((rc = ctx->pin_out.reserve(256 + (size_t)n_map * 4))) return rc;
+    char* d = ctx->misc_a.as<char>();
+    char* h = ctx->pin_in.as<char>();
+    int32_t* const res = (int32_t*)(d + oRes);                           // [0] gate count, [1] nq
+    // the matcher's plan first: it decides whether this form applies at all (nothing is enqueued before it says yes)
+    plslam_match_problem p{};
+    p.d1 = (const uint8_t*)(d + oQ); p.n1 = n_map; p.d2 = (const uint8_t*)(d + oT); p.n2 = nt;
+    p.nnr = nnr; p.mutual = 1; p.matches_12 = (int32_t*)(d + oM); p.n_matches = nullptr; p.keep_prior = 0;
+    if (!map_dev) {
+        memcpy(h + oLM, LM, (size_t)n_map * lw * 8);
+        memcpy(h + oMD, med_desc, (size_t)n_map * 32);
+        memcpy(h + oCand, candidate, (size_t)n_map);
+    }
+    const char* const d_LM = map_dev ? reinterpret_cast<const char*>(LM) : d + oLM;
+    const char* const d_MD = map_dev ? reinterpret_cast<const char*>(med_desc) : d + oMD;
+    const uint8_t* const d_cand = map_dev ? candidate : (const uint8_t*)(d + oCand);
+    for (int32_t b = 0; b < nt; ++b) {                                   // the T matrix and its features, gathered here (:563-569)
+        memcpy(h + oT + (size_t)b * 32, kf_desc + (size_t)ti[b] * 32, 32);
+        memcpy(h + oTF + (size_t)b * fw * 8, kf_feat + (size_t)ti[b] * fw, (size_t)fw * 8);
+    }
+    memcpy(h + oTi, ti.data(), (size_t)nt * 4);
+    memset(h + oRes, 0, 16);
+    memset(h + oPart, 0, visible_compact_part_words(n_map) * 4);
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image, hipMemcpyHostToDevice, s));
+    if ((rc = launch_visible_compact(*K, Twf, (const double*)d_LM, d_cand, n_map, lines, (int32_t*)(d + oQi), res + 1,
+                                     (int32_t*)(d + oMap), nullptr, (uint32_t*)(d + oPart), s)))
+        return rc;
+    if ((rc = launch_prepare_rows(*K, Twf, d_MD, (const double*)d_LM, (const int32_t*)(d + oQi), res + 1, n_map, lines, 0.0, 0.0,
+                                  d + oQ, (double*)(d + oQL), nullptr, nullptr, s)))
+        return rc;
+    rc = match_problems_on_ctx_stream(ctx, &p, 1, res + 1);              // :597 / :712
+    if (rc == PLSLAM_ENOTSUP) {                                          // (what is in flight is harmless: scratch only)
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        sg.dismiss();
+        return PLSLAM_OK;
+    }
+    if (rc) return rc;
+    if ((rc = launch_gate_n(lines, *K, Twf, (const double*)(d + oQL), (const int32_t*)(d + oM), res + 1, n_map, (const double*)(d + oTF),
+                            max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi), (const int32_t*)(d + oTi),
+                            (int32_t*)(d + oMap), s)))
+        return rc;
+    // ---- one download (the counters' page and the table behind it), one synchronisation
+    char* ho = ctx->pin_out.as<char>();
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oRes, (oMap - oRes) + (size_t)n_map * 4, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    sg.dismiss();
+    *done = 1;
+    const int32_t* r = reinterpret_cast<const int32_t*>(ho);
+    if (!(r[1] > min_matches)) return PLSLAM_OK;                          // match() would not have run: map_to_kf stays -1 everywhere
+    memcpy(map_to_kf, ho + (oMap - oRes), (size_t)n_map * 4);
+    if (n_matches) *n_matches = r[0];
+    if (used_match) *used_match = 1;
+    return PLSLAM_OK;
+}
+
 // MapHandler::matchKF2KFPoints / matchKF2KFLines, compute part (src/mapHandler.cpp:246-278 / :378-426)
 int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* DT, const double* X_prev,
                  const uint8_t* desc_prev, int32_t n_prev, const double* feat_curr, const uint8_t* desc_curr,
@@ -474,6 +563,13 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
         const int rc1 = map2kf_fast_once(ctx, lines, K, Twf, LM, med_desc, candidate, n_map, kf_desc, kf_feat, kf_seg, ti, nnr, mutual,
                                          max_epip, min_matches, fm, map_to_kf, n_matches, map_dev, &redo);
         if (rc1 || !redo) return rc1;
+    } else {
+        // no matcher would run at all (:594 / :709 with no table from matchGrid: matches = 0 < min_matches is the condition)
+        if (!(0 < min_matches)) return PLSLAM_OK;
+        int done = 0;
+        const int rc1 = map2kf_bf_once(ctx, lines, K, Twf, LM, med_desc, candidate, n_map, kf_desc, kf_feat, ti, nnr, mutual, max_epip,
+                                       min_matches, map_to_kf, n_matches, used_match, map_dev, &done);
+        if (rc1 || done) return rc1;
     }
     hipStream_t s = ctx->stream;
     StreamSyncOnError sg(s);

@@ -318,3 +318,68 @@ def test_gpu_fast_driver_without_visible_candidates_and_on_a_large_map(ctx, orac
     big = scene(70001, 600, lines=lines, seed=78)
     ref = both(big, big["cand"], big["LM"], nnr=0.9, mm=5)
     assert ref[1] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["points", "lines"])
+def test_gpu_brute_force_driver_in_one_synchronisation(ctx, oracle, kind):
+    """Without fast_matching the drivers run as ONE launch sequence too: the candidate list and its length stay on the device,
+    the matcher is a two-launch column-split plan sized for the whole map whose kernels read the row count themselves.  Cases
+    the C3-sized tests do not reach: no candidate at all / every landmark behind the camera (row count zero), fewer candidates
+    than min_matches (the matcher's table must not be used), one visible candidate, a 70 001-landmark map, a map of a few
+    landmarks (one column range), and a context whose options the plan cannot honour (it falls back to the step-by-step form).
+    Host-pointer and device-resident entry points against the oracle."""
+    import torch
+    import plslam_amd
+    cam, ocam = plslam_amd.make_cam(**synth.EUROC), oracle.make_cam(**synth.EUROC)
+    lines = kind == "lines"
+    dev = torch.device("cuda", ctx.device)
+    off = fast_cfg(enabled=0)
+
+    def both(s, cand, lm, nnr=0.75, mm=10, th=1.5):
+        a = (s["Twf"], lm, s["med"], cand, s["kf_desc"], s["kf_feat"], s["kf_idx"])
+        ref = oracle.map2kf_match(kind, ocam, *a, nnr, True, th, mm)
+        got = ctx.map2kf_match(kind, cam, *a, nnr, True, th, mm)
+        d = [torch.from_numpy(np.ascontiguousarray(x)).to(dev) for x in (lm, s["med"], cand)]
+        gotd = ctx.map2kf_match_dev(kind, cam, s["Twf"], d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), lm.shape[0], s["kf_desc"],
+                                    s["kf_feat"], s["kf_idx"], nnr, True, th, mm, off, kf_seg=s.get("kf_seg"))
+        for g in (got, gotd):
+            np.testing.assert_array_equal(g[0], ref[0])
+            assert g[1] == ref[1]
+        return ref
+
+    s = scene(3000, 400, lines=lines, seed=177)
+    n = s["LM"].shape[0]
+    ref = both(s, s["cand"], s["LM"])
+    assert ref[1] > 0
+    ref = both(s, np.zeros_like(s["cand"]), s["LM"])                       # no candidate flag set: row count zero
+    assert ref[1] == 0 and (ref[0] == -1).all()
+    behind = np.array(s["LM"], np.float64)
+    Tfw = np.linalg.inv(s["Twf"])
+    for e in range(2 if lines else 1):                                      # every landmark 50 m behind the camera
+        Xc = np.stack([np.zeros(n), np.zeros(n), np.full(n, -50.0)], 1)
+        behind[:, 3 * e:3 * e + 3] = Xc @ Tfw[:3, :3].T + Tfw[:3, 3]
+    ref = both(s, s["cand"], behind)
+    assert ref[1] == 0 and (ref[0] == -1).all()
+    few = np.zeros_like(s["cand"])
+    few[np.flatnonzero(s["cand"])[:40]] = 1                                 # at most 40 candidates: below min_matches = 60 ...
+    ref = both(s, few, s["LM"], mm=60)
+    assert ref[1] == 0 and (ref[0] == -1).all()
+    both(s, few, s["LM"], mm=3)                                             # ... and above another
+    one = np.zeros_like(s["cand"])
+    one[np.flatnonzero(s["cand"])[7]] = 1
+    both(s, one, s["LM"], mm=1)
+    tiny = scene(90, 30, lines=lines, seed=178)                             # one column range, one row block
+    both(tiny, tiny["cand"], tiny["LM"], nnr=0.9, mm=2)
+    big = scene(70001, 600, lines=lines, seed=179)
+    ref = both(big, big["cand"], big["LM"], nnr=0.9, mm=5)
+    assert ref[1] > 0
+    try:                                                                    # options the device-count plan refuses
+        for key, val in (("scan_variant", plslam_amd.SCAN_LANE_PER_QUERY), ("mfma_form", 5), ("split_post", 1), ("col_split", 1)):
+            ctx.set_option(key, val)
+            ref = both(s, s["cand"], s["LM"], mm=5)
+            assert ref[1] > 0
+            ctx.set_option(key, 0)
+    finally:
+        for key in ("scan_variant", "mfma_form", "split_post", "col_split"):
+            ctx.set_option(key, 0)
