@@ -483,6 +483,9 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     // XCD runs its long blocks (ORB) first and the short ones (LBD) fill the drain phase.  Rows are
     // padded to equal length with no-op entries (item = -1).
     struct Group { int64_t cost; int32_t first, count; };
+    // (Dealing the SHORT groups -- the LBD problems of a stereo batch, seven tiles of mostly memory latency -- evenly among the
+    // long ones instead of running them together at the end measured 1-3 % SLOWER, 2.62-2.70 against 2.60-2.64 ms per
+    // 4096-pair scan: round 4, option removed.)
     auto stripe = [](std::vector<BlockDesc>& blocks, std::vector<Group> groups) {
         std::stable_sort(groups.begin(), groups.end(), [](const Group& a, const Group& b) { return a.cost > b.cost; });
         std::vector<BlockDesc> rows[8];

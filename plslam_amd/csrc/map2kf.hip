@@ -224,15 +224,16 @@ bool fast_ok(const plslam_fast_matching* fm)
 // the gate and the association read it from device memory, matchGrid's descriptor is patched with it behind the upload (its
 // launch geometry follows the upper bound n_map; k_match_grid / k_grid_candidates pick their form from the patched row count)
 // -- and the one host decision of the reference loop that needs it, `|Q| > min && matches < min` (:594-598, :709-713), is taken
-// AFTER the results are back: *redo = 1 then, and the caller runs the step-by-step form (rare: matchGrid found too little).
+// AFTER the results are back: the brute-force matcher then runs on what is still resident (Q, T, matchGrid's table as the
+// vector it is handed), followed by the gate -- a second, short launch sequence.  *redo = 1 only when the candidate store would
+// have to be sized for every landmark of a huge map: the caller runs the step-by-step form.
 // Everything the host knows beforehand travels in ONE upload: [the map, unless it is resident] | T rows | their features | ti |
 // the grid of the unmatched keyframe features | matchGrid's descriptor | zeroed counters.  Caller holds ctx->mu.
 int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* Twf, const double* LM, const uint8_t* med_desc,
                      const uint8_t* candidate, int32_t n_map, const uint8_t* kf_desc, const double* kf_feat, const double* kf_seg,
                      const std::vector<int32_t>& ti, float nnr, int mutual, double max_epip, int32_t min_matches,
-                     const plslam_fast_matching* fm, int32_t* map_to_kf, int32_t* n_matches, bool map_dev, int* redo)
+                     const plslam_fast_matching* fm, int32_t* map_to_kf, int32_t* n_matches, int32_t* used_match, bool map_dev, int* redo)
 {
-    (void)nnr;
     *redo = 0;
     hipStream_t s = ctx->stream;
     StreamSyncOnError sg(s);
@@ -321,9 +322,27 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
     sg.dismiss();
     const int32_t* r = reinterpret_cast<const int32_t*>(ho);
     PLSLAM_REQUIRE(r[2] >= 0, PLSLAM_ERANGE);                            // (matchGrid's candidate store: the capacity is an upper bound)
-    if (r[1] > min_matches && r[2] < min_matches) {                      // the brute-force matcher replaces matchGrid's table
-        *redo = 1;
-        return PLSLAM_OK;
+    if (r[1] > min_matches && r[2] < min_matches) {
+        // :594-598 / :709-713 -- matchGrid found too little: StVO::match runs over the SAME Q and T with the vector matchGrid
+        // filled (keep_prior), then the gate.  Everything it needs is still on the device -- Q, T, their features, the lists,
+        // matchGrid's table -- and the list's length is known now: no re-staging, no second visibility pass.  The association
+        // table and the gate's counter start over.
+        StreamSyncOnError sg2(s);
+        const int32_t nq = r[1];
+        PLSLAM_HIP_CHECK(hipMemsetAsync(d + oMap, 0xFF, (size_t)n_map * 4, s));
+        PLSLAM_HIP_CHECK(hipMemsetAsync(res, 0, 4, s));
+        plslam_match_problem p{};
+        p.d1 = (const uint8_t*)(d + oQ); p.n1 = nq; p.d2 = (const uint8_t*)(d + oT); p.n2 = nt;
+        p.nnr = nnr; p.mutual = mutual ? 1 : 0; p.matches_12 = (int32_t*)(d + oM); p.n_matches = nullptr; p.keep_prior = 1;
+        if ((rc = match_problems_on_ctx_stream(ctx, &p, 1))) return rc;
+        if ((rc = launch_gate_n(lines, *K, Twf, (const double*)(d + oQL), (const int32_t*)(d + oM), res + 1, n_map,
+                                (const double*)(d + oTF), max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi),
+                                (const int32_t*)(d + oTi), (int32_t*)(d + oMap), s)))
+            return rc;
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oRes, (oMap - oRes) + (size_t)n_map * 4, hipMemcpyDeviceToHost, s));
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        sg2.dismiss();
+        if (used_match) *used_match = 1;
     }
     memcpy(map_to_kf, ho + (oMap - oRes), (size_t)n_map * 4);
     if (n_matches) *n_matches = r[0];
@@ -557,11 +576,11 @@ int map2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double*
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard dg_(ctx->device);    // every entry point runs on the context's device, whatever the calling thread's current one
     if (fast) {
-        // one launch sequence, one synchronisation; it asks for the step-by-step form below when the brute-force matcher
-        // has to replace matchGrid's table (which needs the candidate list's length on the host)
+        // one launch sequence, one synchronisation (+ a second, short one on what is resident when the brute-force matcher
+        // has to replace matchGrid's table); it asks for the step-by-step form below only for a huge map
         int redo = 0;
         const int rc1 = map2kf_fast_once(ctx, lines, K, Twf, LM, med_desc, candidate, n_map, kf_desc, kf_feat, kf_seg, ti, nnr, mutual,
-                                         max_epip, min_matches, fm, map_to_kf, n_matches, map_dev, &redo);
+                                         max_epip, min_matches, fm, map_to_kf, n_matches, used_match, map_dev, &redo);
         if (rc1 || !redo) return rc1;
     } else {
         // no matcher would run at all (:594 / :709 with no table from matchGrid: matches = 0 < min_matches is the condition)

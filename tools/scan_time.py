@@ -21,6 +21,8 @@ ctx = plslam_amd.Context(0)
 ctx.set_option("scan_variant", variant)
 ctx.set_option("mfma_form", form)
 ctx.set_option("fuse", fuse)
+for kv in filter(None, os.environ.get("PLSLAM_OPTS", "").split(",")):      # any other option: PLSLAM_OPTS=stripe_mix=4,group_cap=2
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 s = synth.stereo_stream(64, 1500, 200, seed=synth.SEED0)
 reps = pairs // 64
 big = {k: np.concatenate([v[:1]] + [v[1:]] * reps) for k, v in s.items()}
@@ -35,5 +37,5 @@ for _ in range(5):
     bm.plan.run(st.cuda_stream)
 st.synchronize()
 a, b, n = bm.plan.elapsed()
-print(f"{os.path.basename(os.environ.get('PLSLAM_HIP_LIB_EXPERIMENT', 'shipped')):16s} variant {variant} form {form} fuse {fuse} pairs {pairs} "
+print(f"[{os.environ.get('PLSLAM_OPTS', '')}] {os.path.basename(os.environ.get('PLSLAM_HIP_LIB_EXPERIMENT', 'shipped')):16s} variant {variant} form {form} fuse {fuse} pairs {pairs} "
       f"mutual {int(mutual)}: scan {a / n:.3f} ms  merge+finalize {b / n:.3f} ms")
