@@ -109,10 +109,11 @@ void plslam_ctx_destroy(plslam_ctx* ctx);
  * "split_post" (column-split plans of mutual problems -- a few LARGE problems, e.g. one local map against one frame: 0 = auto
  * (default): everything behind the scan is ONE kernel, which merges the column partials and decides the matches from the
  * column side -- two launches per run | 1 = never: merge kernel + finalize kernel; identical tables and counts),
- * "post_xcd" (0 = default: the finalize kernel takes its block table in order | 1 = every XCD takes a contiguous run of the
- * table, so the row blocks of one problem gather the problem's column keys through ONE L2 -- measured SLOWER on MI355X, 0.302
- * against 0.280 ms per 4096-pair step for the stages behind the scan: the gathers of a problem then queue on one L2 instead of
- * six; identical tables),
+ * "post_xcd" (how the finalize kernel's workgroups take the block table: 2 = default: the table is dealt to the eight XCDs problem
+ * by problem, so the row blocks of one problem gather the problem's column keys through ONE L2 while consecutive problems sit on
+ * different XCDs -- by the counters 0.36 instead of 1.0 GB fetched per 4096-pair step, step time equal or 1 % better | 1 = every
+ * XCD takes a contiguous eighth of the table: the same bytes, measured 8 % SLOWER for the stage | 0 = table order: a problem's
+ * six row blocks sit on six XCDs and each fetches the whole column table; identical tables),
  * "split_target", "split_min_tiles" (column-split plans: workgroups per CU the split aims at, 0 = 3; tiles of 32 columns per
  * range at least, 0 = 4),
  * "graph" (plslam_match_plan_run as ONE replayed HIP graph -- the run's launches captured on the caller's stream at its first

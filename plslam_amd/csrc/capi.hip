@@ -76,6 +76,7 @@ struct plslam_match_plan {
     plslam_ctx* ctx = nullptr;
     int variant = 0, block_threads = 0;
     int32_t nprob = 0, nscan = 0, nscan_blocks = 0, nfin_blocks = 0, ncounts = 0;
+    int32_t fin_row = 0;               // > 0: the finalize table is dealt to the XCDs problem by problem, 8 rows of this length (option post_xcd 2)
     int32_t nsym = 0, nsym_blocks = 0, nmerge_blocks = 0, sym_rows = 1;
     bool sym_mfma = false;             // symmetric problems run on K1e (matrix cores)
     bool sym_mfma_multi = false;       // ... and some of them have n2 > 2048 (multi-window instantiation)
@@ -557,6 +558,33 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     }
     P->nscan = (int32_t)scans.size();
     P->nscan_blocks = (int32_t)sblocks.size();
+    // option "post_xcd" = 2: the finalize table dealt to the XCDs PROBLEM BY PROBLEM (a problem's row blocks gather its column keys
+    // through one L2, and consecutive problems sit on different XCDs, so the eight of them sweep memory together): rows of equal
+    // length, no-op entries (item = -1) behind the short ones; table entry (b % 8) * row + b / 8 is workgroup b's
+    P->fin_row = 0;
+    if (ctx->post_xcd == 2 && fblocks.size() >= 64) {
+        std::vector<BlockDesc> rows[8];
+        size_t x = 0;
+        for (size_t i = 0; i < fblocks.size();) {
+            size_t j = i;
+            while (j < fblocks.size() && fblocks[j].item == fblocks[i].item) ++j;
+            size_t best = x;
+            for (size_t t = 0; t < 8; ++t) {
+                const size_t c = (x + t) & 7;
+                if (rows[c].size() < rows[best].size()) best = c;
+            }
+            for (size_t k = i; k < j; ++k) rows[best].push_back(fblocks[k]);
+            x = (best + 1) & 7;
+            i = j;
+        }
+        size_t L = 0;
+        for (auto& r_ : rows) L = std::max(L, r_.size());
+        std::vector<BlockDesc> out(8 * L, BlockDesc{-1, 0});
+        for (size_t c = 0; c < 8; ++c)
+            for (size_t k = 0; k < rows[c].size(); ++k) out[c * L + k] = rows[c][k];
+        fblocks.swap(out);
+        P->fin_row = (int32_t)L;
+    }
     P->nfin_blocks = (int32_t)fblocks.size();
     P->nsym = (int32_t)syms.size();
     P->nsym_blocks = (int32_t)yblocks.size();
@@ -710,7 +738,7 @@ static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
     if (r) return r;
     // the gate stage: its counters are cleared first; gates over the plan's own tables run inside the finalize kernel
     if (P->ngates > 0 && P->d_gate_counts) PLSLAM_HIP_CHECK(hipMemsetAsync(P->d_gate_counts, 0, sizeof(int32_t) * (size_t)P->ngates, s));
-    r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, P->ngates > 0 ? P->d_gates : nullptr, s, split ? P->ctx->post_workgroups : 0, P->ctx->post_xcd != 0);
+    r = launch_finalize(P->d_probs, P->d_fin_blocks, P->nfin_blocks, P->ngates > 0 ? P->d_gates : nullptr, s, split ? P->ctx->post_workgroups : 0, P->ctx->post_xcd == 1, P->fin_row);
     if (r) return r;
     }
     if (P->ngate_blocks > 0) {
@@ -866,7 +894,7 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         return PLSLAM_OK;
     }
     if (!strcmp(key, "post_xcd")) {
-        PLSLAM_REQUIRE(value >= 0 && value <= 1, PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(value >= 0 && value <= 2, PLSLAM_EINVAL);
         ctx->post_xcd = value;
         return PLSLAM_OK;
     }

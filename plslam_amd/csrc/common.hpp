@@ -129,7 +129,7 @@ struct plslam_ctx {
     int post_workgroups = 0;   // > 0: the stages behind a scan (merge of K1h's partials, finalize) run as at most this many workgroups walking their block tables
     int split_target = 0, split_min_tiles = 0;   // column split: workgroups per CU aimed at (0 = 3), tiles per column range at least (0 = 4)
     int split_post = 0;  // column-split K1f plans: 0 = auto (merge + ratio + mutual behind the scan in ONE kernel: two launches per run), 1 = never
-    int post_xcd = 0;    // finalize: 1 = an XCD takes contiguous entries of the block table (a problem's row blocks share one L2), 0 = table order
+    int post_xcd = 2;    // finalize: 0 = table order, 1 = an XCD takes contiguous entries of the block table (a problem's row blocks share one L2), 2 = the table dealt to the XCDs problem by problem (default)
     int post_fuse = 0;   // K1h / K1i plans: merge + finalize + gates behind the scan as ONE kernel: 0 = auto (throughput plans), 1 = never, 2 = whenever eligible
     int fuse = 0;        // K1f: 0 = auto (one workgroup per problem incl. merge + finalize when the plan is large), 1 = never, 2 = always
     std::mutex mu;       // serialises the host-pointer entry points
@@ -234,7 +234,7 @@ struct BlockDesc {      // one workgroup's slice of a scan / problem
 int launch_scan(const plslam_ctx* ctx, int variant, int block_threads, const ScanDesc* d_scans,
                 const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero, hipStream_t s);
 int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int nblocks,
-                    const plslam_stereo_gate_problem* d_gates, hipStream_t s, int grid_cap = 0, bool xcd_chunks = false);
+                    const plslam_stereo_gate_problem* d_gates, hipStream_t s, int grid_cap = 0, bool xcd_chunks = false, int dealt_row = 0);
 // K2' (hamming.hip): merge of K1h's / K1i's column partials + finalize + gates, one workgroup per problem; lds_bytes = 8 x the
 // largest n2 of the plan
 constexpr int POST_FUSED_MAX_N2 = 4096;

@@ -674,18 +674,21 @@ __global__ void __launch_bounds__(256)
 k_finalize(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ blocks,
            const plslam_stereo_gate_problem* __restrict__ gates, int nblocks, int per_xcd)
 {
-  // per_xcd > 0 (option "post_xcd", off by default): workgroup b runs on XCD b % 8, and with per_xcd = ceil(nblocks / 8) XCD x
-  // takes the CONTIGUOUS table entries [x per_xcd, (x + 1) per_xcd), so the (<= 6) row blocks of one problem gather their
-  // column pairs keys21[m] through ONE L2 -- in table order they sit on six XCDs and each fetches the problem's whole column
-  // table (round-4 counters: 0.49 M KiB fetched per 4096-pair step for 0.22 GB of keys).  Measured SLOWER (stages behind the
-  // scan 0.302 against 0.280 ms per step, twice each on one box): the kernel is bound by its chain of dependent accesses, and
-  // a problem's 1500 gathers then queue on one L2's channels instead of six.
+  // per_xcd > 0: workgroup b runs on XCD b % 8 and takes table entry (b % 8) * per_xcd + b / 8, so that the (<= 6) row blocks of
+  // one problem gather their column pairs keys21[m] through ONE L2 -- in table order they sit on six XCDs and each fetches
+  // the problem's whole column table (round-4 counters: FETCH_SIZE 488 k KiB per 4096-pair step against 174 k; tools/
+  // fetch_gather_calib.hip reproduces the pattern and the factor).  Option "post_xcd" 2 (default): plan_build deals the table
+  // to the XCDs problem by problem (rows of per_xcd entries, padding item = -1) -- consecutive problems on different XCDs, the
+  // eight sweep memory together: step time equal to 1 % better, the stage alone 2 % slower.  Option 1: per_xcd = ceil(nblocks /
+  // 8) over the table in problem order, i.e. a contiguous eighth per XCD: the same bytes but 8 % SLOWER for the stage (0.302
+  // against 0.280 ms per step) -- eight distant regions of memory at a time.
   // (a capped grid walks the block table: plslam_ctx option "post_workgroups")
   const int nslots = per_xcd > 0 ? 8 * per_xcd : nblocks;
   for (int b = blockIdx.x; b < nslots; b += gridDim.x) {
     const int blk = per_xcd > 0 ? (b & 7) * per_xcd + (b >> 3) : b;
     if (blk >= nblocks) continue;                      // (the whole workgroup: finalize_row's DPP rotations see all lanes or none)
     const BlockDesc bd = blocks[blk];
+    if (bd.item < 0) continue;                         // padding entry of a table dealt to the XCDs (option "post_xcd" 2)
     const ProblemDesc p = probs[bd.item];
     finalize_row(p, bd.row0 + (int)threadIdx.x, gates, [&](int m) {
         const gvec2_t kv = g_(reinterpret_cast<const gvec2_t*>(p.keys21))[m];
@@ -867,11 +870,12 @@ int launch_post_fused(const ProblemDesc* d_probs, int nprob, const plslam_stereo
 }
 
 int launch_finalize(const ProblemDesc* d_probs, const BlockDesc* d_blocks, int nblocks,
-                    const plslam_stereo_gate_problem* d_gates, hipStream_t s, int grid_cap, bool xcd_chunks)
+                    const plslam_stereo_gate_problem* d_gates, hipStream_t s, int grid_cap, bool xcd_chunks, int dealt_row)
 {
     if (nblocks <= 0) return PLSLAM_OK;
-    // xcd_chunks: contiguous table entries per XCD (k_finalize; option post_xcd, measured slower); pointless below a few entries per XCD
-    const int per_xcd = xcd_chunks && nblocks >= 64 ? (nblocks + 7) / 8 : 0;
+    // xcd_chunks: contiguous table entries per XCD (k_finalize; option post_xcd 1, measured slower); pointless below a few entries
+    // per XCD.  dealt_row > 0: the table is already dealt to the XCDs in 8 rows of that length (plan_build, option post_xcd 2).
+    const int per_xcd = dealt_row > 0 ? dealt_row : (xcd_chunks && nblocks >= 64 ? (nblocks + 7) / 8 : 0);
     const int nslots = per_xcd > 0 ? 8 * per_xcd : nblocks;
     int grid = grid_cap > 0 && grid_cap < nslots ? grid_cap : nslots;
     if (per_xcd > 0 && grid < nslots) grid = grid >= 8 ? grid & ~7 : 8;   // a walking workgroup stays on its XCD's chunk

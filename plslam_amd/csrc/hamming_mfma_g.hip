@@ -746,6 +746,7 @@ __global__ void __launch_bounds__(256)
 k_split_rows_dump(const ProblemDesc* __restrict__ probs, const BlockDesc* __restrict__ blocks)
 {
     const BlockDesc bd = blocks[blockIdx.x];
+    if (bd.item < 0) return;                               // (padding entry of a dealt table)
     const ProblemDesc p = probs[bd.item];
     const int i1 = bd.row0 + (int)threadIdx.x;
     if (i1 >= p.n1 || p.nsplit <= 1) return;

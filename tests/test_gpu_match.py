@@ -886,17 +886,17 @@ def test_column_split_plan_with_a_gate_or_prior_entries_keeps_the_finalize_kerne
 
 
 def test_finalize_kernel_options(ctx, oracle):
-    """Options of the finalize kernel, schedule-only: post_xcd = 1 hands every XCD a contiguous run of the block table (the row
-    blocks of one problem gather its column keys through one L2; with a capped grid -- post_workgroups -- the walking workgroups
-    stay on their XCD's chunk).  Same tables, counts, gated associations and disparities as the defaults and as the oracle, on
-    a plan whose table has ragged chunks."""
+    """Options of the finalize kernel, schedule-only: post_xcd = 1 hands every XCD a contiguous run of the block table, 2 deals
+    the table to the XCDs problem by problem with padding entries (either way the row blocks of one problem gather its column
+    keys through one L2; with a capped grid -- post_workgroups -- the walking workgroups stay on their XCD's entries).  Same
+    tables, counts, gated associations and disparities as the defaults and as the oracle, on a plan whose table has ragged chunks."""
     import torch
     pairs, n_orb, n_lbd = 37, 300, 70                        # 37 x (2 x 2 + 2 x 1) = 222 blocks: chunks of 28, the last one short
     s = synth.stereo_stream(pairs, n_orb, n_lbd, seed=4242)
     geo = synth.stereo_geometry(s, seed=6)
     out = {}
     try:
-        for xcd, cap in ((0, 0), (1, 0), (1, 21), (1, 5), (0, 9)):
+        for xcd, cap in ((0, 0), (1, 0), (1, 21), (1, 5), (0, 9), (2, 0), (2, 13)):
             ctx.set_option("post_xcd", xcd)
             ctx.set_option("post_workgroups", cap)
             bm = frontend.StereoBatchMatcher(ctx, s, nnr_p=0.8, nnr_l=0.9, mutual=True, geometry=geo, gates=dict(synth.KITTI_GATES), n_buffers=2)
