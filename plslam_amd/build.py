@@ -10,14 +10,16 @@ _ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 OUT = os.path.join(_HERE, "lib", "libplslam_hip.so")
 SOURCES = ["hamming.hip", "hamming_mfma.hip", "hamming_mfma_g.hip", "hamming_mfma_d.hip", "hamming_mfma_h.hip", "hamming_mfma_i.hip", "lba.hip", "lba_assemble.hip", "map2kf.hip", "lbd.hip", "median_desc.hip", "match_grid.hip", "stereo_gates.hip", "pose_gn.hip", "lbd_float.hip", "capi.hip"]
-HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(_ROOT, "include", "plslam_hip.h")]
+HEADERS = [os.path.join(CSRC, "common.hpp"), os.path.join(CSRC, "gfx950_only.hpp"), os.path.join(_ROOT, "include", "plslam_hip.h")]
 # -ffp-contract=off: the fp64 row kernels must execute the reference's operation order
 # (no FMA contraction) so that thresholded masks reproduce the CPU restatement bit for bit.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
          "-Wall", "-Wextra", "-Wno-unused-command-line-argument",
          # K1i declares M0 clobbered by its LDS-DMA statement (hamming_mfma_i.hip); the pragma form of this does not reach the
          # diagnostic, which is raised at code generation
-         "-Wno-inline-asm"]
+         "-Wno-inline-asm",
+         # every translation unit refuses any device target but gfx950 (the LDS-DMA asm of K1h / K1i, hand-counted vmcnt waits)
+         "-include", os.path.join(CSRC, "gfx950_only.hpp")]
 
 
 def hipcc_path() -> str:

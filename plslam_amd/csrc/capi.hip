@@ -377,6 +377,9 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
         pd.d1 = p.d1; pd.d2 = p.d2;
         pd.gate = -1;
         const bool mf_path = P->sym_mfma && p.n1 > 0 && p.n2 > 0;    // this problem runs on K1e / K1f
+        // (finalize blocks start at multiples of 256 rows and run all 256 lanes: the lazy completion of K1h's / K1i's column keys
+        // rotates the neighbouring rows' keys through DPP within aligned groups of 16 lanes -- hamming.hip, finalize_row)
+        static_assert(256 % 16 == 0, "a finalize block must hold whole groups of 16 rows");
         if (!(P->fused && mf_path))
             for (int32_t r0 = 0; r0 < p.n1; r0 += 256) fblocks.push_back({i, r0});
         int32_t cstep = 0;

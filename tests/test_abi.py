@@ -107,3 +107,24 @@ def test_header_is_plain_c(tmp_path):
         r = subprocess.run(cmd + ["-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-fsyntax-only",
                                   str(src)], capture_output=True, text=True)
         assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_the_library_refuses_other_device_targets(tmp_path):
+    """K1h / K1i rely on gfx9's in-order vmcnt and on gfx950 instructions through inline asm.  build.py force-includes
+    gfx950_only.hpp into every translation unit: the same flags with another --offload-arch must fail at the #error, not compile."""
+    import shutil
+    import subprocess
+    from plslam_amd import build as B
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    assert "-include" in B.FLAGS and B.FLAGS[B.FLAGS.index("-include") + 1].endswith("gfx950_only.hpp")
+    src = tmp_path / "t.hip"
+    src.write_text("#include <hip/hip_runtime.h>\n__global__ void k(int* p) { *p = 1; }\n")
+    flags = [f for f in B.FLAGS if f not in ("-shared", "--offload-arch=gfx950")]
+    ok = subprocess.run([hipcc, "--offload-arch=gfx950"] + flags + ["-c", "--cuda-device-only", str(src), "-o", str(tmp_path / "a.o")],
+                        capture_output=True, text=True)
+    assert ok.returncode == 0, ok.stderr
+    bad = subprocess.run([hipcc, "--offload-arch=gfx942"] + flags + ["-c", "--cuda-device-only", str(src), "-o", str(tmp_path / "b.o")],
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and "gfx950" in bad.stderr

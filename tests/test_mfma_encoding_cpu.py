@@ -352,3 +352,36 @@ def test_k1i_workgroup_column_combine_model():
             assert d1 == others[0] >> 8, (it, d1, others[0] >> 8)
         else:
             assert d1 > 256
+
+
+def test_column_side_decision_equals_the_row_side_one():
+    """k_split_post (the kernel behind a column-split scan, two launches per run) decides the matches from the COLUMN side: column
+    j's ratio test names the one row i* it can match, row i*'s ratio test names its column m, and (i*, j) is a match iff m = j.
+    stvo-pl's match() reads the same set from the row side (row i's candidate m survives iff column m's candidate is i).  Model of
+    both on the oracle's two kNN-2 tables: identical tables and counts on random, tie-heavy, tiny and one-column inputs."""
+    from oracle import oracle as O
+    from plslam_amd import synth
+    r = np.random.Generator(np.random.PCG64(20260925))
+
+    def ratio_pick(idx, dist, nnr):
+        ok = (idx[:, 1] >= 0) & (dist[:, 0].astype(np.float32) < dist[:, 1].astype(np.float32) * np.float32(nnr))
+        return np.where(ok, idx[:, 0], -1)
+
+    for n1, n2, gen in ((700, 300, synth.random_desc), (257, 513, synth.tie_stress_desc), (5, 2, synth.random_desc),
+                        (64, 1, synth.random_desc), (300, 300, synth.tie_stress_desc)):
+        d2 = gen(r, n2)
+        d1 = np.concatenate([synth.noisy_copy(r, d2)[0], gen(r, n1)])[:n1]
+        d1 = np.ascontiguousarray(d1[r.permutation(n1)])
+        for nnr in (0.6, 0.75, 0.9):
+            i12, t12 = O.knn2(d1, d2)
+            i21, t21 = O.knn2(d2, d1)
+            m12, m21 = ratio_pick(i12, t12, nnr), ratio_pick(i21, t21, nnr)
+            rows = np.where((m12 >= 0) & (m21[np.clip(m12, 0, None)] == np.arange(n1)), m12, -1)        # match(): row side
+            cols = np.full(n1, -1, np.int64)                                                            # k_split_post: column side
+            for j in range(n2):
+                istar = m21[j]
+                if istar >= 0 and m12[istar] == j:
+                    cols[istar] = j
+            ref, nref = O.match(d1, d2, nnr, True)
+            assert np.array_equal(rows, ref) and np.array_equal(cols, ref), (n1, n2, nnr)
+            assert int((cols >= 0).sum()) == nref
