@@ -23,6 +23,13 @@ _ROOT = os.path.dirname(os.path.abspath(__file__))
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 
+# HIP backs its streams with a few hardware queues (GPU_MAX_HW_QUEUES, default 4 per priority); streams that share one run their
+# kernels in order.  This process keeps several in flight -- scan stream, stage stream, the process group's collective stream,
+# torch's own -- and with 4 queues the collective of the N > 1 step lands behind the scans for some stream-creation orders: the
+# one-rank RCCL step measured 0.84-0.88 of the plain step with 4 and 8 queues, 0.98 with 16 and 32 (profiles/
+# r4_e_hw_queues.txt).  Must be set before the HIP runtime initialises (torch is imported in main()).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md)
@@ -550,6 +557,7 @@ def main():
                 "stereo_gates": gates,
                 "scan_variant": info["scan_variant"], "scan_block_threads": info["scan_block_threads"],
                 "mfma_form": form, "kernel": kernel_name, "kernel_source_hash": src_hash,
+                "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                 "parallelism": f"pairs sharded over {world} rank(s); per-step RCCL gather of the match tables "
                                "to rank 0, overlapped with the next step" if use_dist else
                                ("single GPU; consecutive steps alternate two output buffers; every scan on one HIP stream, the stages behind a scan (merge, finalize, gates) on a second, high-priority one: they run under the next step's scan" if overlap

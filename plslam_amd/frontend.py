@@ -243,7 +243,7 @@ class TableGatherPipeline:
     are viewed as uint8."""
 
     def __init__(self, rows: int, stride: int, max_index: int, world: int, rank: int, root: int = 0, nbuf: int = 2,
-                 device=None, group=None, compact=None):
+                 device=None, group=None, compact=None, comm_stream=None):
         import torch
         self.torch, self.world, self.rank, self.root, self.group, self.nbuf = torch, world, rank, root, group, nbuf
         self.rows, self.stride = rows, stride
@@ -260,7 +260,9 @@ class TableGatherPipeline:
             if (rank == root and self.compact and self.cuda) else None
         # high priority: the gather's kernels are short and must take the workgroup slots the running scan frees -- at normal
         # priority they queue behind the scan's whole backlog, and the step that recomputes this buffer waits for them
-        self.comm = torch.cuda.Stream(device=self.dev, priority=-1) if self.cuda else None
+        # comm_stream: run the wait for the collective and the widening on a stream the caller already has (the matcher's stage
+        # stream) instead of a third one of our own
+        self.comm = (comm_stream if comm_stream is not None else torch.cuda.Stream(device=self.dev, priority=-1)) if self.cuda else None
         self.done_ev = [None] * nbuf         # CUDA: recorded on the comm stream after buffer b's gather
         self.works = [None] * nbuf
 
@@ -327,10 +329,22 @@ class PipelinedGather:
     """Gathers the per-step match tables of all ranks to `root` on a communication stream while the
     next step computes: StereoBatchMatcher (compute) + TableGatherPipeline (wire format, buffers, ordering)."""
 
-    def __init__(self, bm: StereoBatchMatcher, world: int, rank: int, root: int = 0, group=None, compact=None):
+    def __init__(self, bm: StereoBatchMatcher, world: int, rank: int, root: int = 0, group=None, compact=None,
+                 comm_on_stage_stream: bool = True):
+        """comm_on_stage_stream (default): the wait for the collective and the root's widening go on the matcher's STAGE stream,
+        behind the stages and the narrowing copy of the step -- no third stream.  Measured on a one-rank RCCL group
+        (tools/gather_step_probe.py, 512-pair steps): the step then costs what the plain step costs (0.344-0.349 against
+        0.336-0.366 ms) whatever streams were created before, while a communication stream of its own -- from torch's
+        high-priority pool, whose streams share a few hardware queues -- landed on 0.345-0.379 ms or, deterministically for
+        some creation orders, on 0.45 ms (the gather queued behind other work of its hardware queue).  The collective itself
+        runs on the process group's internal stream either way; a HIGH-priority process-group stream (ProcessGroupNCCL.Options.
+        is_high_priority_stream) made every step slower, the plain one included (0.44-0.59 ms): do not use it.  What the shared
+        stream costs: the next step's stages queue behind this step's gather -- harmless while a gather is shorter than a
+        step minus its stages (7 x 3.5 MB over seven links at 512 pairs per rank: ~0.1 of 0.33 ms)."""
         self.bm = bm
         self.pipe = TableGatherPipeline(bm.B, bm.stride, max(bm.n_orb, bm.n_lbd), world, rank, root,
-                                        nbuf=len(bm.tables), device=bm.dev, group=group, compact=compact)
+                                        nbuf=len(bm.tables), device=bm.dev, group=group, compact=compact,
+                                        comm_stream=bm.streams[min(1, len(bm.streams) - 1)] if comm_on_stage_stream else None)
 
     def step(self, k: int):
         """Compute step k into buffer k % nbuf and start gathering it."""

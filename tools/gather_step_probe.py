@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """The N > 1 step on a one-rank RCCL group: step time and host enqueue time of PipelinedGather around a 512-pair matcher, beside
-the plain overlapped step.  usage: gather_step_probe.py [pairs] [steps]"""
+the plain overlapped step; modes: gather (own communication stream, int16 wire), gather_int32, gather_stage (wait + widening on
+the matcher's stage stream: PipelinedGather's default); PG_HIGH=1: a high-priority process-group stream.
+usage: gather_step_probe.py [pairs] [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,15 +16,22 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
 t0 = time.perf_counter()
-dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-print(f"process group up in {time.perf_counter() - t0:.2f} s", flush=True)
+pg_high = int(os.environ.get("PG_HIGH", "0"))      # PG_HIGH=1: the collective's own stream comes from the high-priority pool
+opts = None
+if pg_high:
+    from torch.distributed import ProcessGroupNCCL
+    opts = ProcessGroupNCCL.Options()
+    opts.is_high_priority_stream = True
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=opts)
+print(f"process group up in {time.perf_counter() - t0:.2f} s (high-priority collective stream: {pg_high})", flush=True)
 ctx = plslam_amd.Context(0)
 st = synth.stereo_stream(pairs, 1500, 200, seed=synth.SEED0)
 geo = synth.stereo_geometry(st, first_pair=0)
 for nb in (2, 3):
     bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=0.75, nnr_l=0.75, mutual=True, n_buffers=nb, geometry=geo, gates=dict(synth.KITTI_GATES))
-    for mode in ("plain", "gather", "gather_int32", "plain", "gather"):
-        pg = None if mode == "plain" else frontend.PipelinedGather(bm, 1, 0, root=0, compact=(mode == "gather"))
+    for mode in ("plain", "gather", "gather_int32", "gather_stage", "plain", "gather", "gather_stage", "gather", "gather_stage"):
+        pg = None if mode == "plain" else frontend.PipelinedGather(bm, 1, 0, root=0, compact=(mode != "gather_int32"),
+                                                                   comm_on_stage_stream=(mode == "gather_stage"))     # "gather" / "gather_int32": a communication stream of its own
         step = (lambda k: bm.run_overlapped(k)) if pg is None else pg.step
         for k in range(6):
             step(k)
