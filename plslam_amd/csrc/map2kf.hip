@@ -268,7 +268,7 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
                  oD1 = c.take(lines ? (size_t)n_map * 16 : 0), oM = c.take((size_t)n_map * 4), oMask = c.take((size_t)n_map);
     if ((rc = ctx->misc_a.reserve(c.off))) return rc;
     if ((rc = ctx->pin_in.reserve(image))) return rc;
-    if ((rc = ctx->pin_out.reserve(256 + (size_t)n_map * 4))) return rc;
+    if ((rc = ctx->pin_out.reserve((oMap - oRes) + (size_t)n_map * 4))) return rc;      // the counters' pages + the table behind them
     if ((rc = ctx->misc_c.reserve(grid_scratch_words(n_map, nt, (int64_t)cols * rows, (int32_t)cap) * 4 + 256))) return rc;
     char* d = ctx->misc_a.as<char>();
     char* h = ctx->pin_in.as<char>();
@@ -383,7 +383,7 @@ int map2kf_bf_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const double
                  oM = c.take((size_t)n_map * 4), oMask = c.take((size_t)n_map);
     if ((rc = ctx->misc_a.reserve(c.off))) return rc;
     if ((rc = ctx->pin_in.reserve(image))) return rc;
-    if ((rc = ctx->pin_out.reserve(256 + (size_t)n_map * 4))) return rc;
+    if ((rc = ctx->pin_out.reserve((oMap - oRes) + (size_t)n_map * 4))) return rc;      // the counters' pages + the table behind them
     char* d = ctx->misc_a.as<char>();
     char* h = ctx->pin_in.as<char>();
     int32_t* const res = (int32_t*)(d + oRes);                           // [0] gate count, [1] nq
