@@ -509,8 +509,14 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
         p.d1 = d_Q; p.n1 = n_prev; p.d2 = d_T; p.n2 = n_curr;
         p.nnr = nnr; p.mutual = mutual ? 1 : 0; p.n_matches = (int32_t*)(d + oCnt);
         p.keep_prior = have ? 1 : 0;             // the vector matchGrid filled is handed on (:271 -> :277, :418 -> :424)
-        if (p.keep_prior) {
-            // (rare) the kernel reads the earlier table as well as writing it: keep it on the device
+        bool count_only = false;                 // the table is (stays) in page-locked memory: only the counter comes back
+        if (p.keep_prior && on_host && tab_mapped) {
+            // the finalize kernel reads the earlier entry of a rejected row and writes every row: a few hundred to a few
+            // thousand 4-byte accesses to page-locked memory cost less than moving the table to the device and back (two
+            // copy commands on the call's critical path)
+            p.matches_12 = tab_mapped;
+            count_only = true;
+        } else if (p.keep_prior) {
             if (on_host) PLSLAM_HIP_CHECK(hipMemcpyAsync(tab_dev, tab_host, (size_t)n_prev * 4, hipMemcpyHostToDevice, s));
             p.matches_12 = tab_dev;
             on_host = false;
@@ -523,8 +529,11 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
         if (!on_host) {
             PLSLAM_HIP_CHECK(hipMemcpyAsync(tab_host, tab_dev, (size_t)n_prev * 4, hipMemcpyDeviceToHost, s));
             PLSLAM_HIP_CHECK(hipMemcpyAsync(&matches, d + oCnt, 4, hipMemcpyDeviceToHost, s));
+        } else if (count_only) {
+            PLSLAM_HIP_CHECK(hipMemcpyAsync(tab_host + n_prev, d + oCnt, 4, hipMemcpyDeviceToHost, s));    // (page-locked: behind the table)
         }
         PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        if (count_only) matches = tab_host[n_prev];
         on_host = true;
         have = true;
         if (used_match) *used_match = 1;
