@@ -385,3 +385,58 @@ def test_column_side_decision_equals_the_row_side_one():
             ref, nref = O.match(d1, d2, nnr, True)
             assert np.array_equal(rows, ref) and np.array_equal(cols, ref), (n1, n2, nnr)
             assert int((cols >= 0).sum()) == nref
+
+
+def test_dealt_finalize_table_covers_every_entry_once():
+    """plan_build (option post_xcd 2) deals the finalize kernel's block table to the 8 XCDs problem by problem -- rows of equal
+    length, padding entries behind the short ones -- and workgroup b (which the hardware places on XCD b % 8) takes entry
+    (b % 8) * row + b / 8; a capped grid (a multiple of 8 workgroups) walks b += grid.  Model of both: every real entry is taken
+    exactly once, by a workgroup of the XCD whose row holds it, a problem's entries all lie in one row, rows differ by at most one
+    problem's blocks, and with the contiguous-eighth mapping (post_xcd 1) the same holds for the chunk a workgroup's XCD owns."""
+    r = np.random.Generator(np.random.PCG64(77))
+    for trial in range(20):
+        nprob = int(r.integers(11, 400))
+        nblk = r.choice([1, 1, 6, 6, 6, 2, 16], size=nprob)              # row blocks per problem (LBD 1, ORB 6, ...)
+        table = [(p, 256 * k) for p in range(nprob) for k in range(int(nblk[p]))]
+        # --- the dealing of plan_build
+        rows, x = [[] for _ in range(8)], 0
+        i = 0
+        while i < len(table):
+            j = i
+            while j < len(table) and table[j][0] == table[i][0]:
+                j += 1
+            best = x
+            for t in range(8):
+                c = (x + t) & 7
+                if len(rows[c]) < len(rows[best]):
+                    best = c
+            rows[best] += table[i:j]
+            x = (best + 1) & 7
+            i = j
+        L = max(len(q) for q in rows)
+        dealt = [(-1, 0)] * (8 * L)
+        for c in range(8):
+            dealt[c * L:c * L + len(rows[c])] = rows[c]
+        assert max(len(q) for q in rows) - min(len(q) for q in rows) <= int(nblk.max())
+        row_of = {}
+        for c in range(8):
+            for p, _ in rows[c]:
+                assert row_of.setdefault(p, c) == c                      # a problem's blocks share one XCD
+        # --- the kernel's walk, uncapped and capped
+        for grid in (8 * L, 8, 8 * max(1, L // 3), 16):
+            grid = min(grid, 8 * L)
+            taken = []
+            for wg in range(grid):
+                b = wg
+                while b < 8 * L:
+                    blk = (b & 7) * L + (b >> 3)
+                    assert blk // L == wg % 8                            # the entry lies in the row of the workgroup's XCD
+                    if dealt[blk][0] >= 0:
+                        taken.append(dealt[blk])
+                    b += grid
+            assert sorted(taken) == sorted(table)
+        # --- post_xcd 1: a contiguous eighth per XCD over the table in problem order
+        n = len(table)
+        per = (n + 7) // 8
+        taken = [table[(b & 7) * per + (b >> 3)] for b in range(8 * per) if (b & 7) * per + (b >> 3) < n]
+        assert sorted(taken) == sorted(table)
