@@ -186,6 +186,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the secondary records (tables only, popcount kernels, C5, C3) of the N = 1 line")
+    ap.add_argument("--gather-wire", choices=("auto", "int16", "int32"), default="auto",
+                    help="N > 1: wire format of the table gather (auto: both are tried for a few untimed steps, the faster one runs)")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the NCCL(RCCL) process group and run the table gather even with one rank")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
@@ -284,7 +286,48 @@ def main():
     rotation = [bm.plans[0]] + [e.plans[0] for e in extra_bms]
     # N > 1: the table of step k is gathered to rank 0 over RCCL on a communication stream while
     # step k+1 computes into the other table buffer (steps are independent batches of a stream).
-    pg = frontend.PipelinedGather(bm, world, rank, root=0) if use_dist else None
+    # Wire format of the gather, chosen by measurement before the warm-up: int16 (half the bytes on every xGMI link, but a
+    # narrowing copy on every rank and the widening of world x the table on the root: 43 + 39 us per 4096-pair table at one
+    # rank, i.e. ~0.3 ms per step on the root of 8) or int32 (no extra kernels, 20 GB/s per link at 1.5 M pairs/s per GPU).
+    # Which is cheaper depends on the links: a few untimed steps of each, the slowest rank's clock decides, every rank takes the
+    # same decision (all-reduce of the times).  A failure of the probe keeps int16.
+    gather_wire = None
+    pg = None
+    if use_dist:
+        probe = {}
+        if max(n_orb, n_lbd) <= 32767 and args.gather_wire == "auto":
+            for name, compact in (("int16", True), ("int32", False)):
+                g_ = None
+                try:
+                    g_ = frontend.PipelinedGather(bm, world, rank, root=0, compact=compact)
+                    for k in range(2):
+                        g_.step(k)
+                    g_.finish()
+                    bm.synchronize_all()
+                    dist.barrier()
+                    t0_ = time.perf_counter()
+                    for k in range(2, 8):
+                        g_.step(k)
+                    g_.finish()
+                    bm.synchronize_all()
+                    tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=dev)
+                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                    probe[name] = float(tt.item()) / 6
+                except Exception as e:                     # (every rank runs the same code: a failure is a failure everywhere)
+                    probe[name] = float("inf")
+                    note(f"gather wire probe {name}: {type(e).__name__}: {e}")
+                finally:
+                    del g_
+            torch.cuda.synchronize(dev)
+        choice = "int32" if probe.get("int32", float("inf")) < 0.98 * probe.get("int16", float("inf")) else "int16"
+        if args.gather_wire in ("int16", "int32"):
+            choice = args.gather_wire
+        if max(n_orb, n_lbd) > 32767:
+            choice = "int32"
+        pg = frontend.PipelinedGather(bm, world, rank, root=0, compact=(choice == "int16"))
+        gather_wire = {"format": choice, "probe_s_per_step": {k: (v if v != float("inf") else None) for k, v in probe.items()},
+                       "how": "six untimed steps per format before the warm-up, max over ranks; int32 must win by 2 %"}
+        note(f"gather wire format: {gather_wire}")
     scan_stream, stage_stream = bm.streams[0], bm.stage_stream
 
     def run_steps(matcher, gather, n, k0=0, events=None, rotate=True):
@@ -557,7 +600,7 @@ def main():
                 "stereo_gates": gates,
                 "scan_variant": info["scan_variant"], "scan_block_threads": info["scan_block_threads"],
                 "mfma_form": form, "kernel": kernel_name, "kernel_source_hash": src_hash,
-                "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "gather_wire": gather_wire,
                 "parallelism": f"pairs sharded over {world} rank(s); per-step RCCL gather of the match tables "
                                "to rank 0, overlapped with the next step" if use_dist else
                                ("single GPU; consecutive steps alternate two output buffers; every scan on one HIP stream, the stages behind a scan (merge, finalize, gates) on a second, high-priority one: they run under the next step's scan" if overlap
