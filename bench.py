@@ -155,6 +155,179 @@ def cpu_baseline(stream, n_orb, n_lbd, nnr_p, nnr_l, budget_s=15.0):
     return rec, tables
 
 
+def self_launch(n: int, argv) -> int:
+    """Re-executes this script as `n` ranks of one node: python -m torch.distributed.run --nnodes=1 --nproc-per-node n
+    --master-addr 127.0.0.1 --master-port <a free port> bench.py <the same arguments>.  The ranks inherit stdout: rank 0's one
+    JSON line is this command's one JSON line.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, usable_cpus() // max(n, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] self-launch: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check() -> int:
+    """The launch path without a GPU (tests/test_dist_cpu.py): every rank joins a gloo group, the ranks' numbers are summed,
+    rank 0 prints one JSON line."""
+    sys.stdout.flush()
+    real_stdout = os.dup(1)                 # (gloo / RCCL print banners on fd 1: stdout carries the JSON line only)
+    os.dup2(2, 1)
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        os.write(real_stdout, (json.dumps({"launch_check": True, "world_size": world, "rank_sum": int(t.item()),
+                                           "argv": sys.argv[1:]}) + "\n").encode())
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
+
+
+def gather_probe(bm, world, rank, dev, cands, note):
+    """A few untimed-by-the-bench steps of every (wire format, communication stream) candidate; seconds per step, max over ranks
+    (None = a rank could not set the candidate up).  Every rank takes every collective of this function or none: the local
+    set-up (allocations) is the only thing inside a try, its outcome is agreed on by an all-reduce OUTSIDE it, and the timed
+    steps run unguarded -- an error there must end the run, not let one rank skip ahead while the others wait in a gather."""
+    import torch
+    import torch.distributed as dist
+    from plslam_amd import frontend
+    out = {}
+    for wire, comm in cands:
+        name, g_, ok = f"{wire}/{comm}", None, 1
+        try:
+            g_ = frontend.PipelinedGather(bm, world, rank, root=0, compact=(wire == "int16"), comm_on_stage_stream=(comm == "stage"))
+        except Exception as e:                       # (an allocation failed on THIS rank)
+            ok = 0
+            note(f"gather probe {name}: set-up failed on rank {rank}: {type(e).__name__}: {e}")
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            out[name] = None
+            if g_ is not None:
+                g_.close()
+            del g_
+            continue
+        for k in range(2):
+            g_.step(k)
+        g_.finish()
+        bm.synchronize_all()
+        dist.barrier()
+        t0_ = time.perf_counter()
+        for k in range(2, 8):
+            g_.step(k)
+        g_.finish()
+        bm.synchronize_all()
+        tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        out[name] = float(tt.item()) / 6
+        g_.close()
+        del g_
+    torch.cuda.synchronize(dev)
+    return out
+
+
+def shard_gather_record(ctx, dev, args, world, rank, pairs_total, wire, comm, steps, warm, reps, note, tag):
+    """ONE batch of `pairs_total` stereo pairs per step, sharded contiguously over the ranks (BASELINE config 4 as written:
+    4096 pairs -> 512 per GPU at N = 8), stepped exactly as the headline's N > 1 loop steps (PipelinedGather.step + one event per
+    step on the stage stream) -- and, in the same process on the same matcher, the plain step without the gather.  Every rank
+    calls this (the timings are all-reduced); the record comes back on rank 0, whose check covers >= 64 pairs of EVERY rank's
+    shard in both gathered buffers.  world == 1: a (forced) one-rank RCCL group -- the step's own overhead, not a link."""
+    import torch
+    import torch.distributed as dist
+    from plslam_amd import frontend, synth
+    n_orb, n_lbd = args.n_orb, args.n_lbd
+    lo, hi = frontend.shard_range(pairs_total, world, rank)
+    Bs = hi - lo
+    if pairs_total % world:
+        return {"skipped": f"{pairs_total} pairs do not divide over {world} ranks"}
+    st = synth.stereo_stream(Bs, n_orb, n_lbd, seed=synth.SEED0, first_pair=lo)
+    bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev, n_buffers=2,
+                                     geometry=synth.stereo_geometry(st, first_pair=lo), gates=dict(synth.KITTI_GATES))
+    stage = bm.stage_stream
+
+    def maxed(dt):
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def stretches(step_fn, sync_fn):
+        for k in range(warm):
+            step_fn(k)
+        sync_fn()
+        dts = []
+        for r_ in range(reps):
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps)]
+            t0 = time.perf_counter()
+            for k in range(steps):
+                step_fn(warm + r_ * steps + k)
+                evs[k].record(stage)
+            sync_fn()
+            dts.append(maxed(time.perf_counter() - t0))
+        return dts
+
+    def sync_plain():
+        bm.synchronize_all()
+        torch.cuda.synchronize(dev)
+
+    plain = stretches(lambda k: bm.run_overlapped(k), sync_plain)
+    pg = frontend.PipelinedGather(bm, world, rank, root=0, compact=(wire == "int16"), comm_on_stage_stream=(comm == "stage"))
+
+    def sync_gather():
+        pg.finish()
+        bm.synchronize_all()
+        torch.cuda.synchronize(dev)
+
+    pg.host_ms_per_step()
+    gath = stretches(pg.step, sync_gather)
+    host_ms = pg.host_ms_per_step()
+    rec = None
+    if rank == 0:
+        from oracle import oracle as O
+        sample = frontend.spread_sample(Bs, 64)
+        firsts = [frontend.shard_range(pairs_total, world, r_)[0] for r_ in range(world)]
+        for b_ in range(2):
+            bad = frontend.verify_gathered_tables(pg.gathered(b_).cpu().numpy(), world, Bs, n_orb, n_lbd, args.nnr_p, args.nnr_l, sample,
+                                                  lambda d1, d2, nnr: O.match(d1, d2, nnr, True)[0], local_stream=st, first_pairs=firsts)
+            if bad:
+                raise SystemExit(f"{tag}: gathered buffer {b_} differs from the oracle: (rank, pair, problem) = {bad[:4]}")
+        dp, dg = float(np.median(plain)), float(np.median(gath))
+        rec = {"metric": f"stereo pairs/sec ({n_orb} ORB + {n_lbd} LBD BF-match)", "value": pairs_total * steps / dg,
+               "unit": "stereo pairs/s", "n_gpus": world, "scaling": "strong", "pairs_per_step_all_gpus": pairs_total,
+               "pairs_per_gpu_per_step": Bs, "steps": steps, "ms_per_step": 1e3 * dg / steps,
+               "workload": f"{pairs_total} pairs per step in contiguous shards of {Bs} per rank with a one-pair halo, gate stage "
+                           "included, RCCL gather of the match tables to rank 0 under the next step's scan "
+                           "(BASELINE config 4 when pairs_per_step_all_gpus = 4096 and n_gpus = 8)",
+               "gather": {"format": wire, "comm": comm, "int16_written_by": "k_finalize" if pg.kernel_wire16 else None},
+               "plain_step_same_run": {"value": pairs_total * steps / dp, "ms_per_step": 1e3 * dp / steps,
+                                       "what": "the same matcher, the same stepping, no gather: what the shard's step costs by itself"},
+               "over_plain_step_same_run": dp / dg,
+               "host_ms_per_step": host_ms,
+               "stretches_pairs_per_s": [pairs_total * steps / d for d in gath],
+               "plain_stretches_pairs_per_s": [pairs_total * steps / d for d in plain],
+               "how": f"median of {reps} stretches of {steps} steps after {warm} warm-up steps, each stretch between barriers, max "
+                      "over ranks; host_ms_per_step = wall time inside PipelinedGather.step (enqueueing only)",
+               "verified": f"{len(sample)} pairs x 4 problems of each of {world} rank(s), both GATHERED buffers, bit-exact vs the oracle",
+               "note": ("one rank: what it measures is the step's own overhead (events, the collective's launch, the int16 table), "
+                        "not a link; " if world == 1 else "") + "no 1 -> 8 curve has been measured on hardware by the builder"}
+        note(f"  {tag}: {rec['value']:.0f} pairs/s ({rec['over_plain_step_same_run']:.3f} of the plain step), host {host_ms:.3f} ms/step")
+    pg.close()
+    bm.close()
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -190,8 +363,22 @@ def main():
                     help="N > 1: wire format of the table gather (auto: both are tried for a few untimed steps, the faster one runs)")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the NCCL(RCCL) process group and run the table gather even with one rank")
+    ap.add_argument("--gather-comm", choices=("auto", "stage", "own"), default="auto",
+                    help="N > 1: where the wait for the collective (and the root's widening) is enqueued -- the matcher's stage stream "
+                         "or a communication stream of its own (auto: both are tried by the probe; without a probe: stage at one "
+                         "rank, own at N > 1)")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--launch-check", action="store_true",
+                    help="(tests) after the self-launch: a gloo rendezvous of the ranks and ONE JSON line from rank 0 -- no GPU work")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` by itself: one process per GPU under torch.distributed.run on this node (the driver's
+    # `python -m torch.distributed.run ... bench.py --gpus N` form arrives with WORLD_SIZE set and runs as it is).  --force-dist
+    # takes the same road at N = 1, so that the one-rank RCCL run exercises the launch path a SCALE run would take.
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.force_dist or args.launch_check):
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+    if args.launch_check:
+        raise SystemExit(launch_check())
 
     # stdout must carry exactly ONE JSON line; libraries (e.g. RCCL's version banner, flushed at
     # exit) also write to fd 1.  Keep the real stdout aside and point fd 1 at stderr meanwhile.
@@ -214,10 +401,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 "
-                             "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-        args.gpus = world
+        args.gpus = world                               # (the launcher's world size is the truth)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # one rank per GPU: LOCAL_RANK is the device index -- unless the launcher masks the devices per process (each then sees one)
     ndev = torch.cuda.device_count()
@@ -228,7 +412,9 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        import datetime
+        # (a rank that dies leaves the others in a collective: they give up after this long instead of hanging the node)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(minutes=10))
 
     n_orb, n_lbd = args.n_orb, args.n_lbd
     if args.scaling == "strong":
@@ -294,40 +480,28 @@ def main():
     gather_wire = None
     pg = None
     if use_dist:
-        probe = {}
-        if max(n_orb, n_lbd) <= 32767 and args.gather_wire == "auto":
-            for name, compact in (("int16", True), ("int32", False)):
-                g_ = None
-                try:
-                    g_ = frontend.PipelinedGather(bm, world, rank, root=0, compact=compact)
-                    for k in range(2):
-                        g_.step(k)
-                    g_.finish()
-                    bm.synchronize_all()
-                    dist.barrier()
-                    t0_ = time.perf_counter()
-                    for k in range(2, 8):
-                        g_.step(k)
-                    g_.finish()
-                    bm.synchronize_all()
-                    tt = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=dev)
-                    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                    probe[name] = float(tt.item()) / 6
-                except Exception as e:                     # (every rank runs the same code: a failure is a failure everywhere)
-                    probe[name] = float("inf")
-                    note(f"gather wire probe {name}: {type(e).__name__}: {e}")
-                finally:
-                    del g_
-            torch.cuda.synchronize(dev)
-        choice = "int32" if probe.get("int32", float("inf")) < 0.98 * probe.get("int16", float("inf")) else "int16"
-        if args.gather_wire in ("int16", "int32"):
-            choice = args.gather_wire
+        wires = ("int16", "int32") if args.gather_wire == "auto" else (args.gather_wire,)
         if max(n_orb, n_lbd) > 32767:
-            choice = "int32"
-        pg = frontend.PipelinedGather(bm, world, rank, root=0, compact=(choice == "int16"))
-        gather_wire = {"format": choice, "probe_s_per_step": {k: (v if v != float("inf") else None) for k, v in probe.items()},
-                       "how": "six untimed steps per format before the warm-up, max over ranks; int32 must win by 2 %"}
-        note(f"gather wire format: {gather_wire}")
+            wires = ("int32",)
+        comms = ("stage", "own") if args.gather_comm == "auto" else (args.gather_comm,)
+        default = ("int16" if "int16" in wires else wires[0], ("stage" if world == 1 else "own") if len(comms) > 1 else comms[0])
+        cands = [(w_, c_) for w_ in wires for c_ in comms]
+        probe = gather_probe(bm, world, rank, dev, cands, note) if len(cands) > 1 else {}
+        choice = default
+        timed_ok = {k: v for k, v in probe.items() if v is not None}
+        if timed_ok:
+            best = min(timed_ok, key=timed_ok.get)
+            dkey = "/".join(default)
+            # the default keeps its place unless another combination wins by 2 % (the probe is six steps long)
+            if dkey not in timed_ok or timed_ok[best] < 0.98 * timed_ok[dkey]:
+                choice = tuple(best.split("/"))
+        pg = frontend.PipelinedGather(bm, world, rank, root=0, compact=(choice[0] == "int16"),
+                                      comm_on_stage_stream=(choice[1] == "stage"))
+        gather_wire = {"format": choice[0], "comm": choice[1], "int16_written_by": "k_finalize" if pg.kernel_wire16 else None,
+                       "probe_s_per_step": probe,
+                       "how": "six untimed steps per (wire format, communication stream) before the warm-up, max over ranks; the "
+                              f"default ({'/'.join(default)}) keeps its place unless another wins by 2 %"}
+        note(f"gather: {gather_wire}")
     scan_stream, stage_stream = bm.streams[0], bm.stage_stream
 
     def run_steps(matcher, gather, n, k0=0, events=None, rotate=True):
@@ -396,6 +570,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
+    # N > 1: BASELINE config 4 AS WRITTEN beside the weak-scaling headline, from the same process group -- ONE batch of 4096
+    # pairs per step sharded over the ranks (512 per GPU at N = 8), gathered with the format the probe chose.  Every rank takes
+    # part; rank 0's (long) verification of the headline's tables comes after it, when no collective is left.  A forced one-rank
+    # group runs config 4's per-GPU shard (512 pairs) instead: the step's own overhead.
+    config4 = None
+    if use_dist and not args.no_secondary:
+        total4 = 4096 if world > 1 else 512
+        note(f"config 4 as written: {total4} pairs per step over {world} rank(s) ...")
+        config4 = shard_gather_record(ctx, dev, args, world, rank, total4, gather_wire["format"], gather_wire["comm"],
+                                      steps=150, warm=10, reps=3, note=note, tag="config4_strong")
+
     # In the timed region consecutive steps overlap on two streams, so a kernel's start-to-end time
     # there includes the share of the GPU the other step's kernels took.  Measure the scan kernel's
     # EXCLUSIVE duration too: a few strictly serial launches, same plan, same data, HIP events.
@@ -447,17 +632,19 @@ def main():
             verified["match_tables"] = f"all {B} pairs x 4 problems bit-exact vs the oracle ({len(bufs)} buffer(s))"
         # N > 1 (or no CPU baseline): pair 0 and a spread of pairs of EVERY rank's table as it arrived on rank 0
         # (through the RCCL gather, both buffers)
-        sample = sorted({0, 1, B // 3, B // 2, B - 1}) if cpu_tables is None else [0]
+        sample = frontend.spread_sample(B, 64) if cpu_tables is None else [0]
+        firsts = [frontend.shard_range(args.pairs_per_gpu, world, r_)[0] if args.scaling == "strong" else r_ * B for r_ in range(world)]
         for b_ in bufs:
             full = (pg.gathered(b_) if pg is not None else bm.tables[b_]).cpu().numpy()
             bad = frontend.verify_gathered_tables(full, world if pg is not None else 1, B, n_orb, n_lbd, args.nnr_p,
                                                   args.nnr_l, sample, lambda d1, d2, nnr: O.match(d1, d2, nnr, True)[0],
-                                                  local_stream=stream)
+                                                  local_stream=stream, first_pairs=firsts)
             if bad:
                 raise SystemExit(f"bench output differs from the oracle: buffer {b_}, (rank, pair, problem) = {bad[:4]}")
         if verified["match_tables"] is None:
-            verified["match_tables"] = (f"pairs {sample} x 4 problems of {world if pg is not None else 1} rank(s) bit-exact "
-                                        f"vs the oracle ({len(bufs)} buffer(s))")
+            verified["match_tables"] = (f"{len(sample)} pairs (the shard's ends + four runs spread over it) x 4 problems of EACH of "
+                                        f"{world if pg is not None else 1} rank(s) bit-exact vs the oracle ({len(bufs)} buffer(s)"
+                                        f"{', as gathered on rank 0' if pg is not None else ''})")
         if gates is not None:
             gsample = sorted(set(range(0, B, max(1, B // 64))) | {B - 1})
             ref_tab = cpu_tables if cpu_tables is not None else bm.tables[0].cpu().numpy()
@@ -488,7 +675,7 @@ def main():
                     raise SystemExit(f"bench output differs from the oracle: batch {k_}, {len(bad)} entries, first at pair {bad[0][0]}")
             else:
                 bad = frontend.verify_gathered_tables(got, 1, B, n_orb, n_lbd, args.nnr_p, args.nnr_l,
-                                                      sorted({0, 1, B // 3, B // 2, B - 1}),
+                                                      frontend.spread_sample(B, 64),
                                                       lambda d1, d2, nnr: O.match(d1, d2, nnr, True)[0], local_stream=st_k)
                 if bad:
                     raise SystemExit(f"bench output differs from the oracle: batch {k_}, (rank, pair, problem) = {bad[:4]}")
@@ -630,6 +817,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_secondary and not use_dist:
         note("secondary records ...")
         out["secondary"] = secondary_records(ctx, dev, args, note, cpu_tables if out is not None else None)
+    elif rank == 0 and config4 is not None:
+        out["secondary"] = {"config4_strong": config4}
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
@@ -716,10 +905,9 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
             rec[tag]["cpu_cores"] = usable_cpus()
         note(f"  {tag}: {rec[tag]['value']:.0f} pairs/s, scan {scan_ms:.3f} ms")
 
-    def gather_1rank(tag, n_orb, n_lbd, pairs, steps, warm=2, reps=1):
-        """The strong_512 step as rank 0 of N > 1 runs it: a (forced) one-rank RCCL process group, PipelinedGather around the
-        same matcher -- narrowing copy, gather on the communication stream, widening -- under the next step's scan.  What it
-        shows: the N > 1 step costs what the N = 1 step costs when the link is free (one rank: RCCL copies locally)."""
+    def gather_1rank(tags_wires, pairs, steps, warm=2, reps=1):
+        """Config 4's per-GPU shard as rank 0 of N > 1 runs it: a (forced) one-rank RCCL process group around
+        shard_gather_record -- the very stepping of the N > 1 main loop, the plain step measured beside it in the same run."""
         import torch.distributed as dist
         if dist.is_initialized():
             return
@@ -728,42 +916,14 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
         try:
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         except Exception as e:                         # (no RCCL in this process: the record says so instead of failing the line)
-            rec[tag] = {"skipped": f"RCCL process group unavailable: {type(e).__name__}"}
+            for tag, _, _ in tags_wires:
+                rec[tag] = {"skipped": f"RCCL process group unavailable: {type(e).__name__}"}
             return
         try:
-            st = synth.stereo_stream(pairs, n_orb, n_lbd, seed=synth.SEED0)
-            bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev, n_buffers=2,
-                                             geometry=synth.stereo_geometry(st, first_pair=0), gates=dict(synth.KITTI_GATES))
-            pg = frontend.PipelinedGather(bm, 1, 0, root=0)
-            for k in range(warm):
-                pg.step(k)
-            pg.finish()
-            bm.synchronize_all()
-            dts = []
-            for r_ in range(reps):
-                t0 = time.perf_counter()
-                for k in range(steps):
-                    pg.step(warm + r_ * steps + k)
-                pg.finish()
-                bm.synchronize_all()
-                dts.append(time.perf_counter() - t0)
-            dt = float(np.median(dts))
-            ref, _ = oracle_tables(st, n_orb, n_lbd, args.nnr_p, args.nnr_l)
-            for b_ in range(2):
-                if not np.array_equal(pg.gathered(b_).cpu().numpy(), ref):
-                    raise SystemExit(f"secondary record {tag}: gathered buffer {b_} differs from the oracle")
-            bm.close()
-            rec[tag] = {"metric": f"stereo pairs/sec ({n_orb} ORB + {n_lbd} LBD BF-match)", "value": pairs * steps / dt,
-                        "unit": "stereo pairs/s", "pairs_per_step": pairs, "steps": steps,
-                        "workload": "strong_512 with the N > 1 step around it: one-rank RCCL group, int16 wire format, gather on "
-                                    "the communication stream under the next step's scan, widening to the int32 tables",
-                        "over_strong_512": (pairs * steps / dt) / rec["strong_512"]["value"] if "strong_512" in rec else None,
-                        "stretches_pairs_per_s": [pairs * steps / d for d in dts],
-                        "how": f"median of {reps} stretches of {steps} steps after {warm} warm-up steps",
-                        "verified": f"all {pairs} pairs x 4 problems of both GATHERED buffers bit-exact vs the oracle",
-                        "note": "one rank: what it measures is the step's own overhead (copies, events, the collective's launch), "
-                                "not a link; no 1 -> 8 curve has been measured"}
-            note(f"  {tag}: {rec[tag]['value']:.0f} pairs/s")
+            for tag, wire, comm in tags_wires:
+                rec[tag] = shard_gather_record(ctx, dev, args, 1, 0, pairs, wire, comm, steps, warm, reps, note, tag)
+                if "strong_512" in rec and "value" in rec[tag]:
+                    rec[tag]["over_strong_512"] = rec[tag]["value"] / rec["strong_512"]["value"]
         finally:
             dist.destroy_process_group()
 
@@ -776,7 +936,8 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
     # 512-pair steps settles after a few tens of them)
     pairs_run("strong_512", n_orb, n_lbd, 512, 150, {}, "the per-GPU shard of BASELINE config 4 (4096 pairs over 8 GPUs = 512 per GPU "
               "per step), gate stage included: the single-GPU rate at that step size", with_gates=True, warm=10, reps=3)
-    gather_1rank("strong_512_gather_1rank", n_orb, n_lbd, 512, 150, warm=10, reps=3)
+    gather_1rank((("strong_512_gather_1rank", "int16", "stage"), ("strong_512_gather_1rank_int32", "int32", "stage")),
+                 512, 150, warm=10, reps=3)
     pairs_run("c1_substitute", 800, 100, min(B, 4096), 6, {}, "C1 substitute (SURVEY 8d): KITTI-00-shaped descriptor-level replay, "
               "800 ORB + 100 LBD per image (config_kitti.yaml:62,71), nnr_p 0.75, nnr_l 0.9, mutual; the reference's own "
               "plslam_dataset run cannot be built in this image", nnr_l=0.9, cpu_rate=True)

@@ -41,7 +41,7 @@ extern "C" {
 /* 2: plslam_match_problem grew (keep_prior, reserved: 56 bytes), plslam_lba_plan_iterate's flags became a bit mask, options
  * "mfma_form" 3/4 and "exact_second"; 3 (round 4): "mfma_form" 5 (the default), "post_fuse", plslam_match_plan_key_state.
  * Clients compare plslam_abi_version() with the value they were compiled against. */
-#define PLSLAM_ABI_VERSION 3
+#define PLSLAM_ABI_VERSION 4
 #define PLSLAM_DESC_BYTES 32
 /* largest train set of one directed scan: the composite (distance,index) key keeps 23
  * index bits beside the 9 distance bits */
@@ -413,6 +413,14 @@ typedef struct plslam_stereo_gate_problem {
  * that are being replaced.) */
 int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_stereo_gate_problem* gates,
                                        int32_t ngates);
+
+/* A 16-bit mirror of a plan's match tables (round 5): the wire format of the N > 1 table gather (the per-frame
+ * tables the reference's loop would hand on, app/plslam_dataset.cpp:111-135).  Every problem whose matches_12 lies in
+ * [table32, table32 + n_entries) also stores its entries, as int16, at the same index of table16 (device pointers) -- by the
+ * kernel that decides them, so that no narrowing pass over the table is needed before the gather.  Requires n2 <= 32768 for
+ * those problems and a plan whose tables are written by the finalize kernel (PLSLAM_ENOTSUP for fused and column-split
+ * plans).  table16 = NULL removes the mirror.  Like plslam_match_plan_add_stereo_gates the call waits for the device. */
+int plslam_match_plan_set_wire16(plslam_match_plan* plan, const int32_t* table32, int16_t* table16, size_t n_entries);
 
 /* ---- K3/K4: local-BA residual + Jacobian rows ------------------------------------------- */
 /* Point rows: the per-observation body of MapHandler::levMarquardtOptimizationLBA,

@@ -24,7 +24,7 @@ SCAN_AUTO, SCAN_LANE_PER_QUERY, SCAN_WAVE_PER_QUERY, SCAN_SYMMETRIC, SCAN_MFMA =
 MAX_TRAIN_ROWS = 1 << 23
 
 # every symbol include/plslam_hip.h declares (tests check the .so exports all of them)
-ABI_VERSION = 3          # include/plslam_hip.h: PLSLAM_ABI_VERSION
+ABI_VERSION = 4          # include/plslam_hip.h: PLSLAM_ABI_VERSION
 ABI_SYMBOLS = (
     "plslam_strerror", "plslam_last_error", "plslam_abi_version",
     "plslam_ctx_create", "plslam_ctx_destroy", "plslam_ctx_set_option", "plslam_ctx_get_option",
@@ -44,7 +44,7 @@ ABI_SYMBOLS = (
     "plslam_lbd_binarise", "plslam_lbd_binarise_dev", "plslam_lbd_compute", "plslam_lbd_compute_dev",
     "plslam_median_desc_batched", "plslam_median_desc_batched_dev",
     "plslam_stereo_point_gate", "plslam_stereo_line_gate", "plslam_stereo_point_gate_dev", "plslam_stereo_line_gate_dev",
-    "plslam_match_plan_add_stereo_gates", "plslam_pose_gn_accumulate",
+    "plslam_match_plan_add_stereo_gates", "plslam_match_plan_set_wire16", "plslam_pose_gn_accumulate",
     "plslam_match_pipeline_create", "plslam_match_pipeline_submit", "plslam_match_pipeline_wait",
     "plslam_match_pipeline_destroy", "plslam_pinned_alloc", "plslam_pinned_free",
     "plslam_match_grid", "plslam_grid_plan_create", "plslam_grid_plan_run", "plslam_grid_plan_overflows",
@@ -241,6 +241,7 @@ def load() -> C.CDLL:
     L.plslam_stereo_point_gate_dev.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, vp, vp, vp, vp]
     L.plslam_stereo_line_gate_dev.argtypes = [vp, vp, i32, vp, vp, i32, f64, f64, f64, f64, vp, vp, vp, vp]
     L.plslam_match_plan_add_stereo_gates.argtypes = [vp, C.POINTER(StereoGateProblem), i32]
+    L.plslam_match_plan_set_wire16.argtypes = [vp, vp, vp, C.c_size_t]
     L.plslam_match_pipeline_create.argtypes = [vp, C.c_size_t, C.POINTER(ArenaProblem), i32, C.c_size_t, i32, C.POINTER(vp)]
     L.plslam_match_pipeline_submit.argtypes = [vp, vp, vp, vp]
     L.plslam_match_pipeline_wait.argtypes = [vp]
@@ -902,6 +903,12 @@ class MatchPlan:
                                        float(g.get("stereo_overlap_th", 0.0)), float(g.get("ls_min_disp_ratio", 0.0)),
                                        g["stereo_12"] or None, g["disp"] or None, g.get("n_stereo") or None)
         _check(self._L.plslam_match_plan_add_stereo_gates(self._h, arr, len(gates)), "plslam_match_plan_add_stereo_gates")
+
+    def set_wire16(self, table32: int, table16: int, n_entries: int) -> None:
+        """An int16 mirror of the plan's match tables inside [table32, table32 + n_entries) (device pointers as ints), written by
+        the finalize kernel beside the int32 entries: the wire format of the N > 1 gather.  table16 = 0 removes it."""
+        _check(self._L.plslam_match_plan_set_wire16(self._h, table32 or None, table16 or None, int(n_entries)),
+               "plslam_match_plan_set_wire16")
 
     def set_profiling(self, on: bool) -> None:
         _check(self._L.plslam_match_plan_set_profiling(self._h, int(bool(on))),

@@ -1064,6 +1064,36 @@ int plslam_match_plan_add_stereo_gates(plslam_match_plan* plan, const plslam_ste
     return PLSLAM_OK;
 }
 
+int plslam_match_plan_set_wire16(plslam_match_plan* plan, const int32_t* table32, int16_t* table16, size_t n_entries)
+{
+    PLSLAM_REQUIRE(plan != nullptr && (table16 == nullptr || table32 != nullptr), PLSLAM_EINVAL);
+    DeviceGuard g(plan->ctx->device);
+    // only the finalize kernel (k_finalize / k_post_fused: finalize_row) stores the mirror: a fused plan decides its entries in
+    // the scan kernel, a column-split plan in k_split_post
+    if (table16 && (plan->fused || plan->col_split)) {
+        set_last_error("plslam_match_plan_set_wire16: this plan's tables are not written by the finalize kernel");
+        return PLSLAM_ENOTSUP;
+    }
+    std::vector<int16_t*> mirror(plan->h_probs.size(), nullptr);
+    if (table16)
+        for (size_t k = 0; k < plan->h_probs.size(); ++k) {
+            const ProblemDesc& pd = plan->h_probs[k];
+            if (pd.n1 <= 0 || pd.matches_12 < table32 || pd.matches_12 >= table32 + n_entries) continue;
+            PLSLAM_REQUIRE((size_t)(pd.matches_12 - table32) + (size_t)pd.n1 <= n_entries, PLSLAM_EINVAL);
+            PLSLAM_REQUIRE(pd.n2 <= 32768, PLSLAM_EINVAL);
+            mirror[k] = table16 + (pd.matches_12 - table32);
+        }
+    PLSLAM_HIP_CHECK(hipDeviceSynchronize());               // (as add_stereo_gates: rare, so it waits for whatever is in flight)
+    if (plan->graph_exec) plan->drop_graph();
+    for (size_t k = 0; k < plan->h_probs.size(); ++k) plan->h_probs[k].matches_16 = mirror[k];
+    if (!plan->h_probs.empty()) {
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(plan->d_probs, plan->h_probs.data(), plan->h_probs.size() * sizeof(ProblemDesc),
+                                        plan->probs_in_place ? hipMemcpyHostToHost : hipMemcpyHostToDevice, plan->ctx->stream));
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(plan->ctx->stream));
+    }
+    return PLSLAM_OK;
+}
+
 int plslam_match_plan_run(plslam_match_plan* plan, void* stream)
 {
     PLSLAM_REQUIRE(plan != nullptr, PLSLAM_EINVAL);

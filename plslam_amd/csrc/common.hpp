@@ -223,6 +223,8 @@ struct ProblemDesc {    // one StVO::match problem = scan12 (+ scan21 when mutua
     // K1h / K1i plans with the fused stage behind the scan (k_post_fused): the problem's column partials -- [row block][slot]
     // words, SymDesc::part21 -- or nullptr
     const uint32_t* part21;
+    // plslam_match_plan_set_wire16: the int16 mirror of matches_12 (the gather's wire format), or nullptr
+    int16_t* matches_16;
 };
 
 struct BlockDesc {      // one workgroup's slice of a scan / problem

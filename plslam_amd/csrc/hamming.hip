@@ -652,6 +652,8 @@ __device__ __forceinline__ void finalize_row(const ProblemDesc& p, const int i1,
     if (i1 < p.n1) {
         if (PLSLAM_NT_FINALIZE) __builtin_nontemporal_store(m, g_(p.matches_12) + i1);
         else g_(p.matches_12)[i1] = m;
+        // the gather's wire table (plslam_match_plan_set_wire16): the same entry as int16 (m < n2 <= 32768)
+        if (p.matches_16) g_(p.matches_16)[i1] = (int16_t)m;
     }
     if (p.n_matches) {
         // the reference's arithmetic: +1 per row the ratio test accepts, -1 per entry the consistency loop clears (equal

@@ -135,6 +135,20 @@ class StereoBatchMatcher:
         # k+1 fill the slots the last wave of step k's scan leaves idle.  A 512-pair step is 9.3 rounds of the chip's 768
         # workgroup slots: its last round is a third full, and on one stream the next scan starts only when it is over.
         self.scan_streams = [self.streams[0]] + [torch.cuda.Stream(device=dev) for _ in range(max(1, scan_streams) - 1)]
+        self.wire16 = None                 # enable_wire16(): per-buffer int16 mirrors of the tables, written by the finalize kernel
+
+    def enable_wire16(self, on: bool = True):
+        """int16 mirrors of the match tables (the N > 1 gather's wire format), stored by the finalize kernel beside the int32
+        entries (plslam_match_plan_set_wire16): no narrowing pass between the step and its gather."""
+        torch = self.torch
+        if on and self.wire16 is None:
+            self.wire16 = [torch.full((self.B, self.stride), -2, dtype=torch.int16, device=self.dev) for _ in self.tables]
+            for plan, t32, t16 in zip(self.plans, self.tables, self.wire16):
+                plan.set_wire16(t32.data_ptr(), t16.data_ptr(), t32.numel())
+        elif not on and self.wire16 is not None:
+            for plan, t32 in zip(self.plans, self.tables):
+                plan.set_wire16(t32.data_ptr(), 0, t32.numel())
+            self.wire16 = None
 
     def run_overlapped(self, k: int):
         """Step k of a stream of independent batches into buffer k % n_buffers: every scan on one HIP stream, the
@@ -251,7 +265,9 @@ class TableGatherPipeline:
         self.cuda = self.dev.type == "cuda"
         self.compact = (max_index <= 32767) if compact is None else bool(compact)
         self.wire = torch.int16 if self.compact else torch.int32
-        self.send = [torch.empty((rows, stride), dtype=self.wire, device=self.dev) for _ in range(nbuf)]
+        # int16 wire: the narrowed copy of table b (unless the producer writes one itself: submit(..., wire16=...)).  int32 wire:
+        # the table itself travels -- no send buffer, no copy (round 4 copied 55.7 MB per 4096-pair step for nothing)
+        self.send = [torch.empty((rows, stride), dtype=self.wire, device=self.dev) for _ in range(nbuf)] if self.compact else None
         self.recv = [torch.empty((world, rows, stride), dtype=self.wire, device=self.dev)
                      for _ in range(nbuf)] if rank == root else [None] * nbuf
         # root, compact wire format, GPU: the int32 tables of the C ABI are rebuilt on the communication stream right behind each
@@ -275,21 +291,34 @@ class TableGatherPipeline:
             self.works[b].wait()
             self.works[b] = None
 
-    def submit(self, b: int, table, compute_stream=None):
-        """Narrow table (rows, stride) int32 into send buffer b and start its gather.  CUDA: `table` was produced on
-        `compute_stream`; the narrowing is enqueued there, the gather on the communication stream behind an event."""
+    def submit(self, b: int, table, compute_stream=None, wire16=None):
+        """Start the gather of table (rows, stride) int32 of buffer b.  int32 wire: the table itself is the send buffer (it is
+        not overwritten before before_overwrite(b) has seen this gather's end).  int16 wire: `wire16` -- a (rows, stride) int16
+        table the producer wrote beside the int32 one (plan.set_wire16: the finalize kernel stores both) -- travels as it is;
+        without it the table is narrowed into send buffer b first.  CUDA: `table` / `wire16` were produced on `compute_stream`;
+        the narrowing (if any) is enqueued there, the gather on the communication stream behind an event."""
         import torch.distributed as dist
         torch = self.torch
+        narrow = False
+        if self.compact and wire16 is not None:
+            assert wire16.dtype == torch.int16 and tuple(wire16.shape) == (self.rows, self.stride) and wire16.is_contiguous()
+            src = wire16
+        elif self.compact:
+            src, narrow = self.send[b], True
+        else:
+            assert table.dtype == torch.int32 and table.is_contiguous()
+            src = table
         if self.cuda:
             st = compute_stream or torch.cuda.current_stream(self.dev)
             with torch.cuda.stream(st):
-                self.send[b].copy_(table)                  # int32 -> wire type right behind the producer
+                if narrow:
+                    src.copy_(table)                       # int32 -> int16 right behind the producer
                 ev = torch.cuda.Event()
                 ev.record(st)
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ev)
                 glist = list(self.recv[b].view(torch.uint8).unbind(0)) if self.rank == self.root else None
-                w = dist.gather(self.send[b].view(torch.uint8), gather_list=glist, dst=self.root, group=self.group,
+                w = dist.gather(src.view(torch.uint8), gather_list=glist, dst=self.root, group=self.group,
                                 async_op=True)
                 w.wait()                                   # stream-level wait (comm stream), not a host block
                 if self.wide is not None:
@@ -298,9 +327,10 @@ class TableGatherPipeline:
                 done.record(self.comm)
             self.works[b], self.done_ev[b] = w, done
         else:
-            self.send[b].copy_(table)
+            if narrow:
+                src.copy_(table)
             glist = list(self.recv[b].view(torch.uint8).unbind(0)) if self.rank == self.root else None
-            self.works[b] = dist.gather(self.send[b].view(torch.uint8), gather_list=glist, dst=self.root,
+            self.works[b] = dist.gather(src.view(torch.uint8), gather_list=glist, dst=self.root,
                                         group=self.group, async_op=True)
         return b
 
@@ -330,32 +360,53 @@ class PipelinedGather:
     next step computes: StereoBatchMatcher (compute) + TableGatherPipeline (wire format, buffers, ordering)."""
 
     def __init__(self, bm: StereoBatchMatcher, world: int, rank: int, root: int = 0, group=None, compact=None,
-                 comm_on_stage_stream: bool = True):
-        """comm_on_stage_stream (default): the wait for the collective and the root's widening go on the matcher's STAGE stream,
-        behind the stages and the narrowing copy of the step -- no third stream.  Measured on a one-rank RCCL group
+                 comm_on_stage_stream=None, wire16_from_kernel: bool = True):
+        """comm_on_stage_stream: the wait for the collective and the root's widening go on the matcher's STAGE stream, behind the
+        stages (and the narrowing copy, if any) of the step -- no third stream.  Measured on a ONE-rank RCCL group
         (tools/gather_step_probe.py, 512-pair steps): the step then costs what the plain step costs (0.344-0.349 against
         0.336-0.366 ms) whatever streams were created before, while a communication stream of its own -- from torch's
         high-priority pool, whose streams share a few hardware queues -- landed on 0.345-0.379 ms or, deterministically for
-        some creation orders, on 0.45 ms (the gather queued behind other work of its hardware queue).  The collective itself
-        runs on the process group's internal stream either way; a HIGH-priority process-group stream (ProcessGroupNCCL.Options.
-        is_high_priority_stream) made every step slower, the plain one included (0.44-0.59 ms): do not use it.  What the shared
-        stream costs: the next step's stages queue behind this step's gather -- harmless while a gather is shorter than a
-        step minus its stages (7 x 3.5 MB over seven links at 512 pairs per rank: ~0.1 of 0.33 ms)."""
+        some creation orders, on 0.45 ms.  A one-rank group only copies locally: with real links the collective's time would
+        land on the stage stream's critical path (the next step's merge / finalize queue behind this step's gather), so the
+        default (None) is the stage stream for world == 1 and a communication stream of its own for world > 1, where nothing has
+        been measured; bench.py's probe times both.  The collective itself runs on the process group's internal stream either
+        way; a HIGH-priority process-group stream made every step slower (0.44-0.59 ms): do not use it.
+        wire16_from_kernel: with the int16 wire format the finalize kernel writes the int16 table itself
+        (StereoBatchMatcher.enable_wire16) instead of a narrowing copy behind it."""
+        import time
+        self._clock = time.perf_counter
         self.bm = bm
+        if comm_on_stage_stream is None:
+            comm_on_stage_stream = world == 1
+        self.comm_on_stage_stream = bool(comm_on_stage_stream)
         self.pipe = TableGatherPipeline(bm.B, bm.stride, max(bm.n_orb, bm.n_lbd), world, rank, root,
                                         nbuf=len(bm.tables), device=bm.dev, group=group, compact=compact,
                                         comm_stream=bm.streams[min(1, len(bm.streams) - 1)] if comm_on_stage_stream else None)
+        self.kernel_wire16 = bool(self.pipe.compact and wire16_from_kernel and self.pipe.cuda)
+        if self.kernel_wire16:
+            bm.enable_wire16(True)
+        self.host_s, self.host_n = 0.0, 0          # host time spent inside step() (enqueueing only: nothing in it waits for the GPU)
 
     def step(self, k: int):
         """Compute step k into buffer k % nbuf and start gathering it."""
+        t0 = self._clock()
         b = k % self.pipe.nbuf
         # as run_overlapped(): every scan on streams[0], the stages behind it -- which write table b -- on the
-        # high-priority streams[1]; that stream therefore waits for the previous gather of buffer b, and the narrowing
-        # copy + the gather's event go behind the stages on it
+        # high-priority streams[1]; that stream therefore waits for the previous gather of buffer b, and the gather's event
+        # (behind the narrowing copy, when there is one) goes behind the stages on it
         scan, post = self.bm.scan_stream_of(k), self.bm.streams[min(1, len(self.bm.streams) - 1)]
         self.pipe.before_overwrite(b, post)
         self.bm.plans[b].run_split(scan.cuda_stream, post.cuda_stream)
-        return self.pipe.submit(b, self.bm.tables[b], post)
+        r = self.pipe.submit(b, self.bm.tables[b], post, wire16=self.bm.wire16[b] if self.kernel_wire16 else None)
+        self.host_s += self._clock() - t0
+        self.host_n += 1
+        return r
+
+    def host_ms_per_step(self, reset: bool = True):
+        v = 1e3 * self.host_s / max(self.host_n, 1)
+        if reset:
+            self.host_s, self.host_n = 0.0, 0
+        return v
 
     def finish(self):
         self.pipe.finish()
@@ -363,25 +414,62 @@ class PipelinedGather:
     def gathered(self, b: int):
         return self.pipe.gathered(b)
 
+    def close(self):
+        """Detach from the matcher (the int16 mirrors go; the matcher can be wrapped again with another wire format)."""
+        if self.kernel_wire16:
+            self.pipe.finish()
+            self.bm.enable_wire16(False)
+            self.kernel_wire16 = False
+
+
+def spread_sample(B: int, n: int = 64):
+    """>= min(n, B) pair indices of a B-pair shard for the root-side check: the shard's ends (0, 1, B - 2, B - 1: where the halo and
+    the shard boundary are) and contiguous runs in between (a run costs one regeneration of its rank's inputs)."""
+    if B <= n:
+        return list(range(B))
+    runs, per = 4, (n - 4) // 4
+    idx = {0, 1, B - 2, B - 1}
+    for q in range(runs):
+        lo = min(max(2, (q * B) // runs + (B // runs - per) // 2), B - 2 - per)
+        idx.update(range(lo, lo + per))
+    i = 2
+    while len(idx) < n:                     # (overlapping runs of a short shard)
+        idx.add(i)
+        i += 1
+    return sorted(idx)
+
 
 def verify_gathered_tables(full, world: int, B: int, n_orb: int, n_lbd: int, nnr_p: float, nnr_l: float, sample,
-                           match_fn, seed=None, local_stream=None):
+                           match_fn, seed=None, local_stream=None, first_pairs=None):
     """Root-side check of a gathered (world * B, stride) table: pairs `sample` of EVERY rank against `match_fn(d1, d2,
-    nnr) -> matches_12` (the caller's checker).  Rank r's inputs are regenerated from (seed, first_pair = r * B) -- the weak-scaling
-    shard rule of bench.py -- except rank 0's, which may be passed in.  Returns the list of mismatches (rank, pair,
-    problem); empty = verified."""
+    nnr) -> matches_12` (the caller's checker).  Rank r's inputs are regenerated from (seed, first_pairs[r]; default r * B:
+    the weak-scaling shard rule of bench.py) -- except rank 0's, which may be passed in.  Contiguous runs of the sample are
+    regenerated together (the synthetic chain restarts every 64 frames: a run costs at most 64 frames more than its length).
+    Returns the list of mismatches (rank, pair, problem); empty = verified."""
     from . import synth
     sl = table_slices(n_orb, n_lbd)
+    sample = sorted(set(int(i) for i in sample))
+    runs = []
+    for i_ in sample:
+        if runs and i_ == runs[-1][1]:
+            runs[-1][1] = i_ + 1
+        else:
+            runs.append([i_, i_ + 1])
     bad = []
     for r_ in range(world):
-        for i_ in sample:
-            st = local_stream if (r_ == 0 and local_stream is not None) else \
-                synth.stereo_stream(i_ + 1, n_orb, n_lbd, seed=synth.SEED0 if seed is None else seed, first_pair=r_ * B)
-            tab = full[r_ * B + i_]
-            for name, d1, d2 in pair_problems(st["orb_l"], st["orb_r"], st["lbd_l"], st["lbd_r"], i_):
-                em = match_fn(d1, d2, nnr_p if name.startswith("orb") else nnr_l)
-                if not np.array_equal(np.asarray(tab[sl[name]]), em):
-                    bad.append((r_, i_, name))
+        first = r_ * B if first_pairs is None else first_pairs[r_]
+        for lo, hi in runs:
+            if r_ == 0 and local_stream is not None:
+                st, off = local_stream, 0
+            else:
+                st = synth.stereo_stream(hi - lo, n_orb, n_lbd, seed=synth.SEED0 if seed is None else seed, first_pair=first + lo)
+                off = lo
+            for i_ in range(lo, hi):
+                tab = full[r_ * B + i_]
+                for name, d1, d2 in pair_problems(st["orb_l"], st["orb_r"], st["lbd_l"], st["lbd_r"], i_ - off):
+                    em = match_fn(d1, d2, nnr_p if name.startswith("orb") else nnr_l)
+                    if not np.array_equal(np.asarray(tab[sl[name]]), em):
+                        bad.append((r_, i_, name))
     return bad
 
 

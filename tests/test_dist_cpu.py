@@ -200,3 +200,42 @@ def test_gloo_world2_strong_scaling_shards(tmp_path):
     bad = frontend.verify_gathered_tables(got, 2, total // 2, N_ORB, N_LBD, 0.75, 0.9, [0, 1, 2],
                                           lambda d1, d2, nnr: O.match(d1, d2, nnr, True)[0])
     assert [b[:2] for b in bad] == [(1, 0)]
+
+
+# ---- bench.py launches itself at N > 1 (`python bench.py --gpus 8` exited with a usage message) ----------------
+def test_bench_launches_itself_at_two_ranks():
+    """`python bench.py --gpus 2 ...` with no launcher around it re-executes under torch.distributed.run; --launch-check
+    stops after the rendezvous (gloo: no GPU here) -- one JSON line on stdout, from rank 0, the arguments intact."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "7", "--launch-check"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d == {"launch_check": True, "world_size": 2, "rank_sum": 3, "argv": ["--gpus", "2", "--steps", "7", "--launch-check"]}
+    assert "torch.distributed.run" in res.stderr and "--nproc-per-node=2" in res.stderr
+
+
+def test_root_side_check_of_strong_scaling_shards():
+    """verify_gathered_tables with per-rank first pairs (config 4's contiguous shards) and a sample of runs: clean tables pass,
+    one wrong entry in the second rank's shard is found and named."""
+    from oracle import oracle as O
+    world, total = 2, 12
+    full = _oracle_tables(synth.stereo_stream(total, N_ORB, N_LBD, seed=synth.SEED0, first_pair=0))
+    # (_oracle_tables uses nnr 0.75 / 0.9)
+    per = total // world
+    firsts = [frontend.shard_range(total, world, r)[0] for r in range(world)]
+    sample = frontend.spread_sample(per, 4)
+    assert sample == sorted(set(sample)) and {0, per - 1} <= set(sample) and max(sample) < per
+    fn = lambda d1, d2, nnr: O.match(d1, d2, nnr, True)[0]     # noqa: E731
+    assert frontend.verify_gathered_tables(full, world, per, N_ORB, N_LBD, 0.75, 0.9, sample, fn, first_pairs=firsts) == []
+    bad = full.copy()
+    bad[per + sample[-1], 3] += 1
+    got = frontend.verify_gathered_tables(bad, world, per, N_ORB, N_LBD, 0.75, 0.9, sample, fn, first_pairs=firsts)
+    assert got == [(1, sample[-1], "orb_lr")]
+    assert len(frontend.spread_sample(4096, 64)) == 64 and len(frontend.spread_sample(40, 64)) == 40

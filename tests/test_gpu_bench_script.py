@@ -53,8 +53,12 @@ def test_bench_single_gpu_line():
     assert sec["c1_substitute"]["value"] > 0 and "800 ORB + 100 LBD" in sec["c1_substitute"]["metric"]
     assert all("all " in sec[k]["verified"] for k in ("strong_512", "c1_substitute", "c5"))
     # the N > 1 step around the strong_512 shard, through a forced one-rank RCCL group, every gathered pair verified
-    g1 = sec["strong_512_gather_1rank"]
-    assert "skipped" in g1 or (g1["value"] > 0 and "GATHERED" in g1["verified"] and g1["over_strong_512"] > 0)
+    for tag, wire in (("strong_512_gather_1rank", "int16"), ("strong_512_gather_1rank_int32", "int32")):
+        g1 = sec[tag]
+        assert "skipped" in g1 or (g1["value"] > 0 and "GATHERED" in g1["verified"] and g1["over_strong_512"] > 0 and
+                                   g1["gather"]["format"] == wire and g1["plain_step_same_run"]["value"] > 0 and
+                                   0 < g1["over_plain_step_same_run"] < 1.5 and g1["host_ms_per_step"] > 0)
+    assert sec["strong_512_gather_1rank"].get("gather", {}).get("int16_written_by", "k_finalize") == "k_finalize"
     assert all("binarise_GBps" not in v for k, v in sec["lbd"].items() if isinstance(v, dict))
     assert d["dtype_note"].startswith("exact") or "exact" in d["dtype_note"]
     assert sec["grid"]["plan_1024_frame_pairs"]["problems"] == 2048 and len([k for k in sec["drivers"] if k != "workload"]) == 8
@@ -80,14 +84,31 @@ def test_bench_matrix_core_branch_of_the_line():
     assert len(d["config"]["kernel_source_hash"]) == 16
     if d["valu_executed"] is not None:
         assert 0 < d["valu_executed"]["frac_of_measured_ceiling"] <= 1.0
-    assert "pairs [0, 1," in d["verified"]["match_tables"]
+    assert d["verified"]["match_tables"].startswith("64 pairs (the shard's ends")
 
 
 def test_bench_forced_rccl_group_one_rank():
-    d = _run(["--no-cpu-baseline", "--force-dist"], env={"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29611"})
+    """`python bench.py --gpus 1 --force-dist` with no launcher around it: the script launches itself under
+    torch.distributed.run (the road `python bench.py --gpus 8` takes), rank 0 prints the one line; the N > 1 stepping, the
+    gather probe, the 64-pair check of the gathered tables and the config-4-as-written record all run on the one-rank group."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--pairs-per-gpu", "24",
+           "--n-orb", "192", "--n-lbd", "40", "--no-cpu-baseline", "--force-dist"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert res.returncode == 0, res.stderr[-3000:]
+    assert "self-launch" in res.stderr
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
     assert REQUIRED <= set(d) and d["value"] > 0
     assert "RCCL gather" in d["config"]["parallelism"]
     assert d["config"]["rccl_ranks_seen"] == {"world_size": 1, "distinct_devices": 1}
+    gw = d["config"]["gather_wire"]
+    assert gw["format"] in ("int16", "int32") and gw["comm"] in ("stage", "own") and len(gw["probe_s_per_step"]) == 4
+    assert d["verified"]["match_tables"].startswith("24 pairs") and "as gathered on rank 0" in d["verified"]["match_tables"]
+    c4 = d["secondary"]["config4_strong"]
+    assert c4["value"] > 0 and c4["scaling"] == "strong" and c4["pairs_per_gpu_per_step"] == 512 and c4["n_gpus"] == 1
+    assert c4["plain_step_same_run"]["value"] > 0 and c4["host_ms_per_step"] > 0 and "GATHERED" in c4["verified"]
 
 
 def test_bench_strong_scaling_flag_at_one_rank():

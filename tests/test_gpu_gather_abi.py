@@ -52,3 +52,59 @@ def test_gather_one_rank_roundtrip(ctx):
     finally:
         rccl.ncclCommDestroy.argtypes = [C.c_void_p]
         rccl.ncclCommDestroy(comm)
+
+
+# ---- plslam_match_plan_set_wire16: the int16 mirror of a plan's match tables (the gather's wire format) -------------------
+@pytest.mark.parametrize("pairs,n_orb,n_lbd", [(3, 96, 20), (40, 512, 64)])      # the latency kernel's plan / the matrix-core scan's
+def test_finalize_kernel_writes_the_int16_wire_table(ctx, oracle, pairs, n_orb, n_lbd):
+    import torch
+    from plslam_amd import frontend, synth
+    st = synth.stereo_stream(pairs, n_orb, n_lbd, seed=77)
+    bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=0.75, nnr_l=0.9, mutual=True, n_buffers=2,
+                                     geometry=synth.stereo_geometry(st), gates=dict(synth.KITTI_GATES))
+    try:
+        bm.enable_wire16(True)
+        for k in range(4):
+            bm.run_overlapped(k)
+        bm.synchronize_all()
+        sl = frontend.table_slices(n_orb, n_lbd)
+        for b in range(2):
+            t32 = bm.tables[b].cpu().numpy()
+            t16 = bm.wire16[b].cpu().numpy()
+            assert t16.dtype == np.int16 and np.array_equal(t16.astype(np.int32), t32)          # the same entries, narrowed
+            for i in (0, pairs - 1):
+                for name, d1, d2 in frontend.pair_problems(st["orb_l"], st["orb_r"], st["lbd_l"], st["lbd_r"], i):
+                    em = oracle.match(d1, d2, 0.75 if name.startswith("orb") else 0.9, True)[0]
+                    assert np.array_equal(t32[i, sl[name]], em)
+        # removing the mirror: the int16 tables are no longer written
+        keep = [w.clone() for w in bm.wire16]
+        w16 = bm.wire16
+        for w in w16:
+            w.fill_(-5)
+        bm.enable_wire16(False)
+        bm.run_overlapped(0)
+        bm.synchronize_all()
+        assert all(bool((w == -5).all()) for w in w16) and keep[0].shape == w16[0].shape
+    finally:
+        bm.close()
+
+
+def test_wire16_is_refused_where_another_kernel_writes_the_table(ctx):
+    """A column-split plan (a few LARGE problems: k_split_post decides the entries) has no finalize kernel to mirror from."""
+    import torch
+    import plslam_amd
+    from plslam_amd import synth
+    r = np.random.Generator(np.random.PCG64(3))
+    a = torch.from_numpy(synth.random_desc(r, 6000)).cuda()
+    b = torch.from_numpy(synth.random_desc(r, 1500)).cuda()
+    m = torch.empty(6000, dtype=torch.int32, device="cuda")
+    w = torch.empty(6000, dtype=torch.int16, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    plan = ctx.plan([(a.data_ptr(), 6000, b.data_ptr(), 1500, 0.75, True, m.data_ptr(), cnt.data_ptr())])
+    try:
+        if plan.info()["scan_variant"] == plslam_amd.SCAN_MFMA:
+            with pytest.raises(Exception):
+                plan.set_wire16(m.data_ptr(), w.data_ptr(), 6000)
+        plan.set_wire16(m.data_ptr(), 0, 6000)              # removing a mirror that is not there is fine
+    finally:
+        plan.close()
