@@ -237,7 +237,7 @@ def gather_probe(bm, world, rank, dev, cands, note):
     return out
 
 
-def shard_gather_record(ctx, dev, args, world, rank, pairs_total, wire, comm, steps, warm, reps, note, tag):
+def shard_gather_record(ctx, dev, args, world, rank, pairs_total, wire, comm, steps, warm, reps, note, tag, streams=None):
     """ONE batch of `pairs_total` stereo pairs per step, sharded contiguously over the ranks (BASELINE config 4 as written:
     4096 pairs -> 512 per GPU at N = 8), stepped exactly as the headline's N > 1 loop steps (PipelinedGather.step + one event per
     step on the stage stream) -- and, in the same process on the same matcher, the plain step without the gather.  Every rank
@@ -252,8 +252,13 @@ def shard_gather_record(ctx, dev, args, world, rank, pairs_total, wire, comm, st
     if pairs_total % world:
         return {"skipped": f"{pairs_total} pairs do not divide over {world} ranks"}
     st = synth.stereo_stream(Bs, n_orb, n_lbd, seed=synth.SEED0, first_pair=lo)
+    # streams: the [scan stream, stage stream] pair of the headline's matcher.  HIP deals streams to a few hardware queues in
+    # creation order, and a scan stream that lands on its stage stream's queue serialises the two (round 4: 0.84 of the plain
+    # step "for some creation orders"; round 5's first run of this record with streams of its own: stretches of 1.48 / 1.13 /
+    # 1.25 M pairs/s) -- the pair the headline ran on is known to be a good one.
     bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev, n_buffers=2,
-                                     geometry=synth.stereo_geometry(st, first_pair=lo), gates=dict(synth.KITTI_GATES))
+                                     geometry=synth.stereo_geometry(st, first_pair=lo), gates=dict(synth.KITTI_GATES),
+                                     streams=streams)
     stage = bm.stage_stream
 
     def maxed(dt):
@@ -579,7 +584,7 @@ def main():
         total4 = 4096 if world > 1 else 512
         note(f"config 4 as written: {total4} pairs per step over {world} rank(s) ...")
         config4 = shard_gather_record(ctx, dev, args, world, rank, total4, gather_wire["format"], gather_wire["comm"],
-                                      steps=150, warm=10, reps=3, note=note, tag="config4_strong")
+                                      steps=150, warm=10, reps=3, note=note, tag="config4_strong", streams=bm.streams)
 
     # In the timed region consecutive steps overlap on two streams, so a kernel's start-to-end time
     # there includes the share of the GPU the other step's kernels took.  Measure the scan kernel's
@@ -816,7 +821,7 @@ def main():
     # ---- secondary records (N = 1): the other single-GPU configurations, timed by this same command ---------------------
     if rank == 0 and world == 1 and not args.no_secondary and not use_dist:
         note("secondary records ...")
-        out["secondary"] = secondary_records(ctx, dev, args, note, cpu_tables if out is not None else None)
+        out["secondary"] = secondary_records(ctx, dev, args, note, cpu_tables if out is not None else None, streams=bm.streams)
     elif rank == 0 and config4 is not None:
         out["secondary"] = {"config4_strong": config4}
     if rank == 0:
@@ -827,7 +832,7 @@ def main():
         dist.destroy_process_group()
 
 
-def secondary_records(ctx, dev, args, note, main_tables=None):
+def secondary_records(ctx, dev, args, note, main_tables=None, streams=None):
     """Driver-timed numbers for the other BASELINE configurations and kernel forms (they existed only as
     builder-run files).  Each is a short run: a few hundred ms of GPU time."""
     import torch
@@ -880,7 +885,7 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
             st = synth.stereo_stream(pairs, n_orb, n_lbd, seed=synth.SEED0)
             geo_ = synth.stereo_geometry(st, first_pair=0) if with_gates else None
             bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=args.nnr_p, nnr_l=nnr_l, mutual=True, device=dev, n_buffers=2,
-                                             geometry=geo_, gates=dict(synth.KITTI_GATES) if with_gates else None)
+                                             geometry=geo_, gates=dict(synth.KITTI_GATES) if with_gates else None, streams=streams)
             info = bm.plan.info()
             dt, scan_ms, post_ms = timed(bm, steps, warm, reps)
             stretches = [pairs * x for x in timed.stretches]
@@ -921,7 +926,7 @@ def secondary_records(ctx, dev, args, note, main_tables=None):
             return
         try:
             for tag, wire, comm in tags_wires:
-                rec[tag] = shard_gather_record(ctx, dev, args, 1, 0, pairs, wire, comm, steps, warm, reps, note, tag)
+                rec[tag] = shard_gather_record(ctx, dev, args, 1, 0, pairs, wire, comm, steps, warm, reps, note, tag, streams=streams)
                 if "strong_512" in rec and "value" in rec[tag]:
                     rec[tag]["over_strong_512"] = rec[tag]["value"] / rec["strong_512"]["value"]
         finally:

@@ -55,6 +55,20 @@
 #define PLSLAM_MI_X 0
 #endif
 #define PLSLAM_MI_LOOK(MT) (PLSLAM_MI_F16 && ((MT) == 1 ? PLSLAM_MI_ROWLOOK >= 1 : PLSLAM_MI_ROWLOOK >= 2))
+// PLSLAM_MI_R5 (round 5; bit set, default all): the per-ITEM work of a wave -- by the counters 39 % of its VALU instructions
+// and by the knock-out builds half of the launch -- made leaner.  Same keys, same tables.
+//   1  row finish: the 32 classes of a row are merged as "best two FIRST entries + the best class's second entry" (3 VALU per
+//      class instead of 6)
+//   2  row finish: the winner cell's 16 columns are re-evaluated from ONE base address with immediate offsets and no per-
+//      candidate validity: a cell that the end of b cuts is read from 16 columns further down instead -- the extra columns are
+//      real columns of earlier cells, which can neither beat nor tie the winner (see finish_rows)
+//   4  group pushes: the first push of a window only writes (nothing is parked yet); the tag replacement is one v_and_or; the
+//      window's last push stays in registers and is consumed by the row finish directly
+//   8  expansion: the validity mask of a ragged group's tile only from the first tile some class has no column for
+// 0 = round 4's code (A/B builds: tools/build_exp.py hamming_mfma_i.hip r4:-DPLSLAM_MI_R5=0)
+#ifndef PLSLAM_MI_R5
+#define PLSLAM_MI_R5 15
+#endif
 
 namespace plslam {
 
@@ -81,6 +95,10 @@ constexpr uint32_t MI_NONE32 = MI_NONE16 * 0x00010001u;
 #define PLSLAM_MI_RESCAN_BATCH 4
 #endif
 constexpr int MI_RESCAN_BATCH = PLSLAM_MI_RESCAN_BATCH;
+#ifndef PLSLAM_MI_RESCAN_BATCH16
+#define PLSLAM_MI_RESCAN_BATCH16 8
+#endif
+constexpr int MI_RESCAN_BATCH16 = PLSLAM_MI_RESCAN_BATCH16;      // the unguarded rescan's rows in flight (8 VGPRs each)
 __device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c)
 {
     uint32_t r;
@@ -165,6 +183,9 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         return rag_s == 0 ? 0 : (v < 0 ? 0 : (v > rag_s ? rag_s : v));
     };
     const int lim_part = rag_s ? rest % rag_s : 0;                 // the one class that is cut (wave-uniform): its lim, 0 = none is
+    // the first tile of the ragged group in which some class has no column (the classes' column counts fall with the class
+    // number: the last class's count); rag_s when every class is full
+    const int mask_from = (PLSLAM_MI_R5 & 8) ? (rest - 31 * rag_s < 0 ? 0 : rest - 31 * rag_s) : 0;
 
     const bool block_ragged = bd.row0 + 256 > n1;  // workgroup-uniform: some groups of 16 rows may hold no row of a at all
     const bool wide_part = !DIRECTED && (sd.flags & 1);
@@ -217,7 +238,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     auto expand_store = [&](uint32_t raw, int buf, int tn, bool full = false) __attribute__((always_inline)) {
         uint8_t* dst = btile + buf * MH_TILE_BYTES + ej * MH_ROW_STRIDE + ewd4 * 4;
         i32x4 v = expand_dword_fp4<false, MI_MAG>(raw);
-        if (!full && tn >= nfull) {                                 // wave-uniform
+        if (!full && tn >= nfull && (tn & 15) >= mask_from) {       // wave-uniform
             const int vm = (int)(__umul24((uint32_t)rag_s, (uint32_t)ej) + (uint32_t)(tn & 15)) < rest ? -1 : 0;
             v &= i32x4{vm, vm, vm, vm};
         }
@@ -328,13 +349,44 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             else *dst = e;
         }
     };
-    // a row group is over: its minima get the group number and go into the parked sorted pairs; the minima restart
-    auto push_groups = [&](int t) __attribute__((always_inline)) {
+    // a row group is over: its minima get the group number and go into the parked sorted pairs; the minima restart.
+    // FINAL (the window's last, possibly partial, group): the merged pairs stay in registers (rb) for the row finish.
+    auto push_groups = [&](int t, auto final_tag, u32x2_t* rb) __attribute__((always_inline)) {
+        constexpr bool FINAL = decltype(final_tag)::value;
+        const uint32_t grp = (uint32_t)(((t - wt0) >> 4) & 3);
 #if PLSLAM_MI_UNSCALED
-        const uint32_t gtag = (uint32_t)(((t - wt0) >> 4) & 3) * 0x00010001u;        // the group number takes the tag's five bits
+        const uint32_t gtag = grp * 0x00010001u;        // the group number takes the tag's five bits
 #else
-        const uint32_t gtag = (uint32_t)(((((t - wt0) >> 4) ^ w) & 3) << 5) * 0x00010001u;   // ... the tag's wave bits (an XOR)
+        const uint32_t gtag = (uint32_t)(((grp ^ (uint32_t)w) & 3) << 5) * 0x00010001u;   // ... the tag's wave bits (an XOR)
 #endif
+#if PLSLAM_MI_UNSCALED && (PLSLAM_MI_R5 & 4)
+        uint32_t gtv = gtag;
+        asm volatile("" : "+v"(gtv));                   // in a vector register: the mask is the instruction's one scalar operand
+        auto retag = [&](uint32_t x) -> uint32_t {
+            uint32_t r;
+            asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(0xFFE0FFE0u), "v"(gtv));
+            return r;
+        };
+        if (grp == 0) {                                 // (wave-uniform) the window's first push: nothing is parked yet
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const u32x2_t v = {retag(gm[s]), 0xFFFFFFFFu};
+                if (FINAL) rb[s] = v;
+                else park[s * 64] = v;
+                gm[s] = MI_NONE32;
+            }
+            return;
+        }
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const u32x2_t v = park[s * 64];
+            uint32_t b0 = v.x, b1 = v.y;
+            pk_push2(b0, b1, retag(gm[s]));
+            if (FINAL) rb[s] = u32x2_t{b0, b1};
+            else park[s * 64] = u32x2_t{b0, b1};
+            gm[s] = MI_NONE32;
+        }
+#else
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const u32x2_t v = park[s * 64];
@@ -343,6 +395,11 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             park[s * 64] = u32x2_t{b0, b1};
             gm[s] = MI_NONE32;
         }
+        if (FINAL) {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) rb[s] = park[s * 64];
+        }
+#endif
     };
     // column minima of a finished tile: c0 / c1 = the packed minima (rows 0-7 | rows 8-15 of the lane's group) of M-tile 0 / 1;
     // parked word = (group minimum of M-tile 0 | group minimum of M-tile 1 << 16), K1h's
@@ -454,7 +511,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             }
             finish_columns(t - 1, cm0_prev, cm1);
             // wave-uniform: tile t-1 closed a row group (both M-tiles of it are in the minima now)
-            if (U == 0 && ((t - 1) & (MH_GROUP - 1)) == MH_GROUP - 1) push_groups(t - 1);
+            if (U == 0 && ((t - 1) & (MH_GROUP - 1)) == MH_GROUP - 1) push_groups(t - 1, std::false_type{}, nullptr);
         }
         __builtin_amdgcn_sched_barrier(0);
         // phase 2: M-tile 1 of tile t under the bookkeeping of M-tile 0 of tile t
@@ -501,7 +558,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         finish_columns(t, cm0_prev, pk_min16(cma, cmb));
 #endif
     };
-    auto pipeline = [&]() __attribute__((always_inline)) {
+    auto pipeline = [&](u32x2_t* rb) __attribute__((always_inline)) {
         // (wt0 is a multiple of 64: t & 3 of the unrolled steps is static.  The first step has no previous tile: its
         // phase 1 runs on "none" accumulators, its column / group actions are skipped)
         {
@@ -541,7 +598,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             __syncthreads();
         }
         epilogue(wt1 - 1);
-        push_groups(wt1 - 1);                      // the (possibly partial) last row group
+        push_groups(wt1 - 1, std::true_type{}, rb);   // the (possibly partial) last row group: merged into registers
     };
 #undef PLSLAM_MI_EPI2
 #undef PLSLAM_MI_EPI
@@ -550,13 +607,12 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 
     // Row results of a window: K1h's finish_rows with this kernel's slot -> row map (slot 8 mt + q: low half = local row
     // 32 mt + 16 g + q, high half = local row 32 mt + 16 g + q + 8 of the wave's 64).  One lane per row after the transpose;
-    // the best entry names the (group, class) that holds the best column, whose S members are recomputed from the raw rows.
-    auto finish_rows = [&]() __attribute__((always_inline)) {
+    // the best entry names the CELL (group, class) that holds the best column, whose S members are recomputed from the raw rows.
+    // rb: the parked sorted pairs with the window's last group merged in (push_groups, FINAL) -- in registers.
+    auto finish_rows = [&](const u32x2_t* rb) __attribute__((always_inline)) {
         uint32_t* rowx = reinterpret_cast<uint32_t*>(smem) + w * (64 * ROWX_STRIDE);
-        u32x2_t rb[16];
-#pragma unroll
-        for (int s = 0; s < 16; ++s) rb[s] = park[s * 64];
-        __syncthreads();                           // every wave holds its pairs: the transpose may overwrite the parking area
+        // (the barrier behind the tile loop stands between every wave's last read of the b tile / of its parked pairs and
+        // these writes: the transpose may overwrite both)
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int lrow = 32 * (s >> 3) + 16 * g + (s & 7);
@@ -568,24 +624,41 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         uint32_t k0 = 0xFFFFFFFFu, k1 = 0xFFFFFFFFu;
         const uint32_t* mine = rowx + lane * ROWX_STRIDE;
+#if PLSLAM_MI_R5 & 1
+        // A class's word is its sorted pair (first | second << 16).  The smallest of the 64 entries is the smallest FIRST entry
+        // (class c*); the second smallest is the second smallest first entry or c*'s second entry -- every other second entry
+        // is no smaller than its own class's first.  (entry << 16 | class: distinct words, so the order is strict)
+#pragma unroll
+        for (int cls = 0; cls < 32; ++cls) {
+            uint32_t x;
+            asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(x) : "v"(mine[cls]), "n"(cls));
+            asm("v_med3_u32 %0, %1, %2, %0" : "+v"(k1) : "v"(k0), "v"(x));         // k0 <= k1: the middle one is the new second
+            k0 = umin_(k0, x);
+        }
+        {
+            const uint32_t cs = k0 & 31u;
+            k1 = umin_(k1, (mine[cs] & 0xFFFF0000u) | cs);
+        }
+#else
 #pragma unroll 8
         for (int cls = 0; cls < 32; ++cls) {
             const uint32_t e = mine[cls];
             merge2(k0, k1, (e << 16) | (uint32_t)cls, (e & 0xFFFF0000u) | (uint32_t)cls);
         }
+#endif
         const int row = iw + lane + (lane & 32) * 3;          // lanes 32..63: M-tile 1's rows, 128 further on
         if (row < n1) {
             const gu2_t out = (gu2_t) reinterpret_cast<u32x2_t*>(sd.keys12) + row;
             const gcu32x4_t ap = (gcu32x4_t)(araw + (size_t)row * 8);
             const u32x4_t a_lo = ap[0], a_hi = ap[1];
-            // (key16 << 16 | class) -> first row of the (group, class), its stride count, the distance
+            // (key16 << 16 | class) -> first row of the cell (group, class), its stride count, the distance
             auto group_of = [&](uint32_t k, uint32_t& jbase, uint32_t& cnt) {
                 const uint32_t t0 = (uint32_t)wt0 + (((k >> (PLSLAM_MI_UNSCALED ? 16 : 21)) & 3u) << 4);   // first tile of the group
                 const uint32_t s = t0 < (uint32_t)nfull ? (uint32_t)MH_GROUP : (uint32_t)rag_s;
                 jbase = (t0 >> 4) * MH_GROUP_ROWS + s * (k & 0xFFFFu);
                 cnt = s;
             };
-            // all members of a (group, class): the smallest (d << 23 | j) and the second smallest (MI_RESCAN_BATCH candidates' rows
+            // all members of a cell: the smallest (d << 23 | j) and the second smallest (MI_RESCAN_BATCH candidates' rows
             // are requested together: the accumulators are dead here, and the loop is a chain of L2 round trips)
             auto rescan = [&](uint32_t jbase, uint32_t cnt, uint32_t& best, uint32_t& second) {
                 best = second = KEY_NONE;
@@ -611,14 +684,58 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
                     }
                 }
             };
+#if PLSLAM_MI_R5 & 2
+            // The winner cell on the fast road: SIXTEEN consecutive columns from one base with immediate offsets and no validity
+            // tests -- the cell's own (16, or rag_s in the ragged group) plus, behind a cell of the ragged group, the first
+            // columns of the next class, or, when the end of b cuts the window, the columns just in front of the cell
+            // (base = n2 - 16).  The extra columns are REAL columns of other cells, and harmless: (i) the winner cell holds the
+            // row's smallest (d, j) -- it is the smallest (d, group, class), and cells are consecutive ranges of j --, so no
+            // extra column beats or ties-and-precedes its best member; (ii) an extra column that becomes the "second" of these
+            // sixteen has the true distance of a column outside the cell, which is no smaller than o1's, the exact minimum over
+            // all other cells: min(second, o1) is unchanged as a distance (and as an index wherever the index is exact).  Not
+            // when the base would leave the window (its columns were already counted by the window before) or b has fewer
+            // than 16 rows: such lanes -- none at the shipped sizes -- send their wave down the guarded road.
+            auto rescan16 = [&](uint32_t jb, uint32_t& best, uint32_t& second) {
+                uint32_t bk = 0xFFFFFFFFu, sk = 0xFFFFFFFFu;                     // (d << 4 | k)
+                const PLSLAM_GLOBAL char* const rbp = bbytes + (size_t)jb * 32;
+                constexpr int RB = MI_RESCAN_BATCH16;
+#pragma unroll
+                for (int k0_ = 0; k0_ < 16; k0_ += RB) {
+                    u32x4_t bl[RB], bh[RB];
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        const gcu32x4_t bp = (gcu32x4_t)(rbp + (k0_ + q) * 32);
+                        bl[q] = bp[0];
+                        bh[q] = bp[1];
+                    }
+#pragma unroll
+                    for (int q = 0; q < RB; ++q) {
+                        const uint32_t d = hamming256(a_lo, a_hi, bl[q], bh[q]);
+                        uint32_t x;
+                        asm("v_lshl_or_b32 %0, %1, 4, %2" : "=v"(x) : "v"(d), "n"(k0_ + q));
+                        asm("v_med3_u32 %0, %1, %2, %0" : "+v"(sk) : "v"(bk), "v"(x));
+                        bk = umin_(bk, x);
+                    }
+                }
+                best = ((bk >> 4) << KEY_IDX_BITS) | (jb + (bk & 15u));
+                second = ((sk >> 4) << KEY_IDX_BITS) | (jb + (sk & 15u));
+            };
+#endif
             uint32_t r0 = KEY_NONE, r1 = KEY_NONE;
             if ((k0 >> 16) <= MI_KEY16_MAX) {
                 uint32_t jb, cnt, in2;
                 group_of(k0, jb, cnt);
+#if PLSLAM_MI_R5 & 2
+                const uint32_t jsh = jb + 16u <= (uint32_t)n2 ? jb : (uint32_t)n2 - 16u;          // (wraps when n2 < 16: caught below)
+                const bool guarded = n2 < 16 || jsh < (uint32_t)wt0 * MH_TILE_N;
+                if (__builtin_amdgcn_ballot_w64(guarded) == 0) rescan16(jsh, r0, in2);
+                else rescan(jb, cnt, r0, in2);
+#else
                 rescan(jb, cnt, r0, in2);
+#endif
                 if ((k1 >> 16) <= MI_KEY16_MAX) {
-                    // the best key outside the winner's (group, class): its distance is exact, its column is the first of
-                    // its (group, class) unless the exact index was asked for and it IS the second best
+                    // the best key outside the winner's cell: its distance is exact, its column is the first of
+                    // its cell unless the exact index was asked for and it IS the second best
                     uint32_t jb1, cnt1;
                     group_of(k1, jb1, cnt1);
                     uint32_t o1 = ((k1 >> (16 + MI_DSHIFT)) << KEY_IDX_BITS) | jb1;
@@ -666,18 +783,21 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #ifdef PLSLAM_MI_PROF
         prof_tl = PLSLAM_MI_TICK();
 #endif
+#if !(PLSLAM_MI_UNSCALED && (PLSLAM_MI_R5 & 4))                 // (else the window's first push writes the parked pairs)
 #pragma unroll
         for (int s = 0; s < 16; ++s) park[s * 64] = u32x2_t{0xFFFFFFFFu, 0xFFFFFFFFu};   // wave-private: no barrier needed
+#endif
         expand_store(raw_first, 0, wt0);           // wt0 is a multiple of 128: buffer parity restarts at 0
         ring_slot = 1;                             // the slot of tile wt0 + 1
-        pipeline();
+        u32x2_t rb[16];                            // the window's parked pairs, its last group merged in
+        pipeline(rb);
 #ifdef PLSLAM_MI_PROF
         { const unsigned long long t = PLSLAM_MI_TICK(); prof_loop += t - prof_tl; prof_tl = t; }
 #endif
         __syncthreads();                           // every wave is past its last operand read of the b tile, every column minimum is parked
         // the window's last block of column results (full or partial)
         combine_columns((wt1 - 1) >> 3);
-        finish_rows();
+        finish_rows(rb);
 #ifdef PLSLAM_MI_PROF
         prof_fin += PLSLAM_MI_TICK() - prof_tl;
 #endif

@@ -142,13 +142,26 @@ class StereoBatchMatcher:
         entries (plslam_match_plan_set_wire16): no narrowing pass between the step and its gather."""
         torch = self.torch
         if on and self.wire16 is None:
-            self.wire16 = [torch.full((self.B, self.stride), -2, dtype=torch.int16, device=self.dev) for _ in self.tables]
-            for plan, t32, t16 in zip(self.plans, self.tables, self.wire16):
-                plan.set_wire16(t32.data_ptr(), t16.data_ptr(), t32.numel())
+            from .capi import ENOTSUP, PlslamError
+            w16 = [torch.full((self.B, self.stride), -2, dtype=torch.int16, device=self.dev) for _ in self.tables]
+            try:
+                for plan, t32, t16 in zip(self.plans, self.tables, w16):
+                    plan.set_wire16(t32.data_ptr(), t16.data_ptr(), t32.numel())
+            except PlslamError as e:
+                # a plan whose tables another kernel than the finalize kernel writes (a column-split plan of a few large problems,
+                # a fused plan): no mirror -- the caller narrows the table with a copy instead
+                if e.code != ENOTSUP:
+                    raise
+                for plan, t32 in zip(self.plans, self.tables):
+                    plan.set_wire16(t32.data_ptr(), 0, t32.numel())
+                return False
+            self.wire16 = w16
+            return True
         elif not on and self.wire16 is not None:
             for plan, t32 in zip(self.plans, self.tables):
                 plan.set_wire16(t32.data_ptr(), 0, t32.numel())
             self.wire16 = None
+        return self.wire16 is not None
 
     def run_overlapped(self, k: int):
         """Step k of a stream of independent batches into buffer k % n_buffers: every scan on one HIP stream, the
@@ -382,9 +395,7 @@ class PipelinedGather:
         self.pipe = TableGatherPipeline(bm.B, bm.stride, max(bm.n_orb, bm.n_lbd), world, rank, root,
                                         nbuf=len(bm.tables), device=bm.dev, group=group, compact=compact,
                                         comm_stream=bm.streams[min(1, len(bm.streams) - 1)] if comm_on_stage_stream else None)
-        self.kernel_wire16 = bool(self.pipe.compact and wire16_from_kernel and self.pipe.cuda)
-        if self.kernel_wire16:
-            bm.enable_wire16(True)
+        self.kernel_wire16 = bool(self.pipe.compact and wire16_from_kernel and self.pipe.cuda) and bm.enable_wire16(True)
         self.host_s, self.host_n = 0.0, 0          # host time spent inside step() (enqueueing only: nothing in it waits for the GPU)
 
     def step(self, k: int):

@@ -55,7 +55,7 @@ def test_gather_one_rank_roundtrip(ctx):
 
 
 # ---- plslam_match_plan_set_wire16: the int16 mirror of a plan's match tables (the gather's wire format) -------------------
-@pytest.mark.parametrize("pairs,n_orb,n_lbd", [(3, 96, 20), (40, 512, 64)])      # the latency kernel's plan / the matrix-core scan's
+@pytest.mark.parametrize("pairs,n_orb,n_lbd", [(3, 96, 20), (160, 512, 64)])      # the latency kernel's plan / the matrix-core scan's
 def test_finalize_kernel_writes_the_int16_wire_table(ctx, oracle, pairs, n_orb, n_lbd):
     import torch
     from plslam_amd import frontend, synth
@@ -63,7 +63,7 @@ def test_finalize_kernel_writes_the_int16_wire_table(ctx, oracle, pairs, n_orb, 
     bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=0.75, nnr_l=0.9, mutual=True, n_buffers=2,
                                      geometry=synth.stereo_geometry(st), gates=dict(synth.KITTI_GATES))
     try:
-        bm.enable_wire16(True)
+        assert bm.enable_wire16(True)
         for k in range(4):
             bm.run_overlapped(k)
         bm.synchronize_all()
@@ -108,3 +108,21 @@ def test_wire16_is_refused_where_another_kernel_writes_the_table(ctx):
         plan.set_wire16(m.data_ptr(), 0, 6000)              # removing a mirror that is not there is fine
     finally:
         plan.close()
+
+
+def test_gather_step_narrows_by_copy_where_the_plan_has_no_finalize_kernel(ctx):
+    """40 pairs of 512 + 64 features: few enough waves for AUTO to take the column-split form (k_split_post writes the tables):
+    the matcher reports that no mirror can be had, and the table pipeline narrows with its copy."""
+    from plslam_amd import frontend, synth
+    st = synth.stereo_stream(40, 512, 64, seed=5)
+    bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=0.75, nnr_l=0.9, mutual=True, n_buffers=2)
+    try:
+        got = bm.enable_wire16(True)
+        assert got == (bm.wire16 is not None)
+        if not got:
+            bm.run_overlapped(0)
+            bm.synchronize_all()
+            pipe = frontend.TableGatherPipeline(bm.B, bm.stride, 512, 1, 0, nbuf=2, device=bm.dev, compact=True)
+            assert pipe.send is not None and pipe.send[0].dtype.itemsize == 2
+    finally:
+        bm.close()
