@@ -50,7 +50,8 @@
 #define PLSLAM_MI_ROWLOOK 0
 #endif
 // build-time experiments (tools/build_exp.py; results are WRONG with any of them on): 1 no tile barrier, 2 no operand reads
-// from LDS, 4 no MFMA, 8 no bookkeeping (pack + minima), 16 no expansion / prefetch
+// from LDS, 4 no MFMA, 8 no bookkeeping (pack + minima), 16 no expansion / prefetch, 32 no gathers in the row finish's
+// re-evaluation of the winner cell (its arithmetic stays), 64 no re-evaluation at all
 #ifndef PLSLAM_MI_X
 #define PLSLAM_MI_X 0
 #endif
@@ -65,9 +66,15 @@
 //   4  group pushes: the first push of a window only writes (nothing is parked yet); the tag replacement is one v_and_or; the
 //      window's last push stays in registers and is consumed by the row finish directly
 //   8  expansion: the validity mask of a ragged group's tile only from the first tile some class has no column for
+//  16  the scalar bookkeeping of the prefetch is carried from step to step instead of being rebuilt: the ring slot as a byte
+//      offset (one scalar add builds M0, one vector add the lane's read address), the full-group row offset (pf32)
 // 0 = round 4's code (A/B builds: tools/build_exp.py hamming_mfma_i.hip r4:-DPLSLAM_MI_R5=0)
 #ifndef PLSLAM_MI_R5
-#define PLSLAM_MI_R5 15
+#define PLSLAM_MI_R5 31
+#endif
+// PLSLAM_MI_PERSIST = N > 0 (experiment): at most N persistent workgroups, each walking its XCD's row of the block table
+#ifndef PLSLAM_MI_PERSIST
+#define PLSLAM_MI_PERSIST 0
 #endif
 
 namespace plslam {
@@ -92,11 +99,11 @@ constexpr uint32_t MI_NONE16 = 0xFFFFu;
 #endif
 constexpr uint32_t MI_NONE32 = MI_NONE16 * 0x00010001u;
 #ifndef PLSLAM_MI_RESCAN_BATCH
-#define PLSLAM_MI_RESCAN_BATCH 4
+#define PLSLAM_MI_RESCAN_BATCH 2
 #endif
 constexpr int MI_RESCAN_BATCH = PLSLAM_MI_RESCAN_BATCH;
 #ifndef PLSLAM_MI_RESCAN_BATCH16
-#define PLSLAM_MI_RESCAN_BATCH16 8
+#define PLSLAM_MI_RESCAN_BATCH16 2
 #endif
 constexpr int MI_RESCAN_BATCH16 = PLSLAM_MI_RESCAN_BATCH16;      // the unguarded rescan's rows in flight (8 VGPRs each)
 __device__ __forceinline__ uint32_t pk_min3_f16(uint32_t a, uint32_t b, uint32_t c)
@@ -118,7 +125,7 @@ __device__ unsigned long long g_mi_prof[MI_PROF_WGS * 4];      // per workgroup 
 // DIRECTED = true: only keys12 (row direction) is produced.
 template <bool DIRECTED>
 __global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
-k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks, int32_t* __restrict__ zero, int nzero)
+k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks, int32_t* __restrict__ zero, int nzero, int nblocks)
 {
     // one buffer, two lives: during the scan the double-buffered b tile (9 216 B) followed by the PARKED sorted pairs of the
     // row direction ([wave][slot][lane] x 8 B = 32 768 B); after the scan the row-result transpose [wave][row 0..63][33]
@@ -129,8 +136,14 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
     // column minima of the last 8 tiles, [tile & 7][wave][lane] (1 KB per tile): see K1h
     __shared__ __attribute__((aligned(16))) uint32_t colstage[MH_CGROUP * 256];
-    // raw b dwords in flight (LDS-DMA ring, 3 slots): see K1h
-    __shared__ __attribute__((aligned(16))) uint32_t rawring[3][256];
+    // raw b dwords in flight (LDS-DMA ring, 3 slots): see K1h.  (A fourth slot would make the slot a compile-time fact of every
+    // unrolled step -- 10 scalar instructions less per tile -- but the kilobyte takes the kernel from 26 to 27 LDS granules
+    // of 2 KB: TWO workgroups per CU instead of three, measured 2.84 against 2.52 ms; PLSLAM_MI_RING4 builds it.)
+#ifndef PLSLAM_MI_RING4
+#define PLSLAM_MI_RING4 0
+#endif
+    constexpr int RING = PLSLAM_MI_RING4 ? 4 : 3;
+    __shared__ __attribute__((aligned(16))) uint32_t rawring[RING][256];
     uint8_t* const btile = smem;
     u32x2_t* const park = reinterpret_cast<u32x2_t*>(smem + PARK_OFF) + (threadIdx.x >> 6) * (16 * 64) + (threadIdx.x & 63);
 
@@ -141,9 +154,20 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
 
+#if PLSLAM_MI_PERSIST
+    // PERSISTENT workgroups (experiment): workgroup p stays on its XCD's row of the table (p & 7) and walks it in steps of
+    // gridDim.x / 8 entries
+    for (int vb = blockIdx.x; vb < nblocks; vb += gridDim.x) {
+    if (vb != (int)blockIdx.x) __syncthreads();    // the item before: every wave is past its reads of the LDS buffers
+    const int wg = (vb & 7) * (nblocks >> 3) + (vb >> 3);
+    const BlockDesc bd = blocks[wg];
+    if (bd.item < 0) continue;                     // padding entry of the XCD-striped table
+#else
+    (void)nblocks;
     const int wg = xcd_remap_(blockIdx.x, gridDim.x);
     const BlockDesc bd = blocks[wg];
     if (bd.item < 0) return;                       // padding entry of the XCD-striped table
+#endif
     const SymDesc sd = syms[bd.item];
     const int n1 = sd.n1, n2 = sd.n2;
     const MhLayout L(n2);
@@ -210,7 +234,8 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // The address: ONE scalar base (b) + a 32-bit byte offset per lane (rows of b are below 2^23); M0 -- the LDS destination --
     // is the compiler's reserved register, which it does not use in this kernel (gfx9 LDS instructions do not need it): it
     // is declared clobbered instead of being saved and restored (tests/test_abi.py: no other m0 in the kernel's ISA).
-    auto load_raw_async = [&](int t, int slot) __attribute__((always_inline)) {
+    // (slot_b: the ring slot as a BYTE offset, 1024 x slot)
+    auto load_raw_async = [&](int t, uint32_t slot_b) __attribute__((always_inline)) {
         const int tc = t < ntiles ? t : ntiles - 1;
         const uint32_t s = tc < nfull ? (uint32_t)MH_GROUP : (uint32_t)rag_s;
         const uint32_t first = ((uint32_t)(tc & ~15) << 5) + (uint32_t)(tc & 15);      // the group's first row + the tile within the group
@@ -218,22 +243,24 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         const uint32_t last = (uint32_t)(n2 - 1);
         row = row < last ? row : last;
         const uint32_t voff = row * 32u + (uint32_t)ewd4;
-        const uint32_t lds_dst = (uint32_t)(uintptr_t)(&rawring[slot][64 * w]);
+        const uint32_t lds_dst = (uint32_t)(uintptr_t)(&rawring[0][64 * w]) + slot_b;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(bbytes), "s"(lds_dst) : "memory", "m0");
     };
     // (the lane's own dword: its index 8 ej + ewd4 / 4 = tid from the two values the expansion keeps anyway -- a register
     // holding tid through the tile loop is spilled, and the reload waits for vmcnt(0): the whole prefetch)
     // the same inside FULL groups (tile t and the group it lies in: 16 tiles of 32 columns that all exist): no clamps, the lane's
     // part of the offset is a constant -- one vector instruction
-    auto load_raw_async_full = [&](int t, int slot) __attribute__((always_inline)) {
-        const uint32_t first32 = (((uint32_t)(t & ~15) << 5) + (uint32_t)(t & 15)) * 32u;     // (scalar)
+    // (PLSLAM_MI_R5 & 16: the scalar part of the offset is carried from step to step -- pf32 -- instead of being rebuilt)
+    uint32_t pf32 = 0;
+    auto load_raw_async_full = [&](int t, uint32_t slot_b) __attribute__((always_inline)) {
+        const uint32_t first32 = (PLSLAM_MI_R5 & 16) ? pf32 : (((uint32_t)(t & ~15) << 5) + (uint32_t)(t & 15)) * 32u;     // (scalar)
         const uint32_t voff = (uint32_t)(ej * (MH_GROUP * 32) + ewd4) + first32;
-        const uint32_t lds_dst = (uint32_t)(uintptr_t)(&rawring[slot][64 * w]);
+        const uint32_t lds_dst = (uint32_t)(uintptr_t)(&rawring[0][64 * w]) + slot_b;
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" : : "v"(voff), "s"(bbytes), "s"(lds_dst) : "memory", "m0");
     };
-    auto take_raw = [&](int slot) __attribute__((always_inline)) -> uint32_t {
+    auto take_raw = [&](uint32_t slot_b) __attribute__((always_inline)) -> uint32_t {
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(&rawring[slot][0]) + (ej * 32 + ewd4));
+        return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(&rawring[0][0]) + slot_b + (ej * 32 + ewd4));
     };
     auto expand_store = [&](uint32_t raw, int buf, int tn, bool full = false) __attribute__((always_inline)) {
         uint8_t* dst = btile + buf * MH_TILE_BYTES + ej * MH_ROW_STRIDE + ewd4 * 4;
@@ -246,7 +273,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     };
 
     int wt0 = 0, wt1 = ntiles < MH_WINDOW ? ntiles : MH_WINDOW;      // the current window of tiles
-    int ring_slot = 1;                                               // rawring slot of the NEXT tile
+    uint32_t ring_slot = 1024;                                       // rawring slot of the NEXT tile (as a byte offset)
 
     // block kb of 8 tiles of column results -> one word per column for the workgroup's 256 rows (K1h's combine_columns)
     const uint64_t part_u = (uint64_t)(uintptr_t)part;
@@ -490,17 +517,24 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         bfr[3] = PLSLAM_MI_READ_B(3);
         PLSLAM_MI_EPI2(m1, 1, 4, PAR1) PLSLAM_MI_MMA(m0, 0, 2, m0)
         // the next tile's raw dword (requested three steps ago) leaves the ring: an LDS latency ahead of its expansion
-        const uint32_t raw_next = (PLSLAM_MI_X & 16) ? 0u : take_raw(ring_slot);
+        const uint32_t raw_next = (PLSLAM_MI_X & 16) ? 0u : take_raw(RING == 4 ? 1024u * ((U + 1) & 3) : ring_slot);
         PLSLAM_MI_EPI2(m1, 1, 6, PAR1) PLSLAM_MI_MMA(m0, 0, 3, m0)
         const uint32_t cm1 = PLSLAM_MI_F16 ? cma : pk_min16(cma, cmb);
         // behind the chain of M-tile 0: the expansion of the next tile (its buffer was read for the last time before this
         // step's barrier) and the prefetch -- independent work while the last MFMA of the chain completes
         if (!(PLSLAM_MI_X & 16)) {
         expand_store(raw_next, (U + 1) & 1, t + 1, FULL);         // past the last tile: a harmless rewrite of the idle buffer
-        if (FULL) load_raw_async_full(t + 4, ring_slot);          // three tiles ahead of its use, into the slot just read
-        else load_raw_async(t + 4, ring_slot);
+        // three tiles ahead of its use -- three slots: into the slot just read; four: into this tile's own (read one step ago)
+        if (FULL) {
+            load_raw_async_full(t + 4, RING == 4 ? 1024u * U : ring_slot);
+            // the next step's tile: the next row of the group's classes, or -- only behind a step with U = 0, the lean chunks
+            // being four tiles long -- the first tile of the next group (16 x 32 rows further on)
+            if (PLSLAM_MI_R5 & 16) pf32 += (U == 3 && ((t + 5) & 15) == 0) ? (MH_GROUP_ROWS - 15) * 32u : 32u;
+        } else {
+            load_raw_async(t + 4, RING == 4 ? 1024u * U : ring_slot);
+        }
         } else asm volatile("" :: "v"(raw_next));
-        ring_slot = ring_slot == 2 ? 0 : ring_slot + 1;           // (scalar)
+        ring_slot = ring_slot == 2048u ? 0u : ring_slot + 1024u;  // (scalar)
         if (with_prev) {
             // block (t - 9) / 8 of column results: its last tile was parked in the step before this one, by every wave before
             // this step's barrier; tile t - 1 is about to take the block's first slot: a second barrier (workgroup-uniform
@@ -577,6 +611,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         {
             // whole chunks of four tiles whose prefetches (four tiles ahead) stay inside full groups: the lean instantiation
             const int lim = (wt1 < nfull ? wt1 : nfull) - 7;          // tb + 3 + 4 < nfull and tb + 3 < wt1
+            pf32 = (((uint32_t)((tb + 4) & ~15) << 5) + (uint32_t)((tb + 4) & 15)) * 32u;      // (the first lean step's prefetch: tile tb + 4)
             for (; tb < lim; tb += 4) {
                 tile_step(tb, std::integral_constant<int, 0>{}, tb != wt0, std::true_type{});
                 tile_step(tb + 1, std::integral_constant<int, 1>{}, true, std::true_type{});
@@ -705,8 +740,14 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #pragma unroll
                     for (int q = 0; q < RB; ++q) {
                         const gcu32x4_t bp = (gcu32x4_t)(rbp + (k0_ + q) * 32);
-                        bl[q] = bp[0];
-                        bh[q] = bp[1];
+                        if (PLSLAM_MI_X & 32) {              // (experiment: no gathers -- the rows of a stand in)
+                            bl[q] = a_hi + (uint32_t)(k0_ + q);
+                            bh[q] = a_lo;
+                            asm volatile("" :: "v"(bp));
+                        } else {
+                            bl[q] = bp[0];
+                            bh[q] = bp[1];
+                        }
                     }
 #pragma unroll
                     for (int q = 0; q < RB; ++q) {
@@ -728,7 +769,8 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #if PLSLAM_MI_R5 & 2
                 const uint32_t jsh = jb + 16u <= (uint32_t)n2 ? jb : (uint32_t)n2 - 16u;          // (wraps when n2 < 16: caught below)
                 const bool guarded = n2 < 16 || jsh < (uint32_t)wt0 * MH_TILE_N;
-                if (__builtin_amdgcn_ballot_w64(guarded) == 0) rescan16(jsh, r0, in2);
+                if (PLSLAM_MI_X & 64) { r0 = jsh; in2 = jb; }
+                else if (__builtin_amdgcn_ballot_w64(guarded) == 0) rescan16(jsh, r0, in2);
                 else rescan(jb, cnt, r0, in2);
 #else
                 rescan(jb, cnt, r0, in2);
@@ -762,9 +804,9 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // the first window's first four tiles of b are requested BEFORE the rows of a: one memory latency for both (a 200 x 200
     // problem is seven tiles long: its workgroup's time is mostly such latencies)
     uint32_t raw_first = load_raw(0);
-    load_raw_async(1, 1);
-    load_raw_async(2, 2);
-    load_raw_async(3, 0);
+    load_raw_async(1, 1024);
+    load_raw_async(2, 2048);
+    load_raw_async(3, RING == 4 ? 3072 : 0);
     // ---- A operands: MFMA row c of M-tile mt = block row 128 mt + 32 w + 16 g' + r' (K1h's mh_block_row): a lane's 16
     // accumulator registers of an M-tile are 16 CONSECUTIVE rows of a ----
 #pragma unroll
@@ -788,7 +830,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         for (int s = 0; s < 16; ++s) park[s * 64] = u32x2_t{0xFFFFFFFFu, 0xFFFFFFFFu};   // wave-private: no barrier needed
 #endif
         expand_store(raw_first, 0, wt0);           // wt0 is a multiple of 128: buffer parity restarts at 0
-        ring_slot = 1;                             // the slot of tile wt0 + 1
+        ring_slot = 1024;                          // the slot of tile wt0 + 1
         u32x2_t rb[16];                            // the window's parked pairs, its last group merged in
         pipeline(rb);
 #ifdef PLSLAM_MI_PROF
@@ -806,10 +848,13 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         wt0 = wt1;
         wt1 = ntiles < wt0 + MH_WINDOW ? ntiles : wt0 + MH_WINDOW;
         raw_first = load_raw(wt0);
-        load_raw_async(wt0 + 1, 1);
-        load_raw_async(wt0 + 2, 2);
-        load_raw_async(wt0 + 3, 0);
+        load_raw_async(wt0 + 1, 1024);
+        load_raw_async(wt0 + 2, 2048);
+        load_raw_async(wt0 + 3, RING == 4 ? 3072 : 0);
     }
+#if PLSLAM_MI_PERSIST
+    }
+#endif
 #ifdef PLSLAM_MI_PROF
     if (threadIdx.x == 0 && blockIdx.x < MI_PROF_WGS) {
         g_mi_prof[4 * blockIdx.x + 0] = prof_t1 - prof_t0;
@@ -832,8 +877,12 @@ int launch_scan_sym_mfma_i(const SymDesc* d_sym, const BlockDesc* d_blocks, int 
                            bool directed, hipStream_t s)
 {
     if (nblocks <= 0) return PLSLAM_OK;
-    if (directed) hipLaunchKernelGGL((k_scan_sym_mfma_i<true>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
-    else hipLaunchKernelGGL((k_scan_sym_mfma_i<false>), dim3(nblocks), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero);
+    int grid = nblocks;
+#if PLSLAM_MI_PERSIST
+    if (grid > PLSLAM_MI_PERSIST) grid = PLSLAM_MI_PERSIST & ~7;
+#endif
+    if (directed) hipLaunchKernelGGL((k_scan_sym_mfma_i<true>), dim3(grid), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero, nblocks);
+    else hipLaunchKernelGGL((k_scan_sym_mfma_i<false>), dim3(grid), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero, nblocks);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
