@@ -868,6 +868,11 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
     }
     if (!strcmp(key, "mfma_form")) {
         PLSLAM_REQUIRE(value >= 0 && value <= 5, PLSLAM_EINVAL);
+        if (!mfma_form_built(value)) {
+            set_last_error("mfma_form 1 / 3 / 4 (K1e, K1g, K1h: earlier generations of the matrix-core scan) are not in this build: "
+                           "PLSLAM_BUILD_LEGACY_SCANS=1 python -m plslam_amd.build");
+            return PLSLAM_ENOTSUP;
+        }
         ctx->mfma_form = value;
         return PLSLAM_OK;
     }
@@ -933,6 +938,7 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "sym_rows")) { *value = ctx->sym_rows; return PLSLAM_OK; }
     if (!strcmp(key, "group_cap")) { *value = ctx->group_cap; return PLSLAM_OK; }
     if (!strcmp(key, "mfma_form")) { *value = ctx->mfma_form; return PLSLAM_OK; }
+    if (!strcmp(key, "legacy_scans")) { *value = PLSLAM_BUILD_LEGACY_SCANS; return PLSLAM_OK; }     // (read-only: a fact of the build)
     if (!strcmp(key, "post_fuse")) { *value = ctx->post_fuse; return PLSLAM_OK; }
     if (!strcmp(key, "fuse")) { *value = ctx->fuse; return PLSLAM_OK; }
     if (!strcmp(key, "col_split")) { *value = ctx->col_split; return PLSLAM_OK; }

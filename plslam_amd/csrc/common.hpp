@@ -304,14 +304,25 @@ int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblo
 int mh_slot_of_column(int n2, int j);
 // K1g (hamming_mfma_d.hip): the directed scan, one item per (directed scan, 256-row block of a); any n2 (windows inside)
 int launch_scan_dir_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero, hipStream_t s);
+// PLSLAM_BUILD_LEGACY_SCANS (plslam_amd/build.py; default 0): the earlier generations of the matrix-core scan -- K1e
+// (hamming_mfma.hip, mfma_form 1), K1g (hamming_mfma_d.hip, 3) and K1h's scan kernel (hamming_mfma_h.hip, 4) -- are compiled in.
+// AUTO never picks them; without them plslam_ctx_set_option("mfma_form", 1 | 3 | 4) returns PLSLAM_ENOTSUP.
+#ifndef PLSLAM_BUILD_LEGACY_SCANS
+#define PLSLAM_BUILD_LEGACY_SCANS 0
+#endif
+inline bool mfma_form_built(int form) { return PLSLAM_BUILD_LEGACY_SCANS || form == 0 || form == 2 || form == 5; }
 inline int launch_scan_mfma_form(int form, const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
                                  int nzero, bool multi_window, bool directed, hipStream_t s, bool fused = false)
 {
+#if PLSLAM_BUILD_LEGACY_SCANS
     if (form == 3 && directed && !fused) return launch_scan_dir_mfma(d_sym, d_blocks, nblocks, d_zero, nzero, s);
     if (form == 4 && !fused) return launch_scan_sym_mfma_h(d_sym, d_blocks, nblocks, d_zero, nzero, directed, s);
+#endif
     if (mfma_form_is_h(form) && !fused) return launch_scan_sym_mfma_i(d_sym, d_blocks, nblocks, d_zero, nzero, directed, s);
-    return form == 1 ? launch_scan_sym_mfma(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, s)
-                     : launch_scan_sym_mfma_g(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, fused, s);
+#if PLSLAM_BUILD_LEGACY_SCANS
+    if (form == 1) return launch_scan_sym_mfma(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, s);
+#endif
+    return launch_scan_sym_mfma_g(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, fused, s);
 }
 int launch_merge_partials(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, hipStream_t s);
 

@@ -57,6 +57,7 @@ int mh_slot_of_column(int n2, int j) { return MhLayout(n2).slot_of(j); }     // 
 // m = (r & 3) + 8 (r >> 2) + 4 g
 __host__ __device__ inline int mh_block_row(int w, int mt, int m) { return 128 * mt + 32 * w + 16 * ((m >> 2) & 1) + (m & 3) + 4 * (m >> 3); }
 
+#if PLSLAM_BUILD_LEGACY_SCANS      // K1h's scan kernel (mfma_form 4): round 3's default, kept as a cross-check; its merge kernel below serves K1i
 // DIRECTED = true: only keys12 (row direction) is produced.
 template <bool DIRECTED>
 __global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
@@ -534,6 +535,7 @@ k_scan_sym_mfma_h(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         wt1 = ntiles < wt0 + MH_WINDOW ? ntiles : wt0 + MH_WINDOW;
     }
 }
+#endif  // PLSLAM_BUILD_LEGACY_SCANS
 
 // K1c''  merge of K1h's column partials + the second-best recomputation: keys21[j] = best-2 over all rows of a.
 // part[256-row block][slot] = (d0 << 17 | row0 << 9 | d1): the block's best row and the distance of its best row OUTSIDE
@@ -577,6 +579,38 @@ k_merge_fix16(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ bl
         return ((k17 >> 8) << KEY_IDX_BITS) | ((k17 & 255u) + 256u * wb);
     };
     // only a block's BEST key is widened and merged per entry
+    // PLSLAM_MERGE_WB (round 5): the default form (one word per entry, a lane per slot) requests the words of up to this many
+    // row blocks together -- a 1500-row problem's six in ONE round trip instead of three
+#ifndef PLSLAM_MERGE_WB
+#define PLSLAM_MERGE_WB 8
+#endif
+    if (PARTS == 1 && !FIX && PLSLAM_MERGE_WB > 2) {
+        constexpr int WB = PLSLAM_MERGE_WB > 2 ? PLSLAM_MERGE_WB : 2;
+        for (int wb0 = 0; wb0 < nwb; wb0 += WB) {
+            uint32_t e[WB][SPT];
+#pragma unroll
+            for (int u = 0; u < WB; ++u) {
+                if (wb0 + u < nwb) {                  // (uniform)
+#pragma unroll
+                    for (int q = 0; q < SPT; ++q)
+                        e[u][q] = PLSLAM_NT_STREAMS ? __builtin_nontemporal_load(&part[(size_t)(wb0 + u) * n2p + slot[q]])
+                                                    : part[(size_t)(wb0 + u) * n2p + slot[q]];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < WB; ++u) {
+                if (wb0 + u < nwb) {
+#pragma unroll
+                    for (int q = 0; q < SPT; ++q) {
+                        const uint32_t k = wide(e[u][q] >> 9, (uint32_t)(wb0 + u)), e1 = ((e[u][q] & 511u) << 8) | 255u;
+                        s0[q] = k < b0[q] ? e1 : s0[q];
+                        b1[q] = umin_(b1[q], umax_(b0[q], k));
+                        b0[q] = umin_(b0[q], k);
+                    }
+                }
+            }
+        }
+    } else
 #pragma unroll 2
     for (int wb = part_id; wb < nwb; wb += PARTS) {
         uint32_t e0[SPT], e1[SPT];
@@ -664,6 +698,7 @@ int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblo
     return PLSLAM_OK;
 }
 
+#if PLSLAM_BUILD_LEGACY_SCANS
 int launch_scan_sym_mfma_h(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
                            bool directed, hipStream_t s)
 {
@@ -673,5 +708,6 @@ int launch_scan_sym_mfma_h(const SymDesc* d_sym, const BlockDesc* d_blocks, int 
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
+#endif  // PLSLAM_BUILD_LEGACY_SCANS
 
 }  // namespace plslam

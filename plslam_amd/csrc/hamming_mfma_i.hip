@@ -153,6 +153,14 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
 #endif
     if (blockIdx.x == 0)
         for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+#if PLSLAM_MI_F16
+    // v_pk_minimum3_f16 is used as an exact integer minimum on 16-bit keys; keys of distances below 32 are half-precision
+    // DENORMALS, which a wave in flush mode would read as zero.  HIP's default mode preserves them; the kernel does not
+    // depend on that: MODE.FP_DENORM[3:2] (f16 / f64, bits 7:6 of the MODE register) = 3, in and out, for this wave.
+    // (Nothing else here is touched by it: the matrix instruction works on integers far above the denormal range, the row
+    // kernels' f64 arithmetic lives in other kernels.)
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 6, 2), 3");
+#endif
 
 #if PLSLAM_MI_PERSIST
     // PERSISTENT workgroups (experiment): workgroup p stays on its XCD's row of the table (p & 7) and walks it in steps of

@@ -25,3 +25,16 @@ def ctx():
 def oracle():
     from oracle import oracle as O
     return O
+
+
+def set_mfma_form(ctx, form: int) -> bool:
+    """ctx.set_option("mfma_form", form); False when the form is one of the earlier generations of the matrix-core scan
+    (1 K1e, 3 K1g, 4 K1h) and the library was built without them (the product: PLSLAM_BUILD_LEGACY_SCANS=1 builds them)."""
+    from plslam_amd.capi import ENOTSUP, PlslamError
+    try:
+        ctx.set_option("mfma_form", form)
+        return True
+    except PlslamError as e:
+        if e.code != ENOTSUP:
+            raise
+        return False

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from plslam_amd import frontend, synth
+from conftest import set_mfma_form
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "match_golden.npz")
@@ -92,7 +93,9 @@ def test_symmetric_and_directed_variants_agree(ctx, oracle, n1, n2):
                                             (plslam_amd.SCAN_AUTO, 1, 0)):
                 ctx.set_option("scan_variant", variant)
                 ctx.set_option("sym_rows", sym_rows)
-                ctx.set_option("mfma_form", {4: 3, 5: 4, 6: 5}.get(form, min(form, 2)))   # 4 = K1g (two directed scans per mutual problem), 5 = K1h, 6 = K1i
+                # 4 = K1g (two directed scans per mutual problem), 5 = K1h, 6 = K1i; the earlier generations only where built
+                if not set_mfma_form(ctx, {4: 3, 5: 4, 6: 5}.get(form, min(form, 2))):
+                    continue
                 ctx.set_option("fuse", 2 if form == 3 else 0)
                 m, n = ctx.match(d1, d2, 0.9, True)
                 assert np.array_equal(m, em) and n == en, (variant, sym_rows, form, gen.__name__)
@@ -129,9 +132,10 @@ def vctx(ctx, request):
          "wave_per_query": plslam_amd.SCAN_WAVE_PER_QUERY, "symmetric": plslam_amd.SCAN_SYMMETRIC,
          "mfma": plslam_amd.SCAN_MFMA, "mfma_k1e": plslam_amd.SCAN_MFMA, "mfma_fused": plslam_amd.SCAN_MFMA,
          "mfma_k1g": plslam_amd.SCAN_MFMA, "mfma_k1h": plslam_amd.SCAN_MFMA, "mfma_k1f": plslam_amd.SCAN_MFMA}[request.param]
-    ctx.set_option("scan_variant", v)
     # "mfma" / "mfma_fused": form 0 = auto = K1i (the default scan; fused plans run K1f)
-    ctx.set_option("mfma_form", {"mfma_k1e": 1, "mfma_k1g": 3, "mfma_k1h": 4, "mfma_k1f": 2}.get(request.param, 0))
+    if not set_mfma_form(ctx, {"mfma_k1e": 1, "mfma_k1g": 3, "mfma_k1h": 4, "mfma_k1f": 2}.get(request.param, 0)):
+        pytest.skip("an earlier generation of the matrix-core scan: not in this build (PLSLAM_BUILD_LEGACY_SCANS=1)")
+    ctx.set_option("scan_variant", v)
     ctx.set_option("fuse", 2 if request.param == "mfma_fused" else 0)      # one workgroup per problem incl. finalize
     yield ctx
     ctx.set_option("scan_variant", plslam_amd.SCAN_AUTO)
@@ -144,7 +148,8 @@ def mform(ctx, request):
     """The forms of the matrix-core scan: 2 = K1f (group minima + recomputed second best, the default), 1 = K1e (best-2
     push per tile), 3 = K1f with one workgroup per problem that also merges the columns and applies ratio + mutual
     (what AUTO picks for large plans; forced here so that small plans exercise it)."""
-    ctx.set_option("mfma_form", {4: 3, 5: 4, 6: 5}.get(request.param, min(request.param, 2)))
+    if not set_mfma_form(ctx, {4: 3, 5: 4, 6: 5}.get(request.param, min(request.param, 2))):
+        pytest.skip("an earlier generation of the matrix-core scan: not in this build (PLSLAM_BUILD_LEGACY_SCANS=1)")
     ctx.set_option("fuse", 2 if request.param == 3 else 1)
     yield request.param
     ctx.set_option("mfma_form", 0)
@@ -514,7 +519,8 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
         # columns' second key to the stages that need them -- the match tables below are compared in that default too)
         # 7 / 8: K1i (the default scan) with exact key tables / in its default
         for form in (1, 2, 3, 4, 5, 6, 7, 8):
-            ctx.set_option("mfma_form", {4: 3, 5: 4, 6: 4, 7: 5, 8: 5}.get(form, min(form, 2)))
+            if not set_mfma_form(ctx, {4: 3, 5: 4, 6: 4, 7: 5, 8: 5}.get(form, min(form, 2))):
+                continue                           # (K1e / K1g / K1h: only in a build with PLSLAM_BUILD_LEGACY_SCANS=1)
             ctx.set_option("exact_second", 1 if form in (4, 5, 7) else 0)
             ctx.set_option("fuse", 2 if form == 3 else 1)
             ctx.set_option("post_fuse", 1)         # the merged column keys are compared below: they exist in memory only with the separate kernels
@@ -534,9 +540,10 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
     # PARTIALS are laid out differently -- K1e: 32-bit keys per 256-row block, K1f: 16-bit keys per 64-row block -- so
     # the column direction is compared after the merge: keys21 is part of the key table.)
     rows = pairs * 2 * ((n_orb + n_lbd) * (2 if mutual else 1))
-    assert got[1][0].size >= 2 * rows
-    k1 = got[1][0][:2 * rows]
-    for form in (2, 3, 4, 5, 6, 7, 8):
+    base = 1 if 1 in got else 2                    # K1e where it is built, else K1f: both push / recompute EXACT keys
+    assert {2, 3, 7, 8} <= set(got) and got[base][0].size >= 2 * rows
+    k1 = got[base][0][:2 * rows]
+    for form in sorted(set(got) - {base}):
         k2 = got[form][0][:2 * rows]
         if form not in (6, 8):
             assert np.array_equal(k1, k2), (form, int((k1 != k2).sum()))
@@ -554,8 +561,8 @@ def test_both_matrix_core_forms_produce_identical_keys(ctx, n_orb, n_lbd, pairs,
             assert at == rows
             assert np.array_equal(a[is12, 0], b[is12, 0]), (form, int((a[is12, 0] != b[is12, 0]).sum()))
             assert np.array_equal(a[is12, 1] >> 23, b[is12, 1] >> 23), form
-        assert np.array_equal(got[1][2], got[form][2]), form
-        assert np.array_equal(got[1][3], got[form][3]), form
+        assert np.array_equal(got[base][2], got[form][2]), form
+        assert np.array_equal(got[base][3], got[form][3]), form
 
 
 def test_batched_tables_equal_oracle_at_loose_ratio(ctx, oracle):
@@ -763,7 +770,8 @@ def test_lazy_second_keys_with_prior_entries_column_split_and_a_capped_post_grid
     r = np.random.Generator(np.random.PCG64(900 + form))
     try:
         ctx.set_option("scan_variant", plslam_amd.SCAN_MFMA)
-        ctx.set_option("mfma_form", form)
+        if not set_mfma_form(ctx, form):
+            pytest.skip("K1h's scan kernel: not in this build (PLSLAM_BUILD_LEGACY_SCANS=1)")
         for n1, n2 in ((1500, 1400), (3000, 2100), (700, 2600)):
             d1, d2 = synth.random_desc(r, n1), synth.random_desc(r, n2)
             k = min(n1, n2) // 2

@@ -121,8 +121,10 @@ def test_final_isa_has_no_mfma_destination_hazard(tmp_path, fname):
         import pytest
         pytest.skip("hipcc not available")
     out = str(tmp_path / (fname + ".s"))
+    # (-DPLSLAM_BUILD_LEGACY_SCANS=1: K1h's scan kernel is compiled only on request -- plslam_amd/build.py -- and is checked here
+    # all the same, like K1e and K1g, whose files the product build leaves out)
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm",
-                    "-I" + os.path.join(root, "include"),
+                    "-DPLSLAM_BUILD_LEGACY_SCANS=1", "-I" + os.path.join(root, "include"),
                     "-S", "--cuda-device-only", "-o", out, os.path.join(root, "plslam_amd", "csrc", fname)],
                    check=True, capture_output=True)
     spec = importlib.util.spec_from_file_location("check_mfma_hazards", os.path.join(root, "tools", "check_mfma_hazards.py"))
@@ -200,30 +202,32 @@ def test_k1h_workgroup_column_combine_model():
             assert (k1 >> 8) == 511
 
 
-def test_k1h_stays_at_three_workgroups_per_cu(tmp_path):
-    """What K1h's 2.8 ms depend on and a careless edit loses silently: 3 workgroups per CU need <= 168 VGPRs and <= 53 248 B of
-    LDS per workgroup (54 272 B measured 2 workgroups per CU and 3.29 ms), and the spilled registers stay outside the
-    tile loop (16 dwords)."""
+@pytest.mark.parametrize("fname,kernel,max_spill", [("hamming_mfma_i.hip", "k_scan_sym_mfma_i", 8), ("hamming_mfma_h.hip", "k_scan_sym_mfma_h", 16)])
+def test_the_scan_stays_at_three_workgroups_per_cu(tmp_path, fname, kernel, max_spill):
+    """What the scan's time depends on and a careless edit loses silently: 3 workgroups per CU need <= 168 VGPRs and <= 53 248 B
+    of LDS per workgroup -- LDS is handed out in granules of 2 KB, so 54 272 B are 27 granules and TWO workgroups per CU (K1h:
+    3.29 ms; K1i with a fourth slot in its LDS-DMA ring, round 5: 2.84 against 2.52 ms) --, and the spilled registers stay
+    few (they sit outside the tile loops).  K1i is the default scan; K1h's kernel is compiled on request only."""
     import os
     import re
     import subprocess
     from plslam_amd import build as B
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = os.path.join(root, "plslam_amd", "csrc", "hamming_mfma_h.hip")
-    r = subprocess.run([B.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                        "-I" + os.path.join(root, "include"), "-S", "--cuda-device-only", src, "-o", "-"],
+    src = os.path.join(root, "plslam_amd", "csrc", fname)
+    r = subprocess.run([B.hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm",
+                        "-DPLSLAM_BUILD_LEGACY_SCANS=1", "-I" + os.path.join(root, "include"), "-S", "--cuda-device-only", src, "-o", "-"],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-1500:]
     seen = 0
     for blk in r.stdout.split("  - .agpr_count:")[1:]:
         name = re.search(r"\.name:\s+(\S+)", blk).group(1)
-        if "k_scan_sym_mfma_h" not in name:
+        if kernel not in name:
             continue
         seen += 1
         lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1))
         vgpr = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1))
         spill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
-        assert lds <= 53248 and vgpr <= 168 and spill <= 16, (name, lds, vgpr, spill)
+        assert lds <= 53248 and vgpr <= 168 and spill <= max_spill, (name, lds, vgpr, spill)
     assert seen == 2                                       # the symmetric and the directed instantiation
 
 

@@ -16,11 +16,8 @@ from plslam_amd import build as B  # noqa: E402
 
 OBJ = os.path.join(ROOT, "build", "exp", "obj")
 OUT = os.path.join(ROOT, "build", "exp")
-CFLAGS = [f for f in B.FLAGS if f not in ("-shared",)] + ["-I" + os.path.join(ROOT, "include")]
-
-
 def compile_obj(src, out, extra=()):
-    cmd = [B.hipcc_path()] + CFLAGS + list(extra) + ["-c", os.path.join(B.CSRC, src), "-o", out]
+    cmd = [B.hipcc_path()] + B._flags_for(src) + list(extra) + ["-c", os.path.join(B.CSRC, src), "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         raise SystemExit(r.stdout + r.stderr)
@@ -29,12 +26,12 @@ def compile_obj(src, out, extra=()):
 def main():
     study = sys.argv[1]
     os.makedirs(OBJ, exist_ok=True)
-    deps = [os.path.join(B.CSRC, "common.hpp"), os.path.join(ROOT, "include", "plslam_hip.h")]
+    deps = list(B.HEADERS)
     objs = []
-    for s in B.SOURCES:
+    for s in B.sources():
         if s == study:
             continue
-        o = os.path.join(OBJ, s + ".o")
+        o = os.path.join(OBJ, s + (".legacy" if B.legacy_scans() else "") + ".o")
         srcs = [os.path.join(B.CSRC, s)] + deps
         if not os.path.exists(o) or any(os.path.getmtime(x) > os.path.getmtime(o) for x in srcs):
             compile_obj(s, o)
