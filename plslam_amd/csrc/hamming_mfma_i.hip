@@ -76,6 +76,10 @@
 #ifndef PLSLAM_MI_PERSIST
 #define PLSLAM_MI_PERSIST 0
 #endif
+// PLSLAM_MI_PRIO = 1 (default): s_setprio 1 around the tile loops (0 = none)
+#ifndef PLSLAM_MI_PRIO
+#define PLSLAM_MI_PRIO 1
+#endif
 
 namespace plslam {
 
@@ -840,7 +844,14 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         expand_store(raw_first, 0, wt0);           // wt0 is a multiple of 128: buffer parity restarts at 0
         ring_slot = 1024;                          // the slot of tile wt0 + 1
         u32x2_t rb[16];                            // the window's parked pairs, its last group merged in
+        // the tile loops issue ahead of the other waves' per-item phases (prologue, row finish: long VALU and gather stretches
+        // with no matrix instruction in them): measured 2.43-2.46 against 2.49-2.51 ms and 2.52 against 2.58 ms on two boxes;
+        // the other way round (the row finish first, so that the workgroup's slot comes free sooner) and lowering the loops'
+        // own per-item steps (group pushes, column combine) measured no better than no priorities at all
+        // (profiles/r5_c_scan_wave_priorities.txt)
+        if (PLSLAM_MI_PRIO) __builtin_amdgcn_s_setprio(1);
         pipeline(rb);
+        if (PLSLAM_MI_PRIO) __builtin_amdgcn_s_setprio(0);
 #ifdef PLSLAM_MI_PROF
         { const unsigned long long t = PLSLAM_MI_TICK(); prof_loop += t - prof_tl; prof_tl = t; }
 #endif
