@@ -252,10 +252,12 @@ def shard_gather_record(ctx, dev, args, world, rank, pairs_total, wire, comm, st
     if pairs_total % world:
         return {"skipped": f"{pairs_total} pairs do not divide over {world} ranks"}
     st = synth.stereo_stream(Bs, n_orb, n_lbd, seed=synth.SEED0, first_pair=lo)
-    # streams: the [scan stream, stage stream] pair of the headline's matcher.  HIP deals streams to a few hardware queues in
-    # creation order, and a scan stream that lands on its stage stream's queue serialises the two (round 4: 0.84 of the plain
-    # step "for some creation orders"; round 5's first run of this record with streams of its own: stretches of 1.48 / 1.13 /
-    # 1.25 M pairs/s) -- the pair the headline ran on is known to be a good one.
+    # streams: the [scan stream, stage stream] pair of the headline's matcher (N > 1: created after the process group, and known
+    # to be a good pair -- the headline ran on it), or None for a pair of this record's own.  HIP deals streams to a few hardware
+    # queues in creation order, and two of {scan stream, stage stream, the collective's internal stream} on one queue serialise
+    # (round 4: 0.84 of the plain step "for some creation orders"; round 5: this record inside an N > 1 run with streams of its
+    # own gave stretches of 1.48 / 1.13 / 1.25 M pairs/s, and inside the N = 1 run on the headline's OLDER pair -- older than
+    # the process group -- 0.62).  The rule that measured 0.98-0.99 every time: process group first, then the streams.
     bm = frontend.StereoBatchMatcher(ctx, st, nnr_p=args.nnr_p, nnr_l=args.nnr_l, mutual=True, device=dev, n_buffers=2,
                                      geometry=synth.stereo_geometry(st, first_pair=lo), gates=dict(synth.KITTI_GATES),
                                      streams=streams)
@@ -575,17 +577,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
-    # N > 1: BASELINE config 4 AS WRITTEN beside the weak-scaling headline, from the same process group -- ONE batch of 4096
-    # pairs per step sharded over the ranks (512 per GPU at N = 8), gathered with the format the probe chose.  Every rank takes
-    # part; rank 0's (long) verification of the headline's tables comes after it, when no collective is left.  A forced one-rank
-    # group runs config 4's per-GPU shard (512 pairs) instead: the step's own overhead.
-    config4 = None
-    if use_dist and not args.no_secondary:
-        total4 = 4096 if world > 1 else 512
-        note(f"config 4 as written: {total4} pairs per step over {world} rank(s) ...")
-        config4 = shard_gather_record(ctx, dev, args, world, rank, total4, gather_wire["format"], gather_wire["comm"],
-                                      steps=150, warm=10, reps=3, note=note, tag="config4_strong", streams=bm.streams)
-
+    # (before the config-4 record below: rank 0's check of that record is seconds of CPU work, and five launches on a chip that
+    # has idled meanwhile measure its clock ramp -- a forced one-rank run printed 2.65-2.90 ms here for a 2.3 ms kernel)
     # In the timed region consecutive steps overlap on two streams, so a kernel's start-to-end time
     # there includes the share of the GPU the other step's kernels took.  Measure the scan kernel's
     # EXCLUSIVE duration too: a few strictly serial launches, same plan, same data, HIP events.
@@ -601,6 +594,17 @@ def main():
         p0.set_profiling(False)
         excl_scan_ms, excl_fin_ms = a_ / max(n_, 1), b_ / max(n_, 1)
         note(f"exclusive kernel times: scan {excl_scan_ms:.3f} ms, post-scan stages {excl_fin_ms:.3f} ms")
+
+    # N > 1: BASELINE config 4 AS WRITTEN beside the weak-scaling headline, from the same process group -- ONE batch of 4096
+    # pairs per step sharded over the ranks (512 per GPU at N = 8), gathered with the format the probe chose.  Every rank takes
+    # part; rank 0's (long) verification of the headline's tables comes after it, when no collective is left.  A forced one-rank
+    # group runs config 4's per-GPU shard (512 pairs) instead: the step's own overhead.
+    config4 = None
+    if use_dist and not args.no_secondary:
+        total4 = 4096 if world > 1 else 512
+        note(f"config 4 as written: {total4} pairs per step over {world} rank(s) ...")
+        config4 = shard_gather_record(ctx, dev, args, world, rank, total4, gather_wire["format"], gather_wire["comm"],
+                                      steps=150, warm=10, reps=3, note=note, tag="config4_strong", streams=bm.streams)
 
     # full-size determinism check: every output buffer was computed from the same inputs (under
     # overlap / contention), so whole tables and count arrays must be bit-identical
@@ -926,7 +930,10 @@ def secondary_records(ctx, dev, args, note, main_tables=None, streams=None):
             return
         try:
             for tag, wire, comm in tags_wires:
-                rec[tag] = shard_gather_record(ctx, dev, args, 1, 0, pairs, wire, comm, steps, warm, reps, note, tag, streams=streams)
+                # (streams of its own, created AFTER the process group -- the order of an N > 1 run, where the group comes up
+                # before any matcher: with the headline's older stream pair the collective's internal stream can land on the
+                # hardware queue of one of them, and the step then runs at 0.62-0.69 of the plain step instead of 0.98-0.99)
+                rec[tag] = shard_gather_record(ctx, dev, args, 1, 0, pairs, wire, comm, steps, warm, reps, note, tag, streams=None)
                 if "strong_512" in rec and "value" in rec[tag]:
                     rec[tag]["over_strong_512"] = rec[tag]["value"] / rec["strong_512"]["value"]
         finally:

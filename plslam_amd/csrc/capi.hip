@@ -145,6 +145,14 @@ struct plslam_match_plan {
 // n1_dev0 (internal; the map<->keyframe driver's one-synchronisation brute-force form): the row count of problem 0 lives on
 // the device, probs[0].n1 is its upper bound.  Only as a two-launch column-split plan of ONE mutual problem (K1f + k_split_post,
 // which read the count themselves); anything else returns PLSLAM_ENOTSUP and the caller takes its two-synchronisation form.
+// the context-only half of that test (the options the two-launch column-split plan cannot honour): callers ask BEFORE they
+// stage or enqueue anything for the one-synchronisation form (map2kf.hip)
+bool plslam::ctx_takes_device_row_count(const plslam_ctx* ctx)
+{
+    return (ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_MFMA) &&
+           (ctx->mfma_form == 0 || ctx->mfma_form == 2) && ctx->col_split != 1 && ctx->split_post != 1 && ctx->fuse != 2;
+}
+
 static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob,
                       plslam_match_plan* P, const int32_t* n1_dev0 = nullptr)
 {
@@ -179,8 +187,7 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->col_split = ctx->col_split != 1 && (split_auto || split_forced);
     if (n1_dev0) {
         const bool can = nprob == 1 && probs[0].mutual && !probs[0].keep_prior && probs[0].n1 > 0 && probs[0].n2 > 0 &&
-                         (ctx->scan_variant == PLSLAM_SCAN_AUTO || ctx->scan_variant == PLSLAM_SCAN_MFMA) &&
-                         (ctx->mfma_form == 0 || ctx->mfma_form == 2) && ctx->col_split != 1 && ctx->split_post != 1 && ctx->fuse != 2;
+                         ctx_takes_device_row_count(ctx);
         if (!can) return PLSLAM_ENOTSUP;
         P->col_split = true;
     }

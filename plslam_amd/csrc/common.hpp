@@ -332,6 +332,8 @@ int scan_rows_per_block(int variant, int block_threads);
 // enqueues it on the context stream; no synchronisation.  Caller holds ctx->mu.  (capi.hip)
 // n1_dev0: the row count of problem 0 on the device (probs[0].n1 = its bound); PLSLAM_ENOTSUP when the plan cannot take it
 int match_problems_on_ctx_stream(plslam_ctx* ctx, const plslam_match_problem* probs, int32_t nprob, const int32_t* n1_dev0 = nullptr);
+// whether the context's options allow the n1_dev0 form at all (asked before anything is staged or enqueued for it)
+bool ctx_takes_device_row_count(const plslam_ctx* ctx);
 // dst[i] = src[idx[i]] for rows of row_bytes (a multiple of 8) bytes  (map2kf.hip)
 int launch_gather_rows(const void* src, const int32_t* idx, int32_t n, int32_t row_bytes, void* dst,
                        hipStream_t s);

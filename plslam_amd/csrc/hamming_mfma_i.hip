@@ -693,7 +693,10 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             merge2(k0, k1, (e << 16) | (uint32_t)cls, (e & 0xFFFF0000u) | (uint32_t)cls);
         }
 #endif
-        const int row = iw + lane + (lane & 32) * 3;          // lanes 32..63: M-tile 1's rows, 128 further on
+        int row = iw + lane + (lane & 32) * 3;                // lanes 32..63: M-tile 1's rows, 128 further on
+        // (opaque: the row's addresses -- its keys, its descriptor -- are loop-invariant over the windows, and hoisted in front
+        // of the tile loops they live in registers the loops need: the compiler spilled them, 1 KB of scratch per wave)
+        asm volatile("" : "+v"(row));
         if (row < n1) {
             const gu2_t out = (gu2_t) reinterpret_cast<u32x2_t*>(sd.keys12) + row;
             const gcu32x4_t ap = (gcu32x4_t)(araw + (size_t)row * 8);

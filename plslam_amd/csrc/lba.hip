@@ -400,12 +400,16 @@ k_prepare_rows(CamD K, Pose12 Twf, const uint64_t* __restrict__ md, const double
     }
 }
 
-// part: visible_compact_part_words(n) device words, zero when the kernel starts
+// part: visible_compact_part_words(n) device words that must be ZERO when the kernel starts (its workgroups chain their counts
+// through them; a stale word gives wrong offsets).  part_zeroed = true: the caller's upload image has just written the zeros
+// on this stream (the drivers: no extra operation on their latency path); false: they are cleared here.
 size_t visible_compact_part_words(int32_t n) { return (size_t)(n > 0 ? (n + VC_NT - 1) / VC_NT : 1); }
 int launch_visible_compact(const plslam_cam& K, const double* Twf16, const double* X, const uint8_t* cand, int32_t n, int lines,
-                           int32_t* idx, int32_t* n_out, int32_t* fill, GridDesc* desc, uint32_t* part, hipStream_t s)
+                           int32_t* idx, int32_t* n_out, int32_t* fill, GridDesc* desc, uint32_t* part, bool part_zeroed,
+                           hipStream_t s)
 {
     const unsigned nb = (unsigned)visible_compact_part_words(n);
+    if (!part_zeroed) PLSLAM_HIP_CHECK(hipMemsetAsync(part, 0, sizeof(uint32_t) * nb, s));
     hipLaunchKernelGGL(k_visible_compact, dim3(nb), dim3(VC_NT), 0, s, cam_d(K), pose12(Twf16), X, cand, n, lines, idx, n_out, fill,
                        desc, part);
     PLSLAM_HIP_CHECK(hipGetLastError());

@@ -32,7 +32,7 @@ int launch_gate_n(int lines, const plslam_cam& K, const double* Twf16, const dou
 // matchGrid descriptor); Q rows + landmarks + window centres of the listed landmarks
 size_t visible_compact_part_words(int32_t n);       // zeroed device words the kernel's workgroups chain their counts through
 int launch_visible_compact(const plslam_cam& K, const double* Twf16, const double* X, const uint8_t* cand, int32_t n, int lines,
-                           int32_t* idx, int32_t* n_out, int32_t* fill, GridDesc* desc, uint32_t* part, hipStream_t s);
+                           int32_t* idx, int32_t* n_out, int32_t* fill, GridDesc* desc, uint32_t* part, bool part_zeroed, hipStream_t s);
 int launch_prepare_rows(const plslam_cam& K, const double* Twf16, const void* md, const double* lm, const int32_t* idx,
                         const int32_t* n_dev, int32_t n_max, int lines, double inv_w, double inv_h, void* Q, double* QL, int32_t* cells,
                         double* dir1, hipStream_t s);
@@ -305,7 +305,7 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image, hipMemcpyHostToDevice, s));
     // ---- the launch sequence (five launches: the small steps are fused -- a launch of a microsecond's work costs 4-5 us)
     if ((rc = launch_visible_compact(*K, Twf, (const double*)d_LM, d_cand, n_map, lines, (int32_t*)(d + oQi), res + 1,
-                                     (int32_t*)(d + oMap), (GridDesc*)(d + oDesc), (uint32_t*)(d + oPart), s)))
+                                     (int32_t*)(d + oMap), (GridDesc*)(d + oDesc), (uint32_t*)(d + oPart), /* zeroed by the image above */ true, s)))
         return rc;
     if ((rc = launch_prepare_rows(*K, Twf, d_MD, (const double*)d_LM, (const int32_t*)(d + oQi), res + 1, n_map, lines, fm->inv_width,
                                   fm->inv_height, d + oQ, (double*)(d + oQL), (int32_t*)(d + oCen), lines ? (double*)(d + oD1) : nullptr, s)))
@@ -355,8 +355,9 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
 // device memory (SymDesc::n1_dev: workgroups behind the last row leave at once), the gate and the association read it too.  The
 // one host decision that needs nq -- match() runs only if |Q| > min_matches -- is applied after the results are back (the
 // matcher's table is then simply not used: every entry of map_to_kf stays -1, as when no matcher ran).  *done = 0: the plan
-// cannot take a device-side row count under the context's options (or the problem is not mutual) -- nothing was enqueued, the
-// caller runs the step-by-step form.  Caller holds ctx->mu.
+// cannot take a device-side row count under the context's options (or the problem is not mutual) -- asked FIRST
+// (ctx_takes_device_row_count), so nothing is staged, uploaded or enqueued -- and the caller runs the step-by-step form.
+// Caller holds ctx->mu.
 int map2kf_bf_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* Twf, const double* LM, const uint8_t* med_desc,
                    const uint8_t* candidate, int32_t n_map, const uint8_t* kf_desc, const double* kf_feat,
                    const std::vector<int32_t>& ti, float nnr, int mutual, double max_epip, int32_t min_matches,
@@ -364,6 +365,7 @@ int map2kf_bf_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const double
 {
     *done = 0;
     if (!mutual || n_map > PLSLAM_MAX_TRAIN_ROWS) return PLSLAM_OK;       // (the plan is sized for the bound n_map, not for |Q|)
+    if (!ctx_takes_device_row_count(ctx) || n_map <= 0 || ti.empty()) return PLSLAM_OK;   // (before anything is staged or enqueued)
     hipStream_t s = ctx->stream;
     StreamSyncOnError sg(s);
     int rc;
@@ -408,13 +410,15 @@ int map2kf_bf_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const double
     memset(h + oPart, 0, visible_compact_part_words(n_map) * 4);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image, hipMemcpyHostToDevice, s));
     if ((rc = launch_visible_compact(*K, Twf, (const double*)d_LM, d_cand, n_map, lines, (int32_t*)(d + oQi), res + 1,
-                                     (int32_t*)(d + oMap), nullptr, (uint32_t*)(d + oPart), s)))
+                                     (int32_t*)(d + oMap), nullptr, (uint32_t*)(d + oPart), /* zeroed by the image above */ true, s)))
         return rc;
     if ((rc = launch_prepare_rows(*K, Twf, d_MD, (const double*)d_LM, (const int32_t*)(d + oQi), res + 1, n_map, lines, 0.0, 0.0,
                                   d + oQ, (double*)(d + oQL), nullptr, nullptr, s)))
         return rc;
     rc = match_problems_on_ctx_stream(ctx, &p, 1, res + 1);              // :597 / :712
-    if (rc == PLSLAM_ENOTSUP) {                                          // (what is in flight is harmless: scratch only)
+    if (rc == PLSLAM_ENOTSUP) {
+        // (cannot happen after the test at the top -- the plan's own refusals are the context's options --; if it ever does, what
+        // is in flight writes scratch only: wait for it and let the caller take the step-by-step form)
         PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
         sg.dismiss();
         return PLSLAM_OK;
