@@ -211,8 +211,47 @@ def lba_iterate(ctx, O):
     if plan.iterate_resident() != err:
         raise SystemExit("secondary record lba_iterate: the resident iteration's error differs")
     resident = _pct(_wall(plan.iterate_resident, 30))["us_median"]
+    # the Schur step on the resident blocks (round 5): the reduced 54 x 54 camera system down, the pose step up, the landmark
+    # steps on the device.  Checked against a float64 numpy Schur complement of the downloaded blocks, the full step against
+    # the block equations themselves (every landmark's own row of the damped system).
+    nkf, npt, nls, lam = 9, 10000, 2000, 1e-3
+    n6 = 6 * nkf
+    Bk = plan.blocks()
+    S, b, nsing = plan.schur(lam)
+    dp = np.linalg.solve(S, b)
+    dxp, dxl = plan.backsub(dp)
+    pkf, lkf = lm["pt_kf"] - 1, lm["ls_kf"] - 1
+    resid_p = np.einsum("jab,jb->ja", Bk["H_pt"] * (1 + lam * np.eye(3))[None], dxp) - Bk["g"][n6:n6 + 3 * npt].reshape(npt, 3)
+    resid_l = np.einsum("jab,jb->ja", Bk["H_ls"] * (1 + lam * np.eye(6))[None], dxl) - Bk["g"][n6 + 3 * npt:].reshape(nls, 6)
+    resid_c = np.einsum("kab,kb->ka", Bk["H_pose"] * (1 + lam * np.eye(6))[None], dp.reshape(nkf, 6)) - Bk["g"][:n6].reshape(nkf, 6)
+    for o in np.nonzero(pkf >= 0)[0]:
+        resid_p[lm["pt_lm"][o]] += Bk["W_pt"][o] @ dp[6 * pkf[o]:6 * pkf[o] + 6]
+        resid_c[pkf[o]] += Bk["W_pt"][o].T @ dxp[lm["pt_lm"][o]]
+    for o in np.nonzero(lkf >= 0)[0]:
+        resid_l[lm["ls_lm"][o]] += Bk["W_ls"][o] @ dp[6 * lkf[o]:6 * lkf[o] + 6]
+        resid_c[lkf[o]] += Bk["W_ls"][o].T @ dxl[lm["ls_lm"][o]]
+    scale = float(np.abs(Bk["g"]).max())
+    worst = max(float(np.abs(resid_p).max()), float(np.abs(resid_l).max()), float(np.abs(resid_c).max())) / scale
+    if nsing != 0 or not worst < 1e-8:
+        raise SystemExit(f"secondary record lba_iterate: the Schur step does not solve the damped block system (residual {worst:.2e} of |g|max, "
+                         f"{nsing} singular landmark blocks)")
+    schur_us = _pct(_wall(lambda: plan.schur(lam), 30))["us_median"]
+    back_us = _pct(_wall(lambda: plan.backsub(dp, apply=False, want=False), 30))["us_median"]
+
+    def lm_iteration():
+        plan.iterate_resident()
+        S_, b_, _ = plan.schur(lam)
+        plan.backsub(np.linalg.solve(S_, b_), apply=False, want=False)
+    whole_us = _pct(_wall(lm_iteration, 30))["us_median"]
     plan.close()
     return dict(_pct(ts), err_only_us_median=err_only, state_resident_us_median=resident,
+                schur_step={"schur_us_median": schur_us, "backsub_us_median": back_us, "lm_iteration_blocks_resident_us_median": whole_us,
+                            "reduced_system": f"{n6} x {n6}", "lambda": lam, "residual_of_the_damped_system_over_gmax": worst,
+                            "what": "plslam_lba_plan_schur (landmark inverses, reduced system S, b: 29 kB down) / plslam_lba_plan_backsub "
+                                    "(pose step up, landmark steps on the device) / one whole LM iteration with the state and the blocks "
+                                    "resident: iterate_resident + schur + the host's dense solve of S + backsub (mapHandler.cpp:1544-1575)",
+                            "verified": "the step (dp, dX) satisfies every block row of the damped normal equations assembled from the "
+                                        "downloaded blocks to 1e-8 of max |g|"},
                 workload="one Levenberg-Marquardt iteration of MapHandler::levMarquardtOptimizationLBA at C3 sizes "
                          "(mapHandler.cpp:1358-1540 rows + :1410-1429, :1519-1538 block assembly; N = 42 054): poses and landmarks "
                          "uploaded (0.34 MB, one copy), three launches (rows + cross blocks + error partials | landmark blocks + "

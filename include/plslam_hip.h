@@ -530,6 +530,28 @@ typedef struct plslam_lba_state {
 } plslam_lba_state;
 int plslam_lba_plan_device_state(plslam_lba_plan* plan, plslam_lba_state* out);
 int plslam_lba_plan_iterate_resident(plslam_lba_plan* plan, int compat_flags, double* err);
+/* The Schur step on the resident blocks (round 5) -- the solve of src/mapHandler.cpp:1544-1575 (and :1779-1800 in the loop)
+ * with everything but a 6 nkf x 6 nkf system staying on the device.  The reference damps H(i,i) += lambda * H(i,i) and solves
+ * the whole N x N system with a sparse LDLT; the landmark blocks of H are independent, so the same step is
+ *     S dp = b,  S = Hpp' - sum_j Wj^T Vj'^-1 Wj,  b = gp - sum_j Wj^T Vj'^-1 gj,  dxj = Vj'^-1 (gj - Wj dp)
+ * (Hpp', Vj': the damped pose / landmark blocks; Wj: the cross blocks of landmark j's observations).  All three calls work on
+ * the blocks of the LAST plslam_lba_plan_iterate / _iterate_dev / _iterate_resident of the plan.
+ *   plslam_lba_plan_diag_max   *hmax = max |H(i,i)| over all N diagonal entries (the reference's "lambda *= Hmax", :1544-1550)
+ *   plslam_lba_plan_schur      S (6 nkf x 6 nkf doubles, row-major, both triangles) and b (6 nkf) for the damping `lambda`;
+ *                              *n_singular (may be NULL) = landmarks whose damped block is not positive definite (a zero
+ *                              diagonal entry: no observation constrains that coordinate) -- they contribute nothing and get
+ *                              a zero step.  Deterministic: fixed-shape sums, no atomics.
+ *   plslam_lba_plan_backsub    the landmark steps for the pose step dpose (6 nkf doubles, the solution of S dp = b that the
+ *                              host's dense LDLT found): dX_pt (npt x 3) / dX_ls (nls x 6), either may be NULL; apply != 0
+ *                              also adds them to the resident Xw / Lw in place (X(i) += DX(i), :1570-1575).  Needs the
+ *                              plslam_lba_plan_schur of the same blocks before it (its landmark inverses are reused).
+ *   plslam_lba_plan_set_poses  uploads the poses alone (n_pose_slots x 16 doubles): the caller applies dp to them
+ *                              (T <- T inv(exp(dp)), :1560-1566: the SE(3) maps stay on the host) -- after which
+ *                              plslam_lba_plan_iterate_resident runs the next iteration with nothing else crossing PCIe. */
+int plslam_lba_plan_diag_max(plslam_lba_plan* plan, double* hmax);
+int plslam_lba_plan_schur(plslam_lba_plan* plan, double lambda, double* S, double* b, int32_t* n_singular);
+int plslam_lba_plan_backsub(plslam_lba_plan* plan, const double* dpose, int apply, double* dX_pt, double* dX_ls);
+int plslam_lba_plan_set_poses(plslam_lba_plan* plan, const double* T_kf_w);
 /* rows of the last iterate() (any pointer may be NULL), e.g. for the write-back logic of :1822-1855 */
 int plslam_lba_plan_rows(plslam_lba_plan* plan, double* pt_J_pose, double* pt_J_lm, double* pt_r, double* pt_w,
                          double* ls_J_pose, double* ls_J_lm, double* ls_r, double* ls_w);

@@ -35,7 +35,8 @@ ABI_SYMBOLS = (
     "plslam_lba_point_rows", "plslam_lba_line_rows", "plslam_lba_point_rows_dev",
     "plslam_lba_line_rows_dev", "plslam_lba_assemble", "plslam_lba_plan_create", "plslam_lba_plan_iterate",
     "plslam_lba_plan_rows", "plslam_lba_plan_destroy", "plslam_lba_plan_iterate_dev", "plslam_lba_plan_device_blocks", "plslam_lba_plan_device_state",
-    "plslam_lba_plan_iterate_resident",
+    "plslam_lba_plan_iterate_resident", "plslam_lba_plan_diag_max", "plslam_lba_plan_schur", "plslam_lba_plan_backsub",
+    "plslam_lba_plan_set_poses",
     "plslam_lba_plan_blocks",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
@@ -211,6 +212,10 @@ def load() -> C.CDLL:
     L.plslam_lba_plan_device_blocks.argtypes = [vp, vp]
     L.plslam_lba_plan_device_state.argtypes = [vp, vp]
     L.plslam_lba_plan_iterate_resident.argtypes = [vp, C.c_int, vp]
+    L.plslam_lba_plan_diag_max.argtypes = [vp, vp]
+    L.plslam_lba_plan_schur.argtypes = [vp, C.c_double, vp, vp, vp]
+    L.plslam_lba_plan_backsub.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.plslam_lba_plan_set_poses.argtypes = [vp, vp]
     L.plslam_lba_plan_blocks.argtypes = [vp] * 8
     L.plslam_lba_plan_destroy.argtypes = [vp]
     L.plslam_lba_plan_destroy.restype = None
@@ -810,6 +815,35 @@ class LbaPlan:
         err = np.empty(1)
         _check(self._L.plslam_lba_plan_iterate_resident(self._h, int(compat_flags), _p(err)), "plslam_lba_plan_iterate_resident")
         return float(err[0])
+
+    def diag_max(self) -> float:
+        """max |H(i,i)| over the blocks of the last iteration (the reference's lambda *= Hmax)."""
+        h = np.empty(1)
+        _check(self._L.plslam_lba_plan_diag_max(self._h, _p(h)), "plslam_lba_plan_diag_max")
+        return float(h[0])
+
+    def schur(self, lam: float):
+        """The reduced camera system of the last iteration's blocks for the damping `lam` -> (S (6 nkf, 6 nkf), b (6 nkf),
+        number of singular landmark blocks)."""
+        nkf = self.dims[0]
+        S, b, ns = np.empty((6 * nkf, 6 * nkf)), np.empty(6 * nkf), np.zeros(1, np.int32)
+        _check(self._L.plslam_lba_plan_schur(self._h, float(lam), _p(S), _p(b), _p(ns)), "plslam_lba_plan_schur")
+        return S, b, int(ns[0])
+
+    def backsub(self, dpose, apply=False, want=True):
+        """The landmark steps for the pose step `dpose` -> (dX_pt (npt, 3), dX_ls (nls, 6)) or None; apply=True also adds them
+        to the resident landmarks."""
+        nkf, npt, nls = self.dims[:3]
+        dp = _arr(dpose, np.float64, (6 * nkf,))
+        dxp, dxl = (np.empty((npt, 3)), np.empty((nls, 6))) if want else (None, None)
+        _check(self._L.plslam_lba_plan_backsub(self._h, _p(dp), int(bool(apply)), _p(dxp) if want else None,
+                                               _p(dxl) if want else None), "plslam_lba_plan_backsub")
+        return (dxp, dxl) if want else None
+
+    def set_poses(self, T_kf_w) -> None:
+        T = _arr(T_kf_w, np.float64, (-1, 16))
+        assert T.shape[0] == self.dims[5]
+        _check(self._L.plslam_lba_plan_set_poses(self._h, _p(T)), "plslam_lba_plan_set_poses")
 
     def device_state(self) -> dict:
         """Device pointers (ints) of T_kf_w / Xw / Lw, their row counts and the plan's HIP stream."""

@@ -509,6 +509,15 @@ struct plslam_lba_plan {
     HostBuf pin_in, pin_out;
     size_t dyn_bytes = 0;
     bool state_valid = false;      // T / Xw / Lw have been uploaded at least once (iterate_resident needs them)
+    bool blocks_valid = false;     // an iteration has left H / g / W on the device (the Schur step consumes them)
+    // ---- the Schur step (round 5): pair lists built on first use from these host copies of the observation lists
+    CsrLists csr;
+    std::vector<int32_t> h_pt_kf, h_ls_kf;
+    DevBuf schur;
+    HostBuf schur_pin;
+    bool schur_ready = false, schur_done = false;
+    int32_t nblk = 0, schur_chunks = 0;
+    size_t oSpair = 0, oSblk = 0, oVp = 0, oVl = 0, oTp = 0, oTl = 0, oSpart = 0, oBpart = 0, oS = 0, oDp = 0, oDx = 0, oSing = 0;
 };
 
 extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, double homog_th, int32_t n_pose_slots,
@@ -533,8 +542,10 @@ extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, doub
     PLSLAM_REQUIRE(P != nullptr, PLSLAM_ENOMEM);
     P->ctx = ctx; P->cam = *K; P->th = homog_th; P->n_slots = n_pose_slots; P->nkf = nkf; P->npt = npt; P->nls = nls;
     P->np = n_pt_obs; P->nl = n_ls_obs;
-    CsrLists c;
+    CsrLists& c = P->csr;
     build_csr(pt_lm_loc, pt_kf_loc, n_pt_obs, ls_lm_loc, ls_kf_loc, n_ls_obs, nkf, npt, nls, c);
+    if (n_pt_obs) P->h_pt_kf.assign(pt_kf_loc, pt_kf_loc + n_pt_obs);
+    if (n_ls_obs) P->h_ls_kf.assign(ls_kf_loc, ls_kf_loc + n_ls_obs);
     const size_t np = (size_t)n_pt_obs, nl = (size_t)n_ls_obs;
     Carve cs;
     P->oPlm = cs.take(np * 4); P->oPslot = cs.take(np * 4); P->oPkf = cs.take(np * 4); P->oPuv = cs.take(np * 16);
@@ -639,6 +650,8 @@ static int lba_plan_enqueue(plslam_lba_plan* P, const double* T_kf_w, const doub
         hipLaunchKernelGGL(k_lba_blocks, dim3(B.nb3 + B.nb6 + nchunk_wgs), dim3(256), 0, s, B);
     hipLaunchKernelGGL(k_lba_finish, dim3(P->nkf + 1), dim3(256), 0, s, B);
     PLSLAM_HIP_CHECK(hipGetLastError());
+    P->blocks_valid = true;
+    P->schur_done = false;             // (the blocks have changed: the landmark inverses of an earlier Schur step are stale)
     return PLSLAM_OK;
 }
 
@@ -781,6 +794,7 @@ extern "C" void plslam_lba_plan_destroy(plslam_lba_plan* P)
     if (!P) return;
     (void)hipStreamSynchronize(P->ctx->stream);
     P->stat.release(); P->dyn.release(); P->rows.release(); P->out.release(); P->pin_in.release(); P->pin_out.release();
+    P->schur.release(); P->schur_pin.release();
     delete P;
 }
 
@@ -856,5 +870,485 @@ extern "C" int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, in
         (rc = down(err, oErr, 8)))
         return rc;
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    return PLSLAM_OK;
+}
+
+
+// =============================================================================================================================
+// The Schur step on the resident blocks (round 5) -- the consumer of plslam_lba_plan_iterate_dev / _resident.
+//
+// The reference solves the damped normal equations whole: H(i,i) += lambda * H(i,i), H.sparseView(), SimplicialLDLT
+// (src/mapHandler.cpp:1552-1556; :1779-1783 in the loop) -- N = 6 Nkf + 3 Npt + 6 Nls unknowns, 42 054 at C3.  H has the block
+// structure this file already produces, and the landmark blocks are independent of each other, so the same system is
+//     S dp = b,   S = Hpp' - sum_j Wj^T Vj'^-1 Wj,   b = gp - sum_j Wj^T Vj'^-1 gj,   dxj = Vj'^-1 (gj - Wj dp)
+// with Hpp' / Vj' the damped pose / landmark blocks and Wj the cross blocks of landmark j's observations: 6 Nkf unknowns (60 at
+// C3) for the host's dense LDLT, everything else stays on the device.  What crosses PCIe per iteration is S and b down (29 kB at
+// C3) and dp up (480 B) instead of 11.5 MB of blocks.  Algebraically the reference's solve; numerically equal to rounding
+// (tests/test_gpu_lba.py compares with a dense solve of the assembled system).
+//
+// No atomics, nothing scheduling-dependent (as everywhere in this file): the pairs (o1, o2) of observations of one landmark that
+// fall into block (k1 <= k2) of S are listed ONCE per plan on the host, sorted by block; a block's sum is a fixed-shape two-level
+// sum -- chunks of SCH_CHUNK pairs sequentially in list order, then the chunk partials in chunk order -- and the lower triangle
+// is the mirror of the upper one.
+//   K19 k_schur_landmarks<DL>   a lane per landmark: Vj' inverse (closed form 3x3 / Gauss-Jordan 6x6), tj = Vj'^-1 gj
+//   K20 k_schur_partials        a lane per (block, chunk, entry of the 6x6 block): sum over the chunk's pairs of W1^T Vinv W2
+//   K21 k_schur_b_partials      a lane per (keyframe, chunk, entry of b): sum over the chunk's observations of W^T tj
+//   K22 k_schur_finish          a lane per (block, entry) / (keyframe, entry): chunk partials -> S (both triangles), b
+//   K23 k_schur_backsub<DL>     a lane per landmark: dxj = tj - Vinv_j sum_o W_o dp[kf(o)]  (+ the update of Xw / Lw in place)
+//   K24 k_lba_diag_max          max |H(i,i)| over all diagonal entries (the reference's lambda *= Hmax, :1544-1550)
+// =============================================================================================================================
+namespace plslam {
+
+constexpr int SCH_CHUNK = 64;
+struct SchurPair { int32_t o1, o2, lm, line; };     // observation ids within their own list (points / lines), the landmark
+
+template <int DL>
+__global__ void __launch_bounds__(256)
+k_schur_landmarks(const double* __restrict__ H, const double* __restrict__ g, int32_t n, double lambda,
+                  double* __restrict__ Vinv, double* __restrict__ t, int32_t* __restrict__ nsing)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double A[DL][DL], I[DL][DL];
+#pragma unroll
+    for (int a = 0; a < DL; ++a)
+#pragma unroll
+        for (int b = 0; b < DL; ++b) {
+            const double h = H[(size_t)j * DL * DL + a * DL + b];
+            A[a][b] = a == b ? h + lambda * h : h;
+            I[a][b] = a == b ? 1.0 : 0.0;
+        }
+    // Gauss-Jordan without pivoting (the damped block is symmetric positive definite whenever its diagonal is positive);
+    // a pivot that is not positive marks the landmark as singular: no step, no contribution (Vinv = 0, t = 0)
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < DL; ++c) {
+        const double piv = A[c][c];
+        ok = ok && piv > 0.0;
+        const double ip = 1.0 / (piv > 0.0 ? piv : 1.0);
+#pragma unroll
+        for (int b = 0; b < DL; ++b) { A[c][b] *= ip; I[c][b] *= ip; }
+#pragma unroll
+        for (int a = 0; a < DL; ++a) {
+            if (a == c) continue;
+            const double f = A[a][c];
+#pragma unroll
+            for (int b = 0; b < DL; ++b) { A[a][b] -= f * A[c][b]; I[a][b] -= f * I[c][b]; }
+        }
+    }
+    double gj[DL];
+#pragma unroll
+    for (int a = 0; a < DL; ++a) gj[a] = g[(size_t)j * DL + a];
+#pragma unroll
+    for (int a = 0; a < DL; ++a) {
+        double acc = 0.0;
+#pragma unroll
+        for (int b = 0; b < DL; ++b) {
+            const double v = ok ? I[a][b] : 0.0;
+            Vinv[(size_t)j * DL * DL + a * DL + b] = v;
+            acc += v * gj[b];
+        }
+        t[(size_t)j * DL + a] = acc;
+    }
+    if (!ok) atomicAdd(nsing, 1);              // (a count only: no sum depends on it)
+}
+
+// W_pt[o]: 3 x 6 (landmark row x, pose column a), W_ls[o]: 6 x 6.  Entry (a, b) of W1^T Vinv W2 = sum_x sum_y W1[x][a] Vinv[x][y] W2[y][b].
+// A workgroup = one chunk of SCH_CHUNK pairs: lane i computes the whole 6 x 6 contribution of pair i (its loads are one round
+// trip: a first form with a lane per entry walking the chunk was a chain of 64 dependent round trips, 177 us per call at C3),
+// parks it in LDS, and lane e < 36 adds the 64 values of entry e SEQUENTIALLY in pair order -- the same sum, term for term.
+template <int DL>
+__device__ __forceinline__ void schur_pair_block(const double* __restrict__ W1, const double* __restrict__ W2,
+                                                 const double* __restrict__ V, double* __restrict__ out /* [36], stride 1 */)
+{
+    double w1[DL * 6], w2[DL * 6], v[DL * DL];
+#pragma unroll
+    for (int i = 0; i < DL * 6; ++i) { w1[i] = W1[i]; w2[i] = W2[i]; }
+#pragma unroll
+    for (int i = 0; i < DL * DL; ++i) v[i] = V[i];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        double u[DL];
+#pragma unroll
+        for (int x = 0; x < DL; ++x) {
+            double t = 0.0;
+#pragma unroll
+            for (int y = 0; y < DL; ++y) t += v[x * DL + y] * w2[y * 6 + b];
+            u[x] = t;
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int x = 0; x < DL; ++x) sacc += w1[x * 6 + a] * u[x];
+            out[a * 6 + b] = sacc;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(SCH_CHUNK)
+k_schur_partials(const SchurPair* __restrict__ pairs, const int32_t* __restrict__ blk_ptr, const double* __restrict__ W_pt,
+                 const double* __restrict__ W_ls, const double* __restrict__ Vp, const double* __restrict__ Vl,
+                 int32_t max_chunks, double* __restrict__ part /* [nblk][max_chunks][36] */)
+{
+    __shared__ double tile[SCH_CHUNK][37];
+    const int B = blockIdx.x, c = blockIdx.y, i = threadIdx.x;
+    const int beg = blk_ptr[B] + c * SCH_CHUNK;
+    const int end = beg + SCH_CHUNK < blk_ptr[B + 1] ? beg + SCH_CHUNK : blk_ptr[B + 1];
+    const int n = end - beg;                       // <= 0: the block has fewer chunks than the grid is wide
+    if (n <= 0) return;
+    if (i < n) {
+        const SchurPair q = pairs[beg + i];
+        double blk[36];
+        if (!q.line) schur_pair_block<3>(W_pt + (size_t)q.o1 * 18, W_pt + (size_t)q.o2 * 18, Vp + (size_t)q.lm * 9, blk);
+        else schur_pair_block<6>(W_ls + (size_t)q.o1 * 36, W_ls + (size_t)q.o2 * 36, Vl + (size_t)q.lm * 36, blk);
+#pragma unroll
+        for (int e = 0; e < 36; ++e) tile[i][e] = blk[e];
+    }
+    __syncthreads();
+    if (i < 36) {
+        double acc = 0.0;
+        for (int k = 0; k < n; ++k) acc += tile[k][i];
+        part[((size_t)B * max_chunks + c) * 36 + i] = acc;
+    }
+}
+
+// b's share of keyframe k: sum over its observations (the keyframe lists of the assembly: points first, then lines) of W_o^T t_lm
+// -- a lane per observation of the chunk, then six lanes add the chunk's terms sequentially in list order
+__global__ void __launch_bounds__(POSE_CHUNK)
+k_schur_b_partials(const int32_t* __restrict__ kf_ptr, const int32_t* __restrict__ kf_obs, int32_t n_pt_obs,
+                   const int32_t* __restrict__ pt_lm, const int32_t* __restrict__ ls_lm, const double* __restrict__ W_pt,
+                   const double* __restrict__ W_ls, const double* __restrict__ tp, const double* __restrict__ tl,
+                   int32_t max_chunks, double* __restrict__ part /* [nkf][max_chunks][6] */)
+{
+    __shared__ double tile[POSE_CHUNK][7];
+    const int k = blockIdx.x, c = blockIdx.y, i = threadIdx.x;
+    const int beg = kf_ptr[k] + c * POSE_CHUNK;
+    const int end = beg + POSE_CHUNK < kf_ptr[k + 1] ? beg + POSE_CHUNK : kf_ptr[k + 1];
+    const int n = end - beg;
+    if (n <= 0) return;
+    if (i < n) {
+        const int o = kf_obs[beg + i];
+        if (o < n_pt_obs) {
+            const double* W = W_pt + (size_t)o * 18;
+            const double* t = tp + (size_t)pt_lm[o] * 3;
+            const double t0 = t[0], t1 = t[1], t2 = t[2];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) tile[i][a] = W[0 * 6 + a] * t0 + W[1 * 6 + a] * t1 + W[2 * 6 + a] * t2;
+        } else {
+            const int ol = o - n_pt_obs;
+            const double* W = W_ls + (size_t)ol * 36;
+            const double* t = tl + (size_t)ls_lm[ol] * 6;
+            double tt[6];
+#pragma unroll
+            for (int x = 0; x < 6; ++x) tt[x] = t[x];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int x = 0; x < 6; ++x) sacc += W[x * 6 + a] * tt[x];
+                tile[i][a] = sacc;
+            }
+        }
+    }
+    __syncthreads();
+    if (i < 6) {
+        double acc = 0.0;
+        for (int q = 0; q < n; ++q) acc += tile[q][i];
+        part[((size_t)k * max_chunks + c) * 6 + i] = acc;
+    }
+}
+
+// block B = (k1 <= k2) in row-major upper-triangle order; S is (6 nkf) x (6 nkf) row-major, b follows it
+__global__ void __launch_bounds__(64)
+k_schur_finish(const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ kf_ptr, const double* __restrict__ spart,
+               const double* __restrict__ bpart, const double* __restrict__ H_pose, const double* __restrict__ g_pose,
+               int32_t nkf, int32_t nblk, int32_t schur_chunks, int32_t pose_chunks, double lambda, double* __restrict__ S,
+               double* __restrict__ bvec)
+{
+    const int B = blockIdx.x, e = threadIdx.x;
+    const int n6 = 6 * nkf;
+    if (B < nblk) {
+        if (e >= 36) return;
+        int k1 = 0, rem = B;                       // B = offset(k1) + (k2 - k1), offset(k1) = sum_{i < k1} (nkf - i)
+        while (rem >= nkf - k1) { rem -= nkf - k1; ++k1; }
+        const int k2 = k1 + rem, a = e / 6, b = e % 6;
+        const int nch = (blk_ptr[B + 1] - blk_ptr[B] + SCH_CHUNK - 1) / SCH_CHUNK;
+        // (the chunk partials are added in chunk order; their loads go out eight at a time -- one by one they are a chain of
+        // round trips)
+        double acc = 0.0;
+        for (int c0 = 0; c0 < nch; c0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = c0 + u < nch ? spart[((size_t)B * schur_chunks + c0 + u) * 36 + e] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (c0 + u < nch) acc += v[u];
+        }
+        double h = 0.0;
+        if (k1 == k2) {
+            h = H_pose[(size_t)k1 * 36 + e];
+            if (a == b) h += lambda * h;
+        }
+        const double v = h - acc;
+        S[(size_t)(6 * k1 + a) * n6 + 6 * k2 + b] = v;
+        if (k1 != k2) S[(size_t)(6 * k2 + b) * n6 + 6 * k1 + a] = v;
+    } else {
+        const int k = B - nblk;
+        if (e >= 6) return;
+        const int nch = (kf_ptr[k + 1] - kf_ptr[k] + POSE_CHUNK - 1) / POSE_CHUNK;
+        double acc = 0.0;
+        for (int c0 = 0; c0 < nch; c0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = c0 + u < nch ? bpart[((size_t)k * pose_chunks + c0 + u) * 6 + e] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (c0 + u < nch) acc += v[u];
+        }
+        bvec[6 * k + e] = g_pose[6 * k + e] - acc;
+    }
+}
+
+template <int DL>
+__global__ void __launch_bounds__(256)
+k_schur_backsub(const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_obs, const int32_t* __restrict__ kf_loc,
+                int32_t n, const double* __restrict__ W, const double* __restrict__ Vinv, const double* __restrict__ t,
+                const double* __restrict__ dp, double* __restrict__ dx, double* __restrict__ X /* nullptr: do not apply */)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= n) return;
+    double acc[DL];
+#pragma unroll
+    for (int x = 0; x < DL; ++x) acc[x] = 0.0;
+    for (int i = lm_ptr[j]; i < lm_ptr[j + 1]; ++i) {
+        const int o = lm_obs[i], k = kf_loc[o];
+        if (k < 0) continue;                       // a fixed keyframe: no cross block, no step
+        const double* Wo = W + (size_t)o * DL * 6;
+#pragma unroll
+        for (int x = 0; x < DL; ++x) {
+            double s = 0.0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) s += Wo[x * 6 + a] * dp[6 * k + a];
+            acc[x] += s;
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < DL; ++x) {
+        double s = 0.0;
+#pragma unroll
+        for (int y = 0; y < DL; ++y) s += Vinv[(size_t)j * DL * DL + x * DL + y] * acc[y];
+        const double d = t[(size_t)j * DL + x] - s;
+        dx[(size_t)j * DL + x] = d;
+        if (X) X[(size_t)j * DL + x] += d;         // :1570-1575 "update point / line LMs": X(i) += DX(i)
+    }
+}
+
+// max over all diagonal entries of |H(i,i)| (a maximum: exact whatever the order)
+__global__ void __launch_bounds__(256)
+k_lba_diag_max(const double* __restrict__ H_pose, int32_t nkf, const double* __restrict__ H_pt, int32_t npt,
+               const double* __restrict__ H_ls, int32_t nls, double* __restrict__ out)
+{
+    __shared__ double red[256];
+    double m = 0.0;
+    const int total = 6 * nkf + 3 * npt + 6 * nls;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        double v;
+        if (i < 6 * nkf) v = H_pose[(size_t)(i / 6) * 36 + (i % 6) * 7];
+        else if (i < 6 * nkf + 3 * npt) { const int q = i - 6 * nkf; v = H_pt[(size_t)(q / 3) * 9 + (q % 3) * 4]; }
+        else { const int q = i - 6 * nkf - 3 * npt; v = H_ls[(size_t)(q / 6) * 36 + (q % 6) * 7]; }
+        v = fabs(v);
+        m = v > m ? v : m;
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] = red[threadIdx.x] > red[threadIdx.x + s] ? red[threadIdx.x] : red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+}  // namespace plslam
+
+// the pair lists of the plan (host, once): every ordered pair (o1, o2) of observations of ONE landmark by OPTIMISED keyframes
+// with kf(o1) <= kf(o2), sorted by block (k1, k2) -- stable: landmark order, then list order
+static int lba_schur_prepare(plslam_lba_plan* P)
+{
+    if (P->schur_ready) return PLSLAM_OK;
+    const int32_t nkf = P->nkf;
+    P->nblk = nkf * (nkf + 1) / 2;
+    auto blk_of = [nkf](int32_t k1, int32_t k2) { return k1 * nkf - k1 * (k1 - 1) / 2 + (k2 - k1); };
+    std::vector<int32_t> cnt((size_t)P->nblk + 1, 0);
+    auto each_pair = [&](auto&& fn) {
+        for (int line = 0; line < 2; ++line) {
+            const std::vector<int32_t>& ptr = line ? P->csr.lsp : P->csr.ptp;
+            const std::vector<int32_t>& ids = line ? P->csr.lsi : P->csr.pti;
+            const std::vector<int32_t>& kf = line ? P->h_ls_kf : P->h_pt_kf;
+            const int32_t nlm = line ? P->nls : P->npt;
+            for (int32_t j = 0; j < nlm; ++j)
+                for (int32_t i1 = ptr[j]; i1 < ptr[j + 1]; ++i1) {
+                    const int32_t o1 = ids[i1], k1 = kf[o1];
+                    if (k1 < 0) continue;
+                    for (int32_t i2 = ptr[j]; i2 < ptr[j + 1]; ++i2) {
+                        const int32_t o2 = ids[i2], k2 = kf[o2];
+                        if (k2 < k1) continue;             // (k2 < 0 included)
+                        fn(blk_of(k1, k2), SchurPair{o1, o2, j, line});
+                    }
+                }
+        }
+    };
+    each_pair([&](int32_t B, const SchurPair&) { ++cnt[(size_t)B + 1]; });
+    for (int32_t B = 0; B < P->nblk; ++B) cnt[(size_t)B + 1] += cnt[B];
+    std::vector<SchurPair> pairs((size_t)cnt[P->nblk]);
+    std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1);
+    each_pair([&](int32_t B, const SchurPair& q) { pairs[(size_t)pos[B]++] = q; });
+    int32_t mc = 0;
+    for (int32_t B = 0; B < P->nblk; ++B) mc = std::max(mc, (cnt[(size_t)B + 1] - cnt[B] + SCH_CHUNK - 1) / SCH_CHUNK);
+    P->schur_chunks = mc;
+    const size_t n6 = 6 * (size_t)nkf;
+    Carve c;
+    P->oSpair = c.take(pairs.size() * sizeof(SchurPair) + 16); P->oSblk = c.take(cnt.size() * 4);
+    P->oVp = c.take((size_t)P->npt * 72 + 8); P->oVl = c.take((size_t)P->nls * 288 + 8);
+    P->oTp = c.take((size_t)P->npt * 24 + 8); P->oTl = c.take((size_t)P->nls * 48 + 8);
+    P->oSpart = c.take((size_t)P->nblk * (size_t)mc * 36 * 8 + 8);
+    P->oBpart = c.take((size_t)nkf * (size_t)P->max_chunks * 6 * 8 + 8);
+    P->oS = c.take((n6 * n6 + n6) * 8 + 16);           // S, then b, then the diagonal maximum
+    P->oDp = c.take(n6 * 8 + 8);
+    P->oDx = c.take((3 * (size_t)P->npt + 6 * (size_t)P->nls) * 8 + 8);
+    P->oSing = c.take(8);
+    int rc;
+    if ((rc = P->schur.reserve(c.off + 256)) || (rc = P->schur_pin.reserve(std::max((n6 * n6 + n6 + 2) * 8, (3 * (size_t)P->npt + 6 * (size_t)P->nls) * 8) + 256)))
+        return rc;
+    hipStream_t s = P->ctx->stream;
+    char* d = P->schur.as<char>();
+    if (!pairs.empty()) PLSLAM_HIP_CHECK(hipMemcpyAsync(d + P->oSpair, pairs.data(), pairs.size() * sizeof(SchurPair), hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(d + P->oSblk, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));          // (the staging vectors die here)
+    P->schur_ready = true;
+    return PLSLAM_OK;
+}
+
+extern "C" int plslam_lba_plan_diag_max(plslam_lba_plan* P, double* hmax)
+{
+    PLSLAM_REQUIRE(P && hmax, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(P->blocks_valid, PLSLAM_EINVAL);        // one plslam_lba_plan_iterate* first
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
+    int rc = lba_schur_prepare(P);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    char *dout = P->out.as<char>(), *d = P->schur.as<char>();
+    const size_t n6 = 6 * (size_t)P->nkf;
+    double* dmax = (double*)(d + P->oS) + n6 * n6 + n6;
+    hipLaunchKernelGGL(k_lba_diag_max, dim3(1), dim3(256), 0, s, (const double*)(dout + P->oHp), P->nkf, (const double*)(dout + P->oHpt),
+                       P->npt, (const double*)(dout + P->oHls), P->nls, dmax);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    double* ho = P->schur_pin.as<double>();
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, dmax, 8, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    *hmax = ho[0];
+    return PLSLAM_OK;
+}
+
+extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* S, double* b, int32_t* n_singular)
+{
+    PLSLAM_REQUIRE(P && S && b && lambda >= 0.0, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(P->blocks_valid && P->nkf > 0, PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
+    int rc = lba_schur_prepare(P);
+    if (rc) return rc;
+    hipStream_t s = ctx->stream;
+    char *ds = P->stat.as<char>(), *dout = P->out.as<char>(), *d = P->schur.as<char>();
+    const size_t n6 = 6 * (size_t)P->nkf;
+    const double* g = (const double*)(dout + P->oG);
+    double *Vp = (double*)(d + P->oVp), *Vl = (double*)(d + P->oVl), *tp = (double*)(d + P->oTp), *tl = (double*)(d + P->oTl);
+    int32_t* sing = (int32_t*)(d + P->oSing);
+    PLSLAM_HIP_CHECK(hipMemsetAsync(sing, 0, 4, s));
+    if (P->npt)
+        hipLaunchKernelGGL(k_schur_landmarks<3>, dim3((P->npt + 255) / 256), dim3(256), 0, s, (const double*)(dout + P->oHpt), g + n6,
+                           P->npt, lambda, Vp, tp, sing);
+    if (P->nls)
+        hipLaunchKernelGGL(k_schur_landmarks<6>, dim3((P->nls + 255) / 256), dim3(256), 0, s, (const double*)(dout + P->oHls),
+                           g + n6 + 3 * (size_t)P->npt, P->nls, lambda, Vl, tl, sing);
+    if (P->schur_chunks > 0)
+        hipLaunchKernelGGL(k_schur_partials, dim3(P->nblk, P->schur_chunks), dim3(64), 0, s, (const SchurPair*)(d + P->oSpair),
+                           (const int32_t*)(d + P->oSblk), (const double*)(dout + P->oWp), (const double*)(dout + P->oWl), Vp, Vl,
+                           P->schur_chunks, (double*)(d + P->oSpart));
+    if (P->max_chunks > 0)
+        hipLaunchKernelGGL(k_schur_b_partials, dim3(P->nkf, P->max_chunks), dim3(64), 0, s, (const int32_t*)(ds + P->oKfp),
+                           (const int32_t*)(ds + P->oKfi), P->np, (const int32_t*)(ds + P->oPlm), (const int32_t*)(ds + P->oLlm),
+                           (const double*)(dout + P->oWp), (const double*)(dout + P->oWl), tp, tl, P->max_chunks, (double*)(d + P->oBpart));
+    double* dS = (double*)(d + P->oS);
+    hipLaunchKernelGGL(k_schur_finish, dim3(P->nblk + P->nkf), dim3(64), 0, s, (const int32_t*)(d + P->oSblk), (const int32_t*)(ds + P->oKfp),
+                       (const double*)(d + P->oSpart), (const double*)(d + P->oBpart), (const double*)(dout + P->oHp), g, P->nkf, P->nblk,
+                       P->schur_chunks, P->max_chunks, lambda, dS, dS + n6 * n6);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    char* ho = P->schur_pin.as<char>();
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, dS, (n6 * n6 + n6) * 8, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho + (n6 * n6 + n6) * 8, sing, 4, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(S, ho, n6 * n6 * 8);
+    memcpy(b, ho + n6 * n6 * 8, n6 * 8);
+    if (n_singular) memcpy(n_singular, ho + (n6 * n6 + n6) * 8, 4);
+    P->schur_done = true;
+    return PLSLAM_OK;
+}
+
+extern "C" int plslam_lba_plan_backsub(plslam_lba_plan* P, const double* dpose, int apply, double* dX_pt, double* dX_ls)
+{
+    PLSLAM_REQUIRE(P && dpose, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(P->schur_done, PLSLAM_EINVAL);          // plslam_lba_plan_schur on the blocks of the last iteration first
+    PLSLAM_REQUIRE(!apply || P->state_valid, PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
+    hipStream_t s = ctx->stream;
+    char *ds = P->stat.as<char>(), *dd = P->dyn.as<char>(), *dout = P->out.as<char>(), *d = P->schur.as<char>();
+    const size_t n6 = 6 * (size_t)P->nkf;
+    char* hp = P->schur_pin.as<char>();
+    memcpy(hp, dpose, n6 * 8);
+    double* ddp = (double*)(d + P->oDp);
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ddp, hp, n6 * 8, hipMemcpyHostToDevice, s));
+    double* dx = (double*)(d + P->oDx);
+    if (P->npt)
+        hipLaunchKernelGGL(k_schur_backsub<3>, dim3((P->npt + 255) / 256), dim3(256), 0, s, (const int32_t*)(ds + P->oPtp),
+                           (const int32_t*)(ds + P->oPti), (const int32_t*)(ds + P->oPkf), P->npt, (const double*)(dout + P->oWp),
+                           (const double*)(d + P->oVp), (const double*)(d + P->oTp), ddp, dx, apply ? (double*)(dd + P->oX) : nullptr);
+    if (P->nls)
+        hipLaunchKernelGGL(k_schur_backsub<6>, dim3((P->nls + 255) / 256), dim3(256), 0, s, (const int32_t*)(ds + P->oLsp),
+                           (const int32_t*)(ds + P->oLsi), (const int32_t*)(ds + P->oLkf), P->nls, (const double*)(dout + P->oWl),
+                           (const double*)(d + P->oVl), (const double*)(d + P->oTl), ddp, dx + 3 * (size_t)P->npt,
+                           apply ? (double*)(dd + P->oL) : nullptr);
+    PLSLAM_HIP_CHECK(hipGetLastError());
+    if (apply) P->schur_done = false;                      // (a second application of the same step would be a bug of the caller)
+    if (dX_pt || dX_ls) {
+        const size_t bytes = (3 * (size_t)P->npt + 6 * (size_t)P->nls) * 8;
+        if (bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(hp, dx, bytes, hipMemcpyDeviceToHost, s));
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        if (dX_pt && P->npt) memcpy(dX_pt, hp, (size_t)P->npt * 24);
+        if (dX_ls && P->nls) memcpy(dX_ls, hp + (size_t)P->npt * 24, (size_t)P->nls * 48);
+    } else {
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));         // (the page-locked image of dp is the caller's to rewrite next)
+    }
+    return PLSLAM_OK;
+}
+
+// the optimised poses alone (the host has applied dp to them: expmap / logmap of SE(3) stay with the caller, :1560-1566)
+extern "C" int plslam_lba_plan_set_poses(plslam_lba_plan* P, const double* T_kf_w)
+{
+    PLSLAM_REQUIRE(P && (P->n_slots == 0 || T_kf_w), PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(P->state_valid, PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
+    hipStream_t s = ctx->stream;
+    if (P->n_slots) {
+        char* hi = P->pin_in.as<char>();
+        memcpy(hi + P->oT, T_kf_w, (size_t)P->n_slots * 128);
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(P->dyn.as<char>() + P->oT, hi + P->oT, (size_t)P->n_slots * 128, hipMemcpyHostToDevice, s));
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    }
     return PLSLAM_OK;
 }

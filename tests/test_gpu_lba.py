@@ -378,6 +378,129 @@ def test_lba_plan_device_resident_iteration_and_gba_blocks(ctx):
             fresh.close()
 
 
+def test_schur_step_on_the_resident_blocks_equals_the_dense_damped_solve(ctx, oracle):
+    """plslam_lba_plan_diag_max / _schur / _backsub / _set_poses (round 5): the solve of src/mapHandler.cpp:1544-1575 with only
+    the 6 nkf x 6 nkf reduced system leaving the device.  Checked against numpy on the DENSE system the oracle accumulates as the
+    reference does (H(i,i) += lambda H(i,i), then a dense solve): the reduced system S, b against the dense Schur complement,
+    the pose step and every landmark step against the dense solution, then the in-place update of the resident landmarks +
+    uploaded poses against an iteration on the same state uploaded whole.  Observations by the fixed keyframe (kf_loc = -1), a
+    landmark seen by the fixed keyframe only, a landmark without any observation (singular block: counted, zero step)."""
+    lm = synth.local_map(n_kf=6, n_pt=400, n_ls=120, obs_per_lm=4, seed=11)
+    cam, ocam = _cams()
+    nkf, npt, nls = 5, 400, 120
+    pt_lm, pt_kf, ls_lm, ls_kf = lm["pt_lm"].copy(), lm["pt_kf"].copy(), lm["ls_lm"].copy(), lm["ls_kf"].copy()
+    pt_kf[pt_lm == 7] = 0                                   # landmark 7: seen by the fixed keyframe only
+    pkf, lkf = pt_kf - 1, ls_kf - 1
+    T, X, L = lm["T_kf_w"].copy(), lm["Xw"].copy(), lm["Lw"].copy()
+    plan = plslam_amd.LbaPlan(ctx, cam, 1e-7, 6, nkf, npt, nls, pt_lm, pt_kf, pkf, lm["obs_uv"], ls_lm, ls_kf, lkf, lm["l_obs"])
+    with pytest.raises(plslam_amd.PlslamError):
+        plan.schur(1e-3)                                    # no iteration yet: no blocks
+    B = plan.iterate(T, X, L)
+    rp = oracle.lba_point_rows(ocam, 1e-7, T, X, lm["obs_uv"], pt_lm, pt_kf)
+    rl = oracle.lba_line_rows(ocam, 1e-7, T, L, lm["l_obs"], ls_lm, ls_kf)
+    H, g, _ = oracle.lba_accumulate("points", nkf, npt, nls, pt_lm, pkf, *rp)
+    H, g, _ = oracle.lba_accumulate("lines", nkf, npt, nls, ls_lm, lkf, *rl, H=H, g=g)
+    hmax = plan.diag_max()
+    assert abs(hmax - np.abs(np.diag(H)).max()) <= 1e-12 * hmax
+    lam = 1e-5 * hmax if hmax < 1e3 else 1e-3               # (the reference: lambda0 * Hmax; any positive value does)
+    lam = 1e-3
+    Hd = H.copy()
+    Hd[np.diag_indices_from(Hd)] *= 1.0 + lam
+    n6 = 6 * nkf
+    Hpp, Hpl, Hll = Hd[:n6, :n6], Hd[:n6, n6:], Hd[n6:, n6:]
+    Vi = np.linalg.inv(Hll)
+    S_ref, b_ref = Hpp - Hpl @ Vi @ Hpl.T, g[:n6] - Hpl @ Vi @ g[n6:]
+    S, b, ns = plan.schur(lam)
+    assert ns == 0
+    assert np.allclose(S, S_ref, rtol=0, atol=1e-9 * np.abs(S_ref).max()) and np.allclose(b, b_ref, rtol=0, atol=1e-9 * np.abs(b_ref).max())
+    assert np.allclose(S, S.T, rtol=0, atol=1e-12 * np.abs(S).max())
+    DX = np.linalg.solve(Hd, g)
+    dp = np.linalg.solve(S, b)
+    dxp, dxl = plan.backsub(dp)
+    got = np.concatenate([dp, dxp.reshape(-1), dxl.reshape(-1)])
+    assert np.allclose(got, DX, rtol=0, atol=1e-7 * np.abs(DX).max()), np.abs(got - DX).max() / np.abs(DX).max()
+    # landmark 7 has no cross block: its step is its own block's solve
+    V7 = B["H_pt"][7] * (1 + lam * np.eye(3))
+    assert np.allclose(dxp[7], np.linalg.solve(V7, B["g"][n6 + 21:n6 + 24]), rtol=1e-9)
+    # determinism: the same call again gives the same words
+    S2, b2, _ = plan.schur(lam)
+    assert np.array_equal(S, S2) and np.array_equal(b, b2)
+    # the update in place: landmarks on the device, poses by the host -> the resident iteration = the uploaded one
+    plan.backsub(dp, apply=True, want=False)
+    with pytest.raises(plslam_amd.PlslamError):
+        plan.backsub(dp, apply=True, want=False)            # the step has been applied: a new schur() is needed
+    T2 = T.copy()
+    for k in range(nkf):
+        T2[k + 1] = (T[k + 1].reshape(4, 4) @ np.linalg.inv(synth.se3_exp(dp[6 * k:6 * k + 6]))).reshape(16)
+    plan.set_poses(T2)
+    e_res = plan.iterate_resident()
+    blocks_res = plan.blocks()
+    e_up, _ = plan.iterate_dev(T2, X + dxp, L + dxl, want_g=False)
+    blocks_up = plan.blocks()
+    assert e_res == e_up
+    for k in ("g", "H_pose", "H_pt", "H_ls", "W_pt", "W_ls"):
+        assert np.array_equal(blocks_res[k], blocks_up[k]), k
+    plan.close()
+    # a landmark nobody observes: its block is zero -- counted, no contribution, zero step
+    plan = plslam_amd.LbaPlan(ctx, cam, 1e-7, 6, nkf, npt + 1, nls, pt_lm, pt_kf, pkf, lm["obs_uv"], ls_lm, ls_kf, lkf, lm["l_obs"])
+    plan.iterate(T, np.vstack([X, [[0.0, 0.0, 5.0]]]), L)
+    S3, b3, ns3 = plan.schur(lam)
+    assert ns3 == 1 and np.allclose(S3, S, rtol=0, atol=1e-12 * np.abs(S).max()) and np.allclose(b3, b, rtol=0, atol=1e-12 * np.abs(b).max())
+    dxp3, _ = plan.backsub(dp)
+    assert np.array_equal(dxp3[npt], np.zeros(3)) and np.allclose(dxp3[:npt], dxp, rtol=0, atol=1e-12 * np.abs(dxp).max())
+    plan.close()
+
+
+def test_schur_step_at_c3_size(ctx):
+    """The C3 map (9 optimised keyframes, 10 000 points, 2 000 lines, 60 000 observations): the reduced system against a
+    float64 numpy Schur complement built from the downloaded blocks, and what one LM iteration costs host to host with the
+    blocks staying on the device (iterate + diag_max once + schur + the host's 54 x 54 solve + backsub with the update)."""
+    import time
+    lm = synth.local_map()
+    cam, _ = _cams()
+    nkf, npt, nls = 9, 10000, 2000
+    pkf, lkf = lm["pt_kf"] - 1, lm["ls_kf"] - 1
+    plan = plslam_amd.LbaPlan(ctx, cam, 1e-7, 10, nkf, npt, nls, lm["pt_lm"], lm["pt_kf"], pkf, lm["obs_uv"], lm["ls_lm"], lm["ls_kf"],
+                              lkf, lm["l_obs"])
+    plan.iterate_dev(lm["T_kf_w"], lm["Xw"], lm["Lw"], want_g=False)
+    Bk = plan.blocks()
+    lam = 1e-3
+    n6 = 6 * nkf
+    S_ref = np.zeros((n6, n6))
+    b_ref = Bk["g"][:n6].copy()
+    for k in range(nkf):
+        S_ref[6 * k:6 * k + 6, 6 * k:6 * k + 6] = Bk["H_pose"][k] * (1 + lam * np.eye(6))
+    for lm_of, kf_of, Hb, Wb, goff, dl in ((lm["pt_lm"], pkf, Bk["H_pt"], Bk["W_pt"], n6, 3),
+                                           (lm["ls_lm"], lkf, Bk["H_ls"], Bk["W_ls"], n6 + 3 * npt, 6)):
+        Vi = np.linalg.inv(Hb * (1 + lam * np.eye(dl))[None])
+        order = np.argsort(lm_of, kind="stable")
+        start = np.searchsorted(lm_of[order], np.arange(Hb.shape[0] + 1))
+        for j in range(Hb.shape[0]):
+            obs = [o for o in order[start[j]:start[j + 1]] if kf_of[o] >= 0]
+            gj = Bk["g"][goff + dl * j:goff + dl * j + dl]
+            for o1 in obs:
+                k1 = kf_of[o1]
+                Y = Wb[o1].T @ Vi[j]                       # 6 x dl
+                b_ref[6 * k1:6 * k1 + 6] -= Y @ gj
+                for o2 in obs:
+                    k2 = kf_of[o2]
+                    S_ref[6 * k1:6 * k1 + 6, 6 * k2:6 * k2 + 6] -= Y @ Wb[o2]
+    S, b, ns = plan.schur(lam)
+    assert ns == 0
+    assert np.allclose(S, S_ref, rtol=0, atol=1e-9 * np.abs(S_ref).max()) and np.allclose(b, b_ref, rtol=0, atol=1e-9 * np.abs(b_ref).max())
+    dp = np.linalg.solve(S, b)
+    for _ in range(3):
+        plan.iterate_resident(); plan.schur(lam); plan.backsub(dp, apply=False, want=False)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        plan.iterate_resident()
+        S, b, _ = plan.schur(lam)
+        dp = np.linalg.solve(S, b)
+        plan.backsub(dp, apply=False, want=False)
+    print(f"C3: one LM iteration with the Schur step, blocks resident: {1e6 * (time.perf_counter() - t0) / 20:.0f} us host to host")
+    plan.close()
+
+
 def test_visibility_gates_and_median_descriptor_against_reference_source_text_outputs(ctx):
     """tests/golden/map2kf_ref_golden.npz = what the reference's OWN loops produce (matchMap2KFPoints / Lines visibility
     pre-filter and gates, src/mapHandler.cpp:545-558, :601-629, :647-663, :716-749, compiled textually; and
