@@ -451,7 +451,7 @@ def spread_sample(B: int, n: int = 64):
 
 
 def verify_gathered_tables(full, world: int, B: int, n_orb: int, n_lbd: int, nnr_p: float, nnr_l: float, sample,
-                           match_fn, seed=None, local_stream=None, first_pairs=None):
+                           match_fn, seed=None, local_stream=None, first_pairs=None, workers=None):
     """Root-side check of a gathered (world * B, stride) table: pairs `sample` of EVERY rank against `match_fn(d1, d2,
     nnr) -> matches_12` (the caller's checker).  Rank r's inputs are regenerated from (seed, first_pairs[r]; default r * B:
     the weak-scaling shard rule of bench.py) -- except rank 0's, which may be passed in.  Contiguous runs of the sample are
@@ -466,22 +466,39 @@ def verify_gathered_tables(full, world: int, B: int, n_orb: int, n_lbd: int, nnr
             runs[-1][1] = i_ + 1
         else:
             runs.append([i_, i_ + 1])
-    bad = []
-    for r_ in range(world):
+    def check_run(job):
+        r_, lo, hi = job
         first = r_ * B if first_pairs is None else first_pairs[r_]
-        for lo, hi in runs:
-            if r_ == 0 and local_stream is not None:
-                st, off = local_stream, 0
-            else:
-                st = synth.stereo_stream(hi - lo, n_orb, n_lbd, seed=synth.SEED0 if seed is None else seed, first_pair=first + lo)
-                off = lo
-            for i_ in range(lo, hi):
-                tab = full[r_ * B + i_]
-                for name, d1, d2 in pair_problems(st["orb_l"], st["orb_r"], st["lbd_l"], st["lbd_r"], i_ - off):
-                    em = match_fn(d1, d2, nnr_p if name.startswith("orb") else nnr_l)
-                    if not np.array_equal(np.asarray(tab[sl[name]]), em):
-                        bad.append((r_, i_, name))
-    return bad
+        if r_ == 0 and local_stream is not None:
+            st, off = local_stream, 0
+        else:
+            st = synth.stereo_stream(hi - lo, n_orb, n_lbd, seed=synth.SEED0 if seed is None else seed, first_pair=first + lo)
+            off = lo
+        out = []
+        for i_ in range(lo, hi):
+            tab = full[r_ * B + i_]
+            for name, d1, d2 in pair_problems(st["orb_l"], st["orb_r"], st["lbd_l"], st["lbd_r"], i_ - off):
+                em = match_fn(d1, d2, nnr_p if name.startswith("orb") else nnr_l)
+                if not np.array_equal(np.asarray(tab[sl[name]]), em):
+                    out.append((r_, i_, name))
+        return out
+
+    # (runs are independent; the checker's C code releases the GIL: at 8 ranks x 64 pairs the root would otherwise spend most
+    # of a minute per table here)
+    jobs = [(r_, lo, hi) for r_ in range(world) for lo, hi in runs]
+    if workers is None:
+        import os
+        try:
+            workers = max(1, min(16, len(os.sched_getaffinity(0))))
+        except AttributeError:
+            workers = 4
+    if workers > 1 and len(jobs) > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=workers) as ex:
+            res = list(ex.map(check_run, jobs))
+    else:
+        res = [check_run(j) for j in jobs]
+    return sorted(x for out in res for x in out)
 
 
 def gather_tables(local, world: int, rank: int, root: int = 0, group=None, force: bool = False):
