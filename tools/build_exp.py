@@ -17,7 +17,7 @@ from plslam_amd import build as B  # noqa: E402
 OBJ = os.path.join(ROOT, "build", "exp", "obj")
 OUT = os.path.join(ROOT, "build", "exp")
 def compile_obj(src, out, extra=()):
-    cmd = [B.hipcc_path()] + B._flags_for(src) + list(extra) + ["-c", os.path.join(B.CSRC, src), "-o", out]
+    cmd = [B.hipcc_path()] + B._flags_for(src, B.legacy_scans()) + list(extra) + ["-c", os.path.join(B.CSRC, src), "-o", out]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         raise SystemExit(r.stdout + r.stderr)
