@@ -155,4 +155,100 @@ private:
     double th_;
 };
 
+// The LM loop of levMarquardtOptimizationLBA on a device-resident plan (round 5): the observation lists go up once, an iteration
+// leaves its blocks on the device, and the step of :1552-1575 / :1777-1807 -- damp H(i,i) += lambda H(i,i), solve, update -- is the
+// Schur step of the C ABI: only the 6 Nkf x 6 Nkf reduced camera system comes down, a dense LDL^T of it runs here (the
+// reference: SimplicialLDLT over all N unknowns, :1555-1556), the landmark steps and their update stay on the device.  The
+// SE(3) maps of the pose update (:1560-1566: expmap_se3 / inverse_se3, stvo-pl) stay with the caller: setPoses() takes the
+// updated matrices.
+class LbaPlanSolver {
+public:
+    LbaPlanSolver(plslam_ctx* ctx, const plslam_cam& cam, double homog_th, const LbaProblem& p) : nkf_(p.Nkf)
+    {
+        npt_ = (int32_t)(p.points.size() / 3); nls_ = (int32_t)(p.lines.size() / 6);
+        nslots_ = (int32_t)(p.poses_T_kf_w.size() / 16);
+        const int32_t np = (int32_t)p.pt_obs_list.size(), nl = (int32_t)p.ls_obs_list.size();
+        std::vector<int32_t> plm(np), pkf(np), llm(nl), lkf(nl);
+        for (int32_t o = 0; o < np; ++o) { plm[o] = p.pt_obs_list[o][1]; pkf[o] = p.pt_obs_list[o][4]; }
+        for (int32_t o = 0; o < nl; ++o) { llm[o] = p.ls_obs_list[o][1]; lkf[o] = p.ls_obs_list[o][4]; }
+        check(plslam_lba_plan_create(ctx, &cam, homog_th, nslots_, nkf_, npt_, nls_, plm.data(), p.pt_pose_slot.data(), pkf.data(),
+                                     p.pt_obs.data(), np, llm.data(), p.ls_pose_slot.data(), lkf.data(), p.ls_obs.data(), nl, &plan_),
+              "plslam_lba_plan_create");
+    }
+    ~LbaPlanSolver() { plslam_lba_plan_destroy(plan_); }
+    LbaPlanSolver(const LbaPlanSolver&) = delete;
+    LbaPlanSolver& operator=(const LbaPlanSolver&) = delete;
+
+    // H, g, err of the state in `p` (uploaded); iteration_pass: the quirks of :1668-1748.  The blocks stay on the device.
+    double iterate(const LbaProblem& p, bool iteration_pass)
+    {
+        double err = 0;
+        check(plslam_lba_plan_iterate_dev(plan_, p.poses_T_kf_w.data(), p.points.data(), p.lines.data(),
+                                          iteration_pass ? PLSLAM_LBA_COMPAT_ITER_PASS : 0, nullptr, &err), "plslam_lba_plan_iterate_dev");
+        return err;
+    }
+    // the same on the state the device already holds (landmarks updated by solveStep(apply), poses by setPoses)
+    double iterateResident(bool iteration_pass)
+    {
+        double err = 0;
+        check(plslam_lba_plan_iterate_resident(plan_, iteration_pass ? PLSLAM_LBA_COMPAT_ITER_PASS : 0, &err), "plslam_lba_plan_iterate_resident");
+        return err;
+    }
+    double diagMax()                                        // :1544-1550 "Hmax"
+    {
+        double h = 0;
+        check(plslam_lba_plan_diag_max(plan_, &h), "plslam_lba_plan_diag_max");
+        return h;
+    }
+    // damp, reduce, solve: dp (6 Nkf); the landmark steps where asked for; apply = true: X(i) += DX(i) on the device (:1570-1575)
+    void solveStep(double lambda, std::vector<double>& dp, bool apply, std::vector<double>* dX_pt = nullptr,
+                   std::vector<double>* dX_ls = nullptr, int32_t* n_singular = nullptr)
+    {
+        const size_t n = 6 * (size_t)nkf_;
+        S_.resize(n * n); dp.resize(n);
+        check(plslam_lba_plan_schur(plan_, lambda, S_.data(), dp.data(), n_singular), "plslam_lba_plan_schur");
+        ldlt_solve(S_, dp, (int)n);
+        if (dX_pt) dX_pt->resize((size_t)npt_ * 3);
+        if (dX_ls) dX_ls->resize((size_t)nls_ * 6);
+        check(plslam_lba_plan_backsub(plan_, dp.data(), apply ? 1 : 0, dX_pt ? dX_pt->data() : nullptr, dX_ls ? dX_ls->data() : nullptr),
+              "plslam_lba_plan_backsub");
+    }
+    void setPoses(const std::vector<double>& T_kf_w)        // n_slots x 16, after T <- T inv(exp(dp)) on the host
+    {
+        if (T_kf_w.size() != (size_t)nslots_ * 16) throw std::runtime_error("[LbaPlanSolver::setPoses] one 4 x 4 per pose slot");
+        check(plslam_lba_plan_set_poses(plan_, T_kf_w.data()), "plslam_lba_plan_set_poses");
+    }
+
+    // x <- A^-1 x for a symmetric positive definite A (n x n, row-major, overwritten): LDL^T without pivoting
+    static void ldlt_solve(std::vector<double>& A, std::vector<double>& x, int n)
+    {
+        for (int j = 0; j < n; ++j) {
+            double d = A[(size_t)j * n + j];
+            for (int k = 0; k < j; ++k) d -= A[(size_t)j * n + k] * A[(size_t)j * n + k] * A[(size_t)k * n + k];
+            if (!(d > 0.0)) throw std::runtime_error("[LbaPlanSolver] the reduced camera system is not positive definite");
+            A[(size_t)j * n + j] = d;
+            for (int i = j + 1; i < n; ++i) {
+                double l = A[(size_t)i * n + j];
+                for (int k = 0; k < j; ++k) l -= A[(size_t)i * n + k] * A[(size_t)j * n + k] * A[(size_t)k * n + k];
+                A[(size_t)i * n + j] = l / d;
+            }
+        }
+        for (int i = 0; i < n; ++i)
+            for (int k = 0; k < i; ++k) x[i] -= A[(size_t)i * n + k] * x[k];
+        for (int i = 0; i < n; ++i) x[i] /= A[(size_t)i * n + i];
+        for (int i = n - 1; i >= 0; --i)
+            for (int k = i + 1; k < n; ++k) x[i] -= A[(size_t)k * n + i] * x[k];
+    }
+
+private:
+    static void check(int rc, const char* fn)
+    {
+        if (rc != PLSLAM_OK)
+            throw std::runtime_error(std::string("[") + fn + "] " + plslam_strerror(rc) + ": " + plslam_last_error());
+    }
+    plslam_lba_plan* plan_ = nullptr;
+    int32_t nkf_, npt_ = 0, nls_ = 0, nslots_ = 0;
+    std::vector<double> S_;
+};
+
 }  // namespace PLSLAM

@@ -364,6 +364,56 @@ int main()
             }
             EXPECT(bad == 0);
             EXPECT(std::fabs(B.err - err) <= 1e-12 * std::fabs(err));
+            if (pass == 0) {
+                // --- the LM step on a device-resident plan (PLSLAM::LbaPlanSolver: Schur step of the C ABI + a dense LDL^T of the
+                // reduced camera system here) against a dense solve of the damped system accumulated above (:1552-1556)
+                PLSLAM::LbaPlanSolver solver(ctx, cam, 1e-7, p);
+                const double e_plan = solver.iterate(p, false);
+                EXPECT(std::fabs(e_plan - err) <= 1e-12 * std::fabs(err));
+                const double hmax = solver.diagMax();
+                double hmax_ref = 0;
+                for (int i = 0; i < N; ++i) hmax_ref = std::fmax(hmax_ref, std::fabs(H[(size_t)i * N + i]));
+                EXPECT(std::fabs(hmax - hmax_ref) <= 1e-12 * hmax_ref);
+                const double lambda = 1e-3;
+                std::vector<double> dp, dxp, dxl;
+                int32_t nsing = -1;
+                solver.solveStep(lambda, dp, /*apply=*/false, &dxp, &dxl, &nsing);
+                EXPECT(nsing == 0);
+                std::vector<double> Hd(H), x(gv);
+                for (int i = 0; i < N; ++i) Hd[(size_t)i * N + i] += lambda * Hd[(size_t)i * N + i];
+                // Gaussian elimination with partial pivoting on the dense damped system
+                for (int c = 0; c < N; ++c) {
+                    int piv = c;
+                    for (int r2 = c + 1; r2 < N; ++r2) if (std::fabs(Hd[(size_t)r2 * N + c]) > std::fabs(Hd[(size_t)piv * N + c])) piv = r2;
+                    if (piv != c) { for (int k = 0; k < N; ++k) std::swap(Hd[(size_t)c * N + k], Hd[(size_t)piv * N + k]); std::swap(x[c], x[piv]); }
+                    for (int r2 = c + 1; r2 < N; ++r2) {
+                        const double f = Hd[(size_t)r2 * N + c] / Hd[(size_t)c * N + c];
+                        if (f == 0.0) continue;
+                        for (int k = c; k < N; ++k) Hd[(size_t)r2 * N + k] -= f * Hd[(size_t)c * N + k];
+                        x[r2] -= f * x[c];
+                    }
+                }
+                for (int r2 = N - 1; r2 >= 0; --r2) {
+                    for (int k = r2 + 1; k < N; ++k) x[r2] -= Hd[(size_t)r2 * N + k] * x[k];
+                    x[r2] /= Hd[(size_t)r2 * N + r2];
+                }
+                double scale = 0, diff = 0;
+                for (int i = 0; i < N; ++i) scale = std::fmax(scale, std::fabs(x[i]));
+                for (int i = 0; i < 6 * p.Nkf; ++i) diff = std::fmax(diff, std::fabs(dp[i] - x[i]));
+                for (int i = 0; i < 3 * Npt; ++i) diff = std::fmax(diff, std::fabs(dxp[i] - x[6 * p.Nkf + i]));
+                for (int i = 0; i < 6 * Nls; ++i) diff = std::fmax(diff, std::fabs(dxl[i] - x[6 * p.Nkf + 3 * Npt + i]));
+                EXPECT(diff <= 1e-7 * scale);
+                std::printf("LBA Schur step: reduced system %d x %d, max |step - dense solve| = %.3g of max |step|\n", 6 * p.Nkf, 6 * p.Nkf, diff / scale);
+                // the update in place + the poses: the resident iteration equals the uploaded one on the same state
+                solver.solveStep(lambda, dp, /*apply=*/true);
+                PLSLAM::LbaProblem p2 = p;
+                for (size_t i = 0; i < p2.points.size(); ++i) p2.points[i] += dxp[i];
+                for (size_t i = 0; i < p2.lines.size(); ++i) p2.lines[i] += dxl[i];
+                solver.setPoses(p2.poses_T_kf_w);                       // (unchanged poses: the call itself is what is exercised)
+                const double e_res = solver.iterateResident(false);
+                PLSLAM::LbaPlanSolver fresh(ctx, cam, 1e-7, p2);
+                EXPECT(e_res == fresh.iterate(p2, false));
+            }
         }
         plslam_ctx_destroy(ctx);
     }
