@@ -535,7 +535,8 @@ int plslam_lba_plan_iterate_resident(plslam_lba_plan* plan, int compat_flags, do
  * the whole N x N system with a sparse LDLT; the landmark blocks of H are independent, so the same step is
  *     S dp = b,  S = Hpp' - sum_j Wj^T Vj'^-1 Wj,  b = gp - sum_j Wj^T Vj'^-1 gj,  dxj = Vj'^-1 (gj - Wj dp)
  * (Hpp', Vj': the damped pose / landmark blocks; Wj: the cross blocks of landmark j's observations).  All three calls work on
- * the blocks of the LAST plslam_lba_plan_iterate / _iterate_dev / _iterate_resident of the plan.
+ * the blocks of the LAST plslam_lba_plan_iterate / _iterate_dev / _iterate_resident of the plan (run WITHOUT
+ * PLSLAM_LBA_COMPAT_GBA: the transposed pose x line cross blocks of the reference's GBA are refused, PLSLAM_EINVAL).
  *   plslam_lba_plan_diag_max   *hmax = max |H(i,i)| over all N diagonal entries (the reference's "lambda *= Hmax", :1544-1550)
  *   plslam_lba_plan_schur      S (6 nkf x 6 nkf doubles, row-major, both triangles) and b (6 nkf) for the damping `lambda`;
  *                              *n_singular (may be NULL) = landmarks whose damped block is not positive definite (a zero

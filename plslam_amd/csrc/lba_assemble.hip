@@ -510,6 +510,7 @@ struct plslam_lba_plan {
     size_t dyn_bytes = 0;
     bool state_valid = false;      // T / Xw / Lw have been uploaded at least once (iterate_resident needs them)
     bool blocks_valid = false;     // an iteration has left H / g / W on the device (the Schur step consumes them)
+    bool blocks_gba = false;       // ... with the pose x line cross blocks transposed (PLSLAM_LBA_COMPAT_GBA): not what the Schur step reads
     // ---- the Schur step (round 5): pair lists built on first use from these host copies of the observation lists
     CsrLists csr;
     std::vector<int32_t> h_pt_kf, h_ls_kf;
@@ -651,6 +652,7 @@ static int lba_plan_enqueue(plslam_lba_plan* P, const double* T_kf_w, const doub
     hipLaunchKernelGGL(k_lba_finish, dim3(P->nkf + 1), dim3(256), 0, s, B);
     PLSLAM_HIP_CHECK(hipGetLastError());
     P->blocks_valid = true;
+    P->blocks_gba = (compat_flags & PLSLAM_LBA_COMPAT_GBA) != 0;
     P->schur_done = false;             // (the blocks have changed: the landmark inverses of an earlier Schur step are stale)
     return PLSLAM_OK;
 }
@@ -1254,6 +1256,9 @@ extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* 
 {
     PLSLAM_REQUIRE(P && S && b && lambda >= 0.0, PLSLAM_EINVAL);
     PLSLAM_REQUIRE(P->blocks_valid && P->nkf > 0, PLSLAM_EINVAL);
+    // the cross blocks must be the local BA's (landmark rows x pose columns): an iteration run with PLSLAM_LBA_COMPAT_GBA wrote the
+    // pose x line blocks transposed, as the reference's GBA does (:2341-2352) -- a defect this step does not reproduce
+    PLSLAM_REQUIRE(!P->blocks_gba, PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard dg_(ctx->device);

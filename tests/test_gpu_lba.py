@@ -422,6 +422,11 @@ def test_schur_step_on_the_resident_blocks_equals_the_dense_damped_solve(ctx, or
     # landmark 7 has no cross block: its step is its own block's solve
     V7 = B["H_pt"][7] * (1 + lam * np.eye(3))
     assert np.allclose(dxp[7], np.linalg.solve(V7, B["g"][n6 + 21:n6 + 24]), rtol=1e-9)
+    # blocks written the GBA way (pose x line cross blocks transposed) are refused
+    plan.iterate_dev(T, X, L, compat_flags=plslam_amd.LbaPlan.COMPAT_GBA, want_g=False)
+    with pytest.raises(plslam_amd.PlslamError):
+        plan.schur(lam)
+    plan.iterate_dev(T, X, L, want_g=False)
     # determinism: the same call again gives the same words
     S2, b2, _ = plan.schur(lam)
     assert np.array_equal(S, S2) and np.array_equal(b, b2)
