@@ -905,12 +905,9 @@ constexpr int SCH_CHUNK = 64;
 struct SchurPair { int32_t o1, o2, lm, line; };     // observation ids within their own list (points / lines), the landmark
 
 template <int DL>
-__global__ void __launch_bounds__(256)
-k_schur_landmarks(const double* __restrict__ H, const double* __restrict__ g, int32_t n, double lambda,
-                  double* __restrict__ Vinv, double* __restrict__ t, int32_t* __restrict__ nsing)
+__device__ __forceinline__ void schur_landmark(const double* __restrict__ H, const double* __restrict__ g, int j, double lambda,
+                                               double* __restrict__ Vinv, double* __restrict__ t, int32_t* __restrict__ nsing)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
     double A[DL][DL], I[DL][DL];
 #pragma unroll
     for (int a = 0; a < DL; ++a)
@@ -953,6 +950,21 @@ k_schur_landmarks(const double* __restrict__ H, const double* __restrict__ g, in
         t[(size_t)j * DL + a] = acc;
     }
     if (!ok) atomicAdd(nsing, 1);              // (a count only: no sum depends on it)
+}
+
+// one launch for both kinds: workgroups [0, nb3) take the points, the rest the lines
+__global__ void __launch_bounds__(256)
+k_schur_landmarks(const double* __restrict__ H_pt, const double* __restrict__ g_pt, int32_t npt, const double* __restrict__ H_ls,
+                  const double* __restrict__ g_ls, int32_t nls, int32_t nb3, double lambda, double* __restrict__ Vp,
+                  double* __restrict__ tp, double* __restrict__ Vl, double* __restrict__ tl, int32_t* __restrict__ nsing)
+{
+    if ((int)blockIdx.x < nb3) {
+        const int j = blockIdx.x * 256 + threadIdx.x;
+        if (j < npt) schur_landmark<3>(H_pt, g_pt, j, lambda, Vp, tp, nsing);
+    } else {
+        const int j = ((int)blockIdx.x - nb3) * 256 + threadIdx.x;
+        if (j < nls) schur_landmark<6>(H_ls, g_ls, j, lambda, Vl, tl, nsing);
+    }
 }
 
 // W_pt[o]: 3 x 6 (landmark row x, pose column a), W_ls[o]: 6 x 6.  Entry (a, b) of W1^T Vinv W2 = sum_x sum_y W1[x][a] Vinv[x][y] W2[y][b].
@@ -1213,7 +1225,7 @@ static int lba_schur_prepare(plslam_lba_plan* P)
     P->oTp = c.take((size_t)P->npt * 24 + 8); P->oTl = c.take((size_t)P->nls * 48 + 8);
     P->oSpart = c.take((size_t)P->nblk * (size_t)mc * 36 * 8 + 8);
     P->oBpart = c.take((size_t)nkf * (size_t)P->max_chunks * 6 * 8 + 8);
-    P->oS = c.take((n6 * n6 + n6) * 8 + 16);           // S, then b, then the diagonal maximum
+    P->oS = c.take((n6 * n6 + n6 + 2) * 8 + 16);       // S, then b, then the diagonal maximum, then the singular-block counter
     P->oDp = c.take(n6 * 8 + 8);
     P->oDx = c.take((3 * (size_t)P->npt + 6 * (size_t)P->nls) * 8 + 8);
     P->oSing = c.take(8);
@@ -1269,14 +1281,13 @@ extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* 
     const size_t n6 = 6 * (size_t)P->nkf;
     const double* g = (const double*)(dout + P->oG);
     double *Vp = (double*)(d + P->oVp), *Vl = (double*)(d + P->oVl), *tp = (double*)(d + P->oTp), *tl = (double*)(d + P->oTl);
-    int32_t* sing = (int32_t*)(d + P->oSing);
-    PLSLAM_HIP_CHECK(hipMemsetAsync(sing, 0, 4, s));
-    if (P->npt)
-        hipLaunchKernelGGL(k_schur_landmarks<3>, dim3((P->npt + 255) / 256), dim3(256), 0, s, (const double*)(dout + P->oHpt), g + n6,
-                           P->npt, lambda, Vp, tp, sing);
-    if (P->nls)
-        hipLaunchKernelGGL(k_schur_landmarks<6>, dim3((P->nls + 255) / 256), dim3(256), 0, s, (const double*)(dout + P->oHls),
-                           g + n6 + 3 * (size_t)P->npt, P->nls, lambda, Vl, tl, sing);
+    double* dS = (double*)(d + P->oS);
+    int32_t* sing = (int32_t*)(dS + n6 * n6 + n6 + 1);       // behind S, b and the diagonal maximum: ONE copy brings S, b and it back
+    PLSLAM_HIP_CHECK(hipMemsetAsync(sing, 0, 8, s));
+    const int32_t nb3 = (P->npt + 255) / 256, nb6 = (P->nls + 255) / 256;
+    if (nb3 + nb6 > 0)
+        hipLaunchKernelGGL(k_schur_landmarks, dim3(nb3 + nb6), dim3(256), 0, s, (const double*)(dout + P->oHpt), g + n6, P->npt,
+                           (const double*)(dout + P->oHls), g + n6 + 3 * (size_t)P->npt, P->nls, nb3, lambda, Vp, tp, Vl, tl, sing);
     if (P->schur_chunks > 0)
         hipLaunchKernelGGL(k_schur_partials, dim3(P->nblk, P->schur_chunks), dim3(64), 0, s, (const SchurPair*)(d + P->oSpair),
                            (const int32_t*)(d + P->oSblk), (const double*)(dout + P->oWp), (const double*)(dout + P->oWl), Vp, Vl,
@@ -1285,18 +1296,16 @@ extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* 
         hipLaunchKernelGGL(k_schur_b_partials, dim3(P->nkf, P->max_chunks), dim3(64), 0, s, (const int32_t*)(ds + P->oKfp),
                            (const int32_t*)(ds + P->oKfi), P->np, (const int32_t*)(ds + P->oPlm), (const int32_t*)(ds + P->oLlm),
                            (const double*)(dout + P->oWp), (const double*)(dout + P->oWl), tp, tl, P->max_chunks, (double*)(d + P->oBpart));
-    double* dS = (double*)(d + P->oS);
     hipLaunchKernelGGL(k_schur_finish, dim3(P->nblk + P->nkf), dim3(64), 0, s, (const int32_t*)(d + P->oSblk), (const int32_t*)(ds + P->oKfp),
                        (const double*)(d + P->oSpart), (const double*)(d + P->oBpart), (const double*)(dout + P->oHp), g, P->nkf, P->nblk,
                        P->schur_chunks, P->max_chunks, lambda, dS, dS + n6 * n6);
     PLSLAM_HIP_CHECK(hipGetLastError());
     char* ho = P->schur_pin.as<char>();
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, dS, (n6 * n6 + n6) * 8, hipMemcpyDeviceToHost, s));
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho + (n6 * n6 + n6) * 8, sing, 4, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, dS, (n6 * n6 + n6 + 2) * 8, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     memcpy(S, ho, n6 * n6 * 8);
     memcpy(b, ho + n6 * n6 * 8, n6 * 8);
-    if (n_singular) memcpy(n_singular, ho + (n6 * n6 + n6) * 8, 4);
+    if (n_singular) memcpy(n_singular, ho + (n6 * n6 + n6 + 1) * 8, 4);
     P->schur_done = true;
     return PLSLAM_OK;
 }
