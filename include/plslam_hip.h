@@ -530,6 +530,20 @@ typedef struct plslam_lba_state {
 } plslam_lba_state;
 int plslam_lba_plan_device_state(plslam_lba_plan* plan, plslam_lba_state* out);
 int plslam_lba_plan_iterate_resident(plslam_lba_plan* plan, int compat_flags, double* err);
+/* The plan's page-locked host images by name (round 5).  Every plslam_lba_plan_iterate / _iterate_dev copies the caller's
+ * T_kf_w / Xw / Lw into one page-locked image (one upload) and g out of another (one download).  A host solver that keeps its
+ * state IN that image -- X_aux of src/mapHandler.cpp:1231-1330 written there, X(i) += DX(i) applied there -- and reads g
+ * there passes these very pointers to the iterate calls, which then skip both staging copies (0.34 MB each way at C3).  The
+ * images belong to the plan (valid until plslam_lba_plan_destroy); the caller may write T / Xw / Lw and read g between calls
+ * only (every plan call returns with the stream synchronised).  g is rewritten by every _iterate_dev with g != NULL;
+ * pointers of any other origin keep working as before, array by array. */
+typedef struct plslam_lba_host_state {
+    double *T_kf_w, *Xw, *Lw;                 /* page-locked: n_pose_slots x 16, npt x 3, nls x 6 */
+    double* g;                                 /* page-locked: n doubles (6 nkf + 3 npt + 6 nls) */
+    int32_t n_pose_slots, npt, nls;
+    int64_t n;
+} plslam_lba_host_state;
+int plslam_lba_plan_host_state(plslam_lba_plan* plan, plslam_lba_host_state* out);
 /* The Schur step on the resident blocks (round 5) -- the solve of src/mapHandler.cpp:1544-1575 (and :1779-1800 in the loop)
  * with everything but a 6 nkf x 6 nkf system staying on the device.  The reference damps H(i,i) += lambda * H(i,i) and solves
  * the whole N x N system with a sparse LDLT; the landmark blocks of H are independent, so the same step is

@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "plslam_lba_line_rows_dev", "plslam_lba_assemble", "plslam_lba_plan_create", "plslam_lba_plan_iterate",
     "plslam_lba_plan_rows", "plslam_lba_plan_destroy", "plslam_lba_plan_iterate_dev", "plslam_lba_plan_device_blocks", "plslam_lba_plan_device_state",
     "plslam_lba_plan_iterate_resident", "plslam_lba_plan_diag_max", "plslam_lba_plan_schur", "plslam_lba_plan_backsub",
-    "plslam_lba_plan_set_poses",
+    "plslam_lba_plan_set_poses", "plslam_lba_plan_host_state",
     "plslam_lba_plan_blocks",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
@@ -216,6 +216,7 @@ def load() -> C.CDLL:
     L.plslam_lba_plan_schur.argtypes = [vp, C.c_double, vp, vp, vp]
     L.plslam_lba_plan_backsub.argtypes = [vp, vp, C.c_int, vp, vp]
     L.plslam_lba_plan_set_poses.argtypes = [vp, vp]
+    L.plslam_lba_plan_host_state.argtypes = [vp, vp]
     L.plslam_lba_plan_blocks.argtypes = [vp] * 8
     L.plslam_lba_plan_destroy.argtypes = [vp]
     L.plslam_lba_plan_destroy.restype = None
@@ -798,12 +799,17 @@ class LbaPlan:
 
     COMPAT_ITER_PASS, COMPAT_GBA = 1, 2
 
-    def iterate_dev(self, T_kf_w, Xw, Lw, compat_flags=0, want_g=True):
-        """One iteration with the blocks left on the device -> (err, g or None)."""
+    def iterate_dev(self, T_kf_w, Xw, Lw, compat_flags=0, want_g=True, g_out=None):
+        """One iteration with the blocks left on the device -> (err, g or None).  With the arrays of host_state() as T_kf_w /
+        Xw / Lw / g_out the call copies nothing on the host."""
         nkf, npt, nls, npo, nlo, nslot = self.dims
         T = _arr(T_kf_w, np.float64, (-1, 16))
         X, Lm = _arr(Xw, np.float64, (-1, 3)), _arr(Lw, np.float64, (-1, 6))
-        g = np.empty(6 * nkf + 3 * npt + 6 * nls) if want_g else None
+        if want_g and g_out is not None:
+            assert g_out.dtype == np.float64 and g_out.flags.c_contiguous and g_out.size == 6 * nkf + 3 * npt + 6 * nls
+            g = g_out
+        else:
+            g = np.empty(6 * nkf + 3 * npt + 6 * nls) if want_g else None
         err = np.empty(1)
         _check(self._L.plslam_lba_plan_iterate_dev(self._h, _p(T), _p(X), _p(Lm), int(compat_flags),
                                                    _p(g) if want_g else None, _p(err)), "plslam_lba_plan_iterate_dev")
@@ -844,6 +850,24 @@ class LbaPlan:
         T = _arr(T_kf_w, np.float64, (-1, 16))
         assert T.shape[0] == self.dims[5]
         _check(self._L.plslam_lba_plan_set_poses(self._h, _p(T)), "plslam_lba_plan_set_poses")
+
+    def host_state(self) -> dict:
+        """The plan's page-locked images as numpy views (T_kf_w (n_pose_slots, 16), Xw (npt, 3), Lw (nls, 6), g (n,)): a
+        solver that keeps its state in them passes them to iterate_dev(..., g_out=g) and nothing is staged.  The views die with
+        the plan."""
+        class _S(C.Structure):
+            _fields_ = [("T_kf_w", C.c_void_p), ("Xw", C.c_void_p), ("Lw", C.c_void_p), ("g", C.c_void_p),
+                        ("n_pose_slots", C.c_int32), ("npt", C.c_int32), ("nls", C.c_int32), ("n", C.c_int64)]
+        st = _S()
+        _check(self._L.plslam_lba_plan_host_state(self._h, C.byref(st)), "plslam_lba_plan_host_state")
+
+        def view(ptr, shape):
+            n = int(np.prod(shape))
+            if n == 0:
+                return np.empty(shape)
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), shape=(n,)).reshape(shape)
+        return dict(T_kf_w=view(st.T_kf_w, (st.n_pose_slots, 16)), Xw=view(st.Xw, (st.npt, 3)), Lw=view(st.Lw, (st.nls, 6)),
+                    g=view(st.g, (st.n,)))
 
     def device_state(self) -> dict:
         """Device pointers (ints) of T_kf_w / Xw / Lw, their row counts and the plan's HIP stream."""

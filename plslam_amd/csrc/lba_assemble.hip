@@ -614,9 +614,10 @@ static int lba_plan_enqueue(plslam_lba_plan* P, const double* T_kf_w, const doub
         // (the page-locked image is rewritten per call: the previous call's copy has completed -- every caller synchronises
         // the stream before it returns)
         char* hi = P->pin_in.as<char>();
-        if (P->n_slots) memcpy(hi + P->oT, T_kf_w, (size_t)P->n_slots * 128);
-        if (P->npt) memcpy(hi + P->oX, Xw, (size_t)P->npt * 24);
-        if (P->nls) memcpy(hi + P->oL, Lw, (size_t)P->nls * 48);
+        // (a caller that keeps its state IN the image -- plslam_lba_plan_host_state -- passes the image's own pointers: no copy)
+        if (P->n_slots && (const char*)T_kf_w != hi + P->oT) memcpy(hi + P->oT, T_kf_w, (size_t)P->n_slots * 128);
+        if (P->npt && (const char*)Xw != hi + P->oX) memcpy(hi + P->oX, Xw, (size_t)P->npt * 24);
+        if (P->nls && (const char*)Lw != hi + P->oL) memcpy(hi + P->oL, Lw, (size_t)P->nls * 48);
         if (P->dyn_bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(dd, hi, P->dyn_bytes, hipMemcpyHostToDevice, s));
         P->state_valid = true;
     }
@@ -675,7 +676,7 @@ static int lba_plan_download(plslam_lba_plan* P, double* g, double* H_pose, doub
         const size_t off = g ? P->oG : P->oErr, bytes = g ? N * 8 + 8 : 8;
         PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, dout + off, bytes, hipMemcpyDeviceToHost, s));
         PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
-        if (g) memcpy(g, ho, N * 8);
+        if (g && (char*)g != ho) memcpy(g, ho, N * 8);      // (g = the page-locked image itself: plslam_lba_plan_host_state)
         if (err) memcpy(err, ho + bytes - 8, 8);
         return PLSLAM_OK;
     }
@@ -742,6 +743,19 @@ extern "C" int plslam_lba_plan_device_state(plslam_lba_plan* P, plslam_lba_state
     out->T_kf_w = (double*)(dd + P->oT); out->Xw = (double*)(dd + P->oX); out->Lw = (double*)(dd + P->oL);
     out->n_pose_slots = P->n_slots; out->npt = P->npt; out->nls = P->nls;
     out->stream = P->ctx->stream;
+    return PLSLAM_OK;
+}
+
+// The plan's page-locked images by name: a host solver that keeps T / Xw / Lw there and reads g from there hands these very
+// pointers to plslam_lba_plan_iterate / _iterate_dev, which then skip their staging copies (0.34 MB in, 0.34 MB out at C3).
+extern "C" int plslam_lba_plan_host_state(plslam_lba_plan* P, plslam_lba_host_state* out)
+{
+    PLSLAM_REQUIRE(P && out, PLSLAM_EINVAL);
+    char *hi = P->pin_in.as<char>(), *ho = P->pin_out.as<char>();      // (fixed at plan creation: nothing to lock)
+    out->T_kf_w = (double*)(hi + P->oT); out->Xw = (double*)(hi + P->oX); out->Lw = (double*)(hi + P->oL);
+    out->g = (double*)ho;
+    out->n_pose_slots = P->n_slots; out->npt = P->npt; out->nls = P->nls;
+    out->n = (int64_t)(6 * (size_t)P->nkf + 3 * (size_t)P->npt + 6 * (size_t)P->nls);
     return PLSLAM_OK;
 }
 

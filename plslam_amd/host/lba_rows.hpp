@@ -187,6 +187,23 @@ public:
                                           iteration_pass ? PLSLAM_LBA_COMPAT_ITER_PASS : 0, nullptr, &err), "plslam_lba_plan_iterate_dev");
         return err;
     }
+    // The plan's page-locked images of the state and of g: a solver whose X_aux (:1231-1330) lives THERE hands them to
+    // iterateInPlace() and no staging copy is made on the host (plslam_lba_plan_host_state)
+    plslam_lba_host_state hostState()
+    {
+        plslam_lba_host_state h{};
+        check(plslam_lba_plan_host_state(plan_, &h), "plslam_lba_plan_host_state");
+        return h;
+    }
+    // H, g, err of the state written into hostState()'s T_kf_w / Xw / Lw; the gradient lands in hostState().g
+    double iterateInPlace(bool iteration_pass, bool want_g = true)
+    {
+        const plslam_lba_host_state h = hostState();
+        double err = 0;
+        check(plslam_lba_plan_iterate_dev(plan_, h.T_kf_w, h.Xw, h.Lw, iteration_pass ? PLSLAM_LBA_COMPAT_ITER_PASS : 0,
+                                          want_g ? h.g : nullptr, &err), "plslam_lba_plan_iterate_dev");
+        return err;
+    }
     // the same on the state the device already holds (landmarks updated by solveStep(apply), poses by setPoses)
     double iterateResident(bool iteration_pass)
     {

@@ -413,6 +413,16 @@ int main()
                 const double e_res = solver.iterateResident(false);
                 PLSLAM::LbaPlanSolver fresh(ctx, cam, 1e-7, p2);
                 EXPECT(e_res == fresh.iterate(p2, false));
+                // the state kept in the plan's page-locked images: the same error, the gradient where the caller reads it
+                const plslam_lba_host_state hs = fresh.hostState();
+                EXPECT(hs.n == (int64_t)N && hs.npt == Npt && hs.nls == Nls);
+                std::copy(p.poses_T_kf_w.begin(), p.poses_T_kf_w.end(), hs.T_kf_w);
+                std::copy(p.points.begin(), p.points.end(), hs.Xw);
+                std::copy(p.lines.begin(), p.lines.end(), hs.Lw);
+                EXPECT(fresh.iterateInPlace(false) == e_plan);
+                double gscale = 0, gdiff = 0;        // (bit-identity with the staged call: tests/test_gpu_lba.py)
+                for (int i = 0; i < N; ++i) { gscale = std::fmax(gscale, std::fabs(B.g[i])); gdiff = std::fmax(gdiff, std::fabs(hs.g[i] - B.g[i])); }
+                EXPECT(gdiff <= 1e-12 * gscale);
             }
         }
         plslam_ctx_destroy(ctx);

@@ -526,3 +526,35 @@ def test_visibility_gates_and_median_descriptor_against_reference_source_text_ou
     idx, md = ctx.median_desc_batched(g["med_desc_lists"], g["med_offsets"])
     assert np.array_equal(idx, g["med_idx"])
     assert np.array_equal(md, g["med_desc_lists"][g["med_offsets"][:-1] + g["med_idx"]])
+
+
+def test_iteration_on_the_plans_page_locked_images_equals_the_staged_call(ctx):
+    """plslam_lba_plan_host_state: a caller that keeps T / Xw / Lw in the plan's page-locked images and reads g there gets the
+    bits of the staged call (which copies the caller's arrays into those images first); pointers of any other origin keep
+    working array by array, and an update written into the images is what the next call sees."""
+    lm = synth.local_map(n_kf=6, n_pt=700, n_ls=150, seed=23)
+    cam, _ = _cams()
+    nkf = 5
+    pkf, lkf = lm["pt_kf"] - 1, lm["ls_kf"] - 1
+    plan = plslam_amd.LbaPlan(ctx, cam, 1e-7, 6, nkf, 700, 150, lm["pt_lm"], lm["pt_kf"], pkf, lm["obs_uv"], lm["ls_lm"], lm["ls_kf"],
+                              lkf, lm["l_obs"])
+    err, g = plan.iterate_dev(lm["T_kf_w"], lm["Xw"], lm["Lw"])
+    hs = plan.host_state()
+    assert hs["T_kf_w"].shape == (6, 16) and hs["Xw"].shape == (700, 3) and hs["Lw"].shape == (150, 6) and hs["g"].shape == g.shape
+    # (the staged call has just left the caller's state in the images)
+    assert np.array_equal(hs["Xw"], lm["Xw"]) and np.array_equal(hs["T_kf_w"].ravel(), np.asarray(lm["T_kf_w"]).ravel())
+    hs["g"][:] = 0
+    err2, g2 = plan.iterate_dev(hs["T_kf_w"], hs["Xw"], hs["Lw"], g_out=hs["g"])
+    assert g2 is hs["g"] and err2 == err and np.array_equal(g2, g)
+    # mixed origins: the landmarks from the image, the poses and g from ordinary memory
+    err3, g3 = plan.iterate_dev(lm["T_kf_w"], hs["Xw"], hs["Lw"])
+    assert err3 == err and np.array_equal(g3, g)
+    # an update in place
+    rng = np.random.default_rng(5)
+    dX = 1e-3 * rng.standard_normal((700, 3))
+    hs["Xw"] += dX
+    err4, g4 = plan.iterate_dev(hs["T_kf_w"], hs["Xw"], hs["Lw"], g_out=hs["g"])
+    g4 = g4.copy()
+    err5, g5 = plan.iterate_dev(lm["T_kf_w"], lm["Xw"] + dX, lm["Lw"])
+    assert err4 == err5 and err4 != err and np.array_equal(g4, g5)
+    plan.close()
