@@ -517,6 +517,7 @@ struct plslam_lba_plan {
     DevBuf schur;
     HostBuf schur_pin;
     bool schur_ready = false, schur_done = false;
+    int schur_parity = 0;              // which of the two counters of singular landmarks the next plslam_lba_plan_schur counts in
     int32_t nblk = 0, schur_chunks = 0;
     size_t oSpair = 0, oSblk = 0, oVp = 0, oVl = 0, oTp = 0, oTl = 0, oSpart = 0, oBpart = 0, oS = 0, oDp = 0, oDx = 0, oSing = 0;
 };
@@ -908,9 +909,9 @@ extern "C" int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, in
 // is the mirror of the upper one.
 //   K19 k_schur_landmarks<DL>   a lane per landmark: Vj' inverse (closed form 3x3 / Gauss-Jordan 6x6), tj = Vj'^-1 gj
 //   K20 k_schur_partials        a lane per (block, chunk, entry of the 6x6 block): sum over the chunk's pairs of W1^T Vinv W2
-//   K21 k_schur_b_partials      a lane per (keyframe, chunk, entry of b): sum over the chunk's observations of W^T tj
+//   K21 (in K20's launch)       a lane per (keyframe, chunk, entry of b): sum over the chunk's observations of W^T tj
 //   K22 k_schur_finish          a lane per (block, entry) / (keyframe, entry): chunk partials -> S (both triangles), b
-//   K23 k_schur_backsub<DL>     a lane per landmark: dxj = tj - Vinv_j sum_o W_o dp[kf(o)]  (+ the update of Xw / Lw in place)
+//   K23 k_schur_backsub         a lane per (landmark, row): dxj = tj - Vinv_j sum_o W_o dp[kf(o)]  (+ the update of Xw / Lw in place)
 //   K24 k_lba_diag_max          max |H(i,i)| over all diagonal entries (the reference's lambda *= Hmax, :1544-1550)
 // =============================================================================================================================
 namespace plslam {
@@ -1014,13 +1015,12 @@ __device__ __forceinline__ void schur_pair_block(const double* __restrict__ W1, 
     }
 }
 
-__global__ void __launch_bounds__(SCH_CHUNK)
-k_schur_partials(const SchurPair* __restrict__ pairs, const int32_t* __restrict__ blk_ptr, const double* __restrict__ W_pt,
-                 const double* __restrict__ W_ls, const double* __restrict__ Vp, const double* __restrict__ Vl,
-                 int32_t max_chunks, double* __restrict__ part /* [nblk][max_chunks][36] */)
+__device__ __forceinline__ void
+schur_partials_wg(double (*tile)[37], int B, int c, const SchurPair* __restrict__ pairs, const int32_t* __restrict__ blk_ptr,
+                  const double* __restrict__ W_pt, const double* __restrict__ W_ls, const double* __restrict__ Vp,
+                  const double* __restrict__ Vl, int32_t max_chunks, double* __restrict__ part /* [nblk][max_chunks][36] */)
 {
-    __shared__ double tile[SCH_CHUNK][37];
-    const int B = blockIdx.x, c = blockIdx.y, i = threadIdx.x;
+    const int i = threadIdx.x;
     const int beg = blk_ptr[B] + c * SCH_CHUNK;
     const int end = beg + SCH_CHUNK < blk_ptr[B + 1] ? beg + SCH_CHUNK : blk_ptr[B + 1];
     const int n = end - beg;                       // <= 0: the block has fewer chunks than the grid is wide
@@ -1043,14 +1043,13 @@ k_schur_partials(const SchurPair* __restrict__ pairs, const int32_t* __restrict_
 
 // b's share of keyframe k: sum over its observations (the keyframe lists of the assembly: points first, then lines) of W_o^T t_lm
 // -- a lane per observation of the chunk, then six lanes add the chunk's terms sequentially in list order
-__global__ void __launch_bounds__(POSE_CHUNK)
-k_schur_b_partials(const int32_t* __restrict__ kf_ptr, const int32_t* __restrict__ kf_obs, int32_t n_pt_obs,
-                   const int32_t* __restrict__ pt_lm, const int32_t* __restrict__ ls_lm, const double* __restrict__ W_pt,
-                   const double* __restrict__ W_ls, const double* __restrict__ tp, const double* __restrict__ tl,
-                   int32_t max_chunks, double* __restrict__ part /* [nkf][max_chunks][6] */)
+__device__ __forceinline__ void
+schur_b_partials_wg(double (*tile)[37], int k, int c, const int32_t* __restrict__ kf_ptr, const int32_t* __restrict__ kf_obs,
+                    int32_t n_pt_obs, const int32_t* __restrict__ pt_lm, const int32_t* __restrict__ ls_lm,
+                    const double* __restrict__ W_pt, const double* __restrict__ W_ls, const double* __restrict__ tp,
+                    const double* __restrict__ tl, int32_t max_chunks, double* __restrict__ part /* [nkf][max_chunks][6] */)
 {
-    __shared__ double tile[POSE_CHUNK][7];
-    const int k = blockIdx.x, c = blockIdx.y, i = threadIdx.x;
+    const int i = threadIdx.x;
     const int beg = kf_ptr[k] + c * POSE_CHUNK;
     const int end = beg + POSE_CHUNK < kf_ptr[k + 1] ? beg + POSE_CHUNK : kf_ptr[k + 1];
     const int n = end - beg;
@@ -1087,15 +1086,38 @@ k_schur_b_partials(const int32_t* __restrict__ kf_ptr, const int32_t* __restrict
     }
 }
 
+// both kinds of chunk partials in ONE launch (they need the landmark inverses and nothing of each other): workgroups
+// [0, nblk * schur_chunks) take the (block, chunk) pairs of S, the rest the (keyframe, chunk) pairs of b
+struct SchurPartArgs {
+    const SchurPair* pairs; const int32_t* blk_ptr; const int32_t* kf_ptr; const int32_t* kf_obs; const int32_t* pt_lm; const int32_t* ls_lm;
+    const double *W_pt, *W_ls, *Vp, *Vl, *tp, *tl;
+    double *spart, *bpart;
+    int32_t nblk, schur_chunks, nkf, pose_chunks, n_pt_obs;
+};
+static_assert(SCH_CHUNK == POSE_CHUNK, "one workgroup shape for both kinds of chunk");
+__global__ void __launch_bounds__(SCH_CHUNK)
+k_schur_partials(SchurPartArgs A)
+{
+    __shared__ double tile[SCH_CHUNK][37];
+    const int nS = A.nblk * A.schur_chunks;
+    if ((int)blockIdx.x < nS)
+        schur_partials_wg(tile, (int)blockIdx.x / A.schur_chunks, (int)blockIdx.x % A.schur_chunks, A.pairs, A.blk_ptr, A.W_pt, A.W_ls,
+                          A.Vp, A.Vl, A.schur_chunks, A.spart);
+    else
+        schur_b_partials_wg(tile, ((int)blockIdx.x - nS) / A.pose_chunks, ((int)blockIdx.x - nS) % A.pose_chunks, A.kf_ptr, A.kf_obs,
+                            A.n_pt_obs, A.pt_lm, A.ls_lm, A.W_pt, A.W_ls, A.tp, A.tl, A.pose_chunks, A.bpart);
+}
+
 // block B = (k1 <= k2) in row-major upper-triangle order; S is (6 nkf) x (6 nkf) row-major, b follows it
 __global__ void __launch_bounds__(64)
 k_schur_finish(const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ kf_ptr, const double* __restrict__ spart,
                const double* __restrict__ bpart, const double* __restrict__ H_pose, const double* __restrict__ g_pose,
                int32_t nkf, int32_t nblk, int32_t schur_chunks, int32_t pose_chunks, double lambda, double* __restrict__ S,
-               double* __restrict__ bvec)
+               double* __restrict__ bvec, int32_t* __restrict__ next_sing)
 {
     const int B = blockIdx.x, e = threadIdx.x;
     const int n6 = 6 * nkf;
+    if (B == 0 && e == 0) *next_sing = 0;          // the NEXT call's counter of singular landmarks (this call's: the other word)
     if (B < nblk) {
         if (e >= 36) return;
         int k1 = 0, rem = B;                       // B = offset(k1) + (k2 - k1), offset(k1) = sum_{i < k1} (nkf - i)
@@ -1136,38 +1158,56 @@ k_schur_finish(const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ 
     }
 }
 
+// A lane per (landmark, row x of its step): the row's share of sum_o W_o dp[kf(o)] in list order, the DL shares of a landmark
+// exchanged through LDS, then row x of Vinv times them.  192 lanes = 64 points or 32 lines per workgroup; points' workgroups
+// first, lines' behind them: ONE launch (a lane per landmark was 8 workgroups for C3's 2 000 lines: 15 + 9 us in two launches).
+constexpr int BACK_WG = 192;
 template <int DL>
-__global__ void __launch_bounds__(256)
-k_schur_backsub(const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_obs, const int32_t* __restrict__ kf_loc,
-                int32_t n, const double* __restrict__ W, const double* __restrict__ Vinv, const double* __restrict__ t,
-                const double* __restrict__ dp, double* __restrict__ dx, double* __restrict__ X /* nullptr: do not apply */)
+__device__ __forceinline__ void
+schur_backsub_wg(double* __restrict__ sh, int wg, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_obs,
+                 const int32_t* __restrict__ kf_loc, int32_t n, const double* __restrict__ W, const double* __restrict__ Vinv,
+                 const double* __restrict__ t, const double* __restrict__ dp, double* __restrict__ dx, double* __restrict__ X)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    if (j >= n) return;
-    double acc[DL];
-#pragma unroll
-    for (int x = 0; x < DL; ++x) acc[x] = 0.0;
-    for (int i = lm_ptr[j]; i < lm_ptr[j + 1]; ++i) {
-        const int o = lm_obs[i], k = kf_loc[o];
-        if (k < 0) continue;                       // a fixed keyframe: no cross block, no step
-        const double* Wo = W + (size_t)o * DL * 6;
-#pragma unroll
-        for (int x = 0; x < DL; ++x) {
+    constexpr int PER_WG = BACK_WG / DL;
+    const int q = (int)threadIdx.x / DL, x = (int)threadIdx.x % DL;
+    const int j = wg * PER_WG + q;
+    double acc = 0.0;
+    if (j < n) {
+        for (int i = lm_ptr[j]; i < lm_ptr[j + 1]; ++i) {
+            const int o = lm_obs[i], k = kf_loc[o];
+            if (k < 0) continue;                       // a fixed keyframe: no cross block, no step
+            const double* Wo = W + (size_t)o * DL * 6 + x * 6;
             double s = 0.0;
 #pragma unroll
-            for (int a = 0; a < 6; ++a) s += Wo[x * 6 + a] * dp[6 * k + a];
-            acc[x] += s;
+            for (int a = 0; a < 6; ++a) s += Wo[a] * dp[6 * k + a];
+            acc += s;
         }
     }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (j >= n) return;
+    double s = 0.0;
 #pragma unroll
-    for (int x = 0; x < DL; ++x) {
-        double s = 0.0;
-#pragma unroll
-        for (int y = 0; y < DL; ++y) s += Vinv[(size_t)j * DL * DL + x * DL + y] * acc[y];
-        const double d = t[(size_t)j * DL + x] - s;
-        dx[(size_t)j * DL + x] = d;
-        if (X) X[(size_t)j * DL + x] += d;         // :1570-1575 "update point / line LMs": X(i) += DX(i)
-    }
+    for (int y = 0; y < DL; ++y) s += Vinv[(size_t)j * DL * DL + x * DL + y] * sh[q * DL + y];
+    const double d = t[(size_t)j * DL + x] - s;
+    dx[(size_t)j * DL + x] = d;
+    if (X) X[(size_t)j * DL + x] += d;                 // :1570-1575 "update point / line LMs": X(i) += DX(i)
+}
+
+struct SchurBackArgs {
+    const int32_t *pt_ptr, *pt_obs, *pt_kf, *ls_ptr, *ls_obs, *ls_kf;
+    const double *W_pt, *W_ls, *Vp, *Vl, *tp, *tl, *dp;
+    double *dx_pt, *dx_ls, *X, *L;                     // X / L = nullptr: do not apply
+    int32_t npt, nls, nwg_pt;
+};
+__global__ void __launch_bounds__(BACK_WG)
+k_schur_backsub(SchurBackArgs A)
+{
+    __shared__ double sh[BACK_WG];
+    if ((int)blockIdx.x < A.nwg_pt)
+        schur_backsub_wg<3>(sh, (int)blockIdx.x, A.pt_ptr, A.pt_obs, A.pt_kf, A.npt, A.W_pt, A.Vp, A.tp, A.dp, A.dx_pt, A.X);
+    else
+        schur_backsub_wg<6>(sh, (int)blockIdx.x - A.nwg_pt, A.ls_ptr, A.ls_obs, A.ls_kf, A.nls, A.W_ls, A.Vl, A.tl, A.dp, A.dx_ls, A.L);
 }
 
 // max over all diagonal entries of |H(i,i)| (a maximum: exact whatever the order)
@@ -1250,6 +1290,8 @@ static int lba_schur_prepare(plslam_lba_plan* P)
     char* d = P->schur.as<char>();
     if (!pairs.empty()) PLSLAM_HIP_CHECK(hipMemcpyAsync(d + P->oSpair, pairs.data(), pairs.size() * sizeof(SchurPair), hipMemcpyHostToDevice, s));
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d + P->oSblk, cnt.data(), cnt.size() * 4, hipMemcpyHostToDevice, s));
+    PLSLAM_HIP_CHECK(hipMemsetAsync(d + P->oS + (n6 * n6 + n6 + 1) * 8, 0, 8, s));      // both counters of singular landmarks
+    P->schur_parity = 0;
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));          // (the staging vectors die here)
     P->schur_ready = true;
     return PLSLAM_OK;
@@ -1296,30 +1338,34 @@ extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* 
     const double* g = (const double*)(dout + P->oG);
     double *Vp = (double*)(d + P->oVp), *Vl = (double*)(d + P->oVl), *tp = (double*)(d + P->oTp), *tl = (double*)(d + P->oTl);
     double* dS = (double*)(d + P->oS);
-    int32_t* sing = (int32_t*)(dS + n6 * n6 + n6 + 1);       // behind S, b and the diagonal maximum: ONE copy brings S, b and it back
-    PLSLAM_HIP_CHECK(hipMemsetAsync(sing, 0, 8, s));
+    // two counters of singular landmarks behind S, b and the diagonal maximum (ONE copy brings S, b and them back): a call counts
+    // in one of them and its last kernel clears the other for the next call (both cleared at plan creation) -- no memset launch
+    int32_t* sing2 = (int32_t*)(dS + n6 * n6 + n6 + 1);
+    const int par = P->schur_parity;
+    P->schur_parity ^= 1;
     const int32_t nb3 = (P->npt + 255) / 256, nb6 = (P->nls + 255) / 256;
     if (nb3 + nb6 > 0)
         hipLaunchKernelGGL(k_schur_landmarks, dim3(nb3 + nb6), dim3(256), 0, s, (const double*)(dout + P->oHpt), g + n6, P->npt,
-                           (const double*)(dout + P->oHls), g + n6 + 3 * (size_t)P->npt, P->nls, nb3, lambda, Vp, tp, Vl, tl, sing);
-    if (P->schur_chunks > 0)
-        hipLaunchKernelGGL(k_schur_partials, dim3(P->nblk, P->schur_chunks), dim3(64), 0, s, (const SchurPair*)(d + P->oSpair),
-                           (const int32_t*)(d + P->oSblk), (const double*)(dout + P->oWp), (const double*)(dout + P->oWl), Vp, Vl,
-                           P->schur_chunks, (double*)(d + P->oSpart));
-    if (P->max_chunks > 0)
-        hipLaunchKernelGGL(k_schur_b_partials, dim3(P->nkf, P->max_chunks), dim3(64), 0, s, (const int32_t*)(ds + P->oKfp),
-                           (const int32_t*)(ds + P->oKfi), P->np, (const int32_t*)(ds + P->oPlm), (const int32_t*)(ds + P->oLlm),
-                           (const double*)(dout + P->oWp), (const double*)(dout + P->oWl), tp, tl, P->max_chunks, (double*)(d + P->oBpart));
+                           (const double*)(dout + P->oHls), g + n6 + 3 * (size_t)P->npt, P->nls, nb3, lambda, Vp, tp, Vl, tl, sing2 + par);
+    SchurPartArgs A{};
+    A.pairs = (const SchurPair*)(d + P->oSpair); A.blk_ptr = (const int32_t*)(d + P->oSblk);
+    A.kf_ptr = (const int32_t*)(ds + P->oKfp); A.kf_obs = (const int32_t*)(ds + P->oKfi);
+    A.pt_lm = (const int32_t*)(ds + P->oPlm); A.ls_lm = (const int32_t*)(ds + P->oLlm);
+    A.W_pt = (const double*)(dout + P->oWp); A.W_ls = (const double*)(dout + P->oWl); A.Vp = Vp; A.Vl = Vl; A.tp = tp; A.tl = tl;
+    A.spart = (double*)(d + P->oSpart); A.bpart = (double*)(d + P->oBpart);
+    A.nblk = P->nblk; A.schur_chunks = P->schur_chunks; A.nkf = P->nkf; A.pose_chunks = P->max_chunks; A.n_pt_obs = P->np;
+    const int32_t npart_wgs = P->nblk * P->schur_chunks + P->nkf * P->max_chunks;
+    if (npart_wgs > 0) hipLaunchKernelGGL(k_schur_partials, dim3(npart_wgs), dim3(SCH_CHUNK), 0, s, A);
     hipLaunchKernelGGL(k_schur_finish, dim3(P->nblk + P->nkf), dim3(64), 0, s, (const int32_t*)(d + P->oSblk), (const int32_t*)(ds + P->oKfp),
                        (const double*)(d + P->oSpart), (const double*)(d + P->oBpart), (const double*)(dout + P->oHp), g, P->nkf, P->nblk,
-                       P->schur_chunks, P->max_chunks, lambda, dS, dS + n6 * n6);
+                       P->schur_chunks, P->max_chunks, lambda, dS, dS + n6 * n6, sing2 + (par ^ 1));
     PLSLAM_HIP_CHECK(hipGetLastError());
     char* ho = P->schur_pin.as<char>();
     PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, dS, (n6 * n6 + n6 + 2) * 8, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     memcpy(S, ho, n6 * n6 * 8);
     memcpy(b, ho + n6 * n6 * 8, n6 * 8);
-    if (n_singular) memcpy(n_singular, ho + (n6 * n6 + n6 + 1) * 8, 4);
+    if (n_singular) memcpy(n_singular, ho + (n6 * n6 + n6 + 1) * 8 + 4 * par, 4);
     P->schur_done = true;
     return PLSLAM_OK;
 }
@@ -1340,15 +1386,16 @@ extern "C" int plslam_lba_plan_backsub(plslam_lba_plan* P, const double* dpose, 
     double* ddp = (double*)(d + P->oDp);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(ddp, hp, n6 * 8, hipMemcpyHostToDevice, s));
     double* dx = (double*)(d + P->oDx);
-    if (P->npt)
-        hipLaunchKernelGGL(k_schur_backsub<3>, dim3((P->npt + 255) / 256), dim3(256), 0, s, (const int32_t*)(ds + P->oPtp),
-                           (const int32_t*)(ds + P->oPti), (const int32_t*)(ds + P->oPkf), P->npt, (const double*)(dout + P->oWp),
-                           (const double*)(d + P->oVp), (const double*)(d + P->oTp), ddp, dx, apply ? (double*)(dd + P->oX) : nullptr);
-    if (P->nls)
-        hipLaunchKernelGGL(k_schur_backsub<6>, dim3((P->nls + 255) / 256), dim3(256), 0, s, (const int32_t*)(ds + P->oLsp),
-                           (const int32_t*)(ds + P->oLsi), (const int32_t*)(ds + P->oLkf), P->nls, (const double*)(dout + P->oWl),
-                           (const double*)(d + P->oVl), (const double*)(d + P->oTl), ddp, dx + 3 * (size_t)P->npt,
-                           apply ? (double*)(dd + P->oL) : nullptr);
+    SchurBackArgs A{};
+    A.pt_ptr = (const int32_t*)(ds + P->oPtp); A.pt_obs = (const int32_t*)(ds + P->oPti); A.pt_kf = (const int32_t*)(ds + P->oPkf);
+    A.ls_ptr = (const int32_t*)(ds + P->oLsp); A.ls_obs = (const int32_t*)(ds + P->oLsi); A.ls_kf = (const int32_t*)(ds + P->oLkf);
+    A.W_pt = (const double*)(dout + P->oWp); A.W_ls = (const double*)(dout + P->oWl);
+    A.Vp = (const double*)(d + P->oVp); A.Vl = (const double*)(d + P->oVl); A.tp = (const double*)(d + P->oTp); A.tl = (const double*)(d + P->oTl);
+    A.dp = ddp; A.dx_pt = dx; A.dx_ls = dx + 3 * (size_t)P->npt;
+    A.X = apply ? (double*)(dd + P->oX) : nullptr; A.L = apply ? (double*)(dd + P->oL) : nullptr;
+    A.npt = P->npt; A.nls = P->nls; A.nwg_pt = (P->npt + BACK_WG / 3 - 1) / (BACK_WG / 3);
+    const int32_t nwg = A.nwg_pt + (P->nls + BACK_WG / 6 - 1) / (BACK_WG / 6);
+    if (nwg > 0) hipLaunchKernelGGL(k_schur_backsub, dim3(nwg), dim3(BACK_WG), 0, s, A);
     PLSLAM_HIP_CHECK(hipGetLastError());
     if (apply) P->schur_done = false;                      // (a second application of the same step would be a bug of the caller)
     if (dX_pt || dX_ls) {
