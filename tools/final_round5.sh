@@ -6,7 +6,7 @@ set -x
 TAG=${TAG:-r5_f}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd $R
-python -m pytest tests -x -q -m gpu 2>&1 | tail -4 > $O/${TAG}_tests.txt; cat $O/${TAG}_tests.txt
+python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $O/${TAG}_tests.txt; cat $O/${TAG}_tests.txt
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > $O/${TAG}_smoke.txt; cat $O/${TAG}_smoke.txt
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/kt_schur; rocprofv3 --kernel-trace --stats -d $O/kt_schur -o run -- python $R/tools/lba_iter_trace.py 60 schur > $O/${TAG}_schur.stdout 2>/dev/null
