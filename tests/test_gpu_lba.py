@@ -562,3 +562,47 @@ def test_iteration_on_the_plans_page_locked_images_equals_the_staged_call(ctx):
     err5, g5 = plan.iterate_dev(lm["T_kf_w"], lm["Xw"] + dX, lm["Lw"])
     assert err4 == err5 and err4 != err and np.array_equal(g4, g5)
     plan.close()
+
+
+@pytest.mark.parametrize("n_kf,n_pt,n_ls,obs", [
+    (6, 300, 0, 4),        # points only: no line workgroups in any of the fused launches
+    (6, 0, 90, 4),         # lines only
+    (2, 200, 40, 2),       # ONE optimised keyframe: a single block of S, one pair per landmark
+    (4, 1500, 300, 4),     # every block's pair list spans several chunks of 64 (the two-level sums)
+    (3, 1, 1, 3),          # a workgroup with two live lanes
+])
+def test_schur_step_edge_shapes(ctx, oracle, n_kf, n_pt, n_ls, obs):
+    """The Schur step against the dense damped solve over shapes that leave parts of its fused launches empty or make its
+    chunked sums long (plslam_lba_plan_schur / _backsub; the reference: src/mapHandler.cpp:1552-1575)."""
+    lm = synth.local_map(n_kf=n_kf, n_pt=n_pt, n_ls=n_ls, obs_per_lm=min(obs, n_kf), seed=100 + n_pt + n_ls)
+    cam, ocam = _cams()
+    nkf = n_kf - 1
+    pkf, lkf = lm["pt_kf"] - 1, lm["ls_kf"] - 1
+    T, X, L = lm["T_kf_w"], lm["Xw"], lm["Lw"]
+    plan = plslam_amd.LbaPlan(ctx, cam, 1e-7, n_kf, nkf, n_pt, n_ls, lm["pt_lm"], lm["pt_kf"], pkf, lm["obs_uv"], lm["ls_lm"], lm["ls_kf"],
+                              lkf, lm["l_obs"])
+    plan.iterate_dev(T, X, L, want_g=False)
+    N = 6 * nkf + 3 * n_pt + 6 * n_ls
+    H, g = np.zeros((N, N)), np.zeros(N)
+    if n_pt:
+        rp = oracle.lba_point_rows(ocam, 1e-7, T, X, lm["obs_uv"], lm["pt_lm"], lm["pt_kf"])
+        H, g, _ = oracle.lba_accumulate("points", nkf, n_pt, n_ls, lm["pt_lm"], pkf, *rp, H=H, g=g)
+    if n_ls:
+        rl = oracle.lba_line_rows(ocam, 1e-7, T, L, lm["l_obs"], lm["ls_lm"], lm["ls_kf"])
+        H, g, _ = oracle.lba_accumulate("lines", nkf, n_pt, n_ls, lm["ls_lm"], lkf, *rl, H=H, g=g)
+    lam = 1e-3
+    Hd = H.copy()
+    Hd[np.diag_indices_from(Hd)] *= 1.0 + lam
+    n6 = 6 * nkf
+    Vi = np.linalg.inv(Hd[n6:, n6:])
+    S_ref, b_ref = Hd[:n6, :n6] - Hd[:n6, n6:] @ Vi @ Hd[n6:, :n6], g[:n6] - Hd[:n6, n6:] @ Vi @ g[n6:]
+    for rep in range(2):                                   # (twice: the two counters of singular blocks take turns)
+        S, b, ns = plan.schur(lam)
+        assert ns == 0
+        assert np.allclose(S, S_ref, rtol=0, atol=1e-9 * np.abs(S_ref).max()) and np.allclose(b, b_ref, rtol=0, atol=1e-9 * np.abs(b_ref).max())
+    DX = np.linalg.solve(Hd, g)
+    dp = np.linalg.solve(S, b)
+    dxp, dxl = plan.backsub(dp)
+    got = np.concatenate([dp, dxp.reshape(-1), dxl.reshape(-1)])
+    assert np.allclose(got, DX, rtol=0, atol=1e-7 * np.abs(DX).max()), np.abs(got - DX).max() / np.abs(DX).max()
+    plan.close()
