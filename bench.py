@@ -8,7 +8,8 @@ StereoFrame's epipolar / disparity / overlap gates over the two L<->R tables -- 
 With N > 1 ranks (one per GPU, torch.distributed 'nccl' == RCCL) every rank runs its own shard of
 pairs (weak scaling) and the per-pair match tables are gathered to rank 0 inside the step.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement" for every field).
+Prints ONE compact JSON line on rank 0 (the contract's keys, < 6 kB) and writes the full record -- secondary
+records, distributions, notes -- to gpurun_out/bench_full.json (see DESIGN.md "Measurement" for every field).
 """
 from __future__ import annotations
 
@@ -75,6 +76,49 @@ def kernel_source_hash() -> str:
         h.update(name.encode())
         h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
+
+
+COMPACT_LINE_CAP = 6144        # bytes of the one stdout line (target <= 6 kB, the driver failed at 22 kB)
+
+
+def _short(s, n=120):
+    return s if not isinstance(s, str) or len(s) <= n else s[:n - 3] + "..."
+
+
+def compact_line(full: dict, side_path) -> dict:
+    """The ONE stdout line: the bench contract's keys, `roofline`, `hbm_roofline`, `cpu_baseline`, `verified` -- numbers and
+    short strings only.  Everything else of the full record (secondary records, step-time distribution, the one-batch
+    comparison, executed-instruction figures, notes) is in the side file `details`."""
+    c = full["config"]
+    r = full["roofline"]
+    out = {k: full[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data")}
+    out["config"] = {"workload": _short(c["workload"], 200), "pairs_per_gpu_per_step": c["pairs_per_gpu_per_step"],
+                     "pairs_per_step_all_gpus": c["pairs_per_step_all_gpus"], "nnr_p": c["nnr_p"], "nnr_l": c["nnr_l"],
+                     "mutual": c["mutual"], "distinct_batches_in_rotation": c["distinct_batches_in_rotation"],
+                     "stereo_gates": c["stereo_gates"] is not None, "kernel": c["kernel"], "mfma_form": c["mfma_form"],
+                     "kernel_source_hash": c["kernel_source_hash"], "rccl_ranks_seen": c["rccl_ranks_seen"],
+                     "gather_wire": None if c["gather_wire"] is None else {k: c["gather_wire"][k] for k in ("format", "comm")},
+                     "parallelism": _short(c["parallelism"], 100)}
+    out["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
+                                             "frac_profiles", "frac_profiles_source")}
+    h = full["hbm_roofline"]
+    out["hbm_roofline"] = {k: h.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}
+    out["kernel_ms"] = {k: v for k, v in full["kernel_ms"].items() if k != "note"}
+    if "cpu_baseline" in full:
+        b = full["cpu_baseline"]
+        out["cpu_baseline"] = {"value": b["value"], "unit": b["unit"], "cores": b["cores"],
+                               "host_logical_cpus": b.get("host_logical_cpus"), "kind": b["kind"],
+                               "cores_note": f"{b['cores']} usable of {b.get('host_logical_cpus')} logical CPUs (cgroup quota)",
+                               "sample": _short(b.get("sample"), 160)}
+    out["verified"] = {k: _short(v, 160) for k, v in full["verified"].items()}
+    c4 = (full.get("secondary") or {}).get("config4_strong")
+    if c4 is not None and full["n_gpus"] >= 1 and "value" in c4:
+        out["config4_strong"] = {k: c4.get(k) for k in ("value", "unit", "n_gpus", "scaling", "pairs_per_gpu_per_step", "ms_per_step",
+                                                        "host_ms_per_step")}
+    out["device"] = full.get("device")
+    out["details"] = side_path
+    return out
 
 
 def oracle_tables(stream, n_orb, n_lbd, nnr_p, nnr_l, threads=None):
@@ -375,6 +419,9 @@ def main():
                          "or a communication stream of its own (auto: both are tried by the probe; without a probe: stage at one "
                          "rank, own at N > 1)")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
+    ap.add_argument("--full-json", default=None, metavar="PATH",
+                    help="where the FULL record goes (secondary records, distributions, notes); default gpurun_out/bench_full.json. "
+                         "stdout carries one compact line of the contract's keys")
     ap.add_argument("--launch-check", action="store_true",
                     help="(tests) after the self-launch: a gloo rendezvous of the ranks and ONE JSON line from rank 0 -- no GPU work")
     args = ap.parse_args()
@@ -829,7 +876,21 @@ def main():
     elif rank == 0 and config4 is not None:
         out["secondary"] = {"config4_strong": config4}
     if rank == 0:
-        os.write(real_stdout, (json.dumps(out) + "\n").encode())
+        # The driver parses the LAST stdout line and keeps only a bounded tail of stdout (round 5's 22 kB line came back
+        # unparsed): the line is the contract's keys and nothing else; every secondary record, distribution and prose note
+        # goes to a side file whose path the line names.
+        side = args.full_json or os.path.join(_ROOT, "gpurun_out", "bench_full.json" if world == 1 and not use_dist else f"bench_full_n{world}.json")
+        try:
+            os.makedirs(os.path.dirname(side), exist_ok=True)
+            with open(side, "w") as f:
+                json.dump(out, f, indent=1)
+        except OSError as e:                         # (a read-only tree: the line still goes out)
+            note(f"side file {side} not written: {e}")
+            side = None
+        line = json.dumps(compact_line(out, side and os.path.relpath(side, _ROOT)), separators=(",", ":"))
+        if len(line) >= COMPACT_LINE_CAP:
+            raise SystemExit(f"bench line of {len(line)} bytes: the driver parses at most {COMPACT_LINE_CAP}")
+        os.write(real_stdout, (line + "\n").encode())
 
     ctx.close()
     if use_dist:

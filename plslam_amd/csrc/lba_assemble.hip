@@ -674,11 +674,13 @@ static int lba_plan_download(plslam_lba_plan* P, double* g, double* H_pose, doub
     if (!H_pose && !H_pt && !H_ls && !W_pt && !W_ls) {
         // g and err (or err alone): one copy into page-locked memory, then out of it
         char* ho = P->pin_out.as<char>();
+        // err alone lands in the slot it has in the g + err copy, BEHIND the image's g (plslam_lba_plan_host_state hands
+        // out ho as g: an err-only iteration -- a rejected LM trial step -- must leave the gradient there untouched)
         const size_t off = g ? P->oG : P->oErr, bytes = g ? N * 8 + 8 : 8;
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, dout + off, bytes, hipMemcpyDeviceToHost, s));
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(ho + (g ? 0 : N * 8), dout + off, bytes, hipMemcpyDeviceToHost, s));
         PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
         if (g && (char*)g != ho) memcpy(g, ho, N * 8);      // (g = the page-locked image itself: plslam_lba_plan_host_state)
-        if (err) memcpy(err, ho + bytes - 8, 8);
+        if (err) memcpy(err, ho + N * 8, 8);
         return PLSLAM_OK;
     }
     if ((rc = down(g, P->oG, N * 8)) || (rc = down(H_pose, P->oHp, (size_t)P->nkf * 288)) ||

@@ -1,6 +1,7 @@
 """bench.py end to end on the GPU with a tiny workload: the script the driver runs must keep
-printing exactly one JSON line with the contract's fields, in plain mode and with the RCCL
-process group forced (1 rank: the only size a 1-GPU box offers)."""
+printing exactly one COMPACT JSON line with the contract's fields (the driver could not parse round 5's
+22 kB line), the full record in a side file, in plain mode and with the RCCL process group forced
+(1 rank: the only size a 1-GPU box offers)."""
 import json
 import os
 import subprocess
@@ -14,21 +15,60 @@ REQUIRED = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step
             "vs_baseline", "dtype", "data", "config", "roofline"}
 
 
-def _run(extra, env=None, pairs=24, n_orb=192, n_lbd=40):
+LINE_KEYS = REQUIRED | {"hbm_roofline", "kernel_ms", "verified", "device", "details"}
+LINE_CAP = 6144                # bytes; the driver parsed <= 18.8 kB lines and failed at 22 kB -- the verdict's hard cap is 12 kB
+
+
+def _check_line(stdout, tmp_path):
+    """The stdout contract: one line, compact, only the contract's keys; returns (line, full record of the side file)."""
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, stdout[-2000:]
+    assert len(lines[0]) < LINE_CAP, len(lines[0])
+    line = json.loads(lines[0])
+    assert REQUIRED <= set(line) and set(line) <= LINE_KEYS | {"cpu_baseline", "config4_strong"}, sorted(line)
+    assert "secondary" not in line and "note" not in line["roofline"]
+    assert set(line["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "kernel_ms",
+                                     "frac_profiles", "frac_profiles_source"}
+    assert all(len(v) <= 200 for v in line["config"].values() if isinstance(v, str))
+    full = json.load(open(tmp_path / "full.json"))
+    assert all(full[k] == line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype"))
+    assert full["roofline"]["frac"] == line["roofline"]["frac"]
+    return line, full
+
+
+def _run(extra, tmp_path, env=None, pairs=24, n_orb=192, n_lbd=40):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
-           "--pairs-per-gpu", str(pairs), "--n-orb", str(n_orb), "--n-lbd", str(n_lbd)] + extra
+           "--pairs-per-gpu", str(pairs), "--n-orb", str(n_orb), "--n-lbd", str(n_lbd), "--full-json", str(tmp_path / "full.json")] + extra
     e = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **(env or {}))
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=e)
     assert res.returncode == 0, res.stderr[-3000:]
-    lines = [l for l in res.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, res.stdout[-2000:]
-    return json.loads(lines[0])
+    return _check_line(res.stdout, tmp_path)
 
 
-def test_bench_single_gpu_line():
+def test_bench_default_workload_line_is_compact(tmp_path):
+    """The driver's own command shape -- default sizes (C2: 4096 pairs of 1500 ORB + 200 LBD, every secondary record) with a
+    short timed region and CPU leg: the line must stay under the cap AT THIS SHAPE (round 5's was 22 kB here and came back
+    `parsed: null`), carry `roofline.frac` and `cpu_baseline.value`, and name the side file holding the rest."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2", "--cpu-budget-s", "1",
+           "--full-json", str(tmp_path / "full.json")]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert res.returncode == 0, res.stderr[-3000:]
+    line, full = _check_line(res.stdout, tmp_path)
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["warmup"] == 2
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1 and line["roofline"]["kernel_ms"] > 0
+    assert 0 < line["hbm_roofline"]["frac"] < 1
+    cb = line["cpu_baseline"]
+    assert cb["value"] > 0 and cb["kind"] == "port" and cb["cores"] >= 1 and "usable of" in cb["cores_note"]
+    assert line["config"]["pairs_per_gpu_per_step"] == 4096 and "1500 ORB + 200 LBD" in line["config"]["workload"]
+    assert line["verified"]["match_tables"].startswith("all 4096 pairs")
+    assert line["details"].endswith("full.json") and len(full["secondary"]) >= 12
+
+
+def test_bench_single_gpu_line(tmp_path):
     """A plan too small for the matrix-core scan (AUTO picks the latency kernel): the HBM branch of the line, with the
     CPU baseline, the full-batch verification it enables, the stereo-gate stage and the secondary records."""
-    d = _run(["--cpu-budget-s", "1"])
+    line, d = _run(["--cpu-budget-s", "1"], tmp_path)
+    assert "cpu_baseline" in line and line["cpu_baseline"]["cores"] == d["cpu_baseline"]["cores"]
     assert REQUIRED <= set(d) and "cpu_baseline" in d
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
@@ -71,11 +111,12 @@ def test_bench_single_gpu_line():
     assert "the 2 other batch(es) of the rotation: every pair" in d["verified"]["match_tables"]
 
 
-def test_bench_matrix_core_branch_of_the_line():
+def test_bench_matrix_core_branch_of_the_line(tmp_path):
     """A plan large enough for AUTO to take the matrix-core scan -- the branch the driver's default run gets: roofline
     bound "mfma", fp4 operand type, the HBM model beside it, PMC-derived fields absent unless the committed passes were
     taken on exactly these kernel sources."""
-    d = _run(["--no-cpu-baseline", "--no-secondary"], pairs=160, n_orb=512, n_lbd=64)
+    line, d = _run(["--no-cpu-baseline", "--no-secondary"], tmp_path, pairs=160, n_orb=512, n_lbd=64)
+    assert line["roofline"]["bound"] == "mfma" and line["dtype"] == "fp4" and "cpu_baseline" not in line
     assert REQUIRED <= set(d) and d["value"] > 0
     assert d["roofline"]["bound"] == "mfma" and d["dtype"] == "fp4" and d["roofline"]["unit"] == "TFLOP/s"
     assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["kernel"] == "k_scan_sym_mfma_i"
@@ -87,19 +128,18 @@ def test_bench_matrix_core_branch_of_the_line():
     assert d["verified"]["match_tables"].startswith("64 pairs (the shard's ends")
 
 
-def test_bench_forced_rccl_group_one_rank():
+def test_bench_forced_rccl_group_one_rank(tmp_path):
     """`python bench.py --gpus 1 --force-dist` with no launcher around it: the script launches itself under
     torch.distributed.run (the road `python bench.py --gpus 8` takes), rank 0 prints the one line; the N > 1 stepping, the
     gather probe, the 64-pair check of the gathered tables and the config-4-as-written record all run on the one-rank group."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--pairs-per-gpu", "24",
-           "--n-orb", "192", "--n-lbd", "40", "--no-cpu-baseline", "--force-dist"]
+           "--n-orb", "192", "--n-lbd", "40", "--no-cpu-baseline", "--force-dist", "--full-json", str(tmp_path / "full.json")]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert res.returncode == 0, res.stderr[-3000:]
     assert "self-launch" in res.stderr
-    lines = [l for l in res.stdout.splitlines() if l.strip()]
-    assert len(lines) == 1, res.stdout[-2000:]
-    d = json.loads(lines[0])
+    line, d = _check_line(res.stdout, tmp_path)
+    assert line["config"]["gather_wire"]["format"] in ("int16", "int32") and line["config4_strong"]["value"] > 0
     assert REQUIRED <= set(d) and d["value"] > 0
     assert "RCCL gather" in d["config"]["parallelism"]
     assert d["config"]["rccl_ranks_seen"] == {"world_size": 1, "distinct_devices": 1}
@@ -111,8 +151,9 @@ def test_bench_forced_rccl_group_one_rank():
     assert c4["plain_step_same_run"]["value"] > 0 and c4["host_ms_per_step"] > 0 and "GATHERED" in c4["verified"]
 
 
-def test_bench_strong_scaling_flag_at_one_rank():
+def test_bench_strong_scaling_flag_at_one_rank(tmp_path):
     """--scaling strong: --pairs-per-gpu is the TOTAL per step, sharded over the ranks (BASELINE config 4); at one rank the
     shard is the whole batch and the line says so."""
-    d = _run(["--no-cpu-baseline", "--no-secondary", "--scaling", "strong"], pairs=32)
+    line, d = _run(["--no-cpu-baseline", "--no-secondary", "--scaling", "strong"], tmp_path, pairs=32)
+    assert line["scaling"] == "strong" and line["config"]["pairs_per_step_all_gpus"] == 32
     assert d["scaling"] == "strong" and d["config"]["pairs_per_gpu_per_step"] == 32 and d["config"]["pairs_per_step_all_gpus"] == 32

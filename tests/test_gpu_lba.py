@@ -561,6 +561,10 @@ def test_iteration_on_the_plans_page_locked_images_equals_the_staged_call(ctx):
     g4 = g4.copy()
     err5, g5 = plan.iterate_dev(lm["T_kf_w"], lm["Xw"] + dX, lm["Lw"])
     assert err4 == err5 and err4 != err and np.array_equal(g4, g5)
+    # an err-only iteration (a rejected LM trial step) leaves the gradient of the image alone (it landed on g[0])
+    err6, none6 = plan.iterate_dev(hs["T_kf_w"], hs["Xw"], hs["Lw"], want_g=False)
+    assert none6 is None and err6 == err4 and np.array_equal(hs["g"], g4)
+    assert plan.iterate_resident() == err4 and np.array_equal(hs["g"], g4)
     plan.close()
 
 
