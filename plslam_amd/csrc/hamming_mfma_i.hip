@@ -51,7 +51,10 @@
 #endif
 // build-time experiments (tools/build_exp.py; results are WRONG with any of them on): 1 no tile barrier, 2 no operand reads
 // from LDS, 4 no MFMA, 8 no bookkeeping (pack + minima), 16 no expansion / prefetch, 32 no gathers in the row finish's
-// re-evaluation of the winner cell (its arithmetic stays), 64 no re-evaluation at all
+// re-evaluation of the winner cell (its arithmetic stays), 64 no re-evaluation at all, 128 (round 6, with the DIRECTED
+// instantiation: `mfma_form 6`'s UPPER BOUND) the whole bookkeeping of an accumulator set = eight v_min3_f32 on the unpacked
+// accumulators into two lane-local running minima per M-tile -- no pack, no row cells, no group pushes, no row finish: what a
+// two-directed-pass scan with column-direction minima only could cost at best (tools/form6_bound.sh)
 #ifndef PLSLAM_MI_X
 #define PLSLAM_MI_X 0
 #endif
@@ -71,6 +74,28 @@
 // 0 = round 4's code (A/B builds: tools/build_exp.py hamming_mfma_i.hip r4:-DPLSLAM_MI_R5=0)
 #ifndef PLSLAM_MI_R5
 #define PLSLAM_MI_R5 31
+#endif
+// PLSLAM_MI_R6 (round 6; bit set, default all): the tile body's bookkeeping WITHOUT THE PACK.
+//   1  An accumulator is the float 2^23 + key: its low half IS the 16-bit key, its high half the constant 0x4B00 -- as a half
+//      float 14.0, above every real key (<= 0x3FFF) and below "none".  v_pk_minimum3_f16 takes op_sel per source, so
+//          gm = pk_min3(gm, acc[q], acc[q + 8])  op_sel:[0,0,1] op_sel_hi:[1,1,0]
+//      is  gm.lo = min(gm.lo, key(acc[q]), 0x4B00), gm.hi = min(gm.hi, 0x4B00, key(acc[q + 8])): the row direction's update of
+//      a row PAIR straight from the two unpacked accumulators -- the v_perm that packed them (16 of the 52 VALU instructions
+//      of a wave-tile) is gone; "none" and the penalty keys of columns that do not exist are capped at 0x4B00, still above
+//      MI_KEY16_MAX wherever they are tested.  The column direction folds the same two accumulators into a float minimum with
+//      v_min3_f32 (2^23 + key orders like the key; one chain per accumulator set, started by a two-input v_min_f32 of the set's
+//      first pair; the parked word is one v_perm of the two M-tiles' minima -- the values K1h parks).  Per accumulator set
+//      8 + 8 instead of 8 + 8 + 4 and one instruction instead of three per parked word: 33 VALU per wave-tile instead of 43
+//      (directed: 16 instead of 32).  The accumulators are inline-asm operands now: the
+//      compiler does not count MFMA -> VALU wait states for them, tools/check_mfma_hazards.py does (tests/test_abi.py).
+// 0 = round 5's code
+#ifndef PLSLAM_MI_R6
+#define PLSLAM_MI_R6 1
+#endif
+#if PLSLAM_MI_F16 && (PLSLAM_MI_R6 & 1) && !PLSLAM_MI_ROWLOOK
+#define PLSLAM_MI_NOPACK 1
+#else
+#define PLSLAM_MI_NOPACK 0
 #endif
 // PLSLAM_MI_PERSIST = N > 0 (experiment): at most N persistent workgroups, each walking its XCD's row of the block table
 #ifndef PLSLAM_MI_PERSIST
@@ -392,6 +417,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // FINAL (the window's last, possibly partial, group): the merged pairs stay in registers (rb) for the row finish.
     auto push_groups = [&](int t, auto final_tag, u32x2_t* rb) __attribute__((always_inline)) {
         constexpr bool FINAL = decltype(final_tag)::value;
+        if (PLSLAM_MI_X & 128) { if (FINAL) { for (int s = 0; s < 16; ++s) rb[s] = u32x2_t{gm[s], 0u}; } return; }
         const uint32_t grp = (uint32_t)(((t - wt0) >> 4) & 3);
 #if PLSLAM_MI_UNSCALED
         const uint32_t gtag = grp * 0x00010001u;        // the group number takes the tag's five bits
@@ -444,6 +470,10 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // parked word = (group minimum of M-tile 0 | group minimum of M-tile 1 << 16), K1h's
     auto finish_columns = [&](int t, uint32_t c0, uint32_t c1) __attribute__((always_inline)) {
         if (DIRECTED) { asm volatile("" ::"v"(c0), "v"(c1)); return; }
+        if (PLSLAM_MI_NOPACK) {      // c0 / c1: the float minima (2^23 + key) of the lane's 16 rows of M-tile 0 / 1
+            cstage[(t & (MH_CGROUP - 1)) * 256 + lane] = __builtin_amdgcn_perm(c1, c0, 0x05040100u);
+            return;
+        }
         const uint32_t lo = __builtin_amdgcn_perm(c1, c0, 0x05040100u);      // (c0.lo | c1.lo << 16)
         const uint32_t hi = __builtin_amdgcn_perm(c1, c0, 0x07060302u);      // (c0.hi | c1.hi << 16)
         cstage[(t & (MH_CGROUP - 1)) * 256 + lane] = pk_min16(lo, hi);
@@ -458,6 +488,20 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // direction: both pairs and the running minimum in ONE instruction.
 #define PLSLAM_MI_EPI2(ACC, MT, Q, PAR)                                                            \
     if (PLSLAM_MI_X & 8) { if ((Q) == 0) { asm volatile("" :: "v"(ACC)); cma = __builtin_bit_cast(uint32_t, (float)ACC[0]); } } else \
+    if (PLSLAM_MI_X & 128) {                                                                       \
+        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(f6[2 * (MT)]) : "v"(ACC[Q]), "v"(ACC[(Q) + 8]));    \
+        asm("v_min3_f32 %0, %0, %1, %2" : "+v"(f6[2 * (MT) + 1]) : "v"(ACC[(Q) + 1]), "v"(ACC[(Q) + 9])); \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } else if (PLSLAM_MI_NOPACK) {                                                                 \
+        asm("v_pk_minimum3_f16 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "+v"(gm[8 * (MT) + (Q)]) : "v"(ACC[Q]), "v"(ACC[(Q) + 8])); \
+        asm("v_pk_minimum3_f16 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "+v"(gm[8 * (MT) + (Q) + 1]) : "v"(ACC[(Q) + 1]), "v"(ACC[(Q) + 9])); \
+        if (!DIRECTED) {   /* ONE chain, started by the set's first pair: no initial value, no join */ \
+            if ((Q) == 0) asm("v_min_f32 %0, %1, %2" : "=v"(cfa) : "v"(ACC[Q]), "v"(ACC[(Q) + 8])); \
+            else asm("v_min3_f32 %0, %0, %1, %2" : "+v"(cfa) : "v"(ACC[Q]), "v"(ACC[(Q) + 8]));    \
+            asm("v_min3_f32 %0, %0, %1, %2" : "+v"(cfa) : "v"(ACC[(Q) + 1]), "v"(ACC[(Q) + 9]));   \
+        }                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                         \
+    } else                                                                                         \
     {                                                                                              \
         uint32_t kc0 = pack_acc(ACC[Q], ACC[(Q) + 8]), kc1 = pack_acc(ACC[(Q) + 1], ACC[(Q) + 9]); \
         if (!PLSLAM_MI_LOOK(MT)) {                                                                 \
@@ -499,6 +543,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // minima of its M-tile 0
     f32x16 m1;
     uint32_t cm0_prev = MI_NONE32;
+    float f6[4] = {3.0e38f, 3.0e38f, 3.0e38f, 3.0e38f};      // (PLSLAM_MI_X & 128 only)
     //   step(t) = barrier | operand reads | M0(t) x E1(t-1) | expand(t+1), prefetch(t+4) | columns(t-1) [| combine | push] | M1(t) x E0(t)
     // FULL: tiles t .. t + 4 lie in full groups (no ragged-group tests, the short prefetch address)
     auto tile_step = [&](int t, auto u_tag, bool with_prev, auto full_tag) __attribute__((always_inline)) {
@@ -520,9 +565,19 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         const f32x16 cseed = __builtin_bit_cast(f32x16, seed);
         f32x16 m0;
         uint32_t cma = MI_NONE32, cmb = MI_NONE32;
+        float cfa = 0.0f;              // (PLSLAM_MI_NOPACK) the column direction's float minimum of the accumulator set in hand
+        auto cf_join = [&]() __attribute__((always_inline)) -> uint32_t { return __builtin_bit_cast(uint32_t, cfa); };
         constexpr int PAR1 = (U + 1) & 1, PAR0 = U & 1;     // the parities of tile t-1 (phase 1) and of tile t (phase 2)
         __builtin_amdgcn_sched_barrier(0);
         // phase 1: M-tile 0 of tile t under the bookkeeping of M-tile 1 of tile t-1
+        // (PLSLAM_MI_NOPACK: the accumulators of M-tile 1 are inline-asm operands -- the wait states behind the chain's last
+        // MFMA, issued one bookkeeping block before the end of the step before, are counted by hand: 14 as the compiler counts
+        // them for its own instructions (round 5's listing: `s_nop 5` here, in front of the v_perm).  They pass under the latency
+        // of the operand reads just requested, which the first MFMA waits for anyway.)
+        if (PLSLAM_MI_NOPACK && !(PLSLAM_MI_X & (8 | 128))) {
+            if (DIRECTED) asm volatile("s_nop 7"); else asm volatile("s_nop 4");
+            __builtin_amdgcn_sched_barrier(0);
+        }
         PLSLAM_MI_EPI2(m1, 1, 0, PAR1) PLSLAM_MI_MMA(m0, 0, 0, cseed)
         bfr[2] = PLSLAM_MI_READ_B(2);
         PLSLAM_MI_EPI2(m1, 1, 2, PAR1) PLSLAM_MI_MMA(m0, 0, 1, m0)
@@ -531,7 +586,7 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         // the next tile's raw dword (requested three steps ago) leaves the ring: an LDS latency ahead of its expansion
         const uint32_t raw_next = (PLSLAM_MI_X & 16) ? 0u : take_raw(RING == 4 ? 1024u * ((U + 1) & 3) : ring_slot);
         PLSLAM_MI_EPI2(m1, 1, 6, PAR1) PLSLAM_MI_MMA(m0, 0, 3, m0)
-        const uint32_t cm1 = PLSLAM_MI_F16 ? cma : pk_min16(cma, cmb);
+        const uint32_t cm1 = PLSLAM_MI_NOPACK ? cf_join() : PLSLAM_MI_F16 ? cma : pk_min16(cma, cmb);
         // behind the chain of M-tile 0: the expansion of the next tile (its buffer was read for the last time before this
         // step's barrier) and the prefetch -- independent work while the last MFMA of the chain completes
         if (!(PLSLAM_MI_X & 16)) {
@@ -579,12 +634,22 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         PLSLAM_MI_MMA(m1, 1, 1, m1)    PLSLAM_MI_EPI2(m0, 0, 2, PAR0)
         PLSLAM_MI_MMA(m1, 1, 2, m1)    PLSLAM_MI_EPI2(m0, 0, 4, PAR0)
         PLSLAM_MI_MMA(m1, 1, 3, m1)    PLSLAM_MI_EPI2(m0, 0, 6, PAR0)
-        cm0_prev = PLSLAM_MI_F16 ? cma : pk_min16(cma, cmb);
+        cm0_prev = PLSLAM_MI_NOPACK ? cf_join() : PLSLAM_MI_F16 ? cma : pk_min16(cma, cmb);
     };
     // the bookkeeping of M-tile 1 of a window's last tile on its own (no following step to hide under)
     auto epilogue = [&](int t) __attribute__((always_inline)) {
         uint32_t cma = MI_NONE32, cmb = MI_NONE32;
 #if PLSLAM_MI_F16
+        float cfa = 0.0f;
+        if (PLSLAM_MI_NOPACK) {
+            // (the accumulators of M-tile 1 are inline-asm operands: the wait states behind the chain's last MFMA -- four VALU
+            // instructions back in the last step -- are counted by hand here: 12 for the 8-pass form)
+            asm volatile("s_nop 7\n\ts_nop 7");
+            __builtin_amdgcn_sched_barrier(0);
+            PLSLAM_MI_EPI2(m1, 1, 0, 0) PLSLAM_MI_EPI2(m1, 1, 2, 0) PLSLAM_MI_EPI2(m1, 1, 4, 0) PLSLAM_MI_EPI2(m1, 1, 6, 0)
+            finish_columns(t, cm0_prev, __builtin_bit_cast(uint32_t, cfa));
+            return;
+        }
         if (t & 1) {                               // (wave-uniform) an odd last tile: the even tile's pairs of M-tile 1 are waiting
             PLSLAM_MI_EPI2(m1, 1, 0, 1) PLSLAM_MI_EPI2(m1, 1, 2, 1) PLSLAM_MI_EPI2(m1, 1, 4, 1) PLSLAM_MI_EPI2(m1, 1, 6, 1)
         } else {
@@ -657,6 +722,12 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // the best entry names the CELL (group, class) that holds the best column, whose S members are recomputed from the raw rows.
     // rb: the parked sorted pairs with the window's last group merged in (push_groups, FINAL) -- in registers.
     auto finish_rows = [&](const u32x2_t* rb) __attribute__((always_inline)) {
+        if (PLSLAM_MI_X & 128) {       // the lane-local minima leave as they are: one store per lane
+            const int row_ = iw + lane + (lane & 32) * 3;
+            if (row_ < n1) ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys12))[row_] =
+                u32x2_t{__builtin_bit_cast(uint32_t, fminf(f6[0], f6[1])), __builtin_bit_cast(uint32_t, fminf(f6[2], f6[3])) + rb[0].x};
+            return;
+        }
         uint32_t* rowx = reinterpret_cast<uint32_t*>(smem) + w * (64 * ROWX_STRIDE);
         // (the barrier behind the tile loop stands between every wave's last read of the b tile / of its parked pairs and
         // these writes: the transpose may overwrite both)

@@ -138,7 +138,11 @@ def test_final_isa_has_no_mfma_destination_hazard(tmp_path, fname):
         assert text.count("v_mfma_f32_32x32x64_f8f6f4") >= 128 and "v_mfma_scale" not in text
     else:
         assert text.count("v_mfma_scale_f32_32x32x64_f8f6f4") >= (24 if fname == "hamming_mfma_d.hip" else 128)
-    findings = mod.check(out, 12)
+    # K1i (round 6) reads its accumulators from inline asm (v_pk_minimum3_f16 with op_sel / v_min3_f32 on the unpacked
+    # registers): the compiler counts no wait states for those operands, so the listing must keep the distance the compiler
+    # keeps for its own instructions -- 14 by this checker's counting (round 5's listing: `s_nop 5` in front of the v_perm
+    # that read a chain's result 8 instructions behind its last MFMA; no finding at 14, five at 15)
+    findings = mod.check(out, 14 if fname == "hamming_mfma_i.hip" else 12)
     assert not findings, findings[:5]
 
 
@@ -231,10 +235,14 @@ def test_the_scan_stays_at_three_workgroups_per_cu(tmp_path, fname, kernel, max_
     assert seen == 2                                       # the symmetric and the directed instantiation
 
 
-def test_k1i_inline_asm_touches_accumulators_only_as_an_mfma_destination():
-    """K1i's one exception to "no asm statement takes an accumulator": the first MFMA of the loop-carried chain is an asm
-    statement with an early-clobber DESTINATION (the compiler's tied form would copy 16 seed registers per tile).  Nothing
-    else: the accumulators are read by pack_acc -- a builtin -- only, and no asm statement takes one as an INPUT."""
+def test_k1i_inline_asm_reads_accumulators_only_in_the_bookkeeping_macro():
+    """K1i's asm statements and the accumulators.  (1) The first MFMA of the loop-carried chain is an asm statement with an
+    early-clobber DESTINATION (the compiler's tied form would copy 16 seed registers per tile) -- never an input.  (2) Round 6:
+    the bookkeeping macro PLSLAM_MI_EPI2 reads accumulator ELEMENTS from asm (v_pk_minimum3_f16 with op_sel, v_min3_f32 /
+    v_min_f32 on the unpacked registers: no v_perm pack).  The compiler counts no MFMA -> VALU wait states for asm operands:
+    every such read must sit in that macro (whose uses are separated from the chain's last MFMA by the other chain's MFMAs,
+    or by the hand-counted s_nop in front of phase 1 and of the epilogue), and the final listing is checked at the compiler's
+    own distance by test_final_isa_has_no_mfma_destination_hazard."""
     import os
     import re
     src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plslam_amd", "csrc", "hamming_mfma_i.hip")).read()
@@ -243,8 +251,12 @@ def test_k1i_inline_asm_touches_accumulators_only_as_an_mfma_destination():
     acc = [b for b in stmts if re.search(r"\(m[01]\)", b)]
     assert len(acc) == 1 and acc[0].lstrip().startswith('"v_mfma_f32_32x32x64_f8f6f4') and '"=&v"(m1)' in acc[0]
     assert not re.search(r':\s*"v"\(m[01]\)|,\s*"v"\(m[01]\)', acc[0])            # not an input
+    # accumulator elements: pack_acc (a builtin) or the macro's asm statements, nowhere else
     uses = [l for l in src.split("\n") if re.search(r"\bACC\[", l) and "ACC[KS]" not in l and "ACC[0]" not in l]
-    assert uses and all("pack_acc(" in l for l in uses), uses
+    ok = re.compile(r'pack_acc\(|asm\("v_pk_minimum3_f16 %0, %0, %1, %2 op_sel:\[0,0,1\] op_sel_hi:\[1,1,0\]"|asm\("v_min3_f32 %0, %0, %1, %2"|asm\("v_min_f32 %0, %1, %2"')
+    assert uses and all(ok.search(l) for l in uses), [l for l in uses if not ok.search(l)]
+    # the hand-counted wait states are there: in front of phase 1 of a step and in front of the epilogue
+    assert 'if (DIRECTED) asm volatile("s_nop 7"); else asm volatile("s_nop 4");' in src and 'asm volatile("s_nop 7\\n\\ts_nop 7");' in src
 
 
 def test_k1i_stays_at_three_workgroups_per_cu_and_owns_m0(tmp_path):

@@ -20,7 +20,19 @@ __global__ void k_check(const uint32_t* a, const uint32_t* b, const uint32_t* c,
     mx[i] = s;
 }
 
-template <int KIND>      // 0: v_pk_min_u16 (2 inputs), 1: v_pk_minimum3_f16 (3 inputs), 2: v_min3_u32, 3: v_perm_b32
+// round 6: the same instruction with op_sel -- low result = min3(a.lo, b.lo, c.HI), high result = min3(a.hi, b.HI, c.lo): with
+// b, c two UNPACKED accumulators (float bits 0x4B00kkkk: key in the low half, 0x4B00 in the high half) and a the packed running
+// minima of two rows, ONE instruction is "a.lo = min(a.lo, key(b)), a.hi = min(a.hi, key(c))", capped at 0x4B00 -- no v_perm
+__global__ void k_check_opsel(const uint32_t* a, const uint32_t* b, const uint32_t* c, uint32_t* mn, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r;
+    asm("v_pk_minimum3_f16 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(a[i]), "v"(b[i]), "v"(c[i]));
+    mn[i] = r;
+}
+
+template <int KIND>      // 0: v_pk_min_u16 (2 inputs), 1: v_pk_minimum3_f16 (3 inputs), 2: v_min3_u32, 3: v_perm_b32, 4: pk_minimum3 with op_sel, 5: v_min3_f32
 __global__ void __launch_bounds__(256) k_rate(int iters, unsigned long long* out, uint32_t* sink)
 {
     uint32_t x[8], y = (threadIdx.x * 2654435761u) & 0x3FFF3FFFu, z = (y >> 1) | 0x04000400u;
@@ -33,6 +45,8 @@ __global__ void __launch_bounds__(256) k_rate(int iters, unsigned long long* out
             if (KIND == 1) asm volatile("v_pk_minimum3_f16 %0, %0, %1, %2" : "+v"(x[v & 7]) : "v"(y), "v"(z));
             if (KIND == 2) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(x[v & 7]) : "v"(y), "v"(z));
             if (KIND == 3) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(x[v & 7]) : "v"(y), "v"(z));
+            if (KIND == 4) asm volatile("v_pk_minimum3_f16 %0, %0, %1, %2 op_sel:[0,0,1] op_sel_hi:[1,1,0]" : "+v"(x[v & 7]) : "v"(y), "v"(z));
+            if (KIND == 5) asm volatile("v_min3_f32 %0, %0, %1, %2" : "+v"(x[v & 7]) : "v"(y | 0x4B000000u), "v"(z | 0x4B000000u));
         }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
@@ -107,11 +121,28 @@ int main()
         if (mx[i] != emx) { if (bad_max < 5) printf("max3 %08x %08x %08x -> %08x expected %08x\n", a[i], b[i], c[i], mx[i], emx); ++bad_max; }
     }
     printf("v_pk_minimum3_f16 / v_pk_maximum3_f16 as integer min / max over %d packed triples of keys < 0x7C00: %ld / %ld wrong\n", n, bad_min, bad_max);
+    {
+        // op_sel form: b, c as accumulators (0x4B00 in the high half), a any packed pair of keys
+        std::vector<uint32_t> b2(n), c2(n);
+        for (int i = 0; i < n; ++i) { b2[i] = 0x4B000000u | (b[i] & 0xFFFFu); c2[i] = 0x4B000000u | (c[i] & 0xFFFFu); }
+        CHECK(hipMemcpy(db, b2.data(), 4 * n, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dc, c2.data(), 4 * n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_check_opsel, dim3((n + 255) / 256), dim3(256), 0, 0, da, db, dc, dmn, n);
+        CHECK(hipMemcpy(mn.data(), dmn, 4 * n, hipMemcpyDeviceToHost));
+        long bad = 0;
+        for (int i = 0; i < n; ++i) {
+            const uint32_t e = std::min({a[i] & 0xFFFFu, b2[i] & 0xFFFFu, 0x4B00u}) | (std::min({a[i] >> 16, 0x4B00u, c2[i] & 0xFFFFu}) << 16);
+            if (mn[i] != e) { if (bad < 5) printf("opsel %08x %08x %08x -> %08x expected %08x\n", a[i], b2[i], c2[i], mn[i], e); ++bad; }
+        }
+        printf("v_pk_minimum3_f16 op_sel:[0,0,1] op_sel_hi:[1,1,0] on (packed minima, accumulator, accumulator) = (min(a.lo, b.lo), min(a.hi, c.lo)) capped at 0x4B00, %d triples: %ld wrong\n", n, bad);
+    }
     unsigned long long* d_out; uint32_t* d_sink;
     CHECK(hipMalloc(&d_out, 8 * 4096)); CHECK(hipMalloc(&d_sink, 4 * 256 * 4096));
     rate<0>("v_pk_min_u16", p.multiProcessorCount, d_out, d_sink);
     rate<1>("v_pk_minimum3_f16", p.multiProcessorCount, d_out, d_sink);
     rate<2>("v_min3_u32", p.multiProcessorCount, d_out, d_sink);
     rate<3>("v_perm_b32", p.multiProcessorCount, d_out, d_sink);
+    rate<4>("v_pk_minimum3_f16 op_sel", p.multiProcessorCount, d_out, d_sink);
+    rate<5>("v_min3_f32", p.multiProcessorCount, d_out, d_sink);
     return 0;
 }
