@@ -39,9 +39,10 @@ extern "C" {
 #endif
 
 /* 2: plslam_match_problem grew (keep_prior, reserved: 56 bytes), plslam_lba_plan_iterate's flags became a bit mask, options
- * "mfma_form" 3/4 and "exact_second"; 3 (round 4): "mfma_form" 5 (the default), "post_fuse", plslam_match_plan_key_state.
+ * "mfma_form" 3/4 and "exact_second"; 3 (round 4): "mfma_form" 5 (the default), "post_fuse", plslam_match_plan_key_state;
+ * 4 (round 5): plslam_match_plan_set_wire16, the Schur step, plslam_lba_plan_host_state; 5 (round 6): plslam_lba_plan_get_landmarks.
  * Clients compare plslam_abi_version() with the value they were compiled against. */
-#define PLSLAM_ABI_VERSION 4
+#define PLSLAM_ABI_VERSION 5
 #define PLSLAM_DESC_BYTES 32
 /* largest train set of one directed scan: the composite (distance,index) key keeps 23
  * index bits beside the 9 distance bits */
@@ -567,6 +568,12 @@ int plslam_lba_plan_diag_max(plslam_lba_plan* plan, double* hmax);
 int plslam_lba_plan_schur(plslam_lba_plan* plan, double lambda, double* S, double* b, int32_t* n_singular);
 int plslam_lba_plan_backsub(plslam_lba_plan* plan, const double* dpose, int apply, double* dX_pt, double* dX_ls);
 int plslam_lba_plan_set_poses(plslam_lba_plan* plan, const double* T_kf_w);
+/* The resident landmarks, device -> host (ABI v5): Xw (npt x 3) / Lw (nls x 6), either may be NULL.  What
+ * plslam_lba_plan_backsub(apply) updated in place comes back for the reference's write-back (src/mapHandler.cpp:1822-1852:
+ * point3D / line3D <- X, inlier = false where ||X - old|| > 0.01).  The plan's page-locked images (plslam_lba_plan_host_state)
+ * are refreshed by the same copy: after backsub(apply) the image holds the landmarks of BEFORE the step until this call (or the
+ * caller) rewrites it -- an iterate / iterate_dev handed the image's pointers in between would upload the old ones. */
+int plslam_lba_plan_get_landmarks(plslam_lba_plan* plan, double* Xw, double* Lw);
 /* rows of the last iterate() (any pointer may be NULL), e.g. for the write-back logic of :1822-1855 */
 int plslam_lba_plan_rows(plslam_lba_plan* plan, double* pt_J_pose, double* pt_J_lm, double* pt_r, double* pt_w,
                          double* ls_J_pose, double* ls_J_lm, double* ls_r, double* ls_w);

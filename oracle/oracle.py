@@ -248,6 +248,41 @@ def ref_lba_accumulate(iter_pass, cam, homog_th, nkf, T_map, T_slot, Xw, Lw, pt_
     return H, g, float(err[0])
 
 
+def ref_lba_lm(cam, homog_th, lambda_lm, lambda_k, max_iters, min_err_change, min_err, nkf, T_map, x_kf, Xw, Lw,
+               pt_lm, pt_kf_map, pt_kf_loc, pt_uv, ls_lm, ls_kf_map, ls_kf_loc, ls_l):
+    """The reference's OWN Levenberg-Marquardt loop of levMarquardtOptimizationLBA (src/mapHandler.cpp:1334-1812: first pass,
+    lambda = lambdaLbaLM * Hmax, the first damped solve, the iterations with their stop tests and lambda schedule), compiled
+    textually from where it lies (oracle/ref_wrap_lba_lm.cpp; stvo-pl's SE(3) maps restated, the sparse LDL^T replaced by a dense
+    envelope one) -> dict(X (N: the final state, poses as se3 logs), lam, err (one entry per solve, err as the text normalises
+    it), iters, err_last, err_prev, lam_last).  None if unavailable."""
+    r = ref_lib()
+    if r is None or not hasattr(r, "ref_lba_lm"):
+        return None
+    T_map = _c(T_map, np.float64).reshape(-1, 16)
+    x_kf = _c(x_kf, np.float64).reshape(-1)
+    assert x_kf.shape[0] == 6 * nkf
+    Xw, Lw = _c(Xw, np.float64).reshape(-1, 3), _c(Lw, np.float64).reshape(-1, 6)
+    npt, nls = Xw.shape[0], Lw.shape[0]
+    N = 6 * nkf + 3 * npt + 6 * nls
+    a = [_c(x, np.int32) for x in (pt_lm, pt_kf_map, pt_kf_loc)] + [_c(pt_uv, np.float64)]
+    b = [_c(x, np.int32) for x in (ls_lm, ls_kf_map, ls_kf_loc)] + [_c(ls_l, np.float64)]
+    c4 = np.array([cam.fx, cam.fy, cam.cx, cam.cy])
+    cfg = np.array([homog_th, lambda_lm, lambda_k, float(max_iters), min_err_change, min_err], np.float64)
+    X, trace, scal = np.zeros(N), np.zeros(2 * (int(max_iters) + 1)), np.zeros(5)
+    r.ref_lba_lm.restype = C.c_int
+    rc = r.ref_lba_lm(*[C.c_void_p(v) for v in (c4.ctypes.data, cfg.ctypes.data)], int(nkf), int(npt), int(nls),
+                      C.c_void_p(T_map.ctypes.data), int(T_map.shape[0]),
+                      *[C.c_void_p(v.ctypes.data) for v in (x_kf, Xw, Lw)],
+                      *[C.c_void_p(x.ctypes.data) for x in a], int(a[0].shape[0]),
+                      *[C.c_void_p(x.ctypes.data) for x in b], int(b[0].shape[0]),
+                      *[C.c_void_p(v.ctypes.data) for v in (X, trace, scal)])
+    if rc != 0:
+        raise RuntimeError(f"ref_lba_lm rc={rc}")
+    ns = int(scal[4])
+    return dict(X=X, lam=trace[0:2 * ns:2].copy(), err=trace[1:2 * ns:2].copy(), iters=int(scal[0]), err_last=float(scal[1]),
+                err_prev=float(scal[2]), lam_last=float(scal[3]))
+
+
 def _cam6(cam):
     return np.array([cam.fx, cam.fy, cam.cx, cam.cy, float(cam.width), float(cam.height)])
 

@@ -11,6 +11,8 @@ oracle/ref_wrap_lba.cpp can compile them textually against the dense-matrix stan
 and the point / line loops of the pose-only Gauss-Newton iterations (K17's checker):
     gn_pt.inc, gn_ls.inc           MapHandler::computeRelativePoseGN        (near :3330, :3370)
     gnr_pt.inc, gnr_ls.inc         MapHandler::computeRelativePoseRobustGN  (first pair of loops, near :3594, :3634)
+and the whole LM body of levMarquardtOptimizationLBA (everything between its opening brace and its write-back section):
+    lba_lm_body.inc                (near :1334-1812)
 and the visibility pre-filter / geometric gate loops of the map <-> key-frame matchers:
     m2kf_pt_vis.inc, m2kf_pt_gate.inc   MapHandler::matchMap2KFPoints  (near :545, :602)
     m2kf_ls_vis.inc, m2kf_ls_gate.inc   MapHandler::matchMap2KFLines   (near :646, :715)
@@ -56,6 +58,14 @@ def main(ref, out):
                          % (start + 1, end + 1))
                 fh.write("\n".join(src[start:end + 1]) + "\n")
             print("[ref_extract_lba] %s = src/mapHandler.cpp:%d-%d" % (name, start + 1, end + 1))
+    # the WHOLE body of levMarquardtOptimizationLBA up to its write-back section (:1334-1812: variables, first pass, lambda,
+    # first solve and update, the LM iterations with their lambda schedule and stop tests) for oracle/ref_wrap_lba_lm.cpp
+    b0 = next(i for i in range(f0, f1) if src[i].strip() == "{") + 1
+    b1 = next(i for i in range(b0, f1) if "vo_status != VO_INSERTING_KF" in src[i])
+    with open(os.path.join(out, "lba_lm_body.inc"), "w") as fh:
+        fh.write("// generated from src/mapHandler.cpp:%d-%d by oracle/ref_extract_lba.py -- not part of the repository\n" % (b0 + 1, b1))
+        fh.write("\n".join(src[b0:b1]) + "\n")
+    print("[ref_extract_lba] lba_lm_body.inc = src/mapHandler.cpp:%d-%d" % (b0 + 1, b1))
     f2 = next(i for i, l in enumerate(src) if "MapHandler::levMarquardtOptimizationGBA" in l)
     f3 = next(i for i, l in enumerate(src) if i > f2 and "MapHandler::removeBadMapLandmarks" in l)
     for key in ("pt", "ls"):

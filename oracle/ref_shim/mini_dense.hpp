@@ -49,6 +49,7 @@ struct Dyn {
         return b;
     }
     Block col(int j) { return block(0, j, r, 1); }
+    const Dyn& sparseView() const { return *this; }      // (H.sparseView(), src/mapHandler.cpp:1555: the dense matrix itself)
     Dyn& operator+=(const Dyn& o) {
         if (o.r != r || o.c != c) throw std::invalid_argument("mini::+= : shape");
         for (size_t k = 0; k < v.size(); ++k) v[k] += o.v[k];

@@ -24,7 +24,7 @@ SCAN_AUTO, SCAN_LANE_PER_QUERY, SCAN_WAVE_PER_QUERY, SCAN_SYMMETRIC, SCAN_MFMA =
 MAX_TRAIN_ROWS = 1 << 23
 
 # every symbol include/plslam_hip.h declares (tests check the .so exports all of them)
-ABI_VERSION = 4          # include/plslam_hip.h: PLSLAM_ABI_VERSION
+ABI_VERSION = 5          # include/plslam_hip.h: PLSLAM_ABI_VERSION
 ABI_SYMBOLS = (
     "plslam_strerror", "plslam_last_error", "plslam_abi_version",
     "plslam_ctx_create", "plslam_ctx_destroy", "plslam_ctx_set_option", "plslam_ctx_get_option",
@@ -36,7 +36,7 @@ ABI_SYMBOLS = (
     "plslam_lba_line_rows_dev", "plslam_lba_assemble", "plslam_lba_plan_create", "plslam_lba_plan_iterate",
     "plslam_lba_plan_rows", "plslam_lba_plan_destroy", "plslam_lba_plan_iterate_dev", "plslam_lba_plan_device_blocks", "plslam_lba_plan_device_state",
     "plslam_lba_plan_iterate_resident", "plslam_lba_plan_diag_max", "plslam_lba_plan_schur", "plslam_lba_plan_backsub",
-    "plslam_lba_plan_set_poses", "plslam_lba_plan_host_state",
+    "plslam_lba_plan_set_poses", "plslam_lba_plan_host_state", "plslam_lba_plan_get_landmarks",
     "plslam_lba_plan_blocks",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
@@ -216,6 +216,7 @@ def load() -> C.CDLL:
     L.plslam_lba_plan_schur.argtypes = [vp, C.c_double, vp, vp, vp]
     L.plslam_lba_plan_backsub.argtypes = [vp, vp, C.c_int, vp, vp]
     L.plslam_lba_plan_set_poses.argtypes = [vp, vp]
+    L.plslam_lba_plan_get_landmarks.argtypes = [vp, vp, vp]
     L.plslam_lba_plan_host_state.argtypes = [vp, vp]
     L.plslam_lba_plan_blocks.argtypes = [vp] * 8
     L.plslam_lba_plan_destroy.argtypes = [vp]
@@ -850,6 +851,14 @@ class LbaPlan:
         T = _arr(T_kf_w, np.float64, (-1, 16))
         assert T.shape[0] == self.dims[5]
         _check(self._L.plslam_lba_plan_set_poses(self._h, _p(T)), "plslam_lba_plan_set_poses")
+
+    def get_landmarks(self):
+        """The resident landmarks (after backsub(apply=True)) -> (Xw (npt, 3), Lw (nls, 6)); also refreshes the page-locked images
+        of host_state()."""
+        nkf, npt, nls, npo, nlo, nslot = self.dims
+        X, Lm = np.empty((npt, 3)), np.empty((nls, 6))
+        _check(self._L.plslam_lba_plan_get_landmarks(self._h, _p(X), _p(Lm)), "plslam_lba_plan_get_landmarks")
+        return X, Lm
 
     def host_state(self) -> dict:
         """The plan's page-locked images as numpy views (T_kf_w (n_pose_slots, 16), Xw (npt, 3), Lw (nls, 6), g (n,)): a

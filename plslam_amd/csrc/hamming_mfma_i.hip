@@ -152,8 +152,21 @@ __device__ unsigned long long g_mi_prof[MI_PROF_WGS * 4];      // per workgroup 
 #endif
 
 // DIRECTED = true: only keys12 (row direction) is produced.
+// PLSLAM_MI_VGPRS (round 6): the kernel's register budget.  Three waves per SIMD allow 168 -- and leave 8 of a SIMD's 512
+// registers per lane free, so a wave of the stages behind the scan (k_merge_fix16, k_finalize: the NEXT step's scan runs beside
+// them) starts only where a scan wave has left.  Without the pack the scan fits 144 with no spill (80 registers per lane free on
+// every SIMD: one stage wave per SIMD BESIDE three scan waves) -- built and measured with the stage stream above, below and level
+// with the scan stream (profiles/r6_e_*, r6_f_*, r6_g_*): the stage kernels then do run beside the scan from its first
+// workgroup on, and the step does not move (2.45 ms in every configuration, the scan 2.40-2.44 ms inside the loop against 2.2 alone).
+// What the stages cost the step is their INSTRUCTIONS (96 M wave-level VALU instructions per step against the scan's 0.81 G:
+// 11 %, and the in-loop scan is 9-10 % longer than alone), wherever their waves sit: the scan is bound by instruction issue.
+// Default 168 (the compiler's own choice under three waves per SIMD).
+// (amdgpu_num_vgpr counts the architected half of gfx950's unified file: the attribute takes budget / 2.)
+#ifndef PLSLAM_MI_VGPRS
+#define PLSLAM_MI_VGPRS 168
+#endif
 template <bool DIRECTED>
-__global__ void __launch_bounds__(256, 3)      // 3 waves per SIMD: <= 168 unified VGPRs
+__global__ void __launch_bounds__(256, 3) __attribute__((amdgpu_num_vgpr(PLSLAM_MI_VGPRS / 2)))
 k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks, int32_t* __restrict__ zero, int nzero, int nblocks)
 {
     // one buffer, two lives: during the scan the double-buffered b tile (9 216 B) followed by the PARKED sorted pairs of the
@@ -673,10 +686,12 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         // (wt0 is a multiple of 64: t & 3 of the unrolled steps is static.  The first step has no previous tile: its
         // phase 1 runs on "none" accumulators, its column / group actions are skipped)
         {
+            // (written HERE by sixteen moves the compiler can neither hoist out of the window loop nor fold: as a loop-invariant
+            // vector it was kept alive across the tile loops -- at a 152-register budget spilled in the prologue and reloaded at
+            // every window start behind an s_waitcnt vmcnt(0), i.e. behind the whole prefetch)
             u32x16 none;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) none[r] = MI_NONE32;     // (the low halves are what the pack takes)
-            asm volatile("" : "+v"(none));
+            for (int r = 0; r < 16; ++r) asm volatile("v_mov_b32 %0, %1" : "=v"(none[r]) : "s"(MI_NONE32));     // (the low halves are what the bookkeeping takes)
             m1 = __builtin_bit_cast(f32x16, none);
 #if PLSLAM_MI_F16
             // the first step folds "the tile before the window" (odd) with whatever is kept: nothing

@@ -1302,9 +1302,9 @@ static int lba_schur_prepare(plslam_lba_plan* P)
 extern "C" int plslam_lba_plan_diag_max(plslam_lba_plan* P, double* hmax)
 {
     PLSLAM_REQUIRE(P && hmax, PLSLAM_EINVAL);
-    PLSLAM_REQUIRE(P->blocks_valid, PLSLAM_EINVAL);        // one plslam_lba_plan_iterate* first
     plslam_ctx* ctx = P->ctx;
-    std::lock_guard<std::mutex> lk(ctx->mu);
+    std::lock_guard<std::mutex> lk(ctx->mu);               // (the plan's state flags are read under the lock: ADVICE r5)
+    PLSLAM_REQUIRE(P->blocks_valid, PLSLAM_EINVAL);        // one plslam_lba_plan_iterate* first
     DeviceGuard dg_(ctx->device);
     int rc = lba_schur_prepare(P);
     if (rc) return rc;
@@ -1325,12 +1325,12 @@ extern "C" int plslam_lba_plan_diag_max(plslam_lba_plan* P, double* hmax)
 extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* S, double* b, int32_t* n_singular)
 {
     PLSLAM_REQUIRE(P && S && b && lambda >= 0.0, PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
     PLSLAM_REQUIRE(P->blocks_valid && P->nkf > 0, PLSLAM_EINVAL);
     // the cross blocks must be the local BA's (landmark rows x pose columns): an iteration run with PLSLAM_LBA_COMPAT_GBA wrote the
     // pose x line blocks transposed, as the reference's GBA does (:2341-2352) -- a defect this step does not reproduce
     PLSLAM_REQUIRE(!P->blocks_gba, PLSLAM_EINVAL);
-    plslam_ctx* ctx = P->ctx;
-    std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard dg_(ctx->device);
     int rc = lba_schur_prepare(P);
     if (rc) return rc;
@@ -1344,7 +1344,6 @@ extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* 
     // in one of them and its last kernel clears the other for the next call (both cleared at plan creation) -- no memset launch
     int32_t* sing2 = (int32_t*)(dS + n6 * n6 + n6 + 1);
     const int par = P->schur_parity;
-    P->schur_parity ^= 1;
     const int32_t nb3 = (P->npt + 255) / 256, nb6 = (P->nls + 255) / 256;
     if (nb3 + nb6 > 0)
         hipLaunchKernelGGL(k_schur_landmarks, dim3(nb3 + nb6), dim3(256), 0, s, (const double*)(dout + P->oHpt), g + n6, P->npt,
@@ -1362,6 +1361,7 @@ extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* 
                        (const double*)(d + P->oSpart), (const double*)(d + P->oBpart), (const double*)(dout + P->oHp), g, P->nkf, P->nblk,
                        P->schur_chunks, P->max_chunks, lambda, dS, dS + n6 * n6, sing2 + (par ^ 1));
     PLSLAM_HIP_CHECK(hipGetLastError());
+    P->schur_parity = par ^ 1;        // (only now: the kernel that clears the other counter is in the stream)
     char* ho = P->schur_pin.as<char>();
     PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, dS, (n6 * n6 + n6 + 2) * 8, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
@@ -1375,10 +1375,10 @@ extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* 
 extern "C" int plslam_lba_plan_backsub(plslam_lba_plan* P, const double* dpose, int apply, double* dX_pt, double* dX_ls)
 {
     PLSLAM_REQUIRE(P && dpose, PLSLAM_EINVAL);
-    PLSLAM_REQUIRE(P->schur_done, PLSLAM_EINVAL);          // plslam_lba_plan_schur on the blocks of the last iteration first
-    PLSLAM_REQUIRE(!apply || P->state_valid, PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    PLSLAM_REQUIRE(P->schur_done, PLSLAM_EINVAL);          // plslam_lba_plan_schur on the blocks of the last iteration first
+    PLSLAM_REQUIRE(!apply || P->state_valid, PLSLAM_EINVAL);
     DeviceGuard dg_(ctx->device);
     hipStream_t s = ctx->stream;
     char *ds = P->stat.as<char>(), *dd = P->dyn.as<char>(), *dout = P->out.as<char>(), *d = P->schur.as<char>();
@@ -1412,13 +1412,35 @@ extern "C" int plslam_lba_plan_backsub(plslam_lba_plan* P, const double* dpose, 
     return PLSLAM_OK;
 }
 
+// The resident landmarks, device -> host (round 6): what plslam_lba_plan_backsub(apply) has updated in place comes back -- into
+// the plan's page-locked images first (plslam_lba_plan_host_state: the image no longer holds the landmarks of BEFORE the step, so
+// a later plslam_lba_plan_iterate / _iterate_dev with the image's own pointers does not revert it -- ADVICE r5), then to the
+// caller's arrays (either may be NULL).  The reference's write-back reads them there (src/mapHandler.cpp:1822-1852).
+extern "C" int plslam_lba_plan_get_landmarks(plslam_lba_plan* P, double* Xw, double* Lw)
+{
+    PLSLAM_REQUIRE(P != nullptr, PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    PLSLAM_REQUIRE(P->state_valid, PLSLAM_EINVAL);         // one plslam_lba_plan_iterate(_dev) first: it uploads the state
+    DeviceGuard dg_(ctx->device);
+    hipStream_t s = ctx->stream;
+    char *hi = P->pin_in.as<char>(), *dd = P->dyn.as<char>();
+    const size_t bx = (size_t)P->npt * 24, bl = (size_t)P->nls * 48;
+    if (bx) PLSLAM_HIP_CHECK(hipMemcpyAsync(hi + P->oX, dd + P->oX, bx, hipMemcpyDeviceToHost, s));
+    if (bl) PLSLAM_HIP_CHECK(hipMemcpyAsync(hi + P->oL, dd + P->oL, bl, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (Xw && bx && (char*)Xw != hi + P->oX) memcpy(Xw, hi + P->oX, bx);
+    if (Lw && bl && (char*)Lw != hi + P->oL) memcpy(Lw, hi + P->oL, bl);
+    return PLSLAM_OK;
+}
+
 // the optimised poses alone (the host has applied dp to them: expmap / logmap of SE(3) stay with the caller, :1560-1566)
 extern "C" int plslam_lba_plan_set_poses(plslam_lba_plan* P, const double* T_kf_w)
 {
     PLSLAM_REQUIRE(P && (P->n_slots == 0 || T_kf_w), PLSLAM_EINVAL);
-    PLSLAM_REQUIRE(P->state_valid, PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    PLSLAM_REQUIRE(P->state_valid, PLSLAM_EINVAL);
     DeviceGuard dg_(ctx->device);
     hipStream_t s = ctx->stream;
     if (P->n_slots) {

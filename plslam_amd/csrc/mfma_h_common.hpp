@@ -28,7 +28,10 @@ constexpr int MH_TILE_BYTES = MH_TILE_N * MH_ROW_STRIDE;
 constexpr int MH_GROUP = 16;                  // tiles per group of the row direction (512 b rows)
 constexpr int MH_GROUP_ROWS = MH_GROUP * MH_TILE_N;
 constexpr int MH_WINDOW = 64;                 // tiles per window: the row keys' tag holds the group within the window (2 bits)
-constexpr int MH_MERGE_SPT = 4;              // slots per lane of the merge kernel (PARTS == 1)
+#ifndef PLSLAM_MERGE_SPT
+#define PLSLAM_MERGE_SPT 4
+#endif
+constexpr int MH_MERGE_SPT = PLSLAM_MERGE_SPT;   // slots per lane of the merge kernel (PARTS == 1)
 constexpr int MH_CGROUP = 8;                  // tiles whose column results are staged in LDS and stored together (256 slots)
 #ifndef PLSLAM_NT_STREAMS
 #define PLSLAM_NT_STREAMS 1

@@ -126,11 +126,15 @@ class StereoBatchMatcher:
         # A real (non-NULL) HIP stream: the C ABI reads a NULL stream as "the context's own stream",
         # and torch's legacy default stream has handle 0.
         # (`streams`: share another matcher's [scan stream, stage stream]: several batches stepping through one pipeline)
-        self.stream = torch.cuda.Stream(device=dev) if streams is None else streams[0]
+        # (PLSLAM_STREAM_PRIO, experiments: "scan_high" = the scan stream above the stage stream, "equal" = both normal)
+        import os as _os
+        prio = _os.environ.get("PLSLAM_STREAM_PRIO", "stage_high")
+        scan_prio, stage_prio = {"stage_high": (0, -1), "scan_high": (-1, 0), "equal": (0, 0)}[prio]
+        self.stream = torch.cuda.Stream(device=dev, priority=scan_prio) if streams is None else streams[0]
         # streams[1] carries the short HBM-bound stages behind a scan in run_overlapped(): high priority, so that they
         # take the workgroup slots the running scan frees instead of queueing behind its backlog
         self.streams = list(streams) if streams is not None else \
-            [self.stream] + [torch.cuda.Stream(device=dev, priority=-1 if i == 0 else 0) for i in range(n_buffers - 1)]
+            [self.stream] + [torch.cuda.Stream(device=dev, priority=stage_prio if i == 0 else 0) for i in range(n_buffers - 1)]
         # `scan_streams` = 2: the scans of consecutive steps alternate between two streams, so the first workgroups of step
         # k+1 fill the slots the last wave of step k's scan leaves idle.  A 512-pair step is 9.3 rounds of the chip's 768
         # workgroup slots: its last round is a third full, and on one stream the next scan starts only when it is over.

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include <array>
+#include <cmath>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -234,6 +235,130 @@ public:
     {
         if (T_kf_w.size() != (size_t)nslots_ * 16) throw std::runtime_error("[LbaPlanSolver::setPoses] one 4 x 4 per pose slot");
         check(plslam_lba_plan_set_poses(plan_, T_kf_w.data()), "plslam_lba_plan_set_poses");
+    }
+
+    // ---- the LM loop as the reference runs it (round 6) ----------------------------------------------------------------------
+    // levMarquardtOptimizationLBA's control flow (src/mapHandler.cpp:1332-1812) on the resident plan:
+    //   first pass (:1358-1540): H, g, err at the stored state; err /= (Npt_obs + Nls_obs) (:1541) -- two counters the text
+    //   declares (:1355, :1433) and never increments: the first err is +inf (NaN for a zero sum), so the first iteration's step is
+    //   always accepted (inf > inf is false) and its |err - err_prev| test never fires.  Kept: it decides the control flow.
+    //   lambda = lambdaLbaLM * max_i |H(i,i)| (:1544-1550); damped solve and the step applied unconditionally (:1552-1575);
+    //   err_prev = err (:1578); then up to max_iters - 1 iterations (:1583-1812):
+    //     H, g, err with the iteration pass's quirks; err /= (Npt + Nls) -- LANDMARKS, not observations (:1773);
+    //     stop if |err - err_prev| < minErrorChange or err < minError (:1775);
+    //     damped solve (:1778-1783); err > err_prev: lambda /= lambda_k and the step is NOT applied; otherwise lambda *= lambda_k
+    //     and the step is applied (:1786-1806: yes, lambda GROWS on success -- the reference's schedule, kept);
+    //     stop if ||DX|| < minErrorChange (:1808); err_prev = err (:1811) -- also after a rejected step, so the iteration after
+    //     a rejection recomputes the same err and stops at the first test.
+    // The pose update X_k <- logmap(expmap(X_k) * inverse(expmap(DX_k))) (:1560-1566, :1793-1799) uses stvo-pl's SE(3) maps, which
+    // stay with the caller: `maps` holds them (in PL-SLAM: expmap_se3 / logmap_se3 / inverse_se3 of stvo-pl's auxiliar.h).
+    // Pose slots (plslam_lba_plan_create): slot `first_estimate_slot + k` holds expmap(X_k) of local key frame k -- what the point
+    // rows of the iteration pass read (:1600-1601); the other slots keep the stored T_kf_w (line rows, :1680, and key frames that
+    // are not optimised).  x_kf (6 Nkf) = the key frames' x_kf_w (:1233), updated in place; p.points / p.lines receive the final
+    // landmarks.  What the reference solves with SimplicialLDLT over all N unknowns is solved here by the Schur step of the C ABI
+    // (landmark blocks on the device, a dense LDL^T of the 6 Nkf x 6 Nkf reduced system on the host): equal to rounding.
+    struct LmParams {                    // SlamConfig::lambdaLbaLM(), lambdaLbaK(), maxItersLba(); Config::minErrorChange(), minError()
+        double lambda_lba_lm = 0.00001, lambda_lba_k = 10.0;
+        int max_iters_lba = 15;
+        double min_error_change = 1e-7, min_error = 1e-7;
+    };
+    struct Se3Maps {
+        void (*expmap)(const double x[6], double T[16]);
+        void (*logmap)(const double T[16], double x[6]);
+        void (*inverse)(const double T[16], double Ti[16]);
+    };
+    struct LmTrace {                     // one entry per H / g build: [0] = the first pass
+        std::vector<double> err, lambda;       // err as the reference normalises it; lambda used by that build's solve (0: none)
+        std::vector<int> applied;              // 1: the step was applied, 0: rejected (err > err_prev), -1: stopped before the solve
+        int iters = 0;                         // the reference's `iters` when its loop ends
+        int stop = 0;                          // 0 max_iters reached, 1 |err - err_prev| / err test, 2 ||DX|| test
+        int n_singular = 0;                    // landmarks whose damped block was not positive definite in any solve
+    };
+    void optimize(LbaProblem& p, std::vector<double>& x_kf, int32_t first_estimate_slot, const LmParams& prm, const Se3Maps& maps,
+                  LmTrace* trace = nullptr)
+    {
+        if (x_kf.size() != 6 * (size_t)nkf_ || first_estimate_slot < 0 || first_estimate_slot + nkf_ > nslots_)
+            throw std::runtime_error("[LbaPlanSolver::optimize] x_kf must hold 6 doubles per optimised key frame, and their estimate slots must exist");
+        const double n_obs_counted = 0.0;                             // Npt_obs + Nls_obs as the reference leaves them (see above)
+        const double n_lm = (double)(npt_ + nls_);
+        LmTrace local;
+        LmTrace& tr = trace ? *trace : local;
+        tr = LmTrace();
+        std::vector<double> dp, dXp, dXl;
+        auto set_estimates = [&]() {                                  // slot first_estimate_slot + k <- expmap(X_k)
+            for (int32_t k = 0; k < nkf_; ++k) maps.expmap(&x_kf[6 * (size_t)k], &p.poses_T_kf_w[16 * (size_t)(first_estimate_slot + k)]);
+        };
+        auto update_poses = [&]() {                                   // :1560-1566
+            double Tprev[16], Tinc[16], Tinv[16], Tcur[16];
+            for (int32_t k = 0; k < nkf_; ++k) {
+                maps.expmap(&x_kf[6 * (size_t)k], Tprev);
+                maps.expmap(&dp[6 * (size_t)k], Tinc);
+                maps.inverse(Tinc, Tinv);
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j) {
+                        double a = 0.0;
+                        for (int q = 0; q < 4; ++q) a += Tprev[4 * i + q] * Tinv[4 * q + j];
+                        Tcur[4 * i + j] = a;
+                    }
+                maps.logmap(Tcur, &x_kf[6 * (size_t)k]);
+            }
+            set_estimates();
+            setPoses(p.poses_T_kf_w);
+        };
+        auto step_norm = [&]() {                                      // DX.norm() over all N unknowns (:1808)
+            double s2 = 0.0;
+            for (double v : dp) s2 += v * v;
+            for (double v : dXp) s2 += v * v;
+            for (double v : dXl) s2 += v * v;
+            return std::sqrt(s2);
+        };
+        // ---- first pass ----
+        set_estimates();
+        double err = iterate(p, false) / n_obs_counted;
+        double lambda = prm.lambda_lba_lm * diagMax();
+        int32_t nsing = 0;
+        solveStep(lambda, dp, true, &dXp, &dXl, &nsing);
+        tr.n_singular += nsing;
+        update_poses();
+        tr.err.push_back(err); tr.lambda.push_back(lambda); tr.applied.push_back(1);
+        double err_prev = err;
+        // ---- LM iterations ----
+        int iters;
+        for (iters = 1; iters < prm.max_iters_lba; ++iters) {
+            err = iterateResident(true) / n_lm;
+            tr.err.push_back(err);
+            if (std::fabs(err - err_prev) < prm.min_error_change || err < prm.min_error) {
+                tr.lambda.push_back(0.0); tr.applied.push_back(-1); tr.stop = 1;
+                break;
+            }
+            const bool reject = err > err_prev;
+            solveStep(lambda, dp, !reject, &dXp, &dXl, &nsing);
+            tr.n_singular += nsing;
+            tr.lambda.push_back(lambda); tr.applied.push_back(reject ? 0 : 1);
+            if (reject) lambda /= prm.lambda_lba_k;
+            else { lambda *= prm.lambda_lba_k; update_poses(); }
+            if (step_norm() < prm.min_error_change) { tr.stop = 2; break; }
+            err_prev = err;
+        }
+        tr.iters = iters;
+        landmarks(p.points, p.lines);
+    }
+    // the reference's write-back test (:1822-1846): landmark i is flagged when its estimate moved by more than `th` (0.01)
+    static void movedLandmarks(const std::vector<double>& before, const std::vector<double>& after, int dim, double th, std::vector<uint8_t>& moved)
+    {
+        const size_t n = before.size() / (size_t)dim;
+        moved.assign(n, 0);
+        for (size_t i = 0; i < n; ++i) {
+            double s2 = 0.0;
+            for (int a = 0; a < dim; ++a) { const double d = after[i * dim + a] - before[i * dim + a]; s2 += d * d; }
+            moved[i] = std::sqrt(s2) > th ? 1 : 0;
+        }
+    }
+    // the resident landmarks (after solveStep(apply) / optimize())
+    void landmarks(std::vector<double>& Xw, std::vector<double>& Lw)
+    {
+        Xw.resize((size_t)npt_ * 3); Lw.resize((size_t)nls_ * 6);
+        check(plslam_lba_plan_get_landmarks(plan_, Xw.data(), Lw.data()), "plslam_lba_plan_get_landmarks");
     }
 
     // x <- A^-1 x for a symmetric positive definite A (n x n, row-major, overwritten): LDL^T without pivoting

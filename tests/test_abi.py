@@ -28,7 +28,7 @@ def test_header_symbols_all_exported():
 
 def test_abi_version_and_strerror():
     L = plslam_amd.load()
-    assert L.plslam_abi_version() == plslam_amd.capi.ABI_VERSION == 4
+    assert L.plslam_abi_version() == plslam_amd.capi.ABI_VERSION == 5
     assert L.plslam_strerror(0) == b"ok"
     assert b"device" in L.plslam_strerror(-2)
 

@@ -202,6 +202,88 @@ def test_gloo_world2_strong_scaling_shards(tmp_path):
     assert [b[:2] for b in bad] == [(1, 0)]
 
 
+# ---- BASELINE config 4's exact partition at world 8: 4096 pairs -> 8 x 512, a halo at every shard boundary ---------------------
+def _world8_worker(rank, world, port, out, total):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = frontend.shard_range(total, world, rank)
+    per = -(-total // world)                                       # fixed-stride payload: a ragged last shard is padded
+    stream = synth.stereo_stream(hi - lo, N_ORB, N_LBD, seed=synth.SEED0, first_pair=lo)
+    tab = np.full((per, frontend.table_stride(N_ORB, N_LBD)), -3, np.int32)
+    tab[: hi - lo] = _oracle_tables(stream)
+    pipe = frontend.TableGatherPipeline(per, tab.shape[1], max(N_ORB, N_LBD), world, rank, root=0, nbuf=2)
+    for k in range(2):
+        pipe.before_overwrite(k % 2)
+        pipe.submit(k % 2, torch.from_numpy(tab))
+    pipe.finish()
+    if rank == 0:
+        np.save(out, pipe.gathered(1).numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total", [4096, 4099])
+def test_gloo_world8_config4_partition(tmp_path, total):
+    """BASELINE config 4 as written, on eight gloo ranks: 4096 pairs in contiguous shards of 512 (and 4099: seven shards of 513
+    and a ragged one of 508, padded on the wire).  Every shard but the first starts with a pair whose prev <-> curr problems need
+    the LEFT descriptors of the pair before it -- the one-pair halo each rank regenerates locally -- so rank 0's
+    check of 64 pairs of EVERY rank (the shard's ends and four runs in between: bench.py's root-side verification, with the
+    per-rank first pairs of the contiguous partition) covers all seven boundaries; the gathered table is also compared whole with
+    the unsharded stream's at the boundaries."""
+    from oracle import oracle as O
+    world = 8
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "w8.npy")
+    mp.spawn(_world8_worker, args=(world, port, out, total), nprocs=world, join=True)
+    got = np.load(out)
+    per = -(-total // world)
+    assert got.shape == (world * per, frontend.table_stride(N_ORB, N_LBD)) and got.dtype == np.int32
+    firsts = [frontend.shard_range(total, world, r)[0] for r in range(world)]
+    sizes = [frontend.shard_range(total, world, r)[1] - firsts[r] for r in range(world)]
+    assert sum(sizes) == total and firsts == [r * per for r in range(world)] and (total % world == 0) == (len(set(sizes)) == 1)
+    fn = lambda d1, d2, nnr: O.match(d1, d2, nnr, True)[0]          # noqa: E731
+    # 64 pairs of every rank (a ragged shard: of the pairs it holds), as bench.py's root does
+    for r in range(world):
+        sample = frontend.spread_sample(sizes[r], 64)
+        assert len(sample) == 64 and sample[0] == 0 and sample[-1] == sizes[r] - 1
+        one = got[r * per:(r + 1) * per]
+        bad = frontend.verify_gathered_tables(one, 1, per, N_ORB, N_LBD, 0.75, 0.9, sample, fn, first_pairs=[firsts[r]])
+        assert bad == [], (r, bad[:4])
+    # the padding of the ragged shard arrived as padding
+    for r in range(world):
+        assert (got[r * per + sizes[r]:(r + 1) * per] == -3).all()
+    # every boundary pair against the UNSHARDED stream (the halo consumer is the first pair of ranks 1..7)
+    for r in range(1, world):
+        st = synth.stereo_stream(2, N_ORB, N_LBD, seed=synth.SEED0, first_pair=firsts[r] - 1)      # pairs firsts[r] - 1 and firsts[r]
+        ref = _oracle_tables(st)
+        assert np.array_equal(got[(r - 1) * per + sizes[r - 1] - 1], ref[0]) and np.array_equal(got[r * per], ref[1]), r
+    # a corrupted boundary entry is found and named
+    got[3 * per, 7] ^= 1
+    bad = frontend.verify_gathered_tables(got[3 * per:4 * per], 1, per, N_ORB, N_LBD, 0.75, 0.9, [0, 1], fn, first_pairs=[firsts[3]])
+    assert [b[:2] for b in bad] == [(0, 0)]
+
+
+def test_bench_launches_itself_at_eight_ranks():
+    """`python bench.py --gpus 8 --launch-check`: the road the driver's SCALE run takes (one rank per GPU under
+    torch.distributed.run on this node) -- eight ranks rendezvous over gloo, rank 0 prints the one line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "5", "--launch-check"],
+                         capture_output=True, text=True, timeout=900, env=dict(env, OMP_NUM_THREADS="1"))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, res.stdout
+    d = json.loads(lines[0])
+    assert d == {"launch_check": True, "world_size": 8, "rank_sum": 36, "argv": ["--gpus", "8", "--steps", "5", "--launch-check"]}
+    assert "--nproc-per-node=8" in res.stderr
+
+
 # ---- bench.py launches itself at N > 1 (VERDICT r4: `python bench.py --gpus 8` exited with a usage message) ----------------
 def test_bench_launches_itself_at_two_ranks():
     """`python bench.py --gpus 2 ...` with no launcher around it re-executes under torch.distributed.run; --launch-check

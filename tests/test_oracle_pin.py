@@ -839,3 +839,31 @@ def test_visibility_gates_median_against_committed_reference_outputs():
         assert np.array_equal(mask, g[f"gate_l{k}"]) and cnt == int(g[f"count_l{k}"][0])
     idx, md = O.median_desc_batched(g["med_desc_lists"], g["med_offsets"])
     assert np.array_equal(idx, g["med_idx"])
+
+
+def test_lm_loop_fixture_is_what_the_references_text_computes():
+    """tests/golden/lba_lm_golden.npz (the fixture the GPU test of LbaPlanSolver::optimize is checked against) re-generated here
+    from the reference's own LM text (oracle/ref_wrap_lba_lm.cpp compiles src/mapHandler.cpp:1334-1812 where it lies): same
+    inputs, same trajectory, bit for bit -- and the trajectory shows the reference's quirks: a first err of +inf (the counters of
+    :1541 are never incremented), lambda multiplied by lambda_k after every accepted step, a rejected step followed by a stop."""
+    import importlib.util
+    if O.ref_lib() is None or not hasattr(O.ref_lib(), "ref_lba_lm"):
+        pytest.skip("oracle/_ref not built (no /root/reference here)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("make_lba_lm_golden", os.path.join(root, "tests", "golden", "make_lba_lm_golden.py"))
+    M = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(M)
+    g = np.load(os.path.join(root, "tests", "golden", "lba_lm_golden.npz"))
+    for name, args in M.CASES.items():
+        p = M.problem(**args)
+        for k, v in p.items():
+            assert np.array_equal(np.asarray(v), g[f"{name}_{k}"]), (name, k)
+        r = M.run_ref(p)
+        for k, v in r.items():
+            assert np.array_equal(np.asarray(v), g[f"{name}_ref_{k}"], equal_nan=True), (name, k)
+        e, lam = r["err"], r["lam"]
+        assert np.isinf(e[0]) and lam[1] == lam[0]
+        for i in range(2, len(e)):
+            assert lam[i] == (lam[i - 1] / 10.0 if (i - 1 >= 1 and e[i - 1] > e[i - 2]) else lam[i - 1] * 10.0)
+    e = g["reject_ref_err"]
+    assert e[2] > e[1] and int(g["reject_ref_iters"]) == 3 and float(g["reject_ref_err_last"]) == e[2]
