@@ -78,6 +78,7 @@ def kernel_source_hash() -> str:
     return h.hexdigest()[:16]
 
 
+NATIVE_STEP = None             # --gather-step: None = the one-call C-ABI step whenever the process group exposes its communicator
 COMPACT_LINE_CAP = 6144        # bytes of the one stdout line (target <= 6 kB, the driver failed at 22 kB)
 
 
@@ -250,7 +251,7 @@ def gather_probe(bm, world, rank, dev, cands, note):
     for wire, comm in cands:
         name, g_, ok = f"{wire}/{comm}", None, 1
         try:
-            g_ = frontend.PipelinedGather(bm, world, rank, root=0, compact=(wire == "int16"), comm_on_stage_stream=(comm == "stage"))
+            g_ = frontend.PipelinedGather(bm, world, rank, root=0, compact=(wire == "int16"), comm_on_stage_stream=(comm == "stage"), native=NATIVE_STEP)
         except Exception as e:                       # (an allocation failed on THIS rank)
             ok = 0
             note(f"gather probe {name}: set-up failed on rank {rank}: {type(e).__name__}: {e}")
@@ -334,7 +335,7 @@ def shard_gather_record(ctx, dev, args, world, rank, pairs_total, wire, comm, st
         torch.cuda.synchronize(dev)
 
     plain = stretches(lambda k: bm.run_overlapped(k), sync_plain)
-    pg = frontend.PipelinedGather(bm, world, rank, root=0, compact=(wire == "int16"), comm_on_stage_stream=(comm == "stage"))
+    pg = frontend.PipelinedGather(bm, world, rank, root=0, compact=(wire == "int16"), comm_on_stage_stream=(comm == "stage"), native=NATIVE_STEP)
 
     def sync_gather():
         pg.finish()
@@ -361,7 +362,8 @@ def shard_gather_record(ctx, dev, args, world, rank, pairs_total, wire, comm, st
                "workload": f"{pairs_total} pairs per step in contiguous shards of {Bs} per rank with a one-pair halo, gate stage "
                            "included, RCCL gather of the match tables to rank 0 under the next step's scan "
                            "(BASELINE config 4 when pairs_per_step_all_gpus = 4096 and n_gpus = 8)",
-               "gather": {"format": wire, "comm": comm, "int16_written_by": "k_finalize" if pg.kernel_wire16 else None},
+               "gather": {"format": wire, "comm": comm, "int16_written_by": "k_finalize" if pg.kernel_wire16 else None,
+                          "step": "plslam_match_plan_step_gather" if pg.native else "torch"},
                "plain_step_same_run": {"value": pairs_total * steps / dp, "ms_per_step": 1e3 * dp / steps,
                                        "what": "the same matcher, the same stepping, no gather: what the shard's step costs by itself"},
                "over_plain_step_same_run": dp / dg,
@@ -418,6 +420,9 @@ def main():
                     help="N > 1: where the wait for the collective (and the root's widening) is enqueued -- the matcher's stage stream "
                          "or a communication stream of its own (auto: both are tried by the probe; without a probe: stage at one "
                          "rank, own at N > 1)")
+    ap.add_argument("--gather-step", choices=("auto", "native", "torch"), default="auto",
+                    help="N > 1: the step as ONE C-ABI call (plslam_match_plan_step_gather on the process group's communicator) or "
+                         "torch's streams / events / c10d gather (round 5); auto = native whenever the communicator can be had")
     ap.add_argument("--cpu-budget-s", type=float, default=15.0)
     ap.add_argument("--full-json", default=None, metavar="PATH",
                     help="where the FULL record goes (secondary records, distributions, notes); default gpurun_out/bench_full.json. "
@@ -425,6 +430,8 @@ def main():
     ap.add_argument("--launch-check", action="store_true",
                     help="(tests) after the self-launch: a gloo rendezvous of the ranks and ONE JSON line from rank 0 -- no GPU work")
     args = ap.parse_args()
+    global NATIVE_STEP
+    NATIVE_STEP = {"auto": None, "native": True, "torch": False}[args.gather_step]
 
     # `python bench.py --gpus N` by itself: one process per GPU under torch.distributed.run on this node (the driver's
     # `python -m torch.distributed.run ... bench.py --gpus N` form arrives with WORLD_SIZE set and runs as it is).  --force-dist
@@ -550,8 +557,9 @@ def main():
             if dkey not in timed_ok or timed_ok[best] < 0.98 * timed_ok[dkey]:
                 choice = tuple(best.split("/"))
         pg = frontend.PipelinedGather(bm, world, rank, root=0, compact=(choice[0] == "int16"),
-                                      comm_on_stage_stream=(choice[1] == "stage"))
+                                      comm_on_stage_stream=(choice[1] == "stage"), native=NATIVE_STEP)
         gather_wire = {"format": choice[0], "comm": choice[1], "int16_written_by": "k_finalize" if pg.kernel_wire16 else None,
+                       "step": "plslam_match_plan_step_gather (one C-ABI call)" if pg.native else "torch (streams, events, c10d gather)",
                        "probe_s_per_step": probe,
                        "how": "six untimed steps per (wire format, communication stream) before the warm-up, max over ranks; the "
                               f"default ({'/'.join(default)}) keeps its place unless another wins by 2 %"}

@@ -40,7 +40,7 @@ extern "C" {
 
 /* 2: plslam_match_problem grew (keep_prior, reserved: 56 bytes), plslam_lba_plan_iterate's flags became a bit mask, options
  * "mfma_form" 3/4 and "exact_second"; 3 (round 4): "mfma_form" 5 (the default), "post_fuse", plslam_match_plan_key_state;
- * 4 (round 5): plslam_match_plan_set_wire16, the Schur step, plslam_lba_plan_host_state; 5 (round 6): plslam_lba_plan_get_landmarks.
+ * 4 (round 5): plslam_match_plan_set_wire16, the Schur step, plslam_lba_plan_host_state; 5 (round 6): plslam_lba_plan_get_landmarks, plslam_match_plan_step_gather / _gather_sync, plslam_rccl_use.
  * Clients compare plslam_abi_version() with the value they were compiled against. */
 #define PLSLAM_ABI_VERSION 5
 #define PLSLAM_DESC_BYTES 32
@@ -790,6 +790,35 @@ int plslam_lbd_binarise_dev(plslam_ctx* ctx, const float* lbd_f32, int32_t n, ui
 int plslam_gather_match_tables(plslam_ctx* ctx, void* comm, int nranks, int rank, int root,
                                const int32_t* local, int64_t n_local, int32_t* gathered,
                                void* stream);
+
+/* Which librccl the host's communicators come from (call before the first gather; NULL = the default search: librccl.so,
+ * librccl.so.1, /opt/rocm/lib/librccl.so).  A communicator belongs to ONE loaded copy of the library -- PyTorch ships its own
+ * beside ROCm's -- and the send / receive entry points must be that copy's. */
+int plslam_rccl_use(const char* path);
+
+/* One step of the N > 1 path in one call (ABI v5): the plan's scan on scan_stream, everything behind it on post_stream
+ * (plslam_match_plan_run_split), then the gather of the finished table to `root` -- one ncclGroup of point-to-point transfers,
+ * each peer on its own xGMI link -- and, on the root with the int16 wire format, the widening to int32; all enqueued, nothing
+ * waited for on the host.  The next step of the SAME plan orders itself behind this gather (both streams) before anything
+ * rewrites the table; plslam_match_plan_gather_sync waits for it on the host.
+ *   wire_bytes 4: `send` = the plan's int32 match table itself (n_entries entries), `recv` (root) = nranks * n_entries int32 in
+ *                 rank order -- the gathered tables of the C ABI; `wide` unused
+ *   wire_bytes 2: `send` = the int16 mirror the finalize kernel writes (plslam_match_plan_set_wire16), `recv` (root) = nranks *
+ *                 n_entries int16, `wide` (root; may be NULL) = nranks * n_entries int32, written behind the gather
+ *   comm_stream   the stream the collective (and the widening) is enqueued on; NULL = post_stream
+ * nranks == 1: no communicator needed (the root's own slice is copied / widened). */
+typedef struct plslam_gather_step {
+    void* comm;                  /* ncclComm_t of this rank */
+    int32_t nranks, rank, root;
+    int32_t wire_bytes;
+    const void* send;
+    int64_t n_entries;
+    void* recv;
+    int32_t* wide;
+    void *scan_stream, *post_stream, *comm_stream;
+} plslam_gather_step;
+int plslam_match_plan_step_gather(plslam_match_plan* plan, const plslam_gather_step* step);
+int plslam_match_plan_gather_sync(plslam_match_plan* plan);
 
 #ifdef __cplusplus
 }

@@ -50,7 +50,7 @@ ABI_SYMBOLS = (
     "plslam_match_pipeline_destroy", "plslam_pinned_alloc", "plslam_pinned_free",
     "plslam_match_grid", "plslam_grid_plan_create", "plslam_grid_plan_run", "plslam_grid_plan_overflows",
     "plslam_grid_plan_destroy", "plslam_grid_pair_capacity", "plslam_grid_pair_capacity_bound",
-    "plslam_gather_match_tables",
+    "plslam_gather_match_tables", "plslam_rccl_use", "plslam_match_plan_step_gather", "plslam_match_plan_gather_sync",
 )
 
 
@@ -74,6 +74,13 @@ class StereoGateProblem(C.Structure):
                 ("min_disp", C.c_double), ("line_horiz_th", C.c_double), ("stereo_overlap_th", C.c_double),
                 ("ls_min_disp_ratio", C.c_double), ("stereo_12", C.c_void_p), ("disp", C.c_void_p),
                 ("n_stereo", C.c_void_p)]
+
+
+class GatherStep(C.Structure):
+    """plslam_gather_step (include/plslam_hip.h)"""
+    _fields_ = [("comm", C.c_void_p), ("nranks", C.c_int32), ("rank", C.c_int32), ("root", C.c_int32), ("wire_bytes", C.c_int32),
+                ("send", C.c_void_p), ("n_entries", C.c_int64), ("recv", C.c_void_p), ("wide", C.c_void_p),
+                ("scan_stream", C.c_void_p), ("post_stream", C.c_void_p), ("comm_stream", C.c_void_p)]
 
 
 class ArenaProblem(C.Structure):
@@ -270,6 +277,9 @@ def load() -> C.CDLL:
     L.plslam_grid_pair_capacity_bound.argtypes = [i32, i32, vp, i32, i32, vp, C.c_int]
     L.plslam_grid_pair_capacity_bound.restype = C.c_int64
     L.plslam_gather_match_tables.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int64, vp, vp]
+    L.plslam_rccl_use.argtypes = [C.c_char_p]
+    L.plslam_match_plan_step_gather.argtypes = [vp, C.POINTER(GatherStep)]
+    L.plslam_match_plan_gather_sync.argtypes = [vp]
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if name not in ("plslam_strerror", "plslam_last_error", "plslam_ctx_destroy",
@@ -957,6 +967,21 @@ class MatchPlan:
         """The scan on one HIP stream, the stages behind it on another (they overlap the next run's scan)."""
         _check(self._L.plslam_match_plan_run_split(self._h, scan_stream or None, post_stream or None),
                "plslam_match_plan_run_split")
+
+    def make_gather_step(self, comm: int, nranks: int, rank: int, root: int, wire_bytes: int, send: int, n_entries: int, recv: int,
+                         wide: int, scan_stream: int, post_stream: int, comm_stream: int = 0):
+        """The argument block of step_gather(), built ONCE per (plan, buffer): the step itself is then one foreign call."""
+        return GatherStep(comm or None, int(nranks), int(rank), int(root), int(wire_bytes), send or None, int(n_entries), recv or None,
+                          wide or None, scan_stream or None, post_stream or None, comm_stream or None)
+
+    def step_gather(self, step) -> None:
+        """plslam_match_plan_step_gather: plan run + gather of the finished table to the root (+ widening), all enqueued."""
+        rc = self._L.plslam_match_plan_step_gather(self._h, C.byref(step))
+        if rc:
+            _check(rc, "plslam_match_plan_step_gather")
+
+    def gather_sync(self) -> None:
+        _check(self._L.plslam_match_plan_gather_sync(self._h), "plslam_match_plan_gather_sync")
 
     def add_stereo_gates(self, gates) -> None:
         """The gate stage (StereoFrame::matchStereoPoints / matchStereoLines over the batch).  gates: iterable of dicts

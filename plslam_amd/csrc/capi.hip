@@ -125,6 +125,9 @@ struct plslam_match_plan {
     // split runs (plslam_match_plan_run_split): the scan on one stream, everything behind it on another
     hipEvent_t scan_done = nullptr, post_done = nullptr;
     bool post_pending = false;
+    // plslam_match_plan_step_gather: the gather of this plan's table (and the root's widening) is over
+    hipEvent_t gather_done = nullptr;
+    bool gather_pending = false;
     size_t ev_used = 0;
     double acc_scan_ms = 0, acc_fin_ms = 0;
     int64_t acc_runs = 0;
@@ -136,8 +139,9 @@ struct plslam_match_plan {
         evs.clear();
         if (scan_done) (void)hipEventDestroy(scan_done);
         if (post_done) (void)hipEventDestroy(post_done);
-        scan_done = post_done = nullptr;
-        post_pending = false;
+        if (gather_done) (void)hipEventDestroy(gather_done);
+        scan_done = post_done = gather_done = nullptr;
+        post_pending = gather_pending = false;
         drop_graph();
     }
 };
@@ -1884,13 +1888,18 @@ struct Rccl {
 } g_rccl;
 std::mutex g_rccl_mu;
 
+std::string g_rccl_path;          // plslam_rccl_use(): the library file the host's communicators come from
+
 bool rccl_load()
 {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl.tried) return g_rccl.h != nullptr;
     g_rccl.tried = true;
-    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // the communicator a caller hands in belongs to ONE loaded copy of RCCL (PyTorch ships its own beside /opt/rocm's): the
+    // entry points must come from that copy -- plslam_rccl_use(path) names it; without it the usual search order
+    const char* names[] = {g_rccl_path.empty() ? nullptr : g_rccl_path.c_str(), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char* n : names) {
+        if (!n) continue;
         g_rccl.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
         if (g_rccl.h) break;
     }
@@ -1906,6 +1915,117 @@ bool rccl_load()
     return g_rccl.h != nullptr;
 }
 }  // namespace
+
+// which librccl the communicators of this process come from (before the first gather; NULL / "" = the default search)
+int plslam_rccl_use(const char* path)
+{
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    PLSLAM_REQUIRE(!g_rccl.tried, PLSLAM_EINVAL);          // (already loaded: too late to choose)
+    g_rccl_path = path ? path : "";
+    return PLSLAM_OK;
+}
+
+namespace plslam {
+__global__ void __launch_bounds__(256) k_widen16(const int16_t* __restrict__ src, int32_t* __restrict__ dst, int64_t n)
+{
+    // four entries per lane: 8 bytes in, 16 out
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i + 3 < n) {
+        const short4 v = *reinterpret_cast<const short4*>(src + i);
+        *reinterpret_cast<int4*>(dst + i) = make_int4(v.x, v.y, v.z, v.w);
+    } else {
+        for (int64_t k = i; k < n; ++k) dst[k] = src[k];
+    }
+}
+}  // namespace plslam
+
+// One step of the N > 1 path in ONE call (round 6; the Python of round 5 spent 0.06-0.2 ms of host time per 0.3 ms step on it):
+// plan run (scan on scan_stream, everything behind it on post_stream) -> gather of the finished table to `root` as ONE ncclGroup
+// of point-to-point transfers (each peer on its own xGMI link) -> on the root with the int16 wire format the widening to the
+// int32 tables of the C ABI -- everything enqueued, nothing waited for on the host.  The plan remembers its gather: the next step
+// of the SAME plan makes both of its streams wait for it before anything rewrites the table (also the scan stream: column-split
+// and fused plans write the table from the scan kernel -- ADVICE r5).
+int plslam_match_plan_step_gather(plslam_match_plan* plan, const plslam_gather_step* st)
+{
+    PLSLAM_REQUIRE(plan && st, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(st->nranks > 0 && st->rank >= 0 && st->rank < st->nranks && st->root >= 0 && st->root < st->nranks, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE((st->wire_bytes == 4 || st->wire_bytes == 2) && st->n_entries >= 0, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(st->n_entries == 0 || st->send, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(st->rank != st->root || st->n_entries == 0 || st->recv, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(st->nranks == 1 || st->comm, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(st->scan_stream && st->post_stream && st->scan_stream != st->post_stream, PLSLAM_EINVAL);
+    // (one rank WITH a communicator: the rank sends its table to itself through RCCL -- what a forced one-rank group measures is
+    // the collective's launch, as at N > 1; without one the slice is copied)
+    const bool use_rccl = st->comm != nullptr && st->n_entries > 0;
+    if (use_rccl && !rccl_load()) {
+        set_last_error("librccl.so could not be loaded: %s", dlerror());
+        return PLSLAM_ENOTSUP;
+    }
+    DeviceGuard g(plan->ctx->device);
+    hipStream_t ss = static_cast<hipStream_t>(st->scan_stream), sp = static_cast<hipStream_t>(st->post_stream);
+    hipStream_t sc = st->comm_stream ? static_cast<hipStream_t>(st->comm_stream) : sp;
+    if (!plan->gather_done) PLSLAM_HIP_CHECK(hipEventCreateWithFlags(&plan->gather_done, hipEventDisableTiming));
+    if (plan->gather_pending) {
+        PLSLAM_HIP_CHECK(hipStreamWaitEvent(ss, plan->gather_done, 0));
+        PLSLAM_HIP_CHECK(hipStreamWaitEvent(sp, plan->gather_done, 0));
+        plan->gather_pending = false;
+    }
+    int r = plan->fused ? plan_run(plan, ss, ss) : plan_run(plan, ss, sp);
+    if (r) return r;
+    hipStream_t last = plan->fused ? ss : sp;             // the stream the table is complete on
+    if (sc != last) {
+        // (post_done is recorded by a split run; a fused plan's table is complete on the scan stream)
+        if (plan->fused) {
+            if (!plan->post_done) PLSLAM_HIP_CHECK(hipEventCreateWithFlags(&plan->post_done, hipEventDisableTiming));
+            PLSLAM_HIP_CHECK(hipEventRecord(plan->post_done, ss));
+        }
+        PLSLAM_HIP_CHECK(hipStreamWaitEvent(sc, plan->post_done, 0));
+    }
+    const size_t bytes = (size_t)st->n_entries * (size_t)st->wire_bytes;
+    const bool root = st->rank == st->root;
+    const bool self_send = use_rccl && st->nranks == 1 && static_cast<char*>(st->recv) != st->send;
+    if (use_rccl && (st->nranks > 1 || self_send)) {
+        const int ncclInt8 = 0;
+        int rc = g_rccl.group_start();
+        if (root) {
+            for (int p = 0; p < st->nranks && rc == 0; ++p) {
+                if (p == st->root && !self_send) continue;
+                rc = g_rccl.recv(static_cast<char*>(st->recv) + (size_t)p * bytes, bytes, ncclInt8, p, st->comm, sc);
+            }
+            if (self_send && rc == 0) rc = g_rccl.send(const_cast<void*>(st->send), bytes, ncclInt8, st->root, st->comm, sc);
+        } else if (rc == 0) {
+            rc = g_rccl.send(const_cast<void*>(st->send), bytes, ncclInt8, st->root, st->comm, sc);
+        }
+        const int rc2 = g_rccl.group_end();
+        if (rc || rc2) {
+            set_last_error("RCCL point-to-point gather failed (ncclResult %d/%d)", rc, rc2);
+            return PLSLAM_EHIP;
+        }
+    }
+    if (root && bytes) {
+        char* mine = static_cast<char*>(st->recv) + (size_t)st->root * bytes;
+        if (mine != st->send && !self_send) PLSLAM_HIP_CHECK(hipMemcpyAsync(mine, st->send, bytes, hipMemcpyDeviceToDevice, sc));
+        if (st->wire_bytes == 2 && st->wide) {
+            const int64_t n = st->n_entries * st->nranks;
+            hipLaunchKernelGGL(plslam::k_widen16, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, sc,
+                               static_cast<const int16_t*>(st->recv), st->wide, n);
+            PLSLAM_HIP_CHECK(hipGetLastError());
+        }
+    }
+    PLSLAM_HIP_CHECK(hipEventRecord(plan->gather_done, sc));
+    plan->gather_pending = true;
+    return PLSLAM_OK;
+}
+
+// host wait for the plan's last plslam_match_plan_step_gather (table gathered, root's widening done)
+int plslam_match_plan_gather_sync(plslam_match_plan* plan)
+{
+    PLSLAM_REQUIRE(plan != nullptr, PLSLAM_EINVAL);
+    if (!plan->gather_done || !plan->gather_pending) return PLSLAM_OK;
+    DeviceGuard g(plan->ctx->device);
+    PLSLAM_HIP_CHECK(hipEventSynchronize(plan->gather_done));
+    return PLSLAM_OK;
+}
 
 int plslam_gather_match_tables(plslam_ctx* ctx, void* comm, int nranks, int rank, int root,
                                const int32_t* local, int64_t n_local, int32_t* gathered,

@@ -303,12 +303,16 @@ int launch_gate_n(int lines, const plslam_cam& K, const double* Twf16, const dou
 // candidate pre-filter (:549-551, :650-655) x candidate flags -> the STABLE list of the landmarks that pass (ascending) + its
 // length, the association table's -1 start, and the row count of the matchGrid problem that follows (its uploaded descriptor).
 // A workgroup per 256 landmarks, all of them at once (a single workgroup evaluated 10 000 landmarks in 17 - 28 us: fp64 on one
-// CU); a workgroup's survivors are counted by ballot, the count is published in part[b] with a flag bit, and the workgroup's
-// first slot is the sum of the counts published before it -- it spins on its predecessors' flags (they were dispatched earlier:
-// the chain cannot wait on itself).  The list comes out ascending.  part: (n + 255) / 256 words, ZERO when the kernel starts
-// (the drivers' upload image holds them).
+// CU); a workgroup's survivors are counted by ballot and the list comes out ascending: a workgroup's first slot is the number of
+// survivors in front of it, found by DECOUPLED LOOK-BACK (round 6; rounds 3-5 summed ALL predecessors' counts, b words per
+// workgroup b: fine at C3's 40 workgroups, 7.6 M polls at a 1 M-landmark map).  part[b] is one word: bit 30 = "my own count is
+// here", bit 31 = "the count of everything up to and including me is here".  A workgroup publishes its own count at once; its
+// first wave then looks back 64 predecessors at a time -- the nearest one that already knows its inclusive sum ends the walk,
+// the ones in between contribute their own counts -- and publishes its inclusive sum.  Normally one or two loads per lane.  It
+// waits only for workgroups dispatched before it (a word without either bit), which were started earlier: the chain cannot
+// wait on itself.  part: (n + 255) / 256 words, ZERO when the kernel starts (the drivers' upload image holds them).
 constexpr int VC_NT = 256;
-constexpr uint32_t VC_FLAG = 0x80000000u;
+constexpr uint32_t VC_INCL = 0x80000000u, VC_AGG = 0x40000000u, VC_VAL = 0x3FFFFFFFu;
 __global__ void __launch_bounds__(VC_NT)
 k_visible_compact(CamD K, Pose12 Twf, const double* __restrict__ X, const uint8_t* __restrict__ cand, int32_t n, int lines,
                   int32_t* __restrict__ idx, int32_t* __restrict__ n_out, int32_t* __restrict__ fill, GridDesc* __restrict__ desc,
@@ -341,20 +345,29 @@ k_visible_compact(CamD K, Pose12 Twf, const double* __restrict__ X, const uint8_
         inside_wg += w < wv ? s_w[w] : 0u;
         own += s_w[w];
     }
-    if (tid == 0) __hip_atomic_store(part + b, own | VC_FLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    uint32_t before = 0;                                    // the counts of the workgroups in front, a lane each
-    for (int p = tid; p < b; p += VC_NT) {
-        uint32_t x;
-        while (!((x = __hip_atomic_load(part + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & VC_FLAG)) __builtin_amdgcn_s_sleep(1);
-        before += x & ~VC_FLAG;
+    if (tid == 0) __hip_atomic_store(part + b, own | (b == 0 ? VC_INCL : VC_AGG), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wv == 0) {
+        uint32_t before = 0;                                // survivors in front of this workgroup
+        for (int base = b - 1; base >= 0; base -= 64) {
+            const int p = base - lane;                      // lane 0 looks at the nearest predecessor
+            uint32_t x = VC_INCL;                           // (in front of workgroup 0: an inclusive sum of nothing)
+            if (p >= 0)
+                while (!((x = __hip_atomic_load(part + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & (VC_INCL | VC_AGG))) __builtin_amdgcn_s_sleep(1);
+            const uint64_t incl = __ballot((x & VC_INCL) != 0);
+            const int first = incl ? (int)__builtin_ctzll(incl) : 64;        // the nearest predecessor that knows its inclusive sum
+            uint32_t t = lane <= first ? (x & VC_VAL) : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t += (uint32_t)__shfl_xor((int)t, o);
+            before += t;
+            if (incl) break;
+        }
+        if (lane == 0) {
+            s_before[0] = before;
+            if (b > 0) __hip_atomic_store(part + b, (before + own) | VC_INCL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) before += (uint32_t)__shfl_xor((int)before, o);
-    if (lane == 0) s_before[wv] = before;
     __syncthreads();
-    before = 0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) before += s_before[w];
+    const uint32_t before = s_before[0];
     if (v) idx[before + inside_wg + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
     if (b == (int)gridDim.x - 1 && tid == 0) {
         *n_out = (int32_t)(before + own);

@@ -377,7 +377,7 @@ class PipelinedGather:
     next step computes: StereoBatchMatcher (compute) + TableGatherPipeline (wire format, buffers, ordering)."""
 
     def __init__(self, bm: StereoBatchMatcher, world: int, rank: int, root: int = 0, group=None, compact=None,
-                 comm_on_stage_stream=None, wire16_from_kernel: bool = True):
+                 comm_on_stage_stream=None, wire16_from_kernel: bool = True, native=None):
         """comm_on_stage_stream: the wait for the collective and the root's widening go on the matcher's STAGE stream, behind the
         stages (and the narrowing copy, if any) of the step -- no third stream.  Measured on a ONE-rank RCCL group
         (tools/gather_step_probe.py, 512-pair steps): the step then costs what the plain step costs (0.344-0.349 against
@@ -389,7 +389,10 @@ class PipelinedGather:
         been measured; bench.py's probe times both.  The collective itself runs on the process group's internal stream either
         way; a HIGH-priority process-group stream made every step slower (0.44-0.59 ms): do not use it.
         wire16_from_kernel: with the int16 wire format the finalize kernel writes the int16 table itself
-        (StereoBatchMatcher.enable_wire16) instead of a narrowing copy behind it."""
+        (StereoBatchMatcher.enable_wire16) instead of a narrowing copy behind it.
+        native (round 6; None = whenever possible): the whole step -- plan run, ncclGroup of sends / receives on the process
+        group's own communicator, the root's widening -- is ONE call into the C ABI (plslam_match_plan_step_gather): no torch
+        stream contexts, events or c10d work objects on the step's path (they were 0.06-0.2 ms of host time per 0.3 ms step)."""
         import time
         self._clock = time.perf_counter
         self.bm = bm
@@ -401,11 +404,59 @@ class PipelinedGather:
                                         comm_stream=bm.streams[min(1, len(bm.streams) - 1)] if comm_on_stage_stream else None)
         self.kernel_wire16 = bool(self.pipe.compact and wire16_from_kernel and self.pipe.cuda) and bm.enable_wire16(True)
         self.host_s, self.host_n = 0.0, 0          # host time spent inside step() (enqueueing only: nothing in it waits for the GPU)
+        self.native, self._steps = False, {}
+        if native is not False and self.pipe.cuda and (not self.pipe.compact or self.kernel_wire16):
+            comm = self._native_comm(world, group)
+            if comm is not None:
+                self.native, self._comm, self._world, self._rank, self._root = True, comm, world, rank, root
+            elif native:
+                raise RuntimeError("PipelinedGather(native=True): the process group exposes no communicator (ProcessGroupNCCL._comm_ptr)")
+
+    def _native_comm(self, world, group):
+        """The ncclComm_t of this rank in `group` (0 for a one-rank job: the C entry point then needs none), with the C library
+        told which loaded copy of librccl it belongs to; None if it cannot be had."""
+        from . import capi
+        try:
+            import torch.distributed as dist
+            if world == 1 and not (dist.is_available() and dist.is_initialized()):
+                return 0                                    # a one-rank job without a process group: nothing to send
+            pg = group if group is not None else dist.distributed_c10d._get_default_group()
+            comm = int(pg._get_backend(self.bm.dev)._comm_ptr())
+        except Exception:                                   # noqa: BLE001 -- any torch without the accessor: the torch path stays
+            return 0 if world == 1 else None
+        if not comm:
+            return 0 if world == 1 else None
+        try:
+            path = next((l.split()[-1] for l in open("/proc/self/maps") if "librccl.so" in l), None)
+        except OSError:
+            path = None
+        if path:
+            capi.load().plslam_rccl_use(path.encode())     # (EINVAL once the library is loaded: the choice was made then)
+        return comm
+
+    def _native_step(self, b: int, scan):
+        key = (b, scan.cuda_stream)
+        st = self._steps.get(key)
+        if st is None:
+            p, post = self.pipe, self.bm.streams[min(1, len(self.bm.streams) - 1)]
+            send = self.bm.wire16[b] if p.compact else self.bm.tables[b]
+            root = self._rank == self._root
+            st = self.bm.plans[b].make_gather_step(
+                self._comm, self._world, self._rank, self._root, 2 if p.compact else 4, send.data_ptr(), send.numel(),
+                p.recv[b].data_ptr() if root else 0, p.wide[b].data_ptr() if (root and p.wide is not None) else 0,
+                scan.cuda_stream, post.cuda_stream, p.comm.cuda_stream)
+            self._steps[key] = st
+        return st
 
     def step(self, k: int):
         """Compute step k into buffer k % nbuf and start gathering it."""
         t0 = self._clock()
         b = k % self.pipe.nbuf
+        if self.native:
+            self.bm.plans[b].step_gather(self._native_step(b, self.bm.scan_stream_of(k)))
+            self.host_s += self._clock() - t0
+            self.host_n += 1
+            return b
         # as run_overlapped(): every scan on streams[0], the stages behind it -- which write table b -- on the
         # high-priority streams[1]; that stream therefore waits for the previous gather of buffer b, and the gather's event
         # (behind the narrowing copy, when there is one) goes behind the stages on it
@@ -424,6 +475,9 @@ class PipelinedGather:
         return v
 
     def finish(self):
+        if self.native:
+            for p in self.bm.plans:
+                p.gather_sync()
         self.pipe.finish()
 
     def gathered(self, b: int):
@@ -431,6 +485,9 @@ class PipelinedGather:
 
     def close(self):
         """Detach from the matcher (the int16 mirrors go; the matcher can be wrapped again with another wire format)."""
+        if self.native:
+            self.finish()
+            self.native, self._steps = False, {}
         if self.kernel_wire16:
             self.pipe.finish()
             self.bm.enable_wire16(False)

@@ -145,6 +145,7 @@ def test_bench_forced_rccl_group_one_rank(tmp_path):
     assert d["config"]["rccl_ranks_seen"] == {"world_size": 1, "distinct_devices": 1}
     gw = d["config"]["gather_wire"]
     assert gw["format"] in ("int16", "int32") and gw["comm"] in ("stage", "own") and len(gw["probe_s_per_step"]) == 4
+    assert gw["step"].startswith("plslam_match_plan_step_gather")          # the process group's own communicator, one C-ABI call per step
     assert d["verified"]["match_tables"].startswith("24 pairs") and "as gathered on rank 0" in d["verified"]["match_tables"]
     c4 = d["secondary"]["config4_strong"]
     assert c4["value"] > 0 and c4["scaling"] == "strong" and c4["pairs_per_gpu_per_step"] == 512 and c4["n_gpus"] == 1
