@@ -912,6 +912,16 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         ctx->graph = value;
         return PLSLAM_OK;
     }
+    if (!strcmp(key, "grid_dense")) {               // (process-wide: the lone small matchGrid problem on one dense workgroup)
+        PLSLAM_REQUIRE(value >= 0 && value <= 1, PLSLAM_EINVAL);
+        plslam::g_grid_dense = value;
+        return PLSLAM_OK;
+    }
+    if (!strcmp(key, "zero_copy_kb")) {
+        PLSLAM_REQUIRE(value >= 0 && value <= (1 << 20), PLSLAM_EINVAL);
+        ctx->zero_copy_kb = value;
+        return PLSLAM_OK;
+    }
     if (!strcmp(key, "post_xcd")) {
         PLSLAM_REQUIRE(value >= 0 && value <= 2, PLSLAM_EINVAL);
         ctx->post_xcd = value;
@@ -956,6 +966,8 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "exact_second")) { *value = ctx->exact_second; return PLSLAM_OK; }
     if (!strcmp(key, "post_workgroups")) { *value = ctx->post_workgroups; return PLSLAM_OK; }
     if (!strcmp(key, "post_xcd")) { *value = ctx->post_xcd; return PLSLAM_OK; }
+    if (!strcmp(key, "zero_copy_kb")) { *value = ctx->zero_copy_kb; return PLSLAM_OK; }
+    if (!strcmp(key, "grid_dense")) { *value = plslam::g_grid_dense; return PLSLAM_OK; }
     if (!strcmp(key, "split_post")) { *value = ctx->split_post; return PLSLAM_OK; }
     if (!strcmp(key, "split_target")) { *value = ctx->split_target; return PLSLAM_OK; }
     if (!strcmp(key, "split_min_tiles")) { *value = ctx->split_min_tiles; return PLSLAM_OK; }

@@ -130,6 +130,7 @@ struct plslam_ctx {
     int split_target = 0, split_min_tiles = 0;   // column split: workgroups per CU aimed at (0 = 3), tiles per column range at least (0 = 4)
     int split_post = 0;  // column-split K1f plans: 0 = auto (merge + ratio + mutual behind the scan in ONE kernel: two launches per run), 1 = never
     int post_xcd = 2;    // finalize: 0 = table order, 1 = an XCD takes contiguous entries of the block table (a problem's row blocks share one L2), 2 = the table dealt to the XCDs problem by problem (default)
+    int zero_copy_kb = 0;   // (round 6) host-pointer calls of ONE small problem (plslam_match_grid): an upload image of at most this many KB is read by the kernels where it lies in page-locked host memory -- no H2D copy command in front of them (0 = always copy)
     int post_fuse = 0;   // K1h / K1i plans: merge + finalize + gates behind the scan as ONE kernel: 0 = auto (throughput plans), 1 = never, 2 = whenever eligible
     int fuse = 0;        // K1f: 0 = auto (one workgroup per problem incl. merge + finalize when the plan is large), 1 = never, 2 = always
     std::mutex mu;       // serialises the host-pointer entry points
@@ -386,6 +387,7 @@ struct GridDesc {              // one matchGrid problem; every pointer is a devi
     int32_t pair_cap;
     int32_t n_items;           // entries of cell_items the caller declared (cell_start[cols*rows] must not exceed it)
 };
+extern int g_grid_dense;       // ctx option "grid_dense" (process-wide): 1 = a small lone problem runs on k_match_grid_dense
 size_t grid_fixed_words(int32_t n1, int32_t n2, int64_t ncell);   // tables kept in LDS when they fit
 bool grid_fits_lds(int32_t n1, int32_t n2, int64_t ncell);
 size_t grid_lds_bytes(int mode, int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs = false);

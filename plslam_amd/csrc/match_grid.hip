@@ -1590,6 +1590,291 @@ static int launch_group(const GridDesc* d_probs, int32_t n, size_t lds_bytes, hi
     return PLSLAM_OK;
 }
 
+// ---- a SMALL lone problem, dense (round 6) ---------------------------------------------------------------------------------
+// The line problems of the SLAM loop are 200 x 200 (src/mapHandler.cpp:418, :706; config_kitti.yaml's 200 LSD lines): the
+// machinery above -- records found cell by cell on every CU, a list bucketed by column, record passes for items that sit in several
+// cells (every line segment does) -- spent 15 + 24 us of kernels on 7 600 candidate pairs.  At this size the problem is a 256 x 256
+// bit matrix: ONE workgroup, everything in LDS, no candidate list at all.
+//   A  membership: member(i1, i2) = item i2 lies in a cell of a window of row i1 and passes the range and direction tests
+//      (GridStructure::get + the two `continue`s of matchGrid) -- four lanes per row walk the window's cell columns, one LDS
+//      atomic OR per item
+//   B  (mutual) a lane per COLUMN walks the rows in order: the rows that strictly improve the column's running distance are its
+//      records -- upstream's `if (d < distances[i2]) ... else continue`, evaluated where it is sequential by definition -- and the
+//      last of them is m21
+//   C  a lane per ROW folds its live candidates (ascending i2: the defined visiting order) into the best two keys, applies the
+//      fp64 ratio test, the mutual check, counts.
+// Same results as the kernels above on every problem both accept (tests/test_gpu_match_grid.py runs its cases through both).
+constexpr int DENSE_MAX = 256, DENSE_NT = 1024, DENSE_CHUNK = 16;
+int g_grid_dense = 1;               // ctx option "grid_dense": 0 = the small lone problem takes the general kernels as before
+// LDS words: d1 8 n1 | d2 8 n2 | member 8 n1 | live 8 n1 | any n1 | memberT 8 n2 | m21 n2 | centres 2 nc n1 | R | (dirs: 4 n1 + 4 n2
+// doubles' words, 8-byte aligned)
+// R is one region with three lives: the grid (cell_start ncell + 1, items) while A runs; the chunk minima of the columns
+// (nchunk n2) while B runs; the rows' per-word best pairs (16 n1) while C runs
+static size_t dense_region_words(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items)
+{
+    const size_t nchunk = (size_t)(n1 + DENSE_CHUNK - 1) / DENSE_CHUNK;
+    return std::max<size_t>((size_t)ncell + 1 + (size_t)n_items, std::max<size_t>(nchunk * (size_t)n2, 16 * (size_t)n1));
+}
+size_t grid_dense_lds_bytes(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs, int32_t n_centres = 2)
+{
+    size_t w = (size_t)(25 + 2 * n_centres) * (size_t)n1 + (size_t)17 * (size_t)n2 + dense_region_words(n1, n2, ncell, n_items) + 2;
+    if (dirs) w += 4 * ((size_t)n1 + (size_t)n2);
+    return w * 4;
+}
+constexpr size_t DENSE_LDS_MAX_BYTES = 128 * 1024;
+bool grid_dense_ok(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs, int32_t n_centres)
+{
+    return g_grid_dense && n1 > 0 && n1 <= DENSE_MAX && n2 > 0 && n2 <= DENSE_MAX && n_centres >= 1 && n_centres <= 4 &&
+           grid_dense_lds_bytes(n1, n2, ncell, n_items, dirs, n_centres) <= DENSE_LDS_MAX_BYTES;
+}
+
+__global__ void __launch_bounds__(DENSE_NT)
+k_match_grid_dense(GridDesc g)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_w[];
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const int32_t n1 = g.n1, n2 = g.n2, rows = g.rows, cols = g.cols;
+    const int32_t ncell = cols * rows;
+    const int32_t nchunk = (n1 + DENSE_CHUNK - 1) / DENSE_CHUNK;
+    const bool dirs = g.dir1 != nullptr && g.dir2 != nullptr;
+    uint32_t* const d1w = s_w;
+    uint32_t* const d2w = d1w + 8 * n1;
+    uint32_t* const member = d2w + 8 * n2;
+    uint32_t* const live = member + 8 * n1;
+    uint32_t* const anyitem = live + 8 * n1;
+    uint32_t* const memberT = anyitem + n1;                              // [column][row bits]: a column's 16-row chunk is 16 bits of one word
+    int32_t* const m21 = reinterpret_cast<int32_t*>(memberT + 8 * n2);
+    int32_t* const scen = m21 + n2;                                      // the window centres
+    uint32_t* const region = reinterpret_cast<uint32_t*>(scen + 2 * g.n_centres * n1);
+    uint32_t* const cs = region;                                         // life 1: the grid
+    const int32_t n_items_decl = g.n_items;
+    int32_t* const items = reinterpret_cast<int32_t*>(cs + ncell + 1);
+    uint32_t* const cmin = region;                                       // life 2: [chunk][column] (d << 8 | row) of the chunk's best row
+    uint32_t* const pairs = region;                                      // life 3: [row][word][2] best two keys of the word's candidates
+    double* const sdir = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(region + (size_t)std::max<int64_t>(
+        (int64_t)ncell + 1 + n_items_decl, std::max<int64_t>((int64_t)nchunk * n2, 16 * (int64_t)n1))) + 7) & ~uintptr_t(7));   // dir1 | dir2
+    __shared__ uint32_t s_cnt[DENSE_NT / 64];
+#ifdef PLSLAM_DENSE_TIMING
+    unsigned long long ts[8]; int nts = 0;
+#define DENSE_STAMP() do { __syncthreads(); ts[nts++] = wall_clock64(); } while (0)
+#else
+#define DENSE_STAMP() do {} while (0)
+#endif
+    DENSE_STAMP();
+
+    // ---- everything into LDS: the requests of a lane's first pieces of every array go out together (one round trip for the
+    // shipped sizes: 64 x 48 cells, a few thousand items); longer arrays continue in loops.  The bit matrices are cleared. ----
+    {
+        const PLSLAM_AS_GLOBAL u32x4* a = (const PLSLAM_AS_GLOBAL u32x4*)(uintptr_t)g.d1;       // (16-byte aligned: grid_check_problem)
+        const PLSLAM_AS_GLOBAL u32x4* b = (const PLSLAM_AS_GLOBAL u32x4*)(uintptr_t)g.d2;
+        const PLSLAM_AS_GLOBAL uint32_t* c = (const PLSLAM_AS_GLOBAL uint32_t*)(uintptr_t)g.cell_start;
+        const PLSLAM_AS_GLOBAL int32_t* it = (const PLSLAM_AS_GLOBAL int32_t*)(uintptr_t)g.cell_items;
+        const PLSLAM_AS_GLOBAL int32_t* cen = (const PLSLAM_AS_GLOBAL int32_t*)(uintptr_t)g.centres;
+        const PLSLAM_AS_GLOBAL double* p1 = (const PLSLAM_AS_GLOBAL double*)(uintptr_t)g.dir1;
+        const PLSLAM_AS_GLOBAL double* p2 = (const PLSLAM_AS_GLOBAL double*)(uintptr_t)g.dir2;
+        constexpr int E = 4;                                              // pieces per lane requested at once
+        const int ncen = 2 * g.n_centres * n1;
+        u32x4 ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+        uint32_t rc[E], ri[E];
+        int32_t rce[2] = {0, 0};
+        double rd1 = 0.0, rd2 = 0.0;
+        if (tid < 2 * n1) ra = a[tid];
+        if (tid < 2 * n2) rb = b[tid];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = tid + e * DENSE_NT;
+            rc[e] = k <= ncell ? c[k] : 0u;
+            ri[e] = k < n_items_decl ? (uint32_t)it[k] : 0u;
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { const int k = tid + e * DENSE_NT; if (k < ncen) rce[e] = cen[k]; }
+        if (dirs) {
+            if (tid < 2 * n1) rd1 = p1[tid];
+            if (tid < 2 * n2) rd2 = p2[tid];
+        }
+        for (int k = tid; k < 17 * n1; k += DENSE_NT) member[k] = 0u;          // member | live | anyitem
+        for (int k = tid; k < 8 * n2; k += DENSE_NT) memberT[k] = 0u;
+        if (tid < 2 * n1) reinterpret_cast<u32x4*>(d1w)[tid] = ra;
+        if (tid < 2 * n2) reinterpret_cast<u32x4*>(d2w)[tid] = rb;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int k = tid + e * DENSE_NT;
+            if (k <= ncell) cs[k] = rc[e];
+            if (k < n_items_decl) items[k] = (int32_t)ri[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) { const int k = tid + e * DENSE_NT; if (k < ncen) scen[k] = rce[e]; }
+        if (dirs) {
+            if (tid < 2 * n1) sdir[tid] = rd1;
+            if (tid < 2 * n2) sdir[2 * n1 + tid] = rd2;
+        }
+        for (int k = tid + E * DENSE_NT; k <= ncell; k += DENSE_NT) cs[k] = c[k];
+        for (int k = tid + E * DENSE_NT; k < n_items_decl; k += DENSE_NT) items[k] = it[k];
+        for (int k = tid + 2 * DENSE_NT; k < ncen; k += DENSE_NT) scen[k] = cen[k];
+    }
+    __syncthreads();
+    // (cell_start is the caller's: an offset beyond the declared item count would read past the copy)
+    const uint32_t n_items = cs[ncell] < (uint32_t)n_items_decl ? cs[ncell] : (uint32_t)n_items_decl;
+
+    DENSE_STAMP();
+    // ---- A: membership.  A task = (row, centre, cell column of its window): the cells (x, min_y .. max_y - 1) have consecutive
+    // ids, i.e. ONE run of the item list.  One LDS atomic OR per hit and matrix (measured: the LDS pipe of the one CU this kernel
+    // runs on is what bounds it -- ~2 500 wave-level atomic instructions are 11 of this phase's 12.5 us at 200 x 200 lines; a lane
+    // per (row, centre) with masks of its own and no atomics was slower still, 25 us: the serial chain per lane) ----
+    {
+        const int32_t* const cen = scen;
+        const int wx = g.w[0] + g.w[1] + 1;                                 // columns of an unclamped window
+        const int per_row = g.n_centres * wx;
+        for (int task = tid; task < n1 * per_row; task += DENSE_NT) {
+            const int i1 = task / per_row, rem = task - i1 * per_row, c = rem / wx, dx = rem - c * wx;
+            const int64_t x = cen[((size_t)i1 * g.n_centres + c) * 2], y = cen[((size_t)i1 * g.n_centres + c) * 2 + 1];
+            const int64_t x_ = x - g.w[0] + dx;
+            if (x_ < 0 || x_ >= cols) continue;
+            const int64_t min_y = y - g.w[2] > 0 ? y - g.w[2] : 0, max_y = y + g.w[3] + 1 < rows ? y + g.w[3] + 1 : rows;
+            if (min_y >= max_y) continue;
+            uint32_t k0 = cs[x_ * rows + min_y], k1 = cs[x_ * rows + max_y];
+            k1 = k1 < n_items ? k1 : n_items;
+            if (k0 >= k1) continue;
+            anyitem[i1] = 1u;
+            double ux = 0.0, uy = 0.0;
+            if (dirs) { ux = sdir[2 * i1]; uy = sdir[2 * i1 + 1]; }
+            for (uint32_t k = k0; k < k1; ++k) {
+                const int32_t i2 = items[k];
+                if (i2 < 0 || i2 >= n2) continue;
+                if (dirs) {
+                    const double dot = ux * sdir[2 * n1 + 2 * i2] + uy * sdir[2 * n1 + 2 * i2 + 1];
+                    if (fabs(dot) < g.sim_th) continue;
+                }
+                const uint32_t bit = 1u << (i2 & 31);
+                if (member[8 * i1 + (i2 >> 5)] & bit) continue;          // (seen through another cell: a plain read is cheaper than the atomics)
+                atomicOr(&member[8 * i1 + (i2 >> 5)], bit);
+                if (g.mutual) atomicOr(&memberT[8 * i2 + (i1 >> 5)], 1u << (i1 & 31));
+            }
+        }
+    }
+    __syncthreads();
+
+    DENSE_STAMP();
+    // ---- B: the columns' records (mutual problems).  A task = (chunk of 16 rows, column): the chunk's member rows are 16 bits of
+    // ONE word of the transposed matrix (a fifth of the pairs are members: only those distances are evaluated); the chunk's best
+    // (d, row) is published, then -- behind one barrier -- the rows that beat everything in front of them are the column's
+    // records: upstream's `if (d < distances[i2]) ... else continue`, evaluated in row order where it is sequential by definition ----
+    if (g.mutual) {
+        auto dist = [&](int i1, const u32x4& b0, const u32x4& b1) -> uint32_t {
+            const u32x4 a0 = reinterpret_cast<const u32x4*>(d1w)[2 * i1], a1 = reinterpret_cast<const u32x4*>(d1w)[2 * i1 + 1];
+            return (uint32_t)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                              __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w));
+        };
+        for (int task = tid; task < nchunk * n2; task += DENSE_NT) {
+            const int ch = task / n2, j = task - ch * n2;
+            uint32_t bits = (memberT[8 * j + (ch >> 1)] >> (16 * (ch & 1))) & 0xFFFFu;
+            uint32_t best = 0xFFFFFFFFu;
+            if (bits) {
+                const u32x4 b0 = reinterpret_cast<const u32x4*>(d2w)[2 * j], b1 = reinterpret_cast<const u32x4*>(d2w)[2 * j + 1];
+                while (bits) {
+                    const int i1 = DENSE_CHUNK * ch + __builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    const uint32_t key = (dist(i1, b0, b1) << 8) | (uint32_t)i1;      // (d, row): the earliest row among equals
+                    best = key < best ? key : best;
+                }
+            }
+            cmin[task] = best;
+        }
+        __syncthreads();
+        for (int task = tid; task < nchunk * n2; task += DENSE_NT) {
+            const int ch = task / n2, j = task - ch * n2;
+            uint32_t bits = (memberT[8 * j + (ch >> 1)] >> (16 * (ch & 1))) & 0xFFFFu;
+            if (bits) {
+                uint32_t run = 0xFFFFu;                                      // the column's distance in front of this chunk
+                for (int c2 = 0; c2 < ch; ++c2) { const uint32_t v = cmin[c2 * n2 + j] >> 8; run = v < run ? v : run; }
+                const u32x4 b0 = reinterpret_cast<const u32x4*>(d2w)[2 * j], b1 = reinterpret_cast<const u32x4*>(d2w)[2 * j + 1];
+                const uint32_t bit = 1u << (j & 31);
+                while (bits) {
+                    const int i1 = DENSE_CHUNK * ch + __builtin_ctz(bits);
+                    bits &= bits - 1u;
+                    const uint32_t d = dist(i1, b0, b1);
+                    if (d < run) {                                           // upstream: `if (d < distances[i2])`
+                        run = d;
+                        atomicOr(&live[8 * i1 + (j >> 5)], bit);
+                    }
+                }
+            }
+            if (ch == 0) {                                                   // m21: the row of the column's smallest (d, row)
+                uint32_t bk = 0xFFFFFFFFu;
+                for (int c2 = 0; c2 < nchunk; ++c2) { const uint32_t v = cmin[c2 * n2 + j]; bk = v < bk ? v : bk; }
+                m21[j] = bk == 0xFFFFFFFFu ? -1 : (int32_t)(bk & 255u);
+            }
+        }
+        __syncthreads();
+    }
+
+    DENSE_STAMP();
+    // ---- C: rows.  A task = (row, word of its candidate mask): the word's candidates folded into the best two keys (ascending
+    // i2 inside the word, words merged in ascending order: upstream's strict `<` updates); then a lane per row ----
+    const uint32_t* const mask = g.mutual ? live : member;
+    for (int task = tid; task < 8 * n1; task += DENSE_NT) {
+        const int i1 = task >> 3, w = task & 7;
+        uint32_t bits = mask[task];
+        uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+        if (bits) {
+            const u32x4 a0 = reinterpret_cast<const u32x4*>(d1w)[2 * i1], a1 = reinterpret_cast<const u32x4*>(d1w)[2 * i1 + 1];
+            while (bits) {
+                const int b = __builtin_ctz(bits);
+                bits &= bits - 1u;
+                const int j = 32 * w + b;
+                const u32x4 b0 = reinterpret_cast<const u32x4*>(d2w)[2 * j], b1 = reinterpret_cast<const u32x4*>(d2w)[2 * j + 1];
+                const uint32_t d = (uint32_t)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
+                                              __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w));
+                const uint32_t key = (d << KEY_IDX_BITS) | (uint32_t)j;
+                if (key < k1) { k2 = k1; k1 = key; }
+                else if (key < k2) k2 = key;
+            }
+        }
+        pairs[2 * task] = k1;
+        pairs[2 * task + 1] = k2;
+    }
+    __syncthreads();
+    uint32_t cnt = 0;
+    PLSLAM_AS_GLOBAL int32_t* const out = (PLSLAM_AS_GLOBAL int32_t*)(uintptr_t)g.matches_12;
+    for (int i1 = tid; i1 < n1; i1 += DENSE_NT) {
+        uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const uint32_t p1 = pairs[16 * i1 + 2 * w], p2 = pairs[16 * i1 + 2 * w + 1];      // (distinct keys: a column appears once)
+            if (p1 < k1) { k2 = k1 < p2 ? k1 : p2; k1 = p1; }
+            else if (p1 < k2) k2 = p1;
+        }
+        int32_t m = -1;
+        if (k1 != KEY_NONE) {
+            const double best_d = (double)(int32_t)(k1 >> KEY_IDX_BITS);
+            const double best_d2 = k2 == KEY_NONE ? 2147483647.0 : (double)(int32_t)(k2 >> KEY_IDX_BITS);
+            if (best_d < best_d2 * g.nnr) {
+                const int32_t i2 = (int32_t)(k1 & KEY_IDX_MASK);
+                if (!g.mutual || m21[i2] == i1) m = i2;
+            }
+        } else if (2147483647.0 < 2147483647.0 * g.nnr && anyitem[i1]) {
+            cnt += 1;       // upstream, nnr > 1 only: a row whose candidates all fail passes `best_d < best_d2 * nnr` with best_idx = -1 and is COUNTED
+        }
+        out[i1] = m;
+        cnt += m >= 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o);
+    if (lane == 0) s_cnt[tid >> 6] = cnt;
+    __syncthreads();
+    if (tid == 0 && g.n_matches) {
+        uint32_t all = 0;
+        for (int w = 0; w < DENSE_NT / 64; ++w) all += s_cnt[w];
+        *(PLSLAM_AS_GLOBAL int32_t*)(uintptr_t)g.n_matches = (int32_t)all;
+    }
+#ifdef PLSLAM_DENSE_TIMING
+    DENSE_STAMP();
+    if (tid == 0) printf("[k_match_grid_dense n1=%d n2=%d] load %d A %d B %d C %d (x10 ns)\n", n1, n2, (int)(ts[1] - ts[0]), (int)(ts[2] - ts[1]),
+                         (int)(ts[3] - ts[2]), (int)(ts[4] - ts[3]));
+#endif
+#undef DENSE_STAMP
+}
+
 // ONE problem on `s`: a mutual problem that runs LDS-resident with packed candidate words (what k_match_grid decides for
 // itself: row and column numbers of 23 bits together) and has enough rows to be worth a second launch gets its distances
 // from k_grid_candidates on many workgroups, then k_match_grid<2, 1024> with pre = 1; everything else is one launch.
@@ -1605,6 +1890,19 @@ int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hip
 {
     const int64_t ncell = (int64_t)q.grid_cols * q.grid_rows;
     const bool dirs = q.dir1 != nullptr && q.dir2 != nullptr;
+    // a small lone problem whose row count the host knows: one workgroup, dense (k_match_grid_dense)
+    if (h_desc && !n1_upper_bound && grid_dense_ok(q.n1, q.n2, ncell, q.n_items, dirs, q.n_centres)) {
+        static std::once_flag once;
+        static hipError_t attr = hipSuccess;
+        std::call_once(once, [] {
+            attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_match_grid_dense), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)DENSE_LDS_MAX_BYTES);
+        });
+        PLSLAM_HIP_CHECK(attr);
+        hipLaunchKernelGGL(k_match_grid_dense, dim3(1), dim3(DENSE_NT), grid_dense_lds_bytes(q.n1, q.n2, ncell, q.n_items, dirs, q.n_centres), s, *h_desc);
+        PLSLAM_HIP_CHECK(hipGetLastError());
+        return PLSLAM_OK;
+    }
     int group = grid_group(q.n1, q.n2, ncell, q.n_items, dirs);
     // ONE problem: nothing shares the CU, and a mutual problem of <= 256 rows still has up to 1024 (row, window part) tasks
     if (group == 3 && q.mutual && q.n1 * GRID_SPLIT > GRID_SMALL_ROWS) group = 2;
@@ -1861,6 +2159,11 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     char* h = ctx->pin_in.as<char>();
     char* d = ctx->in_a.as<char>();
     char* dout = ctx->out_a.as<char>();
+    // (option "zero_copy_kb": a small upload image is read by the kernels where it lies in page-locked host memory -- the copy
+    // command in front of them, with its completion signal, is the larger part of such a call's device-side time)
+    bool zero_copy = false;
+    if (ctx->zero_copy_kb > 0 && ci.off <= (size_t)ctx->zero_copy_kb * 1024)
+        if (char* m = static_cast<char*>(mapped_device_pointer(h))) { d = m; zero_copy = true; }
     memcpy(h + oC, centres1, (size_t)n1 * n_centres * 8);
     memcpy(h + oS, cell_start, (size_t)(ncell + 1) * 4);
     if (n_items) memcpy(h + oI, cell_items, (size_t)n_items * 4);
@@ -1894,7 +2197,7 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     grid_aux_fill(h + oX, n2);
     hipStream_t s = ctx->stream;
     StreamSyncOnError sg(s);
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, ci.off, hipMemcpyHostToDevice, s));
+    if (!zero_copy) PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, ci.off, hipMemcpyHostToDevice, s));
     if (!hout_dev) PLSLAM_HIP_CHECK(hipMemsetAsync(dout + oN, 0, 8, s));
     if ((rc = grid_launch_single(dq, (const GridDesc*)(d + oT), s, (uint32_t*)(d + oX), false, (const GridDesc*)(h + oT)))) return rc;
     if (!hout_dev) PLSLAM_HIP_CHECK(hipMemcpyAsync(ctx->pin_out.p, dout, co.off, hipMemcpyDeviceToHost, s));

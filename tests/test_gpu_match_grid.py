@@ -12,6 +12,16 @@ from test_match_grid_cpu import line_case, point_case
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["dense_small", "general"], autouse=True)
+def small_problem_kernel(request, ctx):
+    """Every test of this module twice: with a lone problem of at most 256 x 256 rows on the one-workgroup dense kernel (round 6,
+    k_match_grid_dense: the default) and with that kernel off, i.e. on the general kernels (records / candidate list / passes)
+    every other problem takes anyway."""
+    ctx.set_option("grid_dense", 1 if request.param == "dense_small" else 0)
+    yield request.param
+    ctx.set_option("grid_dense", 1)
+
+
 def _rng(seed):
     return np.random.Generator(np.random.PCG64(seed))
 
