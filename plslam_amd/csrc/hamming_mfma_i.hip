@@ -89,8 +89,21 @@
 //      (directed: 16 instead of 32).  The accumulators are inline-asm operands now: the
 //      compiler does not count MFMA -> VALU wait states for them, tools/check_mfma_hazards.py does (tests/test_abi.py).
 // 0 = round 5's code
+//   2  (experiment) the b tile in LDS without the 16 padding bytes per row: rows of 128 bytes whose 16-byte chunks are XOR-
+//      swizzled with the row number (chunk ^ (row & 7) ^ (row >> 3 & 1): conflict-free b128 operand reads and expansion stores on
+//      32 or 64 banks) -- the kilobyte this frees is the FOURTH slot of the prefetch ring (the slot becomes a compile-time fact
+//      of every unrolled step, a tile's raw words are requested one step earlier) at the same three workgroups per CU
+// 0 = round 5's code
 #ifndef PLSLAM_MI_R6
 #define PLSLAM_MI_R6 1
+#endif
+#if PLSLAM_MI_R6 & 2
+#define PLSLAM_MI_SWZ 1
+#ifndef PLSLAM_MI_RING4
+#define PLSLAM_MI_RING4 1
+#endif
+#else
+#define PLSLAM_MI_SWZ 0
 #endif
 #if PLSLAM_MI_F16 && (PLSLAM_MI_R6 & 1) && !PLSLAM_MI_ROWLOOK
 #define PLSLAM_MI_NOPACK 1
@@ -172,7 +185,8 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
     // one buffer, two lives: during the scan the double-buffered b tile (9 216 B) followed by the PARKED sorted pairs of the
     // row direction ([wave][slot][lane] x 8 B = 32 768 B); after the scan the row-result transpose [wave][row 0..63][33]
     constexpr int ROWX_STRIDE = 33;               // dwords per row: lane = row reads are conflict-free
-    constexpr int PARK_OFF = 2 * MH_TILE_BYTES;
+    constexpr int MI_ROW_STRIDE = PLSLAM_MI_SWZ ? 128 : MH_ROW_STRIDE, MI_TILE_BYTES = MH_TILE_N * MI_ROW_STRIDE;
+    constexpr int PARK_OFF = 2 * MI_TILE_BYTES;
     constexpr int SMEM_BYTES = PARK_OFF + 4 * 16 * 64 * 8;
     static_assert(SMEM_BYTES >= 4 * 64 * ROWX_STRIDE * 4, "the transpose must fit");
     __shared__ __attribute__((aligned(16))) uint8_t smem[SMEM_BYTES];
@@ -313,7 +327,8 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint8_t*>(&rawring[0][0]) + slot_b + (ej * 32 + ewd4));
     };
     auto expand_store = [&](uint32_t raw, int buf, int tn, bool full = false) __attribute__((always_inline)) {
-        uint8_t* dst = btile + buf * MH_TILE_BYTES + ej * MH_ROW_STRIDE + ewd4 * 4;
+        uint8_t* dst = PLSLAM_MI_SWZ ? btile + buf * MI_TILE_BYTES + ej * MI_ROW_STRIDE + 16 * ((tid & 7) ^ (ej & 7) ^ ((ej >> 3) & 1))
+                                     : btile + buf * MI_TILE_BYTES + ej * MI_ROW_STRIDE + ewd4 * 4;
         i32x4 v = expand_dword_fp4<false, MI_MAG>(raw);
         if (!full && tn >= nfull && (tn & 15) >= mask_from) {       // wave-uniform
             const int vm = (int)(__umul24((uint32_t)rag_s, (uint32_t)ej) + (uint32_t)(tn & 15)) < rest ? -1 : 0;
@@ -322,6 +337,14 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         *reinterpret_cast<i32x4*>(dst) = v;
     };
 
+#if PLSLAM_MI_SWZ
+    uint32_t bswz[MH_KSTEPS];
+    {
+        const uint32_t key = (uint32_t)((c & 7) ^ ((c >> 3) & 1));
+#pragma unroll
+        for (int ks = 0; ks < MH_KSTEPS; ++ks) bswz[ks] = (uint32_t)(c * MI_ROW_STRIDE) + 16u * ((uint32_t)(2 * ks + g) ^ key);
+    }
+#endif
     int wt0 = 0, wt1 = ntiles < MH_WINDOW ? ntiles : MH_WINDOW;      // the current window of tiles
     uint32_t ring_slot = 1024;                                       // rawring slot of the NEXT tile (as a byte offset)
 
@@ -563,9 +586,15 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         constexpr bool FULL = decltype(full_tag)::value;
         constexpr int U = decltype(u_tag)::value;                      // t & 3
         if (!(PLSLAM_MI_X & 1)) __syncthreads();   // tile t expanded; every wave is past its reads of the other buffer
-        const uint8_t* bt = btile + (U & 1) * MH_TILE_BYTES + c * MH_ROW_STRIDE + 16 * g;
+        const uint8_t* bt = btile + (U & 1) * MI_TILE_BYTES + c * MI_ROW_STRIDE + 16 * g;
         i32x4 bfr[MH_KSTEPS];
+#if PLSLAM_MI_SWZ
+        // (the lane's four chunk addresses of buffer 0 are loop-invariant registers; the buffer is an immediate offset)
+#define PLSLAM_MI_READ_B(KS) (*reinterpret_cast<const i32x4*>(btile + bswz[KS] + (U & 1) * MI_TILE_BYTES))
+        (void)bt;
+#else
 #define PLSLAM_MI_READ_B(KS) ((PLSLAM_MI_X & 2) ? i32x4{(int)MI_MAG + t, (int)MI_MAG, (int)MI_MAG + (KS), (int)MI_MAG} : *reinterpret_cast<const i32x4*>(bt + 32 * (KS)))
+#endif
         bfr[0] = PLSLAM_MI_READ_B(0);
         bfr[1] = PLSLAM_MI_READ_B(1);
         // ragged group: lanes whose class has run out of columns take the penalty from this tile on (K1h)

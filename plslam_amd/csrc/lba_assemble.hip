@@ -1304,8 +1304,8 @@ extern "C" int plslam_lba_plan_diag_max(plslam_lba_plan* P, double* hmax)
     PLSLAM_REQUIRE(P && hmax, PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);               // (the plan's state flags are read under the lock: ADVICE r5)
-    PLSLAM_REQUIRE(P->blocks_valid, PLSLAM_EINVAL);        // one plslam_lba_plan_iterate* first
     DeviceGuard dg_(ctx->device);
+    PLSLAM_REQUIRE(P->blocks_valid, PLSLAM_EINVAL);        // one plslam_lba_plan_iterate* first
     int rc = lba_schur_prepare(P);
     if (rc) return rc;
     hipStream_t s = ctx->stream;
@@ -1327,11 +1327,11 @@ extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* 
     PLSLAM_REQUIRE(P && S && b && lambda >= 0.0, PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
     PLSLAM_REQUIRE(P->blocks_valid && P->nkf > 0, PLSLAM_EINVAL);
     // the cross blocks must be the local BA's (landmark rows x pose columns): an iteration run with PLSLAM_LBA_COMPAT_GBA wrote the
     // pose x line blocks transposed, as the reference's GBA does (:2341-2352) -- a defect this step does not reproduce
     PLSLAM_REQUIRE(!P->blocks_gba, PLSLAM_EINVAL);
-    DeviceGuard dg_(ctx->device);
     int rc = lba_schur_prepare(P);
     if (rc) return rc;
     hipStream_t s = ctx->stream;
@@ -1377,9 +1377,9 @@ extern "C" int plslam_lba_plan_backsub(plslam_lba_plan* P, const double* dpose, 
     PLSLAM_REQUIRE(P && dpose, PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
     PLSLAM_REQUIRE(P->schur_done, PLSLAM_EINVAL);          // plslam_lba_plan_schur on the blocks of the last iteration first
     PLSLAM_REQUIRE(!apply || P->state_valid, PLSLAM_EINVAL);
-    DeviceGuard dg_(ctx->device);
     hipStream_t s = ctx->stream;
     char *ds = P->stat.as<char>(), *dd = P->dyn.as<char>(), *dout = P->out.as<char>(), *d = P->schur.as<char>();
     const size_t n6 = 6 * (size_t)P->nkf;
@@ -1421,8 +1421,8 @@ extern "C" int plslam_lba_plan_get_landmarks(plslam_lba_plan* P, double* Xw, dou
     PLSLAM_REQUIRE(P != nullptr, PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    PLSLAM_REQUIRE(P->state_valid, PLSLAM_EINVAL);         // one plslam_lba_plan_iterate(_dev) first: it uploads the state
     DeviceGuard dg_(ctx->device);
+    PLSLAM_REQUIRE(P->state_valid, PLSLAM_EINVAL);         // one plslam_lba_plan_iterate(_dev) first: it uploads the state
     hipStream_t s = ctx->stream;
     char *hi = P->pin_in.as<char>(), *dd = P->dyn.as<char>();
     const size_t bx = (size_t)P->npt * 24, bl = (size_t)P->nls * 48;
@@ -1440,8 +1440,8 @@ extern "C" int plslam_lba_plan_set_poses(plslam_lba_plan* P, const double* T_kf_
     PLSLAM_REQUIRE(P && (P->n_slots == 0 || T_kf_w), PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    PLSLAM_REQUIRE(P->state_valid, PLSLAM_EINVAL);
     DeviceGuard dg_(ctx->device);
+    PLSLAM_REQUIRE(P->state_valid, PLSLAM_EINVAL);
     hipStream_t s = ctx->stream;
     if (P->n_slots) {
         char* hi = P->pin_in.as<char>();

@@ -1637,22 +1637,29 @@ k_match_grid_dense(GridDesc g)
     const int32_t ncell = cols * rows;
     const int32_t nchunk = (n1 + DENSE_CHUNK - 1) / DENSE_CHUNK;
     const bool dirs = g.dir1 != nullptr && g.dir2 != nullptr;
-    uint32_t* const d1w = s_w;
-    uint32_t* const d2w = d1w + 8 * n1;
-    uint32_t* const member = d2w + 8 * n2;
-    uint32_t* const live = member + 8 * n1;
-    uint32_t* const anyitem = live + 8 * n1;
-    uint32_t* const memberT = anyitem + n1;                              // [column][row bits]: a column's 16-row chunk is 16 bits of one word
-    int32_t* const m21 = reinterpret_cast<int32_t*>(memberT + 8 * n2);
-    int32_t* const scen = m21 + n2;                                      // the window centres
-    uint32_t* const region = reinterpret_cast<uint32_t*>(scen + 2 * g.n_centres * n1);
-    uint32_t* const cs = region;                                         // life 1: the grid
+    // (every LDS pointer carries its address space: a generic one makes the compiler emit FLAT accesses)
+    typedef PLSLAM_AS_LDS uint32_t* lds_u32;
+    typedef PLSLAM_AS_LDS int32_t* lds_i32;
+    typedef PLSLAM_AS_LDS u32x4* lds_u32x4;
+    const lds_u32 base = (lds_u32)s_w;
+    const lds_u32 d1w = base;
+    const lds_u32 d2w = d1w + 8 * n1;
+    const lds_u32 member = d2w + 8 * n2;
+    const lds_u32 live = member + 8 * n1;
+    const lds_u32 anyitem = live + 8 * n1;
+    const lds_u32 memberT = anyitem + n1;                                // [column][row bits]: a column's 16-row chunk is 16 bits of one word
+    const lds_i32 m21 = (lds_i32)(memberT + 8 * n2);
+    const lds_i32 scen = m21 + n2;                                       // the window centres
+    const lds_u32 region = (lds_u32)(scen + 2 * g.n_centres * n1);
+    const lds_u32 cs = region;                                           // life 1: the grid
     const int32_t n_items_decl = g.n_items;
-    int32_t* const items = reinterpret_cast<int32_t*>(cs + ncell + 1);
-    uint32_t* const cmin = region;                                       // life 2: [chunk][column] (d << 8 | row) of the chunk's best row
-    uint32_t* const pairs = region;                                      // life 3: [row][word][2] best two keys of the word's candidates
-    double* const sdir = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(region + (size_t)std::max<int64_t>(
-        (int64_t)ncell + 1 + n_items_decl, std::max<int64_t>((int64_t)nchunk * n2, 16 * (int64_t)n1))) + 7) & ~uintptr_t(7));   // dir1 | dir2
+    const lds_i32 items = (lds_i32)(cs + ncell + 1);
+    const lds_u32 cmin = region;                                         // life 2: [chunk][column] (d << 8 | row) of the chunk's best row
+    const lds_u32 pairs = region;                                        // life 3: [row][word][2] best two keys of the word's candidates
+    const int64_t rwords = std::max<int64_t>((int64_t)ncell + 1 + n_items_decl, std::max<int64_t>((int64_t)nchunk * n2, 16 * (int64_t)n1));
+    const int64_t dir_off = ((region - base) + rwords + 1) & ~int64_t(1);            // (even word offset from a 16-byte aligned base: 8-byte aligned)
+    PLSLAM_AS_LDS double* const sdir = (PLSLAM_AS_LDS double*)(base + dir_off);       // dir1 | dir2
+    const lds_u32x4 d1v = (lds_u32x4)d1w, d2v = (lds_u32x4)d2w;
     __shared__ uint32_t s_cnt[DENSE_NT / 64];
 #ifdef PLSLAM_DENSE_TIMING
     unsigned long long ts[8]; int nts = 0;
@@ -1694,8 +1701,8 @@ k_match_grid_dense(GridDesc g)
         }
         for (int k = tid; k < 17 * n1; k += DENSE_NT) member[k] = 0u;          // member | live | anyitem
         for (int k = tid; k < 8 * n2; k += DENSE_NT) memberT[k] = 0u;
-        if (tid < 2 * n1) reinterpret_cast<u32x4*>(d1w)[tid] = ra;
-        if (tid < 2 * n2) reinterpret_cast<u32x4*>(d2w)[tid] = rb;
+        if (tid < 2 * n1) d1v[tid] = ra;
+        if (tid < 2 * n2) d2v[tid] = rb;
 #pragma unroll
         for (int e = 0; e < E; ++e) {
             const int k = tid + e * DENSE_NT;
@@ -1722,7 +1729,7 @@ k_match_grid_dense(GridDesc g)
     // runs on is what bounds it -- ~2 500 wave-level atomic instructions are 11 of this phase's 12.5 us at 200 x 200 lines; a lane
     // per (row, centre) with masks of its own and no atomics was slower still, 25 us: the serial chain per lane) ----
     {
-        const int32_t* const cen = scen;
+        const lds_i32 cen = scen;
         const int wx = g.w[0] + g.w[1] + 1;                                 // columns of an unclamped window
         const int per_row = g.n_centres * wx;
         for (int task = tid; task < n1 * per_row; task += DENSE_NT) {
@@ -1747,8 +1754,8 @@ k_match_grid_dense(GridDesc g)
                 }
                 const uint32_t bit = 1u << (i2 & 31);
                 if (member[8 * i1 + (i2 >> 5)] & bit) continue;          // (seen through another cell: a plain read is cheaper than the atomics)
-                atomicOr(&member[8 * i1 + (i2 >> 5)], bit);
-                if (g.mutual) atomicOr(&memberT[8 * i2 + (i1 >> 5)], 1u << (i1 & 31));
+                atomicOr((uint32_t*)&member[8 * i1 + (i2 >> 5)], bit);
+                if (g.mutual) atomicOr((uint32_t*)&memberT[8 * i2 + (i1 >> 5)], 1u << (i1 & 31));
             }
         }
     }
@@ -1761,7 +1768,7 @@ k_match_grid_dense(GridDesc g)
     // records: upstream's `if (d < distances[i2]) ... else continue`, evaluated in row order where it is sequential by definition ----
     if (g.mutual) {
         auto dist = [&](int i1, const u32x4& b0, const u32x4& b1) -> uint32_t {
-            const u32x4 a0 = reinterpret_cast<const u32x4*>(d1w)[2 * i1], a1 = reinterpret_cast<const u32x4*>(d1w)[2 * i1 + 1];
+            const u32x4 a0 = d1v[2 * i1], a1 = d1v[2 * i1 + 1];
             return (uint32_t)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
                               __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w));
         };
@@ -1770,7 +1777,7 @@ k_match_grid_dense(GridDesc g)
             uint32_t bits = (memberT[8 * j + (ch >> 1)] >> (16 * (ch & 1))) & 0xFFFFu;
             uint32_t best = 0xFFFFFFFFu;
             if (bits) {
-                const u32x4 b0 = reinterpret_cast<const u32x4*>(d2w)[2 * j], b1 = reinterpret_cast<const u32x4*>(d2w)[2 * j + 1];
+                const u32x4 b0 = d2v[2 * j], b1 = d2v[2 * j + 1];
                 while (bits) {
                     const int i1 = DENSE_CHUNK * ch + __builtin_ctz(bits);
                     bits &= bits - 1u;
@@ -1787,7 +1794,7 @@ k_match_grid_dense(GridDesc g)
             if (bits) {
                 uint32_t run = 0xFFFFu;                                      // the column's distance in front of this chunk
                 for (int c2 = 0; c2 < ch; ++c2) { const uint32_t v = cmin[c2 * n2 + j] >> 8; run = v < run ? v : run; }
-                const u32x4 b0 = reinterpret_cast<const u32x4*>(d2w)[2 * j], b1 = reinterpret_cast<const u32x4*>(d2w)[2 * j + 1];
+                const u32x4 b0 = d2v[2 * j], b1 = d2v[2 * j + 1];
                 const uint32_t bit = 1u << (j & 31);
                 while (bits) {
                     const int i1 = DENSE_CHUNK * ch + __builtin_ctz(bits);
@@ -1795,7 +1802,7 @@ k_match_grid_dense(GridDesc g)
                     const uint32_t d = dist(i1, b0, b1);
                     if (d < run) {                                           // upstream: `if (d < distances[i2])`
                         run = d;
-                        atomicOr(&live[8 * i1 + (j >> 5)], bit);
+                        atomicOr((uint32_t*)&live[8 * i1 + (j >> 5)], bit);
                     }
                 }
             }
@@ -1811,18 +1818,18 @@ k_match_grid_dense(GridDesc g)
     DENSE_STAMP();
     // ---- C: rows.  A task = (row, word of its candidate mask): the word's candidates folded into the best two keys (ascending
     // i2 inside the word, words merged in ascending order: upstream's strict `<` updates); then a lane per row ----
-    const uint32_t* const mask = g.mutual ? live : member;
+    const lds_u32 mask = g.mutual ? live : member;
     for (int task = tid; task < 8 * n1; task += DENSE_NT) {
         const int i1 = task >> 3, w = task & 7;
         uint32_t bits = mask[task];
         uint32_t k1 = KEY_NONE, k2 = KEY_NONE;
         if (bits) {
-            const u32x4 a0 = reinterpret_cast<const u32x4*>(d1w)[2 * i1], a1 = reinterpret_cast<const u32x4*>(d1w)[2 * i1 + 1];
+            const u32x4 a0 = d1v[2 * i1], a1 = d1v[2 * i1 + 1];
             while (bits) {
                 const int b = __builtin_ctz(bits);
                 bits &= bits - 1u;
                 const int j = 32 * w + b;
-                const u32x4 b0 = reinterpret_cast<const u32x4*>(d2w)[2 * j], b1 = reinterpret_cast<const u32x4*>(d2w)[2 * j + 1];
+                const u32x4 b0 = d2v[2 * j], b1 = d2v[2 * j + 1];
                 const uint32_t d = (uint32_t)(__popc(a0.x ^ b0.x) + __popc(a0.y ^ b0.y) + __popc(a0.z ^ b0.z) + __popc(a0.w ^ b0.w) +
                                               __popc(a1.x ^ b1.x) + __popc(a1.y ^ b1.y) + __popc(a1.z ^ b1.z) + __popc(a1.w ^ b1.w));
                 const uint32_t key = (d << KEY_IDX_BITS) | (uint32_t)j;
