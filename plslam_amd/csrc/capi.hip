@@ -1110,6 +1110,12 @@ int plslam_match_plan_set_wire16(plslam_match_plan* plan, const int32_t* table32
             if (pd.n1 <= 0 || pd.matches_12 < table32 || pd.matches_12 >= table32 + n_entries) continue;
             PLSLAM_REQUIRE((size_t)(pd.matches_12 - table32) + (size_t)pd.n1 <= n_entries, PLSLAM_EINVAL);
             PLSLAM_REQUIRE(pd.n2 <= 32768, PLSLAM_EINVAL);
+            // a kept prior entry of a NON-mutual problem reaches the table unchecked (upstream's resize(); a mutual problem
+            // clears whatever lies outside [0, n2)): it could be any int32 and would wrap in the mirror
+            if (pd.keep_prior && !pd.mutual) {
+                set_last_error("plslam_match_plan_set_wire16: problem %zu keeps prior entries without the mutual check (unbounded values)", k);
+                return PLSLAM_ENOTSUP;
+            }
             mirror[k] = table16 + (pd.matches_12 - table32);
         }
     PLSLAM_HIP_CHECK(hipDeviceSynchronize());               // (as add_stereo_gates: rare, so it waits for whatever is in flight)

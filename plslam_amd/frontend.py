@@ -462,6 +462,8 @@ class PipelinedGather:
         # (behind the narrowing copy, when there is one) goes behind the stages on it
         scan, post = self.bm.scan_stream_of(k), self.bm.streams[min(1, len(self.bm.streams) - 1)]
         self.pipe.before_overwrite(b, post)
+        if scan is not post:                     # (column-split / fused plans write the table from the SCAN kernel: ADVICE r5)
+            self.pipe.before_overwrite(b, scan)
         self.bm.plans[b].run_split(scan.cuda_stream, post.cuda_stream)
         r = self.pipe.submit(b, self.bm.tables[b], post, wire16=self.bm.wire16[b] if self.kernel_wire16 else None)
         self.host_s += self._clock() - t0
