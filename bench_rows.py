@@ -251,9 +251,26 @@ def lba_iterate(ctx, O):
         S_, b_, _ = plan.schur(lam)
         plan.backsub(np.linalg.solve(S_, b_), apply=False, want=False)
     whole_us = _pct(_wall(lm_iteration, 30))["us_median"]
+
+    def lm_iteration_two_calls():                           # round 6: plslam_lba_plan_iterate_schur + plslam_lba_plan_apply_step
+        _, S_, b_, _n = plan.iterate_schur(lam)
+        plan.apply_step(np.linalg.solve(S_, b_), None, apply=False)
+    e2, S2, b2, _n2 = plan.iterate_schur(lam)
+    if not (np.array_equal(S2, S) and np.array_equal(b2, b)):
+        raise SystemExit("secondary record lba_iterate: plslam_lba_plan_iterate_schur does not return plslam_lba_plan_schur's system")
+    ss = plan.apply_step(dp, None, apply=False)
+    want_ss = float((dxp ** 2).sum() + (dxl ** 2).sum())
+    if not abs(ss - want_ss) <= 1e-12 * want_ss:
+        raise SystemExit(f"secondary record lba_iterate: plslam_lba_plan_apply_step's sum of squares {ss!r} != {want_ss!r}")
+    two_us = _pct(_wall(lm_iteration_two_calls, 30))["us_median"]
+    solve_us = _pct(_wall(lambda: np.linalg.solve(S, b), 30))["us_median"]
     plan.close()
     return dict(_pct(ts), err_only_us_median=err_only, state_resident_us_median=resident, state_in_page_locked_images_us_median=in_place,
                 schur_step={"schur_us_median": schur_us, "backsub_us_median": back_us, "lm_iteration_blocks_resident_us_median": whole_us,
+                            "lm_iteration_two_calls_us_median": two_us, "host_numpy_solve_us_median": solve_us,
+                            "two_calls": "plslam_lba_plan_iterate_schur (H, g, err + the Schur step, one synchronisation) + numpy's solve of S + "
+                                         "plslam_lba_plan_apply_step (back-substitution + sum DX^2, one synchronisation): the iteration as "
+                                         "LbaPlanSolver::optimize runs it; host_numpy_solve = the share of numpy's 54 x 54 solve in both figures",
                             "reduced_system": f"{n6} x {n6}", "lambda": lam, "residual_of_the_damped_system_over_gmax": worst,
                             "what": "plslam_lba_plan_schur (landmark inverses, reduced system S, b: 29 kB down) / plslam_lba_plan_backsub "
                                     "(pose step up, landmark steps on the device) / one whole LM iteration with the state and the blocks "

@@ -40,7 +40,7 @@ extern "C" {
 
 /* 2: plslam_match_problem grew (keep_prior, reserved: 56 bytes), plslam_lba_plan_iterate's flags became a bit mask, options
  * "mfma_form" 3/4 and "exact_second"; 3 (round 4): "mfma_form" 5 (the default), "post_fuse", plslam_match_plan_key_state;
- * 4 (round 5): plslam_match_plan_set_wire16, the Schur step, plslam_lba_plan_host_state; 5 (round 6): plslam_lba_plan_get_landmarks, plslam_match_plan_step_gather / _gather_sync, plslam_rccl_use.
+ * 4 (round 5): plslam_match_plan_set_wire16, the Schur step, plslam_lba_plan_host_state; 5 (round 6): plslam_lba_plan_get_landmarks, plslam_lba_plan_iterate_schur / _apply_step, plslam_match_plan_step_gather / _gather_sync, plslam_rccl_use.
  * Clients compare plslam_abi_version() with the value they were compiled against. */
 #define PLSLAM_ABI_VERSION 5
 #define PLSLAM_DESC_BYTES 32
@@ -568,6 +568,17 @@ int plslam_lba_plan_diag_max(plslam_lba_plan* plan, double* hmax);
 int plslam_lba_plan_schur(plslam_lba_plan* plan, double lambda, double* S, double* b, int32_t* n_singular);
 int plslam_lba_plan_backsub(plslam_lba_plan* plan, const double* dpose, int apply, double* dX_pt, double* dX_ls);
 int plslam_lba_plan_set_poses(plslam_lba_plan* plan, const double* T_kf_w);
+/* An LM iteration of src/mapHandler.cpp:1583-1812 in TWO calls and two synchronisations (ABI v5, round 6):
+ *   plslam_lba_plan_iterate_schur = plslam_lba_plan_iterate_resident + plslam_lba_plan_schur for a lambda known beforehand
+ *                              (every iteration but the first pass, whose lambda needs plslam_lba_plan_diag_max): err, S, b and
+ *                              the count of singular landmark blocks come back behind ONE synchronisation;
+ *   plslam_lba_plan_apply_step = plslam_lba_plan_backsub(dpose, apply) + plslam_lba_plan_set_poses(T_kf_w; NULL = leave the
+ *                              pose slots, a rejected step) + sum_i DX(i)^2 over the LANDMARK steps (dx_sumsq, may be NULL): with
+ *                              |dpose|^2 added on the host this is the ||DX|| of the loop's last test (:1808), and 8 bytes
+ *                              cross PCIe instead of the steps.  The sum is taken in a fixed order: the same bits on every run. */
+int plslam_lba_plan_iterate_schur(plslam_lba_plan* plan, int compat_flags, double lambda, double* err, double* S, double* b,
+                                  int32_t* n_singular);
+int plslam_lba_plan_apply_step(plslam_lba_plan* plan, const double* dpose, const double* T_kf_w, int apply, double* dx_sumsq);
 /* The resident landmarks, device -> host (ABI v5): Xw (npt x 3) / Lw (nls x 6), either may be NULL.  What
  * plslam_lba_plan_backsub(apply) updated in place comes back for the reference's write-back (src/mapHandler.cpp:1822-1852:
  * point3D / line3D <- X, inlier = false where ||X - old|| > 0.01).  The plan's page-locked images (plslam_lba_plan_host_state)

@@ -37,6 +37,7 @@ ABI_SYMBOLS = (
     "plslam_lba_plan_rows", "plslam_lba_plan_destroy", "plslam_lba_plan_iterate_dev", "plslam_lba_plan_device_blocks", "plslam_lba_plan_device_state",
     "plslam_lba_plan_iterate_resident", "plslam_lba_plan_diag_max", "plslam_lba_plan_schur", "plslam_lba_plan_backsub",
     "plslam_lba_plan_set_poses", "plslam_lba_plan_host_state", "plslam_lba_plan_get_landmarks",
+    "plslam_lba_plan_iterate_schur", "plslam_lba_plan_apply_step",
     "plslam_lba_plan_blocks",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
@@ -224,6 +225,8 @@ def load() -> C.CDLL:
     L.plslam_lba_plan_backsub.argtypes = [vp, vp, C.c_int, vp, vp]
     L.plslam_lba_plan_set_poses.argtypes = [vp, vp]
     L.plslam_lba_plan_get_landmarks.argtypes = [vp, vp, vp]
+    L.plslam_lba_plan_iterate_schur.argtypes = [vp, C.c_int, C.c_double, vp, vp, vp, vp]
+    L.plslam_lba_plan_apply_step.argtypes = [vp, vp, vp, C.c_int, vp]
     L.plslam_lba_plan_host_state.argtypes = [vp, vp]
     L.plslam_lba_plan_blocks.argtypes = [vp] * 8
     L.plslam_lba_plan_destroy.argtypes = [vp]
@@ -861,6 +864,28 @@ class LbaPlan:
         T = _arr(T_kf_w, np.float64, (-1, 16))
         assert T.shape[0] == self.dims[5]
         _check(self._L.plslam_lba_plan_set_poses(self._h, _p(T)), "plslam_lba_plan_set_poses")
+
+    def iterate_schur(self, lam: float, compat_flags: int = 0):
+        """iterate_resident + schur(lam) behind one synchronisation -> (err, S, b, number of singular landmark blocks)."""
+        nkf = self.dims[0]
+        err, S, b, ns = np.empty(1), np.empty((6 * nkf, 6 * nkf)), np.empty(6 * nkf), np.zeros(1, np.int32)
+        _check(self._L.plslam_lba_plan_iterate_schur(self._h, int(compat_flags), float(lam), _p(err), _p(S), _p(b), _p(ns)),
+               "plslam_lba_plan_iterate_schur")
+        return float(err[0]), S, b, int(ns[0])
+
+    def apply_step(self, dpose, T_kf_w=None, apply=True) -> float:
+        """backsub(dpose, apply) + set_poses(T_kf_w, None: leave them) behind one synchronisation -> sum of squares of the
+        landmark steps."""
+        nkf = self.dims[0]
+        dp = _arr(dpose, np.float64, (6 * nkf,))
+        T = None
+        if T_kf_w is not None:
+            T = _arr(T_kf_w, np.float64, (-1, 16))
+            assert T.shape[0] == self.dims[5]
+        ss = np.empty(1)
+        _check(self._L.plslam_lba_plan_apply_step(self._h, _p(dp), _p(T) if T is not None else None, int(bool(apply)), _p(ss)),
+               "plslam_lba_plan_apply_step")
+        return float(ss[0])
 
     def get_landmarks(self):
         """The resident landmarks (after backsub(apply=True)) -> (Xw (npt, 3), Lw (nls, 6)); also refreshes the page-locked images

@@ -223,7 +223,9 @@ struct LbaIterArgs {
 __global__ void __launch_bounds__(256)
 k_lba_rows_cross(const LbaIterArgs A)
 {
-    __shared__ __attribute__((aligned(16))) double slabs[4][64 * 6];
+    // (a slab holds a wave's 64 rows of up to 18 doubles: the cross blocks leave through it too -- written lane by lane they were 18 /
+    // 36 instructions of 64 scattered 8-byte stores each)
+    __shared__ __attribute__((aligned(16))) double slabs[4][64 * 18];
     __shared__ double red[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool lines = (int)blockIdx.x >= A.nbp;
@@ -244,12 +246,14 @@ k_lba_rows_cross(const LbaIterArgs A)
             if (o < nobs) {
                 A.pr[o] = nrm;
                 A.pw[o] = wgt;
-                const bool opt = A.pt_kf_loc[o] >= 0;          // kf_loc == -1: the keyframe is not optimised, no cross block
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-#pragma unroll
-                    for (int b = 0; b < 6; ++b) A.Wp[((size_t)o * 3 + a) * 6 + b] = opt ? out3[a] * out6[b] * wgt : 0.0;
             }
+            const bool opt = A.pt_kf_loc[oc] >= 0;             // kf_loc == -1: the keyframe is not optimised, no cross block
+            double w18[18];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) w18[a * 6 + b] = opt ? out3[a] * out6[b] * wgt : 0.0;
+            wave_store_rows<18>(A.Wp + 18 * (size_t)o0, w18, slabs[wave], lane, valid);
         } else {
             double outl[6], outp[6];
             const size_t l0 = (size_t)A.ls_lm[oc];
@@ -262,12 +266,19 @@ k_lba_rows_cross(const LbaIterArgs A)
             if (o < nobs) {
                 A.lr[o] = nrm;
                 A.lw[o] = wgt;
-                const bool opt = A.ls_kf_loc[o] >= 0;
+            }
+            const bool opt = A.ls_kf_loc[oc] >= 0;
 #pragma unroll
-                for (int a = 0; a < 6; ++a)
+            for (int half = 0; half < 2; ++half) {             // rows 0-2, then rows 3-5 of the 6 x 6 block
+                double w18[18];
 #pragma unroll
-                    for (int b = 0; b < 6; ++b)
-                        A.Wl[A.transpose_ls_cross ? ((size_t)o * 6 + b) * 6 + a : ((size_t)o * 6 + a) * 6 + b] = opt ? outl[a] * outp[b] * wgt : 0.0;
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 6; ++b) {
+                        const int r = 3 * half + a;            // (transposed: entry (r, b) of what is stored is outl[b] * outp[r])
+                        w18[a * 6 + b] = !opt ? 0.0 : A.transpose_ls_cross ? outl[b] * outp[r] * wgt : outl[r] * outp[b] * wgt;
+                    }
+                wave_store_row_parts<18, 36>(A.Wl + 36 * (size_t)o0 + 18 * half, w18, slabs[wave], lane, valid);
             }
         }
         if (o < nobs) e2w = nrm * nrm * wgt;
@@ -282,9 +293,15 @@ k_lba_rows_cross(const LbaIterArgs A)
 }
 
 template <int DL>
+__device__ __forceinline__ void schur_landmark(const double* __restrict__ H, const double* __restrict__ g, int j, double lambda,
+                                               double* __restrict__ Vinv, double* __restrict__ t, int32_t* __restrict__ nsing);
+
+template <int DL>
 __device__ __forceinline__ void landmark_block(int l, int32_t nlm, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_obs,
                                                const double* __restrict__ Jl, const double* __restrict__ r, const double* __restrict__ w,
-                                               double* __restrict__ Hll, double* __restrict__ gl)
+                                               double* __restrict__ Hll, double* __restrict__ gl, double lambda = 0.0,
+                                               double* __restrict__ Vinv = nullptr, double* __restrict__ t = nullptr,
+                                               int32_t* __restrict__ nsing = nullptr)
 {
     if (l >= nlm) return;
     double H[DL * DL], g[DL];
@@ -292,23 +309,41 @@ __device__ __forceinline__ void landmark_block(int l, int32_t nlm, const int32_t
     for (int i = 0; i < DL * DL; ++i) H[i] = 0.0;
 #pragma unroll
     for (int i = 0; i < DL; ++i) g[i] = 0.0;
-    for (int k = lm_ptr[l]; k < lm_ptr[l + 1]; ++k) {
-        const int o = lm_obs[k];
-        double J[DL];
+    // (the observations go PB at a time: their ids in one round trip, their rows in a second -- one by one a landmark's list was a
+    // chain of two dependent round trips per observation; the sums keep their order)
+    constexpr int PB = DL == 3 ? 8 : 4;
+    const int kbeg = lm_ptr[l], kend = lm_ptr[l + 1];
+    for (int k0 = kbeg; k0 < kend; k0 += PB) {
+        int oo[PB];
 #pragma unroll
-        for (int a = 0; a < DL; ++a) J[a] = Jl[(size_t)o * DL + a];
-        const double rr = r[o], ww = w[o];
+        for (int u = 0; u < PB; ++u) oo[u] = lm_obs[k0 + u < kend ? k0 + u : kend - 1];
+        double J[PB][DL], rr[PB], ww[PB];
 #pragma unroll
-        for (int a = 0; a < DL; ++a) g[a] += J[a] * rr * ww;
+        for (int u = 0; u < PB; ++u) {
 #pragma unroll
-        for (int a = 0; a < DL; ++a)
+            for (int a = 0; a < DL; ++a) J[u][a] = Jl[(size_t)oo[u] * DL + a];
+            rr[u] = r[oo[u]];
+            ww[u] = w[oo[u]];
+        }
 #pragma unroll
-            for (int b = 0; b < DL; ++b) H[a * DL + b] += J[a] * J[b] * ww;
+        for (int u = 0; u < PB; ++u) {
+            if (k0 + u < kend) {
+#pragma unroll
+                for (int a = 0; a < DL; ++a) g[a] += J[u][a] * rr[u] * ww[u];
+#pragma unroll
+                for (int a = 0; a < DL; ++a)
+#pragma unroll
+                    for (int b = 0; b < DL; ++b) H[a * DL + b] += J[u][a] * J[u][b] * ww[u];
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < DL * DL; ++i) Hll[(size_t)l * DL * DL + i] = H[i];
 #pragma unroll
     for (int i = 0; i < DL; ++i) gl[(size_t)l * DL + i] = g[i];
+    // plslam_lba_plan_iterate_schur: lambda is known when the blocks are built, so the landmark's damped inverse and t = Vinv g
+    // (K20's work) follow from the registers -- the same arithmetic on the same words, one launch and one round trip less
+    if (Vinv) schur_landmark<DL>(H, g, 0, lambda, Vinv + (size_t)l * DL * DL, t + (size_t)l * DL, nsing);
 }
 
 struct LbaBlockArgs {
@@ -317,6 +352,10 @@ struct LbaBlockArgs {
     double *H_pt, *g_pt, *H_ls, *g_ls, *pose_part, *H_pose, *g_pose, *err;
     const double* err_part;
     int32_t npt, nls, nkf, np, nb3, nb6, max_chunks, nerr;
+    // the Schur step's landmark inverses in the same launch (Vp = nullptr: not asked for)
+    double lambda = 0.0;
+    double *Vp = nullptr, *tp = nullptr, *Vl = nullptr, *tl = nullptr;
+    int32_t* nsing = nullptr;
 };
 
 __global__ void __launch_bounds__(256)
@@ -324,9 +363,10 @@ k_lba_blocks(const LbaBlockArgs A)
 {
     const int b = blockIdx.x;
     if (b < A.nb3) {
-        landmark_block<3>(b * 256 + (int)threadIdx.x, A.npt, A.pt_ptr, A.pt_ids, A.pJl, A.pr, A.pw, A.H_pt, A.g_pt);
+        landmark_block<3>(b * 256 + (int)threadIdx.x, A.npt, A.pt_ptr, A.pt_ids, A.pJl, A.pr, A.pw, A.H_pt, A.g_pt, A.lambda, A.Vp, A.tp, A.nsing);
     } else if (b < A.nb3 + A.nb6) {
-        landmark_block<6>((b - A.nb3) * 256 + (int)threadIdx.x, A.nls, A.ls_ptr, A.ls_ids, A.lJl, A.lr, A.lw, A.H_ls, A.g_ls);
+        landmark_block<6>((b - A.nb3) * 256 + (int)threadIdx.x, A.nls, A.ls_ptr, A.ls_ids, A.lJl, A.lr, A.lw, A.H_ls, A.g_ls, A.lambda,
+                          A.Vl, A.tl, A.nsing);
     } else {
         // chunk partials of the keyframes (K9): item = keyframe * max_chunks + chunk, one wave per item, lane e < 42 an entry
         const int item = (b - A.nb3 - A.nb6) * 4 + ((int)threadIdx.x >> 6), e = (int)threadIdx.x & 63;
@@ -362,10 +402,13 @@ k_lba_blocks(const LbaBlockArgs A)
     }
 }
 
-__global__ void __launch_bounds__(256)
-k_lba_finish(const LbaBlockArgs A)
+// NT = 256: a lane per partial-sum slot; NT = 64 (inside the Schur partials' launch): a lane plays the four lanes e, e + 64,
+// e + 128, e + 192 of the 256-lane form and adds them as its tree's first two levels do -- the same sums in the same order
+template <int NT>
+__device__ __forceinline__ void lba_finish_wg(const LbaBlockArgs& A, int k, double* __restrict__ red /* [NT] */)
 {
-    const int k = blockIdx.x, e = threadIdx.x;
+    static_assert(NT == 256 || NT == 64, "256 lanes, or 64 lanes playing four each");
+    const int e = threadIdx.x;
     if (k < A.nkf) {
         if (e >= 42) return;
         const int nchunks = (A.kf_ptr[k + 1] - A.kf_ptr[k] + POSE_CHUNK - 1) / POSE_CHUNK;
@@ -384,16 +427,28 @@ k_lba_finish(const LbaBlockArgs A)
         return;
     }
     // err: lane e sums the row workgroups' partials e, e + 256, ... in that order, then a tree over the lanes
-    __shared__ double red[256];
-    double acc = 0.0;
-    for (int i = e; i < A.nerr; i += 256) acc += A.err_part[i];
-    red[e] = acc;
+    constexpr int Q = 256 / NT;
+    double acc[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        acc[q] = 0.0;
+        for (int i = e + q * NT; i < A.nerr; i += 256) acc[q] += A.err_part[i];
+    }
+    if (Q == 4) { acc[0] += acc[2]; acc[1] += acc[3]; acc[0] += acc[1]; }      // the tree's levels 128 and 64
+    red[e] = acc[0];
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
+    for (int s = NT / 2; s > 0; s >>= 1) {
         if (e < s) red[e] += red[e + s];
         __syncthreads();
     }
     if (e == 0) A.err[0] = red[0];
+}
+
+__global__ void __launch_bounds__(256)
+k_lba_finish(const LbaBlockArgs A)
+{
+    __shared__ double red[256];
+    lba_finish_wg<256>(A, (int)blockIdx.x, red);
 }
 
 namespace {
@@ -516,10 +571,11 @@ struct plslam_lba_plan {
     std::vector<int32_t> h_pt_kf, h_ls_kf;
     DevBuf schur;
     HostBuf schur_pin;
+    char* schur_pin_dev = nullptr;   // the device address of schur_pin (mapped page-locked memory), or nullptr: kernels write S, b in place
     bool schur_ready = false, schur_done = false;
     int schur_parity = 0;              // which of the two counters of singular landmarks the next plslam_lba_plan_schur counts in
     int32_t nblk = 0, schur_chunks = 0;
-    size_t oSpair = 0, oSblk = 0, oVp = 0, oVl = 0, oTp = 0, oTl = 0, oSpart = 0, oBpart = 0, oS = 0, oDp = 0, oDx = 0, oSing = 0;
+    size_t oSpair = 0, oSblk = 0, oVp = 0, oVl = 0, oTp = 0, oTl = 0, oSpart = 0, oBpart = 0, oS = 0, oDp = 0, oDx = 0, oDxPart = 0, oSing = 0;
 };
 
 extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, double homog_th, int32_t n_pose_slots,
@@ -601,12 +657,34 @@ extern "C" int plslam_lba_plan_create(plslam_ctx* ctx, const plslam_cam* K, doub
     return PLSLAM_OK;
 }
 
+static LbaBlockArgs lba_block_args(plslam_lba_plan* P)
+{
+    char *ds = P->stat.as<char>(), *dr = P->rows.as<char>(), *dout = P->out.as<char>();
+    const size_t N6 = 6 * (size_t)P->nkf;
+    LbaBlockArgs B{};
+    B.pt_ptr = (int32_t*)(ds + P->oPtp); B.pt_ids = (int32_t*)(ds + P->oPti); B.ls_ptr = (int32_t*)(ds + P->oLsp);
+    B.ls_ids = (int32_t*)(ds + P->oLsi); B.kf_ptr = (int32_t*)(ds + P->oKfp); B.kf_ids = (int32_t*)(ds + P->oKfi);
+    B.pJp = (double*)(dr + P->oPJp); B.pJl = (double*)(dr + P->oPJl); B.pr = (double*)(dr + P->oPr); B.pw = (double*)(dr + P->oPw);
+    B.lJp = (double*)(dr + P->oLJp); B.lJl = (double*)(dr + P->oLJl); B.lr = (double*)(dr + P->oLr); B.lw = (double*)(dr + P->oLw);
+    double* g = (double*)(dout + P->oG);
+    B.H_pt = (double*)(dout + P->oHpt); B.g_pt = g + N6; B.H_ls = (double*)(dout + P->oHls); B.g_ls = g + N6 + 3 * (size_t)P->npt;
+    B.pose_part = (double*)(dout + P->oPart); B.H_pose = (double*)(dout + P->oHp); B.g_pose = g;
+    B.err = (double*)(dout + P->oErr); B.err_part = (double*)(dout + P->oErrPart);
+    B.npt = P->npt; B.nls = P->nls; B.nkf = P->nkf; B.np = P->np;
+    B.nb3 = (P->npt + 255) / 256; B.nb6 = (P->nls + 255) / 256; B.max_chunks = P->max_chunks;
+    B.nerr = (P->np + 255) / 256 + (P->nl + 255) / 256;
+    return B;
+}
+
 // upload X (one copy), rows + cross blocks + err partials (F1), landmark blocks + keyframe chunk partials (F2), keyframe blocks +
 // err (F3): enqueued on the context's stream, nothing downloaded.  Caller holds ctx->mu.
 // upload = false: the poses and landmarks already on the device are used (plslam_lba_plan_iterate_resident: a device-side
 // solver has updated them in place)
+// fused_lambda >= 0 (plslam_lba_plan_iterate_schur; the Schur step's buffers exist): the landmark inverses for that damping are
+// written by the blocks' launch, and the last stage (K10) is NOT launched here -- it rides in the Schur partials' launch
+// (lba_schur_enqueue(fused)), which the caller enqueues next
 static int lba_plan_enqueue(plslam_lba_plan* P, const double* T_kf_w, const double* Xw, const double* Lw, int compat_flags,
-                            bool upload = true)
+                            bool upload = true, double fused_lambda = -1.0)
 {
     plslam_ctx* ctx = P->ctx;
     hipStream_t s = ctx->stream;
@@ -638,20 +716,18 @@ static int lba_plan_enqueue(plslam_lba_plan* P, const double* T_kf_w, const doub
     A.lJp = (double*)(dr + P->oLJp); A.lJl = (double*)(dr + P->oLJl); A.lr = (double*)(dr + P->oLr); A.lw = (double*)(dr + P->oLw);
     A.Wp = (double*)(dout + P->oWp); A.Wl = (double*)(dout + P->oWl); A.err_part = (double*)(dout + P->oErrPart);
     if (nbp + nbl > 0) hipLaunchKernelGGL(k_lba_rows_cross, dim3(nbp + nbl), dim3(256), 0, s, A);
-    LbaBlockArgs B{};
-    B.pt_ptr = (int32_t*)(ds + P->oPtp); B.pt_ids = (int32_t*)(ds + P->oPti); B.ls_ptr = (int32_t*)(ds + P->oLsp);
-    B.ls_ids = (int32_t*)(ds + P->oLsi); B.kf_ptr = (int32_t*)(ds + P->oKfp); B.kf_ids = (int32_t*)(ds + P->oKfi);
-    B.pJp = A.pJp; B.pJl = A.pJl; B.pr = A.pr; B.pw = A.pw; B.lJp = A.lJp; B.lJl = A.lJl; B.lr = A.lr; B.lw = A.lw;
-    double* g = (double*)(dout + P->oG);
-    B.H_pt = (double*)(dout + P->oHpt); B.g_pt = g + N6; B.H_ls = (double*)(dout + P->oHls); B.g_ls = g + N6 + 3 * (size_t)P->npt;
-    B.pose_part = (double*)(dout + P->oPart); B.H_pose = (double*)(dout + P->oHp); B.g_pose = g;
-    B.err = (double*)(dout + P->oErr); B.err_part = A.err_part;
-    B.npt = P->npt; B.nls = P->nls; B.nkf = P->nkf; B.np = P->np;
-    B.nb3 = (P->npt + 255) / 256; B.nb6 = (P->nls + 255) / 256; B.max_chunks = P->max_chunks; B.nerr = nbp + nbl;
+    LbaBlockArgs B = lba_block_args(P);
+    const bool fused = fused_lambda >= 0.0;
+    if (fused) {
+        char* d = P->schur.as<char>();
+        B.lambda = fused_lambda;
+        B.Vp = (double*)(d + P->oVp); B.Vl = (double*)(d + P->oVl); B.tp = (double*)(d + P->oTp); B.tl = (double*)(d + P->oTl);
+        B.nsing = (int32_t*)((double*)(d + P->oS) + N6 * N6 + N6 + 1) + P->schur_parity;
+    }
     const int32_t nchunk_wgs = (P->nkf * P->max_chunks + 3) / 4;
     if (B.nb3 + B.nb6 + nchunk_wgs > 0)
         hipLaunchKernelGGL(k_lba_blocks, dim3(B.nb3 + B.nb6 + nchunk_wgs), dim3(256), 0, s, B);
-    hipLaunchKernelGGL(k_lba_finish, dim3(P->nkf + 1), dim3(256), 0, s, B);
+    if (!fused) hipLaunchKernelGGL(k_lba_finish, dim3(P->nkf + 1), dim3(256), 0, s, B);
     PLSLAM_HIP_CHECK(hipGetLastError());
     P->blocks_valid = true;
     P->blocks_gba = (compat_flags & PLSLAM_LBA_COMPAT_GBA) != 0;
@@ -989,14 +1065,9 @@ k_schur_landmarks(const double* __restrict__ H_pt, const double* __restrict__ g_
 // trip: a first form with a lane per entry walking the chunk was a chain of 64 dependent round trips, 177 us per call at C3),
 // parks it in LDS, and lane e < 36 adds the 64 values of entry e SEQUENTIALLY in pair order -- the same sum, term for term.
 template <int DL>
-__device__ __forceinline__ void schur_pair_block(const double* __restrict__ W1, const double* __restrict__ W2,
-                                                 const double* __restrict__ V, double* __restrict__ out /* [36], stride 1 */)
+__device__ __forceinline__ void schur_pair_product(const double (&w1)[DL * 6], const double (&w2)[DL * 6], const double (&v)[DL * DL],
+                                                   double* __restrict__ out /* [36], stride 1 */)
 {
-    double w1[DL * 6], w2[DL * 6], v[DL * DL];
-#pragma unroll
-    for (int i = 0; i < DL * 6; ++i) { w1[i] = W1[i]; w2[i] = W2[i]; }
-#pragma unroll
-    for (int i = 0; i < DL * DL; ++i) v[i] = V[i];
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
         double u[DL];
@@ -1016,6 +1087,50 @@ __device__ __forceinline__ void schur_pair_block(const double* __restrict__ W1, 
         }
     }
 }
+template <int DL>
+__device__ __forceinline__ void schur_pair_block(const double* __restrict__ W1, const double* __restrict__ W2,
+                                                 const double* __restrict__ V, double* __restrict__ out /* [36], stride 1 */)
+{
+    double w1[DL * 6], w2[DL * 6], v[DL * DL];
+#pragma unroll
+    for (int i = 0; i < DL * 6; ++i) { w1[i] = W1[i]; w2[i] = W2[i]; }
+#pragma unroll
+    for (int i = 0; i < DL * DL; ++i) v[i] = V[i];
+    schur_pair_product<DL>(w1, w2, v, out);
+}
+
+// 64 rows of NE doubles, row r at base + NE * id(r) where lane r holds id(r): fetched by the WAVE in runs (consecutive lanes read
+// consecutive words of a row: 4-8 cache lines per instruction; a lane reading its own row word by word touches 64), parked in
+// the tile, and every lane takes its own row out of it.  One wave per workgroup: the barriers are the wave's own.
+template <int NE>
+__device__ __forceinline__ void gather_rows(double (*tile)[37], const double* __restrict__ base, int id, double (&row_out)[NE])
+{
+    static_assert(NE <= 36, "the tile is 37 doubles wide");
+    const int lane = threadIdx.x;
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    if constexpr (NE % 2 == 0) {
+        constexpr int H = NE / 2;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const int idx = j * 64 + lane, r = idx / H, c2 = idx - r * H;
+            const int rid = __shfl(id, r);
+            const f64x2 v = *reinterpret_cast<const f64x2*>(base + (size_t)rid * NE + 2 * c2);
+            tile[r][2 * c2] = v.x;
+            tile[r][2 * c2 + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int idx = j * 64 + lane, r = idx / NE, c = idx - r * NE;
+            const int rid = __shfl(id, r);
+            tile[r][c] = base[(size_t)rid * NE + c];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) row_out[e] = tile[lane][e];
+    __syncthreads();
+}
 
 __device__ __forceinline__ void
 schur_partials_wg(double (*tile)[37], int B, int c, const SchurPair* __restrict__ pairs, const int32_t* __restrict__ blk_ptr,
@@ -1027,11 +1142,26 @@ schur_partials_wg(double (*tile)[37], int B, int c, const SchurPair* __restrict_
     const int end = beg + SCH_CHUNK < blk_ptr[B + 1] ? beg + SCH_CHUNK : blk_ptr[B + 1];
     const int n = end - beg;                       // <= 0: the block has fewer chunks than the grid is wide
     if (n <= 0) return;
-    if (i < n) {
-        const SchurPair q = pairs[beg + i];
-        double blk[36];
+    const SchurPair q = pairs[beg + (i < n ? i : n - 1)];     // (lanes past the chunk's end replay its last pair: their block is dropped)
+    const int kinds = (__ballot(q.line != 0) != 0 ? 2 : 0) | (__ballot(q.line == 0) != 0 ? 1 : 0);
+    double blk[36];
+    if (kinds == 1) {                              // a chunk of point pairs (the usual case): the wave fetches the rows together
+        double w1[18], w2[18], v[9];
+        gather_rows<18>(tile, W_pt, q.o1, w1);
+        gather_rows<18>(tile, W_pt, q.o2, w2);
+        gather_rows<9>(tile, Vp, q.lm, v);
+        schur_pair_product<3>(w1, w2, v, blk);
+    } else if (kinds == 2) {                       // ... of line pairs
+        double w1[36], w2[36], v[36];
+        gather_rows<36>(tile, W_ls, q.o1, w1);
+        gather_rows<36>(tile, W_ls, q.o2, w2);
+        gather_rows<36>(tile, Vl, q.lm, v);
+        schur_pair_product<6>(w1, w2, v, blk);
+    } else {                                       // the one chunk of a block where its point pairs end and its line pairs begin
         if (!q.line) schur_pair_block<3>(W_pt + (size_t)q.o1 * 18, W_pt + (size_t)q.o2 * 18, Vp + (size_t)q.lm * 9, blk);
         else schur_pair_block<6>(W_ls + (size_t)q.o1 * 36, W_ls + (size_t)q.o2 * 36, Vl + (size_t)q.lm * 36, blk);
+    }
+    if (i < n) {
 #pragma unroll
         for (int e = 0; e < 36; ++e) tile[i][e] = blk[e];
     }
@@ -1110,16 +1240,39 @@ k_schur_partials(SchurPartArgs A)
                             A.n_pt_obs, A.pt_lm, A.ls_lm, A.W_pt, A.W_ls, A.tp, A.tl, A.pose_chunks, A.bpart);
 }
 
+// plslam_lba_plan_iterate_schur: the Schur partials and, behind them in the SAME launch, the iteration's last stage (K10: keyframe
+// blocks and err from their partials) -- the two are independent (the partials read W and the landmark inverses, K22 behind them
+// reads H_pose / g_pose), so the iteration's third launch rides in the Schur step's second
+__global__ void __launch_bounds__(SCH_CHUNK)
+k_schur_partials_lba_finish(SchurPartArgs A, const LbaBlockArgs B, int32_t npart_wgs)
+{
+    __shared__ double tile[SCH_CHUNK][37];
+    const int nS = A.nblk * A.schur_chunks;
+    if ((int)blockIdx.x < nS)
+        schur_partials_wg(tile, (int)blockIdx.x / A.schur_chunks, (int)blockIdx.x % A.schur_chunks, A.pairs, A.blk_ptr, A.W_pt, A.W_ls,
+                          A.Vp, A.Vl, A.schur_chunks, A.spart);
+    else if ((int)blockIdx.x < npart_wgs)
+        schur_b_partials_wg(tile, ((int)blockIdx.x - nS) / A.pose_chunks, ((int)blockIdx.x - nS) % A.pose_chunks, A.kf_ptr, A.kf_obs,
+                            A.n_pt_obs, A.pt_lm, A.ls_lm, A.W_pt, A.W_ls, A.tp, A.tl, A.pose_chunks, A.bpart);
+    else
+        lba_finish_wg<SCH_CHUNK>(B, (int)blockIdx.x - npart_wgs, &tile[0][0]);
+}
+
 // block B = (k1 <= k2) in row-major upper-triangle order; S is (6 nkf) x (6 nkf) row-major, b follows it
 __global__ void __launch_bounds__(64)
 k_schur_finish(const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ kf_ptr, const double* __restrict__ spart,
                const double* __restrict__ bpart, const double* __restrict__ H_pose, const double* __restrict__ g_pose,
                int32_t nkf, int32_t nblk, int32_t schur_chunks, int32_t pose_chunks, double lambda, double* __restrict__ S,
-               double* __restrict__ bvec, int32_t* __restrict__ next_sing)
+               double* __restrict__ bvec, int32_t* __restrict__ next_sing, const double* __restrict__ err_src, double* __restrict__ err_dst,
+               const int32_t* __restrict__ sing_cur, int32_t* __restrict__ sing_out)
 {
     const int B = blockIdx.x, e = threadIdx.x;
     const int n6 = 6 * nkf;
-    if (B == 0 && e == 0) *next_sing = 0;          // the NEXT call's counter of singular landmarks (this call's: the other word)
+    if (B == 0 && e == 0) {
+        *next_sing = 0;                            // the NEXT call's counter of singular landmarks (this call's: the other word)
+        *err_dst = *err_src;                       // the iteration's err beside S and b: plslam_lba_plan_iterate_schur's ONE copy
+        if (sing_out) *sing_out = *sing_cur;       // (S, b written in place in the host's image: this call's counter beside them)
+    }
     if (B < nblk) {
         if (e >= 36) return;
         int k1 = 0, rem = B;                       // B = offset(k1) + (k2 - k1), offset(k1) = sum_{i < k1} (nkf - i)
@@ -1168,7 +1321,8 @@ template <int DL>
 __device__ __forceinline__ void
 schur_backsub_wg(double* __restrict__ sh, int wg, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_obs,
                  const int32_t* __restrict__ kf_loc, int32_t n, const double* __restrict__ W, const double* __restrict__ Vinv,
-                 const double* __restrict__ t, const double* __restrict__ dp, double* __restrict__ dx, double* __restrict__ X)
+                 const double* __restrict__ t, const double* __restrict__ dp, double* __restrict__ dx, double* __restrict__ X,
+                 double* __restrict__ part)
 {
     constexpr int PER_WG = BACK_WG / DL;
     const int q = (int)threadIdx.x / DL, x = (int)threadIdx.x % DL;
@@ -1187,19 +1341,30 @@ schur_backsub_wg(double* __restrict__ sh, int wg, const int32_t* __restrict__ lm
     }
     sh[threadIdx.x] = acc;
     __syncthreads();
-    if (j >= n) return;
-    double s = 0.0;
+    double d = 0.0;
+    if (j < n) {
+        double s = 0.0;
 #pragma unroll
-    for (int y = 0; y < DL; ++y) s += Vinv[(size_t)j * DL * DL + x * DL + y] * sh[q * DL + y];
-    const double d = t[(size_t)j * DL + x] - s;
-    dx[(size_t)j * DL + x] = d;
-    if (X) X[(size_t)j * DL + x] += d;                 // :1570-1575 "update point / line LMs": X(i) += DX(i)
+        for (int y = 0; y < DL; ++y) s += Vinv[(size_t)j * DL * DL + x * DL + y] * sh[q * DL + y];
+        d = t[(size_t)j * DL + x] - s;
+        dx[(size_t)j * DL + x] = d;
+        if (X) X[(size_t)j * DL + x] += d;             // :1570-1575 "update point / line LMs": X(i) += DX(i)
+    }
+    // the workgroup's share of sum DX^2 (the loop's ||DX|| test, :1808), summed in a fixed tree: the same bits on every run
+    __syncthreads();
+    sh[threadIdx.x] = d * d;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w && (int)threadIdx.x + w < BACK_WG) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *part = sh[0];
 }
 
 struct SchurBackArgs {
     const int32_t *pt_ptr, *pt_obs, *pt_kf, *ls_ptr, *ls_obs, *ls_kf;
     const double *W_pt, *W_ls, *Vp, *Vl, *tp, *tl, *dp;
-    double *dx_pt, *dx_ls, *X, *L;                     // X / L = nullptr: do not apply
+    double *dx_pt, *dx_ls, *X, *L, *part;              // X / L = nullptr: do not apply; part: a sum of squares per workgroup
     int32_t npt, nls, nwg_pt;
 };
 __global__ void __launch_bounds__(BACK_WG)
@@ -1207,9 +1372,9 @@ k_schur_backsub(SchurBackArgs A)
 {
     __shared__ double sh[BACK_WG];
     if ((int)blockIdx.x < A.nwg_pt)
-        schur_backsub_wg<3>(sh, (int)blockIdx.x, A.pt_ptr, A.pt_obs, A.pt_kf, A.npt, A.W_pt, A.Vp, A.tp, A.dp, A.dx_pt, A.X);
+        schur_backsub_wg<3>(sh, (int)blockIdx.x, A.pt_ptr, A.pt_obs, A.pt_kf, A.npt, A.W_pt, A.Vp, A.tp, A.dp, A.dx_pt, A.X, A.part + blockIdx.x);
     else
-        schur_backsub_wg<6>(sh, (int)blockIdx.x - A.nwg_pt, A.ls_ptr, A.ls_obs, A.ls_kf, A.nls, A.W_ls, A.Vl, A.tl, A.dp, A.dx_ls, A.L);
+        schur_backsub_wg<6>(sh, (int)blockIdx.x - A.nwg_pt, A.ls_ptr, A.ls_obs, A.ls_kf, A.nls, A.W_ls, A.Vl, A.tl, A.dp, A.dx_ls, A.L, A.part + blockIdx.x);
 }
 
 // max over all diagonal entries of |H(i,i)| (a maximum: exact whatever the order)
@@ -1281,13 +1446,17 @@ static int lba_schur_prepare(plslam_lba_plan* P)
     P->oTp = c.take((size_t)P->npt * 24 + 8); P->oTl = c.take((size_t)P->nls * 48 + 8);
     P->oSpart = c.take((size_t)P->nblk * (size_t)mc * 36 * 8 + 8);
     P->oBpart = c.take((size_t)nkf * (size_t)P->max_chunks * 6 * 8 + 8);
-    P->oS = c.take((n6 * n6 + n6 + 2) * 8 + 16);       // S, then b, then the diagonal maximum, then the singular-block counter
+    P->oS = c.take((n6 * n6 + n6 + 3) * 8 + 16);       // S, then b, then the diagonal maximum, the singular-block counters, err
     P->oDp = c.take(n6 * 8 + 8);
     P->oDx = c.take((3 * (size_t)P->npt + 6 * (size_t)P->nls) * 8 + 8);
+    // (then a partial sum of squares per workgroup of the back-substitution, and their sum)
+    P->oDxPart = c.take(((size_t)(P->npt + BACK_WG / 3 - 1) / (BACK_WG / 3) + (size_t)(P->nls + BACK_WG / 6 - 1) / (BACK_WG / 6) + 2) * 8);
     P->oSing = c.take(8);
     int rc;
-    if ((rc = P->schur.reserve(c.off + 256)) || (rc = P->schur_pin.reserve(std::max((n6 * n6 + n6 + 2) * 8, (3 * (size_t)P->npt + 6 * (size_t)P->nls) * 8) + 256)))
+    if ((rc = P->schur.reserve(c.off + 256)) || (rc = P->schur_pin.reserve(std::max((n6 * n6 + n6 + 3) * 8, (3 * (size_t)P->npt + 6 * (size_t)P->nls) * 8) + n6 * 8 +
+                                                                              ((size_t)P->npt / (BACK_WG / 3) + (size_t)P->nls / (BACK_WG / 6) + 2) * 8 + 256)))
         return rc;
+    P->schur_pin_dev = static_cast<char*>(mapped_device_pointer(P->schur_pin.p));
     hipStream_t s = P->ctx->stream;
     char* d = P->schur.as<char>();
     if (!pairs.empty()) PLSLAM_HIP_CHECK(hipMemcpyAsync(d + P->oSpair, pairs.data(), pairs.size() * sizeof(SchurPair), hipMemcpyHostToDevice, s));
@@ -1322,19 +1491,13 @@ extern "C" int plslam_lba_plan_diag_max(plslam_lba_plan* P, double* hmax)
     return PLSLAM_OK;
 }
 
-extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* S, double* b, int32_t* n_singular)
+// the Schur step's three launches on the blocks of the last iteration (no copy, no synchronisation); *par = the counter word of
+// singular landmarks this call counts in
+static int lba_schur_enqueue(plslam_lba_plan* P, double lambda, int* par_out, bool fused = false)
 {
-    PLSLAM_REQUIRE(P && S && b && lambda >= 0.0, PLSLAM_EINVAL);
-    plslam_ctx* ctx = P->ctx;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    DeviceGuard dg_(ctx->device);
-    PLSLAM_REQUIRE(P->blocks_valid && P->nkf > 0, PLSLAM_EINVAL);
-    // the cross blocks must be the local BA's (landmark rows x pose columns): an iteration run with PLSLAM_LBA_COMPAT_GBA wrote the
-    // pose x line blocks transposed, as the reference's GBA does (:2341-2352) -- a defect this step does not reproduce
-    PLSLAM_REQUIRE(!P->blocks_gba, PLSLAM_EINVAL);
     int rc = lba_schur_prepare(P);
     if (rc) return rc;
-    hipStream_t s = ctx->stream;
+    hipStream_t s = P->ctx->stream;
     char *ds = P->stat.as<char>(), *dout = P->out.as<char>(), *d = P->schur.as<char>();
     const size_t n6 = 6 * (size_t)P->nkf;
     const double* g = (const double*)(dout + P->oG);
@@ -1345,7 +1508,7 @@ extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* 
     int32_t* sing2 = (int32_t*)(dS + n6 * n6 + n6 + 1);
     const int par = P->schur_parity;
     const int32_t nb3 = (P->npt + 255) / 256, nb6 = (P->nls + 255) / 256;
-    if (nb3 + nb6 > 0)
+    if (nb3 + nb6 > 0 && !fused)                          // (fused: the iteration's blocks launch has written them)
         hipLaunchKernelGGL(k_schur_landmarks, dim3(nb3 + nb6), dim3(256), 0, s, (const double*)(dout + P->oHpt), g + n6, P->npt,
                            (const double*)(dout + P->oHls), g + n6 + 3 * (size_t)P->npt, P->nls, nb3, lambda, Vp, tp, Vl, tl, sing2 + par);
     SchurPartArgs A{};
@@ -1356,31 +1519,83 @@ extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* 
     A.spart = (double*)(d + P->oSpart); A.bpart = (double*)(d + P->oBpart);
     A.nblk = P->nblk; A.schur_chunks = P->schur_chunks; A.nkf = P->nkf; A.pose_chunks = P->max_chunks; A.n_pt_obs = P->np;
     const int32_t npart_wgs = P->nblk * P->schur_chunks + P->nkf * P->max_chunks;
-    if (npart_wgs > 0) hipLaunchKernelGGL(k_schur_partials, dim3(npart_wgs), dim3(SCH_CHUNK), 0, s, A);
+    if (fused)
+        hipLaunchKernelGGL(k_schur_partials_lba_finish, dim3(npart_wgs + P->nkf + 1), dim3(SCH_CHUNK), 0, s, A, lba_block_args(P), npart_wgs);
+    else if (npart_wgs > 0) hipLaunchKernelGGL(k_schur_partials, dim3(npart_wgs), dim3(SCH_CHUNK), 0, s, A);
+    // S, b, err and this call's counter: written where the host reads them (the page-locked image, mapped) when it can be -- no
+    // copy behind the kernel; otherwise beside the partials on the device, and lba_schur_fetch copies
+    const bool in_place = P->schur_pin_dev != nullptr;
+    double* oS = in_place ? (double*)P->schur_pin_dev : dS;
     hipLaunchKernelGGL(k_schur_finish, dim3(P->nblk + P->nkf), dim3(64), 0, s, (const int32_t*)(d + P->oSblk), (const int32_t*)(ds + P->oKfp),
                        (const double*)(d + P->oSpart), (const double*)(d + P->oBpart), (const double*)(dout + P->oHp), g, P->nkf, P->nblk,
-                       P->schur_chunks, P->max_chunks, lambda, dS, dS + n6 * n6, sing2 + (par ^ 1));
+                       P->schur_chunks, P->max_chunks, lambda, oS, oS + n6 * n6, sing2 + (par ^ 1), (const double*)(dout + P->oErr),
+                       oS + n6 * n6 + n6 + 2, sing2 + par, in_place ? (int32_t*)(oS + n6 * n6 + n6 + 1) + par : nullptr);
     PLSLAM_HIP_CHECK(hipGetLastError());
     P->schur_parity = par ^ 1;        // (only now: the kernel that clears the other counter is in the stream)
+    *par_out = par;
+    return PLSLAM_OK;
+}
+
+// S, b and the counter behind them: one copy, one synchronisation
+static int lba_schur_fetch(plslam_lba_plan* P, int par, double* S, double* b, int32_t* n_singular, double* err = nullptr)
+{
+    hipStream_t s = P->ctx->stream;
+    const size_t n6 = 6 * (size_t)P->nkf;
+    double* dS = (double*)(P->schur.as<char>() + P->oS);
     char* ho = P->schur_pin.as<char>();
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, dS, (n6 * n6 + n6 + 2) * 8, hipMemcpyDeviceToHost, s));
+    if (!P->schur_pin_dev) PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, dS, (n6 * n6 + n6 + 3) * 8, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     memcpy(S, ho, n6 * n6 * 8);
     memcpy(b, ho + n6 * n6 * 8, n6 * 8);
     if (n_singular) memcpy(n_singular, ho + (n6 * n6 + n6 + 1) * 8 + 4 * par, 4);
+    if (err) memcpy(err, ho + (n6 * n6 + n6 + 2) * 8, 8);
     P->schur_done = true;
     return PLSLAM_OK;
 }
 
-extern "C" int plslam_lba_plan_backsub(plslam_lba_plan* P, const double* dpose, int apply, double* dX_pt, double* dX_ls)
+extern "C" int plslam_lba_plan_schur(plslam_lba_plan* P, double lambda, double* S, double* b, int32_t* n_singular)
 {
-    PLSLAM_REQUIRE(P && dpose, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(P && S && b && lambda >= 0.0, PLSLAM_EINVAL);
     plslam_ctx* ctx = P->ctx;
     std::lock_guard<std::mutex> lk(ctx->mu);
     DeviceGuard dg_(ctx->device);
-    PLSLAM_REQUIRE(P->schur_done, PLSLAM_EINVAL);          // plslam_lba_plan_schur on the blocks of the last iteration first
-    PLSLAM_REQUIRE(!apply || P->state_valid, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(P->blocks_valid && P->nkf > 0, PLSLAM_EINVAL);
+    // the cross blocks must be the local BA's (landmark rows x pose columns): an iteration run with PLSLAM_LBA_COMPAT_GBA wrote the
+    // pose x line blocks transposed, as the reference's GBA does (:2341-2352) -- a defect this step does not reproduce
+    PLSLAM_REQUIRE(!P->blocks_gba, PLSLAM_EINVAL);
+    int par = 0;
+    int rc = lba_schur_enqueue(P, lambda, &par);
+    if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+    return lba_schur_fetch(P, par, S, b, n_singular);
+}
+
+// One LM iteration's device half in ONE call and ONE synchronisation (round 6): H, g, err on the RESIDENT state
+// (plslam_lba_plan_iterate_resident) and, straight behind it, the Schur step for `lambda` (plslam_lba_plan_schur) -- the
+// reference's :1587-1783 for a lambda the caller already knows (every iteration but the first, whose lambda needs Hmax).
+extern "C" int plslam_lba_plan_iterate_schur(plslam_lba_plan* P, int compat_flags, double lambda, double* err, double* S, double* b,
+                                             int32_t* n_singular)
+{
+    PLSLAM_REQUIRE(P && err && S && b && lambda >= 0.0, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(!(compat_flags & PLSLAM_LBA_COMPAT_GBA), PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
+    PLSLAM_REQUIRE(P->state_valid && P->nkf > 0, PLSLAM_EINVAL);
     hipStream_t s = ctx->stream;
+    // four launches for the iteration and its Schur step: rows + cross blocks | landmark blocks AND their damped inverses, keyframe
+    // chunk partials | Schur partials AND the keyframe blocks + err | S, b (+ err beside them); the separate calls make seven
+    int rc = lba_schur_prepare(P);
+    if (!rc) rc = lba_plan_enqueue(P, nullptr, nullptr, nullptr, compat_flags, false, lambda);
+    int par = 0;
+    if (!rc) rc = lba_schur_enqueue(P, lambda, &par, true);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    return lba_schur_fetch(P, par, S, b, n_singular, err);    // (err rides behind S and b: k_schur_finish put it there)
+}
+
+// dp up, the back-substitution (and the landmark update when `apply`) into the stream; no synchronisation
+static int lba_backsub_enqueue(plslam_lba_plan* P, const double* dpose, int apply, double* part_out = nullptr)
+{
+    hipStream_t s = P->ctx->stream;
     char *ds = P->stat.as<char>(), *dd = P->dyn.as<char>(), *dout = P->out.as<char>(), *d = P->schur.as<char>();
     const size_t n6 = 6 * (size_t)P->nkf;
     char* hp = P->schur_pin.as<char>();
@@ -1393,13 +1608,29 @@ extern "C" int plslam_lba_plan_backsub(plslam_lba_plan* P, const double* dpose, 
     A.ls_ptr = (const int32_t*)(ds + P->oLsp); A.ls_obs = (const int32_t*)(ds + P->oLsi); A.ls_kf = (const int32_t*)(ds + P->oLkf);
     A.W_pt = (const double*)(dout + P->oWp); A.W_ls = (const double*)(dout + P->oWl);
     A.Vp = (const double*)(d + P->oVp); A.Vl = (const double*)(d + P->oVl); A.tp = (const double*)(d + P->oTp); A.tl = (const double*)(d + P->oTl);
-    A.dp = ddp; A.dx_pt = dx; A.dx_ls = dx + 3 * (size_t)P->npt;
+    A.dp = ddp; A.dx_pt = dx; A.dx_ls = dx + 3 * (size_t)P->npt; A.part = part_out ? part_out : (double*)(d + P->oDxPart);
     A.X = apply ? (double*)(dd + P->oX) : nullptr; A.L = apply ? (double*)(dd + P->oL) : nullptr;
     A.npt = P->npt; A.nls = P->nls; A.nwg_pt = (P->npt + BACK_WG / 3 - 1) / (BACK_WG / 3);
     const int32_t nwg = A.nwg_pt + (P->nls + BACK_WG / 6 - 1) / (BACK_WG / 6);
     if (nwg > 0) hipLaunchKernelGGL(k_schur_backsub, dim3(nwg), dim3(BACK_WG), 0, s, A);
     PLSLAM_HIP_CHECK(hipGetLastError());
     if (apply) P->schur_done = false;                      // (a second application of the same step would be a bug of the caller)
+    return PLSLAM_OK;
+}
+
+extern "C" int plslam_lba_plan_backsub(plslam_lba_plan* P, const double* dpose, int apply, double* dX_pt, double* dX_ls)
+{
+    PLSLAM_REQUIRE(P && dpose, PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
+    PLSLAM_REQUIRE(P->schur_done, PLSLAM_EINVAL);          // plslam_lba_plan_schur on the blocks of the last iteration first
+    PLSLAM_REQUIRE(!apply || P->state_valid, PLSLAM_EINVAL);
+    hipStream_t s = ctx->stream;
+    int rc = lba_backsub_enqueue(P, dpose, apply);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    char* hp = P->schur_pin.as<char>();
+    const double* dx = (const double*)(P->schur.as<char>() + P->oDx);
     if (dX_pt || dX_ls) {
         const size_t bytes = (3 * (size_t)P->npt + 6 * (size_t)P->nls) * 8;
         if (bytes) PLSLAM_HIP_CHECK(hipMemcpyAsync(hp, dx, bytes, hipMemcpyDeviceToHost, s));
@@ -1408,6 +1639,44 @@ extern "C" int plslam_lba_plan_backsub(plslam_lba_plan* P, const double* dpose, 
         if (dX_ls && P->nls) memcpy(dX_ls, hp + (size_t)P->npt * 24, (size_t)P->nls * 48);
     } else {
         PLSLAM_HIP_CHECK(hipStreamSynchronize(s));         // (the page-locked image of dp is the caller's to rewrite next)
+    }
+    return PLSLAM_OK;
+}
+
+// The rest of an LM iteration in ONE call and ONE synchronisation (round 6): the back-substitution of `dpose` (and X(i) += DX(i)
+// when `apply`, :1570-1575 / :1801-1806), the pose slots for the next iteration (T_kf_w: n_slots x 16 or NULL to leave them --
+// a rejected step), and sum_i DX_landmark(i)^2 for the loop's ||DX|| test (:1808) -- 8 bytes come back instead of the steps.
+extern "C" int plslam_lba_plan_apply_step(plslam_lba_plan* P, const double* dpose, const double* T_kf_w, int apply, double* dx_sumsq)
+{
+    PLSLAM_REQUIRE(P && dpose, PLSLAM_EINVAL);
+    plslam_ctx* ctx = P->ctx;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    DeviceGuard dg_(ctx->device);
+    PLSLAM_REQUIRE(P->schur_done, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(P->state_valid || (!apply && !T_kf_w), PLSLAM_EINVAL);
+    hipStream_t s = ctx->stream;
+    // (the per-workgroup sums of squares: written in place behind dp's image when the image is mapped)
+    const size_t n6 = 6 * (size_t)P->nkf;
+    const bool in_place = dx_sumsq && P->schur_pin_dev;
+    int rc = lba_backsub_enqueue(P, dpose, apply, in_place ? (double*)(P->schur_pin_dev + n6 * 8) : nullptr);
+    if (rc) { (void)hipStreamSynchronize(s); return rc; }
+    if (T_kf_w && P->n_slots) {
+        char* hi = P->pin_in.as<char>();
+        memcpy(hi + P->oT, T_kf_w, (size_t)P->n_slots * 128);
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(P->dyn.as<char>() + P->oT, hi + P->oT, (size_t)P->n_slots * 128, hipMemcpyHostToDevice, s));
+    }
+    char* hp = P->schur_pin.as<char>();
+    // the back-substitution left one sum of squares per workgroup (220 at C3): they come down and are added here in workgroup
+    // order -- a fixed order, and no launch for it
+    const size_t nwg = (size_t)(P->npt + BACK_WG / 3 - 1) / (BACK_WG / 3) + (size_t)(P->nls + BACK_WG / 6 - 1) / (BACK_WG / 6);
+    if (dx_sumsq && nwg && !in_place)
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(hp + n6 * 8, P->schur.as<char>() + P->oDxPart, nwg * 8, hipMemcpyDeviceToHost, s));
+    PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+    if (dx_sumsq) {
+        const double* part = (const double*)(hp + n6 * 8);
+        double acc = 0.0;
+        for (size_t i = 0; i < nwg; ++i) acc += part[i];
+        *dx_sumsq = acc;
     }
     return PLSLAM_OK;
 }

@@ -82,6 +82,34 @@ __device__ __forceinline__ void wave_store_rows(double* __restrict__ gbase /* ro
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same for a PART of a wider row: every lane holds NW (even) doubles that belong at columns [col0, col0 + NW) of its row of
+// STRIDE doubles (gbase = row 0 of this wave, column col0; 16-byte aligned).  The slab streams out in runs of NW doubles: 8 * NW
+// contiguous bytes per row instead of one 8-byte store per lane and column.
+template <int NW, int STRIDE>
+__device__ __forceinline__ void wave_store_row_parts(double* __restrict__ gbase, const double (&v)[NW], double* __restrict__ slab,
+                                                     int lane, int valid)
+{
+    static_assert(NW % 2 == 0 && STRIDE % 2 == 0, "double2 chunks");
+#pragma unroll
+    for (int c = 0; c < NW; ++c) slab[lane * NW + c] = v[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const int total2 = valid * (NW / 2);
+    const f64x2* s2 = reinterpret_cast<const f64x2*>(slab);
+    f64x2* g2 = reinterpret_cast<f64x2*>(gbase);
+#pragma unroll
+    for (int k = 0; k < NW / 2; ++k) {
+        const int i = k * 64 + lane;
+        if (i < total2) {
+            const int row = i / (NW / 2), c2 = i - row * (NW / 2);
+            __builtin_nontemporal_store(s2[i], g2 + (size_t)row * (STRIDE / 2) + c2);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // One point row (src/mapHandler.cpp:1358-1407): J_pose (6), J_lm (3), r, w from the keyframe's pose T (row-major 4x4), the
 // landmark Xw and the observation ob.
 __device__ __forceinline__ void point_row(const CamD& K, double th, const double* __restrict__ T, const double* __restrict__ X,

@@ -231,6 +231,28 @@ public:
         check(plslam_lba_plan_backsub(plan_, dp.data(), apply ? 1 : 0, dX_pt ? dX_pt->data() : nullptr, dX_ls ? dX_ls->data() : nullptr),
               "plslam_lba_plan_backsub");
     }
+    // An LM iteration in two calls and two synchronisations (round 6; what optimize() runs):
+    //   iterateSchur: H, g, err on the RESIDENT state, the Schur step for `lambda` behind it, the dense LDL^T here -> dp (6 Nkf);
+    //   applyStep: the back-substitution of dp (+ X(i) += DX(i) when apply), the pose slots for the next iteration (T_kf_w, or
+    //   nullptr to leave them: a rejected step) -> sum of squares of the landmark steps (for ||DX||, :1808)
+    double iterateSchur(double lambda, bool iteration_pass, std::vector<double>& dp, int32_t* n_singular = nullptr)
+    {
+        const size_t n = 6 * (size_t)nkf_;
+        S_.resize(n * n); dp.resize(n);
+        double err = 0;
+        check(plslam_lba_plan_iterate_schur(plan_, iteration_pass ? PLSLAM_LBA_COMPAT_ITER_PASS : 0, lambda, &err, S_.data(), dp.data(),
+                                            n_singular), "plslam_lba_plan_iterate_schur");
+        ldlt_solve(S_, dp, (int)n);
+        return err;
+    }
+    double applyStep(const std::vector<double>& dp, const std::vector<double>* T_kf_w, bool apply)
+    {
+        if (dp.size() != 6 * (size_t)nkf_ || (T_kf_w && T_kf_w->size() != (size_t)nslots_ * 16))
+            throw std::runtime_error("[LbaPlanSolver::applyStep] dp: 6 doubles per optimised key frame; T_kf_w: one 4 x 4 per pose slot");
+        double s2 = 0;
+        check(plslam_lba_plan_apply_step(plan_, dp.data(), T_kf_w ? T_kf_w->data() : nullptr, apply ? 1 : 0, &s2), "plslam_lba_plan_apply_step");
+        return s2;
+    }
     void setPoses(const std::vector<double>& T_kf_w)        // n_slots x 16, after T <- T inv(exp(dp)) on the host
     {
         if (T_kf_w.size() != (size_t)nslots_ * 16) throw std::runtime_error("[LbaPlanSolver::setPoses] one 4 x 4 per pose slot");
@@ -284,11 +306,11 @@ public:
         LmTrace local;
         LmTrace& tr = trace ? *trace : local;
         tr = LmTrace();
-        std::vector<double> dp, dXp, dXl;
+        std::vector<double> dp;
         auto set_estimates = [&]() {                                  // slot first_estimate_slot + k <- expmap(X_k)
             for (int32_t k = 0; k < nkf_; ++k) maps.expmap(&x_kf[6 * (size_t)k], &p.poses_T_kf_w[16 * (size_t)(first_estimate_slot + k)]);
         };
-        auto update_poses = [&]() {                                   // :1560-1566
+        auto update_poses = [&]() {                                   // :1560-1566 (the matrices go up with the step)
             double Tprev[16], Tinc[16], Tinv[16], Tcur[16];
             for (int32_t k = 0; k < nkf_; ++k) {
                 maps.expmap(&x_kf[6 * (size_t)k], Tprev);
@@ -303,41 +325,45 @@ public:
                 maps.logmap(Tcur, &x_kf[6 * (size_t)k]);
             }
             set_estimates();
-            setPoses(p.poses_T_kf_w);
-        };
-        auto step_norm = [&]() {                                      // DX.norm() over all N unknowns (:1808)
-            double s2 = 0.0;
-            for (double v : dp) s2 += v * v;
-            for (double v : dXp) s2 += v * v;
-            for (double v : dXl) s2 += v * v;
-            return std::sqrt(s2);
         };
         // ---- first pass ----
         set_estimates();
         double err = iterate(p, false) / n_obs_counted;
         double lambda = prm.lambda_lba_lm * diagMax();
         int32_t nsing = 0;
-        solveStep(lambda, dp, true, &dXp, &dXl, &nsing);
+        const size_t n6 = 6 * (size_t)nkf_;
+        S_.resize(n6 * n6); dp.resize(n6);
+        check(plslam_lba_plan_schur(plan_, lambda, S_.data(), dp.data(), &nsing), "plslam_lba_plan_schur");
+        ldlt_solve(S_, dp, (int)n6);
         tr.n_singular += nsing;
         update_poses();
+        check(plslam_lba_plan_apply_step(plan_, dp.data(), p.poses_T_kf_w.data(), 1, nullptr), "plslam_lba_plan_apply_step");
         tr.err.push_back(err); tr.lambda.push_back(lambda); tr.applied.push_back(1);
         double err_prev = err;
         // ---- LM iterations ----
         int iters;
+        // an iteration = two calls, two synchronisations: [H, g, err + Schur step] -> dense LDL^T here -> [back-substitution,
+        // landmark update, pose slots, sum DX^2].  (The Schur step of the build that stops at the first test is computed and unused.)
         for (iters = 1; iters < prm.max_iters_lba; ++iters) {
-            err = iterateResident(true) / n_lm;
+            check(plslam_lba_plan_iterate_schur(plan_, PLSLAM_LBA_COMPAT_ITER_PASS, lambda, &err, S_.data(), dp.data(), &nsing),
+                  "plslam_lba_plan_iterate_schur");     // (iterateSchur() without the solve: the first stop test comes before it)
+            err /= n_lm;
             tr.err.push_back(err);
             if (std::fabs(err - err_prev) < prm.min_error_change || err < prm.min_error) {
                 tr.lambda.push_back(0.0); tr.applied.push_back(-1); tr.stop = 1;
                 break;
             }
             const bool reject = err > err_prev;
-            solveStep(lambda, dp, !reject, &dXp, &dXl, &nsing);
+            ldlt_solve(S_, dp, (int)n6);
             tr.n_singular += nsing;
             tr.lambda.push_back(lambda); tr.applied.push_back(reject ? 0 : 1);
             if (reject) lambda /= prm.lambda_lba_k;
             else { lambda *= prm.lambda_lba_k; update_poses(); }
-            if (step_norm() < prm.min_error_change) { tr.stop = 2; break; }
+            double s2 = 0.0, s2_lm = 0.0;
+            for (double v : dp) s2 += v * v;
+            check(plslam_lba_plan_apply_step(plan_, dp.data(), reject ? nullptr : p.poses_T_kf_w.data(), reject ? 0 : 1, &s2_lm),
+                  "plslam_lba_plan_apply_step");
+            if (std::sqrt(s2 + s2_lm) < prm.min_error_change) { tr.stop = 2; break; }      // ||DX|| over all N unknowns (:1808)
             err_prev = err;
         }
         tr.iters = iters;

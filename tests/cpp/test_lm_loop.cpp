@@ -4,9 +4,14 @@
 // stvo-pl's SE(3) maps are not in the reference tree: the checker's restatements (oracle/plslam_oracle.c) stand in for them here,
 // exactly as they do inside the fixture's generator.
 // usage: test_lm_loop <problem.bin> <result.bin>
+//        test_lm_loop <problem.bin> --time <reps>      one LM iteration with state and blocks resident, host to host, as optimize()
+//                                                      runs it (iterateSchur + applyStep without the update): microseconds, printed
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "../../oracle/plslam_oracle.h"
@@ -23,7 +28,10 @@ static void wr(FILE* f, const std::vector<T>& v) { if (!v.empty()) fwrite(v.data
 
 int main(int argc, char** argv)
 {
-    if (argc != 3) { std::fprintf(stderr, "usage: %s <problem.bin> <result.bin>\n", argv[0]); return 2; }
+    if (argc != 3 && !(argc == 4 && std::string(argv[2]) == "--time")) {
+        std::fprintf(stderr, "usage: %s <problem.bin> <result.bin> | <problem.bin> --time <reps>\n", argv[0]);
+        return 2;
+    }
     FILE* f = fopen(argv[1], "rb");
     if (!f) { std::perror(argv[1]); return 2; }
     std::vector<int32_t> hdr;
@@ -58,12 +66,33 @@ int main(int argc, char** argv)
     plslam_cam cam{};
     cam.fx = cam4[0]; cam.fy = cam4[1]; cam.cx = cam4[2]; cam.cy = cam4[3];
     int rc = 0;
+    bool timed = false;
     try {
         PLSLAM::LbaPlanSolver::LmParams prm;
         prm.lambda_lba_lm = cfg[1]; prm.lambda_lba_k = cfg[2]; prm.max_iters_lba = (int)cfg[3];
         prm.min_error_change = cfg[4]; prm.min_error = cfg[5];
         const PLSLAM::LbaPlanSolver::Se3Maps maps = {plo_expmap_se3, plo_logmap_se3, plo_inverse_se3};
         const std::vector<double> Xw0 = p.points, Lw0 = p.lines;
+        if (argc == 4) {
+            PLSLAM::LbaPlanSolver solver(ctx, cam, cfg[0], p);
+            const int reps = std::atoi(argv[3]);
+            for (int k = 0; k < nkf; ++k) plo_expmap_se3(&x_kf[6 * (size_t)k], &p.poses_T_kf_w[16 * (size_t)(n_kf_map + k)]);
+            solver.iterate(p, false);
+            const double lambda = 1e-5 * solver.diagMax();
+            std::vector<double> dp, us;
+            for (int it = 0; it < reps + 10; ++it) {
+                const auto t0 = std::chrono::steady_clock::now();
+                solver.iterateSchur(lambda, true, dp);
+                solver.applyStep(dp, nullptr, false);
+                const auto t1 = std::chrono::steady_clock::now();
+                if (it >= 10) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+            }
+            std::sort(us.begin(), us.end());
+            std::printf("LM iteration resident: median %.1f us, p10 %.1f, p90 %.1f over %d\n", us[us.size() / 2], us[us.size() / 10],
+                        us[us.size() * 9 / 10], reps);
+            timed = true;
+        }
+        if (timed) { plslam_ctx_destroy(ctx); return 0; }     // (the solver has died first: its plan belongs to the context)
         PLSLAM::LbaPlanSolver solver(ctx, cam, cfg[0], p);
         PLSLAM::LbaPlanSolver::LmTrace tr;
         solver.optimize(p, x_kf, n_kf_map, prm, maps, &tr);

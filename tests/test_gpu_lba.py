@@ -610,3 +610,60 @@ def test_schur_step_edge_shapes(ctx, oracle, n_kf, n_pt, n_ls, obs):
     got = np.concatenate([dp, dxp.reshape(-1), dxl.reshape(-1)])
     assert np.allclose(got, DX, rtol=0, atol=1e-7 * np.abs(DX).max()), np.abs(got - DX).max() / np.abs(DX).max()
     plan.close()
+
+
+def test_fused_iteration_calls_equal_the_separate_ones(ctx):
+    """plslam_lba_plan_iterate_schur / _apply_step (round 6): an LM iteration in two calls and two synchronisations.  Two plans
+    on the same map run three iterations, one through iterate_resident + schur + backsub + set_poses, the other through the
+    fused calls: the same words for err, S, b, the resident landmarks after each step, and the sum of squares of the landmark
+    steps equal to numpy's on the downloaded steps (to rounding: the device sums in a tree).  A rejected step (apply = False,
+    poses left) changes nothing resident; a step applied twice and blocks written the GBA way are refused."""
+    lm = synth.local_map(n_kf=6, n_pt=700, n_ls=150, obs_per_lm=4, seed=23)
+    cam, _ = _cams()
+    nkf, npt, nls = 5, 700, 150
+    pkf, lkf = lm["pt_kf"] - 1, lm["ls_kf"] - 1
+    T, X, L = lm["T_kf_w"].copy(), lm["Xw"].copy(), lm["Lw"].copy()
+    mk = lambda: plslam_amd.LbaPlan(ctx, cam, 1e-7, 6, nkf, npt, nls, lm["pt_lm"], lm["pt_kf"], pkf, lm["obs_uv"],
+                                    lm["ls_lm"], lm["ls_kf"], lkf, lm["l_obs"])
+    a, f = mk(), mk()
+    with pytest.raises(plslam_amd.PlslamError):
+        f.iterate_schur(1e-3)                               # no resident state yet
+    a.iterate_dev(T, X, L, want_g=False)
+    f.iterate_dev(T, X, L, want_g=False)
+    lam, Tcur = 1e-3, T.copy()
+    for it in range(3):
+        flags = plslam_amd.LbaPlan.COMPAT_ITER_PASS if it else 0
+        e_a = a.iterate_resident(flags)
+        S_a, b_a, ns_a = a.schur(lam)
+        e_f, S_f, b_f, ns_f = f.iterate_schur(lam, flags)
+        assert e_a == e_f and ns_a == ns_f and np.array_equal(S_a, S_f) and np.array_equal(b_a, b_f), it
+        dp = np.linalg.solve(S_a, b_a)
+        apply = it != 1                                     # the middle step is "rejected"
+        dxp, dxl = a.backsub(dp, apply=apply)
+        Tn = None
+        if apply:
+            Tn = Tcur.copy()
+            for k in range(nkf):
+                Tn[k + 1] = (Tcur[k + 1].reshape(4, 4) @ np.linalg.inv(synth.se3_exp(dp[6 * k:6 * k + 6]))).reshape(16)
+            a.set_poses(Tn)
+            Tcur = Tn
+        ss = f.apply_step(dp, Tn, apply=apply)
+        want = float((dxp ** 2).sum() + (dxl ** 2).sum())
+        assert abs(ss - want) <= 1e-13 * want, (ss, want)
+        Xa, La = a.get_landmarks()
+        Xf, Lf = f.get_landmarks()
+        assert np.array_equal(Xa, Xf) and np.array_equal(La, Lf), it
+        if apply:
+            with pytest.raises(plslam_amd.PlslamError):
+                f.apply_step(dp, Tn)                        # applied: a new Schur step is needed
+        lam *= 10.0
+    assert a.iterate_resident(plslam_amd.LbaPlan.COMPAT_ITER_PASS) == f.iterate_resident(plslam_amd.LbaPlan.COMPAT_ITER_PASS)
+    with pytest.raises(plslam_amd.PlslamError):
+        f.iterate_schur(lam, plslam_amd.LbaPlan.COMPAT_GBA)
+    # determinism of the sum: the same step again -> the same word
+    e1, S1, b1, _ = f.iterate_schur(lam, 0)
+    dp = np.linalg.solve(S1, b1)
+    s1 = f.apply_step(dp, None, apply=False)
+    s2 = f.apply_step(dp, None, apply=False)
+    assert s1 == s2
+    a.close(); f.close()

@@ -110,3 +110,41 @@ def test_lm_loop_equals_the_references_own_text(tmp_path, name):
     ml = np.linalg.norm(Xref[6 * nkf + 3 * npt:].reshape(-1, 6) - g[f"{name}_Lw"], axis=1) > 0.01 if nls else np.zeros(0, bool)
     # (a landmark within 1e-9 of the threshold could flip; none is in these fixtures)
     assert np.array_equal(got["moved_p"].astype(bool), mp) and np.array_equal(got["moved_l"].astype(bool), ml)
+
+
+@pytest.mark.gpu
+def test_resident_iteration_time_at_c3_native(tmp_path):
+    """One LM iteration at the C3 map (9 optimised key frames, 10 000 points, 2 000 lines, 60 000 observations) as
+    LbaPlanSolver::optimize runs it -- plslam_lba_plan_iterate_schur + the host's 54 x 54 LDL^T + plslam_lba_plan_apply_step --
+    timed host to host from C++ (no interpreter in the loop).  Written to gpurun_out/lm_iteration_native.json; the bound here is
+    a loose one against a regression to per-kernel synchronisation, not the target."""
+    import json
+    import re
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as O
+    from plslam_amd import synth
+    lm = synth.local_map()
+    n_kf_map = lm["T_kf_w"].shape[0]
+    x = np.stack([O.logmap_se3(T) for T in lm["T_kf_w"].reshape(-1, 4, 4)])
+    g = {"cfg": np.array([1e-7, 1e-5, 10.0, 15, 1e-7, 1e-7]), "c3_nkf": n_kf_map - 1, "c3_n_kf_map": n_kf_map,
+         "c3_T_map": lm["T_kf_w"], "c3_x_kf": x[1:].reshape(-1), "c3_Xw": lm["Xw"], "c3_Lw": lm["Lw"],
+         "c3_pt_lm": lm["pt_lm"], "c3_pt_kf_map": lm["pt_kf"], "c3_pt_kf_loc": lm["pt_kf"] - 1, "c3_pt_uv": lm["obs_uv"],
+         "c3_ls_lm": lm["ls_lm"], "c3_ls_kf_map": lm["ls_kf"], "c3_ls_kf_loc": lm["ls_kf"] - 1, "c3_ls_l": lm["l_obs"]}
+    exe = _compile(str(tmp_path))
+    prob = str(tmp_path / "c3.bin")
+    nkf, npt, nls = _write_problem(prob, g, "c3")
+    assert (nkf, npt, nls) == (9, 10000, 2000)
+    r = subprocess.run([exe, prob, "--time", "300"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-2000:]
+    m = re.search(r"median ([0-9.]+) us, p10 ([0-9.]+), p90 ([0-9.]+)", r.stdout)
+    assert m, r.stdout
+    med, p10, p90 = (float(v) for v in m.groups())
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "lm_iteration_native.json"), "w") as f:
+        json.dump({"what": "one LM iteration, state and blocks resident, C3 sizes, C++ host to host: plslam_lba_plan_iterate_schur + "
+                           "dense LDL^T of the 54 x 54 reduced system + plslam_lba_plan_apply_step (no update)",
+                   "us_median": med, "us_p10": p10, "us_p90": p90, "reps": 300}, f)
+    print(r.stdout.strip())
+    assert med < 400.0

@@ -26,12 +26,17 @@ if len(sys.argv) > 2 and sys.argv[2] == "schur":
         plan.iterate_resident()
         S, b, _ = plan.schur(lam)
         plan.backsub(np.linalg.solve(S, b), apply=False, want=False)
+    def it2():
+        _, S, b, _n = plan.iterate_schur(lam)
+        plan.apply_step(np.linalg.solve(S, b), None, apply=False)
+    if len(sys.argv) > 3 and sys.argv[3] == "two":
+        it = it2
     for _ in range(5):
         it()
     t0 = time.perf_counter()
     for _ in range(reps):
         it()
-    print(f"LM iteration, state and blocks resident (iterate_resident + schur + 54 x 54 solve + backsub): "
+    print(f"LM iteration, state and blocks resident ({'iterate_schur + 54 x 54 solve + apply_step' if it is it2 else 'iterate_resident + schur + 54 x 54 solve + backsub'}): "
           f"{1e6 * (time.perf_counter() - t0) / reps:.1f} us per iteration over {reps}")
     plan.close()
     sys.exit(0)
