@@ -296,14 +296,20 @@ template <int DL>
 __device__ __forceinline__ void schur_landmark(const double* __restrict__ H, const double* __restrict__ g, int j, double lambda,
                                                double* __restrict__ Vinv, double* __restrict__ t, int32_t* __restrict__ nsing);
 
+// One lane per landmark, 64 landmarks per workgroup (a wave: the 2 000 lines of C3 were 8 workgroups of 256 on 8 CUs).  The blocks
+// leave through an LDS slab in runs (wave_store_rows): a lane storing its own 36 doubles word by word is 36 instructions of 64
+// scattered 8-byte stores.  Lanes past the last landmark replay it and store nothing.
 template <int DL>
-__device__ __forceinline__ void landmark_block(int l, int32_t nlm, const int32_t* __restrict__ lm_ptr, const int32_t* __restrict__ lm_obs,
-                                               const double* __restrict__ Jl, const double* __restrict__ r, const double* __restrict__ w,
-                                               double* __restrict__ Hll, double* __restrict__ gl, double lambda = 0.0,
-                                               double* __restrict__ Vinv = nullptr, double* __restrict__ t = nullptr,
-                                               int32_t* __restrict__ nsing = nullptr)
+__device__ __forceinline__ void landmark_block(int l0 /* the wave's first landmark */, int32_t nlm, const int32_t* __restrict__ lm_ptr,
+                                               const int32_t* __restrict__ lm_obs, const double* __restrict__ Jl,
+                                               const double* __restrict__ r, const double* __restrict__ w, double* __restrict__ Hll,
+                                               double* __restrict__ gl, double* __restrict__ slab /* [64 * DL * DL] */, double lambda,
+                                               double* __restrict__ Vinv, double* __restrict__ t, int32_t* __restrict__ nsing)
 {
-    if (l >= nlm) return;
+    const int lane = threadIdx.x;
+    const int valid = nlm - l0 < 64 ? nlm - l0 : 64;
+    const bool live = lane < valid;
+    const int l = live ? l0 + lane : nlm - 1;
     double H[DL * DL], g[DL];
 #pragma unroll
     for (int i = 0; i < DL * DL; ++i) H[i] = 0.0;
@@ -337,13 +343,16 @@ __device__ __forceinline__ void landmark_block(int l, int32_t nlm, const int32_t
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < DL * DL; ++i) Hll[(size_t)l * DL * DL + i] = H[i];
-#pragma unroll
-    for (int i = 0; i < DL; ++i) gl[(size_t)l * DL + i] = g[i];
+    wave_store_rows<DL * DL>(Hll + (size_t)l0 * DL * DL, H, slab, lane, valid);
+    wave_store_rows<DL>(gl + (size_t)l0 * DL, g, slab, lane, valid);
     // plslam_lba_plan_iterate_schur: lambda is known when the blocks are built, so the landmark's damped inverse and t = Vinv g
     // (K20's work) follow from the registers -- the same arithmetic on the same words, one launch and one round trip less
-    if (Vinv) schur_landmark<DL>(H, g, 0, lambda, Vinv + (size_t)l * DL * DL, t + (size_t)l * DL, nsing);
+    if (Vinv) {                                                  // (kernel argument: uniform)
+        double Vo[DL * DL], to[DL];
+        schur_landmark<DL>(H, g, 0, lambda, Vo, to, live ? nsing : nullptr);
+        wave_store_rows<DL * DL>(Vinv + (size_t)l0 * DL * DL, Vo, slab, lane, valid);
+        wave_store_rows<DL>(t + (size_t)l0 * DL, to, slab, lane, valid);
+    }
 }
 
 struct LbaBlockArgs {
@@ -361,15 +370,19 @@ struct LbaBlockArgs {
 __global__ void __launch_bounds__(256)
 k_lba_blocks(const LbaBlockArgs A)
 {
+    __shared__ __attribute__((aligned(16))) double slab[64 * 36];
     const int b = blockIdx.x;
-    if (b < A.nb3) {
-        landmark_block<3>(b * 256 + (int)threadIdx.x, A.npt, A.pt_ptr, A.pt_ids, A.pJl, A.pr, A.pw, A.H_pt, A.g_pt, A.lambda, A.Vp, A.tp, A.nsing);
+    if (b < A.nb3) {                                   // (64 landmarks: the workgroup's first wave; the others leave)
+        if (threadIdx.x >= 64) return;
+        landmark_block<3>(b * 64, A.npt, A.pt_ptr, A.pt_ids, A.pJl, A.pr, A.pw, A.H_pt, A.g_pt, slab, A.lambda, A.Vp, A.tp, A.nsing);
     } else if (b < A.nb3 + A.nb6) {
-        landmark_block<6>((b - A.nb3) * 256 + (int)threadIdx.x, A.nls, A.ls_ptr, A.ls_ids, A.lJl, A.lr, A.lw, A.H_ls, A.g_ls, A.lambda,
-                          A.Vl, A.tl, A.nsing);
+        if (threadIdx.x >= 64) return;
+        landmark_block<6>((b - A.nb3) * 64, A.nls, A.ls_ptr, A.ls_ids, A.lJl, A.lr, A.lw, A.H_ls, A.g_ls, slab, A.lambda, A.Vl, A.tl,
+                          A.nsing);
     } else {
         // chunk partials of the keyframes (K9): item = keyframe * max_chunks + chunk, one wave per item, lane e < 42 an entry
-        const int item = (b - A.nb3 - A.nb6) * 4 + ((int)threadIdx.x >> 6), e = (int)threadIdx.x & 63;
+        // (the item is the wave's: said so, the observation ids are scalar loads)
+        const int item = __builtin_amdgcn_readfirstlane((b - A.nb3 - A.nb6) * 4 + ((int)threadIdx.x >> 6)), e = (int)threadIdx.x & 63;
         if (item >= A.nkf * A.max_chunks || e >= 42) return;
         const int k = item / A.max_chunks, c = item - k * A.max_chunks;
         const int beg = A.kf_ptr[k] + c * POSE_CHUNK;
@@ -402,6 +415,9 @@ k_lba_blocks(const LbaBlockArgs A)
     }
 }
 
+#ifndef PLSLAM_SCH_WAVES
+#define PLSLAM_SCH_WAVES 1                 // chunks per workgroup of the Schur partials' launch (see wave_sync)
+#endif
 // NT = 256: a lane per partial-sum slot; NT = 64 (inside the Schur partials' launch): a lane plays the four lanes e, e + 64,
 // e + 128, e + 192 of the 256-lane form and adds them as its tree's first two levels do -- the same sums in the same order
 template <int NT>
@@ -413,7 +429,7 @@ __device__ __forceinline__ void lba_finish_wg(const LbaBlockArgs& A, int k, doub
         if (e >= 42) return;
         const int nchunks = (A.kf_ptr[k + 1] - A.kf_ptr[k] + POSE_CHUNK - 1) / POSE_CHUNK;
         double acc = 0.0;
-        constexpr int PB = 8;
+        constexpr int PB = 32;                     // (loads in flight per round trip: C3's 105 chunks were 14 round trips at 8)
         for (int c0 = 0; c0 < nchunks; c0 += PB) {
             double v[PB];
 #pragma unroll
@@ -434,12 +450,21 @@ __device__ __forceinline__ void lba_finish_wg(const LbaBlockArgs& A, int k, doub
         acc[q] = 0.0;
         for (int i = e + q * NT; i < A.nerr; i += 256) acc[q] += A.err_part[i];
     }
-    if (Q == 4) { acc[0] += acc[2]; acc[1] += acc[3]; acc[0] += acc[1]; }      // the tree's levels 128 and 64
+    if constexpr (Q == 4) { acc[0] += acc[2]; acc[1] += acc[3]; acc[0] += acc[1]; }      // the tree's levels 128 and 64
+    auto sync = [] {
+        if (NT == 64 && PLSLAM_SCH_WAVES != 1) {   // (one wave, inside a workgroup whose other waves are elsewhere)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
+    };
     red[e] = acc[0];
-    __syncthreads();
+    sync();
     for (int s = NT / 2; s > 0; s >>= 1) {
         if (e < s) red[e] += red[e + s];
-        __syncthreads();
+        sync();
     }
     if (e == 0) A.err[0] = red[0];
 }
@@ -671,7 +696,7 @@ static LbaBlockArgs lba_block_args(plslam_lba_plan* P)
     B.pose_part = (double*)(dout + P->oPart); B.H_pose = (double*)(dout + P->oHp); B.g_pose = g;
     B.err = (double*)(dout + P->oErr); B.err_part = (double*)(dout + P->oErrPart);
     B.npt = P->npt; B.nls = P->nls; B.nkf = P->nkf; B.np = P->np;
-    B.nb3 = (P->npt + 255) / 256; B.nb6 = (P->nls + 255) / 256; B.max_chunks = P->max_chunks;
+    B.nb3 = (P->npt + 63) / 64; B.nb6 = (P->nls + 63) / 64; B.max_chunks = P->max_chunks;
     B.nerr = (P->np + 255) / 256 + (P->nl + 255) / 256;
     return B;
 }
@@ -995,6 +1020,9 @@ extern "C" int plslam_lba_assemble(plslam_ctx* ctx, int32_t nkf, int32_t npt, in
 namespace plslam {
 
 constexpr int SCH_CHUNK = 64;
+#ifndef PLSLAM_SCHUR_X
+#define PLSLAM_SCHUR_X 0            // timing experiments only (tools/r6_schur_knockouts.sh): parts of the partials' launch left out
+#endif
 struct SchurPair { int32_t o1, o2, lm, line; };     // observation ids within their own list (points / lines), the landmark
 
 template <int DL>
@@ -1042,7 +1070,7 @@ __device__ __forceinline__ void schur_landmark(const double* __restrict__ H, con
         }
         t[(size_t)j * DL + a] = acc;
     }
-    if (!ok) atomicAdd(nsing, 1);              // (a count only: no sum depends on it)
+    if (!ok && nsing) atomicAdd(nsing, 1);     // (a count only: no sum depends on it)
 }
 
 // one launch for both kinds: workgroups [0, nb3) take the points, the rest the lines
@@ -1102,11 +1130,34 @@ __device__ __forceinline__ void schur_pair_block(const double* __restrict__ W1, 
 // 64 rows of NE doubles, row r at base + NE * id(r) where lane r holds id(r): fetched by the WAVE in runs (consecutive lanes read
 // consecutive words of a row: 4-8 cache lines per instruction; a lane reading its own row word by word touches 64), parked in
 // the tile, and every lane takes its own row out of it.  One wave per workgroup: the barriers are the wave's own.
-template <int NE>
-__device__ __forceinline__ void gather_rows(double (*tile)[37], const double* __restrict__ base, int id, double (&row_out)[NE])
+// One chunk per workgroup of one wave (PLSLAM_SCH_WAVES = 1).  Measured at C3 (tools/r6_schur_knockouts.sh): two or four chunks
+// per workgroup, a wave each with its own tile and wave-level synchronisation, are SLOWER (24.0 / 24.9 us against 19.8: a
+// workgroup's LDS and registers stay taken until its slowest wave is through), and so is the wave-level form at one wave (22.3: the
+// scheduler takes the weaker barrier as leave to spread the gathers' loads over 285 registers).
+#ifndef PLSLAM_SCH_OFF64
+#define PLSLAM_SCH_OFF64 0
+#endif
+#ifndef PLSLAM_SCH_STATIC_LDS
+#define PLSLAM_SCH_STATIC_LDS (PLSLAM_SCH_WAVES == 1)   // (a tile of known size: 20.8 us against 26.8 with the same tile as dynamic LDS --
+#endif                                                  //  the register allocator sees what the workgroup's LDS allows and keeps two waves)
+#ifndef PLSLAM_SCH_FINISH_LAST
+#define PLSLAM_SCH_FINISH_LAST 0
+#endif
+__device__ __forceinline__ void wave_sync()
 {
-    static_assert(NE <= 36, "the tile is 37 doubles wide");
-    const int lane = threadIdx.x;
+#if PLSLAM_SCH_WAVES == 1
+    __syncthreads();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+// (fetch: the loads, into registers -- several gathers' loads can be in flight together; park: through the tile, one at a time)
+template <int NE>
+__device__ __forceinline__ void gather_fetch(const double* __restrict__ base, int id, double (&flat)[NE])
+{
+    const int lane = threadIdx.x & 63;
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     if constexpr (NE % 2 == 0) {
         constexpr int H = NE / 2;
@@ -1114,22 +1165,78 @@ __device__ __forceinline__ void gather_rows(double (*tile)[37], const double* __
         for (int j = 0; j < H; ++j) {
             const int idx = j * 64 + lane, r = idx / H, c2 = idx - r * H;
             const int rid = __shfl(id, r);
+            // (a 32-bit byte offset from the uniform base: the load takes it beside the base in scalar registers -- a 64-bit
+            // address per load was two more registers for each of the 18 loads in flight; lba_schur_prepare bounds the tables)
+#if PLSLAM_SCH_OFF64
             const f64x2 v = *reinterpret_cast<const f64x2*>(base + (size_t)rid * NE + 2 * c2);
-            tile[r][2 * c2] = v.x;
-            tile[r][2 * c2 + 1] = v.y;
+#else
+            const uint32_t boff = ((uint32_t)rid * NE + 2 * c2) * 8u;
+            const f64x2 v = *reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(base) + boff);
+#endif
+            flat[2 * j] = v.x;
+            flat[2 * j + 1] = v.y;
         }
     } else {
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
             const int idx = j * 64 + lane, r = idx / NE, c = idx - r * NE;
             const int rid = __shfl(id, r);
-            tile[r][c] = base[(size_t)rid * NE + c];
+#if PLSLAM_SCH_OFF64
+            flat[j] = base[(size_t)rid * NE + c];
+#else
+            const uint32_t boff = ((uint32_t)rid * NE + c) * 8u;
+            flat[j] = *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + boff);
+#endif
         }
     }
-    __syncthreads();
+}
+// (park_only: the rows stay in the tile -- every lane reads its own row from there as it goes; the caller synchronises before the
+// tile's next use)
+template <int NE>
+__device__ __forceinline__ void gather_park_only(double (*tile)[37], const double (&flat)[NE])
+{
+    static_assert(NE <= 36 && NE % 2 == 0, "the tile is 37 doubles wide");
+    const int lane = threadIdx.x & 63;
+    constexpr int H = NE / 2;
+#pragma unroll
+    for (int j = 0; j < H; ++j) {
+        const int idx = j * 64 + lane, r = idx / H, c2 = idx - r * H;
+        tile[r][2 * c2] = flat[2 * j];
+        tile[r][2 * c2 + 1] = flat[2 * j + 1];
+    }
+    wave_sync();
+}
+template <int NE>
+__device__ __forceinline__ void gather_park(double (*tile)[37], const double (&flat)[NE], double (&row_out)[NE])
+{
+    static_assert(NE <= 36, "the tile is 37 doubles wide");
+    const int lane = threadIdx.x & 63;
+    if constexpr (NE % 2 == 0) {
+        constexpr int H = NE / 2;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+            const int idx = j * 64 + lane, r = idx / H, c2 = idx - r * H;
+            tile[r][2 * c2] = flat[2 * j];
+            tile[r][2 * c2 + 1] = flat[2 * j + 1];
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            const int idx = j * 64 + lane, r = idx / NE, c = idx - r * NE;
+            tile[r][c] = flat[j];
+        }
+    }
+    wave_sync();
 #pragma unroll
     for (int e = 0; e < NE; ++e) row_out[e] = tile[lane][e];
-    __syncthreads();
+    wave_sync();
+}
+template <int NE>
+__device__ __forceinline__ void gather_rows(double (*tile)[37], const double* __restrict__ base, int id, double (&row_out)[NE])
+{
+    double flat[NE];
+    gather_fetch<NE>(base, id, flat);
+    gather_park<NE>(tile, flat, row_out);
 }
 
 __device__ __forceinline__ void
@@ -1137,38 +1244,123 @@ schur_partials_wg(double (*tile)[37], int B, int c, const SchurPair* __restrict_
                   const double* __restrict__ W_pt, const double* __restrict__ W_ls, const double* __restrict__ Vp,
                   const double* __restrict__ Vl, int32_t max_chunks, double* __restrict__ part /* [nblk][max_chunks][36] */)
 {
-    const int i = threadIdx.x;
+    const int i = threadIdx.x & 63;
     const int beg = blk_ptr[B] + c * SCH_CHUNK;
     const int end = beg + SCH_CHUNK < blk_ptr[B + 1] ? beg + SCH_CHUNK : blk_ptr[B + 1];
     const int n = end - beg;                       // <= 0: the block has fewer chunks than the grid is wide
     if (n <= 0) return;
-    const SchurPair q = pairs[beg + (i < n ? i : n - 1)];     // (lanes past the chunk's end replay its last pair: their block is dropped)
-    const int kinds = (__ballot(q.line != 0) != 0 ? 2 : 0) | (__ballot(q.line == 0) != 0 ? 1 : 0);
-    double blk[36];
-    if (kinds == 1) {                              // a chunk of point pairs (the usual case): the wave fetches the rows together
+    SchurPair q = pairs[beg + (i < n ? i : n - 1)];           // (lanes past the chunk's end replay its last pair: their block is dropped)
+#if PLSLAM_SCHUR_X & 1
+    if (q.o1 != -12345) return;
+#endif
+    // the chunk's kind (lba_schur_prepare: one kind per chunk, null pairs -- line = 2 -- behind a block's last point pairs); a null
+    // pair fetches what the chunk's first pair fetches and contributes zeros
+    const bool null_pair = q.line == 2;
+    if (null_pair) { q.o1 = __shfl(q.o1, 0); q.o2 = __shfl(q.o2, 0); q.lm = __shfl(q.lm, 0); }
+    const bool line_chunk = __shfl(q.line, 0) == 1;
+    // The wave fetches its 64 pairs' rows together (gather_*), each lane takes its own out of the tile, and the pair's 6 x 6 block
+    // goes straight back into the tile (the sums are schur_pair_product's, term for term).  Registers: what a lane holds at once
+    // decides how many waves a SIMD keeps (a first form with all operands and the block in registers: 256 and one wave; this one: two).
+#if PLSLAM_SCHUR_X & 16
+    if (line_chunk) return;
+#endif
+    if (!line_chunk) {
         double w1[18], w2[18], v[9];
-        gather_rows<18>(tile, W_pt, q.o1, w1);
-        gather_rows<18>(tile, W_pt, q.o2, w2);
-        gather_rows<9>(tile, Vp, q.lm, v);
-        schur_pair_product<3>(w1, w2, v, blk);
-    } else if (kinds == 2) {                       // ... of line pairs
-        double w1[36], w2[36], v[36];
-        gather_rows<36>(tile, W_ls, q.o1, w1);
-        gather_rows<36>(tile, W_ls, q.o2, w2);
-        gather_rows<36>(tile, Vl, q.lm, v);
-        schur_pair_product<6>(w1, w2, v, blk);
-    } else {                                       // the one chunk of a block where its point pairs end and its line pairs begin
-        if (!q.line) schur_pair_block<3>(W_pt + (size_t)q.o1 * 18, W_pt + (size_t)q.o2 * 18, Vp + (size_t)q.lm * 9, blk);
-        else schur_pair_block<6>(W_ls + (size_t)q.o1 * 36, W_ls + (size_t)q.o2 * 36, Vl + (size_t)q.lm * 36, blk);
-    }
-    if (i < n) {
+        {
+            double f1[18], f2[18], fv[9];
+            gather_fetch<18>(W_pt, q.o1, f1);      // (the three gathers' loads: one round trip)
+            gather_fetch<18>(W_pt, q.o2, f2);
+            gather_fetch<9>(Vp, q.lm, fv);
+            gather_park<18>(tile, f1, w1);
+            gather_park<18>(tile, f2, w2);
+            gather_park<9>(tile, fv, v);
+        }
 #pragma unroll
-        for (int e = 0; e < 36; ++e) tile[i][e] = blk[e];
+        for (int b = 0; b < 6; ++b) {
+            double u[3];
+#pragma unroll
+            for (int x = 0; x < 3; ++x) {
+                double t = 0.0;
+#pragma unroll
+                for (int y = 0; y < 3; ++y) t += v[x * 3 + y] * w2[y * 6 + b];
+                u[x] = t;
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int x = 0; x < 3; ++x) sacc += w1[x * 6 + a] * u[x];
+                tile[i][a * 6 + b] = null_pair ? 0.0 : sacc;
+            }
+        }
+    } else {
+        // W2, then Y = Vinv W2 (column b of a lane's W2 row is dead once Y's column b is known: Y overwrites W2 in place), then W1,
+        // and entry (a, b) = sum_x W1[x][a] Y[x][b] lands where W1[b][a] was (column a of W1 is dead by then): the block sits
+        // TRANSPOSED in the tile, and the lanes that add the chunk's blocks read it so
+        {
+            double v[36];
+            {
+                double fv[36], f2[36];
+                gather_fetch<36>(Vl, q.lm, fv);
+                gather_fetch<36>(W_ls, q.o2, f2);
+                gather_park<36>(tile, fv, v);
+                gather_park_only<36>(tile, f2);
+            }
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                double w2c[6], yc[6];
+#pragma unroll
+                for (int y = 0; y < 6; ++y) w2c[y] = tile[i][y * 6 + b];
+#pragma unroll
+                for (int x = 0; x < 6; ++x) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int y = 0; y < 6; ++y) t += v[x * 6 + y] * w2c[y];
+                    yc[x] = t;                     // u[x] of column b
+                }
+#pragma unroll
+                for (int x = 0; x < 6; ++x) tile[i][x * 6 + b] = yc[x];
+            }
+        }
+        double Y[36];
+#pragma unroll
+        for (int e = 0; e < 36; ++e) Y[e] = tile[i][e];
+        {
+            double f1[36];
+            gather_fetch<36>(W_ls, q.o1, f1);
+            wave_sync();                       // (every lane has taken its Y)
+            gather_park_only<36>(tile, f1);
+        }
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            double w1c[6], oc[6];
+#pragma unroll
+            for (int x = 0; x < 6; ++x) w1c[x] = tile[i][x * 6 + a];
+#pragma unroll
+            for (int b = 0; b < 6; ++b) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int x = 0; x < 6; ++x) sacc += w1c[x] * Y[x * 6 + b];
+                oc[b] = sacc;
+            }
+#pragma unroll
+            for (int b = 0; b < 6; ++b) tile[i][b * 6 + a] = null_pair ? 0.0 : oc[b];
+        }
     }
-    __syncthreads();
-    if (i < 36) {
+    wave_sync();
+#if PLSLAM_SCHUR_X & 8
+    if (n != -12345) return;
+#endif
+    if (i < 36) {                                  // (eight LDS reads in flight, added in pair order)
+        const int slot = line_chunk ? (i % 6) * 6 + i / 6 : i;
         double acc = 0.0;
-        for (int k = 0; k < n; ++k) acc += tile[k][i];
+        for (int k0 = 0; k0 < n; k0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = tile[k0 + u < n ? k0 + u : n - 1][slot];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (k0 + u < n) acc += v[u];
+        }
         part[((size_t)B * max_chunks + c) * 36 + i] = acc;
     }
 }
@@ -1181,7 +1373,7 @@ schur_b_partials_wg(double (*tile)[37], int k, int c, const int32_t* __restrict_
                     const double* __restrict__ W_pt, const double* __restrict__ W_ls, const double* __restrict__ tp,
                     const double* __restrict__ tl, int32_t max_chunks, double* __restrict__ part /* [nkf][max_chunks][6] */)
 {
-    const int i = threadIdx.x;
+    const int i = threadIdx.x & 63;
     const int beg = kf_ptr[k] + c * POSE_CHUNK;
     const int end = beg + POSE_CHUNK < kf_ptr[k + 1] ? beg + POSE_CHUNK : kf_ptr[k + 1];
     const int n = end - beg;
@@ -1210,10 +1402,16 @@ schur_b_partials_wg(double (*tile)[37], int k, int c, const int32_t* __restrict_
             }
         }
     }
-    __syncthreads();
+    wave_sync();
     if (i < 6) {
         double acc = 0.0;
-        for (int q = 0; q < n; ++q) acc += tile[q][i];
+        for (int q0 = 0; q0 < n; q0 += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = tile[q0 + u < n ? q0 + u : n - 1][i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (q0 + u < n) acc += v[u];
+        }
         part[((size_t)k * max_chunks + c) * 6 + i] = acc;
     }
 }
@@ -1227,35 +1425,68 @@ struct SchurPartArgs {
     int32_t nblk, schur_chunks, nkf, pose_chunks, n_pt_obs;
 };
 static_assert(SCH_CHUNK == POSE_CHUNK, "one workgroup shape for both kinds of chunk");
-__global__ void __launch_bounds__(SCH_CHUNK)
-k_schur_partials(SchurPartArgs A)
+// (PLSLAM_SCH_WAVES chunks per workgroup, a wave and a tile each: see wave_sync; the tiles are dynamic LDS -- four of them are past
+// the 64 kB a kernel may use without asking; PLSLAM_SCH_VGPRS: a register budget for the experiments, 0 = the compiler's own)
+constexpr int SCH_WAVES = PLSLAM_SCH_WAVES;
+#ifndef PLSLAM_SCH_VGPRS
+#define PLSLAM_SCH_VGPRS 0
+#endif
+#if PLSLAM_SCH_VGPRS
+#define SCH_VGPR_ATTR __attribute__((amdgpu_num_vgpr(PLSLAM_SCH_VGPRS / 2)))
+#else
+#define SCH_VGPR_ATTR
+#endif
+constexpr size_t SCH_TILE_DOUBLES = (size_t)SCH_CHUNK * 37;
+constexpr size_t SCH_LDS_BYTES = SCH_WAVES * SCH_TILE_DOUBLES * 8;
+__device__ __forceinline__ void schur_partials_item(double (*tile)[37], const SchurPartArgs& A, int w, int npart)
 {
-    __shared__ double tile[SCH_CHUNK][37];
     const int nS = A.nblk * A.schur_chunks;
-    if ((int)blockIdx.x < nS)
-        schur_partials_wg(tile, (int)blockIdx.x / A.schur_chunks, (int)blockIdx.x % A.schur_chunks, A.pairs, A.blk_ptr, A.W_pt, A.W_ls,
-                          A.Vp, A.Vl, A.schur_chunks, A.spart);
-    else
-        schur_b_partials_wg(tile, ((int)blockIdx.x - nS) / A.pose_chunks, ((int)blockIdx.x - nS) % A.pose_chunks, A.kf_ptr, A.kf_obs,
-                            A.n_pt_obs, A.pt_lm, A.ls_lm, A.W_pt, A.W_ls, A.tp, A.tl, A.pose_chunks, A.bpart);
+    if (w < nS)
+        schur_partials_wg(tile, w / A.schur_chunks, w % A.schur_chunks, A.pairs, A.blk_ptr, A.W_pt, A.W_ls, A.Vp, A.Vl, A.schur_chunks, A.spart);
+    else if (w < npart)
+        schur_b_partials_wg(tile, (w - nS) / A.pose_chunks, (w - nS) % A.pose_chunks, A.kf_ptr, A.kf_obs, A.n_pt_obs, A.pt_lm, A.ls_lm,
+                            A.W_pt, A.W_ls, A.tp, A.tl, A.pose_chunks, A.bpart);
+}
+__global__ void __launch_bounds__(SCH_CHUNK * SCH_WAVES) SCH_VGPR_ATTR
+k_schur_partials(SchurPartArgs A, int32_t npart)
+{
+#if PLSLAM_SCH_STATIC_LDS
+    __shared__ __attribute__((aligned(16))) double sch_lds[SCH_WAVES * SCH_TILE_DOUBLES];
+#else
+    extern __shared__ __attribute__((aligned(16))) double sch_lds[];
+#endif
+    const int wv = (int)threadIdx.x >> 6;
+    schur_partials_item(reinterpret_cast<double (*)[37]>(sch_lds + wv * SCH_TILE_DOUBLES), A, (int)blockIdx.x * SCH_WAVES + wv, npart);
 }
 
-// plslam_lba_plan_iterate_schur: the Schur partials and, behind them in the SAME launch, the iteration's last stage (K10: keyframe
-// blocks and err from their partials) -- the two are independent (the partials read W and the landmark inverses, K22 behind them
-// reads H_pose / g_pose), so the iteration's third launch rides in the Schur step's second
-__global__ void __launch_bounds__(SCH_CHUNK)
-k_schur_partials_lba_finish(SchurPartArgs A, const LbaBlockArgs B, int32_t npart_wgs)
+// plslam_lba_plan_iterate_schur: the Schur partials and, in the SAME launch, the iteration's last stage (K10: keyframe blocks and err
+// from their partials) -- the two are independent (the partials read W and the landmark inverses, K22 behind them reads H_pose /
+// g_pose), so the iteration's third launch rides in the Schur step's second.  The last stage's workgroups come FIRST (a wave each;
+// chains of round trips: at the grid's end they would be the launch's tail).
+__global__ void __launch_bounds__(SCH_CHUNK * SCH_WAVES) SCH_VGPR_ATTR
+k_schur_partials_lba_finish(SchurPartArgs A, const LbaBlockArgs B, int32_t npart)
 {
-    __shared__ double tile[SCH_CHUNK][37];
-    const int nS = A.nblk * A.schur_chunks;
-    if ((int)blockIdx.x < nS)
-        schur_partials_wg(tile, (int)blockIdx.x / A.schur_chunks, (int)blockIdx.x % A.schur_chunks, A.pairs, A.blk_ptr, A.W_pt, A.W_ls,
-                          A.Vp, A.Vl, A.schur_chunks, A.spart);
-    else if ((int)blockIdx.x < npart_wgs)
-        schur_b_partials_wg(tile, ((int)blockIdx.x - nS) / A.pose_chunks, ((int)blockIdx.x - nS) % A.pose_chunks, A.kf_ptr, A.kf_obs,
-                            A.n_pt_obs, A.pt_lm, A.ls_lm, A.W_pt, A.W_ls, A.tp, A.tl, A.pose_chunks, A.bpart);
-    else
-        lba_finish_wg<SCH_CHUNK>(B, (int)blockIdx.x - npart_wgs, &tile[0][0]);
+#if PLSLAM_SCH_STATIC_LDS
+    __shared__ __attribute__((aligned(16))) double sch_lds[SCH_WAVES * SCH_TILE_DOUBLES];
+#else
+    extern __shared__ __attribute__((aligned(16))) double sch_lds[];
+#endif
+    const int wv = (int)threadIdx.x >> 6;
+    const int nF = B.nkf + 1;
+#if PLSLAM_SCH_FINISH_LAST
+    const int ngrid = (npart + SCH_WAVES - 1) / SCH_WAVES;
+    if ((int)blockIdx.x >= ngrid) {
+        if (wv == 0) lba_finish_wg<SCH_CHUNK>(B, (int)blockIdx.x - ngrid, sch_lds);
+        return;
+    }
+    schur_partials_item(reinterpret_cast<double (*)[37]>(sch_lds + wv * SCH_TILE_DOUBLES), A, (int)blockIdx.x * SCH_WAVES + wv, npart);
+#else
+    if ((int)blockIdx.x < nF) {
+        if (wv == 0) lba_finish_wg<SCH_CHUNK>(B, (int)blockIdx.x, sch_lds);
+        return;
+    }
+    schur_partials_item(reinterpret_cast<double (*)[37]>(sch_lds + wv * SCH_TILE_DOUBLES), A, ((int)blockIdx.x - nF) * SCH_WAVES + wv, npart);
+#endif
 }
 
 // block B = (k1 <= k2) in row-major upper-triangle order; S is (6 nkf) x (6 nkf) row-major, b follows it
@@ -1282,12 +1513,12 @@ k_schur_finish(const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ 
         // (the chunk partials are added in chunk order; their loads go out eight at a time -- one by one they are a chain of
         // round trips)
         double acc = 0.0;
-        for (int c0 = 0; c0 < nch; c0 += 8) {
-            double v[8];
+        for (int c0 = 0; c0 < nch; c0 += 32) {
+            double v[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = c0 + u < nch ? spart[((size_t)B * schur_chunks + c0 + u) * 36 + e] : 0.0;
+            for (int u = 0; u < 32; ++u) v[u] = c0 + u < nch ? spart[((size_t)B * schur_chunks + c0 + u) * 36 + e] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (c0 + u < nch) acc += v[u];
+            for (int u = 0; u < 32; ++u) if (c0 + u < nch) acc += v[u];
         }
         double h = 0.0;
         if (k1 == k2) {
@@ -1302,12 +1533,12 @@ k_schur_finish(const int32_t* __restrict__ blk_ptr, const int32_t* __restrict__ 
         if (e >= 6) return;
         const int nch = (kf_ptr[k + 1] - kf_ptr[k] + POSE_CHUNK - 1) / POSE_CHUNK;
         double acc = 0.0;
-        for (int c0 = 0; c0 < nch; c0 += 8) {
-            double v[8];
+        for (int c0 = 0; c0 < nch; c0 += 32) {
+            double v[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = c0 + u < nch ? bpart[((size_t)k * pose_chunks + c0 + u) * 6 + e] : 0.0;
+            for (int u = 0; u < 32; ++u) v[u] = c0 + u < nch ? bpart[((size_t)k * pose_chunks + c0 + u) * 6 + e] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) if (c0 + u < nch) acc += v[u];
+            for (int u = 0; u < 32; ++u) if (c0 + u < nch) acc += v[u];
         }
         bvec[6 * k + e] = g_pose[6 * k + e] - acc;
     }
@@ -1409,6 +1640,9 @@ k_lba_diag_max(const double* __restrict__ H_pose, int32_t nkf, const double* __r
 static int lba_schur_prepare(plslam_lba_plan* P)
 {
     if (P->schur_ready) return PLSLAM_OK;
+    // (the partials address the cross blocks and the landmark inverses by 32-bit byte offsets: 288 bytes per line row)
+    PLSLAM_REQUIRE((size_t)P->np * 144 < (size_t(1) << 32) && (size_t)P->nl * 288 < (size_t(1) << 32) &&
+                   (size_t)P->npt * 72 < (size_t(1) << 32) && (size_t)P->nls * 288 < (size_t(1) << 32), PLSLAM_EINVAL);
     const int32_t nkf = P->nkf;
     P->nblk = nkf * (nkf + 1) / 2;
     auto blk_of = [nkf](int32_t k1, int32_t k2) { return k1 * nkf - k1 * (k1 - 1) / 2 + (k2 - k1); };
@@ -1431,11 +1665,19 @@ static int lba_schur_prepare(plslam_lba_plan* P)
                 }
         }
     };
-    each_pair([&](int32_t B, const SchurPair&) { ++cnt[(size_t)B + 1]; });
-    for (int32_t B = 0; B < P->nblk; ++B) cnt[(size_t)B + 1] += cnt[B];
-    std::vector<SchurPair> pairs((size_t)cnt[P->nblk]);
-    std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1);
-    each_pair([&](int32_t B, const SchurPair& q) { pairs[(size_t)pos[B]++] = q; });
+    // a block's point pairs, then its line pairs starting at a CHUNK boundary (null pairs -- line = 2: no contribution -- fill the last
+    // point chunk of a block that has both kinds): every chunk is of one kind, and the wave fetches its rows together
+    std::vector<int32_t> npt_pairs((size_t)P->nblk, 0), nls_pairs((size_t)P->nblk, 0);
+    each_pair([&](int32_t B, const SchurPair& q) { ++(q.line ? nls_pairs : npt_pairs)[(size_t)B]; });
+    auto pt_room = [&](int32_t B) {
+        const int32_t np_ = npt_pairs[(size_t)B];
+        return nls_pairs[(size_t)B] ? (np_ + SCH_CHUNK - 1) / SCH_CHUNK * SCH_CHUNK : np_;
+    };
+    for (int32_t B = 0; B < P->nblk; ++B) cnt[(size_t)B + 1] = cnt[B] + pt_room(B) + nls_pairs[(size_t)B];
+    std::vector<SchurPair> pairs((size_t)cnt[P->nblk], SchurPair{0, 0, 0, 2});
+    std::vector<int32_t> pos_pt(cnt.begin(), cnt.end() - 1), pos_ls((size_t)P->nblk);
+    for (int32_t B = 0; B < P->nblk; ++B) pos_ls[(size_t)B] = cnt[B] + pt_room(B);
+    each_pair([&](int32_t B, const SchurPair& q) { pairs[(size_t)(q.line ? pos_ls : pos_pt)[(size_t)B]++] = q; });
     int32_t mc = 0;
     for (int32_t B = 0; B < P->nblk; ++B) mc = std::max(mc, (cnt[(size_t)B + 1] - cnt[B] + SCH_CHUNK - 1) / SCH_CHUNK);
     P->schur_chunks = mc;
@@ -1457,6 +1699,12 @@ static int lba_schur_prepare(plslam_lba_plan* P)
                                                                               ((size_t)P->npt / (BACK_WG / 3) + (size_t)P->nls / (BACK_WG / 6) + 2) * 8 + 256)))
         return rc;
     P->schur_pin_dev = static_cast<char*>(mapped_device_pointer(P->schur_pin.p));
+#if !PLSLAM_SCH_STATIC_LDS
+    // (the experiments' four tiles are past the 64 kB a kernel may use without asking)
+    PLSLAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_partials), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCH_LDS_BYTES));
+    PLSLAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_partials_lba_finish), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)SCH_LDS_BYTES));
+#endif
     hipStream_t s = P->ctx->stream;
     char* d = P->schur.as<char>();
     if (!pairs.empty()) PLSLAM_HIP_CHECK(hipMemcpyAsync(d + P->oSpair, pairs.data(), pairs.size() * sizeof(SchurPair), hipMemcpyHostToDevice, s));
@@ -1519,9 +1767,12 @@ static int lba_schur_enqueue(plslam_lba_plan* P, double lambda, int* par_out, bo
     A.spart = (double*)(d + P->oSpart); A.bpart = (double*)(d + P->oBpart);
     A.nblk = P->nblk; A.schur_chunks = P->schur_chunks; A.nkf = P->nkf; A.pose_chunks = P->max_chunks; A.n_pt_obs = P->np;
     const int32_t npart_wgs = P->nblk * P->schur_chunks + P->nkf * P->max_chunks;
+    const int32_t npart_grid = (npart_wgs + SCH_WAVES - 1) / SCH_WAVES;
     if (fused)
-        hipLaunchKernelGGL(k_schur_partials_lba_finish, dim3(npart_wgs + P->nkf + 1), dim3(SCH_CHUNK), 0, s, A, lba_block_args(P), npart_wgs);
-    else if (npart_wgs > 0) hipLaunchKernelGGL(k_schur_partials, dim3(npart_wgs), dim3(SCH_CHUNK), 0, s, A);
+        hipLaunchKernelGGL(k_schur_partials_lba_finish, dim3(npart_grid + P->nkf + 1), dim3(SCH_CHUNK * SCH_WAVES), PLSLAM_SCH_STATIC_LDS ? 0 : SCH_LDS_BYTES, s, A,
+                           lba_block_args(P), npart_wgs);
+    else if (npart_grid > 0)
+        hipLaunchKernelGGL(k_schur_partials, dim3(npart_grid), dim3(SCH_CHUNK * SCH_WAVES), PLSLAM_SCH_STATIC_LDS ? 0 : SCH_LDS_BYTES, s, A, npart_wgs);
     // S, b, err and this call's counter: written where the host reads them (the page-locked image, mapped) when it can be -- no
     // copy behind the kernel; otherwise beside the partials on the device, and lba_schur_fetch copies
     const bool in_place = P->schur_pin_dev != nullptr;

@@ -67,6 +67,15 @@ __device__ __forceinline__ void wave_store_rows(double* __restrict__ gbase /* ro
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (reinterpret_cast<uintptr_t>(gbase) & 15) {          // (wave-uniform) a base that is only 8-byte aligned: word by word, in runs
+#pragma unroll
+        for (int k = 0; k < NW; ++k) {
+            const int i = k * 64 + lane;
+            if (i < valid * NW) __builtin_nontemporal_store(slab[i], gbase + i);
+        }
+        __builtin_amdgcn_wave_barrier();
+        return;
+    }
     typedef double f64x2 __attribute__((ext_vector_type(2)));
     const int total2 = valid * NW / 2;                      // number of double2 chunks (NW*valid is even
     const f64x2* s2 = reinterpret_cast<const f64x2*>(slab);      //  unless NW and valid are odd)
