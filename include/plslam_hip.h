@@ -121,7 +121,12 @@ void plslam_ctx_destroy(plslam_ctx* ctx);
  * use: 0 = plans of fewer waves than the chip has SIMDs | 1 = never (default: measured SLOWER on ROCm 7 -- C3's three-kernel
  * run 26.9 us per back-to-back run against 22.3 us with plain launches) | 2 = always; never while profiling),
  * "fuse" (K1f: one workgroup per problem that also merges the column results and applies the ratio test + mutual
- * check, i.e. one kernel per plan run: 0 = auto (currently: never -- measured no faster) | 1 = never | 2 = always) */
+ * check, i.e. one kernel per plan run: 0 = auto (currently: never -- measured no faster) | 1 = never | 2 = always),
+ * "grid_dense" (plslam_match_grid, process-wide: 1 (default) = a lone problem of at most 256 x 256 rows runs on ONE workgroup with
+ * everything in LDS (the SLAM loop's 200 x 200 line problems) | 0 = the general kernels; identical tables),
+ * "zero_copy_kb" (plslam_match_grid: n > 0 (default 64) = an upload image of at most n KB is read by the dense kernel where it
+ * lies in page-locked host memory -- no copy command in front of the kernel: 57 -> 51 us per 200 x 200 call | -n = for the general
+ * kernels too (measured neutral to slower: they read their inputs many times) | 0 = always copy; identical tables) */
 int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value);
 int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value);
 /* device facts for reports: CU count, max clock (kHz), LDS bytes per workgroup */

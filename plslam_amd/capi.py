@@ -308,9 +308,18 @@ def _arr(a, dt, shape=None):
     return a
 
 
+_from_buffer, _addressof = C.c_char.from_buffer, C.addressof
+
+
 def _p(a):
-    return a.ctypes.data_as(C.c_void_p) if a is not None and a.size else C.c_void_p(
-        a.ctypes.data if a is not None else None)
+    """The address of a contiguous array as an int (every bound function declares void* arguments), None for None.  Through the
+    buffer protocol: `a.ctypes.data_as(...)` builds a ctypes helper object per call -- 2 us each, 20 us of a matchGrid call's 58."""
+    if a is None:
+        return None
+    try:
+        return _addressof(_from_buffer(a))
+    except (TypeError, ValueError, BufferError):          # a read-only or an empty array
+        return a.ctypes.data
 
 
 def grid_pair_capacity(centres, cell_start, cols, rows, window, mutual=True, bound=False) -> int:

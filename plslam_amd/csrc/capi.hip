@@ -49,12 +49,14 @@ int HostBuf::reserve(size_t bytes)
     if (p) {
         (void)hipHostFree(p);
         p = nullptr;
+        dev = nullptr;
         cap = 0;
     }
     size_t want = bytes + (bytes >> 2);
     want = (want + 4095) & ~size_t(4095);
     PLSLAM_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocDefault));
     cap = want;
+    dev = mapped_device_pointer(p);                // (asked once: hipPointerGetAttributes per call was 1-2 us of a 40 us call)
     return PLSLAM_OK;
 }
 
@@ -62,6 +64,7 @@ void HostBuf::release()
 {
     if (p) (void)hipHostFree(p);
     p = nullptr;
+    dev = nullptr;
     cap = 0;
 }
 
@@ -918,7 +921,7 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         return PLSLAM_OK;
     }
     if (!strcmp(key, "zero_copy_kb")) {
-        PLSLAM_REQUIRE(value >= 0 && value <= (1 << 20), PLSLAM_EINVAL);
+        PLSLAM_REQUIRE(value >= -(1 << 20) && value <= (1 << 20), PLSLAM_EINVAL);
         ctx->zero_copy_kb = value;
         return PLSLAM_OK;
     }

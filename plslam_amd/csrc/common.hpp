@@ -46,6 +46,7 @@ struct DevBuf {
 // points -- copies from/to pinned memory are plain DMA enqueues, copies from pageable memory are not
 struct HostBuf {
     void* p = nullptr;
+    void* dev = nullptr;     // the device address of the block (mapped page-locked memory), nullptr if the device cannot address it
     size_t cap = 0;
     int reserve(size_t bytes);
     void release();
@@ -130,7 +131,7 @@ struct plslam_ctx {
     int split_target = 0, split_min_tiles = 0;   // column split: workgroups per CU aimed at (0 = 3), tiles per column range at least (0 = 4)
     int split_post = 0;  // column-split K1f plans: 0 = auto (merge + ratio + mutual behind the scan in ONE kernel: two launches per run), 1 = never
     int post_xcd = 2;    // finalize: 0 = table order, 1 = an XCD takes contiguous entries of the block table (a problem's row blocks share one L2), 2 = the table dealt to the XCDs problem by problem (default)
-    int zero_copy_kb = 0;   // (round 6) host-pointer calls of ONE small problem (plslam_match_grid): an upload image of at most this many KB is read by the kernels where it lies in page-locked host memory -- no H2D copy command in front of them (0 = always copy)
+    int zero_copy_kb = 64;  // (round 6) host-pointer calls of ONE small problem (plslam_match_grid): an upload image of at most this many KB is read by the kernel where it lies in page-locked host memory -- no H2D copy command in front of it -- when the dense one-workgroup kernel takes the problem (it reads every word once); negative: for every problem whose image fits; 0 = always copy
     int post_fuse = 0;   // K1h / K1i plans: merge + finalize + gates behind the scan as ONE kernel: 0 = auto (throughput plans), 1 = never, 2 = whenever eligible
     int fuse = 0;        // K1f: 0 = auto (one workgroup per problem incl. merge + finalize when the plan is large), 1 = never, 2 = always
     std::mutex mu;       // serialises the host-pointer entry points

@@ -1698,7 +1698,7 @@ static int lba_schur_prepare(plslam_lba_plan* P)
     if ((rc = P->schur.reserve(c.off + 256)) || (rc = P->schur_pin.reserve(std::max((n6 * n6 + n6 + 3) * 8, (3 * (size_t)P->npt + 6 * (size_t)P->nls) * 8) + n6 * 8 +
                                                                               ((size_t)P->npt / (BACK_WG / 3) + (size_t)P->nls / (BACK_WG / 6) + 2) * 8 + 256)))
         return rc;
-    P->schur_pin_dev = static_cast<char*>(mapped_device_pointer(P->schur_pin.p));
+    P->schur_pin_dev = static_cast<char*>(P->schur_pin.dev);
 #if !PLSLAM_SCH_STATIC_LDS
     // (the experiments' four tiles are past the 64 kB a kernel may use without asking)
     PLSLAM_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_schur_partials), hipFuncAttributeMaxDynamicSharedMemorySize, (int)SCH_LDS_BYTES));

@@ -2168,9 +2168,15 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     char* dout = ctx->out_a.as<char>();
     // (option "zero_copy_kb": a small upload image is read by the kernels where it lies in page-locked host memory -- the copy
     // command in front of them, with its completion signal, is the larger part of such a call's device-side time)
+    // Taken where it was measured to pay (profiles/r6_r_grid_latency_dense_zero_copy.txt): a problem the dense one-workgroup kernel
+    // takes -- it reads every input word ONCE, into LDS: 200 x 200 lines 57.3 -> 50.9 us per call; the general kernels walk the
+    // cells and the descriptors again and again (neutral to 64 kB, slower beyond) and keep the copy unless the option is negative
+    // (-kb: every problem whose image fits |kb|).
     bool zero_copy = false;
-    if (ctx->zero_copy_kb > 0 && ci.off <= (size_t)ctx->zero_copy_kb * 1024)
-        if (char* m = static_cast<char*>(mapped_device_pointer(h))) { d = m; zero_copy = true; }
+    const bool dense = grid_dense_ok(n1, n2, ncell, n_items, dirs, n_centres);
+    const size_t zc_limit = (size_t)(ctx->zero_copy_kb < 0 ? -ctx->zero_copy_kb : ctx->zero_copy_kb) * 1024;
+    if (zc_limit > 0 && ci.off <= zc_limit && (dense || ctx->zero_copy_kb < 0))
+        if (char* m = static_cast<char*>(ctx->pin_in.dev)) { d = m; zero_copy = true; }
     memcpy(h + oC, centres1, (size_t)n1 * n_centres * 8);
     memcpy(h + oS, cell_start, (size_t)(ncell + 1) * 4);
     if (n_items) memcpy(h + oI, cell_items, (size_t)n_items * 4);
@@ -2190,7 +2196,7 @@ int plslam_match_grid(plslam_ctx* ctx, const int32_t* centres1, int32_t n_centre
     dq.dir2 = dirs ? (const double*)(d + oD2) : nullptr;
     // results: the kernel writes the table, the count and the status word straight into the page-locked block when the
     // device can address it (one copy-engine command less on the call's critical path)
-    char* hout_dev = static_cast<char*>(mapped_device_pointer(ctx->pin_out.p));
+    char* hout_dev = static_cast<char*>(ctx->pin_out.dev);
     int32_t* hres = (int32_t*)(ctx->pin_out.as<char>() + oN);
     if (hout_dev) {
         hres[0] = hres[1] = 0;

@@ -12,14 +12,17 @@ from test_match_grid_cpu import line_case, point_case
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["dense_small", "general"], autouse=True)
+@pytest.fixture(params=["dense_small", "dense_small_copied", "general", "general_in_place"], autouse=True)
 def small_problem_kernel(request, ctx):
-    """Every test of this module twice: with a lone problem of at most 256 x 256 rows on the one-workgroup dense kernel (round 6,
-    k_match_grid_dense: the default) and with that kernel off, i.e. on the general kernels (records / candidate list / passes)
-    every other problem takes anyway."""
-    ctx.set_option("grid_dense", 1 if request.param == "dense_small" else 0)
+    """Every test of this module four times: with a lone problem of at most 256 x 256 rows on the one-workgroup dense kernel (round
+    6, k_match_grid_dense: the default) reading its upload image where it lies in page-locked host memory (the default,
+    zero_copy_kb = 64) or copied to the device first; and with that kernel off, i.e. on the general kernels (records / candidate
+    list / passes) every other problem takes anyway -- behind the copy (their default) or reading the image in place."""
+    ctx.set_option("grid_dense", 1 if request.param.startswith("dense_small") else 0)
+    ctx.set_option("zero_copy_kb", {"dense_small": 64, "dense_small_copied": 0, "general": 64, "general_in_place": -1024}[request.param])
     yield request.param
     ctx.set_option("grid_dense", 1)
+    ctx.set_option("zero_copy_kb", 64)
 
 
 def _rng(seed):

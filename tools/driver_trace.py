@@ -18,6 +18,7 @@ import test_map2kf as TM  # noqa: E402
 what = sys.argv[1] if len(sys.argv) > 1 else "map2kf_points"
 fast = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+min_matches = int(sys.argv[4]) if len(sys.argv) > 4 else None       # default: 10 (map<->KF) / 20 (KF<->KF) as the bench's records
 ctx = plslam_amd.Context(0)
 cam = plslam_amd.make_cam(**synth.EUROC)
 fm = TM.fast_cfg(enabled=fast)
@@ -26,13 +27,13 @@ if what.startswith("map2kf"):
     n_map, n_kf = (10000, 1500) if kind == "points" else (2000, 200)
     s = TM.scene(n_map, n_kf, lines=(kind == "lines"), seed=n_map + 1)
     a = (s["Twf"], s["LM"], s["med"], s["cand"], s["kf_desc"], s["kf_feat"], s["kf_idx"])
-    call = lambda: ctx.map2kf_match_fast(kind, cam, *a, 0.9, True, 1.5, 10, fm, kf_seg=s.get("kf_seg"))   # noqa: E731
+    call = lambda: ctx.map2kf_match_fast(kind, cam, *a, 0.9, True, 1.5, 10 if min_matches is None else min_matches, fm, kf_seg=s.get("kf_seg"))   # noqa: E731
     extra = f"candidates {int(np.count_nonzero(s['cand']))} of {n_map}, unmatched keyframe features {int((s['kf_idx'] == -1).sum())}"
 else:
     n = 1500 if kind == "points" else 200
     s = TM.kf_pair(n, n - 100, lines=(kind == "lines"), seed=n)
     a = (s["DT"], s["X"], s["d_prev"], s["feat"], s["d_curr"])
-    call = lambda: ctx.kf2kf_match(kind, cam, *a, 0.75, True, 20, fm)   # noqa: E731
+    call = lambda: ctx.kf2kf_match(kind, cam, *a, 0.75, True, 20 if min_matches is None else min_matches, fm)   # noqa: E731
     extra = ""
 for _ in range(5):
     out = call()
@@ -40,4 +41,4 @@ t0 = time.perf_counter()
 for _ in range(reps):
     call()
 dt = (time.perf_counter() - t0) / reps
-print(f"{what} fast_matching {fast}: {1e6 * dt:.1f} us per call over {reps} calls; result count {out[1]}; {extra}")
+print(f"{what} fast_matching {fast}: {1e6 * dt:.1f} us per call over {reps} calls; result count {out[1]}, match() used {out[2]}; {extra}")

@@ -40,4 +40,4 @@ for name, mk, n in (("points_1500x1500", point_case, 1500), ("lines_200x200", li
             ts.append(time.perf_counter() - t0)
         ts = np.array(ts) * 1e6
         print(f"{name} dense {ctx.get_option('grid_dense')} zero_copy_kb {zc:5d}: median {np.median(ts):6.1f} us  p10 {np.percentile(ts, 10):6.1f}  p90 {np.percentile(ts, 90):6.1f}  ({k} matches, bit-exact vs the oracle)")
-ctx.set_option("zero_copy_kb", 0)
+ctx.set_option("zero_copy_kb", 64)
