@@ -1135,11 +1135,12 @@ def secondary_records(ctx, dev, args, note, main_tables=None, streams=None):
         if kind == "pt":
             fn = lambda: ctx.lba_point_rows_dev(cam, 1e-7, g["T_kf_w"].data_ptr(), X.data_ptr(), big["obs_uv"].data_ptr(),  # noqa: E731
                                                 big["pt_lm"].data_ptr(), big["pt_kf"].data_ptr(), nb, Jp.data_ptr(),
-                                                Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), s_)
+                                                Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), s_, n_pose_slots=int(g["T_kf_w"].shape[0]))
         else:
             fn = lambda: ctx.lba_line_rows_dev(cam, 1e-7, False, g["T_kf_w"].data_ptr(), X.data_ptr(),  # noqa: E731
                                                big["l_obs"].data_ptr(), big["ls_lm"].data_ptr(), big["ls_kf"].data_ptr(), nb,
-                                               Jp.data_ptr(), Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), s_)
+                                               Jp.data_ptr(), Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), s_,
+                                               n_pose_slots=int(g["T_kf_w"].shape[0]))
         return ev_time(fn, iters=30 if nrep > 1 else 200, warm=5)
     ms_p1, ms_l1 = rows("pt", npt, 1), rows("ls", nls, 1)
     ms_pb0, ms_lb0 = rows("pt", npt, reps_pt[0]), rows("ls", nls, reps_ls[0])

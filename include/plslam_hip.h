@@ -40,7 +40,7 @@ extern "C" {
 
 /* 2: plslam_match_problem grew (keep_prior, reserved: 56 bytes), plslam_lba_plan_iterate's flags became a bit mask, options
  * "mfma_form" 3/4 and "exact_second"; 3 (round 4): "mfma_form" 5 (the default), "post_fuse", plslam_match_plan_key_state;
- * 4 (round 5): plslam_match_plan_set_wire16, the Schur step, plslam_lba_plan_host_state; 5 (round 6): plslam_lba_plan_get_landmarks, plslam_lba_plan_iterate_schur / _apply_step, plslam_match_plan_step_gather / _gather_sync, plslam_rccl_use.
+ * 4 (round 5): plslam_match_plan_set_wire16, the Schur step, plslam_lba_plan_host_state; 5 (round 6): plslam_lba_plan_get_landmarks, plslam_lba_plan_iterate_schur / _apply_step, plslam_lba_point_rows_dev_n / _line_rows_dev_n, plslam_match_plan_step_gather / _gather_sync, plslam_rccl_use.
  * Clients compare plslam_abi_version() with the value they were compiled against. */
 #define PLSLAM_ABI_VERSION 5
 #define PLSLAM_DESC_BYTES 32
@@ -460,6 +460,18 @@ int plslam_lba_line_rows_dev(plslam_ctx* ctx, const plslam_cam* K, double homog_
                              const double* l_obs, const int32_t* lm_loc, const int32_t* kf_slot,
                              int32_t nobs, double* J_pose, double* J_lm, double* r, double* w,
                              void* stream);
+/* The same with the length of T_kf_w stated (ABI v5, round 6): n_pose_slots = the number of 4 x 4 matrices behind T_kf_w (> max
+ * kf_slot).  The kernels then keep the first 32 of them in LDS instead of gathering them from global memory row by row: K3 at C3
+ * sizes 0.345 -> 0.276 ms per 12.8 M rows.  n_pose_slots = 0 is the call above.  Identical rows. */
+int plslam_lba_point_rows_dev_n(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                                const double* T_kf_w, int32_t n_pose_slots, const double* Xw, const double* obs_uv,
+                                const int32_t* lm_loc, const int32_t* kf_slot, int32_t nobs,
+                                double* J_pose, double* J_lm, double* r, double* w, void* stream);
+int plslam_lba_line_rows_dev_n(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                               int compat_iter_pass, const double* T_kf_w, int32_t n_pose_slots, const double* Lw,
+                               const double* l_obs, const int32_t* lm_loc, const int32_t* kf_slot,
+                               int32_t nobs, double* J_pose, double* J_lm, double* r, double* w,
+                               void* stream);
 
 /* ---- K7-K10: normal equations of the local BA in block form ------------------------------- */
 /* Replaces the accumulation into the dense H / g of levMarquardtOptimizationLBA

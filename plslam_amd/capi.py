@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "plslam_lba_plan_rows", "plslam_lba_plan_destroy", "plslam_lba_plan_iterate_dev", "plslam_lba_plan_device_blocks", "plslam_lba_plan_device_state",
     "plslam_lba_plan_iterate_resident", "plslam_lba_plan_diag_max", "plslam_lba_plan_schur", "plslam_lba_plan_backsub",
     "plslam_lba_plan_set_poses", "plslam_lba_plan_host_state", "plslam_lba_plan_get_landmarks",
-    "plslam_lba_plan_iterate_schur", "plslam_lba_plan_apply_step",
+    "plslam_lba_plan_iterate_schur", "plslam_lba_plan_apply_step", "plslam_lba_point_rows_dev_n", "plslam_lba_line_rows_dev_n",
     "plslam_lba_plan_blocks",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
@@ -212,6 +212,8 @@ def load() -> C.CDLL:
                                            vp, vp, vp, vp, vp]
     L.plslam_lba_assemble.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp,
                                       vp, vp, vp, vp, vp, vp, vp]
+    L.plslam_lba_point_rows_dev_n.argtypes = [vp, C.POINTER(Cam), f64, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
+    L.plslam_lba_line_rows_dev_n.argtypes = [vp, C.POINTER(Cam), f64, C.c_int, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     L.plslam_lba_plan_create.argtypes = [vp, C.POINTER(Cam), f64, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp,
                                          i32, C.POINTER(vp)]
     L.plslam_lba_plan_iterate.argtypes = [vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
@@ -726,15 +728,16 @@ class Context:
         return out, n.value, used.value
 
     # ---- device-pointer calls ----------------------------------------------------------------
-    def lba_point_rows_dev(self, cam, homog_th, T, Xw, uv, lm, kf, nobs, Jp, Jl, r, w, stream=0):
-        _check(self._L.plslam_lba_point_rows_dev(self._h, C.byref(cam), float(homog_th), T, Xw, uv, lm, kf,
-                                                 int(nobs), Jp, Jl, r, w, stream or None),
-               "plslam_lba_point_rows_dev")
+    def lba_point_rows_dev(self, cam, homog_th, T, Xw, uv, lm, kf, nobs, Jp, Jl, r, w, stream=0, n_pose_slots=0):
+        """n_pose_slots: how many 4 x 4 matrices T holds (0 = not stated: the kernels gather them from global memory)."""
+        _check(self._L.plslam_lba_point_rows_dev_n(self._h, C.byref(cam), float(homog_th), T, int(n_pose_slots), Xw, uv, lm, kf,
+                                                   int(nobs), Jp, Jl, r, w, stream or None),
+               "plslam_lba_point_rows_dev_n")
 
-    def lba_line_rows_dev(self, cam, homog_th, compat, T, Lw, lo, lm, kf, nobs, Jp, Jl, r, w, stream=0):
-        _check(self._L.plslam_lba_line_rows_dev(self._h, C.byref(cam), float(homog_th), int(bool(compat)), T,
-                                                Lw, lo, lm, kf, int(nobs), Jp, Jl, r, w, stream or None),
-               "plslam_lba_line_rows_dev")
+    def lba_line_rows_dev(self, cam, homog_th, compat, T, Lw, lo, lm, kf, nobs, Jp, Jl, r, w, stream=0, n_pose_slots=0):
+        _check(self._L.plslam_lba_line_rows_dev_n(self._h, C.byref(cam), float(homog_th), int(bool(compat)), T, int(n_pose_slots),
+                                                  Lw, lo, lm, kf, int(nobs), Jp, Jl, r, w, stream or None),
+               "plslam_lba_line_rows_dev_n")
 
     def plan(self, problems) -> "MatchPlan":
         return MatchPlan(self, problems)

@@ -1470,17 +1470,40 @@ int plslam_knn2_hamming256(plslam_ctx* ctx, const uint8_t* q, int32_t nq, const 
 }
 
 // ---- LBA rows --------------------------------------------------------------------------------
+int plslam_lba_point_rows_dev_n(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                                const double* T_kf_w, int32_t n_pose_slots, const double* Xw, const double* obs_uv,
+                                const int32_t* lm_loc, const int32_t* kf_slot, int32_t nobs,
+                                double* J_pose, double* J_lm, double* r, double* w, void* stream)
+{
+    PLSLAM_REQUIRE(ctx && K && nobs >= 0 && n_pose_slots >= 0, PLSLAM_EINVAL);
+    if (nobs == 0) return PLSLAM_OK;
+    PLSLAM_REQUIRE(T_kf_w && Xw && obs_uv && lm_loc && kf_slot && J_pose && J_lm && r && w, PLSLAM_EINVAL);
+    DeviceGuard g(ctx->device);
+    return launch_point_rows(*K, homog_th, T_kf_w, Xw, obs_uv, lm_loc, kf_slot, nobs, J_pose, J_lm, r, w,
+                             stream ? static_cast<hipStream_t>(stream) : ctx->stream, n_pose_slots);
+}
+
 int plslam_lba_point_rows_dev(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
                               const double* T_kf_w, const double* Xw, const double* obs_uv,
                               const int32_t* lm_loc, const int32_t* kf_slot, int32_t nobs,
                               double* J_pose, double* J_lm, double* r, double* w, void* stream)
 {
-    PLSLAM_REQUIRE(ctx && K && nobs >= 0, PLSLAM_EINVAL);
+    return plslam_lba_point_rows_dev_n(ctx, K, homog_th, T_kf_w, 0, Xw, obs_uv, lm_loc, kf_slot, nobs, J_pose, J_lm, r, w, stream);
+}
+
+int plslam_lba_line_rows_dev_n(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
+                               int compat_iter_pass, const double* T_kf_w, int32_t n_pose_slots, const double* Lw,
+                               const double* l_obs, const int32_t* lm_loc, const int32_t* kf_slot,
+                               int32_t nobs, double* J_pose, double* J_lm, double* r, double* w,
+                               void* stream)
+{
+    PLSLAM_REQUIRE(ctx && K && nobs >= 0 && n_pose_slots >= 0, PLSLAM_EINVAL);
     if (nobs == 0) return PLSLAM_OK;
-    PLSLAM_REQUIRE(T_kf_w && Xw && obs_uv && lm_loc && kf_slot && J_pose && J_lm && r && w, PLSLAM_EINVAL);
+    PLSLAM_REQUIRE(T_kf_w && Lw && l_obs && lm_loc && kf_slot && J_pose && J_lm && r && w, PLSLAM_EINVAL);
     DeviceGuard g(ctx->device);
-    return launch_point_rows(*K, homog_th, T_kf_w, Xw, obs_uv, lm_loc, kf_slot, nobs, J_pose, J_lm, r, w,
-                             stream ? static_cast<hipStream_t>(stream) : ctx->stream);
+    return launch_line_rows(*K, homog_th, compat_iter_pass ? 1 : 0, T_kf_w, Lw, l_obs, lm_loc, kf_slot,
+                            nobs, J_pose, J_lm, r, w,
+                            stream ? static_cast<hipStream_t>(stream) : ctx->stream, n_pose_slots);
 }
 
 int plslam_lba_line_rows_dev(plslam_ctx* ctx, const plslam_cam* K, double homog_th,
@@ -1489,13 +1512,8 @@ int plslam_lba_line_rows_dev(plslam_ctx* ctx, const plslam_cam* K, double homog_
                              int32_t nobs, double* J_pose, double* J_lm, double* r, double* w,
                              void* stream)
 {
-    PLSLAM_REQUIRE(ctx && K && nobs >= 0, PLSLAM_EINVAL);
-    if (nobs == 0) return PLSLAM_OK;
-    PLSLAM_REQUIRE(T_kf_w && Lw && l_obs && lm_loc && kf_slot && J_pose && J_lm && r && w, PLSLAM_EINVAL);
-    DeviceGuard g(ctx->device);
-    return launch_line_rows(*K, homog_th, compat_iter_pass ? 1 : 0, T_kf_w, Lw, l_obs, lm_loc, kf_slot,
-                            nobs, J_pose, J_lm, r, w,
-                            stream ? static_cast<hipStream_t>(stream) : ctx->stream);
+    return plslam_lba_line_rows_dev_n(ctx, K, homog_th, compat_iter_pass, T_kf_w, 0, Lw, l_obs, lm_loc, kf_slot, nobs, J_pose, J_lm, r, w,
+                                      stream);
 }
 
 
@@ -1537,11 +1555,11 @@ static int lba_rows_host(plslam_ctx* ctx, const plslam_cam* K, double th, int li
     if (!lines)
         rc = launch_point_rows(*K, th, (double*)(di + oT), (double*)(di + oL), (double*)(di + oO),
                                (int32_t*)(di + oLm), (int32_t*)(di + oKf), nobs, (double*)(dout + oJp),
-                               (double*)(dout + oJl), (double*)(dout + oR), (double*)(dout + oW), s);
+                               (double*)(dout + oJl), (double*)(dout + oR), (double*)(dout + oW), s, nkf);
     else
         rc = launch_line_rows(*K, th, compat, (double*)(di + oT), (double*)(di + oL), (double*)(di + oO),
                               (int32_t*)(di + oLm), (int32_t*)(di + oKf), nobs, (double*)(dout + oJp),
-                              (double*)(dout + oJl), (double*)(dout + oR), (double*)(dout + oW), s);
+                              (double*)(dout + oJl), (double*)(dout + oR), (double*)(dout + oW), s, nkf);
     if (rc) return rc;
     PLSLAM_HIP_CHECK(hipMemcpyAsync(Jp, dout + oJp, (size_t)nobs * 48, hipMemcpyDeviceToHost, s));
     PLSLAM_HIP_CHECK(hipMemcpyAsync(Jl, dout + oJl, (size_t)nobs * lmw * 8, hipMemcpyDeviceToHost, s));

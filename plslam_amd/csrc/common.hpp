@@ -343,10 +343,10 @@ int launch_gather_rows(const void* src, const int32_t* idx, int32_t n, int32_t r
 // --- LBA rows + gates (lba.hip) --------------------------------------------------------------
 int launch_point_rows(const plslam_cam& K, double th, const double* T, const double* Xw,
                       const double* uv, const int32_t* lm, const int32_t* kf, int32_t nobs,
-                      double* Jp, double* Jl, double* r, double* w, hipStream_t s);
+                      double* Jp, double* Jl, double* r, double* w, hipStream_t s, int32_t n_pose_slots = 0);
 int launch_line_rows(const plslam_cam& K, double th, int compat, const double* T, const double* Lw,
                      const double* lobs, const int32_t* lm, const int32_t* kf, int32_t nobs,
-                     double* Jp, double* Jl, double* r, double* w, hipStream_t s);
+                     double* Jp, double* Jl, double* r, double* w, hipStream_t s, int32_t n_pose_slots = 0);
 int launch_point_gate(const plslam_cam& K, const double* Twf16, const double* Xw, const int32_t* m12,
                       int32_t nq, const double* pl, double th, uint8_t* mask, int32_t* count,
                       hipStream_t s);

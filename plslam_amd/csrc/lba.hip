@@ -14,17 +14,26 @@ __global__ void __launch_bounds__(256)
 k_point_rows(CamD K, double th, const double* __restrict__ T, const double* __restrict__ Xw,
              const double* __restrict__ uv, const int32_t* __restrict__ lm,
              const int32_t* __restrict__ kf, int32_t nobs, double* __restrict__ Jp,
-             double* __restrict__ Jl, double* __restrict__ r, double* __restrict__ w)
+             double* __restrict__ Jl, double* __restrict__ r, double* __restrict__ w, int32_t n_pose_slots)
 {
     __shared__ __attribute__((aligned(16))) double slabs[4][64 * 6];
+    __shared__ PoseCache<PLSLAM_POSE_LINES> poses;
     const int o = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int o0 = o - lane;                                 // first observation of this wave
+    const int oc = o < nobs ? o : nobs - 1;                  // clamp: tail lanes recompute the last row
+    // every load a row needs goes out before the workgroup's one barrier: slot number, landmark index, observation, the copy of
+    // the pose matrices into LDS, the landmark
+    const int32_t slot = kf[oc], l = lm[oc];
+    const double2 ob = reinterpret_cast<const double2*>(uv)[oc];
+    pose_cache_fill(poses, T, n_pose_slots);
+    double X3[3], T12[12];
+    load3(Xw + 3 * (size_t)l, X3);
+    pose12_take(poses, T, n_pose_slots, slot, T12);          // (every wave of the workgroup: a barrier inside)
     if (o0 >= nobs) return;                                  // whole wave out of range (wave-uniform)
     const int valid = nobs - o0 < 64 ? nobs - o0 : 64;
-    const int oc = o < nobs ? o : nobs - 1;                  // clamp: tail lanes recompute the last row
     double out6[6], out3[3], nrm, wgt;
-    point_row(K, th, T + 16 * (size_t)kf[oc], Xw + 3 * (size_t)lm[oc], reinterpret_cast<const double2*>(uv)[oc], out6, out3, nrm, wgt);
+    point_row(K, th, T12, X3, ob, out6, out3, nrm, wgt);
     wave_store_rows<6>(Jp + 6 * (size_t)o0, out6, slabs[wave], lane, valid);
     wave_store_rows<3>(Jl + 3 * (size_t)o0, out3, slabs[wave], lane, valid);
     if (o < nobs) {
@@ -33,27 +42,41 @@ k_point_rows(CamD K, double th, const double* __restrict__ T, const double* __re
     }
 }
 
-// K4: line rows
+// K4: line rows.  The pose matrices are NOT taken through LDS here (n_pose_slots is accepted and unused): measured on one box
+// (tools/r6_rows_ab.sh) 0.344 ms per 10.2 M rows with the copy against 0.326 without -- a line row's loads (9 doubles of landmark
+// and observation more than a point row's) hide the gather.  A register budget of 80 / 72 instead of the compiler's 84 (six / seven
+// waves per SIMD instead of five) changed nothing; 64 spills and doubles the time.
 __global__ void __launch_bounds__(256)
 k_line_rows(CamD K, double th, int compat, const double* __restrict__ T,
             const double* __restrict__ Lw, const double* __restrict__ lobs,
             const int32_t* __restrict__ lm, const int32_t* __restrict__ kf, int32_t nobs,
             double* __restrict__ Jp, double* __restrict__ Jl, double* __restrict__ r,
-            double* __restrict__ w)
+            double* __restrict__ w, int32_t n_pose_slots)
 {
     __shared__ __attribute__((aligned(16))) double slabs[4][64 * 6];
     const int o = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int o0 = o - lane;
+    const int oc = o < nobs ? o : nobs - 1;
+    const int32_t slot = kf[oc];
+    const size_t l0 = (size_t)lm[oc];
+    double PQ[6], lo[3], T12[12];
+    load3(lobs + 3 * (size_t)oc, lo);
+    (void)n_pose_slots;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T12[e] = g_(T)[(size_t)slot * 16 + e];
+    if (compat) {                                            // (the iteration pass's quirk: both end points = the 3 doubles at 3 l0)
+        double P3[3];
+        load3(Lw + 3 * l0, P3);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) PQ[a] = PQ[3 + a] = P3[a];
+    } else {
+        load6(Lw + 6 * l0, PQ);
+    }
     if (o0 >= nobs) return;
     const int valid = nobs - o0 < 64 ? nobs - o0 : 64;
-    const int oc = o < nobs ? o : nobs - 1;
     double outl[6], outp[6], nrm, wgt;
-    const size_t l0 = (size_t)lm[oc];
-    const double* Pw = compat ? Lw + 3 * l0 : Lw + 6 * l0;
-    const double* Qw = compat ? Lw + 3 * l0 : Lw + 6 * l0 + 3;
-    line_row(K, th, T + 16 * (size_t)kf[oc], Pw, Qw, lobs[3 * (size_t)oc], lobs[3 * (size_t)oc + 1], lobs[3 * (size_t)oc + 2], outl, outp,
-             nrm, wgt);
+    line_row(K, th, T12, PQ, PQ + 3, lo[0], lo[1], lo[2], outl, outp, nrm, wgt);
     wave_store_rows<6>(Jl + 6 * (size_t)o0, outl, slabs[wave], lane, valid);
     wave_store_rows<6>(Jp + 6 * (size_t)o0, outp, slabs[wave], lane, valid);
     if (o < nobs) {
@@ -172,22 +195,22 @@ static Pose12 pose12(const double* T16)
 
 int launch_point_rows(const plslam_cam& K, double th, const double* T, const double* Xw,
                       const double* uv, const int32_t* lm, const int32_t* kf, int32_t nobs,
-                      double* Jp, double* Jl, double* r, double* w, hipStream_t s)
+                      double* Jp, double* Jl, double* r, double* w, hipStream_t s, int32_t n_pose_slots)
 {
     if (nobs <= 0) return PLSLAM_OK;
     hipLaunchKernelGGL(k_point_rows, dim3((nobs + 255) / 256), dim3(256), 0, s, cam_d(K), th, T, Xw,
-                       uv, lm, kf, nobs, Jp, Jl, r, w);
+                       uv, lm, kf, nobs, Jp, Jl, r, w, n_pose_slots);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
 
 int launch_line_rows(const plslam_cam& K, double th, int compat, const double* T, const double* Lw,
                      const double* lobs, const int32_t* lm, const int32_t* kf, int32_t nobs,
-                     double* Jp, double* Jl, double* r, double* w, hipStream_t s)
+                     double* Jp, double* Jl, double* r, double* w, hipStream_t s, int32_t n_pose_slots)
 {
     if (nobs <= 0) return PLSLAM_OK;
     hipLaunchKernelGGL(k_line_rows, dim3((nobs + 255) / 256), dim3(256), 0, s, cam_d(K), th, compat, T,
-                       Lw, lobs, lm, kf, nobs, Jp, Jl, r, w);
+                       Lw, lobs, lm, kf, nobs, Jp, Jl, r, w, n_pose_slots);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

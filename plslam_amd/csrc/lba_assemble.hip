@@ -217,6 +217,7 @@ struct LbaIterArgs {
     const double *T, *Xw, *Lw, *uv, *lobs;
     const int32_t *pt_lm, *pt_slot, *pt_kf_loc, *ls_lm, *ls_slot, *ls_kf_loc;
     int32_t np, nl, nbp, nbl;                 // observations and row workgroups (points, lines)
+    int32_t n_slots;                          // pose slots behind T (the first of them ride in LDS: pose12_cached)
     double *pJp, *pJl, *pr, *pw, *lJp, *lJl, *lr, *lw, *Wp, *Wl, *err_part;   // err_part[nbp + nbl]
 };
 
@@ -227,11 +228,36 @@ k_lba_rows_cross(const LbaIterArgs A)
     // 36 instructions of 64 scattered 8-byte stores each)
     __shared__ __attribute__((aligned(16))) double slabs[4][64 * 18];
     __shared__ double red[256];
+    __shared__ PoseCache<PLSLAM_POSE_LINES> poses;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool lines = (int)blockIdx.x >= A.nbp;
     const int nobs = lines ? A.nl : A.np;
     const int o = (lines ? (int)blockIdx.x - A.nbp : (int)blockIdx.x) * 256 + (int)threadIdx.x;
     const int o0 = o - lane;
+    // every load a row needs goes out before the workgroup's one barrier (lba_rows_dev.hpp: pose_cache_fill): slot number, landmark
+    // index, observation, the pose matrices' copy into LDS, the landmark
+    double T12[12], LM6[6], ob3[3];
+    {
+        const int oq = o < nobs ? o : nobs - 1;
+        const int32_t slot = (lines ? A.ls_slot : A.pt_slot)[oq];
+        const size_t l0 = (size_t)(lines ? A.ls_lm : A.pt_lm)[oq];
+        if (!lines) {
+            const double2 ob = reinterpret_cast<const double2*>(A.uv)[oq];
+            ob3[0] = ob.x; ob3[1] = ob.y; ob3[2] = 0.0;
+        } else {
+            load3(A.lobs + 3 * (size_t)oq, ob3);
+        }
+        pose_cache_fill(poses, A.T, A.n_slots);
+        if (!lines || A.compat_iter) {                       // (the iteration pass's quirk: both end points = the 3 doubles at 3 l0)
+            double P3[3];
+            load3((lines ? A.Lw : A.Xw) + 3 * l0, P3);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) LM6[a] = LM6[3 + a] = P3[a];
+        } else {
+            load6(A.Lw + 6 * l0, LM6);
+        }
+        pose12_take(poses, A.T, A.n_slots, slot, T12);       // (every wave of the workgroup: a barrier inside)
+    }
     double e2w = 0.0;
     if (o0 < nobs) {                                         // (wave-uniform)
         const int valid = nobs - o0 < 64 ? nobs - o0 : 64;
@@ -239,8 +265,9 @@ k_lba_rows_cross(const LbaIterArgs A)
         double nrm, wgt;
         if (!lines) {
             double out6[6], out3[3];
-            point_row(A.K, A.th, A.T + 16 * (size_t)A.pt_slot[oc], A.Xw + 3 * (size_t)A.pt_lm[oc],
-                      reinterpret_cast<const double2*>(A.uv)[oc], out6, out3, nrm, wgt);
+            double2 ob;
+            ob.x = ob3[0]; ob.y = ob3[1];
+            point_row(A.K, A.th, T12, LM6, ob, out6, out3, nrm, wgt);
             wave_store_rows<6>(A.pJp + 6 * (size_t)o0, out6, slabs[wave], lane, valid);
             wave_store_rows<3>(A.pJl + 3 * (size_t)o0, out3, slabs[wave], lane, valid);
             if (o < nobs) {
@@ -256,11 +283,7 @@ k_lba_rows_cross(const LbaIterArgs A)
             wave_store_rows<18>(A.Wp + 18 * (size_t)o0, w18, slabs[wave], lane, valid);
         } else {
             double outl[6], outp[6];
-            const size_t l0 = (size_t)A.ls_lm[oc];
-            const double* Pw = A.compat_iter ? A.Lw + 3 * l0 : A.Lw + 6 * l0;
-            const double* Qw = A.compat_iter ? A.Lw + 3 * l0 : A.Lw + 6 * l0 + 3;
-            line_row(A.K, A.th, A.T + 16 * (size_t)A.ls_slot[oc], Pw, Qw, A.lobs[3 * (size_t)oc], A.lobs[3 * (size_t)oc + 1],
-                     A.lobs[3 * (size_t)oc + 2], outl, outp, nrm, wgt);
+            line_row(A.K, A.th, T12, LM6, LM6 + 3, ob3[0], ob3[1], ob3[2], outl, outp, nrm, wgt);
             wave_store_rows<6>(A.lJl + 6 * (size_t)o0, outl, slabs[wave], lane, valid);
             wave_store_rows<6>(A.lJp + 6 * (size_t)o0, outp, slabs[wave], lane, valid);
             if (o < nobs) {
@@ -736,7 +759,7 @@ static int lba_plan_enqueue(plslam_lba_plan* P, const double* T_kf_w, const doub
     A.uv = (double*)(ds + P->oPuv); A.lobs = (double*)(ds + P->oLobs);
     A.pt_lm = (int32_t*)(ds + P->oPlm); A.pt_slot = (int32_t*)(ds + P->oPslot); A.pt_kf_loc = (int32_t*)(ds + P->oPkf);
     A.ls_lm = (int32_t*)(ds + P->oLlm); A.ls_slot = (int32_t*)(ds + P->oLslot); A.ls_kf_loc = (int32_t*)(ds + P->oLkf);
-    A.np = P->np; A.nl = P->nl; A.nbp = nbp; A.nbl = nbl;
+    A.np = P->np; A.nl = P->nl; A.nbp = nbp; A.nbl = nbl; A.n_slots = P->n_slots;
     A.pJp = (double*)(dr + P->oPJp); A.pJl = (double*)(dr + P->oPJl); A.pr = (double*)(dr + P->oPr); A.pw = (double*)(dr + P->oPw);
     A.lJp = (double*)(dr + P->oLJp); A.lJl = (double*)(dr + P->oLJl); A.lr = (double*)(dr + P->oLr); A.lw = (double*)(dr + P->oLw);
     A.Wp = (double*)(dout + P->oWp); A.Wl = (double*)(dout + P->oWl); A.err_part = (double*)(dout + P->oErrPart);

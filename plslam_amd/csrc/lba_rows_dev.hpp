@@ -33,6 +33,70 @@ __device__ __forceinline__ void inv_pose(const double* __restrict__ T, double R[
     }
 }
 
+// A landmark's 3 (or 6) doubles with the fewest load instructions: a 16-byte load needs dword alignment only on this hardware,
+// so a row of 24 bytes at an 8-byte aligned address is one 16-byte load and one of 8 -- gathers touch 64 cache lines per
+// instruction whatever their width, and the vector memory path is what the row kernels wait for.
+typedef double f64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ void load3(const double* __restrict__ p, double (&v)[3])
+{
+    const f64x2_a8 a = *reinterpret_cast<PLSLAM_AS1 const f64x2_a8*>(g_(p));
+    v[0] = a.x; v[1] = a.y; v[2] = g_(p)[2];
+}
+__device__ __forceinline__ void load6(const double* __restrict__ p, double (&v)[6])
+{
+    const PLSLAM_AS1 f64x2_a8* q = reinterpret_cast<PLSLAM_AS1 const f64x2_a8*>(g_(p));
+    const f64x2_a8 a = q[0], b = q[1], c = q[2];
+    v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y; v[4] = c.x; v[5] = c.y;
+}
+
+// The pose matrices of a workgroup's rows through LDS (round 6).  A row reads the first 12 doubles of its keyframe's 4 x 4; the
+// lanes of a wave name a handful of keyframes between them, and 12 loads of 64 addresses each, nearly all equal, kept the vector
+// memory path as busy as the row stores did (K3 at C3 sizes, same box: 0.345 -> 0.276 ms per launch with the matrices in LDS).
+// The workgroup copies the first min(n_pose_slots, NC) matrices into LDS -- loads that wait for nothing, beside the loads of the
+// rows' slot numbers -- and a row whose slot is among them reads LDS, any other one global memory as before.  n_pose_slots = how
+// many matrices the caller says the array holds (0: unknown -- nothing is copied).  A first form that cached the slots the
+// workgroup's rows NAME (no count needed) chained slot numbers -> tags -> matrices -> rows through two barriers and was no
+// faster than the global loads.  Every thread of the workgroup calls pose_cache_fill and pose12_take (one barrier).
+#ifndef PLSLAM_POSE_LINES
+#define PLSLAM_POSE_LINES 32
+#endif
+template <int NC>
+struct PoseCache {
+    double T[NC * 16];
+};
+// pose_cache_fill: the copy's loads and LDS stores (no barrier) -- the caller issues its rows' own loads (slot numbers, landmark
+// indices, observations, the landmark gather) AROUND it, so that the matrices arrive beside them and the one barrier
+// (pose12_take) waits for nothing a row would not have waited for anyway.  A first placement had the landmark index loaded behind
+// the barrier: three dependent round trips per row instead of two, and no gain over the global loads.
+template <int NC>
+__device__ __forceinline__ void pose_cache_fill(PoseCache<NC>& c, const double* __restrict__ Tg, int32_t n_pose_slots)
+{
+    static_assert(NC * 16 <= 512, "two loads per lane of a 256-lane workgroup");
+    const int n16 = (n_pose_slots < NC ? n_pose_slots : NC) * 16, i0 = threadIdx.x, i1 = threadIdx.x + blockDim.x;
+    double a = 0.0, b = 0.0;
+    if (i0 < n16) a = g_(Tg)[i0];
+    if (i1 < n16) b = g_(Tg)[i1];
+    if (i0 < n16) c.T[i0] = a;
+    if (i1 < n16) c.T[i1] = b;
+}
+template <int NC>
+__device__ __forceinline__ void pose12_take(PoseCache<NC>& c, const double* __restrict__ Tg, int32_t n_pose_slots, int32_t slot,
+                                            double (&T12)[12])
+{
+    const int ncache = n_pose_slots < NC ? n_pose_slots : NC;
+    __syncthreads();
+    // (the two address spaces spelt out: one pointer chosen between them would be a generic one -- FLAT loads)
+    typedef __attribute__((address_space(3))) const double* lds_f64;
+    if (slot < ncache) {
+        const lds_f64 lt = (lds_f64)c.T + slot * 16;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T12[e] = lt[e];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) T12[e] = g_(Tg)[(size_t)slot * 16 + e];
+    }
+}
+
 __device__ __forceinline__ void xform(const double R[9], const double t[3], const double* X,
                                       double o[3])
 {

@@ -37,6 +37,67 @@ def test_c3_point_and_line_rows(ctx, oracle):
         assert _close(g, e, RTOL) and _close(g, e, 1e-12)
 
 
+def test_rows_with_more_pose_slots_than_the_workgroups_cache_has_lines(ctx, oracle):
+    """The row kernels keep their workgroup's pose matrices in a direct-mapped LDS cache of 32 lines (round 6): 70 key frames whose
+    observations are shuffled put several slots on one line in every workgroup -- the losers read global memory.  Same rows as
+    the oracle's, for the row kernels and for the plan's fused iteration (err and gradient against the dense accumulation)."""
+    lm = synth.local_map(n_kf=70, n_pt=3000, n_ls=600, obs_per_lm=6, seed=5)
+    cam, ocam = _cams()
+    rng = np.random.Generator(np.random.PCG64(9))
+    pp, pl = rng.permutation(lm["pt_lm"].shape[0]), rng.permutation(lm["ls_lm"].shape[0])
+    pt = {k: lm[k][pp] for k in ("obs_uv", "pt_lm", "pt_kf")}
+    ls = {k: lm[k][pl] for k in ("l_obs", "ls_lm", "ls_kf")}
+    got = ctx.lba_point_rows(cam, 1e-7, lm["T_kf_w"], lm["Xw"], pt["obs_uv"], pt["pt_lm"], pt["pt_kf"])
+    exp = oracle.lba_point_rows(ocam, 1e-7, lm["T_kf_w"], lm["Xw"], pt["obs_uv"], pt["pt_lm"], pt["pt_kf"])
+    for g, e in zip(got, exp):
+        assert _close(g, e, 1e-12)
+    for compat in (False, True):
+        got = ctx.lba_line_rows(cam, 1e-7, lm["T_kf_w"], lm["Lw"], ls["l_obs"], ls["ls_lm"], ls["ls_kf"], compat_iter_pass=compat)
+        exp = oracle.lba_line_rows(ocam, 1e-7, lm["T_kf_w"], lm["Lw"], ls["l_obs"], ls["ls_lm"], ls["ls_kf"], compat_iter_pass=compat)
+        for g, e in zip(got, exp):
+            assert _close(g, e, 1e-12)
+    nkf, npt, nls = 69, 3000, 600
+    plan = plslam_amd.LbaPlan(ctx, cam, 1e-7, 70, nkf, npt, nls, pt["pt_lm"], pt["pt_kf"], pt["pt_kf"] - 1, pt["obs_uv"],
+                              ls["ls_lm"], ls["ls_kf"], ls["ls_kf"] - 1, ls["l_obs"])
+    B = plan.iterate(lm["T_kf_w"], lm["Xw"], lm["Lw"])
+    rp = oracle.lba_point_rows(ocam, 1e-7, lm["T_kf_w"], lm["Xw"], pt["obs_uv"], pt["pt_lm"], pt["pt_kf"])
+    rl = oracle.lba_line_rows(ocam, 1e-7, lm["T_kf_w"], lm["Lw"], ls["l_obs"], ls["ls_lm"], ls["ls_kf"])
+    H, g, e1 = oracle.lba_accumulate("points", nkf, npt, nls, pt["pt_lm"], pt["pt_kf"] - 1, *rp)
+    H, g, e2 = oracle.lba_accumulate("lines", nkf, npt, nls, ls["ls_lm"], ls["ls_kf"] - 1, *rl, H=H, g=g)
+    assert np.allclose(B["g"], g, rtol=0, atol=1e-9 * np.abs(g).max())
+    assert abs(B["err"] - (e1 + e2)) <= 1e-9 * (e1 + e2)
+    plan.close()
+
+
+def test_device_pointer_rows_with_and_without_the_pose_count(ctx):
+    """plslam_lba_point_rows_dev_n / _line_rows_dev_n (round 6): stating how many pose matrices T holds lets the kernels keep the
+    first 32 in LDS; the rows are the same words as with the count left out (0), for 70 slots (38 of them beyond the cache) and 10."""
+    import torch
+    dev = torch.device("cuda", 0)
+    cam, _ = _cams()
+    for n_kf in (70, 10):
+        lm = synth.local_map(n_kf=n_kf, n_pt=2000, n_ls=500, obs_per_lm=5, seed=n_kf)
+        g = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in lm.items()}
+        for kind in ("pt", "ls"):
+            n = lm["pt_lm" if kind == "pt" else "ls_lm"].shape[0]
+            outs = []
+            for slots in (0, n_kf):
+                Jp = torch.zeros((n, 6), dtype=torch.float64, device=dev)
+                Jl = torch.zeros((n, 3 if kind == "pt" else 6), dtype=torch.float64, device=dev)
+                rr, ww = torch.zeros(n, dtype=torch.float64, device=dev), torch.zeros(n, dtype=torch.float64, device=dev)
+                if kind == "pt":
+                    ctx.lba_point_rows_dev(cam, 1e-7, g["T_kf_w"].data_ptr(), g["Xw"].data_ptr(), g["obs_uv"].data_ptr(), g["pt_lm"].data_ptr(),
+                                           g["pt_kf"].data_ptr(), n, Jp.data_ptr(), Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), 0, n_pose_slots=slots)
+                else:
+                    ctx.lba_line_rows_dev(cam, 1e-7, False, g["T_kf_w"].data_ptr(), g["Lw"].data_ptr(), g["l_obs"].data_ptr(), g["ls_lm"].data_ptr(),
+                                          g["ls_kf"].data_ptr(), n, Jp.data_ptr(), Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), 0, n_pose_slots=slots)
+                torch.cuda.synchronize()
+                outs.append([t.cpu().numpy() for t in (Jp, Jl, rr, ww)])
+            for a, b in zip(*outs):
+                assert np.array_equal(a, b), (n_kf, kind)
+            assert np.abs(outs[0][0]).max() > 0
+
+
 def test_line_rows_iteration_pass_compat(ctx, oracle):
     lm = synth.local_map(n_kf=6, n_pt=0, n_ls=500, obs_per_lm=4)
     cam, ocam = _cams()

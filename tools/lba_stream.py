@@ -24,6 +24,8 @@ def main():
     cam = plslam_amd.make_cam(**synth.EUROC)
     g = {k: torch.from_numpy(np.ascontiguousarray(v)).to(dev) for k, v in lm.items()}
     reps_of = {"point": int(sys.argv[1]) if len(sys.argv) > 1 else 256, "line": int(sys.argv[2]) if len(sys.argv) > 2 else 1024}
+    # (the number of pose matrices, stated to the kernels: 0 = not stated, as before round 6; env PLSLAM_STREAM_SLOTS overrides)
+    NSLOTS = int(os.environ.get("PLSLAM_STREAM_SLOTS", lm["T_kf_w"].shape[0]))
     out = {}
     for kind, n, nlm, lmk, xk, keys, nl in (("point", lm["pt_lm"].shape[0], lm["Xw"].shape[0], "pt_lm", "Xw", ("obs_uv", "pt_kf"), 3),
                                              ("line", lm["ls_lm"].shape[0], lm["Lw"].shape[0], "ls_lm", "Lw", ("l_obs", "ls_kf"), 6)):
@@ -38,11 +40,11 @@ def main():
         ww = torch.empty(nb, dtype=torch.float64, device=dev)
         if kind == "point":
             fn = lambda: ctx.lba_point_rows_dev(cam, 1e-7, g["T_kf_w"].data_ptr(), X.data_ptr(), big["obs_uv"].data_ptr(), idx.data_ptr(),  # noqa: E731
-                                                big["pt_kf"].data_ptr(), nb, Jp.data_ptr(), Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), st.cuda_stream)
+                                                big["pt_kf"].data_ptr(), nb, Jp.data_ptr(), Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), st.cuda_stream, n_pose_slots=NSLOTS)
             moved = 8 + 16 + 88 + 24.0 * nlm / n
         else:
             fn = lambda: ctx.lba_line_rows_dev(cam, 1e-7, False, g["T_kf_w"].data_ptr(), X.data_ptr(), big["l_obs"].data_ptr(), idx.data_ptr(),  # noqa: E731
-                                               big["ls_kf"].data_ptr(), nb, Jp.data_ptr(), Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), st.cuda_stream)
+                                               big["ls_kf"].data_ptr(), nb, Jp.data_ptr(), Jl.data_ptr(), rr.data_ptr(), ww.data_ptr(), st.cuda_stream, n_pose_slots=NSLOTS)
             moved = 8 + 24 + 112 + 48.0 * nlm / n
         for _ in range(3):
             fn()
