@@ -19,6 +19,7 @@ namespace plslam {
 // many-workgroup launch)
 int grid_launch_single(const plslam_grid_problem& q, const GridDesc* d_desc, hipStream_t s, uint32_t* aux, bool n1_upper_bound,
                        const GridDesc* h_desc = nullptr);   // h_desc: the host's copy (kernels of a lone problem take it by value)
+bool grid_dense_ok(int32_t n1, int32_t n2, int64_t ncell, int32_t n_items, bool dirs, int32_t n_centres);   // the one-workgroup kernel takes it
 size_t grid_aux_words(int32_t n2);            // the words the two launches share, prefilled by grid_aux_fill in the upload image
 void grid_aux_fill(void* host_image, int32_t n2);
 // lba.hip: the visibility pre-filter AND the candidate flags, both on the device
@@ -152,8 +153,10 @@ void fill_grid_tables(int lines, const double* feat_curr, const int32_t* sel, in
 // and ctx->misc_c (kernel scratch).  Synchronises the stream once, at the end.
 int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16, const double* d_X3, int32_t nq, double sx,
               double sy, const uint8_t* d_Q, const double* feat_curr, const int32_t* sel, int32_t nt, const uint8_t* d_T,
-              const plslam_fast_matching* fm, int mutual, int32_t* d_m12, int32_t* matches)
+              const plslam_fast_matching* fm, int mutual, int32_t* d_m12, int32_t* matches, const int32_t** deferred = nullptr)
 {
+    // deferred != nullptr: nothing is waited for here -- the caller has more work for the stream and synchronises itself; then
+    // (*deferred)[0] is the count and (*deferred)[1] must be 0 ((*deferred)[0] >= 0): grid_path_check
     hipStream_t s = ctx->stream;
     StreamSyncOnError sg(s);
     int rc;
@@ -174,6 +177,13 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     if ((rc = ctx->misc_b.reserve(cf.off))) return rc;
     char* h = ctx->pin_misc.as<char>();
     char* f = ctx->misc_b.as<char>();
+    // (the image of a problem the dense one-workgroup kernel takes is read ONCE, into LDS: it is read where it lies in page-locked
+    // memory -- ctx option "zero_copy_kb", as plslam_match_grid -- and one copy command leaves the call; the projected cells and
+    // the query directions, written by a kernel, stay in device memory: fi = the image's base as the kernels see it)
+    const bool dense = grid_dense_ok(nq, nt, (int64_t)cols * rows, n_items, lines != 0, nc);
+    const size_t zc_limit = (size_t)(ctx->zero_copy_kb < 0 ? -ctx->zero_copy_kb : ctx->zero_copy_kb) * 1024;
+    const bool zero_copy = ctx->pin_misc.dev && zc_limit > 0 && image <= zc_limit && (dense || ctx->zero_copy_kb < 0);
+    char* fi = zero_copy ? static_cast<char*>(ctx->pin_misc.dev) : f;
     memcpy(h + oCs, cs.data(), cs.size() * 4);
     memcpy(h + oIt, items.data(), (size_t)(n_items + 1) * 4);
     if (lines) memcpy(h + oD2, dir2.data(), (size_t)nt * 16);
@@ -186,13 +196,13 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     // the count: written by the kernel into the page-locked image when the device can address it (no status word then: it
     // is bumped with an atomic; an overflow also shows as a count of -1)
     int32_t* res_host = (int32_t*)(h + oSt);
-    int32_t* res_dev = static_cast<int32_t*>(mapped_device_pointer(res_host));
+    int32_t* res_dev = ctx->pin_misc.dev ? (int32_t*)(static_cast<char*>(ctx->pin_misc.dev) + oSt) : nullptr;
     const bool in_place = res_dev != nullptr;
     res_host[0] = res_host[1] = 0;
     plslam_grid_problem q{};
     q.d1 = d_Q; q.d2 = d_T; q.centres1 = (int32_t*)(f + oCen);
-    q.cell_start = (int32_t*)(f + oCs); q.cell_items = (int32_t*)(f + oIt);
-    q.dir1 = lines ? (double*)(f + oD1) : nullptr; q.dir2 = lines ? (double*)(f + oD2) : nullptr;
+    q.cell_start = (int32_t*)(fi + oCs); q.cell_items = (int32_t*)(fi + oIt);
+    q.dir1 = lines ? (double*)(f + oD1) : nullptr; q.dir2 = lines ? (double*)(fi + oD2) : nullptr;
     q.n1 = nq; q.n2 = nt; q.n_centres = nc; q.grid_cols = cols; q.grid_rows = rows; q.n_items = n_items;
     for (int k = 0; k < 4; ++k) q.window[k] = fm->ws;
     q.sim_th = fm->line_sim_th; q.nnr = fm->nnr_grid; q.mutual = mutual ? 1 : 0;
@@ -201,17 +211,49 @@ int grid_path(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* T16
     if ((rc = grid_prepare_one(q, ctx->misc_c.as<uint32_t>(), in_place ? nullptr : (int32_t*)(f + oSt) + 1, (GridDesc*)(h + oDesc))))
         return rc;
     grid_aux_fill(h + oAux, nt);
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(f, h, image, hipMemcpyHostToDevice, s));      // (zeroes the device result words too)
+    if (!zero_copy) PLSLAM_HIP_CHECK(hipMemcpyAsync(f, h, image, hipMemcpyHostToDevice, s));      // (zeroes the device result words too)
+    else if (!in_place) PLSLAM_HIP_CHECK(hipMemsetAsync(f + oSt, 0, 16, s));
     if ((rc = launch_project_cells(*K, T16, d_X3, nq, lines, sx, sy, (int32_t*)(f + oCen),
                                    lines ? (double*)(f + oD1) : nullptr, s)))
         return rc;
-    if ((rc = grid_launch_single(q, (const GridDesc*)(f + oDesc), s, (uint32_t*)(f + oAux), false, (const GridDesc*)(h + oDesc)))) return rc;
+    if ((rc = grid_launch_single(q, (const GridDesc*)(fi + oDesc), s, (uint32_t*)(fi + oAux), false, (const GridDesc*)(h + oDesc)))) return rc;
     if (!in_place) PLSLAM_HIP_CHECK(hipMemcpyAsync(res_host, f + oSt, 8, hipMemcpyDeviceToHost, s));
+    if (deferred) {
+        sg.dismiss();
+        *deferred = res_host;
+        return PLSLAM_OK;
+    }
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     sg.dismiss();
     PLSLAM_REQUIRE(res_host[1] == 0 && res_host[0] >= 0, PLSLAM_ERANGE);
     *matches = res_host[0];
     return PLSLAM_OK;
+}
+
+// An upper bound of what the windowed matcher can find for the KF<->KF LINE call, from the host's copy of the previous key frame's
+// lines: a row can only match if one of its two window centres has a grid cell in its window.  The reference hands matchGrid the
+// projected end points in PIXELS there (:392-393; the point call scales by the grid, :256), so on a 752 x 480 image nearly every
+// window lies outside the 64 x 48 grid and the windowed pass finds next to nothing -- StVO::match runs behind it (:421-425) in
+// practically every call.  When this bound is below min_matches that is KNOWN before anything is launched, and the driver
+// enqueues both matchers and waits once.  Conservative: the host's projection may differ from the device's in the last bit, so a
+// centre within two cells of the window's reach, or not finite, counts as "may have candidates".
+int32_t kf2kf_line_grid_bound(const plslam_cam* K, const double* DT, const double* sPeP, int32_t n, const plslam_fast_matching* fm)
+{
+    const double reach = (double)fm->ws + 2.0;
+    int32_t may = 0;
+    for (int32_t i = 0; i < n; ++i) {
+        bool any = false;
+        for (int e = 0; e < 2 && !any; ++e) {
+            const double* X = sPeP + 6 * (size_t)i + 3 * e;
+            double P[3];
+            for (int r = 0; r < 3; ++r) P[r] = DT[4 * r] * X[0] + DT[4 * r + 1] * X[1] + DT[4 * r + 2] * X[2] + DT[4 * r + 3];
+            const double u = K->cx + K->fx * P[0] / P[2], v = K->cy + K->fy * P[1] / P[2];
+            const bool out = u < -reach || u > (double)fm->grid_cols + reach || v < -reach || v > (double)fm->grid_rows + reach;
+            any = !out;                            // (NaN compares false everywhere: "may")
+        }
+        may += any;
+    }
+    return may;
 }
 
 bool fast_ok(const plslam_fast_matching* fm)
@@ -494,21 +536,26 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
     const uint8_t* const d_T = rows_dev ? desc_curr : (const uint8_t*)(d + oT);
     const double* const d_X = rows_dev ? X_prev : (const double*)(d + oX);
     int32_t* tab_host = ctx->pin_out.as<int32_t>();
-    int32_t* tab_mapped = static_cast<int32_t*>(mapped_device_pointer(tab_host));
+    int32_t* tab_mapped = static_cast<int32_t*>(ctx->pin_out.dev);
     int32_t* tab_dev = (int32_t*)(d + oM);
     int32_t matches = 0;
     bool have = false, on_host = false;            // on_host: the current table is in tab_host (written by a kernel, synchronised)
+    // (lines: when the windowed pass provably stays below min_matches -- kf2kf_line_grid_bound -- StVO::match is enqueued behind it
+    // at once: one synchronisation for the call instead of two)
+    const bool both_known = fast && lines && bf_possible && !rows_dev && tab_mapped &&
+                            kf2kf_line_grid_bound(K, DT, X_prev, n_prev, fm) < min_matches;
+    const int32_t* grid_res = nullptr;
     if (fast) {
         // points: pj_points = projection * inv (:256); lines: pj_lines = the projected PIXELS (:392-393, as upstream)
         if ((rc = grid_path(ctx, lines, K, DT, d_X, n_prev, lines ? 1.0 : fm->inv_width,
                             lines ? 1.0 : fm->inv_height, d_Q, feat_curr, nullptr, n_curr,
-                            d_T, fm, mutual, tab_mapped ? tab_mapped : tab_dev, &matches)))
+                            d_T, fm, mutual, tab_mapped ? tab_mapped : tab_dev, &matches, both_known ? &grid_res : nullptr)))
             return rc;
         have = true;
-        on_host = tab_mapped != nullptr;
+        on_host = tab_mapped != nullptr;           // (both_known: "will be" -- the stream's order puts match() behind the kernel that writes it)
     }
     bool count_entries = false;
-    if (bf_possible && matches < min_matches) {                            // :274-278 / :421-425
+    if (bf_possible && (both_known || matches < min_matches)) {            // :274-278 / :421-425
         plslam_match_problem p{};
         p.d1 = d_Q; p.n1 = n_prev; p.d2 = d_T; p.n2 = n_curr;
         p.nnr = nnr; p.mutual = mutual ? 1 : 0; p.n_matches = (int32_t*)(d + oCnt);
@@ -537,6 +584,7 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
             PLSLAM_HIP_CHECK(hipMemcpyAsync(tab_host + n_prev, d + oCnt, 4, hipMemcpyDeviceToHost, s));    // (page-locked: behind the table)
         }
         PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
+        if (grid_res) PLSLAM_REQUIRE(grid_res[1] == 0 && grid_res[0] >= 0 && grid_res[0] < min_matches, PLSLAM_ERANGE);   // (the bound held)
         if (count_only) matches = tab_host[n_prev];
         on_host = true;
         have = true;
