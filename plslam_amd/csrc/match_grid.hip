@@ -1726,8 +1726,10 @@ k_match_grid_dense(GridDesc g)
     DENSE_STAMP();
     // ---- A: membership.  A task = (row, centre, cell column of its window): the cells (x, min_y .. max_y - 1) have consecutive
     // ids, i.e. ONE run of the item list.  One LDS atomic OR per hit and matrix (measured: the LDS pipe of the one CU this kernel
-    // runs on is what bounds it -- ~2 500 wave-level atomic instructions are 11 of this phase's 12.5 us at 200 x 200 lines; a lane
-    // per (row, centre) with masks of its own and no atomics was slower still, 25 us: the serial chain per lane) ----
+    // runs on is what bounds it -- ~2 500 wave-level atomic instructions are 11 of this phase's 12.5 us at 200 x 200 lines.  Built
+    // and measured slower: a lane per (row, centre) with masks of its own and no atomics, 25 us -- the serial chain per lane; a wave
+    // per row, the lanes' masks OR-ed by shuffles, kernel 22 -> 57 us -- 48 cross-lane exchanges per row through the same LDS pipe;
+    // this form with the transposed matrix built afterwards by ballots instead of the second atomic per hit: call 41.8 -> 46.1 us) ----
     {
         const lds_i32 cen = scen;
         const int wx = g.w[0] + g.w[1] + 1;                                 // columns of an unclamped window
