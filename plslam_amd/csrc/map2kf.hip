@@ -65,6 +65,22 @@ int launch_gather_rows(const void* src, const int32_t* idx, int32_t n, int32_t r
 }
 
 
+// the drivers' counters, device -> the page-locked block the host reads (one lane per word): a LAUNCH behind the last kernel
+// instead of a copy command -- on the timeline a small device-to-host copy starts ~13 us after the kernel in front of it, a kernel
+// 2-3 us (profiles/r6_r_call_timeline_map2kf_points_fast.txt)
+__global__ void k_publish_words(const int32_t* __restrict__ src, int32_t* __restrict__ dst, int n)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = src[threadIdx.x];
+}
+
+// (env PLSLAM_MAP2KF_TABLE_IN_PLACE=0: the association table on the device and one copy at the call's end, as before round 6 -- for
+// same-box comparisons)
+static bool tab_in_place_enabled()
+{
+    static const bool on = [] { const char* e = getenv("PLSLAM_MAP2KF_TABLE_IN_PLACE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
 namespace {
 struct Carve {
     size_t off = 0;
@@ -334,6 +350,12 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
     memset(h + oPart, 0, visible_compact_part_words(n_map) * 4);
     grid_aux_fill(h + oAux, nt);
     int32_t* const res = (int32_t*)(d + oRes);                           // [0] gate count, [1] nq, [2] matchGrid's count
+    // the association table: written where the host reads it (the page-locked block, mapped) when the device can address it --
+    // its -1 fill and the few hundred entries the gate sets cross PCIe as posted writes; the counters follow by k_publish_words:
+    // no copy command at the call's end
+    char* ho = ctx->pin_out.as<char>();
+    const bool tab_in_place = ctx->pin_out.dev != nullptr && tab_in_place_enabled();
+    int32_t* const tab = tab_in_place ? (int32_t*)(static_cast<char*>(ctx->pin_out.dev) + (oMap - oRes)) : (int32_t*)(d + oMap);
     plslam_grid_problem q{};
     q.d1 = (const uint8_t*)(d + oQ); q.d2 = (const uint8_t*)(d + oT); q.centres1 = (int32_t*)(d + oCen);
     q.cell_start = (int32_t*)(d + oCs); q.cell_items = (int32_t*)(d + oIt);
@@ -347,19 +369,22 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image, hipMemcpyHostToDevice, s));
     // ---- the launch sequence (five launches: the small steps are fused -- a launch of a microsecond's work costs 4-5 us)
     if ((rc = launch_visible_compact(*K, Twf, (const double*)d_LM, d_cand, n_map, lines, (int32_t*)(d + oQi), res + 1,
-                                     (int32_t*)(d + oMap), (GridDesc*)(d + oDesc), (uint32_t*)(d + oPart), /* zeroed by the image above */ true, s)))
+                                     tab, (GridDesc*)(d + oDesc), (uint32_t*)(d + oPart), /* zeroed by the image above */ true, s)))
         return rc;
     if ((rc = launch_prepare_rows(*K, Twf, d_MD, (const double*)d_LM, (const int32_t*)(d + oQi), res + 1, n_map, lines, fm->inv_width,
                                   fm->inv_height, d + oQ, (double*)(d + oQL), (int32_t*)(d + oCen), lines ? (double*)(d + oD1) : nullptr, s)))
         return rc;
     if ((rc = grid_launch_single(q, (const GridDesc*)(d + oDesc), s, (uint32_t*)(d + oAux), true, (const GridDesc*)(h + oDesc)))) return rc;
     if ((rc = launch_gate_n(lines, *K, Twf, (const double*)(d + oQL), (const int32_t*)(d + oM), res + 1, n_map, (const double*)(d + oTF),
-                            max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi), (const int32_t*)(d + oTi),
-                            (int32_t*)(d + oMap), s)))
+                            max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi), (const int32_t*)(d + oTi), tab, s)))
         return rc;
-    // ---- one download (the counters' page and the table behind it), one synchronisation
-    char* ho = ctx->pin_out.as<char>();
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oRes, (oMap - oRes) + (size_t)n_map * 4, hipMemcpyDeviceToHost, s));
+    // ---- the counters (and, when it is not there already, the table behind them) down; one synchronisation
+    if (tab_in_place) {
+        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, s, (const int32_t*)res, (int32_t*)ctx->pin_out.dev, 4);
+        PLSLAM_HIP_CHECK(hipGetLastError());
+    } else {
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oRes, (oMap - oRes) + (size_t)n_map * 4, hipMemcpyDeviceToHost, s));
+    }
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     sg.dismiss();
     const int32_t* r = reinterpret_cast<const int32_t*>(ho);
@@ -451,8 +476,12 @@ int map2kf_bf_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const double
     memset(h + oRes, 0, 16);
     memset(h + oPart, 0, visible_compact_part_words(n_map) * 4);
     PLSLAM_HIP_CHECK(hipMemcpyAsync(d, h, image, hipMemcpyHostToDevice, s));
+    // (the association table where the host reads it, the counters by k_publish_words: as map2kf_fast_once)
+    char* ho = ctx->pin_out.as<char>();
+    const bool tab_in_place = ctx->pin_out.dev != nullptr && tab_in_place_enabled();
+    int32_t* const tab = tab_in_place ? (int32_t*)(static_cast<char*>(ctx->pin_out.dev) + (oMap - oRes)) : (int32_t*)(d + oMap);
     if ((rc = launch_visible_compact(*K, Twf, (const double*)d_LM, d_cand, n_map, lines, (int32_t*)(d + oQi), res + 1,
-                                     (int32_t*)(d + oMap), nullptr, (uint32_t*)(d + oPart), /* zeroed by the image above */ true, s)))
+                                     tab, nullptr, (uint32_t*)(d + oPart), /* zeroed by the image above */ true, s)))
         return rc;
     if ((rc = launch_prepare_rows(*K, Twf, d_MD, (const double*)d_LM, (const int32_t*)(d + oQi), res + 1, n_map, lines, 0.0, 0.0,
                                   d + oQ, (double*)(d + oQL), nullptr, nullptr, s)))
@@ -467,12 +496,15 @@ int map2kf_bf_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const double
     }
     if (rc) return rc;
     if ((rc = launch_gate_n(lines, *K, Twf, (const double*)(d + oQL), (const int32_t*)(d + oM), res + 1, n_map, (const double*)(d + oTF),
-                            max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi), (const int32_t*)(d + oTi),
-                            (int32_t*)(d + oMap), s)))
+                            max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi), (const int32_t*)(d + oTi), tab, s)))
         return rc;
-    // ---- one download (the counters' page and the table behind it), one synchronisation
-    char* ho = ctx->pin_out.as<char>();
-    PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oRes, (oMap - oRes) + (size_t)n_map * 4, hipMemcpyDeviceToHost, s));
+    // ---- the counters (and, when it is not there already, the table behind them) down; one synchronisation
+    if (tab_in_place) {
+        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, s, (const int32_t*)res, (int32_t*)ctx->pin_out.dev, 4);
+        PLSLAM_HIP_CHECK(hipGetLastError());
+    } else {
+        PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oRes, (oMap - oRes) + (size_t)n_map * 4, hipMemcpyDeviceToHost, s));
+    }
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
     sg.dismiss();
     *done = 1;
@@ -581,7 +613,10 @@ int kf2kf_driver(plslam_ctx* ctx, int lines, const plslam_cam* K, const double* 
             PLSLAM_HIP_CHECK(hipMemcpyAsync(tab_host, tab_dev, (size_t)n_prev * 4, hipMemcpyDeviceToHost, s));
             PLSLAM_HIP_CHECK(hipMemcpyAsync(&matches, d + oCnt, 4, hipMemcpyDeviceToHost, s));
         } else if (count_only) {
-            PLSLAM_HIP_CHECK(hipMemcpyAsync(tab_host + n_prev, d + oCnt, 4, hipMemcpyDeviceToHost, s));    // (page-locked: behind the table)
+            // (the count: behind the table in the page-locked block, by a one-lane launch -- a small copy command starts ~13 us after
+            // the kernel in front of it, a kernel 2-3 us)
+            hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, s, (const int32_t*)(d + oCnt), tab_mapped + n_prev, 1);
+            PLSLAM_HIP_CHECK(hipGetLastError());
         }
         PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
         if (grid_res) PLSLAM_REQUIRE(grid_res[1] == 0 && grid_res[0] >= 0 && grid_res[0] < min_matches, PLSLAM_ERANGE);   // (the bound held)
