@@ -783,6 +783,16 @@ static int lba_plan_enqueue(plslam_lba_plan* P, const double* T_kf_w, const doub
     return PLSLAM_OK;
 }
 
+// g (+ err) down by a KERNEL that writes the page-locked block where the device can address it: a copy command of this size runs on
+// the copy engine, which starts ~13 us after the kernel in front of it (profiles/r6_r_call_timeline_map2kf_points_fast.txt: the
+// same pattern); a kernel starts 2-3 us after, and 0.34 MB of posted writes cross PCIe in ~7 us either way
+__global__ void __launch_bounds__(256)
+k_copy_out(const double* __restrict__ src, double* __restrict__ dst, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 // device -> host copies of the blocks of the last iteration (NULL pointers are skipped), then one synchronise
 static int lba_plan_download(plslam_lba_plan* P, double* g, double* H_pose, double* H_pt, double* H_ls, double* W_pt,
                              double* W_ls, double* err)
@@ -801,7 +811,14 @@ static int lba_plan_download(plslam_lba_plan* P, double* g, double* H_pose, doub
         // err alone lands in the slot it has in the g + err copy, BEHIND the image's g (plslam_lba_plan_host_state hands
         // out ho as g: an err-only iteration -- a rejected LM trial step -- must leave the gradient there untouched)
         const size_t off = g ? P->oG : P->oErr, bytes = g ? N * 8 + 8 : 8;
-        PLSLAM_HIP_CHECK(hipMemcpyAsync(ho + (g ? 0 : N * 8), dout + off, bytes, hipMemcpyDeviceToHost, s));
+        if (g && P->pin_out.dev) {
+            const size_t nd = N + 1;
+            hipLaunchKernelGGL(k_copy_out, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, s, (const double*)(dout + off),
+                               static_cast<double*>(P->pin_out.dev), nd);
+            PLSLAM_HIP_CHECK(hipGetLastError());
+        } else {
+            PLSLAM_HIP_CHECK(hipMemcpyAsync(ho + (g ? 0 : N * 8), dout + off, bytes, hipMemcpyDeviceToHost, s));
+        }
         PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
         if (g && (char*)g != ho) memcpy(g, ho, N * 8);      // (g = the page-locked image itself: plslam_lba_plan_host_state)
         if (err) memcpy(err, ho + N * 8, 8);
