@@ -97,6 +97,8 @@ struct plslam_match_plan {
     bool dir_multi = false;
     SymDesc* d_dirs = nullptr; BlockDesc* d_dir_blocks = nullptr;
     DevBuf keys, counts, partials;
+    DevBuf tail_counts;                // experiment builds (-DPLSLAM_MI_TAIL=1) with ctx option "scan_tail": a counter per symmetric problem
+    bool scan_tail = false;            // ... the scan's last workgroup of a problem merges its column partials: no merge launch
     DevBuf tables;                     // all launch tables, packed, uploaded with ONE copy
     std::vector<char> staging;         // host image of `tables` (kept alive: the copy is async)
     HostBuf staging_pin;               // ... in pinned memory when pin_tables (the context's host-path plan)
@@ -136,7 +138,7 @@ struct plslam_match_plan {
     int64_t acc_runs = 0;
     void free_all()
     {
-        keys.release(); counts.release(); partials.release(); tables.release(); staging_pin.release();
+        keys.release(); counts.release(); partials.release(); tail_counts.release(); tables.release(); staging_pin.release();
         gate_tables.release(); rowtmp.release();
         for (auto& e : evs) { (void)hipEventDestroy(e.e0); (void)hipEventDestroy(e.e1); (void)hipEventDestroy(e.e2); }
         evs.clear();
@@ -608,6 +610,13 @@ static int plan_build(plslam_ctx* ctx, const plslam_match_problem* probs, int32_
     P->ndir = (int32_t)dirs.size();
     P->ndir_blocks = (int32_t)dblocks.size();
     P->nmerge_blocks = (int32_t)mblocks.size();
+    P->scan_tail = ctx->scan_tail && k1i_tail_built() && P->nsym > 0 && P->sym_mfma && mfma_form_is_h(P->mfma_form) && !P->fused &&
+                   !P->exact_second && P->merge_parts == 1 && !P->post_fused && !P->split_post && !P->col_split;
+    if (P->scan_tail) {
+        if ((r = P->tail_counts.reserve(sizeof(int32_t) * (size_t)P->nsym))) return r;
+        PLSLAM_HIP_CHECK(hipMemsetAsync(P->tail_counts.p, 0, sizeof(int32_t) * (size_t)P->nsym, ctx->stream));   // (the kernel leaves them zero)
+        PLSLAM_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
     P->info.distance_evals = evals;      // executed
     P->info.directed_evals = devals;     // what two directed knnMatch calls per mutual problem evaluate
     P->info.algorithmic_bytes = abytes;  // 32(Q+T)+16Q per DIRECTED scan, however executed
@@ -713,7 +722,8 @@ static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
     }
     if (P->nsym_blocks > 0) {
         r = P->sym_mfma ? launch_scan_mfma_form(P->mfma_form, P->d_syms, P->d_sym_blocks, P->nsym_blocks, P->d_counts_zero,
-                                                zeroed ? 0 : P->ncounts, P->sym_mfma_multi, false, s, P->fused)
+                                                zeroed ? 0 : P->ncounts, P->sym_mfma_multi, false, s, P->fused,
+                                                P->scan_tail ? P->tail_counts.as<int32_t>() : nullptr)
                         : launch_scan_sym(P->sym_rows, P->d_syms, P->d_sym_blocks,
                                           P->nsym_blocks, P->d_counts_zero, P->ncounts, s);
         if (r) return r;
@@ -748,7 +758,8 @@ static int plan_run(plslam_match_plan* P, hipStream_t s, hipStream_t sp)
         r = launch_post_fused(P->d_probs, P->nprob, P->ngates > 0 ? P->d_gates : nullptr, P->post_lds, s);
         if (r) return r;
     } else {
-    r = P->sym_mfma && mfma_form_is_h(P->mfma_form) && !P->fused
+    r = P->scan_tail ? PLSLAM_OK          // (the scan's last workgroup per problem has written keys21)
+        : P->sym_mfma && mfma_form_is_h(P->mfma_form) && !P->fused
             ? launch_merge_fix16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, P->exact_second, s, split ? P->ctx->post_workgroups : 0)
             : P->sym_mfma && P->mfma_form != 1 ? launch_merge_partials16(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, P->merge_parts, s)
                                                : launch_merge_partials(P->d_syms, P->d_merge_blocks, P->nmerge_blocks, s);
@@ -925,6 +936,12 @@ int plslam_ctx_set_option(plslam_ctx* ctx, const char* key, int value)
         ctx->zero_copy_kb = value;
         return PLSLAM_OK;
     }
+    if (!strcmp(key, "scan_tail")) {                // (experiment builds only: see hamming_mfma_i.hip, PLSLAM_MI_TAIL)
+        PLSLAM_REQUIRE(value == 0 || value == 1, PLSLAM_EINVAL);
+        if (value && !plslam::k1i_tail_built()) return PLSLAM_ENOTSUP;
+        ctx->scan_tail = value;
+        return PLSLAM_OK;
+    }
     if (!strcmp(key, "post_xcd")) {
         PLSLAM_REQUIRE(value >= 0 && value <= 2, PLSLAM_EINVAL);
         ctx->post_xcd = value;
@@ -969,6 +986,7 @@ int plslam_ctx_get_option(plslam_ctx* ctx, const char* key, int* value)
     if (!strcmp(key, "exact_second")) { *value = ctx->exact_second; return PLSLAM_OK; }
     if (!strcmp(key, "post_workgroups")) { *value = ctx->post_workgroups; return PLSLAM_OK; }
     if (!strcmp(key, "post_xcd")) { *value = ctx->post_xcd; return PLSLAM_OK; }
+    if (!strcmp(key, "scan_tail")) { *value = ctx->scan_tail; return PLSLAM_OK; }
     if (!strcmp(key, "zero_copy_kb")) { *value = ctx->zero_copy_kb; return PLSLAM_OK; }
     if (!strcmp(key, "grid_dense")) { *value = plslam::g_grid_dense; return PLSLAM_OK; }
     if (!strcmp(key, "split_post")) { *value = ctx->split_post; return PLSLAM_OK; }

@@ -127,6 +127,7 @@ struct plslam_ctx {
     int col_split = 0;   // K1f, few large problems: 0 = auto (cut the columns into ranges when the plan cannot fill the chip), 1 = never, 2 = always
     int exact_second = 0; // K1h: 1 = the index of every second-best row key is exact (0: only where it is an output -- knnMatch)
     int graph = 1;             // plslam_match_plan_run as a replayed HIP graph: 0 = latency plans, 1 = never (default until measured), 2 = always
+    int scan_tail = 0;         // (experiment builds -DPLSLAM_MI_TAIL=1) 1: K1i's last workgroup of a problem merges the column partials, no merge launch
     int post_workgroups = 0;   // > 0: the stages behind a scan (merge of K1h's partials, finalize) run as at most this many workgroups walking their block tables
     int split_target = 0, split_min_tiles = 0;   // column split: workgroups per CU aimed at (0 = 3), tiles per column range at least (0 = 4)
     int split_post = 0;  // column-split K1f plans: 0 = auto (merge + ratio + mutual behind the scan in ONE kernel: two launches per run), 1 = never
@@ -299,8 +300,11 @@ inline bool mfma_form_is_h(int form) { return form == 0 || form == 4 || form == 
 int launch_scan_sym_mfma_h(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
                            bool directed, hipStream_t s);
 // K1i (hamming_mfma_i.hip): K1h with the two M-tiles of a wave pipelined against each other; same tables, same merge kernel
+// tail_counts (experiment builds -DPLSLAM_MI_TAIL=1 only; k1i_tail_built()): one zeroed counter per problem -- the last workgroup
+// of a problem merges its column partials into keys21 itself, no merge kernel behind the scan
 int launch_scan_sym_mfma_i(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
-                           bool directed, hipStream_t s);
+                           bool directed, hipStream_t s, int32_t* tail_counts = nullptr);
+bool k1i_tail_built();
 int merge_fix16_cols(int parts);      // column slots per block-table entry of launch_merge_fix16
 int launch_merge_fix16(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int parts, bool fix, hipStream_t s, int grid_cap = 0);
 int mh_slot_of_column(int n2, int j);
@@ -314,13 +318,14 @@ int launch_scan_dir_mfma(const SymDesc* d_sym, const BlockDesc* d_blocks, int nb
 #endif
 inline bool mfma_form_built(int form) { return PLSLAM_BUILD_LEGACY_SCANS || form == 0 || form == 2 || form == 5; }
 inline int launch_scan_mfma_form(int form, const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero,
-                                 int nzero, bool multi_window, bool directed, hipStream_t s, bool fused = false)
+                                 int nzero, bool multi_window, bool directed, hipStream_t s, bool fused = false,
+                                 int32_t* tail_counts = nullptr)
 {
 #if PLSLAM_BUILD_LEGACY_SCANS
     if (form == 3 && directed && !fused) return launch_scan_dir_mfma(d_sym, d_blocks, nblocks, d_zero, nzero, s);
     if (form == 4 && !fused) return launch_scan_sym_mfma_h(d_sym, d_blocks, nblocks, d_zero, nzero, directed, s);
 #endif
-    if (mfma_form_is_h(form) && !fused) return launch_scan_sym_mfma_i(d_sym, d_blocks, nblocks, d_zero, nzero, directed, s);
+    if (mfma_form_is_h(form) && !fused) return launch_scan_sym_mfma_i(d_sym, d_blocks, nblocks, d_zero, nzero, directed, s, tail_counts);
 #if PLSLAM_BUILD_LEGACY_SCANS
     if (form == 1) return launch_scan_sym_mfma(d_sym, d_blocks, nblocks, d_zero, nzero, multi_window, directed, s);
 #endif

@@ -178,9 +178,22 @@ __device__ unsigned long long g_mi_prof[MI_PROF_WGS * 4];      // per workgroup 
 #ifndef PLSLAM_MI_VGPRS
 #define PLSLAM_MI_VGPRS 168
 #endif
+// PLSLAM_MI_TAIL = 1 (experiment build; NOT in the product library: it needs agent-scope fences, which
+// tests/test_abi.py keeps out of every kernel): the LAST workgroup of a problem to finish -- one atomic on a per-problem counter,
+// agent-scope release before it, acquire behind it on that workgroup only -- merges the problem's row-block partials into keys21
+// itself (what k_merge_fix16<1, false> does), and the plan run launches no merge kernel (context option "scan_tail").
+#ifndef PLSLAM_MI_TAIL
+#define PLSLAM_MI_TAIL 0
+#endif
+#if PLSLAM_MI_TAIL
+#define PLSLAM_MI_TAIL_PARAM , int32_t* __restrict__ tail_counts
+#else
+#define PLSLAM_MI_TAIL_PARAM
+#endif
 template <bool DIRECTED>
 __global__ void __launch_bounds__(256, 3) __attribute__((amdgpu_num_vgpr(PLSLAM_MI_VGPRS / 2)))
-k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks, int32_t* __restrict__ zero, int nzero, int nblocks)
+k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict__ blocks, int32_t* __restrict__ zero, int nzero, int nblocks
+                  PLSLAM_MI_TAIL_PARAM)
 {
     // one buffer, two lives: during the scan the double-buffered b tile (9 216 B) followed by the PARKED sorted pairs of the
     // row direction ([wave][slot][lane] x 8 B = 32 768 B); after the scan the row-result transpose [wave][row 0..63][33]
@@ -440,8 +453,12 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
             // ("none" and penalty keys widen to distances above 511: the word's fields are 17 + 6 and 9 bits)
             const uint32_t e = (umin_(k0, 0x1FFFFu) << 9) | umin_(k1 >> 8, 511u);
             PLSLAM_GLOBAL uint32_t* dst = (PLSLAM_GLOBAL uint32_t*)((PLSLAM_GLOBAL char*)(uintptr_t)(part_s + slot4) + 4u * l_);
+#if PLSLAM_MI_TAIL == 2      // (the partial written THROUGH to memory, agent scope: no L2 write-back fence before the counter)
+            __hip_atomic_store((uint32_t*)dst, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
             if (PLSLAM_NT_STREAMS) __builtin_nontemporal_store(e, dst);
             else *dst = e;
+#endif
         } else {
             const u32x2_t e = {k0, k1};
             PLSLAM_GLOBAL u32x2_t* dst = (PLSLAM_GLOBAL u32x2_t*)((PLSLAM_GLOBAL char*)(uintptr_t)(part_s + 2u * slot4) + 8u * l_);
@@ -989,6 +1006,80 @@ k_scan_sym_mfma_i(const SymDesc* __restrict__ syms, const BlockDesc* __restrict_
         load_raw_async(wt0 + 2, 2048);
         load_raw_async(wt0 + 3, RING == 4 ? 3072 : 0);
     }
+#if PLSLAM_MI_TAIL
+    if (!DIRECTED && tail_counts) {
+        __shared__ int s_last;
+#if PLSLAM_MI_TAIL == 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the write-through stores of the partials have been acknowledged
+#else
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // this workgroup's partials (and row results) leave its XCD's L2
+#endif
+        __syncthreads();
+        const int nwb = (n1 + 255) >> 8;                            // the problem's workgroups: one per 256 rows of a
+        if (tid == 0) s_last = atomicAdd(&tail_counts[bd.item], 1) == nwb - 1;
+        __syncthreads();
+        if (s_last) {
+#if PLSLAM_MI_TAIL != 2
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // the other workgroups' partials are read from memory
+#endif
+            const gcu32_t part = (gcu32_t) sd.part21;
+            auto wide = [](uint32_t k17, uint32_t wb) -> uint32_t { return ((k17 >> 8) << KEY_IDX_BITS) | ((k17 & 255u) + 256u * wb); };
+            // (every load of a lane's slots goes out before the first is used: the loads bypass this XCD's L2, and a chain of them
+            // keeps the workgroup's slot for microseconds per link -- measured with one slot at a time: scan + 0.18 ms per step)
+            constexpr int TQ = 8, TWB = 8;                          // slots per lane and row blocks per round: 2048 columns, 2048 rows
+            const int nslots = MH_TILE_N * ntiles;
+            for (int s0_ = 0; s0_ < nslots; s0_ += 256 * TQ) {
+                uint32_t b0[TQ], b1[TQ], sx[TQ];
+#pragma unroll
+                for (int q = 0; q < TQ; ++q) { b0[q] = b1[q] = KEY_NONE; sx[q] = 0xFFFFFFFFu; }
+                for (int wb0 = 0; wb0 < nwb; wb0 += TWB) {
+                    uint32_t e[TWB][TQ];
+#pragma unroll
+                    for (int u = 0; u < TWB; ++u)
+#pragma unroll
+                        for (int q = 0; q < TQ; ++q) {
+                            const int slot = s0_ + tid + 256 * q;
+                            const bool on = wb0 + u < nwb && slot < nslots;
+#if PLSLAM_MI_TAIL == 2      // (an agent-scope load: past this XCD's L2)
+                            e[u][q] = on ? __hip_atomic_load((const uint32_t*)(part + ((size_t)(wb0 + u) * n2p + slot)), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)
+                                         : 0xFFFFFFFFu;
+#else
+                            e[u][q] = on ? part[(size_t)(wb0 + u) * n2p + slot] : 0xFFFFFFFFu;
+#endif
+                        }
+#pragma unroll
+                    for (int u = 0; u < TWB; ++u)
+#pragma unroll
+                        for (int q = 0; q < TQ; ++q) {
+                            if (wb0 + u < nwb) {                    // (uniform)
+                                const uint32_t k = wide(e[u][q] >> 9, (uint32_t)(wb0 + u)), e1 = ((e[u][q] & 511u) << 8) | 255u;
+                                sx[q] = k < b0[q] ? e1 : sx[q];
+                                b1[q] = umin_(b1[q], umax_(b0[q], k));
+                                b0[q] = umin_(b0[q], k);
+                            }
+                        }
+                }
+#pragma unroll
+                for (int q = 0; q < TQ; ++q) {
+                    const int slot = s0_ + tid + 256 * q;
+                    if (slot >= nslots) continue;
+                    const int j = L.row_of(slot >> 5, slot & 31);
+                    if (j >= n2) continue;
+                    uint32_t r0 = b0[q], r1 = b1[q];
+                    if (r0 < (257u << KEY_IDX_BITS)) {
+                        r1 = umin_(r1, ((sx[q] >> 8) << KEY_IDX_BITS) | KEY_IDX_MASK);
+                        if (r1 >= (257u << KEY_IDX_BITS)) r1 = KEY_NONE;
+                    } else {
+                        r0 = r1 = KEY_NONE;
+                    }
+                    ((gu2_t) reinterpret_cast<u32x2_t*>(sd.keys21))[j] = u32x2_t{r0, r1};
+                }
+            }
+            if (tid == 0) tail_counts[bd.item] = 0;                 // (the next run of the plan counts afresh)
+        }
+    }
+#endif
 #if PLSLAM_MI_PERSIST
     }
 #endif
@@ -1010,16 +1101,24 @@ extern "C" int plslam_debug_k1i_profile(unsigned long long* out, int nwg)
 }
 #endif
 
+bool k1i_tail_built() { return PLSLAM_MI_TAIL != 0; }
+
 int launch_scan_sym_mfma_i(const SymDesc* d_sym, const BlockDesc* d_blocks, int nblocks, int32_t* d_zero, int nzero,
-                           bool directed, hipStream_t s)
+                           bool directed, hipStream_t s, int32_t* tail_counts)
 {
     if (nblocks <= 0) return PLSLAM_OK;
     int grid = nblocks;
 #if PLSLAM_MI_PERSIST
     if (grid > PLSLAM_MI_PERSIST) grid = PLSLAM_MI_PERSIST & ~7;
 #endif
+#if PLSLAM_MI_TAIL
+    if (directed) hipLaunchKernelGGL((k_scan_sym_mfma_i<true>), dim3(grid), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero, nblocks, (int32_t*)nullptr);
+    else hipLaunchKernelGGL((k_scan_sym_mfma_i<false>), dim3(grid), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero, nblocks, tail_counts);
+#else
+    (void)tail_counts;
     if (directed) hipLaunchKernelGGL((k_scan_sym_mfma_i<true>), dim3(grid), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero, nblocks);
     else hipLaunchKernelGGL((k_scan_sym_mfma_i<false>), dim3(grid), dim3(256), 0, s, d_sym, d_blocks, d_zero, nzero, nblocks);
+#endif
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
