@@ -40,7 +40,7 @@ extern "C" {
 
 /* 2: plslam_match_problem grew (keep_prior, reserved: 56 bytes), plslam_lba_plan_iterate's flags became a bit mask, options
  * "mfma_form" 3/4 and "exact_second"; 3 (round 4): "mfma_form" 5 (the default), "post_fuse", plslam_match_plan_key_state;
- * 4 (round 5): plslam_match_plan_set_wire16, the Schur step, plslam_lba_plan_host_state; 5 (round 6): plslam_lba_plan_get_landmarks, plslam_lba_plan_iterate_schur / _apply_step, plslam_lba_point_rows_dev_n / _line_rows_dev_n, plslam_match_plan_step_gather / _gather_sync, plslam_rccl_use.
+ * 4 (round 5): plslam_match_plan_set_wire16, the Schur step, plslam_lba_plan_host_state; 5 (round 6): plslam_lba_plan_get_landmarks, plslam_lba_plan_iterate_schur / _apply_step, plslam_lba_point_rows_dev_n / _line_rows_dev_n, plslam_match_plan_step_gather / _gather_sync, plslam_rccl_use / _rccl_available.
  * Clients compare plslam_abi_version() with the value they were compiled against. */
 #define PLSLAM_ABI_VERSION 5
 #define PLSLAM_DESC_BYTES 32
@@ -823,6 +823,9 @@ int plslam_gather_match_tables(plslam_ctx* ctx, void* comm, int nranks, int rank
  * librccl.so.1, /opt/rocm/lib/librccl.so).  A communicator belongs to ONE loaded copy of the library -- PyTorch ships its own
  * beside ROCm's -- and the send / receive entry points must be that copy's. */
 int plslam_rccl_use(const char* path);
+/* 1 when librccl's group / send / recv entry points could be loaded (the first call loads them), 0 otherwise: asked before the
+ * first plslam_match_plan_step_gather, so that a missing library is a set-up failure and the caller can keep its own gather. */
+int plslam_rccl_available(void);
 
 /* One step of the N > 1 path in one call (ABI v5): the plan's scan on scan_stream, everything behind it on post_stream
  * (plslam_match_plan_run_split), then the gather of the finished table to `root` -- one ncclGroup of point-to-point transfers,

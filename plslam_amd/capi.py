@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "plslam_lba_plan_rows", "plslam_lba_plan_destroy", "plslam_lba_plan_iterate_dev", "plslam_lba_plan_device_blocks", "plslam_lba_plan_device_state",
     "plslam_lba_plan_iterate_resident", "plslam_lba_plan_diag_max", "plslam_lba_plan_schur", "plslam_lba_plan_backsub",
     "plslam_lba_plan_set_poses", "plslam_lba_plan_host_state", "plslam_lba_plan_get_landmarks",
-    "plslam_lba_plan_iterate_schur", "plslam_lba_plan_apply_step", "plslam_lba_point_rows_dev_n", "plslam_lba_line_rows_dev_n",
+    "plslam_lba_plan_iterate_schur", "plslam_lba_plan_apply_step", "plslam_lba_point_rows_dev_n", "plslam_lba_line_rows_dev_n", "plslam_rccl_available",
     "plslam_lba_plan_blocks",
     "plslam_map2kf_point_gate", "plslam_map2kf_line_gate", "plslam_map_point_visible",
     "plslam_map_line_visible", "plslam_map2kf_match_points", "plslam_map2kf_match_lines",
@@ -285,6 +285,7 @@ def load() -> C.CDLL:
     L.plslam_rccl_use.argtypes = [C.c_char_p]
     L.plslam_match_plan_step_gather.argtypes = [vp, C.POINTER(GatherStep)]
     L.plslam_match_plan_gather_sync.argtypes = [vp]
+    L.plslam_rccl_available.argtypes = []
     for name in ABI_SYMBOLS:
         f = getattr(L, name)
         if name not in ("plslam_strerror", "plslam_last_error", "plslam_ctx_destroy",

@@ -1982,6 +1982,13 @@ int plslam_rccl_use(const char* path)
     return PLSLAM_OK;
 }
 
+// 1 when librccl's group / send / recv entry points are loaded (loads them on the first call), 0 when they cannot be: a caller that
+// is about to take the one-call gather step asks BEFORE its first step -- a failure there is a set-up failure, not a step's
+int plslam_rccl_available(void)
+{
+    return rccl_load() ? 1 : 0;
+}
+
 namespace plslam {
 __global__ void __launch_bounds__(256) k_widen16(const int16_t* __restrict__ src, int32_t* __restrict__ dst, int64_t n)
 {

@@ -432,6 +432,9 @@ class PipelinedGather:
             path = None
         if path:
             capi.load().plslam_rccl_use(path.encode())     # (EINVAL once the library is loaded: the choice was made then)
+        if world > 1 or comm:
+            if not capi.load().plslam_rccl_available():     # (no librccl to be had: a set-up failure -- the torch path stays)
+                return 0 if world == 1 and not comm else None
         return comm
 
     def _native_step(self, b: int, scan):
