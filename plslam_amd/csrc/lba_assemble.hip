@@ -390,11 +390,21 @@ struct LbaBlockArgs {
     int32_t* nsing = nullptr;
 };
 
+#ifndef PLSLAM_CHUNK_PB
+#define PLSLAM_CHUNK_PB 32
+#endif
 __global__ void __launch_bounds__(256)
 k_lba_blocks(const LbaBlockArgs A)
 {
     __shared__ __attribute__((aligned(16))) double slab[64 * 36];
     const int b = blockIdx.x;
+#ifdef PLSLAM_BLOCKS_X            // timing experiments (tools/r6_blocks_knockouts.sh): 1 no point landmarks, 2 no line landmarks, 4 no keyframe chunk
+                                  // partials.  At C3 the launch is 16.3 us; points alone 5.1, lines alone 8.9, the chunk partials alone 13.9 --
+                                  // the launch's critical path, and not a matter of round trips (16 / 32 observations in flight: 16.3 / 16.1 us)
+    if ((PLSLAM_BLOCKS_X & 1) && b < A.nb3) return;
+    if ((PLSLAM_BLOCKS_X & 2) && b >= A.nb3 && b < A.nb3 + A.nb6) return;
+    if ((PLSLAM_BLOCKS_X & 4) && b >= A.nb3 + A.nb6) return;
+#endif
     if (b < A.nb3) {                                   // (64 landmarks: the workgroup's first wave; the others leave)
         if (threadIdx.x >= 64) return;
         landmark_block<3>(b * 64, A.npt, A.pt_ptr, A.pt_ids, A.pJl, A.pr, A.pw, A.H_pt, A.g_pt, slab, A.lambda, A.Vp, A.tp, A.nsing);
@@ -412,7 +422,7 @@ k_lba_blocks(const LbaBlockArgs A)
         const int end = beg + POSE_CHUNK < A.kf_ptr[k + 1] ? beg + POSE_CHUNK : A.kf_ptr[k + 1];
         const int a = e < 36 ? e / 6 : e - 36, bb = e < 36 ? e % 6 : 0;
         double acc = 0.0;
-        constexpr int PB = 16;
+        constexpr int PB = PLSLAM_CHUNK_PB;   // (observations whose loads are in flight together: 32 = two round trips per 64-observation chunk; 16 was four, and this part of the launch its critical path: 13.9 us alone)
         for (int i0 = beg; i0 < end; i0 += PB) {
             int oo[PB];
             bool pt[PB];
