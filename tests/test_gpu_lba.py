@@ -728,3 +728,40 @@ def test_fused_iteration_calls_equal_the_separate_ones(ctx):
     s2 = f.apply_step(dp, None, apply=False)
     assert s1 == s2
     a.close(); f.close()
+
+
+@pytest.mark.parametrize("n_kf,n_pt,n_ls,obs", [
+    (6, 300, 0, 4),        # points only: no line workgroups, no line chunk of the pair lists
+    (6, 0, 90, 4),         # lines only: every chunk of the pair lists is a line chunk
+    (2, 200, 40, 2),       # ONE optimised keyframe
+    (4, 1500, 300, 4),     # point chunks padded by null pairs in front of the line chunks of every block
+    (3, 1, 1, 3),          # a workgroup with two live lanes
+    (31, 900, 200, 6),     # 30 optimised key frames: a 180 x 180 reduced system written in place, 465 blocks
+])
+def test_fused_iteration_edge_shapes(ctx, n_kf, n_pt, n_ls, obs):
+    """plslam_lba_plan_iterate_schur / _apply_step over the shapes of test_schur_step_edge_shapes (and a wide one): the same words
+    as iterate_resident + schur + backsub, twice in a row (the singular-block counters alternate), with and without the update."""
+    lm = synth.local_map(n_kf=n_kf, n_pt=n_pt, n_ls=n_ls, obs_per_lm=obs, seed=77 + n_kf)
+    cam, _ = _cams()
+    nkf = n_kf - 1
+    mk = lambda: plslam_amd.LbaPlan(ctx, cam, 1e-7, n_kf, nkf, n_pt, n_ls, lm["pt_lm"], lm["pt_kf"], lm["pt_kf"] - 1, lm["obs_uv"],
+                                    lm["ls_lm"], lm["ls_kf"], lm["ls_kf"] - 1, lm["l_obs"])
+    a, f = mk(), mk()
+    for p in (a, f):
+        p.iterate_dev(lm["T_kf_w"], lm["Xw"], lm["Lw"], want_g=False)
+    lam = 1e-3
+    for it in range(3):
+        e_a = a.iterate_resident(plslam_amd.LbaPlan.COMPAT_ITER_PASS)
+        S_a, b_a, ns_a = a.schur(lam)
+        e_f, S_f, b_f, ns_f = f.iterate_schur(lam, plslam_amd.LbaPlan.COMPAT_ITER_PASS)
+        assert e_a == e_f and ns_a == ns_f and np.array_equal(S_a, S_f) and np.array_equal(b_a, b_f), it
+        dp = np.linalg.solve(S_a, b_a) * 0.5
+        dxp, dxl = a.backsub(dp, apply=(it != 1))
+        ss = f.apply_step(dp, None, apply=(it != 1))
+        want = float((dxp ** 2).sum() + (dxl ** 2).sum())
+        assert abs(ss - want) <= 1e-12 * max(want, 1e-300)
+        Xa, La = a.get_landmarks()
+        Xf, Lf = f.get_landmarks()
+        assert np.array_equal(Xa, Xf) and np.array_equal(La, Lf), it
+        lam *= 3.0
+    a.close(); f.close()
