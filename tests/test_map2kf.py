@@ -251,6 +251,42 @@ def test_oracle_kf2kf_semantics(oracle):
 
 
 @pytest.mark.gpu
+def test_gpu_kf2kf_lines_when_the_windowed_pass_can_succeed(ctx, oracle):
+    """matchKF2KFLines hands matchGrid PIXEL coordinates (:392-393): on a real image nearly every window misses the 64 x 48 grid and
+    the driver, knowing so from a host-side bound, enqueues StVO::match behind the windowed pass at once (round 6).  Here the camera
+    is so small that the projected pixels ARE grid cells (fx = 30, 64 x 48 pixels): the bound is large, the windowed pass finds its
+    matches, and the call must take the ordinary road -- with min_matches below what it finds (no StVO::match), above it (the
+    fall-back after the count is known) and far above the bound's reach.  Bit-exact against the oracle every time."""
+    import plslam_amd
+    K = dict(fx=30.0, fy=30.0, cx=32.0, cy=24.0, b=0.11, width=64, height=48)
+    cam, ocam = plslam_amd.make_cam(**K), oracle.make_cam(**K)
+    r = np.random.Generator(np.random.PCG64(12))
+    n_prev, n_curr = 220, 200
+    DT = synth.se3_exp([0.02, -0.01, 0.05, 0.002, -0.003, 0.002])
+    z = r.uniform(2.0, 12.0, n_prev)
+    P = np.stack([r.uniform(-0.9, 0.9, n_prev) * z, r.uniform(-0.7, 0.7, n_prev) * z, z], 1)
+    E = P + r.uniform(-0.3, 0.3, (n_prev, 3))
+    proj = lambda X: np.stack([K["cx"] + K["fx"] * X[:, 0] / X[:, 2], K["cy"] + K["fy"] * X[:, 1] / X[:, 2]], 1)
+    d_prev = synth.random_desc(r, n_prev)
+    src = r.permutation(n_prev)[:n_curr]
+    d_curr = d_prev[src] ^ np.packbits(r.random((n_curr, 256)) < 0.04, axis=1)
+    Pc, Ec = P @ DT[:3, :3].T + DT[:3, 3], E @ DT[:3, :3].T + DT[:3, 3]
+    seg = np.concatenate([proj(Pc[src]), proj(Ec[src])], 1) + r.normal(0, 0.2, (n_curr, 4))
+    a = (DT, np.concatenate([P, E], 1), d_prev, seg, np.ascontiguousarray(d_curr))
+    fm = dict(enabled=1, grid_cols=64, grid_rows=48, ws=3, inv_width=1.0, inv_height=1.0, nnr_grid=0.85, line_sim_th=0.75)
+    base = oracle.kf2kf_match("lines", ocam, *a, 0.85, True, 5, fm)
+    assert base[2] == 0 and base[1] > 40                      # the windowed pass alone: plenty of matches, no StVO::match
+    seen = set()
+    for mm in (5, base[1] + 20, 199, 10 ** 6):
+        got = ctx.kf2kf_match("lines", cam, *a, 0.85, True, mm, fm)
+        ref = oracle.kf2kf_match("lines", ocam, *a, 0.85, True, mm, fm)
+        np.testing.assert_array_equal(got[0], ref[0])
+        assert got[1] == ref[1] and got[2] == ref[2], mm
+        seen.add(ref[2])
+    assert seen == {0, 1}
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,n_prev,n_curr", [("points", 1500, 1400), ("lines", 200, 180), ("points", 60, 50),
                                                 ("lines", 30, 40), ("points", 4000, 4000)])
 def test_gpu_kf2kf_driver_bit_exact(ctx, oracle, kind, n_prev, n_curr):
