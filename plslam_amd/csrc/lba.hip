@@ -95,12 +95,40 @@ __device__ __forceinline__ void xform44(const Pose12& T, const double* X, double
         o[i] = (T.m[4 * i] * x + T.m[4 * i + 1] * y + T.m[4 * i + 2] * z) + T.m[4 * i + 3];
 }
 
+// The gates as the LAST kernel of a one-synchronisation driver call (map2kf.hip): the workgroup that finishes last copies the call's
+// counters (device words, some of them this kernel's own atomic counts) into the page-locked block the host reads -- a launch less
+// at the end of a call that is bound by its launches.  Every wave WAITS for its count atomic (a returning one) before the
+// workgroup's barrier, one lane then counts the workgroup in; the last one reads the counters with agent-scope loads.
+struct GatePublish { int32_t* done; const int32_t* src; int32_t* dst; int32_t n; };     // done = nullptr: nothing to publish
+__device__ __forceinline__ void gate_count_and_publish(int ok, int32_t* __restrict__ count, const GatePublish& pub)
+{
+    if (count) {
+        const unsigned long long b = __ballot(ok);
+        if ((threadIdx.x & 63) == 0 && b) {
+            if (pub.done) {
+                const int old = atomicAdd(count, (int)__popcll(b));
+                asm volatile("" ::"v"(old));              // (the atomic has been performed when the wave passes here)
+            } else {
+                atomicAdd(count, (int)__popcll(b));
+            }
+        }
+    }
+    if (pub.done) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int prev = atomicAdd(pub.done, 1);
+            if (prev == (int)gridDim.x - 1)
+                for (int w = 0; w < pub.n; ++w) pub.dst[w] = __hip_atomic_load(pub.src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // K5: point gate  (:601-613)
 __global__ void __launch_bounds__(256)
 k_point_gate(CamD K, Pose12 Twf, const double* __restrict__ Xw, const int32_t* __restrict__ m12,
              int32_t nq, const double* __restrict__ pl, double th, uint8_t* __restrict__ mask,
              int32_t* __restrict__ count, const int32_t* __restrict__ nq_dev, const int32_t* __restrict__ idx,
-             const int32_t* __restrict__ ti, int32_t* __restrict__ map_to_kf)
+             const int32_t* __restrict__ ti, int32_t* __restrict__ map_to_kf, GatePublish pub)
 {
     if (nq_dev) nq = *nq_dev;                  // (the row count lives on the device: the launch covers an upper bound)
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -117,10 +145,7 @@ k_point_gate(CamD K, Pose12 Twf, const double* __restrict__ Xw, const int32_t* _
         mask[i] = (uint8_t)ok;
         if (ok && map_to_kf) map_to_kf[idx[i]] = ti[i2];          // :614-619, the association (table pre-filled with -1)
     }
-    if (count) {
-        const unsigned long long b = __ballot(ok);
-        if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (int)__popcll(b));
-    }
+    gate_count_and_publish(ok, count, pub);
 }
 
 // K6: line gate  (:716-729), signed test on both endpoints
@@ -128,7 +153,7 @@ __global__ void __launch_bounds__(256)
 k_line_gate(CamD K, Pose12 Twf, const double* __restrict__ Lw, const int32_t* __restrict__ m12,
             int32_t nq, const double* __restrict__ le, double th, uint8_t* __restrict__ mask,
             int32_t* __restrict__ count, const int32_t* __restrict__ nq_dev, const int32_t* __restrict__ idx,
-            const int32_t* __restrict__ ti, int32_t* __restrict__ map_to_kf)
+            const int32_t* __restrict__ ti, int32_t* __restrict__ map_to_kf, GatePublish pub)
 {
     if (nq_dev) nq = *nq_dev;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -149,10 +174,7 @@ k_line_gate(CamD K, Pose12 Twf, const double* __restrict__ Lw, const int32_t* __
         mask[i] = (uint8_t)ok;
         if (ok && map_to_kf) map_to_kf[idx[i]] = ti[i2];
     }
-    if (count) {
-        const unsigned long long b = __ballot(ok);
-        if ((threadIdx.x & 63) == 0 && b) atomicAdd(count, (int)__popcll(b));
-    }
+    gate_count_and_publish(ok, count, pub);
 }
 
 __device__ __forceinline__ int inside(const CamD& K, const double P[3])
@@ -223,7 +245,7 @@ int launch_point_gate(const plslam_cam& K, const double* Twf16, const double* Xw
     if (nq <= 0) return PLSLAM_OK;
     hipLaunchKernelGGL(k_point_gate, dim3((nq + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16),
                        Xw, m12, nq, pl, th, mask, count, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr,
-                       (int32_t*)nullptr);
+                       (int32_t*)nullptr, GatePublish{nullptr, nullptr, nullptr, 0});
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
@@ -236,7 +258,7 @@ int launch_line_gate(const plslam_cam& K, const double* Twf16, const double* Lw,
     if (nq <= 0) return PLSLAM_OK;
     hipLaunchKernelGGL(k_line_gate, dim3((nq + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16),
                        Lw, m12, nq, le, th, mask, count, (const int32_t*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr,
-                       (int32_t*)nullptr);
+                       (int32_t*)nullptr, GatePublish{nullptr, nullptr, nullptr, 0});
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }
@@ -305,17 +327,25 @@ int launch_project_cells(const plslam_cam& K, const double* Twf16, const double*
 // The gates with the row count ON THE DEVICE (*n_dev <= n_max; the launch covers n_max rows): the drivers' one-synchronisation
 // form builds its candidate list on the device and never learns its length before the results are back.  The gate's counter is
 // NOT cleared here (the caller's image holds the zero); idx / ti / map_to_kf: the association of the rows that pass.
+// publish_*: the call's counters (publish_n device words at publish_src) go to publish_dst -- page-locked, mapped -- from the last
+// workgroup to finish; publish_done: a ZERO device word the workgroups count themselves into (nullptr: nothing is published)
 int launch_gate_n(int lines, const plslam_cam& K, const double* Twf16, const double* LM, const int32_t* m12, const int32_t* n_dev,
                   int32_t n_max, const double* feat, double th, uint8_t* mask, int32_t* count, const int32_t* idx, const int32_t* ti,
-                  int32_t* map_to_kf, hipStream_t s)
+                  int32_t* map_to_kf, hipStream_t s, int32_t* publish_done, const int32_t* publish_src, int32_t* publish_dst,
+                  int32_t publish_n)
 {
-    if (n_max <= 0) return PLSLAM_OK;
+    if (n_max <= 0) {
+        // (no gate workgroup will run: the counters still have to come down)
+        PLSLAM_REQUIRE(!publish_done, PLSLAM_EINVAL);
+        return PLSLAM_OK;
+    }
+    const GatePublish pub{publish_done, publish_src, publish_dst, publish_n};
     if (lines)
         hipLaunchKernelGGL(k_line_gate, dim3((n_max + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), LM, m12, n_max, feat,
-                           th, mask, count, n_dev, idx, ti, map_to_kf);
+                           th, mask, count, n_dev, idx, ti, map_to_kf, pub);
     else
         hipLaunchKernelGGL(k_point_gate, dim3((n_max + 255) / 256), dim3(256), 0, s, cam_d(K), pose12(Twf16), LM, m12, n_max, feat,
-                           th, mask, count, n_dev, idx, ti, map_to_kf);
+                           th, mask, count, n_dev, idx, ti, map_to_kf, pub);
     PLSLAM_HIP_CHECK(hipGetLastError());
     return PLSLAM_OK;
 }

@@ -28,7 +28,8 @@ int launch_visible_cand(const plslam_cam& K, const double* Twf16, const double* 
 // lba.hip: the epipolar gate with the row count on the device (*n_dev <= n_max) and, optionally, the association behind it
 int launch_gate_n(int lines, const plslam_cam& K, const double* Twf16, const double* LM, const int32_t* m12, const int32_t* n_dev,
                   int32_t n_max, const double* feat, double th, uint8_t* mask, int32_t* count, const int32_t* idx, const int32_t* ti,
-                  int32_t* map_to_kf, hipStream_t s);
+                  int32_t* map_to_kf, hipStream_t s, int32_t* publish_done = nullptr, const int32_t* publish_src = nullptr,
+                  int32_t* publish_dst = nullptr, int32_t publish_n = 0);
 // lba.hip: visibility x candidate flags -> stable list + length (+ -1 fill of the association table, + the row count into a
 // matchGrid descriptor); Q rows + landmarks + window centres of the listed landmarks
 size_t visible_compact_part_words(int32_t n);       // zeroed device words the kernel's workgroups chain their counts through
@@ -376,13 +377,11 @@ int map2kf_fast_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const doub
         return rc;
     if ((rc = grid_launch_single(q, (const GridDesc*)(d + oDesc), s, (uint32_t*)(d + oAux), true, (const GridDesc*)(h + oDesc)))) return rc;
     if ((rc = launch_gate_n(lines, *K, Twf, (const double*)(d + oQL), (const int32_t*)(d + oM), res + 1, n_map, (const double*)(d + oTF),
-                            max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi), (const int32_t*)(d + oTi), tab, s)))
+                            max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi), (const int32_t*)(d + oTi), tab, s,
+                            tab_in_place ? res + 3 : nullptr, res, (int32_t*)ctx->pin_out.dev, 3)))     // (res[3]: zero in the image)
         return rc;
-    // ---- the counters (and, when it is not there already, the table behind them) down; one synchronisation
-    if (tab_in_place) {
-        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, s, (const int32_t*)res, (int32_t*)ctx->pin_out.dev, 4);
-        PLSLAM_HIP_CHECK(hipGetLastError());
-    } else {
+    // ---- the counters (from the gate's last workgroup) and, when it is not there already, the table behind them down; one synchronisation
+    if (!tab_in_place) {
         PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oRes, (oMap - oRes) + (size_t)n_map * 4, hipMemcpyDeviceToHost, s));
     }
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
@@ -496,13 +495,11 @@ int map2kf_bf_once(plslam_ctx* ctx, int lines, const plslam_cam* K, const double
     }
     if (rc) return rc;
     if ((rc = launch_gate_n(lines, *K, Twf, (const double*)(d + oQL), (const int32_t*)(d + oM), res + 1, n_map, (const double*)(d + oTF),
-                            max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi), (const int32_t*)(d + oTi), tab, s)))
+                            max_epip, (uint8_t*)(d + oMask), res, (const int32_t*)(d + oQi), (const int32_t*)(d + oTi), tab, s,
+                            tab_in_place ? res + 3 : nullptr, res, (int32_t*)ctx->pin_out.dev, 3)))     // (res[3]: zero in the image)
         return rc;
-    // ---- the counters (and, when it is not there already, the table behind them) down; one synchronisation
-    if (tab_in_place) {
-        hipLaunchKernelGGL(k_publish_words, dim3(1), dim3(64), 0, s, (const int32_t*)res, (int32_t*)ctx->pin_out.dev, 4);
-        PLSLAM_HIP_CHECK(hipGetLastError());
-    } else {
+    // ---- the counters (from the gate's last workgroup) and, when it is not there already, the table behind them down; one synchronisation
+    if (!tab_in_place) {
         PLSLAM_HIP_CHECK(hipMemcpyAsync(ho, d + oRes, (oMap - oRes) + (size_t)n_map * 4, hipMemcpyDeviceToHost, s));
     }
     PLSLAM_HIP_CHECK(hipStreamSynchronize(s));
